@@ -1,0 +1,80 @@
+/*
+ * oracle_batch.c — CPU ORACLE, batch driver used only as bench.py's `cpu_baseline`
+ * ("port" of the reference scalar path) and by tests.
+ *
+ * Arrangement mirrors how a rayon user of the reference would decode a batch: one
+ * image per task over all host threads; inside an image the pixel pipeline is the
+ * serial one of src/worker/immediate.rs + src/worker/mod.rs:97-128 (IDCT of every MCU
+ * row, then upsample + colour-convert of every output row).  Only the pixel pipeline
+ * (coefficients -> pixels, the path the GPU kernels replace) is run here.
+ */
+#include "jpeg_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    const orc_component *comps;
+    int ncomp;
+    const uint16_t *qts; /* ncomp * 64 */
+    const int16_t *const *coefs; /* n_images * ncomp pointers */
+    int n_images;
+    uint16_t out_w, out_h;
+    int ct;
+    uint8_t *const *outs;
+    int next; /* work counter */
+    int status;
+    pthread_mutex_t mu;
+} batch_t;
+
+static void *batch_worker(void *arg) {
+    batch_t *b = (batch_t *)arg;
+    uint8_t *planes[4] = {NULL, NULL, NULL, NULL};
+    for (int c = 0; c < b->ncomp; c++) planes[c] = (uint8_t *)malloc(orc_plane_bytes(&b->comps[c]) + 1);
+    for (;;) {
+        pthread_mutex_lock(&b->mu);
+        int i = b->next++;
+        pthread_mutex_unlock(&b->mu);
+        if (i >= b->n_images) break;
+        for (int c = 0; c < b->ncomp; c++) {
+            const orc_component *cp = &b->comps[c];
+            size_t mcu_rows = cp->block_h / cp->v;
+            orc_append_rows(cp, b->qts + 64 * c, b->coefs[(size_t)i * b->ncomp + c], 0, mcu_rows, planes[c]);
+        }
+        int rc = orc_compute_image(b->comps, b->ncomp, planes, b->out_w, b->out_h, b->ct, b->outs[i], NULL);
+        if (rc) {
+            pthread_mutex_lock(&b->mu);
+            b->status = rc;
+            pthread_mutex_unlock(&b->mu);
+        }
+    }
+    for (int c = 0; c < b->ncomp; c++) free(planes[c]);
+    return NULL;
+}
+
+/* Runs the pixel pipeline for n_images images of identical geometry on `nthreads`
+ * host threads.  Returns 0 or the last non-zero status. */
+int orc_batch_pixels(const orc_component *comps, int ncomp, const uint16_t *qts,
+                     const int16_t *const *coefs, int n_images, uint16_t out_w, uint16_t out_h,
+                     int color_transform, uint8_t *const *outs, int nthreads) {
+    batch_t b;
+    memset(&b, 0, sizeof(b));
+    b.comps = comps;
+    b.ncomp = ncomp;
+    b.qts = qts;
+    b.coefs = coefs;
+    b.n_images = n_images;
+    b.out_w = out_w;
+    b.out_h = out_h;
+    b.ct = color_transform;
+    b.outs = outs;
+    pthread_mutex_init(&b.mu, NULL);
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, batch_worker, &b);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&b.mu);
+    return b.status;
+}

@@ -1,0 +1,158 @@
+"""Pins the CPU oracle against everything the reference's own tests hold for the hot path:
+KATs of src/idct.rs, src/parser.rs:312-329, src/idct.rs:30-203, the reftest JPEG/PNG pairs
+(<=3 rule, tests/reftest/mod.rs:93-120) and the SURVEY Appendix B sha256 vectors."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import refimages as R
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return json.load(open(os.path.join(R.GOLDEN, "idct_kat.json")))
+
+
+def test_idct_8x8_kat_exact(kat):
+    k = kat["kat_8x8"]
+    out = O.idct_block(k["coefficients"], k["quantization_table"]).reshape(-1)
+    # the reference allows +-1 so that SIMD variants pass; the scalar path is exact
+    assert np.array_equal(out, np.array(k["expected"], dtype=np.uint8))
+
+
+def test_idct_all_zero(kat):
+    k = kat["all_zero"]
+    out = O.idct_block(k["coefficients"], k["quantization_table"]).reshape(-1)
+    assert np.array_equal(out, np.full(64, 128, np.uint8))
+
+
+def test_idct_saturated_wrapping(kat):
+    k = kat["saturated"]
+    out = O.idct_block(k["coefficients"], k["quantization_table"]).reshape(-1)
+    assert np.array_equal(out, np.array(k["expected"], dtype=np.uint8))
+
+
+def test_idct_column_shortcut_under_wraparound(kat):
+    k = kat["h2_column_shortcut"]
+    out = O.idct_block(k["coefficients"], k["quantization_table"])
+    assert list(out[0]) == k["expected_row0"]
+
+
+def test_choose_idct_size():
+    # src/idct.rs:30-203
+    f = O.lib().orc_choose_idct_size
+    vectors = [(5472, 3648, 200, 200, 1), (5472, 3648, 500, 500, 1), (5472, 3648, 684, 456, 1),
+               (5472, 3648, 999, 456, 1), (5472, 3648, 684, 999, 1), (500, 333, 63, 42, 1),
+               (5472, 3648, 685, 999, 2), (5472, 3648, 1000, 1000, 2), (5472, 3648, 1400, 1400, 4),
+               (5472, 3648, 5472, 3648, 8), (5472, 3648, 16384, 16384, 8), (1, 1, 65535, 65535, 8)]
+    for fw, fh, rw, rh, want in vectors:
+        assert f(fw, fh, rw, rh) == want, (fw, fh, rw, rh)
+
+
+def test_update_component_sizes():
+    # src/parser.rs:312-329
+    comps, mcu = O.make_components(800, 280, [(2, 2)])
+    assert mcu == (50, 18)
+    assert (comps[0].block_w, comps[0].block_h) == (100, 36)
+    assert (comps[0].size_w, comps[0].size_h) == (800, 280)
+
+
+def test_geometry_1080p_420():
+    # SURVEY §8a sizes
+    comps, mcu = O.make_components(1920, 1080, [(2, 2), (1, 1), (1, 1)])
+    assert mcu == (120, 68)
+    assert (comps[0].block_w, comps[0].block_h) == (240, 136)
+    assert (comps[1].block_w, comps[1].block_h) == (120, 68)
+    assert (comps[1].size_w, comps[1].size_h) == (960, 540)
+    assert sum(c.block_w * c.block_h * 128 for c in comps) == 6266880
+
+
+@pytest.mark.parametrize("rel", R.reftest_files())
+def test_reftest_within_reference_tolerance(rel):
+    """tests/reftest/mod.rs: decode, compare with sibling PNG, abs diff <= 3."""
+    path = os.path.join(R.REFTEST, rel)
+    d = O.decode(open(path, "rb").read())
+    md = R.max_diff_vs_png(d.pixels, d.ncomp, os.path.splitext(path)[0] + ".png")
+    assert md <= 3, (rel, md)
+
+
+@pytest.mark.parametrize("req,png", [((500, 333), "rgb.png"), ((250, 167), "rgb_250x167.png"),
+                                     ((125, 84), "rgb_125x84.png"), ((63, 42), "rgb_63x42.png")])
+def test_reftest_scaled(req, png):
+    """tests/reftest/mod.rs:18-25"""
+    d = O.decode(open(os.path.join(R.REFTEST, "rgb.jpg"), "rb").read(), scale_to=req)
+    assert (d.width, d.height) == req
+    assert R.max_diff_vs_png(d.pixels, 3, os.path.join(R.REFTEST, png)) <= 3
+
+
+def _decode_key(key):
+    rel, _, scale = key.partition("@")
+    req = tuple(int(v) for v in scale.split("x")) if scale else None
+    return O.decode(open(os.path.join(R.GOLDEN, rel), "rb").read(), scale_to=req)
+
+
+@pytest.mark.parametrize("key", sorted(R.golden_hashes()))
+def test_appendix_b_sha256(key):
+    """Byte-exact agreement with the independent survey-time restatement."""
+    d = _decode_key(key)
+    assert hashlib.sha256(d.pixels.tobytes()).hexdigest() == R.golden_hashes()[key]
+
+
+def test_disabled_files_fail_like_the_reference():
+    """tests/reftest/images/disabled.list: 3x3 / 4x4 exceed the tolerance, 6x6 is not a JPEG."""
+    for rel, n_bad in (("mozilla/jpg-size-3x3.jpg", 24), ("mozilla/jpg-size-4x4.jpg", 36)):
+        path = os.path.join(R.REFTEST, rel)
+        d = O.decode(open(path, "rb").read())
+        ref, _ = R.load_png(os.path.splitext(path)[0] + ".png")
+        assert int((np.abs(ref.astype(int) - d.pixels.astype(int)) > 3).sum()) == n_bad
+    with pytest.raises(O.OracleError) as e:
+        O.decode(open(os.path.join(R.REFTEST, "mozilla/jpg-size-6x6.jpg"), "rb").read())
+    assert e.value.kind == "Format"
+
+
+def test_intermediates_reproduce_pixels():
+    """What crossed the Worker boundary (coefficients, q-tables) re-run through the pixel
+    pipeline alone gives the same bytes as decode(): the oracle entry the GPU tests use."""
+    for rel in ("mjpeg.jpg", "mozilla/jpg-cmyk-2.jpg", "mozilla/jpg-size-17x17.jpg", "grayscale_16x24_sampling2x2.jpg",
+                "non-interleaved-mcu.jpg", "partial_progressive.jpg"):
+        d = O.decode(open(os.path.join(R.REFTEST, rel), "rb").read(), keep_intermediates=True)
+        planes = []
+        for i in range(d.ncomp):
+            p = O.idct_plane(d.components[i], d.qtables[i], d.coefs[i])
+            assert np.array_equal(p, d.planes[i]), rel
+            planes.append(p)
+        px = O.compute_image(d.components, planes, d.width, d.height, d.color_transform)
+        assert np.array_equal(px, d.pixels), rel
+
+
+def test_ycbcr_matches_formula_exhaustively():
+    """src/decoder.rs:1486-1508 with the f32-derived constants of SURVEY A.4."""
+    import ctypes as C
+    y, cb, cr = np.meshgrid(np.arange(0, 256, 5), np.arange(256), np.arange(256), indexing="ij")
+    Y = y.astype(np.int64) * (1 << 20) + (1 << 19)
+    cbs, crs = cb.astype(np.int64) - 128, cr.astype(np.int64) - 128
+    r = np.clip((Y + 1470104 * crs) >> 20, 0, 255)
+    g = np.clip((Y - 360857 * cbs - 748830 * crs) >> 20, 0, 255)
+    b = np.clip((Y + 1858077 * cbs) >> 20, 0, 255)
+    out = (C.c_uint8 * 3)()
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        i, j, k = rng.integers(0, y.shape[0]), rng.integers(0, 256), rng.integers(0, 256)
+        O.lib().orc_ycbcr_to_rgb(int(y[i, j, k]), int(cb[i, j, k]), int(cr[i, j, k]), out)
+        assert (out[0], out[1], out[2]) == (r[i, j, k], g[i, j, k], b[i, j, k])
+
+
+def test_batch_driver_matches_single():
+    comps, _ = O.make_components(48, 40, [(2, 2), (1, 1), (1, 1)])
+    rng = np.random.default_rng(3)
+    qts = [rng.integers(1, 64, 64).astype(np.uint16) for _ in range(3)]
+    imgs = []
+    for _ in range(5):
+        imgs.append([(rng.integers(-64, 64, c.block_w * c.block_h * 64) * (rng.random(c.block_w * c.block_h * 64) < 0.2)).astype(np.int16) for c in comps])
+    outs = O.batch_pixels(comps, qts, imgs, 48, 40, "YCBCR", 3)
+    for im, out in zip(imgs, outs):
+        assert np.array_equal(out, O.pixels_from_coefficients(comps, qts, im, 48, 40, "YCBCR"))
