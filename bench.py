@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+  metric : megapixels/s decoded (batch, whole node); % of HBM roofline for the pixel kernels
+  N=1 workload (configs[1]): 1920x1080 baseline 4:2:0 YCbCr, batch of 256 images, 1 MI355X.
+  A "step" = one pass of the hot path (dequantize + IDCT + upsample + YCbCr->RGB) over the whole
+  batch, coefficients already resident in HBM, RGB left resident in HBM.
+  N>1: one process per GPU (torch.distributed / RCCL), the batch shards one-image-per-task with
+  NO data-path collective (weak scaling: 256 images per GPU); the final RCCL gather of the
+  pixels to rank 0 that north_star mentions runs after the timed region and is reported apart.
+
+Prints ONE JSON line on rank 0."""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    # name: (width, height, sampling, mode, colour transform, default batch)
+    "1080p-420": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
+    "2160p-420": (3840, 2160, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 64),
+    "1080p-444": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
+    "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1080p-420", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
+    ap.add_argument("--generic", action="store_true", help="force the two-kernel generic path")
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_image(comps, out_bytes):
+    """coefficient bytes in (int16) + pixel bytes out; q-tables ignored."""
+    return sum(c.block_width * c.block_height * 64 * 2 for c in comps) + out_bytes
+
+
+def cpu_baseline(O, ocomps, qts, coefs, w, h, ct, target_seconds):
+    """Oracle ("port" of the reference's scalar path) on all host cores, bounded sample."""
+    cores = os.cpu_count() or 1
+    n0 = max(cores, 4)
+    t0 = time.perf_counter()
+    O.batch_pixels(ocomps, qts, [coefs] * n0, w, h, ct.upper(), cores)
+    dt = time.perf_counter() - t0
+    n = int(max(n0, min(4096, n0 * target_seconds / max(dt, 1e-3))))
+    n = (n // cores) * cores or cores
+    t0 = time.perf_counter()
+    O.batch_pixels(ocomps, qts, [coefs] * n, w, h, ct.upper(), cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * w * h / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"{n} images {w}x{h} of the same workload, pixel pipeline only (coefficients -> pixels), "
+                      f"{cores} threads one image per task, {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import jpeg_decoder_amd as J
+    import synth
+
+    w, h, sampling, mode, ct, default_batch = WORKLOADS[args.workload]
+    n_img = args.batch or default_batch
+    comps, mcu = J.make_components(w, h, sampling)
+    lum, chr_ = synth.quality_tables(85)
+    qts = [lum, chr_, chr_][: len(sampling)]
+    rgb = synth.synthetic_rgb(w, h)
+    coefs = synth.coefficients_from_rgb(rgb, comps, mode, qts)
+    sane = all((np.abs(c.astype(np.int64)).reshape(-1, 64).max(axis=0) * q.astype(np.int64) < (1 << 19)).all()
+               for c, q in zip(coefs, qts))
+
+    desc = J.image_desc(list(comps), qts, w, h, ct)
+    flags = J._native.BATCH_EXTERNAL_BUFFERS | (J._native.BATCH_FORCE_GENERIC if args.generic else 0)
+    batch = J.Batch([desc] * n_img, device=local_rank, flags=flags)
+    dev = torch.device("cuda", local_rank)
+    coef_arena = torch.zeros(batch.coef_arena_bytes(), dtype=torch.uint8, device=dev)
+    out_arena = torch.zeros(batch.out_arena_bytes(), dtype=torch.uint8, device=dev)
+    # N distinct coefficient buffers in HBM (no aliasing): upload image 0, replicate on device
+    for c in range(len(comps)):
+        src = torch.from_numpy(coefs[c].view(np.uint8)).to(dev)
+        for i in range(n_img):
+            off = batch.coef_offset(i, c)
+            coef_arena[off: off + src.numel()] = src
+    batch.bind(coef_arena.data_ptr(), out_arena.data_ptr())
+    for i in range(n_img):
+        batch.set_range_hint(i, sane)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    for _ in range(max(args.warmup, 0)):
+        batch.decode(stream)
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream the kernels are launched on
+    for _ in range(args.steps):
+        batch.decode(stream)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    if dist:
+        t = torch.tensor([elapsed, gpu_ms_per_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, gpu_ms_per_step = float(t[0]), float(t[1])
+
+    # parity spot check inside the bench (oracle = checker only, never the thing measured)
+    verified = None
+    gather_ms = None
+    out_bytes = batch.out_bytes(0)
+    if rank == 0:
+        import oracle as O
+        ocomps, _ = O.make_components(w, h, sampling)
+        want = O.pixels_from_coefficients(ocomps, qts, coefs, w, h, ct.upper())
+        digest = hashlib.sha256(want.tobytes()).hexdigest()
+        verified = True
+        for i in (0, n_img // 2, n_img - 1):
+            off = batch.out_offset(i)
+            got = out_arena[off: off + out_bytes].cpu().numpy()
+            verified = verified and hashlib.sha256(got.tobytes()).hexdigest() == digest
+    if dist and not args.no_gather:
+        try:  # north_star's "RCCL over xGMI only for the final gather", outside the timed region
+            pix = out_arena[: batch.out_offset(n_img - 1) + out_bytes]
+            gl = [torch.empty_like(pix) for _ in range(world)] if rank == 0 else None
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            g0 = time.perf_counter()
+            dist.gather(pix, gl, dst=0)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            del gl
+        except Exception as e:  # the gather is informational; never lose the bench line to it
+            gather_ms = None
+            if rank == 0:
+                print(f"# gather skipped: {e}", file=sys.stderr)
+
+    if rank == 0:
+        mp_per_step = world * n_img * w * h / 1e6
+        value = mp_per_step * args.steps / elapsed
+        alg_bytes = algorithmic_bytes_per_image(comps, out_bytes) * n_img  # per launch (one GPU's batch)
+        achieved = alg_bytes / (gpu_ms_per_step * 1e-3) / 1e9
+        line = {
+            "metric": "megapixels/s decoded (batch, whole node)", "value": round(value, 1), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i32 fixed-point (i16 coefficients -> u8 pixels)", "data": "synthetic",
+            "config": {"workload": f"{w}x{h} baseline {'x'.join(str(hh) + str(vv) for hh, vv in sampling)} "
+                                   f"{ct}, batch of {n_img} images per GPU (coefficients resident in HBM -> RGB in HBM)",
+                       "name": args.workload, "images_per_gpu": n_img, "kernel_path": batch.path,
+                       "parallelism": f"images sharded {n_img}/GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": round(gpu_ms_per_step, 4)},
+            "verified_vs_oracle": verified,
+        }
+        if gather_ms is not None:
+            line["gather_ms_after_timed_region"] = round(gather_ms, 2)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(O, ocomps, qts, coefs, w, h, ct, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/*
+ * jpgpu.h — C ABI of the MI355X (gfx950) pixel-pipeline backend for image-rs/jpeg-decoder.
+ *
+ * This is the drop-in boundary: exactly what a `src/worker/hip.rs` backend of the crate
+ * binds over FFI (see INTEGRATION.md for the Rust `extern "C"` block).  Plain pointers and
+ * sizes only; no C++ / torch types.  Every entry point cites the reference interface
+ * (paths relative to the reference crate root, v0.3.2) it replaces.
+ *
+ * Semantics are those of the crate's *scalar* path (`--features platform_independent`):
+ * integer IDCT of src/idct.rs, upsamplers of src/upsampler.rs, colour conversion of
+ * src/decoder.rs:1391-1508 — bit-exact, including i32 wrap-around on hostile input.
+ *
+ * Threading: a context object (worker / batch / decoder) is used by one thread at a time
+ * (the crate holds its worker behind a RefCell, src/worker/mod.rs:44-46); different
+ * contexts may be used concurrently from any threads.  Nothing unwinds across this ABI.
+ */
+#ifndef JPGPU_H
+#define JPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPGPU_MAX_COMPONENTS 4 /* src/decoder.rs:21 MAX_COMPONENTS */
+
+/* Status codes. 1..4 map one-to-one onto src/error.rs:16-48 Error::{Format, Unsupported,
+ * Io, Internal}; the Rust shim turns them back into that enum. */
+enum {
+    JPGPU_OK = 0,
+    JPGPU_ERR_FORMAT = 1,      /* Error::Format(String)            */
+    JPGPU_ERR_UNSUPPORTED = 2, /* Error::Unsupported(..)           */
+    JPGPU_ERR_IO = 3,          /* Error::Io (incl. device/runtime) */
+    JPGPU_ERR_INTERNAL = 4,    /* Error::Internal / would-panic    */
+    JPGPU_ERR_NO_DEVICE = 5,   /* no usable gfx950 device (maps to Error::Io) */
+};
+
+/* ColorTransform, src/decoder.rs:76-98 (same order). */
+enum {
+    JPGPU_CT_NONE = 0,
+    JPGPU_CT_UNKNOWN = 1,
+    JPGPU_CT_GRAYSCALE = 2,
+    JPGPU_CT_RGB = 3,
+    JPGPU_CT_YCBCR = 4,
+    JPGPU_CT_CMYK = 5,
+    JPGPU_CT_YCCK = 6,
+    JPGPU_CT_JCS_BG_YCC = 7,
+    JPGPU_CT_JCS_BG_RGB = 8,
+};
+
+/* parser::Component, src/parser.rs:76-89 (what RowData carries, src/worker/mod.rs:18-22). */
+typedef struct jpgpu_component {
+    uint8_t identifier;
+    uint8_t horizontal_sampling_factor;
+    uint8_t vertical_sampling_factor;
+    uint8_t quantization_table_index;
+    uint32_t dct_scale;                  /* 8 (full), 4, 2 or 1 */
+    uint16_t size_width, size_height;    /* size       */
+    uint16_t block_width, block_height;  /* block_size */
+} jpgpu_component;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char *jpgpu_version(void);
+int jpgpu_device_count(int *count);            /* number of visible HIP devices */
+const char *jpgpu_status_string(int status);
+
+/* ---- Worker: trait Worker, src/worker/mod.rs:24-35 ----------------------------------- */
+/* One worker per decode() (WorkerScope, src/worker/mod.rs:44-95).  Planes live in HBM. */
+typedef struct jpgpu_worker jpgpu_worker;
+
+int jpgpu_worker_create(int device, jpgpu_worker **out); /* WorkerScopeInner::Hip(Default) */
+void jpgpu_worker_destroy(jpgpu_worker *w);
+const char *jpgpu_worker_last_error(const jpgpu_worker *w);
+
+/* Worker::start(RowData{index, component, quantization_table}) — src/worker/mod.rs:25,
+ * src/worker/rayon.rs:40-49.  `quantization_table` is in natural (un-zigzagged) order. */
+int jpgpu_worker_start(jpgpu_worker *w, uint32_t index, const jpgpu_component *component,
+                       const uint16_t quantization_table[64]);
+
+/* Worker::append_row((index, Vec<i16>)) — src/worker/mod.rs:26, src/worker/rayon.rs:71-132.
+ * `len` must equal block_width * vertical_sampling_factor * 64 (the reference asserts).
+ * The data is consumed (copied to pinned staging) before the call returns. */
+int jpgpu_worker_append_row(jpgpu_worker *w, uint32_t index, const int16_t *coefficients,
+                            size_t len);
+
+/* Worker::append_rows(iterator) — src/worker/mod.rs:29-34, src/worker/rayon.rs:140-185:
+ * `n_rows` consecutive MCU rows stored back to back. */
+int jpgpu_worker_append_rows(jpgpu_worker *w, uint32_t index, const int16_t *coefficients,
+                             size_t n_rows);
+
+/* Worker::get_result(index) -> Vec<u8> — src/worker/mod.rs:27, src/worker/rayon.rs:134-137.
+ * Runs the IDCT of everything appended, copies the plane (block_w*block_h*dct_scale^2
+ * bytes) to `dst`, and (mem::take) forgets the host-visible result; the device plane is
+ * kept for jpgpu_compute_image under the same index until the next start(). */
+int jpgpu_worker_get_result(jpgpu_worker *w, uint32_t index, uint8_t *dst, size_t cap,
+                            size_t *len);
+
+/* Device-resident variant: finish the plane but do not download it.  `plane_slot` is the
+ * frame-level component position it will have in jpgpu_compute_image (decode_scan uses
+ * scan-local indices, src/decoder.rs:848-852,1072-1075). */
+int jpgpu_worker_finish_plane(jpgpu_worker *w, uint32_t index, uint32_t plane_slot);
+
+/* compute_image, src/decoder.rs:1300-1336 == 1-component compaction + compute_image_parallel
+ * (src/worker/mod.rs:97-128, src/worker/rayon.rs:193-219).  If host_planes is NULL the
+ * device planes left by get_result / finish_plane are used (slot i = components[i]);
+ * otherwise host_planes[i] (plane bytes as returned by get_result) are uploaded first.
+ * Output: out_w*out_h*ncomp bytes (1 component: size_w*size_h). */
+int jpgpu_compute_image(jpgpu_worker *w, const jpgpu_component *components, uint32_t ncomp,
+                        const uint8_t *const *host_planes, uint16_t out_w, uint16_t out_h,
+                        int color_transform, uint8_t *dst, size_t cap, size_t *len);
+
+/* ---- Batch: N independent images per launch (no reference counterpart: the crate decodes
+ * one image per Decoder; this is how a batch shards one-image-per-task across a GPU) ------ */
+typedef struct jpgpu_image_desc {
+    uint32_t ncomp;
+    jpgpu_component components[JPGPU_MAX_COMPONENTS];
+    uint16_t quantization_tables[JPGPU_MAX_COMPONENTS][64]; /* per component, natural order */
+    uint16_t out_w, out_h;   /* FrameInfo::output_size */
+    int32_t color_transform; /* determine_color_transform() result */
+} jpgpu_image_desc;
+
+typedef struct jpgpu_batch jpgpu_batch;
+
+enum {
+    JPGPU_BATCH_DEFAULT = 0,
+    JPGPU_BATCH_EXTERNAL_BUFFERS = 1, /* caller binds device memory (e.g. torch tensors)   */
+    JPGPU_BATCH_FORCE_GENERIC = 2,    /* never take the fused fast paths (two-kernel path)  */
+    JPGPU_BATCH_ASSUME_HOSTILE = 4,   /* skip the range scan: always use the exact 32-bit path */
+};
+
+int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_images,
+                       uint32_t flags, jpgpu_batch **out);
+void jpgpu_batch_destroy(jpgpu_batch *b);
+const char *jpgpu_batch_last_error(const jpgpu_batch *b);
+
+/* Arena layout (bytes): coefficients of image i, component c start at coef_offset(i,c) and
+ * hold block_w*block_h*64 int16 in block-raster order (the concatenation of that
+ * component's append_row buffers); pixels of image i start at out_offset(i). */
+size_t jpgpu_batch_coef_arena_bytes(const jpgpu_batch *b);
+size_t jpgpu_batch_out_arena_bytes(const jpgpu_batch *b);
+size_t jpgpu_batch_coef_offset(const jpgpu_batch *b, uint32_t image, uint32_t comp);
+size_t jpgpu_batch_coef_bytes(const jpgpu_batch *b, uint32_t image, uint32_t comp);
+size_t jpgpu_batch_out_offset(const jpgpu_batch *b, uint32_t image);
+size_t jpgpu_batch_out_bytes(const jpgpu_batch *b, uint32_t image);
+
+/* EXTERNAL_BUFFERS: device pointers owned by the caller (>= *_arena_bytes, 256-B aligned). */
+int jpgpu_batch_bind(jpgpu_batch *b, void *device_coef_arena, void *device_out_arena);
+void *jpgpu_batch_coef_arena(const jpgpu_batch *b); /* device pointer */
+void *jpgpu_batch_out_arena(const jpgpu_batch *b);  /* device pointer */
+
+/* Host -> HBM upload of one component's coefficients (also range-scans them, see
+ * jpgpu_batch_set_range_hint). Blocking. */
+int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int16_t *coefficients,
+                       size_t len);
+/* For coefficients written straight into a bound arena: tell the backend whether every
+ * |coefficient * q| stays below 2^19 for this image (sane != 0) so the 24-bit multiply path
+ * is exact, or 0 to force the wrap-exact path. Default for never-uploaded images: 0. */
+int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane);
+
+/* Enqueue the whole batch on `hip_stream` (a hipStream_t; NULL = the null stream). */
+int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream);
+int jpgpu_batch_synchronize(jpgpu_batch *b, void *hip_stream);
+/* HBM -> host download of one image's pixels. Blocking. */
+int jpgpu_batch_download(jpgpu_batch *b, uint32_t image, uint8_t *dst, size_t cap, size_t *len);
+/* Timing helper: `iters` back-to-back jpgpu_batch_decode on `hip_stream` bracketed by
+ * hipEvents on that stream; returns the average milliseconds per decode of the batch. */
+int jpgpu_batch_time(jpgpu_batch *b, void *hip_stream, uint32_t iters, float *ms_per_decode);
+/* Name of the kernel path the batch resolved to ("fused420", "generic", ...). */
+const char *jpgpu_batch_path(const jpgpu_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPGPU_H */

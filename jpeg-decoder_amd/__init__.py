@@ -1,0 +1,18 @@
+"""jpeg-decoder_amd — MI355X (gfx950) pixel-pipeline backend for image-rs/jpeg-decoder.
+
+Python face of the C ABI in include/jpgpu.h: the Worker boundary (HipWorker,
+compute_image_parallel), the batch driver and the Decoder front-end.  The product path is
+HIP-only: nothing here falls back to a CPU implementation."""
+from . import _native
+from ._native import Component, ImageDesc, build, device_count, lib
+from .batch import Batch, image_desc
+from .error import Error, FormatError, InternalError, IoError, NoDeviceError, UnsupportedError
+from .parser import Dimensions, choose_idct_size, make_components, scaled_output_size, update_component_sizes
+from .worker import COLOR_TRANSFORMS, HipWorker, RowData, color_transform_id, compute_image_parallel
+
+__all__ = [
+    "Batch", "COLOR_TRANSFORMS", "Component", "Dimensions", "Error", "FormatError", "HipWorker", "ImageDesc",
+    "InternalError", "IoError", "NoDeviceError", "RowData", "UnsupportedError", "build", "choose_idct_size",
+    "color_transform_id", "compute_image_parallel", "device_count", "image_desc", "lib", "make_components",
+    "scaled_output_size", "update_component_sizes",
+]

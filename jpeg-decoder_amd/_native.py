@@ -1,0 +1,126 @@
+"""ctypes binding of libjpgpu.so (the C ABI declared in include/jpgpu.h).
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing or no
+MI355X is visible, compute entry points raise.  PyTorch is not needed by the product path
+(only bench.py uses it for torch.distributed and device tensors)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libjpgpu.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "jpgpu.h")
+
+OK, ERR_FORMAT, ERR_UNSUPPORTED, ERR_IO, ERR_INTERNAL, ERR_NO_DEVICE = range(6)
+MAX_COMPONENTS = 4
+
+BATCH_DEFAULT, BATCH_EXTERNAL_BUFFERS, BATCH_FORCE_GENERIC, BATCH_ASSUME_HOSTILE = 0, 1, 2, 4
+
+
+class Component(C.Structure):
+    """parser::Component (src/parser.rs:76-89) as laid out in include/jpgpu.h."""
+    _fields_ = [
+        ("identifier", C.c_uint8),
+        ("horizontal_sampling_factor", C.c_uint8),
+        ("vertical_sampling_factor", C.c_uint8),
+        ("quantization_table_index", C.c_uint8),
+        ("dct_scale", C.c_uint32),
+        ("size_width", C.c_uint16),
+        ("size_height", C.c_uint16),
+        ("block_width", C.c_uint16),
+        ("block_height", C.c_uint16),
+    ]
+
+    def plane_bytes(self):
+        return self.block_width * self.block_height * self.dct_scale * self.dct_scale
+
+    def coefficient_count(self):
+        return self.block_width * self.block_height * 64
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [
+        ("ncomp", C.c_uint32),
+        ("components", Component * 4),
+        ("quantization_tables", (C.c_uint16 * 64) * 4),
+        ("out_w", C.c_uint16),
+        ("out_h", C.c_uint16),
+        ("color_transform", C.c_int32),
+    ]
+
+
+def build(force=False, verbose=False):
+    """Compile libjpgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".cpp", ".hip", ".hpp"))] + [HEADER_PATH]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        cmd = ["make", "-C", csrc, "-j8"] + ([] if verbose else ["-s"])
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "jpgpu_version": (C.c_char_p, []),
+    "jpgpu_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "jpgpu_status_string": (C.c_char_p, [C.c_int]),
+    "jpgpu_worker_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "jpgpu_worker_destroy": (None, [C.c_void_p]),
+    "jpgpu_worker_last_error": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_worker_start": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Component), C.c_void_p]),
+    "jpgpu_worker_append_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "jpgpu_worker_append_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "jpgpu_worker_get_result": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "jpgpu_worker_finish_plane": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "jpgpu_compute_image": (C.c_int, [C.c_void_p, C.POINTER(Component), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint16,
+                                      C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "jpgpu_batch_create": (C.c_int, [C.c_int, C.POINTER(ImageDesc), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "jpgpu_batch_destroy": (None, [C.c_void_p]),
+    "jpgpu_batch_last_error": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_batch_coef_arena_bytes": (C.c_size_t, [C.c_void_p]),
+    "jpgpu_batch_out_arena_bytes": (C.c_size_t, [C.c_void_p]),
+    "jpgpu_batch_coef_offset": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "jpgpu_batch_coef_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "jpgpu_batch_out_offset": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "jpgpu_batch_out_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "jpgpu_batch_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jpgpu_batch_coef_arena": (C.c_void_p, [C.c_void_p]),
+    "jpgpu_batch_out_arena": (C.c_void_p, [C.c_void_p]),
+    "jpgpu_batch_upload": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "jpgpu_batch_set_range_hint": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
+    "jpgpu_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jpgpu_batch_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "jpgpu_batch_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "jpgpu_batch_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
+    "jpgpu_batch_path": (C.c_char_p, [C.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def lib():
+    """Load libjpgpu.so (must have been built: `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                               "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().jpgpu_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,101 @@
+"""Batch driver mirror (include/jpgpu.h jpgpu_batch_*): N independent images per launch."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .error import check
+from .worker import color_transform_id
+
+
+def image_desc(components, quantization_tables, out_w, out_h, color_transform):
+    d = N.ImageDesc()
+    d.ncomp = len(components)
+    for i, c in enumerate(components):
+        d.components[i] = c
+        q = np.ascontiguousarray(quantization_tables[i], dtype=np.uint16).reshape(64)
+        for k in range(64):
+            d.quantization_tables[i][k] = int(q[k])
+    d.out_w, d.out_h = out_w, out_h
+    d.color_transform = color_transform_id(color_transform)
+    return d
+
+
+class Batch:
+    def __init__(self, descs, device=0, flags=N.BATCH_DEFAULT):
+        self._h = C.c_void_p()
+        arr = (N.ImageDesc * len(descs))(*descs)
+        st = N.lib().jpgpu_batch_create(device, arr, len(descs), flags, C.byref(self._h))
+        if st:
+            msg = N.lib().jpgpu_batch_last_error(self._h) if self._h else b"jpgpu_batch_create"
+            msg = bytes(msg)
+            self.close()
+            check(st, msg)
+        self.n_images = len(descs)
+        self.descs = descs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().jpgpu_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, st):
+        check(st, N.lib().jpgpu_batch_last_error(self._h) if st else b"")
+
+    @property
+    def path(self):
+        return N.lib().jpgpu_batch_path(self._h).decode()
+
+    def coef_arena_bytes(self):
+        return N.lib().jpgpu_batch_coef_arena_bytes(self._h)
+
+    def out_arena_bytes(self):
+        return N.lib().jpgpu_batch_out_arena_bytes(self._h)
+
+    def coef_offset(self, image, comp):
+        return N.lib().jpgpu_batch_coef_offset(self._h, image, comp)
+
+    def coef_bytes(self, image, comp):
+        return N.lib().jpgpu_batch_coef_bytes(self._h, image, comp)
+
+    def out_offset(self, image):
+        return N.lib().jpgpu_batch_out_offset(self._h, image)
+
+    def out_bytes(self, image):
+        return N.lib().jpgpu_batch_out_bytes(self._h, image)
+
+    def bind(self, coef_ptr, out_ptr):
+        self._check(N.lib().jpgpu_batch_bind(self._h, coef_ptr, out_ptr))
+
+    def coef_arena(self):
+        return N.lib().jpgpu_batch_coef_arena(self._h)
+
+    def out_arena(self):
+        return N.lib().jpgpu_batch_out_arena(self._h)
+
+    def upload(self, image, comp, coefficients):
+        a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
+        self._check(N.lib().jpgpu_batch_upload(self._h, image, comp, a.ctypes.data, a.size))
+
+    def set_range_hint(self, image, sane):
+        self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, 1 if sane else 0))
+
+    def decode(self, stream=None):
+        self._check(N.lib().jpgpu_batch_decode(self._h, stream))
+
+    def synchronize(self, stream=None):
+        self._check(N.lib().jpgpu_batch_synchronize(self._h, stream))
+
+    def download(self, image):
+        n = self.out_bytes(image)
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        got = C.c_size_t(0)
+        self._check(N.lib().jpgpu_batch_download(self._h, image, out.ctypes.data, out.size, C.byref(got)))
+        return out[: got.value]
+
+    def time(self, iters, stream=None):
+        ms = C.c_float(0)
+        self._check(N.lib().jpgpu_batch_time(self._h, stream, iters, C.byref(ms)))
+        return ms.value

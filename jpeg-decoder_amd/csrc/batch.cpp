@@ -1,0 +1,338 @@
+// batch.cpp — batch driver of the C ABI (include/jpgpu.h, jpgpu_batch_*).
+//
+// A batch is N independent images (the unit the reference decodes one-per-Decoder,
+// src/decoder.rs:134-154) laid out in two HBM arenas: all coefficient planes (int16,
+// block-raster = the concatenation of each component's append_row buffers)
+// and all output pixels.  One decode = a handful of launches over the whole batch.
+// Same-geometry 4:2:0 / 4:4:4 / gray batches resolve to the fused kernels (fused.hip);
+// everything else runs the generic two-kernel path (kernels.hip) through device job tables.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fused.hpp"
+#include "host_common.hpp"
+
+using namespace jpgpu;
+
+struct jpgpu_batch {
+    int device = 0;
+    uint32_t flags = 0;
+    std::string err;
+    std::string path = "generic";
+    std::vector<jpgpu_image_desc> descs;
+    // arena layout
+    std::vector<size_t> coef_off;   // [image*4 + comp]
+    std::vector<size_t> coef_len;   // bytes
+    std::vector<size_t> plane_off;  // [image*4 + comp] (generic path scratch)
+    std::vector<size_t> out_off, out_len;
+    size_t coef_bytes = 0, out_bytes = 0, plane_bytes_total = 0;
+    uint8_t *d_coef = nullptr, *d_out = nullptr;
+    bool own_coef = false, own_out = false;
+    uint8_t *d_planes = nullptr;
+    uint16_t *d_qt = nullptr;
+    PlaneJob *d_plane_jobs = nullptr;
+    ImageJob *d_image_jobs = nullptr;
+    std::vector<PlaneJob> plane_jobs;
+    std::vector<ImageJob> image_jobs;
+    std::vector<uint8_t> sane;  // per image*4+comp: 1 if every |c*q| < 2^19 (24-bit path exact)
+    uint32_t max_blocks = 0, max_w = 0, max_h = 0;
+    bool scales[9] = {false, false, false, false, false, false, false, false, false};
+    bool jobs_dirty = true;
+    FusedPlan fused;  // valid when path != "generic"
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define B_HIP(call)                                                                                     \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+static int batch_refresh_jobs(jpgpu_batch *b) {
+    if (!b->jobs_dirty) return JPGPU_OK;
+    if (!b->d_coef || !b->d_out) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    const uint32_t n = (uint32_t)b->descs.size();
+    b->plane_jobs.clear();
+    b->image_jobs.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        const jpgpu_image_desc &d = b->descs[i];
+        uint8_t *planes[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (uint32_t c = 0; c < d.ncomp; c++) {
+            const jpgpu_component &cc = d.components[c];
+            PlaneJob j{};
+            j.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
+            j.plane = b->d_planes ? b->d_planes + b->plane_off[i * 4 + c] : nullptr;
+            j.qt = b->d_qt + ((size_t)i * 4 + c) * 64;
+            j.block_w = cc.block_width;
+            j.n_blocks = (uint32_t)cc.block_width * cc.block_height;
+            j.scale = cc.dct_scale;
+            j.flags = b->sane[i * 4 + c] ? 1u : 0u;
+            planes[c] = j.plane;
+            b->plane_jobs.push_back(j);
+        }
+        ImageJob ij;
+        size_t out_len = 0;
+        int rc = build_image_job(d.components, d.ncomp, planes, d.out_w, d.out_h, d.color_transform,
+                                 b->d_out + b->out_off[i], ij, out_len, b->err);
+        if (rc) return rc;
+        b->image_jobs.push_back(ij);
+    }
+    if (!b->plane_jobs.empty())
+        B_HIP(hipMemcpy(b->d_plane_jobs, b->plane_jobs.data(), b->plane_jobs.size() * sizeof(PlaneJob), hipMemcpyHostToDevice));
+    if (!b->image_jobs.empty())
+        B_HIP(hipMemcpy(b->d_image_jobs, b->image_jobs.data(), b->image_jobs.size() * sizeof(ImageJob), hipMemcpyHostToDevice));
+    if (b->path != "generic") {
+        int rc = fused_bind(b->fused, b->d_coef, b->d_out, b->d_qt, b->coef_off, b->out_off, b->sane, b->err);
+        if (rc) return rc;
+    }
+    b->jobs_dirty = false;
+    return JPGPU_OK;
+}
+
+extern "C" {
+
+int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_images, uint32_t flags,
+                       jpgpu_batch **out) {
+    if (!out) return JPGPU_ERR_FORMAT;
+    *out = nullptr;
+    if (!descs || n_images == 0 || n_images > 65535) return JPGPU_ERR_FORMAT;
+    jpgpu_batch *b = new jpgpu_batch();
+    *out = b;  // returned even on failure so the caller can read last_error, then destroy
+    b->device = device;
+    b->flags = flags;
+    int rc = use_device(device, b->err);
+    if (rc) return rc;
+    b->descs.assign(descs, descs + n_images);
+    b->coef_off.assign((size_t)n_images * 4, 0);
+    b->coef_len.assign((size_t)n_images * 4, 0);
+    b->plane_off.assign((size_t)n_images * 4, 0);
+    b->out_off.assign(n_images, 0);
+    b->out_len.assign(n_images, 0);
+    b->sane.assign((size_t)n_images * 4, 0);
+    size_t co = 0, po = 0, oo = 0;
+    for (uint32_t i = 0; i < n_images; i++) {
+        const jpgpu_image_desc &d = b->descs[i];
+        if (d.ncomp == 0 || d.ncomp > 4) return set_err(b->err, JPGPU_ERR_FORMAT, "image %u: bad component count %u", i, d.ncomp);
+        // validate once with dummy plane pointers (same checks as compute_image)
+        uint8_t *dummy[4] = {nullptr, nullptr, nullptr, nullptr};
+        ImageJob ij;
+        size_t out_len = 0;
+        rc = build_image_job(d.components, d.ncomp, dummy, d.out_w, d.out_h, d.color_transform, nullptr, ij, out_len, b->err);
+        if (rc) return rc;
+        for (uint32_t c = 0; c < d.ncomp; c++) {
+            const jpgpu_component &cc = d.components[c];
+            size_t cb = (size_t)cc.block_width * cc.block_height * 64 * sizeof(int16_t);
+            b->coef_off[i * 4 + c] = co;
+            b->coef_len[i * 4 + c] = cb;
+            co += align_up(cb, 256);
+            b->plane_off[i * 4 + c] = po;
+            po += align_up(plane_bytes(cc), 256);
+            b->max_blocks = std::max<uint32_t>(b->max_blocks, (uint32_t)cc.block_width * cc.block_height);
+            b->scales[cc.dct_scale] = true;
+        }
+        b->out_off[i] = oo;
+        b->out_len[i] = out_len;
+        oo += align_up(out_len, 256);
+        b->max_w = std::max<uint32_t>(b->max_w, d.ncomp == 1 ? d.components[0].size_width : d.out_w);
+        b->max_h = std::max<uint32_t>(b->max_h, d.ncomp == 1 ? d.components[0].size_height : d.out_h);
+    }
+    b->coef_bytes = std::max<size_t>(co, 256);
+    b->out_bytes = std::max<size_t>(oo, 256);
+    b->plane_bytes_total = std::max<size_t>(po, 256);
+
+    // path resolution: fused kernels need one shared geometry
+    if (!(flags & JPGPU_BATCH_FORCE_GENERIC)) {
+        std::string why;
+        if (fused_plan(b->descs, b->fused, why)) b->path = b->fused.name;
+    }
+    hipError_t e;
+#define C_HIP(call)                                                                        \
+    if ((e = (call)) != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(e))
+    if (!(flags & JPGPU_BATCH_EXTERNAL_BUFFERS)) {
+        C_HIP(hipMalloc((void **)&b->d_coef, b->coef_bytes));
+        b->own_coef = true;
+        C_HIP(hipMalloc((void **)&b->d_out, b->out_bytes));
+        b->own_out = true;
+    }
+    if (b->path == "generic") {
+        C_HIP(hipMalloc((void **)&b->d_planes, b->plane_bytes_total));
+    } else {
+        rc = fused_alloc(b->fused, b->err);
+        if (rc) return rc;
+    }
+    C_HIP(hipMalloc((void **)&b->d_qt, (size_t)n_images * 4 * 64 * sizeof(uint16_t)));
+    {
+        std::vector<uint16_t> qt((size_t)n_images * 4 * 64, 1);
+        for (uint32_t i = 0; i < n_images; i++)
+            for (uint32_t c = 0; c < b->descs[i].ncomp; c++)
+                memcpy(&qt[((size_t)i * 4 + c) * 64], b->descs[i].quantization_tables[c], 128);
+        C_HIP(hipMemcpy(b->d_qt, qt.data(), qt.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    C_HIP(hipMalloc((void **)&b->d_plane_jobs, (size_t)n_images * 4 * sizeof(PlaneJob)));
+    C_HIP(hipMalloc((void **)&b->d_image_jobs, (size_t)n_images * sizeof(ImageJob)));
+    C_HIP(hipEventCreate(&b->ev0));
+    C_HIP(hipEventCreate(&b->ev1));
+#undef C_HIP
+    return JPGPU_OK;
+}
+
+void jpgpu_batch_destroy(jpgpu_batch *b) {
+    if (!b) return;
+    std::string err;
+    if (use_device(b->device, err) == JPGPU_OK) {
+        hipDeviceSynchronize();
+        if (b->own_coef && b->d_coef) hipFree(b->d_coef);
+        if (b->own_out && b->d_out) hipFree(b->d_out);
+        if (b->d_planes) hipFree(b->d_planes);
+        if (b->d_qt) hipFree(b->d_qt);
+        if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
+        if (b->d_image_jobs) hipFree(b->d_image_jobs);
+        fused_free(b->fused);
+        if (b->ev0) hipEventDestroy(b->ev0);
+        if (b->ev1) hipEventDestroy(b->ev1);
+    }
+    delete b;
+}
+
+const char *jpgpu_batch_last_error(const jpgpu_batch *b) { return b ? b->err.c_str() : ""; }
+const char *jpgpu_batch_path(const jpgpu_batch *b) { return b ? b->path.c_str() : ""; }
+size_t jpgpu_batch_coef_arena_bytes(const jpgpu_batch *b) { return b ? b->coef_bytes : 0; }
+size_t jpgpu_batch_out_arena_bytes(const jpgpu_batch *b) { return b ? b->out_bytes : 0; }
+size_t jpgpu_batch_coef_offset(const jpgpu_batch *b, uint32_t image, uint32_t comp) {
+    return (b && image < b->descs.size() && comp < 4) ? b->coef_off[image * 4 + comp] : 0;
+}
+size_t jpgpu_batch_coef_bytes(const jpgpu_batch *b, uint32_t image, uint32_t comp) {
+    return (b && image < b->descs.size() && comp < 4) ? b->coef_len[image * 4 + comp] : 0;
+}
+size_t jpgpu_batch_out_offset(const jpgpu_batch *b, uint32_t image) {
+    return (b && image < b->descs.size()) ? b->out_off[image] : 0;
+}
+size_t jpgpu_batch_out_bytes(const jpgpu_batch *b, uint32_t image) {
+    return (b && image < b->descs.size()) ? b->out_len[image] : 0;
+}
+void *jpgpu_batch_coef_arena(const jpgpu_batch *b) { return b ? b->d_coef : nullptr; }
+void *jpgpu_batch_out_arena(const jpgpu_batch *b) { return b ? b->d_out : nullptr; }
+
+int jpgpu_batch_bind(jpgpu_batch *b, void *device_coef_arena, void *device_out_arena) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    if (!(b->flags & JPGPU_BATCH_EXTERNAL_BUFFERS)) return set_err(b->err, JPGPU_ERR_FORMAT, "batch owns its buffers");
+    if (!device_coef_arena || !device_out_arena || ((uintptr_t)device_coef_arena & 255) || ((uintptr_t)device_out_arena & 255))
+        return set_err(b->err, JPGPU_ERR_FORMAT, "bind: arenas must be non-null and 256-byte aligned");
+    b->d_coef = (uint8_t *)device_coef_arena;
+    b->d_out = (uint8_t *)device_out_arena;
+    b->jobs_dirty = true;
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane) {
+    if (!b || image >= b->descs.size()) return JPGPU_ERR_FORMAT;
+    for (uint32_t c = 0; c < 4; c++) b->sane[image * 4 + c] = sane ? 1 : 0;
+    b->jobs_dirty = true;
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int16_t *coefficients, size_t len) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    if (image >= b->descs.size() || comp >= b->descs[image].ncomp || !coefficients)
+        return set_err(b->err, JPGPU_ERR_FORMAT, "upload: bad image/component");
+    if (len * sizeof(int16_t) != b->coef_len[image * 4 + comp])
+        return set_err(b->err, JPGPU_ERR_FORMAT, "upload: %zu coefficients, geometry needs %zu", len,
+                       b->coef_len[image * 4 + comp] / sizeof(int16_t));
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    // range scan (part of H2D staging): per-position max |c| times q must stay below 2^19 for
+    // the 24-bit multiply path to be exact (see DESIGN.md "exactness of the fast path")
+    uint8_t sane = 0;
+    if (!(b->flags & JPGPU_BATCH_ASSUME_HOSTILE)) {
+        int32_t mx[64];
+        for (int k = 0; k < 64; k++) mx[k] = 0;
+        const size_t nblk = len / 64;
+        for (size_t blk = 0; blk < nblk; blk++) {
+            const int16_t *p = coefficients + blk * 64;
+            for (int k = 0; k < 64; k++) {
+                int32_t v = p[k];
+                v = v < 0 ? -v : v;
+                mx[k] = v > mx[k] ? v : mx[k];
+            }
+        }
+        sane = 1;
+        const uint16_t *q = b->descs[image].quantization_tables[comp];
+        for (int k = 0; k < 64; k++)
+            if ((int64_t)mx[k] * q[k] >= (1 << 19)) sane = 0;
+    }
+    if (b->sane[image * 4 + comp] != sane) {
+        b->sane[image * 4 + comp] = sane;
+        b->jobs_dirty = true;
+    }
+    B_HIP(hipMemcpy(b->d_coef + b->coef_off[image * 4 + comp], coefficients, len * sizeof(int16_t), hipMemcpyHostToDevice));
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    rc = batch_refresh_jobs(b);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (b->path != "generic") {
+        B_HIP(fused_launch(b->fused, s));
+        return JPGPU_OK;
+    }
+    const uint32_t n = (uint32_t)b->descs.size();
+    static const uint32_t kScales[4] = {8, 4, 2, 1};
+    for (uint32_t sc : kScales)
+        if (b->scales[sc]) B_HIP(launch_idct_planes(b->d_plane_jobs, (uint32_t)b->plane_jobs.size(), b->max_blocks, sc, s));
+    B_HIP(launch_upsample_color(b->d_image_jobs, n, b->max_w, b->max_h, s));
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_synchronize(jpgpu_batch *b, void *hip_stream) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    B_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_download(jpgpu_batch *b, uint32_t image, uint8_t *dst, size_t cap, size_t *len) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    if (image >= b->descs.size()) return set_err(b->err, JPGPU_ERR_FORMAT, "download: bad image");
+    const size_t n = b->out_len[image];
+    if (len) *len = n;
+    if (!dst || cap < n) return set_err(b->err, JPGPU_ERR_FORMAT, "download: destination too small");
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_out) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    B_HIP(hipDeviceSynchronize());
+    if (n) B_HIP(hipMemcpy(dst, b->d_out + b->out_off[image], n, hipMemcpyDeviceToHost));
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_time(jpgpu_batch *b, void *hip_stream, uint32_t iters, float *ms_per_decode) {
+    if (!b || !ms_per_decode || iters == 0) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    rc = jpgpu_batch_decode(b, hip_stream);  // warm-up + job upload
+    if (rc) return rc;
+    B_HIP(hipStreamSynchronize(s));
+    B_HIP(hipEventRecord(b->ev0, s));
+    for (uint32_t i = 0; i < iters; i++) {
+        rc = jpgpu_batch_decode(b, hip_stream);
+        if (rc) return rc;
+    }
+    B_HIP(hipEventRecord(b->ev1, s));
+    B_HIP(hipEventSynchronize(b->ev1));
+    float ms = 0.f;
+    B_HIP(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    *ms_per_decode = ms / (float)iters;
+    return JPGPU_OK;
+}
+
+}  // extern "C"

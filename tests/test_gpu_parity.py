@@ -1,0 +1,320 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/jpgpu.h), against
+the CPU oracle on the same seeded inputs and against the committed golden vectors.
+Bit-exact everywhere (integer / byte work)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import refimages as R
+import synth
+
+pytestmark = pytest.mark.gpu
+
+J = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _load():
+    global J
+    import jpeg_decoder_amd as pkg
+    J = pkg
+    assert J.device_count() >= 1, "no MI355X visible: the HIP path has no CPU fallback"
+
+
+def to_j(comps):
+    """oracle Component -> product Component (same field order and layout)."""
+    out = (J.Component * len(comps))()
+    for i, c in enumerate(comps):
+        out[i].identifier, out[i].horizontal_sampling_factor, out[i].vertical_sampling_factor = c.identifier, c.h, c.v
+        out[i].quantization_table_index, out[i].dct_scale = c.tq, c.dct_scale
+        out[i].size_width, out[i].size_height, out[i].block_width, out[i].block_height = c.size_w, c.size_h, c.block_w, c.block_h
+    return out
+
+
+def gpu_plane(worker, comp, qt, coefs, index=0, row_by_row=False):
+    per_row = comp.block_width * comp.vertical_sampling_factor * 64
+    n_rows = len(coefs) // per_row
+    worker.start(J.RowData(index, comp, qt))
+    if row_by_row:
+        for r in range(n_rows):
+            worker.append_row((index, coefs[r * per_row:(r + 1) * per_row]))
+    elif n_rows:
+        worker.append_rows_contiguous(index, coefs, n_rows)
+    return worker.get_result(index, comp)
+
+
+# ---- IDCT --------------------------------------------------------------------------------
+def test_idct_kats_through_worker():
+    kat = json.load(open(os.path.join(R.GOLDEN, "idct_kat.json")))
+    ocomps, _ = O.make_components(8, 8, [(1, 1)])
+    comps = to_j(ocomps)
+    with J.HipWorker() as w:
+        for name in ("kat_8x8", "all_zero", "saturated"):
+            k = kat[name]
+            plane = gpu_plane(w, comps[0], k["quantization_table"], np.array(k["coefficients"], np.int16))
+            assert list(plane) == k["expected"], name
+        k = kat["h2_column_shortcut"]
+        plane = gpu_plane(w, comps[0], k["quantization_table"], np.array(k["coefficients"], np.int16))
+        assert list(plane[:8]) == k["expected_row0"]
+
+
+def test_idct_adversarial_blocks_bit_exact():
+    rng = np.random.default_rng(11)
+    blocks, qts = synth.adversarial_blocks(rng)
+    ocomps, _ = O.make_components(8, 8, [(1, 1)])
+    comps = to_j(ocomps)
+    with J.HipWorker() as w:
+        for c, q in zip(blocks, qts):
+            got = gpu_plane(w, comps[0], q, c)
+            want = O.idct_plane(ocomps[0], q, c)
+            assert np.array_equal(got, want), (c.tolist(), q.tolist())
+
+
+@pytest.mark.parametrize("scale", [8, 4, 2, 1])
+@pytest.mark.parametrize("kind", ["sparse", "full_range"])
+def test_idct_random_planes_bit_exact(scale, kind):
+    rng = np.random.default_rng(100 + scale)
+    for (w_, h_, samp) in [(333, 97, [(1, 1)]), (640, 480, [(2, 2), (1, 1), (1, 1)]), (17, 1000, [(1, 2), (1, 1), (1, 1)])]:
+        ocomps, _ = O.make_components(w_, h_, samp, dct_scale=scale)
+        comps = to_j(ocomps)
+        with J.HipWorker() as w:
+            for i, oc in enumerate(ocomps):
+                nblk = oc.block_w * oc.block_h
+                if kind == "sparse":
+                    coefs = synth.sparse_coefficients(rng, nblk)
+                    qt = rng.integers(1, 256, 64).astype(np.uint16)
+                else:  # uniform i16 x u16: wraps everywhere (reference: src/idct.rs:1-3)
+                    coefs = rng.integers(-32768, 32768, nblk * 64).astype(np.int16)
+                    qt = rng.integers(1, 65536, 64).astype(np.uint16)
+                got = gpu_plane(w, comps[i], qt, coefs, index=i, row_by_row=(i == 1))
+                want = O.idct_plane(oc, qt, coefs)
+                assert np.array_equal(got, want), (scale, kind, w_, h_, i)
+
+
+def test_partial_rows_leave_zero_plane_tail():
+    """rows never appended stay 0 (results.resize(.., 0), src/worker/rayon.rs:40-49)."""
+    ocomps, _ = O.make_components(64, 64, [(1, 1)])
+    comps = to_j(ocomps)
+    rng = np.random.default_rng(5)
+    coefs = synth.sparse_coefficients(rng, 8 * 3)
+    qt = rng.integers(1, 64, 64).astype(np.uint16)
+    with J.HipWorker() as w:
+        got = gpu_plane(w, comps[0], qt, coefs)
+    want = O.idct_plane(ocomps[0], qt, coefs, n_mcu_rows=3)
+    assert np.array_equal(got, want)
+    assert not got[3 * 8 * 64:].any()
+
+
+def test_worker_error_behaviour():
+    ocomps, _ = O.make_components(16, 16, [(1, 1)])
+    comps = to_j(ocomps)
+    with J.HipWorker() as w:
+        with pytest.raises(J.InternalError):  # append before start
+            w.append_row((0, np.zeros(128, np.int16)))
+        w.start(J.RowData(0, comps[0], np.ones(64, np.uint16)))
+        with pytest.raises(J.InternalError):  # assert_eq!(data.len(), block_count * 64)
+            w.append_row((0, np.zeros(64, np.int16)))
+        assert w.get_result(3).size == 0  # mem::take of an empty Vec
+
+
+# ---- upsample + colour ---------------------------------------------------------------------
+CASES = [
+    # (w, h, sampling, colour transform)
+    (33, 17, [(2, 2), (1, 1), (1, 1)], "YCbCr"),   # H2V2 (4:2:0)
+    (1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),     # output_width == 1 -> H1V1 override
+    (2, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),     # output_height == 1 -> v1 override (H2V1)
+    (1, 5, [(2, 2), (1, 1), (1, 1)], "YCbCr"),     # H1V2 through the width-1 override
+    (3, 3, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (960, 72, [(2, 1), (1, 1), (1, 1)], "YCbCr"),  # H2V1 (4:2:2)
+    (50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"),   # H1V2 (4:4:0)
+    (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"),   # 4:4:4
+    (45, 29, [(1, 1), (1, 1), (1, 1)], "RGB"),
+    (45, 29, [(1, 1), (1, 1), (1, 1)], "None"),    # planar-in-row quirk (src/decoder.rs:1476-1484)
+    (70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"),   # Generic (4:1:1)
+    (70, 41, [(4, 2), (1, 1), (2, 1)], "YCbCr"),   # Generic + H2V... mixes
+    (64, 48, [(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"),
+    (65, 47, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"),   # jpg-cmyk-2 shape
+    (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
+    (37, 21, [(1, 1)], "Grayscale"),
+    (40, 24, [(2, 2)], "Grayscale"),                      # stride compaction
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[1]}-{'_'.join(f'{h}{v}' for h, v in c[2])}-{c[3]}")
+@pytest.mark.parametrize("scale", [8, 2])
+def test_compute_image_matches_oracle(case, scale):
+    w_, h_, samp, ct = case
+    rng = np.random.default_rng(hash((w_, h_, len(samp), scale)) % (2 ** 32))
+    ocomps, _ = O.make_components(w_, h_, samp, dct_scale=scale)
+    comps = to_j(ocomps)
+    out_w, out_h = J.scaled_output_size(w_, h_, scale)
+    planes = [rng.integers(0, 256, O.plane_bytes(c)).astype(np.uint8) for c in ocomps]
+    want = O.compute_image(ocomps, planes, out_w, out_h, ct.upper())
+    got = J.compute_image_parallel(list(comps), planes, (out_w, out_h), ct)
+    assert got.size == want.size
+    assert np.array_equal(got, want)
+
+
+def test_compute_image_errors_match_reference():
+    ocomps, _ = O.make_components(16, 16, [(2, 2), (1, 1), (1, 1)])
+    comps = list(to_j(ocomps))
+    planes = [np.zeros(O.plane_bytes(c), np.uint8) for c in ocomps]
+    for ct, exc in (("Grayscale", J.FormatError), ("CMYK", J.FormatError), ("YCCK", J.FormatError),
+                    ("JcsBgYcc", J.UnsupportedError), ("Unknown", J.FormatError)):
+        with pytest.raises(exc):
+            J.compute_image_parallel(comps, planes, (16, 16), ct)
+    with pytest.raises(J.FormatError):  # "not all components have data"
+        J.compute_image_parallel(comps, [planes[0], np.zeros(0, np.uint8), planes[2]], (16, 16), "YCbCr")
+    bad, _ = O.make_components(16, 16, [(3, 1), (2, 1), (1, 1)])
+    with pytest.raises(J.UnsupportedError):  # NonIntegerSubsamplingRatio
+        J.compute_image_parallel(list(to_j(bad)), [np.zeros(O.plane_bytes(c), np.uint8) for c in bad], (16, 16), "YCbCr")
+
+
+# ---- whole path on the reference's own images ------------------------------------------------
+def _gpu_pixels_from_intermediates(d, device_resident):
+    comps = to_j(d.components)
+    with J.HipWorker() as w:
+        planes = []
+        for i in range(d.ncomp):
+            assert d.coefs[i] is not None
+            w.start(J.RowData(i, comps[i], d.qtables[i]))
+            per_row = comps[i].block_width * comps[i].vertical_sampling_factor * 64
+            for r in range(len(d.coefs[i]) // per_row):
+                w.append_row((i, d.coefs[i][r * per_row:(r + 1) * per_row]))
+            if device_resident:
+                w.finish_plane(i, i)
+            else:
+                planes.append(w.get_result(i, comps[i]))
+        return w.compute_image(list(comps), None if device_resident else planes, (d.width, d.height), d.color_transform)
+
+
+@pytest.mark.parametrize("rel", R.reftest_files(include_disabled=False))
+def test_reftest_images_bit_exact_and_within_tolerance(rel):
+    path = os.path.join(R.REFTEST, rel)
+    d = O.decode(open(path, "rb").read(), keep_intermediates=True)
+    got = _gpu_pixels_from_intermediates(d, device_resident=True)
+    assert np.array_equal(got, d.pixels), rel
+    key = "reftest/" + rel
+    hashes = R.golden_hashes()
+    if key in hashes:
+        assert hashlib.sha256(got.tobytes()).hexdigest() == hashes[key]
+    assert R.max_diff_vs_png(got, d.ncomp, os.path.splitext(path)[0] + ".png") <= 3
+
+
+@pytest.mark.parametrize("name", ["tower.jpg", "tower_progressive.jpg", "tower_grayscale.jpg", "large_image.jpg"])
+def test_bench_images_bit_exact(name):
+    d = O.decode(open(os.path.join(R.GOLDEN, "benches", name), "rb").read(), keep_intermediates=True)
+    got = _gpu_pixels_from_intermediates(d, device_resident=False)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == R.golden_hashes()["benches/" + name]
+
+
+@pytest.mark.parametrize("req", [(250, 167), (125, 84), (63, 42)])
+def test_scaled_decode_bit_exact(req):
+    d = O.decode(open(os.path.join(R.REFTEST, "rgb.jpg"), "rb").read(), scale_to=req, keep_intermediates=True)
+    got = _gpu_pixels_from_intermediates(d, device_resident=True)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == R.golden_hashes()[f"reftest/rgb.jpg@{req[0]}x{req[1]}"]
+
+
+# ---- batch driver ------------------------------------------------------------------------------
+def _batch_case(rng, w_, h_, samp, ct, kind="sparse"):
+    ocomps, _ = O.make_components(w_, h_, samp)
+    qts = [rng.integers(1, 200, 64).astype(np.uint16) for _ in ocomps]
+    if kind == "sparse":
+        coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h) for c in ocomps]
+    else:
+        coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
+        qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
+    return ocomps, qts, coefs, ct, w_, h_
+
+
+def _run_batch(cases, flags=0):
+    descs = [J.image_desc(list(to_j(oc)), qts, w_, h_, ct) for oc, qts, _, ct, w_, h_ in cases]
+    b = J.Batch(descs, flags=flags)
+    for i, (oc, qts, coefs, ct, _w, _h) in enumerate(cases):
+        for c in range(len(oc)):
+            b.upload(i, c, coefs[c])
+    b.decode()
+    b.synchronize()
+    outs = [b.download(i) for i in range(len(cases))]
+    path = b.path
+    b.close()
+    return outs, path
+
+
+def test_batch_heterogeneous_generic_path():
+    rng = np.random.default_rng(77)
+    cases = [
+        _batch_case(rng, 64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+        _batch_case(rng, 33, 21, [(1, 1), (1, 1), (1, 1)], "RGB"),
+        _batch_case(rng, 100, 9, [(1, 1)], "Grayscale"),
+        _batch_case(rng, 31, 70, [(2, 1), (1, 1), (1, 1)], "YCbCr", kind="full"),
+        _batch_case(rng, 16, 16, [(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"),
+    ]
+    outs, path = _run_batch(cases)
+    assert path == "generic"
+    for (oc, qts, coefs, ct, w_, h_), got in zip(cases, outs):
+        want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper())
+        assert np.array_equal(got, want)
+
+
+SAME_GEOMETRY = [
+    (64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (33, 17, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (129, 257, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+    (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+    (37, 21, [(1, 1)], "Grayscale"),
+    (300, 200, [(1, 1)], "Grayscale"),
+]
+
+
+@pytest.mark.parametrize("case", SAME_GEOMETRY, ids=lambda c: f"{c[0]}x{c[1]}-{len(c[2])}c-{c[2][0][0]}{c[2][0][1]}")
+@pytest.mark.parametrize("kind", ["sparse", "full"])
+def test_batch_same_geometry_fast_path_bit_exact(case, kind):
+    """Same-geometry batches resolve to the fused kernels; results must equal the oracle and the
+    generic path byte for byte, for sane (24-bit multiply path) and hostile (wrap-exact) data."""
+    w_, h_, samp, ct = case
+    rng = np.random.default_rng(w_ * 1000 + h_)
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind=kind) for _ in range(5)]
+    # all images of a batch share q-tables only by accident; keep them distinct on purpose
+    outs, path = _run_batch(cases)
+    outs_generic, path_g = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
+    assert path_g == "generic"
+    for (oc, qts, coefs, ct_, _w, _h), got, gen in zip(cases, outs, outs_generic):
+        want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
+        assert np.array_equal(gen, want), "generic path"
+        assert np.array_equal(got, want), f"path {path}"
+
+
+def test_batch_1080p_420_full_size_properties():
+    """BASELINE configs[1] geometry at full size: oracle on 2 images, then size-independent
+    properties over the whole batch (identical inputs -> identical outputs; distinct seeds differ)."""
+    rng = np.random.default_rng(2024)
+    w_, h_ = 1920, 1080
+    ocomps, _ = O.make_components(w_, h_, [(2, 2), (1, 1), (1, 1)])
+    jc = to_j(ocomps)
+    lum, chr_ = synth.quality_tables(85)
+    qts = [lum, chr_, chr_]
+    rgb = synth.synthetic_rgb(w_, h_)
+    base = synth.coefficients_from_rgb(rgb, jc, "ycbcr", qts)
+    other = [synth.sparse_coefficients(rng, c.block_w * c.block_h) for c in ocomps]
+    n = 12
+    cases = [(ocomps, qts, other if i == 5 else base, "YCbCr", w_, h_) for i in range(n)]
+    outs, path = _run_batch(cases)
+    want_base = O.pixels_from_coefficients(ocomps, qts, base, w_, h_, "YCBCR")
+    want_other = O.pixels_from_coefficients(ocomps, qts, other, w_, h_, "YCBCR")
+    digest = hashlib.sha256(want_base.tobytes()).hexdigest()
+    for i, got in enumerate(outs):
+        if i == 5:
+            assert np.array_equal(got, want_other)
+        else:
+            assert hashlib.sha256(got.tobytes()).hexdigest() == digest, (i, path)
+    # the decoded synthetic image is close to its source (sanity of the whole chain)
+    err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
+    assert err.mean() < 6.0
