@@ -155,7 +155,7 @@ void *jpgpu_batch_out_arena(const jpgpu_batch *b);  /* device pointer */
 int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int16_t *coefficients,
                        size_t len);
 /* For coefficients written straight into a bound arena: tell the backend whether every
- * |coefficient * q| stays below 2^19 for this image (sane != 0) so the 24-bit multiply path
+ * |coefficient * q| stays below 2^15 for this image (sane != 0) so the 24-bit multiply path
  * is exact, or 0 to force the wrap-exact path. Default for never-uploaded images: 0. */
 int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane);
 

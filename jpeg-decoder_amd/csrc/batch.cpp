@@ -38,7 +38,7 @@ struct jpgpu_batch {
     ImageJob *d_image_jobs = nullptr;
     std::vector<PlaneJob> plane_jobs;
     std::vector<ImageJob> image_jobs;
-    std::vector<uint8_t> sane;  // per image*4+comp: 1 if every |c*q| < 2^19 (24-bit path exact)
+    std::vector<uint8_t> sane;  // per image*4+comp: 1 if every |c*q| < 2^15 (24-bit path exact)
     uint32_t max_blocks = 0, max_w = 0, max_h = 0;
     bool scales[9] = {false, false, false, false, false, false, false, false, false};
     bool jobs_dirty = true;
@@ -245,8 +245,8 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
     int rc = use_device(b->device, b->err);
     if (rc) return rc;
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
-    // range scan (part of H2D staging): per-position max |c| times q must stay below 2^19 for
-    // the 24-bit multiply path to be exact (see DESIGN.md "exactness of the fast path")
+    // range scan (part of H2D staging): per-position max |c| times q must stay below 2^15 for
+    // the 24-bit multiply path to be exact (pixel_math.hpp idct8x8<SANE>)
     uint8_t sane = 0;
     if (!(b->flags & JPGPU_BATCH_ASSUME_HOSTILE)) {
         int32_t mx[64];
@@ -263,7 +263,7 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
         sane = 1;
         const uint16_t *q = b->descs[image].quantization_tables[comp];
         for (int k = 0; k < 64; k++)
-            if ((int64_t)mx[k] * q[k] >= (1 << 19)) sane = 0;
+            if ((int64_t)mx[k] * q[k] >= (1 << 15)) sane = 0;
     }
     if (b->sane[image * 4 + comp] != sane) {
         b->sane[image * 4 + comp] = sane;

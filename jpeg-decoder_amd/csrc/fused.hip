@@ -1,11 +1,157 @@
-// fused.hip — placeholder until the fused kernels land (next commit): no plan resolves.
+// fused.hip — gfx950 wrappers + host plan of the fused fast-path kernels (fused_core.hpp).
+//
+// Launch geometry: grid = (tiles per MCU row, MCU rows, images), 256 threads.  One workgroup
+// covers TX consecutive MCUs of one MCU row, so its pixel stores are 16 (4:2:0) or 8 scanline
+// runs of TX*48 / TX*24 contiguous bytes, and its coefficient loads are two (4:2:0 luma) or
+// three (4:4:4) contiguous runs of TX*256 / TX*128 bytes.
 #include "fused.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "fused_plan.hpp"
 #include "host_common.hpp"
+#include "idct_plane_body.hpp"
+
 namespace jpgpu {
-bool fused_plan(const std::vector<jpgpu_image_desc> &, FusedPlan &, std::string &why) { why = "not built"; return false; }
-int fused_alloc(FusedPlan &, std::string &) { return JPGPU_OK; }
-int fused_bind(FusedPlan &, uint8_t *, uint8_t *, uint16_t *, const std::vector<size_t> &, const std::vector<size_t> &,
-               const std::vector<uint8_t> &, std::string &) { return JPGPU_OK; }
-hipError_t fused_launch(FusedPlan &, hipStream_t) { return hipSuccess; }
-void fused_free(FusedPlan &) {}
+
+__global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const FusedImage *__restrict__ imgs, uint32_t n_blocks) {
+    __shared__ uint4 lds[256 * 8];
+    const FusedImage &img = imgs[blockIdx.z];
+    PlaneJob job;
+    job.coefs = img.coefs[1 + blockIdx.y];
+    job.plane = img.scratch + (size_t)blockIdx.y * g.chroma_plane_bytes;
+    job.qt = img.qt[1 + blockIdx.y];
+    job.block_w = g.bwc;
+    job.n_blocks = n_blocks;
+    job.scale = 8;
+    job.flags = img.flags;
+    idct_planes_body<8>(job, blockIdx.x, lds);
+}
+
+__global__ __launch_bounds__(256) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    __shared__ FusedLds lds;
+    const FusedImage img = imgs[blockIdx.z];
+    FusedRegs r;
+    F420::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    __syncthreads();
+    F420::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    __syncthreads();
+    F420::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    __syncthreads();
+    F420::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+}
+
+__global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    __shared__ FusedLds lds;
+    const FusedImage img = imgs[blockIdx.z];
+    FusedRegs r;
+    F444::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    __syncthreads();
+    F444::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    __syncthreads();
+    F444::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    __syncthreads();
+    F444::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+}
+
+__global__ __launch_bounds__(256) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    __shared__ FusedLds lds;
+    const FusedImage img = imgs[blockIdx.z];
+    FGray::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    __syncthreads();
+    FGray::phase1(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+}
+
+// ---- host side ------------------------------------------------------------------------------
+bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std::string &why) {
+    plan.kind = FUSED_NONE;
+    if (descs.empty() || descs.size() > 65535u) return false;
+    const jpgpu_image_desc &d0 = descs[0];
+    for (const auto &d : descs) {
+        if (d.ncomp != d0.ncomp || d.out_w != d0.out_w || d.out_h != d0.out_h || d.color_transform != d0.color_transform) {
+            why = "mixed geometry";
+            return false;
+        }
+        for (uint32_t c = 0; c < d.ncomp; c++)
+            if (!fused_same_component(d.components[c], d0.components[c])) {
+                why = "mixed geometry";
+                return false;
+            }
+    }
+    FusedGeom g{};
+    const char *name = "", *w = "";
+    int kind = fused_geom_from_desc(d0, g, name, w);
+    if (kind == FUSED_NONE) {
+        why = w;
+        return false;
+    }
+    plan.kind = kind;
+    plan.name = name;
+    plan.geom = g;
+    plan.desc = d0;
+    plan.n_images = (uint32_t)descs.size();
+    plan.scratch_per_image = plan.kind == FUSED_420 ? align_up(2 * (size_t)g.chroma_plane_bytes, 256) : 0;
+    plan.images.assign(plan.n_images, FusedImage{});
+    return true;
+}
+
+int fused_alloc(FusedPlan &plan, std::string &err) {
+    if (plan.kind == FUSED_NONE) return JPGPU_OK;
+    hipError_t e;
+    if (plan.scratch_per_image) {
+        e = hipMalloc((void **)&plan.d_scratch, plan.scratch_per_image * plan.n_images);
+        if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(scratch): %s", hipGetErrorString(e));
+    }
+    e = hipMalloc((void **)&plan.d_images, sizeof(FusedImage) * plan.n_images);
+    if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(images): %s", hipGetErrorString(e));
+    return JPGPU_OK;
+}
+
+int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt, const std::vector<size_t> &coef_off,
+               const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err) {
+    if (plan.kind == FUSED_NONE) return JPGPU_OK;
+    for (uint32_t i = 0; i < plan.n_images; i++) {
+        FusedImage &im = plan.images[i];
+        bool all_sane = true;
+        for (uint32_t c = 0; c < plan.desc.ncomp; c++) {
+            im.coefs[c] = reinterpret_cast<const int16_t *>(d_coef + coef_off[i * 4 + c]);
+            im.qt[c] = d_qt + ((size_t)i * 4 + c) * 64;
+            all_sane = all_sane && sane[i * 4 + c];
+        }
+        im.out = d_out + out_off[i];
+        im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)i * plan.scratch_per_image : nullptr;
+        im.flags = all_sane ? 1u : 0u;
+    }
+    hipError_t e = hipMemcpy(plan.d_images, plan.images.data(), sizeof(FusedImage) * plan.n_images, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMemcpy(images): %s", hipGetErrorString(e));
+    return JPGPU_OK;
+}
+
+hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
+    const FusedGeom &g = plan.geom;
+    dim3 block(FUSED_NT);
+    dim3 grid(g.tiles_x, g.mcu_h, plan.n_images);
+    switch (plan.kind) {
+    case FUSED_420: {
+        uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
+        dim3 cgrid((nblk + 255u) / 256u, 2, plan.n_images);
+        f420_chroma_kernel<<<cgrid, block, 0, stream>>>(g, plan.d_images, nblk);
+        f420_main_kernel<<<grid, block, 0, stream>>>(g, plan.d_images);
+        break;
+    }
+    case FUSED_444: f444_kernel<<<grid, block, 0, stream>>>(g, plan.d_images); break;
+    case FUSED_GRAY: fgray_kernel<<<grid, block, 0, stream>>>(g, plan.d_images); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+void fused_free(FusedPlan &plan) {
+    if (plan.d_scratch) (void)hipFree(plan.d_scratch);
+    if (plan.d_images) (void)hipFree(plan.d_images);
+    plan.d_scratch = nullptr;
+    plan.d_images = nullptr;
+}
+
 }  // namespace jpgpu

@@ -7,27 +7,16 @@
 #include <vector>
 
 #include "../../include/jpgpu.h"
+#include "fused_core.hpp"
 
 namespace jpgpu {
-
-enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3 };
-
-// Per-image pointers of a same-geometry batch.
-struct FusedImage {
-    const int16_t *coefs[4];
-    const uint16_t *qt[4];
-    uint8_t *out;
-    uint8_t *scratch;   // 4:2:0: Cb plane followed by Cr plane
-    uint32_t flags;     // bit0: all components "sane" -> 24-bit multiply path
-    uint32_t _pad;
-};
 
 struct FusedPlan {
     std::string name;
     int kind = FUSED_NONE;
     uint32_t n_images = 0;
     jpgpu_image_desc desc{};  // the shared geometry
-    uint32_t mcu_w = 0, mcu_h = 0;
+    FusedGeom geom{};
     size_t scratch_per_image = 0;
     uint8_t *d_scratch = nullptr;
     FusedImage *d_images = nullptr;

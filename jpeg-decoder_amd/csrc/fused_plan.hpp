@@ -1,0 +1,94 @@
+// fused_plan.hpp — host-only: which fused kernel (if any) serves a frame geometry, and its
+// tiling.  No HIP dependency so that tests/emu can use the same planner.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/jpgpu.h"
+#include "fused_core.hpp"
+
+namespace jpgpu {
+
+inline bool fused_same_component(const jpgpu_component &a, const jpgpu_component &b) {
+    return a.horizontal_sampling_factor == b.horizontal_sampling_factor &&
+           a.vertical_sampling_factor == b.vertical_sampling_factor && a.dct_scale == b.dct_scale &&
+           a.size_width == b.size_width && a.size_height == b.size_height && a.block_width == b.block_width &&
+           a.block_height == b.block_height;
+}
+
+// Returns FUSED_* and fills `g`; FUSED_NONE (with `why`) sends the batch down the generic path.
+inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why) {
+    g = FusedGeom{};
+    for (uint32_t c = 0; c < d0.ncomp; c++)
+        if (d0.components[c].dct_scale != 8) {
+            why = "scaled IDCT";
+            return FUSED_NONE;
+        }
+    auto hv = [&](uint32_t c, uint32_t h, uint32_t v) {
+        return d0.components[c].horizontal_sampling_factor == h && d0.components[c].vertical_sampling_factor == v;
+    };
+    int kind = FUSED_NONE;
+    uint32_t tx_max = 0;
+    g.out_w = d0.out_w;
+    g.out_h = d0.out_h;
+    g.bw0 = d0.components[0].block_width;
+    if (d0.ncomp == 3 && hv(0, 2, 2) && hv(1, 1, 1) && hv(2, 1, 1) && d0.color_transform == JPGPU_CT_YCBCR &&
+        d0.out_w > 1 && d0.out_h > 1 && fused_same_component(d0.components[1], d0.components[2])) {
+        // choose_upsampler (src/upsampler.rs:80-81): an output width/height of 1 overrides H2V2,
+        // such frames stay on the generic path
+        kind = FUSED_420;
+        name = "fused420";
+        g.mcu_w = d0.components[1].block_width;
+        g.mcu_h = d0.components[1].block_height;
+        g.bwc = d0.components[1].block_width;
+        g.cw = d0.components[1].size_width;
+        g.ch = d0.components[1].size_height;
+        g.chroma_plane_bytes = (uint32_t)d0.components[1].block_width * d0.components[1].block_height * 64u;
+        if (d0.components[0].block_width != 2u * g.mcu_w || d0.components[0].block_height != 2u * g.mcu_h ||
+            d0.out_w > 2u * g.cw || d0.out_h > 2u * g.ch) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = F420_TX_MAX;
+    } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&
+               (d0.color_transform == JPGPU_CT_YCBCR || d0.color_transform == JPGPU_CT_RGB) &&
+               fused_same_component(d0.components[0], d0.components[1]) &&
+               fused_same_component(d0.components[1], d0.components[2])) {
+        kind = FUSED_444;
+        name = "fused444";
+        g.mcu_w = d0.components[0].block_width;
+        g.mcu_h = d0.components[0].block_height;
+        g.bwc = d0.components[0].block_width;
+        g.color = d0.color_transform == JPGPU_CT_RGB ? FCOLOR_RGB : FCOLOR_YCBCR;
+        if (d0.out_w > 8u * g.mcu_w || d0.out_h > 8u * g.mcu_h) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = F444_TX_MAX;
+    } else if (d0.ncomp == 1 && hv(0, 1, 1)) {
+        kind = FUSED_GRAY;
+        name = "fusedgray";
+        g.mcu_w = d0.components[0].block_width;
+        g.mcu_h = d0.components[0].block_height;
+        g.out_w = d0.components[0].size_width;  // compute_image's 1-component size (src/decoder.rs:1314-1316)
+        g.out_h = d0.components[0].size_height;
+        if (g.out_w > 8u * g.mcu_w || g.out_h > 8u * g.mcu_h) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = FGRAY_TX_MAX;
+    } else {
+        why = "no fused kernel for this sampling / colour transform";
+        return FUSED_NONE;
+    }
+    if (g.mcu_w == 0 || g.mcu_h == 0 || g.mcu_h > 65535u) {
+        why = "grid limits";
+        return FUSED_NONE;
+    }
+    g.kind = (uint32_t)kind;
+    uint32_t n_tiles = (g.mcu_w + tx_max - 1) / tx_max;
+    g.tx = (g.mcu_w + n_tiles - 1) / n_tiles;
+    g.tiles_x = (g.mcu_w + g.tx - 1) / g.tx;
+    return kind;
+}
+
+}  // namespace jpgpu

@@ -1,0 +1,65 @@
+// idct_plane_body.hpp — workgroup body of the plane IDCT (shared by kernels.hip and fused.hip).
+#pragma once
+#include "kernels.hpp"
+#include "pixel_math.hpp"
+
+namespace jpgpu {
+
+// One lane per 8x8 block, 256 blocks per workgroup.  Coefficients are fetched with fully
+// coalesced 16-B loads (lane j of the workgroup reads chunk j of the workgroup's contiguous
+// 32 KiB) and staged in LDS so that each lane can then pull its own 128-B block with 8
+// ds_read_b128.  LDS slot of (block b, row k): b*8 + (k ^ ((b >> 1) & 7)), conflict-free for both
+// the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups (MI355X_MICROARCH.md §LDS).
+template <int SCALE>
+__device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t wg, uint4 *lds) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t first = wg * 256u;
+    if (first >= job.n_blocks) return;  // whole workgroup out of range (uniform)
+    const uint32_t nb = min(256u, job.n_blocks - first);
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(job.coefs + (size_t)first * 64);
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        uint32_t j = it * 256u + tid;
+        if (j < nb * 8u) {
+            uint32_t b = j >> 3, k = j & 7u;
+            lds[b * 8u + (k ^ ((b >> 1) & 7u))] = src[j];
+        }
+    }
+    __syncthreads();
+    if (tid >= nb) return;
+    uint32_t cw[32];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint4 v = lds[tid * 8u + ((uint32_t)k ^ ((tid >> 1) & 7u))];
+        cw[k * 4 + 0] = v.x;
+        cw[k * 4 + 1] = v.y;
+        cw[k * 4 + 2] = v.z;
+        cw[k * 4 + 3] = v.w;
+    }
+    const uint32_t b = first + tid;
+    const uint32_t bx = b % job.block_w, by = b / job.block_w;
+    const size_t stride = (size_t)job.block_w * SCALE;
+    uint8_t *dst = job.plane + (size_t)by * SCALE * stride + (size_t)bx * SCALE;
+    if constexpr (SCALE == 8) {
+        uint32_t out[16];
+        if (job.flags & 1u) idct8x8<true>(cw, job.qt, out);  // wave-uniform: one job per workgroup
+        else idct8x8<false>(cw, job.qt, out);
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            *reinterpret_cast<uint2 *>(dst + (size_t)r * stride) = make_uint2(out[2 * r], out[2 * r + 1]);
+    } else if constexpr (SCALE == 4) {
+        uint32_t out[4];
+        idct4x4_exact(cw, job.qt, out);
+#pragma unroll
+        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t *>(dst + (size_t)r * stride) = out[r];
+    } else if constexpr (SCALE == 2) {
+        uint32_t o = idct2x2_exact(cw, job.qt);
+        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(o & 0xffffu);
+        *reinterpret_cast<uint16_t *>(dst + stride) = (uint16_t)(o >> 16);
+    } else {
+        dst[0] = (uint8_t)idct1x1_exact(cw[0], job.qt);
+    }
+}
+
+
+}  // namespace jpgpu

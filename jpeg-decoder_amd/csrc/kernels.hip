@@ -12,6 +12,7 @@
 // fused.hip instead; this file is the path everything else (and every odd edge) runs on.
 #include "kernels.hpp"
 #include "pixel_math.hpp"
+#include "idct_plane_body.hpp"
 
 namespace jpgpu {
 
@@ -25,56 +26,6 @@ namespace jpgpu {
 // block = 8 consecutive 16-B slots; a ds_read_b128 16-lane group ({0-3,12-15,20-27}, ...) hits
 // 16 distinct slots mod 16 (MI355X_MICROARCH.md §LDS).
 // ------------------------------------------------------------------------------------------
-template <int SCALE>
-__device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t wg, uint4 *lds) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t first = wg * 256u;
-    if (first >= job.n_blocks) return;  // whole workgroup out of range (uniform)
-    const uint32_t nb = min(256u, job.n_blocks - first);
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(job.coefs + (size_t)first * 64);
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        uint32_t j = it * 256u + tid;
-        if (j < nb * 8u) {
-            uint32_t b = j >> 3, k = j & 7u;
-            lds[b * 8u + (k ^ ((b >> 1) & 7u))] = src[j];
-        }
-    }
-    __syncthreads();
-    if (tid >= nb) return;
-    uint32_t cw[32];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        uint4 v = lds[tid * 8u + ((uint32_t)k ^ ((tid >> 1) & 7u))];
-        cw[k * 4 + 0] = v.x;
-        cw[k * 4 + 1] = v.y;
-        cw[k * 4 + 2] = v.z;
-        cw[k * 4 + 3] = v.w;
-    }
-    const uint32_t b = first + tid;
-    const uint32_t bx = b % job.block_w, by = b / job.block_w;
-    const size_t stride = (size_t)job.block_w * SCALE;
-    uint8_t *dst = job.plane + (size_t)by * SCALE * stride + (size_t)bx * SCALE;
-    if constexpr (SCALE == 8) {
-        uint32_t out[16];
-        idct8x8_exact(cw, job.qt, out);
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-            *reinterpret_cast<uint2 *>(dst + (size_t)r * stride) = make_uint2(out[2 * r], out[2 * r + 1]);
-    } else if constexpr (SCALE == 4) {
-        uint32_t out[4];
-        idct4x4_exact(cw, job.qt, out);
-#pragma unroll
-        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t *>(dst + (size_t)r * stride) = out[r];
-    } else if constexpr (SCALE == 2) {
-        uint32_t o = idct2x2_exact(cw, job.qt);
-        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(o & 0xffffu);
-        *reinterpret_cast<uint16_t *>(dst + stride) = (uint16_t)(o >> 16);
-    } else {
-        dst[0] = (uint8_t)idct1x1_exact(cw[0], job.qt);
-    }
-}
-
 template <int SCALE>
 __global__ __launch_bounds__(256) void idct_planes_kernel(const PlaneJob *__restrict__ jobs) {
     __shared__ uint4 lds[256 * 8];
@@ -159,39 +110,36 @@ __device__ __forceinline__ void upsample_color_body(const ImageJob &job, uint32_
                 job.out[(size_t)row * job.out_w * nc + (size_t)c * job.out_w + x0 + k] = (uint8_t)s[c][k];
         return;
     }
-    uint32_t px[4][4];
+    // px[k] = byte 0..ncomp-1 of output pixel k
+    uint32_t px[4];
     for (uint32_t k = 0; k < 4; k++) {
         switch (job.color_fn) {
         case CC_RGB:  // :1391-1404
-            px[k][0] = s[0][k]; px[k][1] = s[1][k]; px[k][2] = s[2][k];
+            px[k] = s[0][k] | (s[1][k] << 8) | (s[2][k] << 16);
             break;
         case CC_YCBCR:  // :1406-1437
-            ycbcr_to_rgb(s[0][k], s[1][k], s[2][k], px[k][0], px[k][1], px[k][2]);
+            px[k] = ycbcr_to_rgb24(s[0][k], s[1][k], s[2][k]);
             break;
         case CC_YCCK:  // :1439-1456
-            ycbcr_to_rgb(s[0][k], s[1][k], s[2][k], px[k][0], px[k][1], px[k][2]);
-            px[k][3] = 255u - s[3][k];
+            px[k] = ycbcr_to_rgb24(s[0][k], s[1][k], s[2][k]) | ((255u - s[3][k]) << 24);
             break;
         default:  // CC_CMYK :1458-1474
-            px[k][0] = 255u - s[0][k]; px[k][1] = 255u - s[1][k];
-            px[k][2] = 255u - s[2][k]; px[k][3] = 255u - s[3][k];
+            px[k] = (255u - s[0][k]) | ((255u - s[1][k]) << 8) | ((255u - s[2][k]) << 16) | ((255u - s[3][k]) << 24);
             break;
         }
     }
     const size_t off = ((size_t)row * job.out_w + x0) * nc;
     uint8_t *o = job.out + off;
     if (nc == 4) {
-        for (uint32_t k = 0; k < n; k++)
-            reinterpret_cast<uint32_t *>(o)[k] = px[k][0] | (px[k][1] << 8) | (px[k][2] << 16) | (px[k][3] << 24);
+        for (uint32_t k = 0; k < n; k++) reinterpret_cast<uint32_t *>(o)[k] = px[k];
     } else if (n == 4 && ((reinterpret_cast<uintptr_t>(o) & 3u) == 0)) {
-        uint32_t d0 = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
-        uint32_t d1 = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
-        uint32_t d2 = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
         uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-        o32[0] = d0; o32[1] = d1; o32[2] = d2;
+        o32[0] = px[0] | (px[1] << 24);
+        o32[1] = (px[1] >> 8) | (px[2] << 16);
+        o32[2] = (px[2] >> 16) | (px[3] << 8);
     } else {
         for (uint32_t k = 0; k < n; k++) {
-            o[3 * k] = (uint8_t)px[k][0]; o[3 * k + 1] = (uint8_t)px[k][1]; o[3 * k + 2] = (uint8_t)px[k][2];
+            o[3 * k] = (uint8_t)px[k]; o[3 * k + 1] = (uint8_t)(px[k] >> 8); o[3 * k + 2] = (uint8_t)(px[k] >> 16);
         }
     }
 }

@@ -15,7 +15,7 @@ struct PlaneJob {
     uint32_t block_w;
     uint32_t n_blocks;     // blocks to transform (appended MCU rows * block_w * v)
     uint32_t scale;        // dct_scale: 8, 4, 2, 1
-    uint32_t flags;        // bit0: coefficients proven "sane" (|c*q| < 2^19) -> 24-bit multiply path allowed
+    uint32_t flags;        // bit0: coefficients proven "sane" (|c*q| < 2^15) -> 24-bit multiply path allowed
 };
 
 enum UpKind : uint32_t { UP_H1V1 = 0, UP_H2V1 = 1, UP_H1V2 = 2, UP_H2V2 = 3, UP_GENERIC = 4 };

@@ -3,12 +3,16 @@
 // Bit-exact restatement targets (image-rs/jpeg-decoder v0.3.2, scalar / platform_independent):
 //   src/idct.rs:241-452,568-578   dequantize + 8x8 IDCT (stb_image derived, Wrapping<i32>)
 //   src/idct.rs:456-565           reduced 4x4 / 2x2 / 1x1
-//   src/upsampler.rs:119-250      H1V1 / H2V1 / H1V2 / H2V2 / Generic
-//   src/decoder.rs:1391-1508      colour conversion (20-bit fixed point BT.601)
+//   src/decoder.rs:1486-1508      YCbCr -> RGB (20-bit fixed point BT.601)
 // All arithmetic that can wrap is done on uint32_t (defined mod 2^32); arithmetic right
 // shifts and clamps are done on int32_t, exactly as Wrapping<i32> behaves.
+//
+// The header is also compiled by g++ (tests/emu, -DJPGPU_HOST_EMULATION) so that kernel
+// logic can be checked against the oracle on the CPU; the product only ever runs it on gfx950.
 #pragma once
+#ifndef JPGPU_HOST_EMULATION
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace jpgpu {
@@ -16,7 +20,8 @@ namespace jpgpu {
 typedef uint32_t w32;
 
 // stbi_f2f(x) = (x * 4096.0f + 0.5f) as i32, evaluated in f32 (src/idct.rs:572-574).
-// Values pinned by SURVEY Appendix A.1 (static_asserts in tests/test_constants via the oracle).
+// Values as listed in SURVEY Appendix A.1; the oracle computes them with the f32 formula and
+// tests/test_emulation.py checks both agree on every block.
 constexpr int32_t F_0_5411961 = 2217;
 constexpr int32_t F_N1_847759065 = -7567;
 constexpr int32_t F_0_765366865 = 3135;
@@ -31,37 +36,82 @@ constexpr int32_t F_N1_961570560 = -8034;
 constexpr int32_t F_N0_390180644 = -1597;
 
 __device__ __forceinline__ w32 sar(w32 x, int n) { return (w32)((int32_t)x >> n); }
-__device__ __forceinline__ w32 mulc(w32 a, int32_t c) { return a * (w32)c; }
+
+// 24-bit multiply: low 32 bits of sext24(a) * sext24(b).  Exact mod 2^32 whenever both true
+// operands lie in [-2^23, 2^23) — v_mul_i32_i24 / v_mad_i32_i24 are full rate on gfx950 while
+// v_mul_lo_u32 is not.
+__device__ __forceinline__ w32 mul24(w32 a, int32_t c) {
+#ifdef JPGPU_HOST_EMULATION
+    int64_t x = (int64_t)((int32_t)(a << 8) >> 8) * (int64_t)((int32_t)((w32)c << 8) >> 8);
+    return (w32)x;
+#else
+    return (w32)__mul24((int)a, c);
+#endif
+}
+
+// multiply by an IDCT constant: SANE -> 24-bit path (caller guarantees the operand range),
+// otherwise the full 32-bit wrapping multiply.
+template <bool SANE>
+__device__ __forceinline__ w32 mulc(w32 a, int32_t c) {
+    if constexpr (SANE) return mul24(a, c);
+    else return a * (w32)c;
+}
+
+// sat_u8(a >> n) | sat_u8(b >> n) << 8, upper 16 bits zero.
+// gfx950 has v_ashr_pk_u8_i32 for exactly this.  NOTE (ROCm 7.2 / LLVM 22): when the compiler
+// pattern-matches the instruction on its own from `clamp(a>>n) | clamp(b>>n)<<8 | c<<16 ...`
+// it does not clear bits 31:16 of the result (found on the first GPU run: bytes 2,3 of every
+// packed dword were corrupted).  So the instruction is always used through the builtin, whose
+// 16-bit return type makes the compiler mask the upper half.
+__device__ __forceinline__ uint32_t sar_sat_u8x2(w32 a, w32 b, int n) {
+#ifdef JPGPU_HOST_EMULATION
+    int32_t x = (int32_t)a >> n, y = (int32_t)b >> n;
+    x = x < 0 ? 0 : (x > 255 ? 255 : x);
+    y = y < 0 ? 0 : (y > 255 ? 255 : y);
+    return (uint32_t)x | ((uint32_t)y << 8);
+#else
+    return (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a, (int)b, n);
+#endif
+}
+// four values -> one dword, byte 0 = a
+__device__ __forceinline__ uint32_t sar_sat_u8x4(w32 a, w32 b, w32 c, w32 d, int n) {
+    uint32_t lo = sar_sat_u8x2(a, b, n), hi = sar_sat_u8x2(c, d, n);
+#ifdef JPGPU_HOST_EMULATION
+    return lo | (hi << 16);
+#else
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // bytes: lo.0 lo.1 hi.0 hi.1
+#endif
+}
 __device__ __forceinline__ uint32_t clamp_u8(w32 x) {  // stbi_clamp, src/idct.rs:568-570
-    int32_t v = (int32_t)x;
-    return (uint32_t)min(max(v, 0), 255);
+    return sar_sat_u8x2(x, 0u, 0) & 0xffu;
 }
 
 // One 8-point pass = kernel_x + kernel_t (src/idct.rs:377-447) followed by the butterfly
 // of :318-325 / :361-368.  o[k] is the value *before* the final shift.
+template <bool SANE>
 __device__ __forceinline__ void idct_pass8(const w32 (&s)[8], w32 x_scale, w32 (&o)[8]) {
     // kernel_x (even part)
-    w32 p1 = mulc(s[2] + s[6], F_0_5411961);
-    w32 t2 = p1 + mulc(s[6], F_N1_847759065);
-    w32 t3 = p1 + mulc(s[2], F_0_765366865);
-    w32 t0 = (s[0] + s[4]) << 12;
-    w32 t1 = (s[0] - s[4]) << 12;
-    w32 x0 = t0 + t3 + x_scale;
-    w32 x3 = t0 - t3 + x_scale;
-    w32 x1 = t1 + t2 + x_scale;
-    w32 x2 = t1 - t2 + x_scale;
+    w32 p1 = mulc<SANE>(s[2] + s[6], F_0_5411961);
+    w32 t2 = p1 + mulc<SANE>(s[6], F_N1_847759065);
+    w32 t3 = p1 + mulc<SANE>(s[2], F_0_765366865);
+    w32 t0 = ((s[0] + s[4]) << 12) + x_scale;
+    w32 t1 = ((s[0] - s[4]) << 12) + x_scale;
+    w32 x0 = t0 + t3;
+    w32 x3 = t0 - t3;
+    w32 x1 = t1 + t2;
+    w32 x2 = t1 - t2;
     // kernel_t (odd part)
     w32 u0 = s[7], u1 = s[5], u2 = s[3], u3 = s[1];
     w32 p3 = u0 + u2, p4 = u1 + u3, q1 = u0 + u3, q2 = u1 + u2;
-    w32 p5 = mulc(p3 + p4, F_1_175875602);
-    u0 = mulc(u0, F_0_298631336);
-    u1 = mulc(u1, F_2_053119869);
-    u2 = mulc(u2, F_3_072711026);
-    u3 = mulc(u3, F_1_501321110);
-    q1 = p5 + mulc(q1, F_N0_899976223);
-    q2 = p5 + mulc(q2, F_N2_562915447);
-    p3 = mulc(p3, F_N1_961570560);
-    p4 = mulc(p4, F_N0_390180644);
+    w32 p5 = mulc<SANE>(p3 + p4, F_1_175875602);
+    u0 = mulc<SANE>(u0, F_0_298631336);
+    u1 = mulc<SANE>(u1, F_2_053119869);
+    u2 = mulc<SANE>(u2, F_3_072711026);
+    u3 = mulc<SANE>(u3, F_1_501321110);
+    q1 = p5 + mulc<SANE>(q1, F_N0_899976223);
+    q2 = p5 + mulc<SANE>(q2, F_N2_562915447);
+    p3 = mulc<SANE>(p3, F_N1_961570560);
+    p4 = mulc<SANE>(p4, F_N0_390180644);
     u3 += q1 + p4;
     u2 += q2 + p3;
     u1 += q2 + p4;
@@ -83,31 +133,41 @@ __device__ __forceinline__ int32_t coef_at(const uint32_t (&cw)[32], int r, int 
     return (c & 1) ? ((int32_t)d >> 16) : (int32_t)(int16_t)(d & 0xffffu);
 }
 
-// Exact 8x8 dequantize + IDCT of one block held by ONE lane.
+// 8x8 dequantize + IDCT of one block held by ONE lane (src/idct.rs:278-369).
 //   cw : 64 coefficients, packed as above
-//   q  : 64 u16 quantization values (natural order); wave-uniform pointer (scalar loads)
+//   q  : 64 u16 quantization values (natural order)
 //   out: 8 rows x 8 bytes, two dwords per row (byte 0 = leftmost sample)
-// Follows src/idct.rs:278-369 including both DC-only short-cuts: the column one is NOT
-// value-neutral under wrap-around and is selected per column; the row one is
-// algebraically identical to the general formula and is therefore not special-cased.
-__device__ __forceinline__ void idct8x8_exact(const uint32_t (&cw)[32], const uint16_t *__restrict__ q,
-                                              uint32_t (&out)[16]) {
+// SANE == false: wrap-exact for any input.  Both DC-only short-cuts of the reference are
+//   honoured: the column one is NOT value-neutral under wrap-around and is
+//   selected per column; the row one is algebraically identical to the general formula.
+// SANE == true : caller guarantees |c*q| < 2^15 for every coefficient.  Then every multiplicand
+//   of both passes lies inside [-2^23, 2^23) (column outputs are bounded by 5.55*sum|s| < 2^21,
+//   row multiplicands are sums of at most four of them), so 24-bit multiplies are exact, and the
+//   column short-cut equals the general formula (s0 << 12 cannot wrap).  See DESIGN.md.
+template <bool SANE>
+__device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint16_t *__restrict__ q,
+                                        uint32_t (&out)[16]) {
     w32 temp[64];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         w32 s[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = (w32)(coef_at(cw, k, i) * (int32_t)q[k * 8 + i]);
-        // raw-coefficient test of :279-285 on the packed halves
-        uint32_t acbits = 0;
-#pragma unroll
-        for (int k = 1; k < 8; k++) acbits |= cw[k * 4 + (i >> 1)];
-        bool dc_only = ((i & 1) ? (acbits >> 16) : (acbits & 0xffffu)) == 0;
+        for (int k = 0; k < 8; k++) s[k] = mul24((w32)coef_at(cw, k, i), (int32_t)q[k * 8 + i]);  // i16 x u16: always exact
         w32 o[8];
-        idct_pass8(s, 512u, o);
-        w32 dcterm = s[0] << 2;
+        idct_pass8<SANE>(s, 512u, o);
+        if constexpr (SANE) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) temp[k * 8 + i] = dc_only ? dcterm : sar(o[k], 10);
+            for (int k = 0; k < 8; k++) temp[k * 8 + i] = sar(o[k], 10);
+        } else {
+            // raw-coefficient test of :279-285 on the packed halves
+            uint32_t acbits = 0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) acbits |= cw[k * 4 + (i >> 1)];
+            bool dc_only = ((i & 1) ? (acbits >> 16) : (acbits & 0xffffu)) == 0;
+            w32 dcterm = s[0] << 2;
+#pragma unroll
+            for (int k = 0; k < 8; k++) temp[k * 8 + i] = dc_only ? dcterm : sar(o[k], 10);
+        }
     }
     const w32 X_SCALE = 65536u + (128u << 17);
 #pragma unroll
@@ -115,12 +175,9 @@ __device__ __forceinline__ void idct8x8_exact(const uint32_t (&cw)[32], const ui
         w32 s[8], o[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = temp[r * 8 + k];
-        idct_pass8(s, X_SCALE, o);
-        uint32_t b[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) b[k] = clamp_u8(sar(o[k], 17));
-        out[r * 2] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        out[r * 2 + 1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        idct_pass8<SANE>(s, X_SCALE, o);
+        out[r * 2] = sar_sat_u8x4(o[0], o[1], o[2], o[3], 17);
+        out[r * 2 + 1] = sar_sat_u8x4(o[4], o[5], o[6], o[7], 17);
     }
 }
 
@@ -136,9 +193,9 @@ __device__ __forceinline__ void idct4x4_exact(const uint32_t (&cw)[32], const ui
         w32 s3 = (w32)(coef_at(cw, 3, i) * (int32_t)q[24 + i]);
         w32 x0 = (s0 + s2) << 2;
         w32 x2 = (s0 - s2) << 2;
-        w32 p1 = mulc(s1 + s3, F_0_5411961);
-        w32 t0 = sar(p1 + mulc(s3, F_N1_847759065) + 512u, 10);
-        w32 t2 = sar(p1 + mulc(s1, F_0_765366865) + 512u, 10);
+        w32 p1 = (s1 + s3) * (w32)F_0_5411961;
+        w32 t0 = sar(p1 + s3 * (w32)F_N1_847759065 + 512u, 10);
+        w32 t2 = sar(p1 + s1 * (w32)F_0_765366865 + 512u, 10);
         temp[i] = x0 + t2;
         temp[i + 12] = x0 - t2;
         temp[i + 4] = x2 + t0;
@@ -149,15 +206,14 @@ __device__ __forceinline__ void idct4x4_exact(const uint32_t (&cw)[32], const ui
         w32 s0 = temp[i * 4], s1 = temp[i * 4 + 1], s2 = temp[i * 4 + 2], s3 = temp[i * 4 + 3];
         w32 x0 = ((s0 + s2) << 12) + (1u << 16) + (128u << 17);
         w32 x2 = ((s0 - s2) << 12) + (1u << 16) + (128u << 17);
-        w32 p1 = mulc(s1 + s3, F_0_5411961);
-        w32 t0 = p1 + mulc(s3, F_N1_847759065);
-        w32 t2 = p1 + mulc(s1, F_0_765366865);
-        out[i] = clamp_u8(sar(x0 + t2, 17)) | (clamp_u8(sar(x2 + t0, 17)) << 8) |
-                 (clamp_u8(sar(x2 - t0, 17)) << 16) | (clamp_u8(sar(x0 - t2, 17)) << 24);
+        w32 p1 = (s1 + s3) * (w32)F_0_5411961;
+        w32 t0 = p1 + s3 * (w32)F_N1_847759065;
+        w32 t2 = p1 + s1 * (w32)F_0_765366865;
+        out[i] = sar_sat_u8x4(x0 + t2, x2 + t0, x2 - t0, x0 - t2, 17);
     }
 }
 
-// src/idct.rs:519-553; out: 2 rows x 2 bytes packed as row0 | row1 << 16
+// src/idct.rs:519-553; out: row0 in bytes 0,1 and row1 in bytes 2,3
 __device__ __forceinline__ uint32_t idct2x2_exact(const uint32_t (&cw)[32], const uint16_t *__restrict__ q) {
     w32 s00 = (w32)(coef_at(cw, 0, 0) * (int32_t)q[0]);
     w32 s10 = (w32)(coef_at(cw, 1, 0) * (int32_t)q[8]);
@@ -166,8 +222,7 @@ __device__ __forceinline__ uint32_t idct2x2_exact(const uint32_t (&cw)[32], cons
     w32 x0 = s00 + s10 + 4u + (128u << 3);
     w32 x2 = s00 - s10 + 4u + (128u << 3);
     w32 x1 = s01 + s11, x3 = s01 - s11;
-    return clamp_u8(sar(x0 + x1, 3)) | (clamp_u8(sar(x0 - x1, 3)) << 8) | (clamp_u8(sar(x2 + x3, 3)) << 16) |
-           (clamp_u8(sar(x2 - x3, 3)) << 24);
+    return sar_sat_u8x4(x0 + x1, x0 - x1, x2 + x3, x2 - x3, 3);
 }
 
 // src/idct.rs:555-565 — truncating division by 8 of the wrapped sum
@@ -179,15 +234,26 @@ __device__ __forceinline__ uint32_t idct1x1_exact(uint32_t c0_word, const uint16
 // ---- colour, src/decoder.rs:1486-1508 -----------------------------------------------------
 // stbi_f2f(x) = (x * 2^20 + 0.5) as i32 in f32: 1.402 -> 1470104, 0.34414 -> 360857,
 // 0.71414 -> 748830, 1.772 -> 1858077.
-__device__ __forceinline__ uint32_t clamp_fixed20(int32_t v) { return (uint32_t)min(max(v >> 20, 0), 255); }
-__device__ __forceinline__ void ycbcr_to_rgb(uint32_t y8, uint32_t cb8, uint32_t cr8, uint32_t &r, uint32_t &g,
-                                             uint32_t &b) {
-    int32_t y = (int32_t)y8 * (1 << 20) + (1 << 19);
-    int32_t cb = (int32_t)cb8 - 128;
-    int32_t cr = (int32_t)cr8 - 128;
-    r = clamp_fixed20(y + 1470104 * cr);
-    g = clamp_fixed20(y - 360857 * cb - 748830 * cr);
-    b = clamp_fixed20(y + 1858077 * cb);
+//   r = clamp((Y + CR_R*cr') >> 20), Y = y*2^20 + 2^19, cr' = cr - 128  ... etc.
+// Restated with the -128 offsets folded into constants (pure integer re-association, no
+// intermediate can overflow: every term is below 2^29):
+//   r_raw = (y << 20) + KR + CR_R*cr,               KR = 2^19 - 128*CR_R
+//   g_raw = (y << 20) + KG - CB_G*cb - CR_G*cr,     KG = 2^19 + 128*(CB_G + CR_G)
+//   b_raw = (y << 20) + KB + CB_B*cb,               KB = 2^19 - 128*CB_B
+// Returns r | g << 8 | b << 16.
+constexpr int32_t CR_R = 1470104, CB_G = 360857, CR_G = 748830, CB_B = 1858077;
+constexpr int32_t KR = (1 << 19) - 128 * CR_R;
+constexpr int32_t KG = (1 << 19) + 128 * (CB_G + CR_G);
+constexpr int32_t KB = (1 << 19) - 128 * CB_B;
+
+__device__ __forceinline__ uint32_t ycbcr_to_rgb24(uint32_t y, uint32_t cb, uint32_t cr) {
+    w32 yb = y << 20;
+    w32 r = yb + (w32)KR + mul24(cr, CR_R);
+    w32 g = yb + (w32)KG + mul24(cb, -CB_G) + mul24(cr, -CR_G);
+    w32 b = yb + (w32)KB + mul24(cb, CB_B);
+    uint32_t rg = sar_sat_u8x2(r, g, 20);
+    uint32_t b8 = sar_sat_u8x2(b, 0u, 20);
+    return rg | (b8 << 16);
 }
 
 }  // namespace jpgpu

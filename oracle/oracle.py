@@ -209,8 +209,9 @@ def decode(data, scale_to=None, color_transform="AUTO", keep_intermediates=False
         lib().orc_free_result(C.byref(res))
 
 
-def batch_pixels(comps, qts, coefs_per_image, out_w, out_h, color_transform, nthreads):
-    """CPU baseline leg: pixel pipeline for a batch of same-geometry images (oracle_batch.c)."""
+def batch_pixels(comps, qts, coefs_per_image, out_w, out_h, color_transform, nthreads, keep_outputs=True):
+    """CPU baseline leg: pixel pipeline for a batch of same-geometry images (oracle_batch.c).
+    keep_outputs=False: timing mode, each thread decodes into one private reused buffer."""
     n = len(comps)
     n_images = len(coefs_per_image)
     qarr = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.uint16).reshape(64) for q in qts]))
@@ -222,8 +223,8 @@ def batch_pixels(comps, qts, coefs_per_image, out_w, out_h, color_transform, nth
             keep.append(a)
             cptrs[i * n + c] = a.ctypes.data
     out_len = comps[0].size_w * comps[0].size_h if n == 1 else out_w * out_h * n
-    outs = [np.zeros(out_len, dtype=np.uint8) for _ in range(n_images)]
-    optrs = (C.c_void_p * n_images)(*[o.ctypes.data for o in outs])
+    outs = [np.zeros(out_len, dtype=np.uint8) for _ in range(n_images)] if keep_outputs else []
+    optrs = (C.c_void_p * n_images)(*[o.ctypes.data for o in outs]) if keep_outputs else None
     ct = CT[color_transform] if isinstance(color_transform, str) else int(color_transform)
     rc = lib().orc_batch_pixels(comps, n, qarr.ctypes.data, cptrs, n_images, out_w, out_h, ct, optrs, nthreads)
     if rc:

@@ -32,6 +32,10 @@ static void *batch_worker(void *arg) {
     batch_t *b = (batch_t *)arg;
     uint8_t *planes[4] = {NULL, NULL, NULL, NULL};
     for (int c = 0; c < b->ncomp; c++) planes[c] = (uint8_t *)malloc(orc_plane_bytes(&b->comps[c]) + 1);
+    /* outs == NULL: timing mode, every thread decodes into one private, reused buffer */
+    size_t out_len = b->ncomp == 1 ? (size_t)b->comps[0].size_w * b->comps[0].size_h
+                                   : (size_t)b->out_w * b->out_h * (size_t)b->ncomp;
+    uint8_t *priv = b->outs ? NULL : (uint8_t *)malloc(out_len + 1);
     for (;;) {
         pthread_mutex_lock(&b->mu);
         int i = b->next++;
@@ -42,7 +46,7 @@ static void *batch_worker(void *arg) {
             size_t mcu_rows = cp->block_h / cp->v;
             orc_append_rows(cp, b->qts + 64 * c, b->coefs[(size_t)i * b->ncomp + c], 0, mcu_rows, planes[c]);
         }
-        int rc = orc_compute_image(b->comps, b->ncomp, planes, b->out_w, b->out_h, b->ct, b->outs[i], NULL);
+        int rc = orc_compute_image(b->comps, b->ncomp, planes, b->out_w, b->out_h, b->ct, priv ? priv : b->outs[i], NULL);
         if (rc) {
             pthread_mutex_lock(&b->mu);
             b->status = rc;
@@ -50,6 +54,7 @@ static void *batch_worker(void *arg) {
         }
     }
     for (int c = 0; c < b->ncomp; c++) free(planes[c]);
+    free(priv);
     return NULL;
 }
 

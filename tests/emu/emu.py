@@ -1,0 +1,22 @@
+"""TEST-ONLY: loader for the CPU emulation of the product's device code (tests/emu/*.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        L = C.CDLL(os.path.join(_HERE, "libemu.so"))
+        L.emu_idct8x8.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.emu_idct_small.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.emu_ycbcr.argtypes = [C.c_uint32] * 3
+        L.emu_ycbcr.restype = C.c_uint32
+        L.emu_fused_decode.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.emu_fused_decode.restype = C.c_int
+        _LIB = L
+    return _LIB

@@ -1,0 +1,68 @@
+// emu_fused.cpp — TEST-ONLY CPU emulation of the product's fused kernels: runs the very same
+// phase functions (jpeg-decoder_amd/csrc/fused_core.hpp) for every workgroup / lane with
+// sequential "barriers", so tile / halo / edge logic can be checked against the oracle without a
+// GPU.  Not part of the product; the product path only ever runs on gfx950.
+#include "hip_shim.hpp"
+#include <vector>
+#include "../../jpeg-decoder_amd/csrc/fused_plan.hpp"
+
+using namespace jpgpu;
+
+extern "C" {
+
+// returns the fused kind the planner picked (0 = none -> generic path on the GPU)
+int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, int sane, uint8_t* out,
+                     uint32_t* tx_out) {
+    FusedGeom g;
+    const char *name = "", *why = "";
+    int kind = fused_geom_from_desc(*desc, g, name, why);
+    if (kind == FUSED_NONE) return 0;
+    if (tx_out) *tx_out = g.tx;
+    FusedImage img{};
+    for (uint32_t c = 0; c < desc->ncomp; c++) {
+        img.coefs[c] = coefs[c];
+        img.qt[c] = desc->quantization_tables[c];
+    }
+    img.out = out;
+    img.flags = sane ? 1u : 0u;
+    std::vector<uint8_t> scratch;
+    if (kind == FUSED_420) {
+        scratch.assign(2 * (size_t)g.chroma_plane_bytes, 0xAB);
+        img.scratch = scratch.data();
+        // chroma pass (f420_chroma_kernel): one block per lane, plane stride bwc*8
+        for (uint32_t comp = 0; comp < 2; comp++) {
+            uint8_t* plane = scratch.data() + (size_t)comp * g.chroma_plane_bytes;
+            const uint32_t stride = g.bwc * 8u, nblk = g.bwc * g.mcu_h;
+            for (uint32_t b = 0; b < nblk; b++) {
+                uint32_t cw[32], o[16];
+                memcpy(cw, coefs[1 + comp] + (size_t)b * 64, 128);
+                idct_block(sane != 0, cw, img.qt[1 + comp], o);
+                uint32_t bx = b % g.bwc, by = b / g.bwc;
+                for (int r = 0; r < 8; r++) memcpy(plane + (size_t)(by * 8 + r) * stride + bx * 8, &o[2 * r], 8);
+            }
+        }
+    }
+    FusedLds* lds = new FusedLds;
+    std::vector<FusedRegs> regs(FUSED_NT);
+    for (uint32_t my = 0; my < g.mcu_h; my++)
+        for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
+            memset(lds, 0xCD, sizeof(FusedLds));  // garbage, like real LDS
+            if (kind == FUSED_420) {
+                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase0(g, img, tile, my, t, *lds);
+                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase1(g, img, tile, t, *lds, regs[t]);
+                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase2(g, tile, t, *lds, regs[t]);
+                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase3(g, img, tile, my, t, *lds);
+            } else if (kind == FUSED_444) {
+                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase0(g, img, tile, my, t, *lds);
+                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase1(g, img, tile, t, *lds, regs[t]);
+                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase2(g, tile, t, *lds, regs[t]);
+                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase3(g, img, tile, my, t, *lds);
+            } else {
+                for (uint32_t t = 0; t < FUSED_NT; t++) FGray::phase0(g, img, tile, my, t, *lds);
+                for (uint32_t t = 0; t < FUSED_NT; t++) FGray::phase1(g, img, tile, my, t, *lds);
+            }
+        }
+    delete lds;
+    return kind;
+}
+}

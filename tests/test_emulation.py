@@ -1,0 +1,154 @@
+"""CPU emulation of the product's device code against the oracle.
+
+tests/emu compiles the SAME headers the gfx950 kernels are built from (pixel_math.hpp,
+fused_core.hpp, fused_plan.hpp) with g++ and runs every workgroup / lane / phase sequentially.
+This checks arithmetic, tiling, halo and edge logic here, without a GPU; the real kernels are
+then checked again on the MI355X by tests/test_gpu_parity.py."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu  # noqa: E402
+import oracle as O  # noqa: E402
+import synth  # noqa: E402
+
+import jpeg_decoder_amd as J  # noqa: E402  (host-side structs only; nothing here touches a GPU)
+
+
+def _orc_blocks(c, q, scale=8):
+    n = len(c) // 64
+    return np.concatenate([O.idct_block(c[i * 64:(i + 1) * 64], q, scale).reshape(-1) for i in range(n)])
+
+
+def test_device_idct_exact_path_matches_oracle():
+    rng = np.random.default_rng(1)
+    n = 1500
+    for kind in ("full", "sparse"):
+        if kind == "full":
+            c = rng.integers(-32768, 32768, n * 64).astype(np.int16)
+            q = rng.integers(1, 65536, 64).astype(np.uint16)
+        else:
+            c = synth.sparse_coefficients(rng, n)
+            q = rng.integers(1, 256, 64).astype(np.uint16)
+        out = np.zeros(n * 64, np.uint8)
+        emu.lib().emu_idct8x8(0, c.ctypes.data, q.ctypes.data, out.ctypes.data, n)
+        assert np.array_equal(out, _orc_blocks(c, q)), kind
+    blocks, qts = synth.adversarial_blocks(rng)
+    for c, q in zip(blocks, qts):
+        out = np.zeros(64, np.uint8)
+        emu.lib().emu_idct8x8(0, c.ctypes.data, q.ctypes.data, out.ctypes.data, 1)
+        assert np.array_equal(out, _orc_blocks(c, q))
+
+
+def test_device_idct_sane_path_exact_up_to_its_bound():
+    """24-bit multiply path: exact whenever every |c*q| < 2^15 (worst case: all at the bound)."""
+    rng = np.random.default_rng(2)
+    n = 1500
+    for trial in range(6):
+        q = rng.integers(1, 256, 64).astype(np.uint16) if trial % 2 else rng.integers(1, 4096, 64).astype(np.uint16)
+        lim = ((1 << 15) - 1) // q.astype(np.int64)
+        sign = rng.choice([-1, 1], (n, 64))
+        mag = np.broadcast_to(lim, (n, 64)) if trial < 3 else rng.integers(0, lim + 1, (n, 64))
+        c = (sign * mag).astype(np.int16).reshape(-1)
+        out = np.zeros(n * 64, np.uint8)
+        emu.lib().emu_idct8x8(1, c.ctypes.data, q.ctypes.data, out.ctypes.data, n)
+        assert np.array_equal(out, _orc_blocks(c, q)), trial
+
+
+@pytest.mark.parametrize("scale", [4, 2, 1])
+def test_device_reduced_idct(scale):
+    rng = np.random.default_rng(scale)
+    n = 800
+    c = rng.integers(-32768, 32768, n * 64).astype(np.int16)
+    q = rng.integers(1, 65536, 64).astype(np.uint16)
+    out = np.zeros(n * scale * scale, np.uint8)
+    emu.lib().emu_idct_small(scale, c.ctypes.data, q.ctypes.data, out.ctypes.data, n)
+    assert np.array_equal(out, _orc_blocks(c, q, scale))
+
+
+def test_device_ycbcr_all_inputs():
+    y, cb, cr = np.meshgrid(np.arange(256), np.arange(256), np.arange(0, 256, 3), indexing="ij")
+    Y = y.astype(np.int64) * (1 << 20) + (1 << 19)
+    r = np.clip((Y + 1470104 * (cr - 128)) >> 20, 0, 255)
+    g = np.clip((Y - 360857 * (cb - 128) - 748830 * (cr - 128)) >> 20, 0, 255)
+    b = np.clip((Y + 1858077 * (cb - 128)) >> 20, 0, 255)
+    want = (r | (g << 8) | (b << 16)).astype(np.uint32)
+    rng = np.random.default_rng(0)
+    for _ in range(20000):
+        i, j, k = rng.integers(0, 256), rng.integers(0, 256), rng.integers(0, y.shape[2])
+        assert emu.lib().emu_ycbcr(int(y[i, j, k]), int(cb[i, j, k]), int(cr[i, j, k])) == int(want[i, j, k])
+
+
+def _to_j(ocomps):
+    out = (J.Component * len(ocomps))()
+    for i, c in enumerate(ocomps):
+        out[i].identifier, out[i].horizontal_sampling_factor, out[i].vertical_sampling_factor = c.identifier, c.h, c.v
+        out[i].quantization_table_index, out[i].dct_scale = c.tq, c.dct_scale
+        out[i].size_width, out[i].size_height, out[i].block_width, out[i].block_height = c.size_w, c.size_h, c.block_w, c.block_h
+    return out
+
+
+def _emulate(w_, h_, samp, ct, coefs, qts, sane):
+    ocomps, _ = O.make_components(w_, h_, samp)
+    desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
+    n = len(samp)
+    ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in coefs])
+    out_len = w_ * h_ * (1 if n == 1 else 3)
+    out = np.full(out_len + 64, 0x5A, np.uint8)  # guard band: the kernels must not write past the image
+    tx = C.c_uint32(0)
+    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, 1 if sane else 0, out.ctypes.data, C.byref(tx))
+    assert (out[out_len:] == 0x5A).all(), "emulated kernel wrote past the output"
+    return kind, out[:out_len], tx.value
+
+
+GEOMS = [
+    (64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (2, 2, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (3, 5, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (16, 16, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (17, 33, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (1025, 40, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1920, 24, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (2050, 18, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (45, 29, [(1, 1), (1, 1), (1, 1)], "RGB"),
+    (650, 20, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (1, 1, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+    (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
+    (1000, 1, [(1, 1)], "Grayscale"),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
+@pytest.mark.parametrize("kind", ["sane", "hostile"])
+def test_fused_kernel_logic_matches_oracle(geom, kind):
+    w_, h_, samp, ct = geom
+    rng = np.random.default_rng(w_ * 131 + h_)
+    ocomps, _ = O.make_components(w_, h_, samp)
+    if kind == "sane":
+        qts = [rng.integers(1, 64, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h, amp=64, dc_amp=500) for c in ocomps]
+        assert all((np.abs(c.astype(np.int64)).reshape(-1, 64) * q < (1 << 15)).all() for c, q in zip(coefs, qts))
+    else:
+        qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
+    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, kind == "sane")
+    assert got_kind != 0, "planner refused a geometry the fused kernels are meant to cover"
+    want = O.pixels_from_coefficients(ocomps, qts, coefs, w_, h_, ct.upper())
+    assert got.size == want.size
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (f"tx={tx}", bad[:10], got[bad[:10]], want[bad[:10]])
+
+
+def test_planner_keeps_odd_geometries_on_the_generic_path():
+    for (w_, h_, samp, ct) in [(1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+                               (64, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 2)], "Grayscale"),
+                               (64, 64, [(1, 1)] * 4, "CMYK")]:
+        rng = np.random.default_rng(0)
+        ocomps, _ = O.make_components(w_, h_, samp)
+        qts = [np.ones(64, np.uint16) for _ in ocomps]
+        coefs = [np.zeros(c.block_w * c.block_h * 64, np.int16) for c in ocomps]
+        ocomps, _ = O.make_components(w_, h_, samp)
+        desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
+        ptrs = (C.c_void_p * len(samp))(*[c.ctypes.data for c in coefs])
+        out = np.zeros(w_ * h_ * 4 + 64, np.uint8)
+        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None) == 0
