@@ -15,7 +15,7 @@
 
 namespace jpgpu {
 
-__global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const FusedImage *__restrict__ imgs, uint32_t n_blocks) {
+__global__ __launch_bounds__(256, 4) void f420_chroma_kernel(FusedGeom g, const FusedImage *__restrict__ imgs, uint32_t n_blocks) {
     __shared__ uint4 lds[256 * 8];
     const FusedImage &img = imgs[blockIdx.z];
     PlaneJob job;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const Fus
     idct_planes_body<8>(job, blockIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(256, 4) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLds lds;
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void f420_main_kernel(FusedGeom g, const Fused
     F420::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(256, 4) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLds lds;
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage
     F444::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(256, 4) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLds lds;
     const FusedImage img = imgs[blockIdx.z];
     FGray::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);

@@ -122,6 +122,12 @@ __device__ __forceinline__ uint32_t byte_of(uint32_t d, uint32_t i) { return (d 
 // =============================================================================================
 // FUSED_420 main pass
 // =============================================================================================
+// SWAR helpers: two 16-bit lanes per dword (values stay below 2^12, so plain 32-bit adds and
+// shifts never carry between lanes).
+__device__ __forceinline__ uint32_t swar_even(uint32_t d) { return d & 0x00ff00ffu; }          // bytes 0,2
+__device__ __forceinline__ uint32_t swar_odd(uint32_t d) { return (d >> 8) & 0x00ff00ffu; }    // bytes 1,3
+__device__ __forceinline__ uint32_t swar_3a_b(uint32_t a, uint32_t b) { return (a << 1) + a + b; }
+
 struct F420 {
     // effective MCUs of tile `tile_x`
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
@@ -130,34 +136,57 @@ struct F420 {
 
     // phase 0: stage luma coefficients (two block rows of the MCU row) and the chroma
     // neighbourhood [8*my-1, 8*my+8] x [8*x0-8, 8*(x0+txe)+8) of both chroma planes into LDS.
+    // All global loads of a lane are issued before the first LDS store (one exposed latency).
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t run = 2u * te;        // luma blocks per block row of the tile
-        const uint32_t nchunks = 2u * run * 8u;  // 16-B chunks to stage
+        const uint32_t run = 2u * te;            // luma blocks per block row of the tile
+        const uint32_t nchunks = 2u * run * 8u;  // 16-B chunks to stage (<= 2048)
         uint4 *dst = reinterpret_cast<uint4 *>(lds.coef);
         const uint4 *src = reinterpret_cast<const uint4 *>(img.coefs[0]);
-        for (uint32_t j = tid; j < nchunks; j += FUSED_NT) {
-            uint32_t lb = j >> 3, k = j & 7u;
-            uint32_t ry = lb / run, cx = lb - ry * run;
-            size_t gblock = (size_t)(2u * my + ry) * g.bw0 + (2u * x0m + cx);
-            dst[coef_slot(lb, k)] = src[gblock * 8u + k];
-        }
-        // chroma: uint2 (8 B) granules; LDS column lc <-> plane column 8*x0m - 8 + lc
-        const uint32_t stride = g.bwc * 8u;
-        const uint32_t gran_per_row = te + 2u;
-        const uint32_t items = 2u * 10u * gran_per_row;
-        for (uint32_t it = tid; it < items; it += FUSED_NT) {
-            uint32_t comp = it / (10u * gran_per_row);
-            uint32_t rem = it - comp * 10u * gran_per_row;
-            uint32_t rr = rem / gran_per_row, gi = rem - rr * gran_per_row;
-            int32_t crow = (int32_t)(8u * my) - 1 + (int32_t)rr;
-            int32_t col = (int32_t)(8u * x0m) - 8 + (int32_t)(8u * gi);
-            if (crow < 0 || crow >= (int32_t)g.ch || col < 0 || col >= (int32_t)stride) continue;
-            const uint8_t *plane = img.scratch + (size_t)comp * g.chroma_plane_bytes;
-            uint2 v = *reinterpret_cast<const uint2 *>(plane + (size_t)crow * stride + (uint32_t)col);
-            *reinterpret_cast<uint2 *>(&lds.chroma[(comp * 10u + rr) * F420_CPITCH + 8u * gi]) = v;
-        }
+        const size_t row0 = ((size_t)(2u * my) * g.bw0 + 2u * x0m) * 8u;  // chunk index of block (2my, 2x0)
+        const size_t row1 = row0 + (size_t)g.bw0 * 8u;
+        // All loads of a lane are issued before its first LDS store.  Named scalars + clamped
+        // indices on purpose: a predicated `uint4 v[8]` array is kept in scratch by hipcc.
+        const uint32_t lastc = nchunks - 1u, run8 = run * 8u;
+#define JP_LD(i)                                                   \
+    const uint32_t j##i = min(tid + FUSED_NT * (i), lastc);        \
+    const uint4 v##i = j##i < run8 ? src[row0 + j##i] : src[row1 + (j##i - run8)];
+        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
+#undef JP_LD
+        // chroma: 8-B granules; LDS column lc <-> plane column 8*x0m - 8 + lc.
+        // wave w takes (component, row) items w, w+4, ... < 20; lanes walk the granules of a row.
+        const uint32_t stride = g.bwc * 8u, gran_per_row = te + 2u;
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const int32_t col0 = (int32_t)(8u * x0m) - 8 + (int32_t)(8u * lane), col1 = col0 + 512;
+        const bool okc0 = lane < gran_per_row && col0 >= 0 && col0 < (int32_t)stride;
+        const bool okc1 = lane + 64u < gran_per_row && col1 >= 0 && col1 < (int32_t)stride;
+        const uint32_t colc0 = (uint32_t)min(max(col0, 0), (int32_t)stride - 8);
+        const uint32_t colc1 = (uint32_t)min(max(col1, 0), (int32_t)stride - 8);
+#define JP_CLD(i)                                                                                              \
+    const uint32_t item##i = wave + 4u * (i);                                                                  \
+    const uint32_t comp##i = item##i >= 10u ? 1u : 0u;                                                         \
+    const int32_t crow##i = (int32_t)(8u * my) - 1 + (int32_t)(item##i - comp##i * 10u);                       \
+    const int32_t crowc##i = min(max(crow##i, 0), (int32_t)g.ch - 1);                                          \
+    const uint8_t *prow##i = img.scratch + (size_t)comp##i * g.chroma_plane_bytes + (size_t)crowc##i * stride; \
+    const uint2 ca##i = *reinterpret_cast<const uint2 *>(prow##i + colc0);                                     \
+    const uint2 cb##i = *reinterpret_cast<const uint2 *>(prow##i + colc1);
+        JP_CLD(0) JP_CLD(1) JP_CLD(2) JP_CLD(3) JP_CLD(4)
+#undef JP_CLD
+#define JP_ST(i)                                                   \
+    {                                                              \
+        const uint32_t j = tid + FUSED_NT * (i);                   \
+        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i;     \
+    }
+        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
+#undef JP_ST
+#define JP_CST(i)                                                                                             \
+    if (crow##i == crowc##i) {                                                                                \
+        if (okc0) *reinterpret_cast<uint2 *>(&lds.chroma[item##i * F420_CPITCH + 8u * lane]) = ca##i;         \
+        if (okc1) *reinterpret_cast<uint2 *>(&lds.chroma[item##i * F420_CPITCH + 8u * (lane + 64u)]) = cb##i; \
+    }
+        JP_CST(0) JP_CST(1) JP_CST(2) JP_CST(3) JP_CST(4)
+#undef JP_CST
     }
 
     // phase 1: one lane per luma block: LDS -> registers -> IDCT
@@ -177,60 +206,119 @@ struct F420 {
         const uint32_t te = txe(g, tile_x);
         if (tid >= 4u * te) return;
         const uint32_t run = 2u * te, ypitch = 16u * g.tx;
-        uint32_t ry = tid / run, cx = tid - ry * run;
+        const uint32_t ry = tid >= run ? 1u : 0u, cx = tid - ry * run;
 #pragma unroll
         for (int row = 0; row < 8; row++)
             *reinterpret_cast<uint2 *>(&lds.coef[(ry * 8u + (uint32_t)row) * ypitch + cx * 8u]) =
                 make_uint2(r.out[2 * row], r.out[2 * row + 1]);
     }
 
-    // phase 3: upsample + colour convert + store; lanes walk consecutive 8-pixel chunks
+    // t' = 3*near + far + 2 for the chroma columns of one 8-pixel chunk, both components, as
+    // SWAR lane pairs.  Plane column j0 + i (j0 = ox0/2) is sample s_i; s_-1 .. s_4 are needed:
+    //   tE1 = (s2, s0)  tO1 = (s3, s1)  tOm = (s1, s_-1)  tEp = (s4, s2)      (hi, lo)
+    struct TPrime {
+        uint32_t tE1, tO1, tOm, tEp;
+    };
+    static __device__ __forceinline__ TPrime tprime(const uint8_t *near_row, const uint8_t *far_row) {
+        const uint32_t *n = reinterpret_cast<const uint32_t *>(near_row);  // dwords: cols j0-4.., j0.., j0+4..
+        const uint32_t *f = reinterpret_cast<const uint32_t *>(far_row);
+        const uint32_t two = 0x00020002u;
+        const uint32_t tO0 = swar_3a_b(swar_odd(n[0]), swar_odd(f[0])) + two;   // (s_-1, s_-3)
+        const uint32_t tE1 = swar_3a_b(swar_even(n[1]), swar_even(f[1])) + two;  // (s2, s0)
+        const uint32_t tO1 = swar_3a_b(swar_odd(n[1]), swar_odd(f[1])) + two;    // (s3, s1)
+        const uint32_t tE2 = swar_3a_b(swar_even(n[2]), swar_even(f[2])) + two;  // (s6, s4)
+        TPrime t;
+        t.tE1 = tE1;
+        t.tO1 = tO1;
+        t.tOm = (tO1 << 16) | (tO0 >> 16);
+        t.tEp = (tE2 << 16) | (tE1 >> 16);
+        return t;
+    }
+
+    // One output row of one 8-pixel chunk (src/upsampler.rs:191-228 + src/decoder.rs:1406-1437).
+    //   pixel k: main sample s_(k>>1), other tap s_(k>>1)+-1:  c = (3*t'main + t'other) >> 4
+    //   first / last column of the image: c = t'main >> 2
+    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, const FusedImage &img, const TPrime (&t)[2],
+                                                      uint2 yy, uint32_t oy, uint32_t ox0) {
+        uint32_t c[2][8];
+#pragma unroll
+        for (uint32_t comp = 0; comp < 2; comp++) {
+            const TPrime &q = t[comp];
+            const uint32_t A = (swar_3a_b(q.tE1, q.tO1) >> 4) & 0x00ff00ffu;  // (px5, px1)
+            const uint32_t B = (swar_3a_b(q.tO1, q.tE1) >> 4) & 0x00ff00ffu;  // (px6, px2)
+            const uint32_t D = (swar_3a_b(q.tE1, q.tOm) >> 4) & 0x00ff00ffu;  // (px4, px0)
+            const uint32_t F = (swar_3a_b(q.tO1, q.tEp) >> 4) & 0x00ff00ffu;  // (px7, px3)
+            c[comp][0] = D & 0xffffu; c[comp][4] = D >> 16;
+            c[comp][1] = A & 0xffffu; c[comp][5] = A >> 16;
+            c[comp][2] = B & 0xffffu; c[comp][6] = B >> 16;
+            c[comp][3] = F & 0xffffu; c[comp][7] = F >> 16;
+        }
+        const uint32_t last_x = 2u * g.cw - 1u;
+        if (ox0 == 0u) {  // src/upsampler.rs:213-214
+            c[0][0] = (t[0].tE1 & 0xffffu) >> 2;
+            c[1][0] = (t[1].tE1 & 0xffffu) >> 2;
+        }
+        if (last_x - ox0 < 8u) {  // src/upsampler.rs:226 (only when the output width is even)
+            const uint32_t k = last_x - ox0, sidx = k >> 1;  // main sample s_sidx, k is odd
+#pragma unroll
+            for (uint32_t comp = 0; comp < 2; comp++) {
+                const uint32_t tm = sidx == 0 ? (t[comp].tE1 & 0xffffu) : sidx == 1 ? (t[comp].tO1 & 0xffffu)
+                                    : sidx == 2 ? (t[comp].tE1 >> 16) : (t[comp].tO1 >> 16);
+#pragma unroll
+                for (uint32_t kk = 1; kk < 8; kk += 2)
+                    if (kk == k) c[comp][kk] = tm >> 2;
+            }
+        }
+        uint32_t px[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) px[k] = ycbcr_to_rgb24(byte_of(k < 4 ? yy.x : yy.y, k & 3u), c[0][k], c[1][k]);
+        store_rgb_run(img.out, ((size_t)oy * g.out_w + ox0) * 3u, px, min(8u, g.out_w - ox0));
+    }
+
+    // phase 3: upsample + colour convert + store.
+    // Work unit = "slot" p (0..8) x 8-pixel chunk: slot p reads chroma LDS rows (p, p+1) and
+    // produces tile rows 2p-1 (near = row p) and 2p (near = row p+1).  Wave w takes slots
+    // w, w+4, w+8 (slots 0 and 8 are half slots, so every wave does two slots' worth); lanes walk
+    // consecutive chunks, i.e. 24-B pixel runs next to each other on one scanline.
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
         const uint32_t nch = 2u * te, ypitch = 16u * g.tx;
-        const uint32_t units = 16u * nch;
-        for (uint32_t u = tid; u < units; u += FUSED_NT) {
-            const uint32_t row = u / nch, chk = u - row * nch;
-            const uint32_t oy = 16u * my + row, ox0 = 16u * x0m + 8u * chk;
-            if (oy >= g.out_h || ox0 >= g.out_w) continue;
-            const uint32_t npx = min(8u, g.out_w - ox0);
-            // luma
-            const uint2 yy = *reinterpret_cast<const uint2 *>(&lds.coef[row * ypitch + 8u * chk]);
-            // chroma rows (src/upsampler.rs:200-206)
-            const uint32_t near = oy >> 1;
-            const uint32_t far = (oy & 1u) ? min(near + 1u, g.ch - 1u) : (near > 0u ? near - 1u : 0u);
-            const uint32_t rn = near + 1u - 8u * my, rf = far + 1u - 8u * my;  // LDS rows (row 0 <-> 8*my-1)
-            // t'[j] = 3*near[j] + far[j] + 2 for plane columns j0-4 .. j0+7 (j0 = ox0/2); LDS column of j0-4 is 4*chk+4
-            uint32_t tp[2][12];
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        for (uint32_t slot = wave; slot < 9u; slot += 4u) {
+            // output rows of the slot
+            const int32_t ra = 2 * (int32_t)slot - 1, rb = 2 * (int32_t)slot;  // tile rows
+            const uint32_t oya = 16u * my + (uint32_t)ra, oyb = 16u * my + (uint32_t)rb;
+            const bool va = slot >= 1u && oya < g.out_h, vb = slot <= 7u && oyb < g.out_h;
+            if (!va && !vb) continue;
+            // chroma rows (src/upsampler.rs:200-206): LDS row r <-> plane row 8*my - 1 + r
+            const int32_t cu = (int32_t)(8u * my) - 1 + (int32_t)slot;  // plane row of LDS row `slot`
+            const uint32_t U = slot, L = slot + 1u;
+            const uint32_t fa = (cu + 1 <= (int32_t)g.ch - 1) ? L : U;  // row a: near U, far min(near+1, ch-1)
+            const uint32_t fb = (cu >= 0) ? U : L;                      // row b: near L, far max(near-1, 0)
+            for (uint32_t chk = lane; chk < nch; chk += 64u) {
+                const uint32_t ox0 = 16u * x0m + 8u * chk;
+                if (ox0 >= g.out_w) continue;
+                const uint32_t coff = 4u * chk + 4u;  // LDS column of plane column j0 - 4
+                if (va) {
+                    TPrime t[2];
 #pragma unroll
-            for (uint32_t comp = 0; comp < 2; comp++) {
-                const uint8_t *bn = &lds.chroma[(comp * 10u + rn) * F420_CPITCH + 4u * chk + 4u];
-                const uint8_t *bf = &lds.chroma[(comp * 10u + rf) * F420_CPITCH + 4u * chk + 4u];
+                    for (uint32_t comp = 0; comp < 2; comp++)
+                        t[comp] = tprime(&lds.chroma[(comp * 10u + U) * F420_CPITCH + coff],
+                                         &lds.chroma[(comp * 10u + fa) * F420_CPITCH + coff]);
+                    const uint2 yy = *reinterpret_cast<const uint2 *>(&lds.coef[(uint32_t)ra * ypitch + 8u * chk]);
+                    row_pixels(g, img, t, yy, oya, ox0);
+                }
+                if (vb) {
+                    TPrime t[2];
 #pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    uint32_t nn = *reinterpret_cast<const uint32_t *>(bn + 4u * d);
-                    uint32_t ff = *reinterpret_cast<const uint32_t *>(bf + 4u * d);
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; b++) tp[comp][4 * d + b] = 3u * byte_of(nn, b) + byte_of(ff, b) + 2u;
+                    for (uint32_t comp = 0; comp < 2; comp++)
+                        t[comp] = tprime(&lds.chroma[(comp * 10u + L) * F420_CPITCH + coff],
+                                         &lds.chroma[(comp * 10u + fb) * F420_CPITCH + coff]);
+                    const uint2 yy = *reinterpret_cast<const uint2 *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
+                    row_pixels(g, img, t, yy, oyb, ox0);
                 }
             }
-            uint32_t px[8];
-            const uint32_t last_x = 2u * g.cw - 1u;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t x = ox0 + k;
-                const uint32_t ji = 4u + (k >> 1);                 // index of t'[x>>1] in tp
-                const uint32_t jo = (k & 1u) ? ji + 1u : ji - 1u;  // the "other" tap
-                const bool edge = (x == 0u) || (x == last_x);      // src/upsampler.rs:213-214,226
-                uint32_t c[2];
-#pragma unroll
-                for (uint32_t comp = 0; comp < 2; comp++)
-                    c[comp] = edge ? (tp[comp][ji] >> 2) : ((3u * tp[comp][ji] + tp[comp][jo]) >> 4);
-                const uint32_t y = byte_of(k < 4 ? yy.x : yy.y, k & 3u);
-                px[k] = ycbcr_to_rgb24(y, c[0], c[1]);
-            }
-            store_rgb_run(img.out, ((size_t)oy * g.out_w + ox0) * 3u, px, npx);
         }
     }
 };
@@ -245,14 +333,23 @@ struct F444 {
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t nchunks = 3u * te * 8u;
+        const uint32_t nchunks = 3u * te * 8u;  // <= 1920
         uint4 *dst = reinterpret_cast<uint4 *>(lds.coef);
-        for (uint32_t j = tid; j < nchunks; j += FUSED_NT) {
-            uint32_t lb = j >> 3, k = j & 7u;
-            uint32_t comp = lb / te, cx = lb - comp * te;
-            size_t gblock = (size_t)my * g.bwc + (x0m + cx);
-            dst[coef_slot(lb, k)] = reinterpret_cast<const uint4 *>(img.coefs[comp])[gblock * 8u + k];
-        }
+        const size_t base = ((size_t)my * g.bwc + x0m) * 8u;  // chunk index of the tile's first block
+        const uint32_t lastc = nchunks - 1u;
+#define JP_LD(i)                                                                              \
+    const uint32_t j##i = min(tid + FUSED_NT * (i), lastc);                                   \
+    const uint32_t c##i = ((j##i >> 3) >= te ? 1u : 0u) + ((j##i >> 3) >= 2u * te ? 1u : 0u); \
+    const uint4 v##i = reinterpret_cast<const uint4 *>(img.coefs[c##i])[base + (j##i - c##i * te * 8u)];
+        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
+#undef JP_LD
+#define JP_ST(i)                                                   \
+    {                                                              \
+        const uint32_t j = tid + FUSED_NT * (i);                   \
+        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i;     \
+    }
+        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
+#undef JP_ST
     }
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t tid,
                                                   const FusedLds &lds, FusedRegs &r) {
@@ -260,7 +357,7 @@ struct F444 {
         if (tid >= 3u * te) return;
         uint32_t cw[32];
         load_block_from_lds(lds, tid, cw);
-        idct_block(img.flags & 1u, cw, img.qt[tid / te], r.out);
+        idct_block(img.flags & 1u, cw, img.qt[(tid >= te ? 1u : 0u) + (tid >= 2u * te ? 1u : 0u)], r.out);
     }
     // sample tiles: [3 comps][8 rows][pitch 8*tx]
     static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLds &lds,
@@ -268,7 +365,7 @@ struct F444 {
         const uint32_t te = txe(g, tile_x);
         if (tid >= 3u * te) return;
         const uint32_t pitch = 8u * g.tx;
-        uint32_t comp = tid / te, cx = tid - comp * te;
+        uint32_t comp = (tid >= te ? 1u : 0u) + (tid >= 2u * te ? 1u : 0u), cx = tid - comp * te;
 #pragma unroll
         for (int row = 0; row < 8; row++)
             *reinterpret_cast<uint2 *>(&lds.coef[(comp * 8u + (uint32_t)row) * pitch + cx * 8u]) =
@@ -277,9 +374,10 @@ struct F444 {
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t pitch = 8u * g.tx, units = 8u * te;
-        for (uint32_t u = tid; u < units; u += FUSED_NT) {
-            const uint32_t row = u / te, chk = u - row * te;
+        const uint32_t pitch = 8u * g.tx;
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        for (uint32_t row = wave; row < 8u; row += 4u)
+        for (uint32_t chk = lane; chk < te; chk += 64u) {
             const uint32_t oy = 8u * my + row, ox0 = 8u * (x0m + chk);
             if (oy >= g.out_h || ox0 >= g.out_w) continue;
             const uint32_t npx = min(8u, g.out_w - ox0);
@@ -312,7 +410,17 @@ struct FGray {
         const uint32_t x0 = tile_x * g.tx, te = txe(g, tile_x);
         uint4 *dst = reinterpret_cast<uint4 *>(lds.coef);
         const uint4 *src = reinterpret_cast<const uint4 *>(img.coefs[0]) + ((size_t)my * g.bw0 + x0) * 8u;
-        for (uint32_t j = tid; j < te * 8u; j += FUSED_NT) dst[coef_slot(j >> 3, j & 7u)] = src[j];
+        const uint32_t lastc = te * 8u - 1u;
+#define JP_LD(i) const uint4 v##i = src[min(tid + FUSED_NT * (i), lastc)];
+        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
+#undef JP_LD
+#define JP_ST(i)                                                   \
+    {                                                              \
+        const uint32_t j = tid + FUSED_NT * (i);                   \
+        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i;     \
+    }
+        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
+#undef JP_ST
     }
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLds &lds) {

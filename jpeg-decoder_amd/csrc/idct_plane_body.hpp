@@ -17,14 +17,20 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
     if (first >= job.n_blocks) return;  // whole workgroup out of range (uniform)
     const uint32_t nb = min(256u, job.n_blocks - first);
     const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(job.coefs + (size_t)first * 64);
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        uint32_t j = it * 256u + tid;
-        if (j < nb * 8u) {
-            uint32_t b = j >> 3, k = j & 7u;
-            lds[b * 8u + (k ^ ((b >> 1) & 7u))] = src[j];
-        }
+    // All eight 16-B loads are issued before the first LDS store (one exposed memory latency, not
+    // eight).  Named scalars + clamped indices on purpose: a predicated `uint4 v[8]` array is
+    // kept in scratch memory by hipcc (ROCm 7.2) instead of VGPRs.
+    const uint32_t lastc = nb * 8u - 1u;
+#define JP_LD(i) const uint4 v##i = src[min((i) * 256u + tid, lastc)];
+#define JP_ST(i)                                                      \
+    {                                                                 \
+        const uint32_t j = (i) * 256u + tid;                          \
+        if (j <= lastc) lds[(j >> 3) * 8u + ((j & 7u) ^ ((j >> 4) & 7u))] = v##i; \
     }
+    JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
+    JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
+#undef JP_LD
+#undef JP_ST
     __syncthreads();
     if (tid >= nb) return;
     uint32_t cw[32];
