@@ -15,8 +15,8 @@
 
 namespace jpgpu {
 
-__global__ __launch_bounds__(256, 4) void f420_chroma_kernel(FusedGeom g, const FusedImage *__restrict__ imgs, uint32_t n_blocks) {
-    __shared__ uint4 lds[256 * 8];
+__global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const FusedImage *__restrict__ imgs, uint32_t n_blocks) {
+    __shared__ v4u lds[256 * 8];
     const FusedImage &img = imgs[blockIdx.z];
     PlaneJob job;
     job.coefs = img.coefs[1 + blockIdx.y];
@@ -29,38 +29,41 @@ __global__ __launch_bounds__(256, 4) void f420_chroma_kernel(FusedGeom g, const 
     idct_planes_body<8>(job, blockIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256, 4) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+template <bool SANE>
+__global__ __launch_bounds__(256) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLds lds;
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
-    F420::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F420<SANE>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    F420::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    F420<SANE>::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F420::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    F420<SANE>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F420::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F420<SANE>::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256, 4) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
-    __shared__ FusedLds lds;
+template <bool SANE>
+__global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    __shared__ FusedLdsSmall lds;
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
-    F444::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F444<SANE>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    F444::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    F444<SANE>::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F444::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    F444<SANE>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F444::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F444<SANE>::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256, 4) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
-    __shared__ FusedLds lds;
+template <bool SANE>
+__global__ __launch_bounds__(256) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    __shared__ FusedLdsSmall lds;
     const FusedImage img = imgs[blockIdx.z];
-    FGray::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    FGray<SANE>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    FGray::phase1(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    FGray<SANE>::phase1(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -111,6 +114,7 @@ int fused_alloc(FusedPlan &plan, std::string &err) {
 int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt, const std::vector<size_t> &coef_off,
                const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
+    plan.all_sane = true;
     for (uint32_t i = 0; i < plan.n_images; i++) {
         FusedImage &im = plan.images[i];
         bool all_sane = true;
@@ -122,6 +126,7 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
         im.out = d_out + out_off[i];
         im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)i * plan.scratch_per_image : nullptr;
         im.flags = all_sane ? 1u : 0u;
+        plan.all_sane = plan.all_sane && all_sane;  // one hostile image sends the whole batch down the wrap-exact kernels
     }
     hipError_t e = hipMemcpy(plan.d_images, plan.images.data(), sizeof(FusedImage) * plan.n_images, hipMemcpyHostToDevice);
     if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMemcpy(images): %s", hipGetErrorString(e));
@@ -137,11 +142,18 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
         uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
         dim3 cgrid((nblk + 255u) / 256u, 2, plan.n_images);
         f420_chroma_kernel<<<cgrid, block, 0, stream>>>(g, plan.d_images, nblk);
-        f420_main_kernel<<<grid, block, 0, stream>>>(g, plan.d_images);
+        if (plan.all_sane) f420_main_kernel<true><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else f420_main_kernel<false><<<grid, block, 0, stream>>>(g, plan.d_images);
         break;
     }
-    case FUSED_444: f444_kernel<<<grid, block, 0, stream>>>(g, plan.d_images); break;
-    case FUSED_GRAY: fgray_kernel<<<grid, block, 0, stream>>>(g, plan.d_images); break;
+    case FUSED_444:
+        if (plan.all_sane) f444_kernel<true><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else f444_kernel<false><<<grid, block, 0, stream>>>(g, plan.d_images);
+        break;
+    case FUSED_GRAY:
+        if (plan.all_sane) fgray_kernel<true><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else fgray_kernel<false><<<grid, block, 0, stream>>>(g, plan.d_images);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -25,7 +25,7 @@ namespace jpgpu {
 
 constexpr uint32_t FUSED_NT = 256;       // threads per workgroup
 constexpr uint32_t F420_TX_MAX = 64;     // 4 luma blocks per MCU -> <= 256 lanes
-constexpr uint32_t F444_TX_MAX = 80;     // 3 blocks per MCU -> <= 240 lanes
+constexpr uint32_t F444_TX_MAX = 64;     // one wave per component, one lane per block
 constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
 constexpr uint32_t F420_CPITCH = 8 * F420_TX_MAX + 16;  // chroma LDS row: 8 halo + 8*TX + 8 halo
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
@@ -46,8 +46,6 @@ struct FusedGeom {
     uint32_t chroma_plane_bytes;  // 420 scratch: bytes of one chroma plane (bwc*8 * bhc*8)
 };
 
-#ifndef JPGPU_FUSED_IMAGE_DEFINED
-#define JPGPU_FUSED_IMAGE_DEFINED
 struct FusedImage {
     const int16_t *coefs[4];
     const uint16_t *qt[4];
@@ -56,27 +54,38 @@ struct FusedImage {
     uint32_t flags;    // bit0: every component "sane" (|c*q| < 2^15) -> 24-bit multiply path
     uint32_t _pad;
 };
-#endif
 
 struct alignas(16) FusedLds {
     uint8_t coef[FUSED_COEF_LDS];           // coefficient staging, later the sample tile(s)
     uint8_t chroma[2 * 10 * F420_CPITCH];   // 4:2:0 only
+};
+struct alignas(16) FusedLdsSmall {          // kernels without a chroma neighbourhood
+    uint8_t coef[FUSED_COEF_LDS];
 };
 
 struct FusedRegs {
     uint32_t out[16];  // one IDCT'd block: 8 rows x 2 dwords
 };
 
+// wave-uniform value -> SGPR (lets the compiler keep per-wave pointers / tables scalar)
+__device__ __forceinline__ uint32_t uniform(uint32_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    return v;
+#else
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
 // LDS slot (in 16-B units) of row k of local block lb: conflict-free for both the 8-lane
 // ds_write_b128 groups (one block = 8 consecutive slots) and the 16-lane ds_read_b128 groups
 // (MI355X_MICROARCH.md §LDS): lb*8 + (k ^ ((lb >> 1) & 7)).
 __device__ __forceinline__ uint32_t coef_slot(uint32_t lb, uint32_t k) { return lb * 8u + (k ^ ((lb >> 1) & 7u)); }
 
-__device__ __forceinline__ void load_block_from_lds(const FusedLds &lds, uint32_t lb, uint32_t (&cw)[32]) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(lds.coef);
+__device__ __forceinline__ void load_block_from_lds(const uint8_t *coef_lds, uint32_t lb, uint32_t (&cw)[32]) {
+    const v4u *p = reinterpret_cast<const v4u *>(coef_lds);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        uint4 v = p[coef_slot(lb, (uint32_t)k)];
+        v4u v = p[coef_slot(lb, (uint32_t)k)];
         cw[k * 4 + 0] = v.x;
         cw[k * 4 + 1] = v.y;
         cw[k * 4 + 2] = v.z;
@@ -84,30 +93,15 @@ __device__ __forceinline__ void load_block_from_lds(const FusedLds &lds, uint32_
     }
 }
 
-__device__ __forceinline__ void idct_block(bool sane, const uint32_t (&cw)[32], const uint16_t *q, uint32_t (&out)[16]) {
-    if (sane) idct8x8<true>(cw, q, out);
-    else idct8x8<false>(cw, q, out);
-}
-
-// store n (<= 8) RGB24 pixels held as packed 24-bit values; off = byte offset in `out`
-__device__ __forceinline__ void store_rgb_run(uint8_t *out, size_t off, const uint32_t (&px)[8], uint32_t n) {
-    uint8_t *o = out + off;
+// store n (<= 8) RGB24 pixels held as packed 24-bit values; off = byte offset in `out`.
+// Full chunks at a 4-byte aligned offset go out as two 12-B stores (global_store_dwordx3).
+__device__ __forceinline__ void store_rgb_run(JP_GLOBAL uint8_t *out, size_t off, const uint32_t (&px)[8], uint32_t n) {
+    JP_GLOBAL uint8_t *o = out + off;
     if (n == 8 && (off & 3u) == 0) {
-        uint32_t d0 = px[0] | (px[1] << 24);
-        uint32_t d1 = (px[1] >> 8) | (px[2] << 16);
-        uint32_t d2 = (px[2] >> 16) | (px[3] << 8);
-        uint32_t d3 = px[4] | (px[5] << 24);
-        uint32_t d4 = (px[5] >> 8) | (px[6] << 16);
-        uint32_t d5 = (px[6] >> 16) | (px[7] << 8);
-        if ((off & 7u) == 0) {
-            uint2 *o64 = reinterpret_cast<uint2 *>(o);
-            o64[0] = make_uint2(d0, d1);
-            o64[1] = make_uint2(d2, d3);
-            o64[2] = make_uint2(d4, d5);
-        } else {
-            uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-            o32[0] = d0; o32[1] = d1; o32[2] = d2; o32[3] = d3; o32[4] = d4; o32[5] = d5;
-        }
+        const v3u lo = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+        const v3u hi = {px[4] | (px[5] << 24), (px[5] >> 8) | (px[6] << 16), (px[6] >> 16) | (px[7] << 8)};
+        *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = lo;
+        *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = hi;
     } else {
         for (uint32_t k = 0; k < n; k++) {
             o[3 * k] = (uint8_t)px[k];
@@ -119,6 +113,26 @@ __device__ __forceinline__ void store_rgb_run(uint8_t *out, size_t off, const ui
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t d, uint32_t i) { return (d >> (8u * i)) & 0xffu; }
 
+// Stage up to 2048 16-B coefficient chunks of a tile into LDS.  `addr(j)` maps the tile-local
+// chunk index to a global pointer.  All eight loads of a lane are issued before its first LDS
+// store (one exposed memory latency, not eight).  Named scalars + clamped indices on purpose: a
+// predicated `v4u v[8]` array is kept in scratch memory by hipcc (ROCm 7.2), not in VGPRs.
+template <class AddrFn>
+__device__ __forceinline__ void stage_coefficients(uint8_t *coef_lds, uint32_t nchunks, uint32_t tid, AddrFn addr) {
+    v4u *dst = reinterpret_cast<v4u *>(coef_lds);
+    const uint32_t lastc = nchunks - 1u;
+#define JP_LD(i) const v4u v##i = *addr(min(tid + FUSED_NT * (i), lastc));
+    JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
+#undef JP_LD
+#define JP_ST(i)                                               \
+    {                                                          \
+        const uint32_t j = tid + FUSED_NT * (i);               \
+        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i; \
+    }
+    JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
+#undef JP_ST
+}
+
 // =============================================================================================
 // FUSED_420 main pass
 // =============================================================================================
@@ -128,6 +142,7 @@ __device__ __forceinline__ uint32_t swar_even(uint32_t d) { return d & 0x00ff00f
 __device__ __forceinline__ uint32_t swar_odd(uint32_t d) { return (d >> 8) & 0x00ff00ffu; }    // bytes 1,3
 __device__ __forceinline__ uint32_t swar_3a_b(uint32_t a, uint32_t b) { return (a << 1) + a + b; }
 
+template <bool SANE>
 struct F420 {
     // effective MCUs of tile `tile_x`
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
@@ -136,54 +151,41 @@ struct F420 {
 
     // phase 0: stage luma coefficients (two block rows of the MCU row) and the chroma
     // neighbourhood [8*my-1, 8*my+8] x [8*x0-8, 8*(x0+txe)+8) of both chroma planes into LDS.
-    // All global loads of a lane are issued before the first LDS store (one exposed latency).
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t run = 2u * te;            // luma blocks per block row of the tile
-        const uint32_t nchunks = 2u * run * 8u;  // 16-B chunks to stage (<= 2048)
-        uint4 *dst = reinterpret_cast<uint4 *>(lds.coef);
-        const uint4 *src = reinterpret_cast<const uint4 *>(img.coefs[0]);
-        const size_t row0 = ((size_t)(2u * my) * g.bw0 + 2u * x0m) * 8u;  // chunk index of block (2my, 2x0)
-        const size_t row1 = row0 + (size_t)g.bw0 * 8u;
-        // All loads of a lane are issued before its first LDS store.  Named scalars + clamped
-        // indices on purpose: a predicated `uint4 v[8]` array is kept in scratch by hipcc.
-        const uint32_t lastc = nchunks - 1u, run8 = run * 8u;
-#define JP_LD(i)                                                   \
-    const uint32_t j##i = min(tid + FUSED_NT * (i), lastc);        \
-    const uint4 v##i = j##i < run8 ? src[row0 + j##i] : src[row1 + (j##i - run8)];
-        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
-#undef JP_LD
-        // chroma: 8-B granules; LDS column lc <-> plane column 8*x0m - 8 + lc.
-        // wave w takes (component, row) items w, w+4, ... < 20; lanes walk the granules of a row.
+        const uint32_t run8 = 2u * te * 8u;  // 16-B chunks per luma block row of the tile
+        const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)img.coefs[0];
+        const JP_GLOBAL v4u *row0 = src + ((size_t)(2u * my) * g.bw0 + 2u * x0m) * 8u;
+        const JP_GLOBAL v4u *row1 = row0 + (size_t)g.bw0 * 8u;
+        // chroma loads are issued first, the (larger) coefficient staging overlaps their latency.
+        // 8-B granules; LDS column lc <-> plane column 8*x0m - 8 + lc.  Wave w takes
+        // (component, row) items w, w+4, ... < 20; lanes walk the granules of a row.
         const uint32_t stride = g.bwc * 8u, gran_per_row = te + 2u;
-        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
         const int32_t col0 = (int32_t)(8u * x0m) - 8 + (int32_t)(8u * lane), col1 = col0 + 512;
         const bool okc0 = lane < gran_per_row && col0 >= 0 && col0 < (int32_t)stride;
         const bool okc1 = lane + 64u < gran_per_row && col1 >= 0 && col1 < (int32_t)stride;
         const uint32_t colc0 = (uint32_t)min(max(col0, 0), (int32_t)stride - 8);
         const uint32_t colc1 = (uint32_t)min(max(col1, 0), (int32_t)stride - 8);
-#define JP_CLD(i)                                                                                              \
-    const uint32_t item##i = wave + 4u * (i);                                                                  \
-    const uint32_t comp##i = item##i >= 10u ? 1u : 0u;                                                         \
-    const int32_t crow##i = (int32_t)(8u * my) - 1 + (int32_t)(item##i - comp##i * 10u);                       \
-    const int32_t crowc##i = min(max(crow##i, 0), (int32_t)g.ch - 1);                                          \
-    const uint8_t *prow##i = img.scratch + (size_t)comp##i * g.chroma_plane_bytes + (size_t)crowc##i * stride; \
-    const uint2 ca##i = *reinterpret_cast<const uint2 *>(prow##i + colc0);                                     \
-    const uint2 cb##i = *reinterpret_cast<const uint2 *>(prow##i + colc1);
+        const JP_GLOBAL uint8_t *planes = (const JP_GLOBAL uint8_t *)img.scratch;
+#define JP_CLD(i)                                                                                                  \
+    const uint32_t item##i = wave + 4u * (i);                                                                      \
+    const uint32_t comp##i = item##i >= 10u ? 1u : 0u;                                                             \
+    const int32_t crow##i = (int32_t)(8u * my) - 1 + (int32_t)(item##i - comp##i * 10u);                           \
+    const int32_t crowc##i = min(max(crow##i, 0), (int32_t)g.ch - 1);                                              \
+    const JP_GLOBAL uint8_t *prow##i = planes + (size_t)comp##i * g.chroma_plane_bytes + (size_t)crowc##i * stride; \
+    const v2u ca##i = *reinterpret_cast<const JP_GLOBAL v2u *>(prow##i + colc0);                               \
+    v2u cb##i = v2u{0u, 0u};                                                                              \
+    if (gran_per_row > 64u) cb##i = *reinterpret_cast<const JP_GLOBAL v2u *>(prow##i + colc1);
         JP_CLD(0) JP_CLD(1) JP_CLD(2) JP_CLD(3) JP_CLD(4)
 #undef JP_CLD
-#define JP_ST(i)                                                   \
-    {                                                              \
-        const uint32_t j = tid + FUSED_NT * (i);                   \
-        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i;     \
-    }
-        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
-#undef JP_ST
+        stage_coefficients(lds.coef, 2u * run8, tid,
+                           [&](uint32_t j) { return j < run8 ? row0 + j : row1 + (j - run8); });
 #define JP_CST(i)                                                                                             \
     if (crow##i == crowc##i) {                                                                                \
-        if (okc0) *reinterpret_cast<uint2 *>(&lds.chroma[item##i * F420_CPITCH + 8u * lane]) = ca##i;         \
-        if (okc1) *reinterpret_cast<uint2 *>(&lds.chroma[item##i * F420_CPITCH + 8u * (lane + 64u)]) = cb##i; \
+        if (okc0) *reinterpret_cast<v2u *>(&lds.chroma[item##i * F420_CPITCH + 8u * lane]) = ca##i;         \
+        if (okc1) *reinterpret_cast<v2u *>(&lds.chroma[item##i * F420_CPITCH + 8u * (lane + 64u)]) = cb##i; \
     }
         JP_CST(0) JP_CST(1) JP_CST(2) JP_CST(3) JP_CST(4)
 #undef JP_CST
@@ -195,8 +197,8 @@ struct F420 {
         const uint32_t te = txe(g, tile_x);
         if (tid >= 4u * te) return;
         uint32_t cw[32];
-        load_block_from_lds(lds, tid, cw);
-        idct_block(img.flags & 1u, cw, img.qt[0], r.out);
+        load_block_from_lds(lds.coef, tid, cw);
+        idct8x8<SANE>(cw, as_qtab(img.qt[0]), r.out);
     }
 
     // phase 2: luma samples into the LDS tile (16 rows x 16*te bytes, pitch 16*tx), which
@@ -209,8 +211,8 @@ struct F420 {
         const uint32_t ry = tid >= run ? 1u : 0u, cx = tid - ry * run;
 #pragma unroll
         for (int row = 0; row < 8; row++)
-            *reinterpret_cast<uint2 *>(&lds.coef[(ry * 8u + (uint32_t)row) * ypitch + cx * 8u]) =
-                make_uint2(r.out[2 * row], r.out[2 * row + 1]);
+            *reinterpret_cast<v2u *>(&lds.coef[(ry * 8u + (uint32_t)row) * ypitch + cx * 8u]) =
+                v2u{r.out[2 * row], r.out[2 * row + 1]};
     }
 
     // t' = 3*near + far + 2 for the chroma columns of one 8-pixel chunk, both components, as
@@ -223,7 +225,7 @@ struct F420 {
         const uint32_t *n = reinterpret_cast<const uint32_t *>(near_row);  // dwords: cols j0-4.., j0.., j0+4..
         const uint32_t *f = reinterpret_cast<const uint32_t *>(far_row);
         const uint32_t two = 0x00020002u;
-        const uint32_t tO0 = swar_3a_b(swar_odd(n[0]), swar_odd(f[0])) + two;   // (s_-1, s_-3)
+        const uint32_t tO0 = swar_3a_b(swar_odd(n[0]), swar_odd(f[0])) + two;    // (s_-1, s_-3)
         const uint32_t tE1 = swar_3a_b(swar_even(n[1]), swar_even(f[1])) + two;  // (s2, s0)
         const uint32_t tO1 = swar_3a_b(swar_odd(n[1]), swar_odd(f[1])) + two;    // (s3, s1)
         const uint32_t tE2 = swar_3a_b(swar_even(n[2]), swar_even(f[2])) + two;  // (s6, s4)
@@ -238,8 +240,8 @@ struct F420 {
     // One output row of one 8-pixel chunk (src/upsampler.rs:191-228 + src/decoder.rs:1406-1437).
     //   pixel k: main sample s_(k>>1), other tap s_(k>>1)+-1:  c = (3*t'main + t'other) >> 4
     //   first / last column of the image: c = t'main >> 2
-    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, const FusedImage &img, const TPrime (&t)[2],
-                                                      uint2 yy, uint32_t oy, uint32_t ox0) {
+    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *out, const TPrime (&t)[2],
+                                                      v2u yy, uint32_t oy, uint32_t ox0) {
         uint32_t c[2][8];
 #pragma unroll
         for (uint32_t comp = 0; comp < 2; comp++) {
@@ -272,7 +274,7 @@ struct F420 {
         uint32_t px[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) px[k] = ycbcr_to_rgb24(byte_of(k < 4 ? yy.x : yy.y, k & 3u), c[0][k], c[1][k]);
-        store_rgb_run(img.out, ((size_t)oy * g.out_w + ox0) * 3u, px, min(8u, g.out_w - ox0));
+        store_rgb_run(out, ((size_t)oy * g.out_w + ox0) * 3u, px, min(8u, g.out_w - ox0));
     }
 
     // phase 3: upsample + colour convert + store.
@@ -284,7 +286,8 @@ struct F420 {
                                                   uint32_t tid, const FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
         const uint32_t nch = 2u * te, ypitch = 16u * g.tx;
-        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
+        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
         for (uint32_t slot = wave; slot < 9u; slot += 4u) {
             // output rows of the slot
             const int32_t ra = 2 * (int32_t)slot - 1, rb = 2 * (int32_t)slot;  // tile rows
@@ -306,8 +309,8 @@ struct F420 {
                     for (uint32_t comp = 0; comp < 2; comp++)
                         t[comp] = tprime(&lds.chroma[(comp * 10u + U) * F420_CPITCH + coff],
                                          &lds.chroma[(comp * 10u + fa) * F420_CPITCH + coff]);
-                    const uint2 yy = *reinterpret_cast<const uint2 *>(&lds.coef[(uint32_t)ra * ypitch + 8u * chk]);
-                    row_pixels(g, img, t, yy, oya, ox0);
+                    const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)ra * ypitch + 8u * chk]);
+                    row_pixels(g, out, t, yy, oya, ox0);
                 }
                 if (vb) {
                     TPrime t[2];
@@ -315,8 +318,8 @@ struct F420 {
                     for (uint32_t comp = 0; comp < 2; comp++)
                         t[comp] = tprime(&lds.chroma[(comp * 10u + L) * F420_CPITCH + coff],
                                          &lds.chroma[(comp * 10u + fb) * F420_CPITCH + coff]);
-                    const uint2 yy = *reinterpret_cast<const uint2 *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
-                    row_pixels(g, img, t, yy, oyb, ox0);
+                    const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
+                    row_pixels(g, out, t, yy, oyb, ox0);
                 }
             }
         }
@@ -324,67 +327,77 @@ struct F420 {
 };
 
 // =============================================================================================
-// FUSED_444: MCU = one 8x8 block per component
+// FUSED_444: MCU = one 8x8 block per component.  Wave c (0..2) transforms component c (so the
+// quantization table stays wave-uniform in SGPRs), lane = block; wave 3 only helps staging and
+// the pixel phase.
 // =============================================================================================
+template <bool SANE>
 struct F444 {
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.mcu_w - tile_x * g.tx);
     }
+    // LDS block index of (component, block) = comp*64 + cx
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, FusedLds &lds) {
+                                                  uint32_t tid, FusedLdsSmall &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t nchunks = 3u * te * 8u;  // <= 1920
-        uint4 *dst = reinterpret_cast<uint4 *>(lds.coef);
         const size_t base = ((size_t)my * g.bwc + x0m) * 8u;  // chunk index of the tile's first block
-        const uint32_t lastc = nchunks - 1u;
-#define JP_LD(i)                                                                              \
-    const uint32_t j##i = min(tid + FUSED_NT * (i), lastc);                                   \
-    const uint32_t c##i = ((j##i >> 3) >= te ? 1u : 0u) + ((j##i >> 3) >= 2u * te ? 1u : 0u); \
-    const uint4 v##i = reinterpret_cast<const uint4 *>(img.coefs[c##i])[base + (j##i - c##i * te * 8u)];
-        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
+        const JP_GLOBAL v4u *c0 = (const JP_GLOBAL v4u *)img.coefs[0] + base;
+        const JP_GLOBAL v4u *c1 = (const JP_GLOBAL v4u *)img.coefs[1] + base;
+        const JP_GLOBAL v4u *c2 = (const JP_GLOBAL v4u *)img.coefs[2] + base;
+        const uint32_t te8 = te * 8u;
+        // tile-local chunk j: component j / te8; stored at LDS block comp*64 + cx
+        v4u *dst = reinterpret_cast<v4u *>(lds.coef);
+        const uint32_t lastc = 3u * te8 - 1u;
+#define JP_LD(i)                                                                  \
+    const uint32_t j##i = min(tid + FUSED_NT * (i), lastc);                       \
+    const uint32_t k##i = (j##i >= te8 ? 1u : 0u) + (j##i >= 2u * te8 ? 1u : 0u); \
+    const uint32_t r##i = j##i - k##i * te8;                                      \
+    const v4u v##i = k##i == 0u ? c0[r##i] : (k##i == 1u ? c1[r##i] : c2[r##i]);
+        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5)
 #undef JP_LD
-#define JP_ST(i)                                                   \
-    {                                                              \
-        const uint32_t j = tid + FUSED_NT * (i);                   \
-        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i;     \
-    }
-        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
+#define JP_ST(i) \
+    if (tid + FUSED_NT * (i) <= lastc) dst[coef_slot(k##i * 64u + (r##i >> 3), r##i & 7u)] = v##i;
+        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5)
 #undef JP_ST
     }
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t tid,
-                                                  const FusedLds &lds, FusedRegs &r) {
+                                                  const FusedLdsSmall &lds, FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
-        if (tid >= 3u * te) return;
+        const uint32_t comp = uniform(tid >> 6), cx = tid & 63u;
+        if (comp >= 3u || cx >= te) return;
         uint32_t cw[32];
-        load_block_from_lds(lds, tid, cw);
-        idct_block(img.flags & 1u, cw, img.qt[(tid >= te ? 1u : 0u) + (tid >= 2u * te ? 1u : 0u)], r.out);
+        load_block_from_lds(lds.coef, comp * 64u + cx, cw);
+        idct8x8<SANE>(cw, as_qtab(img.qt[comp]), r.out);
     }
     // sample tiles: [3 comps][8 rows][pitch 8*tx]
-    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLds &lds,
+    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLdsSmall &lds,
                                                   const FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
-        if (tid >= 3u * te) return;
+        const uint32_t comp = tid >> 6, cx = tid & 63u;
+        if (comp >= 3u || cx >= te) return;
         const uint32_t pitch = 8u * g.tx;
-        uint32_t comp = (tid >= te ? 1u : 0u) + (tid >= 2u * te ? 1u : 0u), cx = tid - comp * te;
 #pragma unroll
         for (int row = 0; row < 8; row++)
-            *reinterpret_cast<uint2 *>(&lds.coef[(comp * 8u + (uint32_t)row) * pitch + cx * 8u]) =
-                make_uint2(r.out[2 * row], r.out[2 * row + 1]);
+            *reinterpret_cast<v2u *>(&lds.coef[(comp * 8u + (uint32_t)row) * pitch + cx * 8u]) =
+                v2u{r.out[2 * row], r.out[2 * row + 1]};
     }
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, const FusedLds &lds) {
+                                                  uint32_t tid, const FusedLdsSmall &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
         const uint32_t pitch = 8u * g.tx;
-        const uint32_t wave = tid >> 6, lane = tid & 63u;
-        for (uint32_t row = wave; row < 8u; row += 4u)
-        for (uint32_t chk = lane; chk < te; chk += 64u) {
-            const uint32_t oy = 8u * my + row, ox0 = 8u * (x0m + chk);
-            if (oy >= g.out_h || ox0 >= g.out_w) continue;
-            const uint32_t npx = min(8u, g.out_w - ox0);
-            uint2 s[3];
+        const uint32_t wave = uniform(tid >> 6), chk = tid & 63u;
+        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
+        if (chk >= te) return;
+        const uint32_t ox0 = 8u * (x0m + chk);
+        if (ox0 >= g.out_w) return;
+        const uint32_t npx = min(8u, g.out_w - ox0);
+        for (uint32_t row = wave; row < 8u; row += 4u) {
+            const uint32_t oy = 8u * my + row;
+            if (oy >= g.out_h) continue;
+            v2u s[3];
 #pragma unroll
             for (uint32_t comp = 0; comp < 3; comp++)
-                s[comp] = *reinterpret_cast<const uint2 *>(&lds.coef[(comp * 8u + row) * pitch + chk * 8u]);
+                s[comp] = *reinterpret_cast<const v2u *>(&lds.coef[(comp * 8u + row) * pitch + chk * 8u]);
             uint32_t px[8];
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
@@ -393,7 +406,7 @@ struct F444 {
                 uint32_t c = byte_of(k < 4 ? s[2].x : s[2].y, k & 3u);
                 px[k] = g.color == FCOLOR_RGB ? (a | (b << 8) | (c << 16)) : ycbcr_to_rgb24(a, b, c);
             }
-            store_rgb_run(img.out, ((size_t)oy * g.out_w + ox0) * 3u, px, npx);
+            store_rgb_run(out, ((size_t)oy * g.out_w + ox0) * 3u, px, npx);
         }
     }
 };
@@ -401,46 +414,37 @@ struct F444 {
 // =============================================================================================
 // FUSED_GRAY: one block per lane, straight to the output rows
 // =============================================================================================
+template <bool SANE>
 struct FGray {
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.bw0 - tile_x * g.tx);
     }
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, FusedLds &lds) {
+                                                  uint32_t tid, FusedLdsSmall &lds) {
         const uint32_t x0 = tile_x * g.tx, te = txe(g, tile_x);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds.coef);
-        const uint4 *src = reinterpret_cast<const uint4 *>(img.coefs[0]) + ((size_t)my * g.bw0 + x0) * 8u;
-        const uint32_t lastc = te * 8u - 1u;
-#define JP_LD(i) const uint4 v##i = src[min(tid + FUSED_NT * (i), lastc)];
-        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
-#undef JP_LD
-#define JP_ST(i)                                                   \
-    {                                                              \
-        const uint32_t j = tid + FUSED_NT * (i);                   \
-        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i;     \
-    }
-        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
-#undef JP_ST
+        const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)img.coefs[0] + ((size_t)my * g.bw0 + x0) * 8u;
+        stage_coefficients(lds.coef, te * 8u, tid, [&](uint32_t j) { return src + j; });
     }
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, const FusedLds &lds) {
+                                                  uint32_t tid, const FusedLdsSmall &lds) {
         const uint32_t x0 = tile_x * g.tx, te = txe(g, tile_x);
         if (tid >= te) return;
         uint32_t cw[32], out[16];
-        load_block_from_lds(lds, tid, cw);
-        idct_block(img.flags & 1u, cw, img.qt[0], out);
+        load_block_from_lds(lds.coef, tid, cw);
+        idct8x8<SANE>(cw, as_qtab(img.qt[0]), out);
         const uint32_t ox = 8u * (x0 + tid);
         if (ox >= g.out_w) return;
         const uint32_t n = min(8u, g.out_w - ox);
+        JP_GLOBAL uint8_t *dst = (JP_GLOBAL uint8_t *)img.out;
 #pragma unroll
         for (uint32_t row = 0; row < 8; row++) {
             const uint32_t oy = 8u * my + row;
             if (oy >= g.out_h) break;
             const size_t off = (size_t)oy * g.out_w + ox;
             if (n == 8 && (off & 7u) == 0) {
-                *reinterpret_cast<uint2 *>(img.out + off) = make_uint2(out[2 * row], out[2 * row + 1]);
+                *reinterpret_cast<JP_GLOBAL v2u *>(dst + off) = v2u{out[2 * row], out[2 * row + 1]};
             } else {
-                for (uint32_t k = 0; k < n; k++) img.out[off + k] = (uint8_t)byte_of(k < 4 ? out[2 * row] : out[2 * row + 1], k & 3u);
+                for (uint32_t k = 0; k < n; k++) dst[off + k] = (uint8_t)byte_of(k < 4 ? out[2 * row] : out[2 * row + 1], k & 3u);
             }
         }
     }

@@ -11,17 +11,17 @@ namespace jpgpu {
 // ds_read_b128.  LDS slot of (block b, row k): b*8 + (k ^ ((b >> 1) & 7)), conflict-free for both
 // the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups (MI355X_MICROARCH.md §LDS).
 template <int SCALE>
-__device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t wg, uint4 *lds) {
+__device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t wg, v4u *lds) {
     const uint32_t tid = threadIdx.x;
     const uint32_t first = wg * 256u;
     if (first >= job.n_blocks) return;  // whole workgroup out of range (uniform)
     const uint32_t nb = min(256u, job.n_blocks - first);
-    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(job.coefs + (size_t)first * 64);
+    const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)(job.coefs + (size_t)first * 64);
     // All eight 16-B loads are issued before the first LDS store (one exposed memory latency, not
-    // eight).  Named scalars + clamped indices on purpose: a predicated `uint4 v[8]` array is
+    // eight).  Named scalars + clamped indices on purpose: a predicated `v4u v[8]` array is
     // kept in scratch memory by hipcc (ROCm 7.2) instead of VGPRs.
     const uint32_t lastc = nb * 8u - 1u;
-#define JP_LD(i) const uint4 v##i = src[min((i) * 256u + tid, lastc)];
+#define JP_LD(i) const v4u v##i = src[min((i) * 256u + tid, lastc)];
 #define JP_ST(i)                                                      \
     {                                                                 \
         const uint32_t j = (i) * 256u + tid;                          \
@@ -36,7 +36,7 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
     uint32_t cw[32];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        uint4 v = lds[tid * 8u + ((uint32_t)k ^ ((tid >> 1) & 7u))];
+        v4u v = lds[tid * 8u + ((uint32_t)k ^ ((tid >> 1) & 7u))];
         cw[k * 4 + 0] = v.x;
         cw[k * 4 + 1] = v.y;
         cw[k * 4 + 2] = v.z;
@@ -45,25 +45,25 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
     const uint32_t b = first + tid;
     const uint32_t bx = b % job.block_w, by = b / job.block_w;
     const size_t stride = (size_t)job.block_w * SCALE;
-    uint8_t *dst = job.plane + (size_t)by * SCALE * stride + (size_t)bx * SCALE;
+    JP_GLOBAL uint8_t *dst = (JP_GLOBAL uint8_t *)job.plane + (size_t)by * SCALE * stride + (size_t)bx * SCALE;
     if constexpr (SCALE == 8) {
         uint32_t out[16];
-        if (job.flags & 1u) idct8x8<true>(cw, job.qt, out);  // wave-uniform: one job per workgroup
-        else idct8x8<false>(cw, job.qt, out);
+        if (job.flags & 1u) idct8x8<true>(cw, as_qtab(job.qt), out);  // uniform: one job per workgroup
+        else idct8x8<false>(cw, as_qtab(job.qt), out);
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            *reinterpret_cast<uint2 *>(dst + (size_t)r * stride) = make_uint2(out[2 * r], out[2 * r + 1]);
+            *reinterpret_cast<JP_GLOBAL v2u *>(dst + (size_t)r * stride) = v2u{out[2 * r], out[2 * r + 1]};
     } else if constexpr (SCALE == 4) {
         uint32_t out[4];
-        idct4x4_exact(cw, job.qt, out);
+        idct4x4_exact(cw, as_qtab(job.qt), out);
 #pragma unroll
-        for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t *>(dst + (size_t)r * stride) = out[r];
+        for (int r = 0; r < 4; r++) *reinterpret_cast<JP_GLOBAL uint32_t *>(dst + (size_t)r * stride) = out[r];
     } else if constexpr (SCALE == 2) {
-        uint32_t o = idct2x2_exact(cw, job.qt);
-        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(o & 0xffffu);
-        *reinterpret_cast<uint16_t *>(dst + stride) = (uint16_t)(o >> 16);
+        uint32_t o = idct2x2_exact(cw, as_qtab(job.qt));
+        *reinterpret_cast<JP_GLOBAL uint16_t *>(dst) = (uint16_t)(o & 0xffffu);
+        *reinterpret_cast<JP_GLOBAL uint16_t *>(dst + stride) = (uint16_t)(o >> 16);
     } else {
-        dst[0] = (uint8_t)idct1x1_exact(cw[0], job.qt);
+        dst[0] = (uint8_t)idct1x1_exact(cw[0], as_qtab(job.qt));
     }
 }
 

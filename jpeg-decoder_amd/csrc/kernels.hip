@@ -28,7 +28,7 @@ namespace jpgpu {
 // ------------------------------------------------------------------------------------------
 template <int SCALE>
 __global__ __launch_bounds__(256) void idct_planes_kernel(const PlaneJob *__restrict__ jobs) {
-    __shared__ uint4 lds[256 * 8];
+    __shared__ v4u lds[256 * 8];
     const PlaneJob job = jobs[blockIdx.y];
     if (job.scale != SCALE) return;
     idct_planes_body<SCALE>(job, blockIdx.x, lds);
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void idct_planes_kernel(const PlaneJob *__rest
 
 template <int SCALE>
 __global__ __launch_bounds__(256) void idct_plane_one_kernel(PlaneJob job) {
-    __shared__ uint4 lds[256 * 8];
+    __shared__ v4u lds[256 * 8];
     idct_planes_body<SCALE>(job, blockIdx.x, lds);
 }
 

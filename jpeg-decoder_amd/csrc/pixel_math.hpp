@@ -15,9 +15,42 @@
 #endif
 #include <stdint.h>
 
+// Address spaces.  Pointers that reach a kernel inside a struct are "flat" to the compiler:
+// flat_load/flat_store instead of global_*, no scalar loads, no wide stores.  The kernels
+// therefore cast them once: JP_GLOBAL = global memory, JP_CONST = read-only global memory whose
+// wave-uniform loads become s_load (used for the quantization tables, which then live in SGPRs).
+#ifdef JPGPU_HOST_EMULATION
+#define JP_GLOBAL
+#define JP_CONST
+#else
+#define JP_GLOBAL __attribute__((address_space(1)))
+#define JP_CONST __attribute__((address_space(4)))
+#endif
+
 namespace jpgpu {
 
+// Plain vector types for memory access (the HIP uint2/uint4 classes cannot be assigned through
+// address-space qualified pointers).  v3u_a4: 12 bytes at 4-byte alignment -> *_dwordx3.
+#ifdef JPGPU_HOST_EMULATION
+struct v2u { uint32_t x, y; };
+struct v3u { uint32_t x, y, z; };
+struct v4u { uint32_t x, y, z, w; };
+typedef v3u v3u_a4;
+#else
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef v3u v3u_a4 __attribute__((aligned(4)));
+#endif
+
 typedef uint32_t w32;
+typedef const JP_CONST uint32_t *qtab_t;  // 64 u16 quantization values packed two per dword, 4-B aligned
+
+__device__ __forceinline__ qtab_t as_qtab(const uint16_t *q) { return (qtab_t)q; }
+__device__ __forceinline__ int32_t q_at(qtab_t q, int idx) {
+    uint32_t d = q[idx >> 1];
+    return (int32_t)((idx & 1) ? (d >> 16) : (d & 0xffffu));
+}
 
 // stbi_f2f(x) = (x * 4096.0f + 0.5f) as i32, evaluated in f32 (src/idct.rs:572-574).
 // Values as listed in SURVEY Appendix A.1; the oracle computes them with the f32 formula and
@@ -145,28 +178,38 @@ __device__ __forceinline__ int32_t coef_at(const uint32_t (&cw)[32], int r, int 
 //   row multiplicands are sums of at most four of them), so 24-bit multiplies are exact, and the
 //   column short-cut equals the general formula (s0 << 12 cannot wrap).  See DESIGN.md.
 template <bool SANE>
-__device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint16_t *__restrict__ q,
-                                        uint32_t (&out)[16]) {
-    w32 temp[64];
+__device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint32_t (&out)[16]) {
+    // dequantize first (row by row, so the packed coefficients and the table die early and the
+    // 64 products are the only long-lived values), then both passes in place
+    w32 t[64];
+    uint32_t acbits[4] = {0u, 0u, 0u, 0u};  // OR of the packed raw coefficients of rows 1..7
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[k * 8 + i] = mul24((w32)coef_at(cw, k, i), q_at(q, k * 8 + i));  // i16 x u16: always exact
+        if constexpr (!SANE) {
+            if (k >= 1) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) acbits[d] |= cw[k * 4 + d];
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        w32 s[8];
+        w32 s[8], o[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = mul24((w32)coef_at(cw, k, i), (int32_t)q[k * 8 + i]);  // i16 x u16: always exact
-        w32 o[8];
+        for (int k = 0; k < 8; k++) s[k] = t[k * 8 + i];
         idct_pass8<SANE>(s, 512u, o);
         if constexpr (SANE) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) temp[k * 8 + i] = sar(o[k], 10);
+            for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
         } else {
             // raw-coefficient test of :279-285 on the packed halves
-            uint32_t acbits = 0;
+            const uint32_t bits = acbits[i >> 1];
+            const bool dc_only = ((i & 1) ? (bits >> 16) : (bits & 0xffffu)) == 0;
+            const w32 dcterm = s[0] << 2;
 #pragma unroll
-            for (int k = 1; k < 8; k++) acbits |= cw[k * 4 + (i >> 1)];
-            bool dc_only = ((i & 1) ? (acbits >> 16) : (acbits & 0xffffu)) == 0;
-            w32 dcterm = s[0] << 2;
-#pragma unroll
-            for (int k = 0; k < 8; k++) temp[k * 8 + i] = dc_only ? dcterm : sar(o[k], 10);
+            for (int k = 0; k < 8; k++) t[k * 8 + i] = dc_only ? dcterm : sar(o[k], 10);
         }
     }
     const w32 X_SCALE = 65536u + (128u << 17);
@@ -174,7 +217,7 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint16_t
     for (int r = 0; r < 8; r++) {
         w32 s[8], o[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = temp[r * 8 + k];
+        for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
         idct_pass8<SANE>(s, X_SCALE, o);
         out[r * 2] = sar_sat_u8x4(o[0], o[1], o[2], o[3], 17);
         out[r * 2 + 1] = sar_sat_u8x4(o[4], o[5], o[6], o[7], 17);
@@ -182,15 +225,14 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint16_t
 }
 
 // src/idct.rs:456-517; out: 4 rows x 4 bytes (one dword per row)
-__device__ __forceinline__ void idct4x4_exact(const uint32_t (&cw)[32], const uint16_t *__restrict__ q,
-                                              uint32_t (&out)[4]) {
+__device__ __forceinline__ void idct4x4_exact(const uint32_t (&cw)[32], qtab_t q, uint32_t (&out)[4]) {
     w32 temp[16];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        w32 s0 = (w32)(coef_at(cw, 0, i) * (int32_t)q[i]);
-        w32 s1 = (w32)(coef_at(cw, 1, i) * (int32_t)q[8 + i]);
-        w32 s2 = (w32)(coef_at(cw, 2, i) * (int32_t)q[16 + i]);
-        w32 s3 = (w32)(coef_at(cw, 3, i) * (int32_t)q[24 + i]);
+        w32 s0 = (w32)(coef_at(cw, 0, i) * q_at(q, i));
+        w32 s1 = (w32)(coef_at(cw, 1, i) * q_at(q, 8 + i));
+        w32 s2 = (w32)(coef_at(cw, 2, i) * q_at(q, 16 + i));
+        w32 s3 = (w32)(coef_at(cw, 3, i) * q_at(q, 24 + i));
         w32 x0 = (s0 + s2) << 2;
         w32 x2 = (s0 - s2) << 2;
         w32 p1 = (s1 + s3) * (w32)F_0_5411961;
@@ -214,11 +256,11 @@ __device__ __forceinline__ void idct4x4_exact(const uint32_t (&cw)[32], const ui
 }
 
 // src/idct.rs:519-553; out: row0 in bytes 0,1 and row1 in bytes 2,3
-__device__ __forceinline__ uint32_t idct2x2_exact(const uint32_t (&cw)[32], const uint16_t *__restrict__ q) {
-    w32 s00 = (w32)(coef_at(cw, 0, 0) * (int32_t)q[0]);
-    w32 s10 = (w32)(coef_at(cw, 1, 0) * (int32_t)q[8]);
-    w32 s01 = (w32)(coef_at(cw, 0, 1) * (int32_t)q[1]);
-    w32 s11 = (w32)(coef_at(cw, 1, 1) * (int32_t)q[9]);
+__device__ __forceinline__ uint32_t idct2x2_exact(const uint32_t (&cw)[32], qtab_t q) {
+    w32 s00 = (w32)(coef_at(cw, 0, 0) * q_at(q, 0));
+    w32 s10 = (w32)(coef_at(cw, 1, 0) * q_at(q, 8));
+    w32 s01 = (w32)(coef_at(cw, 0, 1) * q_at(q, 1));
+    w32 s11 = (w32)(coef_at(cw, 1, 1) * q_at(q, 9));
     w32 x0 = s00 + s10 + 4u + (128u << 3);
     w32 x2 = s00 - s10 + 4u + (128u << 3);
     w32 x1 = s01 + s11, x3 = s01 - s11;
@@ -226,8 +268,8 @@ __device__ __forceinline__ uint32_t idct2x2_exact(const uint32_t (&cw)[32], cons
 }
 
 // src/idct.rs:555-565 — truncating division by 8 of the wrapped sum
-__device__ __forceinline__ uint32_t idct1x1_exact(uint32_t c0_word, const uint16_t *__restrict__ q) {
-    int32_t s0 = (int32_t)((w32)((int32_t)(int16_t)(c0_word & 0xffffu) * (int32_t)q[0]) + 1024u);
+__device__ __forceinline__ uint32_t idct1x1_exact(uint32_t c0_word, qtab_t q) {
+    int32_t s0 = (int32_t)((w32)((int32_t)(int16_t)(c0_word & 0xffffu) * q_at(q, 0)) + 1024u);
     return clamp_u8((w32)(s0 / 8));
 }
 

@@ -36,32 +36,41 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             for (uint32_t b = 0; b < nblk; b++) {
                 uint32_t cw[32], o[16];
                 memcpy(cw, coefs[1 + comp] + (size_t)b * 64, 128);
-                idct_block(sane != 0, cw, img.qt[1 + comp], o);
+                if (sane) idct8x8<true>(cw, as_qtab(img.qt[1 + comp]), o);
+                else idct8x8<false>(cw, as_qtab(img.qt[1 + comp]), o);
                 uint32_t bx = b % g.bwc, by = b / g.bwc;
                 for (int r = 0; r < 8; r++) memcpy(plane + (size_t)(by * 8 + r) * stride + bx * 8, &o[2 * r], 8);
             }
         }
     }
     FusedLds* lds = new FusedLds;
+    FusedLdsSmall* lds_s = new FusedLdsSmall;
     std::vector<FusedRegs> regs(FUSED_NT);
+#define RUN(BODY) for (uint32_t t = 0; t < FUSED_NT; t++) { BODY; }
     for (uint32_t my = 0; my < g.mcu_h; my++)
         for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
             memset(lds, 0xCD, sizeof(FusedLds));  // garbage, like real LDS
-            if (kind == FUSED_420) {
-                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase0(g, img, tile, my, t, *lds);
-                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase1(g, img, tile, t, *lds, regs[t]);
-                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase2(g, tile, t, *lds, regs[t]);
-                for (uint32_t t = 0; t < FUSED_NT; t++) F420::phase3(g, img, tile, my, t, *lds);
+            memset(lds_s, 0xCD, sizeof(FusedLdsSmall));
+            if (kind == FUSED_420 && sane) {
+                RUN(F420<true>::phase0(g, img, tile, my, t, *lds)) RUN(F420<true>::phase1(g, img, tile, t, *lds, regs[t]))
+                RUN(F420<true>::phase2(g, tile, t, *lds, regs[t])) RUN(F420<true>::phase3(g, img, tile, my, t, *lds))
+            } else if (kind == FUSED_420) {
+                RUN(F420<false>::phase0(g, img, tile, my, t, *lds)) RUN(F420<false>::phase1(g, img, tile, t, *lds, regs[t]))
+                RUN(F420<false>::phase2(g, tile, t, *lds, regs[t])) RUN(F420<false>::phase3(g, img, tile, my, t, *lds))
+            } else if (kind == FUSED_444 && sane) {
+                RUN(F444<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(F444<true>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(F444<true>::phase2(g, tile, t, *lds_s, regs[t])) RUN(F444<true>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444) {
-                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase0(g, img, tile, my, t, *lds);
-                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase1(g, img, tile, t, *lds, regs[t]);
-                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase2(g, tile, t, *lds, regs[t]);
-                for (uint32_t t = 0; t < FUSED_NT; t++) F444::phase3(g, img, tile, my, t, *lds);
+                RUN(F444<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(F444<false>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(F444<false>::phase2(g, tile, t, *lds_s, regs[t])) RUN(F444<false>::phase3(g, img, tile, my, t, *lds_s))
+            } else if (sane) {
+                RUN(FGray<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(FGray<true>::phase1(g, img, tile, my, t, *lds_s))
             } else {
-                for (uint32_t t = 0; t < FUSED_NT; t++) FGray::phase0(g, img, tile, my, t, *lds);
-                for (uint32_t t = 0; t < FUSED_NT; t++) FGray::phase1(g, img, tile, my, t, *lds);
+                RUN(FGray<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(FGray<false>::phase1(g, img, tile, my, t, *lds_s))
             }
         }
+#undef RUN
+    delete lds_s;
     delete lds;
     return kind;
 }

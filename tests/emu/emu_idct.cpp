@@ -6,16 +6,16 @@ void emu_idct8x8(int sane, const int16_t* c, const uint16_t* q, uint8_t* out, in
     for (int b = 0; b < nblocks; b++) {
         uint32_t cw[32]; memcpy(cw, c + b * 64, 128);
         uint32_t o[16];
-        if (sane) jpgpu::idct8x8<true>(cw, q, o); else jpgpu::idct8x8<false>(cw, q, o);
+        if (sane) jpgpu::idct8x8<true>(cw, jpgpu::as_qtab(q), o); else jpgpu::idct8x8<false>(cw, jpgpu::as_qtab(q), o);
         memcpy(out + b * 64, o, 64);
     }
 }
 void emu_idct_small(int scale, const int16_t* c, const uint16_t* q, uint8_t* out, int nblocks) {
     for (int b = 0; b < nblocks; b++) {
         uint32_t cw[32]; memcpy(cw, c + b * 64, 128);
-        if (scale == 4) { uint32_t o[4]; jpgpu::idct4x4_exact(cw, q, o); memcpy(out + b * 16, o, 16); }
-        else if (scale == 2) { uint32_t o = jpgpu::idct2x2_exact(cw, q); memcpy(out + b * 4, &o, 4); }
-        else { out[b] = (uint8_t)jpgpu::idct1x1_exact(cw[0], q); }
+        if (scale == 4) { uint32_t o[4]; jpgpu::idct4x4_exact(cw, jpgpu::as_qtab(q), o); memcpy(out + b * 16, o, 16); }
+        else if (scale == 2) { uint32_t o = jpgpu::idct2x2_exact(cw, jpgpu::as_qtab(q)); memcpy(out + b * 4, &o, 4); }
+        else { out[b] = (uint8_t)jpgpu::idct1x1_exact(cw[0], jpgpu::as_qtab(q)); }
     }
 }
 uint32_t emu_ycbcr(uint32_t y, uint32_t cb, uint32_t cr) { return jpgpu::ycbcr_to_rgb24(y, cb, cr); }
