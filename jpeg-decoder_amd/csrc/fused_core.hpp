@@ -103,11 +103,13 @@ __device__ __forceinline__ void store_rgb_run(JP_GLOBAL uint8_t *out, size_t off
         *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = lo;
         *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = hi;
     } else {
-        for (uint32_t k = 0; k < n; k++) {
-            o[3 * k] = (uint8_t)px[k];
-            o[3 * k + 1] = (uint8_t)(px[k] >> 8);
-            o[3 * k + 2] = (uint8_t)(px[k] >> 16);
-        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++)
+            if (k < n) {
+                o[3 * k] = (uint8_t)px[k];
+                o[3 * k + 1] = (uint8_t)(px[k] >> 8);
+                o[3 * k + 2] = (uint8_t)(px[k] >> 16);
+            }
     }
 }
 
@@ -215,25 +217,37 @@ struct F420 {
                 v2u{r.out[2 * row], r.out[2 * row + 1]};
     }
 
-    // t' = 3*near + far + 2 for the chroma columns of one 8-pixel chunk, both components, as
-    // SWAR lane pairs.  Plane column j0 + i (j0 = ox0/2) is sample s_i; s_-1 .. s_4 are needed:
-    //   tE1 = (s2, s0)  tO1 = (s3, s1)  tOm = (s1, s_-1)  tEp = (s4, s2)      (hi, lo)
+    // Chroma columns of one 8-pixel chunk as packed 16-bit lane pairs (hi, lo).  Plane column
+    // j0 + i (j0 = ox0/2) is sample s_i; an output row needs s_-1 .. s_4.
+    //   O0 = (s_-1, s_-3)   E1 = (s2, s0)   O1 = (s3, s1)   E2 = (s6, s4)
+    struct ChromaEO {
+        uint32_t O0, E1, O1, E2;
+    };
+    static __device__ __forceinline__ ChromaEO load_eo(const uint8_t *row) {
+        const uint32_t *d = reinterpret_cast<const uint32_t *>(row);  // dwords: cols j0-4.., j0.., j0+4..
+        ChromaEO c;
+        c.O0 = pk_shr(d[0], 8);
+        c.E1 = d[1] & 0x00ff00ffu;
+        c.O1 = pk_shr(d[1], 8);
+        c.E2 = d[2] & 0x00ff00ffu;
+        return c;
+    }
+    // t' = 3*near + far + 2 (src/upsampler.rs:209,217):
+    //   tE1 = (s2, s0)  tO1 = (s3, s1)  tOm = (s1, s_-1)  tEp = (s4, s2)
     struct TPrime {
         uint32_t tE1, tO1, tOm, tEp;
     };
-    static __device__ __forceinline__ TPrime tprime(const uint8_t *near_row, const uint8_t *far_row) {
-        const uint32_t *n = reinterpret_cast<const uint32_t *>(near_row);  // dwords: cols j0-4.., j0.., j0+4..
-        const uint32_t *f = reinterpret_cast<const uint32_t *>(far_row);
+    static __device__ __forceinline__ TPrime tprime(const ChromaEO &n, const ChromaEO &f) {
         const uint32_t two = 0x00020002u;
-        const uint32_t tO0 = swar_3a_b(swar_odd(n[0]), swar_odd(f[0])) + two;    // (s_-1, s_-3)
-        const uint32_t tE1 = swar_3a_b(swar_even(n[1]), swar_even(f[1])) + two;  // (s2, s0)
-        const uint32_t tO1 = swar_3a_b(swar_odd(n[1]), swar_odd(f[1])) + two;    // (s3, s1)
-        const uint32_t tE2 = swar_3a_b(swar_even(n[2]), swar_even(f[2])) + two;  // (s6, s4)
+        const uint32_t tO0 = pk_add(pk_mad3(n.O0, f.O0), two);
+        const uint32_t tE1 = pk_add(pk_mad3(n.E1, f.E1), two);
+        const uint32_t tO1 = pk_add(pk_mad3(n.O1, f.O1), two);
+        const uint32_t tE2 = pk_add(pk_mad3(n.E2, f.E2), two);
         TPrime t;
         t.tE1 = tE1;
         t.tO1 = tO1;
-        t.tOm = (tO1 << 16) | (tO0 >> 16);
-        t.tEp = (tE2 << 16) | (tE1 >> 16);
+        t.tOm = alignbit(tO1, tO0, 16);  // (tO1.lo, tO0.hi) = (s1, s_-1)
+        t.tEp = alignbit(tE2, tE1, 16);  // (tE2.lo, tE1.hi) = (s4, s2)
         return t;
     }
 
@@ -242,46 +256,66 @@ struct F420 {
     //   first / last column of the image: c = t'main >> 2
     static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *out, const TPrime (&t)[2],
                                                       v2u yy, uint32_t oy, uint32_t ox0) {
-        uint32_t c[2][8];
+        // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
+        uint32_t pk[2][4];
 #pragma unroll
         for (uint32_t comp = 0; comp < 2; comp++) {
             const TPrime &q = t[comp];
-            const uint32_t A = (swar_3a_b(q.tE1, q.tO1) >> 4) & 0x00ff00ffu;  // (px5, px1)
-            const uint32_t B = (swar_3a_b(q.tO1, q.tE1) >> 4) & 0x00ff00ffu;  // (px6, px2)
-            const uint32_t D = (swar_3a_b(q.tE1, q.tOm) >> 4) & 0x00ff00ffu;  // (px4, px0)
-            const uint32_t F = (swar_3a_b(q.tO1, q.tEp) >> 4) & 0x00ff00ffu;  // (px7, px3)
-            c[comp][0] = D & 0xffffu; c[comp][4] = D >> 16;
-            c[comp][1] = A & 0xffffu; c[comp][5] = A >> 16;
-            c[comp][2] = B & 0xffffu; c[comp][6] = B >> 16;
-            c[comp][3] = F & 0xffffu; c[comp][7] = F >> 16;
+            pk[comp][0] = pk_shr(pk_mad3(q.tE1, q.tOm), 4);
+            pk[comp][1] = pk_shr(pk_mad3(q.tE1, q.tO1), 4);
+            pk[comp][2] = pk_shr(pk_mad3(q.tO1, q.tE1), 4);
+            pk[comp][3] = pk_shr(pk_mad3(q.tO1, q.tEp), 4);
         }
         const uint32_t last_x = 2u * g.cw - 1u;
-        if (ox0 == 0u) {  // src/upsampler.rs:213-214
-            c[0][0] = (t[0].tE1 & 0xffffu) >> 2;
-            c[1][0] = (t[1].tE1 & 0xffffu) >> 2;
-        }
-        if (last_x - ox0 < 8u) {  // src/upsampler.rs:226 (only when the output width is even)
-            const uint32_t k = last_x - ox0, sidx = k >> 1;  // main sample s_sidx, k is odd
+        if (ox0 == 0u || last_x - ox0 < 8u) {  // rare: first / last image column
 #pragma unroll
             for (uint32_t comp = 0; comp < 2; comp++) {
-                const uint32_t tm = sidx == 0 ? (t[comp].tE1 & 0xffffu) : sidx == 1 ? (t[comp].tO1 & 0xffffu)
-                                    : sidx == 2 ? (t[comp].tE1 >> 16) : (t[comp].tO1 >> 16);
-#pragma unroll
-                for (uint32_t kk = 1; kk < 8; kk += 2)
-                    if (kk == k) c[comp][kk] = tm >> 2;
+                if (ox0 == 0u)  // src/upsampler.rs:213-214: px0 = t'(s0) >> 2
+                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | ((t[comp].tE1 & 0xffffu) >> 2);
+                if (last_x - ox0 < 8u) {  // src/upsampler.rs:226: last column (odd k): t'(s_(k>>1)) >> 2
+                    const uint32_t k = last_x - ox0;
+                    const uint32_t tm = k == 1u ? (t[comp].tE1 & 0xffffu) : k == 3u ? (t[comp].tO1 & 0xffffu)
+                                        : k == 5u ? (t[comp].tE1 >> 16) : (t[comp].tO1 >> 16);
+                    const uint32_t v = tm >> 2;
+                    if (k == 1u) pk[comp][1] = (pk[comp][1] & 0xffff0000u) | v;
+                    if (k == 3u) pk[comp][3] = (pk[comp][3] & 0xffff0000u) | v;
+                    if (k == 5u) pk[comp][1] = (pk[comp][1] & 0x0000ffffu) | (v << 16);
+                    if (k == 7u) pk[comp][3] = (pk[comp][3] & 0x0000ffffu) | (v << 16);
+                }
             }
         }
-        uint32_t px[8];
+        RawRgb p[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) px[k] = ycbcr_to_rgb24(byte_of(k < 4 ? yy.x : yy.y, k & 3u), c[0][k], c[1][k]);
-        store_rgb_run(out, ((size_t)oy * g.out_w + ox0) * 3u, px, min(8u, g.out_w - ox0));
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t cb = (k < 4) ? (pk[0][k & 3u] & 0xffffu) : (pk[0][k & 3u] >> 16);
+            const uint32_t cr = (k < 4) ? (pk[1][k & 3u] & 0xffffu) : (pk[1][k & 3u] >> 16);
+            p[k] = ycbcr_raw(byte_of(k < 4 ? yy.x : yy.y, k & 3u), cb, cr);
+        }
+        const size_t off = ((size_t)oy * g.out_w + ox0) * 3u;
+        const uint32_t n = min(8u, g.out_w - ox0);
+        if (n == 8u && (off & 3u) == 0) {
+            uint32_t d0, d1, d2, d3, d4, d5;
+            rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
+            rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off) = v3u{d0, d1, d2};
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off + 12) = v3u{d3, d4, d5};
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++)  // unrolled + predicated: a runtime-indexed p[] would live in scratch
+                if (k < n) {
+                    out[off + 3 * k] = (uint8_t)sar_sat_u8x2(p[k].r, 0u, 20);
+                    out[off + 3 * k + 1] = (uint8_t)sar_sat_u8x2(p[k].g, 0u, 20);
+                    out[off + 3 * k + 2] = (uint8_t)sar_sat_u8x2(p[k].b, 0u, 20);
+                }
+        }
     }
 
     // phase 3: upsample + colour convert + store.
     // Work unit = "slot" p (0..8) x 8-pixel chunk: slot p reads chroma LDS rows (p, p+1) and
-    // produces tile rows 2p-1 (near = row p) and 2p (near = row p+1).  Wave w takes slots
-    // w, w+4, w+8 (slots 0 and 8 are half slots, so every wave does two slots' worth); lanes walk
-    // consecutive chunks, i.e. 24-B pixel runs next to each other on one scanline.
+    // produces tile rows 2p-1 (near = row p) and 2p (near = row p+1), sharing the unpacking of the
+    // two chroma rows.  Wave w takes slots w, w+4, w+8 (slots 0 and 8 are half slots, so every wave
+    // does two slots' worth); lanes walk consecutive chunks, i.e. 24-B pixel runs next to each
+    // other on one scanline.
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
@@ -297,27 +331,26 @@ struct F420 {
             // chroma rows (src/upsampler.rs:200-206): LDS row r <-> plane row 8*my - 1 + r
             const int32_t cu = (int32_t)(8u * my) - 1 + (int32_t)slot;  // plane row of LDS row `slot`
             const uint32_t U = slot, L = slot + 1u;
-            const uint32_t fa = (cu + 1 <= (int32_t)g.ch - 1) ? L : U;  // row a: near U, far min(near+1, ch-1)
-            const uint32_t fb = (cu >= 0) ? U : L;                      // row b: near L, far max(near-1, 0)
+            // row a: near U, far min(near+1, ch-1);  row b: near L, far max(near-1, 0)
+            const bool clamp_a = !(cu + 1 <= (int32_t)g.ch - 1), clamp_b = !(cu >= 0);
             for (uint32_t chk = lane; chk < nch; chk += 64u) {
                 const uint32_t ox0 = 16u * x0m + 8u * chk;
                 if (ox0 >= g.out_w) continue;
                 const uint32_t coff = 4u * chk + 4u;  // LDS column of plane column j0 - 4
-                if (va) {
-                    TPrime t[2];
+                ChromaEO eu[2], el[2];
 #pragma unroll
-                    for (uint32_t comp = 0; comp < 2; comp++)
-                        t[comp] = tprime(&lds.chroma[(comp * 10u + U) * F420_CPITCH + coff],
-                                         &lds.chroma[(comp * 10u + fa) * F420_CPITCH + coff]);
+                for (uint32_t comp = 0; comp < 2; comp++) {
+                    // a clamped row is never staged: substitute its partner (uniform per slot)
+                    eu[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * F420_CPITCH + coff]);
+                    el[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * F420_CPITCH + coff]);
+                }
+                if (va) {
+                    const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};
                     const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)ra * ypitch + 8u * chk]);
                     row_pixels(g, out, t, yy, oya, ox0);
                 }
                 if (vb) {
-                    TPrime t[2];
-#pragma unroll
-                    for (uint32_t comp = 0; comp < 2; comp++)
-                        t[comp] = tprime(&lds.chroma[(comp * 10u + L) * F420_CPITCH + coff],
-                                         &lds.chroma[(comp * 10u + fb) * F420_CPITCH + coff]);
+                    const TPrime t[2] = {tprime(el[0], eu[0]), tprime(el[1], eu[1])};
                     const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
                     row_pixels(g, out, t, yy, oyb, ox0);
                 }
@@ -367,7 +400,9 @@ struct F444 {
         if (comp >= 3u || cx >= te) return;
         uint32_t cw[32];
         load_block_from_lds(lds.coef, comp * 64u + cx, cw);
-        idct8x8<SANE>(cw, as_qtab(img.qt[comp]), r.out);
+        // (no img.qt[comp]: a runtime index into the by-value image struct would put it in scratch)
+        const uint16_t *qt = comp == 0u ? img.qt[0] : (comp == 1u ? img.qt[1] : img.qt[2]);
+        idct8x8<SANE>(cw, as_qtab(qt), r.out);
     }
     // sample tiles: [3 comps][8 rows][pitch 8*tx]
     static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLdsSmall &lds,
@@ -398,15 +433,36 @@ struct F444 {
 #pragma unroll
             for (uint32_t comp = 0; comp < 3; comp++)
                 s[comp] = *reinterpret_cast<const v2u *>(&lds.coef[(comp * 8u + row) * pitch + chk * 8u]);
-            uint32_t px[8];
+            const size_t off = ((size_t)oy * g.out_w + ox0) * 3u;
+            if (g.color == FCOLOR_RGB) {  // src/decoder.rs:1391-1404: interleave only
+                uint32_t px[8];
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                uint32_t a = byte_of(k < 4 ? s[0].x : s[0].y, k & 3u);
-                uint32_t b = byte_of(k < 4 ? s[1].x : s[1].y, k & 3u);
-                uint32_t c = byte_of(k < 4 ? s[2].x : s[2].y, k & 3u);
-                px[k] = g.color == FCOLOR_RGB ? (a | (b << 8) | (c << 16)) : ycbcr_to_rgb24(a, b, c);
+                for (uint32_t k = 0; k < 8; k++)
+                    px[k] = byte_of(k < 4 ? s[0].x : s[0].y, k & 3u) | (byte_of(k < 4 ? s[1].x : s[1].y, k & 3u) << 8) |
+                            (byte_of(k < 4 ? s[2].x : s[2].y, k & 3u) << 16);
+                store_rgb_run(out, off, px, npx);
+            } else {
+                RawRgb p[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
+                    p[k] = ycbcr_raw(byte_of(k < 4 ? s[0].x : s[0].y, k & 3u), byte_of(k < 4 ? s[1].x : s[1].y, k & 3u),
+                                     byte_of(k < 4 ? s[2].x : s[2].y, k & 3u));
+                if (npx == 8u && (off & 3u) == 0) {
+                    uint32_t d0, d1, d2, d3, d4, d5;
+                    rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
+                    rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
+                    *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off) = v3u{d0, d1, d2};
+                    *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off + 12) = v3u{d3, d4, d5};
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (k < npx) {
+                            out[off + 3 * k] = (uint8_t)sar_sat_u8x2(p[k].r, 0u, 20);
+                            out[off + 3 * k + 1] = (uint8_t)sar_sat_u8x2(p[k].g, 0u, 20);
+                            out[off + 3 * k + 2] = (uint8_t)sar_sat_u8x2(p[k].b, 0u, 20);
+                        }
+                }
             }
-            store_rgb_run(out, ((size_t)oy * g.out_w + ox0) * 3u, px, npx);
         }
     }
 };
@@ -444,7 +500,9 @@ struct FGray {
             if (n == 8 && (off & 7u) == 0) {
                 *reinterpret_cast<JP_GLOBAL v2u *>(dst + off) = v2u{out[2 * row], out[2 * row + 1]};
             } else {
-                for (uint32_t k = 0; k < n; k++) dst[off + k] = (uint8_t)byte_of(k < 4 ? out[2 * row] : out[2 * row + 1], k & 3u);
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
+                    if (k < n) dst[off + k] = (uint8_t)byte_of(k < 4 ? out[2 * row] : out[2 * row + 1], k & 3u);
             }
         }
     }

@@ -70,6 +70,44 @@ constexpr int32_t F_N0_390180644 = -1597;
 
 __device__ __forceinline__ w32 sar(w32 x, int n) { return (w32)((int32_t)x >> n); }
 
+// ---- packed 2 x u16 helpers (v_pk_mad_u16 / v_pk_add_u16 / v_pk_lshrrev_b16, v_alignbit, v_perm) ----
+#ifdef JPGPU_HOST_EMULATION
+__device__ __forceinline__ uint32_t pk_mad3(uint32_t a, uint32_t b) {  // per 16-bit lane: 3*a + b
+    uint32_t lo = (3u * (a & 0xffffu) + (b & 0xffffu)) & 0xffffu, hi = (3u * (a >> 16) + (b >> 16)) & 0xffffu;
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return (((a & 0xffffu) + (b & 0xffffu)) & 0xffffu) | ((((a >> 16) + (b >> 16)) & 0xffffu) << 16);
+}
+__device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int n) {
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> n);
+}
+// byte i of the result = byte sel[i] of {src0 (4..7), src1 (0..3)}; 0x0c = zero
+__device__ __forceinline__ uint32_t perm_b32(uint32_t src0, uint32_t src1, uint32_t sel) {
+    uint64_t all = ((uint64_t)src0 << 32) | src1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t s = (sel >> (8 * i)) & 0xffu;
+        uint32_t b = s < 8 ? (uint32_t)((all >> (8 * s)) & 0xffu) : 0u;
+        r |= b << (8 * i);
+    }
+    return r;
+}
+#else
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2_t as_us2(uint32_t x) { return __builtin_bit_cast(us2_t, x); }
+__device__ __forceinline__ uint32_t us2_bits(us2_t x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_mad3(uint32_t a, uint32_t b) {
+    const us2_t three = {3, 3};
+    return us2_bits(as_us2(a) * three + as_us2(b));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return us2_bits(as_us2(a) + as_us2(b)); }
+__device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return us2_bits(as_us2(a) >> (unsigned short)n); }
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
+__device__ __forceinline__ uint32_t perm_b32(uint32_t src0, uint32_t src1, uint32_t sel) { return __builtin_amdgcn_perm(src0, src1, sel); }
+#endif
+
 // 24-bit multiply: low 32 bits of sext24(a) * sext24(b).  Exact mod 2^32 whenever both true
 // operands lie in [-2^23, 2^23) — v_mul_i32_i24 / v_mad_i32_i24 are full rate on gfx950 while
 // v_mul_lo_u32 is not.
@@ -109,11 +147,7 @@ __device__ __forceinline__ uint32_t sar_sat_u8x2(w32 a, w32 b, int n) {
 // four values -> one dword, byte 0 = a
 __device__ __forceinline__ uint32_t sar_sat_u8x4(w32 a, w32 b, w32 c, w32 d, int n) {
     uint32_t lo = sar_sat_u8x2(a, b, n), hi = sar_sat_u8x2(c, d, n);
-#ifdef JPGPU_HOST_EMULATION
-    return lo | (hi << 16);
-#else
-    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // bytes: lo.0 lo.1 hi.0 hi.1
-#endif
+    return perm_b32(hi, lo, 0x05040100u);  // bytes: lo.0 lo.1 hi.0 hi.1
 }
 __device__ __forceinline__ uint32_t clamp_u8(w32 x) {  // stbi_clamp, src/idct.rs:568-570
     return sar_sat_u8x2(x, 0u, 0) & 0xffu;
@@ -287,6 +321,30 @@ constexpr int32_t CR_R = 1470104, CB_G = 360857, CR_G = 748830, CB_B = 1858077;
 constexpr int32_t KR = (1 << 19) - 128 * CR_R;
 constexpr int32_t KG = (1 << 19) + 128 * (CB_G + CR_G);
 constexpr int32_t KB = (1 << 19) - 128 * CB_B;
+
+struct RawRgb {
+    w32 r, g, b;  // 20-bit fixed point, before the >> 20 and the clamp
+};
+__device__ __forceinline__ RawRgb ycbcr_raw(uint32_t y, uint32_t cb, uint32_t cr) {
+    const w32 yb = y << 20;
+    RawRgb o;
+    o.r = yb + (mul24(cr, CR_R) + (w32)KR);
+    o.g = yb + (mul24(cb, -CB_G) + (mul24(cr, -CR_G) + (w32)KG));
+    o.b = yb + (mul24(cb, CB_B) + (w32)KB);
+    return o;
+}
+// Four pixels -> the 12 output bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3.  The shift-saturate-
+// pack instruction takes two values at a time, so the pairs are chosen in output byte order and
+// each dword is then one byte permute of two pairs.
+__device__ __forceinline__ void rgb4_to_12bytes(const RawRgb &p0, const RawRgb &p1, const RawRgb &p2, const RawRgb &p3,
+                                                uint32_t &d0, uint32_t &d1, uint32_t &d2) {
+    const uint32_t a = sar_sat_u8x2(p0.r, p0.g, 20), b = sar_sat_u8x2(p0.b, p1.r, 20);
+    const uint32_t c = sar_sat_u8x2(p1.g, p1.b, 20), d = sar_sat_u8x2(p2.r, p2.g, 20);
+    const uint32_t e = sar_sat_u8x2(p2.b, p3.r, 20), f = sar_sat_u8x2(p3.g, p3.b, 20);
+    d0 = perm_b32(b, a, 0x05040100u);
+    d1 = perm_b32(d, c, 0x05040100u);
+    d2 = perm_b32(f, e, 0x05040100u);
+}
 
 __device__ __forceinline__ uint32_t ycbcr_to_rgb24(uint32_t y, uint32_t cb, uint32_t cr) {
     w32 yb = y << 20;
