@@ -254,8 +254,10 @@ struct F420 {
     // One output row of one 8-pixel chunk (src/upsampler.rs:191-228 + src/decoder.rs:1406-1437).
     //   pixel k: main sample s_(k>>1), other tap s_(k>>1)+-1:  c = (3*t'main + t'other) >> 4
     //   first / last column of the image: c = t'main >> 2
-    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *out, const TPrime (&t)[2],
-                                                      v2u yy, uint32_t oy, uint32_t ox0) {
+    // `rowp` = first byte of the output scanline (wave-uniform -> scalar address math), `row_al4` =
+    // that scanline starts 4-byte aligned (then every 8-pixel chunk does: 24*chk is a multiple of 4)
+    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *rowp, bool row_al4,
+                                                      const TPrime (&t)[2], v2u yy, uint32_t ox0) {
         // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
         uint32_t pk[2][4];
 #pragma unroll
@@ -285,27 +287,29 @@ struct F420 {
             }
         }
         RawRgb p[8];
+        const w32 yb[8] = {byte_shl20<0>(yy.x), byte_shl20<1>(yy.x), byte_shl20<2>(yy.x), byte_shl20<3>(yy.x),
+                           byte_shl20<0>(yy.y), byte_shl20<1>(yy.y), byte_shl20<2>(yy.y), byte_shl20<3>(yy.y)};
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t cb = (k < 4) ? (pk[0][k & 3u] & 0xffffu) : (pk[0][k & 3u] >> 16);
             const uint32_t cr = (k < 4) ? (pk[1][k & 3u] & 0xffffu) : (pk[1][k & 3u] >> 16);
-            p[k] = ycbcr_raw(byte_of(k < 4 ? yy.x : yy.y, k & 3u), cb, cr);
+            p[k] = ycbcr_raw_yb(yb[k], cb, cr);
         }
-        const size_t off = ((size_t)oy * g.out_w + ox0) * 3u;
+        JP_GLOBAL uint8_t *o = rowp + ox0 * 3u;
         const uint32_t n = min(8u, g.out_w - ox0);
-        if (n == 8u && (off & 3u) == 0) {
+        if (n == 8u && row_al4) {
             uint32_t d0, d1, d2, d3, d4, d5;
             rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
             rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
-            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off) = v3u{d0, d1, d2};
-            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off + 12) = v3u{d3, d4, d5};
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{d0, d1, d2};
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{d3, d4, d5};
         } else {
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++)  // unrolled + predicated: a runtime-indexed p[] would live in scratch
                 if (k < n) {
-                    out[off + 3 * k] = (uint8_t)sar_sat_u8x2(p[k].r, 0u, 20);
-                    out[off + 3 * k + 1] = (uint8_t)sar_sat_u8x2(p[k].g, 0u, 20);
-                    out[off + 3 * k + 2] = (uint8_t)sar_sat_u8x2(p[k].b, 0u, 20);
+                    o[3 * k] = (uint8_t)sar_sat_u8x2(p[k].r, 0u, 20);
+                    o[3 * k + 1] = (uint8_t)sar_sat_u8x2(p[k].g, 0u, 20);
+                    o[3 * k + 2] = (uint8_t)sar_sat_u8x2(p[k].b, 0u, 20);
                 }
         }
     }
@@ -333,6 +337,9 @@ struct F420 {
             const uint32_t U = slot, L = slot + 1u;
             // row a: near U, far min(near+1, ch-1);  row b: near L, far max(near-1, 0)
             const bool clamp_a = !(cu + 1 <= (int32_t)g.ch - 1), clamp_b = !(cu >= 0);
+            const size_t pitch = (size_t)g.out_w * 3u;
+            JP_GLOBAL uint8_t *rowa = out + (size_t)oya * pitch, *rowb = out + (size_t)oyb * pitch;
+            const bool al4a = (((size_t)oya * pitch) & 3u) == 0, al4b = (((size_t)oyb * pitch) & 3u) == 0;
             for (uint32_t chk = lane; chk < nch; chk += 64u) {
                 const uint32_t ox0 = 16u * x0m + 8u * chk;
                 if (ox0 >= g.out_w) continue;
@@ -347,12 +354,12 @@ struct F420 {
                 if (va) {
                     const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};
                     const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)ra * ypitch + 8u * chk]);
-                    row_pixels(g, out, t, yy, oya, ox0);
+                    row_pixels(g, rowa, al4a, t, yy, ox0);
                 }
                 if (vb) {
                     const TPrime t[2] = {tprime(el[0], eu[0]), tprime(el[1], eu[1])};
                     const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
-                    row_pixels(g, out, t, yy, oyb, ox0);
+                    row_pixels(g, rowb, al4b, t, yy, ox0);
                 }
             }
         }

@@ -144,10 +144,22 @@ __device__ __forceinline__ uint32_t sar_sat_u8x2(w32 a, w32 b, int n) {
     return (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32((int)a, (int)b, n);
 #endif
 }
+// Same, but bits 31:16 of the result are UNDEFINED (the raw instruction leaves garbage there).
+// Only for consumers that read bytes 0,1 alone (v_perm_b32): saves the v_and the builtin costs.
+template <int N>
+__device__ __forceinline__ uint32_t sar_sat_u8x2_raw(w32 a, w32 b) {
+#ifdef JPGPU_HOST_EMULATION
+    return sar_sat_u8x2(a, b, N) | 0xdead0000u;  // poison the undefined half so misuse shows up in emulation
+#else
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(N));
+    return r;
+#endif
+}
 // four values -> one dword, byte 0 = a
-__device__ __forceinline__ uint32_t sar_sat_u8x4(w32 a, w32 b, w32 c, w32 d, int n) {
-    uint32_t lo = sar_sat_u8x2(a, b, n), hi = sar_sat_u8x2(c, d, n);
-    return perm_b32(hi, lo, 0x05040100u);  // bytes: lo.0 lo.1 hi.0 hi.1
+template <int N>
+__device__ __forceinline__ uint32_t sar_sat_u8x4(w32 a, w32 b, w32 c, w32 d) {
+    return perm_b32(sar_sat_u8x2_raw<N>(c, d), sar_sat_u8x2_raw<N>(a, b), 0x05040100u);  // bytes: lo.0 lo.1 hi.0 hi.1
 }
 __device__ __forceinline__ uint32_t clamp_u8(w32 x) {  // stbi_clamp, src/idct.rs:568-570
     return sar_sat_u8x2(x, 0u, 0) & 0xffu;
@@ -253,8 +265,8 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
         idct_pass8<SANE>(s, X_SCALE, o);
-        out[r * 2] = sar_sat_u8x4(o[0], o[1], o[2], o[3], 17);
-        out[r * 2 + 1] = sar_sat_u8x4(o[4], o[5], o[6], o[7], 17);
+        out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
+        out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
     }
 }
 
@@ -285,7 +297,7 @@ __device__ __forceinline__ void idct4x4_exact(const uint32_t (&cw)[32], qtab_t q
         w32 p1 = (s1 + s3) * (w32)F_0_5411961;
         w32 t0 = p1 + s3 * (w32)F_N1_847759065;
         w32 t2 = p1 + s1 * (w32)F_0_765366865;
-        out[i] = sar_sat_u8x4(x0 + t2, x2 + t0, x2 - t0, x0 - t2, 17);
+        out[i] = sar_sat_u8x4<17>(x0 + t2, x2 + t0, x2 - t0, x0 - t2);
     }
 }
 
@@ -298,7 +310,7 @@ __device__ __forceinline__ uint32_t idct2x2_exact(const uint32_t (&cw)[32], qtab
     w32 x0 = s00 + s10 + 4u + (128u << 3);
     w32 x2 = s00 - s10 + 4u + (128u << 3);
     w32 x1 = s01 + s11, x3 = s01 - s11;
-    return sar_sat_u8x4(x0 + x1, x0 - x1, x2 + x3, x2 - x3, 3);
+    return sar_sat_u8x4<3>(x0 + x1, x0 - x1, x2 + x3, x2 - x3);
 }
 
 // src/idct.rs:555-565 — truncating division by 8 of the wrapped sum
@@ -322,9 +334,33 @@ constexpr int32_t KR = (1 << 19) - 128 * CR_R;
 constexpr int32_t KG = (1 << 19) + 128 * (CB_G + CR_G);
 constexpr int32_t KB = (1 << 19) - 128 * CB_B;
 
+// (byte k of d) << 20 in ONE instruction: a shift with an SDWA byte select on its operand
+// (hipcc emits shift + mask for bytes 0..2).
+template <int K>
+__device__ __forceinline__ w32 byte_shl20(uint32_t d) {
+#ifdef JPGPU_HOST_EMULATION
+    return ((d >> (8 * K)) & 0xffu) << 20;
+#else
+    uint32_t r;
+    if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(20u), "v"(d));
+    else if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(20u), "v"(d));
+    else if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(20u), "v"(d));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(20u), "v"(d));
+    return r;
+#endif
+}
+
 struct RawRgb {
     w32 r, g, b;  // 20-bit fixed point, before the >> 20 and the clamp
 };
+// yb = y << 20
+__device__ __forceinline__ RawRgb ycbcr_raw_yb(w32 yb, uint32_t cb, uint32_t cr) {
+    RawRgb o;
+    o.r = yb + (mul24(cr, CR_R) + (w32)KR);
+    o.g = yb + (mul24(cb, -CB_G) + (mul24(cr, -CR_G) + (w32)KG));
+    o.b = yb + (mul24(cb, CB_B) + (w32)KB);
+    return o;
+}
 __device__ __forceinline__ RawRgb ycbcr_raw(uint32_t y, uint32_t cb, uint32_t cr) {
     const w32 yb = y << 20;
     RawRgb o;
@@ -338,9 +374,9 @@ __device__ __forceinline__ RawRgb ycbcr_raw(uint32_t y, uint32_t cb, uint32_t cr
 // each dword is then one byte permute of two pairs.
 __device__ __forceinline__ void rgb4_to_12bytes(const RawRgb &p0, const RawRgb &p1, const RawRgb &p2, const RawRgb &p3,
                                                 uint32_t &d0, uint32_t &d1, uint32_t &d2) {
-    const uint32_t a = sar_sat_u8x2(p0.r, p0.g, 20), b = sar_sat_u8x2(p0.b, p1.r, 20);
-    const uint32_t c = sar_sat_u8x2(p1.g, p1.b, 20), d = sar_sat_u8x2(p2.r, p2.g, 20);
-    const uint32_t e = sar_sat_u8x2(p2.b, p3.r, 20), f = sar_sat_u8x2(p3.g, p3.b, 20);
+    const uint32_t a = sar_sat_u8x2_raw<20>(p0.r, p0.g), b = sar_sat_u8x2_raw<20>(p0.b, p1.r);
+    const uint32_t c = sar_sat_u8x2_raw<20>(p1.g, p1.b), d = sar_sat_u8x2_raw<20>(p2.r, p2.g);
+    const uint32_t e = sar_sat_u8x2_raw<20>(p2.b, p3.r), f = sar_sat_u8x2_raw<20>(p3.g, p3.b);
     d0 = perm_b32(b, a, 0x05040100u);
     d1 = perm_b32(d, c, 0x05040100u);
     d2 = perm_b32(f, e, 0x05040100u);
