@@ -7,6 +7,7 @@
 #include "fused.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "fused_plan.hpp"
@@ -29,18 +30,19 @@ __global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const Fus
     idct_planes_body<8>(job, blockIdx.x, lds);
 }
 
-template <bool SANE>
-__global__ __launch_bounds__(256) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
-    __shared__ FusedLds lds;
+template <bool SANE, uint32_t NT>
+__global__ __launch_bounds__(NT, 4) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    typedef F420<SANE, NT> K;
+    __shared__ typename K::Lds lds;
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
-    F420<SANE>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    K::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    F420<SANE>::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    K::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F420<SANE>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    K::phase2(g, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F420<SANE>::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    K::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
 template <bool SANE>
@@ -84,7 +86,9 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
     }
     FusedGeom g{};
     const char *name = "", *w = "";
-    int kind = fused_geom_from_desc(d0, g, name, w);
+    // JPGPU_F420_TX=64 selects the 256-thread / 64-MCU tiling of the 4:2:0 main pass (tuning knob)
+    const char *txenv = getenv("JPGPU_F420_TX");
+    int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 32u);
     if (kind == FUSED_NONE) {
         why = w;
         return false;
@@ -142,8 +146,13 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
         uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
         dim3 cgrid((nblk + 255u) / 256u, 2, plan.n_images);
         f420_chroma_kernel<<<cgrid, block, 0, stream>>>(g, plan.d_images, nblk);
-        if (plan.all_sane) f420_main_kernel<true><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else f420_main_kernel<false><<<grid, block, 0, stream>>>(g, plan.d_images);
+        if (g.tx <= 32u) {  // 128-thread workgroups, 32 MCUs per tile
+            if (plan.all_sane) f420_main_kernel<true, 128><<<grid, dim3(128), 0, stream>>>(g, plan.d_images);
+            else f420_main_kernel<false, 128><<<grid, dim3(128), 0, stream>>>(g, plan.d_images);
+        } else {
+            if (plan.all_sane) f420_main_kernel<true, 256><<<grid, block, 0, stream>>>(g, plan.d_images);
+            else f420_main_kernel<false, 256><<<grid, block, 0, stream>>>(g, plan.d_images);
+        }
         break;
     }
     case FUSED_444:

@@ -27,7 +27,6 @@ constexpr uint32_t FUSED_NT = 256;       // threads per workgroup
 constexpr uint32_t F420_TX_MAX = 64;     // 4 luma blocks per MCU -> <= 256 lanes
 constexpr uint32_t F444_TX_MAX = 64;     // one wave per component, one lane per block
 constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
-constexpr uint32_t F420_CPITCH = 8 * F420_TX_MAX + 16;  // chroma LDS row: 8 halo + 8*TX + 8 halo
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
 
 enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1 };
@@ -55,9 +54,13 @@ struct FusedImage {
     uint32_t _pad;
 };
 
-struct alignas(16) FusedLds {
-    uint8_t coef[FUSED_COEF_LDS];           // coefficient staging, later the sample tile(s)
-    uint8_t chroma[2 * 10 * F420_CPITCH];   // 4:2:0 only
+// 4:2:0 main pass, NT threads per workgroup: NT luma blocks (NT/4 MCUs) per tile
+template <uint32_t NT>
+struct alignas(16) F420Lds {
+    static constexpr uint32_t TX_MAX = NT / 4;
+    static constexpr uint32_t CPITCH = 8 * TX_MAX + 16;  // chroma LDS row: 8 halo + 8*TX + 8 halo
+    uint8_t coef[NT * 128];                              // coefficient staging, later the luma tile
+    uint8_t chroma[2 * 10 * CPITCH];
 };
 struct alignas(16) FusedLdsSmall {          // kernels without a chroma neighbourhood
     uint8_t coef[FUSED_COEF_LDS];
@@ -115,24 +118,21 @@ __device__ __forceinline__ void store_rgb_run(JP_GLOBAL uint8_t *out, size_t off
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t d, uint32_t i) { return (d >> (8u * i)) & 0xffu; }
 
-// Stage up to 2048 16-B coefficient chunks of a tile into LDS.  `addr(j)` maps the tile-local
+// Stage up to 8*NT 16-B coefficient chunks of a tile into LDS (NT = threads per workgroup).  `addr(j)` maps the tile-local
 // chunk index to a global pointer.  All eight loads of a lane are issued before its first LDS
-// store (one exposed memory latency, not eight).  Named scalars + clamped indices on purpose: a
-// predicated `v4u v[8]` array is kept in scratch memory by hipcc (ROCm 7.2), not in VGPRs.
-template <class AddrFn>
+// store (one exposed memory latency, not eight).
+template <uint32_t NT, class AddrFn>
 __device__ __forceinline__ void stage_coefficients(uint8_t *coef_lds, uint32_t nchunks, uint32_t tid, AddrFn addr) {
     v4u *dst = reinterpret_cast<v4u *>(coef_lds);
     const uint32_t lastc = nchunks - 1u;
-#define JP_LD(i) const v4u v##i = *addr(min(tid + FUSED_NT * (i), lastc));
-    JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5) JP_LD(6) JP_LD(7)
-#undef JP_LD
-#define JP_ST(i)                                               \
-    {                                                          \
-        const uint32_t j = tid + FUSED_NT * (i);               \
-        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v##i; \
+    v4u v[8];  // (plain vector type: an array of HIP's uint4 class would be kept in scratch by hipcc)
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) v[i] = *addr(min(tid + NT * i, lastc));  // clamped: unconditional loads
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {
+        const uint32_t j = tid + NT * i;
+        if (j <= lastc) dst[coef_slot(j >> 3, j & 7u)] = v[i];
     }
-    JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5) JP_ST(6) JP_ST(7)
-#undef JP_ST
 }
 
 // =============================================================================================
@@ -144,8 +144,13 @@ __device__ __forceinline__ uint32_t swar_even(uint32_t d) { return d & 0x00ff00f
 __device__ __forceinline__ uint32_t swar_odd(uint32_t d) { return (d >> 8) & 0x00ff00ffu; }    // bytes 1,3
 __device__ __forceinline__ uint32_t swar_3a_b(uint32_t a, uint32_t b) { return (a << 1) + a + b; }
 
-template <bool SANE>
+template <bool SANE, uint32_t NT>
 struct F420 {
+    typedef F420Lds<NT> Lds;
+    static constexpr uint32_t CPITCH = Lds::CPITCH;
+    static constexpr uint32_t NWAVES = NT / 64;
+    static constexpr uint32_t CITEMS = 20 / NWAVES;  // (component,row) chroma items per wave
+    static constexpr bool HAS_CB = Lds::TX_MAX + 2 > 64;  // a chroma row has more than 64 8-B granules
     // effective MCUs of tile `tile_x`
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.mcu_w - tile_x * g.tx);
@@ -154,7 +159,7 @@ struct F420 {
     // phase 0: stage luma coefficients (two block rows of the MCU row) and the chroma
     // neighbourhood [8*my-1, 8*my+8] x [8*x0-8, 8*(x0+txe)+8) of both chroma planes into LDS.
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, FusedLds &lds) {
+                                                  uint32_t tid, Lds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
         const uint32_t run8 = 2u * te * 8u;  // 16-B chunks per luma block row of the tile
         const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)img.coefs[0];
@@ -171,31 +176,35 @@ struct F420 {
         const uint32_t colc0 = (uint32_t)min(max(col0, 0), (int32_t)stride - 8);
         const uint32_t colc1 = (uint32_t)min(max(col1, 0), (int32_t)stride - 8);
         const JP_GLOBAL uint8_t *planes = (const JP_GLOBAL uint8_t *)img.scratch;
-#define JP_CLD(i)                                                                                                  \
-    const uint32_t item##i = wave + 4u * (i);                                                                      \
-    const uint32_t comp##i = item##i >= 10u ? 1u : 0u;                                                             \
-    const int32_t crow##i = (int32_t)(8u * my) - 1 + (int32_t)(item##i - comp##i * 10u);                           \
-    const int32_t crowc##i = min(max(crow##i, 0), (int32_t)g.ch - 1);                                              \
-    const JP_GLOBAL uint8_t *prow##i = planes + (size_t)comp##i * g.chroma_plane_bytes + (size_t)crowc##i * stride; \
-    const v2u ca##i = *reinterpret_cast<const JP_GLOBAL v2u *>(prow##i + colc0);                               \
-    v2u cb##i = v2u{0u, 0u};                                                                              \
-    if (gran_per_row > 64u) cb##i = *reinterpret_cast<const JP_GLOBAL v2u *>(prow##i + colc1);
-        JP_CLD(0) JP_CLD(1) JP_CLD(2) JP_CLD(3) JP_CLD(4)
-#undef JP_CLD
-        stage_coefficients(lds.coef, 2u * run8, tid,
-                           [&](uint32_t j) { return j < run8 ? row0 + j : row1 + (j - run8); });
-#define JP_CST(i)                                                                                             \
-    if (crow##i == crowc##i) {                                                                                \
-        if (okc0) *reinterpret_cast<v2u *>(&lds.chroma[item##i * F420_CPITCH + 8u * lane]) = ca##i;         \
-        if (okc1) *reinterpret_cast<v2u *>(&lds.chroma[item##i * F420_CPITCH + 8u * (lane + 64u)]) = cb##i; \
-    }
-        JP_CST(0) JP_CST(1) JP_CST(2) JP_CST(3) JP_CST(4)
-#undef JP_CST
+        v2u ca[CITEMS], cb[HAS_CB ? CITEMS : 1];
+        bool rok[CITEMS];
+#pragma unroll
+        for (uint32_t i = 0; i < CITEMS; i++) {
+            const uint32_t item = wave + NWAVES * i;  // < 20
+            const uint32_t comp = item >= 10u ? 1u : 0u;
+            const int32_t crow = (int32_t)(8u * my) - 1 + (int32_t)(item - comp * 10u);
+            const int32_t crowc = min(max(crow, 0), (int32_t)g.ch - 1);
+            rok[i] = crow == crowc;
+            const JP_GLOBAL uint8_t *prow = planes + (size_t)comp * g.chroma_plane_bytes + (size_t)crowc * stride;
+            ca[i] = *reinterpret_cast<const JP_GLOBAL v2u *>(prow + colc0);  // clamped address: unconditional
+            if constexpr (HAS_CB) cb[i] = *reinterpret_cast<const JP_GLOBAL v2u *>(prow + colc1);
+        }
+        stage_coefficients<NT>(lds.coef, 2u * run8, tid,
+                               [&](uint32_t j) { return j < run8 ? row0 + j : row1 + (j - run8); });
+#pragma unroll
+        for (uint32_t i = 0; i < CITEMS; i++) {
+            const uint32_t item = wave + NWAVES * i;
+            if (rok[i]) {
+                if (okc0) *reinterpret_cast<v2u *>(&lds.chroma[item * CPITCH + 8u * lane]) = ca[i];
+                if constexpr (HAS_CB)
+                    if (okc1) *reinterpret_cast<v2u *>(&lds.chroma[item * CPITCH + 8u * (lane + 64u)]) = cb[i];
+            }
+        }
     }
 
     // phase 1: one lane per luma block: LDS -> registers -> IDCT
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t tid,
-                                                  const FusedLds &lds, FusedRegs &r) {
+                                                  const Lds &lds, FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
         if (tid >= 4u * te) return;
         uint32_t cw[32];
@@ -205,7 +214,7 @@ struct F420 {
 
     // phase 2: luma samples into the LDS tile (16 rows x 16*te bytes, pitch 16*tx), which
     // aliases the (now consumed) coefficient staging area
-    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLds &lds,
+    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, Lds &lds,
                                                   const FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
         if (tid >= 4u * te) return;
@@ -321,12 +330,13 @@ struct F420 {
     // does two slots' worth); lanes walk consecutive chunks, i.e. 24-B pixel runs next to each
     // other on one scanline.
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, const FusedLds &lds) {
+                                                  uint32_t tid, const Lds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
         const uint32_t nch = 2u * te, ypitch = 16u * g.tx;
         const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
         JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
-        for (uint32_t slot = wave; slot < 9u; slot += 4u) {
+#pragma unroll 1
+        for (uint32_t slot = wave; slot < 9u; slot += NWAVES) {
             // output rows of the slot
             const int32_t ra = 2 * (int32_t)slot - 1, rb = 2 * (int32_t)slot;  // tile rows
             const uint32_t oya = 16u * my + (uint32_t)ra, oyb = 16u * my + (uint32_t)rb;
@@ -340,6 +350,7 @@ struct F420 {
             const size_t pitch = (size_t)g.out_w * 3u;
             JP_GLOBAL uint8_t *rowa = out + (size_t)oya * pitch, *rowb = out + (size_t)oyb * pitch;
             const bool al4a = (((size_t)oya * pitch) & 3u) == 0, al4b = (((size_t)oyb * pitch) & 3u) == 0;
+#pragma unroll 1
             for (uint32_t chk = lane; chk < nch; chk += 64u) {
                 const uint32_t ox0 = 16u * x0m + 8u * chk;
                 if (ox0 >= g.out_w) continue;
@@ -348,8 +359,8 @@ struct F420 {
 #pragma unroll
                 for (uint32_t comp = 0; comp < 2; comp++) {
                     // a clamped row is never staged: substitute its partner (uniform per slot)
-                    eu[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * F420_CPITCH + coff]);
-                    el[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * F420_CPITCH + coff]);
+                    eu[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * CPITCH + coff]);
+                    el[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * CPITCH + coff]);
                 }
                 if (va) {
                     const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};
@@ -388,17 +399,18 @@ struct F444 {
         // tile-local chunk j: component j / te8; stored at LDS block comp*64 + cx
         v4u *dst = reinterpret_cast<v4u *>(lds.coef);
         const uint32_t lastc = 3u * te8 - 1u;
-#define JP_LD(i)                                                                  \
-    const uint32_t j##i = min(tid + FUSED_NT * (i), lastc);                       \
-    const uint32_t k##i = (j##i >= te8 ? 1u : 0u) + (j##i >= 2u * te8 ? 1u : 0u); \
-    const uint32_t r##i = j##i - k##i * te8;                                      \
-    const v4u v##i = k##i == 0u ? c0[r##i] : (k##i == 1u ? c1[r##i] : c2[r##i]);
-        JP_LD(0) JP_LD(1) JP_LD(2) JP_LD(3) JP_LD(4) JP_LD(5)
-#undef JP_LD
-#define JP_ST(i) \
-    if (tid + FUSED_NT * (i) <= lastc) dst[coef_slot(k##i * 64u + (r##i >> 3), r##i & 7u)] = v##i;
-        JP_ST(0) JP_ST(1) JP_ST(2) JP_ST(3) JP_ST(4) JP_ST(5)
-#undef JP_ST
+        v4u v[6];
+        uint32_t kk[6], rr[6];
+#pragma unroll
+        for (uint32_t i = 0; i < 6; i++) {
+            const uint32_t j = min(tid + FUSED_NT * i, lastc);  // clamped: unconditional loads
+            kk[i] = (j >= te8 ? 1u : 0u) + (j >= 2u * te8 ? 1u : 0u);
+            rr[i] = j - kk[i] * te8;
+            v[i] = kk[i] == 0u ? c0[rr[i]] : (kk[i] == 1u ? c1[rr[i]] : c2[rr[i]]);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 6; i++)
+            if (tid + FUSED_NT * i <= lastc) dst[coef_slot(kk[i] * 64u + (rr[i] >> 3), rr[i] & 7u)] = v[i];
     }
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t tid,
                                                   const FusedLdsSmall &lds, FusedRegs &r) {
@@ -486,7 +498,7 @@ struct FGray {
                                                   uint32_t tid, FusedLdsSmall &lds) {
         const uint32_t x0 = tile_x * g.tx, te = txe(g, tile_x);
         const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)img.coefs[0] + ((size_t)my * g.bw0 + x0) * 8u;
-        stage_coefficients(lds.coef, te * 8u, tid, [&](uint32_t j) { return src + j; });
+        stage_coefficients<FUSED_NT>(lds.coef, te * 8u, tid, [&](uint32_t j) { return src + j; });
     }
     static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLdsSmall &lds) {

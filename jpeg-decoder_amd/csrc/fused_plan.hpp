@@ -16,7 +16,9 @@ inline bool fused_same_component(const jpgpu_component &a, const jpgpu_component
 }
 
 // Returns FUSED_* and fills `g`; FUSED_NONE (with `why`) sends the batch down the generic path.
-inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why) {
+// f420_tx_max: MCUs per 4:2:0 tile (32 -> 128-thread workgroups, 64 -> 256-thread workgroups)
+inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why,
+                                uint32_t f420_tx_max = 32) {
     g = FusedGeom{};
     for (uint32_t c = 0; c < d0.ncomp; c++)
         if (d0.components[c].dct_scale != 8) {
@@ -48,7 +50,7 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             why = "inconsistent block grid";
             return FUSED_NONE;
         }
-        tx_max = F420_TX_MAX;
+        tx_max = f420_tx_max <= 32u ? 32u : F420_TX_MAX;
     } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&
                (d0.color_transform == JPGPU_CT_YCBCR || d0.color_transform == JPGPU_CT_RGB) &&
                fused_same_component(d0.components[0], d0.components[1]) &&

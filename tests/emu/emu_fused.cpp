@@ -12,10 +12,10 @@ extern "C" {
 
 // returns the fused kind the planner picked (0 = none -> generic path on the GPU)
 int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, int sane, uint8_t* out,
-                     uint32_t* tx_out) {
+                     uint32_t* tx_out, uint32_t f420_tx_max) {
     FusedGeom g;
     const char *name = "", *why = "";
-    int kind = fused_geom_from_desc(*desc, g, name, why);
+    int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max);
     if (kind == FUSED_NONE) return 0;
     if (tx_out) *tx_out = g.tx;
     FusedImage img{};
@@ -43,34 +43,38 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             }
         }
     }
-    FusedLds* lds = new FusedLds;
+    F420Lds<256>* lds = new F420Lds<256>;
+    F420Lds<128>* lds128 = new F420Lds<128>;
     FusedLdsSmall* lds_s = new FusedLdsSmall;
     std::vector<FusedRegs> regs(FUSED_NT);
-#define RUN(BODY) for (uint32_t t = 0; t < FUSED_NT; t++) { BODY; }
+#define RUN(NTH, BODY) for (uint32_t t = 0; t < NTH; t++) { BODY; }
+#define RUN420(S, NTH, L) \
+    RUN(NTH, (F420<S, NTH>::phase0(g, img, tile, my, t, *L))) RUN(NTH, (F420<S, NTH>::phase1(g, img, tile, t, *L, regs[t]))) \
+    RUN(NTH, (F420<S, NTH>::phase2(g, tile, t, *L, regs[t]))) RUN(NTH, (F420<S, NTH>::phase3(g, img, tile, my, t, *L)))
     for (uint32_t my = 0; my < g.mcu_h; my++)
         for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
-            memset(lds, 0xCD, sizeof(FusedLds));  // garbage, like real LDS
+            memset(lds, 0xCD, sizeof(*lds));  // garbage, like real LDS
+            memset(lds128, 0xCD, sizeof(*lds128));
             memset(lds_s, 0xCD, sizeof(FusedLdsSmall));
-            if (kind == FUSED_420 && sane) {
-                RUN(F420<true>::phase0(g, img, tile, my, t, *lds)) RUN(F420<true>::phase1(g, img, tile, t, *lds, regs[t]))
-                RUN(F420<true>::phase2(g, tile, t, *lds, regs[t])) RUN(F420<true>::phase3(g, img, tile, my, t, *lds))
-            } else if (kind == FUSED_420) {
-                RUN(F420<false>::phase0(g, img, tile, my, t, *lds)) RUN(F420<false>::phase1(g, img, tile, t, *lds, regs[t]))
-                RUN(F420<false>::phase2(g, tile, t, *lds, regs[t])) RUN(F420<false>::phase3(g, img, tile, my, t, *lds))
+            if (kind == FUSED_420) {
+                if (g.tx <= 32u) { if (sane) { RUN420(true, 128, lds128) } else { RUN420(false, 128, lds128) } }
+                else { if (sane) { RUN420(true, 256, lds) } else { RUN420(false, 256, lds) } }
             } else if (kind == FUSED_444 && sane) {
-                RUN(F444<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(F444<true>::phase1(g, img, tile, t, *lds_s, regs[t]))
-                RUN(F444<true>::phase2(g, tile, t, *lds_s, regs[t])) RUN(F444<true>::phase3(g, img, tile, my, t, *lds_s))
+                RUN(256, F444<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<true>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<true>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<true>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444) {
-                RUN(F444<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(F444<false>::phase1(g, img, tile, t, *lds_s, regs[t]))
-                RUN(F444<false>::phase2(g, tile, t, *lds_s, regs[t])) RUN(F444<false>::phase3(g, img, tile, my, t, *lds_s))
+                RUN(256, F444<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<false>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<false>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<false>::phase3(g, img, tile, my, t, *lds_s))
             } else if (sane) {
-                RUN(FGray<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(FGray<true>::phase1(g, img, tile, my, t, *lds_s))
+                RUN(256, FGray<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<true>::phase1(g, img, tile, my, t, *lds_s))
             } else {
-                RUN(FGray<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(FGray<false>::phase1(g, img, tile, my, t, *lds_s))
+                RUN(256, FGray<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<false>::phase1(g, img, tile, my, t, *lds_s))
             }
         }
 #undef RUN
+#undef RUN420
     delete lds_s;
+    delete lds128;
     delete lds;
     return kind;
 }

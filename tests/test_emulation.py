@@ -92,7 +92,7 @@ def _to_j(ocomps):
     return out
 
 
-def _emulate(w_, h_, samp, ct, coefs, qts, sane):
+def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=32):
     ocomps, _ = O.make_components(w_, h_, samp)
     desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
     n = len(samp)
@@ -100,7 +100,7 @@ def _emulate(w_, h_, samp, ct, coefs, qts, sane):
     out_len = w_ * h_ * (1 if n == 1 else 3)
     out = np.full(out_len + 64, 0x5A, np.uint8)  # guard band: the kernels must not write past the image
     tx = C.c_uint32(0)
-    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, 1 if sane else 0, out.ctypes.data, C.byref(tx))
+    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, 1 if sane else 0, out.ctypes.data, C.byref(tx), f420_tx)
     assert (out[out_len:] == 0x5A).all(), "emulated kernel wrote past the output"
     return kind, out[:out_len], tx.value
 
@@ -120,7 +120,10 @@ GEOMS = [
 
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
 @pytest.mark.parametrize("kind", ["sane", "hostile"])
-def test_fused_kernel_logic_matches_oracle(geom, kind):
+@pytest.mark.parametrize("f420_tx", [32, 64])
+def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
+    if f420_tx == 64 and not (len(geom[2]) == 3 and geom[2][0] == (2, 2)):
+        pytest.skip("tile-size knob only affects the 4:2:0 kernel")
     w_, h_, samp, ct = geom
     rng = np.random.default_rng(w_ * 131 + h_)
     ocomps, _ = O.make_components(w_, h_, samp)
@@ -131,7 +134,7 @@ def test_fused_kernel_logic_matches_oracle(geom, kind):
     else:
         qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
         coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
-    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, kind == "sane")
+    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, kind == "sane", f420_tx)
     assert got_kind != 0, "planner refused a geometry the fused kernels are meant to cover"
     want = O.pixels_from_coefficients(ocomps, qts, coefs, w_, h_, ct.upper())
     assert got.size == want.size
@@ -151,4 +154,4 @@ def test_planner_keeps_odd_geometries_on_the_generic_path():
         desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
         ptrs = (C.c_void_p * len(samp))(*[c.ctypes.data for c in coefs])
         out = np.zeros(w_ * h_ * 4 + 64, np.uint8)
-        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None) == 0
+        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None, 32) == 0
