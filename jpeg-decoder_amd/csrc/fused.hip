@@ -86,9 +86,9 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
     }
     FusedGeom g{};
     const char *name = "", *w = "";
-    // JPGPU_F420_TX=64 selects the 256-thread / 64-MCU tiling of the 4:2:0 main pass (tuning knob)
+    // JPGPU_F420_TX=32 selects the 128-thread / 32-MCU tiling of the 4:2:0 main pass (tuning knob)
     const char *txenv = getenv("JPGPU_F420_TX");
-    int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 32u);
+    int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 64u);
     if (kind == FUSED_NONE) {
         why = w;
         return false;

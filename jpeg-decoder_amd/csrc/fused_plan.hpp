@@ -16,9 +16,10 @@ inline bool fused_same_component(const jpgpu_component &a, const jpgpu_component
 }
 
 // Returns FUSED_* and fills `g`; FUSED_NONE (with `why`) sends the batch down the generic path.
-// f420_tx_max: MCUs per 4:2:0 tile (32 -> 128-thread workgroups, 64 -> 256-thread workgroups)
+// f420_tx_max: MCUs per 4:2:0 tile (32 -> 128-thread workgroups, 64 -> 256-thread workgroups; measured on
+// MI355X, 1080p x256: 0.899 ms with 64 vs 0.941 ms with 32 — profiles/round1)
 inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why,
-                                uint32_t f420_tx_max = 32) {
+                                uint32_t f420_tx_max = 64) {
     g = FusedGeom{};
     for (uint32_t c = 0; c < d0.ncomp; c++)
         if (d0.components[c].dct_scale != 8) {
