@@ -1,0 +1,76 @@
+/*
+ * jpgpu_decoder.h — C ABI of the host front-end: the crate's public `Decoder` surface
+ * (src/decoder.rs:101-295, src/lib.rs:39-41) on top of the MI355X pixel backend (jpgpu.h).
+ *
+ * The reference's front-end is Rust; no Rust toolchain exists in this image, so the marker
+ * parser (src/parser.rs), Huffman / progressive entropy decoder (src/huffman.rs,
+ * src/decoder.rs:794-1298) and the marker loop (src/decoder.rs:297-615) are restated in C++
+ * (jpeg-decoder_amd/csrc/host) and feed exactly what the crate hands to `Worker::append_row`.
+ * Entropy decoding runs on the host (inherently serial); every pixel is produced on the GPU.
+ */
+#ifndef JPGPU_DECODER_H
+#define JPGPU_DECODER_H
+
+#include "jpgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* PixelFormat, src/decoder.rs:39-60 */
+enum { JPGPU_PIXEL_L8 = 0, JPGPU_PIXEL_L16 = 1, JPGPU_PIXEL_RGB24 = 2, JPGPU_PIXEL_CMYK32 = 3 };
+/* CodingProcess, src/parser.rs:24-33 */
+enum { JPGPU_CODING_DCT_SEQUENTIAL = 0, JPGPU_CODING_DCT_PROGRESSIVE = 1, JPGPU_CODING_LOSSLESS = 2 };
+
+/* ImageInfo, src/decoder.rs:62-73 */
+typedef struct jpgpu_image_info {
+    uint16_t width, height;
+    int32_t pixel_format;
+    int32_t coding_process;
+} jpgpu_image_info;
+
+typedef struct jpgpu_decoder jpgpu_decoder;
+
+/* Decoder::new(reader) — src/decoder.rs:134-154.  The bytes are copied. `device` is the HIP
+ * device the pixel work runs on (-1: host-only object, usable for read_info / metadata /
+ * jpgpu_decoder_decode_coefficients but not for decode()). */
+int jpgpu_decoder_create(const uint8_t *data, size_t len, int device, jpgpu_decoder **out);
+void jpgpu_decoder_destroy(jpgpu_decoder *d);
+const char *jpgpu_decoder_last_error(const jpgpu_decoder *d);
+
+/* set_color_transform / set_max_decoding_buffer_size — src/decoder.rs:158-165 */
+int jpgpu_decoder_set_color_transform(jpgpu_decoder *d, int color_transform);
+int jpgpu_decoder_set_max_decoding_buffer_size(jpgpu_decoder *d, size_t max_bytes);
+
+/* read_info / info / scale — src/decoder.rs:170-197, 265-290.  info returns JPGPU_ERR_FORMAT
+ * until read_info or decode succeeded (Option::None). */
+int jpgpu_decoder_read_info(jpgpu_decoder *d);
+int jpgpu_decoder_info(const jpgpu_decoder *d, jpgpu_image_info *info);
+int jpgpu_decoder_scale(jpgpu_decoder *d, uint16_t requested_width, uint16_t requested_height,
+                        uint16_t *out_width, uint16_t *out_height);
+
+/* decode() -> Vec<u8> — src/decoder.rs:293-295.  `*len` receives the pixel byte count even when
+ * `cap` is too small (then JPGPU_ERR_FORMAT and nothing is decoded twice: call again with room;
+ * a decoder decodes once). */
+int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len);
+/* Size decode() will produce, valid after read_info: width*height*bytes_per_pixel. */
+size_t jpgpu_decoder_output_bytes(const jpgpu_decoder *d);
+
+/* Metadata — src/decoder.rs:200-243. Pointers stay valid until the decoder is destroyed;
+ * NULL/0 when absent.  icc_profile assembles the APP2 chunks (validity rules of :213-243). */
+const uint8_t *jpgpu_decoder_exif_data(const jpgpu_decoder *d, size_t *len);
+const uint8_t *jpgpu_decoder_xmp_data(const jpgpu_decoder *d, size_t *len);
+const uint8_t *jpgpu_decoder_icc_profile(jpgpu_decoder *d, size_t *len);
+
+/* Host half only (no GPU): run the marker loop and entropy decoder and return what would
+ * cross the Worker boundary — the frame geometry / tables as a jpgpu_image_desc and, per
+ * component, the coefficient rows that were appended (block-raster int16, natural order).
+ * `coefs[c]` / `n_coefs[c]` are owned by the decoder.  This is what feeds jpgpu_batch_upload
+ * when a batch of files is decoded (host parse of image i+1 overlaps the kernels of image i). */
+int jpgpu_decoder_decode_coefficients(jpgpu_decoder *d, jpgpu_image_desc *desc, const int16_t **coefs,
+                                      size_t *n_coefs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPGPU_DECODER_H */

@@ -50,10 +50,15 @@ class ImageDesc(C.Structure):
     ]
 
 
+class ImageInfoStruct(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("pixel_format", C.c_int32), ("coding_process", C.c_int32)]
+
+
 def build(force=False, verbose=False):
     """Compile libjpgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     csrc = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".cpp", ".hip", ".hpp"))] + [HEADER_PATH]
+    srcs = [os.path.join(dp, f) for dp, _, fs in os.walk(csrc) for f in fs if f.endswith((".cpp", ".hip", ".hpp"))]
+    srcs += [HEADER_PATH, os.path.join(_ROOT, "include", "jpgpu_decoder.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         cmd = ["make", "-C", csrc, "-j8"] + ([] if verbose else ["-s"])
@@ -97,6 +102,21 @@ _PROTOS = {
     "jpgpu_batch_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "jpgpu_batch_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     "jpgpu_batch_path": (C.c_char_p, [C.c_void_p]),
+    # include/jpgpu_decoder.h
+    "jpgpu_decoder_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "jpgpu_decoder_destroy": (None, [C.c_void_p]),
+    "jpgpu_decoder_last_error": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_decoder_set_color_transform": (C.c_int, [C.c_void_p, C.c_int]),
+    "jpgpu_decoder_set_max_decoding_buffer_size": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "jpgpu_decoder_read_info": (C.c_int, [C.c_void_p]),
+    "jpgpu_decoder_info": (C.c_int, [C.c_void_p, C.POINTER(ImageInfoStruct)]),
+    "jpgpu_decoder_scale": (C.c_int, [C.c_void_p, C.c_uint16, C.c_uint16, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]),
+    "jpgpu_decoder_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "jpgpu_decoder_output_bytes": (C.c_size_t, [C.c_void_p]),
+    "jpgpu_decoder_exif_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "jpgpu_decoder_xmp_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "jpgpu_decoder_icc_profile": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "jpgpu_decoder_decode_coefficients": (C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
 }
 
 

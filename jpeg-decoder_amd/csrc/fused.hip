@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const Fus
 }
 
 template <bool SANE, uint32_t NT>
-__global__ __launch_bounds__(NT, 4) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     typedef F420<SANE, NT> K;
     __shared__ typename K::Lds lds;
     const FusedImage img = imgs[blockIdx.z];

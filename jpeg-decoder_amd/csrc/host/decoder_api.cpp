@@ -1,0 +1,207 @@
+// decoder_api.cpp — C ABI of include/jpgpu_decoder.h: the crate's `Decoder` surface
+// (src/decoder.rs:101-295) = host front-end (frontend.cpp) + MI355X pixel backend (jpgpu.h).
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "frontend.hpp"
+
+using jpgpu::host::DecodeError;
+using jpgpu::host::Frontend;
+using jpgpu::host::RowSink;
+
+namespace {
+
+// Worker backed by the GPU: rows go straight to jpgpu_worker_append_row, planes stay in HBM.
+class GpuSink : public RowSink {
+public:
+    explicit GpuSink(jpgpu_worker *w) : w_(w) {}
+    void check(int rc) {
+        if (rc) throw DecodeError{rc, jpgpu_worker_last_error(w_)};
+    }
+    void start(uint32_t index, const jpgpu_component &c, const uint16_t qt[64]) override { check(jpgpu_worker_start(w_, index, &c, qt)); }
+    void append_row(uint32_t index, const int16_t *co, size_t len) override { check(jpgpu_worker_append_row(w_, index, co, len)); }
+    void finish(uint32_t index, uint32_t slot) override { check(jpgpu_worker_finish_plane(w_, index, slot)); }
+
+private:
+    jpgpu_worker *w_;
+};
+
+// Collects what crosses the boundary (for the batch driver and for GPU-less tests).
+class CoefSink : public RowSink {
+public:
+    std::vector<int16_t> work[JPGPU_MAX_COMPONENTS];   // by worker index
+    std::vector<int16_t> frame[JPGPU_MAX_COMPONENTS];  // by frame component
+    void start(uint32_t index, const jpgpu_component &, const uint16_t *) override { work[index].clear(); }
+    void append_row(uint32_t index, const int16_t *co, size_t len) override { work[index].insert(work[index].end(), co, co + len); }
+    void finish(uint32_t index, uint32_t slot) override {
+        std::vector<int16_t> taken;
+        taken.swap(work[index]);  // (index may equal slot)
+        frame[slot].swap(taken);
+    }
+};
+
+}  // namespace
+
+struct jpgpu_decoder {
+    std::unique_ptr<Frontend> fe;
+    int device = 0;
+    jpgpu_worker *worker = nullptr;
+    std::string err;
+    bool decoded = false;
+    std::vector<uint8_t> pixels;
+    std::vector<uint8_t> icc;
+    CoefSink coefs;
+    bool coefs_done = false;
+};
+
+static int fail(jpgpu_decoder *d, const DecodeError &e) {
+    d->err = e.message;
+    return e.code;
+}
+
+extern "C" {
+
+int jpgpu_decoder_create(const uint8_t *data, size_t len, int device, jpgpu_decoder **out) {
+    if (!out || (!data && len)) return JPGPU_ERR_FORMAT;
+    jpgpu_decoder *d = new jpgpu_decoder();
+    d->fe.reset(new Frontend(data, len));
+    d->device = device;
+    *out = d;
+    return JPGPU_OK;
+}
+
+void jpgpu_decoder_destroy(jpgpu_decoder *d) {
+    if (!d) return;
+    if (d->worker) jpgpu_worker_destroy(d->worker);
+    delete d;
+}
+
+const char *jpgpu_decoder_last_error(const jpgpu_decoder *d) { return d ? d->err.c_str() : ""; }
+
+int jpgpu_decoder_set_color_transform(jpgpu_decoder *d, int ct) {
+    if (!d || ct < 0 || ct > JPGPU_CT_JCS_BG_RGB) return JPGPU_ERR_FORMAT;
+    d->fe->set_color_transform(ct);
+    return JPGPU_OK;
+}
+
+int jpgpu_decoder_set_max_decoding_buffer_size(jpgpu_decoder *d, size_t max_bytes) {
+    if (!d) return JPGPU_ERR_FORMAT;
+    d->fe->set_max_decoding_buffer_size(max_bytes);
+    return JPGPU_OK;
+}
+
+int jpgpu_decoder_read_info(jpgpu_decoder *d) {
+    if (!d) return JPGPU_ERR_FORMAT;
+    try {
+        d->fe->read_info();
+    } catch (const DecodeError &e) {
+        return fail(d, e);
+    }
+    return JPGPU_OK;
+}
+
+int jpgpu_decoder_info(const jpgpu_decoder *d, jpgpu_image_info *info) {
+    if (!d || !info || !d->fe->has_frame()) return JPGPU_ERR_FORMAT;
+    *info = d->fe->info();
+    return JPGPU_OK;
+}
+
+int jpgpu_decoder_scale(jpgpu_decoder *d, uint16_t rw, uint16_t rh, uint16_t *ow, uint16_t *oh) {
+    if (!d) return JPGPU_ERR_FORMAT;
+    try {
+        uint16_t w = 0, h = 0;
+        d->fe->scale(rw, rh, w, h);
+        if (ow) *ow = w;
+        if (oh) *oh = h;
+    } catch (const DecodeError &e) {
+        return fail(d, e);
+    }
+    return JPGPU_OK;
+}
+
+size_t jpgpu_decoder_output_bytes(const jpgpu_decoder *d) {
+    if (!d || !d->fe->has_frame()) return 0;
+    const jpgpu_image_info i = d->fe->info();
+    const size_t bpp = i.pixel_format == JPGPU_PIXEL_L8 ? 1 : i.pixel_format == JPGPU_PIXEL_L16 ? 2 : i.pixel_format == JPGPU_PIXEL_RGB24 ? 3 : 4;
+    return (size_t)i.width * i.height * bpp;
+}
+
+int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len) {
+    if (!d) return JPGPU_ERR_FORMAT;
+    if (!d->decoded) {
+        try {
+            if (d->device < 0) throw DecodeError{JPGPU_ERR_NO_DEVICE, "decoder was created without a device (host-only)"};
+            if (!d->worker) {
+                int rc = jpgpu_worker_create(d->device, &d->worker);
+                if (rc) throw DecodeError{rc, "no usable MI355X device: the pixel pipeline has no CPU fallback"};
+            }
+            GpuSink sink(d->worker);
+            d->fe->decode_to(sink);
+            const uint32_t n = d->fe->ncomp();
+            const jpgpu_component *comps = d->fe->components();
+            const uint16_t w = d->fe->output_width(), h = d->fe->output_height();
+            const size_t out_len = n == 1 ? (size_t)comps[0].size_width * comps[0].size_height : (size_t)w * h * n;
+            d->pixels.resize(out_len ? out_len : 1);
+            size_t got = 0;
+            sink.check(jpgpu_compute_image(d->worker, comps, n, nullptr, w, h, d->fe->color_transform(), d->pixels.data(),
+                                           d->pixels.size(), &got));
+            d->pixels.resize(got);
+            d->decoded = true;
+        } catch (const DecodeError &e) {
+            return fail(d, e);
+        }
+    }
+    if (len) *len = d->pixels.size();
+    if (!dst || cap < d->pixels.size()) {
+        d->err = "decode: destination too small";
+        return JPGPU_ERR_FORMAT;
+    }
+    if (!d->pixels.empty()) memcpy(dst, d->pixels.data(), d->pixels.size());
+    return JPGPU_OK;
+}
+
+const uint8_t *jpgpu_decoder_exif_data(const jpgpu_decoder *d, size_t *len) {
+    const std::vector<uint8_t> *v = d ? d->fe->exif() : nullptr;
+    if (len) *len = v ? v->size() : 0;
+    return v ? v->data() : nullptr;
+}
+const uint8_t *jpgpu_decoder_xmp_data(const jpgpu_decoder *d, size_t *len) {
+    const std::vector<uint8_t> *v = d ? d->fe->xmp() : nullptr;
+    if (len) *len = v ? v->size() : 0;
+    return v ? v->data() : nullptr;
+}
+const uint8_t *jpgpu_decoder_icc_profile(jpgpu_decoder *d, size_t *len) {
+    if (len) *len = 0;
+    if (!d || !d->fe->icc_profile(d->icc)) return nullptr;
+    if (len) *len = d->icc.size();
+    return d->icc.data();
+}
+
+int jpgpu_decoder_decode_coefficients(jpgpu_decoder *d, jpgpu_image_desc *desc, const int16_t **coefs, size_t *n_coefs) {
+    if (!d || !desc || !coefs || !n_coefs) return JPGPU_ERR_FORMAT;
+    if (!d->coefs_done) {
+        try {
+            d->fe->decode_to(d->coefs);
+            d->coefs_done = true;
+        } catch (const DecodeError &e) {
+            return fail(d, e);
+        }
+    }
+    memset(desc, 0, sizeof(*desc));
+    desc->ncomp = d->fe->ncomp();
+    for (uint32_t c = 0; c < desc->ncomp; c++) {
+        desc->components[c] = d->fe->components()[c];
+        memcpy(desc->quantization_tables[c], d->fe->qtable_of_component(c), 128);
+        coefs[c] = d->coefs.frame[c].data();
+        n_coefs[c] = d->coefs.frame[c].size();
+    }
+    desc->out_w = d->fe->output_width();
+    desc->out_h = d->fe->output_height();
+    desc->color_transform = d->fe->color_transform();
+    return JPGPU_OK;
+}
+
+}  // extern "C"

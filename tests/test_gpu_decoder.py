@@ -1,0 +1,103 @@
+"""End to end on the MI355X: jpeg_decoder_amd.Decoder (C++ front-end + HIP kernels through the C ABI)
+on the reference's own test and bench images, byte-exact against the oracle / golden hashes."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import refimages as R
+
+pytestmark = pytest.mark.gpu
+J = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _load():
+    global J
+    import jpeg_decoder_amd as pkg
+    J = pkg
+    assert J.device_count() >= 1
+
+
+@pytest.mark.parametrize("rel", R.reftest_files())
+def test_reftest_decode(rel):
+    """tests/reftest/mod.rs: Decoder::new(file).decode() vs the sibling PNG (<= 3) — and exact vs oracle."""
+    path = os.path.join(R.REFTEST, rel)
+    data = open(path, "rb").read()
+    d = J.Decoder(data)
+    got = d.decode()
+    od = O.decode(data)
+    assert np.array_equal(got, od.pixels)
+    i = d.info()
+    assert (i.width, i.height, i.pixel_format) == (od.width, od.height, od.pixel_format)
+    assert R.max_diff_vs_png(got, od.ncomp, os.path.splitext(path)[0] + ".png") <= 3
+
+
+@pytest.mark.parametrize("key", sorted(R.golden_hashes()))
+def test_golden_sha256(key):
+    rel, _, scale = key.partition("@")
+    d = J.Decoder(open(os.path.join(R.GOLDEN, rel), "rb").read())
+    if scale:
+        w, h = (int(v) for v in scale.split("x"))
+        assert d.scale(w, h) == (w, h)
+    assert hashlib.sha256(d.decode().tobytes()).hexdigest() == R.golden_hashes()[key]
+
+
+def test_read_info_then_decode_same_as_decode():
+    # tests/lib.rs:34-50
+    data = open(os.path.join(R.REFTEST, "mozilla", "jpg-progressive.jpg"), "rb").read()
+    a = J.Decoder(data)
+    ref = a.decode()
+    b = J.Decoder(data)
+    b.read_info()
+    info = b.info()
+    got = b.decode()
+    assert info == b.info() == a.info()
+    assert np.array_equal(got, ref)
+
+
+def test_color_transform_override():
+    data = open(os.path.join(R.GOLDEN, "benches", "tower.jpg"), "rb").read()
+    for ct in ("RGB", "YCbCr", "None"):
+        d = J.Decoder(data)
+        d.set_color_transform(ct)
+        assert np.array_equal(d.decode(), O.decode(data, color_transform=ct.upper()).pixels), ct
+    d = J.Decoder(data)
+    d.set_color_transform("CMYK")
+    with pytest.raises(J.FormatError):
+        d.decode()
+
+
+def test_decode_batch_of_files():
+    names = ["benches/tower.jpg", "reftest/mjpeg.jpg", "reftest/rgb.jpg", "benches/tower_grayscale.jpg",
+             "reftest/mozilla/jpg-cmyk-2.jpg", "benches/tower_progressive.jpg", "reftest/non-interleaved-mcu.jpg"]
+    files = [open(os.path.join(R.GOLDEN, n), "rb").read() for n in names]
+    out = J.decode_batch(files)
+    for n, f, (info, px) in zip(names, files, out):
+        assert np.array_equal(px, O.decode(f).pixels), n
+    same = J.decode_batch([files[0]] * 6)  # same geometry -> fused kernels
+    for info, px in same:
+        assert hashlib.sha256(px.tobytes()).hexdigest() == R.golden_hashes()["benches/tower.jpg"]
+
+
+def test_hostile_files_never_crash_the_gpu_path():
+    """tests/crashtest/mod.rs on the full decode(): errors allowed, crashes not; files that decode
+    must still match the oracle (wrap-around IDCT semantics on hostile coefficients)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(R.GOLDEN, "crashtest", "*.jpg")) +
+                   glob.glob(os.path.join(R.GOLDEN, "crashtest", "imagetestsuite", "*.jpg")))
+    n_ok = 0
+    for f in files:
+        data = open(f, "rb").read()
+        try:
+            want = O.decode(data).pixels
+        except O.OracleError as e:
+            with pytest.raises(J.Error) as pe:
+                J.Decoder(data).decode()
+            assert pe.value.kind == e.kind, f
+            continue
+        assert np.array_equal(J.Decoder(data).decode(), want), f
+        n_ok += 1
+    assert n_ok >= 5
