@@ -71,6 +71,17 @@ def cpu_baseline(O, ocomps, qts, coefs, w, h, ct, target_seconds):
                       f"{cores} threads one image per task, {dt:.1f} s"}
 
 
+def measured_traffic(workload, path):
+    """HBM bytes per decode from the committed rocprofv3 PMC passes (profiles/round1/pmc_traffic.json,
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc runs); None if not measured."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")))
+        e = t.get(f"{workload}:{path}")
+        return e["hbm_bytes_per_decode"] if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse_args()
     import torch
@@ -83,14 +94,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     import jpeg_decoder_amd as J
+    import jpeg_decoder_amd.distributed as D
     import synth
+
+    dist = D.init(backend="nccl") if world > 1 else None
 
     w, h, sampling, mode, ct, default_batch = WORKLOADS[args.workload]
     n_img = args.batch or default_batch
@@ -138,9 +146,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     if dist:
-        t = torch.tensor([elapsed, gpu_ms_per_step], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms_per_step = float(t[0]), float(t[1])
+        elapsed, gpu_ms_per_step = D.max_over_ranks([elapsed, gpu_ms_per_step], device=dev)
 
     # parity spot check inside the bench (oracle = checker only, never the thing measured)
     verified = None
@@ -159,11 +165,10 @@ def main():
     if dist and not args.no_gather:
         try:  # north_star's "RCCL over xGMI only for the final gather", outside the timed region
             pix = out_arena[: batch.out_offset(n_img - 1) + out_bytes]
-            gl = [torch.empty_like(pix) for _ in range(world)] if rank == 0 else None
             torch.cuda.synchronize(dev)
             dist.barrier()
             g0 = time.perf_counter()
-            dist.gather(pix, gl, dst=0)
+            gl = D.gather_pixels(pix, dst=0)
             torch.cuda.synchronize(dev)
             dist.barrier()
             gather_ms = (time.perf_counter() - g0) * 1e3
@@ -188,7 +193,8 @@ def main():
                        "name": args.workload, "images_per_gpu": n_img, "kernel_path": batch.path,
                        "parallelism": f"images sharded {n_img}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": measured_traffic(args.workload, batch.path) if n_img == default_batch else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": round(gpu_ms_per_step, 4)},
             "verified_vs_oracle": verified,
         }

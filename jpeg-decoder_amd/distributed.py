@@ -1,0 +1,61 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo"
+in the CPU tests).  Images are independent, so a batch shards by image with NO data-path collective;
+the only optional collective is the final gather of the pixel buffers to one rank."""
+import os
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard(n_items, rank, world):
+    """Contiguous shard of `n_items` images for `rank`: sizes differ by at most one, order preserved."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_rank_world()
+    if world == 1:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kw["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def max_over_ranks(values, device="cpu"):
+    """Element-wise MAX of a list of floats over all ranks (bench timing contract)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t]
+
+
+def gather_pixels(local, dst=0):
+    """Final gather of equal-sized per-rank pixel arenas to rank `dst` (north_star's only collective).
+    Returns the list of per-rank tensors on `dst`, None elsewhere.  On a fully connected xGMI node each
+    peer->root transfer rides its own link; there is nothing to reduce, so gather (not all-gather)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, out, dst=dst)
+    return out

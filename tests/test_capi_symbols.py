@@ -1,0 +1,58 @@
+"""The C-ABI library loads on a GPU-less machine and exports every entry point that include/*.h
+declares (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import jpeg_decoder_amd as J
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for h in ("jpgpu.h", "jpgpu_decoder.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(jpgpu_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_declares_the_boundary():
+    fns = declared_functions()
+    for must in ("jpgpu_worker_start", "jpgpu_worker_append_row", "jpgpu_worker_append_rows", "jpgpu_worker_get_result",
+                 "jpgpu_compute_image", "jpgpu_batch_decode", "jpgpu_decoder_decode", "jpgpu_decoder_read_info"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    J.build()
+    lib = C.CDLL(J._native.LIB_PATH)
+    missing = [f for f in declared_functions() if not hasattr(lib, f)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(J._native.exported_symbols()) == declared_functions()
+
+
+def test_no_device_fails_loudly_not_silently():
+    if J.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(J.NoDeviceError):
+        J.HipWorker()
+    comps, _ = J.make_components(16, 16, [(1, 1)])
+    with pytest.raises(J.Error):
+        J.Batch([J.image_desc(list(comps), [[1] * 64], 16, 16, "Grayscale")])
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package (or include/) may reference it."""
+    pkg = os.path.join(ROOT, "jpeg-decoder_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dp, f), errors="replace").read()
+                assert "liboracle" not in text and "import oracle" not in text and "jpeg_oracle.h" not in text, os.path.join(dp, f)
