@@ -83,6 +83,15 @@ __device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return ((a & 0xf
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int n) {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> n);
 }
+__device__ __forceinline__ uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) {  // per 16-bit lane: low 16 bits of a*b
+    return (((a & 0xffffu) * (b & 0xffffu)) & 0xffffu) | ((((a >> 16) * (b >> 16)) & 0xffffu) << 16);
+}
+// c + a.lo*b.lo + a.hi*b.hi with the halves read as signed 16-bit (wraps mod 2^32)
+__device__ __forceinline__ w32 dot2_i16(uint32_t a, uint32_t b, w32 c) {
+    int64_t r = (int64_t)(int16_t)(a & 0xffffu) * (int16_t)(b & 0xffffu) + (int64_t)(int16_t)(a >> 16) * (int16_t)(b >> 16);
+    return (w32)((uint64_t)r + c);
+}
+__device__ __forceinline__ w32 dot2_i16_sc(uint32_t a, uint32_t b, w32 c) { return dot2_i16(a, b, c); }
 // byte i of the result = byte sel[i] of {src0 (4..7), src1 (0..3)}; 0x0c = zero
 __device__ __forceinline__ uint32_t perm_b32(uint32_t src0, uint32_t src1, uint32_t sel) {
     uint64_t all = ((uint64_t)src0 << 32) | src1;
@@ -104,6 +113,22 @@ __device__ __forceinline__ uint32_t pk_mad3(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return us2_bits(as_us2(a) + as_us2(b)); }
 __device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return us2_bits(as_us2(a) >> (unsigned short)n); }
+__device__ __forceinline__ uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) { return us2_bits(as_us2(a) * as_us2(b)); }
+typedef short s2_t __attribute__((ext_vector_type(2)));
+// v_dot2_i32_i16 in its three-operand (VOP3P) form.  Through the builtin hipcc picks the accumulating
+// VOP2 form v_dot2c and pays a v_mov per chain to seed the accumulator with the rounding constant; gfx9
+// allows one SGPR per VALU instruction, so the constant pair sits in a VGPR and the addend may be an
+// SGPR / inline constant.
+__device__ __forceinline__ w32 dot2_i16(uint32_t a, uint32_t b, w32 c) {
+    uint32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ w32 dot2_i16_sc(uint32_t a, uint32_t b, w32 c_uniform) {  // addend wave-uniform (SGPR / inline)
+    uint32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
 __device__ __forceinline__ uint32_t perm_b32(uint32_t src0, uint32_t src1, uint32_t sel) { return __builtin_amdgcn_perm(src0, src1, sel); }
 #endif
@@ -223,33 +248,78 @@ __device__ __forceinline__ int32_t coef_at(const uint32_t (&cw)[32], int r, int 
 //   of both passes lies inside [-2^23, 2^23) (column outputs are bounded by 5.55*sum|s| < 2^21,
 //   row multiplicands are sums of at most four of them), so 24-bit multiplies are exact, and the
 //   column short-cut equals the general formula (s0 << 12 cannot wrap).  See DESIGN.md.
+// (lo, hi) pair of signed 16-bit constants as one dword
+constexpr uint32_t pk_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+// One 8-point pass written as the exact integer linear map it is (mod 2^32), derived from
+// kernel_x / kernel_t (src/idct.rs:377-447) by distributing the constants:
+//   x0..x3 = Ex * (s0,s2,s4,s6) + x_scale        u0..u3 = Ou * (s1,s3,s5,s7)
+//   Ex = [4096  5352  4096  2217]   Ou = [1131 -3218  4816 -5680]
+//        [4096  2217 -4096 -5350]        [3219 -5681  1132  4816]
+//        [4096 -2217 -4096  5350]        [4816 -1129 -5681 -3218]
+//        [4096 -5352  4096 -2217]        [5683  4816  3219  1131]
+// Inputs arrive as signed 16-bit pairs p02 = (s0,s2), p46 = (s4,s6), p13 = (s1,s3), p57 = (s5,s7), so each
+// row of the maps is two v_dot2_i32_i16 (2 MACs per instruction, full rate): 16 dot2 + 8 add/sub per
+// pass instead of 12 multiplies + 29 adds.  Valid whenever every input fits i16.
+__device__ __forceinline__ void idct_pass8_dot2(uint32_t p02, uint32_t p46, uint32_t p13, uint32_t p57, w32 x_scale,
+                                                w32 (&o)[8]) {
+    const w32 x0 = dot2_i16(p02, pk_i16(4096, 5352), dot2_i16_sc(p46, pk_i16(4096, 2217), x_scale));
+    const w32 x1 = dot2_i16(p02, pk_i16(4096, 2217), dot2_i16_sc(p46, pk_i16(-4096, -5350), x_scale));
+    const w32 x2 = dot2_i16(p02, pk_i16(4096, -2217), dot2_i16_sc(p46, pk_i16(-4096, 5350), x_scale));
+    const w32 x3 = dot2_i16(p02, pk_i16(4096, -5352), dot2_i16_sc(p46, pk_i16(4096, -2217), x_scale));
+    const w32 u0 = dot2_i16(p13, pk_i16(1131, -3218), dot2_i16_sc(p57, pk_i16(4816, -5680), 0u));
+    const w32 u1 = dot2_i16(p13, pk_i16(3219, -5681), dot2_i16_sc(p57, pk_i16(1132, 4816), 0u));
+    const w32 u2 = dot2_i16(p13, pk_i16(4816, -1129), dot2_i16_sc(p57, pk_i16(-5681, -3218), 0u));
+    const w32 u3 = dot2_i16(p13, pk_i16(5683, 4816), dot2_i16_sc(p57, pk_i16(3219, 1131), 0u));
+    o[0] = x0 + u3;
+    o[7] = x0 - u3;
+    o[1] = x1 + u2;
+    o[6] = x1 - u2;
+    o[2] = x2 + u1;
+    o[5] = x2 - u1;
+    o[3] = x3 + u0;
+    o[4] = x3 - u0;
+}
+
 template <bool SANE>
 __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint32_t (&out)[16]) {
-    // dequantize first (row by row, so the packed coefficients and the table die early and the
-    // 64 products are the only long-lived values), then both passes in place
     w32 t[64];
-    uint32_t acbits[4] = {0u, 0u, 0u, 0u};  // OR of the packed raw coefficients of rows 1..7
+    if constexpr (SANE) {
+        // |c*q| < 2^15: the products fit i16, so the dequantization is a packed 16-bit multiply
+        // (two coefficients per instruction) and the column pass runs on dot2.
+        uint32_t d[32];  // d[k*4+j] = (s[k][2j], s[k][2j+1])
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+        for (int i = 0; i < 32; i++) d[i] = pk_mul_lo_u16(cw[i], q[i]);
 #pragma unroll
-        for (int i = 0; i < 8; i++) t[k * 8 + i] = mul24((w32)coef_at(cw, k, i), q_at(q, k * 8 + i));  // i16 x u16: always exact
-        if constexpr (!SANE) {
-            if (k >= 1) {
-#pragma unroll
-                for (int d = 0; d < 4; d++) acbits[d] |= cw[k * 4 + d];
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        w32 s[8], o[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = t[k * 8 + i];
-        idct_pass8<SANE>(s, 512u, o);
-        if constexpr (SANE) {
+        for (int i = 0; i < 8; i++) {
+            const int j = i >> 1;
+            const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
+            const uint32_t p02 = perm_b32(d[2 * 4 + j], d[0 * 4 + j], sel), p46 = perm_b32(d[6 * 4 + j], d[4 * 4 + j], sel);
+            const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
+            w32 o[8];
+            idct_pass8_dot2(p02, p46, p13, p57, 512u, o);
 #pragma unroll
             for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
-        } else {
+        }
+    } else {
+        // dequantize first (row by row, so the packed coefficients and the table die early and the
+        // 64 products are the only long-lived values), then the column pass in place
+        uint32_t acbits[4] = {0u, 0u, 0u, 0u};  // OR of the packed raw coefficients of rows 1..7
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) t[k * 8 + i] = mul24((w32)coef_at(cw, k, i), q_at(q, k * 8 + i));  // i16 x u16: always exact
+            if (k >= 1) {
+#pragma unroll
+                for (int dd = 0; dd < 4; dd++) acbits[dd] |= cw[k * 4 + dd];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            w32 s[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = t[k * 8 + i];
+            idct_pass8<false>(s, 512u, o);
             // raw-coefficient test of :279-285 on the packed halves
             const uint32_t bits = acbits[i >> 1];
             const bool dc_only = ((i & 1) ? (bits >> 16) : (bits & 0xffffu)) == 0;
