@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const Fus
 template <bool SANE, uint32_t NT>
 __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     typedef F420<SANE, NT> K;
-    __shared__ typename K::Lds lds;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const F420Lds lds = F420Lds::make(lds_raw, g.tx);
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
     K::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
@@ -99,6 +100,13 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
     plan.desc = d0;
     plan.n_images = (uint32_t)descs.size();
     plan.scratch_per_image = plan.kind == FUSED_420 ? align_up(2 * (size_t)g.chroma_plane_bytes, 256) : 0;
+    // images per chunk of the 4:2:0 path: chroma planes of a chunk <= 64 MiB (JPGPU_CHUNK overrides)
+    {
+        const char *ce = getenv("JPGPU_CHUNK");
+        uint32_t chunk = ce ? (uint32_t)atoi(ce) : 0u;
+        if (chunk == 0u) chunk = plan.n_images;  // measured on MI355X: chunking (16..128 images) is slower than one pass over the batch
+        plan.chunk = std::max(1u, std::min(chunk, plan.n_images));
+    }
     plan.images.assign(plan.n_images, FusedImage{});
     return true;
 }
@@ -107,7 +115,7 @@ int fused_alloc(FusedPlan &plan, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
     hipError_t e;
     if (plan.scratch_per_image) {
-        e = hipMalloc((void **)&plan.d_scratch, plan.scratch_per_image * plan.n_images);
+        e = hipMalloc((void **)&plan.d_scratch, plan.scratch_per_image * plan.chunk);
         if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(scratch): %s", hipGetErrorString(e));
     }
     e = hipMalloc((void **)&plan.d_images, sizeof(FusedImage) * plan.n_images);
@@ -128,7 +136,7 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
             all_sane = all_sane && sane[i * 4 + c];
         }
         im.out = d_out + out_off[i];
-        im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)i * plan.scratch_per_image : nullptr;
+        im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)(i % plan.chunk) * plan.scratch_per_image : nullptr;
         im.flags = all_sane ? 1u : 0u;
         plan.all_sane = plan.all_sane && all_sane;  // one hostile image sends the whole batch down the wrap-exact kernels
     }
@@ -143,15 +151,24 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
     dim3 grid(g.tiles_x, g.mcu_h, plan.n_images);
     switch (plan.kind) {
     case FUSED_420: {
-        uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
-        dim3 cgrid((nblk + 255u) / 256u, 2, plan.n_images);
-        f420_chroma_kernel<<<cgrid, block, 0, stream>>>(g, plan.d_images, nblk);
-        if (g.tx <= 32u) {  // 128-thread workgroups, 32 MCUs per tile
-            if (plan.all_sane) f420_main_kernel<true, 128><<<grid, dim3(128), 0, stream>>>(g, plan.d_images);
-            else f420_main_kernel<false, 128><<<grid, dim3(128), 0, stream>>>(g, plan.d_images);
-        } else {
-            if (plan.all_sane) f420_main_kernel<true, 256><<<grid, block, 0, stream>>>(g, plan.d_images);
-            else f420_main_kernel<false, 256><<<grid, block, 0, stream>>>(g, plan.d_images);
+        // The batch may be walked in chunks of `chunk` images (chroma pass, then main pass) sharing one
+        // scratch area (JPGPU_CHUNK).  Default: one chunk — keeping a chunk's chroma planes within the
+        // 256 MiB Infinity Cache did not pay on MI355X (profiles/round1: 16/32/64/128-image chunks
+        // were 23/9/4/1 % slower than the whole 256-image batch).
+        const uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
+        for (uint32_t first = 0; first < plan.n_images; first += plan.chunk) {
+            const uint32_t n = std::min(plan.chunk, plan.n_images - first);
+            const FusedImage *imgs = plan.d_images + first;
+            dim3 cgrid((nblk + 255u) / 256u, 2, n), mgrid(g.tiles_x, g.mcu_h, n);
+            const size_t shm = F420Lds::total_bytes(g.tx);
+            f420_chroma_kernel<<<cgrid, block, 0, stream>>>(g, imgs, nblk);
+            if (g.tx <= 32u) {  // 128-thread workgroups, 32 MCUs per tile
+                if (plan.all_sane) f420_main_kernel<true, 128><<<mgrid, dim3(128), shm, stream>>>(g, imgs);
+                else f420_main_kernel<false, 128><<<mgrid, dim3(128), shm, stream>>>(g, imgs);
+            } else {
+                if (plan.all_sane) f420_main_kernel<true, 256><<<mgrid, block, shm, stream>>>(g, imgs);
+                else f420_main_kernel<false, 256><<<mgrid, block, shm, stream>>>(g, imgs);
+            }
         }
         break;
     }

@@ -18,6 +18,7 @@ struct FusedPlan {
     jpgpu_image_desc desc{};  // the shared geometry
     FusedGeom geom{};
     size_t scratch_per_image = 0;
+    uint32_t chunk = 1;  // 4:2:0: images per (chroma pass, main pass) pair; they share the scratch area
     uint8_t *d_scratch = nullptr;
     FusedImage *d_images = nullptr;
     std::vector<FusedImage> images;

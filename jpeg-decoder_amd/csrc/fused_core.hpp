@@ -54,13 +54,23 @@ struct FusedImage {
     uint32_t _pad;
 };
 
-// 4:2:0 main pass, NT threads per workgroup: NT luma blocks (NT/4 MCUs) per tile
-template <uint32_t NT>
-struct alignas(16) F420Lds {
-    static constexpr uint32_t TX_MAX = NT / 4;
-    static constexpr uint32_t CPITCH = 8 * TX_MAX + 16;  // chroma LDS row: 8 halo + 8*TX + 8 halo
-    uint8_t coef[NT * 128];                              // coefficient staging, later the luma tile
-    uint8_t chroma[2 * 10 * CPITCH];
+// 4:2:0 main pass LDS, sized at launch from the tile width (dynamic shared memory):
+//   coef   : 4*tx luma blocks x 128 B of coefficient staging, later the 16-row luma tile
+//   chroma : 2 components x 10 rows x cpitch, cpitch = 8 halo + 8*tx + 8 halo bytes
+// 1080p (tx = 60): 40,640 B -> four workgroups per CU instead of three with a fixed-size struct.
+struct F420Lds {
+    uint8_t *coef;
+    uint8_t *chroma;
+    uint32_t cpitch;
+    static __device__ __host__ __forceinline__ uint32_t coef_bytes(uint32_t tx) { return 4u * tx * 128u; }
+    static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx) { return coef_bytes(tx) + 20u * (8u * tx + 16u); }
+    static __device__ __forceinline__ F420Lds make(uint8_t *base, uint32_t tx) {
+        F420Lds l;
+        l.coef = base;
+        l.chroma = base + coef_bytes(tx);
+        l.cpitch = 8u * tx + 16u;
+        return l;
+    }
 };
 struct alignas(16) FusedLdsSmall {          // kernels without a chroma neighbourhood
     uint8_t coef[FUSED_COEF_LDS];
@@ -146,11 +156,11 @@ __device__ __forceinline__ uint32_t swar_3a_b(uint32_t a, uint32_t b) { return (
 
 template <bool SANE, uint32_t NT>
 struct F420 {
-    typedef F420Lds<NT> Lds;
-    static constexpr uint32_t CPITCH = Lds::CPITCH;
+    typedef F420Lds Lds;
+    static constexpr uint32_t TX_MAX = NT / 4;
     static constexpr uint32_t NWAVES = NT / 64;
     static constexpr uint32_t CITEMS = 20 / NWAVES;  // (component,row) chroma items per wave
-    static constexpr bool HAS_CB = Lds::TX_MAX + 2 > 64;  // a chroma row has more than 64 8-B granules
+    static constexpr bool HAS_CB = TX_MAX + 2 > 64;  // a chroma row has more than 64 8-B granules
     // effective MCUs of tile `tile_x`
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.mcu_w - tile_x * g.tx);
@@ -159,7 +169,7 @@ struct F420 {
     // phase 0: stage luma coefficients (two block rows of the MCU row) and the chroma
     // neighbourhood [8*my-1, 8*my+8] x [8*x0-8, 8*(x0+txe)+8) of both chroma planes into LDS.
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, Lds &lds) {
+                                                  uint32_t tid, const Lds &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
         const uint32_t run8 = 2u * te * 8u;  // 16-B chunks per luma block row of the tile
         const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)img.coefs[0];
@@ -195,9 +205,9 @@ struct F420 {
         for (uint32_t i = 0; i < CITEMS; i++) {
             const uint32_t item = wave + NWAVES * i;
             if (rok[i]) {
-                if (okc0) *reinterpret_cast<v2u *>(&lds.chroma[item * CPITCH + 8u * lane]) = ca[i];
+                if (okc0) *reinterpret_cast<v2u *>(&lds.chroma[item * lds.cpitch + 8u * lane]) = ca[i];
                 if constexpr (HAS_CB)
-                    if (okc1) *reinterpret_cast<v2u *>(&lds.chroma[item * CPITCH + 8u * (lane + 64u)]) = cb[i];
+                    if (okc1) *reinterpret_cast<v2u *>(&lds.chroma[item * lds.cpitch + 8u * (lane + 64u)]) = cb[i];
             }
         }
     }
@@ -214,7 +224,7 @@ struct F420 {
 
     // phase 2: luma samples into the LDS tile (16 rows x 16*te bytes, pitch 16*tx), which
     // aliases the (now consumed) coefficient staging area
-    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, Lds &lds,
+    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, const Lds &lds,
                                                   const FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
         if (tid >= 4u * te) return;
@@ -359,8 +369,8 @@ struct F420 {
 #pragma unroll
                 for (uint32_t comp = 0; comp < 2; comp++) {
                     // a clamped row is never staged: substitute its partner (uniform per slot)
-                    eu[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * CPITCH + coff]);
-                    el[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * CPITCH + coff]);
+                    eu[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * lds.cpitch + coff]);
+                    el[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * lds.cpitch + coff]);
                 }
                 if (va) {
                     const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};

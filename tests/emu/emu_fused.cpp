@@ -43,8 +43,8 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             }
         }
     }
-    F420Lds<256>* lds = new F420Lds<256>;
-    F420Lds<128>* lds128 = new F420Lds<128>;
+    std::vector<uint8_t> lds420(F420Lds::total_bytes(g.tx ? g.tx : 1) + 64);
+    F420Lds ldsv = F420Lds::make(lds420.data(), g.tx), *lds = &ldsv, *lds128 = &ldsv;
     FusedLdsSmall* lds_s = new FusedLdsSmall;
     std::vector<FusedRegs> regs(FUSED_NT);
 #define RUN(NTH, BODY) for (uint32_t t = 0; t < NTH; t++) { BODY; }
@@ -53,8 +53,7 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
     RUN(NTH, (F420<S, NTH>::phase2(g, tile, t, *L, regs[t]))) RUN(NTH, (F420<S, NTH>::phase3(g, img, tile, my, t, *L)))
     for (uint32_t my = 0; my < g.mcu_h; my++)
         for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
-            memset(lds, 0xCD, sizeof(*lds));  // garbage, like real LDS
-            memset(lds128, 0xCD, sizeof(*lds128));
+            memset(lds420.data(), 0xCD, lds420.size());  // garbage, like real LDS
             memset(lds_s, 0xCD, sizeof(FusedLdsSmall));
             if (kind == FUSED_420) {
                 if (g.tx <= 32u) { if (sane) { RUN420(true, 128, lds128) } else { RUN420(false, 128, lds128) } }
@@ -74,8 +73,6 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
 #undef RUN
 #undef RUN420
     delete lds_s;
-    delete lds128;
-    delete lds;
     return kind;
 }
 }
