@@ -107,8 +107,11 @@ def main():
     qts = [lum, chr_, chr_][: len(sampling)]
     rgb = synth.synthetic_rgb(w, h)
     coefs = synth.coefficients_from_rgb(rgb, comps, mode, qts)
-    sane = all((np.abs(c.astype(np.int64)).reshape(-1, 64).max(axis=0) * q.astype(np.int64) < (1 << 15)).all()
-               for c, q in zip(coefs, qts))
+    # range class of the dequantized coefficients (what jpgpu_batch_upload computes when it stages data itself)
+    prod = [np.abs(c.astype(np.int64).reshape(-1, 8, 8) * q.astype(np.int64).reshape(8, 8)) for c, q in zip(coefs, qts)]
+    sane = 0
+    if all((p < (1 << 15)).all() for p in prod):
+        sane = 3 if all((p.sum(axis=1) <= 5900).all() for p in prod) else 1
 
     desc = J.image_desc(list(comps), qts, w, h, ct)
     flags = J._native.BATCH_EXTERNAL_BUFFERS | (J._native.BATCH_FORCE_GENERIC if args.generic else 0)
@@ -190,7 +193,7 @@ def main():
             "vs_baseline": None, "dtype": "i32 fixed-point (i16 coefficients -> u8 pixels)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} baseline {'x'.join(str(hh) + str(vv) for hh, vv in sampling)} "
                                    f"{ct}, batch of {n_img} images per GPU (coefficients resident in HBM -> RGB in HBM)",
-                       "name": args.workload, "images_per_gpu": n_img, "kernel_path": batch.path,
+                       "name": args.workload, "images_per_gpu": n_img, "kernel_path": batch.path, "range_class": sane,
                        "parallelism": f"images sharded {n_img}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),

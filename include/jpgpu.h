@@ -154,9 +154,13 @@ void *jpgpu_batch_out_arena(const jpgpu_batch *b);  /* device pointer */
  * jpgpu_batch_set_range_hint). Blocking. */
 int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int16_t *coefficients,
                        size_t len);
-/* For coefficients written straight into a bound arena: tell the backend whether every
- * |coefficient * q| stays below 2^15 for this image (sane != 0) so the 24-bit multiply path
- * is exact, or 0 to force the wrap-exact path. Default for never-uploaded images: 0. */
+/* For coefficients written straight into a bound arena: range class of this image's
+ * dequantized coefficients s = coefficient * q (what jpgpu_batch_upload computes itself):
+ *   0  unknown / hostile -> wrap-exact kernels (always correct);
+ *   1  every |s| < 2^15;
+ *   3  additionally, in every 8x8 block, each column's sum of |s| is <= 5900.
+ * Higher classes select faster arithmetic that is bit-exact only on such data.
+ * Default for never-uploaded images: 0. */
 int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane);
 
 /* Enqueue the whole batch on `hip_stream` (a hipStream_t; NULL = the null stream). */

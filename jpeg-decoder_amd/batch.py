@@ -79,8 +79,9 @@ class Batch:
         a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
         self._check(N.lib().jpgpu_batch_upload(self._h, image, comp, a.ctypes.data, a.size))
 
-    def set_range_hint(self, image, sane):
-        self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, 1 if sane else 0))
+    def set_range_hint(self, image, range_class):
+        """0 unknown/hostile, 1 every |c*q| < 2^15, 3 additionally every block-column sum of |c*q| <= 5900."""
+        self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, int(range_class)))
 
     def decode(self, stream=None):
         self._check(N.lib().jpgpu_batch_decode(self._h, stream))

@@ -70,7 +70,7 @@ static int batch_refresh_jobs(jpgpu_batch *b) {
             j.block_w = cc.block_width;
             j.n_blocks = (uint32_t)cc.block_width * cc.block_height;
             j.scale = cc.dct_scale;
-            j.flags = b->sane[i * 4 + c] ? 1u : 0u;
+            j.flags = b->sane[i * 4 + c];
             planes[c] = j.plane;
             b->plane_jobs.push_back(j);
         }
@@ -230,7 +230,7 @@ int jpgpu_batch_bind(jpgpu_batch *b, void *device_coef_arena, void *device_out_a
 
 int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane) {
     if (!b || image >= b->descs.size()) return JPGPU_ERR_FORMAT;
-    for (uint32_t c = 0; c < 4; c++) b->sane[image * 4 + c] = sane ? 1 : 0;
+    for (uint32_t c = 0; c < 4; c++) b->sane[image * 4 + c] = (uint8_t)(sane & 3);
     b->jobs_dirty = true;
     return JPGPU_OK;
 }
@@ -247,23 +247,25 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
     // range scan (part of H2D staging): per-position max |c| times q must stay below 2^15 for
     // the 24-bit multiply path to be exact (pixel_math.hpp idct8x8<SANE>)
-    uint8_t sane = 0;
+    uint8_t sane = 0;  // bit0: every |c*q| < 2^15; bit1: additionally every column sum of |c*q| <= 5900
     if (!(b->flags & JPGPU_BATCH_ASSUME_HOSTILE)) {
-        int32_t mx[64];
-        for (int k = 0; k < 64; k++) mx[k] = 0;
+        const uint16_t *q = b->descs[image].quantization_tables[comp];
+        int32_t qq[64];
+        for (int k = 0; k < 64; k++) qq[k] = q[k];
+        int32_t max_abs = 0, max_col = 0;
         const size_t nblk = len / 64;
         for (size_t blk = 0; blk < nblk; blk++) {
             const int16_t *p = coefficients + blk * 64;
+            int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int k = 0; k < 64; k++) {
-                int32_t v = p[k];
+                int32_t v = (int32_t)p[k] * qq[k];
                 v = v < 0 ? -v : v;
-                mx[k] = v > mx[k] ? v : mx[k];
+                max_abs = v > max_abs ? v : max_abs;
+                col[k & 7] += v;
             }
+            for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? col[i] : max_col;
         }
-        sane = 1;
-        const uint16_t *q = b->descs[image].quantization_tables[comp];
-        for (int k = 0; k < 64; k++)
-            if ((int64_t)mx[k] * q[k] >= (1 << 15)) sane = 0;
+        if (max_abs < (1 << 15)) sane = (max_col <= 5900) ? 3 : 1;
     }
     if (b->sane[image * 4 + comp] != sane) {
         b->sane[image * 4 + comp] = sane;

@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const Fus
     idct_planes_body<8>(job, blockIdx.x, lds);
 }
 
-template <bool SANE, uint32_t NT>
+template <int ARITH, uint32_t NT>
 __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
-    typedef F420<SANE, NT> K;
+    typedef F420<ARITH, NT> K;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const F420Lds lds = F420Lds::make(lds_raw, g.tx);
     const FusedImage img = imgs[blockIdx.z];
@@ -46,27 +46,27 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedG
     K::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-template <bool SANE>
+template <int ARITH>
 __global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLdsSmall lds;
     const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
-    F444<SANE>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F444<ARITH>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    F444<SANE>::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    F444<ARITH>::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F444<SANE>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    F444<ARITH>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
-    F444<SANE>::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F444<ARITH>::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-template <bool SANE>
+template <int ARITH>
 __global__ __launch_bounds__(256) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLdsSmall lds;
     const FusedImage img = imgs[blockIdx.z];
-    FGray<SANE>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    FGray<ARITH>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    FGray<SANE>::phase1(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    FGray<ARITH>::phase1(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -106,6 +106,11 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
         uint32_t chunk = ce ? (uint32_t)atoi(ce) : 0u;
         if (chunk == 0u) chunk = plan.n_images;  // measured on MI355X: chunking (16..128 images) is slower than one pass over the batch
         plan.chunk = std::max(1u, std::min(chunk, plan.n_images));
+        const char *se = getenv("JPGPU_STREAMS");
+        plan.n_streams = se ? (uint32_t)std::max(1, std::min(4, atoi(se))) : 1u;
+        if (plan.kind != FUSED_420) plan.n_streams = 1;
+        // scratch slots are shared modulo `chunk`: chunks in flight on different streams need their own
+        if (plan.n_streams > 1 && !ce) plan.chunk = std::max(1u, (plan.n_images + 2u * plan.n_streams - 1u) / (2u * plan.n_streams));
     }
     plan.images.assign(plan.n_images, FusedImage{});
     return true;
@@ -115,31 +120,43 @@ int fused_alloc(FusedPlan &plan, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
     hipError_t e;
     if (plan.scratch_per_image) {
-        e = hipMalloc((void **)&plan.d_scratch, plan.scratch_per_image * plan.chunk);
+        plan.scratch_slots = std::min(plan.n_images, plan.chunk * plan.n_streams);
+        e = hipMalloc((void **)&plan.d_scratch, plan.scratch_per_image * plan.scratch_slots);
         if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(scratch): %s", hipGetErrorString(e));
     }
     e = hipMalloc((void **)&plan.d_images, sizeof(FusedImage) * plan.n_images);
     if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(images): %s", hipGetErrorString(e));
+    if (plan.n_streams > 1) {
+        e = hipEventCreateWithFlags(&plan.ev_fork, hipEventDisableTiming);
+        for (uint32_t k = 0; k < plan.n_streams && e == hipSuccess; k++) {
+            e = hipStreamCreateWithFlags(&plan.streams[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&plan.ev_join[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "stream setup: %s", hipGetErrorString(e));
+    }
     return JPGPU_OK;
 }
 
 int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt, const std::vector<size_t> &coef_off,
                const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
-    plan.all_sane = true;
+    uint32_t common = 3u;  // AND of the per-image flags: one hostile image sends the whole batch down the wrap-exact kernels
     for (uint32_t i = 0; i < plan.n_images; i++) {
         FusedImage &im = plan.images[i];
-        bool all_sane = true;
+        uint32_t fl = 3u;
         for (uint32_t c = 0; c < plan.desc.ncomp; c++) {
             im.coefs[c] = reinterpret_cast<const int16_t *>(d_coef + coef_off[i * 4 + c]);
             im.qt[c] = d_qt + ((size_t)i * 4 + c) * 64;
-            all_sane = all_sane && sane[i * 4 + c];
+            fl &= sane[i * 4 + c];
         }
         im.out = d_out + out_off[i];
-        im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)(i % plan.chunk) * plan.scratch_per_image : nullptr;
-        im.flags = all_sane ? 1u : 0u;
-        plan.all_sane = plan.all_sane && all_sane;  // one hostile image sends the whole batch down the wrap-exact kernels
+        im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)(i % plan.scratch_slots) * plan.scratch_per_image : nullptr;
+        if (!(fl & 1u)) fl = 0u;  // tight implies sane
+        im.flags = fl;
+        common &= fl;
     }
+    plan.arith = (common & 2u) ? ARITH_TIGHT : ((common & 1u) ? ARITH_SANE : ARITH_EXACT);
+    if (const char *ae = getenv("JPGPU_ARITH")) plan.arith = std::min(plan.arith, atoi(ae));  // tuning/testing knob: cap the variant
     hipError_t e = hipMemcpy(plan.d_images, plan.images.data(), sizeof(FusedImage) * plan.n_images, hipMemcpyHostToDevice);
     if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMemcpy(images): %s", hipGetErrorString(e));
     return JPGPU_OK;
@@ -156,29 +173,53 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
         // 256 MiB Infinity Cache did not pay on MI355X (profiles/round1: 16/32/64/128-image chunks
         // were 23/9/4/1 % slower than the whole 256-image batch).
         const uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
-        for (uint32_t first = 0; first < plan.n_images; first += plan.chunk) {
+        const size_t shm = F420Lds::total_bytes(g.tx);
+        // The chroma pass is HBM-bound and the main pass VALU-bound (profiles/round1), so with
+        // JPGPU_STREAMS=2 the chunks alternate between two internal streams: the chroma pass of one
+        // chunk can share the machine with the main pass of another.  Forked from / joined to the
+        // caller's stream with events, so ordering on that stream is unchanged.
+        const uint32_t ns = plan.n_streams;
+        if (ns > 1) {
+            hipError_t e = hipEventRecord(plan.ev_fork, stream);
+            if (e != hipSuccess) return e;
+            for (uint32_t k = 0; k < ns; k++)
+                if ((e = hipStreamWaitEvent(plan.streams[k], plan.ev_fork, 0)) != hipSuccess) return e;
+        }
+        uint32_t ci = 0;
+        for (uint32_t first = 0; first < plan.n_images; first += plan.chunk, ci++) {
             const uint32_t n = std::min(plan.chunk, plan.n_images - first);
             const FusedImage *imgs = plan.d_images + first;
+            hipStream_t st = ns > 1 ? plan.streams[ci % ns] : stream;
             dim3 cgrid((nblk + 255u) / 256u, 2, n), mgrid(g.tiles_x, g.mcu_h, n);
-            const size_t shm = F420Lds::total_bytes(g.tx);
-            f420_chroma_kernel<<<cgrid, block, 0, stream>>>(g, imgs, nblk);
+            f420_chroma_kernel<<<cgrid, block, 0, st>>>(g, imgs, nblk);
+            const int ar = plan.arith;
             if (g.tx <= 32u) {  // 128-thread workgroups, 32 MCUs per tile
-                if (plan.all_sane) f420_main_kernel<true, 128><<<mgrid, dim3(128), shm, stream>>>(g, imgs);
-                else f420_main_kernel<false, 128><<<mgrid, dim3(128), shm, stream>>>(g, imgs);
+                if (ar == ARITH_TIGHT) f420_main_kernel<ARITH_TIGHT, 128><<<mgrid, dim3(128), shm, st>>>(g, imgs);
+                else if (ar == ARITH_SANE) f420_main_kernel<ARITH_SANE, 128><<<mgrid, dim3(128), shm, st>>>(g, imgs);
+                else f420_main_kernel<ARITH_EXACT, 128><<<mgrid, dim3(128), shm, st>>>(g, imgs);
             } else {
-                if (plan.all_sane) f420_main_kernel<true, 256><<<mgrid, block, shm, stream>>>(g, imgs);
-                else f420_main_kernel<false, 256><<<mgrid, block, shm, stream>>>(g, imgs);
+                if (ar == ARITH_TIGHT) f420_main_kernel<ARITH_TIGHT, 256><<<mgrid, block, shm, st>>>(g, imgs);
+                else if (ar == ARITH_SANE) f420_main_kernel<ARITH_SANE, 256><<<mgrid, block, shm, st>>>(g, imgs);
+                else f420_main_kernel<ARITH_EXACT, 256><<<mgrid, block, shm, st>>>(g, imgs);
             }
         }
+        if (ns > 1)
+            for (uint32_t k = 0; k < ns; k++) {
+                hipError_t e = hipEventRecord(plan.ev_join[k], plan.streams[k]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(stream, plan.ev_join[k], 0);
+                if (e != hipSuccess) return e;
+            }
         break;
     }
     case FUSED_444:
-        if (plan.all_sane) f444_kernel<true><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else f444_kernel<false><<<grid, block, 0, stream>>>(g, plan.d_images);
+        if (plan.arith == ARITH_TIGHT) f444_kernel<ARITH_TIGHT><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else if (plan.arith == ARITH_SANE) f444_kernel<ARITH_SANE><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else f444_kernel<ARITH_EXACT><<<grid, block, 0, stream>>>(g, plan.d_images);
         break;
     case FUSED_GRAY:
-        if (plan.all_sane) fgray_kernel<true><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else fgray_kernel<false><<<grid, block, 0, stream>>>(g, plan.d_images);
+        if (plan.arith == ARITH_TIGHT) fgray_kernel<ARITH_TIGHT><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else if (plan.arith == ARITH_SANE) fgray_kernel<ARITH_SANE><<<grid, block, 0, stream>>>(g, plan.d_images);
+        else fgray_kernel<ARITH_EXACT><<<grid, block, 0, stream>>>(g, plan.d_images);
         break;
     default: return hipErrorInvalidValue;
     }
@@ -188,6 +229,14 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
 void fused_free(FusedPlan &plan) {
     if (plan.d_scratch) (void)hipFree(plan.d_scratch);
     if (plan.d_images) (void)hipFree(plan.d_images);
+    for (uint32_t k = 0; k < 4; k++) {
+        if (plan.streams[k]) (void)hipStreamDestroy(plan.streams[k]);
+        if (plan.ev_join[k]) (void)hipEventDestroy(plan.ev_join[k]);
+        plan.streams[k] = nullptr;
+        plan.ev_join[k] = nullptr;
+    }
+    if (plan.ev_fork) (void)hipEventDestroy(plan.ev_fork);
+    plan.ev_fork = nullptr;
     plan.d_scratch = nullptr;
     plan.d_images = nullptr;
 }

@@ -18,11 +18,15 @@ struct FusedPlan {
     jpgpu_image_desc desc{};  // the shared geometry
     FusedGeom geom{};
     size_t scratch_per_image = 0;
-    uint32_t chunk = 1;  // 4:2:0: images per (chroma pass, main pass) pair; they share the scratch area
+    uint32_t chunk = 1;  // 4:2:0: images per (chroma pass, main pass) pair
+    uint32_t scratch_slots = 1;
+    uint32_t n_streams = 1;
+    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_scratch = nullptr;
     FusedImage *d_images = nullptr;
     std::vector<FusedImage> images;
-    bool all_sane = false;
+    int arith = 0;  // ARITH_* variant every image of the batch qualifies for
 };
 
 bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std::string &why);

@@ -50,7 +50,7 @@ struct FusedImage {
     const uint16_t *qt[4];
     uint8_t *out;
     uint8_t *scratch;  // 4:2:0: Cb plane followed by Cr plane
-    uint32_t flags;    // bit0: every component "sane" (|c*q| < 2^15) -> 24-bit multiply path
+    uint32_t flags;    // bit0: every component "sane" (|c*q| < 2^15), bit1: "tight" (column sums <= 5900) — pixel_math.hpp
     uint32_t _pad;
 };
 
@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t swar_even(uint32_t d) { return d & 0x00ff00f
 __device__ __forceinline__ uint32_t swar_odd(uint32_t d) { return (d >> 8) & 0x00ff00ffu; }    // bytes 1,3
 __device__ __forceinline__ uint32_t swar_3a_b(uint32_t a, uint32_t b) { return (a << 1) + a + b; }
 
-template <bool SANE, uint32_t NT>
+template <int ARITH, uint32_t NT>
 struct F420 {
     typedef F420Lds Lds;
     static constexpr uint32_t TX_MAX = NT / 4;
@@ -219,7 +219,7 @@ struct F420 {
         if (tid >= 4u * te) return;
         uint32_t cw[32];
         load_block_from_lds(lds.coef, tid, cw);
-        idct8x8<SANE>(cw, as_qtab(img.qt[0]), r.out);
+        idct8x8<ARITH>(cw, as_qtab(img.qt[0]), r.out);
     }
 
     // phase 2: luma samples into the LDS tile (16 rows x 16*te bytes, pitch 16*tx), which
@@ -392,7 +392,7 @@ struct F420 {
 // quantization table stays wave-uniform in SGPRs), lane = block; wave 3 only helps staging and
 // the pixel phase.
 // =============================================================================================
-template <bool SANE>
+template <int ARITH>
 struct F444 {
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.mcu_w - tile_x * g.tx);
@@ -431,7 +431,7 @@ struct F444 {
         load_block_from_lds(lds.coef, comp * 64u + cx, cw);
         // (no img.qt[comp]: a runtime index into the by-value image struct would put it in scratch)
         const uint16_t *qt = comp == 0u ? img.qt[0] : (comp == 1u ? img.qt[1] : img.qt[2]);
-        idct8x8<SANE>(cw, as_qtab(qt), r.out);
+        idct8x8<ARITH>(cw, as_qtab(qt), r.out);
     }
     // sample tiles: [3 comps][8 rows][pitch 8*tx]
     static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLdsSmall &lds,
@@ -499,7 +499,7 @@ struct F444 {
 // =============================================================================================
 // FUSED_GRAY: one block per lane, straight to the output rows
 // =============================================================================================
-template <bool SANE>
+template <int ARITH>
 struct FGray {
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.bw0 - tile_x * g.tx);
@@ -516,7 +516,7 @@ struct FGray {
         if (tid >= te) return;
         uint32_t cw[32], out[16];
         load_block_from_lds(lds.coef, tid, cw);
-        idct8x8<SANE>(cw, as_qtab(img.qt[0]), out);
+        idct8x8<ARITH>(cw, as_qtab(img.qt[0]), out);
         const uint32_t ox = 8u * (x0 + tid);
         if (ox >= g.out_w) return;
         const uint32_t n = min(8u, g.out_w - ox);

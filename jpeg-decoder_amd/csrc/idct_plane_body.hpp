@@ -48,8 +48,9 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
     JP_GLOBAL uint8_t *dst = (JP_GLOBAL uint8_t *)job.plane + (size_t)by * SCALE * stride + (size_t)bx * SCALE;
     if constexpr (SCALE == 8) {
         uint32_t out[16];
-        if (job.flags & 1u) idct8x8<true>(cw, as_qtab(job.qt), out);  // uniform: one job per workgroup
-        else idct8x8<false>(cw, as_qtab(job.qt), out);
+        if (job.flags & 2u) idct8x8<ARITH_TIGHT>(cw, as_qtab(job.qt), out);  // uniform: one job per workgroup
+        else if (job.flags & 1u) idct8x8<ARITH_SANE>(cw, as_qtab(job.qt), out);
+        else idct8x8<ARITH_EXACT>(cw, as_qtab(job.qt), out);
 #pragma unroll
         for (int r = 0; r < 8; r++)
             *reinterpret_cast<JP_GLOBAL v2u *>(dst + (size_t)r * stride) = v2u{out[2 * r], out[2 * r + 1]};

@@ -281,27 +281,19 @@ __device__ __forceinline__ void idct_pass8_dot2(uint32_t p02, uint32_t p46, uint
     o[4] = x3 - u0;
 }
 
-template <bool SANE>
+// Arithmetic variants of the 8x8 IDCT (all bit-exact with the reference on the inputs they accept):
+enum : int {
+    ARITH_EXACT = 0,  // any input: 32-bit wrapping multiplies + the per-column DC short-cut select
+    ARITH_SANE = 1,   // every |c*q| < 2^15: packed 16-bit dequantization, dot2 column pass, 24-bit row pass
+    ARITH_TIGHT = 2,  // additionally every column of every block has sum_k |c*q| <= 5900, so the column-pass
+                      // outputs (<= (5683*5900 + 512) >> 10 < 2^15) fit i16 and the row pass runs on dot2 too
+};
+
+template <int ARITH>
 __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint32_t (&out)[16]) {
-    w32 t[64];
-    if constexpr (SANE) {
-        // |c*q| < 2^15: the products fit i16, so the dequantization is a packed 16-bit multiply
-        // (two coefficients per instruction) and the column pass runs on dot2.
-        uint32_t d[32];  // d[k*4+j] = (s[k][2j], s[k][2j+1])
-#pragma unroll
-        for (int i = 0; i < 32; i++) d[i] = pk_mul_lo_u16(cw[i], q[i]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int j = i >> 1;
-            const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
-            const uint32_t p02 = perm_b32(d[2 * 4 + j], d[0 * 4 + j], sel), p46 = perm_b32(d[6 * 4 + j], d[4 * 4 + j], sel);
-            const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
-            w32 o[8];
-            idct_pass8_dot2(p02, p46, p13, p57, 512u, o);
-#pragma unroll
-            for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
-        }
-    } else {
+    const w32 X_SCALE = 65536u + (128u << 17);
+    if constexpr (ARITH == ARITH_EXACT) {
+        w32 t[64];
         // dequantize first (row by row, so the packed coefficients and the table die early and the
         // 64 products are the only long-lived values), then the column pass in place
         uint32_t acbits[4] = {0u, 0u, 0u, 0u};  // OR of the packed raw coefficients of rows 1..7
@@ -327,16 +319,50 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint
 #pragma unroll
             for (int k = 0; k < 8; k++) t[k * 8 + i] = dc_only ? dcterm : sar(o[k], 10);
         }
-    }
-    const w32 X_SCALE = 65536u + (128u << 17);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        w32 s[8], o[8];
+        for (int r = 0; r < 8; r++) {
+            w32 s[8], o[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
-        idct_pass8<SANE>(s, X_SCALE, o);
-        out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
-        out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
+            for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
+            idct_pass8<false>(s, X_SCALE, o);
+            out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
+            out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
+        }
+    } else {
+        // |c*q| < 2^15: the products fit i16, so the dequantization is a packed 16-bit multiply
+        // (two coefficients per instruction) and the column pass runs on dot2.
+        uint32_t d[32];  // d[k*4+j] = (s[k][2j], s[k][2j+1])
+#pragma unroll
+        for (int i = 0; i < 32; i++) d[i] = pk_mul_lo_u16(cw[i], q[i]);
+        w32 t[64];  // t[k*8+i] = column-pass output (row k, column i)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int j = i >> 1;
+            const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
+            const uint32_t p02 = perm_b32(d[2 * 4 + j], d[0 * 4 + j], sel), p46 = perm_b32(d[6 * 4 + j], d[4 * 4 + j], sel);
+            const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
+            w32 o[8];
+            idct_pass8_dot2(p02, p46, p13, p57, 512u, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            w32 o[8];
+            if constexpr (ARITH == ARITH_TIGHT) {
+                // the row's eight values fit i16: pair them (0,2) (4,6) (1,3) (5,7) and use dot2 again
+                const uint32_t lo16 = 0x05040100u;
+                idct_pass8_dot2(perm_b32(t[r * 8 + 2], t[r * 8 + 0], lo16), perm_b32(t[r * 8 + 6], t[r * 8 + 4], lo16),
+                                perm_b32(t[r * 8 + 3], t[r * 8 + 1], lo16), perm_b32(t[r * 8 + 7], t[r * 8 + 5], lo16), X_SCALE, o);
+            } else {
+                w32 s[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
+                idct_pass8<true>(s, X_SCALE, o);
+            }
+            out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
+            out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
+        }
     }
 }
 

@@ -24,7 +24,7 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         img.qt[c] = desc->quantization_tables[c];
     }
     img.out = out;
-    img.flags = sane ? 1u : 0u;
+    img.flags = sane == 2 ? 3u : (sane ? 1u : 0u);
     std::vector<uint8_t> scratch;
     if (kind == FUSED_420) {
         scratch.assign(2 * (size_t)g.chroma_plane_bytes, 0xAB);
@@ -36,8 +36,9 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             for (uint32_t b = 0; b < nblk; b++) {
                 uint32_t cw[32], o[16];
                 memcpy(cw, coefs[1 + comp] + (size_t)b * 64, 128);
-                if (sane) idct8x8<true>(cw, as_qtab(img.qt[1 + comp]), o);
-                else idct8x8<false>(cw, as_qtab(img.qt[1 + comp]), o);
+                if (sane == 2) idct8x8<ARITH_TIGHT>(cw, as_qtab(img.qt[1 + comp]), o);
+                else if (sane) idct8x8<ARITH_SANE>(cw, as_qtab(img.qt[1 + comp]), o);
+                else idct8x8<ARITH_EXACT>(cw, as_qtab(img.qt[1 + comp]), o);
                 uint32_t bx = b % g.bwc, by = b / g.bwc;
                 for (int r = 0; r < 8; r++) memcpy(plane + (size_t)(by * 8 + r) * stride + bx * 8, &o[2 * r], 8);
             }
@@ -56,18 +57,23 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             memset(lds420.data(), 0xCD, lds420.size());  // garbage, like real LDS
             memset(lds_s, 0xCD, sizeof(FusedLdsSmall));
             if (kind == FUSED_420) {
-                if (g.tx <= 32u) { if (sane) { RUN420(true, 128, lds128) } else { RUN420(false, 128, lds128) } }
-                else { if (sane) { RUN420(true, 256, lds) } else { RUN420(false, 256, lds) } }
+                if (g.tx <= 32u) { if (sane == 2) { RUN420(ARITH_TIGHT, 128, lds128) } else if (sane) { RUN420(ARITH_SANE, 128, lds128) } else { RUN420(ARITH_EXACT, 128, lds128) } }
+                else { if (sane == 2) { RUN420(ARITH_TIGHT, 256, lds) } else if (sane) { RUN420(ARITH_SANE, 256, lds) } else { RUN420(ARITH_EXACT, 256, lds) } }
+            } else if (kind == FUSED_444 && sane == 2) {
+                RUN(256, F444<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_TIGHT>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_TIGHT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_TIGHT>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444 && sane) {
-                RUN(256, F444<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<true>::phase1(g, img, tile, t, *lds_s, regs[t]))
-                RUN(256, F444<true>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<true>::phase3(g, img, tile, my, t, *lds_s))
+                RUN(256, F444<ARITH_SANE>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_SANE>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_SANE>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_SANE>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444) {
-                RUN(256, F444<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<false>::phase1(g, img, tile, t, *lds_s, regs[t]))
-                RUN(256, F444<false>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<false>::phase3(g, img, tile, my, t, *lds_s))
+                RUN(256, F444<ARITH_EXACT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_EXACT>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_EXACT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_EXACT>::phase3(g, img, tile, my, t, *lds_s))
+            } else if (sane == 2) {
+                RUN(256, FGray<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<ARITH_TIGHT>::phase1(g, img, tile, my, t, *lds_s))
             } else if (sane) {
-                RUN(256, FGray<true>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<true>::phase1(g, img, tile, my, t, *lds_s))
+                RUN(256, FGray<ARITH_SANE>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<ARITH_SANE>::phase1(g, img, tile, my, t, *lds_s))
             } else {
-                RUN(256, FGray<false>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<false>::phase1(g, img, tile, my, t, *lds_s))
+                RUN(256, FGray<ARITH_EXACT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<ARITH_EXACT>::phase1(g, img, tile, my, t, *lds_s))
             }
         }
 #undef RUN

@@ -6,7 +6,7 @@ void emu_idct8x8(int sane, const int16_t* c, const uint16_t* q, uint8_t* out, in
     for (int b = 0; b < nblocks; b++) {
         uint32_t cw[32]; memcpy(cw, c + b * 64, 128);
         uint32_t o[16];
-        if (sane) jpgpu::idct8x8<true>(cw, jpgpu::as_qtab(q), o); else jpgpu::idct8x8<false>(cw, jpgpu::as_qtab(q), o);
+        if (sane == 2) jpgpu::idct8x8<jpgpu::ARITH_TIGHT>(cw, jpgpu::as_qtab(q), o); else if (sane) jpgpu::idct8x8<jpgpu::ARITH_SANE>(cw, jpgpu::as_qtab(q), o); else jpgpu::idct8x8<jpgpu::ARITH_EXACT>(cw, jpgpu::as_qtab(q), o);
         memcpy(out + b * 64, o, 64);
     }
 }

@@ -99,3 +99,19 @@ def adversarial_blocks(rng, n_random=256):
         c = np.zeros(64, np.int16); c[pos] = 32767; c[0] = -32768
         blocks.append(c); qts.append(np.full(64, 65535, np.uint16))
     return blocks, qts
+
+
+def tight_blocks(rng, n, q):
+    """Blocks at the edge of the TIGHT class: every column's sum of |c*q| is (nearly) as large as allowed
+    (5900), spread over a random subset of the column's rows; one block in eight puts it all on one row."""
+    qm = q.astype(np.int64).reshape(1, 8, 8)
+    w = rng.random((n, 8, 8)) * (rng.random((n, 8, 8)) < 0.6)
+    one = rng.integers(0, 8, (n, 1, 8))
+    single = (np.arange(8).reshape(1, 8, 1) == one) & (rng.random((n, 1, 1)) < 0.125)
+    w = np.where(single.any(axis=1, keepdims=True), single.astype(np.float64), w)
+    tot = w.sum(axis=1, keepdims=True)
+    tot[tot == 0] = 1.0
+    mag = np.floor(w / tot * 5900.0 / qm).astype(np.int64)
+    c = mag * rng.choice([-1, 1], (n, 8, 8))
+    assert (np.abs(c * qm).sum(axis=1) <= 5900).all() and (np.abs(c * qm) < (1 << 15)).all()
+    return c.astype(np.int16).reshape(-1)

@@ -59,6 +59,30 @@ def test_device_idct_sane_path_exact_up_to_its_bound():
         assert np.array_equal(out, _orc_blocks(c, q)), trial
 
 
+def test_device_idct_tight_path_exact_up_to_its_bound():
+    """dot2 row pass: exact whenever each column's sum of |c*q| <= 5900 (column outputs then fit i16)."""
+    rng = np.random.default_rng(7)
+    n = 1500
+    for trial in range(4):
+        q = rng.integers(1, 64, 64).astype(np.uint16) if trial % 2 else np.ones(64, np.uint16)
+        c = synth.tight_blocks(rng, n, q)
+        out = np.zeros(n * 64, np.uint8)
+        emu.lib().emu_idct8x8(2, c.ctypes.data, q.ctypes.data, out.ctypes.data, n)
+        assert np.array_equal(out, _orc_blocks(c, q)), trial
+    # worst case for the i16 claim: the whole budget on the coefficient with the largest gain
+    for row in range(8):
+        c = np.zeros((4, 8, 8), np.int16)
+        c[0, row, :] = 5900
+        c[1, row, :] = -5900
+        c[2, row, ::2] = 5900
+        c[3, row, 1::2] = -5900
+        c = c.reshape(-1)
+        q = np.ones(64, np.uint16)
+        out = np.zeros(4 * 64, np.uint8)
+        emu.lib().emu_idct8x8(2, c.ctypes.data, q.ctypes.data, out.ctypes.data, 4)
+        assert np.array_equal(out, _orc_blocks(c, q)), row
+
+
 @pytest.mark.parametrize("scale", [4, 2, 1])
 def test_device_reduced_idct(scale):
     rng = np.random.default_rng(scale)
@@ -100,7 +124,7 @@ def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64):
     out_len = w_ * h_ * (1 if n == 1 else 3)
     out = np.full(out_len + 64, 0x5A, np.uint8)  # guard band: the kernels must not write past the image
     tx = C.c_uint32(0)
-    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, 1 if sane else 0, out.ctypes.data, C.byref(tx), f420_tx)
+    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, int(sane), out.ctypes.data, C.byref(tx), f420_tx)
     assert (out[out_len:] == 0x5A).all(), "emulated kernel wrote past the output"
     return kind, out[:out_len], tx.value
 
@@ -119,7 +143,7 @@ GEOMS = [
 
 
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
-@pytest.mark.parametrize("kind", ["sane", "hostile"])
+@pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
 @pytest.mark.parametrize("f420_tx", [64, 32])
 def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     if f420_tx == 32 and not (len(geom[2]) == 3 and geom[2][0] == (2, 2)):
@@ -131,10 +155,13 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
         qts = [rng.integers(1, 64, 64).astype(np.uint16) for _ in ocomps]
         coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h, amp=64, dc_amp=500) for c in ocomps]
         assert all((np.abs(c.astype(np.int64)).reshape(-1, 64) * q < (1 << 15)).all() for c, q in zip(coefs, qts))
+    elif kind == "tight":
+        qts = [rng.integers(1, 32, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [synth.tight_blocks(rng, c.block_w * c.block_h, q) for c, q in zip(ocomps, qts)]
     else:
         qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
         coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
-    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, kind == "sane", f420_tx)
+    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, {"hostile": 0, "sane": 1, "tight": 2}[kind], f420_tx)
     assert got_kind != 0, "planner refused a geometry the fused kernels are meant to cover"
     want = O.pixels_from_coefficients(ocomps, qts, coefs, w_, h_, ct.upper())
     assert got.size == want.size

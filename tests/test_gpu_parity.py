@@ -225,6 +225,12 @@ def _batch_case(rng, w_, h_, samp, ct, kind="sparse"):
     qts = [rng.integers(1, 200, 64).astype(np.uint16) for _ in ocomps]
     if kind == "sparse":
         coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h) for c in ocomps]
+    elif kind == "tight":  # every column sum of |c*q| at the 5900 limit of the dot2 row pass
+        qts = [rng.integers(1, 32, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [synth.tight_blocks(rng, c.block_w * c.block_h, q) for c, q in zip(ocomps, qts)]
+    elif kind == "sane":  # |c*q| < 2^15 but column sums far above the tight limit
+        qts = [rng.integers(1, 16, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [(rng.integers(-2000, 2001, c.block_w * c.block_h * 64)).astype(np.int16) for c in ocomps]
     else:
         coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
         qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
@@ -275,7 +281,7 @@ SAME_GEOMETRY = [
 
 
 @pytest.mark.parametrize("case", SAME_GEOMETRY, ids=lambda c: f"{c[0]}x{c[1]}-{len(c[2])}c-{c[2][0][0]}{c[2][0][1]}")
-@pytest.mark.parametrize("kind", ["sparse", "full"])
+@pytest.mark.parametrize("kind", ["sparse", "tight", "sane", "full"])
 def test_batch_same_geometry_fast_path_bit_exact(case, kind):
     """Same-geometry batches resolve to the fused kernels; results must equal the oracle and the
     generic path byte for byte, for sane (24-bit multiply path) and hostile (wrap-exact) data."""
