@@ -46,6 +46,43 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedG
     K::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
+// 4:2:0 in one launch: grid = (strips, row segments, images); see S420 in fused_core.hpp
+template <int ARITH>
+__global__ __launch_bounds__(256, 4) void s420_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    typedef S420<ARITH> K;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const S420Lds lds = S420Lds::make(lds_raw, g.tx);
+    const FusedImage img = imgs[blockIdx.z];
+    const uint32_t strip = blockIdx.x, tid = threadIdx.x;
+    const uint32_t k0 = blockIdx.y * g.seg_rows, k1 = min(k0 + g.seg_rows, g.mcu_h);
+    S420Regs r;
+    K::init(img, tid, lds);
+    if (k0 > 0) {  // carry rows of the MCU row above this segment
+        K::stage(g, img, strip, k0 - 1, tid, lds);
+        __syncthreads();
+        K::read_block(g, strip, tid, lds, r);
+        K::transform(g, strip, k0 - 1, tid, lds, r, true);
+        __syncthreads();
+    }
+    for (uint32_t k = k0; k < k1; k++) {
+        // A fresh, opaque copy of the lane id per phase: otherwise every per-lane address of every phase is hoisted
+        // out of the loop and kept live across it (~100 VGPRs), which spills the coefficient block at 4 waves/SIMD.
+        uint32_t t0 = tid, t1 = tid, t2 = tid;
+        asm volatile("" : "+v"(t0));
+        K::stage(g, img, strip, k, t0, lds);
+        __syncthreads();
+        asm volatile("" : "+v"(t1));
+        K::read_block(g, strip, t1, lds, r);
+        __syncthreads();  // the tiles alias the staging area
+        K::transform(g, strip, k, t1, lds, r, false);
+        __syncthreads();
+        asm volatile("" : "+v"(t2));
+        K::colour(g, img, strip, k, t2, lds);
+        __syncthreads();
+    }
+    if (k1 == g.mcu_h) K::colour(g, img, strip, g.mcu_h, tid, lds);  // the image's last row (far chroma row clamped onto the near one)
+}
+
 template <int ARITH>
 __global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
     __shared__ FusedLdsSmall lds;
@@ -89,17 +126,26 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
     const char *name = "", *w = "";
     // JPGPU_F420_TX=32 selects the 128-thread / 32-MCU tiling of the 4:2:0 main pass (tuning knob)
     const char *txenv = getenv("JPGPU_F420_TX");
-    int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 64u);
+    // JPGPU_420_TWOPASS=1 selects the chroma-pass + main-pass form of the 4:2:0 path, JPGPU_S420_TX / _SEG the
+    // strip width and rows per workgroup of the single-launch form (A/B knobs)
+    const char *tp = getenv("JPGPU_420_TWOPASS");
+    const bool strip420 = !(tp && atoi(tp) != 0);
+    const char *stx = getenv("JPGPU_S420_TX");
+    int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 64u, strip420, stx ? (uint32_t)atoi(stx) : S420_TX_MAX);
     if (kind == FUSED_NONE) {
         why = w;
         return false;
+    }
+    if (kind == FUSED_420 && g.strip) {
+        const char *sr = getenv("JPGPU_S420_SEG");
+        s420_set_segments(g, (uint32_t)descs.size(), sr ? (uint32_t)atoi(sr) : 0u);
     }
     plan.kind = kind;
     plan.name = name;
     plan.geom = g;
     plan.desc = d0;
     plan.n_images = (uint32_t)descs.size();
-    plan.scratch_per_image = plan.kind == FUSED_420 ? align_up(2 * (size_t)g.chroma_plane_bytes, 256) : 0;
+    plan.scratch_per_image = plan.kind == FUSED_420 && !g.strip ? align_up(2 * (size_t)g.chroma_plane_bytes, 256) : 0;
     // images per chunk of the 4:2:0 path: chroma planes of a chunk <= 64 MiB (JPGPU_CHUNK overrides)
     {
         const char *ce = getenv("JPGPU_CHUNK");
@@ -108,7 +154,7 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
         plan.chunk = std::max(1u, std::min(chunk, plan.n_images));
         const char *se = getenv("JPGPU_STREAMS");
         plan.n_streams = se ? (uint32_t)std::max(1, std::min(4, atoi(se))) : 1u;
-        if (plan.kind != FUSED_420) plan.n_streams = 1;
+        if (plan.kind != FUSED_420 || g.strip) plan.n_streams = 1;
         // scratch slots are shared modulo `chunk`: chunks in flight on different streams need their own
         if (plan.n_streams > 1 && !ce) plan.chunk = std::max(1u, (plan.n_images + 2u * plan.n_streams - 1u) / (2u * plan.n_streams));
     }
@@ -168,6 +214,14 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
     dim3 grid(g.tiles_x, g.mcu_h, plan.n_images);
     switch (plan.kind) {
     case FUSED_420: {
+        if (g.strip) {
+            const size_t shm = S420Lds::total_bytes(g.tx);
+            dim3 sgrid(g.tiles_x, g.n_seg, plan.n_images);
+            if (plan.arith == ARITH_TIGHT) s420_kernel<ARITH_TIGHT><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+            else if (plan.arith == ARITH_SANE) s420_kernel<ARITH_SANE><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+            else s420_kernel<ARITH_EXACT><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+            break;
+        }
         // The batch may be walked in chunks of `chunk` images (chroma pass, then main pass) sharing one
         // scratch area (JPGPU_CHUNK).  Default: one chunk — keeping a chunk's chroma planes within the
         // 256 MiB Infinity Cache did not pay on MI355X (profiles/round1: 16/32/64/128-image chunks

@@ -43,6 +43,9 @@ struct FusedGeom {
     uint32_t cw, ch;   // chroma component size (420)
     uint32_t color;    // FCOLOR_* (444)
     uint32_t chroma_plane_bytes;  // 420 scratch: bytes of one chroma plane (bwc*8 * bhc*8)
+    uint32_t strip;    // 420: 1 = single-launch strip walk (S420), 0 = chroma pass + main pass (F420)
+    uint32_t seg_rows; // S420: MCU rows per workgroup
+    uint32_t n_seg;    // S420: ceil(mcu_h / seg_rows)
 };
 
 struct FusedImage {
@@ -382,6 +385,247 @@ struct F420 {
                     const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
                     row_pixels(g, rowb, al4b, t, yy, ox0);
                 }
+            }
+        }
+    }
+};
+
+// =============================================================================================
+// FUSED_420, single launch ("strip walk"): a workgroup owns a strip of `tx` (<= 42) MCU columns and walks
+// `seg_rows` MCU rows of it top to bottom.  Per MCU row it stages the 4*te luma blocks AND the 2*(te+2) chroma
+// blocks under them (one halo block each side: the fancy upsampler reads +-1 chroma sample) in LDS, transforms
+// all of them (one lane per block), and keeps the chroma samples in LDS next to the luma tile: chroma never
+// makes the round trip through HBM that the two-pass form needs (0.8 of its 4.0 GB per 256 x 1080p).
+// The vertical +-1 chroma row comes from the previous MCU row, whose last chroma row and last luma row are
+// carried in LDS (two carry buffers, alternating by MCU row parity): step k emits output rows 16k-1 .. 16k+14
+// (eight slots of two rows, every slot uses two adjacent chroma rows); the last row of the image is emitted after
+// the last step.  A workgroup that does not start at MCU row 0 first transforms MCU row k0-1 only to fill the
+// carry rows.  The sample tiles alias the coefficient staging area (consumed before they are written).
+// =============================================================================================
+struct S420Lds {
+    uint8_t *stage;   // (6*tx + 4) blocks x 128 B coefficient staging; later luma rows 1..15 and chroma rows 1..7
+    uint8_t *ctile;   // inside `stage`: 2 comps x 7 rows x cpitch; column lc <-> plane column 8*(x0m-1) + lc
+    uint8_t *carry;   // 2 buffers x (ypitch + 2*cpitch): luma row 16 / chroma rows 8 of an MCU row = rows 0 of the next
+    uint8_t *qtab;    // 3 x 128 B packed quantization tables (lanes of one wave may use different ones)
+    uint32_t ypitch, cpitch;
+    static __device__ __host__ __forceinline__ uint32_t stage_bytes(uint32_t tx) { return (6u * tx + 4u) * 128u; }
+    static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx) {
+        return stage_bytes(tx) + 2u * (16u * tx + 16u * (tx + 2u)) + 384u;
+    }
+    static __device__ __forceinline__ S420Lds make(uint8_t *base, uint32_t tx) {
+        S420Lds l;
+        l.ypitch = 16u * tx;
+        l.cpitch = 8u * (tx + 2u);
+        l.stage = base;
+        l.ctile = base + 15u * l.ypitch;  // 15*16*tx + 14*8*(tx+2) <= (6*tx+4)*128
+        l.carry = base + stage_bytes(tx);
+        l.qtab = l.carry + 2u * (l.ypitch + 2u * l.cpitch);
+        return l;
+    }
+    // luma tile row r (0..16) / chroma tile row r (0..8) of component c during step k
+    __device__ __forceinline__ uint8_t *yrow(uint32_t k, uint32_t r) const {
+        if (r == 0u) return carry + (k & 1u) * (ypitch + 2u * cpitch);
+        if (r == 16u) return carry + ((k + 1u) & 1u) * (ypitch + 2u * cpitch);
+        return stage + (r - 1u) * ypitch;
+    }
+    __device__ __forceinline__ uint8_t *crow(uint32_t k, uint32_t c, uint32_t r) const {
+        if (r == 0u) return carry + (k & 1u) * (ypitch + 2u * cpitch) + ypitch + c * cpitch;
+        if (r == 8u) return carry + ((k + 1u) & 1u) * (ypitch + 2u * cpitch) + ypitch + c * cpitch;
+        return ctile + (c * 7u + r - 1u) * cpitch;
+    }
+};
+constexpr uint32_t S420_TX_MAX = 42;  // 4*tx luma + 2*(tx+2) chroma blocks <= 256 lanes
+
+struct S420Regs {
+    uint32_t cw[32];   // the lane's coefficient block (between read_block and transform)
+    uint32_t out[16];  // ... transformed
+};
+
+template <int ARITH>
+struct S420 {
+    typedef S420Lds Lds;
+    typedef F420<ARITH, 256> P;  // pixel helpers (upsample + colour + store)
+    static constexpr uint32_t NT = 256;
+    static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t strip) {
+        return min(g.tx, g.mcu_w - strip * g.tx);
+    }
+
+    // once per workgroup: quantization tables -> LDS (made visible by the first barrier)
+    static __device__ __forceinline__ void init(const FusedImage &img, uint32_t tid, const Lds &lds) {
+        if (tid < 32u) {  // (three fixed copies: a per-lane choice of img.qt[c] would put the image struct in scratch)
+            uint32_t *d = reinterpret_cast<uint32_t *>(lds.qtab);
+            d[tid] = ((const JP_GLOBAL uint32_t *)img.qt[0])[tid];
+            d[32u + tid] = ((const JP_GLOBAL uint32_t *)img.qt[1])[tid];
+            d[64u + tid] = ((const JP_GLOBAL uint32_t *)img.qt[2])[tid];
+        }
+    }
+
+    // Stage the coefficients of MCU row k.  Four contiguous runs of 16-B chunks: luma block rows 2k and 2k+1
+    // (16*te chunks each), Cb and Cr (8*(te+2) each, one halo block either side).  Every load instruction reads
+    // from one run — wave-uniform base, the lane's chunk index as 32-bit offset — so the address math stays
+    // scalar; the price is 3+3+2+2 = 10 loads with idle lanes in the last load of each run.
+    // Staging block index = lane that transforms it: [0,2te) luma row 0, [2te,4te) luma row 1, then Cb, Cr.
+    static __device__ __forceinline__ void stage(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
+                                                 uint32_t tid, const Lds &lds) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip);
+        const uint32_t nl = 16u * te, ncc = 8u * (te + 2u);
+        const JP_GLOBAL v4u *y0 = (const JP_GLOBAL v4u *)img.coefs[0] + ((size_t)(2u * k) * g.bw0 + 2u * x0m) * 8u;
+        const JP_GLOBAL v4u *y1 = y0 + (size_t)g.bw0 * 8u;
+        const JP_GLOBAL v4u *cb = (const JP_GLOBAL v4u *)img.coefs[1] + (size_t)k * g.bwc * 8u;
+        const JP_GLOBAL v4u *cr = (const JP_GLOBAL v4u *)img.coefs[2] + (size_t)k * g.bwc * 8u;
+        // halo blocks outside the plane (image edges) are never transformed: clamp them onto valid chunks
+        const int32_t cfirst = ((int32_t)x0m - 1) * 8, cmax = (int32_t)(g.bwc * 8u) - 1;
+        v4u pre[10];
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {
+            const uint32_t j = min(tid + NT * i, nl - 1u);  // clamped: unconditional loads
+            pre[i] = y0[j];
+            pre[3 + i] = y1[j];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t e = (uint32_t)min(max(cfirst + (int32_t)min(tid + NT * i, ncc - 1u), 0), cmax);
+            pre[6 + i] = cb[e];
+            pre[8 + i] = cr[e];
+        }
+        v4u *dst = reinterpret_cast<v4u *>(lds.stage);
+        const uint32_t row = tid & 7u, b = tid >> 3;
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++)
+            if (tid + NT * i < nl) {
+                dst[coef_slot(b + 32u * i, row)] = pre[i];
+                dst[coef_slot(2u * te + b + 32u * i, row)] = pre[3 + i];
+            }
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++)
+            if (tid + NT * i < ncc) {
+                dst[coef_slot(4u * te + b + 32u * i, row)] = pre[6 + i];
+                dst[coef_slot(5u * te + 2u + b + 32u * i, row)] = pre[8 + i];
+            }
+    }
+
+    // lane -> block: returns false for idle lanes.  comp 0 = luma (ry, cx), 1/2 = Cb/Cr (cx = LDS block column)
+    static __device__ __forceinline__ bool lane_block(const FusedGeom &g, uint32_t strip, uint32_t tid, uint32_t &comp,
+                                                      uint32_t &ry, uint32_t &cx) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip);
+        if (tid < 4u * te) {
+            comp = 0u;
+            ry = tid >= 2u * te ? 1u : 0u;
+            cx = tid - ry * 2u * te;
+            return true;
+        }
+        const uint32_t t = tid - 4u * te;
+        comp = 1u;
+        ry = 0u;
+        cx = 0u;
+        if (t >= 2u * (te + 2u)) return false;
+        const uint32_t c = t >= te + 2u ? 1u : 0u;
+        comp = 1u + c;
+        cx = t - c * (te + 2u);
+        const int32_t bx = (int32_t)x0m - 1 + (int32_t)cx;
+        return bx >= 0 && bx < (int32_t)g.bwc;
+    }
+
+    // Touch the lane's block of MCU row k (both 64-B halves) so that stage(k) finds it in L2 / Infinity Cache:
+    // issued before the colour phase of row k-1, it takes the HBM latency off the critical path of the next step
+    // at the price of two live VGPRs (a full register prefetch of the 40 staging VGPRs does not fit next to the
+    // colour phase at 4 waves/SIMD).  The caller keeps the returned value alive until after the colour phase.
+    static __device__ __forceinline__ uint32_t touch(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
+                                                     uint32_t tid) {
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, strip, tid, comp, ry, cx)) return 0u;
+        const uint32_t x0m = strip * g.tx;
+        const uint32_t bl = (2u * k + ry) * g.bw0 + 2u * x0m + cx;  // luma block index
+        const uint32_t bc = k * g.bwc + x0m - 1u + cx;              // chroma block index (lane_block: inside the plane)
+        const JP_GLOBAL uint32_t *p0 = (const JP_GLOBAL uint32_t *)img.coefs[0] + (size_t)bl * 32u;
+        const JP_GLOBAL uint32_t *p1 = (const JP_GLOBAL uint32_t *)img.coefs[1] + (size_t)bc * 32u;
+        const JP_GLOBAL uint32_t *p2 = (const JP_GLOBAL uint32_t *)img.coefs[2] + (size_t)bc * 32u;
+        const JP_GLOBAL uint32_t *p = comp == 0u ? p0 : (comp == 1u ? p1 : p2);
+        return p[0] | p[16];
+    }
+
+    // staging -> registers (a barrier follows: the tiles written by put_tiles alias the staging area)
+    static __device__ __forceinline__ void read_block(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds,
+                                                      S420Regs &r) {
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, strip, tid, comp, ry, cx)) return;
+        load_block_from_lds(lds.stage, tid, r.cw);
+    }
+
+    // transform the lane's block and write the samples to the tiles.  carry_only: just the rows the next MCU row
+    // needs (luma row 16, chroma rows 8) — the warm-up step of a workgroup that starts below MCU row 0.
+    static __device__ __forceinline__ void transform(const FusedGeom &g, uint32_t strip, uint32_t k, uint32_t tid,
+                                                     const Lds &lds, S420Regs &r, bool carry_only) {
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, strip, tid, comp, ry, cx)) return;
+        if (carry_only && comp == 0u && ry == 0u) return;
+        uint32_t qw[32];
+        const v4u *q = reinterpret_cast<const v4u *>(lds.qtab) + comp * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const v4u v = q[i];
+            qw[4 * i] = v.x;
+            qw[4 * i + 1] = v.y;
+            qw[4 * i + 2] = v.z;
+            qw[4 * i + 3] = v.w;
+        }
+        idct8x8<ARITH>(r.cw, qw, r.out);
+        // rows 1..: luma tile row ry*8 + 1 + row, chroma tile row 1 + row
+        const uint32_t c = comp == 0u ? 0u : comp - 1u;
+        uint8_t *last = comp == 0u ? lds.yrow(k, 16u) : lds.crow(k, c, 8u);
+        if (!carry_only) {
+            uint8_t *base = comp == 0u ? lds.stage + (ry * 8u) * lds.ypitch : lds.ctile + (c * 7u) * lds.cpitch;
+            const uint32_t pitch = comp == 0u ? lds.ypitch : lds.cpitch;
+#pragma unroll
+            for (int row = 0; row < 7; row++)
+                *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch + cx * 8u) = v2u{r.out[2 * row], r.out[2 * row + 1]};
+            if (comp == 0u && ry == 0u) last = base + 7u * pitch;  // luma tile row 8 is an ordinary row
+        }
+        *reinterpret_cast<v2u *>(last + cx * 8u) = v2u{r.out[14], r.out[15]};
+    }
+
+    // output rows 16k-1 .. 16k+14: slot p (0..7) pairs chroma tile rows (p, p+1) = plane rows 8k-1+p, 8k+p and
+    // emits luma tile rows 2p (near = upper chroma row) and 2p+1 (near = lower chroma row).
+    // Wave w takes slots 2w and 2w+1; its lanes walk the 2*nch (slot, chunk) units.
+    // k == mcu_h is the closing call: only the very last image row (slot 0, first row) is in range.
+    static __device__ __forceinline__ void colour(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
+                                                  uint32_t tid, const Lds &lds) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip);
+        const uint32_t nch = 2u * te;
+        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
+        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
+        const size_t pitch = (size_t)g.out_w * 3u;
+#pragma unroll 1
+        for (uint32_t u = lane; u < 2u * nch; u += 64u) {
+            const uint32_t hi = u >= nch ? 1u : 0u;
+            const uint32_t slot = 2u * wave + hi, chk = u - hi * nch;
+            const int32_t oya = 16 * (int32_t)k - 1 + 2 * (int32_t)slot;
+            const uint32_t oyb = (uint32_t)(oya + 1);
+            const bool va = oya >= 0 && (uint32_t)oya < g.out_h, vb = oyb < g.out_h;
+            const uint32_t ox0 = 16u * x0m + 8u * chk;
+            if ((!va && !vb) || ox0 >= g.out_w) continue;
+            const int32_t cu = 8 * (int32_t)k - 1 + (int32_t)slot;  // plane row of the slot's upper chroma row
+            // row a: near U, far min(near+1, ch-1);  row b: near L, far max(near-1, 0) (src/upsampler.rs:200-206)
+            const bool clamp_a = cu + 1 > (int32_t)g.ch - 1, clamp_b = cu < 0;
+            const uint32_t U = clamp_b ? slot + 1u : slot, L = clamp_a ? slot : slot + 1u;
+            const uint32_t coff = 4u * chk + 4u;  // tile column of plane column j0 - 4
+            typename P::ChromaEO eu[2], el[2];
+#pragma unroll
+            for (uint32_t comp = 0; comp < 2; comp++) {
+                eu[comp] = P::load_eo(lds.crow(k, comp, U) + coff);
+                el[comp] = P::load_eo(lds.crow(k, comp, L) + coff);
+            }
+            if (va) {
+                const typename P::TPrime t[2] = {P::tprime(eu[0], el[0]), P::tprime(eu[1], el[1])};
+                const v2u yy = *reinterpret_cast<const v2u *>(lds.yrow(k, 2u * slot) + 8u * chk);
+                const size_t ro = (size_t)oya * pitch;
+                P::row_pixels(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
+            }
+            if (vb) {
+                const typename P::TPrime t[2] = {P::tprime(el[0], eu[0]), P::tprime(el[1], eu[1])};
+                const v2u yy = *reinterpret_cast<const v2u *>(lds.yrow(k, 2u * slot + 1u) + 8u * chk);
+                const size_t ro = (size_t)oyb * pitch;
+                P::row_pixels(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
             }
         }
     }

@@ -18,8 +18,9 @@ inline bool fused_same_component(const jpgpu_component &a, const jpgpu_component
 // Returns FUSED_* and fills `g`; FUSED_NONE (with `why`) sends the batch down the generic path.
 // f420_tx_max: MCUs per 4:2:0 tile (32 -> 128-thread workgroups, 64 -> 256-thread workgroups; measured on
 // MI355X, 1080p x256: 0.899 ms with 64 vs 0.941 ms with 32 — profiles/round1)
+// strip420: 4:2:0 as the single-launch strip walk (S420) instead of chroma pass + main pass.
 inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why,
-                                uint32_t f420_tx_max = 64) {
+                                uint32_t f420_tx_max = 64, bool strip420 = false, uint32_t s420_tx_max = S420_TX_MAX) {
     g = FusedGeom{};
     for (uint32_t c = 0; c < d0.ncomp; c++)
         if (d0.components[c].dct_scale != 8) {
@@ -51,7 +52,9 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             why = "inconsistent block grid";
             return FUSED_NONE;
         }
-        tx_max = f420_tx_max <= 32u ? 32u : F420_TX_MAX;
+        tx_max = strip420 ? (s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max)) : (f420_tx_max <= 32u ? 32u : F420_TX_MAX);
+        g.strip = strip420 ? 1u : 0u;
+        if (strip420) name = "fused420s";
     } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&
                (d0.color_transform == JPGPU_CT_YCBCR || d0.color_transform == JPGPU_CT_RGB) &&
                fused_same_component(d0.components[0], d0.components[1]) &&
@@ -91,7 +94,27 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
     uint32_t n_tiles = (g.mcu_w + tx_max - 1) / tx_max;
     g.tx = (g.mcu_w + n_tiles - 1) / n_tiles;
     g.tiles_x = (g.mcu_w + g.tx - 1) / g.tx;
+    g.seg_rows = g.mcu_h;
+    g.n_seg = 1;
     return kind;
+}
+
+// S420: split the MCU rows of a strip between workgroups.  Every workgroup but the first re-transforms one
+// MCU row for its carry rows, so segments are as long as the machine allows: enough workgroups to fill
+// 256 CUs x 3 resident workgroups a few times over, and no more.
+inline void s420_set_segments(FusedGeom &g, uint32_t n_images, uint32_t seg_rows_override = 0) {
+    uint32_t seg = seg_rows_override;
+    if (seg == 0) {
+        const uint32_t target = 3072;  // workgroups
+        const uint32_t per_seg = g.tiles_x * (n_images ? n_images : 1u);
+        uint32_t n_seg = (target + per_seg - 1) / per_seg;
+        n_seg = n_seg < 1u ? 1u : n_seg;
+        seg = (g.mcu_h + n_seg - 1) / n_seg;
+        if (seg < 4u) seg = 4u;
+    }
+    if (seg > g.mcu_h) seg = g.mcu_h;
+    g.seg_rows = seg;
+    g.n_seg = (g.mcu_h + seg - 1) / seg;
 }
 
 }  // namespace jpgpu

@@ -51,6 +51,10 @@ __device__ __forceinline__ int32_t q_at(qtab_t q, int idx) {
     uint32_t d = q[idx >> 1];
     return (int32_t)((idx & 1) ? (d >> 16) : (d & 0xffffu));
 }
+__device__ __forceinline__ int32_t qw_at(const uint32_t (&qw)[32], int idx) {
+    uint32_t d = qw[idx >> 1];
+    return (int32_t)((idx & 1) ? (d >> 16) : (d & 0xffffu));
+}
 
 // stbi_f2f(x) = (x * 4096.0f + 0.5f) as i32, evaluated in f32 (src/idct.rs:572-574).
 // Values as listed in SURVEY Appendix A.1; the oracle computes them with the f32 formula and
@@ -289,8 +293,10 @@ enum : int {
                       // outputs (<= (5683*5900 + 512) >> 10 < 2^15) fit i16 and the row pass runs on dot2 too
 };
 
+// qw: the 64 quantization values packed two per dword (natural order), as VALUES — in SGPRs when they
+// were loaded through a wave-uniform table pointer, in VGPRs when lanes of a wave use different tables.
 template <int ARITH>
-__device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint32_t (&out)[16]) {
+__device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint32_t (&qw)[32], uint32_t (&out)[16]) {
     const w32 X_SCALE = 65536u + (128u << 17);
     if constexpr (ARITH == ARITH_EXACT) {
         w32 t[64];
@@ -300,7 +306,7 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint
 #pragma unroll
         for (int k = 0; k < 8; k++) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) t[k * 8 + i] = mul24((w32)coef_at(cw, k, i), q_at(q, k * 8 + i));  // i16 x u16: always exact
+            for (int i = 0; i < 8; i++) t[k * 8 + i] = mul24((w32)coef_at(cw, k, i), qw_at(qw, k * 8 + i));  // i16 x u16: always exact
             if (k >= 1) {
 #pragma unroll
                 for (int dd = 0; dd < 4; dd++) acbits[dd] |= cw[k * 4 + dd];
@@ -333,7 +339,7 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint
         // (two coefficients per instruction) and the column pass runs on dot2.
         uint32_t d[32];  // d[k*4+j] = (s[k][2j], s[k][2j+1])
 #pragma unroll
-        for (int i = 0; i < 32; i++) d[i] = pk_mul_lo_u16(cw[i], q[i]);
+        for (int i = 0; i < 32; i++) d[i] = pk_mul_lo_u16(cw[i], qw[i]);
         w32 t[64];  // t[k*8+i] = column-pass output (row k, column i)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -364,6 +370,15 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint
             out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
         }
     }
+}
+
+// table through a wave-uniform pointer: the 32 dwords are s_load'ed and stay in SGPRs
+template <int ARITH>
+__device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], qtab_t q, uint32_t (&out)[16]) {
+    uint32_t qw[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) qw[i] = q[i];
+    idct8x8<ARITH>(cw, qw, out);
 }
 
 // src/idct.rs:456-517; out: 4 rows x 4 bytes (one dword per row)

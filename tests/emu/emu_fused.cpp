@@ -3,20 +3,64 @@
 // sequential "barriers", so tile / halo / edge logic can be checked against the oracle without a
 // GPU.  Not part of the product; the product path only ever runs on gfx950.
 #include "hip_shim.hpp"
+#include <algorithm>
 #include <vector>
 #include "../../jpeg-decoder_amd/csrc/fused_plan.hpp"
 
 using namespace jpgpu;
 
+// strip420 != 0: 4:2:0 through the strip-walk kernel (S420) with `seg_rows` MCU rows per workgroup (0 = planner's choice)
+template <int A>
+static void run_s420(const FusedGeom& g, const FusedImage& img) {
+    typedef S420<A> K;
+    std::vector<uint8_t> mem(S420Lds::total_bytes(g.tx) + 64);
+    std::vector<S420Regs> regs(256);
+#define LANES(BODY) for (uint32_t t = 0; t < 256; t++) { BODY; }
+    for (uint32_t seg = 0; seg < g.n_seg; seg++)
+        for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
+            memset(mem.data(), 0xCD, mem.size());  // garbage, like real LDS
+            const S420Lds lds = S420Lds::make(mem.data(), g.tx);
+            const uint32_t k0 = seg * g.seg_rows, k1 = std::min(k0 + g.seg_rows, g.mcu_h);
+            LANES(K::init(img, t, lds))
+            if (k0 > 0) {
+                LANES(K::stage(g, img, strip, k0 - 1, t, lds))
+                LANES(K::read_block(g, strip, t, lds, regs[t]))
+                LANES(K::transform(g, strip, k0 - 1, t, lds, regs[t], true))
+            }
+            for (uint32_t k = k0; k < k1; k++) {
+                LANES(K::stage(g, img, strip, k, t, lds))
+                LANES(K::read_block(g, strip, t, lds, regs[t]))
+                LANES(K::transform(g, strip, k, t, lds, regs[t], false))
+                LANES(K::colour(g, img, strip, k, t, lds))
+            }
+            if (k1 == g.mcu_h) LANES(K::colour(g, img, strip, g.mcu_h, t, lds))
+        }
+#undef LANES
+}
+
 extern "C" {
 
 // returns the fused kind the planner picked (0 = none -> generic path on the GPU)
 int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, int sane, uint8_t* out,
-                     uint32_t* tx_out, uint32_t f420_tx_max) {
+                     uint32_t* tx_out, uint32_t f420_tx_max, int strip420, uint32_t seg_rows) {
     FusedGeom g;
     const char *name = "", *why = "";
-    int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max);
+    int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max, strip420 != 0);
     if (kind == FUSED_NONE) return 0;
+    if (kind == FUSED_420 && g.strip) {
+        s420_set_segments(g, 1, seg_rows);
+        FusedImage im{};
+        for (uint32_t c = 0; c < desc->ncomp; c++) {
+            im.coefs[c] = coefs[c];
+            im.qt[c] = desc->quantization_tables[c];
+        }
+        im.out = out;
+        if (tx_out) *tx_out = g.tx;
+        if (sane == 2) run_s420<ARITH_TIGHT>(g, im);
+        else if (sane) run_s420<ARITH_SANE>(g, im);
+        else run_s420<ARITH_EXACT>(g, im);
+        return kind;
+    }
     if (tx_out) *tx_out = g.tx;
     FusedImage img{};
     for (uint32_t c = 0; c < desc->ncomp; c++) {
