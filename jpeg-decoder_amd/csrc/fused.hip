@@ -47,9 +47,9 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedG
 }
 
 // 4:2:0 in one launch: grid = (strips, row segments, images); see S420 in fused_core.hpp
-template <int ARITH>
-__global__ __launch_bounds__(256, 4) void s420_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
-    typedef S420<ARITH> K;
+template <int ARITH, uint32_t NT>
+__global__ __launch_bounds__(NT, 4) void s420_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+    typedef S420<ARITH, NT> K;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const S420Lds lds = S420Lds::make(lds_raw, g.tx);
     const FusedImage img = imgs[blockIdx.z];
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage
     FusedRegs r;
     F444<ARITH>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    F444<ARITH>::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    const uint32_t wcomp = min((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), 2u);
+    F444<ARITH>::phase1(g, imgs[blockIdx.z].qt[wcomp], blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
     F444<ARITH>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
     __syncthreads();
@@ -126,10 +127,11 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std
     const char *name = "", *w = "";
     // JPGPU_F420_TX=32 selects the 128-thread / 32-MCU tiling of the 4:2:0 main pass (tuning knob)
     const char *txenv = getenv("JPGPU_F420_TX");
-    // JPGPU_420_TWOPASS=1 selects the chroma-pass + main-pass form of the 4:2:0 path, JPGPU_S420_TX / _SEG the
-    // strip width and rows per workgroup of the single-launch form (A/B knobs)
-    const char *tp = getenv("JPGPU_420_TWOPASS");
-    const bool strip420 = !(tp && atoi(tp) != 0);
+    // JPGPU_420_STRIP=1 selects the single-launch strip walk (S420) for 4:2:0 instead of chroma pass + main pass;
+    // JPGPU_S420_TX / JPGPU_S420_SEG set its strip width and MCU rows per workgroup.  Off by default: on MI355X it
+    // moves 15 % fewer bytes but runs 3 % slower (0.88 vs 0.85 ms per 256 x 1080p) — DESIGN.md §5.
+    const char *tp = getenv("JPGPU_420_STRIP");
+    const bool strip420 = tp && atoi(tp) != 0;
     const char *stx = getenv("JPGPU_S420_TX");
     int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 64u, strip420, stx ? (uint32_t)atoi(stx) : S420_TX_MAX);
     if (kind == FUSED_NONE) {
@@ -217,9 +219,15 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
         if (g.strip) {
             const size_t shm = S420Lds::total_bytes(g.tx);
             dim3 sgrid(g.tiles_x, g.n_seg, plan.n_images);
-            if (plan.arith == ARITH_TIGHT) s420_kernel<ARITH_TIGHT><<<sgrid, block, shm, stream>>>(g, plan.d_images);
-            else if (plan.arith == ARITH_SANE) s420_kernel<ARITH_SANE><<<sgrid, block, shm, stream>>>(g, plan.d_images);
-            else s420_kernel<ARITH_EXACT><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+            if (g.tx <= 20u) {  // 128-thread workgroups
+                if (plan.arith == ARITH_TIGHT) s420_kernel<ARITH_TIGHT, 128><<<sgrid, dim3(128), shm, stream>>>(g, plan.d_images);
+                else if (plan.arith == ARITH_SANE) s420_kernel<ARITH_SANE, 128><<<sgrid, dim3(128), shm, stream>>>(g, plan.d_images);
+                else s420_kernel<ARITH_EXACT, 128><<<sgrid, dim3(128), shm, stream>>>(g, plan.d_images);
+            } else {
+                if (plan.arith == ARITH_TIGHT) s420_kernel<ARITH_TIGHT, 256><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+                else if (plan.arith == ARITH_SANE) s420_kernel<ARITH_SANE, 256><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+                else s420_kernel<ARITH_EXACT, 256><<<sgrid, block, shm, stream>>>(g, plan.d_images);
+            }
             break;
         }
         // The batch may be walked in chunks of `chunk` images (chroma pass, then main pass) sharing one

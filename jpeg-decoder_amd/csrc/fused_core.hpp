@@ -434,18 +434,18 @@ struct S420Lds {
         return ctile + (c * 7u + r - 1u) * cpitch;
     }
 };
-constexpr uint32_t S420_TX_MAX = 42;  // 4*tx luma + 2*(tx+2) chroma blocks <= 256 lanes
+constexpr uint32_t S420_TX_MAX = 42;  // 4*tx luma + 2*(tx+2) chroma blocks <= 256 lanes (<= 20 with 128-thread workgroups)
 
 struct S420Regs {
     uint32_t cw[32];   // the lane's coefficient block (between read_block and transform)
     uint32_t out[16];  // ... transformed
 };
 
-template <int ARITH>
+template <int ARITH, uint32_t NTHREADS = 256>
 struct S420 {
     typedef S420Lds Lds;
     typedef F420<ARITH, 256> P;  // pixel helpers (upsample + colour + store)
-    static constexpr uint32_t NT = 256;
+    static constexpr uint32_t NT = NTHREADS;  // 256: strips of <= 42 MCUs; 128: <= 20
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t strip) {
         return min(g.tx, g.mcu_w - strip * g.tx);
     }
@@ -493,14 +493,14 @@ struct S420 {
 #pragma unroll
         for (uint32_t i = 0; i < 3; i++)
             if (tid + NT * i < nl) {
-                dst[coef_slot(b + 32u * i, row)] = pre[i];
-                dst[coef_slot(2u * te + b + 32u * i, row)] = pre[3 + i];
+                dst[coef_slot(b + (NT / 8u) * i, row)] = pre[i];
+                dst[coef_slot(2u * te + b + (NT / 8u) * i, row)] = pre[3 + i];
             }
 #pragma unroll
         for (uint32_t i = 0; i < 2; i++)
             if (tid + NT * i < ncc) {
-                dst[coef_slot(4u * te + b + 32u * i, row)] = pre[6 + i];
-                dst[coef_slot(5u * te + 2u + b + 32u * i, row)] = pre[8 + i];
+                dst[coef_slot(4u * te + b + (NT / 8u) * i, row)] = pre[6 + i];
+                dst[coef_slot(5u * te + 2u + b + (NT / 8u) * i, row)] = pre[8 + i];
             }
     }
 
@@ -524,24 +524,6 @@ struct S420 {
         cx = t - c * (te + 2u);
         const int32_t bx = (int32_t)x0m - 1 + (int32_t)cx;
         return bx >= 0 && bx < (int32_t)g.bwc;
-    }
-
-    // Touch the lane's block of MCU row k (both 64-B halves) so that stage(k) finds it in L2 / Infinity Cache:
-    // issued before the colour phase of row k-1, it takes the HBM latency off the critical path of the next step
-    // at the price of two live VGPRs (a full register prefetch of the 40 staging VGPRs does not fit next to the
-    // colour phase at 4 waves/SIMD).  The caller keeps the returned value alive until after the colour phase.
-    static __device__ __forceinline__ uint32_t touch(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
-                                                     uint32_t tid) {
-        uint32_t comp, ry, cx;
-        if (!lane_block(g, strip, tid, comp, ry, cx)) return 0u;
-        const uint32_t x0m = strip * g.tx;
-        const uint32_t bl = (2u * k + ry) * g.bw0 + 2u * x0m + cx;  // luma block index
-        const uint32_t bc = k * g.bwc + x0m - 1u + cx;              // chroma block index (lane_block: inside the plane)
-        const JP_GLOBAL uint32_t *p0 = (const JP_GLOBAL uint32_t *)img.coefs[0] + (size_t)bl * 32u;
-        const JP_GLOBAL uint32_t *p1 = (const JP_GLOBAL uint32_t *)img.coefs[1] + (size_t)bc * 32u;
-        const JP_GLOBAL uint32_t *p2 = (const JP_GLOBAL uint32_t *)img.coefs[2] + (size_t)bc * 32u;
-        const JP_GLOBAL uint32_t *p = comp == 0u ? p0 : (comp == 1u ? p1 : p2);
-        return p[0] | p[16];
     }
 
     // staging -> registers (a barrier follows: the tiles written by put_tiles alias the staging area)
@@ -586,19 +568,21 @@ struct S420 {
 
     // output rows 16k-1 .. 16k+14: slot p (0..7) pairs chroma tile rows (p, p+1) = plane rows 8k-1+p, 8k+p and
     // emits luma tile rows 2p (near = upper chroma row) and 2p+1 (near = lower chroma row).
-    // Wave w takes slots 2w and 2w+1; its lanes walk the 2*nch (slot, chunk) units.
+    // The 8*nch (slot, chunk) units are dealt to the 256 lanes in order, so consecutive lanes write consecutive
+    // 24-B runs of a scanline; with nch = 80 that is 2.5 rounds: the waves that sit out the last round rotate
+    // with k (waves map to SIMDs round-robin: a fixed assignment would load two SIMDs more than the others).
     // k == mcu_h is the closing call: only the very last image row (slot 0, first row) is in range.
     static __device__ __forceinline__ void colour(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
                                                   uint32_t tid, const Lds &lds) {
         const uint32_t x0m = strip * g.tx, te = txe(g, strip);
-        const uint32_t nch = 2u * te;
-        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
+        const uint32_t nch = 2u * te, nunits = 8u * nch;
+        const uint32_t magic = 0xffffffffu / nch + 1u;  // mul_hi(u, magic) == u / nch for u < 65536
+        const uint32_t vt = (tid + 64u * (k & (NT / 64u - 1u))) & (NT - 1u);
         JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
         const size_t pitch = (size_t)g.out_w * 3u;
 #pragma unroll 1
-        for (uint32_t u = lane; u < 2u * nch; u += 64u) {
-            const uint32_t hi = u >= nch ? 1u : 0u;
-            const uint32_t slot = 2u * wave + hi, chk = u - hi * nch;
+        for (uint32_t u = vt; u < nunits; u += NT) {
+            const uint32_t slot = __umulhi(u, magic), chk = u - slot * nch;
             const int32_t oya = 16 * (int32_t)k - 1 + 2 * (int32_t)slot;
             const uint32_t oyb = (uint32_t)(oya + 1);
             const bool va = oya >= 0 && (uint32_t)oya < g.out_h, vb = oyb < g.out_h;
@@ -666,16 +650,17 @@ struct F444 {
         for (uint32_t i = 0; i < 6; i++)
             if (tid + FUSED_NT * i <= lastc) dst[coef_slot(kk[i] * 64u + (rr[i] >> 3), rr[i] & 7u)] = v[i];
     }
-    static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t tid,
+    // qt_of_wave: quantization table of component (tid >> 6), fetched by the caller from the image array in memory
+    // (a runtime index — or a chain of selects, which the compiler turns into one — into the by-value image struct
+    // would move the whole struct to scratch)
+    static __device__ __forceinline__ void phase1(const FusedGeom &g, const uint16_t *qt_of_wave, uint32_t tile_x, uint32_t tid,
                                                   const FusedLdsSmall &lds, FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
         const uint32_t comp = uniform(tid >> 6), cx = tid & 63u;
         if (comp >= 3u || cx >= te) return;
         uint32_t cw[32];
         load_block_from_lds(lds.coef, comp * 64u + cx, cw);
-        // (no img.qt[comp]: a runtime index into the by-value image struct would put it in scratch)
-        const uint16_t *qt = comp == 0u ? img.qt[0] : (comp == 1u ? img.qt[1] : img.qt[2]);
-        idct8x8<ARITH>(cw, as_qtab(qt), r.out);
+        idct8x8<ARITH>(cw, as_qtab(qt_of_wave), r.out);
     }
     // sample tiles: [3 comps][8 rows][pitch 8*tx]
     static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLdsSmall &lds,

@@ -105,7 +105,7 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
 inline void s420_set_segments(FusedGeom &g, uint32_t n_images, uint32_t seg_rows_override = 0) {
     uint32_t seg = seg_rows_override;
     if (seg == 0) {
-        const uint32_t target = 3072;  // workgroups
+        const uint32_t target = g.tx <= 20u ? 6144u : 3072u;  // workgroups (128-thread ones are half the size)
         const uint32_t per_seg = g.tiles_x * (n_images ? n_images : 1u);
         uint32_t n_seg = (target + per_seg - 1) / per_seg;
         n_seg = n_seg < 1u ? 1u : n_seg;

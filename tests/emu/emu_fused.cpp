@@ -10,12 +10,12 @@
 using namespace jpgpu;
 
 // strip420 != 0: 4:2:0 through the strip-walk kernel (S420) with `seg_rows` MCU rows per workgroup (0 = planner's choice)
-template <int A>
+template <int A, uint32_t NT>
 static void run_s420(const FusedGeom& g, const FusedImage& img) {
-    typedef S420<A> K;
+    typedef S420<A, NT> K;
     std::vector<uint8_t> mem(S420Lds::total_bytes(g.tx) + 64);
-    std::vector<S420Regs> regs(256);
-#define LANES(BODY) for (uint32_t t = 0; t < 256; t++) { BODY; }
+    std::vector<S420Regs> regs(NT);
+#define LANES(BODY) for (uint32_t t = 0; t < NT; t++) { BODY; }
     for (uint32_t seg = 0; seg < g.n_seg; seg++)
         for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
             memset(mem.data(), 0xCD, mem.size());  // garbage, like real LDS
@@ -42,10 +42,10 @@ extern "C" {
 
 // returns the fused kind the planner picked (0 = none -> generic path on the GPU)
 int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, int sane, uint8_t* out,
-                     uint32_t* tx_out, uint32_t f420_tx_max, int strip420, uint32_t seg_rows) {
+                     uint32_t* tx_out, uint32_t f420_tx_max, int strip420, uint32_t seg_rows, uint32_t s420_tx_max) {
     FusedGeom g;
     const char *name = "", *why = "";
-    int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max, strip420 != 0);
+    int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max, strip420 != 0, s420_tx_max ? s420_tx_max : S420_TX_MAX);
     if (kind == FUSED_NONE) return 0;
     if (kind == FUSED_420 && g.strip) {
         s420_set_segments(g, 1, seg_rows);
@@ -56,9 +56,15 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         }
         im.out = out;
         if (tx_out) *tx_out = g.tx;
-        if (sane == 2) run_s420<ARITH_TIGHT>(g, im);
-        else if (sane) run_s420<ARITH_SANE>(g, im);
-        else run_s420<ARITH_EXACT>(g, im);
+        if (g.tx <= 20u) {
+            if (sane == 2) run_s420<ARITH_TIGHT, 128>(g, im);
+            else if (sane) run_s420<ARITH_SANE, 128>(g, im);
+            else run_s420<ARITH_EXACT, 128>(g, im);
+        } else {
+            if (sane == 2) run_s420<ARITH_TIGHT, 256>(g, im);
+            else if (sane) run_s420<ARITH_SANE, 256>(g, im);
+            else run_s420<ARITH_EXACT, 256>(g, im);
+        }
         return kind;
     }
     if (tx_out) *tx_out = g.tx;
@@ -104,13 +110,13 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
                 if (g.tx <= 32u) { if (sane == 2) { RUN420(ARITH_TIGHT, 128, lds128) } else if (sane) { RUN420(ARITH_SANE, 128, lds128) } else { RUN420(ARITH_EXACT, 128, lds128) } }
                 else { if (sane == 2) { RUN420(ARITH_TIGHT, 256, lds) } else if (sane) { RUN420(ARITH_SANE, 256, lds) } else { RUN420(ARITH_EXACT, 256, lds) } }
             } else if (kind == FUSED_444 && sane == 2) {
-                RUN(256, F444<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_TIGHT>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_TIGHT>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_TIGHT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_TIGHT>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444 && sane) {
-                RUN(256, F444<ARITH_SANE>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_SANE>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_SANE>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_SANE>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_SANE>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_SANE>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444) {
-                RUN(256, F444<ARITH_EXACT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_EXACT>::phase1(g, img, tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_EXACT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_EXACT>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_EXACT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_EXACT>::phase3(g, img, tile, my, t, *lds_s))
             } else if (sane == 2) {
                 RUN(256, FGray<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<ARITH_TIGHT>::phase1(g, img, tile, my, t, *lds_s))

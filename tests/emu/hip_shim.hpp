@@ -17,3 +17,4 @@ struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }

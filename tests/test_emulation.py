@@ -116,7 +116,7 @@ def _to_j(ocomps):
     return out
 
 
-def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64, strip=0, seg_rows=0):
+def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64, strip=0, seg_rows=0, s420_tx=0):
     ocomps, _ = O.make_components(w_, h_, samp)
     desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
     n = len(samp)
@@ -124,7 +124,7 @@ def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64, strip=0, seg_rows=0
     out_len = w_ * h_ * (1 if n == 1 else 3)
     out = np.full(out_len + 64, 0x5A, np.uint8)  # guard band: the kernels must not write past the image
     tx = C.c_uint32(0)
-    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, int(sane), out.ctypes.data, C.byref(tx), f420_tx, strip, seg_rows)
+    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, int(sane), out.ctypes.data, C.byref(tx), f420_tx, strip, seg_rows, s420_tx)
     assert (out[out_len:] == 0x5A).all(), "emulated kernel wrote past the output"
     return kind, out[:out_len], tx.value
 
@@ -145,13 +145,16 @@ GEOMS = [
 
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
 @pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
-@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3"])
+@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7"])
 def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     if f420_tx != 64 and not (len(geom[2]) == 3 and geom[2][0] == (2, 2)):
         pytest.skip("variant knob only affects the 4:2:0 kernels")
-    strip, seg_rows = 0, 0
-    if isinstance(f420_tx, str):  # single-launch strip walk; seg_rows = MCU rows per workgroup (0: whole strip)
-        strip, seg_rows, f420_tx = 1, {"strip": 1000, "strip-seg1": 1, "strip-seg3": 3}[f420_tx], 64
+    strip, seg_rows, s420_tx = 0, 0, 0
+    if isinstance(f420_tx, str):  # single-launch strip walk: (MCU rows per workgroup, widest strip)
+        strip = 1
+        seg_rows, s420_tx = {"strip": (1000, 0), "strip-seg1": (1, 0), "strip-seg3": (3, 0), "strip-tx20": (1000, 20),
+                             "strip-tx20-seg2": (2, 20), "strip-tx7": (5, 7)}[f420_tx]
+        f420_tx = 64
     w_, h_, samp, ct = geom
     rng = np.random.default_rng(w_ * 131 + h_)
     ocomps, _ = O.make_components(w_, h_, samp)
@@ -165,7 +168,7 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     else:
         qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
         coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
-    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, {"hostile": 0, "sane": 1, "tight": 2}[kind], f420_tx, strip, seg_rows)
+    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, {"hostile": 0, "sane": 1, "tight": 2}[kind], f420_tx, strip, seg_rows, s420_tx)
     assert got_kind != 0, "planner refused a geometry the fused kernels are meant to cover"
     want = O.pixels_from_coefficients(ocomps, qts, coefs, w_, h_, ct.upper())
     assert got.size == want.size
@@ -185,4 +188,4 @@ def test_planner_keeps_odd_geometries_on_the_generic_path():
         desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
         ptrs = (C.c_void_p * len(samp))(*[c.ctypes.data for c in coefs])
         out = np.zeros(w_ * h_ * 4 + 64, np.uint8)
-        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None, 32, 0, 0) == 0
+        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None, 32, 0, 0, 0) == 0

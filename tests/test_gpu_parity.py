@@ -324,3 +324,25 @@ def test_batch_1080p_420_full_size_properties():
     # the decoded synthetic image is close to its source (sanity of the whole chain)
     err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
     assert err.mean() < 6.0
+
+
+STRIP_GEOMETRY = [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (673, 79), (1920, 64), (30, 160)]
+
+
+@pytest.mark.parametrize("size", STRIP_GEOMETRY, ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("knobs", [{}, {"JPGPU_S420_SEG": "1"}, {"JPGPU_S420_SEG": "3", "JPGPU_S420_TX": "20"}, {"JPGPU_S420_TX": "7"}],
+                         ids=["default", "seg1", "seg3-tx20", "tx7"])
+@pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
+def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
+    """The opt-in single-launch 4:2:0 kernel (JPGPU_420_STRIP=1): strip / segment seams, carry rows, image edges."""
+    monkeypatch.setenv("JPGPU_420_STRIP", "1")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    w_, h_ = size
+    rng = np.random.default_rng(w_ * 77 + h_)
+    cases = [_batch_case(rng, w_, h_, [(2, 2), (1, 1), (1, 1)], "YCbCr", kind=kind) for _ in range(3)]
+    outs, path = _run_batch(cases)
+    assert path == "fused420s"
+    for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
+        want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
+        assert np.array_equal(got, want)
