@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libjpgpu.so")
+# JPGPU_LIBRARY: development knob for A/B builds of the same ABI (e.g. libjpgpu_alt.so built with other -D flags)
+LIB_PATH = os.environ.get("JPGPU_LIBRARY") or os.path.join(_HERE, "libjpgpu.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "jpgpu.h")
 
 OK, ERR_FORMAT, ERR_UNSUPPORTED, ERR_IO, ERR_INTERNAL, ERR_NO_DEVICE = range(6)

@@ -116,8 +116,8 @@ __device__ __forceinline__ void store_rgb_run(JP_GLOBAL uint8_t *out, size_t off
     if (n == 8 && (off & 3u) == 0) {
         const v3u lo = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
         const v3u hi = {px[4] | (px[5] << 24), (px[5] >> 8) | (px[6] << 16), (px[6] >> 16) | (px[7] << 8)};
-        *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = lo;
-        *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = hi;
+        stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o), lo);
+        stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12), hi);
     } else {
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++)
@@ -140,7 +140,7 @@ __device__ __forceinline__ void stage_coefficients(uint8_t *coef_lds, uint32_t n
     const uint32_t lastc = nchunks - 1u;
     v4u v[8];  // (plain vector type: an array of HIP's uint4 class would be kept in scratch by hipcc)
 #pragma unroll
-    for (uint32_t i = 0; i < 8; i++) v[i] = *addr(min(tid + NT * i, lastc));  // clamped: unconditional loads
+    for (uint32_t i = 0; i < 8; i++) v[i] = stream_load(addr(min(tid + NT * i, lastc)));  // clamped: unconditional loads
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++) {
         const uint32_t j = tid + NT * i;
@@ -323,8 +323,8 @@ struct F420 {
             uint32_t d0, d1, d2, d3, d4, d5;
             rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
             rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
-            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{d0, d1, d2};
-            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{d3, d4, d5};
+            stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o), v3u{d0, d1, d2});
+            stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12), v3u{d3, d4, d5});
         } else {
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++)  // unrolled + predicated: a runtime-indexed p[] would live in scratch
@@ -479,14 +479,14 @@ struct S420 {
 #pragma unroll
         for (uint32_t i = 0; i < 3; i++) {
             const uint32_t j = min(tid + NT * i, nl - 1u);  // clamped: unconditional loads
-            pre[i] = y0[j];
-            pre[3 + i] = y1[j];
+            pre[i] = stream_load(y0 + j);
+            pre[3 + i] = stream_load(y1 + j);
         }
 #pragma unroll
         for (uint32_t i = 0; i < 2; i++) {
             const uint32_t e = (uint32_t)min(max(cfirst + (int32_t)min(tid + NT * i, ncc - 1u), 0), cmax);
-            pre[6 + i] = cb[e];
-            pre[8 + i] = cr[e];
+            pre[6 + i] = stream_load(cb + e);
+            pre[8 + i] = stream_load(cr + e);
         }
         v4u *dst = reinterpret_cast<v4u *>(lds.stage);
         const uint32_t row = tid & 7u, b = tid >> 3;
@@ -644,7 +644,7 @@ struct F444 {
             const uint32_t j = min(tid + FUSED_NT * i, lastc);  // clamped: unconditional loads
             kk[i] = (j >= te8 ? 1u : 0u) + (j >= 2u * te8 ? 1u : 0u);
             rr[i] = j - kk[i] * te8;
-            v[i] = kk[i] == 0u ? c0[rr[i]] : (kk[i] == 1u ? c1[rr[i]] : c2[rr[i]]);
+            v[i] = stream_load((kk[i] == 0u ? c0 : (kk[i] == 1u ? c1 : c2)) + rr[i]);
         }
 #pragma unroll
         for (uint32_t i = 0; i < 6; i++)
@@ -709,8 +709,8 @@ struct F444 {
                     uint32_t d0, d1, d2, d3, d4, d5;
                     rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
                     rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
-                    *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off) = v3u{d0, d1, d2};
-                    *reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off + 12) = v3u{d3, d4, d5};
+                    stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off), v3u{d0, d1, d2});
+                    stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(out + off + 12), v3u{d3, d4, d5});
                 } else {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
@@ -756,7 +756,7 @@ struct FGray {
             if (oy >= g.out_h) break;
             const size_t off = (size_t)oy * g.out_w + ox;
             if (n == 8 && (off & 7u) == 0) {
-                *reinterpret_cast<JP_GLOBAL v2u *>(dst + off) = v2u{out[2 * row], out[2 * row + 1]};
+                stream_store(reinterpret_cast<JP_GLOBAL v2u *>(dst + off), v2u{out[2 * row], out[2 * row + 1]});
             } else {
 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++)
