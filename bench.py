@@ -38,8 +38,8 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="1080p-420", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests -m gpu -q -x -k "${AB_TESTS:-batch or smoke o
 tail -n 3 gpurun_out/pytest_gpu.log
 run() { # name, env...
   name=$1; shift
-  env "$@" bash -c 'timeout 600 python bench.py --steps 20 --warmup 3 --workload ${WL:-1080p-420} --no-cpu-baseline' > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
+  env "$@" bash -c 'timeout 600 python bench.py --steps ${STEPS:-500} --warmup ${WARM:-50} --workload ${WL:-1080p-420} --no-cpu-baseline' > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
   python -c "
 import json
 d=json.load(open('gpurun_out/ab_$name.json'))
