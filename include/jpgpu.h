@@ -162,6 +162,13 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
  * Higher classes select faster arithmetic that is bit-exact only on such data.
  * Default for never-uploaded images: 0. */
 int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane);
+/* Same, for one component; and the class of a buffer as jpgpu_batch_upload would compute it (pure host function,
+ * no device needed) — for feeders that stage coefficients themselves (jpgpu_pipeline_*, jpgpu_decoder.h). */
+int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, int range_class);
+int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t quantization_table[64]);
+/* Replace the quantization table given in the image descriptor (RowData.quantization_table of Worker::start,
+ * src/worker/mod.rs:18-22): feeders learn it only while parsing the stream. Takes effect at the next decode. */
+int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t quantization_table[64]);
 
 /* Enqueue the whole batch on `hip_stream` (a hipStream_t; NULL = the null stream). */
 int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream);

@@ -70,6 +70,46 @@ const uint8_t *jpgpu_decoder_icc_profile(jpgpu_decoder *d, size_t *len);
 int jpgpu_decoder_decode_coefficients(jpgpu_decoder *d, jpgpu_image_desc *desc, const int16_t **coefs,
                                       size_t *n_coefs);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pipeline: many JPEG streams -> pixels, host entropy decoding on a thread pool feeding the batch
+ * kernels ("multi-threaded per-image feeders").  The reference decodes one image per
+ * `Decoder` on the calling thread (src/decoder.rs:134-154, 293-295); a pipeline is N such decoders:
+ *   1. headers of all streams in parallel (read_info)            -> geometry -> one jpgpu_batch
+ *   2. entropy decoding in parallel, one image per task, rows written to pinned staging memory;
+ *      each image is sent to HBM (hipMemcpyAsync) as soon as its last scan is done, so the copy of
+ *      image i overlaps the Huffman decoding of the others
+ *   3. the batch kernels (fused when all images share a geometry), optional download.
+ * Per-image failures (src/error.rs) do not fail the call: query them per image.  The batch and its
+ * arenas are kept and reused while the sequence of geometries stays the same (fixed-size frames).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct jpgpu_pipeline jpgpu_pipeline;
+
+typedef struct jpgpu_pipeline_timings { /* wall-clock milliseconds of the last decode call */
+    double headers_ms, setup_ms, entropy_and_upload_ms, kernels_ms, download_ms, total_ms;
+    uint32_t threads, images_ok;
+    uint64_t jpeg_bytes, coefficient_bytes, pixel_bytes;
+} jpgpu_pipeline_timings;
+
+enum { JPGPU_PIPELINE_DOWNLOAD = 1u /* also copy the pixels to pinned host memory (jpgpu_pipeline_pixels_host) */ };
+
+/* n_threads 0 = one per hardware thread. */
+int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out);
+void jpgpu_pipeline_destroy(jpgpu_pipeline *p);
+const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p);
+/* The streams must stay valid during the call only.  Returns JPGPU_OK if the machinery worked, even
+ * when individual images failed. */
+int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n_images,
+                          uint32_t flags);
+/* Results of the last decode call, valid until the next one / destroy. */
+int jpgpu_pipeline_image_status(const jpgpu_pipeline *p, uint32_t image);        /* JPGPU_OK or the image's error */
+const char *jpgpu_pipeline_image_error(const jpgpu_pipeline *p, uint32_t image); /* its message */
+int jpgpu_pipeline_image_info(const jpgpu_pipeline *p, uint32_t image, jpgpu_image_info *info);
+size_t jpgpu_pipeline_pixel_bytes(const jpgpu_pipeline *p, uint32_t image);
+const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t image); /* HBM, NULL if the image failed */
+const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t image); /* only with JPGPU_PIPELINE_DOWNLOAD */
+const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p);                   /* "fused420", "generic", ... */
+int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t);
+
 #ifdef __cplusplus
 }
 #endif

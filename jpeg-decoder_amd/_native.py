@@ -51,6 +51,15 @@ class ImageDesc(C.Structure):
     ]
 
 
+class PipelineTimings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "kernels_ms", "download_ms", "total_ms")] + \
+               [("threads", C.c_uint32), ("images_ok", C.c_uint32), ("jpeg_bytes", C.c_uint64), ("coefficient_bytes", C.c_uint64),
+                ("pixel_bytes", C.c_uint64)]
+
+
+PIPELINE_DOWNLOAD = 1
+
+
 class ImageInfoStruct(C.Structure):
     _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("pixel_format", C.c_int32), ("coding_process", C.c_int32)]
 
@@ -98,6 +107,9 @@ _PROTOS = {
     "jpgpu_batch_out_arena": (C.c_void_p, [C.c_void_p]),
     "jpgpu_batch_upload": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
     "jpgpu_batch_set_range_hint": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
+    "jpgpu_batch_set_range_class": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "jpgpu_range_class": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "jpgpu_batch_set_quantization_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "jpgpu_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jpgpu_batch_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jpgpu_batch_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -118,6 +130,18 @@ _PROTOS = {
     "jpgpu_decoder_xmp_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "jpgpu_decoder_icc_profile": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "jpgpu_decoder_decode_coefficients": (C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "jpgpu_pipeline_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "jpgpu_pipeline_destroy": (None, [C.c_void_p]),
+    "jpgpu_pipeline_last_error": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_pipeline_decode": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32]),
+    "jpgpu_pipeline_image_status": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "jpgpu_pipeline_image_error": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "jpgpu_pipeline_image_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(ImageInfoStruct)]),
+    "jpgpu_pipeline_pixel_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "jpgpu_pipeline_pixels_device": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "jpgpu_pipeline_pixels_host": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "jpgpu_pipeline_kernel_path": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_pipeline_last_timings": (C.c_int, [C.c_void_p, C.POINTER(PipelineTimings)]),
 }
 
 

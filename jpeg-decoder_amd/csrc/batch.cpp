@@ -42,6 +42,7 @@ struct jpgpu_batch {
     uint32_t max_blocks = 0, max_w = 0, max_h = 0;
     bool scales[9] = {false, false, false, false, false, false, false, false, false};
     bool jobs_dirty = true;
+    bool qt_dirty = false;
     FusedPlan fused;  // valid when path != "generic"
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -88,6 +89,14 @@ static int batch_refresh_jobs(jpgpu_batch *b) {
     if (b->path != "generic") {
         int rc = fused_bind(b->fused, b->d_coef, b->d_out, b->d_qt, b->coef_off, b->out_off, b->sane, b->err);
         if (rc) return rc;
+    }
+    if (b->qt_dirty) {
+        std::vector<uint16_t> qt((size_t)n * 4 * 64, 1);
+        for (uint32_t i = 0; i < n; i++)
+            for (uint32_t c = 0; c < b->descs[i].ncomp; c++)
+                memcpy(&qt[((size_t)i * 4 + c) * 64], b->descs[i].quantization_tables[c], 128);
+        B_HIP(hipMemcpy(b->d_qt, qt.data(), qt.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        b->qt_dirty = false;
     }
     b->jobs_dirty = false;
     return JPGPU_OK;
@@ -235,6 +244,44 @@ int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane) {
     return JPGPU_OK;
 }
 
+int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, int range_class) {
+    if (!b || image >= b->descs.size() || comp >= 4) return JPGPU_ERR_FORMAT;
+    b->sane[image * 4 + comp] = (uint8_t)(range_class & 3);
+    b->jobs_dirty = true;
+    return JPGPU_OK;
+}
+
+// range scan (part of H2D staging): per-position |c|*q must stay below 2^15 for the 24-bit / packed paths to be
+// exact, and block-column sums below 5900 for the dot2 row pass (pixel_math.hpp idct8x8<ARITH>)
+int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t q[64]) {
+    if (!coefficients || !q) return 0;
+    int32_t qq[64];
+    for (int k = 0; k < 64; k++) qq[k] = q[k];
+    int32_t max_abs = 0, max_col = 0;
+    const size_t nblk = len / 64;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        const int16_t *p = coefficients + blk * 64;
+        int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 64; k++) {
+            int32_t v = (int32_t)p[k] * qq[k];
+            v = v < 0 ? -v : v;
+            max_abs = v > max_abs ? v : max_abs;
+            col[k & 7] += v;
+        }
+        for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? col[i] : max_col;
+    }
+    if (max_abs < (1 << 15)) return (max_col <= 5900) ? 3 : 1;
+    return 0;
+}
+
+int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t q[64]) {
+    if (!b || !q || image >= b->descs.size() || comp >= b->descs[image].ncomp) return JPGPU_ERR_FORMAT;
+    memcpy(b->descs[image].quantization_tables[comp], q, 128);
+    b->qt_dirty = true;
+    b->jobs_dirty = true;
+    return JPGPU_OK;
+}
+
 int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int16_t *coefficients, size_t len) {
     if (!b) return JPGPU_ERR_FORMAT;
     if (image >= b->descs.size() || comp >= b->descs[image].ncomp || !coefficients)
@@ -248,25 +295,8 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
     // range scan (part of H2D staging): per-position max |c| times q must stay below 2^15 for
     // the 24-bit multiply path to be exact (pixel_math.hpp idct8x8<SANE>)
     uint8_t sane = 0;  // bit0: every |c*q| < 2^15; bit1: additionally every column sum of |c*q| <= 5900
-    if (!(b->flags & JPGPU_BATCH_ASSUME_HOSTILE)) {
-        const uint16_t *q = b->descs[image].quantization_tables[comp];
-        int32_t qq[64];
-        for (int k = 0; k < 64; k++) qq[k] = q[k];
-        int32_t max_abs = 0, max_col = 0;
-        const size_t nblk = len / 64;
-        for (size_t blk = 0; blk < nblk; blk++) {
-            const int16_t *p = coefficients + blk * 64;
-            int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int k = 0; k < 64; k++) {
-                int32_t v = (int32_t)p[k] * qq[k];
-                v = v < 0 ? -v : v;
-                max_abs = v > max_abs ? v : max_abs;
-                col[k & 7] += v;
-            }
-            for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? col[i] : max_col;
-        }
-        if (max_abs < (1 << 15)) sane = (max_col <= 5900) ? 3 : 1;
-    }
+    if (!(b->flags & JPGPU_BATCH_ASSUME_HOSTILE))
+        sane = (uint8_t)jpgpu_range_class(coefficients, len, b->descs[image].quantization_tables[comp]);
     if (b->sane[image * 4 + comp] != sane) {
         b->sane[image * 4 + comp] = sane;
         b->jobs_dirty = true;

@@ -235,7 +235,8 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
         // 256 MiB Infinity Cache did not pay on MI355X (profiles/round1: 16/32/64/128-image chunks
         // were 23/9/4/1 % slower than the whole 256-image batch).
         const uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
-        const size_t shm = F420Lds::total_bytes(g.tx);
+        size_t shm = F420Lds::total_bytes(g.tx);
+        if (const char *pe = getenv("JPGPU_F420_LDS")) shm = std::max(shm, (size_t)atoi(pe));  // experiment knob: pad the workgroup's LDS claim
         // The chroma pass is HBM-bound and the main pass VALU-bound (profiles/round1), so with
         // JPGPU_STREAMS=2 the chunks alternate between two internal streams: the chroma pass of one
         // chunk can share the machine with the main pass of another.  Forked from / joined to the

@@ -52,7 +52,7 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             why = "inconsistent block grid";
             return FUSED_NONE;
         }
-        tx_max = strip420 ? (s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max)) : (f420_tx_max <= 32u ? 32u : F420_TX_MAX);
+        tx_max = strip420 ? (s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max)) : (f420_tx_max <= 32u ? 32u : (f420_tx_max < F420_TX_MAX ? f420_tx_max : F420_TX_MAX));
         g.strip = strip420 ? 1u : 0u;
         if (strip420) name = "fused420s";
     } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&

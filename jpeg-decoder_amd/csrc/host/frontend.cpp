@@ -703,6 +703,7 @@ struct Frontend::Impl {
             if (finished[i]) {
                 const int ci = scan.component_indices[i];
                 memcpy(plane_qt[ci], qt[comps[i].quantization_table_index], 128);
+                sink.frame_slot_hint((uint32_t)i, (uint32_t)ci);
                 sink.start((uint32_t)i, comps[i], qt[comps[i].quantization_table_index]);
             }
 
@@ -886,6 +887,7 @@ struct Frontend::Impl {
                 const jpgpu_component &c = f.components[i];
                 if (!has_qt[c.quantization_table_index]) continue;
                 memcpy(plane_qt[i], qt[c.quantization_table_index], 128);
+                sink->frame_slot_hint((uint32_t)i, (uint32_t)i);
                 sink->start((uint32_t)i, c, qt[c.quantization_table_index]);
                 const size_t per_row = (size_t)c.block_width * c.vertical_sampling_factor * 64;
                 for (uint32_t my = 0; my < f.mcu_h; my++) {

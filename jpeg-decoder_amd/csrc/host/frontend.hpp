@@ -28,6 +28,9 @@ struct DecodeError {
 class RowSink {
 public:
     virtual ~RowSink() {}
+    // called right before start(index, ...): the frame component this worker index will deliver (finish()'s frame_slot),
+    // for sinks that place rows at their final address instead of collecting them
+    virtual void frame_slot_hint(uint32_t /*index*/, uint32_t /*frame_slot*/) {}
     virtual void start(uint32_t index, const jpgpu_component &component, const uint16_t qt[64]) = 0;
     virtual void append_row(uint32_t index, const int16_t *coefficients, size_t len) = 0;
     virtual void finish(uint32_t index, uint32_t frame_slot) = 0;  // get_result + keep for compute_image

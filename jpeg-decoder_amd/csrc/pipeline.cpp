@@ -1,0 +1,459 @@
+// pipeline.cpp — jpgpu_pipeline_* (include/jpgpu_decoder.h): many JPEG streams -> pixels.
+// Host entropy decoding (csrc/host/frontend.cpp, the restatement of src/decoder.rs:794-1298) on a thread pool,
+// one image per task, rows staged in pinned memory, per-image async H2D, then the batch kernels (batch.cpp).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "host/frontend.hpp"
+#include "host_common.hpp"
+
+using jpgpu::host::DecodeError;
+using jpgpu::host::Frontend;
+using jpgpu::host::RowSink;
+
+namespace {
+
+constexpr uint32_t kCopyStreams = 4;
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Minimal fork-join pool: run(n, fn) calls fn(i) for i in [0, n) on the workers and returns when all are done.
+class Pool {
+public:
+    explicit Pool(uint32_t n) {
+        for (uint32_t t = 0; t < n; t++) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    uint32_t size() const { return (uint32_t)workers_.size(); }
+    void run(uint32_t n, const std::function<void(uint32_t)> &fn) {
+        if (n == 0) return;
+        std::unique_lock<std::mutex> g(m_);
+        fn_ = &fn;
+        n_ = n;
+        next_.store(0);
+        pending_ = n;
+        generation_++;
+        cv_work_.notify_all();
+        cv_done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(uint32_t)> *fn;
+            uint32_t n;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_work_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                fn = fn_;
+                n = n_;
+            }
+            uint32_t done = 0;
+            for (;;) {
+                const uint32_t i = next_.fetch_add(1);
+                if (i >= n) break;
+                (*fn)(i);
+                done++;
+            }
+            if (done) {
+                std::lock_guard<std::mutex> g(m_);
+                pending_ -= done;
+                if (pending_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(uint32_t)> *fn_ = nullptr;
+    uint32_t n_ = 0, pending_ = 0;
+    std::atomic<uint32_t> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
+// Worker of one image: rows go straight to their final place in the pinned staging arena (the frame slot of a
+// worker index is known from frame_slot_hint), so a coefficient is written once on the host.
+class StageSink : public RowSink {
+public:
+    StageSink(uint8_t *stage, const size_t (&off)[4], const size_t (&len)[4]) : stage_(stage) {
+        for (int c = 0; c < 4; c++) {
+            off_[c] = off[c];
+            len_[c] = len[c];
+            range_[c] = 0;
+            done_[c] = false;
+            slot_of_[c] = (uint32_t)c;
+            written_[c] = 0;
+        }
+    }
+    void frame_slot_hint(uint32_t index, uint32_t slot) override { slot_of_[index] = slot; }
+    void start(uint32_t index, const jpgpu_component &, const uint16_t qt[64]) override {
+        written_[index] = 0;
+        memcpy(qt_[index], qt, 128);
+    }
+    void append_row(uint32_t index, const int16_t *co, size_t len) override {
+        const uint32_t slot = slot_of_[index];
+        const size_t room = len_[slot] - written_[index], bytes = len * sizeof(int16_t);
+        const size_t n = bytes < room ? bytes : room;  // rows past the plane are dropped like the Worker drops them
+        memcpy(stage_ + off_[slot] + written_[index], co, n);
+        written_[index] += n;
+    }
+    void finish(uint32_t index, uint32_t slot) override {
+        if (slot != slot_of_[index]) throw DecodeError{JPGPU_ERR_INTERNAL, "pipeline: plane finished under another frame slot"};
+        // a scan may end early (src/decoder.rs:1000-1006 breaks out of the MCU loops at the image edge): the
+        // plane keeps zeros where no row was appended, like the Worker's zero-initialised plane
+        if (written_[index] < len_[slot]) memset(stage_ + off_[slot] + written_[index], 0, len_[slot] - written_[index]);
+        range_[slot] = jpgpu_range_class(reinterpret_cast<const int16_t *>(stage_ + off_[slot]), len_[slot] / sizeof(int16_t), qt_[index]);
+        memcpy(slot_qt_[slot], qt_[index], 128);
+        done_[slot] = true;
+    }
+    int range_class(uint32_t slot) const { return range_[slot]; }
+    bool done(uint32_t slot) const { return done_[slot]; }
+    const uint16_t *qt(uint32_t slot) const { return slot_qt_[slot]; }
+
+private:
+    uint8_t *stage_;
+    size_t off_[4], len_[4], written_[4];
+    uint32_t slot_of_[4];
+    uint16_t qt_[4][64], slot_qt_[4][64];
+    int range_[4];
+    bool done_[4];
+};
+
+// Finished images are handed to one uploader thread: hipMemcpyAsync calls from hundreds of threads contend in the
+// runtime, one caller keeps the copy queues busy.
+struct UploadQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<uint32_t> ready;  // image indices
+    uint32_t closed = 0;          // images that will never be uploaded (failed) + uploaded ones are counted by the consumer
+    void push(uint32_t i) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            ready.push_back(i);
+        }
+        cv.notify_one();
+    }
+    void skip() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            closed++;
+        }
+        cv.notify_one();
+    }
+};
+
+bool same_geometry(const jpgpu_image_desc &a, const jpgpu_image_desc &b) {
+    if (a.ncomp != b.ncomp || a.out_w != b.out_w || a.out_h != b.out_h || a.color_transform != b.color_transform) return false;
+    for (uint32_t c = 0; c < a.ncomp; c++)
+        if (memcmp(&a.components[c], &b.components[c], sizeof(jpgpu_component)) != 0) return false;
+    return true;
+}
+
+}  // namespace
+
+struct jpgpu_pipeline {
+    int device = 0;
+    std::string err;
+    std::unique_ptr<Pool> pool;
+    // results of the last call
+    uint32_t n = 0;
+    std::vector<std::unique_ptr<Frontend>> fes;
+    std::vector<int> status;
+    std::vector<std::string> errors;
+    std::vector<jpgpu_image_info> infos;
+    std::vector<int32_t> slot;  // image -> index in the batch, -1 if it never got there
+    // the batch of the current geometry sequence
+    jpgpu_batch *batch = nullptr;
+    std::vector<jpgpu_image_desc> descs;
+    uint8_t *h_coef = nullptr, *h_out = nullptr;
+    size_t h_coef_bytes = 0, h_out_bytes = 0;
+    hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t compute = nullptr;
+    jpgpu_pipeline_timings t{};
+};
+
+static void drop_batch(jpgpu_pipeline *p) {
+    if (p->batch) jpgpu_batch_destroy(p->batch);
+    p->batch = nullptr;
+    if (p->h_coef) (void)hipHostFree(p->h_coef);
+    if (p->h_out) (void)hipHostFree(p->h_out);
+    p->h_coef = p->h_out = nullptr;
+    p->h_coef_bytes = p->h_out_bytes = 0;
+    p->descs.clear();
+}
+
+#define P_HIP(call)                                                                                              \
+    do {                                                                                                         \
+        hipError_t _e = (call);                                                                                  \
+        if (_e != hipSuccess) return jpgpu::set_err(p->err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" {
+
+int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) {
+    if (!out) return JPGPU_ERR_FORMAT;
+    jpgpu_pipeline *p = new jpgpu_pipeline();
+    *out = p;  // returned even on failure so that last_error can be read
+    p->device = device;
+    int rc = jpgpu::use_device(device, p->err);
+    if (rc) return rc;  // no usable MI355X: there is no CPU fallback for the pixel work
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    p->pool.reset(new Pool(n_threads));
+    for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
+    P_HIP(hipStreamCreateWithFlags(&p->compute, hipStreamNonBlocking));
+    return JPGPU_OK;
+}
+
+void jpgpu_pipeline_destroy(jpgpu_pipeline *p) {
+    if (!p) return;
+    std::string e;
+    if (jpgpu::use_device(p->device, e) == JPGPU_OK) {
+        (void)hipDeviceSynchronize();
+        drop_batch(p);
+        for (uint32_t k = 0; k < kCopyStreams; k++)
+            if (p->copy_streams[k]) (void)hipStreamDestroy(p->copy_streams[k]);
+        if (p->compute) (void)hipStreamDestroy(p->compute);
+    }
+    delete p;
+}
+
+const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p) { return p ? p->err.c_str() : ""; }
+
+int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
+    if (!p || !p->pool || (n && (!data || !len))) return JPGPU_ERR_FORMAT;
+    int rc = jpgpu::use_device(p->device, p->err);
+    if (rc) return rc;
+    const double t0 = now_ms();
+    p->n = n;
+    p->fes.clear();
+    p->fes.resize(n);
+    p->status.assign(n, JPGPU_ERR_INTERNAL);
+    p->errors.assign(n, std::string());
+    p->infos.assign(n, jpgpu_image_info{});
+    p->slot.assign(n, -1);
+    p->t = jpgpu_pipeline_timings{};
+    p->t.threads = p->pool->size();
+    std::vector<jpgpu_image_desc> cand(n);
+
+    // 1. headers
+    p->pool->run(n, [&](uint32_t i) {
+        try {
+            p->fes[i].reset(new Frontend(data[i], len[i]));
+            Frontend &fe = *p->fes[i];
+            fe.read_info();
+            p->infos[i] = fe.info();
+            jpgpu_image_desc d;
+            memset(&d, 0, sizeof(d));
+            d.ncomp = fe.ncomp();
+            for (uint32_t c = 0; c < d.ncomp; c++) {
+                d.components[c] = fe.components()[c];
+                for (int k = 0; k < 64; k++) d.quantization_tables[c][k] = 1;  // set once the scans are parsed
+            }
+            d.out_w = fe.output_width();
+            d.out_h = fe.output_height();
+            d.color_transform = fe.color_transform();
+            cand[i] = d;
+            p->status[i] = JPGPU_OK;
+        } catch (const DecodeError &e) {
+            p->status[i] = e.code;
+            p->errors[i] = e.message;
+        } catch (const std::exception &e) {
+            p->status[i] = JPGPU_ERR_INTERNAL;
+            p->errors[i] = e.what();
+        }
+    });
+    const double t1 = now_ms();
+
+    // 2. batch of the images that have a frame (kept while the geometry sequence repeats)
+    std::vector<jpgpu_image_desc> descs;
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK) {
+            p->slot[i] = (int32_t)descs.size();
+            descs.push_back(cand[i]);
+        }
+    if (descs.empty()) {
+        p->t.headers_ms = t1 - t0;
+        p->t.total_ms = now_ms() - t0;
+        return JPGPU_OK;
+    }
+    bool reuse = p->batch && descs.size() == p->descs.size();
+    for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], p->descs[k]);
+    if (!reuse) {
+        drop_batch(p);
+        rc = jpgpu_batch_create(p->device, descs.data(), (uint32_t)descs.size(), JPGPU_BATCH_DEFAULT, &p->batch);
+        if (rc) {
+            p->err = p->batch ? jpgpu_batch_last_error(p->batch) : "batch_create";
+            // a frame the pixel backend refuses (e.g. an impossible sampling combination) fails every image of
+            // the call the same way the reference fails it in compute_image
+            for (uint32_t i = 0; i < n; i++)
+                if (p->status[i] == JPGPU_OK) {
+                    p->status[i] = rc;
+                    p->errors[i] = p->err;
+                    p->slot[i] = -1;
+                }
+            drop_batch(p);
+            p->t.total_ms = now_ms() - t0;
+            return JPGPU_OK;
+        }
+        p->descs = descs;
+        p->h_coef_bytes = jpgpu_batch_coef_arena_bytes(p->batch);
+        P_HIP(hipHostMalloc((void **)&p->h_coef, p->h_coef_bytes, hipHostMallocDefault));
+    }
+    if ((flags & JPGPU_PIPELINE_DOWNLOAD) && !p->h_out) {
+        p->h_out_bytes = jpgpu_batch_out_arena_bytes(p->batch);
+        P_HIP(hipHostMalloc((void **)&p->h_out, p->h_out_bytes, hipHostMallocDefault));
+    }
+    uint8_t *d_coef = (uint8_t *)jpgpu_batch_coef_arena(p->batch);
+    const double t2 = now_ms();
+
+    // 3. entropy decoding (pool) + per-image upload (one uploader thread)
+    std::atomic<uint64_t> jpeg_bytes{0}, coef_bytes{0};
+    std::atomic<int> hip_failed{0};
+    UploadQueue q;
+    const uint32_t n_jobs = (uint32_t)descs.size();
+    std::vector<size_t> first_of(n), bytes_of(n);
+    std::thread uploader([&] {
+        std::string e;
+        if (jpgpu::use_device(p->device, e) != JPGPU_OK) hip_failed.store(1);
+        uint32_t handled = 0, k = 0;
+        std::vector<uint32_t> take;
+        while (handled < n_jobs) {
+            {
+                std::unique_lock<std::mutex> g(q.m);
+                q.cv.wait(g, [&] { return !q.ready.empty() || q.closed > 0; });
+                take.swap(q.ready);
+                handled += q.closed;
+                q.closed = 0;
+            }
+            for (uint32_t i : take) {
+                if (!hip_failed.load() &&
+                    hipMemcpyAsync(d_coef + first_of[i], p->h_coef + first_of[i], bytes_of[i], hipMemcpyHostToDevice,
+                                   p->copy_streams[k++ % kCopyStreams]) != hipSuccess)
+                    hip_failed.store(1);
+                handled++;
+            }
+            take.clear();
+        }
+    });
+    p->pool->run(n, [&](uint32_t i) {
+        if (p->status[i] != JPGPU_OK) return;
+        const uint32_t bi = (uint32_t)p->slot[i];
+        Frontend &fe = *p->fes[i];
+        size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
+        const uint32_t nc = fe.ncomp();
+        for (uint32_t c = 0; c < nc; c++) {
+            off[c] = jpgpu_batch_coef_offset(p->batch, bi, c);
+            ln[c] = jpgpu_batch_coef_bytes(p->batch, bi, c);
+        }
+        try {
+            StageSink sink(p->h_coef, off, ln);
+            fe.decode_to(sink);
+            for (uint32_t c = 0; c < nc; c++)
+                if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
+            for (uint32_t c = 0; c < nc; c++) {
+                jpgpu_batch_set_quantization_table(p->batch, bi, c, sink.qt(c));
+                jpgpu_batch_set_range_class(p->batch, bi, c, sink.range_class(c));
+            }
+            // planes of one image are consecutive in the arena: one copy
+            first_of[i] = off[0];
+            bytes_of[i] = off[nc - 1] + ln[nc - 1] - off[0];
+            jpeg_bytes += len[i];
+            coef_bytes += bytes_of[i];
+            q.push(i);
+        } catch (const DecodeError &e) {
+            p->status[i] = e.code;
+            p->errors[i] = e.message;
+            q.skip();
+        } catch (const std::exception &e) {
+            p->status[i] = JPGPU_ERR_INTERNAL;
+            p->errors[i] = e.what();
+            q.skip();
+        }
+    });
+    uploader.join();
+    if (hip_failed.load()) return jpgpu::set_err(p->err, JPGPU_ERR_IO, "hipMemcpyAsync (coefficient upload) failed");
+    for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamSynchronize(p->copy_streams[k]));
+    const double t3 = now_ms();
+
+    // 4. pixels
+    rc = jpgpu_batch_decode(p->batch, p->compute);
+    if (rc) return jpgpu::set_err(p->err, rc, "%s", jpgpu_batch_last_error(p->batch));
+    P_HIP(hipStreamSynchronize(p->compute));
+    const double t4 = now_ms();
+    uint64_t pixel_bytes = 0;
+    uint32_t ok = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK) {
+            ok++;
+            pixel_bytes += jpgpu_batch_out_bytes(p->batch, (uint32_t)p->slot[i]);
+        }
+    if (flags & JPGPU_PIPELINE_DOWNLOAD) {
+        const uint8_t *d_out = (const uint8_t *)jpgpu_batch_out_arena(p->batch);
+        P_HIP(hipMemcpyAsync(p->h_out, d_out, p->h_out_bytes, hipMemcpyDeviceToHost, p->compute));
+        P_HIP(hipStreamSynchronize(p->compute));
+    }
+    const double t5 = now_ms();
+    p->t.headers_ms = t1 - t0;
+    p->t.setup_ms = t2 - t1;
+    p->t.entropy_and_upload_ms = t3 - t2;
+    p->t.kernels_ms = t4 - t3;
+    p->t.download_ms = t5 - t4;
+    p->t.total_ms = t5 - t0;
+    p->t.images_ok = ok;
+    p->t.jpeg_bytes = jpeg_bytes.load();
+    p->t.coefficient_bytes = coef_bytes.load();
+    p->t.pixel_bytes = pixel_bytes;
+    return JPGPU_OK;
+}
+
+int jpgpu_pipeline_image_status(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->status[i] : JPGPU_ERR_FORMAT; }
+const char *jpgpu_pipeline_image_error(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->errors[i].c_str() : ""; }
+int jpgpu_pipeline_image_info(const jpgpu_pipeline *p, uint32_t i, jpgpu_image_info *info) {
+    if (!p || i >= p->n || !info || !p->fes[i] || !p->fes[i]->has_frame()) return JPGPU_ERR_FORMAT;
+    *info = p->infos[i];
+    return JPGPU_OK;
+}
+size_t jpgpu_pipeline_pixel_bytes(const jpgpu_pipeline *p, uint32_t i) {
+    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->slot[i] < 0 || !p->batch) return 0;
+    return jpgpu_batch_out_bytes(p->batch, (uint32_t)p->slot[i]);
+}
+const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t i) {
+    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->slot[i] < 0 || !p->batch) return nullptr;
+    return (const uint8_t *)jpgpu_batch_out_arena(p->batch) + jpgpu_batch_out_offset(p->batch, (uint32_t)p->slot[i]);
+}
+const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t i) {
+    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->slot[i] < 0 || !p->batch || !p->h_out) return nullptr;
+    return p->h_out + jpgpu_batch_out_offset(p->batch, (uint32_t)p->slot[i]);
+}
+const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return (p && p->batch) ? jpgpu_batch_path(p->batch) : ""; }
+int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t) {
+    if (!p || !t) return JPGPU_ERR_FORMAT;
+    *t = p->t;
+    return JPGPU_OK;
+}
+
+}  // extern "C"

@@ -38,3 +38,10 @@ def check(status, message=b""):
     if isinstance(message, bytes):
         message = message.decode(errors="replace")
     raise _BY_STATUS.get(status, Error)(message or N.lib().jpgpu_status_string(status).decode())
+
+
+def error_for_status(status, message=b""):
+    """The exception `check` would raise, as a value (per-image results of a pipeline)."""
+    if isinstance(message, bytes):
+        message = message.decode(errors="replace")
+    return _BY_STATUS.get(status, Error)(message or N.lib().jpgpu_status_string(status).decode())

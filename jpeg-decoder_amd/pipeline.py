@@ -1,0 +1,74 @@
+"""Many JPEG streams -> pixels: ``Pipeline(device, threads).decode([bytes, ...])``.
+
+N reference ``Decoder``s (src/decoder.rs:134-154, 293-295) run as one pipeline: headers and entropy decoding on a host
+thread pool (one image per task), per-image asynchronous upload, one batch of kernels on the MI355X
+(include/jpgpu_decoder.h, jpgpu_pipeline_*).  A failed image yields its ``Error`` in the result list instead of
+pixels, the others are unaffected — as with independent decoders."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .decoder import CODING_PROCESSES, PIXEL_FORMATS, ImageInfo
+from .error import check, error_for_status
+
+
+class Pipeline:
+    def __init__(self, device=0, threads=0):
+        self._h = C.c_void_p()
+        st = N.lib().jpgpu_pipeline_create(device, threads, C.byref(self._h))
+        if st:
+            msg = N.lib().jpgpu_pipeline_last_error(self._h) if self._h else b"jpgpu_pipeline_create"
+            self.close()
+            check(st, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().jpgpu_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def decode(self, streams, download=True):
+        """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
+        ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``)."""
+        L = N.lib()
+        bufs = [bytes(s.read() if hasattr(s, "read") else s) for s in streams]
+        n = len(bufs)
+        keep = [(C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0") for b in bufs]
+        ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(k) for k in keep])
+        lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+        st = L.jpgpu_pipeline_decode(self._h, ptrs, lens, n, N.PIPELINE_DOWNLOAD if download else 0)
+        check(st, L.jpgpu_pipeline_last_error(self._h) if st else b"")
+        out = []
+        for i in range(n):
+            s = L.jpgpu_pipeline_image_status(self._h, i)
+            if s:
+                out.append(error_for_status(s, L.jpgpu_pipeline_image_error(self._h, i)))
+                continue
+            nbytes = L.jpgpu_pipeline_pixel_bytes(self._h, i)
+            if download:
+                p = L.jpgpu_pipeline_pixels_host(self._h, i)
+                out.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy() if nbytes else
+                           np.zeros(0, np.uint8))
+            else:
+                out.append(nbytes)
+        return out
+
+    def info(self, image):
+        i = N.ImageInfoStruct()
+        if N.lib().jpgpu_pipeline_image_info(self._h, image, C.byref(i)):
+            return None
+        return ImageInfo(i.width, i.height, PIXEL_FORMATS[i.pixel_format], CODING_PROCESSES[i.coding_process])
+
+    def device_pointer(self, image):
+        return N.lib().jpgpu_pipeline_pixels_device(self._h, image)
+
+    @property
+    def kernel_path(self):
+        return N.lib().jpgpu_pipeline_kernel_path(self._h).decode()
+
+    def timings(self):
+        t = N.PipelineTimings()
+        check(N.lib().jpgpu_pipeline_last_timings(self._h, C.byref(t)), b"timings")
+        return {name: getattr(t, name) for name, _ in N.PipelineTimings._fields_}

@@ -56,3 +56,42 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(dp, f), errors="replace").read()
                 assert "liboracle" not in text and "import oracle" not in text and "jpeg_oracle.h" not in text, os.path.join(dp, f)
+
+
+def test_range_class_host_function_matches_its_definition():
+    """jpgpu_range_class (pure host code in the library): 0 hostile, 1 every |c*q| < 2^15, 3 additionally every block
+    column's sum of |c*q| <= 5900 (include/jpgpu.h)."""
+    import numpy as np
+    lib = J.lib()
+    rng = np.random.default_rng(5)
+
+    def cls(c, q):
+        c = np.ascontiguousarray(c, np.int16)
+        q = np.ascontiguousarray(q, np.uint16)
+        return lib.jpgpu_range_class(c.ctypes.data, c.size, q.ctypes.data)
+
+    def want(c, q):
+        s = np.abs(c.astype(np.int64).reshape(-1, 8, 8) * q.astype(np.int64).reshape(1, 8, 8))
+        if s.max(initial=0) >= 1 << 15:
+            return 0
+        return 3 if s.sum(axis=1).max(initial=0) <= 5900 else 1
+
+    q = rng.integers(1, 40, 64).astype(np.uint16)
+    for _ in range(200):
+        amp = int(rng.choice([3, 20, 200, 3000, 32767]))
+        c = rng.integers(-amp, amp + 1, 64 * 7).astype(np.int16)
+        assert cls(c, q) == want(c, q)
+    one = np.zeros(64, np.int16); one[8] = 5900; ones = np.ones(64, np.uint16)
+    assert cls(one, ones) == 3
+    one[16] = 1
+    assert cls(one, ones) == 1
+    one[:] = 0; one[5] = 32767
+    assert cls(one, ones) == 1 and cls(one, ones * 2) == 0
+    assert cls(np.zeros(0, np.int16), ones) == 3
+
+
+def test_pipeline_needs_a_device():
+    if J.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(J.NoDeviceError):
+        J.Pipeline()

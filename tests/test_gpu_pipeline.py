@@ -1,0 +1,97 @@
+"""jpgpu_pipeline_* (threaded host entropy decoding feeding the batch kernels) on the MI355X: every stream of a call
+must come out exactly as its own Decoder would produce it — pixels or the same kind of error."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import refimages as R
+
+pytestmark = pytest.mark.gpu
+J = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _load():
+    global J
+    import jpeg_decoder_amd as pkg
+    J = pkg
+    assert J.device_count() >= 1
+
+
+def _expect(data):
+    try:
+        return O.decode(data).pixels
+    except O.OracleError as e:
+        return e
+
+
+def _check(names, files, out):
+    for n, f, got in zip(names, files, out):
+        want = _expect(f)
+        if isinstance(want, O.OracleError):
+            assert isinstance(got, J.Error), n
+            assert got.kind == want.kind, (n, got, want)
+        else:
+            assert not isinstance(got, Exception), (n, got)
+            assert np.array_equal(got, want), n
+
+
+def test_pipeline_mixed_files_one_call():
+    """Everything the reference's reftest / bench / crash corpora hold, in ONE call: heterogeneous geometries,
+    progressive, CMYK, 16-bit-less oddities, hostile streams; a failing stream must not disturb its neighbours."""
+    names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
+    files = [open(n, "rb").read() for n in names]
+    with_errors = sum(isinstance(_expect(f), O.OracleError) for f in files)
+    assert with_errors >= 3 and len(files) - with_errors >= 40
+    p = J.Pipeline(threads=8)
+    out = p.decode(files)
+    assert p.kernel_path == "generic"
+    _check(names, files, out)
+    t = p.timings()
+    assert t["images_ok"] == len(files) - with_errors and t["total_ms"] > 0
+    # the same pipeline object, different batch afterwards
+    out2 = p.decode(files[:5])
+    _check(names[:5], files[:5], out2)
+    p.close()
+
+
+@pytest.mark.parametrize("name,path", [("benches/tower.jpg", "fused444"), ("benches/tower_grayscale.jpg", "fusedgray"),
+                                       ("benches/tower_progressive.jpg", "fused444"),
+                                       ("reftest/mozilla/jpg-size-32x32.jpg", None)])
+def test_pipeline_same_geometry_uses_fused_kernels_and_reuses_the_batch(name, path):
+    data = open(os.path.join(R.GOLDEN, name), "rb").read()
+    want = O.decode(data).pixels
+    p = J.Pipeline(threads=4)
+    for rounds in range(3):  # second and third call reuse arenas and pinned staging
+        out = p.decode([data] * 9)
+        if path:
+            assert p.kernel_path == path
+        for got in out:
+            assert np.array_equal(got, want)
+    # one broken stream in the middle: same geometry list is impossible -> new batch, others still fine
+    bad = data[: len(data) // 2]
+    out = p.decode([data, bad, data])
+    assert np.array_equal(out[0], want) and np.array_equal(out[2], want)
+    wb = _expect(bad)
+    if isinstance(wb, O.OracleError):
+        assert isinstance(out[1], J.Error) and out[1].kind == wb.kind
+    else:
+        assert np.array_equal(out[1], wb)
+    p.close()
+
+
+def test_pipeline_device_resident_output_and_empty_call():
+    data = open(os.path.join(R.GOLDEN, "benches", "tower.jpg"), "rb").read()
+    p = J.Pipeline(threads=2)
+    assert p.decode([]) == []
+    sizes = p.decode([data, data], download=False)
+    assert sizes == [512 * 512 * 3] * 2 and p.device_pointer(0) and p.device_pointer(1) != p.device_pointer(0)
+    assert p.info(0).width == 512 and p.info(1).pixel_format == "RGB24"
+    # garbage only
+    out = p.decode([b"not a jpeg", b""])
+    assert all(isinstance(o, J.Error) for o in out)
+    p.close()

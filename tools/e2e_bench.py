@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""End-to-end rate of jpgpu_pipeline_* (JPEG bytes in host memory -> RGB, PCIe-inclusive): the number DESIGN.md §5 quotes
+next to the kernel-only bench value.  Needs Pillow only to WRITE the synthetic input files (libjpeg-turbo encoder)."""
+import argparse
+import io
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=256)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--quality", type=int, default=85)
+    ap.add_argument("--subsampling", default="4:2:0")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--no-download", action="store_true")
+    ap.add_argument("--progressive", action="store_true")
+    args = ap.parse_args()
+    from PIL import Image
+    import synth
+    import jpeg_decoder_amd as J
+    distinct = []
+    for k in range(4):  # a few different images, repeated
+        rgb = synth.synthetic_rgb(args.width, args.height, seed=0x5EED + k)
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, format="JPEG", quality=args.quality, subsampling=args.subsampling,
+                                  progressive=args.progressive)
+        distinct.append(buf.getvalue())
+    files = [distinct[i % len(distinct)] for i in range(args.images)]
+    p = J.Pipeline(threads=args.threads)
+    best = None
+    for r in range(args.rounds):
+        out = p.decode(files, download=not args.no_download)
+        bad = [o for o in out if isinstance(o, Exception)]
+        assert not bad, bad[:1]
+        t = p.timings()
+        if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
+            best = t
+    mp = args.images * args.width * args.height / 1e6
+    print(json.dumps({
+        "what": "jpgpu_pipeline_decode: JPEG bytes (host) -> RGB" + (" (left in HBM)" if args.no_download else " (pinned host memory)"),
+        "images": args.images, "geometry": f"{args.width}x{args.height} {args.subsampling} q{args.quality}" +
+        (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
+        "MP_per_s": round(mp / best["total_ms"] * 1e3, 1), "images_per_s": round(args.images / best["total_ms"] * 1e3, 1),
+        "ms": {k: round(v, 2) for k, v in best.items() if k.endswith("_ms")},
+        "jpeg_MB": round(best["jpeg_bytes"] / 1e6, 1), "coefficient_MB": round(best["coefficient_bytes"] / 1e6, 1),
+        "pixel_MB": round(best["pixel_bytes"] / 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    main()
