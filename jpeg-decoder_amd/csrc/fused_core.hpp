@@ -148,6 +148,25 @@ __device__ __forceinline__ void stage_coefficients(uint8_t *coef_lds, uint32_t n
     }
 }
 
+// The same for a tile made of several contiguous runs of chunks (block rows, components): every load instruction
+// reads from ONE run — wave-uniform base pointer, the lane's chunk index as 32-bit offset — so the address math is
+// scalar (a per-lane choice between run bases costs ~6 VALU per load).  load_run / store_run are split so that a
+// caller can issue the loads of all its runs before the first LDS store.
+template <uint32_t NT, uint32_t LOADS>
+__device__ __forceinline__ void load_run(v4u (&v)[LOADS], const JP_GLOBAL v4u *run, uint32_t nchunks, uint32_t tid) {
+#pragma unroll
+    for (uint32_t i = 0; i < LOADS; i++) v[i] = stream_load(run + min(tid + NT * i, nchunks - 1u));  // clamped: unconditional
+}
+// first_block: LDS block index of the run's first block
+template <uint32_t NT, uint32_t LOADS>
+__device__ __forceinline__ void store_run(uint8_t *coef_lds, const v4u (&v)[LOADS], uint32_t nchunks, uint32_t first_block,
+                                          uint32_t tid) {
+    v4u *dst = reinterpret_cast<v4u *>(coef_lds);
+#pragma unroll
+    for (uint32_t i = 0; i < LOADS; i++)
+        if (tid + NT * i < nchunks) dst[coef_slot(first_block + (tid >> 3) + (NT / 8u) * i, tid & 7u)] = v[i];
+}
+
 // =============================================================================================
 // FUSED_420 main pass
 // =============================================================================================
@@ -202,8 +221,11 @@ struct F420 {
             ca[i] = *reinterpret_cast<const JP_GLOBAL v2u *>(prow + colc0);  // clamped address: unconditional
             if constexpr (HAS_CB) cb[i] = *reinterpret_cast<const JP_GLOBAL v2u *>(prow + colc1);
         }
-        stage_coefficients<NT>(lds.coef, 2u * run8, tid,
-                               [&](uint32_t j) { return j < run8 ? row0 + j : row1 + (j - run8); });
+        v4u c0[4], c1[4];  // run8 <= 16 * TX_MAX = 4 * NT chunks per block row
+        load_run<NT, 4>(c0, row0, run8, tid);
+        load_run<NT, 4>(c1, row1, run8, tid);
+        store_run<NT, 4>(lds.coef, c0, run8, 0u, tid);
+        store_run<NT, 4>(lds.coef, c1, run8, 2u * te, tid);
 #pragma unroll
         for (uint32_t i = 0; i < CITEMS; i++) {
             const uint32_t item = wave + NWAVES * i;
@@ -633,22 +655,14 @@ struct F444 {
         const JP_GLOBAL v4u *c0 = (const JP_GLOBAL v4u *)img.coefs[0] + base;
         const JP_GLOBAL v4u *c1 = (const JP_GLOBAL v4u *)img.coefs[1] + base;
         const JP_GLOBAL v4u *c2 = (const JP_GLOBAL v4u *)img.coefs[2] + base;
-        const uint32_t te8 = te * 8u;
-        // tile-local chunk j: component j / te8; stored at LDS block comp*64 + cx
-        v4u *dst = reinterpret_cast<v4u *>(lds.coef);
-        const uint32_t lastc = 3u * te8 - 1u;
-        v4u v[6];
-        uint32_t kk[6], rr[6];
-#pragma unroll
-        for (uint32_t i = 0; i < 6; i++) {
-            const uint32_t j = min(tid + FUSED_NT * i, lastc);  // clamped: unconditional loads
-            kk[i] = (j >= te8 ? 1u : 0u) + (j >= 2u * te8 ? 1u : 0u);
-            rr[i] = j - kk[i] * te8;
-            v[i] = stream_load((kk[i] == 0u ? c0 : (kk[i] == 1u ? c1 : c2)) + rr[i]);
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < 6; i++)
-            if (tid + FUSED_NT * i <= lastc) dst[coef_slot(kk[i] * 64u + (rr[i] >> 3), rr[i] & 7u)] = v[i];
+        const uint32_t te8 = te * 8u;  // <= 512 chunks per component: two loads each
+        v4u v0[2], v1[2], v2[2];
+        load_run<FUSED_NT, 2>(v0, c0, te8, tid);
+        load_run<FUSED_NT, 2>(v1, c1, te8, tid);
+        load_run<FUSED_NT, 2>(v2, c2, te8, tid);
+        store_run<FUSED_NT, 2>(lds.coef, v0, te8, 0u, tid);  // LDS block of (component, block) = comp*64 + cx
+        store_run<FUSED_NT, 2>(lds.coef, v1, te8, 64u, tid);
+        store_run<FUSED_NT, 2>(lds.coef, v2, te8, 128u, tid);
     }
     // qt_of_wave: quantization table of component (tid >> 6), fetched by the caller from the image array in memory
     // (a runtime index — or a chain of selects, which the compiler turns into one — into the by-value image struct
