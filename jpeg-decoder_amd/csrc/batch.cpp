@@ -15,6 +15,7 @@
 
 #include "fused.hpp"
 #include "host_common.hpp"
+#include "kernels.hpp"
 
 using namespace jpgpu;
 

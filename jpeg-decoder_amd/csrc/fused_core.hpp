@@ -109,26 +109,6 @@ __device__ __forceinline__ void load_block_from_lds(const uint8_t *coef_lds, uin
     }
 }
 
-// store n (<= 8) RGB24 pixels held as packed 24-bit values; off = byte offset in `out`.
-// Full chunks at a 4-byte aligned offset go out as two 12-B stores (global_store_dwordx3).
-__device__ __forceinline__ void store_rgb_run(JP_GLOBAL uint8_t *out, size_t off, const uint32_t (&px)[8], uint32_t n) {
-    JP_GLOBAL uint8_t *o = out + off;
-    if (n == 8 && (off & 3u) == 0) {
-        const v3u lo = {px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
-        const v3u hi = {px[4] | (px[5] << 24), (px[5] >> 8) | (px[6] << 16), (px[6] >> 16) | (px[7] << 8)};
-        stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o), lo);
-        stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12), hi);
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++)
-            if (k < n) {
-                o[3 * k] = (uint8_t)px[k];
-                o[3 * k + 1] = (uint8_t)(px[k] >> 8);
-                o[3 * k + 2] = (uint8_t)(px[k] >> 16);
-            }
-    }
-}
-
 __device__ __forceinline__ uint32_t byte_of(uint32_t d, uint32_t i) { return (d >> (8u * i)) & 0xffu; }
 
 // Stage up to 8*NT 16-B coefficient chunks of a tile into LDS (NT = threads per workgroup).  `addr(j)` maps the tile-local

@@ -5,7 +5,7 @@
 #include <string>
 
 #include "../../include/jpgpu.h"
-#include "kernels.hpp"
+#include "jobs.hpp"
 
 namespace jpgpu {
 

@@ -189,3 +189,47 @@ def test_planner_keeps_odd_geometries_on_the_generic_path():
         ptrs = (C.c_void_p * len(samp))(*[c.ctypes.data for c in coefs])
         out = np.zeros(w_ * h_ * 4 + 64, np.uint8)
         assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None, 32, 0, 0, 0) == 0
+
+
+# ---- generic upsample + colour kernel (csrc/upsample_color_body.hpp + csrc/image_job.cpp) ----------------------------
+UPSAMPLE_CASES = [
+    (33, 17, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (2, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (1, 5, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (3, 3, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (16, 16, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (15, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (17, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (2049, 5, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (960, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (961, 3, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (7, 3, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (8, 2, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+    (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (45, 29, [(1, 1), (1, 1), (1, 1)], "RGB"), (45, 29, [(1, 1), (1, 1), (1, 1)], "None"),
+    (70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (70, 41, [(4, 2), (1, 1), (2, 1)], "YCbCr"),
+    (64, 48, [(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"), (65, 47, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"),
+    (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"), (37, 21, [(1, 1)], "Grayscale"), (40, 24, [(2, 2)], "Grayscale"),
+]
+
+
+@pytest.mark.parametrize("case", UPSAMPLE_CASES, ids=lambda c: f"{c[0]}x{c[1]}-{'_'.join(f'{h}{v}' for h, v in c[2])}-{c[3]}")
+@pytest.mark.parametrize("scale", [8, 4, 1])
+@pytest.mark.parametrize("force_slow", [0, 1], ids=["dword-path", "byte-path"])
+def test_generic_upsample_color_kernel_logic_matches_oracle(case, scale, force_slow):
+    w_, h_, samp, ct = case
+    rng = np.random.default_rng(w_ * 7919 + h_ * 31 + scale)
+    ocomps, _ = O.make_components(w_, h_, samp, dct_scale=scale)
+    out_w, out_h = J.scaled_output_size(w_, h_, scale)
+    planes = [rng.integers(0, 256, O.plane_bytes(c)).astype(np.uint8) for c in ocomps]
+    try:
+        want = O.compute_image(ocomps, planes, out_w, out_h, ct.upper())
+    except O.OracleError as e:
+        want = e
+    jc = _to_j(ocomps)
+    n = len(samp)
+    ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in planes])
+    out_len = (ocomps[0].size_w * ocomps[0].size_h) if n == 1 else out_w * out_h * n
+    out = np.full(out_len + 64, 0x5A, np.uint8)
+    ln, fast = C.c_size_t(0), C.c_int(0)
+    rc = emu.lib().emu_compute_image(jc, n, ptrs, out_w, out_h, J.color_transform_id(ct), out.ctypes.data, C.byref(ln), force_slow, C.byref(fast))
+    if isinstance(want, O.OracleError):
+        assert rc != 0
+        return
+    assert rc == 0 and ln.value == want.size
+    assert (out[out_len:] == 0x5A).all(), "emulated kernel wrote past the output"
+    assert np.array_equal(out[:out_len], want)
+    if scale == 8 and not force_slow and ct not in ("None", "Grayscale") and all(max(s[0] for s in samp) // h in (1, 2) and max(s[1] for s in samp) // v in (1, 2) for h, v in samp):
+        assert fast.value == 1, "planner did not take the dword path for a geometry it is meant to cover"
