@@ -1,9 +1,12 @@
 // fused.hip — gfx950 wrappers + host plan of the fused fast-path kernels (fused_core.hpp).
 //
-// Launch geometry: grid = (tiles per MCU row, MCU rows, images), 256 threads.  One workgroup
-// covers TX consecutive MCUs of one MCU row, so its pixel stores are 16 (4:2:0) or 8 scanline
-// runs of TX*48 / TX*24 contiguous bytes, and its coefficient loads are two (4:2:0 luma) or
-// three (4:4:4) contiguous runs of TX*256 / TX*128 bytes.
+// A batch takes the fused path when every image is of ONE fusable kind (4:2:0 YCbCr, 4:4:4 YCbCr/RGB, or gray) at
+// dct_scale 8; the images may differ in size.  The launch is a flat list of workgroups: a work table (built once
+// per batch on the host) tells workgroup i which image and which tile it owns, and a per-image geometry table gives
+// the tiling, so mixed-size batches run the same kernels as uniform ones (two scalar loads per workgroup).
+// One workgroup covers TX consecutive MCUs of one MCU row, so its pixel stores are 16 (4:2:0) or 8 scanline runs of
+// TX*48 / TX*24 contiguous bytes, and its coefficient loads are two (4:2:0 luma) or three (4:4:4) contiguous runs.
+// Order of the table = x fastest, then MCU row, then image: neighbouring workgroups touch neighbouring memory.
 #include "fused.hpp"
 
 #include <algorithm>
@@ -16,45 +19,65 @@
 
 namespace jpgpu {
 
-__global__ __launch_bounds__(256) void f420_chroma_kernel(FusedGeom g, const FusedImage *__restrict__ imgs, uint32_t n_blocks) {
-    __shared__ v4u lds[256 * 8];
-    const FusedImage &img = imgs[blockIdx.z];
-    PlaneJob job;
-    job.coefs = img.coefs[1 + blockIdx.y];
-    job.plane = img.scratch + (size_t)blockIdx.y * g.chroma_plane_bytes;
-    job.qt = img.qt[1 + blockIdx.y];
-    job.block_w = g.bwc;
-    job.n_blocks = n_blocks;
-    job.scale = 8;
-    job.flags = img.flags;
-    idct_planes_body<8>(job, blockIdx.x, lds);
+// Which image / tile a workgroup owns: from the work table (mixed-size batches, 1-D grid) or, when the batch is uniform
+// and no table is passed, straight from the 3-D grid (x, y, image) — that saves the dependent scalar load at the
+// start of every workgroup (measured: 2 % on the 4:2:0 bench).
+__device__ __forceinline__ FusedWork locate(const FusedWork *__restrict__ work) {
+    if (work) return work[blockIdx.x];
+    return FusedWork{blockIdx.z, blockIdx.x, blockIdx.y, 0u};
 }
 
+// work item of the chroma pass: a = component (0 Cb, 1 Cr), b = 256-block group within the plane
+__global__ __launch_bounds__(256) void f420_chroma_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                          const FusedWork *__restrict__ work) {
+    __shared__ v4u lds[256 * 8];
+    const FusedWork w = locate(work);
+    const FusedGeom &g = geoms[w.image];
+    const FusedImage *img = imgs + w.image;  // (indexed through memory: a runtime index into a by-value copy would go to scratch)
+    PlaneJob job;
+    job.coefs = img->coefs[1u + w.a];
+    job.plane = img->scratch + (size_t)w.a * g.chroma_plane_bytes;
+    job.qt = img->qt[1u + w.a];
+    job.block_w = g.bwc;
+    job.n_blocks = g.bwc * g.mcu_h;
+    job.scale = 8;
+    job.flags = img->flags;
+    idct_planes_body<8>(job, w.b, lds);
+}
+
+// main pass / 4:4:4 / gray: a = tile within the MCU row, b = MCU row
 template <int ARITH, uint32_t NT>
-__global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const FusedGeom *__restrict__ geoms,
+                                                                           const FusedImage *__restrict__ imgs,
+                                                                           const FusedWork *__restrict__ work) {
     typedef F420<ARITH, NT> K;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
     const F420Lds lds = F420Lds::make(lds_raw, g.tx);
-    const FusedImage img = imgs[blockIdx.z];
     FusedRegs r;
-    K::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    K::phase0(g, img, w.a, w.b, threadIdx.x, lds);
     __syncthreads();
-    K::phase1(g, img, blockIdx.x, threadIdx.x, lds, r);
+    K::phase1(g, img, w.a, threadIdx.x, lds, r);
     __syncthreads();
-    K::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    K::phase2(g, w.a, threadIdx.x, lds, r);
     __syncthreads();
-    K::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    K::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
 
-// 4:2:0 in one launch: grid = (strips, row segments, images); see S420 in fused_core.hpp
+// 4:2:0 in one launch (opt-in): a = strip, b = row segment; see S420 in fused_core.hpp
 template <int ARITH, uint32_t NT>
-__global__ __launch_bounds__(NT, 4) void s420_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                     const FusedWork *__restrict__ work) {
     typedef S420<ARITH, NT> K;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
     const S420Lds lds = S420Lds::make(lds_raw, g.tx);
-    const FusedImage img = imgs[blockIdx.z];
-    const uint32_t strip = blockIdx.x, tid = threadIdx.x;
-    const uint32_t k0 = blockIdx.y * g.seg_rows, k1 = min(k0 + g.seg_rows, g.mcu_h);
+    const uint32_t strip = w.a, tid = threadIdx.x;
+    const uint32_t k0 = w.b * g.seg_rows, k1 = min(k0 + g.seg_rows, g.mcu_h);
     S420Regs r;
     K::init(img, tid, lds);
     if (k0 > 0) {  // carry rows of the MCU row above this segment
@@ -84,104 +107,130 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel(FusedGeom g, const FusedIma
 }
 
 template <int ARITH>
-__global__ __launch_bounds__(256) void f444_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                   const FusedWork *__restrict__ work) {
     __shared__ FusedLdsSmall lds;
-    const FusedImage img = imgs[blockIdx.z];
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
     FusedRegs r;
-    F444<ARITH>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F444<ARITH>::phase0(g, img, w.a, w.b, threadIdx.x, lds);
     __syncthreads();
     const uint32_t wcomp = min((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), 2u);
-    F444<ARITH>::phase1(g, imgs[blockIdx.z].qt[wcomp], blockIdx.x, threadIdx.x, lds, r);
+    F444<ARITH>::phase1(g, imgs[w.image].qt[wcomp], w.a, threadIdx.x, lds, r);
     __syncthreads();
-    F444<ARITH>::phase2(g, blockIdx.x, threadIdx.x, lds, r);
+    F444<ARITH>::phase2(g, w.a, threadIdx.x, lds, r);
     __syncthreads();
-    F444<ARITH>::phase3(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    F444<ARITH>::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
 
 template <int ARITH>
-__global__ __launch_bounds__(256) void fgray_kernel(FusedGeom g, const FusedImage *__restrict__ imgs) {
+__global__ __launch_bounds__(256) void fgray_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                    const FusedWork *__restrict__ work) {
     __shared__ FusedLdsSmall lds;
-    const FusedImage img = imgs[blockIdx.z];
-    FGray<ARITH>::phase0(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
+    FGray<ARITH>::phase0(g, img, w.a, w.b, threadIdx.x, lds);
     __syncthreads();
-    FGray<ARITH>::phase1(g, img, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    FGray<ARITH>::phase1(g, img, w.a, w.b, threadIdx.x, lds);
 }
 
 // ---- host side ------------------------------------------------------------------------------
 bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std::string &why) {
-    plan.kind = FUSED_NONE;
+    plan = FusedPlan();
+    plan.uniform = false;
     if (descs.empty() || descs.size() > 65535u) return false;
-    const jpgpu_image_desc &d0 = descs[0];
-    for (const auto &d : descs) {
-        if (d.ncomp != d0.ncomp || d.out_w != d0.out_w || d.out_h != d0.out_h || d.color_transform != d0.color_transform) {
-            why = "mixed geometry";
+    // Tuning knobs (A/B experiments, profiles/round1/04_strip_walk_experiments.md):
+    //   JPGPU_F420_TX    MCUs per tile of the 4:2:0 main pass (<= 32 selects 128-thread workgroups)
+    //   JPGPU_420_STRIP  1 = the single-launch strip walk (S420) for 4:2:0 — uniform batches only; off by default: on
+    //                    MI355X it moves 15 % fewer bytes but runs 10 % slower (0.79 vs 0.72 ms per 256 x 1080p)
+    //   JPGPU_S420_TX / JPGPU_S420_SEG  its strip width and MCU rows per workgroup
+    const char *txenv = getenv("JPGPU_F420_TX"), *tp = getenv("JPGPU_420_STRIP"), *stx = getenv("JPGPU_S420_TX");
+    const uint32_t f420_tx = txenv ? (uint32_t)atoi(txenv) : 64u;
+    bool strip420 = tp && atoi(tp) != 0;
+    const uint32_t n = (uint32_t)descs.size();
+    bool uniform = true;
+    for (uint32_t i = 1; i < n && uniform; i++) {
+        const jpgpu_image_desc &d = descs[i], &d0 = descs[0];
+        uniform = d.ncomp == d0.ncomp && d.out_w == d0.out_w && d.out_h == d0.out_h && d.color_transform == d0.color_transform;
+        for (uint32_t c = 0; uniform && c < d.ncomp; c++) uniform = fused_same_component(d.components[c], d0.components[c]);
+    }
+    if (!uniform) strip420 = false;
+    plan.uniform = uniform;
+    plan.geoms.resize(n);
+    const char *name = "";
+    for (uint32_t i = 0; i < n; i++) {
+        const char *nm = "", *w = "";
+        int kind = fused_geom_from_desc(descs[i], plan.geoms[i], nm, w, f420_tx, strip420, stx ? (uint32_t)atoi(stx) : S420_TX_MAX);
+        if (kind == FUSED_NONE) {
+            why = w;
             return false;
         }
-        for (uint32_t c = 0; c < d.ncomp; c++)
-            if (!fused_same_component(d.components[c], d0.components[c])) {
-                why = "mixed geometry";
-                return false;
-            }
+        if (i == 0) {
+            plan.kind = kind;
+            name = nm;
+        } else if (kind != plan.kind || plan.geoms[i].color != plan.geoms[0].color) {
+            why = "images of different kinds";  // e.g. gray next to 4:2:0: the generic path takes the batch
+            plan.kind = FUSED_NONE;
+            return false;
+        }
     }
-    FusedGeom g{};
-    const char *name = "", *w = "";
-    // JPGPU_F420_TX=32 selects the 128-thread / 32-MCU tiling of the 4:2:0 main pass (tuning knob)
-    const char *txenv = getenv("JPGPU_F420_TX");
-    // JPGPU_420_STRIP=1 selects the single-launch strip walk (S420) for 4:2:0 instead of chroma pass + main pass;
-    // JPGPU_S420_TX / JPGPU_S420_SEG set its strip width and MCU rows per workgroup.  Off by default: on MI355X it
-    // moves 15 % fewer bytes but runs 3 % slower (0.88 vs 0.85 ms per 256 x 1080p) — DESIGN.md §5.
-    const char *tp = getenv("JPGPU_420_STRIP");
-    const bool strip420 = tp && atoi(tp) != 0;
-    const char *stx = getenv("JPGPU_S420_TX");
-    int kind = fused_geom_from_desc(d0, g, name, w, txenv ? (uint32_t)atoi(txenv) : 64u, strip420, stx ? (uint32_t)atoi(stx) : S420_TX_MAX);
-    if (kind == FUSED_NONE) {
-        why = w;
-        return false;
-    }
-    if (kind == FUSED_420 && g.strip) {
-        const char *sr = getenv("JPGPU_S420_SEG");
-        s420_set_segments(g, (uint32_t)descs.size(), sr ? (uint32_t)atoi(sr) : 0u);
-    }
-    plan.kind = kind;
     plan.name = name;
-    plan.geom = g;
-    plan.desc = d0;
-    plan.n_images = (uint32_t)descs.size();
-    plan.scratch_per_image = plan.kind == FUSED_420 && !g.strip ? align_up(2 * (size_t)g.chroma_plane_bytes, 256) : 0;
-    // images per chunk of the 4:2:0 path: chroma planes of a chunk <= 64 MiB (JPGPU_CHUNK overrides)
-    {
-        const char *ce = getenv("JPGPU_CHUNK");
-        uint32_t chunk = ce ? (uint32_t)atoi(ce) : 0u;
-        if (chunk == 0u) chunk = plan.n_images;  // measured on MI355X: chunking (16..128 images) is slower than one pass over the batch
-        plan.chunk = std::max(1u, std::min(chunk, plan.n_images));
-        const char *se = getenv("JPGPU_STREAMS");
-        plan.n_streams = se ? (uint32_t)std::max(1, std::min(4, atoi(se))) : 1u;
-        if (plan.kind != FUSED_420 || g.strip) plan.n_streams = 1;
-        // scratch slots are shared modulo `chunk`: chunks in flight on different streams need their own
-        if (plan.n_streams > 1 && !ce) plan.chunk = std::max(1u, (plan.n_images + 2u * plan.n_streams - 1u) / (2u * plan.n_streams));
+    plan.n_images = n;
+    plan.ncomp = descs[0].ncomp;
+    plan.strip = plan.kind == FUSED_420 && plan.geoms[0].strip != 0;
+    if (plan.strip) {
+        const char *sr = getenv("JPGPU_S420_SEG");
+        for (auto &g : plan.geoms) s420_set_segments(g, n, sr ? (uint32_t)atoi(sr) : 0u);
     }
-    plan.images.assign(plan.n_images, FusedImage{});
+    // workgroup size, LDS claim, scratch layout, work tables
+    uint32_t tx_max = 0;
+    for (const auto &g : plan.geoms) tx_max = std::max(tx_max, g.tx);
+    plan.nt = 256;
+    if (plan.kind == FUSED_420) plan.nt = plan.strip ? (tx_max <= 20u ? 128u : 256u) : (tx_max <= 32u ? 128u : 256u);
+    plan.lds_bytes = plan.kind != FUSED_420 ? 0 : (plan.strip ? S420Lds::total_bytes(tx_max) : F420Lds::total_bytes(tx_max));
+    plan.scratch_off.assign(n, 0);
+    size_t so = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const FusedGeom &g = plan.geoms[i];
+        plan.scratch_off[i] = so;
+        if (plan.kind == FUSED_420 && !plan.strip) {
+            so += align_up(2 * (size_t)g.chroma_plane_bytes, 256);
+            const uint32_t groups = (g.bwc * g.mcu_h + 255u) / 256u;
+            for (uint32_t comp = 0; comp < 2; comp++)
+                for (uint32_t wg = 0; wg < groups; wg++) plan.work_pre.push_back(FusedWork{i, comp, wg, 0u});
+        }
+        const uint32_t ny = plan.strip ? g.n_seg : g.mcu_h;
+        for (uint32_t y = 0; y < ny; y++)
+            for (uint32_t x = 0; x < g.tiles_x; x++) plan.work_main.push_back(FusedWork{i, x, y, 0u});
+    }
+    plan.scratch_bytes = so;
+    // the 3-D grid needs its y extent within 65535; JPGPU_FUSED_TABLE=1 forces the table form (test knob)
+    if (plan.kind == FUSED_420 && !plan.strip && (plan.geoms[0].bwc * plan.geoms[0].mcu_h + 255u) / 256u > 65535u) plan.uniform = false;
+    if (const char *ft = getenv("JPGPU_FUSED_TABLE")) if (atoi(ft) != 0) plan.uniform = false;
+    plan.images.assign(n, FusedImage{});
     return true;
 }
 
 int fused_alloc(FusedPlan &plan, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
-    hipError_t e;
-    if (plan.scratch_per_image) {
-        plan.scratch_slots = std::min(plan.n_images, plan.chunk * plan.n_streams);
-        e = hipMalloc((void **)&plan.d_scratch, plan.scratch_per_image * plan.scratch_slots);
-        if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(scratch): %s", hipGetErrorString(e));
+#define F_HIP(call)                                                                                            \
+    do {                                                                                                       \
+        hipError_t _e = (call);                                                                                \
+        if (_e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(_e));        \
+    } while (0)
+    if (plan.scratch_bytes) F_HIP(hipMalloc((void **)&plan.d_scratch, plan.scratch_bytes));
+    F_HIP(hipMalloc((void **)&plan.d_images, sizeof(FusedImage) * plan.n_images));
+    F_HIP(hipMalloc((void **)&plan.d_geoms, sizeof(FusedGeom) * plan.n_images));
+    F_HIP(hipMemcpy(plan.d_geoms, plan.geoms.data(), sizeof(FusedGeom) * plan.n_images, hipMemcpyHostToDevice));
+    F_HIP(hipMalloc((void **)&plan.d_work_main, sizeof(FusedWork) * std::max<size_t>(plan.work_main.size(), 1)));
+    F_HIP(hipMemcpy(plan.d_work_main, plan.work_main.data(), sizeof(FusedWork) * plan.work_main.size(), hipMemcpyHostToDevice));
+    if (!plan.work_pre.empty()) {
+        F_HIP(hipMalloc((void **)&plan.d_work_pre, sizeof(FusedWork) * plan.work_pre.size()));
+        F_HIP(hipMemcpy(plan.d_work_pre, plan.work_pre.data(), sizeof(FusedWork) * plan.work_pre.size(), hipMemcpyHostToDevice));
     }
-    e = hipMalloc((void **)&plan.d_images, sizeof(FusedImage) * plan.n_images);
-    if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(images): %s", hipGetErrorString(e));
-    if (plan.n_streams > 1) {
-        e = hipEventCreateWithFlags(&plan.ev_fork, hipEventDisableTiming);
-        for (uint32_t k = 0; k < plan.n_streams && e == hipSuccess; k++) {
-            e = hipStreamCreateWithFlags(&plan.streams[k], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&plan.ev_join[k], hipEventDisableTiming);
-        }
-        if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "stream setup: %s", hipGetErrorString(e));
-    }
+#undef F_HIP
     return JPGPU_OK;
 }
 
@@ -192,13 +241,13 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
     for (uint32_t i = 0; i < plan.n_images; i++) {
         FusedImage &im = plan.images[i];
         uint32_t fl = 3u;
-        for (uint32_t c = 0; c < plan.desc.ncomp; c++) {
+        for (uint32_t c = 0; c < plan.ncomp; c++) {
             im.coefs[c] = reinterpret_cast<const int16_t *>(d_coef + coef_off[i * 4 + c]);
             im.qt[c] = d_qt + ((size_t)i * 4 + c) * 64;
             fl &= sane[i * 4 + c];
         }
         im.out = d_out + out_off[i];
-        im.scratch = plan.d_scratch ? plan.d_scratch + (size_t)(i % plan.scratch_slots) * plan.scratch_per_image : nullptr;
+        im.scratch = plan.d_scratch ? plan.d_scratch + plan.scratch_off[i] : nullptr;
         if (!(fl & 1u)) fl = 0u;  // tight implies sane
         im.flags = fl;
         common &= fl;
@@ -210,98 +259,58 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
     return JPGPU_OK;
 }
 
+// One batch = the chroma pass (two-pass 4:2:0 only) and the main launch.  (Walking the batch in chunks so that a
+// chunk's chroma planes stay in the 256 MiB Infinity Cache, and alternating chunks between two streams so that the
+// HBM-bound chroma pass overlaps the VALU-bound main pass, were both measured on MI355X and did not pay: chunks of
+// 16/32/64/128 images were 23/9/4/1 % slower, two streams 3 % slower — profiles/round1.)
 hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
-    const FusedGeom &g = plan.geom;
-    dim3 block(FUSED_NT);
-    dim3 grid(g.tiles_x, g.mcu_h, plan.n_images);
+    const FusedGeom *G = plan.d_geoms;
+    const FusedImage *I = plan.d_images;
+    const FusedGeom &g0 = plan.geoms[0];
+    const FusedWork *W = plan.uniform ? nullptr : plan.d_work_main;
+    const dim3 grid = plan.uniform ? dim3(g0.tiles_x, plan.strip ? g0.n_seg : g0.mcu_h, plan.n_images)
+                                   : dim3((uint32_t)plan.work_main.size());
+    const dim3 block(plan.nt);
+    const size_t shm = plan.lds_bytes;
+    const int ar = plan.arith;
+#define ARITH_SWITCH(KERNEL, ...)                                                                      \
+    do {                                                                                               \
+        if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);  \
+        else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W); \
+        else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);                  \
+    } while (0)
     switch (plan.kind) {
-    case FUSED_420: {
-        if (g.strip) {
-            const size_t shm = S420Lds::total_bytes(g.tx);
-            dim3 sgrid(g.tiles_x, g.n_seg, plan.n_images);
-            if (g.tx <= 20u) {  // 128-thread workgroups
-                if (plan.arith == ARITH_TIGHT) s420_kernel<ARITH_TIGHT, 128><<<sgrid, dim3(128), shm, stream>>>(g, plan.d_images);
-                else if (plan.arith == ARITH_SANE) s420_kernel<ARITH_SANE, 128><<<sgrid, dim3(128), shm, stream>>>(g, plan.d_images);
-                else s420_kernel<ARITH_EXACT, 128><<<sgrid, dim3(128), shm, stream>>>(g, plan.d_images);
-            } else {
-                if (plan.arith == ARITH_TIGHT) s420_kernel<ARITH_TIGHT, 256><<<sgrid, block, shm, stream>>>(g, plan.d_images);
-                else if (plan.arith == ARITH_SANE) s420_kernel<ARITH_SANE, 256><<<sgrid, block, shm, stream>>>(g, plan.d_images);
-                else s420_kernel<ARITH_EXACT, 256><<<sgrid, block, shm, stream>>>(g, plan.d_images);
-            }
+    case FUSED_420:
+        if (plan.strip) {
+            if (plan.nt == 128) ARITH_SWITCH(s420_kernel, 128);
+            else ARITH_SWITCH(s420_kernel, 256);
             break;
         }
-        // The batch may be walked in chunks of `chunk` images (chroma pass, then main pass) sharing one
-        // scratch area (JPGPU_CHUNK).  Default: one chunk — keeping a chunk's chroma planes within the
-        // 256 MiB Infinity Cache did not pay on MI355X (profiles/round1: 16/32/64/128-image chunks
-        // were 23/9/4/1 % slower than the whole 256-image batch).
-        const uint32_t nblk = g.bwc * g.mcu_h;  // chroma blocks per component
-        size_t shm = F420Lds::total_bytes(g.tx);
-        if (const char *pe = getenv("JPGPU_F420_LDS")) shm = std::max(shm, (size_t)atoi(pe));  // experiment knob: pad the workgroup's LDS claim
-        // The chroma pass is HBM-bound and the main pass VALU-bound (profiles/round1), so with
-        // JPGPU_STREAMS=2 the chunks alternate between two internal streams: the chroma pass of one
-        // chunk can share the machine with the main pass of another.  Forked from / joined to the
-        // caller's stream with events, so ordering on that stream is unchanged.
-        const uint32_t ns = plan.n_streams;
-        if (ns > 1) {
-            hipError_t e = hipEventRecord(plan.ev_fork, stream);
-            if (e != hipSuccess) return e;
-            for (uint32_t k = 0; k < ns; k++)
-                if ((e = hipStreamWaitEvent(plan.streams[k], plan.ev_fork, 0)) != hipSuccess) return e;
-        }
-        uint32_t ci = 0;
-        for (uint32_t first = 0; first < plan.n_images; first += plan.chunk, ci++) {
-            const uint32_t n = std::min(plan.chunk, plan.n_images - first);
-            const FusedImage *imgs = plan.d_images + first;
-            hipStream_t st = ns > 1 ? plan.streams[ci % ns] : stream;
-            dim3 cgrid((nblk + 255u) / 256u, 2, n), mgrid(g.tiles_x, g.mcu_h, n);
-            f420_chroma_kernel<<<cgrid, block, 0, st>>>(g, imgs, nblk);
-            const int ar = plan.arith;
-            if (g.tx <= 32u) {  // 128-thread workgroups, 32 MCUs per tile
-                if (ar == ARITH_TIGHT) f420_main_kernel<ARITH_TIGHT, 128><<<mgrid, dim3(128), shm, st>>>(g, imgs);
-                else if (ar == ARITH_SANE) f420_main_kernel<ARITH_SANE, 128><<<mgrid, dim3(128), shm, st>>>(g, imgs);
-                else f420_main_kernel<ARITH_EXACT, 128><<<mgrid, dim3(128), shm, st>>>(g, imgs);
-            } else {
-                if (ar == ARITH_TIGHT) f420_main_kernel<ARITH_TIGHT, 256><<<mgrid, block, shm, st>>>(g, imgs);
-                else if (ar == ARITH_SANE) f420_main_kernel<ARITH_SANE, 256><<<mgrid, block, shm, st>>>(g, imgs);
-                else f420_main_kernel<ARITH_EXACT, 256><<<mgrid, block, shm, st>>>(g, imgs);
-            }
-        }
-        if (ns > 1)
-            for (uint32_t k = 0; k < ns; k++) {
-                hipError_t e = hipEventRecord(plan.ev_join[k], plan.streams[k]);
-                if (e == hipSuccess) e = hipStreamWaitEvent(stream, plan.ev_join[k], 0);
-                if (e != hipSuccess) return e;
-            }
+        if (plan.uniform)  // (component, 256-block group, image)
+            f420_chroma_kernel<<<dim3(2, (g0.bwc * g0.mcu_h + 255u) / 256u, plan.n_images), dim3(256), 0, stream>>>(G, I, nullptr);
+        else
+            f420_chroma_kernel<<<dim3((uint32_t)plan.work_pre.size()), dim3(256), 0, stream>>>(G, I, plan.d_work_pre);
+        if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, 128);
+        else ARITH_SWITCH(f420_main_kernel, 256);
         break;
-    }
-    case FUSED_444:
-        if (plan.arith == ARITH_TIGHT) f444_kernel<ARITH_TIGHT><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else if (plan.arith == ARITH_SANE) f444_kernel<ARITH_SANE><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else f444_kernel<ARITH_EXACT><<<grid, block, 0, stream>>>(g, plan.d_images);
-        break;
-    case FUSED_GRAY:
-        if (plan.arith == ARITH_TIGHT) fgray_kernel<ARITH_TIGHT><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else if (plan.arith == ARITH_SANE) fgray_kernel<ARITH_SANE><<<grid, block, 0, stream>>>(g, plan.d_images);
-        else fgray_kernel<ARITH_EXACT><<<grid, block, 0, stream>>>(g, plan.d_images);
-        break;
+    case FUSED_444: ARITH_SWITCH(f444_kernel); break;
+    case FUSED_GRAY: ARITH_SWITCH(fgray_kernel); break;
     default: return hipErrorInvalidValue;
     }
+#undef ARITH_SWITCH
     return hipGetLastError();
 }
 
 void fused_free(FusedPlan &plan) {
     if (plan.d_scratch) (void)hipFree(plan.d_scratch);
     if (plan.d_images) (void)hipFree(plan.d_images);
-    for (uint32_t k = 0; k < 4; k++) {
-        if (plan.streams[k]) (void)hipStreamDestroy(plan.streams[k]);
-        if (plan.ev_join[k]) (void)hipEventDestroy(plan.ev_join[k]);
-        plan.streams[k] = nullptr;
-        plan.ev_join[k] = nullptr;
-    }
-    if (plan.ev_fork) (void)hipEventDestroy(plan.ev_fork);
-    plan.ev_fork = nullptr;
+    if (plan.d_geoms) (void)hipFree(plan.d_geoms);
+    if (plan.d_work_main) (void)hipFree(plan.d_work_main);
+    if (plan.d_work_pre) (void)hipFree(plan.d_work_pre);
     plan.d_scratch = nullptr;
     plan.d_images = nullptr;
+    plan.d_geoms = nullptr;
+    plan.d_work_main = plan.d_work_pre = nullptr;
 }
 
 }  // namespace jpgpu

@@ -14,17 +14,19 @@ namespace jpgpu {
 struct FusedPlan {
     std::string name;
     int kind = FUSED_NONE;
-    uint32_t n_images = 0;
-    jpgpu_image_desc desc{};  // the shared geometry
-    FusedGeom geom{};
-    size_t scratch_per_image = 0;
-    uint32_t chunk = 1;  // 4:2:0: images per (chroma pass, main pass) pair
-    uint32_t scratch_slots = 1;
-    uint32_t n_streams = 1;
-    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n_images = 0, ncomp = 0;
+    bool strip = false;              // 4:2:0 through the single-launch strip walk
+    bool uniform = false;            // every image has the same geometry: 3-D grid, no work table
+    uint32_t nt = 256;               // threads per workgroup of the main launch
+    size_t lds_bytes = 0;            // dynamic LDS of the main launch (largest tile of the batch)
+    std::vector<FusedGeom> geoms;    // per image
+    std::vector<FusedWork> work_main, work_pre;  // one entry per workgroup: main launch / 4:2:0 chroma pass
+    std::vector<size_t> scratch_off; // per image: its Cb|Cr planes in d_scratch
+    size_t scratch_bytes = 0;
     uint8_t *d_scratch = nullptr;
     FusedImage *d_images = nullptr;
+    FusedGeom *d_geoms = nullptr;
+    FusedWork *d_work_main = nullptr, *d_work_pre = nullptr;
     std::vector<FusedImage> images;
     int arith = 0;  // ARITH_* variant every image of the batch qualifies for
 };

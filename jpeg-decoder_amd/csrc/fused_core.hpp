@@ -48,6 +48,11 @@ struct FusedGeom {
     uint32_t n_seg;    // S420: ceil(mcu_h / seg_rows)
 };
 
+// One workgroup of a fused launch: which image, and which of its tiles (meaning of a/b per kernel, fused.hip).
+struct alignas(16) FusedWork {
+    uint32_t image, a, b, _pad;
+};
+
 struct FusedImage {
     const int16_t *coefs[4];
     const uint16_t *qt[4];

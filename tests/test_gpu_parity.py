@@ -346,3 +346,53 @@ def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
     for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
         want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
         assert np.array_equal(got, want)
+
+
+MIXED_SIZES = {
+    "420": ([(2, 2), (1, 1), (1, 1)], "YCbCr", "fused420", [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (1920, 64), (17, 1080), (640, 480)]),
+    "444": ([(1, 1), (1, 1), (1, 1)], "YCbCr", "fused444", [(45, 29), (200, 120), (1, 1), (513, 8), (9, 300), (640, 480)]),
+    "444rgb": ([(1, 1), (1, 1), (1, 1)], "RGB", "fused444", [(45, 29), (8, 8), (700, 33)]),
+    "gray": ([(1, 1)], "Grayscale", "fusedgray", [(37, 21), (300, 200), (1, 1000), (2056, 9), (8, 8)]),
+}
+
+
+@pytest.mark.parametrize("key", sorted(MIXED_SIZES))
+@pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
+def test_batch_mixed_sizes_of_one_kind_take_the_fused_path(key, kind):
+    """Images of one fusable kind but different sizes: per-image geometry + work tables, same kernels, bit-exact."""
+    samp, ct, want_path, sizes = MIXED_SIZES[key]
+    rng = np.random.default_rng(len(key) * 1009 + len(kind))
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind=kind) for (w_, h_) in sizes]
+    outs, path = _run_batch(cases)
+    assert path == want_path
+    for (oc, qts, coefs, ct_, w_, h_), got in zip(cases, outs):
+        want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
+        assert np.array_equal(got, want), (w_, h_)
+
+
+@pytest.mark.parametrize("case", [(250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+                                  (300, 200, [(1, 1)], "Grayscale")], ids=["420", "444", "gray"])
+@pytest.mark.parametrize("strip", ["0", "1"])
+def test_uniform_batch_through_the_work_table_form(case, strip, monkeypatch):
+    """Uniform batches normally use the 3-D grid; JPGPU_FUSED_TABLE=1 sends them through the work tables as well."""
+    monkeypatch.setenv("JPGPU_FUSED_TABLE", "1")
+    monkeypatch.setenv("JPGPU_420_STRIP", strip)
+    w_, h_, samp, ct = case
+    rng = np.random.default_rng(w_ + h_)
+    cases = [_batch_case(rng, w_, h_, samp, ct) for _ in range(4)]
+    outs, path = _run_batch(cases)
+    assert path.startswith("fused")
+    for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
+        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+
+
+def test_batch_of_different_kinds_falls_back_to_generic():
+    rng = np.random.default_rng(4)
+    cases = [_batch_case(rng, 64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"), _batch_case(rng, 64, 48, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+             _batch_case(rng, 64, 48, [(1, 1), (1, 1), (1, 1)], "RGB"), _batch_case(rng, 30, 20, [(1, 1)], "Grayscale")]
+    outs, path = _run_batch(cases)
+    assert path == "generic"
+    for (oc, qts, coefs, ct_, w_, h_), got in zip(cases, outs):
+        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+    outs, path = _run_batch(cases[1:3])  # 4:4:4 YCbCr next to 4:4:4 RGB: different colour functions
+    assert path == "generic"
