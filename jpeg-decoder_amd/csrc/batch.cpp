@@ -4,8 +4,9 @@
 // src/decoder.rs:134-154) laid out in two HBM arenas: all coefficient planes (int16,
 // block-raster = the concatenation of each component's append_row buffers)
 // and all output pixels.  One decode = a handful of launches over the whole batch.
-// Same-geometry 4:2:0 / 4:4:4 / gray batches resolve to the fused kernels (fused.hip);
-// everything else runs the generic two-kernel path (kernels.hip) through device job tables.
+// Images of a fusable kind (4:2:0 YCbCr, 4:4:4 YCbCr / RGB, gray; any size) are grouped per kind and run the fused
+// kernels (fused.hip), one launch group per kind; everything else runs the generic two-kernel path (kernels.hip)
+// through device job tables.  jpgpu_batch_path names the kernels: "fused420", ..., "generic", or "mixed".
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -44,7 +45,8 @@ struct jpgpu_batch {
     bool scales[9] = {false, false, false, false, false, false, false, false, false};
     bool jobs_dirty = true;
     bool qt_dirty = false;
-    FusedPlan fused;  // valid when path != "generic"
+    std::vector<FusedPlan> fused;       // one per fusable kind present in the batch
+    std::vector<uint32_t> generic_ids;  // images on the generic path
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -60,7 +62,7 @@ static int batch_refresh_jobs(jpgpu_batch *b) {
     const uint32_t n = (uint32_t)b->descs.size();
     b->plane_jobs.clear();
     b->image_jobs.clear();
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i : b->generic_ids) {
         const jpgpu_image_desc &d = b->descs[i];
         uint8_t *planes[4] = {nullptr, nullptr, nullptr, nullptr};
         for (uint32_t c = 0; c < d.ncomp; c++) {
@@ -87,8 +89,8 @@ static int batch_refresh_jobs(jpgpu_batch *b) {
         B_HIP(hipMemcpy(b->d_plane_jobs, b->plane_jobs.data(), b->plane_jobs.size() * sizeof(PlaneJob), hipMemcpyHostToDevice));
     if (!b->image_jobs.empty())
         B_HIP(hipMemcpy(b->d_image_jobs, b->image_jobs.data(), b->image_jobs.size() * sizeof(ImageJob), hipMemcpyHostToDevice));
-    if (b->path != "generic") {
-        int rc = fused_bind(b->fused, b->d_coef, b->d_out, b->d_qt, b->coef_off, b->out_off, b->sane, b->err);
+    for (FusedPlan &fp : b->fused) {
+        int rc = fused_bind(fp, b->d_coef, b->d_out, b->d_qt, b->coef_off, b->out_off, b->sane, b->err);
         if (rc) return rc;
     }
     if (b->qt_dirty) {
@@ -123,6 +125,11 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
     b->out_off.assign(n_images, 0);
     b->out_len.assign(n_images, 0);
     b->sane.assign((size_t)n_images * 4, 0);
+    // path resolution: group the images that can share a fused launch, the rest is generic
+    std::vector<uint32_t> kind_key(n_images, 0);
+    if (!(flags & JPGPU_BATCH_FORCE_GENERIC))
+        for (uint32_t i = 0; i < n_images; i++)
+            if (b->descs[i].ncomp >= 1 && b->descs[i].ncomp <= 4) kind_key[i] = fused_kind_key(b->descs[i]);
     size_t co = 0, po = 0, oo = 0;
     for (uint32_t i = 0; i < n_images; i++) {
         const jpgpu_image_desc &d = b->descs[i];
@@ -139,25 +146,46 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
             b->coef_off[i * 4 + c] = co;
             b->coef_len[i * 4 + c] = cb;
             co += align_up(cb, 256);
-            b->plane_off[i * 4 + c] = po;
-            po += align_up(plane_bytes(cc), 256);
-            b->max_blocks = std::max<uint32_t>(b->max_blocks, (uint32_t)cc.block_width * cc.block_height);
-            b->scales[cc.dct_scale] = true;
+            if (kind_key[i] == 0) {  // generic path: intermediate u8 plane, launch extents
+                b->plane_off[i * 4 + c] = po;
+                po += align_up(plane_bytes(cc), 256);
+                b->max_blocks = std::max<uint32_t>(b->max_blocks, (uint32_t)cc.block_width * cc.block_height);
+                b->scales[cc.dct_scale] = true;
+            }
         }
         b->out_off[i] = oo;
         b->out_len[i] = out_len;
         oo += align_up(out_len, 256);
-        b->max_w = std::max<uint32_t>(b->max_w, d.ncomp == 1 ? d.components[0].size_width : d.out_w);
-        b->max_h = std::max<uint32_t>(b->max_h, d.ncomp == 1 ? d.components[0].size_height : d.out_h);
+        if (kind_key[i] == 0) {
+            b->generic_ids.push_back(i);
+            b->max_w = std::max<uint32_t>(b->max_w, d.ncomp == 1 ? d.components[0].size_width : d.out_w);
+            b->max_h = std::max<uint32_t>(b->max_h, d.ncomp == 1 ? d.components[0].size_height : d.out_h);
+        }
     }
     b->coef_bytes = std::max<size_t>(co, 256);
     b->out_bytes = std::max<size_t>(oo, 256);
     b->plane_bytes_total = std::max<size_t>(po, 256);
 
-    // path resolution: fused kernels need one shared geometry
-    if (!(flags & JPGPU_BATCH_FORCE_GENERIC)) {
-        std::string why;
-        if (fused_plan(b->descs, b->fused, why)) b->path = b->fused.name;
+    {
+        std::vector<uint32_t> keys;
+        for (uint32_t i = 0; i < n_images; i++)
+            if (kind_key[i] && std::find(keys.begin(), keys.end(), kind_key[i]) == keys.end()) keys.push_back(kind_key[i]);
+        for (uint32_t key : keys) {
+            std::vector<jpgpu_image_desc> sub;
+            std::vector<uint32_t> ids;
+            for (uint32_t i = 0; i < n_images; i++)
+                if (kind_key[i] == key) {
+                    sub.push_back(b->descs[i]);
+                    ids.push_back(i);
+                }
+            FusedPlan fp;
+            std::string why;
+            if (!fused_plan(sub, ids, fp, why)) return set_err(b->err, JPGPU_ERR_INTERNAL, "fused plan: %s", why.c_str());
+            b->fused.push_back(std::move(fp));
+        }
+        if (b->fused.empty()) b->path = "generic";
+        else if (b->fused.size() == 1 && b->generic_ids.empty()) b->path = b->fused[0].name;
+        else b->path = "mixed";
     }
     hipError_t e;
 #define C_HIP(call)                                                                        \
@@ -168,10 +196,9 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         C_HIP(hipMalloc((void **)&b->d_out, b->out_bytes));
         b->own_out = true;
     }
-    if (b->path == "generic") {
-        C_HIP(hipMalloc((void **)&b->d_planes, b->plane_bytes_total));
-    } else {
-        rc = fused_alloc(b->fused, b->err);
+    if (!b->generic_ids.empty()) C_HIP(hipMalloc((void **)&b->d_planes, b->plane_bytes_total));
+    for (FusedPlan &fp : b->fused) {
+        rc = fused_alloc(fp, b->err);
         if (rc) return rc;
     }
     C_HIP(hipMalloc((void **)&b->d_qt, (size_t)n_images * 4 * 64 * sizeof(uint16_t)));
@@ -201,7 +228,7 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->d_qt) hipFree(b->d_qt);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
         if (b->d_image_jobs) hipFree(b->d_image_jobs);
-        fused_free(b->fused);
+        for (FusedPlan &fp : b->fused) fused_free(fp);
         if (b->ev0) hipEventDestroy(b->ev0);
         if (b->ev1) hipEventDestroy(b->ev1);
     }
@@ -313,11 +340,9 @@ int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     rc = batch_refresh_jobs(b);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
-    if (b->path != "generic") {
-        B_HIP(fused_launch(b->fused, s));
-        return JPGPU_OK;
-    }
-    const uint32_t n = (uint32_t)b->descs.size();
+    for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s));
+    if (b->generic_ids.empty()) return JPGPU_OK;
+    const uint32_t n = (uint32_t)b->image_jobs.size();
     static const uint32_t kScales[4] = {8, 4, 2, 1};
     for (uint32_t sc : kScales)
         if (b->scales[sc]) B_HIP(launch_idct_planes(b->d_plane_jobs, (uint32_t)b->plane_jobs.size(), b->max_blocks, sc, s));

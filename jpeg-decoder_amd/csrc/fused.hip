@@ -137,10 +137,18 @@ __global__ __launch_bounds__(256) void fgray_kernel(const FusedGeom *__restrict_
 }
 
 // ---- host side ------------------------------------------------------------------------------
-bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std::string &why) {
+uint32_t fused_kind_key(const jpgpu_image_desc &d) {
+    FusedGeom g;
+    const char *nm = "", *w = "";
+    const int kind = fused_geom_from_desc(d, g, nm, w);
+    return kind == FUSED_NONE ? 0u : (uint32_t)kind * 4u + g.color;
+}
+
+bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<uint32_t> &ids, FusedPlan &plan, std::string &why) {
     plan = FusedPlan();
     plan.uniform = false;
-    if (descs.empty() || descs.size() > 65535u) return false;
+    if (descs.empty() || descs.size() > 65535u || ids.size() != descs.size()) return false;
+    plan.ids = ids;
     // Tuning knobs (A/B experiments, profiles/round1/04_strip_walk_experiments.md):
     //   JPGPU_F420_TX    MCUs per tile of the 4:2:0 main pass (<= 32 selects 128-thread workgroups)
     //   JPGPU_420_STRIP  1 = the single-launch strip walk (S420) for 4:2:0 — uniform batches only; off by default: on
@@ -241,12 +249,13 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
     for (uint32_t i = 0; i < plan.n_images; i++) {
         FusedImage &im = plan.images[i];
         uint32_t fl = 3u;
+        const size_t gi = plan.ids[i];  // index in the batch
         for (uint32_t c = 0; c < plan.ncomp; c++) {
-            im.coefs[c] = reinterpret_cast<const int16_t *>(d_coef + coef_off[i * 4 + c]);
-            im.qt[c] = d_qt + ((size_t)i * 4 + c) * 64;
-            fl &= sane[i * 4 + c];
+            im.coefs[c] = reinterpret_cast<const int16_t *>(d_coef + coef_off[gi * 4 + c]);
+            im.qt[c] = d_qt + (gi * 4 + c) * 64;
+            fl &= sane[gi * 4 + c];
         }
-        im.out = d_out + out_off[i];
+        im.out = d_out + out_off[gi];
         im.scratch = plan.d_scratch ? plan.d_scratch + plan.scratch_off[i] : nullptr;
         if (!(fl & 1u)) fl = 0u;  // tight implies sane
         im.flags = fl;

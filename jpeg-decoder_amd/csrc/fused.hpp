@@ -15,6 +15,7 @@ struct FusedPlan {
     std::string name;
     int kind = FUSED_NONE;
     uint32_t n_images = 0, ncomp = 0;
+    std::vector<uint32_t> ids;       // batch-level index of each image of this plan (a batch may hold several plans)
     bool strip = false;              // 4:2:0 through the single-launch strip walk
     bool uniform = false;            // every image has the same geometry: 3-D grid, no work table
     uint32_t nt = 256;               // threads per workgroup of the main launch
@@ -31,7 +32,10 @@ struct FusedPlan {
     int arith = 0;  // ARITH_* variant every image of the batch qualifies for
 };
 
-bool fused_plan(const std::vector<jpgpu_image_desc> &descs, FusedPlan &plan, std::string &why);
+// descs: the images of ONE kind (fused_kind_key); ids: their indices in the batch (for fused_bind's offset tables)
+bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<uint32_t> &ids, FusedPlan &plan, std::string &why);
+// 0 if the image cannot take a fused kernel, else a key shared by the images that can share a launch
+uint32_t fused_kind_key(const jpgpu_image_desc &d);
 int fused_alloc(FusedPlan &plan, std::string &err);
 int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt, const std::vector<size_t> &coef_off,
                const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err);

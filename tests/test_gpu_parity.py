@@ -251,7 +251,7 @@ def _run_batch(cases, flags=0):
     return outs, path
 
 
-def test_batch_heterogeneous_generic_path():
+def test_batch_heterogeneous_mixed_paths():
     rng = np.random.default_rng(77)
     cases = [
         _batch_case(rng, 64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
@@ -261,10 +261,17 @@ def test_batch_heterogeneous_generic_path():
         _batch_case(rng, 16, 16, [(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"),
     ]
     outs, path = _run_batch(cases)
-    assert path == "generic"
-    for (oc, qts, coefs, ct, w_, h_), got in zip(cases, outs):
+    assert path == "mixed"  # 4:2:0, 4:4:4 RGB and gray each get their fused launch, 4:2:2 and CMYK the generic kernels
+    outs_g, path_g = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
+    assert path_g == "generic"
+    outs_2, path_2 = _run_batch(cases[3:])
+    assert path_2 == "generic"
+    for (oc, qts, coefs, ct, w_, h_), got, gen in zip(cases, outs, outs_g):
         want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper())
         assert np.array_equal(got, want)
+        assert np.array_equal(gen, want)
+    for (oc, qts, coefs, ct, w_, h_), got in zip(cases[3:], outs_2):
+        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper()))
 
 
 SAME_GEOMETRY = [
@@ -386,13 +393,15 @@ def test_uniform_batch_through_the_work_table_form(case, strip, monkeypatch):
         assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
 
 
-def test_batch_of_different_kinds_falls_back_to_generic():
+def test_batch_of_different_kinds_runs_one_fused_launch_per_kind():
     rng = np.random.default_rng(4)
     cases = [_batch_case(rng, 64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"), _batch_case(rng, 64, 48, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
              _batch_case(rng, 64, 48, [(1, 1), (1, 1), (1, 1)], "RGB"), _batch_case(rng, 30, 20, [(1, 1)], "Grayscale")]
     outs, path = _run_batch(cases)
-    assert path == "generic"
+    assert path == "mixed"
     for (oc, qts, coefs, ct_, w_, h_), got in zip(cases, outs):
         assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
-    outs, path = _run_batch(cases[1:3])  # 4:4:4 YCbCr next to 4:4:4 RGB: different colour functions
-    assert path == "generic"
+    outs, path = _run_batch(cases[1:3])  # 4:4:4 YCbCr next to 4:4:4 RGB: different colour functions, two launches
+    assert path == "mixed"
+    for (oc, qts, coefs, ct_, w_, h_), got in zip(cases[1:3], outs):
+        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))

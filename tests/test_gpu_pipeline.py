@@ -49,7 +49,7 @@ def test_pipeline_mixed_files_one_call():
     assert with_errors >= 3 and len(files) - with_errors >= 40
     p = J.Pipeline(threads=8)
     out = p.decode(files)
-    assert p.kernel_path == "generic"
+    assert p.kernel_path == "mixed"  # fused launches per kind + generic kernels for the rest
     _check(names, files, out)
     t = p.timings()
     assert t["images_ok"] == len(files) - with_errors and t["total_ms"] > 0
