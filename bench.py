@@ -31,6 +31,7 @@ WORKLOADS = {
     "1080p-420": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "2160p-420": (3840, 2160, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 64),
     "1080p-444": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
+    "1080p-422": (1920, 1080, [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
 }
 

@@ -125,6 +125,24 @@ __global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__
 }
 
 template <int ARITH>
+__global__ __launch_bounds__(256) void f422_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                   const FusedWork *__restrict__ work) {
+    __shared__ FusedLdsSmall lds;
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
+    FusedRegs r;
+    F422<ARITH>::phase0(g, img, w.a, w.b, threadIdx.x, lds);
+    __syncthreads();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    F422<ARITH>::phase1(g, imgs[w.image].qt[wave < 2u ? 0u : wave - 1u], w.a, threadIdx.x, lds, r);
+    __syncthreads();
+    F422<ARITH>::phase2(g, w.a, threadIdx.x, lds, r);
+    __syncthreads();
+    F422<ARITH>::phase3(g, img, w.a, w.b, threadIdx.x, lds);
+}
+
+template <int ARITH>
 __global__ __launch_bounds__(256) void fgray_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                     const FusedWork *__restrict__ work) {
     __shared__ FusedLdsSmall lds;
@@ -303,6 +321,7 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
         else ARITH_SWITCH(f420_main_kernel, 256);
         break;
     case FUSED_444: ARITH_SWITCH(f444_kernel); break;
+    case FUSED_422: ARITH_SWITCH(f422_kernel); break;
     case FUSED_GRAY: ARITH_SWITCH(fgray_kernel); break;
     default: return hipErrorInvalidValue;
     }

@@ -26,11 +26,12 @@ namespace jpgpu {
 constexpr uint32_t FUSED_NT = 256;       // threads per workgroup
 constexpr uint32_t F420_TX_MAX = 64;     // 4 luma blocks per MCU -> <= 256 lanes
 constexpr uint32_t F444_TX_MAX = 64;     // one wave per component, one lane per block
+constexpr uint32_t F422_TX_MAX = 62;     // 2 luma waves (124 blocks), one wave per chroma component (62 + 2 halo blocks)
 constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
 
 enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1 };
-enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3 };
+enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4 };
 
 struct FusedGeom {
     uint32_t kind;
@@ -285,29 +286,32 @@ struct F420 {
     //   first / last column of the image: c = t'main >> 2
     // `rowp` = first byte of the output scanline (wave-uniform -> scalar address math), `row_al4` =
     // that scanline starts 4-byte aligned (then every 8-pixel chunk does: 24*chk is a multiple of 4)
+    // H2V1 = true: `t` holds raw samples and only the horizontal step of UpsamplerH2V1 is applied
+    // (src/upsampler.rs:134-163): c = (3*s_main + s_other + 2) >> 2, first / last column c = s_main.
+    template <bool H2V1 = false>
     static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *rowp, bool row_al4,
                                                       const TPrime (&t)[2], v2u yy, uint32_t ox0) {
         // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
+        constexpr uint32_t SH = H2V1 ? 2u : 4u, ESH = H2V1 ? 0u : 2u;
         uint32_t pk[2][4];
 #pragma unroll
         for (uint32_t comp = 0; comp < 2; comp++) {
             const TPrime &q = t[comp];
-            pk[comp][0] = pk_shr(pk_mad3(q.tE1, q.tOm), 4);
-            pk[comp][1] = pk_shr(pk_mad3(q.tE1, q.tO1), 4);
-            pk[comp][2] = pk_shr(pk_mad3(q.tO1, q.tE1), 4);
-            pk[comp][3] = pk_shr(pk_mad3(q.tO1, q.tEp), 4);
+            uint32_t m[4] = {pk_mad3(q.tE1, q.tOm), pk_mad3(q.tE1, q.tO1), pk_mad3(q.tO1, q.tE1), pk_mad3(q.tO1, q.tEp)};
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) pk[comp][i] = pk_shr(H2V1 ? pk_add(m[i], 0x00020002u) : m[i], SH);
         }
         const uint32_t last_x = 2u * g.cw - 1u;
         if (ox0 == 0u || last_x - ox0 < 8u) {  // rare: first / last image column
 #pragma unroll
             for (uint32_t comp = 0; comp < 2; comp++) {
                 if (ox0 == 0u)  // src/upsampler.rs:213-214: px0 = t'(s0) >> 2
-                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | ((t[comp].tE1 & 0xffffu) >> 2);
+                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | ((t[comp].tE1 & 0xffffu) >> ESH);
                 if (last_x - ox0 < 8u) {  // src/upsampler.rs:226: last column (odd k): t'(s_(k>>1)) >> 2
                     const uint32_t k = last_x - ox0;
                     const uint32_t tm = k == 1u ? (t[comp].tE1 & 0xffffu) : k == 3u ? (t[comp].tO1 & 0xffffu)
                                         : k == 5u ? (t[comp].tE1 >> 16) : (t[comp].tO1 >> 16);
-                    const uint32_t v = tm >> 2;
+                    const uint32_t v = tm >> ESH;
                     if (k == 1u) pk[comp][1] = (pk[comp][1] & 0xffff0000u) | v;
                     if (k == 3u) pk[comp][3] = (pk[comp][3] & 0xffff0000u) | v;
                     if (k == 5u) pk[comp][1] = (pk[comp][1] & 0x0000ffffu) | (v << 16);
@@ -618,6 +622,109 @@ struct S420 {
                 const size_t ro = (size_t)oyb * pitch;
                 P::row_pixels(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
             }
+        }
+    }
+};
+
+// =============================================================================================
+// FUSED_422: 4:2:2 YCbCr (H2V1 / H1V1 / H1V1) -> RGB24, one launch.  MCU = 16x8 pixels = two luma blocks side by side
+// + one Cb + one Cr block.  A workgroup owns TX <= 62 MCUs of one MCU row: waves 0-1 transform the 2*te luma blocks,
+// wave 2 the te+2 Cb blocks and wave 3 the te+2 Cr blocks under them — one halo block either side, because
+// UpsamplerH2V1 (src/upsampler.rs:134-163) reads the sample left / right of each chroma sample; there is no vertical
+// neighbourhood, so nothing has to come from other MCU rows.  Every wave works on one component: its quantization
+// table stays in SGPRs.  The pixel phase deals the 8 rows x 2*te chunks over all lanes.
+// =============================================================================================
+template <int ARITH>
+struct F422 {
+    typedef F420<ARITH, 256> P;  // pixel helpers
+    static constexpr uint32_t NT = 256;
+    static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
+        return min(g.tx, g.mcu_w - tile_x * g.tx);
+    }
+    // lane -> block.  Staging block index = tid: [0,128) luma block column, [128,192) Cb, [192,256) Cr (cx = column in
+    // the chroma tile, plane block x0m - 1 + cx).  false: idle lane.
+    static __device__ __forceinline__ bool lane_block(const FusedGeom &g, uint32_t tile_x, uint32_t tid, uint32_t &comp, uint32_t &cx) {
+        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
+        if (tid < 128u) {
+            comp = 0u;
+            cx = tid;
+            return tid < 2u * te;
+        }
+        comp = tid < 192u ? 1u : 2u;
+        cx = tid & 63u;
+        const int32_t bx = (int32_t)x0m - 1 + (int32_t)cx;
+        return cx < te + 2u && bx >= 0 && bx < (int32_t)g.bwc;
+    }
+    static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
+                                                  uint32_t tid, FusedLdsSmall &lds) {
+        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
+        const uint32_t nl = 16u * te, ncc = 8u * (te + 2u);  // chunks: luma run (<= 992), chroma run (<= 512)
+        const JP_GLOBAL v4u *y = (const JP_GLOBAL v4u *)img.coefs[0] + ((size_t)my * g.bw0 + 2u * x0m) * 8u;
+        const JP_GLOBAL v4u *cb = (const JP_GLOBAL v4u *)img.coefs[1] + (size_t)my * g.bwc * 8u;
+        const JP_GLOBAL v4u *cr = (const JP_GLOBAL v4u *)img.coefs[2] + (size_t)my * g.bwc * 8u;
+        // halo blocks outside the plane (image edges) are never transformed: clamp them onto valid chunks
+        const int32_t cfirst = ((int32_t)x0m - 1) * 8, cmax = (int32_t)(g.bwc * 8u) - 1;
+        v4u vy[4], vb[2], vr[2];
+        load_run<NT, 4>(vy, y, nl, tid);
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t e = (uint32_t)min(max(cfirst + (int32_t)min(tid + NT * i, ncc - 1u), 0), cmax);
+            vb[i] = stream_load(cb + e);
+            vr[i] = stream_load(cr + e);
+        }
+        store_run<NT, 4>(lds.coef, vy, nl, 0u, tid);
+        store_run<NT, 2>(lds.coef, vb, ncc, 128u, tid);
+        store_run<NT, 2>(lds.coef, vr, ncc, 192u, tid);
+    }
+    // qt_of_wave: table of the wave's component (0, 0, 1, 2), fetched by the caller from the image array in memory
+    static __device__ __forceinline__ void phase1(const FusedGeom &g, const uint16_t *qt_of_wave, uint32_t tile_x, uint32_t tid,
+                                                  const FusedLdsSmall &lds, FusedRegs &r) {
+        uint32_t comp, cx;
+        if (!lane_block(g, tile_x, tid, comp, cx)) return;
+        uint32_t cw[32];
+        load_block_from_lds(lds.coef, tid, cw);
+        idct8x8<ARITH>(cw, as_qtab(qt_of_wave), r.out);
+    }
+    // sample tiles (alias the staging area): luma 8 rows x 16*tx, then [2 comps][8 rows][cpitch = 8*(tx+2)]
+    static __device__ __forceinline__ uint32_t cpitch(const FusedGeom &g) { return 8u * (g.tx + 2u); }
+    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLdsSmall &lds,
+                                                  const FusedRegs &r) {
+        uint32_t comp, cx;
+        if (!lane_block(g, tile_x, tid, comp, cx)) return;
+        const uint32_t ypitch = 16u * g.tx, cp = cpitch(g);
+        uint8_t *base = comp == 0u ? lds.coef + cx * 8u : lds.coef + 8u * ypitch + (comp - 1u) * 8u * cp + cx * 8u;
+        const uint32_t pitch = comp == 0u ? ypitch : cp;
+#pragma unroll
+        for (int row = 0; row < 8; row++)
+            *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch) = v2u{r.out[2 * row], r.out[2 * row + 1]};
+    }
+    static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
+                                                  uint32_t tid, const FusedLdsSmall &lds) {
+        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
+        const uint32_t nch = 2u * te, nunits = 8u * nch;
+        const uint32_t magic = 0xffffffffu / nch + 1u;  // mul_hi(u, magic) == u / nch for u < 65536
+        const uint32_t ypitch = 16u * g.tx, cp = cpitch(g);
+        const uint8_t *ctile = lds.coef + 8u * ypitch;
+        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
+        const size_t pitch = (size_t)g.out_w * 3u;
+#pragma unroll 1
+        for (uint32_t u = tid; u < nunits; u += NT) {
+            const uint32_t row = __umulhi(u, magic), chk = u - row * nch;
+            const uint32_t oy = 8u * my + row, ox0 = 16u * x0m + 8u * chk;
+            if (oy >= g.out_h || ox0 >= g.out_w) continue;
+            typename P::TPrime t[2];
+#pragma unroll
+            for (uint32_t comp = 0; comp < 2; comp++) {
+                // tile column of plane column j0 - 4 (j0 = ox0 / 2): 4*chk + 4, as in the 4:2:0 kernels
+                const typename P::ChromaEO e = P::load_eo(ctile + (comp * 8u + row) * cp + 4u * chk + 4u);
+                t[comp].tE1 = e.E1;
+                t[comp].tO1 = e.O1;
+                t[comp].tOm = alignbit(e.O1, e.O0, 16);  // (s1, s_-1)
+                t[comp].tEp = alignbit(e.E2, e.E1, 16);  // (s4, s2)
+            }
+            const v2u yy = *reinterpret_cast<const v2u *>(lds.coef + row * ypitch + 8u * chk);
+            const size_t ro = (size_t)oy * pitch;
+            P::template row_pixels<true>(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
         }
     }
 };

@@ -55,6 +55,22 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
         tx_max = strip420 ? (s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max)) : (f420_tx_max <= 32u ? 32u : (f420_tx_max < F420_TX_MAX ? f420_tx_max : F420_TX_MAX));
         g.strip = strip420 ? 1u : 0u;
         if (strip420) name = "fused420s";
+    } else if (d0.ncomp == 3 && hv(0, 2, 1) && hv(1, 1, 1) && hv(2, 1, 1) && d0.color_transform == JPGPU_CT_YCBCR && d0.out_w > 1 &&
+               fused_same_component(d0.components[1], d0.components[2])) {
+        // (an output width of 1 overrides H2V1 with H1V1, src/upsampler.rs:80: generic path)
+        kind = FUSED_422;
+        name = "fused422";
+        g.mcu_w = d0.components[1].block_width;
+        g.mcu_h = d0.components[1].block_height;
+        g.bwc = d0.components[1].block_width;
+        g.cw = d0.components[1].size_width;
+        g.ch = d0.components[1].size_height;
+        if (d0.components[0].block_width != 2u * g.mcu_w || d0.components[0].block_height != g.mcu_h || d0.out_w > 2u * g.cw ||
+            d0.out_h > g.ch || d0.out_h > 8u * g.mcu_h) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = F422_TX_MAX;
     } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&
                (d0.color_transform == JPGPU_CT_YCBCR || d0.color_transform == JPGPU_CT_RGB) &&
                fused_same_component(d0.components[0], d0.components[1]) &&

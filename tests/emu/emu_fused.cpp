@@ -109,6 +109,11 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             if (kind == FUSED_420) {
                 if (g.tx <= 32u) { if (sane == 2) { RUN420(ARITH_TIGHT, 128, lds128) } else if (sane) { RUN420(ARITH_SANE, 128, lds128) } else { RUN420(ARITH_EXACT, 128, lds128) } }
                 else { if (sane == 2) { RUN420(ARITH_TIGHT, 256, lds) } else if (sane) { RUN420(ARITH_SANE, 256, lds) } else { RUN420(ARITH_EXACT, 256, lds) } }
+            } else if (kind == FUSED_422) {
+#define RUN422(S) RUN(256, F422<S>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F422<S>::phase1(g, img.qt[(t >> 6) < 2 ? 0 : (t >> 6) - 1], tile, t, *lds_s, regs[t])) \
+    RUN(256, F422<S>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F422<S>::phase3(g, img, tile, my, t, *lds_s))
+                if (sane == 2) { RUN422(ARITH_TIGHT) } else if (sane) { RUN422(ARITH_SANE) } else { RUN422(ARITH_EXACT) }
+#undef RUN422
             } else if (kind == FUSED_444 && sane == 2) {
                 RUN(256, F444<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_TIGHT>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_TIGHT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_TIGHT>::phase3(g, img, tile, my, t, *lds_s))

@@ -138,6 +138,9 @@ GEOMS = [
     (672, 65, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (673, 79, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (30, 160, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (45, 29, [(1, 1), (1, 1), (1, 1)], "RGB"),
     (650, 20, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (1, 1, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+    (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2, 1, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (3, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (16, 8, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (17, 8, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (993, 10, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (1920, 16, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2017, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
     (1000, 1, [(1, 1)], "Grayscale"),
 ]

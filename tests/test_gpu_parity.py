@@ -259,18 +259,20 @@ def test_batch_heterogeneous_mixed_paths():
         _batch_case(rng, 100, 9, [(1, 1)], "Grayscale"),
         _batch_case(rng, 31, 70, [(2, 1), (1, 1), (1, 1)], "YCbCr", kind="full"),
         _batch_case(rng, 16, 16, [(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"),
+        _batch_case(rng, 70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"),
+        _batch_case(rng, 50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
     ]
     outs, path = _run_batch(cases)
-    assert path == "mixed"  # 4:2:0, 4:4:4 RGB and gray each get their fused launch, 4:2:2 and CMYK the generic kernels
+    assert path == "mixed"  # 4:2:0, 4:2:2, 4:4:4 RGB and gray each get their fused launch; CMYK, 4:1:1 and 4:4:0 the generic kernels
     outs_g, path_g = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
     assert path_g == "generic"
-    outs_2, path_2 = _run_batch(cases[3:])
+    outs_2, path_2 = _run_batch(cases[4:])
     assert path_2 == "generic"
     for (oc, qts, coefs, ct, w_, h_), got, gen in zip(cases, outs, outs_g):
         want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper())
         assert np.array_equal(got, want)
         assert np.array_equal(gen, want)
-    for (oc, qts, coefs, ct, w_, h_), got in zip(cases[3:], outs_2):
+    for (oc, qts, coefs, ct, w_, h_), got in zip(cases[4:], outs_2):
         assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper()))
 
 
@@ -282,6 +284,9 @@ SAME_GEOMETRY = [
     (129, 257, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
     (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+    (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (993, 21, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (2, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (37, 21, [(1, 1)], "Grayscale"),
     (300, 200, [(1, 1)], "Grayscale"),
 ]
@@ -359,6 +364,7 @@ MIXED_SIZES = {
     "420": ([(2, 2), (1, 1), (1, 1)], "YCbCr", "fused420", [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (1920, 64), (17, 1080), (640, 480)]),
     "444": ([(1, 1), (1, 1), (1, 1)], "YCbCr", "fused444", [(45, 29), (200, 120), (1, 1), (513, 8), (9, 300), (640, 480)]),
     "444rgb": ([(1, 1), (1, 1), (1, 1)], "RGB", "fused444", [(45, 29), (8, 8), (700, 33)]),
+    "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr", "fused422", [(64, 24), (33, 17), (2, 1), (1000, 9), (17, 300), (1984, 8), (1985, 8), (640, 480)]),
     "gray": ([(1, 1)], "Grayscale", "fusedgray", [(37, 21), (300, 200), (1, 1000), (2056, 9), (8, 8)]),
 }
 
