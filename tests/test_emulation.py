@@ -181,7 +181,8 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
 
 def test_planner_keeps_odd_geometries_on_the_generic_path():
     for (w_, h_, samp, ct) in [(1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
-                               (64, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 2)], "Grayscale"),
+                               (1, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+                               (64, 64, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 1), (1, 1), (1, 1)], "RGB"), (64, 64, [(2, 2)], "Grayscale"),
                                (64, 64, [(1, 1)] * 4, "CMYK")]:
         rng = np.random.default_rng(0)
         ocomps, _ = O.make_components(w_, h_, samp)
