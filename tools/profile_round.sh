@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-for wl in 1080p-444 1080p-gray 2160p-420; do
+for wl in 1080p-444 1080p-422 1080p-gray 2160p-420; do
   timeout 600 python bench.py --workload $wl --no-cpu-baseline > gpurun_out/bench_$wl.json 2> gpurun_out/bench_$wl.err
 done
 timeout 600 python bench.py --steps 50 --warmup 10 --generic --no-cpu-baseline > gpurun_out/bench_generic.json 2> gpurun_out/bench_generic.err
