@@ -23,12 +23,19 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--no-download", action="store_true")
     ap.add_argument("--progressive", action="store_true")
+    ap.add_argument("--file", default=None, help="use this JPEG (replicated) instead of the synthetic images")
     args = ap.parse_args()
     from PIL import Image
     import synth
     import jpeg_decoder_amd as J
     distinct = []
-    for k in range(4):  # a few different images, repeated
+    if args.file:
+        data = open(args.file, "rb").read()
+        info = J.Decoder(data, device=-1)
+        info.read_info()
+        args.width, args.height = info.info().width, info.info().height
+        distinct.append(data)
+    for k in range(0 if args.file else 4):  # a few different images, repeated
         rgb = synth.synthetic_rgb(args.width, args.height, seed=0x5EED + k)
         buf = io.BytesIO()
         Image.fromarray(rgb).save(buf, format="JPEG", quality=args.quality, subsampling=args.subsampling,
@@ -47,8 +54,8 @@ def main():
     mp = args.images * args.width * args.height / 1e6
     print(json.dumps({
         "what": "jpgpu_pipeline_decode: JPEG bytes (host) -> RGB" + (" (left in HBM)" if args.no_download else " (pinned host memory)"),
-        "images": args.images, "geometry": f"{args.width}x{args.height} {args.subsampling} q{args.quality}" +
-        (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
+        "images": args.images, "geometry": (os.path.basename(args.file) + f" {args.width}x{args.height}") if args.file else
+        f"{args.width}x{args.height} {args.subsampling} q{args.quality}" + (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
         "MP_per_s": round(mp / best["total_ms"] * 1e3, 1), "images_per_s": round(args.images / best["total_ms"] * 1e3, 1),
         "ms": {k: round(v, 2) for k, v in best.items() if k.endswith("_ms")},
         "jpeg_MB": round(best["jpeg_bytes"] / 1e6, 1), "coefficient_MB": round(best["coefficient_bytes"] / 1e6, 1),
