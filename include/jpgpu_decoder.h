@@ -78,13 +78,18 @@ int jpgpu_decoder_decode_coefficients(jpgpu_decoder *d, jpgpu_image_desc *desc, 
  *   2. entropy decoding in parallel, one image per task, rows written to pinned staging memory;
  *      each image is sent to HBM (hipMemcpyAsync) as soon as its last scan is done, so the copy of
  *      image i overlaps the Huffman decoding of the others
- *   3. the batch kernels (fused when all images share a geometry), optional download.
+ *   3. the batch kernels (fused launch groups per image kind) and the optional download, per sub-batch of ~64 images,
+ *      overlapped with step 2 of the following sub-batches.
  * Per-image failures (src/error.rs) do not fail the call: query them per image.  The batch and its
  * arenas are kept and reused while the sequence of geometries stays the same (fixed-size frames).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct jpgpu_pipeline jpgpu_pipeline;
 
-typedef struct jpgpu_pipeline_timings { /* wall-clock milliseconds of the last decode call */
+/* Wall-clock milliseconds of the last decode call.  The call's images are cut into sub-batches of about 64; the kernels and
+ * the download of a sub-batch are enqueued as soon as its last image is uploaded and overlap the entropy decoding of the
+ * following ones: entropy_and_upload_ms ends when the host threads are done, download_ms is the drain after that (the
+ * last sub-batch's kernels + copy), kernels_ms is 0 (never exposed on its own). */
+typedef struct jpgpu_pipeline_timings {
     double headers_ms, setup_ms, entropy_and_upload_ms, kernels_ms, download_ms, total_ms;
     uint32_t threads, images_ok;
     uint64_t jpeg_bytes, coefficient_bytes, pixel_bytes;

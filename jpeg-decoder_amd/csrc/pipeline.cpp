@@ -144,23 +144,15 @@ private:
 };
 
 // Finished images are handed to one uploader thread: hipMemcpyAsync calls from hundreds of threads contend in the
-// runtime, one caller keeps the copy queues busy.
+// runtime, one caller keeps the copy queues busy.  skip = the image failed and will never be uploaded.
 struct UploadQueue {
     std::mutex m;
     std::condition_variable cv;
-    std::vector<uint32_t> ready;  // image indices
-    uint32_t closed = 0;          // images that will never be uploaded (failed) + uploaded ones are counted by the consumer
-    void push(uint32_t i) {
+    std::vector<std::pair<uint32_t, bool>> items;  // (image, upload?)
+    void push(uint32_t i, bool upload) {
         {
             std::lock_guard<std::mutex> g(m);
-            ready.push_back(i);
-        }
-        cv.notify_one();
-    }
-    void skip() {
-        {
-            std::lock_guard<std::mutex> g(m);
-            closed++;
+            items.emplace_back(i, upload);
         }
         cv.notify_one();
     }
@@ -172,6 +164,29 @@ bool same_geometry(const jpgpu_image_desc &a, const jpgpu_image_desc &b) {
         if (memcmp(&a.components[c], &b.components[c], sizeof(jpgpu_component)) != 0) return false;
     return true;
 }
+
+// The images of a call are cut into sub-batches (own jpgpu_batch, arenas and pinned staging each): as soon as the
+// last image of a sub-batch is uploaded its kernels and its download are enqueued, while the pool is still busy with
+// the entropy decoding of the following sub-batches.
+struct SubBatch {
+    jpgpu_batch *batch = nullptr;
+    std::vector<jpgpu_image_desc> descs;
+    uint8_t *h_coef = nullptr, *h_out = nullptr;
+    size_t h_coef_bytes = 0, h_out_bytes = 0;
+    uint32_t remaining = 0;  // images not yet uploaded / failed (uploader thread only)
+    hipEvent_t ready[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
+    void drop() {
+        if (batch) jpgpu_batch_destroy(batch);
+        batch = nullptr;
+        if (h_coef) (void)hipHostFree(h_coef);
+        if (h_out) (void)hipHostFree(h_out);
+        h_coef = h_out = nullptr;
+        h_coef_bytes = h_out_bytes = 0;
+        descs.clear();
+    }
+};
+
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 8, kComputeStreams = 2;
 
 }  // namespace
 
@@ -185,26 +200,15 @@ struct jpgpu_pipeline {
     std::vector<int> status;
     std::vector<std::string> errors;
     std::vector<jpgpu_image_info> infos;
-    std::vector<int32_t> slot;  // image -> index in the batch, -1 if it never got there
-    // the batch of the current geometry sequence
-    jpgpu_batch *batch = nullptr;
-    std::vector<jpgpu_image_desc> descs;
-    uint8_t *h_coef = nullptr, *h_out = nullptr;
-    size_t h_coef_bytes = 0, h_out_bytes = 0;
+    std::vector<int32_t> sub_of, slot;  // image -> sub-batch / index in it, -1 if it never got there
+    std::vector<SubBatch> subs;          // kept across calls while the geometry sequence repeats
+    uint32_t n_subs = 0;                 // sub-batches used by the last call
+    std::string path;
+    bool downloaded = false;  // the last call copied the pixels to host memory
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t compute = nullptr;
+    hipStream_t compute[kComputeStreams] = {nullptr, nullptr};
     jpgpu_pipeline_timings t{};
 };
-
-static void drop_batch(jpgpu_pipeline *p) {
-    if (p->batch) jpgpu_batch_destroy(p->batch);
-    p->batch = nullptr;
-    if (p->h_coef) (void)hipHostFree(p->h_coef);
-    if (p->h_out) (void)hipHostFree(p->h_out);
-    p->h_coef = p->h_out = nullptr;
-    p->h_coef_bytes = p->h_out_bytes = 0;
-    p->descs.clear();
-}
 
 #define P_HIP(call)                                                                                              \
     do {                                                                                                         \
@@ -223,8 +227,11 @@ int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) 
     if (rc) return rc;  // no usable MI355X: there is no CPU fallback for the pixel work
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
     p->pool.reset(new Pool(n_threads));
+    p->subs.resize(kMaxSubBatches);
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
-    P_HIP(hipStreamCreateWithFlags(&p->compute, hipStreamNonBlocking));
+    for (uint32_t k = 0; k < kComputeStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->compute[k], hipStreamNonBlocking));
+    for (SubBatch &sb : p->subs)
+        for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipEventCreateWithFlags(&sb.ready[k], hipEventDisableTiming));
     return JPGPU_OK;
 }
 
@@ -233,10 +240,15 @@ void jpgpu_pipeline_destroy(jpgpu_pipeline *p) {
     std::string e;
     if (jpgpu::use_device(p->device, e) == JPGPU_OK) {
         (void)hipDeviceSynchronize();
-        drop_batch(p);
+        for (SubBatch &sb : p->subs) {
+            sb.drop();
+            for (uint32_t k = 0; k < kCopyStreams; k++)
+                if (sb.ready[k]) (void)hipEventDestroy(sb.ready[k]);
+        }
         for (uint32_t k = 0; k < kCopyStreams; k++)
             if (p->copy_streams[k]) (void)hipStreamDestroy(p->copy_streams[k]);
-        if (p->compute) (void)hipStreamDestroy(p->compute);
+        for (uint32_t k = 0; k < kComputeStreams; k++)
+            if (p->compute[k]) (void)hipStreamDestroy(p->compute[k]);
     }
     delete p;
 }
@@ -248,13 +260,18 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     int rc = jpgpu::use_device(p->device, p->err);
     if (rc) return rc;
     const double t0 = now_ms();
+    const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0;
     p->n = n;
     p->fes.clear();
     p->fes.resize(n);
     p->status.assign(n, JPGPU_ERR_INTERNAL);
     p->errors.assign(n, std::string());
     p->infos.assign(n, jpgpu_image_info{});
+    p->sub_of.assign(n, -1);
     p->slot.assign(n, -1);
+    p->n_subs = 0;
+    p->downloaded = download;
+    p->path.clear();
     p->t = jpgpu_pipeline_timings{};
     p->t.threads = p->pool->size();
     std::vector<jpgpu_image_desc> cand(n);
@@ -288,146 +305,180 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     });
     const double t1 = now_ms();
 
-    // 2. batch of the images that have a frame (kept while the geometry sequence repeats)
-    std::vector<jpgpu_image_desc> descs;
+    // 2. sub-batches of the images that have a frame (each kept while its geometry sequence repeats)
+    std::vector<uint32_t> ok;
     for (uint32_t i = 0; i < n; i++)
-        if (p->status[i] == JPGPU_OK) {
-            p->slot[i] = (int32_t)descs.size();
-            descs.push_back(cand[i]);
-        }
-    if (descs.empty()) {
+        if (p->status[i] == JPGPU_OK) ok.push_back(i);
+    if (ok.empty()) {
         p->t.headers_ms = t1 - t0;
         p->t.total_ms = now_ms() - t0;
         return JPGPU_OK;
     }
-    bool reuse = p->batch && descs.size() == p->descs.size();
-    for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], p->descs[k]);
-    if (!reuse) {
-        drop_batch(p);
-        rc = jpgpu_batch_create(p->device, descs.data(), (uint32_t)descs.size(), JPGPU_BATCH_DEFAULT, &p->batch);
-        if (rc) {
-            p->err = p->batch ? jpgpu_batch_last_error(p->batch) : "batch_create";
-            // a frame the pixel backend refuses (e.g. an impossible sampling combination) fails every image of
-            // the call the same way the reference fails it in compute_image
-            for (uint32_t i = 0; i < n; i++)
-                if (p->status[i] == JPGPU_OK) {
-                    p->status[i] = rc;
-                    p->errors[i] = p->err;
-                    p->slot[i] = -1;
-                }
-            drop_batch(p);
-            p->t.total_ms = now_ms() - t0;
-            return JPGPU_OK;
+    const uint32_t n_subs = std::min<uint32_t>(kMaxSubBatches, ((uint32_t)ok.size() + kSubBatchImages - 1) / kSubBatchImages);
+    const uint32_t per_sub = ((uint32_t)ok.size() + n_subs - 1) / n_subs;
+    p->n_subs = n_subs;
+    for (uint32_t j = 0; j < n_subs; j++) {
+        SubBatch &sb = p->subs[j];
+        const uint32_t first = j * per_sub, last = std::min<uint32_t>(first + per_sub, (uint32_t)ok.size());
+        std::vector<jpgpu_image_desc> descs;
+        for (uint32_t k = first; k < last; k++) {
+            p->sub_of[ok[k]] = (int32_t)j;
+            p->slot[ok[k]] = (int32_t)(k - first);
+            descs.push_back(cand[ok[k]]);
         }
-        p->descs = descs;
-        p->h_coef_bytes = jpgpu_batch_coef_arena_bytes(p->batch);
-        P_HIP(hipHostMalloc((void **)&p->h_coef, p->h_coef_bytes, hipHostMallocDefault));
+        sb.remaining = last - first;
+        bool reuse = sb.batch && descs.size() == sb.descs.size();
+        for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], sb.descs[k]);
+        if (!reuse) {
+            sb.drop();
+            rc = jpgpu_batch_create(p->device, descs.data(), (uint32_t)descs.size(), JPGPU_BATCH_DEFAULT, &sb.batch);
+            if (rc) {
+                // a frame the pixel backend refuses (e.g. an impossible sampling combination) fails the images of
+                // its sub-batch the way the reference fails it in compute_image
+                const std::string msg = sb.batch ? jpgpu_batch_last_error(sb.batch) : "batch_create";
+                for (uint32_t k = first; k < last; k++) {
+                    p->status[ok[k]] = rc;
+                    p->errors[ok[k]] = msg;
+                    p->sub_of[ok[k]] = p->slot[ok[k]] = -1;
+                }
+                sb.drop();
+                sb.remaining = 0;
+                continue;
+            }
+            sb.descs = descs;
+            sb.h_coef_bytes = jpgpu_batch_coef_arena_bytes(sb.batch);
+            P_HIP(hipHostMalloc((void **)&sb.h_coef, sb.h_coef_bytes, hipHostMallocDefault));
+        }
+        if (download && !sb.h_out) {
+            sb.h_out_bytes = jpgpu_batch_out_arena_bytes(sb.batch);
+            P_HIP(hipHostMalloc((void **)&sb.h_out, sb.h_out_bytes, hipHostMallocDefault));
+        }
+        const char *pth = jpgpu_batch_path(sb.batch);
+        if (p->path.empty()) p->path = pth;
+        else if (p->path != pth) p->path = "mixed";
     }
-    if ((flags & JPGPU_PIPELINE_DOWNLOAD) && !p->h_out) {
-        p->h_out_bytes = jpgpu_batch_out_arena_bytes(p->batch);
-        P_HIP(hipHostMalloc((void **)&p->h_out, p->h_out_bytes, hipHostMallocDefault));
-    }
-    uint8_t *d_coef = (uint8_t *)jpgpu_batch_coef_arena(p->batch);
     const double t2 = now_ms();
 
-    // 3. entropy decoding (pool) + per-image upload (one uploader thread)
+    // 3. entropy decoding (pool) + per-image upload and per-sub-batch kernels / download (one uploader thread)
     std::atomic<uint64_t> jpeg_bytes{0}, coef_bytes{0};
     std::atomic<int> hip_failed{0};
     UploadQueue q;
-    const uint32_t n_jobs = (uint32_t)descs.size();
+    uint32_t n_jobs = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK) n_jobs++;
     std::vector<size_t> first_of(n), bytes_of(n);
+    std::string launch_err;
+    double t_last_upload = t2;
     std::thread uploader([&] {
         std::string e;
         if (jpgpu::use_device(p->device, e) != JPGPU_OK) hip_failed.store(1);
         uint32_t handled = 0, k = 0;
-        std::vector<uint32_t> take;
+        std::vector<std::pair<uint32_t, bool>> take;
         while (handled < n_jobs) {
             {
                 std::unique_lock<std::mutex> g(q.m);
-                q.cv.wait(g, [&] { return !q.ready.empty() || q.closed > 0; });
-                take.swap(q.ready);
-                handled += q.closed;
-                q.closed = 0;
+                q.cv.wait(g, [&] { return !q.items.empty(); });
+                take.swap(q.items);
             }
-            for (uint32_t i : take) {
-                if (!hip_failed.load() &&
-                    hipMemcpyAsync(d_coef + first_of[i], p->h_coef + first_of[i], bytes_of[i], hipMemcpyHostToDevice,
-                                   p->copy_streams[k++ % kCopyStreams]) != hipSuccess)
-                    hip_failed.store(1);
+            for (const auto &it : take) {
+                const uint32_t i = it.first;
+                SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
+                if (it.second && !hip_failed.load()) {
+                    uint8_t *d_coef = (uint8_t *)jpgpu_batch_coef_arena(sb.batch);
+                    if (hipMemcpyAsync(d_coef + first_of[i], sb.h_coef + first_of[i], bytes_of[i], hipMemcpyHostToDevice,
+                                       p->copy_streams[k++ % kCopyStreams]) != hipSuccess)
+                        hip_failed.store(1);
+                }
                 handled++;
+                if (--sb.remaining == 0 && !hip_failed.load()) {  // sub-batch complete: kernels + download behind its uploads
+                    hipStream_t cs = p->compute[(uint32_t)p->sub_of[i] % kComputeStreams];
+                    bool okk = true;
+                    for (uint32_t c = 0; c < kCopyStreams && okk; c++)
+                        okk = hipEventRecord(sb.ready[c], p->copy_streams[c]) == hipSuccess &&
+                              hipStreamWaitEvent(cs, sb.ready[c], 0) == hipSuccess;
+                    if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {
+                        launch_err = jpgpu_batch_last_error(sb.batch);
+                        okk = false;
+                    }
+                    if (okk && download)
+                        okk = hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, cs) == hipSuccess;
+                    if (!okk) hip_failed.store(1);
+                }
             }
             take.clear();
         }
+        t_last_upload = now_ms();
     });
     p->pool->run(n, [&](uint32_t i) {
         if (p->status[i] != JPGPU_OK) return;
+        SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
         const uint32_t bi = (uint32_t)p->slot[i];
         Frontend &fe = *p->fes[i];
         size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
         const uint32_t nc = fe.ncomp();
         for (uint32_t c = 0; c < nc; c++) {
-            off[c] = jpgpu_batch_coef_offset(p->batch, bi, c);
-            ln[c] = jpgpu_batch_coef_bytes(p->batch, bi, c);
+            off[c] = jpgpu_batch_coef_offset(sb.batch, bi, c);
+            ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
         }
         try {
-            StageSink sink(p->h_coef, off, ln);
+            StageSink sink(sb.h_coef, off, ln);
             fe.decode_to(sink);
             for (uint32_t c = 0; c < nc; c++)
                 if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
             for (uint32_t c = 0; c < nc; c++) {
-                jpgpu_batch_set_quantization_table(p->batch, bi, c, sink.qt(c));
-                jpgpu_batch_set_range_class(p->batch, bi, c, sink.range_class(c));
+                jpgpu_batch_set_quantization_table(sb.batch, bi, c, sink.qt(c));
+                jpgpu_batch_set_range_class(sb.batch, bi, c, sink.range_class(c));
             }
             // planes of one image are consecutive in the arena: one copy
             first_of[i] = off[0];
             bytes_of[i] = off[nc - 1] + ln[nc - 1] - off[0];
             jpeg_bytes += len[i];
             coef_bytes += bytes_of[i];
-            q.push(i);
+            q.push(i, true);
         } catch (const DecodeError &e) {
             p->status[i] = e.code;
             p->errors[i] = e.message;
-            q.skip();
+            q.push(i, false);
         } catch (const std::exception &e) {
             p->status[i] = JPGPU_ERR_INTERNAL;
             p->errors[i] = e.what();
-            q.skip();
+            q.push(i, false);
         }
     });
-    uploader.join();
-    if (hip_failed.load()) return jpgpu::set_err(p->err, JPGPU_ERR_IO, "hipMemcpyAsync (coefficient upload) failed");
-    for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamSynchronize(p->copy_streams[k]));
     const double t3 = now_ms();
+    uploader.join();
+    if (hip_failed.load())
+        return jpgpu::set_err(p->err, JPGPU_ERR_IO, "pipeline: upload / launch failed%s%s", launch_err.empty() ? "" : ": ", launch_err.c_str());
 
-    // 4. pixels
-    rc = jpgpu_batch_decode(p->batch, p->compute);
-    if (rc) return jpgpu::set_err(p->err, rc, "%s", jpgpu_batch_last_error(p->batch));
-    P_HIP(hipStreamSynchronize(p->compute));
+    // 4. drain: whatever kernels and downloads are still in flight
+    for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamSynchronize(p->copy_streams[k]));
+    for (uint32_t k = 0; k < kComputeStreams; k++) P_HIP(hipStreamSynchronize(p->compute[k]));
     const double t4 = now_ms();
     uint64_t pixel_bytes = 0;
-    uint32_t ok = 0;
+    uint32_t okc = 0;
     for (uint32_t i = 0; i < n; i++)
         if (p->status[i] == JPGPU_OK) {
-            ok++;
-            pixel_bytes += jpgpu_batch_out_bytes(p->batch, (uint32_t)p->slot[i]);
+            okc++;
+            pixel_bytes += jpgpu_batch_out_bytes(p->subs[(uint32_t)p->sub_of[i]].batch, (uint32_t)p->slot[i]);
         }
-    if (flags & JPGPU_PIPELINE_DOWNLOAD) {
-        const uint8_t *d_out = (const uint8_t *)jpgpu_batch_out_arena(p->batch);
-        P_HIP(hipMemcpyAsync(p->h_out, d_out, p->h_out_bytes, hipMemcpyDeviceToHost, p->compute));
-        P_HIP(hipStreamSynchronize(p->compute));
-    }
-    const double t5 = now_ms();
     p->t.headers_ms = t1 - t0;
     p->t.setup_ms = t2 - t1;
     p->t.entropy_and_upload_ms = t3 - t2;
-    p->t.kernels_ms = t4 - t3;
-    p->t.download_ms = t5 - t4;
-    p->t.total_ms = t5 - t0;
-    p->t.images_ok = ok;
+    p->t.kernels_ms = 0.0;  // overlapped: see drain_ms
+    p->t.download_ms = t4 - t3;
+    p->t.total_ms = t4 - t0;
+    p->t.images_ok = okc;
     p->t.jpeg_bytes = jpeg_bytes.load();
     p->t.coefficient_bytes = coef_bytes.load();
     p->t.pixel_bytes = pixel_bytes;
+    (void)t_last_upload;
     return JPGPU_OK;
+}
+
+static const SubBatch *sub_of(const jpgpu_pipeline *p, uint32_t i) {
+    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->sub_of[i] < 0) return nullptr;
+    const SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
+    return sb.batch ? &sb : nullptr;
 }
 
 int jpgpu_pipeline_image_status(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->status[i] : JPGPU_ERR_FORMAT; }
@@ -438,18 +489,18 @@ int jpgpu_pipeline_image_info(const jpgpu_pipeline *p, uint32_t i, jpgpu_image_i
     return JPGPU_OK;
 }
 size_t jpgpu_pipeline_pixel_bytes(const jpgpu_pipeline *p, uint32_t i) {
-    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->slot[i] < 0 || !p->batch) return 0;
-    return jpgpu_batch_out_bytes(p->batch, (uint32_t)p->slot[i]);
+    const SubBatch *sb = sub_of(p, i);
+    return sb ? jpgpu_batch_out_bytes(sb->batch, (uint32_t)p->slot[i]) : 0;
 }
 const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t i) {
-    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->slot[i] < 0 || !p->batch) return nullptr;
-    return (const uint8_t *)jpgpu_batch_out_arena(p->batch) + jpgpu_batch_out_offset(p->batch, (uint32_t)p->slot[i]);
+    const SubBatch *sb = sub_of(p, i);
+    return sb ? (const uint8_t *)jpgpu_batch_out_arena(sb->batch) + jpgpu_batch_out_offset(sb->batch, (uint32_t)p->slot[i]) : nullptr;
 }
 const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t i) {
-    if (!p || i >= p->n || p->status[i] != JPGPU_OK || p->slot[i] < 0 || !p->batch || !p->h_out) return nullptr;
-    return p->h_out + jpgpu_batch_out_offset(p->batch, (uint32_t)p->slot[i]);
+    const SubBatch *sb = sub_of(p, i);
+    return (sb && sb->h_out && p->downloaded) ? sb->h_out + jpgpu_batch_out_offset(sb->batch, (uint32_t)p->slot[i]) : nullptr;
 }
-const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return (p && p->batch) ? jpgpu_batch_path(p->batch) : ""; }
+const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return p ? p->path.c_str() : ""; }
 int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t) {
     if (!p || !t) return JPGPU_ERR_FORMAT;
     *t = p->t;
