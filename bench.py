@@ -57,9 +57,34 @@ def algorithmic_bytes_per_image(comps, out_bytes):
     return sum(c.block_width * c.block_height * 64 * 2 for c in comps) + out_bytes
 
 
+def effective_cpus():
+    """CPUs this process can really use: affinity mask and the cgroup CPU quota (the GPU box runs the container with
+    cpu.max = 16 CPUs although 256 hardware threads are visible)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, -(-q // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(O, ocomps, qts, coefs, w, h, ct, target_seconds):
-    """Oracle ("port" of the reference's scalar path) on all host cores, bounded sample."""
-    cores = os.cpu_count() or 1
+    """Oracle ("port" of the reference's scalar path) on the CPUs the process may use, bounded sample."""
+    cores = effective_cpus()
     n0 = max(cores, 4)
     t0 = time.perf_counter()
     O.batch_pixels(ocomps, qts, [coefs] * n0, w, h, ct.upper(), cores, keep_outputs=False)

@@ -170,6 +170,21 @@ int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t qu
  * src/worker/mod.rs:18-22): feeders learn it only while parsing the stream. Takes effect at the next decode. */
 int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t quantization_table[64]);
 
+/* Compact coefficient transport: PCIe carries, per component,
+ *     [ n_blocks x u64 bitmap | n_blocks x u32 first-value index | nnz x i16 values ]
+ * (bit k of a bitmap = natural-order coefficient k of the block is non-zero; values in ascending k; the index is the
+ * block's position in the value array) and a kernel expands it into the coefficient arena at the start of the next
+ * decode.  jpgpu_compact_encode converts `n_blocks` dense blocks (pure host function), returns the bytes written
+ * (<= jpgpu_compact_max_bytes) and, if asked, the range class of jpgpu_batch_set_range_hint.
+ * jpgpu_batch_upload_compact validates the buffer, copies it asynchronously on `hip_stream` (the buffer must stay
+ * valid until that stream reaches the copy; use pinned memory for real overlap) and marks the component for expansion;
+ * it also sets the component's range class when `range_class` >= 0. */
+size_t jpgpu_compact_max_bytes(size_t n_blocks);
+size_t jpgpu_compact_encode(const int16_t *coefficients, size_t n_blocks, const uint16_t quantization_table[64], void *dst,
+                            int *range_class);
+int jpgpu_batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes,
+                               int range_class, void *hip_stream);
+
 /* Enqueue the whole batch on `hip_stream` (a hipStream_t; NULL = the null stream). */
 int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream);
 int jpgpu_batch_synchronize(jpgpu_batch *b, void *hip_stream);

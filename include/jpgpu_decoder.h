@@ -95,9 +95,13 @@ typedef struct jpgpu_pipeline_timings {
     uint64_t jpeg_bytes, coefficient_bytes, pixel_bytes;
 } jpgpu_pipeline_timings;
 
-enum { JPGPU_PIPELINE_DOWNLOAD = 1u /* also copy the pixels to pinned host memory (jpgpu_pipeline_pixels_host) */ };
+enum {
+    JPGPU_PIPELINE_DOWNLOAD = 1u, /* also copy the pixels to pinned host memory (jpgpu_pipeline_pixels_host) */
+    JPGPU_PIPELINE_DENSE = 2u     /* send all 64 coefficients of every block over PCIe instead of the compact form
+                                   * (bitmap + index + non-zero values, jpgpu.h) — A/B switch, same pixels */
+};
 
-/* n_threads 0 = one per hardware thread. */
+/* n_threads 0 = half the hardware threads (one per physical core on an SMT-2 host). */
 int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out);
 void jpgpu_pipeline_destroy(jpgpu_pipeline *p);
 const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p);

@@ -57,7 +57,7 @@ class PipelineTimings(C.Structure):
                 ("pixel_bytes", C.c_uint64)]
 
 
-PIPELINE_DOWNLOAD = 1
+PIPELINE_DOWNLOAD, PIPELINE_DENSE = 1, 2
 
 
 class ImageInfoStruct(C.Structure):
@@ -110,6 +110,9 @@ _PROTOS = {
     "jpgpu_batch_set_range_class": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "jpgpu_range_class": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_batch_set_quantization_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "jpgpu_compact_max_bytes": (C.c_size_t, [C.c_size_t]),
+    "jpgpu_compact_encode": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "jpgpu_batch_upload_compact": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "jpgpu_batch_decode": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jpgpu_batch_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jpgpu_batch_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

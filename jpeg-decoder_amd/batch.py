@@ -79,6 +79,18 @@ class Batch:
         a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
         self._check(N.lib().jpgpu_batch_upload(self._h, image, comp, a.ctypes.data, a.size))
 
+    def upload_compact(self, image, comp, coefficients, stream=None):
+        """Same result as upload(), but PCIe carries only the non-zero coefficients (bitmap + index + values per block,
+        include/jpgpu.h); a kernel expands them into the arena at the start of the next decode()."""
+        a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
+        q = np.ascontiguousarray(np.ctypeslib.as_array(self.descs[image].quantization_tables[comp]), dtype=np.uint16)
+        buf = np.empty(N.lib().jpgpu_compact_max_bytes(a.size // 64), np.uint8)
+        rc = C.c_int(0)
+        n = N.lib().jpgpu_compact_encode(a.ctypes.data, a.size // 64, q.ctypes.data, buf.ctypes.data, C.byref(rc))
+        self._check(N.lib().jpgpu_batch_upload_compact(self._h, image, comp, buf.ctypes.data, n, rc.value, stream))
+        self.synchronize(stream)  # the host buffer is pageable and about to go away
+        return n
+
     def set_range_hint(self, image, range_class):
         """0 unknown/hostile, 1 every |c*q| < 2^15, 3 additionally every block-column sum of |c*q| <= 5900."""
         self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, int(range_class)))

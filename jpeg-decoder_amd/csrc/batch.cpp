@@ -14,6 +14,9 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
+#include "compact.hpp"
 #include "fused.hpp"
 #include "host_common.hpp"
 #include "kernels.hpp"
@@ -48,6 +51,13 @@ struct jpgpu_batch {
     std::vector<FusedPlan> fused;       // one per fusable kind present in the batch
     std::vector<uint32_t> generic_ids;  // images on the generic path
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // compact transport (compact.hpp): staging area in HBM, allocated at the first jpgpu_batch_upload_compact
+    std::mutex compact_mutex;
+    uint8_t *d_compact = nullptr;
+    std::vector<size_t> compact_off;      // [image*4 + comp]
+    std::vector<uint8_t> compact_pending; // [image*4 + comp]: uploaded, to be expanded by the next decode
+    ExpandJob *d_expand_jobs = nullptr;
+    bool any_compact_pending = false;
 };
 
 #define B_HIP(call)                                                                                     \
@@ -226,6 +236,8 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->own_out && b->d_out) hipFree(b->d_out);
         if (b->d_planes) hipFree(b->d_planes);
         if (b->d_qt) hipFree(b->d_qt);
+        if (b->d_compact) hipFree(b->d_compact);
+        if (b->d_expand_jobs) hipFree(b->d_expand_jobs);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
         if (b->d_image_jobs) hipFree(b->d_image_jobs);
         for (FusedPlan &fp : b->fused) fused_free(fp);
@@ -333,6 +345,89 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
     return JPGPU_OK;
 }
 
+}  // extern "C"
+
+// `trusted`: the buffer comes from CompactWriter in this library (pipeline.cpp) — skip the consistency pass
+int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes,
+                                int range_class, void *hip_stream, bool trusted) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    if (image >= b->descs.size() || comp >= b->descs[image].ncomp || !compact)
+        return set_err(b->err, JPGPU_ERR_FORMAT, "upload_compact: bad image/component");
+    const size_t idx = (size_t)image * 4 + comp, nblk = b->coef_len[idx] / 128;
+    // the device trusts the index: check it here (one pass over the fixed part)
+    if (bytes < nblk * 12 || ((bytes - nblk * 12) & 1) || bytes > compact_max_bytes(nblk))
+        return set_err(b->err, JPGPU_ERR_FORMAT, "upload_compact: %zu bytes do not fit %zu blocks", bytes, nblk);
+    if (!trusted) {
+        const uint64_t *bm = static_cast<const uint64_t *>(compact);
+        const uint32_t *first = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(compact) + nblk * 8);
+        size_t n = 0;
+        for (size_t k = 0; k < nblk; k++) {
+            if (first[k] != n) return set_err(b->err, JPGPU_ERR_FORMAT, "upload_compact: inconsistent value index at block %zu", k);
+            n += (size_t)__builtin_popcountll(bm[k]);
+        }
+        if (n * 2 != bytes - nblk * 12) return set_err(b->err, JPGPU_ERR_FORMAT, "upload_compact: value count does not match the bitmaps");
+    }
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    {
+        std::lock_guard<std::mutex> g(b->compact_mutex);
+        if (!b->d_compact) {
+            const size_t n = b->descs.size();
+            b->compact_off.assign(n * 4, 0);
+            b->compact_pending.assign(n * 4, 0);
+            size_t off = 0;
+            for (size_t i = 0; i < n; i++)
+                for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
+                    b->compact_off[i * 4 + c] = off;
+                    off += align_up(compact_max_bytes(b->coef_len[i * 4 + c] / 128), 256);
+                }
+            B_HIP(hipMalloc((void **)&b->d_compact, std::max<size_t>(off, 256)));
+            B_HIP(hipMalloc((void **)&b->d_expand_jobs, n * 4 * sizeof(ExpandJob)));
+        }
+        b->compact_pending[idx] = 1;
+        b->any_compact_pending = true;
+    }
+    if (range_class >= 0 && b->sane[idx] != (uint8_t)(range_class & 3)) {
+        b->sane[idx] = (uint8_t)(range_class & 3);
+        b->jobs_dirty = true;
+    }
+    B_HIP(hipMemcpyAsync(b->d_compact + b->compact_off[idx], compact, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    return JPGPU_OK;
+}
+
+extern "C" {
+
+int jpgpu_batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes,
+                               int range_class, void *hip_stream) {
+    return jpgpu::batch_upload_compact(b, image, comp, compact, bytes, range_class, hip_stream, false);
+}
+
+// compact uploads since the last decode -> dense coefficient arena, on the decode stream
+static int batch_expand_pending(jpgpu_batch *b, hipStream_t s) {
+    std::vector<ExpandJob> jobs;
+    uint32_t max_blocks = 0;
+    {
+        std::lock_guard<std::mutex> g(b->compact_mutex);
+        if (!b->any_compact_pending) return JPGPU_OK;
+        for (size_t idx = 0; idx < b->compact_pending.size(); idx++)
+            if (b->compact_pending[idx]) {
+                ExpandJob j{};
+                j.compact = b->d_compact + b->compact_off[idx];
+                j.dense = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]);
+                j.n_blocks = (uint32_t)(b->coef_len[idx] / 128);
+                max_blocks = std::max(max_blocks, j.n_blocks);
+                jobs.push_back(j);
+                b->compact_pending[idx] = 0;
+            }
+        b->any_compact_pending = false;
+    }
+    if (jobs.empty()) return JPGPU_OK;
+    B_HIP(hipMemcpy(b->d_expand_jobs, jobs.data(), jobs.size() * sizeof(ExpandJob), hipMemcpyHostToDevice));
+    B_HIP(launch_expand_compact(b->d_expand_jobs, (uint32_t)jobs.size(), max_blocks, s));
+    return JPGPU_OK;
+}
+
 int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     if (!b) return JPGPU_ERR_FORMAT;
     int rc = use_device(b->device, b->err);
@@ -340,6 +435,8 @@ int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     rc = batch_refresh_jobs(b);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
+    rc = batch_expand_pending(b, s);
+    if (rc) return rc;
     for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s));
     if (b->generic_ids.empty()) return JPGPU_OK;
     const uint32_t n = (uint32_t)b->image_jobs.size();

@@ -19,4 +19,8 @@ int build_image_job(const jpgpu_component *comps, uint32_t ncomp, uint8_t *const
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// jpgpu_batch_upload_compact for buffers written by CompactWriter inside this library (no consistency pass)
+int batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes, int range_class,
+                         void *hip_stream, bool trusted);
+
 }  // namespace jpgpu

@@ -9,6 +9,8 @@
 
 #include "host_common.hpp"
 
+#include "compact.hpp"
+
 namespace jpgpu {
 
 int set_err(std::string &dst, int code, const char *fmt, ...) {
@@ -150,3 +152,17 @@ int build_image_job(const jpgpu_component *comps, uint32_t ncomp, uint8_t *const
 }
 
 }  // namespace jpgpu
+
+// ---- compact coefficient transport: host encoder (include/jpgpu.h) ---------------------------------------------
+extern "C" {
+
+size_t jpgpu_compact_max_bytes(size_t n_blocks) { return jpgpu::compact_max_bytes(n_blocks); }
+
+size_t jpgpu_compact_encode(const int16_t *coefficients, size_t n_blocks, const uint16_t q[64], void *dst, int *range_class) {
+    if (!coefficients || !dst) return 0;
+    jpgpu::CompactWriter w(dst, n_blocks, q);
+    w.add_blocks(coefficients, n_blocks);
+    return w.finish(range_class);
+}
+
+}  // extern "C"

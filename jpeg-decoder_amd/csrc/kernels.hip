@@ -11,6 +11,7 @@
 // supports.  Same-geometry 4:2:0 / 4:4:4 / gray batches take the fused kernels in
 // fused.hip instead; this file is the path everything else (and every odd edge) runs on.
 #include "kernels.hpp"
+#include "compact.hpp"
 #include "pixel_math.hpp"
 #include "idct_plane_body.hpp"
 #include "upsample_color_body.hpp"
@@ -50,7 +51,39 @@ __global__ __launch_bounds__(256) void upsample_color_one_kernel(ImageJob job) {
     upsample_color_lane(job, (blockIdx.x * 256u + threadIdx.x) * 8u, blockIdx.y);
 }
 
+// ------------------------------------------------------------------------------------------
+// Compact transport -> dense coefficient arena (compact.hpp).  Eight lanes per block, one per row of eight
+// coefficients: a lane finds its values at index[block] + popcount(bitmap bits below its row) and writes its 16-B row,
+// so a wave writes 1 KiB of consecutive arena bytes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_compact_kernel(const ExpandJob *__restrict__ jobs) {
+    const ExpandJob job = jobs[blockIdx.y];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, b = t >> 3, r = t & 7u;
+    if (b >= job.n_blocks) return;
+    const JP_GLOBAL uint64_t *bitmaps = (const JP_GLOBAL uint64_t *)job.compact;
+    const JP_GLOBAL uint32_t *first = (const JP_GLOBAL uint32_t *)(job.compact + (size_t)job.n_blocks * 8u);
+    const JP_GLOBAL int16_t *values = (const JP_GLOBAL int16_t *)(job.compact + (size_t)job.n_blocks * 12u);
+    const uint64_t bm = bitmaps[b];
+    const uint32_t bits = (uint32_t)(bm >> (8u * r)) & 0xffu;
+    uint32_t idx = first[b] + (uint32_t)__popcll(bm & ((1ull << (8u * r)) - 1ull));
+    uint32_t v[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        v[k] = 0u;
+        if (bits & (1u << k)) v[k] = (uint16_t)values[idx++];
+    }
+    const v4u row = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    *reinterpret_cast<JP_GLOBAL v4u *>((JP_GLOBAL uint8_t *)job.dense + (size_t)b * 128u + r * 16u) = row;
+}
+
 // ---- launchers ---------------------------------------------------------------------------
+hipError_t launch_expand_compact(const ExpandJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, hipStream_t stream) {
+    if (n_jobs == 0 || max_blocks == 0) return hipSuccess;
+    dim3 grid((max_blocks * 8u + 255u) / 256u, n_jobs), block(256);
+    expand_compact_kernel<<<grid, block, 0, stream>>>(d_jobs);
+    return hipGetLastError();
+}
+
 hipError_t launch_idct_planes(const PlaneJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t scale,
                               hipStream_t stream) {
     if (n_jobs == 0 || max_blocks == 0) return hipSuccess;

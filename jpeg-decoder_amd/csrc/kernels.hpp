@@ -8,6 +8,8 @@
 
 namespace jpgpu {
 
+struct ExpandJob;
+hipError_t launch_expand_compact(const ExpandJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, hipStream_t stream);
 hipError_t launch_idct_planes(const PlaneJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t scale,
                               hipStream_t stream);
 hipError_t launch_idct_plane_one(const PlaneJob &job, hipStream_t stream);

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -14,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "compact.hpp"
 #include "host/frontend.hpp"
 #include "host_common.hpp"
 
@@ -95,11 +98,15 @@ private:
     bool stop_ = false;
 };
 
-// Worker of one image: rows go straight to their final place in the pinned staging arena (the frame slot of a
-// worker index is known from frame_slot_hint), so a coefficient is written once on the host.
+// Worker of one image: rows go straight to their final place in the pinned staging memory (the frame slot of a worker
+// index is known from frame_slot_hint), so a coefficient is written once on the host — either as it is (dense mode:
+// the staging memory mirrors the coefficient arena) or in the compact transport form (compact.hpp), which is what
+// the pipeline sends by default.
 class StageSink : public RowSink {
 public:
-    StageSink(uint8_t *stage, const size_t (&off)[4], const size_t (&len)[4]) : stage_(stage) {
+    // dense: off/len = the component's place in the arena image of `stage`; compact: off = its compact region
+    // (compact_max_bytes(len / 128)) in `stage`
+    StageSink(uint8_t *stage, const size_t (&off)[4], const size_t (&len)[4], bool compact) : stage_(stage), compact_(compact) {
         for (int c = 0; c < 4; c++) {
             off_[c] = off[c];
             len_[c] = len[c];
@@ -107,14 +114,23 @@ public:
             done_[c] = false;
             slot_of_[c] = (uint32_t)c;
             written_[c] = 0;
+            bytes_[c] = 0;
         }
     }
     void frame_slot_hint(uint32_t index, uint32_t slot) override { slot_of_[index] = slot; }
     void start(uint32_t index, const jpgpu_component &, const uint16_t qt[64]) override {
         written_[index] = 0;
         memcpy(qt_[index], qt, 128);
+        if (compact_) {
+            const uint32_t slot = slot_of_[index];
+            writer_[index].reset(new jpgpu::CompactWriter(stage_ + off_[slot], len_[slot] / 128, qt_[index]));
+        }
     }
     void append_row(uint32_t index, const int16_t *co, size_t len) override {
+        if (compact_) {
+            writer_[index]->add_blocks(co, len / 64);
+            return;
+        }
         const uint32_t slot = slot_of_[index];
         const size_t room = len_[slot] - written_[index], bytes = len * sizeof(int16_t);
         const size_t n = bytes < room ? bytes : room;  // rows past the plane are dropped like the Worker drops them
@@ -125,22 +141,31 @@ public:
         if (slot != slot_of_[index]) throw DecodeError{JPGPU_ERR_INTERNAL, "pipeline: plane finished under another frame slot"};
         // a scan may end early (src/decoder.rs:1000-1006 breaks out of the MCU loops at the image edge): the
         // plane keeps zeros where no row was appended, like the Worker's zero-initialised plane
-        if (written_[index] < len_[slot]) memset(stage_ + off_[slot] + written_[index], 0, len_[slot] - written_[index]);
-        range_[slot] = jpgpu_range_class(reinterpret_cast<const int16_t *>(stage_ + off_[slot]), len_[slot] / sizeof(int16_t), qt_[index]);
+        if (compact_) {
+            bytes_[slot] = writer_[index]->finish(&range_[slot]);
+            writer_[index].reset();
+        } else {
+            if (written_[index] < len_[slot]) memset(stage_ + off_[slot] + written_[index], 0, len_[slot] - written_[index]);
+            range_[slot] = jpgpu_range_class(reinterpret_cast<const int16_t *>(stage_ + off_[slot]), len_[slot] / sizeof(int16_t), qt_[index]);
+            bytes_[slot] = len_[slot];
+        }
         memcpy(slot_qt_[slot], qt_[index], 128);
         done_[slot] = true;
     }
     int range_class(uint32_t slot) const { return range_[slot]; }
     bool done(uint32_t slot) const { return done_[slot]; }
     const uint16_t *qt(uint32_t slot) const { return slot_qt_[slot]; }
+    size_t bytes(uint32_t slot) const { return bytes_[slot]; }  // to send for this component
 
 private:
     uint8_t *stage_;
-    size_t off_[4], len_[4], written_[4];
+    bool compact_;
+    size_t off_[4], len_[4], written_[4], bytes_[4];
     uint32_t slot_of_[4];
     uint16_t qt_[4][64], slot_qt_[4][64];
     int range_[4];
     bool done_[4];
+    std::unique_ptr<jpgpu::CompactWriter> writer_[4];
 };
 
 // Finished images are handed to one uploader thread: hipMemcpyAsync calls from hundreds of threads contend in the
@@ -173,6 +198,8 @@ struct SubBatch {
     std::vector<jpgpu_image_desc> descs;
     uint8_t *h_coef = nullptr, *h_out = nullptr;
     size_t h_coef_bytes = 0, h_out_bytes = 0;
+    bool compact = false;             // layout of h_coef: compact regions (stage_off) or a mirror of the arena
+    std::vector<size_t> stage_off;    // compact mode: [image*4 + comp] offset of the component's region in h_coef
     uint32_t remaining = 0;  // images not yet uploaded / failed (uploader thread only)
     hipEvent_t ready[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     void drop() {
@@ -183,6 +210,7 @@ struct SubBatch {
         h_coef = h_out = nullptr;
         h_coef_bytes = h_out_bytes = 0;
         descs.clear();
+        stage_off.clear();
     }
 };
 
@@ -225,7 +253,7 @@ int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) 
     p->device = device;
     int rc = jpgpu::use_device(device, p->err);
     if (rc) return rc;  // no usable MI355X: there is no CPU fallback for the pixel work
-    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency() / 2u);  // one per physical core: SMT siblings and the uploader thread made 256 threads slower and erratic on the 2 x 64-core host
     p->pool.reset(new Pool(n_threads));
     p->subs.resize(kMaxSubBatches);
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
@@ -260,7 +288,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     int rc = jpgpu::use_device(p->device, p->err);
     if (rc) return rc;
     const double t0 = now_ms();
-    const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0;
+    const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0, compact = (flags & JPGPU_PIPELINE_DENSE) == 0;
     p->n = n;
     p->fes.clear();
     p->fes.resize(n);
@@ -327,7 +355,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             descs.push_back(cand[ok[k]]);
         }
         sb.remaining = last - first;
-        bool reuse = sb.batch && descs.size() == sb.descs.size();
+        bool reuse = sb.batch && descs.size() == sb.descs.size() && sb.compact == compact;
         for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], sb.descs[k]);
         if (!reuse) {
             sb.drop();
@@ -346,7 +374,18 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 continue;
             }
             sb.descs = descs;
+            sb.compact = compact;
             sb.h_coef_bytes = jpgpu_batch_coef_arena_bytes(sb.batch);
+            if (compact) {  // worst-case compact size per component (12 B/block more than dense), 256-B aligned
+                sb.stage_off.assign(descs.size() * 4, 0);
+                size_t so = 0;
+                for (size_t k = 0; k < descs.size(); k++)
+                    for (uint32_t c = 0; c < descs[k].ncomp; c++) {
+                        sb.stage_off[k * 4 + c] = so;
+                        so += jpgpu::align_up(jpgpu::compact_max_bytes(jpgpu_batch_coef_bytes(sb.batch, (uint32_t)k, c) / 128), 256);
+                    }
+                sb.h_coef_bytes = std::max<size_t>(so, 256);
+            }
             P_HIP(hipHostMalloc((void **)&sb.h_coef, sb.h_coef_bytes, hipHostMallocDefault));
         }
         if (download && !sb.h_out) {
@@ -366,9 +405,14 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     uint32_t n_jobs = 0;
     for (uint32_t i = 0; i < n; i++)
         if (p->status[i] == JPGPU_OK) n_jobs++;
-    std::vector<size_t> first_of(n), bytes_of(n);
+    std::vector<size_t> first_of(n), bytes_of(n);  // dense mode: one copy per image
+    std::vector<size_t> cbytes((size_t)n * 4, 0);  // compact mode: bytes per component
+    std::vector<int> crange((size_t)n * 4, 0);
     std::string launch_err;
     double t_last_upload = t2;
+    const bool trace = getenv("JPGPU_PIPE_TRACE") != nullptr;
+    std::mutex trace_m;
+    double busy_sum = 0, busy_max = 0, last_end = 0;
     std::thread uploader([&] {
         std::string e;
         if (jpgpu::use_device(p->device, e) != JPGPU_OK) hip_failed.store(1);
@@ -384,10 +428,20 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 const uint32_t i = it.first;
                 SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
                 if (it.second && !hip_failed.load()) {
-                    uint8_t *d_coef = (uint8_t *)jpgpu_batch_coef_arena(sb.batch);
-                    if (hipMemcpyAsync(d_coef + first_of[i], sb.h_coef + first_of[i], bytes_of[i], hipMemcpyHostToDevice,
-                                       p->copy_streams[k++ % kCopyStreams]) != hipSuccess)
-                        hip_failed.store(1);
+                    hipStream_t cps = p->copy_streams[k++ % kCopyStreams];
+                    if (sb.compact) {
+                        const uint32_t bi = (uint32_t)p->slot[i];
+                        for (uint32_t c = 0; c < sb.descs[bi].ncomp; c++)
+                            if (jpgpu::batch_upload_compact(sb.batch, bi, c, sb.h_coef + sb.stage_off[(size_t)bi * 4 + c],
+                                                            cbytes[(size_t)i * 4 + c], crange[(size_t)i * 4 + c], cps, true) != JPGPU_OK) {
+                                launch_err = jpgpu_batch_last_error(sb.batch);
+                                hip_failed.store(1);
+                            }
+                    } else {
+                        uint8_t *d_coef = (uint8_t *)jpgpu_batch_coef_arena(sb.batch);
+                        if (hipMemcpyAsync(d_coef + first_of[i], sb.h_coef + first_of[i], bytes_of[i], hipMemcpyHostToDevice, cps) != hipSuccess)
+                            hip_failed.store(1);
+                    }
                 }
                 handled++;
                 if (--sb.remaining == 0 && !hip_failed.load()) {  // sub-batch complete: kernels + download behind its uploads
@@ -417,23 +471,35 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
         const uint32_t nc = fe.ncomp();
         for (uint32_t c = 0; c < nc; c++) {
-            off[c] = jpgpu_batch_coef_offset(sb.batch, bi, c);
+            off[c] = sb.compact ? sb.stage_off[(size_t)bi * 4 + c] : jpgpu_batch_coef_offset(sb.batch, bi, c);
             ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
         }
         try {
-            StageSink sink(sb.h_coef, off, ln);
+            const double w0 = trace ? now_ms() : 0.0;
+            StageSink sink(sb.h_coef, off, ln, sb.compact);
             fe.decode_to(sink);
+            if (trace) {
+                const double w1 = now_ms();
+                std::lock_guard<std::mutex> g(trace_m);
+                busy_sum += w1 - w0;
+                busy_max = std::max(busy_max, w1 - w0);
+                last_end = std::max(last_end, w1);
+            }
             for (uint32_t c = 0; c < nc; c++)
                 if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
+            size_t sent = 0;
             for (uint32_t c = 0; c < nc; c++) {
                 jpgpu_batch_set_quantization_table(sb.batch, bi, c, sink.qt(c));
                 jpgpu_batch_set_range_class(sb.batch, bi, c, sink.range_class(c));
+                cbytes[(size_t)i * 4 + c] = sink.bytes(c);
+                crange[(size_t)i * 4 + c] = sink.range_class(c);
+                sent += sink.bytes(c);
             }
-            // planes of one image are consecutive in the arena: one copy
+            // dense mode: the planes of one image are consecutive in the arena: one copy
             first_of[i] = off[0];
             bytes_of[i] = off[nc - 1] + ln[nc - 1] - off[0];
             jpeg_bytes += len[i];
-            coef_bytes += bytes_of[i];
+            coef_bytes += sb.compact ? sent : bytes_of[i];
             q.push(i, true);
         } catch (const DecodeError &e) {
             p->status[i] = e.code;
@@ -446,6 +512,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         }
     });
     const double t3 = now_ms();
+    if (trace) fprintf(stderr, "pipeline trace: workers %.1f ms wall, decode_to sum %.1f ms (avg %.2f, max %.2f), last decode end +%.1f ms\n", t3 - t2, busy_sum, busy_sum / std::max(1u, n_jobs), busy_max, last_end - t2);
     uploader.join();
     if (hip_failed.load())
         return jpgpu::set_err(p->err, JPGPU_ERR_IO, "pipeline: upload / launch failed%s%s", launch_err.empty() ? "" : ": ", launch_err.c_str());

@@ -95,3 +95,36 @@ def test_pipeline_needs_a_device():
         pytest.skip("a GPU is visible")
     with pytest.raises(J.NoDeviceError):
         J.Pipeline()
+
+
+def _expand_compact(buf, n_blocks):
+    """Reference reading of the compact format of include/jpgpu.h (numpy, test side)."""
+    import numpy as np
+    bm = np.frombuffer(buf, np.uint64, n_blocks, 0)
+    first = np.frombuffer(buf, np.uint32, n_blocks, 8 * n_blocks)
+    values = np.frombuffer(buf, np.int16, (len(buf) - 12 * n_blocks) // 2, 12 * n_blocks)
+    out = np.zeros((n_blocks, 64), np.int16)
+    for b in range(n_blocks):
+        ks = [k for k in range(64) if (int(bm[b]) >> k) & 1]
+        out[b, ks] = values[int(first[b]): int(first[b]) + len(ks)]
+    return out.reshape(-1)
+
+
+def test_compact_encoder_round_trip_and_range_class():
+    """jpgpu_compact_encode (pure host code): bitmap + index + values reproduce the dense blocks; size and range class
+    as documented."""
+    import numpy as np
+    import synth
+    lib = J.lib()
+    rng = np.random.default_rng(11)
+    q = rng.integers(1, 60, 64).astype(np.uint16)
+    for nblk, maker in [(1, lambda: np.zeros(64, np.int16)), (37, lambda: synth.sparse_coefficients(rng, 37)),
+                        (5, lambda: rng.integers(-32768, 32768, 5 * 64).astype(np.int16)), (0, lambda: np.zeros(0, np.int16))]:
+        c = np.ascontiguousarray(maker(), np.int16)
+        buf = np.zeros(lib.jpgpu_compact_max_bytes(nblk) + 16, np.uint8)
+        rc = C.c_int(-1)
+        n = lib.jpgpu_compact_encode(c.ctypes.data, nblk, q.ctypes.data, buf.ctypes.data, C.byref(rc))
+        assert n == 12 * nblk + 2 * int(np.count_nonzero(c)) <= lib.jpgpu_compact_max_bytes(nblk)
+        assert (buf[n:] == 0).all()
+        assert np.array_equal(_expand_compact(buf[:n].tobytes(), nblk), c)
+        assert rc.value == lib.jpgpu_range_class(c.ctypes.data, c.size, q.ctypes.data)

@@ -411,3 +411,59 @@ def test_batch_of_different_kinds_runs_one_fused_launch_per_kind():
     assert path == "mixed"
     for (oc, qts, coefs, ct_, w_, h_), got in zip(cases[1:3], outs):
         assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+
+
+@pytest.mark.parametrize("case", [(250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+                                  (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (300, 200, [(1, 1)], "Grayscale"),
+                                  (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK")], ids=["420", "444", "422", "gray", "ycck-generic"])
+@pytest.mark.parametrize("kind", ["sparse", "full"])
+def test_batch_compact_upload_equals_dense_upload(case, kind):
+    """Compact coefficient transport (bitmap + index + values over PCIe, expand kernel on the device): same pixels as
+    the dense upload, for sparse JPEG-like data and for blocks without a single zero."""
+    w_, h_, samp, ct = case
+    rng = np.random.default_rng(w_ * 3 + h_)
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind=kind) for _ in range(3)]
+    descs = [J.image_desc(list(to_j(oc)), qts, w_, h_, ct) for oc, qts, _, ct, w_, h_ in cases]
+    b = J.Batch(descs)
+    sent = dense = 0
+    for i, (oc, qts, coefs, _ct, _w, _h) in enumerate(cases):
+        for c in range(len(oc)):
+            sent += b.upload_compact(i, c, coefs[c])
+            dense += coefs[c].size * 2
+    b.decode()
+    b.synchronize()
+    for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+        assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+    if kind == "sparse":
+        assert sent < dense / 2
+    # a second decode without new uploads works on the expanded arena; dense uploads afterwards still work
+    b.decode()
+    b.synchronize()
+    oc, qts, coefs, ct_, _w, _h = cases[0]
+    assert np.array_equal(b.download(0), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+    oc1, qts1, coefs1, ct1, _w, _h = cases[1]
+    for c in range(len(oc1)):
+        b.upload(1, c, coefs1[c][::-1].copy())  # something else, densely
+    b.decode()
+    b.synchronize()
+    assert np.array_equal(b.download(1), O.pixels_from_coefficients(oc1, qts1, [x[::-1].copy() for x in coefs1], w_, h_, ct1.upper()))
+    assert np.array_equal(b.download(0), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+    b.close()
+
+
+def test_batch_compact_upload_rejects_inconsistent_buffers():
+    rng = np.random.default_rng(1)
+    oc, qts, coefs, ct, w_, h_ = _batch_case(rng, 64, 48, [(1, 1)], "Grayscale")
+    b = J.Batch([J.image_desc(list(to_j(oc)), qts, w_, h_, ct)])
+    L = J.lib()
+    nblk = coefs[0].size // 64
+    buf = np.zeros(L.jpgpu_compact_max_bytes(nblk), np.uint8)
+    n = L.jpgpu_compact_encode(coefs[0].ctypes.data, nblk, qts[0].ctypes.data, buf.ctypes.data, None)
+    assert L.jpgpu_batch_upload_compact(b._h, 0, 0, buf.ctypes.data, n - 2, -1, None) == J._native.ERR_FORMAT   # short
+    bad = buf.copy()
+    bad[8 * nblk + 4] ^= 1  # index of block 1
+    assert L.jpgpu_batch_upload_compact(b._h, 0, 0, bad.ctypes.data, n, -1, None) == J._native.ERR_FORMAT
+    assert L.jpgpu_batch_upload_compact(b._h, 0, 0, buf.ctypes.data, 12 * nblk - 1, -1, None) == J._native.ERR_FORMAT
+    assert L.jpgpu_batch_upload_compact(b._h, 0, 0, buf.ctypes.data, n, -1, None) == 0
+    b.synchronize()
+    b.close()

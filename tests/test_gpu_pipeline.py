@@ -53,9 +53,13 @@ def test_pipeline_mixed_files_one_call():
     _check(names, files, out)
     t = p.timings()
     assert t["images_ok"] == len(files) - with_errors and t["total_ms"] > 0
-    # the same pipeline object, different batch afterwards
+
+    # the same pipeline object, different batch afterwards; then the dense transport (A/B switch)
     out2 = p.decode(files[:5])
     _check(names[:5], files[:5], out2)
+    out3 = p.decode(files, dense=True)
+    _check(names, files, out3)
+    assert p.timings()["coefficient_bytes"] > t["coefficient_bytes"]
     p.close()
 
 

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--no-download", action="store_true")
     ap.add_argument("--progressive", action="store_true")
+    ap.add_argument("--sleep", type=float, default=0.0, help="seconds to idle between rounds")
+    ap.add_argument("--dense", action="store_true", help="send dense coefficient planes (A/B against the compact transport)")
     ap.add_argument("--file", default=None, help="use this JPEG (replicated) instead of the synthetic images")
     args = ap.parse_args()
     from PIL import Image
@@ -44,8 +46,10 @@ def main():
     files = [distinct[i % len(distinct)] for i in range(args.images)]
     p = J.Pipeline(threads=args.threads)
     best = None
+    import time
     for r in range(args.rounds):
-        out = p.decode(files, download=not args.no_download)
+        time.sleep(args.sleep)
+        out = p.decode(files, download=not args.no_download, dense=args.dense)
         bad = [o for o in out if isinstance(o, Exception)]
         assert not bad, bad[:1]
         t = p.timings()
@@ -54,7 +58,7 @@ def main():
     mp = args.images * args.width * args.height / 1e6
     print(json.dumps({
         "what": "jpgpu_pipeline_decode: JPEG bytes (host) -> RGB" + (" (left in HBM)" if args.no_download else " (pinned host memory)"),
-        "images": args.images, "geometry": (os.path.basename(args.file) + f" {args.width}x{args.height}") if args.file else
+        "transport": "dense" if args.dense else "compact", "images": args.images, "geometry": (os.path.basename(args.file) + f" {args.width}x{args.height}") if args.file else
         f"{args.width}x{args.height} {args.subsampling} q{args.quality}" + (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
         "MP_per_s": round(mp / best["total_ms"] * 1e3, 1), "images_per_s": round(args.images / best["total_ms"] * 1e3, 1),
         "ms": {k: round(v, 2) for k, v in best.items() if k.endswith("_ms")},
