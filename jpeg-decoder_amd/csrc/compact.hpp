@@ -7,6 +7,9 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace jpgpu {
 
@@ -27,23 +30,71 @@ struct CompactWriter {
     size_t n_blocks, done = 0;
     uint32_t n_values = 0;
     int32_t qq[64], max_abs = 0, max_col = 0;
-    bool have_q;
+    bool have_q, simd_total = false;
+#if defined(__SSE2__)
+    __m128i qv[8];
+#endif
     CompactWriter(void *dst, size_t n_blocks_, const uint16_t *q) : n_blocks(n_blocks_), have_q(q != nullptr) {
         uint8_t *out = static_cast<uint8_t *>(dst);
         bitmaps = reinterpret_cast<uint64_t *>(out);
         first = reinterpret_cast<uint32_t *>(out + n_blocks * 8u);
         values = reinterpret_cast<int16_t *>(out + n_blocks * 12u);
         for (int k = 0; k < 64; k++) qq[k] = q ? q[k] : 0;
+#if defined(__SSE2__)
+        if (q) {
+            simd_total = true;
+            // 8-bit tables only: then 32 pmaddwd pair sums (each <= 2 * 32767 * 255) cannot overflow the 32-bit total, so
+            // hostile coefficients can never wrap it into the accepted range; 16-bit tables take the exact path
+            for (int k = 0; k < 64; k++) simd_total = simd_total && q[k] <= 255;
+            for (int g = 0; g < 8; g++) qv[g] = _mm_loadu_si128(reinterpret_cast<const __m128i *>(q + 8 * g));
+        }
+#endif
     }
     void add_blocks(const int16_t *coefficients, size_t count) {
         if (count > n_blocks - done) count = n_blocks - done;  // rows past the plane are dropped
         for (size_t b = 0; b < count; b++) {
             const int16_t *p = coefficients + b * 64;
             uint64_t bm = 0;
-            for (int k = 0; k < 64; k++) bm |= (uint64_t)(p[k] != 0) << k;  // (vectorises)
+            bool detail = true;  // per-coefficient range bookkeeping needed for this block
+#if defined(__SSE2__)
+            // bitmap of non-zeros, 16 coefficients per step; and sum of |c|*q over the block: if even that total is
+            // within the column-sum limit of class 3 (8-bit tables only, see the constructor), every
+            // column sum and every single product is, and the block needs no further range work
+            const __m128i zero = _mm_setzero_si128();
+            __m128i total = zero;
+            for (int g = 0; g < 4; g++) {
+                const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p + 16 * g));
+                const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p + 16 * g + 8));
+                const uint32_t z = (uint32_t)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(a, zero), _mm_cmpeq_epi16(c, zero)));
+                bm |= (uint64_t)(~z & 0xffffu) << (16 * g);
+                if (simd_total) {
+                    // |x| as max(x, -x) with a saturating negate: |-32768| reads 32767, and the exact path below
+                    // takes over long before that matters (32767 * 1 already exceeds the limit)
+                    const __m128i aa = _mm_max_epi16(a, _mm_subs_epi16(zero, a)), ca = _mm_max_epi16(c, _mm_subs_epi16(zero, c));
+                    total = _mm_add_epi32(total, _mm_madd_epi16(aa, qv[2 * g]));
+                    total = _mm_add_epi32(total, _mm_madd_epi16(ca, qv[2 * g + 1]));
+                }
+            }
+            if (simd_total) {
+                total = _mm_add_epi32(total, _mm_shuffle_epi32(total, 0x4e));
+                total = _mm_add_epi32(total, _mm_shuffle_epi32(total, 0xb1));
+                const int32_t t = _mm_cvtsi128_si32(total);
+                if (t >= 0 && t <= 5900) {
+                    detail = false;
+                    max_abs = t > max_abs ? t : max_abs;  // upper bounds are enough: both stay inside class 3
+                    max_col = t > max_col ? t : max_col;
+                }
+            }
+#else
+            for (int k = 0; k < 64; k++) bm |= (uint64_t)(p[k] != 0) << k;
+#endif
             bitmaps[done] = bm;
             first[done] = n_values;
             done++;
+            if (!detail) {
+                for (uint64_t m = bm; m; m &= m - 1) values[n_values++] = p[__builtin_ctzll(m)];
+                continue;
+            }
             int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (uint64_t m = bm; m; m &= m - 1) {
                 const int k = __builtin_ctzll(m);

@@ -92,15 +92,21 @@ inline int16_t extend(uint16_t value, uint8_t count) {  // :165-173
     return value < vt ? (int16_t)((int)value + (int)(int16_t)(uint16_t)(0xFFFFu << count) + 1) : (int16_t)value;
 }
 
+// Lookahead of the code LUT and of the fused AC table.  The reference uses 8 bits (src/huffman.rs:16); the tables are
+// caches of the canonical decoding procedure, so a wider lookahead decodes every valid stream to the same symbols
+// with fewer trips through the bit-serial tail (n1 of SURVEY §8f: "wider LUTs").
+constexpr int kLutBits = 10;
+constexpr int kLutSize = 1 << kLutBits;
+
 struct HuffTable {
     bool present = false;
     bool is_ac = false;
     int nvalues = 0;
     uint8_t values[256];
     int32_t delta[16], maxcode[16];
-    uint8_t lut_value[256], lut_size[256];
-    int16_t ac_value[256];
-    uint8_t ac_run_size[256];
+    uint8_t lut_value[kLutSize], lut_size[kLutSize];
+    int16_t ac_value[kLutSize];
+    uint8_t ac_run_size[kLutSize];
 
     void build(const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
         uint8_t size_of[256];
@@ -138,21 +144,48 @@ struct HuffTable {
                 maxcode[i] = code_of[j - 1];
             }
         }
+        // The reference's 8-bit tables (src/huffman.rs:190-243), then the wide ones as an exact cache of its decoding
+        // PROCEDURE — 8-bit LUT first, then the maxcode walk (:31-58) — evaluated for every kLutBits-bit prefix.
+        // Derived this way (not from the code list) the wide tables also agree with the reference on malformed
+        // tables, where the maxcode walk accepts bit patterns that are not codes (tests/golden/crashtest).
+        uint8_t lut8_value[256], lut8_size[256];
+        memset(lut8_value, 0, sizeof(lut8_value));
+        memset(lut8_size, 0, sizeof(lut8_size));
         for (int i = 0; i < count; i++)
             if (size_of[i] <= 8) {
                 const int pad = 8 - size_of[i], first = code_of[i] << pad;
                 for (int b = 0; b < (1 << pad); b++) {
-                    lut_value[first + b] = vals[i];
-                    lut_size[first + b] = size_of[i];
+                    lut8_value[first + b] = vals[i];
+                    lut8_size[first + b] = size_of[i];
                 }
             }
-        if (ac)  // fused run/size/value table for short codes, :224-243
-            for (int i = 0; i < 256; i++) {
-                const uint8_t v = lut_value[i], sz = lut_size[i], run = v >> 4, cat = v & 15;
-                if (cat > 0 && sz + cat <= 8) {
-                    const uint16_t raw = (uint16_t)((((unsigned)i << sz) & 0xFF) >> (8 - cat));
-                    ac_value[i] = extend(raw, cat);
-                    ac_run_size[i] = (uint8_t)((run << 4) | (sz + cat));
+        for (int idx = 0; idx < kLutSize; idx++) {
+            const int i8 = idx >> (kLutBits - 8);
+            if (lut8_size[i8]) {
+                lut_value[idx] = lut8_value[i8];
+                lut_size[idx] = lut8_size[i8];
+                continue;
+            }
+            for (int i = 8; i < kLutBits; i++) {
+                const int32_t code = idx >> (kLutBits - 1 - i);
+                if (code <= maxcode[i]) {
+                    const int32_t index = code + delta[i];
+                    if (index >= 0 && index < nvalues) {  // else: left to the walk at decode time, which reports it
+                        lut_value[idx] = values[index];
+                        lut_size[idx] = (uint8_t)(i + 1);
+                    }
+                    break;
+                }
+            }
+        }
+        if (ac)  // fused run/size/value table, :224-243: the reference's entries (code + magnitude within 8 bits), then
+                 // what its fallback — decode() followed by receive_extend() — yields when both fit the wide lookahead
+            for (int idx = 0; idx < kLutSize; idx++) {
+                const uint8_t v = lut_value[idx], sz = lut_size[idx], run = v >> 4, cat = v & 15;
+                if (sz > 0 && cat > 0 && sz + cat <= kLutBits) {
+                    const uint16_t raw = (uint16_t)((((unsigned)idx << sz) & (kLutSize - 1)) >> (kLutBits - cat));
+                    ac_value[idx] = extend(raw, cat);
+                    ac_run_size[idx] = (uint8_t)((run << 4) | (sz + cat));
                 }
             }
     }
@@ -198,6 +231,21 @@ struct BitReader {
     Marker marker{Mk::RES, 0};
 
     void refill(ByteSource &src) {
+        // eight bytes at once while the stream is ordinary entropy-coded data (no 0xFF among them, no pending
+        // marker, not near the end); anything else goes through the byte loop below, which holds the marker logic
+        if (!has_marker && nbits <= 56 && src.len - src.pos >= 8) {
+            uint64_t x;
+            memcpy(&x, src.p + src.pos, 8);
+            const uint64_t nx = ~x;  // a 0xFF byte <=> a zero byte here
+            if (((nx - 0x0101010101010101ull) & ~nx & 0x8080808080808080ull) == 0) {
+                const uint32_t k = (64u - nbits) >> 3;  // bytes the loop would append (until nbits > 56)
+                const uint64_t be = __builtin_bswap64(x);
+                bits |= (be >> (64u - 8u * k)) << (64u - nbits - 8u * k);
+                nbits = (uint8_t)(nbits + 8u * k);
+                src.pos += k;
+                return;
+            }
+        }
         while (nbits <= 56) {
             uint8_t byte = has_marker ? 0 : src.u8();
             if (byte == 0xFF) {
@@ -221,13 +269,13 @@ struct BitReader {
     }
     uint8_t decode(ByteSource &src, const HuffTable &t) {  // :31-58
         if (nbits < 16) refill(src);
-        const uint16_t idx = peek(8);
+        const uint16_t idx = peek(kLutBits);
         if (const uint8_t size = t.lut_size[idx]) {
             consume(size);
             return t.lut_value[idx];
         }
         const uint16_t b16 = peek(16);
-        for (int i = 8; i < 16; i++) {
+        for (int i = 8; i < 16; i++) {  // (from 8: prefixes the wide table left unresolved include the walk's own error cases)
             const int32_t code = b16 >> (15 - i);
             if (code <= t.maxcode[i]) {
                 consume((uint8_t)(i + 1));
@@ -238,14 +286,18 @@ struct BitReader {
         }
         fail(JPGPU_ERR_FORMAT, "failed to decode huffman code");
     }
-    bool decode_fast_ac(ByteSource &src, const HuffTable &t, int16_t &value, uint8_t &run) {  // :60-78
+    // :60-78, on the wide table.  Does not consume: the caller needs `code_bits` for entries the reference's 8-bit
+    // table does not have (`total_bits` > 8) — there the reference decodes the symbol first and reads the magnitude
+    // bits only if the coefficient index is still inside the band (decode_block).
+    bool peek_fast_ac(ByteSource &src, const HuffTable &t, int16_t &value, uint8_t &run, uint8_t &total_bits, uint8_t &code_bits) {
         if (!t.is_ac) return false;
-        if (nbits < 8) refill(src);
-        const uint16_t idx = peek(8);
+        if (nbits < kLutBits) refill(src);
+        const uint16_t idx = peek(kLutBits);
         const uint8_t rs = t.ac_run_size[idx];
         if (!rs) return false;
         run = rs >> 4;
-        consume(rs & 15);
+        total_bits = rs & 15;
+        code_bits = t.lut_size[idx];
         value = t.ac_value[idx];
         return true;
     }
@@ -599,10 +651,14 @@ struct Frontend::Impl {
         }
         while (k < s.ss_end) {
             int16_t v;
-            uint8_t run;
-            if (br.decode_fast_ac(src, *act, v, run)) {
+            uint8_t run, total_bits, code_bits;
+            if (br.peek_fast_ac(src, *act, v, run, total_bits, code_bits)) {
                 k = (uint8_t)(k + run);
-                if (k >= s.ss_end) break;
+                if (k >= s.ss_end) {  // (invalid stream) the reference's fused entries took the magnitude bits, its
+                    br.consume(total_bits > 8 ? code_bits : total_bits);  // symbol-then-magnitude path did not
+                    break;
+                }
+                br.consume(total_bits);
                 co[kUnzigzag[k++]] = (int16_t)((uint16_t)v << s.al);
                 continue;
             }

@@ -156,6 +156,29 @@ int build_image_job(const jpgpu_component *comps, uint32_t ncomp, uint8_t *const
 // ---- compact coefficient transport: host encoder (include/jpgpu.h) ---------------------------------------------
 extern "C" {
 
+// range scan (part of H2D staging): per-position |c|*q must stay below 2^15 for the 24-bit / packed paths to be
+// exact, and block-column sums below 5900 for the dot2 row pass (pixel_math.hpp idct8x8<ARITH>)
+int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t q[64]) {
+    if (!coefficients || !q) return 0;
+    int32_t qq[64];
+    for (int k = 0; k < 64; k++) qq[k] = q[k];
+    int32_t max_abs = 0, max_col = 0;
+    const size_t nblk = len / 64;
+    for (size_t blk = 0; blk < nblk; blk++) {
+        const int16_t *p = coefficients + blk * 64;
+        int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 64; k++) {
+            int32_t v = (int32_t)p[k] * qq[k];
+            v = v < 0 ? -v : v;
+            max_abs = v > max_abs ? v : max_abs;
+            col[k & 7] += v;
+        }
+        for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? col[i] : max_col;
+    }
+    if (max_abs < (1 << 15)) return (max_col <= 5900) ? 3 : 1;
+    return 0;
+}
+
 size_t jpgpu_compact_max_bytes(size_t n_blocks) { return jpgpu::compact_max_bytes(n_blocks); }
 
 size_t jpgpu_compact_encode(const int16_t *coefficients, size_t n_blocks, const uint16_t q[64], void *dst, int *range_class) {

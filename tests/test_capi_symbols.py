@@ -128,3 +128,33 @@ def test_compact_encoder_round_trip_and_range_class():
         assert (buf[n:] == 0).all()
         assert np.array_equal(_expand_compact(buf[:n].tobytes(), nblk), c)
         assert rc.value == lib.jpgpu_range_class(c.ctypes.data, c.size, q.ctypes.data)
+
+
+def test_compact_encoder_range_class_on_hostile_and_16bit_tables():
+    """The SIMD block-total shortcut of the compact encoder must never promote hostile data: extreme coefficients with
+    8-bit and 16-bit tables, block totals just below / above the class-3 limit."""
+    import numpy as np
+    lib = J.lib()
+    rng = np.random.default_rng(3)
+
+    def both(c, q):
+        c = np.ascontiguousarray(c, np.int16)
+        q = np.ascontiguousarray(q, np.uint16)
+        buf = np.zeros(lib.jpgpu_compact_max_bytes(c.size // 64), np.uint8)
+        rc = C.c_int(-1)
+        lib.jpgpu_compact_encode(c.ctypes.data, c.size // 64, q.ctypes.data, buf.ctypes.data, C.byref(rc))
+        return rc.value, lib.jpgpu_range_class(c.ctypes.data, c.size, q.ctypes.data)
+
+    for q in (np.full(64, 255, np.uint16), np.full(64, 65535, np.uint16), np.full(64, 32767, np.uint16), np.ones(64, np.uint16),
+              rng.integers(1, 256, 64).astype(np.uint16), rng.integers(1, 65536, 64).astype(np.uint16)):
+        for c in (np.full(64, -32768, np.int16), np.full(64, 32767, np.int16), rng.integers(-32768, 32768, 640).astype(np.int16),
+                  np.zeros(64, np.int16), rng.integers(-3, 4, 640).astype(np.int16), rng.integers(-40, 41, 640).astype(np.int16)):
+            got, want = both(c, q)
+            assert got == want, (q[:4], c[:4], got, want)
+    ones = np.ones(64, np.uint16)
+    edge = np.zeros(64, np.int16); edge[0:8] = [737, 737, 737, 737, 738, 738, 738, 738]   # block total 5900: every column sum <= 5900
+    assert both(edge, ones) == (3, 3)
+    edge[8] = 5164  # block total now above the limit, column 0 sum = 737 + 5164 = 5901 -> class 1
+    assert both(edge, ones) == (1, 1)
+    edge[8] = 5163  # column 0 sum exactly 5900, block total far above: the exact path must still say 3
+    assert both(edge, ones) == (3, 3)
