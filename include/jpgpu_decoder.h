@@ -101,7 +101,7 @@ enum {
                                    * (bitmap + index + non-zero values, jpgpu.h) — A/B switch, same pixels */
 };
 
-/* n_threads 0 = half the hardware threads (one per physical core on an SMT-2 host). */
+/* n_threads 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if there is one. */
 int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out);
 void jpgpu_pipeline_destroy(jpgpu_pipeline *p);
 const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p);
