@@ -467,3 +467,30 @@ def test_batch_compact_upload_rejects_inconsistent_buffers():
     assert L.jpgpu_batch_upload_compact(b._h, 0, 0, buf.ctypes.data, n, -1, None) == 0
     b.synchronize()
     b.close()
+
+
+@pytest.mark.parametrize("name,samp,mode,ct,path", [
+    ("422", [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused422"), ("444", [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused444"),
+    ("gray", [(1, 1)], "gray", "Grayscale", "fusedgray")])
+def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
+    """BASELINE geometry at full size for the other fused kinds: oracle on the decoded synthetic image, identical
+    inputs -> identical outputs across the batch, and the decode is close to its source."""
+    w_, h_ = 1920, 1080
+    ocomps, _ = O.make_components(w_, h_, samp)
+    jc = to_j(ocomps)
+    lum, chr_ = synth.quality_tables(85)
+    qts = [lum, chr_, chr_][: len(samp)]
+    rgb = synth.synthetic_rgb(w_, h_)
+    base = synth.coefficients_from_rgb(rgb, jc, mode, qts)
+    cases = [(ocomps, qts, base, ct, w_, h_)] * 5
+    outs, got_path = _run_batch(cases)
+    assert got_path == path
+    want = O.pixels_from_coefficients(ocomps, qts, base, w_, h_, ct.upper())
+    for got in outs:
+        assert np.array_equal(got, want)
+    if mode == "gray":
+        y = 0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2]
+        err = np.abs(outs[0].reshape(h_, w_).astype(float) - y)
+    else:
+        err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
+    assert err.mean() < 6.0
