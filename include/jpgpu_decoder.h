@@ -97,8 +97,12 @@ typedef struct jpgpu_pipeline_timings {
 
 enum {
     JPGPU_PIPELINE_DOWNLOAD = 1u, /* also copy the pixels to pinned host memory (jpgpu_pipeline_pixels_host) */
-    JPGPU_PIPELINE_DENSE = 2u     /* send all 64 coefficients of every block over PCIe instead of the compact form
+    JPGPU_PIPELINE_DENSE = 2u,    /* send all 64 coefficients of every block over PCIe instead of the compact form
                                    * (bitmap + index + non-zero values, jpgpu.h) — A/B switch, same pixels */
+    JPGPU_PIPELINE_DEVICE_ENTROPY = 4u /* sequential Huffman streams with restart markers (DRI): send the entropy-coded
+                                   * bytes and decode them on the device, one lane per restart segment (src/decoder.rs:920-956:
+                                   * segments are independent); every other stream, and any stream the device decoder flags,
+                                   * takes the host path */
 };
 
 /* n_threads 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if there is one. */

@@ -57,7 +57,7 @@ class PipelineTimings(C.Structure):
                 ("pixel_bytes", C.c_uint64)]
 
 
-PIPELINE_DOWNLOAD, PIPELINE_DENSE = 1, 2
+PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY = 1, 2, 4
 
 
 class ImageInfoStruct(C.Structure):

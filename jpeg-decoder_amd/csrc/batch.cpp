@@ -17,6 +17,8 @@
 #include <mutex>
 
 #include "compact.hpp"
+#include "host/frontend.hpp"
+#include "huff.hpp"
 #include "fused.hpp"
 #include "host_common.hpp"
 #include "kernels.hpp"
@@ -58,6 +60,13 @@ struct jpgpu_batch {
     std::vector<uint8_t> compact_pending; // [image*4 + comp]: uploaded, to be expanded by the next decode
     ExpandJob *d_expand_jobs = nullptr;
     bool any_compact_pending = false;
+    // device entropy decoding (huff.hip): one pinned + one device staging block, grown on demand
+    uint8_t *h_entropy = nullptr, *d_entropy = nullptr;
+    size_t entropy_cap = 0;
+    uint32_t *h_entropy_out = nullptr;  // pinned read-back: status per listed image, then 2 range stats per (image, comp)
+    size_t entropy_out_cap = 0;
+    std::vector<uint32_t> entropy_images;  // images of the launch in flight
+    size_t entropy_out_off = 0;            // offset of the status / stats words inside d_entropy
 };
 
 #define B_HIP(call)                                                                                     \
@@ -238,6 +247,9 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->d_qt) hipFree(b->d_qt);
         if (b->d_compact) hipFree(b->d_compact);
         if (b->d_expand_jobs) hipFree(b->d_expand_jobs);
+        if (b->d_entropy) hipFree(b->d_entropy);
+        if (b->h_entropy) hipHostFree(b->h_entropy);
+        if (b->h_entropy_out) hipHostFree(b->h_entropy_out);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
         if (b->d_image_jobs) hipFree(b->d_image_jobs);
         for (FusedPlan &fp : b->fused) fused_free(fp);
@@ -370,6 +382,140 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
         b->jobs_dirty = true;
     }
     B_HIP(hipMemcpyAsync(b->d_compact + b->compact_off[idx], compact, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    return JPGPU_OK;
+}
+
+// ---- device entropy decoding -----------------------------------------------------------------------------------
+// Staging block layout (same offsets in the pinned and the device copy):
+//   [ status: n x u32 | stats: n x 4 x 2 x u32 | HuffScanJob[] | RangeJob[] | DevHuffTable[8] per scan | segment offsets | scan bytes ]
+int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream) {
+    if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    hipStream_t s = (hipStream_t)hip_stream;
+    size_t n_scans = 0, n_range = 0, seg_words = 0, data_bytes = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
+        n_range += b->descs[images[k].image].ncomp;
+        for (const host::PlannedScan &ps : *images[k].scans) {
+            n_scans++;
+            seg_words += ps.seg_off.size();
+            data_bytes += align_up((size_t)ps.seg_off.back() + 64, 16);  // + padding: the reader fetches 16-byte chunks ahead
+        }
+    }
+    const size_t off_status = 0, off_stats = align_up(off_status + (size_t)n * 4, 16), off_jobs = align_up(off_stats + (size_t)n * 32, 16);
+    const size_t off_range = align_up(off_jobs + n_scans * sizeof(HuffScanJob), 16), off_tables = align_up(off_range + n_range * sizeof(RangeJob), 16);
+    const size_t off_seg = align_up(off_tables + n_scans * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
+    const size_t total = off_data + data_bytes;
+    if (total > b->entropy_cap) {
+        if (b->d_entropy) (void)hipFree(b->d_entropy);
+        if (b->h_entropy) (void)hipHostFree(b->h_entropy);
+        b->d_entropy = b->h_entropy = nullptr;
+        b->entropy_cap = 0;
+        const size_t cap = total + total / 4;
+        B_HIP(hipMalloc((void **)&b->d_entropy, cap));
+        B_HIP(hipHostMalloc((void **)&b->h_entropy, cap, hipHostMallocDefault));
+        b->entropy_cap = cap;
+    }
+    const size_t out_words = (size_t)n * 9;
+    if (out_words > b->entropy_out_cap) {
+        if (b->h_entropy_out) (void)hipHostFree(b->h_entropy_out);
+        b->h_entropy_out = nullptr;
+        B_HIP(hipHostMalloc((void **)&b->h_entropy_out, (out_words + 64) * 4, hipHostMallocDefault));
+        b->entropy_out_cap = out_words + 64;
+    }
+    uint8_t *h = b->h_entropy, *d = b->d_entropy;
+    memset(h, 0, off_jobs);  // status and stats start at zero
+    HuffScanJob *jobs = reinterpret_cast<HuffScanJob *>(h + off_jobs);
+    RangeJob *rjobs = reinterpret_cast<RangeJob *>(h + off_range);
+    size_t ji = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data;
+    uint32_t max_seg = 0, max_blocks = 0;
+    b->entropy_images.clear();
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t img = images[k].image;
+        b->entropy_images.push_back(img);
+        const jpgpu_image_desc &desc = b->descs[img];
+        // every decoded block is written whole; blocks no MCU covers (a single component declared with sampling
+        // factors above 1) must read as zeros like the Worker's zero-initialised plane
+        bool covered = true;
+        for (const host::PlannedScan &ps : *images[k].scans)
+            for (uint32_t c = 0; c < ps.ncomp; c++) {
+                const uint32_t fi = ps.comp[c].frame_index;
+                if (fi < desc.ncomp && (size_t)ps.n_mcu * ps.comp[c].h * ps.comp[c].v * 128 != b->coef_len[(size_t)img * 4 + fi]) covered = false;
+            }
+        if (!covered) {
+            const size_t first = b->coef_off[(size_t)img * 4], last = b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1];
+            B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, s));
+        }
+        for (const host::PlannedScan &ps : *images[k].scans) {
+            HuffScanJob &j = jobs[ji++];
+            memset(&j, 0, sizeof(j));
+            const size_t nbytes = (size_t)ps.seg_off.back();
+            memcpy(h + dcur, images[k].file + ps.data_off, nbytes);
+            memset(h + dcur + nbytes, 0, 64);
+            memcpy(h + scur, ps.seg_off.data(), ps.seg_off.size() * 4);
+            memcpy(h + tcur, ps.tables, sizeof(ps.tables));
+            j.data = d + dcur;
+            j.seg_off = reinterpret_cast<const uint32_t *>(d + scur);
+            j.tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
+            j.status = reinterpret_cast<uint32_t *>(d + off_status) + k;
+            j.n_seg = (uint32_t)(ps.seg_off.size() / 2);
+            j.ri = ps.ri;
+            j.cols = ps.cols;
+            j.n_mcu = ps.n_mcu;
+            j.ncomp = ps.ncomp;
+            for (uint32_t c = 0; c < ps.ncomp; c++) {
+                const uint32_t fi = ps.comp[c].frame_index;
+                if (fi >= desc.ncomp || ps.comp[c].block_w != desc.components[fi].block_width)
+                    return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: plan does not match the image descriptor");
+                j.comp[c].dst = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
+                j.comp[c].block_w = ps.comp[c].block_w;
+                j.comp[c].h = ps.comp[c].h;
+                j.comp[c].v = ps.comp[c].v;
+                j.comp[c].dc = ps.comp[c].dc;
+                j.comp[c].ac = ps.comp[c].ac;
+            }
+            max_seg = std::max(max_seg, j.n_seg);
+            dcur += align_up(nbytes + 64, 16);
+            scur += ps.seg_off.size() * 4;
+            tcur += 8 * sizeof(DevHuffTable);
+        }
+        for (uint32_t c = 0; c < desc.ncomp; c++) {
+            RangeJob &r = rjobs[ri++];
+            r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + c]);
+            r.n_blocks = (uint32_t)(b->coef_len[(size_t)img * 4 + c] / 128);
+            r.slot = k * 4 + c;
+            memcpy(r.q, desc.quantization_tables[c], 128);
+            max_blocks = std::max(max_blocks, r.n_blocks);
+        }
+    }
+    B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
+    B_HIP(launch_huff_segments(reinterpret_cast<const HuffScanJob *>(d + off_jobs), (uint32_t)n_scans, max_seg, s));
+    B_HIP(launch_range_scan(reinterpret_cast<const RangeJob *>(d + off_range), (uint32_t)n_range, max_blocks,
+                            reinterpret_cast<uint32_t *>(d + off_stats), s));
+    // status words, then the stats (8 per image), into pinned memory
+    B_HIP(hipMemcpyAsync(b->h_entropy_out, d + off_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    B_HIP(hipMemcpyAsync(b->h_entropy_out + n, d + off_stats, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    return JPGPU_OK;
+}
+
+int jpgpu::batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n) {
+    if (!b || !status || n != b->entropy_images.size()) return JPGPU_ERR_FORMAT;
+    for (uint32_t k = 0; k < n; k++) {
+        status[k] = b->h_entropy_out[k];
+        if (status[k]) continue;
+        const uint32_t img = b->entropy_images[k];
+        for (uint32_t c = 0; c < b->descs[img].ncomp; c++) {
+            const uint32_t max_abs = b->h_entropy_out[n + (size_t)k * 8 + 2 * c], max_col = b->h_entropy_out[n + (size_t)k * 8 + 2 * c + 1];
+            const uint8_t cls = max_abs < (1u << 15) ? (max_col <= 5900u ? 3 : 1) : 0;
+            if (b->sane[(size_t)img * 4 + c] != cls) {
+                b->sane[(size_t)img * 4 + c] = cls;
+                b->jobs_dirty = true;
+            }
+        }
+    }
+    b->entropy_images.clear();
     return JPGPU_OK;
 }
 

@@ -378,6 +378,7 @@ struct Frontend::Impl {
     bool has_exif = false, has_xmp = false;
     std::vector<uint8_t> exif, xmp;
     std::vector<IccChunk> icc;
+    std::vector<PlannedScan> *plan = nullptr;  // plan_device_scans: describe scans instead of decoding them
 
     size_t read_length() {  // src/parser.rs:137-147
         const uint16_t l = src.u16be();
@@ -728,6 +729,129 @@ struct Frontend::Impl {
 
     // ---- decode_scan (src/decoder.rs:794-1082) ----------------------------------------------------
     // returns true and sets `pending` when a marker was captured at the end of the scan
+    struct NotEligible {
+        int where;  // which check of plan_scan refused (diagnostics: JPGPU_PLAN_TRACE)
+    };
+    // plan_device_scans: the checks decode_scan makes before it touches the entropy data, then cut the data into
+    // restart segments instead of decoding it
+    bool plan_scan(const ScanInfo &scan, const bool (&finished)[JPGPU_MAX_COMPONENTS], Marker &pending) {
+        const FrameInfo &f = frame;
+        const int nc = scan.n;
+        if (f.coding_process != JPGPU_CODING_DCT_SEQUENTIAL || f.precision != 8 || restart_interval == 0) throw NotEligible{1};
+        if (scan.ss_start != 0 || scan.ss_end != 64 || scan.ah != 0 || scan.al != 0) throw NotEligible{2};
+        // one scan carrying all components (what encoders write for sequential files; per-component scans stay on the host)
+        if ((size_t)nc != f.components.size()) throw NotEligible{13};
+        jpgpu_component comps[JPGPU_MAX_COMPONENTS];
+        for (int i = 0; i < nc; i++) {
+            const int ci = scan.component_indices[i];
+            if (!finished[i] || plane_present[ci]) throw NotEligible{3};
+            comps[i] = f.components[ci];
+            if (!has_qt[comps[i].quantization_table_index]) throw NotEligible{4};
+        }
+        if (is_mjpeg) {  // fill_default_mjpeg_tables, as in decode_scan
+            bool d0 = false, d1 = false, a0 = false, a1 = false;
+            for (int i = 0; i < nc; i++) {
+                d0 |= scan.dc_tables[i] == 0;
+                d1 |= scan.dc_tables[i] == 1;
+                a0 |= scan.ac_tables[i] == 0;
+                a1 |= scan.ac_tables[i] == 1;
+            }
+            if (d0 && !dc[0].present) dc[0].build(kK3Bits, kDcVals, 12, false);
+            if (d1 && !dc[1].present) dc[1].build(kK4Bits, kDcVals, 12, false);
+            if (a0 && !ac[0].present) ac[0].build(kK5Bits, kK5Vals, 162, true);
+            if (a1 && !ac[1].present) ac[1].build(kK6Bits, kK6Vals, 162, true);
+        }
+        for (int i = 0; i < nc; i++)
+            if (!dc[scan.dc_tables[i]].present || !ac[scan.ac_tables[i]].present) throw NotEligible{5};
+        PlannedScan ps;
+        const bool interleaved = nc > 1;
+        const uint32_t max_x = interleaved ? f.mcu_w : comps[0].block_width, max_y = interleaved ? f.mcu_h : comps[0].block_height;
+        // the MCU loops of decode_scan stop at the image edge (my * 8 >= image_h, mx * 8 >= image_w)
+        ps.cols = std::min<uint32_t>(max_x, ((uint32_t)f.image_w + 7u) / 8u);
+        const uint32_t rows = std::min<uint32_t>(max_y, ((uint32_t)f.image_h + 7u) / 8u);
+        ps.n_mcu = ps.cols * rows;
+        ps.ri = restart_interval;
+        ps.ncomp = (uint32_t)nc;
+        if (ps.n_mcu == 0) throw NotEligible{6};
+        for (int i = 0; i < nc; i++) {
+            ps.comp[i].frame_index = (uint32_t)scan.component_indices[i];
+            ps.comp[i].block_w = comps[i].block_width;
+            ps.comp[i].h = interleaved ? comps[i].horizontal_sampling_factor : 1u;
+            ps.comp[i].v = interleaved ? comps[i].vertical_sampling_factor : 1u;
+            ps.comp[i].dc = (uint32_t)scan.dc_tables[i];
+            ps.comp[i].ac = (uint32_t)scan.ac_tables[i];
+        }
+        for (int t = 0; t < 8; t++) {
+            const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
+            DevHuffTable &d = ps.tables[t];
+            memset(&d, 0, sizeof(d));
+            if (!h.present) continue;
+            static_assert(sizeof(d.lut) / sizeof(d.lut[0]) == sizeof(h.lut_value) && sizeof(d.values) == sizeof(h.values), "table layouts");
+            for (int i = 0; i < kLutSize; i++) d.lut[i] = (uint16_t)(h.lut_value[i] | (h.lut_size[i] << 8));
+            memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode));
+            memcpy(d.delta, h.delta, sizeof(d.delta));
+            memcpy(d.values, h.values, sizeof(d.values));
+            d.nvalues = h.nvalues;
+        }
+        // cut the entropy-coded data at the RSTn markers: exactly one every `ri` MCUs, numbered 0..7 cyclically
+        // (src/decoder.rs:920-956), 0xFF00 pairs inside, one other marker right after the last segment
+        const uint32_t n_seg = (ps.n_mcu + ps.ri - 1u) / ps.ri;
+        ps.data_off = src.pos;
+        ps.seg_off.reserve((size_t)n_seg + 1u);
+        ps.seg_off.push_back(0u);
+        const uint8_t *p = src.p;
+        size_t pos = src.pos;
+        uint32_t expected_rst = 0;
+        for (;;) {
+            const void *ff = pos < src.len ? memchr(p + pos, 0xFF, src.len - pos) : nullptr;
+            if (!ff) throw NotEligible{7};  // ran off the end without a marker
+            pos = (size_t)(static_cast<const uint8_t *>(ff) - p);
+            if (pos + 1 >= src.len) throw NotEligible{8};
+            const uint8_t nb = p[pos + 1];
+            if (nb == 0x00) {  // stuffed byte
+                pos += 2;
+                continue;
+            }
+            if (nb == 0xFF) throw NotEligible{9};  // fill bytes: legal, rare, host path
+            if (pos - ps.data_off > 0xFFFFFFF0u) throw NotEligible{10};
+            if (nb >= 0xD0 && nb <= 0xD7) {
+                if ((uint32_t)(nb - 0xD0) != expected_rst || ps.seg_off.size() >= n_seg) throw NotEligible{11};
+                expected_rst = (expected_rst + 1u) % 8u;
+                ps.seg_off.push_back((uint32_t)(pos - ps.data_off));      // end of this segment
+                pos += 2;
+                // (the next segment starts after the marker: keep one offset list by storing segment starts shifted)
+                seg_start_after.push_back((uint32_t)(pos - ps.data_off));
+                continue;
+            }
+            // any other marker ends the scan
+            if (ps.seg_off.size() != n_seg) throw NotEligible{12};
+            ps.seg_off.push_back((uint32_t)(pos - ps.data_off));
+            pending = marker_from(nb);
+            src.pos = pos + 2;
+            break;
+        }
+        // seg_off so far holds [0, end_0, end_1, ..., end_last]; starts of segments 1.. are the bytes after the markers.
+        // The device wants start/end per segment: interleave into 2 * n_seg entries [start_0, end_0, start_1, end_1, ...]
+        {
+            std::vector<uint32_t> se;
+            se.reserve(2u * n_seg);
+            for (uint32_t s = 0; s < n_seg; s++) {
+                se.push_back(s == 0 ? 0u : seg_start_after[s - 1]);
+                se.push_back(ps.seg_off[s + 1]);
+            }
+            ps.seg_off.swap(se);
+            seg_start_after.clear();
+        }
+        for (int i = 0; i < nc; i++) {
+            const int ci = scan.component_indices[i];
+            memcpy(plane_qt[ci], qt[comps[i].quantization_table_index], 128);
+            plane_present[ci] = true;
+        }
+        plan->push_back(std::move(ps));
+        return true;  // `pending` holds the marker that ended the scan
+    }
+    std::vector<uint32_t> seg_start_after;
+
     bool decode_scan(const ScanInfo &scan, const bool (&finished)[JPGPU_MAX_COMPONENTS], RowSink &sink, Marker &pending) {
         const FrameInfo &f = frame;
         jpgpu_component comps[JPGPU_MAX_COMPONENTS];
@@ -901,7 +1025,7 @@ struct Frontend::Impl {
                         for (int j = scan.ss_start; j < scan.ss_end; j++) finished_mask[i] |= (uint64_t)1 << j;
                         if (finished_mask[i] == ~(uint64_t)0) finished[k] = true;
                     }
-                has_pending = decode_scan(scan, finished, *sink, pending);
+                has_pending = plan ? plan_scan(scan, finished, pending) : decode_scan(scan, finished, *sink, pending);
                 scans++;
                 break;
             }
@@ -1016,6 +1140,23 @@ void Frontend::scale(uint16_t req_w, uint16_t req_h, uint16_t &out_w, uint16_t &
 }
 
 void Frontend::decode_to(RowSink &sink) { impl_->run(false, &sink); }
+bool Frontend::plan_device_scans(std::vector<PlannedScan> &scans) {
+    scans.clear();
+    impl_->plan = &scans;
+    bool ok = true;
+    try {
+        impl_->run(false, nullptr);
+        ok = !scans.empty();
+    } catch (const Impl::NotEligible &ne) {
+        if (getenv("JPGPU_PLAN_TRACE")) fprintf(stderr, "plan_device_scans: not eligible (check %d)\n", ne.where);
+        ok = false;
+    } catch (const DecodeError &) {
+        ok = false;  // the host decoder reports it
+    }
+    impl_->plan = nullptr;
+    if (!ok) scans.clear();
+    return ok;
+}
 bool Frontend::has_frame() const { return impl_->has_frame; }
 
 jpgpu_image_info Frontend::info() const {  // src/decoder.rs:170-197

@@ -13,6 +13,7 @@
 
 #include "../../../include/jpgpu.h"
 #include "../../../include/jpgpu_decoder.h"
+#include "../huff_job.hpp"
 
 namespace jpgpu {
 namespace host {
@@ -36,6 +37,17 @@ public:
     virtual void finish(uint32_t index, uint32_t frame_slot) = 0;  // get_result + keep for compute_image
 };
 
+// What the device entropy decoder (csrc/huff_core.hpp) needs for one sequential Huffman scan with restart markers.
+struct PlannedScan {
+    size_t data_off = 0;            // offset of the scan's entropy-coded bytes in the stream given to the Frontend
+    std::vector<uint32_t> seg_off;  // 2 * n_seg offsets relative to data_off: segment s = [seg_off[2s], seg_off[2s+1]), no markers
+    uint32_t ri = 0, cols = 0, n_mcu = 0, ncomp = 0;
+    struct Comp {
+        uint32_t frame_index, block_w, h, v, dc, ac;
+    } comp[4];
+    DevHuffTable tables[8];         // dc 0..3, ac 0..3 as they stand at this scan
+};
+
 struct IccChunk {
     uint8_t num_markers, seq_no;
     std::vector<uint8_t> data;
@@ -52,6 +64,14 @@ public:
     // Runs the marker loop to EOI feeding `sink`; afterwards planes_present()[i] tells which
     // frame components produced a plane (compute_image fails if any is missing).
     void decode_to(RowSink &sink);
+    // Instead of decoding: walk the markers to EOI and describe every scan for the device entropy decoder.  Returns
+    // false — the object is then spent, decode with a fresh Frontend — unless the stream is plainly eligible: 8-bit
+    // sequential Huffman, one scan carrying all components, a restart interval in force,
+    // RST markers exactly where and as numbered as the interval says, nothing else inside or after the entropy
+    // data.  Anything doubtful (including every error the marker loop would raise) is "not eligible": the host
+    // decoder is the one whose behaviour on odd streams is pinned.  On success the tables handed to Worker::start
+    // (qtable_of_component) and planes_present() are set as decode_to would have set them.
+    bool plan_device_scans(std::vector<PlannedScan> &scans);
 
     bool has_frame() const;
     jpgpu_image_info info() const;

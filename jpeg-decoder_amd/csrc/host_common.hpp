@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/jpgpu.h"
 #include "jobs.hpp"
@@ -22,5 +23,20 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // jpgpu_batch_upload_compact for buffers written by CompactWriter inside this library (no consistency pass)
 int batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes, int range_class,
                          void *hip_stream, bool trusted);
+
+// ---- device entropy decoding of restart-marker streams (huff_core.hpp), used by the pipeline ----------------------
+namespace host {
+struct PlannedScan;
+}
+struct DeviceEntropyImage {
+    uint32_t image;                                  // index in the batch
+    const uint8_t *file;                             // the stream the plan refers to (host memory)
+    const std::vector<host::PlannedScan> *scans;     // Frontend::plan_device_scans
+};
+// Enqueue on `hip_stream`: upload of the scans' bytes, tables and job records, zero-fill of the images' coefficient
+// planes, the segment decoder, the range scan.  Then (after the stream has been synchronised) collect: status[k] != 0
+// means image k of the list must be decoded on the host instead; the others have their range classes set.
+int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream);
+int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 
 }  // namespace jpgpu

@@ -1,0 +1,35 @@
+// huff_job.hpp — job descriptors of the device entropy decoder (huff_core.hpp); no HIP dependency: the host front-end
+// fills them (csrc/host/frontend.cpp, plan_device_scans).
+#pragma once
+#include <stdint.h>
+
+namespace jpgpu {
+
+constexpr int HUFF_LUT_BITS = 10;  // == kLutBits of the host front-end
+
+struct DevHuffTable {
+    uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: symbol | code length << 8 (length 0: not resolved within the lookahead)
+    int32_t maxcode[16], delta[16];
+    uint8_t values[256];
+    int32_t nvalues;
+};
+
+struct HuffScanComp {
+    int16_t *dst;       // the component's coefficient plane in the arena (zero-filled before the launch)
+    uint32_t block_w;   // blocks per plane row
+    uint32_t h, v;      // blocks per MCU (1, 1 in a single-component scan)
+    uint32_t dc, ac;    // table slots: dc in tables[0..3], ac in tables[4..7]
+};
+
+struct HuffScanJob {            // one scan of one image
+    const uint8_t *data;        // entropy-coded bytes of the scan
+    const uint32_t *seg_off;    // 2 * n_seg byte offsets into data: segment s = [seg_off[2s], seg_off[2s+1]), markers excluded
+    const DevHuffTable *tables; // 8 tables of this scan
+    uint32_t *status;           // the image's status word: bit 0 set = decode this image on the host instead
+    uint32_t n_seg, ri;         // restart interval in MCUs
+    uint32_t cols, n_mcu;       // MCUs per row / in the scan
+    uint32_t ncomp, _pad;
+    HuffScanComp comp[4];
+};
+
+}  // namespace jpgpu

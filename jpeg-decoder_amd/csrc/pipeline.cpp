@@ -190,11 +190,11 @@ private:
 struct UploadQueue {
     std::mutex m;
     std::condition_variable cv;
-    std::vector<std::pair<uint32_t, bool>> items;  // (image, upload?)
-    void push(uint32_t i, bool upload) {
+    std::vector<std::pair<uint32_t, int>> items;  // (image, 0 failed / 1 staged: upload it / 2 decode its entropy data on the device)
+    void push(uint32_t i, int kind) {
         {
             std::lock_guard<std::mutex> g(m);
-            items.emplace_back(i, upload);
+            items.emplace_back(i, kind);
         }
         cv.notify_one();
     }
@@ -231,7 +231,7 @@ struct SubBatch {
     }
 };
 
-constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 8, kComputeStreams = 2;
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 8, kComputeStreams = 8;  // one compute stream per sub-batch
 
 }  // namespace
 
@@ -246,14 +246,49 @@ struct jpgpu_pipeline {
     std::vector<std::string> errors;
     std::vector<jpgpu_image_info> infos;
     std::vector<int32_t> sub_of, slot;  // image -> sub-batch / index in it, -1 if it never got there
+    std::vector<std::vector<jpgpu::host::PlannedScan>> plans;  // per image: scans for the device entropy decoder (empty: host)
     std::vector<SubBatch> subs;          // kept across calls while the geometry sequence repeats
     uint32_t n_subs = 0;                 // sub-batches used by the last call
     std::string path;
     bool downloaded = false;  // the last call copied the pixels to host memory
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t compute[kComputeStreams] = {nullptr, nullptr};
+    hipStream_t compute[kComputeStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     jpgpu_pipeline_timings t{};
 };
+
+// An image the device entropy decoder handed back: the pinned behaviour is the host decoder's — decode it here (uploader
+// thread; rare) and upload it densely, or record the error it raises.
+static void host_redecode(jpgpu_pipeline *p, SubBatch &sb, uint32_t i, const uint8_t *data, size_t len) {
+    const uint32_t bi = (uint32_t)p->slot[i];
+    try {
+        Frontend fe(data, len);
+        fe.read_info();
+        const uint32_t nc = fe.ncomp();
+        size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
+        std::vector<uint8_t> tmp;
+        size_t total = 0;
+        for (uint32_t c = 0; c < nc; c++) {
+            ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
+            off[c] = total;
+            total += ln[c];
+        }
+        tmp.resize(total);
+        StageSink sink(tmp.data(), off, ln, false);
+        fe.decode_to(sink);
+        for (uint32_t c = 0; c < nc; c++) {
+            if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
+            jpgpu_batch_set_quantization_table(sb.batch, bi, c, sink.qt(c));
+            if (jpgpu_batch_upload(sb.batch, bi, c, reinterpret_cast<const int16_t *>(tmp.data() + off[c]), ln[c] / 2) != JPGPU_OK)
+                throw DecodeError{JPGPU_ERR_IO, jpgpu_batch_last_error(sb.batch)};
+        }
+    } catch (const DecodeError &e) {
+        p->status[i] = e.code;
+        p->errors[i] = e.message;
+    } catch (const std::exception &e) {
+        p->status[i] = JPGPU_ERR_INTERNAL;
+        p->errors[i] = e.what();
+    }
+}
 
 #define P_HIP(call)                                                                                              \
     do {                                                                                                         \
@@ -306,6 +341,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     if (rc) return rc;
     const double t0 = now_ms();
     const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0, compact = (flags & JPGPU_PIPELINE_DENSE) == 0;
+    const bool device_entropy = (flags & JPGPU_PIPELINE_DEVICE_ENTROPY) != 0;
     p->n = n;
     p->fes.clear();
     p->fes.resize(n);
@@ -313,6 +349,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->errors.assign(n, std::string());
     p->infos.assign(n, jpgpu_image_info{});
     p->sub_of.assign(n, -1);
+    p->plans.clear();
+    p->plans.resize(n);
     p->slot.assign(n, -1);
     p->n_subs = 0;
     p->downloaded = download;
@@ -359,7 +397,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         p->t.total_ms = now_ms() - t0;
         return JPGPU_OK;
     }
-    const uint32_t n_subs = std::min<uint32_t>(kMaxSubBatches, ((uint32_t)ok.size() + kSubBatchImages - 1) / kSubBatchImages);
+    // (device entropy decoding: larger sub-batches — one lane decodes one restart segment, a launch needs many images to
+    // fill the machine, and launches of different sub-batches were observed to run one after the other)
+    const uint32_t sub_images = device_entropy ? 16u * kSubBatchImages : kSubBatchImages;
+    const uint32_t n_subs = std::min<uint32_t>(kMaxSubBatches, ((uint32_t)ok.size() + sub_images - 1) / sub_images);
     const uint32_t per_sub = ((uint32_t)ok.size() + n_subs - 1) / n_subs;
     p->n_subs = n_subs;
     for (uint32_t j = 0; j < n_subs; j++) {
@@ -430,11 +471,14 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const bool trace = getenv("JPGPU_PIPE_TRACE") != nullptr;
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0;
+    uint32_t device_rejected = 0;
     std::thread uploader([&] {
         std::string e;
         if (jpgpu::use_device(p->device, e) != JPGPU_OK) hip_failed.store(1);
         uint32_t handled = 0, k = 0;
-        std::vector<std::pair<uint32_t, bool>> take;
+        std::vector<std::pair<uint32_t, int>> take;
+        std::vector<std::vector<uint32_t>> dev_images(p->n_subs);  // per sub-batch: images whose entropy data goes to the device
+        std::vector<uint32_t> pending_subs;                         // sub-batches whose device entropy launch is in flight
         while (handled < n_jobs) {
             {
                 std::unique_lock<std::mutex> g(q.m);
@@ -444,7 +488,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             for (const auto &it : take) {
                 const uint32_t i = it.first;
                 SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
-                if (it.second && !hip_failed.load()) {
+                if (it.second == 2) dev_images[(uint32_t)p->sub_of[i]].push_back(i);
+                if (it.second == 1 && !hip_failed.load()) {
                     hipStream_t cps = p->copy_streams[k++ % kCopyStreams];
                     if (sb.compact) {
                         const uint32_t bi = (uint32_t)p->slot[i];
@@ -467,6 +512,21 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     for (uint32_t c = 0; c < kCopyStreams && okk; c++)
                         okk = hipEventRecord(sb.ready[c], p->copy_streams[c]) == hipSuccess &&
                               hipStreamWaitEvent(cs, sb.ready[c], 0) == hipSuccess;
+                    std::vector<uint32_t> &dv = dev_images[(uint32_t)p->sub_of[i]];
+                    if (okk && !dv.empty()) {
+                        // entropy decoding on the device: enqueue now, finish the sub-batch (collect, stragglers, pixel
+                        // kernels, download) when nothing else is waiting — the launches of several sub-batches then
+                        // run side by side (one wave per SIMD each: they do not compete)
+                        std::vector<jpgpu::DeviceEntropyImage> list;
+                        for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
+                        const double l0 = now_ms();
+                        okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs) == JPGPU_OK;
+                        if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
+                        if (!okk) launch_err = jpgpu_batch_last_error(sb.batch);
+                        else pending_subs.push_back((uint32_t)p->sub_of[i]);
+                        if (!okk) hip_failed.store(1);
+                        continue;
+                    }
                     if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {
                         launch_err = jpgpu_batch_last_error(sb.batch);
                         okk = false;
@@ -477,6 +537,34 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 }
             }
             take.clear();
+            // (only once every image is accounted for: synchronising earlier would hold back the launches of the
+            // sub-batches that complete in the meantime)
+            if (handled >= n_jobs && !pending_subs.empty() && !hip_failed.load()) {
+                for (uint32_t sj : pending_subs) {
+                    SubBatch &sb = p->subs[sj];
+                    hipStream_t cs = p->compute[sj % kComputeStreams];
+                    std::vector<uint32_t> &dv = dev_images[sj];
+                    std::vector<uint32_t> st(dv.size(), 0);
+                    const double s0 = now_ms();
+                    bool okk = hipStreamSynchronize(cs) == hipSuccess;
+                    if (trace) fprintf(stderr, "pipeline trace: sub-batch %u synchronised at +%.2f ms after waiting %.2f ms\n", sj, now_ms() - t2, now_ms() - s0);
+                    okk = okk &&
+                               jpgpu::batch_device_entropy_collect(sb.batch, st.data(), (uint32_t)st.size()) == JPGPU_OK;
+                    for (size_t k2 = 0; okk && k2 < dv.size(); k2++)
+                        if (st[k2]) {
+                            device_rejected++;
+                            host_redecode(p, sb, dv[k2], data[dv[k2]], len[dv[k2]]);
+                        }
+                    if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {
+                        launch_err = jpgpu_batch_last_error(sb.batch);
+                        okk = false;
+                    }
+                    if (okk && download)
+                        okk = hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, cs) == hipSuccess;
+                    if (!okk) hip_failed.store(1);
+                }
+                pending_subs.clear();
+            }
         }
         t_last_upload = now_ms();
     });
@@ -484,15 +572,27 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         if (p->status[i] != JPGPU_OK) return;
         SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
         const uint32_t bi = (uint32_t)p->slot[i];
-        Frontend &fe = *p->fes[i];
+        Frontend &fe0 = *p->fes[i];  // (re-created below if the device planner spends it)
         size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
-        const uint32_t nc = fe.ncomp();
+        const uint32_t nc = fe0.ncomp();
         for (uint32_t c = 0; c < nc; c++) {
             off[c] = sb.compact ? sb.stage_off[(size_t)bi * 4 + c] : jpgpu_batch_coef_offset(sb.batch, bi, c);
             ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
         }
         try {
             const double w0 = trace ? now_ms() : 0.0;
+            if (device_entropy) {
+                if (fe0.plan_device_scans(p->plans[i])) {
+                    for (uint32_t c = 0; c < nc; c++) jpgpu_batch_set_quantization_table(sb.batch, bi, c, fe0.qtable_of_component(c));
+                    jpeg_bytes += len[i];
+                    for (const auto &ps : p->plans[i]) coef_bytes += ps.seg_off.back();  // bytes that cross PCIe for this image
+                    q.push(i, 2);
+                    return;
+                }
+                p->fes[i].reset(new Frontend(data[i], len[i]));  // the planning pass spent the object
+                p->fes[i]->read_info();
+            }
+            Frontend &fe = *p->fes[i];
             StageSink sink(sb.h_coef, off, ln, sb.compact);
             fe.decode_to(sink);
             if (trace) {
@@ -517,18 +617,19 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             bytes_of[i] = off[nc - 1] + ln[nc - 1] - off[0];
             jpeg_bytes += len[i];
             coef_bytes += sb.compact ? sent : bytes_of[i];
-            q.push(i, true);
+            q.push(i, 1);
         } catch (const DecodeError &e) {
             p->status[i] = e.code;
             p->errors[i] = e.message;
-            q.push(i, false);
+            q.push(i, 0);
         } catch (const std::exception &e) {
             p->status[i] = JPGPU_ERR_INTERNAL;
             p->errors[i] = e.what();
-            q.push(i, false);
+            q.push(i, 0);
         }
     });
     const double t3 = now_ms();
+    if (trace && device_entropy) fprintf(stderr, "pipeline trace: device entropy decoder handed %u image(s) back to the host\n", device_rejected);
     if (trace) fprintf(stderr, "pipeline trace: workers %.1f ms wall, decode_to sum %.1f ms (avg %.2f, max %.2f), last decode end +%.1f ms\n", t3 - t2, busy_sum, busy_sum / std::max(1u, n_jobs), busy_max, last_end - t2);
     uploader.join();
     if (hip_failed.load())

@@ -22,9 +22,11 @@
 #ifdef JPGPU_HOST_EMULATION
 #define JP_GLOBAL
 #define JP_CONST
+#define JP_LDS
 #else
 #define JP_GLOBAL __attribute__((address_space(1)))
 #define JP_CONST __attribute__((address_space(4)))
+#define JP_LDS __attribute__((address_space(3)))  // ds_* instead of flat_* when a pointer to LDS crosses a function boundary
 #endif
 
 namespace jpgpu {

@@ -1,0 +1,75 @@
+// emu_huff.cpp — TEST-ONLY CPU run of the device entropy decoder (csrc/huff_core.hpp) on the plan the host front-end
+// makes (Frontend::plan_device_scans): every restart segment decoded by the device code, into zero-filled planes.
+#include "hip_shim.hpp"
+#include <vector>
+#include "../../jpeg-decoder_amd/csrc/host/frontend.hpp"
+#include "../../jpeg-decoder_amd/csrc/huff_core.hpp"
+
+using namespace jpgpu;
+using jpgpu::host::Frontend;
+using jpgpu::host::PlannedScan;
+
+extern "C" {
+// Returns: -1 not eligible; otherwise the status word (0 = every segment decoded cleanly).  coefs[c] must hold
+// block_w*block_h*64 zeros for frame component c (sizes from *desc, filled when eligible).
+int emu_huff_plan(const uint8_t* data, size_t len, jpgpu_image_desc* desc, uint32_t* n_scans, uint32_t* n_segments) {
+    Frontend fe(data, len);
+    std::vector<PlannedScan> scans;
+    try {
+        fe.read_info();
+    } catch (...) {
+        return -1;
+    }
+    if (!fe.plan_device_scans(scans)) return -1;
+    memset(desc, 0, sizeof(*desc));
+    desc->ncomp = fe.ncomp();
+    for (uint32_t c = 0; c < desc->ncomp; c++) {
+        desc->components[c] = fe.components()[c];
+        memcpy(desc->quantization_tables[c], fe.qtable_of_component(c), 128);
+    }
+    desc->out_w = fe.output_width();
+    desc->out_h = fe.output_height();
+    desc->color_transform = fe.color_transform();
+    *n_scans = (uint32_t)scans.size();
+    *n_segments = 0;
+    for (auto& s : scans) *n_segments += (uint32_t)(s.seg_off.size() / 2);
+    return 0;
+}
+int emu_huff_decode(const uint8_t* data_in, size_t len, int16_t* const* coefs) {
+    std::vector<uint8_t> padded(len + 64, 0);  // the device reader fetches aligned 16-byte chunks, up to 31 bytes past a segment
+    memcpy(padded.data(), data_in, len);
+    const uint8_t* data = padded.data();
+    Frontend fe(data, len);
+    std::vector<PlannedScan> scans;
+    fe.read_info();
+    if (!fe.plan_device_scans(scans)) return -1;
+    uint32_t status = 0;
+    HuffLds* L = new HuffLds;
+    for (const PlannedScan& ps : scans) {
+        HuffScanJob& job = L->job;
+        memset(&job, 0, sizeof(job));
+        job.data = data + ps.data_off;
+        job.seg_off = ps.seg_off.data();
+        job.tables = ps.tables;
+        job.status = &status;
+        job.n_seg = (uint32_t)(ps.seg_off.size() / 2);
+        job.ri = ps.ri;
+        job.cols = ps.cols;
+        job.n_mcu = ps.n_mcu;
+        job.ncomp = ps.ncomp;
+        for (uint32_t c = 0; c < ps.ncomp; c++) {
+            job.comp[c].dst = coefs[ps.comp[c].frame_index];
+            job.comp[c].block_w = ps.comp[c].block_w;
+            job.comp[c].h = ps.comp[c].h;
+            job.comp[c].v = ps.comp[c].v;
+            job.comp[c].dc = ps.comp[c].dc;
+            job.comp[c].ac = ps.comp[c].ac;
+        }
+        memcpy(L->tables, ps.tables, sizeof(L->tables));
+        for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(L->unzig, t);
+        for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s, s & 63u);
+    }
+    delete L;
+    return (int)status;
+}
+}

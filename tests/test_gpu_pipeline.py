@@ -99,3 +99,55 @@ def test_pipeline_device_resident_output_and_empty_call():
     out = p.decode([b"not a jpeg", b""])
     assert all(isinstance(o, J.Error) for o in out)
     p.close()
+
+
+def _pil_restart(w, h, subsampling, rows=0, blocks=0, gray=False, seed=3):
+    import io
+    from PIL import Image
+    import synth
+    rgb = synth.synthetic_rgb(w, h, seed=seed)
+    im = Image.fromarray(rgb[..., 0] if gray else rgb)
+    buf = io.BytesIO()
+    kw = {"restart_marker_blocks": blocks} if blocks else {"restart_marker_rows": rows}
+    im.save(buf, format="JPEG", quality=85, subsampling=subsampling, **kw)
+    return buf.getvalue()
+
+
+def test_pipeline_device_entropy_decoder_matches_host_path():
+    """Restart-marker streams decoded on the GPU (one lane per restart segment) next to streams that must stay on the host
+    and damaged restart streams the device decoder has to hand back: every result equals the per-image oracle outcome."""
+    pytest.importorskip("PIL")
+    names, files = [], []
+    for rel in ["reftest/restarts.jpg", "reftest/mjpeg.jpg", "benches/tower.jpg", "reftest/mozilla/jpg-progressive.jpg",
+                "reftest/non-interleaved-mcu.jpg", "reftest/mozilla/jpg-gray.jpg"]:
+        names.append(rel)
+        files.append(open(os.path.join(R.GOLDEN, rel), "rb").read())
+    for (w, h, sub, rows, blocks, gray) in [(250, 130, "4:2:0", 1, 0, False), (129, 257, "4:2:2", 0, 5, False), (200, 120, "4:4:4", 2, 0, False),
+                                            (300, 200, "4:4:4", 1, 0, True), (640, 480, "4:2:0", 0, 7, False), (33, 17, "4:2:0", 0, 1, False)]:
+        names.append(f"pil-{w}x{h}-{sub}-r{rows}b{blocks}{'-gray' if gray else ''}")
+        files.append(_pil_restart(w, h, sub, rows, blocks, gray))
+    rng = np.random.default_rng(21)
+    base = files[6]
+    sos = base.rfind(b"\xff\xda")
+    for k in range(12):  # damaged entropy data of a restart stream
+        d = bytearray(base)
+        pos = int(rng.integers(sos + 14, len(d) - 2))
+        if k % 3 == 0:
+            d[pos] ^= 1 << int(rng.integers(0, 8))
+        elif k % 3 == 1:
+            del d[pos]
+        else:
+            d[pos] = 0xFF
+        names.append(f"damaged-{k}")
+        files.append(bytes(d))
+    p = J.Pipeline(threads=8)
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    out_host = p.decode(files)
+    _check(names, files, out_host)
+    # same-geometry restart streams: fused kernels after the device entropy decoder
+    same = [_pil_restart(320, 240, "4:2:0", 1, 0, seed=s) for s in range(9)]
+    out = p.decode(same, device_entropy=True)
+    assert p.kernel_path == "fused420"
+    _check([f"same-{i}" for i in range(9)], same, out)
+    p.close()

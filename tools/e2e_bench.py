@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--no-download", action="store_true")
     ap.add_argument("--progressive", action="store_true")
+    ap.add_argument("--device-entropy", action="store_true", help="decode restart-marker streams on the GPU")
+    ap.add_argument("--restart-rows", type=int, default=0, help="write the synthetic files with a restart marker every N MCU rows")
     ap.add_argument("--sleep", type=float, default=0.0, help="seconds to idle between rounds")
     ap.add_argument("--dense", action="store_true", help="send dense coefficient planes (A/B against the compact transport)")
     ap.add_argument("--file", default=None, help="use this JPEG (replicated) instead of the synthetic images")
@@ -41,7 +43,7 @@ def main():
         rgb = synth.synthetic_rgb(args.width, args.height, seed=0x5EED + k)
         buf = io.BytesIO()
         Image.fromarray(rgb).save(buf, format="JPEG", quality=args.quality, subsampling=args.subsampling,
-                                  progressive=args.progressive)
+                                  progressive=args.progressive, **({"restart_marker_rows": args.restart_rows} if args.restart_rows else {}))
         distinct.append(buf.getvalue())
     files = [distinct[i % len(distinct)] for i in range(args.images)]
     p = J.Pipeline(threads=args.threads)
@@ -49,7 +51,7 @@ def main():
     import time
     for r in range(args.rounds):
         time.sleep(args.sleep)
-        out = p.decode(files, download=not args.no_download, dense=args.dense)
+        out = p.decode(files, download=not args.no_download, dense=args.dense, device_entropy=args.device_entropy)
         bad = [o for o in out if isinstance(o, Exception)]
         assert not bad, bad[:1]
         t = p.timings()
@@ -60,12 +62,13 @@ def main():
     t0 = time.perf_counter()
     reps = 6
     for _ in range(reps):
-        p.decode(files, download=False, dense=args.dense)
+        p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy)
     sustained = reps * args.images / (time.perf_counter() - t0)
     mp = args.images * args.width * args.height / 1e6
     print(json.dumps({
         "what": "jpgpu_pipeline_decode: JPEG bytes (host) -> RGB" + (" (left in HBM)" if args.no_download else " (pinned host memory)"),
-        "transport": "dense" if args.dense else "compact", "images": args.images, "geometry": (os.path.basename(args.file) + f" {args.width}x{args.height}") if args.file else
+        "transport": "entropy-coded bytes, decoded on the device" if args.device_entropy else ("dense" if args.dense else "compact"),
+        "restart_rows": args.restart_rows, "images": args.images, "geometry": (os.path.basename(args.file) + f" {args.width}x{args.height}") if args.file else
         f"{args.width}x{args.height} {args.subsampling} q{args.quality}" + (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
         "MP_per_s": round(mp / best["total_ms"] * 1e3, 1), "images_per_s": round(args.images / best["total_ms"] * 1e3, 1),
         "sustained_images_per_s_pixels_left_in_hbm": round(sustained, 1),
