@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -388,7 +389,8 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
 // ---- device entropy decoding -----------------------------------------------------------------------------------
 // Staging block layout (same offsets in the pinned and the device copy):
 //   [ status: n x u32 | stats: n x 4 x 2 x u32 | HuffScanJob[] | RangeJob[] | DevHuffTable[8] per scan | segment offsets | scan bytes ]
-int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream) {
+int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
+                                       const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
     int rc = use_device(b->device, b->err);
     if (rc) return rc;
@@ -431,6 +433,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     RangeJob *rjobs = reinterpret_cast<RangeJob *>(h + off_range);
     size_t ji = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data;
     uint32_t max_seg = 0, max_blocks = 0;
+    struct CopyTask {
+        uint8_t *dst;
+        const uint8_t *src;
+        size_t n;
+    };
+    std::vector<CopyTask> copies;
     b->entropy_images.clear();
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t img = images[k].image;
@@ -452,8 +460,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             HuffScanJob &j = jobs[ji++];
             memset(&j, 0, sizeof(j));
             const size_t nbytes = (size_t)ps.seg_off.back();
-            memcpy(h + dcur, images[k].file + ps.data_off, nbytes);
-            memset(h + dcur + nbytes, 0, 64);
+            copies.push_back(CopyTask{h + dcur, images[k].file + ps.data_off, nbytes});  // (+ 64 zero bytes after it)
             memcpy(h + scur, ps.seg_off.data(), ps.seg_off.size() * 4);
             memcpy(h + tcur, ps.tables, sizeof(ps.tables));
             j.data = d + dcur;
@@ -489,6 +496,15 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             memcpy(r.q, desc.quantization_tables[c], 128);
             max_blocks = std::max(max_blocks, r.n_blocks);
         }
+    }
+    {
+        const std::function<void(uint32_t)> body = [&](uint32_t t) {
+            memcpy(copies[t].dst, copies[t].src, copies[t].n);
+            memset(copies[t].dst + copies[t].n, 0, 64);
+        };
+        if (par && copies.size() > 1) (*par)((uint32_t)copies.size(), body);
+        else
+            for (uint32_t t = 0; t < copies.size(); t++) body(t);
     }
     B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffScanJob *>(d + off_jobs), (uint32_t)n_scans, max_seg, s));

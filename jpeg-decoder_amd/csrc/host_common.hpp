@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -36,7 +37,9 @@ struct DeviceEntropyImage {
 // Enqueue on `hip_stream`: upload of the scans' bytes, tables and job records, zero-fill of the images' coefficient
 // planes, the segment decoder, the range scan.  Then (after the stream has been synchronised) collect: status[k] != 0
 // means image k of the list must be decoded on the host instead; the others have their range classes set.
-int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream);
+// `par`: optional parallel-for (count, body) used for the staging copies of the scans' bytes.
+int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
+                                const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 
 }  // namespace jpgpu

@@ -377,6 +377,15 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             d.out_h = fe.output_height();
             d.color_transform = fe.color_transform();
             cand[i] = d;
+            if (device_entropy) {  // eligible for the device entropy decoder?  (the planning pass spends the object)
+                if (fe.plan_device_scans(p->plans[i])) {
+                    for (uint32_t c = 0; c < d.ncomp; c++) memcpy(cand[i].quantization_tables[c], fe.qtable_of_component(c), 128);
+                } else {
+                    p->plans[i].clear();
+                    p->fes[i].reset(new Frontend(data[i], len[i]));
+                    p->fes[i]->read_info();
+                }
+            }
             p->status[i] = JPGPU_OK;
         } catch (const DecodeError &e) {
             p->status[i] = e.code;
@@ -389,23 +398,34 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const double t1 = now_ms();
 
     // 2. sub-batches of the images that have a frame (each kept while its geometry sequence repeats)
+    // Images bound for the device entropy decoder go first, in large sub-batches: one lane decodes one restart segment, a
+    // launch needs many images to fill the machine (and launches of different sub-batches were observed to run one
+    // after the other); host-decoded images follow in sub-batches of about 64 so that uploads, kernels and downloads overlap
+    // the remaining entropy decoding.
     std::vector<uint32_t> ok;
     for (uint32_t i = 0; i < n; i++)
-        if (p->status[i] == JPGPU_OK) ok.push_back(i);
+        if (p->status[i] == JPGPU_OK && !p->plans[i].empty()) ok.push_back(i);
+    const uint32_t n_dev = (uint32_t)ok.size();
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK && p->plans[i].empty()) ok.push_back(i);
     if (ok.empty()) {
         p->t.headers_ms = t1 - t0;
         p->t.total_ms = now_ms() - t0;
         return JPGPU_OK;
     }
-    // (device entropy decoding: larger sub-batches — one lane decodes one restart segment, a launch needs many images to
-    // fill the machine, and launches of different sub-batches were observed to run one after the other)
-    const uint32_t sub_images = device_entropy ? 16u * kSubBatchImages : kSubBatchImages;
-    const uint32_t n_subs = std::min<uint32_t>(kMaxSubBatches, ((uint32_t)ok.size() + sub_images - 1) / sub_images);
-    const uint32_t per_sub = ((uint32_t)ok.size() + n_subs - 1) / n_subs;
+    std::vector<uint32_t> bounds{0u};  // sub-batch j = ok[bounds[j] .. bounds[j+1])
+    {
+        const uint32_t dev_subs = n_dev ? std::min<uint32_t>(kMaxSubBatches / 2u, (n_dev + 16u * kSubBatchImages - 1u) / (16u * kSubBatchImages)) : 0u;
+        for (uint32_t j = 1; j <= dev_subs; j++) bounds.push_back((uint32_t)((uint64_t)n_dev * j / dev_subs));
+        const uint32_t n_host = (uint32_t)ok.size() - n_dev;
+        const uint32_t host_subs = n_host ? std::min<uint32_t>(kMaxSubBatches - dev_subs, (n_host + kSubBatchImages - 1u) / kSubBatchImages) : 0u;
+        for (uint32_t j = 1; j <= host_subs; j++) bounds.push_back(n_dev + (uint32_t)((uint64_t)n_host * j / host_subs));
+    }
+    const uint32_t n_subs = (uint32_t)bounds.size() - 1u;
     p->n_subs = n_subs;
     for (uint32_t j = 0; j < n_subs; j++) {
         SubBatch &sb = p->subs[j];
-        const uint32_t first = j * per_sub, last = std::min<uint32_t>(first + per_sub, (uint32_t)ok.size());
+        const uint32_t first = bounds[j], last = bounds[j + 1];
         std::vector<jpgpu_image_desc> descs;
         for (uint32_t k = first; k < last; k++) {
             p->sub_of[ok[k]] = (int32_t)j;
@@ -472,6 +492,19 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0;
     uint32_t device_rejected = 0;
+    // the pool is idle while device-entropy images are staged (its tasks for them return at once): lend it to the copy
+    std::mutex par_m;
+    const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> par_for = [&](uint32_t cnt, const std::function<void(uint32_t)> &fn) {
+        std::vector<std::thread> ts;
+        std::atomic<uint32_t> next{0};
+        const uint32_t nt = std::min<uint32_t>(cnt, 8u);
+        for (uint32_t t = 0; t < nt; t++)
+            ts.emplace_back([&] {
+                for (uint32_t k = next.fetch_add(1); k < cnt; k = next.fetch_add(1)) fn(k);
+            });
+        for (auto &t : ts) t.join();
+    };
+    (void)par_m;
     std::thread uploader([&] {
         std::string e;
         if (jpgpu::use_device(p->device, e) != JPGPU_OK) hip_failed.store(1);
@@ -520,7 +553,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         std::vector<jpgpu::DeviceEntropyImage> list;
                         for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
                         const double l0 = now_ms();
-                        okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs) == JPGPU_OK;
+                        okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for) == JPGPU_OK;
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         if (!okk) launch_err = jpgpu_batch_last_error(sb.batch);
                         else pending_subs.push_back((uint32_t)p->sub_of[i]);
@@ -581,16 +614,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         }
         try {
             const double w0 = trace ? now_ms() : 0.0;
-            if (device_entropy) {
-                if (fe0.plan_device_scans(p->plans[i])) {
-                    for (uint32_t c = 0; c < nc; c++) jpgpu_batch_set_quantization_table(sb.batch, bi, c, fe0.qtable_of_component(c));
-                    jpeg_bytes += len[i];
-                    for (const auto &ps : p->plans[i]) coef_bytes += ps.seg_off.back();  // bytes that cross PCIe for this image
-                    q.push(i, 2);
-                    return;
-                }
-                p->fes[i].reset(new Frontend(data[i], len[i]));  // the planning pass spent the object
-                p->fes[i]->read_info();
+            if (!p->plans[i].empty()) {  // planned in the headers phase: the entropy-coded bytes go to the device as they are
+                for (uint32_t c = 0; c < nc; c++) jpgpu_batch_set_quantization_table(sb.batch, bi, c, cand[i].quantization_tables[c]);
+                jpeg_bytes += len[i];
+                for (const auto &ps : p->plans[i]) coef_bytes += ps.seg_off.back();  // bytes that cross PCIe for this image
+                q.push(i, 2);
+                return;
             }
             Frontend &fe = *p->fes[i];
             StageSink sink(sb.h_coef, off, ln, sb.compact);
