@@ -403,7 +403,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         for (const host::PlannedScan &ps : *images[k].scans) {
             n_scans++;
             seg_words += ps.seg_off.size();
-            data_bytes += align_up((size_t)ps.seg_off.back() + 64, 16);  // + padding: the reader fetches 16-byte chunks ahead
+            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) data_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
         }
     }
     const size_t off_status = 0, off_stats = align_up(off_status + (size_t)n * 4, 16), off_jobs = align_up(off_stats + (size_t)n * 32, 16);
@@ -434,9 +434,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     size_t ji = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data;
     uint32_t max_seg = 0, max_blocks = 0;
     struct CopyTask {
-        uint8_t *dst;
-        const uint8_t *src;
-        size_t n;
+        uint8_t *dst;        // first slot of the scan in the pinned block
+        uint32_t *seg_table; // its 2 * n_seg words
+        uint32_t dst_off;    // offset of dst inside the data area
+        const uint8_t *src;  // the scan's entropy-coded bytes
+        const host::PlannedScan *ps;
     };
     std::vector<CopyTask> copies;
     b->entropy_images.clear();
@@ -444,26 +446,20 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const uint32_t img = images[k].image;
         b->entropy_images.push_back(img);
         const jpgpu_image_desc &desc = b->descs[img];
-        // every decoded block is written whole; blocks no MCU covers (a single component declared with sampling
-        // factors above 1) must read as zeros like the Worker's zero-initialised plane
-        bool covered = true;
-        for (const host::PlannedScan &ps : *images[k].scans)
-            for (uint32_t c = 0; c < ps.ncomp; c++) {
-                const uint32_t fi = ps.comp[c].frame_index;
-                if (fi < desc.ncomp && (size_t)ps.n_mcu * ps.comp[c].h * ps.comp[c].v * 128 != b->coef_len[(size_t)img * 4 + fi]) covered = false;
-            }
-        if (!covered) {
+        // the planes start as zeros (the Worker's zero-initialised plane): only non-zero coefficients are written
+        {
             const size_t first = b->coef_off[(size_t)img * 4], last = b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1];
             B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, s));
         }
         for (const host::PlannedScan &ps : *images[k].scans) {
             HuffScanJob &j = jobs[ji++];
             memset(&j, 0, sizeof(j));
-            const size_t nbytes = (size_t)ps.seg_off.back();
-            copies.push_back(CopyTask{h + dcur, images[k].file + ps.data_off, nbytes});  // (+ 64 zero bytes after it)
-            memcpy(h + scur, ps.seg_off.data(), ps.seg_off.size() * 4);
+            // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
+            copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps});
+            size_t scan_bytes = 0;
+            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
             memcpy(h + tcur, ps.tables, sizeof(ps.tables));
-            j.data = d + dcur;
+            j.data = d + off_data;  // (segment offsets are relative to the start of the data area)
             j.seg_off = reinterpret_cast<const uint32_t *>(d + scur);
             j.tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
             j.status = reinterpret_cast<uint32_t *>(d + off_status) + k;
@@ -484,7 +480,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 j.comp[c].ac = ps.comp[c].ac;
             }
             max_seg = std::max(max_seg, j.n_seg);
-            dcur += align_up(nbytes + 64, 16);
+            dcur += scan_bytes;
             scur += ps.seg_off.size() * 4;
             tcur += 8 * sizeof(DevHuffTable);
         }
@@ -499,8 +495,14 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     }
     {
         const std::function<void(uint32_t)> body = [&](uint32_t t) {
-            memcpy(copies[t].dst, copies[t].src, copies[t].n);
-            memset(copies[t].dst + copies[t].n, 0, 64);
+            const CopyTask &ct = copies[t];
+            uint32_t o = 0;
+            for (size_t sg = 0; sg + 1 < ct.ps->seg_off.size(); sg += 2) {
+                const uint32_t first = ct.ps->seg_off[sg], n = ct.ps->seg_off[sg + 1] - first;
+                ct.seg_table[sg] = ct.dst_off + o;
+                ct.seg_table[sg + 1] = huff_stage_segment(ct.dst + o, ct.src + first, n);
+                o += huff_slot_bytes(n);
+            }
         };
         if (par && copies.size() > 1) (*par)((uint32_t)copies.size(), body);
         else

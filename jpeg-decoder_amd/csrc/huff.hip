@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffScanJob *__
     __syncthreads();
     const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
     if (seg >= L.job.n_seg) return;
-    huff_decode_segment(*(JP_LDS HuffLds *)&L, seg, threadIdx.x);
+    huff_decode_segment(*(JP_LDS HuffLds *)&L, seg);
 }
 
 // one lane per block: max |c*q| and the largest block-column sum of |c*q| (the two quantities behind the range classes of

@@ -1,88 +1,60 @@
 // huff_core.hpp — entropy decoding ON THE DEVICE for sequential Huffman scans that carry restart markers
 // ("DRI segments are independently decodable", src/decoder.rs:920-956).  One lane decodes one restart
-// segment: `ri` MCUs, DC predictors starting at 0 (src/decoder.rs:928-931), straight into the dense coefficient arena
-// (natural order, block raster per component — what the host front-end would have appended row by row).
-// The decoding procedure is the reference's (src/huffman.rs:31-96, src/decoder.rs:1086-1172) on the same wide tables
-// the host front-end uses (csrc/host/frontend.cpp: an exact cache of the 8-bit LUT + maxcode walk).  Anything
-// unexpected — an undecodable code, a segment that is not consumed exactly — raises the image's status flag and the
-// caller re-decodes that image on the host, whose behaviour on damaged streams is the pinned one.
-// Compiled by hipcc for the kernel (huff.hip) and by g++ for tests/emu.
+// segment: `ri` MCUs, DC predictors starting at 0 (src/decoder.rs:928-931), straight into the zero-filled dense
+// coefficient arena (natural order, block raster per component — what the host front-end would have appended row by
+// row).  The decoding procedure is the reference's (src/huffman.rs:31-96, src/decoder.rs:1086-1172) on the same wide
+// tables the host front-end uses (csrc/host/frontend.cpp: an exact cache of the 8-bit LUT + maxcode walk).  Anything
+// unexpected — an undecodable code, a segment that is not consumed the way the reference would accept — raises the
+// image's status flag and the caller re-decodes that image on the host, whose behaviour on damaged streams is the
+// pinned one.  Compiled by hipcc for the kernel (huff.hip) and by g++ for tests/emu.
+//
+// Shape of the code.  The lanes of a wave walk unrelated bit streams: whatever any lane does, the wave executes, and a
+// wave has nothing to overlap with (one wave per SIMD at best), so every dependent instruction costs its full latency
+// (~12 cycles).  The run time is therefore the number of instructions on the UNION of the lanes' paths.  Hence:
+//   * the host removes the 0xFF00 stuffing and aligns every segment (huff_stage_segment): the bit reader appends one
+//     aligned dword when it holds <= 32 bits — no byte loop, no marker logic on the device;
+//   * decode_block is unrolled into ONE step per Huffman symbol (k == 0: the DC symbol of the next block; k >= 1: an AC
+//     symbol) computed with selects; only the rare table miss and the end of a block are branches;
+//   * per-step memory operations are LDS reads through address-space-3 pointers (generic pointers made them flat_*
+//     operations at several hundred cycles each) and one 2-byte store per non-zero coefficient.
+// History (MI355X, 68 one-MCU-row segments per 1080p image): block-structured decoder with a byte-wise reader 22 ms for 64
+// images — the same 22 ms for 256 (latency-bound); this form: see DESIGN.md §5.
 #pragma once
 #include "huff_job.hpp"
 #include "pixel_math.hpp"
 
 namespace jpgpu {
 
-// Bit reader of one lane.  The segment is read in aligned 16-byte chunks, the next chunk is requested as soon as the
-// current one is entered: with one lane per segment and only a few waves in flight a byte-at-a-time reader spent
-// ~2 us per symbol waiting for memory (measured: 25 ms per 64 images).  Reads may run up to 31 bytes past the segment:
-// the staging block is padded.
 struct DevBits {
-    uint64_t bits;
+    uint64_t bits;   // unread bits, left-aligned
     uint32_t nbits;
-    int32_t pad_bits;  // zero bits appended after the end of the segment that are still in `bits` (what the reference
-                       // feeds after it has seen the marker, src/huffman.rs:123-160)
-    uint32_t pos, end; // byte offsets from the 16-byte aligned address `g` (pos = next byte to read)
-    const v4u *g;
-    v4u cur, nxt;
+    uint32_t wpos;   // dwords taken from the segment slot so far
+    const v4u *g;    // the slot (16-byte aligned)
+    v4u cur, nxt;    // chunk wpos / 4 and the one after it
     bool bad;
 };
 
-__device__ __forceinline__ void huff_open(DevBits &b, const uint8_t *data, uint32_t first, uint32_t last) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(data) + first;
-    b.g = reinterpret_cast<const v4u *>(a & ~(uintptr_t)15);
-    b.pos = (uint32_t)(a & 15u);
-    b.end = b.pos + (last - first);
+__device__ __forceinline__ void huff_open(DevBits &b, const uint8_t *slot) {
+    b.g = reinterpret_cast<const v4u *>(slot);
     b.cur = b.g[0];
     b.nxt = b.g[1];
     b.bits = 0;
     b.nbits = 0;
-    b.pad_bits = 0;
+    b.wpos = 0;
     b.bad = false;
 }
-__device__ __forceinline__ uint32_t huff_dword(const DevBits &b, uint32_t w) {  // dword w (0..3) of the current chunk
-    return w == 0u ? b.cur.x : (w == 1u ? b.cur.y : (w == 2u ? b.cur.z : b.cur.w));
-}
-__device__ __forceinline__ void huff_advance(DevBits &b, uint32_t n) {  // consume n bytes (never across more than one chunk edge)
-    const uint32_t before = b.pos >> 4;
-    b.pos += n;
-    if ((b.pos >> 4) != before) {
-        b.cur = b.nxt;
-        b.nxt = b.g[(b.pos >> 4) + 1u];
-    }
-}
-__device__ __forceinline__ uint32_t huff_byte(DevBits &b) {
-    const uint32_t v = (huff_dword(b, (b.pos >> 2) & 3u) >> (8u * (b.pos & 3u))) & 0xffu;
-    huff_advance(b, 1u);
-    return v;
-}
-
+// at most once per step: afterwards more than 32 bits are available (a step reads <= 16 + 15)
 __device__ __forceinline__ void huff_refill(DevBits &b) {
-    // four bytes at once when they are ordinary entropy-coded data: aligned in the chunk, inside the segment, no 0xFF
-    if (b.nbits <= 32u && (b.pos & 3u) == 0u && b.pos + 4u <= b.end) {
-        const uint32_t x = huff_dword(b, (b.pos >> 2) & 3u), nx = ~x;
-        if (((nx - 0x01010101u) & ~nx & 0x80808080u) == 0u) {
-            const uint32_t be = __builtin_bswap32(x);
-            b.bits |= (uint64_t)be << (32u - b.nbits);
-            b.nbits += 32u;
-            huff_advance(b, 4u);
+    if (b.nbits <= 32u) {
+        const uint32_t w = b.wpos & 3u;
+        const uint32_t x = w == 0u ? b.cur.x : (w == 1u ? b.cur.y : (w == 2u ? b.cur.z : b.cur.w));
+        b.bits |= (uint64_t)__builtin_bswap32(x) << (32u - b.nbits);
+        b.nbits += 32u;
+        b.wpos++;
+        if ((b.wpos & 3u) == 0u) {
+            b.cur = b.nxt;
+            b.nxt = b.g[(b.wpos >> 2) + 1u];
         }
-    }
-    while (b.nbits <= 56u) {
-        uint32_t byte = 0;
-        if (b.pos < b.end) {
-            byte = huff_byte(b);
-            if (byte == 0xFFu) {  // inside a segment only stuffed 0xFF00 pairs occur (the host cut the segments at markers)
-                if (b.pos < b.end && huff_byte(b) == 0u) {
-                } else {
-                    b.bad = true;
-                }
-            }
-        } else {
-            b.pad_bits += 8;
-        }
-        b.bits |= (uint64_t)byte << (56u - b.nbits);
-        b.nbits += 8u;
     }
 }
 __device__ __forceinline__ uint32_t huff_peek(const DevBits &b, uint32_t n) { return n ? (uint32_t)(b.bits >> (64u - n)) : 0u; }
@@ -90,8 +62,8 @@ __device__ __forceinline__ void huff_consume(DevBits &b, uint32_t n) {
     b.bits <<= n;
     b.nbits -= n;
 }
-__device__ __forceinline__ int32_t huff_extend(uint32_t v, uint32_t n) {  // :98-101
-    const int32_t vt = 1 << (n - 1u);
+__device__ __forceinline__ int32_t huff_extend(uint32_t v, uint32_t n) {  // src/huffman.rs:98-101 (n == 0 -> 0)
+    const int32_t vt = n ? 1 << (n - 1u) : 0;
     return (int32_t)v < vt ? (int32_t)v + (int32_t)(0xffffffffu << n) + 1 : (int32_t)v;
 }
 
@@ -114,12 +86,11 @@ __device__ __forceinline__ uint32_t huff_walk(DevBits &b, const JP_LDS DevHuffTa
     return 0u;
 }
 
-// What a workgroup keeps in LDS: the scan's job record and tables, the zig-zag table, one 128-byte block buffer per lane.
+// What a workgroup keeps in LDS: the scan's job record and tables and the zig-zag table.
 struct HuffLds {
     DevHuffTable tables[8];
     HuffScanJob job;
     uint8_t unzig[64];
-    v4u blocks[64 * 8];
 };
 // zig-zag -> natural order (src/decoder.rs:27-36), written to LDS once per workgroup
 __device__ __forceinline__ void huff_fill_unzigzag(JP_LDS uint8_t *dst, uint32_t lane) {
@@ -129,27 +100,12 @@ __device__ __forceinline__ void huff_fill_unzigzag(JP_LDS uint8_t *dst, uint32_t
     if (lane < 64u) dst[lane] = unzig[lane];
 }
 
-// One restart segment.  A block is assembled in the lane's LDS buffer and leaves as eight 16-byte stores
-// (coefficient-by-coefficient 2-byte stores were partial-line writes by the million).
-//
-// The lanes of a wave walk unrelated bit streams, so the decoder is written as ONE step that every lane executes
-// per Huffman symbol — decode_block of a sequential scan (ss = 0, se = 63, ah = al = 0, src/decoder.rs:1086-1172)
-// unrolled into a state machine (k == 0: the DC symbol of the next block; k >= 1: an AC symbol).  A wave has nothing to
-// overlap with (one wave per SIMD at best), so every dependent instruction costs its full latency: per-step memory
-// operations are LDS reads through address-space-3 pointers (generic pointers made them flat_* operations at several
-// hundred cycles each), the per-component fields are cached in registers.  Measured on MI355X: ~2 us per symbol and lane
-// (64 divergent lanes cost ~220 VALU + ~130 SALU wave-instructions per step at ~12 cycles each), i.e. 22 ms for the 68
-// one-MCU-row segments of a 1080p image — the same 22 ms for 256 images at once (one wave per SIMD), 55 ms for 1024.
-// Writing coefficients straight to a zero-filled arena instead of through the block buffer made no difference.
-// Returns false (and has raised the status bit) if the image must go to the host.
-__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffLds &L, uint32_t seg, uint32_t lane) {
+// One restart segment.  Returns false (and has raised the status bit) if the image must go to the host.
+__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffLds &L, uint32_t seg) {
     const JP_LDS HuffScanJob &job = L.job;
     DevBits b;
-    huff_open(b, job.data, job.seg_off[2u * seg], job.seg_off[2u * seg + 1u]);
-    JP_LDS v4u *lb = &L.blocks[lane * 8u];
-    JP_LDS int16_t *blk = reinterpret_cast<JP_LDS int16_t *>(lb);
-#pragma unroll
-    for (int r = 0; r < 8; r++) lb[r] = v4u{0u, 0u, 0u, 0u};
+    huff_open(b, job.data + job.seg_off[2u * seg]);
+    const uint32_t seg_bits = job.seg_off[2u * seg + 1u] * 8u;
     int32_t pred0 = 0, pred1 = 0, pred2 = 0, pred3 = 0;  // (named scalars: a runtime-indexed array would live in scratch)
     uint32_t eob_run = 0;
     uint32_t m = seg * job.ri;                        // MCU
@@ -160,77 +116,62 @@ __device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffLds &L, uint32_t 
     uint32_t c_h = job.comp[0].h, c_hv = job.comp[0].h * job.comp[0].v, c_v = job.comp[0].v, c_bw = job.comp[0].block_w;
     uint32_t c_dc = job.comp[0].dc, c_ac = 4u + job.comp[0].ac;
     int16_t *c_dst = job.comp[0].dst;
+    JP_GLOBAL int16_t *blk;  // the current block in the arena
+    {
+        const uint32_t my = m / cols, mx = m - my * cols;
+        blk = (JP_GLOBAL int16_t *)(c_dst + ((size_t)(my * c_v) * c_bw + mx * c_h) * 64u);
+    }
     while (m < m1 && !b.bad) {
-        // every read of this step fits 32 bits: code <= 16, then <= 15 magnitude / run-length bits
-        if (b.nbits < 32u) huff_refill(b);
+        huff_refill(b);
         const bool is_dc = k == 0u;
         const JP_LDS DevHuffTable &t = L.tables[is_dc ? c_dc : c_ac];
         const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> 8;
         uint32_t sym = e & 0xffu;
-        if (csz) huff_consume(b, csz);
-        else sym = huff_walk(b, t);
-        if (b.bad) break;
+        if (csz) {
+            huff_consume(b, csz);
+        } else {
+            sym = huff_walk(b, t);
+            if (b.bad) break;
+        }
         const uint32_t r = sym >> 4, sz = sym & 15u;
-        bool done = false;  // block finished by this symbol
+        if (is_dc && sym > 11u) {  // "invalid DC difference magnitude category"
+            b.bad = true;
+            break;
+        }
+        // what the symbol is, and where the coefficient index stands after its run
+        const bool is_coef = !is_dc && sz != 0u, is_zrl = !is_dc && sz == 0u && r == 15u, is_eob = !is_dc && sz == 0u && r != 15u;
+        const uint32_t knew = is_dc ? 0u : k + (is_zrl ? 16u : (is_coef ? r : 0u));
+        const bool over = is_coef && knew >= 64u;
+        // (invalid stream, `over`) the reference's fused (run, size, value) table — code resolved by the 8-bit LUT, code +
+        // magnitude within 8 bits — has taken the magnitude bits by now, its symbol-then-magnitude path has not
+        const bool fused = csz > 0u && csz <= 8u && csz + sz <= 8u;
+        const uint32_t nread = is_dc ? sym : (is_coef ? ((!over || fused) ? sz : 0u) : (is_eob ? r : 0u));
+        const uint32_t raw = huff_peek(b, nread);
+        huff_consume(b, nread);
+        const int32_t val = huff_extend(raw, nread);
         if (is_dc) {
-            if (sym > 11u) {
-                b.bad = true;
-                break;
-            }
-            int32_t diff = 0;
-            if (sym) {
-                diff = huff_extend(huff_peek(b, sym), sym);
-                huff_consume(b, sym);
-            }
             int32_t pr = c == 0u ? pred0 : (c == 1u ? pred1 : (c == 2u ? pred2 : pred3));
-            pr = (int16_t)(uint16_t)((uint32_t)pr + (uint32_t)diff);  // i16 wrapping_add
+            pr = (int16_t)(uint16_t)((uint32_t)pr + (uint32_t)val);  // i16 wrapping_add
             pred0 = c == 0u ? pr : pred0;
             pred1 = c == 1u ? pr : pred1;
             pred2 = c == 2u ? pr : pred2;
             pred3 = c == 3u ? pr : pred3;
-            blk[0] = (int16_t)pr;
+            if (pr) blk[0] = (int16_t)pr;
+        } else if (is_coef && !over) {
+            blk[L.unzig[knew]] = (int16_t)val;
+        }
+        if (is_eob) eob_run = ((1u << r) - 1u + raw) & 0xffffu;
+        // end of the block?  DC inside an end-of-band run (src/decoder.rs:1101-1104); EOB; index past 63
+        bool done;
+        if (is_dc) {
+            done = eob_run > 0u;
+            eob_run -= done ? 1u : 0u;
             k = 1u;
-            if (eob_run > 0u) {  // inside an end-of-band run: the block has no AC symbols (src/decoder.rs:1101-1104)
-                eob_run--;
-                done = true;
-            }
-        } else if (sz == 0u) {
-            if (r == 15u) {  // ZRL
-                k += 16u;
-                done = k >= 64u;
-            } else {  // EOBn
-                eob_run = (1u << r) - 1u;
-                if (r) {
-                    eob_run += huff_peek(b, r);
-                    huff_consume(b, r);
-                }
-                eob_run &= 0xffffu;
-                done = true;
-            }
         } else {
-            k += r;
-            if (k >= 64u) {
-                // (invalid stream) the reference's fused (run, size, value) table — code resolved by the 8-bit LUT, code +
-                // magnitude within 8 bits — has taken the magnitude bits by now, its symbol-then-magnitude path has not
-                if (csz > 0u && csz <= 8u && csz + sz <= 8u) huff_consume(b, sz);
-                done = true;
-            } else {
-                blk[L.unzig[k]] = (int16_t)huff_extend(huff_peek(b, sz), sz);
-                huff_consume(b, sz);
-                k++;
-                done = k >= 64u;
-            }
+            k = is_coef ? knew + 1u : knew;
+            done = is_eob || over || k >= 64u;
         }
         if (done) {
-            const uint32_t my = m / cols, mx = m - my * cols;
-            const uint32_t vp = sub / c_h, hp = sub - vp * c_h;
-            const size_t block = (size_t)(my * c_v + vp) * c_bw + (mx * c_h + hp);
-            JP_GLOBAL v4u *gd = (JP_GLOBAL v4u *)(c_dst + block * 64u);
-#pragma unroll
-            for (int rr = 0; rr < 8; rr++) {
-                gd[rr] = lb[rr];
-                lb[rr] = v4u{0u, 0u, 0u, 0u};
-            }
             k = 0u;
             sub++;
             if (sub == c_hv) {
@@ -249,17 +190,19 @@ __device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffLds &L, uint32_t 
                 c_ac = 4u + sc.ac;
                 c_dst = sc.dst;
             }
+            const uint32_t my = m / cols, mx = m - my * cols;
+            const uint32_t vp = sub / c_h, hp = sub - vp * c_h;
+            blk = (JP_GLOBAL int16_t *)(c_dst + ((size_t)(my * c_v + vp) * c_bw + (mx * c_h + hp)) * 64u);
         }
     }
     // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it keeps reading until it
     // meets the marker, which works iff the unread rest of the segment fits its 64-bit buffer; left-over bits are
-    // dropped.  Same rule here: one more refill must reach the end of the segment.  A segment that ran dry (bits taken
-    // from beyond its end — the reference would have fed zeros as well) is left to the host to be safe.
-    huff_refill(b);
-    const int32_t real_left = (int32_t)b.nbits - b.pad_bits;
-    if (b.bad || b.pos != b.end || real_left < 0) {
+    // dropped.  A segment that ran dry (bits taken from beyond its end — the reference would have fed zeros as well) is
+    // left to the host to be safe.
+    const int64_t consumed = (int64_t)b.wpos * 32 - (int64_t)b.nbits, left = (int64_t)seg_bits - consumed;
+    if (b.bad || left < 0 || left > 64) {
         // bit 0 = re-decode on the host; bits 1..3 say why (diagnostics)
-        const uint32_t why = 1u | (b.bad ? 2u : 0u) | (b.pos != b.end ? 4u : 0u) | (real_left < 0 ? 8u : 0u);
+        const uint32_t why = 1u | (b.bad ? 2u : 0u) | (left > 64 ? 4u : 0u) | (left < 0 ? 8u : 0u);
 #ifdef JPGPU_HOST_EMULATION
         *job.status |= why;
 #else

@@ -35,10 +35,7 @@ int emu_huff_plan(const uint8_t* data, size_t len, jpgpu_image_desc* desc, uint3
     for (auto& s : scans) *n_segments += (uint32_t)(s.seg_off.size() / 2);
     return 0;
 }
-int emu_huff_decode(const uint8_t* data_in, size_t len, int16_t* const* coefs) {
-    std::vector<uint8_t> padded(len + 64, 0);  // the device reader fetches aligned 16-byte chunks, up to 31 bytes past a segment
-    memcpy(padded.data(), data_in, len);
-    const uint8_t* data = padded.data();
+int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs) {
     Frontend fe(data, len);
     std::vector<PlannedScan> scans;
     fe.read_info();
@@ -46,10 +43,23 @@ int emu_huff_decode(const uint8_t* data_in, size_t len, int16_t* const* coefs) {
     uint32_t status = 0;
     HuffLds* L = new HuffLds;
     for (const PlannedScan& ps : scans) {
+        // staging as batch.cpp does it: every segment unstuffed into its own 16-byte aligned, zero padded slot
+        size_t total = 0;
+        for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) total += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
+        std::vector<uint8_t> stage_raw(total + 16);
+        uint8_t* stage = stage_raw.data() + ((16 - (reinterpret_cast<uintptr_t>(stage_raw.data()) & 15)) & 15);
+        std::vector<uint32_t> table(ps.seg_off.size());
+        uint32_t o = 0;
+        for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+            const uint32_t first = ps.seg_off[sg], n = ps.seg_off[sg + 1] - first;
+            table[sg] = o;
+            table[sg + 1] = huff_stage_segment(stage + o, data + ps.data_off + first, n);
+            o += huff_slot_bytes(n);
+        }
         HuffScanJob& job = L->job;
         memset(&job, 0, sizeof(job));
-        job.data = data + ps.data_off;
-        job.seg_off = ps.seg_off.data();
+        job.data = stage;
+        job.seg_off = table.data();
         job.tables = ps.tables;
         job.status = &status;
         job.n_seg = (uint32_t)(ps.seg_off.size() / 2);
@@ -67,7 +77,7 @@ int emu_huff_decode(const uint8_t* data_in, size_t len, int16_t* const* coefs) {
         }
         memcpy(L->tables, ps.tables, sizeof(L->tables));
         for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(L->unzig, t);
-        for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s, s & 63u);
+        for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s);
     }
     delete L;
     return (int)status;
