@@ -18,7 +18,7 @@
 //   * per-step memory operations are LDS reads through address-space-3 pointers (generic pointers made them flat_*
 //     operations at several hundred cycles each) and one 2-byte store per non-zero coefficient.
 // History (MI355X, 68 one-MCU-row segments per 1080p image): block-structured decoder with a byte-wise reader 22 ms for 64
-// images — the same 22 ms for 256 (latency-bound); this form: see DESIGN.md §5.
+// images — the same 22 ms for 256 (latency-bound); this form 13.4 ms for 1,024 images.
 #pragma once
 #include "huff_job.hpp"
 #include "pixel_math.hpp"

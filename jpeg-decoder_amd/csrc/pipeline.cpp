@@ -497,7 +497,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> par_for = [&](uint32_t cnt, const std::function<void(uint32_t)> &fn) {
         std::vector<std::thread> ts;
         std::atomic<uint32_t> next{0};
-        const uint32_t nt = std::min<uint32_t>(cnt, 8u);
+        const uint32_t nt = std::min<uint32_t>(cnt, std::max<uint32_t>(2u, p->pool->size() / 2u));
         for (uint32_t t = 0; t < nt; t++)
             ts.emplace_back([&] {
                 for (uint32_t k = next.fetch_add(1); k < cnt; k = next.fetch_add(1)) fn(k);
