@@ -93,16 +93,19 @@ typedef struct jpgpu_pipeline_timings {
     double headers_ms, setup_ms, entropy_and_upload_ms, kernels_ms, download_ms, total_ms;
     uint32_t threads, images_ok;
     uint64_t jpeg_bytes, coefficient_bytes, pixel_bytes;
+    uint32_t images_device_entropy;  /* entropy-decoded on the device (JPGPU_PIPELINE_DEVICE_ENTROPY) ... */
+    uint32_t images_device_rejected; /* ... of which the device decoder handed this many back to the host */
 } jpgpu_pipeline_timings;
 
 enum {
     JPGPU_PIPELINE_DOWNLOAD = 1u, /* also copy the pixels to pinned host memory (jpgpu_pipeline_pixels_host) */
     JPGPU_PIPELINE_DENSE = 2u,    /* send all 64 coefficients of every block over PCIe instead of the compact form
                                    * (bitmap + index + non-zero values, jpgpu.h) — A/B switch, same pixels */
-    JPGPU_PIPELINE_DEVICE_ENTROPY = 4u /* sequential Huffman streams with restart markers (DRI): send the entropy-coded
-                                   * bytes and decode them on the device, one lane per restart segment (src/decoder.rs:920-956:
-                                   * segments are independent); every other stream, and any stream the device decoder flags,
-                                   * takes the host path */
+    JPGPU_PIPELINE_DEVICE_ENTROPY = 4u /* 8-bit sequential Huffman streams with one all-component scan: send the entropy-coded
+                                   * bytes and decode them on the device — with restart markers (DRI) one lane per restart
+                                   * segment (src/decoder.rs:920-956: segments are independent), without them the
+                                   * self-synchronising chunk decoder (one lane per 128 bytes, csrc/huff_sync_core.hpp); every
+                                   * other stream, and any stream the device decoder flags, takes the host path */
 };
 
 /* n_threads 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if there is one. */

@@ -54,7 +54,7 @@ class ImageDesc(C.Structure):
 class PipelineTimings(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "kernels_ms", "download_ms", "total_ms")] + \
                [("threads", C.c_uint32), ("images_ok", C.c_uint32), ("jpeg_bytes", C.c_uint64), ("coefficient_bytes", C.c_uint64),
-                ("pixel_bytes", C.c_uint64)]
+                ("pixel_bytes", C.c_uint64), ("images_device_entropy", C.c_uint32), ("images_device_rejected", C.c_uint32)]
 
 
 PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY = 1, 2, 4

@@ -63,7 +63,7 @@ struct jpgpu_batch {
     bool any_compact_pending = false;
     // device entropy decoding (huff.hip): one pinned + one device staging block, grown on demand
     uint8_t *h_entropy = nullptr, *d_entropy = nullptr;
-    size_t entropy_cap = 0;
+    size_t entropy_cap = 0, entropy_host_cap = 0;
     uint32_t *h_entropy_out = nullptr;  // pinned read-back: status per listed image, then 2 range stats per (image, comp)
     size_t entropy_out_cap = 0;
     std::vector<uint32_t> entropy_images;  // images of the launch in flight
@@ -387,8 +387,16 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
 }
 
 // ---- device entropy decoding -----------------------------------------------------------------------------------
+static uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const long v = atol(e);
+    return (uint32_t)std::min<long>(std::max<long>(v, lo), hi);
+}
+
 // Staging block layout (same offsets in the pinned and the device copy):
-//   [ status: n x u32 | stats: n x 4 x 2 x u32 | HuffScanJob[] | RangeJob[] | DevHuffTable[8] per scan | segment offsets | scan bytes ]
+//   [ status: n x u32 | stats: n x 4 x 2 x u32 | settle counters: 4 x u32 per sync job | HuffScanJob[] | HuffSyncJob[] | RangeJob[] |
+//     DevHuffTable[8] per scan | segment offsets | scan bytes ]   + device only: per-chunk state of the sync jobs
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
@@ -396,29 +404,51 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     if (rc) return rc;
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
     hipStream_t s = (hipStream_t)hip_stream;
-    size_t n_scans = 0, n_range = 0, seg_words = 0, data_bytes = 0;
+    size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, n_range = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
         n_range += b->descs[images[k].image].ncomp;
         for (const host::PlannedScan &ps : *images[k].scans) {
             n_scans++;
             seg_words += ps.seg_off.size();
-            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) data_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
+            size_t stuffed = 0;
+            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+                data_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
+                stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
+            }
+            if (ps.ri == 0) {  // no restart markers: the chunk decoder and its per-chunk state (device only)
+                if (ps.seg_off.size() != 2 || stuffed >= (1u << 28)) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad plan");
+                n_sync_jobs++;
+                uint32_t blocks = 0;
+                for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
+                const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu);
+                scratch_bytes += align_up((size_t)huff_sync_chunks((uint32_t)stuffed, shift) * 5 * 4, 16);
+            } else {
+                n_seg_jobs++;
+            }
         }
     }
-    const size_t off_status = 0, off_stats = align_up(off_status + (size_t)n * 4, 16), off_jobs = align_up(off_stats + (size_t)n * 32, 16);
-    const size_t off_range = align_up(off_jobs + n_scans * sizeof(HuffScanJob), 16), off_tables = align_up(off_range + n_range * sizeof(RangeJob), 16);
+    const size_t off_status = 0, off_stats = align_up(off_status + (size_t)n * 4, 16), off_cnt = align_up(off_stats + (size_t)n * 32, 16);
+    const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = align_up(off_jobs + n_seg_jobs * sizeof(HuffScanJob), 16);
+    const size_t off_range = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16), off_tables = align_up(off_range + n_range * sizeof(RangeJob), 16);
     const size_t off_seg = align_up(off_tables + n_scans * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
-    const size_t total = off_data + data_bytes;
-    if (total > b->entropy_cap) {
+    const size_t total = off_data + data_bytes;              // uploaded
+    const size_t off_scratch = align_up(total, 256), total_dev = off_scratch + scratch_bytes;
+    if (total_dev > b->entropy_cap) {
         if (b->d_entropy) (void)hipFree(b->d_entropy);
-        if (b->h_entropy) (void)hipHostFree(b->h_entropy);
-        b->d_entropy = b->h_entropy = nullptr;
+        b->d_entropy = nullptr;
         b->entropy_cap = 0;
-        const size_t cap = total + total / 4;
+        const size_t cap = total_dev + total_dev / 4;
         B_HIP(hipMalloc((void **)&b->d_entropy, cap));
-        B_HIP(hipHostMalloc((void **)&b->h_entropy, cap, hipHostMallocDefault));
         b->entropy_cap = cap;
+    }
+    if (total > b->entropy_host_cap) {
+        if (b->h_entropy) (void)hipHostFree(b->h_entropy);
+        b->h_entropy = nullptr;
+        b->entropy_host_cap = 0;
+        const size_t cap = total + total / 4;
+        B_HIP(hipHostMalloc((void **)&b->h_entropy, cap, hipHostMallocDefault));
+        b->entropy_host_cap = cap;
     }
     const size_t out_words = (size_t)n * 9;
     if (out_words > b->entropy_out_cap) {
@@ -430,15 +460,17 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     uint8_t *h = b->h_entropy, *d = b->d_entropy;
     memset(h, 0, off_jobs);  // status and stats start at zero
     HuffScanJob *jobs = reinterpret_cast<HuffScanJob *>(h + off_jobs);
+    HuffSyncJob *sjobs = reinterpret_cast<HuffSyncJob *>(h + off_sjobs);
     RangeJob *rjobs = reinterpret_cast<RangeJob *>(h + off_range);
-    size_t ji = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data;
-    uint32_t max_seg = 0, max_blocks = 0;
+    size_t ji = 0, si = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
+    uint32_t max_seg = 0, max_blocks = 0, max_chunks = 0;
     struct CopyTask {
         uint8_t *dst;        // first slot of the scan in the pinned block
         uint32_t *seg_table; // its 2 * n_seg words
         uint32_t dst_off;    // offset of dst inside the data area
         const uint8_t *src;  // the scan's entropy-coded bytes
         const host::PlannedScan *ps;
+        HuffSyncJob *sync;   // scan without restart markers: its job record (the unstuffed length goes there)
     };
     std::vector<CopyTask> copies;
     std::vector<std::pair<size_t, size_t>> zero_ranges;  // coefficient planes of the listed images
@@ -449,34 +481,65 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const jpgpu_image_desc &desc = b->descs[img];
         zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
         for (const host::PlannedScan &ps : *images[k].scans) {
-            HuffScanJob &j = jobs[ji++];
-            memset(&j, 0, sizeof(j));
             // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
-            copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps});
-            size_t scan_bytes = 0;
-            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
+            HuffSyncJob *sj = ps.ri == 0 ? &sjobs[si] : nullptr;
+            copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps, sj});
+            size_t scan_bytes = 0, stuffed = 0;
+            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+                scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
+                stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
+            }
             memcpy(h + tcur, ps.tables, sizeof(ps.tables));
-            j.data = d + off_data;  // (segment offsets are relative to the start of the data area)
-            j.seg_off = reinterpret_cast<const uint32_t *>(d + scur);
-            j.tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
-            j.status = reinterpret_cast<uint32_t *>(d + off_status) + k;
-            j.n_seg = (uint32_t)(ps.seg_off.size() / 2);
-            j.ri = ps.ri;
-            j.cols = ps.cols;
-            j.n_mcu = ps.n_mcu;
-            j.ncomp = ps.ncomp;
+            HuffScanComp comp[4];
+            memset(comp, 0, sizeof(comp));
             for (uint32_t c = 0; c < ps.ncomp; c++) {
                 const uint32_t fi = ps.comp[c].frame_index;
                 if (fi >= desc.ncomp || ps.comp[c].block_w != desc.components[fi].block_width)
                     return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: plan does not match the image descriptor");
-                j.comp[c].dst = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
-                j.comp[c].block_w = ps.comp[c].block_w;
-                j.comp[c].h = ps.comp[c].h;
-                j.comp[c].v = ps.comp[c].v;
-                j.comp[c].dc = ps.comp[c].dc;
-                j.comp[c].ac = ps.comp[c].ac;
+                comp[c].dst = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
+                comp[c].block_w = ps.comp[c].block_w;
+                comp[c].h = ps.comp[c].h;
+                comp[c].v = ps.comp[c].v;
+                comp[c].dc = ps.comp[c].dc;
+                comp[c].ac = ps.comp[c].ac;
             }
-            max_seg = std::max(max_seg, j.n_seg);
+            if (sj) {
+                memset(sj, 0, sizeof(*sj));
+                memcpy(sj->comp, comp, sizeof(comp));
+                sj->ncomp = ps.ncomp;
+                huff_sync_finish_job(*sj);
+                sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu);
+                const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
+                uint32_t *st = reinterpret_cast<uint32_t *>(d + xcur);
+                sj->data = d + dcur;
+                sj->tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
+                sj->status = reinterpret_cast<uint32_t *>(d + off_status) + k;
+                sj->changed = reinterpret_cast<uint32_t *>(d + off_cnt) + si * 4;
+                sj->in_pos = st;
+                sj->in_qk = st + chunks;
+                sj->out_pos = st + 2 * (size_t)chunks;
+                sj->out_qk = st + 3 * (size_t)chunks;
+                sj->n_blocks = st + 4 * (size_t)chunks;
+                sj->cols = ps.cols;
+                sj->n_mcu = ps.n_mcu;
+                max_chunks = std::max(max_chunks, chunks);
+                xcur += align_up((size_t)chunks * 5 * 4, 16);
+                si++;
+            } else {
+                HuffScanJob &j = jobs[ji++];
+                memset(&j, 0, sizeof(j));
+                j.data = d + off_data;  // (segment offsets are relative to the start of the data area)
+                j.seg_off = reinterpret_cast<const uint32_t *>(d + scur);
+                j.tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
+                j.status = reinterpret_cast<uint32_t *>(d + off_status) + k;
+                j.n_seg = (uint32_t)(ps.seg_off.size() / 2);
+                j.ri = ps.ri;
+                j.cols = ps.cols;
+                j.n_mcu = ps.n_mcu;
+                j.ncomp = ps.ncomp;
+                memcpy(j.comp, comp, sizeof(comp));
+                max_seg = std::max(max_seg, j.n_seg);
+            }
             dcur += scan_bytes;
             scur += ps.seg_off.size() * 4;
             tcur += 8 * sizeof(DevHuffTable);
@@ -500,6 +563,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 ct.seg_table[sg + 1] = huff_stage_segment(ct.dst + o, ct.src + first, n);
                 o += huff_slot_bytes(n);
             }
+            if (ct.sync) {
+                ct.sync->n_bits = ct.seg_table[1] * 8u;
+                ct.sync->n_chunks = huff_sync_chunks(ct.seg_table[1], ct.sync->chunk_shift);
+            }
         };
         if (par && copies.size() > 1) (*par)((uint32_t)copies.size(), body);
         else
@@ -514,7 +581,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, s));
     }
     B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
-    B_HIP(launch_huff_segments(reinterpret_cast<const HuffScanJob *>(d + off_jobs), (uint32_t)n_scans, max_seg, s));
+    B_HIP(launch_huff_segments(reinterpret_cast<const HuffScanJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
+    {
+        static const uint32_t launches = env_u32("JPGPU_SYNC_LAUNCHES", 10, 1, 64), iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
+        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, launches, iters, s));
+    }
     B_HIP(launch_range_scan(reinterpret_cast<const RangeJob *>(d + off_range), (uint32_t)n_range, max_blocks,
                             reinterpret_cast<uint32_t *>(d + off_stats), s));
     // status words, then the stats (8 per image), into pinned memory

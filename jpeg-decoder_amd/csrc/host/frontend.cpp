@@ -737,7 +737,7 @@ struct Frontend::Impl {
     bool plan_scan(const ScanInfo &scan, const bool (&finished)[JPGPU_MAX_COMPONENTS], Marker &pending) {
         const FrameInfo &f = frame;
         const int nc = scan.n;
-        if (f.coding_process != JPGPU_CODING_DCT_SEQUENTIAL || f.precision != 8 || restart_interval == 0) throw NotEligible{1};
+        if (f.coding_process != JPGPU_CODING_DCT_SEQUENTIAL || f.precision != 8) throw NotEligible{1};
         if (scan.ss_start != 0 || scan.ss_end != 64 || scan.ah != 0 || scan.al != 0) throw NotEligible{2};
         // one scan carrying all components (what encoders write for sequential files; per-component scans stay on the host)
         if ((size_t)nc != f.components.size()) throw NotEligible{13};
@@ -770,7 +770,7 @@ struct Frontend::Impl {
         ps.cols = std::min<uint32_t>(max_x, ((uint32_t)f.image_w + 7u) / 8u);
         const uint32_t rows = std::min<uint32_t>(max_y, ((uint32_t)f.image_h + 7u) / 8u);
         ps.n_mcu = ps.cols * rows;
-        ps.ri = restart_interval;
+        ps.ri = restart_interval;  // 0: no restart markers — one segment, decoded by the self-synchronising chunk decoder
         ps.ncomp = (uint32_t)nc;
         if (ps.n_mcu == 0) throw NotEligible{6};
         for (int i = 0; i < nc; i++) {
@@ -795,7 +795,7 @@ struct Frontend::Impl {
         }
         // cut the entropy-coded data at the RSTn markers: exactly one every `ri` MCUs, numbered 0..7 cyclically
         // (src/decoder.rs:920-956), 0xFF00 pairs inside, one other marker right after the last segment
-        const uint32_t n_seg = (ps.n_mcu + ps.ri - 1u) / ps.ri;
+        const uint32_t n_seg = ps.ri ? (ps.n_mcu + ps.ri - 1u) / ps.ri : 1u;
         ps.data_off = src.pos;
         ps.seg_off.reserve((size_t)n_seg + 1u);
         ps.seg_off.push_back(0u);

@@ -41,7 +41,7 @@ public:
 struct PlannedScan {
     size_t data_off = 0;            // offset of the scan's entropy-coded bytes in the stream given to the Frontend
     std::vector<uint32_t> seg_off;  // 2 * n_seg offsets relative to data_off: segment s = [seg_off[2s], seg_off[2s+1]), no markers
-    uint32_t ri = 0, cols = 0, n_mcu = 0, ncomp = 0;
+    uint32_t ri = 0, cols = 0, n_mcu = 0, ncomp = 0;  // ri == 0: no restart interval (one segment)
     struct Comp {
         uint32_t frame_index, block_w, h, v, dc, ac;
     } comp[4];
@@ -66,7 +66,7 @@ public:
     void decode_to(RowSink &sink);
     // Instead of decoding: walk the markers to EOI and describe every scan for the device entropy decoder.  Returns
     // false — the object is then spent, decode with a fresh Frontend — unless the stream is plainly eligible: 8-bit
-    // sequential Huffman, one scan carrying all components, a restart interval in force,
+    // sequential Huffman, one scan carrying all components,
     // RST markers exactly where and as numbered as the interval says, nothing else inside or after the entropy
     // data.  Anything doubtful (including every error the marker loop would raise) is "not eligible": the host
     // decoder is the one whose behaviour on odd streams is pinned.  On success the tables handed to Worker::start

@@ -67,6 +67,29 @@ __device__ __forceinline__ int32_t huff_extend(uint32_t v, uint32_t n) {  // src
     return (int32_t)v < vt ? (int32_t)v + (int32_t)(0xffffffffu << n) + 1 : (int32_t)v;
 }
 
+__device__ __forceinline__ void atomicOr_status(uint32_t *p, uint32_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p |= v;
+#else
+    atomicOr(p, v);
+#endif
+}
+// state words other lanes (possibly of other workgroups, in the same launch) read while we run: straight to/from L2
+__device__ __forceinline__ uint32_t huff_load_shared(const uint32_t *p) {
+#ifdef JPGPU_HOST_EMULATION
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void huff_store_shared(uint32_t *p, uint32_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // The slow tail of src/huffman.rs:31-58 for prefixes the wide table does not resolve: the maxcode walk from length 9.
 __device__ __forceinline__ uint32_t huff_walk(DevBits &b, const JP_LDS DevHuffTable &t) {
     const uint32_t b16 = huff_peek(b, 16);

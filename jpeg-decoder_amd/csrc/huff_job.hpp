@@ -48,4 +48,55 @@ inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n)
     return o;
 }
 
+// ---- scans without restart markers: the self-synchronising chunk decoder (huff_sync_core.hpp) -------------------------
+
+struct HuffSyncJob {             // one scan of one image (exactly one "segment": no restart interval in force)
+    const uint8_t *data;         // staged scan: unstuffed, 16-byte aligned, zero padded
+    const DevHuffTable *tables;  // 8 tables of this scan
+    uint32_t *status;            // the image's status word (bit 0: decode on the host instead)
+    uint32_t *changed;           // per job: lanes that published a new state in the current pass
+    // per chunk (n_chunks entries each)
+    uint32_t *in_pos, *in_qk;    // start state last decoded from          (qk = block-within-MCU << 8 | coefficient index)
+    uint32_t *out_pos, *out_qk;  // published end state
+    uint32_t *n_blocks;          // blocks completed by the chunk; after the scan: number of its first block
+    uint32_t n_bits, n_chunks;
+    uint32_t cols, n_mcu;        // MCUs per row / in the scan
+    uint32_t ncomp, bpm;         // components, blocks per MCU
+    uint32_t uniform, chunk_shift; // chunk = 1 << chunk_shift bits (huff_sync_chunk_shift); uniform: every component uses the same pair of tables: the block-within-MCU index does not influence
+                                 // decoding and stays out of the sync state (else such scans — RGB, CMYK files — settle one chunk
+                                 // per pass: a lane synchronised in position but one block off would hand the error on forever)
+    HuffScanComp comp[4];
+    uint8_t q_comp[16], q_sub[16];  // block-within-MCU -> component of the scan, block inside that component's part of the MCU
+};
+
+// Chunk size.  A lane that starts at a wrong place finds the symbol boundaries within a few symbols, the block boundaries at
+// the next end-of-block — and the position inside the MCU (which tables apply) only by luck, one try per re-synchronisation,
+// so what matters is the number of BLOCKS in a chunk: ~48 of them (measured: 15 blocks per chunk settle 63 % of the lanes per
+// pass, 60 blocks 98 %), between 1,024 and 8,192 bits, from the stream's average (the stuffed length serves: an upper bound
+// taken before the staging copy).
+inline uint32_t huff_sync_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) {
+    const uint64_t target = (uint64_t)stuffed_bytes * 8u * 48u / (total_blocks ? total_blocks : 1u);
+    uint32_t shift = 10;
+    while (shift < 13u && (1ull << shift) * 1414u / 1000u < target) shift++;  // nearest power of two (in the log domain)
+    return shift;
+}
+inline uint32_t huff_sync_chunks(uint32_t bytes, uint32_t chunk_shift) {
+    const uint32_t n = (uint32_t)(((uint64_t)bytes * 8u + (1u << chunk_shift) - 1u) >> chunk_shift);
+    return n ? n : 1u;
+}
+// comp[0..ncomp) filled in -> bpm, the block-within-MCU maps and `uniform`
+inline void huff_sync_finish_job(HuffSyncJob &j) {
+    uint32_t bpm = 0;
+    for (uint32_t c = 0; c < j.ncomp; c++)
+        for (uint32_t b = 0; b < j.comp[c].h * j.comp[c].v && bpm < 16u; b++) {
+            j.q_comp[bpm] = (uint8_t)c;
+            j.q_sub[bpm] = (uint8_t)b;
+            bpm++;
+        }
+    j.bpm = bpm;
+    j.uniform = 1;
+    for (uint32_t c = 1; c < j.ncomp; c++)
+        if (j.comp[c].dc != j.comp[0].dc || j.comp[c].ac != j.comp[0].ac) j.uniform = 0;
+}
+
 }  // namespace jpgpu

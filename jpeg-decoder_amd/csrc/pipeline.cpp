@@ -258,35 +258,57 @@ struct jpgpu_pipeline {
 
 // An image the device entropy decoder handed back: the pinned behaviour is the host decoder's — decode it here (uploader
 // thread; rare) and upload it densely, or record the error it raises.
-static void host_redecode(jpgpu_pipeline *p, SubBatch &sb, uint32_t i, const uint8_t *data, size_t len) {
-    const uint32_t bi = (uint32_t)p->slot[i];
+// An image the device entropy decoder handed back: decode it on the host (dense planes, plain upload).  Two steps so that
+// several of them can be decoded side by side: host_redecode_stage (any thread), host_redecode_upload (the uploader).
+struct Redecode {
+    uint32_t image = 0, nc = 0;
+    size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
+    std::vector<uint8_t> planes;
+    uint16_t qt[4][64];
+    int status = JPGPU_OK;
+    std::string error;
+};
+
+static void host_redecode_stage(jpgpu_pipeline *p, SubBatch &sb, Redecode &r, const uint8_t *data, size_t len) {
+    const uint32_t bi = (uint32_t)p->slot[r.image];
     try {
         Frontend fe(data, len);
         fe.read_info();
-        const uint32_t nc = fe.ncomp();
-        size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
-        std::vector<uint8_t> tmp;
+        r.nc = fe.ncomp();
         size_t total = 0;
-        for (uint32_t c = 0; c < nc; c++) {
-            ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
-            off[c] = total;
-            total += ln[c];
+        for (uint32_t c = 0; c < r.nc; c++) {
+            r.ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
+            r.off[c] = total;
+            total += r.ln[c];
         }
-        tmp.resize(total);
-        StageSink sink(tmp.data(), off, ln, false);
+        r.planes.resize(total);
+        StageSink sink(r.planes.data(), r.off, r.ln, false);
         fe.decode_to(sink);
-        for (uint32_t c = 0; c < nc; c++) {
+        for (uint32_t c = 0; c < r.nc; c++) {
             if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
-            jpgpu_batch_set_quantization_table(sb.batch, bi, c, sink.qt(c));
-            if (jpgpu_batch_upload(sb.batch, bi, c, reinterpret_cast<const int16_t *>(tmp.data() + off[c]), ln[c] / 2) != JPGPU_OK)
-                throw DecodeError{JPGPU_ERR_IO, jpgpu_batch_last_error(sb.batch)};
+            memcpy(r.qt[c], sink.qt(c), 128);
         }
     } catch (const DecodeError &e) {
-        p->status[i] = e.code;
-        p->errors[i] = e.message;
+        r.status = e.code;
+        r.error = e.message;
     } catch (const std::exception &e) {
-        p->status[i] = JPGPU_ERR_INTERNAL;
-        p->errors[i] = e.what();
+        r.status = JPGPU_ERR_INTERNAL;
+        r.error = e.what();
+    }
+}
+
+static void host_redecode_upload(jpgpu_pipeline *p, SubBatch &sb, Redecode &r) {
+    const uint32_t bi = (uint32_t)p->slot[r.image];
+    for (uint32_t c = 0; c < r.nc && r.status == JPGPU_OK; c++) {
+        jpgpu_batch_set_quantization_table(sb.batch, bi, c, r.qt[c]);
+        if (jpgpu_batch_upload(sb.batch, bi, c, reinterpret_cast<const int16_t *>(r.planes.data() + r.off[c]), r.ln[c] / 2) != JPGPU_OK) {
+            r.status = JPGPU_ERR_IO;
+            r.error = jpgpu_batch_last_error(sb.batch);
+        }
+    }
+    if (r.status != JPGPU_OK) {
+        p->status[r.image] = r.status;
+        p->errors[r.image] = r.error;
     }
 }
 
@@ -491,7 +513,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const bool trace = getenv("JPGPU_PIPE_TRACE") != nullptr;
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0;
-    uint32_t device_rejected = 0;
+    uint32_t device_rejected = 0, device_images = 0;
     // the pool is idle while device-entropy images are staged (its tasks for them return at once): lend it to the copy
     std::mutex par_m;
     const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> par_for = [&](uint32_t cnt, const std::function<void(uint32_t)> &fn) {
@@ -521,7 +543,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             for (const auto &it : take) {
                 const uint32_t i = it.first;
                 SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
-                if (it.second == 2) dev_images[(uint32_t)p->sub_of[i]].push_back(i);
+                if (it.second == 2) {
+                    dev_images[(uint32_t)p->sub_of[i]].push_back(i);
+                    device_images++;
+                }
                 if (it.second == 1 && !hip_failed.load()) {
                     hipStream_t cps = p->copy_streams[k++ % kCopyStreams];
                     if (sb.compact) {
@@ -583,11 +608,19 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     if (trace) fprintf(stderr, "pipeline trace: sub-batch %u synchronised at +%.2f ms after waiting %.2f ms\n", sj, now_ms() - t2, now_ms() - s0);
                     okk = okk &&
                                jpgpu::batch_device_entropy_collect(sb.batch, st.data(), (uint32_t)st.size()) == JPGPU_OK;
+                    std::vector<Redecode> redo;
                     for (size_t k2 = 0; okk && k2 < dv.size(); k2++)
                         if (st[k2]) {
                             device_rejected++;
-                            host_redecode(p, sb, dv[k2], data[dv[k2]], len[dv[k2]]);
+                            redo.emplace_back();
+                            redo.back().image = dv[k2];
                         }
+                    if (!redo.empty()) {
+                        const std::function<void(uint32_t)> body = [&](uint32_t r) { host_redecode_stage(p, sb, redo[r], data[redo[r].image], len[redo[r].image]); };
+                        if (redo.size() > 1) par_for((uint32_t)redo.size(), body);
+                        else body(0);
+                        for (Redecode &r : redo) host_redecode_upload(p, sb, r);
+                    }
                     if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {
                         launch_err = jpgpu_batch_last_error(sb.batch);
                         okk = false;
@@ -685,6 +718,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.jpeg_bytes = jpeg_bytes.load();
     p->t.coefficient_bytes = coef_bytes.load();
     p->t.pixel_bytes = pixel_bytes;
+    p->t.images_device_entropy = device_images;
+    p->t.images_device_rejected = device_rejected;
     (void)t_last_upload;
     return JPGPU_OK;
 }

@@ -1,15 +1,26 @@
 // emu_huff.cpp — TEST-ONLY CPU run of the device entropy decoder (csrc/huff_core.hpp) on the plan the host front-end
 // makes (Frontend::plan_device_scans): every restart segment decoded by the device code, into zero-filled planes.
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
 #include "hip_shim.hpp"
 #include <vector>
 #include "../../jpeg-decoder_amd/csrc/host/frontend.hpp"
 #include "../../jpeg-decoder_amd/csrc/huff_core.hpp"
+#include "../../jpeg-decoder_amd/csrc/huff_sync_core.hpp"
 
 using namespace jpgpu;
 using jpgpu::host::Frontend;
 using jpgpu::host::PlannedScan;
 
+static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
+
 extern "C" {
+void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
+    g_sync_stale = stale;
+    g_sync_iters = iters ? iters : 1u;
+    g_sync_wg = workgroup ? workgroup : 256u;
+}
 // Returns: -1 not eligible; otherwise the status word (0 = every segment decoded cleanly).  coefs[c] must hold
 // block_w*block_h*64 zeros for frame component c (sizes from *desc, filled when eligible).
 int emu_huff_plan(const uint8_t* data, size_t len, jpgpu_image_desc* desc, uint32_t* n_scans, uint32_t* n_segments) {
@@ -35,7 +46,7 @@ int emu_huff_plan(const uint8_t* data, size_t len, jpgpu_image_desc* desc, uint3
     for (auto& s : scans) *n_segments += (uint32_t)(s.seg_off.size() / 2);
     return 0;
 }
-int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs) {
+int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint32_t* n_passes) {
     Frontend fe(data, len);
     std::vector<PlannedScan> scans;
     fe.read_info();
@@ -55,6 +66,101 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs) {
             table[sg] = o;
             table[sg + 1] = huff_stage_segment(stage + o, data + ps.data_off + first, n);
             o += huff_slot_bytes(n);
+        }
+        if (ps.ri == 0) {  // no restart markers: the self-synchronising chunk decoder, passes run one after the other
+            HuffSyncLds* S = new HuffSyncLds;
+            HuffSyncJob& sj = S->job;
+            memset(&sj, 0, sizeof(sj));
+            uint32_t changed = 0;
+            sj.data = stage;
+            sj.tables = ps.tables;
+            sj.status = &status;
+            sj.changed = &changed;
+            sj.n_bits = table[1] * 8u;
+            sj.cols = ps.cols;
+            sj.n_mcu = ps.n_mcu;
+            sj.ncomp = ps.ncomp;
+            for (uint32_t c = 0; c < ps.ncomp; c++) {
+                sj.comp[c].dst = coefs[ps.comp[c].frame_index];
+                sj.comp[c].block_w = ps.comp[c].block_w;
+                sj.comp[c].h = ps.comp[c].h;
+                sj.comp[c].v = ps.comp[c].v;
+                sj.comp[c].dc = ps.comp[c].dc;
+                sj.comp[c].ac = ps.comp[c].ac;
+            }
+            huff_sync_finish_job(sj);
+            sj.chunk_shift = huff_sync_chunk_shift(ps.seg_off[1] - ps.seg_off[0], sj.bpm * ps.n_mcu);
+            sj.n_chunks = huff_sync_chunks(table[1], sj.chunk_shift);
+            std::vector<uint32_t> arr(5 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
+            sj.in_pos = arr.data();
+            sj.in_qk = arr.data() + sj.n_chunks;
+            sj.out_pos = arr.data() + 2 * (size_t)sj.n_chunks;
+            sj.out_qk = arr.data() + 3 * (size_t)sj.n_chunks;
+            sj.n_blocks = arr.data() + 4 * (size_t)sj.n_chunks;
+            if (g_sync_stale)  // what a previous batch of similar streams leaves in the arrays: states that LOOK right
+                for (uint32_t i = 0; i < sj.n_chunks; i++) {
+                    sj.out_pos[i] = ((i + 1u) << sj.chunk_shift) + (i * 7u + g_sync_stale) % 33u;
+                    sj.out_qk[i] = (((i * 5u + g_sync_stale) % sj.bpm) << 8) | ((i * 11u) % 64u);
+                    sj.in_pos[i] = sj.out_pos[i ? i - 1 : 0];
+                    sj.in_qk[i] = sj.out_qk[i ? i - 1 : 0];
+                    sj.n_blocks[i] = i % 9u;
+                }
+            memcpy(S->tables, ps.tables, sizeof(S->tables));
+            for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(S->unzig, t);
+            // Launches as huff.hip runs them: workgroups of 256 lanes, `iters` iterations each with a barrier in between.
+            // Lanes of a workgroup run concurrently (every lane sees the states its neighbours had before the iteration);
+            // workgroups run one after the other here, last first — each sees its left neighbour's state of the previous
+            // launch, the least the device guarantees.
+            const uint32_t iters = g_sync_iters, WG = g_sync_wg;
+            uint32_t pass = 0, launch = 0;
+            for (; launch < 32; launch++) {
+                changed = 0;
+                const uint32_t n_wg = (sj.n_chunks + WG - 1) / WG;
+                for (uint32_t w = n_wg; w-- > 0;) {
+                    const uint32_t lo = w * WG, hi = std::min(sj.n_chunks, lo + WG);
+                    for (uint32_t it = 0; it < iters; it++) {
+                        const uint32_t first = lo ? lo - 1 : 0;
+                        std::vector<uint32_t> prev_pos(sj.out_pos + first, sj.out_pos + hi), prev_qk(sj.out_qk + first, sj.out_qk + hi);
+                        std::vector<uint32_t> new_pos(prev_pos), new_qk(prev_qk);
+                        for (uint32_t i = lo; i < hi; i++) {
+                            std::copy(prev_pos.begin(), prev_pos.end(), sj.out_pos + first);
+                            std::copy(prev_qk.begin(), prev_qk.end(), sj.out_qk + first);
+                            changed += huff_sync_chunk<false>(*S, i, launch * iters + it) ? 1u : 0u;
+                            new_pos[i - first] = sj.out_pos[i];
+                            new_qk[i - first] = sj.out_qk[i];
+                        }
+                        std::copy(new_pos.begin(), new_pos.end(), sj.out_pos + first);
+                        std::copy(new_qk.begin(), new_qk.end(), sj.out_qk + first);
+                    }
+                }
+                if (getenv("EMU_HUFF_TRACE")) fprintf(stderr, "launch %u changed %u of %u\n", launch, changed, sj.n_chunks);
+                if (launch > 0 && changed == 0) break;
+            }
+            pass = launch;
+            if (pass == 32) status |= 1u | 64u;
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < sj.n_chunks; i++) {  // exclusive scan
+                const uint32_t nb = sj.n_blocks[i];
+                sj.n_blocks[i] = run;
+                run += nb;
+            }
+            for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0);
+            // DC differences -> values, per component in stream order (i16 wrapping)
+            for (uint32_t c = 0; c < ps.ncomp; c++) {
+                const HuffScanComp& sc = sj.comp[c];
+                const uint32_t hv = sc.h * sc.v;
+                uint16_t acc = 0;
+                for (uint32_t m = 0; m < sj.n_mcu; m++)
+                    for (uint32_t sub = 0; sub < hv; sub++) {
+                        const uint32_t my = m / sj.cols, mx = m - my * sj.cols, vp = sub / sc.h, hp = sub - vp * sc.h;
+                        int16_t* blk = sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u;
+                        acc = (uint16_t)(acc + (uint16_t)blk[0]);
+                        blk[0] = (int16_t)acc;
+                    }
+            }
+            if (n_passes) *n_passes = pass;
+            delete S;
+            continue;
         }
         HuffScanJob& job = L->job;
         memset(&job, 0, sizeof(job));

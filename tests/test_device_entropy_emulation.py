@@ -33,7 +33,9 @@ def _device(data):
         return None
     planes = [np.zeros(desc.components[c].block_width * desc.components[c].block_height * 64, np.int16) for c in range(desc.ncomp)]
     ptrs = (C.c_void_p * 4)(*([p.ctypes.data for p in planes] + [None] * (4 - len(planes))))
-    st = L.emu_huff_decode(buf, len(data), ptrs)
+    npass = C.c_uint32(0)
+    st = L.emu_huff_decode(buf, len(data), ptrs, C.byref(npass))
+    _device.last_passes = npass.value
     return st, desc, planes, ns.value, nseg.value
 
 
@@ -80,17 +82,70 @@ def test_encoder_written_restart_streams(case):
         assert np.array_equal(planes[c], hcoefs[c]), c
 
 
-def test_streams_without_restart_markers_stay_on_the_host():
-    for rel in ["benches/tower.jpg", "benches/tower_progressive.jpg", "reftest/mozilla/jpg-progressive.jpg", "reftest/rgb.jpg",
-                "reftest/mozilla/jpg-gray.jpg", "reftest/non-interleaved-mcu.jpg"]:  # (the last: progressive, with DRI)
+def test_only_plain_sequential_streams_are_planned():
+    for rel in ["benches/tower_progressive.jpg", "reftest/mozilla/jpg-progressive.jpg", "reftest/non-interleaved-mcu.jpg",
+                "reftest/progressive3.jpg"]:  # progressive (the third one with DRI)
         assert _device(open(os.path.join(R.GOLDEN, rel), "rb").read()) is None, rel
     assert _device(b"") is None and _device(b"\xff\xd8\xff\xd9") is None
+
+
+NO_RST = ["benches/tower.jpg", "benches/tower_grayscale.jpg", "reftest/rgb.jpg", "reftest/mozilla/jpg-gray.jpg", "reftest/mozilla/jpg-size-33x33.jpg",
+          "reftest/mozilla/jpg-size-1x1.jpg", "reftest/mozilla/jpg-size-8x8.jpg", "reftest/mozilla/jpg-cmyk-1.jpg", "reftest/mozilla/jpg-cmyk-2.jpg",
+          "reftest/16bit-qtables.jpg", "reftest/extraneous-data.jpg", "reftest/blank_800x280.jpg", "benches/large_image.jpg"]
+
+
+@pytest.fixture(params=[(1, 256, 0), (2, 256, 0), (3, 4, 0), (2, 8, 1), (1, 256, 3)], ids=lambda p: f"iters{p[0]}-wg{p[1]}-stale{p[2]}")
+def launch_shape(request):
+    """Sync launches as huff.hip runs them (iterations per launch, lanes per workgroup); tiny workgroups put many
+    workgroup borders — where a lane may see what an earlier batch left in the state arrays — into small streams.
+    stale: the arrays start with plausible-looking states of "an earlier batch" instead of a garbage pattern."""
+    emu.lib().emu_huff_set_launch(*request.param)
+    yield request.param
+    emu.lib().emu_huff_set_launch(1, 256, 0)
+
+
+@pytest.mark.parametrize("rel", NO_RST)
+def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_shape):
+    """Baseline files as encoders write them by default (no DRI): chunked decoding with state hand-over until the
+    segmentation settles, block numbering, write pass, DC accumulation — all device code, run on the CPU."""
+    data = open(os.path.join(R.GOLDEN, rel), "rb").read()
+    got = _device(data)
+    if got is None:
+        pytest.skip("planner keeps this stream on the host (multi-scan or otherwise unusual)")
+    st, desc, planes, _ns, n_seg = got
+    hdesc, hcoefs = _host(data)
+    assert st == 0, (st, _device.last_passes)
+    assert _device.last_passes <= 6, _device.last_passes  # launches until one changed nothing
+    for c in range(desc.ncomp):
+        assert np.array_equal(planes[c], hcoefs[c]), c
+
+
+@pytest.mark.parametrize("case", [(64, 48, "4:2:0"), (250, 130, "4:2:0"), (129, 257, "4:2:2"), (200, 120, "4:4:4"), (300, 200, None),
+                                  (1920, 1080, "4:2:0"), (1, 1, "4:2:0"), (17, 3000, "4:4:4")], ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}")
+def test_encoder_written_streams_without_restart_markers(case, launch_shape):
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    w, h, sub = case
+    rgb = synth.synthetic_rgb(w, h, seed=w + h)
+    buf = io.BytesIO()
+    Image.fromarray(rgb[..., 0] if sub is None else rgb).save(buf, format="JPEG", quality=85, subsampling=sub or "4:4:4")
+    data = buf.getvalue()
+    got = _device(data)
+    assert got is not None
+    st, desc, planes, _ns, _nseg = got
+    assert st == 0
+    hdesc, hcoefs = _host(data)
+    for c in range(desc.ncomp):
+        assert np.array_equal(planes[c], hcoefs[c]), c
+    assert _device.last_passes <= 8, _device.last_passes
 
 
 def test_damaged_restart_streams_never_disagree_silently():
     """Mutations inside the entropy data of DRI streams: not eligible, or flagged, or identical to the host."""
     pytest.importorskip("PIL")
-    seeds = [open(os.path.join(R.GOLDEN, "reftest/restarts.jpg"), "rb").read(), _pil_jpeg(96, 64, "4:2:0", 2, 0)]
+    seeds = [open(os.path.join(R.GOLDEN, "reftest/restarts.jpg"), "rb").read(), _pil_jpeg(96, 64, "4:2:0", 2, 0),
+             open(os.path.join(R.GOLDEN, "reftest/mozilla/jpg-size-33x33.jpg"), "rb").read(), open(os.path.join(R.GOLDEN, "benches/tower.jpg"), "rb").read()]
     rng = np.random.default_rng(9)
     outcomes = {"host": 0, "flag": 0, "same": 0}
     for base in seeds:

@@ -151,3 +151,66 @@ def test_pipeline_device_entropy_decoder_matches_host_path():
     assert p.kernel_path == "fused420"
     _check([f"same-{i}" for i in range(9)], same, out)
     p.close()
+
+
+def _pil_plain(w, h, subsampling, gray=False, seed=0, quality=85):
+    import io
+    from PIL import Image
+    import synth
+    rgb = synth.synthetic_rgb(w, h, seed=seed + w + h)
+    im = Image.fromarray(rgb[..., 0] if gray else rgb)
+    buf = io.BytesIO()
+    im.save(buf, format="JPEG", quality=quality, subsampling=subsampling)
+    return buf.getvalue()
+
+
+def test_pipeline_device_entropy_decoder_streams_without_restart_markers():
+    """Ordinary baseline files (no DRI) entropy-decoded on the GPU by the self-synchronising chunk decoder — every sequential
+    file of the reference's corpora in one call, encoder-written streams of several geometries (single chunk ... thousands
+    of chunks), damaged streams the device must hand back or decode exactly like the host: results equal the oracle's."""
+    pytest.importorskip("PIL")
+    names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
+    files = [open(n, "rb").read() for n in names]
+    p = J.Pipeline(threads=8)
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    t = p.timings()
+    assert t["images_device_entropy"] >= 12, t  # the plain sequential files did go to the device ...
+    assert t["images_device_rejected"] <= 4, t  # ... and (nearly) all stayed there
+    names, files = [], []
+    for (w, h, sub, gray) in [(64, 48, "4:2:0", False), (250, 130, "4:2:0", False), (129, 257, "4:2:2", False), (200, 120, "4:4:4", False),
+                              (300, 200, "4:4:4", True), (1920, 1080, "4:2:0", False), (1, 1, "4:2:0", False), (17, 3000, "4:4:4", False),
+                              (2048, 16, "4:2:0", False), (1000, 1000, "4:4:4", True)]:
+        names.append(f"pil-{w}x{h}-{sub}{'-gray' if gray else ''}")
+        files.append(_pil_plain(w, h, sub, gray))
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    t = p.timings()
+    assert t["images_device_entropy"] == len(files) and t["images_device_rejected"] == 0, t
+    rng = np.random.default_rng(5)
+    base = files[1]
+    sos = base.rfind(b"\xff\xda")
+    names, files = [], []
+    for k in range(24):  # damaged entropy data: bit flips, dropped bytes, inserted markers, truncation
+        d = bytearray(base)
+        pos = int(rng.integers(sos + 14, len(d) - 2))
+        if k % 4 == 0:
+            d[pos] ^= 1 << int(rng.integers(0, 8))
+        elif k % 4 == 1:
+            del d[pos]
+        elif k % 4 == 2:
+            d[pos] = 0xFF
+        else:
+            del d[pos:]
+        names.append(f"damaged-{k}")
+        files.append(bytes(d))
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    # same-geometry plain streams: fused kernels after the chunk decoder, several sub-batches worth of chunks
+    same = [_pil_plain(640, 480, "4:2:0", seed=s) for s in range(20)]
+    out = p.decode(same, device_entropy=True)
+    assert p.kernel_path == "fused420"
+    _check([f"same-{i}" for i in range(20)], same, out)
+    t = p.timings()
+    assert t["images_device_entropy"] == 20 and t["images_device_rejected"] == 0, t
+    p.close()

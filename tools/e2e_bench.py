@@ -74,7 +74,8 @@ def main():
         "sustained_images_per_s_pixels_left_in_hbm": round(sustained, 1),
         "ms": {k: round(v, 2) for k, v in best.items() if k.endswith("_ms")},
         "jpeg_MB": round(best["jpeg_bytes"] / 1e6, 1), "coefficient_MB": round(best["coefficient_bytes"] / 1e6, 1),
-        "pixel_MB": round(best["pixel_bytes"] / 1e6, 1)}))
+        "pixel_MB": round(best["pixel_bytes"] / 1e6, 1),
+        "device_entropy_images": best["images_device_entropy"], "device_entropy_rejected": best["images_device_rejected"]}))
 
 
 if __name__ == "__main__":
