@@ -166,6 +166,11 @@ int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane);
  * no device needed) — for feeders that stage coefficients themselves (jpgpu_pipeline_*, jpgpu_decoder.h). */
 int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, int range_class);
 int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t quantization_table[64]);
+/* The same classification done ON THE DEVICE for every image of the batch, from the coefficients as they stand in the
+ * arena (written there by the caller's own kernels or copies into a bound arena, or by the device entropy decoder):
+ * one pass over the arena at HBM speed on `hip_stream`, blocking; afterwards every component has the range class
+ * jpgpu_batch_upload would have given it. If `classes` is not NULL it receives 4 entries per image. */
+int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes);
 /* Replace the quantization table given in the image descriptor (RowData.quantization_table of Worker::start,
  * src/worker/mod.rs:18-22): feeders learn it only while parsing the stream. Takes effect at the next decode. */
 int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t quantization_table[64]);

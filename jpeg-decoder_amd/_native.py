@@ -108,6 +108,7 @@ _PROTOS = {
     "jpgpu_batch_upload": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
     "jpgpu_batch_set_range_hint": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
     "jpgpu_batch_set_range_class": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "jpgpu_batch_scan_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jpgpu_range_class": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_batch_set_quantization_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "jpgpu_compact_max_bytes": (C.c_size_t, [C.c_size_t]),

@@ -95,6 +95,12 @@ class Batch:
         """0 unknown/hostile, 1 every |c*q| < 2^15, 3 additionally every block-column sum of |c*q| <= 5900."""
         self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, int(range_class)))
 
+    def scan_ranges(self, stream=None):
+        """Range classes from the coefficients as they stand in the device arena (one pass at HBM speed): [image][comp]."""
+        out = np.zeros((self.n_images, 4), np.uint8)
+        self._check(N.lib().jpgpu_batch_scan_ranges(self._h, stream, out.ctypes.data))
+        return out
+
     def decode(self, stream=None):
         self._check(N.lib().jpgpu_batch_decode(self._h, stream))
 

@@ -304,6 +304,53 @@ int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, i
     return JPGPU_OK;
 }
 
+int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    hipStream_t s = (hipStream_t)hip_stream;
+    std::vector<RangeJob> jobs;
+    uint32_t max_blocks = 0;
+    for (size_t i = 0; i < b->descs.size(); i++)
+        for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
+            RangeJob r;
+            r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
+            r.n_blocks = (uint32_t)(b->coef_len[i * 4 + c] / 128);
+            r.slot = (uint32_t)(i * 4 + c);
+            memcpy(r.q, b->descs[i].quantization_tables[c], 128);
+            max_blocks = std::max(max_blocks, r.n_blocks);
+            jobs.push_back(r);
+        }
+    const size_t stats_bytes = b->descs.size() * 4 * 2 * sizeof(uint32_t), jobs_bytes = jobs.size() * sizeof(RangeJob);
+    uint8_t *d = nullptr;
+    B_HIP(hipMalloc((void **)&d, align_up(stats_bytes, 256) + jobs_bytes));
+    std::vector<uint32_t> stats(b->descs.size() * 8, 0);
+    hipError_t e = hipMemsetAsync(d, 0, stats_bytes, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + align_up(stats_bytes, 256), jobs.data(), jobs_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = launch_range_scan(reinterpret_cast<const RangeJob *>(d + align_up(stats_bytes, 256)), (uint32_t)jobs.size(), max_blocks,
+                              reinterpret_cast<uint32_t *>(d), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats.data(), d, stats_bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "scan_ranges: %s", hipGetErrorString(e));
+    for (size_t i = 0; i < b->descs.size(); i++)
+        for (uint32_t c = 0; c < 4; c++) {
+            uint8_t cls = 0;
+            if (c < b->descs[i].ncomp) {
+                const uint32_t max_abs = stats[(i * 4 + c) * 2], max_col = stats[(i * 4 + c) * 2 + 1];
+                cls = max_abs < (1u << 15) ? (max_col <= 5900u ? 3 : 1) : 0;
+                if (b->sane[i * 4 + c] != cls) {
+                    b->sane[i * 4 + c] = cls;
+                    b->jobs_dirty = true;
+                }
+            }
+            if (classes) classes[i * 4 + c] = cls;
+        }
+    return JPGPU_OK;
+}
+
 int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t q[64]) {
     if (!b || !q || image >= b->descs.size() || comp >= b->descs[image].ncomp) return JPGPU_ERR_FORMAT;
     memcpy(b->descs[image].quantization_tables[comp], q, 128);
@@ -404,6 +451,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     if (rc) return rc;
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
     hipStream_t s = (hipStream_t)hip_stream;
+    static const uint32_t sync_blocks = env_u32("JPGPU_SYNC_BLOCKS", 48, 4, 1024);  // tuning knob: blocks per chunk aimed at
     size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, n_range = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
@@ -421,8 +469,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 n_sync_jobs++;
                 uint32_t blocks = 0;
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
-                const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu);
-                scratch_bytes += align_up((size_t)huff_sync_chunks((uint32_t)stuffed, shift) * 5 * 4, 16);
+                const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks);
+                scratch_bytes += align_up((size_t)huff_sync_chunks((uint32_t)stuffed, shift) * 7 * 4, 16);
             } else {
                 n_seg_jobs++;
             }
@@ -508,7 +556,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 memcpy(sj->comp, comp, sizeof(comp));
                 sj->ncomp = ps.ncomp;
                 huff_sync_finish_job(*sj);
-                sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu);
+                sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks);
                 const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
                 uint32_t *st = reinterpret_cast<uint32_t *>(d + xcur);
                 sj->data = d + dcur;
@@ -520,10 +568,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->out_pos = st + 2 * (size_t)chunks;
                 sj->out_qk = st + 3 * (size_t)chunks;
                 sj->n_blocks = st + 4 * (size_t)chunks;
+                sj->dc_sum = st + 5 * (size_t)chunks;
                 sj->cols = ps.cols;
                 sj->n_mcu = ps.n_mcu;
                 max_chunks = std::max(max_chunks, chunks);
-                xcur += align_up((size_t)chunks * 5 * 4, 16);
+                xcur += align_up((size_t)chunks * 7 * 4, 16);
                 si++;
             } else {
                 HuffScanJob &j = jobs[ji++];

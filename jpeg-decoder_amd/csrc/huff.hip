@@ -1,6 +1,7 @@
 // huff.hip — device entropy decoding of restart-marker streams (huff_core.hpp) and the range scan that classifies the
 // coefficients it produced (the host never sees them).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "huff.hpp"
 #include "huff_core.hpp"
@@ -31,29 +32,51 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffScanJob *__
     huff_decode_segment(*(JP_LDS HuffLds *)&L, seg);
 }
 
-// one lane per block: max |c*q| and the largest block-column sum of |c*q| (the two quantities behind the range classes of
-// include/jpgpu.h), reduced per wave and merged with atomicMax
+// max |c*q| and the largest block-column sum of |c*q| per plane (the two quantities behind the range classes of
+// include/jpgpu.h).  Eight lanes per block, one 16-byte row each: a wave reads 1 KB of consecutive coefficients per load
+// (one lane per block — every lane on its own cache line — ran at 1.2 TB/s).  The column sums are folded across the
+// eight lanes by halving (4 + 2 + 1 exchanges), the maxima per wave, then atomicMax.
 __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restrict__ jobs, uint32_t *__restrict__ stats) {
     const RangeJob &job = jobs[blockIdx.y];
-    const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
-    uint32_t max_abs = 0, max_col = 0;
-    if (blk < job.n_blocks) {
-        const JP_GLOBAL v4u *p = (const JP_GLOBAL v4u *)(job.coefs + (size_t)blk * 64u);
-        uint32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t row = threadIdx.x & 7u, first = blockIdx.x * 256u;
+    if (first >= job.n_blocks) return;
+    uint32_t q[8];
+    {
+        const v4u qv = ((const JP_GLOBAL v4u *)job.q)[row];
+        const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-        for (uint32_t r = 0; r < 8; r++) {
-            const v4u v = p[r];
+        for (uint32_t k = 0; k < 8; k++) q[k] = (w[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
+    }
+    uint32_t max_abs = 0, max_col = 0;
+    const uint32_t last = min(first + 256u, job.n_blocks);
+    for (uint32_t blk = first + (threadIdx.x >> 3); blk < first + 256u; blk += 32u) {  // (uniform trip count: shuffles inside)
+        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (blk < last) {
+            const v4u v = stream_load((const JP_GLOBAL v4u *)(job.coefs + (size_t)blk * 64u) + row);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
                 const int32_t c = (int16_t)(uint16_t)(w[k >> 1] >> (16u * (k & 1u)));
-                const uint32_t a = (uint32_t)(c < 0 ? -c : c) * (uint32_t)job.q[r * 8u + k];  // <= 32768 * 65535 < 2^31
-                max_abs = a > max_abs ? a : max_abs;
-                col[k] += a < 0x00ffffffu ? a : 0x00ffffffu;  // saturate the addends: 8 of them cannot wrap
+                const uint32_t p = (uint32_t)(c < 0 ? -c : c) * q[k];  // <= 32768 * 65535 < 2^31
+                max_abs = p > max_abs ? p : max_abs;
+                a[k] = p < 0x00ffffffu ? p : 0x00ffffffu;               // saturate the addends: 8 of them cannot wrap
             }
         }
+        // rows -> column sums: after the three steps lane `row` holds the sum of column (row bit-reversed... any one column)
+        uint32_t b4[4], b2[2];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) max_col = col[k] > max_col ? col[k] : max_col;
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t keep = (row & 4u) ? a[k + 4u] : a[k], give = (row & 4u) ? a[k] : a[k + 4u];
+            b4[k] = keep + (uint32_t)__shfl_xor((int)give, 4);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t keep = (row & 2u) ? b4[k + 2u] : b4[k], give = (row & 2u) ? b4[k] : b4[k + 2u];
+            b2[k] = keep + (uint32_t)__shfl_xor((int)give, 2);
+        }
+        const uint32_t keep = (row & 1u) ? b2[1] : b2[0], give = (row & 1u) ? b2[0] : b2[1];
+        const uint32_t col = keep + (uint32_t)__shfl_xor((int)give, 1);
+        max_col = col > max_col ? col : max_col;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -66,12 +89,11 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restr
     }
 }
 
-
 // ---- scans without restart markers: the self-synchronising chunk decoder (huff_sync_core.hpp) -------------------------
 // grid = (ceil(max chunks / 256), sync jobs); lane = chunk.  `changed` of a job holds three counters used in rotation by
 // consecutive launches: launch t counts into slot t % 3, reads slot (t-1) % 3 (zero: the job has settled, nothing to do)
 // and clears slot (t+1) % 3, so the host can enqueue a fixed number of launches without looking at the device in between.
-constexpr uint32_t SYNC_NT = 256;
+constexpr uint32_t SYNC_NT = HUFF_SYNC_LANES;
 
 __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffSyncJob *gj) {
     {
@@ -86,6 +108,9 @@ __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffS
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)L.tables;
         for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuffTable) / 4u; i += SYNC_NT) dst[i] = src[i];
     }
+    __syncthreads();
+    huff_sync_fill_lds(L, threadIdx.x);
+    if (SYNC_NT < 512u) huff_sync_fill_lds(L, threadIdx.x + SYNC_NT);
     __syncthreads();
 }
 
@@ -151,6 +176,44 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
         carry += total;
         __syncthreads();
     }
+    if (job.uniform) return;
+    // sums of DC differences per chunk and component -> the predictors every chunk starts from (mod 2^16)
+    uint32_t dcarry[4] = {0, 0, 0, 0};
+    for (uint32_t base = 0; base < job.n_chunks; base += SYNC_NT) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t w0 = 0, w1 = 0;
+        if (i < job.n_chunks) {
+            w0 = job.dc_sum[2u * i];
+            w1 = job.dc_sum[2u * i + 1u];
+        }
+        const uint32_t v4[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+        uint32_t excl[4];
+#pragma unroll
+        for (uint32_t f = 0; f < 4; f++) {
+            uint32_t incl = v4[f];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                if ((threadIdx.x & 63u) >= (uint32_t)off) incl += o;
+            }
+            if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < SYNC_NT / 64u; w++) {
+                const uint32_t t = wave_tot[w];
+                before += w < (threadIdx.x >> 6) ? t : 0u;
+                total += t;
+            }
+            excl[f] = (dcarry[f] + before + incl - v4[f]) & 0xffffu;
+            dcarry[f] += total;
+            __syncthreads();
+        }
+        if (i < job.n_chunks) {
+            job.dc_sum[2u * i] = excl[0] | (excl[1] << 16);
+            job.dc_sum[2u * i + 1u] = excl[2] | (excl[3] << 16);
+        }
+    }
 }
 
 __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSyncJob *__restrict__ jobs) {
@@ -164,34 +227,47 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSync
 }
 
 // DC differences -> DC values: a running sum (i16 wrapping, src/decoder.rs:1095-1099) per component over its blocks in
-// the order the stream has them.  grid = (4, sync jobs), four consecutive blocks per lane and tile.
-__global__ __launch_bounds__(SYNC_NT) void huff_dc_prefix_kernel(const HuffSyncJob *__restrict__ jobs) {
-    __shared__ uint32_t wave_tot[SYNC_NT / 64u];
+// the order the stream has them.  grid = (4, sync jobs), one workgroup per component plane walking it in tiles; the walk
+// is a chain of load -> scan -> store round trips, so the tile is as large as a workgroup gets (1,024 lanes x 8 blocks:
+// 4 tiles for the luma plane of a 1080p image instead of 32 with 256 x 4 — 0.77 ms -> see profiles/).
+constexpr uint32_t DC_NT = 1024, DC_E = 8;
+
+__global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob *__restrict__ jobs) {
+    __shared__ uint32_t wave_tot[DC_NT / 64u];
     const HuffSyncJob &job = jobs[blockIdx.y];
     const uint32_t c = blockIdx.x;
-    if (c >= job.ncomp || *job.status != 0u) return;
+    if (c >= job.ncomp || *job.status != 0u || !job.uniform) return;  // (other scans: the write pass stored DC values)
     const HuffScanComp sc = job.comp[c];
     const uint32_t hv = sc.h * sc.v, n = job.n_mcu * hv, cols = job.cols;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += SYNC_NT * 4u) {
-        const uint32_t s0 = base + threadIdx.x * 4u;
-        JP_GLOBAL int16_t *addr[4];
-        uint32_t d[4];
+    for (uint32_t base = 0; base < n; base += DC_NT * DC_E) {
+        const uint32_t s0 = base + threadIdx.x * DC_E;
+        JP_GLOBAL int16_t *addr[DC_E];
+        uint32_t d[DC_E];
+        {
+            // the first element by division, the rest by stepping through the MCU
+            uint32_t m = s0 / hv, sub = s0 - m * hv, my = m / cols, mx = m - my * cols;
 #pragma unroll
-        for (uint32_t e = 0; e < 4; e++) {
-            const uint32_t s = s0 + e;
-            d[e] = 0;
-            addr[e] = nullptr;
-            if (s < n) {
-                const uint32_t m = s / hv, sub = s - m * hv, my = m / cols, mx = m - my * cols, vp = sub / sc.h, hp = sub - vp * sc.h;
-                addr[e] = (JP_GLOBAL int16_t *)(sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u);
-                d[e] = (uint16_t)*addr[e];
+            for (uint32_t e = 0; e < DC_E; e++) {
+                d[e] = 0;
+                addr[e] = nullptr;
+                if (s0 + e < n) {
+                    const uint32_t vp = sub / sc.h, hp = sub - vp * sc.h;
+                    addr[e] = (JP_GLOBAL int16_t *)(sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u);
+                    d[e] = (uint16_t)*addr[e];
+                }
+                if (++sub == hv) {
+                    sub = 0;
+                    if (++mx == cols) {
+                        mx = 0;
+                        my++;
+                    }
+                }
             }
         }
-        d[1] += d[0];
-        d[2] += d[1];
-        d[3] += d[2];
-        uint32_t incl = d[3];
+#pragma unroll
+        for (uint32_t e = 1; e < DC_E; e++) d[e] += d[e - 1u];
+        uint32_t incl = d[DC_E - 1u];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
@@ -201,14 +277,14 @@ __global__ __launch_bounds__(SYNC_NT) void huff_dc_prefix_kernel(const HuffSyncJ
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < SYNC_NT / 64u; w++) {
+        for (uint32_t w = 0; w < DC_NT / 64u; w++) {
             const uint32_t t = wave_tot[w];
             before += w < (threadIdx.x >> 6) ? t : 0u;
             total += t;
         }
-        const uint32_t off = carry + before + incl - d[3];
+        const uint32_t off = carry + before + incl - d[DC_E - 1u];
 #pragma unroll
-        for (uint32_t e = 0; e < 4; e++)
+        for (uint32_t e = 0; e < DC_E; e++)
             if (addr[e]) *addr[e] = (int16_t)(uint16_t)(d[e] + off);
         carry += total;
         __syncthreads();
@@ -235,7 +311,7 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     for (uint32_t l = 0; l < launches; l++) huff_sync_pass_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);
     huff_sync_write_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs);
-    huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs);
+    huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(DC_NT), 0, stream>>>(d_jobs);
     return hipGetLastError();
 }
 

@@ -90,23 +90,31 @@ __device__ __forceinline__ void huff_store_shared(uint32_t *p, uint32_t v) {
 #endif
 }
 
-// The slow tail of src/huffman.rs:31-58 for prefixes the wide table does not resolve: the maxcode walk from length 9.
+// The slow tail of src/huffman.rs:31-58 for prefixes the wide table does not resolve: the maxcode walk from length 9 —
+// first length whose code does not exceed that length's largest code.  All eight comparisons at once (two 16-byte LDS
+// reads) and a find-first-set instead of a loop: with 64 lanes per wave some lane nearly always needs the tail, and as a
+// loop it cost every lane up to eight dependent LDS round trips per symbol.
 __device__ __forceinline__ uint32_t huff_walk(DevBits &b, const JP_LDS DevHuffTable &t) {
     const uint32_t b16 = huff_peek(b, 16);
-    for (int i = 8; i < 16; i++) {
-        const int32_t code = (int32_t)(b16 >> (15 - i));
-        if (code <= t.maxcode[i]) {
-            huff_consume(b, (uint32_t)i + 1u);
-            const int32_t index = code + t.delta[i];
-            if (index < 0 || index >= t.nvalues) {
-                b.bad = true;
-                return 0u;
-            }
-            return t.values[index];
-        }
+    const JP_LDS v4u *mc = (const JP_LDS v4u *)&t.maxcode[8];
+    const v4u m0 = mc[0], m1 = mc[1];
+    const int32_t m[8] = {(int32_t)m0.x, (int32_t)m0.y, (int32_t)m0.z, (int32_t)m0.w, (int32_t)m1.x, (int32_t)m1.y, (int32_t)m1.z, (int32_t)m1.w};
+    uint32_t hits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) hits |= ((int32_t)(b16 >> (7 - j)) <= m[j] ? 1u : 0u) << j;
+    if (hits == 0u) {
+        b.bad = true;
+        return 0u;
     }
-    b.bad = true;
-    return 0u;
+    const uint32_t i = 8u + (uint32_t)__builtin_ctz(hits);
+    const int32_t code = (int32_t)(b16 >> (15u - i));
+    huff_consume(b, i + 1u);
+    const int32_t index = code + t.delta[i];
+    if (index < 0 || index >= t.nvalues) {
+        b.bad = true;
+        return 0u;
+    }
+    return t.values[index];
 }
 
 // What a workgroup keeps in LDS: the scan's job record and tables and the zig-zag table.

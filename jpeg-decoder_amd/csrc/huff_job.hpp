@@ -2,17 +2,19 @@
 // fills them (csrc/host/frontend.cpp, plan_device_scans).
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 namespace jpgpu {
 
 constexpr int HUFF_LUT_BITS = 10;  // == kLutBits of the host front-end
 
-struct DevHuffTable {
+struct alignas(16) DevHuffTable {  // (maxcode[8..15] are read as two 16-byte words)
     uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: symbol | code length << 8 (length 0: not resolved within the lookahead)
     int32_t maxcode[16], delta[16];
     uint8_t values[256];
     int32_t nvalues;
 };
+static_assert(sizeof(DevHuffTable) % 16 == 0 && (sizeof(uint16_t) << HUFF_LUT_BITS) % 16 == 0, "16-byte reads of maxcode");
 
 struct HuffScanComp {
     int16_t *dst;       // the component's coefficient plane in the arena (zero-filled before the launch)
@@ -37,14 +39,18 @@ struct HuffScanJob {            // one scan of one image
 // and treats what follows a segment as zero bits).  Returns the unstuffed length.  Slot size: huff_slot_bytes(n).
 inline uint32_t huff_slot_bytes(uint32_t stuffed_bytes) { return ((stuffed_bytes + 15u) & ~15u) + 32u; }
 inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n) {
-    uint32_t o = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint8_t v = src[i];
-        dst[o++] = v;
-        if (v == 0xFF && i + 1 < n && src[i + 1] == 0) i++;
+    // runs between 0xFF bytes (one per ~256 bytes of entropy-coded data) go through memcpy: ~5x a byte loop
+    uint32_t o = 0, i = 0;
+    while (i < n) {
+        const uint8_t *ff = static_cast<const uint8_t *>(memchr(src + i, 0xFF, n - i));
+        const uint32_t run = ff ? (uint32_t)(ff - (src + i)) + 1u : n - i;  // up to and including the 0xFF
+        memcpy(dst + o, src + i, run);
+        o += run;
+        i += run;
+        if (ff && i < n && src[i] == 0) i++;  // its stuffing zero
     }
     const uint32_t slot = huff_slot_bytes(n);
-    for (uint32_t z = o; z < slot; z++) dst[z] = 0;
+    memset(dst + o, 0, slot - o);
     return o;
 }
 
@@ -54,11 +60,14 @@ struct HuffSyncJob {             // one scan of one image (exactly one "segment"
     const uint8_t *data;         // staged scan: unstuffed, 16-byte aligned, zero padded
     const DevHuffTable *tables;  // 8 tables of this scan
     uint32_t *status;            // the image's status word (bit 0: decode on the host instead)
-    uint32_t *changed;           // per job: lanes that published a new state in the current pass
+    uint32_t *changed;           // per job: 3 counters of published states, used in rotation by consecutive launches (huff.hip)
     // per chunk (n_chunks entries each)
     uint32_t *in_pos, *in_qk;    // start state last decoded from          (qk = block-within-MCU << 8 | coefficient index)
     uint32_t *out_pos, *out_qk;  // published end state
     uint32_t *n_blocks;          // blocks completed by the chunk; after the scan: number of its first block
+    uint32_t *dc_sum;            // 2 words per chunk: the sums of its DC differences per component, 16 bits each (component 0 in the
+                                 // low half of word 0); after the scan: the DC predictors its first block starts from.  Unused
+                                 // when `uniform` (which component a block belongs to is unknown until the blocks are numbered)
     uint32_t n_bits, n_chunks;
     uint32_t cols, n_mcu;        // MCUs per row / in the scan
     uint32_t ncomp, bpm;         // components, blocks per MCU
@@ -74,8 +83,8 @@ struct HuffSyncJob {             // one scan of one image (exactly one "segment"
 // so what matters is the number of BLOCKS in a chunk: ~48 of them (measured: 15 blocks per chunk settle 63 % of the lanes per
 // pass, 60 blocks 98 %), between 1,024 and 8,192 bits, from the stream's average (the stuffed length serves: an upper bound
 // taken before the staging copy).
-inline uint32_t huff_sync_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) {
-    const uint64_t target = (uint64_t)stuffed_bytes * 8u * 48u / (total_blocks ? total_blocks : 1u);
+inline uint32_t huff_sync_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks, uint32_t blocks_per_chunk = 48u) {
+    const uint64_t target = (uint64_t)stuffed_bytes * 8u * blocks_per_chunk / (total_blocks ? total_blocks : 1u);
     uint32_t shift = 10;
     while (shift < 13u && (1ull << shift) * 1414u / 1000u < target) shift++;  // nearest power of two (in the log domain)
     return shift;

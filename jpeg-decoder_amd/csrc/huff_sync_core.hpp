@@ -12,13 +12,16 @@
 //      truth, so a pass that changes nothing has reached the unique consistent — the true — segmentation.
 //   2. an exclusive scan of the blocks completed per chunk gives every chunk its first block number;
 //   3. the write pass (huff_sync_chunk<true>) decodes every chunk once more from its final start state and writes
-//      coefficients into the zero-filled arena, DC positions holding the decoded DIFFERENCE;
-//   4. a scan per component along the order the blocks have in the stream turns the differences into DC values
-//      (i16 wrapping adds, src/decoder.rs:1095-1099).
+//      coefficients into the zero-filled arena;
+//   4. DC values are running sums of differences per component (i16 wrapping adds, src/decoder.rs:1095-1099): every
+//      sync pass also leaves the chunk's sum of DC differences per component, the scan of step 2 turns them into the
+//      predictors each chunk starts from, and the write pass stores finished DC values.  (Scans whose components all share
+//      their tables — `uniform` — do not know the component of a block before step 2: their write pass stores the
+//      differences and huff_dc_prefix_kernel runs the sums afterwards, one scattered read-modify-write per block.)
 // Speculative decoding may run into impossible codes; only what the write pass sees counts: an undecodable code, an
 // EOBn run (legal only in progressive scans), data that ends before the last block — and a segmentation that has not
 // settled after the allotted passes — raise the image's status word and the host decodes that image.
-// The per-symbol step is the one of huff_core.hpp (decode_block as a select-based state machine).
+// The per-symbol step is decode_block (src/decoder.rs:1020-1107) as a table-driven state machine (huff_sym_info).
 #pragma once
 #include "huff_core.hpp"
 
@@ -26,11 +29,45 @@ namespace jpgpu {
 
 constexpr uint32_t HUFF_POS_INVALID = 0xffffffffu;  // published by a lane whose speculative decode hit an impossible code
 
+// Per symbol the decoder needs: how many magnitude bits follow, how far the coefficient index moves (DC: to 1; AC
+// coefficient: run + 1; ZRL: 16; EOB: to 64, which ends the block) and whether the symbol is a coefficient or cannot
+// occur in a sequential scan.  One 16-bit word per (class, symbol) in LDS instead of a dozen compares and selects per
+// step — the loop is bound by instruction issue (one lane = one chunk: every wave executes every path).
+constexpr uint32_t SYM_BAD = 0x8000u, SYM_COEF = 0x4000u;  // | advance << 4 | magnitude bits
+__device__ __forceinline__ uint32_t huff_sym_info(uint32_t ac, uint32_t sym) {
+    const uint32_t r = sym >> 4, sz = sym & 15u;
+    if (!ac) return sym > 11u ? SYM_BAD : ((1u << 4) | sym);          // "invalid DC difference magnitude category"
+    if (sz) return SYM_COEF | ((r + 1u) << 4) | sz;
+    if (r == 15u) return 16u << 4;                                     // ZRL
+    return r == 0u ? (64u << 4) : SYM_BAD;                             // EOB; an EOBn run is for the host
+}
+
 struct HuffSyncLds {
     DevHuffTable tables[8];
     HuffSyncJob job;
+    uint16_t sym_info[2][256];  // [DC | AC][symbol]
+    uint32_t q_tables[16];      // block-within-MCU -> byte offset of its DC table in `tables` | its AC table << 16
+    struct alignas(16) Dst {    // block-within-MCU -> where its coefficients go: base + my * row_stride + mx * mcu_stride (bytes)
+        uint64_t base;
+        uint32_t row_stride, mcu_stride;
+    } q_dst[16];
+    uint32_t dc[256][4];        // per lane and component: sum of DC differences (sync passes) / DC predictor (write pass)
     uint8_t unzig[64];
 };
+constexpr uint32_t HUFF_SYNC_LANES = 256;  // lanes per workgroup (dc[] slots)
+// after job and tables are in place; every lane of the workgroup calls it (lane < 512 does something), then a barrier
+__device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32_t lane) {
+    if (lane < 512u) L.sym_info[lane >> 8][lane & 255u] = (uint16_t)huff_sym_info(lane >> 8, lane & 255u);
+    if (lane < 16u) {
+        const uint32_t c = L.job.q_comp[lane < L.job.bpm ? lane : 0u];
+        L.q_tables[lane] = (uint32_t)(L.job.comp[c].dc * sizeof(DevHuffTable)) | ((uint32_t)((4u + L.job.comp[c].ac) * sizeof(DevHuffTable)) << 16);
+        const JP_LDS HuffScanComp &sc = L.job.comp[c];
+        const uint32_t sub = L.job.q_sub[lane < L.job.bpm ? lane : 0u], h = sc.h ? sc.h : 1u, vp = sub / h, hp = sub - vp * h;
+        L.q_dst[lane].base = (uint64_t)(uintptr_t)sc.dst + ((uint64_t)vp * sc.block_w + hp) * 128u;
+        L.q_dst[lane].row_stride = sc.v * sc.block_w * 128u;
+        L.q_dst[lane].mcu_stride = sc.h * 128u;
+    }
+}
 
 __device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos) {
     b.g = reinterpret_cast<const v4u *>(slot);
@@ -93,75 +130,83 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     uint32_t blkno = WRITE ? job.n_blocks[i] : 0u;  // number of the block being decoded (write pass)
     if (WRITE) q = blkno % job.bpm;                 // (what the settled state says anyway; the only source when `uniform`)
     bool bad = false;
+    const bool dc_sums = !job.uniform;
+    JP_LDS uint32_t *dc = L.dc[i % HUFF_SYNC_LANES];
+    if (dc_sums) {
+        uint32_t w0 = 0, w1 = 0;
+        if (WRITE) {
+            w0 = job.dc_sum[2u * i];
+            w1 = job.dc_sum[2u * i + 1u];
+        }
+        dc[0] = w0 & 0xffffu;
+        dc[1] = w0 >> 16;
+        dc[2] = w1 & 0xffffu;
+        dc[3] = w1 >> 16;
+    }
     if (pos < limit) {
         DevBits b;
         huff_open_at(b, job.data, pos);
-        // fields of the component of block q
-        uint32_t c = job.q_comp[q];
-        uint32_t c_dc = job.comp[c].dc, c_ac = 4u + job.comp[c].ac;
+        uint32_t c = job.q_comp[q];  // component of block q
+        const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
+        uint32_t qt = L.q_tables[q];  // table offsets of block q
         JP_GLOBAL int16_t *blk = nullptr;
-        auto locate = [&]() {  // arena address of block `blkno` (write pass)
-            const uint32_t m = blkno / job.bpm, my = m / job.cols, mx = m - my * job.cols;
-            const JP_LDS HuffScanComp &sc = job.comp[c];
-            const uint32_t sub = job.q_sub[q], vp = sub / sc.h, hp = sub - vp * sc.h;
-            blk = (JP_GLOBAL int16_t *)(sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u);
+        uint32_t mx = 0, my = 0;  // the MCU of block `blkno` (write pass), kept by counting: no divisions per block
+        if (WRITE) {
+            const uint32_t m = blkno / job.bpm;
+            my = m / job.cols;
+            mx = m - my * job.cols;
+        }
+        auto locate = [&]() {  // arena address of block `blkno` = block q of MCU (mx, my)
+            const uint64_t base = L.q_dst[q].base;
+            blk = (JP_GLOBAL int16_t *)(uintptr_t)(base + (uint64_t)my * L.q_dst[q].row_stride + mx * L.q_dst[q].mcu_stride);
         };
         if (WRITE && blkno < total_blocks) locate();
-        while (huff_bit_pos(b) < limit && !(WRITE && blkno >= total_blocks)) {
+        while (!bad && huff_bit_pos(b) < limit && !(WRITE && blkno >= total_blocks)) {
             huff_refill(b);
-            const bool is_dc = k == 0u;
-            const JP_LDS DevHuffTable &t = L.tables[is_dc ? c_dc : c_ac];
+            const uint32_t ac = k != 0u ? 1u : 0u;
+            const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
             const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> 8;
             uint32_t sym = e & 0xffu;
             if (csz) {
                 huff_consume(b, csz);
             } else {
                 sym = huff_walk(b, t);
-                if (b.bad) {
-                    bad = true;
-                    break;
-                }
+                bad = b.bad;
             }
-            const uint32_t r = sym >> 4, sz = sym & 15u;
-            if (is_dc && sym > 11u) {
-                bad = true;
-                break;
-            }
-            const bool is_coef = !is_dc && sz != 0u, is_zrl = !is_dc && sz == 0u && r == 15u, is_eob = !is_dc && sz == 0u && r != 15u;
-            const uint32_t knew = is_dc ? 0u : k + (is_zrl ? 16u : (is_coef ? r : 0u));
-            const bool over = is_coef && knew >= 64u;
-            const bool fused = csz > 0u && csz <= 8u && csz + sz <= 8u;
-            const uint32_t nread = is_dc ? sym : (is_coef ? ((!over || fused) ? sz : 0u) : (is_eob ? r : 0u));
+            const uint32_t info = L.sym_info[ac][sym], nread = info & 15u;
             const uint32_t raw = huff_peek(b, nread);
             huff_consume(b, nread);
-            if (is_eob && r != 0u) {  // an end-of-band RUN: the blocks it covers are not in this chunk's state — host
-                bad = true;
-                break;
-            }
-            if (WRITE) {
-                const int32_t val = huff_extend(raw, nread);
-                if (is_dc) {
-                    if (val) blk[0] = (int16_t)val;  // the difference; pass 4 accumulates
-                } else if (is_coef && !over) {
-                    blk[L.unzig[knew]] = (int16_t)val;
+            const uint32_t k0 = k;
+            k += (info >> 4) & 127u;
+            // a coefficient beyond index 63: the reference breaks out of the block in a way that depends on its own table
+            // layout (src/decoder.rs:1045-1075) — only broken streams have it, the host decides
+            bad = bad || (info & SYM_BAD) != 0u || ((info & SYM_COEF) != 0u && k > 64u);
+            if (!bad) {
+                if (k0 == 0u) {
+                    int32_t val = huff_extend(raw, nread);
+                    if (dc_sums) {  // sync pass: sum of differences; write pass: the predictor -> the DC value
+                        dc[c] += (uint32_t)val;
+                        val = (int16_t)(uint16_t)dc[c];
+                    }
+                    if (WRITE && val) blk[0] = (int16_t)val;  // (uniform scans: the difference; huff_dc_prefix_kernel sums up)
+                } else if (WRITE && (info & SYM_COEF)) {
+                    blk[L.unzig[k - 1u]] = (int16_t)huff_extend(raw, nread);
                 }
             }
-            bool done;
-            if (is_dc) {
-                done = false;
-                k = 1u;
-            } else {
-                k = is_coef ? knew + 1u : knew;
-                done = is_eob || over || k >= 64u;
-            }
-            if (done) {
+            if (k >= 64u && !bad) {  // end of the block
                 k = 0u;
                 nblk++;
                 q++;
-                if (q == job.bpm) q = 0u;
+                if (q == job.bpm) {
+                    q = 0u;
+                    mx++;
+                    if (mx == job.cols) {
+                        mx = 0u;
+                        my++;
+                    }
+                }
+                qt = L.q_tables[q];
                 c = job.q_comp[q];
-                c_dc = job.comp[c].dc;
-                c_ac = 4u + job.comp[c].ac;
                 if (WRITE) {
                     blkno++;
                     if (blkno < total_blocks) locate();
@@ -169,6 +214,10 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
             }
         }
         pos = huff_bit_pos(b);
+    }
+    if (!WRITE && dc_sums) {
+        job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);
+        job.dc_sum[2u * i + 1u] = (dc[2] & 0xffffu) | (dc[3] << 16);
     }
     if (!WRITE) {
         const uint32_t np = bad ? HUFF_POS_INVALID : pos, nqk = bad ? 0u : (((job.uniform ? 0u : q) << 8) | k);

@@ -437,7 +437,14 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     }
     std::vector<uint32_t> bounds{0u};  // sub-batch j = ok[bounds[j] .. bounds[j+1])
     {
-        const uint32_t dev_subs = n_dev ? std::min<uint32_t>(kMaxSubBatches / 2u, (n_dev + 16u * kSubBatchImages - 1u) / (16u * kSubBatchImages)) : 0u;
+        // streams with restart markers: one lane per restart segment, ~1,000 images fill the machine; without: one lane
+        // per chunk of the scan, 256 images do, and smaller sub-batches let staging, upload and kernels of neighbours overlap
+        static const long dev_sub_env = getenv("JPGPU_PIPE_DEV_SUB") ? atol(getenv("JPGPU_PIPE_DEV_SUB")) : 0;  // tuning knob
+        uint32_t n_chunked = 0;
+        for (uint32_t k = 0; k < n_dev; k++)
+            if (!p->plans[ok[k]].empty() && p->plans[ok[k]][0].ri == 0) n_chunked++;
+        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_chunked * 2u >= n_dev ? 4u : 16u) * kSubBatchImages;
+        const uint32_t dev_subs = n_dev ? std::min<uint32_t>(kMaxSubBatches / 2u, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;
         for (uint32_t j = 1; j <= dev_subs; j++) bounds.push_back((uint32_t)((uint64_t)n_dev * j / dev_subs));
         const uint32_t n_host = (uint32_t)ok.size() - n_dev;
         const uint32_t host_subs = n_host ? std::min<uint32_t>(kMaxSubBatches - dev_subs, (n_host + kSubBatchImages - 1u) / kSubBatchImages) : 0u;

@@ -91,12 +91,13 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             huff_sync_finish_job(sj);
             sj.chunk_shift = huff_sync_chunk_shift(ps.seg_off[1] - ps.seg_off[0], sj.bpm * ps.n_mcu);
             sj.n_chunks = huff_sync_chunks(table[1], sj.chunk_shift);
-            std::vector<uint32_t> arr(5 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
+            std::vector<uint32_t> arr(7 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
             sj.in_pos = arr.data();
             sj.in_qk = arr.data() + sj.n_chunks;
             sj.out_pos = arr.data() + 2 * (size_t)sj.n_chunks;
             sj.out_qk = arr.data() + 3 * (size_t)sj.n_chunks;
             sj.n_blocks = arr.data() + 4 * (size_t)sj.n_chunks;
+            sj.dc_sum = arr.data() + 5 * (size_t)sj.n_chunks;
             if (g_sync_stale)  // what a previous batch of similar streams leaves in the arrays: states that LOOK right
                 for (uint32_t i = 0; i < sj.n_chunks; i++) {
                     sj.out_pos[i] = ((i + 1u) << sj.chunk_shift) + (i * 7u + g_sync_stale) % 33u;
@@ -107,6 +108,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 }
             memcpy(S->tables, ps.tables, sizeof(S->tables));
             for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(S->unzig, t);
+            for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*S, t);
             // Launches as huff.hip runs them: workgroups of 256 lanes, `iters` iterations each with a barrier in between.
             // Lanes of a workgroup run concurrently (every lane sees the states its neighbours had before the iteration);
             // workgroups run one after the other here, last first — each sees its left neighbour's state of the previous
@@ -144,9 +146,19 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 sj.n_blocks[i] = run;
                 run += nb;
             }
+            if (!sj.uniform) {  // (huff_sync_scan_kernel) sums of DC differences -> predictors at the start of every chunk
+                uint32_t acc[4] = {0, 0, 0, 0};
+                for (uint32_t i = 0; i < sj.n_chunks; i++) {
+                    const uint32_t w0 = sj.dc_sum[2 * i], w1 = sj.dc_sum[2 * i + 1];
+                    const uint32_t v[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+                    sj.dc_sum[2 * i] = (acc[0] & 0xffffu) | ((acc[1] & 0xffffu) << 16);
+                    sj.dc_sum[2 * i + 1] = (acc[2] & 0xffffu) | ((acc[3] & 0xffffu) << 16);
+                    for (int f = 0; f < 4; f++) acc[f] += v[f];
+                }
+            }
             for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0);
-            // DC differences -> values, per component in stream order (i16 wrapping)
-            for (uint32_t c = 0; c < ps.ncomp; c++) {
+            // (huff_dc_prefix_kernel, uniform scans only) DC differences -> values, per component in stream order (i16 wrapping)
+            for (uint32_t c = 0; sj.uniform && c < ps.ncomp; c++) {
                 const HuffScanComp& sc = sj.comp[c];
                 const uint32_t hv = sc.h * sc.v;
                 uint16_t acc = 0;

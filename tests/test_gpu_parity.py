@@ -494,3 +494,68 @@ def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
     else:
         err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
     assert err.mean() < 6.0
+
+
+def test_batch_scan_ranges_on_device_equals_host_classification():
+    """jpgpu_batch_scan_ranges (the pass the device entropy decoder relies on: the host never sees those coefficients)
+    against jpgpu_range_class on the same planes: every class, the exact boundaries (|c*q| = 2^15 - 1 / 2^15, column sum
+    5900 / 5901), the extreme value in the first / last / a middle block of planes whose block counts are not multiples of
+    the kernel's tile, 16-bit quantization tables."""
+    import ctypes as C
+    from jpeg_decoder_amd import _native as N
+    rng = np.random.default_rng(77)
+    geoms = [(250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (8, 8, [(1, 1)], "Grayscale"), (1000, 600, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+             (300, 200, [(1, 1)], "Grayscale")]
+    cases = []
+    for gi, (w_, h_, samp, ct) in enumerate(geoms):
+        for variant in range(6):
+            oc, qts, coefs, ct_, _w, _h = _batch_case(rng, w_, h_, samp, ct, kind="sparse")
+            coefs = [np.clip(c, -20, 20) for c in coefs]  # class 3 to start with (q <= 255 in _batch_case? keep sums small)
+            qts = [np.minimum(q, 16).astype(np.uint16) for q in qts]
+            for c in range(len(coefs)):
+                plane = coefs[c].reshape(-1, 64)
+                plane[:] = np.where(rng.random(plane.shape) < 0.1, plane, 0)
+                nb = plane.shape[0]
+                where = [0, nb - 1, nb // 2, (nb * 2) // 3, 0, nb - 1][variant] if nb > 1 else 0
+                q = qts[c].reshape(64).astype(np.int64)
+                if variant == 1:    # one column sum of exactly 5900 -> class 3 still
+                    plane[where, :] = 0
+                    q[3::8] = 1
+                    plane[where, 3::8] = [737, 737, 737, 737, 738, 738, 738, 738]
+                elif variant == 2:  # 5901 -> class 1
+                    plane[where, :] = 0
+                    q[3::8] = 1
+                    plane[where, 3::8] = [737, 737, 737, 738, 738, 738, 738, 738]
+                elif variant == 3:  # |c*q| = 32767 -> class 1
+                    plane[where, :] = 0
+                    q[63] = 1
+                    plane[where, 63] = -32767
+                elif variant == 4:  # |c*q| = 32768 -> class 0
+                    plane[where, :] = 0
+                    q[9] = 2
+                    plane[where, 9] = 16384
+                elif variant == 5:  # 16-bit table entry times a small coefficient -> class 0
+                    plane[where, :] = 0
+                    q[17] = 65535
+                    plane[where, 17] = -1
+                qts[c] = q.astype(np.uint16).reshape(qts[c].shape)
+                coefs[c] = plane.reshape(coefs[c].shape).astype(np.int16)
+            cases.append((oc, qts, coefs, ct_, w_, h_))
+    descs = [J.image_desc(list(to_j(oc)), qts, w_, h_, ct) for oc, qts, _, ct, w_, h_ in cases]
+    b = J.Batch(descs)
+    want = np.zeros((len(cases), 4), np.uint8)
+    for i, (oc, qts, coefs, _ct, _w, _h) in enumerate(cases):
+        for c in range(len(oc)):
+            b.upload(i, c, coefs[c])
+            a = np.ascontiguousarray(coefs[c], np.int16).reshape(-1)
+            q = np.ascontiguousarray(qts[c], np.uint16).reshape(64)
+            want[i, c] = N.lib().jpgpu_range_class(a.ctypes.data, a.size, q.ctypes.data)
+            b._check(N.lib().jpgpu_batch_set_range_class(b._h, i, c, 0))  # forget what upload() found out
+    assert set(np.unique(want)) == {0, 1, 3}
+    got = b.scan_ranges()
+    assert np.array_equal(got, want), np.argwhere(got != want)
+    b.decode()
+    b.synchronize()
+    for i, (oc, qts, coefs, ct_, w_, h_) in enumerate(cases):
+        assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
+    b.close()
