@@ -773,6 +773,11 @@ struct Frontend::Impl {
         ps.ri = restart_interval;  // 0: no restart markers — one segment, decoded by the self-synchronising chunk decoder
         ps.ncomp = (uint32_t)nc;
         if (ps.n_mcu == 0) throw NotEligible{6};
+        {  // the chunk decoder keeps per-block-of-the-MCU tables of 16 entries (the standard allows 10 blocks per MCU)
+            uint32_t bpm = 0;
+            for (int i = 0; i < nc; i++) bpm += interleaved ? (uint32_t)comps[i].horizontal_sampling_factor * comps[i].vertical_sampling_factor : 1u;
+            if (bpm > 16u) throw NotEligible{14};
+        }
         for (int i = 0; i < nc; i++) {
             ps.comp[i].frame_index = (uint32_t)scan.component_indices[i];
             ps.comp[i].block_w = comps[i].block_width;

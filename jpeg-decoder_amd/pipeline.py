@@ -33,15 +33,14 @@ class Pipeline:
         """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
         ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``); dense=True sends all
         64 coefficients of every block over PCIe instead of the compact form (same pixels, A/B switch); device_entropy=True
-        decodes sequential Huffman streams that carry restart markers on the GPU (one lane per restart segment), all
-        other streams — and any the device decoder flags — on the host as usual."""
+        decodes 8-bit sequential Huffman streams (one scan with all components; with or without restart markers) on the
+        GPU, all other streams — and any the device decoder flags — on the host as usual."""
         L = N.lib()
         bufs = [bytes(s.read() if hasattr(s, "read") else s) for s in streams]
         n = len(bufs)
-        keep = [(C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0") for b in bufs]
-        ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(k) for k in keep])
+        ptrs = (C.c_char_p * max(n, 1))(*bufs)  # the bytes objects' own buffers (alive in `bufs` during the call): no copies
         lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
-        st = L.jpgpu_pipeline_decode(self._h, ptrs, lens, n, (N.PIPELINE_DOWNLOAD if download else 0) | (N.PIPELINE_DENSE if dense else 0) |
+        st = L.jpgpu_pipeline_decode(self._h, C.cast(ptrs, C.POINTER(C.c_void_p)), lens, n, (N.PIPELINE_DOWNLOAD if download else 0) | (N.PIPELINE_DENSE if dense else 0) |
                                      (N.PIPELINE_DEVICE_ENTROPY if device_entropy else 0))
         check(st, L.jpgpu_pipeline_last_error(self._h) if st else b"")
         out = []

@@ -87,6 +87,14 @@ def test_only_plain_sequential_streams_are_planned():
                 "reftest/progressive3.jpg"]:  # progressive (the third one with DRI)
         assert _device(open(os.path.join(R.GOLDEN, rel), "rb").read()) is None, rel
     assert _device(b"") is None and _device(b"\xff\xd8\xff\xd9") is None
+    # more blocks per MCU than the chunk decoder's per-block tables hold (4x4 + 1x1 + 1x1 = 18; the standard allows 10)
+    pytest.importorskip("PIL")
+    data = bytearray(_pil_jpeg(64, 64, "4:4:4", 0, 0))
+    sof = data.find(b"\xff\xc0")
+    assert sof > 0 and data[sof + 9] == 3
+    assert _device(bytes(data)) is not None
+    data[sof + 11] = 0x44
+    assert _device(bytes(data)) is None
 
 
 NO_RST = ["benches/tower.jpg", "benches/tower_grayscale.jpg", "reftest/rgb.jpg", "reftest/mozilla/jpg-gray.jpg", "reftest/mozilla/jpg-size-33x33.jpg",

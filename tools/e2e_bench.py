@@ -59,11 +59,16 @@ def main():
             best = t
     # sustained rate: calls back to back (a container with a CPU quota below its visible thread count runs the burst
     # above inside one scheduler period, but not this)
+    import resource
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     reps = 6
     for _ in range(reps):
         p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy)
-    sustained = reps * args.images / (time.perf_counter() - t0)
+    wall = time.perf_counter() - t0
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    sustained = reps * args.images / wall
+    cpu_s = (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
     mp = args.images * args.width * args.height / 1e6
     print(json.dumps({
         "what": "jpgpu_pipeline_decode: JPEG bytes (host) -> RGB" + (" (left in HBM)" if args.no_download else " (pinned host memory)"),
@@ -72,6 +77,7 @@ def main():
         f"{args.width}x{args.height} {args.subsampling} q{args.quality}" + (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
         "MP_per_s": round(mp / best["total_ms"] * 1e3, 1), "images_per_s": round(args.images / best["total_ms"] * 1e3, 1),
         "sustained_images_per_s_pixels_left_in_hbm": round(sustained, 1),
+        "sustained_cpu_ms_per_image": round(cpu_s * 1e3 / (reps * args.images), 3), "sustained_cpus_busy": round(cpu_s / wall, 1),
         "ms": {k: round(v, 2) for k, v in best.items() if k.endswith("_ms")},
         "jpeg_MB": round(best["jpeg_bytes"] / 1e6, 1), "coefficient_MB": round(best["coefficient_bytes"] / 1e6, 1),
         "pixel_MB": round(best["pixel_bytes"] / 1e6, 1),
