@@ -442,7 +442,7 @@ static uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t h
 }
 
 // Staging block layout (same offsets in the pinned and the device copy):
-//   [ status: n x u32 | stats: n x 4 x 2 x u32 | settle counters: 4 x u32 per sync job | HuffScanJob[] | HuffSyncJob[] | RangeJob[] |
+//   [ status: n x u32 | stats: n x 4 x 2 x u32 | settle counters: 4 x u32 per sync job | HuffSyncJob[] (segment jobs) | HuffSyncJob[] (chunk jobs) | RangeJob[] |
 //     DevHuffTable[8] per scan | segment offsets | scan bytes ]   + device only: per-chunk state of the sync jobs
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par) {
@@ -477,7 +477,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         }
     }
     const size_t off_status = 0, off_stats = align_up(off_status + (size_t)n * 4, 16), off_cnt = align_up(off_stats + (size_t)n * 32, 16);
-    const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = align_up(off_jobs + n_seg_jobs * sizeof(HuffScanJob), 16);
+    const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = align_up(off_jobs + n_seg_jobs * sizeof(HuffSyncJob), 16);
     const size_t off_range = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16), off_tables = align_up(off_range + n_range * sizeof(RangeJob), 16);
     const size_t off_seg = align_up(off_tables + n_scans * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
@@ -507,7 +507,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     }
     uint8_t *h = b->h_entropy, *d = b->d_entropy;
     memset(h, 0, off_jobs);  // status and stats start at zero
-    HuffScanJob *jobs = reinterpret_cast<HuffScanJob *>(h + off_jobs);
+    HuffSyncJob *jobs = reinterpret_cast<HuffSyncJob *>(h + off_jobs);
     HuffSyncJob *sjobs = reinterpret_cast<HuffSyncJob *>(h + off_sjobs);
     RangeJob *rjobs = reinterpret_cast<RangeJob *>(h + off_range);
     size_t ji = 0, si = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
@@ -575,7 +575,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 xcur += align_up((size_t)chunks * 7 * 4, 16);
                 si++;
             } else {
-                HuffScanJob &j = jobs[ji++];
+                HuffSyncJob &j = jobs[ji++];
                 memset(&j, 0, sizeof(j));
                 j.data = d + off_data;  // (segment offsets are relative to the start of the data area)
                 j.seg_off = reinterpret_cast<const uint32_t *>(d + scur);
@@ -587,6 +587,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 j.n_mcu = ps.n_mcu;
                 j.ncomp = ps.ncomp;
                 memcpy(j.comp, comp, sizeof(comp));
+                huff_sync_finish_job(j);
                 max_seg = std::max(max_seg, j.n_seg);
             }
             dcur += scan_bytes;
@@ -630,7 +631,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, s));
     }
     B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
-    B_HIP(launch_huff_segments(reinterpret_cast<const HuffScanJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
+    B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
         static const uint32_t launches = env_u32("JPGPU_SYNC_LAUNCHES", 10, 1, 64), iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
         B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, launches, iters, s));

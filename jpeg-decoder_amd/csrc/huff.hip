@@ -9,29 +9,6 @@
 
 namespace jpgpu {
 
-// grid = (ceil(max segments / 64), scan jobs), one wave per workgroup: lanes diverge (every lane walks its own bit
-// stream), so small workgroups spread the segments over as many SIMDs as possible
-// The scan's job record and Huffman tables are copied to LDS first: every symbol costs dependent table reads.
-__global__ __launch_bounds__(64) void huff_segments_kernel(const HuffScanJob *__restrict__ jobs) {
-    __shared__ HuffLds L;
-    {
-        const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)&jobs[blockIdx.y];
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&L.job);
-        if (threadIdx.x < sizeof(HuffScanJob) / 4u) dst[threadIdx.x] = src[threadIdx.x];
-    }
-    huff_fill_unzigzag((JP_LDS uint8_t *)L.unzig, threadIdx.x);
-    __syncthreads();
-    {
-        const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)L.job.tables;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(L.tables);
-        for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuffTable) / 4u; i += 64u) dst[i] = src[i];
-    }
-    __syncthreads();
-    const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
-    if (seg >= L.job.n_seg) return;
-    huff_decode_segment(*(JP_LDS HuffLds *)&L, seg);
-}
-
 // max |c*q| and the largest block-column sum of |c*q| per plane (the two quantities behind the range classes of
 // include/jpgpu.h).  Eight lanes per block, one 16-byte row each: a wave reads 1 KB of consecutive coefficients per load
 // (one lane per block — every lane on its own cache line — ran at 1.2 TB/s).  The column sums are folded across the
@@ -95,23 +72,33 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restr
 // and clears slot (t+1) % 3, so the host can enqueue a fixed number of launches without looking at the device in between.
 constexpr uint32_t SYNC_NT = HUFF_SYNC_LANES;
 
+template <uint32_t NT>
 __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffSyncJob *gj) {
     {
         const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj;
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)&L.job;
-        static_assert(sizeof(HuffSyncJob) / 4u <= SYNC_NT, "one word per lane");
-        if (threadIdx.x < sizeof(HuffSyncJob) / 4u) dst[threadIdx.x] = src[threadIdx.x];
+        for (uint32_t i = threadIdx.x; i < sizeof(HuffSyncJob) / 4u; i += NT) dst[i] = src[i];
     }
     huff_fill_unzigzag((JP_LDS uint8_t *)L.unzig, threadIdx.x & 63u);
     {
         const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj->tables;
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)L.tables;
-        for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuffTable) / 4u; i += SYNC_NT) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuffTable) / 4u; i += NT) dst[i] = src[i];
     }
     __syncthreads();
-    huff_sync_fill_lds(L, threadIdx.x);
-    if (SYNC_NT < 512u) huff_sync_fill_lds(L, threadIdx.x + SYNC_NT);
+    for (uint32_t l = threadIdx.x; l < 512u; l += NT) huff_sync_fill_lds(L, l);
     __syncthreads();
+}
+
+// Restart-segment decoder: grid = (ceil(max segments / 64), segment jobs), one wave per workgroup — lanes diverge (every
+// lane walks its own bit stream), so small workgroups spread the segments over as many SIMDs as possible.
+__global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__restrict__ jobs) {
+    __shared__ HuffSyncLds L;
+    const HuffSyncJob *gj = &jobs[blockIdx.y];
+    if (blockIdx.x * 64u >= gj->n_seg) return;
+    sync_load_lds<64>(*(JP_LDS HuffSyncLds *)&L, gj);
+    const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
+    if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg);
 }
 
 __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
@@ -135,7 +122,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
         }
         if (!__syncthreads_or(need)) return;
     }
-    sync_load_lds(*(JP_LDS HuffSyncLds *)&L, gj);
+    sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
     bool published = false;
     for (uint32_t it = 0; it < iters; it++) {
         if (i < n_chunks) published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, i, first_pass + it);
@@ -221,7 +208,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSync
     const HuffSyncJob *gj = &jobs[blockIdx.y];
     if (blockIdx.x * SYNC_NT >= gj->n_chunks) return;
     if (*gj->status != 0u) return;
-    sync_load_lds(*(JP_LDS HuffSyncLds *)&L, gj);
+    sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
     const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
     if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u);
 }
@@ -291,7 +278,7 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
     }
 }
 
-hipError_t launch_huff_segments(const HuffScanJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream) {
+hipError_t launch_huff_segments(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream) {
     if (n_jobs == 0 || max_segments == 0) return hipSuccess;
     huff_segments_kernel<<<dim3((max_segments + 63u) / 64u, n_jobs), dim3(64), 0, stream>>>(d_jobs);
     return hipGetLastError();

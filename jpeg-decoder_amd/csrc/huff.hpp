@@ -14,7 +14,7 @@ struct RangeJob {  // one component plane to classify
     uint16_t q[64];
 };
 
-hipError_t launch_huff_segments(const HuffScanJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream);
+hipError_t launch_huff_segments(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream);
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream);
 hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t *d_stats, hipStream_t stream);
 

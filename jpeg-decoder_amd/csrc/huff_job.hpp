@@ -23,17 +23,6 @@ struct HuffScanComp {
     uint32_t dc, ac;    // table slots: dc in tables[0..3], ac in tables[4..7]
 };
 
-struct HuffScanJob {            // one scan of one image
-    const uint8_t *data;        // staged segments (huff_stage_segment): unstuffed, each in a 16-byte aligned slot, zero padded
-    const uint32_t *seg_off;    // 2 * n_seg words: segment s starts at data + seg_off[2s] and has seg_off[2s+1] unstuffed bytes
-    const DevHuffTable *tables; // 8 tables of this scan
-    uint32_t *status;           // the image's status word: bit 0 set = decode this image on the host instead
-    uint32_t n_seg, ri;         // restart interval in MCUs
-    uint32_t cols, n_mcu;       // MCUs per row / in the scan
-    uint32_t ncomp, _pad;
-    HuffScanComp comp[4];
-};
-
 // Host side of the staging: copy one restart segment (markers excluded, 0xFF00 pairs inside) without its stuffing
 // zeros, then zero bytes up to the next 16-byte boundary plus 16 (the device reader fetches aligned 16-byte chunks ahead
 // and treats what follows a segment as zero bits).  Returns the unstuffed length.  Slot size: huff_slot_bytes(n).
@@ -54,10 +43,14 @@ inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n)
     return o;
 }
 
-// ---- scans without restart markers: the self-synchronising chunk decoder (huff_sync_core.hpp) -------------------------
+// ---- one scan for the device decoders (huff_sync_core.hpp): restart segments, or the self-synchronising chunk decoder ------
 
-struct HuffSyncJob {             // one scan of one image (exactly one "segment": no restart interval in force)
-    const uint8_t *data;         // staged scan: unstuffed, 16-byte aligned, zero padded
+struct HuffSyncJob {             // one scan of one image, for either device decoder:
+                                 //  - ri == 0: no restart interval in force, the scan is one staged slot cut into chunks (all fields);
+                                 //  - ri > 0: restart segments (seg_off, n_seg; the per-chunk arrays and chunk fields are unused)
+    const uint8_t *data;         // staged scan: unstuffed, 16-byte aligned, zero padded (ri > 0: base of the batch's data area)
+    const uint32_t *seg_off;     // ri > 0: 2 * n_seg words, segment s starts at data + seg_off[2s] and has seg_off[2s+1] unstuffed bytes
+    uint32_t n_seg, ri;          // restart interval in MCUs
     const DevHuffTable *tables;  // 8 tables of this scan
     uint32_t *status;            // the image's status word (bit 0: decode on the host instead)
     uint32_t *changed;           // per job: 3 counters of published states, used in rotation by consecutive launches (huff.hip)

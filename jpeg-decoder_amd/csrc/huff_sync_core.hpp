@@ -69,15 +69,20 @@ __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32
     }
 }
 
+template <bool DW>
 __device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos) {
     b.g = reinterpret_cast<const v4u *>(slot);
     b.wpos = bit_pos >> 5;
-    b.cur = b.g[b.wpos >> 2];
-    b.nxt = b.g[(b.wpos >> 2) + 1u];
+    if (DW) {
+        b.ahead = reinterpret_cast<const uint32_t *>(slot)[b.wpos];
+    } else {
+        b.cur = b.g[b.wpos >> 2];
+        b.nxt = b.g[(b.wpos >> 2) + 1u];
+    }
     b.bits = 0;
     b.nbits = 0;
     b.bad = false;
-    huff_refill(b);
+    huff_refill<DW>(b);
     huff_consume(b, bit_pos & 31u);
 }
 __device__ __forceinline__ uint32_t huff_bit_pos(const DevBits &b) { return b.wpos * 32u - b.nbits; }
@@ -85,6 +90,99 @@ __device__ __forceinline__ uint32_t huff_bit_pos(const DevBits &b) { return b.wp
 __device__ __forceinline__ bool huff_sync_state_plausible(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t pos, uint32_t q, uint32_t k) {
     const uint32_t first = i << job.chunk_shift;
     return pos >= first && pos - first <= 32u && q < job.bpm && k < 64u;
+}
+
+// The decoding loop shared by the chunk decoder and the restart-segment decoder: from state (pos, q, k) of the staged bit
+// stream `data` until the bit position reaches `limit` (BY_BITS) and/or `end_blk` blocks are complete (WRITE).
+//   WRITE:   store coefficients; `blkno` = number of the block being decoded (-> its MCU and address)
+//   dc_sums: dc[component] accumulates DC differences (WRITE: they are predictors, and the stored DC values are finished)
+// Returns the bit position reached; q, k, nblk (blocks completed), blkno, bad are updated.
+template <bool WRITE, bool BY_BITS>
+__device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
+                                             uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad) {
+    const JP_LDS HuffSyncJob &job = L.job;
+    constexpr bool DW = !(WRITE && BY_BITS);  // (huff_core.hpp: the chunk decoder's write pass keeps the 16-byte reader)
+    DevBits b;
+    huff_open_at<DW>(b, data, pos);
+    uint32_t c = job.q_comp[q];  // component of block q
+    const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
+    uint32_t qt = L.q_tables[q];  // table offsets of block q
+    JP_GLOBAL int16_t *blk = nullptr;
+    uint32_t mx = 0, my = 0;  // the MCU of block `blkno` (write pass), kept by counting: no divisions per block
+    if (WRITE) {
+        const uint32_t m = blkno / job.bpm;
+        my = m / job.cols;
+        mx = m - my * job.cols;
+    }
+    auto locate = [&]() {  // arena address of block `blkno` = block q of MCU (mx, my)
+        const uint64_t base = L.q_dst[q].base;
+        blk = (JP_GLOBAL int16_t *)(uintptr_t)(base + (uint64_t)my * L.q_dst[q].row_stride + mx * L.q_dst[q].mcu_stride);
+    };
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;  // DC predictors of a restart segment (start at 0, src/decoder.rs:928-931)
+    if (WRITE && blkno < end_blk) locate();
+    while (!bad && (!BY_BITS || huff_bit_pos(b) < limit) && !(WRITE && blkno >= end_blk)) {
+        huff_refill<DW>(b);
+        const uint32_t ac = k != 0u ? 1u : 0u;
+        const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
+        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> 8;
+        uint32_t sym = e & 0xffu;
+        if (csz) {
+            huff_consume(b, csz);
+        } else {
+            sym = huff_walk(b, t);
+            bad = b.bad;
+        }
+        // what the symbol means: chunk decoder (several waves per SIMD, bound by instruction issue) from the LDS table; restart
+        // segments (one wave per SIMD at best: every dependent LDS round trip is paid in full) by a dozen selects
+        const uint32_t info = BY_BITS ? (uint32_t)L.sym_info[ac][sym] : huff_sym_info(ac, sym), nread = info & 15u;
+        const uint32_t raw = huff_peek(b, nread);
+        huff_consume(b, nread);
+        const uint32_t k0 = k;
+        k += (info >> 4) & 127u;
+        // a coefficient beyond index 63: the reference breaks out of the block in a way that depends on its own table
+        // layout (src/decoder.rs:1045-1075) — only broken streams have it, the host decides
+        bad = bad || (info & SYM_BAD) != 0u || ((info & SYM_COEF) != 0u && k > 64u);
+        if (!bad) {
+            if (k0 == 0u) {
+                int32_t val = huff_extend(raw, nread);
+                if (!BY_BITS) {  // restart segments: a wave on its own pays every LDS round trip in full — registers and selects
+                    uint32_t pr = c == 0u ? d0 : (c == 1u ? d1 : (c == 2u ? d2 : d3));
+                    pr += (uint32_t)val;
+                    d0 = c == 0u ? pr : d0;
+                    d1 = c == 1u ? pr : d1;
+                    d2 = c == 2u ? pr : d2;
+                    d3 = c == 3u ? pr : d3;
+                    val = (int16_t)(uint16_t)pr;
+                } else if (dc_sums) {  // sync pass: sum of differences; write pass: the predictor -> the DC value
+                    dc[c] += (uint32_t)val;
+                    val = (int16_t)(uint16_t)dc[c];
+                }
+                if (WRITE && val) blk[0] = (int16_t)val;  // (uniform scans: the difference; huff_dc_prefix_kernel sums up)
+            } else if (WRITE && (info & SYM_COEF)) {
+                blk[L.unzig[k - 1u]] = (int16_t)huff_extend(raw, nread);
+            }
+        }
+        if (k >= 64u && !bad) {  // end of the block
+            k = 0u;
+            nblk++;
+            q++;
+            if (q == job.bpm) {
+                q = 0u;
+                mx++;
+                if (mx == job.cols) {
+                    mx = 0u;
+                    my++;
+                }
+            }
+            qt = L.q_tables[q];
+            c = job.q_comp[q];
+            if (WRITE) {
+                blkno++;
+                if (blkno < end_blk) locate();
+            }
+        }
+    }
+    return huff_bit_pos(b);
 }
 
 // One chunk.  WRITE = false: a sync pass (`pass` = its number), returns whether the lane published a new state (the caller
@@ -143,78 +241,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         dc[2] = w1 & 0xffffu;
         dc[3] = w1 >> 16;
     }
-    if (pos < limit) {
-        DevBits b;
-        huff_open_at(b, job.data, pos);
-        uint32_t c = job.q_comp[q];  // component of block q
-        const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
-        uint32_t qt = L.q_tables[q];  // table offsets of block q
-        JP_GLOBAL int16_t *blk = nullptr;
-        uint32_t mx = 0, my = 0;  // the MCU of block `blkno` (write pass), kept by counting: no divisions per block
-        if (WRITE) {
-            const uint32_t m = blkno / job.bpm;
-            my = m / job.cols;
-            mx = m - my * job.cols;
-        }
-        auto locate = [&]() {  // arena address of block `blkno` = block q of MCU (mx, my)
-            const uint64_t base = L.q_dst[q].base;
-            blk = (JP_GLOBAL int16_t *)(uintptr_t)(base + (uint64_t)my * L.q_dst[q].row_stride + mx * L.q_dst[q].mcu_stride);
-        };
-        if (WRITE && blkno < total_blocks) locate();
-        while (!bad && huff_bit_pos(b) < limit && !(WRITE && blkno >= total_blocks)) {
-            huff_refill(b);
-            const uint32_t ac = k != 0u ? 1u : 0u;
-            const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
-            const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> 8;
-            uint32_t sym = e & 0xffu;
-            if (csz) {
-                huff_consume(b, csz);
-            } else {
-                sym = huff_walk(b, t);
-                bad = b.bad;
-            }
-            const uint32_t info = L.sym_info[ac][sym], nread = info & 15u;
-            const uint32_t raw = huff_peek(b, nread);
-            huff_consume(b, nread);
-            const uint32_t k0 = k;
-            k += (info >> 4) & 127u;
-            // a coefficient beyond index 63: the reference breaks out of the block in a way that depends on its own table
-            // layout (src/decoder.rs:1045-1075) — only broken streams have it, the host decides
-            bad = bad || (info & SYM_BAD) != 0u || ((info & SYM_COEF) != 0u && k > 64u);
-            if (!bad) {
-                if (k0 == 0u) {
-                    int32_t val = huff_extend(raw, nread);
-                    if (dc_sums) {  // sync pass: sum of differences; write pass: the predictor -> the DC value
-                        dc[c] += (uint32_t)val;
-                        val = (int16_t)(uint16_t)dc[c];
-                    }
-                    if (WRITE && val) blk[0] = (int16_t)val;  // (uniform scans: the difference; huff_dc_prefix_kernel sums up)
-                } else if (WRITE && (info & SYM_COEF)) {
-                    blk[L.unzig[k - 1u]] = (int16_t)huff_extend(raw, nread);
-                }
-            }
-            if (k >= 64u && !bad) {  // end of the block
-                k = 0u;
-                nblk++;
-                q++;
-                if (q == job.bpm) {
-                    q = 0u;
-                    mx++;
-                    if (mx == job.cols) {
-                        mx = 0u;
-                        my++;
-                    }
-                }
-                qt = L.q_tables[q];
-                c = job.q_comp[q];
-                if (WRITE) {
-                    blkno++;
-                    if (blkno < total_blocks) locate();
-                }
-            }
-        }
-        pos = huff_bit_pos(b);
-    }
+    if (pos < limit) pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad);
     if (!WRITE && dc_sums) {
         job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);
         job.dc_sum[2u * i + 1u] = (dc[2] & 0xffffu) | (dc[3] << 16);
@@ -234,6 +261,30 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         if (i + 1u == job.n_chunks && (blkno < total_blocks || pos > job.n_bits)) atomicOr_status(job.status, 1u | 8u);
     }
     return false;
+}
+
+// ---- streams WITH restart markers: one lane per restart segment (src/decoder.rs:920-956: the predictors and the bit
+// reader start afresh after every RSTn, so segments are independent).  The job record says where the segments lie
+// (seg_off, staged by huff_stage_segment one slot each) and how many MCUs one holds (ri); the decoding loop is huff_run.
+__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint32_t seg) {
+    const JP_LDS HuffSyncJob &job = L.job;
+    const uint8_t *data = job.data + job.seg_off[2u * seg];
+    const uint32_t seg_bits = job.seg_off[2u * seg + 1u] * 8u;
+    const uint32_t m0 = seg * job.ri, m1 = min(m0 + job.ri, job.n_mcu);
+    uint32_t q = 0, k = 0, nblk = 0, blkno = m0 * job.bpm;
+    bool bad = false;
+    const uint32_t pos = huff_run<true, false>(L, data, 0u, 0u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad);
+    // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it keeps reading until it
+    // meets the marker, which works iff the unread rest of the segment fits its 64-bit buffer; left-over bits are
+    // dropped.  A segment that ran dry (bits taken from beyond its end — the reference would have fed zeros as well) is
+    // left to the host to be safe.
+    const int64_t left = (int64_t)seg_bits - (int64_t)pos;
+    if (bad || left < 0 || left > 64) {
+        // bit 0 = re-decode on the host; bits 1..3 say why (diagnostics)
+        atomicOr_status(job.status, 1u | (bad ? 2u : 0u) | (left > 64 ? 4u : 0u) | (left < 0 ? 8u : 0u));
+        return false;
+    }
+    return true;
 }
 
 }  // namespace jpgpu

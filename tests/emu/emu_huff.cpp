@@ -52,7 +52,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
     fe.read_info();
     if (!fe.plan_device_scans(scans)) return -1;
     uint32_t status = 0;
-    HuffLds* L = new HuffLds;
+    HuffSyncLds* L = new HuffSyncLds;
     for (const PlannedScan& ps : scans) {
         // staging as batch.cpp does it: every segment unstuffed into its own 16-byte aligned, zero padded slot
         size_t total = 0;
@@ -174,7 +174,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             delete S;
             continue;
         }
-        HuffScanJob& job = L->job;
+        HuffSyncJob& job = L->job;
         memset(&job, 0, sizeof(job));
         job.data = stage;
         job.seg_off = table.data();
@@ -193,8 +193,10 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             job.comp[c].dc = ps.comp[c].dc;
             job.comp[c].ac = ps.comp[c].ac;
         }
+        huff_sync_finish_job(job);
         memcpy(L->tables, ps.tables, sizeof(L->tables));
         for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(L->unzig, t);
+        for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*L, t);
         for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s);
     }
     delete L;
