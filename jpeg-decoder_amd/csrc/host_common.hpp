@@ -38,8 +38,10 @@ struct DeviceEntropyImage {
 // planes, the segment decoder, the range scan.  Then (after the stream has been synchronised) collect: status[k] != 0
 // means image k of the list must be decoded on the host instead; the others have their range classes set.
 // `par`: optional parallel-for (count, body) used for the staging copies of the scans' bytes.
+// `copy_stream`: optional second stream for the upload (the kernels on `hip_stream` wait for it through an event).
 int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
-                                const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr);
+                                const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
+                                void *copy_stream = nullptr);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 
 }  // namespace jpgpu

@@ -585,7 +585,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         std::vector<jpgpu::DeviceEntropyImage> list;
                         for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
                         const double l0 = now_ms();
-                        okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for) == JPGPU_OK;
+                        okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
+                                                                 p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams]) == JPGPU_OK;
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         if (!okk) launch_err = jpgpu_batch_last_error(sb.batch);
                         else pending_subs.push_back((uint32_t)p->sub_of[i]);
