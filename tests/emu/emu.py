@@ -22,6 +22,12 @@ def lib():
                                         C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]
         L.emu_compute_image.restype = C.c_int
         L.emu_huff_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.emu_stage_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.emu_stage_segment.restype = C.c_uint32
+        L.emu_slot_bytes.argtypes = [C.c_uint32]
+        L.emu_slot_bytes.restype = C.c_uint32
+        L.emu_chunk_shift.argtypes = [C.c_uint32, C.c_uint32]
+        L.emu_chunk_shift.restype = C.c_uint32
         L.emu_huff_set_launch.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.emu_huff_set_launch.restype = None
         L.emu_huff_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]

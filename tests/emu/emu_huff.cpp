@@ -16,6 +16,11 @@ using jpgpu::host::PlannedScan;
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
 
 extern "C" {
+// huff_stage_segment / huff_sync_chunk_shift as the product uses them (host-side helpers of csrc/huff_job.hpp)
+uint32_t emu_stage_segment(uint8_t* dst, const uint8_t* src, uint32_t n) { return huff_stage_segment(dst, src, n); }
+uint32_t emu_slot_bytes(uint32_t n) { return huff_slot_bytes(n); }
+uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return huff_sync_chunk_shift(stuffed_bytes, total_blocks); }
+
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
     g_sync_stale = stale;
     g_sync_iters = iters ? iters : 1u;

@@ -188,3 +188,48 @@ def test_damaged_restart_streams_never_disagree_silently():
                 assert np.array_equal(planes[c], hcoefs[c]), (trial, c)
             outcomes["same"] += 1
     assert outcomes["same"] > 20 and outcomes["flag"] + outcomes["host"] > 20, outcomes
+
+
+def test_staging_copy_removes_exactly_the_stuffing_zeros():
+    """huff_stage_segment (memchr/memcpy runs): 0xFF 0x00 -> 0xFF, everything else verbatim — 0xFF at the very end, 0xFF
+    followed by something else (cannot occur inside a segment, must not be touched), runs of 0xFF 0x00, empty input; the
+    slot is zero padded to huff_slot_bytes."""
+    L = emu.lib()
+    rng = np.random.default_rng(4)
+    cases = [b"", b"\xff", b"\xff\x00", b"\x00\xff", b"\xff\x00\xff\x00\xff\x00", b"\xff\xff\x00", b"\xff\x01\xff\x00\x00", b"a" * 1000]
+    for density in (0.5, 0.05, 0.004):
+        for n in (1, 15, 16, 17, 257, 4096, 70001):
+            a = rng.integers(0, 256, n, dtype=np.uint8)
+            a[rng.random(n) < density] = 0xFF
+            idx = np.flatnonzero(a[:-1] == 0xFF)
+            a[idx[rng.random(idx.size) < 0.8] + 1] = 0
+            cases.append(a.tobytes())
+    for src in cases:
+        want = bytearray()
+        i = 0
+        while i < len(src):
+            want.append(src[i])
+            if src[i] == 0xFF and i + 1 < len(src) and src[i + 1] == 0:
+                i += 1
+            i += 1
+        slot = L.emu_slot_bytes(len(src))
+        assert slot >= len(src) + 32 and slot % 16 == 0
+        dst = (C.c_uint8 * (slot + 16))(*([0xAA] * (slot + 16)))
+        buf = (C.c_uint8 * max(len(src), 1)).from_buffer_copy(src or b"\0")
+        got = L.emu_stage_segment(dst, buf, len(src))
+        out = bytes(dst)
+        assert got == len(want) and out[:got] == bytes(want)
+        assert out[got:slot] == bytes(slot - got) and out[slot:] == b"\xaa" * 16
+
+
+def test_chunk_size_follows_the_bits_per_block():
+    L = emu.lib()
+    assert L.emu_chunk_shift(1000, 10 ** 6) == 10          # tiny blocks: the minimum, 1,024 bits
+    assert L.emu_chunk_shift(400_000, 48_960) in (11, 12)   # a 1080p 4:2:0 file of 400 kB: 65 bits per block -> 4,096 bits
+    assert L.emu_chunk_shift(10 ** 7, 1000) == 13           # huge blocks: capped at 8,192 bits
+    assert L.emu_chunk_shift(0, 0) == 10
+    prev = 10
+    for kb in range(1, 4000, 37):  # monotonic in the stream size
+        sh = L.emu_chunk_shift(kb * 1000, 48_960)
+        assert sh >= prev
+        prev = sh
