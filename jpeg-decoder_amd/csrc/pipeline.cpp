@@ -417,6 +417,39 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             p->errors[i] = e.what();
         }
     });
+    // Restart-marker streams on the device cost the time of their LONGEST segment (one lane walks it: ≈2.4 µs per byte,
+    // measured with 6 kB segments: 14.7 ms per launch, however many images), on the host the time of ALL their bytes
+    // (≈12 ns per byte and thread).  A few images, or segments of many MCU rows, are better off on the host.
+    if (device_entropy) {
+        size_t max_seg = 0, bytes = 0;
+        uint32_t n_seg_images = 0;
+        for (uint32_t i = 0; i < n; i++)
+            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
+                n_seg_images++;
+                for (const jpgpu::host::PlannedScan &ps : p->plans[i])
+                    for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+                        max_seg = std::max<size_t>(max_seg, ps.seg_off[sg + 1] - ps.seg_off[sg]);
+                        bytes += ps.seg_off[sg + 1] - ps.seg_off[sg];
+                    }
+            }
+        const double device_ms = 1.0 + (double)max_seg * 2.4e-3, host_ms = (double)bytes * 12e-6 / std::max<uint32_t>(1u, p->pool->size() / 2u);
+        if (n_seg_images && device_ms > host_ms && !getenv("JPGPU_PIPE_FORCE_DEVICE")) {
+            if (getenv("JPGPU_PIPE_TRACE"))
+                fprintf(stderr, "pipeline trace: %u restart-marker stream(s) stay on the host (longest segment %zu B: device ~%.1f ms, host ~%.1f ms)\n",
+                        n_seg_images, max_seg, device_ms, host_ms);
+            for (uint32_t i = 0; i < n; i++)
+                if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
+                    p->plans[i].clear();
+                    try {
+                        p->fes[i].reset(new Frontend(data[i], len[i]));
+                        p->fes[i]->read_info();
+                    } catch (const DecodeError &e) {
+                        p->status[i] = e.code;
+                        p->errors[i] = e.message;
+                    }
+                }
+        }
+    }
     const double t1 = now_ms();
 
     // 2. sub-batches of the images that have a frame (each kept while its geometry sequence repeats)

@@ -113,10 +113,11 @@ def _pil_restart(w, h, subsampling, rows=0, blocks=0, gray=False, seed=3):
     return buf.getvalue()
 
 
-def test_pipeline_device_entropy_decoder_matches_host_path():
+def test_pipeline_device_entropy_decoder_matches_host_path(monkeypatch):
     """Restart-marker streams decoded on the GPU (one lane per restart segment) next to streams that must stay on the host
     and damaged restart streams the device decoder has to hand back: every result equals the per-image oracle outcome."""
     pytest.importorskip("PIL")
+    monkeypatch.setenv("JPGPU_PIPE_FORCE_DEVICE", "1")  # (a handful of small files: the pipeline's cost model would keep them on the host)
     names, files = [], []
     for rel in ["reftest/restarts.jpg", "reftest/mjpeg.jpg", "benches/tower.jpg", "reftest/mozilla/jpg-progressive.jpg",
                 "reftest/non-interleaved-mcu.jpg", "reftest/mozilla/jpg-gray.jpg"]:
@@ -143,6 +144,8 @@ def test_pipeline_device_entropy_decoder_matches_host_path():
     p = J.Pipeline(threads=8)
     out = p.decode(files, device_entropy=True)
     _check(names, files, out)
+    t = p.timings()
+    assert t["images_device_entropy"] >= 12, t  # the restart streams did go to the device
     out_host = p.decode(files)
     _check(names, files, out_host)
     # same-geometry restart streams: fused kernels after the device entropy decoder
@@ -150,6 +153,14 @@ def test_pipeline_device_entropy_decoder_matches_host_path():
     out = p.decode(same, device_entropy=True)
     assert p.kernel_path == "fused420"
     _check([f"same-{i}" for i in range(9)], same, out)
+    assert p.timings()["images_device_entropy"] == 9
+    # without the override the cost model keeps these nine small restart streams on the host (one lane per segment pays
+    # off with many images only); streams without restart markers still go to the device
+    monkeypatch.delenv("JPGPU_PIPE_FORCE_DEVICE")
+    mixed = same + [_pil_plain(320, 240, "4:2:0", seed=s) for s in range(3)]
+    out = p.decode(mixed, device_entropy=True)
+    _check([f"mixed-{i}" for i in range(12)], mixed, out)
+    assert p.timings()["images_device_entropy"] == 3, p.timings()
     p.close()
 
 
