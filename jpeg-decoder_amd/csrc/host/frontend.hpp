@@ -37,7 +37,8 @@ public:
     virtual void finish(uint32_t index, uint32_t frame_slot) = 0;  // get_result + keep for compute_image
 };
 
-// What the device entropy decoder (csrc/huff_core.hpp) needs for one sequential Huffman scan with restart markers.
+// What the device entropy decoders (csrc/huff_sync_core.hpp) need for one sequential Huffman scan: its restart segments, or
+// (no restart interval in force) the whole scan as one segment for the chunk decoder.
 struct PlannedScan {
     size_t data_off = 0;            // offset of the scan's entropy-coded bytes in the stream given to the Frontend
     std::vector<uint32_t> seg_off;  // 2 * n_seg offsets relative to data_off: segment s = [seg_off[2s], seg_off[2s+1]), no markers
@@ -66,9 +67,9 @@ public:
     void decode_to(RowSink &sink);
     // Instead of decoding: walk the markers to EOI and describe every scan for the device entropy decoder.  Returns
     // false — the object is then spent, decode with a fresh Frontend — unless the stream is plainly eligible: 8-bit
-    // sequential Huffman, one scan carrying all components,
-    // RST markers exactly where and as numbered as the interval says, nothing else inside or after the entropy
-    // data.  Anything doubtful (including every error the marker loop would raise) is "not eligible": the host
+    // sequential Huffman, one scan carrying all components (at most 16 blocks per MCU), RST markers — if a restart
+    // interval is in force — exactly where and as numbered as the interval says, nothing else inside or after the
+    // entropy data.  Anything doubtful (including every error the marker loop would raise) is "not eligible": the host
     // decoder is the one whose behaviour on odd streams is pinned.  On success the tables handed to Worker::start
     // (qtable_of_component) and planes_present() are set as decode_to would have set them.
     bool plan_device_scans(std::vector<PlannedScan> &scans);

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--no-download", action="store_true")
     ap.add_argument("--progressive", action="store_true")
-    ap.add_argument("--device-entropy", action="store_true", help="decode restart-marker streams on the GPU")
+    ap.add_argument("--device-entropy", action="store_true", help="entropy-decode sequential Huffman streams on the GPU (JPGPU_PIPELINE_DEVICE_ENTROPY)")
     ap.add_argument("--restart-rows", type=int, default=0, help="write the synthetic files with a restart marker every N MCU rows")
     ap.add_argument("--sleep", type=float, default=0.0, help="seconds to idle between rounds")
     ap.add_argument("--dense", action="store_true", help="send dense coefficient planes (A/B against the compact transport)")
