@@ -101,31 +101,51 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__
     if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg);
 }
 
+// does chunk i have a start state it has not decoded from yet?  (what huff_sync_chunk decides itself, ahead of the call)
+__device__ __forceinline__ bool sync_chunk_has_work(const HuffSyncJob *gj, uint32_t i, uint32_t pass) {
+    if (i >= gj->n_chunks) return false;
+    if (pass == 0u) return true;
+    if (i == 0u) return false;  // the first chunk decoded from the truth in pass 0
+    const uint32_t p = huff_load_shared(gj->out_pos + (i - 1u));
+    uint32_t qk = huff_load_shared(gj->out_qk + (i - 1u));
+    if (gj->uniform) qk &= 0xffu;
+    const uint32_t first = i << gj->chunk_shift;  // (huff_sync_state_plausible)
+    return p >= first && p - first <= 32u && (qk >> 8) < gj->bpm && (qk & 0xffu) < 64u && (p != gj->in_pos[i] || qk != gj->in_qk[i]);
+}
+
 __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
                                                                 uint32_t iters) {
     __shared__ HuffSyncLds L;
+    __shared__ uint16_t todo[SYNC_NT];              // chunks (relative to the workgroup's first) with work, packed to the front
+    __shared__ uint32_t wave_cnt[SYNC_NT / 64u];
     const HuffSyncJob *gj = &jobs[blockIdx.y];
     uint32_t *cnt = gj->changed;
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt[(launch + 1u) % 3u] = 0u;
-    const uint32_t n_chunks = gj->n_chunks;
-    if (blockIdx.x * SYNC_NT >= n_chunks) return;
+    if (blockIdx.x * SYNC_NT >= gj->n_chunks) return;
     if (launch > 0u && cnt[(launch - 1u) % 3u] == 0u) return;
-    const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
-    if (launch > 0u) {  // does any lane of this workgroup have a new start state?  (most do not: skip the table load)
-        bool need = false;
-        if (i > 0u && i < n_chunks) {
-            const uint32_t p = huff_load_shared(gj->out_pos + (i - 1u));
-            uint32_t qk = huff_load_shared(gj->out_qk + (i - 1u));
-            if (gj->uniform) qk &= 0xffu;
-            const uint32_t first = i << gj->chunk_shift;  // (huff_sync_state_plausible)
-            need = p >= first && p - first <= 32u && (qk >> 8) < gj->bpm && (qk & 0xffu) < 64u && (p != gj->in_pos[i] || qk != gj->in_qk[i]);
-        }
-        if (!__syncthreads_or(need)) return;
-    }
+    const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // does any lane of this workgroup have a new start state?  (after the first launches most do not: skip the table load)
+    if (!__syncthreads_or(sync_chunk_has_work(gj, i, first_pass))) return;
     sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
     bool published = false;
     for (uint32_t it = 0; it < iters; it++) {
-        if (i < n_chunks) published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, i, first_pass + it);
+        // Lanes with work are packed into as few waves as possible: a wave costs the same with one busy lane as with 64, and
+        // from the third pass on a few per cent of the chunks are still being corrected.
+        const bool need = sync_chunk_has_work(gj, i, first_pass + it);
+        const uint64_t m = __ballot(need);
+        if (lane == 0u) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < SYNC_NT / 64u; w++) {
+            const uint32_t c = wave_cnt[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        if (need) todo[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        if (threadIdx.x < total)
+            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it);
         __syncthreads();
     }
     const uint32_t n_pub = (uint32_t)__syncthreads_count(published);
