@@ -74,12 +74,12 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
 // Chunk size.  A lane that starts at a wrong place finds the symbol boundaries within a few symbols, the block boundaries at
 // the next end-of-block — and the position inside the MCU (which tables apply) only by luck, one try per re-synchronisation,
 // so what matters is the number of BLOCKS in a chunk: ~48 of them (measured: 15 blocks per chunk settle 63 % of the lanes per
-// pass, 60 blocks 98 %), between 1,024 and 8,192 bits, from the stream's average (the stuffed length serves: an upper bound
+// pass, 60 blocks 98 %), between 1,024 and 32,768 bits, from the stream's average (the stuffed length serves: an upper bound
 // taken before the staging copy).
 inline uint32_t huff_sync_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks, uint32_t blocks_per_chunk = 48u) {
     const uint64_t target = (uint64_t)stuffed_bytes * 8u * blocks_per_chunk / (total_blocks ? total_blocks : 1u);
     uint32_t shift = 10;
-    while (shift < 13u && (1ull << shift) * 1414u / 1000u < target) shift++;  // nearest power of two (in the log domain)
+    while (shift < 15u && (1ull << shift) * 1414u / 1000u < target) shift++;  // nearest power of two (in the log domain)
     return shift;
 }
 inline uint32_t huff_sync_chunks(uint32_t bytes, uint32_t chunk_shift) {

@@ -2,7 +2,7 @@
 // self-synchronising chunked decoder (Klein & Wiseman 2003; Weissenberger & Schmidt 2018/2021 for JPEG).
 //
 // A Huffman bit stream decoded from a wrong position re-synchronises with the true symbol boundaries after a few
-// symbols with high probability.  The scan (unstuffed by the host, huff_stage_segment) is cut into chunks of 1,024 to 8,192
+// symbols with high probability.  The scan (unstuffed by the host, huff_stage_segment) is cut into chunks of 1,024 to 32,768
 // bits (huff_sync_chunk_shift), one lane per chunk:
 //   1. sync passes (huff_sync_chunk<false>): lane i decodes from its current start state to the first symbol boundary at
 //      or beyond the end of its chunk and publishes that state for lane i+1.  State = (bit position, block-within-MCU,

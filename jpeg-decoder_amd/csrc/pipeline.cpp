@@ -450,6 +450,28 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 }
         }
     }
+    // Streams without restart markers whose blocks are very long (noise at quality >= 98: no end-of-block symbols at all) keep
+    // the chunk decoder re-synchronising for dozens of passes (measured: beyond ~350 bits per block more launches than it is
+    // given) — it would flag them in the end; the host decodes them right away instead.
+    if (device_entropy && !getenv("JPGPU_PIPE_FORCE_DEVICE"))
+        for (uint32_t i = 0; i < n; i++)
+            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri == 0) {
+                const jpgpu::host::PlannedScan &ps = p->plans[i][0];
+                uint64_t blocks = 0;
+                for (uint32_t c = 0; c < ps.ncomp; c++) blocks += (uint64_t)ps.comp[c].h * ps.comp[c].v;
+                blocks *= ps.n_mcu;
+                const uint64_t bits = ps.seg_off.size() >= 2 ? (uint64_t)(ps.seg_off[1] - ps.seg_off[0]) * 8u : 0u;
+                if (blocks && bits / blocks > 384u) {
+                    p->plans[i].clear();
+                    try {
+                        p->fes[i].reset(new Frontend(data[i], len[i]));
+                        p->fes[i]->read_info();
+                    } catch (const DecodeError &e) {
+                        p->status[i] = e.code;
+                        p->errors[i] = e.message;
+                    }
+                }
+            }
     const double t1 = now_ms();
 
     // 2. sub-batches of the images that have a frame (each kept while its geometry sequence repeats)

@@ -226,7 +226,7 @@ def test_chunk_size_follows_the_bits_per_block():
     L = emu.lib()
     assert L.emu_chunk_shift(1000, 10 ** 6) == 10          # tiny blocks: the minimum, 1,024 bits
     assert L.emu_chunk_shift(400_000, 48_960) in (11, 12)   # a 1080p 4:2:0 file of 400 kB: 65 bits per block -> 4,096 bits
-    assert L.emu_chunk_shift(10 ** 7, 1000) == 13           # huge blocks: capped at 8,192 bits
+    assert L.emu_chunk_shift(10 ** 7, 1000) == 15           # huge blocks: capped at 32,768 bits
     assert L.emu_chunk_shift(0, 0) == 10
     prev = 10
     for kb in range(1, 4000, 37):  # monotonic in the stream size
