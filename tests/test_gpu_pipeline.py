@@ -175,7 +175,7 @@ def _pil_plain(w, h, subsampling, gray=False, seed=0, quality=85):
     return buf.getvalue()
 
 
-def test_pipeline_device_entropy_decoder_streams_without_restart_markers():
+def test_pipeline_device_entropy_decoder_streams_without_restart_markers(monkeypatch):
     """Ordinary baseline files (no DRI) entropy-decoded on the GPU by the self-synchronising chunk decoder — every sequential
     file of the reference's corpora in one call, encoder-written streams of several geometries (single chunk ... thousands
     of chunks), damaged streams the device must hand back or decode exactly like the host: results equal the oracle's."""
@@ -224,4 +224,21 @@ def test_pipeline_device_entropy_decoder_streams_without_restart_markers():
     _check([f"same-{i}" for i in range(20)], same, out)
     t = p.timings()
     assert t["images_device_entropy"] == 20 and t["images_device_rejected"] == 0, t
+    # blocks of many hundred bits (noise at quality 100: no end-of-block symbols to re-synchronise on) are not worth the
+    # chunk decoder's passes: the pipeline keeps them on the host; forced onto the device they still come out right
+    # (settled late, or flagged and re-decoded)
+    import io
+    from PIL import Image
+    noise = []
+    for sd in range(3):
+        buf = io.BytesIO()
+        Image.fromarray(np.random.default_rng(sd).integers(0, 256, (96, 160, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=100, subsampling="4:4:4")
+        noise.append(buf.getvalue())
+    out = p.decode(noise + same[:2], device_entropy=True)
+    _check([f"noise-{i}" for i in range(5)], noise + same[:2], out)
+    assert p.timings()["images_device_entropy"] == 2, p.timings()
+    monkeypatch.setenv("JPGPU_PIPE_FORCE_DEVICE", "1")
+    out = p.decode(noise + same[:2], device_entropy=True)
+    _check([f"noise-forced-{i}" for i in range(5)], noise + same[:2], out)
+    assert p.timings()["images_device_entropy"] == 5, p.timings()
     p.close()
