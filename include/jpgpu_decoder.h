@@ -106,6 +106,10 @@ enum {
                                    * segment (src/decoder.rs:920-956: segments are independent), without them the
                                    * self-synchronising chunk decoder (one lane per 128 bytes, csrc/huff_sync_core.hpp); every
                                    * other stream, and any stream the device decoder flags, takes the host path */
+    , JPGPU_PIPELINE_PROGRESSIVE_DELTAS = 8u /* progressive streams (host-decoded): accumulate the coefficients ON THE DEVICE —
+                                   * after every scan the host sends what the scan changed (jpgpu_batch_add_deltas) instead of
+                                   * the finished planes at the end; same pixels (A/B switch, off by default:
+                                   * more PCIe bytes than the compact planes and nothing off the critical path) */
 };
 
 /* n_threads 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if there is one. */

@@ -57,7 +57,7 @@ class PipelineTimings(C.Structure):
                 ("pixel_bytes", C.c_uint64), ("images_device_entropy", C.c_uint32), ("images_device_rejected", C.c_uint32)]
 
 
-PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY = 1, 2, 4
+PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_PROGRESSIVE_DELTAS = 1, 2, 4, 8
 
 
 class ImageInfoStruct(C.Structure):
@@ -109,6 +109,8 @@ _PROTOS = {
     "jpgpu_batch_set_range_hint": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
     "jpgpu_batch_set_range_class": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "jpgpu_batch_scan_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jpgpu_batch_clear_coefficients": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "jpgpu_batch_add_deltas": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_range_class": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_batch_set_quantization_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "jpgpu_compact_max_bytes": (C.c_size_t, [C.c_size_t]),

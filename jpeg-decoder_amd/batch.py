@@ -95,6 +95,16 @@ class Batch:
         """0 unknown/hostile, 1 every |c*q| < 2^15, 3 additionally every block-column sum of |c*q| <= 5900."""
         self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, int(range_class)))
 
+    def clear_coefficients(self, image, stream=None):
+        self._check(N.lib().jpgpu_batch_clear_coefficients(self._h, image, stream))
+
+    def add_deltas(self, image, comp, index, delta, stream=None):
+        """coefficient[index[k]] += delta[k] on the device (progressive accumulation, include/jpgpu.h); blocks until done."""
+        e = np.empty(len(index), dtype=[("index", np.uint32), ("delta", np.int32)])
+        e["index"], e["delta"] = index, delta
+        self._check(N.lib().jpgpu_batch_add_deltas(self._h, image, comp, e.ctypes.data, len(e), stream))
+        self.synchronize(stream)  # `e` is about to go away
+
     def scan_ranges(self, stream=None):
         """Range classes from the coefficients as they stand in the device arena (one pass at HBM speed): [image][comp]."""
         out = np.zeros((self.n_images, 4), np.uint8)

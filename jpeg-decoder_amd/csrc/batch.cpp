@@ -306,6 +306,50 @@ int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, i
     return JPGPU_OK;
 }
 
+int jpgpu_batch_clear_coefficients(jpgpu_batch *b, uint32_t image, void *hip_stream) {
+    if (!b || image >= b->descs.size()) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    const uint32_t nc = b->descs[image].ncomp;
+    const size_t first = b->coef_off[(size_t)image * 4], last = b->coef_off[(size_t)image * 4 + nc - 1] + b->coef_len[(size_t)image * 4 + nc - 1];
+    B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, (hipStream_t)hip_stream));
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const jpgpu_coef_delta *entries, size_t n, void *hip_stream) {
+    return jpgpu::batch_add_deltas(b, image, comp, entries, n, hip_stream, false);
+}
+
+}  // extern "C"
+
+int jpgpu::batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const jpgpu_coef_delta *entries, size_t n, void *hip_stream, bool trusted) {
+    if (!b || image >= b->descs.size() || comp >= b->descs[image].ncomp || (!entries && n)) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    const size_t idx = (size_t)image * 4 + comp, plane = b->coef_len[idx] / sizeof(int16_t);
+    if (n > 0xFFFFFFFFu) return set_err(b->err, JPGPU_ERR_FORMAT, "add_deltas: too many entries");
+    for (size_t k = 0; !trusted && k < n; k++)
+        if (entries[k].index >= plane) return set_err(b->err, JPGPU_ERR_FORMAT, "add_deltas: index outside the component's plane");
+    if (b->sane[idx] != 0) {
+        b->sane[idx] = 0;
+        b->jobs_dirty = true;
+    }
+    if (n == 0) return JPGPU_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    jpgpu_coef_delta *d = nullptr;
+    B_HIP(hipMallocAsync((void **)&d, n * sizeof(jpgpu_coef_delta), s));
+    hipError_t e = hipMemcpyAsync(d, entries, n * sizeof(jpgpu_coef_delta), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_delta_add(d, (uint32_t)n, reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]), (uint32_t)plane, s);
+    const hipError_t f = hipFreeAsync(d, s);
+    if (e == hipSuccess) e = f;
+    if (e != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "add_deltas: %s", hipGetErrorString(e));
+    return JPGPU_OK;
+}
+
+extern "C" {
+
 int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) {
     if (!b) return JPGPU_ERR_FORMAT;
     int rc = use_device(b->device, b->err);

@@ -379,6 +379,13 @@ struct Frontend::Impl {
     std::vector<uint8_t> exif, xmp;
     std::vector<IccChunk> icc;
     std::vector<PlannedScan> *plan = nullptr;  // plan_device_scans: describe scans instead of decoding them
+    // RowSink::scan_deltas: where the block decoders note what they change (null: nobody asked)
+    std::vector<ScanDelta> *rec = nullptr;
+    const int16_t *rec_base = nullptr;  // start of the plane the current block belongs to
+    inline void put(int16_t &c, int16_t v) {
+        if (rec && v != c) rec->push_back(ScanDelta{(uint32_t)(&c - rec_base), (int32_t)v - (int32_t)c});
+        c = v;
+    }
 
     size_t read_length() {  // src/parser.rs:137-147
         const uint16_t l = src.u16be();
@@ -643,7 +650,7 @@ struct Frontend::Impl {
             if (cat > 11) fail(JPGPU_ERR_FORMAT, "invalid DC difference magnitude category");
             if (cat) diff = br.receive_extend(src, cat);
             pred = (int16_t)((uint16_t)pred + (uint16_t)diff);  // wrapping_add
-            co[0] = (int16_t)((uint16_t)pred << s.al);
+            put(co[0], (int16_t)((uint16_t)pred << s.al));
         }
         uint8_t k = std::max<uint8_t>(s.ss_start, 1);
         if (k < s.ss_end && eob_run > 0) {
@@ -660,7 +667,7 @@ struct Frontend::Impl {
                     break;
                 }
                 br.consume(total_bits);
-                co[kUnzigzag[k++]] = (int16_t)((uint16_t)v << s.al);
+                put(co[kUnzigzag[k++]], (int16_t)((uint16_t)v << s.al));
                 continue;
             }
             const uint8_t rs = br.decode(src, *act), r = rs >> 4, sz = rs & 15;
@@ -675,7 +682,10 @@ struct Frontend::Impl {
             }
             k = (uint8_t)(k + r);
             if (k >= s.ss_end) break;
-            co[kUnzigzag[k++]] = (int16_t)((uint16_t)br.receive_extend(src, sz) << s.al);
+            {
+                const int16_t v2 = (int16_t)((uint16_t)br.receive_extend(src, sz) << s.al);
+                put(co[kUnzigzag[k++]], v2);
+            }
         }
     }
 
@@ -688,7 +698,7 @@ struct Frontend::Impl {
             } else if (br.get_bits(src, 1) == 1 && (c & bit) == 0) {
                 const int32_t v = c > 0 ? (int32_t)c + bit : (int32_t)c - bit;
                 if (v > 32767 || v < -32768) fail(JPGPU_ERR_FORMAT, "Coefficient overflow");
-                c = (int16_t)v;
+                put(c, (int16_t)v);
             }
         }
         return (uint8_t)(end - 1);
@@ -697,7 +707,7 @@ struct Frontend::Impl {
     void decode_block_refine(int16_t *co, BitReader &br, const HuffTable *act, const ScanInfo &s, uint16_t &eob_run) {
         const int16_t bit = (int16_t)(1 << s.al);  // :1174-1258
         if (s.ss_start == 0) {
-            if (br.get_bits(src, 1) == 1) co[0] |= bit;
+            if (br.get_bits(src, 1) == 1) put(co[0], (int16_t)(co[0] | bit));
             return;
         }
         if (eob_run > 0) {
@@ -722,7 +732,7 @@ struct Frontend::Impl {
                 fail(JPGPU_ERR_FORMAT, "unexpected huffman code");
             }
             k = refine_non_zeroes(co, br, k, s.ss_end, zrl, bit);
-            if (value != 0) co[kUnzigzag[k]] = value;
+            if (value != 0) put(co[kUnzigzag[k]], value);
             k++;
         }
     }
@@ -894,6 +904,12 @@ struct Frontend::Impl {
 
         const bool progressive = f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE;
         const bool interleaved = nc > 1;
+        const bool want_deltas = progressive && sink.wants_scan_deltas();
+        std::vector<ScanDelta> deltas[JPGPU_MAX_COMPONENTS];
+        struct RecOff {  // (the block decoders must not record into a vector that is gone)
+            Impl *self;
+            ~RecOff() { self->rec = nullptr; }
+        } rec_off{this};
         int16_t dummy[64];
         memset(dummy, 0, sizeof(dummy));
         BitReader br;
@@ -941,6 +957,8 @@ struct Frontend::Impl {
                                 auto &store = coefficients[scan.component_indices[i]];
                                 if (off + 64 > store.size()) fail(JPGPU_ERR_INTERNAL, "reference would panic: coefficient index");
                                 co = store.data() + off;
+                                rec = want_deltas ? &deltas[i] : nullptr;
+                                rec_base = store.data();
                             } else if (finished[i]) {
                                 const uint32_t batch_row = interleaved ? 0 : my % c.vertical_sampling_factor;
                                 const size_t by = (size_t)batch_row * vs[i] + vp, bx = (size_t)mx * hs[i] + hp;
@@ -971,6 +989,9 @@ struct Frontend::Impl {
                 }
             }
         }
+        rec = nullptr;
+        if (want_deltas)
+            for (int i = 0; i < nc; i++) sink.scan_deltas((uint32_t)scan.component_indices[i], deltas[i].data(), deltas[i].size());
         Marker m;
         bool has = br.take_marker(src, m);
         while (has && m.kind == Mk::RST) {  // :1063-1066  marker = self.read_marker().ok()

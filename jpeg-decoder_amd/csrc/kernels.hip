@@ -76,7 +76,26 @@ __global__ __launch_bounds__(256) void expand_compact_kernel(const ExpandJob *__
     *reinterpret_cast<JP_GLOBAL v4u *>((JP_GLOBAL uint8_t *)job.dense + (size_t)b * 128u + r * 16u) = row;
 }
 
+// Progressive accumulation on the device: coefficient[index] += delta for the changes one scan made to
+// one component plane.  One lane per entry; a scan touches a coefficient at most once (host front-end, RowSink::scan_deltas),
+// so no atomics — launches of consecutive scans are ordered by their stream.  i16 wrapping add: the sum of all deltas is the
+// coefficient the host accumulated, which fits.
+__global__ __launch_bounds__(256) void delta_add_kernel(const jpgpu_coef_delta *__restrict__ d, uint32_t n, int16_t *__restrict__ plane,
+                                                        uint32_t plane_coefficients) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const jpgpu_coef_delta e = d[i];
+    if (e.index >= plane_coefficients) return;  // (checked on the host as well)
+    plane[e.index] = (int16_t)(uint16_t)((uint32_t)(uint16_t)plane[e.index] + (uint32_t)e.delta);
+}
+
 // ---- launchers ---------------------------------------------------------------------------
+hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    delta_add_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, stream>>>(d_entries, n, d_plane, plane_coefficients);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand_compact(const ExpandJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, hipStream_t stream) {
     if (n_jobs == 0 || max_blocks == 0) return hipSuccess;
     dim3 grid((max_blocks * 8u + 255u) / 256u, n_jobs), block(256);

@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/jpgpu.h"
 #include "jobs.hpp"
 
 namespace jpgpu {
 
 struct ExpandJob;
+hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, hipStream_t stream);
 hipError_t launch_expand_compact(const ExpandJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, hipStream_t stream);
 hipError_t launch_idct_planes(const PlaneJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t scale,
                               hipStream_t stream);

@@ -182,3 +182,32 @@ def test_mutated_streams_same_outcome_as_oracle(rel):
         else:
             n_err += 1
     assert n_ok >= 10 and n_err >= 5, (n_ok, n_err)
+
+
+def test_progressive_scan_deltas_add_up_to_the_accumulated_planes():
+    """RowSink::scan_deltas (SURVEY §8f n3: every progressive update is coefficient += delta): a sink that adds up what each
+    scan reports ends with exactly the planes the front-end appends at the end — for every file of the corpora (incl. the
+    partial / missing-scan ones), every coefficient at most once per scan; sequential files report nothing."""
+    import ctypes as C
+    import glob
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import emu
+    L = emu.lib()
+    n_prog = 0
+    for name in ALL_GOOD + sorted(glob.glob(os.path.join(R.GOLDEN, "benches", "*.jp*g"))):
+        data = open(name, "rb").read()
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        calls, prog = C.c_int(0), C.c_int(0)
+        got = L.emu_progressive_deltas(buf, len(data), C.byref(calls), C.byref(prog))
+        if got == -4:
+            continue  # the stream fails to decode (crash corpus): nothing to compare
+        assert got >= 0, (name, got)
+        if prog.value:
+            n_prog += 1
+            assert calls.value >= 1, name
+            if "missing" not in name and "partial" not in name:
+                assert got > 0, name
+        else:
+            assert got == 0 and calls.value == 0, name
+    assert n_prog >= 6
