@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace jpgpu {
 namespace host {
@@ -356,6 +357,58 @@ void update_component_sizes(uint16_t w, uint16_t h, std::vector<jpgpu_component>
 
 }  // namespace
 
+// The accumulation planes of progressive frames (2 bytes per coefficient: 6 MB for a 1080p image) come from a small pool:
+// fresh vectors of that size are mmap'ed, page-faulted in and munmap'ed again by the allocator — with a few dozen decoder
+// threads that was 30-45 % of the time a batch of progressive files took (it showed up in the NEXT call's header phase,
+// where the previous call's front-ends are destroyed).  JPGPU_HOST_POOL_MB bounds what the pool keeps (default 1024).
+namespace {
+class CoefPool {
+public:
+    std::vector<int16_t> take(size_t n) {
+        std::vector<int16_t> v;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].capacity() >= n && free_[i].capacity() <= n + n / 4 + 4096) {
+                    v.swap(free_[i]);
+                    bytes_ -= v.capacity() * sizeof(int16_t);
+                    free_[i].swap(free_.back());
+                    free_.pop_back();
+                    break;
+                }
+        }
+        v.assign(n, 0);
+        return v;
+    }
+    void give(std::vector<int16_t> &v) {
+        const size_t b = v.capacity() * sizeof(int16_t);
+        if (b < (256u << 10)) return;  // small ones are the allocator's business
+        std::lock_guard<std::mutex> g(m_);
+        if (bytes_ + b > limit()) return;
+        bytes_ += b;
+        free_.emplace_back();
+        free_.back().swap(v);
+    }
+
+private:
+    static size_t limit() {
+        static const size_t l = [] {
+            const char *e = getenv("JPGPU_HOST_POOL_MB");
+            const long mb = e ? atol(e) : 1024;
+            return (size_t)(mb < 0 ? 0 : mb) << 20;
+        }();
+        return l;
+    }
+    std::mutex m_;
+    std::vector<std::vector<int16_t>> free_;
+    size_t bytes_ = 0;
+};
+CoefPool &coef_pool() {
+    static CoefPool *p = new CoefPool;  // (never destroyed: front-ends may outlive static destruction order)
+    return *p;
+}
+}  // namespace
+
 struct Frontend::Impl {
     std::vector<uint8_t> bytes;
     ByteSource src;
@@ -371,6 +424,9 @@ struct Frontend::Impl {
     bool is_jfif = false, is_mjpeg = false;
     size_t buffer_limit = (size_t)-1;
     std::vector<int16_t> coefficients[JPGPU_MAX_COMPONENTS];  // progressive accumulation
+    ~Impl() {
+        for (auto &c : coefficients) coef_pool().give(c);
+    }
     bool have_coefficients = false;
     uint64_t finished_mask[JPGPU_MAX_COMPONENTS] = {0, 0, 0, 0};
     bool plane_present[JPGPU_MAX_COMPONENTS] = {false, false, false, false};
@@ -1038,7 +1094,7 @@ struct Frontend::Impl {
                 const FrameInfo &f = frame;
                 if (f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE && !have_coefficients) {
                     for (size_t i = 0; i < f.components.size(); i++)
-                        coefficients[i].assign((size_t)f.components[i].block_width * f.components[i].block_height * 64, 0);
+                        coefficients[i] = coef_pool().take((size_t)f.components[i].block_width * f.components[i].block_height * 64);
                     have_coefficients = true;
                 }
                 if (f.coding_process == JPGPU_CODING_LOSSLESS)
