@@ -383,8 +383,15 @@ public:
     void give(std::vector<int16_t> &v) {
         const size_t b = v.capacity() * sizeof(int16_t);
         if (b < (256u << 10)) return;  // small ones are the allocator's business
+        std::vector<std::vector<int16_t>> evicted;  // (freed after the lock is released)
         std::lock_guard<std::mutex> g(m_);
-        if (bytes_ + b > limit()) return;
+        if (b > limit()) return;
+        while (bytes_ + b > limit() && !free_.empty()) {  // the oldest go first: sizes nobody asks for any more do not pile up
+            bytes_ -= free_.front().capacity() * sizeof(int16_t);
+            evicted.emplace_back();
+            evicted.back().swap(free_.front());
+            free_.erase(free_.begin());
+        }
         bytes_ += b;
         free_.emplace_back();
         free_.back().swap(v);
