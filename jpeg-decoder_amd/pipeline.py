@@ -29,11 +29,11 @@ class Pipeline:
 
     __del__ = close
 
-    def decode(self, streams, download=True, dense=False, device_entropy=False, progressive_deltas=False):
+    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False):
         """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
         ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``); dense=True sends all
         64 coefficients of every block over PCIe instead of the compact form (same pixels, A/B switch); device_entropy=True
-        decodes 8-bit sequential Huffman streams (one scan with all components; with or without restart markers) on the
+        (the default here; JPGPU_PIPELINE_DEVICE_ENTROPY in the C API) decodes 8-bit sequential Huffman streams (one scan with all components; with or without restart markers) on the
         GPU, all other streams — and any the device decoder flags — on the host as usual; progressive_deltas=True accumulates
         the coefficients of progressive streams on the device, scan by scan (same pixels; A/B switch)."""
         L = N.lib()

@@ -53,11 +53,15 @@ def test_pipeline_mixed_files_one_call():
     _check(names, files, out)
     t = p.timings()
     assert t["images_ok"] == len(files) - with_errors and t["total_ms"] > 0
+    assert t["images_device_entropy"] >= 10  # (Pipeline.decode's default: sequential streams are entropy-decoded on the device)
+    out_h = p.decode(files, device_entropy=False)  # everything through the host decoder
+    _check(names, files, out_h)
+    assert p.timings()["images_device_entropy"] == 0
 
     # the same pipeline object, different batch afterwards; then the dense transport (A/B switch)
     out2 = p.decode(files[:5])
     _check(names[:5], files[:5], out2)
-    out3 = p.decode(files, dense=True)
+    out3 = p.decode(files, dense=True, device_entropy=False)
     _check(names, files, out3)
     assert p.timings()["coefficient_bytes"] > t["coefficient_bytes"]
     p.close()
@@ -146,7 +150,7 @@ def test_pipeline_device_entropy_decoder_matches_host_path(monkeypatch):
     _check(names, files, out)
     t = p.timings()
     assert t["images_device_entropy"] >= 12, t  # the restart streams did go to the device
-    out_host = p.decode(files)
+    out_host = p.decode(files, device_entropy=False)
     _check(names, files, out_host)
     # same-geometry restart streams: fused kernels after the device entropy decoder
     same = [_pil_restart(320, 240, "4:2:0", 1, 0, seed=s) for s in range(9)]
@@ -256,7 +260,7 @@ def test_pipeline_progressive_accumulation_on_the_device():
     names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
     files = [open(n, "rb").read() for n in names]
     p = J.Pipeline(threads=8)
-    out = p.decode(files, progressive_deltas=True)
+    out = p.decode(files, progressive_deltas=True, device_entropy=False)
     _check(names, files, out)
     out = p.decode(files, progressive_deltas=True, device_entropy=True)
     _check(names, files, out)
