@@ -1,11 +1,15 @@
 // decoder_api.cpp — C ABI of include/jpgpu_decoder.h: the crate's `Decoder` surface
 // (src/decoder.rs:101-295) = host front-end (frontend.cpp) + MI355X pixel backend (jpgpu.h).
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
+#include "../host_common.hpp"
 #include "frontend.hpp"
 
 using jpgpu::host::DecodeError;
@@ -21,9 +25,25 @@ public:
     void check(int rc) {
         if (rc) throw DecodeError{rc, jpgpu_worker_last_error(w_)};
     }
-    void start(uint32_t index, const jpgpu_component &c, const uint16_t qt[64]) override { check(jpgpu_worker_start(w_, index, &c, qt)); }
-    void append_row(uint32_t index, const int16_t *co, size_t len) override { check(jpgpu_worker_append_row(w_, index, co, len)); }
-    void finish(uint32_t index, uint32_t slot) override { check(jpgpu_worker_finish_plane(w_, index, slot)); }
+    void start(uint32_t index, const jpgpu_component &c, const uint16_t qt[64]) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        check(jpgpu_worker_start(w_, index, &c, qt));
+        other_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void append_row(uint32_t index, const int16_t *co, size_t len) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        check(jpgpu_worker_append_row(w_, index, co, len));
+        append_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        appends++;
+    }
+    double append_ms = 0;  // (JPGPU_DECODER_TRACE)
+    size_t appends = 0;
+    void finish(uint32_t index, uint32_t slot) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        check(jpgpu_worker_finish_plane(w_, index, slot));
+        other_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    double other_ms = 0;  // start + finish_plane (JPGPU_DECODER_TRACE)
 
 private:
     jpgpu_worker *w_;
@@ -43,6 +63,39 @@ public:
     }
 };
 
+}  // namespace
+
+// Idle workers per device: a Decoder borrows one for its decode() and hands it back with its streams, pinned staging and
+// device buffers intact — creating those for every image was 4-5 ms, more than decoding a 512x512 image takes.
+namespace {
+struct WorkerPool {
+    std::mutex m;
+    std::vector<std::pair<int, jpgpu_worker *>> idle;
+    jpgpu_worker *take(int device) {
+        std::lock_guard<std::mutex> g(m);
+        for (size_t k = 0; k < idle.size(); k++)
+            if (idle[k].first == device) {
+                jpgpu_worker *w = idle[k].second;
+                idle.erase(idle.begin() + (long)k);
+                return w;
+            }
+        return nullptr;
+    }
+    void give(int device, jpgpu_worker *w) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (idle.size() < 16) {
+                idle.emplace_back(device, w);
+                return;
+            }
+        }
+        jpgpu_worker_destroy(w);
+    }
+};
+WorkerPool &worker_pool() {
+    static WorkerPool *p = new WorkerPool;  // (never destroyed: the HIP runtime may be gone before static destructors run)
+    return *p;
+}
 }  // namespace
 
 struct jpgpu_decoder {
@@ -134,22 +187,34 @@ int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len
     if (!d->decoded) {
         try {
             if (d->device < 0) throw DecodeError{JPGPU_ERR_NO_DEVICE, "decoder was created without a device (host-only)"};
+            if (!d->worker) d->worker = worker_pool().take(d->device);
             if (!d->worker) {
                 int rc = jpgpu_worker_create(d->device, &d->worker);
                 if (rc) throw DecodeError{rc, "no usable MI355X device: the pixel pipeline has no CPU fallback"};
             }
+            const bool trace = getenv("JPGPU_DECODER_TRACE") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
             GpuSink sink(d->worker);
             d->fe->decode_to(sink);
+            const double t_decode = ms_since(t0);
             const uint32_t n = d->fe->ncomp();
             const jpgpu_component *comps = d->fe->components();
             const uint16_t w = d->fe->output_width(), h = d->fe->output_height();
             const size_t out_len = n == 1 ? (size_t)comps[0].size_width * comps[0].size_height : (size_t)w * h * n;
+            const auto t1 = std::chrono::steady_clock::now();
             d->pixels.resize(out_len ? out_len : 1);
+            const double t_alloc = ms_since(t1);
+            const auto t2 = std::chrono::steady_clock::now();
             size_t got = 0;
             sink.check(jpgpu_compute_image(d->worker, comps, n, nullptr, w, h, d->fe->color_transform(), d->pixels.data(),
                                            d->pixels.size(), &got));
             d->pixels.resize(got);
+            if (trace) fprintf(stderr, "decoder trace: entropy decoding + row uploads %.2f ms (of which %zu append_row calls %.2f ms, start + finish_plane %.2f ms), result buffer %.2f ms, compute_image + download %.2f ms\n", t_decode, sink.appends, sink.append_ms, sink.other_ms, t_alloc, ms_since(t2));
             d->decoded = true;
+            jpgpu::worker_recycle(d->worker);
+            worker_pool().give(d->device, d->worker);  // the pixels are on the host: the next Decoder may have the worker
+            d->worker = nullptr;
         } catch (const DecodeError &e) {
             return fail(d, e);
         }

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -75,28 +76,88 @@ struct jpgpu_worker {
         size_t pinned_cap = 0;
         uint8_t *d_plane = nullptr;
         size_t plane_cap = 0;
+        uint16_t *h_qt = nullptr;  // pinned copies of the callers' tables (a ring of QT_RING): the upload does not have to finish before
+                                   // start() returns, and start() does not have to wait for the stream (a wait on an idle GPU costs ~8 ms)
+        uint32_t qt_next = 0, qt_unsynced = 0;
+        hipEvent_t uploaded = nullptr;  // recorded behind the last row upload of the slot's previous use (non-interleaved and
+        bool upload_pending = false;    // progressive scans reuse worker index 0 for one component after the other)
         size_t rows = 0;      // MCU rows appended since start()
+        size_t sent_rows = 0; // MCU rows whose upload has been enqueued
         size_t idct_rows = 0; // MCU rows already transformed
     } slot[JPGPU_MAX_COMPONENTS];
     struct Frame {
         uint8_t *d_plane = nullptr;
-        size_t len = 0;
+        size_t len = 0, cap = 0;
     } frame[JPGPU_MAX_COMPONENTS];
+    // planes that went out of use (a frame slot was overwritten): start() takes them back instead of allocating —
+    // a worker that decodes image after image reaches a state without any hipMalloc / hipFree (each a device-wide sync)
+    std::vector<std::pair<uint8_t *, size_t>> spare_planes;
     uint8_t *d_out = nullptr;
     size_t out_cap = 0;
+    uint8_t *h_out = nullptr;  // pinned bounce buffer for results going to pageable memory (see worker_download)
+    size_t h_out_cap = 0;
     uint8_t *d_tmp[JPGPU_MAX_COMPONENTS] = {nullptr, nullptr, nullptr, nullptr};
     size_t tmp_cap[JPGPU_MAX_COMPONENTS] = {0, 0, 0, 0};
 };
 
+// JPGPU_WORKER_TRACE=1: report runtime calls of the Worker that take longer than 0.2 ms (diagnostics)
+static const bool g_worker_trace = getenv("JPGPU_WORKER_TRACE") != nullptr;
 #define W_HIP(call)                                                                                     \
     do {                                                                                                \
+        const auto _t0 = std::chrono::steady_clock::now();                                              \
         hipError_t _e = (call);                                                                         \
+        if (g_worker_trace) {                                                                           \
+            const double _ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - _t0).count(); \
+            if (_ms > 0.2) fprintf(stderr, "worker trace: %.2f ms  %s (%s)\n", _ms, #call, __func__);      \
+        }                                                                                               \
         if (_e != hipSuccess) return set_err(w->err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(_e)); \
     } while (0)
+
+// rows staged in pinned memory but not yet on their way: one copy for all of them (a copy per MCU row was 200 enqueues per
+// 1080p image)
+static int worker_send_rows(jpgpu_worker *w, uint32_t index) {
+    auto &s = w->slot[index];
+    if (s.sent_rows == s.rows) return JPGPU_OK;
+    const size_t per_row = (size_t)s.c.block_width * s.c.vertical_sampling_factor * 64;
+    W_HIP(hipMemcpyAsync(s.d_coefs + s.sent_rows * per_row, s.h_pinned + s.sent_rows * per_row, (s.rows - s.sent_rows) * per_row * sizeof(int16_t),
+                         hipMemcpyHostToDevice, w->stream));
+    s.sent_rows = s.rows;
+    return JPGPU_OK;
+}
+
+// Device -> caller's buffer, then wait.  A copy straight into pageable memory ran at 0.5 GB/s (10 MB: 20 ms — the runtime pins
+// the destination page by page); through a pinned buffer of the worker's and a memcpy it is PCIe speed plus ~10 GB/s.
+static int worker_download(jpgpu_worker *w, uint8_t *dst, const uint8_t *d_src, size_t n) {
+    if (n == 0) {
+        W_HIP(hipStreamSynchronize(w->stream));
+        return JPGPU_OK;
+    }
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();  // (an ordinary pointer is "invalid value" to the query: not an error here)
+    if (pinned || n < (64u << 10)) {
+        W_HIP(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, w->stream));
+        W_HIP(hipStreamSynchronize(w->stream));
+        return JPGPU_OK;
+    }
+    if (w->h_out_cap < n) {
+        if (w->h_out) W_HIP(hipHostFree(w->h_out));
+        w->h_out = nullptr;
+        w->h_out_cap = 0;
+        W_HIP(hipHostMalloc((void **)&w->h_out, n + n / 4, hipHostMallocDefault));
+        w->h_out_cap = n + n / 4;
+    }
+    W_HIP(hipMemcpyAsync(w->h_out, d_src, n, hipMemcpyDeviceToHost, w->stream));
+    W_HIP(hipStreamSynchronize(w->stream));
+    memcpy(dst, w->h_out, n);
+    return JPGPU_OK;
+}
 
 static int worker_run_idct(jpgpu_worker *w, uint32_t index) {
     auto &s = w->slot[index];
     if (s.rows == s.idct_rows) return JPGPU_OK;
+    int rc0 = worker_send_rows(w, index);
+    if (rc0) return rc0;
     const size_t blocks_per_row = (size_t)s.c.block_width * s.c.vertical_sampling_factor;
     const size_t row_bytes = blocks_per_row * s.c.dct_scale * s.c.dct_scale;
     PlaneJob job{};
@@ -110,6 +171,19 @@ static int worker_run_idct(jpgpu_worker *w, uint32_t index) {
     W_HIP(launch_idct_plane_one(job, w->stream));
     s.idct_rows = s.rows;
     return JPGPU_OK;
+}
+
+// Forget the planes of the image just finished (a recycled worker must not offer them to the next image's compute_image:
+// "not all components have data" has to stay what it is); their memory stays with the worker.
+void jpgpu::worker_recycle(jpgpu_worker *w) {
+    if (!w) return;
+    for (auto &f : w->frame) {
+        if (f.d_plane) w->spare_planes.emplace_back(f.d_plane, f.cap);
+        f.d_plane = nullptr;
+        f.len = f.cap = 0;
+    }
+    for (auto &s : w->slot) s.started = false;
+    w->err.clear();
 }
 
 extern "C" {
@@ -139,13 +213,17 @@ void jpgpu_worker_destroy(jpgpu_worker *w) {
             if (s.d_qt) hipFree(s.d_qt);
             if (s.d_coefs) hipFree(s.d_coefs);
             if (s.h_pinned) hipHostFree(s.h_pinned);
+            if (s.h_qt) hipHostFree(s.h_qt);
+            if (s.uploaded) hipEventDestroy(s.uploaded);
             if (s.d_plane) hipFree(s.d_plane);
         }
+        for (auto &sp : w->spare_planes) hipFree(sp.first);
         for (auto &f : w->frame)
             if (f.d_plane) hipFree(f.d_plane);
         for (auto &t : w->d_tmp)
             if (t) hipFree(t);
         if (w->d_out) hipFree(w->d_out);
+        if (w->h_out) hipHostFree(w->h_out);
         hipStreamDestroy(w->stream);
     }
     delete w;
@@ -170,10 +248,23 @@ int jpgpu_worker_start(jpgpu_worker *w, uint32_t index, const jpgpu_component *c
     s.rows = s.idct_rows = 0;
     const size_t pbytes = plane_bytes(c);
     const size_t cbytes = (size_t)c.block_width * c.block_height * 64 * sizeof(int16_t);
+    s.sent_rows = 0;
+    if (s.upload_pending) {  // the staging memory below is about to be overwritten: its last upload must have left it
+        W_HIP(hipEventSynchronize(s.uploaded));
+        s.upload_pending = false;
+    }
     if (!s.d_qt) W_HIP(hipMalloc((void **)&s.d_qt, 128));
-    W_HIP(hipMemcpyAsync(s.d_qt, quantization_table, 128, hipMemcpyHostToDevice, w->stream));
-    // the table is caller-owned (Arc<[u16;64]>): finish reading it before returning
-    W_HIP(hipStreamSynchronize(w->stream));
+    constexpr uint32_t QT_RING = 16;
+    if (!s.h_qt) W_HIP(hipHostMalloc((void **)&s.h_qt, 128 * QT_RING, hipHostMallocDefault));
+    if (s.qt_unsynced >= QT_RING - 1) {  // sixteen start() calls on this slot without a get_result / compute_image in between
+        W_HIP(hipStreamSynchronize(w->stream));
+        s.qt_unsynced = 0;
+    }
+    // the table is caller-owned (Arc<[u16;64]>): keep a copy the upload can read after start() has returned
+    uint16_t *hq = s.h_qt + 64 * (s.qt_next++ % QT_RING);
+    s.qt_unsynced++;
+    memcpy(hq, quantization_table, 128);
+    W_HIP(hipMemcpyAsync(s.d_qt, hq, 128, hipMemcpyHostToDevice, w->stream));
     if (s.coef_cap < cbytes) {
         if (s.d_coefs) W_HIP(hipFree(s.d_coefs));
         s.d_coefs = nullptr;
@@ -189,14 +280,27 @@ int jpgpu_worker_start(jpgpu_worker *w, uint32_t index, const jpgpu_component *c
         s.pinned_cap = std::max<size_t>(cbytes, 256);
     }
     if (!s.d_plane || s.plane_cap < pbytes) {
-        if (s.d_plane) W_HIP(hipFree(s.d_plane));
+        if (s.d_plane) w->spare_planes.emplace_back(s.d_plane, s.plane_cap);
         s.d_plane = nullptr;
         s.plane_cap = 0;
-        W_HIP(hipMalloc((void **)&s.d_plane, std::max<size_t>(pbytes, 256)));
-        s.plane_cap = std::max<size_t>(pbytes, 256);
+        for (size_t k = 0; k < w->spare_planes.size(); k++)
+            if (w->spare_planes[k].second >= pbytes && w->spare_planes[k].second <= 2 * std::max<size_t>(pbytes, 256)) {
+                s.d_plane = w->spare_planes[k].first;
+                s.plane_cap = w->spare_planes[k].second;
+                w->spare_planes.erase(w->spare_planes.begin() + (long)k);
+                break;
+            }
+        if (!s.d_plane) {
+            while (w->spare_planes.size() > 8) {  // sizes nobody asks for any more
+                W_HIP(hipFree(w->spare_planes.front().first));
+                w->spare_planes.erase(w->spare_planes.begin());
+            }
+            W_HIP(hipMalloc((void **)&s.d_plane, std::max<size_t>(pbytes, 256)));
+            s.plane_cap = std::max<size_t>(pbytes, 256);
+        }
     }
-    // results[index].resize(elements, 0u8) — rows never appended stay 0 (src/worker/rayon.rs:40-49)
-    W_HIP(hipMemsetAsync(s.d_plane, 0, std::max<size_t>(pbytes, 1), w->stream));
+    // results[index].resize(elements, 0u8) — rows never appended stay 0 (src/worker/rayon.rs:40-49): the transform writes
+    // every appended row completely, finish_plane clears what is left
     s.started = true;
     return JPGPU_OK;
 }
@@ -214,11 +318,10 @@ int jpgpu_worker_append_rows(jpgpu_worker *w, uint32_t index, const int16_t *coe
     const size_t total_rows = s.c.block_height / s.c.vertical_sampling_factor;
     if (s.rows + n_rows > total_rows)
         return set_err(w->err, JPGPU_ERR_INTERNAL, "reference would panic: append_row beyond the plane");
-    int16_t *stage = s.h_pinned + s.rows * per_row;
-    memcpy(stage, coefficients, n_rows * per_row * sizeof(int16_t));
-    W_HIP(hipMemcpyAsync(s.d_coefs + s.rows * per_row, stage, n_rows * per_row * sizeof(int16_t), hipMemcpyHostToDevice,
-                         w->stream));
+    memcpy(s.h_pinned + s.rows * per_row, coefficients, n_rows * per_row * sizeof(int16_t));
     s.rows += n_rows;
+    // upload in pieces of a megabyte or more (the rest at finish_plane): overlaps the host's entropy decoding of the rows to come
+    if ((s.rows - s.sent_rows) * per_row * sizeof(int16_t) >= (1u << 20)) return worker_send_rows(w, index);
     return JPGPU_OK;
 }
 
@@ -243,10 +346,21 @@ int jpgpu_worker_finish_plane(jpgpu_worker *w, uint32_t index, uint32_t plane_sl
     rc = worker_run_idct(w, index);
     if (rc) return rc;
     auto &s = w->slot[index];
+    if (s.rows) {
+        if (!s.uploaded) W_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+        W_HIP(hipEventRecord(s.uploaded, w->stream));
+        s.upload_pending = true;
+    }
+    {
+        const size_t row_bytes = (size_t)s.c.block_width * s.c.vertical_sampling_factor * s.c.dct_scale * s.c.dct_scale, done = s.rows * row_bytes;
+        const size_t pbytes = plane_bytes(s.c);
+        if (done < pbytes) W_HIP(hipMemsetAsync(s.d_plane + done, 0, pbytes - done, w->stream));
+    }
     auto &f = w->frame[plane_slot];
-    if (f.d_plane) W_HIP(hipFree(f.d_plane));
+    if (f.d_plane) w->spare_planes.emplace_back(f.d_plane, f.cap);
     f.d_plane = s.d_plane;  // mem::take
     f.len = plane_bytes(s.c);
+    f.cap = s.plane_cap;
     s.d_plane = nullptr;
     s.plane_cap = 0;
     s.started = false;
@@ -265,8 +379,9 @@ int jpgpu_worker_get_result(jpgpu_worker *w, uint32_t index, uint8_t *dst, size_
     if (!dst || cap < n) return set_err(w->err, JPGPU_ERR_FORMAT, "get_result: destination too small (%zu < %zu)", cap, n);
     int rc = jpgpu_worker_finish_plane(w, index, index);
     if (rc) return rc;
-    if (n) W_HIP(hipMemcpyAsync(dst, w->frame[index].d_plane, n, hipMemcpyDeviceToHost, w->stream));
-    W_HIP(hipStreamSynchronize(w->stream));
+    rc = worker_download(w, dst, w->frame[index].d_plane, n);
+    if (rc) return rc;
+    for (auto &sl : w->slot) sl.qt_unsynced = 0, sl.upload_pending = false;
     return JPGPU_OK;
 }
 
@@ -317,8 +432,9 @@ int jpgpu_compute_image(jpgpu_worker *w, const jpgpu_component *components, uint
     }
     job.out = w->d_out;
     W_HIP(launch_upsample_color_one(job, w->stream));
-    W_HIP(hipMemcpyAsync(dst, w->d_out, out_len, hipMemcpyDeviceToHost, w->stream));
-    W_HIP(hipStreamSynchronize(w->stream));
+    rc = worker_download(w, dst, w->d_out, out_len);
+    if (rc) return rc;
+    for (auto &sl : w->slot) sl.qt_unsynced = 0, sl.upload_pending = false;
     return JPGPU_OK;
 }
 
