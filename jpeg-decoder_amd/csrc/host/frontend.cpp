@@ -1231,6 +1231,11 @@ Frontend::Frontend(const uint8_t *data, size_t len) : impl_(new Impl) {
 }
 Frontend::~Frontend() {}
 
+const uint8_t *Frontend::stream_bytes(size_t *len) const {
+    if (len) *len = impl_->bytes.size();
+    return impl_->bytes.data();
+}
+
 void Frontend::read_info() { impl_->run(true, nullptr); }
 
 void Frontend::scale(uint16_t req_w, uint16_t req_h, uint16_t &out_w, uint16_t &out_h) {  // src/decoder.rs:278-290

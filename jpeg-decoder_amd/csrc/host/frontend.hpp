@@ -88,6 +88,7 @@ public:
     // (qtable_of_component) and planes_present() are set as decode_to would have set them.
     bool plan_device_scans(std::vector<PlannedScan> &scans);
 
+    const uint8_t *stream_bytes(size_t *len) const;  // the copy of the stream this object works on
     bool has_frame() const;
     jpgpu_image_info info() const;
     int color_transform() const;  // determine_color_transform(), src/decoder.rs:698-764

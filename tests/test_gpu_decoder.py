@@ -101,3 +101,43 @@ def test_hostile_files_never_crash_the_gpu_path():
         assert np.array_equal(J.Decoder(data).decode(), want), f
         n_ok += 1
     assert n_ok >= 5
+
+
+def test_large_sequential_images_take_the_device_entropy_route_with_the_same_results(monkeypatch):
+    """Decoder.decode() of sequential images of 1.5 MP and more goes through a one-image device-entropy pipeline call;
+    results, metadata, repeated calls, decode_coefficients() afterwards, options (scale / colour transform: ordinary route)
+    and damaged streams behave as on the ordinary route."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    import synth
+    big = open(os.path.join(R.GOLDEN, "benches", "large_image.jpg"), "rb").read()  # 2268x1512: above the threshold
+    want = O.decode(big).pixels
+    d = J.Decoder(big)
+    a = d.decode()
+    b = d.decode()  # (the first call kept no copy: decoded again)
+    assert np.array_equal(a, want) and np.array_equal(b, want)
+    i = d.info()
+    assert (i.width, i.height) == (2268, 1512)
+    desc, coefs = d.decode_coefficients()  # needs a working front-end again
+    assert desc.ncomp == 3 and all(c.size for c in coefs)
+    monkeypatch.setenv("JPGPU_DECODER_NO_DEVICE_ENTROPY", "1")
+    assert np.array_equal(J.Decoder(big).decode(), want)
+    monkeypatch.delenv("JPGPU_DECODER_NO_DEVICE_ENTROPY")
+    d2 = J.Decoder(big)
+    d2.scale(600, 400)  # options switch to the ordinary route
+    assert np.array_equal(d2.decode(), O.decode(big, scale_to=(600, 400)).pixels)
+    for (w, h, sub, kw) in [(1600, 1200, "4:2:0", {}), (2000, 1000, "4:4:4", {"restart_marker_rows": 4}), (1400, 1100, "4:2:2", {"progressive": True})]:
+        buf = io.BytesIO()
+        Image.fromarray(synth.synthetic_rgb(w, h, seed=w)).save(buf, format="JPEG", quality=85, subsampling=sub, **kw)
+        data = buf.getvalue()
+        assert np.array_equal(J.Decoder(data).decode(), O.decode(data).pixels), (w, h, sub)
+        cut = data[: len(data) * 2 // 3]  # truncated: same outcome as the oracle's (pixels or the same kind of error)
+        try:
+            wantc = O.decode(cut).pixels
+        except O.OracleError as e:
+            with pytest.raises(J.Error) as ei:
+                J.Decoder(cut).decode()
+            assert ei.value.kind == e.kind
+        else:
+            assert np.array_equal(J.Decoder(cut).decode(), wantc)
