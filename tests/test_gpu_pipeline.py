@@ -310,3 +310,51 @@ def _batch_case_420(rng):
     qts = [rng.integers(1, 200, 64).astype(np.uint16) for _ in ocomps]
     coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h) for c in ocomps]
     return ocomps, qts, coefs, "YCbCr", w_, h_
+
+
+def test_pipeline_device_entropy_randomised_encoder_settings(monkeypatch):
+    """150 encoder-written streams with random sizes (1..700 x 1..500), subsamplings, qualities 1..100, optimised Huffman tables
+    or the standard ones, restart intervals of all kinds or none, photographic / noisy / flat content — one call with the
+    entropy decoding on the device (forced: the cost models would keep some on the host), every result equal to the oracle's."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    import synth
+    rng = np.random.default_rng(2024)
+    names, files = [], []
+    while len(files) < 150:
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        sub = ["4:4:4", "4:2:2", "4:2:0", None][int(rng.integers(0, 4))]
+        q = int(rng.choice([1, 5, 20, 50, 75, 85, 95, 100]))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            rgb = synth.synthetic_rgb(w, h, seed=len(files))
+        elif kind == 1:
+            rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        else:
+            rgb = np.full((h, w, 3), int(rng.integers(0, 256)), np.uint8)
+            rgb[h // 2:, :, 1] = 200
+        kw = {}
+        r = int(rng.integers(0, 5))
+        if r == 1:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 40))
+        elif r == 2:
+            kw["restart_marker_rows"] = int(rng.integers(1, 4))
+        buf = io.BytesIO()
+        try:
+            Image.fromarray(rgb[..., 0] if sub is None else rgb).save(buf, format="JPEG", quality=q, subsampling=sub or "4:4:4",
+                                                                      optimize=bool(rng.integers(0, 2)), **kw)
+        except OSError:
+            continue  # (the encoder refuses some tiny-image / restart combinations)
+        names.append(f"rand-{len(files)}-{w}x{h}-{sub}-q{q}-k{kind}-{kw}")
+        files.append(buf.getvalue())
+    monkeypatch.setenv("JPGPU_PIPE_FORCE_DEVICE", "1")
+    p = J.Pipeline(threads=8)
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    t = p.timings()
+    assert t["images_device_entropy"] == len(files), t
+    monkeypatch.delenv("JPGPU_PIPE_FORCE_DEVICE")
+    out = p.decode(files, device_entropy=True)  # with the cost models deciding
+    _check(names, files, out)
+    p.close()
