@@ -1229,11 +1229,15 @@ Frontend::Frontend(const uint8_t *data, size_t len) : impl_(new Impl) {
     impl_->src.p = impl_->bytes.data();
     impl_->src.len = len;
 }
+Frontend::Frontend(const uint8_t *data, size_t len, Borrowed) : impl_(new Impl) {
+    impl_->src.p = data;
+    impl_->src.len = len;
+}
 Frontend::~Frontend() {}
 
 const uint8_t *Frontend::stream_bytes(size_t *len) const {
-    if (len) *len = impl_->bytes.size();
-    return impl_->bytes.data();
+    if (len) *len = impl_->src.len;
+    return impl_->src.p;
 }
 
 void Frontend::read_info() { impl_->run(true, nullptr); }

@@ -70,7 +70,9 @@ struct IccChunk {
 
 class Frontend {
 public:
-    Frontend(const uint8_t *data, size_t len);
+    Frontend(const uint8_t *data, size_t len);  // copies the stream (Decoder::new(reader) reads it in, src/decoder.rs:134-154)
+    struct Borrowed {};                          // ... or works on the caller's bytes, which must outlive every decoding call
+    Frontend(const uint8_t *data, size_t len, Borrowed);
     ~Frontend();
 
     // Decoder::read_info / scale / decode_internal(false) — throw DecodeError

@@ -307,7 +307,7 @@ struct Redecode {
 static void host_redecode_stage(jpgpu_pipeline *p, SubBatch &sb, Redecode &r, const uint8_t *data, size_t len) {
     const uint32_t bi = (uint32_t)p->slot[r.image];
     try {
-        Frontend fe(data, len);
+        Frontend fe(data, len, Frontend::Borrowed{});
         fe.read_info();
         r.nc = fe.ncomp();
         size_t total = 0;
@@ -420,7 +420,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     // 1. headers
     p->pool->run(n, [&](uint32_t i) {
         try {
-            p->fes[i].reset(new Frontend(data[i], len[i]));
+            p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
             Frontend &fe = *p->fes[i];
             fe.read_info();
             p->infos[i] = fe.info();
@@ -440,7 +440,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     for (uint32_t c = 0; c < d.ncomp; c++) memcpy(cand[i].quantization_tables[c], fe.qtable_of_component(c), 128);
                 } else {
                     p->plans[i].clear();
-                    p->fes[i].reset(new Frontend(data[i], len[i]));
+                    p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
                     p->fes[i]->read_info();
                 }
             }
@@ -477,7 +477,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
                     p->plans[i].clear();
                     try {
-                        p->fes[i].reset(new Frontend(data[i], len[i]));
+                        p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
                         p->fes[i]->read_info();
                     } catch (const DecodeError &e) {
                         p->status[i] = e.code;
@@ -500,7 +500,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 if (blocks && bits / blocks > 384u) {
                     p->plans[i].clear();
                     try {
-                        p->fes[i].reset(new Frontend(data[i], len[i]));
+                        p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
                         p->fes[i]->read_info();
                     } catch (const DecodeError &e) {
                         p->status[i] = e.code;
