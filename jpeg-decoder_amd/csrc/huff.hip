@@ -233,6 +233,23 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSync
     if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u);
 }
 
+// The same with whole blocks assembled in LDS and written as 128-byte lines (HuffWriteBuf; two workgroups per CU by its size)
+__global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(const HuffSyncJob *__restrict__ jobs) {
+    __shared__ HuffSyncLds L;
+    __shared__ HuffWriteBuf W;
+    const HuffSyncJob *gj = &jobs[blockIdx.y];
+    if (blockIdx.x * SYNC_NT >= gj->n_chunks) return;
+    if (*gj->status != 0u) return;
+    sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
+    {
+        JP_LDS uint32_t *z = (JP_LDS uint32_t *)&W.blk[0][0];
+        for (uint32_t t = threadIdx.x; t < sizeof(W.blk) / 4u; t += SYNC_NT) z[t] = 0u;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
+    huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks);
+}
+
 // DC differences -> DC values: a running sum (i16 wrapping, src/decoder.rs:1095-1099) per component over its blocks in
 // the order the stream has them.  grid = (4, sync jobs), one workgroup per component plane walking it in tiles; the walk
 // is a chain of load -> scan -> store round trips, so the tile is as large as a workgroup gets (1,024 lanes x 8 blocks:
@@ -324,7 +341,13 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
         const char *e = getenv("JPGPU_SYNC_WRITE_LDS");  // tuning knob: bytes of dynamic LDS added to the write kernel
         return e ? (uint32_t)atoi(e) : 36864u;
     }();
-    huff_sync_write_kernel<<<grid, dim3(SYNC_NT), write_lds, stream>>>(d_jobs);
+    // A/B switch, off by default: whole blocks assembled in LDS and written as 128-byte lines by eight lanes each
+    // (huff_sync_write_assembled_kernel) measured 2.26 ms against 2.14 ms for the plain kernel at two workgroups per CU —
+    // the extra ~35 instructions per step of the cooperative stores cost more than the 2-byte stores they replace.
+    const char *asm_env = getenv("JPGPU_SYNC_WRITE_ASSEMBLE");
+    const bool assembled = asm_env && atoi(asm_env) != 0;
+    if (assembled) huff_sync_write_assembled_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs);
+    else huff_sync_write_kernel<<<grid, dim3(SYNC_NT), write_lds, stream>>>(d_jobs);
     huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(DC_NT), 0, stream>>>(d_jobs);
     return hipGetLastError();
 }

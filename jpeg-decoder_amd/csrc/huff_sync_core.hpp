@@ -92,14 +92,67 @@ __device__ __forceinline__ bool huff_sync_state_plausible(const JP_LDS HuffSyncJ
     return pos >= first && pos - first <= 32u && q < job.bpm && k < 64u;
 }
 
+// The write pass of the chunk decoder assembles every block its lane decodes completely in LDS and lets eight lanes write
+// it as one 128-byte line (huff_flush_blocks): 2-byte stores scattered over as many cache lines as there are lanes were
+// what bound that pass.  Blocks a lane shares with a neighbour (the first and the last of a chunk) still go out coefficient
+// by coefficient into the zero-filled arena.
+__device__ __forceinline__ bool huff_wave_any(bool x) {
+#ifdef JPGPU_HOST_EMULATION
+    return x;
+#else
+    return __ballot(x) != 0ull;
+#endif
+}
+__device__ __forceinline__ uint32_t threadIdx_x_of_lane() {
+#ifdef JPGPU_HOST_EMULATION
+    return 0u;
+#else
+    return threadIdx.x;
+#endif
+}
+
+struct HuffWriteBuf {
+    uint16_t blk[HUFF_SYNC_LANES][72];           // one block per lane, rows of 144 bytes (16-byte aligned, banks spread)
+    uint64_t done_ptr[HUFF_SYNC_LANES / 64][64];  // per wave: arena addresses of the blocks finished in this step ...
+    uint8_t done_lane[HUFF_SYNC_LANES / 64][64];  // ... and the lanes whose buffers hold them
+};
+
+#ifndef JPGPU_HOST_EMULATION
+// All 64 lanes of the wave: `flush` lanes have a finished block in their buffer, to be stored at `addr`.
+__device__ __forceinline__ void huff_flush_blocks(JP_LDS HuffWriteBuf &W, bool flush, uint64_t addr) {
+    const uint64_t m = __ballot(flush);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (flush) {
+        const uint32_t r = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        W.done_lane[wave][r] = (uint8_t)lane;
+        W.done_ptr[wave][r] = addr;
+    }
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this keeps the compiler from reordering them)
+    const uint32_t n = (uint32_t)__popcll(m), sub = lane & 7u;
+    for (uint32_t base = 0; base < n; base += 8u) {
+        const uint32_t g = base + (lane >> 3);
+        if (g < n) {
+            const uint32_t src = W.done_lane[wave][g];
+            JP_LDS v4u *b = (JP_LDS v4u *)&W.blk[wave * 64u + src][sub * 8u];
+            const v4u v = *b;
+            *((JP_GLOBAL v4u *)(uintptr_t)W.done_ptr[wave][g] + sub) = v;
+            *b = v4u{0u, 0u, 0u, 0u};
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+#endif
+
 // The decoding loop shared by the chunk decoder and the restart-segment decoder: from state (pos, q, k) of the staged bit
 // stream `data` until the bit position reaches `limit` (BY_BITS) and/or `end_blk` blocks are complete (WRITE).
 //   WRITE:   store coefficients; `blkno` = number of the block being decoded (-> its MCU and address)
 //   dc_sums: dc[component] accumulates DC differences (WRITE: they are predictors, and the stored DC values are finished)
 // Returns the bit position reached; q, k, nblk (blocks completed), blkno, bad are updated.
-template <bool WRITE, bool BY_BITS>
+template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
 __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
-                                             uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad) {
+                                             uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad,
+                                             JP_LDS HuffWriteBuf *W = nullptr, bool participate = true) {
     const JP_LDS HuffSyncJob &job = L.job;
     constexpr bool DW = !(WRITE && BY_BITS);  // (huff_core.hpp: the chunk decoder's write pass keeps the 16-byte reader)
     DevBits b;
@@ -120,7 +173,15 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
     };
     uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;  // DC predictors of a restart segment (start at 0, src/decoder.rs:928-931)
     if (WRITE && blkno < end_blk) locate();
-    while (!bad && (!BY_BITS || huff_bit_pos(b) < limit) && !(WRITE && blkno >= end_blk)) {
+    // ASSEMBLE: `own` — the block being decoded started in this lane (it will be written as a whole); mine = this lane's buffer
+    bool own = k == 0u;
+    JP_LDS uint16_t *mine = ASSEMBLE ? W->blk[threadIdx_x_of_lane()] : nullptr;
+    for (;;) {
+        const bool active = participate && !bad && (!BY_BITS || huff_bit_pos(b) < limit) && !(WRITE && blkno >= end_blk);
+        if (ASSEMBLE ? !huff_wave_any(active) : !active) break;  // (ASSEMBLE: the wave stays together for the cooperative stores)
+        bool flush = false;
+        uint64_t flush_addr = 0;
+        if (active) {
         huff_refill<DW>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
@@ -157,9 +218,13 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
                     dc[c] += (uint32_t)val;
                     val = (int16_t)(uint16_t)dc[c];
                 }
-                if (WRITE && val) blk[0] = (int16_t)val;  // (uniform scans: the difference; huff_dc_prefix_kernel sums up)
+                if (WRITE && val) {  // (uniform scans: the difference; huff_dc_prefix_kernel sums up)
+                    if (ASSEMBLE && own) mine[0] = (uint16_t)val;
+                    else blk[0] = (int16_t)val;
+                }
             } else if (WRITE && (info & SYM_COEF)) {
-                blk[L.unzig[k - 1u]] = (int16_t)huff_extend(raw, nread);
+                if (ASSEMBLE && own) mine[L.unzig[k - 1u]] = (uint16_t)huff_extend(raw, nread);
+                else blk[L.unzig[k - 1u]] = (int16_t)huff_extend(raw, nread);
             }
         }
         if (k >= 64u && !bad) {  // end of the block
@@ -177,9 +242,27 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
             qt = L.q_tables[q];
             c = job.q_comp[q];
             if (WRITE) {
+                if (ASSEMBLE && own) {
+                    flush = true;
+                    flush_addr = (uint64_t)(uintptr_t)blk;
+                }
+                own = true;
                 blkno++;
                 if (blkno < end_blk) locate();
             }
+        }
+        }  // if (active)
+#ifndef JPGPU_HOST_EMULATION
+        if (ASSEMBLE) huff_flush_blocks(*W, flush, flush_addr);
+#endif
+    }
+    if (ASSEMBLE && participate && own && blkno < end_blk && !bad) {
+        // the chunk ended inside a block this lane began: the lane to the right writes the rest coefficient by coefficient
+        // into the zero-filled line, so what sits in the buffer goes out the same way
+        for (uint32_t z = 0; z < 64u; z++) {
+            const uint16_t v = mine[z];
+            if (v) blk[z] = (int16_t)v;
+            mine[z] = 0;
         }
     }
     return huff_bit_pos(b);
@@ -261,6 +344,46 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         if (i + 1u == job.n_chunks && (blkno < total_blocks || pos > job.n_bits)) atomicOr_status(job.status, 1u | 8u);
     }
     return false;
+}
+
+// The write pass with block assembly (HuffWriteBuf): every lane of the workgroup calls it, `valid` = the lane has a chunk;
+// lanes without work still take part in the cooperative stores.  Same decisions as huff_sync_chunk<true>.
+__device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid) {
+    const JP_LDS HuffSyncJob &job = L.job;
+    uint32_t pos = 0, q = 0, k = 0;
+    bool participate = valid;
+    if (valid && i > 0u) {
+        pos = huff_load_shared(job.out_pos + (i - 1u));
+        const uint32_t qk = huff_load_shared(job.out_qk + (i - 1u));
+        q = qk >> 8;
+        k = qk & 0xffu;
+        if (job.uniform) q = 0u;
+        if (!huff_sync_state_plausible(job, i, pos, q, k)) {
+            atomicOr_status(job.status, 1u | 32u);
+            participate = false;
+            pos = q = k = 0u;
+        }
+    }
+    const uint32_t limit = valid ? min((i + 1u) << job.chunk_shift, job.n_bits) : 0u;
+    const uint32_t total_blocks = job.n_mcu * job.bpm;
+    uint32_t nblk = 0, blkno = participate ? job.n_blocks[i] : 0u;
+    if (participate) q = blkno % job.bpm;
+    bool bad = false;
+    const bool dc_sums = !job.uniform;
+    JP_LDS uint32_t *dc = L.dc[threadIdx_x_of_lane() % HUFF_SYNC_LANES];
+    if (dc_sums) {
+        const uint32_t w0 = participate ? job.dc_sum[2u * i] : 0u, w1 = participate ? job.dc_sum[2u * i + 1u] : 0u;
+        dc[0] = w0 & 0xffffu;
+        dc[1] = w0 >> 16;
+        dc[2] = w1 & 0xffffu;
+        dc[3] = w1 >> 16;
+    }
+    participate = participate && pos < limit;
+    const uint32_t end = huff_run<true, true, true>(L, job.data, participate ? pos : 0u, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, &W, participate);
+    if (participate) pos = end;
+    if (!valid) return;
+    if (bad) atomicOr_status(job.status, 1u | 2u);
+    if (i + 1u == job.n_chunks && (blkno < total_blocks || pos > job.n_bits)) atomicOr_status(job.status, 1u | 8u);
 }
 
 // ---- streams WITH restart markers: one lane per restart segment (src/decoder.rs:920-956: the predictors and the bit

@@ -354,6 +354,11 @@ def test_pipeline_device_entropy_randomised_encoder_settings(monkeypatch):
     _check(names, files, out)
     t = p.timings()
     assert t["images_device_entropy"] == len(files), t
+    monkeypatch.setenv("JPGPU_SYNC_WRITE_ASSEMBLE", "1")  # the write pass that assembles whole blocks in LDS (A/B variant)
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    assert p.timings()["images_device_entropy"] == len(files)
+    monkeypatch.delenv("JPGPU_SYNC_WRITE_ASSEMBLE")
     monkeypatch.delenv("JPGPU_PIPE_FORCE_DEVICE")
     out = p.decode(files, device_entropy=True)  # with the cost models deciding
     _check(names, files, out)
