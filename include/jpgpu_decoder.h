@@ -130,6 +130,11 @@ const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t imag
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p);                   /* "fused420", "generic", ... */
 int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t);
 
+/* Decoders borrow workers (streams, pinned staging, device planes) and one-image pipelines from process-wide pools of idle
+ * ones, and progressive front-ends take their accumulation planes from a pool of host buffers (JPGPU_HOST_POOL_MB): release
+ * whatever is idle at the moment.  Never needed for correctness; for long-running services that want the memory back. */
+void jpgpu_trim_caches(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,7 @@ _PROTOS = {
     "jpgpu_pipeline_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "jpgpu_pipeline_destroy": (None, [C.c_void_p]),
     "jpgpu_pipeline_last_error": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_trim_caches": (None, []),
     "jpgpu_pipeline_decode": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32]),
     "jpgpu_pipeline_image_status": (C.c_int, [C.c_void_p, C.c_uint32]),
     "jpgpu_pipeline_image_error": (C.c_char_p, [C.c_void_p, C.c_uint32]),

@@ -168,6 +168,30 @@ void jpgpu_decoder_destroy(jpgpu_decoder *d) {
     delete d;
 }
 
+void jpgpu_trim_caches(void) {
+    for (;;) {
+        jpgpu_worker *w = nullptr;
+        {
+            std::lock_guard<std::mutex> g(worker_pool().m);
+            if (worker_pool().idle.empty()) break;
+            w = worker_pool().idle.back().second;
+            worker_pool().idle.pop_back();
+        }
+        jpgpu_worker_destroy(w);
+    }
+    for (;;) {
+        jpgpu_pipeline *p = nullptr;
+        {
+            std::lock_guard<std::mutex> g(pipeline_pool().m);
+            if (pipeline_pool().idle.empty()) break;
+            p = pipeline_pool().idle.back().second;
+            pipeline_pool().idle.pop_back();
+        }
+        jpgpu_pipeline_destroy(p);
+    }
+    jpgpu::host::trim_coefficient_pool();
+}
+
 const char *jpgpu_decoder_last_error(const jpgpu_decoder *d) { return d ? d->err.c_str() : ""; }
 
 int jpgpu_decoder_set_color_transform(jpgpu_decoder *d, int ct) {

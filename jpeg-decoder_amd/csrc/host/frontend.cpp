@@ -380,6 +380,12 @@ public:
         v.assign(n, 0);
         return v;
     }
+    void trim() {
+        std::vector<std::vector<int16_t>> gone;
+        std::lock_guard<std::mutex> g(m_);
+        gone.swap(free_);
+        bytes_ = 0;
+    }
     void give(std::vector<int16_t> &v) {
         const size_t b = v.capacity() * sizeof(int16_t);
         if (b < (256u << 10)) return;  // small ones are the allocator's business
@@ -415,6 +421,8 @@ CoefPool &coef_pool() {
     return *p;
 }
 }  // namespace
+
+void trim_coefficient_pool() { coef_pool().trim(); }
 
 struct Frontend::Impl {
     std::vector<uint8_t> bytes;

@@ -34,6 +34,8 @@ struct ScanDelta {
     int32_t delta;
 };
 
+void trim_coefficient_pool();  // frees the idle accumulation planes of progressive frames (see frontend.cpp, CoefPool)
+
 class RowSink {
 public:
     virtual ~RowSink() {}

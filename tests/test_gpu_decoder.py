@@ -141,3 +141,19 @@ def test_large_sequential_images_take_the_device_entropy_route_with_the_same_res
             assert ei.value.kind == e.kind
         else:
             assert np.array_equal(J.Decoder(cut).decode(), wantc)
+
+
+def test_trim_caches_between_decodes():
+    """jpgpu_trim_caches releases the idle workers / pipelines / host buffers the decoders borrow from; decoding afterwards
+    simply builds new ones."""
+    from jpeg_decoder_amd import _native as N
+    data = open(os.path.join(R.GOLDEN, "benches", "tower.jpg"), "rb").read()
+    want = O.decode(data).pixels
+    assert np.array_equal(J.Decoder(data).decode(), want)
+    N.lib().jpgpu_trim_caches()
+    N.lib().jpgpu_trim_caches()
+    assert np.array_equal(J.Decoder(data).decode(), want)
+    prog = open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read()
+    assert np.array_equal(J.Decoder(prog).decode(), O.decode(prog).pixels)
+    N.lib().jpgpu_trim_caches()
+    assert np.array_equal(J.Decoder(prog).decode(), O.decode(prog).pixels)
