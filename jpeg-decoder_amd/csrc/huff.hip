@@ -26,10 +26,21 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restr
     }
     uint32_t max_abs = 0, max_col = 0;
     const uint32_t last = min(first + 256u, job.n_blocks);
-    for (uint32_t blk = first + (threadIdx.x >> 3); blk < first + 256u; blk += 32u) {  // (uniform trip count: shuffles inside)
+    // all eight rows this lane is going to look at are requested before the first one is used (one load per iteration, each
+    // waited for, kept the kernel at 1.8 TB/s: 93 % of the wave cycles were spent waiting for memory)
+    v4u rows[8];
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; it++) {
+        const uint32_t blk = first + (threadIdx.x >> 3) + 32u * it;
+        rows[it] = v4u{0u, 0u, 0u, 0u};
+        if (blk < last) rows[it] = stream_load((const JP_GLOBAL v4u *)(job.coefs + (size_t)blk * 64u) + row);
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; it++) {  // (uniform trip count: shuffles inside)
+        const uint32_t blk = first + (threadIdx.x >> 3) + 32u * it;
         uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (blk < last) {
-            const v4u v = stream_load((const JP_GLOBAL v4u *)(job.coefs + (size_t)blk * 64u) + row);
+            const v4u v = rows[it];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) {
@@ -60,9 +71,17 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restr
         max_abs = max(max_abs, (uint32_t)__shfl_xor((int)max_abs, off));
         max_col = max(max_col, (uint32_t)__shfl_xor((int)max_col, off));
     }
+    // one pair of atomics per workgroup (not per wave: atomics — and even plain L2-scope reads — of a few hundred neighbouring
+    // words by every wave of the launch are what this kernel would otherwise spend its time on)
+    __shared__ uint32_t wg_max[2][4];
     if ((threadIdx.x & 63u) == 0u) {
-        atomicMax(&stats[2u * job.slot], max_abs);
-        atomicMax(&stats[2u * job.slot + 1u], max_col);
+        wg_max[0][threadIdx.x >> 6] = max_abs;
+        wg_max[1][threadIdx.x >> 6] = max_col;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        const uint32_t v = max(max(wg_max[threadIdx.x][0], wg_max[threadIdx.x][1]), max(wg_max[threadIdx.x][2], wg_max[threadIdx.x][3]));
+        if (v) atomicMax(&stats[2u * job.slot + threadIdx.x], v);
     }
 }
 
