@@ -116,8 +116,9 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__
     const HuffSyncJob *gj = &jobs[blockIdx.y];
     if (blockIdx.x * 64u >= gj->n_seg) return;
     sync_load_lds<64>(*(JP_LDS HuffSyncLds *)&L, gj);
+    __shared__ uint32_t ring[HUFF_RING_DWORDS][64];
     const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
-    if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg);
+    if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], 64u);
 }
 
 // does chunk i have a start state it has not decoded from yet?  (what huff_sync_chunk decides itself, ahead of the call)
@@ -248,8 +249,9 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSync
     if (blockIdx.x * SYNC_NT >= gj->n_chunks) return;
     if (*gj->status != 0u) return;
     sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
+    __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
     const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
-    if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u);
+    if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
 }
 
 // The same with whole blocks assembled in LDS and written as 128-byte lines (HuffWriteBuf; two workgroups per CU by its size)
@@ -266,7 +268,8 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(cons
     }
     __syncthreads();
     const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
-    huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks);
+    __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
+    huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
 }
 
 // DC differences -> DC values: a running sum (i16 wrapping, src/decoder.rs:1095-1099) per component over its blocks in
@@ -358,7 +361,7 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     // 4: 2.26, 2: 1.89, 1: 3.2).  Unused dynamic LDS is the occupancy limiter.
     static const uint32_t write_lds = [] {
         const char *e = getenv("JPGPU_SYNC_WRITE_LDS");  // tuning knob: bytes of dynamic LDS added to the write kernel
-        return e ? (uint32_t)atoi(e) : 36864u;
+        return e ? (uint32_t)atoi(e) : 0u;  // (the kernel's own 57 kB — tables, ring — already mean two workgroups per CU)
     }();
     // A/B switch, off by default: whole blocks assembled in LDS and written as 128-byte lines by eight lanes each
     // (huff_sync_write_assembled_kernel) measured 2.26 ms against 2.14 ms for the plain kernel at two workgroups per CU —

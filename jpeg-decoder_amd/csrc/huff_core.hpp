@@ -23,29 +23,65 @@
 
 namespace jpgpu {
 
-// Two ways to fetch the stream (template parameter DW of huff_refill / huff_open_at; the fields of the other one are dead):
-//   DW = false: two 16-byte pieces in registers, one reloaded every fourth refill.  Few memory instructions, but the
-//               compiler waits for the load right behind it (the value has to be copied into the loop-carried registers),
-//               and with 64 lanes per wave some lane reloads in nearly every step.
-//   DW = true:  one dword per refill, fetched one refill AHEAD into the register the previous one just left (the empty asm
-//               keeps the load behind the last use of the old value, so no copy and no wait until the next refill).
-// Measured (256 1080p images): sync passes 2.53 ms with 16-byte pieces, 2.14 ms with dwords; the write pass, whose
-// scattered coefficient stores compete for the same address path, 2.18 against 2.56 ms — each takes what suits it.
+// Three ways to fetch the stream (template parameter of huff_refill / huff_open_at; the fields of the others are dead):
+//   HUFF_READ_16:   two 16-byte pieces in registers, one reloaded every fourth refill.  Few memory instructions, but the
+//                   compiler waits for the load right behind it (the value has to be copied into the loop-carried
+//                   registers), and with 64 lanes per wave some lane reloads in nearly every step.
+//   HUFF_READ_DW:   one dword per refill, fetched one refill AHEAD into the register the previous one just left (the empty
+//                   asm keeps the load behind the last use of the old value, so no copy and no wait until the next refill).
+//   HUFF_READ_RING: a ring of 32 dwords per lane in LDS, topped up every 16 steps (a step takes at most 31 bits, the ring
+//                   then holds at least 96 bytes ahead).  For the kernels that also STORE: on gfx9 a wait for a load
+//                   (vmcnt) is a wait for every store issued before it as well, and with a stream load in nearly every step
+//                   the write pass spent its life in such waits (SQ_WAIT_ANY 56 % of the wave cycles); with the ring the
+//                   wave waits for memory once per 16 steps and the per-step reads are LDS reads.
+// Measured (256 1080p images): sync passes 2.53 ms with 16-byte pieces, 2.14 ms with dwords; write pass: see DESIGN.md §5.
+enum HuffReader { HUFF_READ_16 = 0, HUFF_READ_DW = 1, HUFF_READ_RING = 2 };
+constexpr uint32_t HUFF_RING_DWORDS = 32, HUFF_RING_AHEAD = 24, HUFF_RING_PERIOD = 16;
+
 struct DevBits {
     uint64_t bits;   // unread bits, left-aligned
     uint32_t nbits;
     uint32_t wpos;   // dwords taken from the slot so far
     const v4u *g;    // the slot (16-byte aligned, zero padded: huff_stage_segment)
-    v4u cur, nxt;    // DW = false: 16-byte piece wpos / 4 and the one after it
-    uint32_t ahead;  // DW = true: dword wpos
+    v4u cur, nxt;    // HUFF_READ_16: 16-byte piece wpos / 4 and the one after it
+    uint32_t ahead;  // HUFF_READ_DW: dword wpos
+    JP_LDS uint32_t *ring;  // HUFF_READ_RING: this lane's column of the ring (dword d of the stream at ring[(d % 32) * ring_stride])
+    uint32_t ring_stride;   //   lanes of the workgroup (the ring is stored dword-major: no bank conflicts between lanes)
+    uint32_t fetched;       //   dwords of the stream in the ring so far (a multiple of 4)
     bool bad;
 };
 
+// HUFF_READ_RING: bring the ring to at least HUFF_RING_AHEAD dwords ahead of the reader (at most 4 pieces of 16 bytes: all
+// requested, then one wait)
+__device__ __forceinline__ void huff_ring_topup(DevBits &b) {
+    const uint32_t have = b.fetched - b.wpos;
+    const uint32_t need = have >= HUFF_RING_AHEAD ? 0u : min(4u, (HUFF_RING_AHEAD - have + 3u) >> 2);
+    v4u c[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++)
+        if (j < need) c[j] = b.g[(b.fetched >> 2) + j];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++)
+        if (j < need) {
+            const uint32_t d = b.fetched + 4u * j;
+            b.ring[((d + 0u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].x;
+            b.ring[((d + 1u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].y;
+            b.ring[((d + 2u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].z;
+            b.ring[((d + 3u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].w;
+        }
+    b.fetched += 4u * need;
+}
+
 // at most once per step: afterwards more than 32 bits are available (a step reads <= 16 + 15)
-template <bool DW>
+template <int RD>
 __device__ __forceinline__ void huff_refill(DevBits &b) {
     if (b.nbits <= 32u) {
-        if (DW) {
+        if (RD == HUFF_READ_RING) {
+            const uint32_t x = b.ring[(b.wpos % HUFF_RING_DWORDS) * b.ring_stride];
+            b.bits |= (uint64_t)__builtin_bswap32(x) << (32u - b.nbits);
+            b.nbits += 32u;
+            b.wpos++;
+        } else if (RD == HUFF_READ_DW) {
             b.bits |= (uint64_t)__builtin_bswap32(b.ahead) << (32u - b.nbits);
             b.nbits += 32u;
             b.wpos++;

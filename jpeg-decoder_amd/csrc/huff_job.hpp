@@ -24,9 +24,9 @@ struct HuffScanComp {
 };
 
 // Host side of the staging: copy one restart segment (markers excluded, 0xFF00 pairs inside) without its stuffing
-// zeros, then zero bytes up to the next 16-byte boundary plus 16 (the device reader fetches aligned 16-byte chunks ahead
+// zeros, then zero bytes up to the next 16-byte boundary plus 144 (the device reader fetches aligned 16-byte chunks ahead
 // and treats what follows a segment as zero bits).  Returns the unstuffed length.  Slot size: huff_slot_bytes(n).
-inline uint32_t huff_slot_bytes(uint32_t stuffed_bytes) { return ((stuffed_bytes + 15u) & ~15u) + 32u; }
+inline uint32_t huff_slot_bytes(uint32_t stuffed_bytes) { return ((stuffed_bytes + 15u) & ~15u) + 144u; }  // (the LDS ring reads up to 8 pieces ahead)
 inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n) {
     // runs between 0xFF bytes (one per ~256 bytes of entropy-coded data) go through memcpy: ~5x a byte loop
     uint32_t o = 0, i = 0;

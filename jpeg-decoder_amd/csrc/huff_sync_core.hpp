@@ -69,11 +69,17 @@ __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32
     }
 }
 
-template <bool DW>
-__device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos) {
+template <int RD>
+__device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
     b.g = reinterpret_cast<const v4u *>(slot);
     b.wpos = bit_pos >> 5;
-    if (DW) {
+    if (RD == HUFF_READ_RING) {
+        b.ring = ring;
+        b.ring_stride = ring_stride;
+        b.fetched = b.wpos & ~3u;
+        huff_ring_topup(b);  // (twice: up to 7 pieces until HUFF_RING_AHEAD dwords lie ahead of a reader that starts mid-piece)
+        huff_ring_topup(b);
+    } else if (RD == HUFF_READ_DW) {
         b.ahead = reinterpret_cast<const uint32_t *>(slot)[b.wpos];
     } else {
         b.cur = b.g[b.wpos >> 2];
@@ -82,7 +88,7 @@ __device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, ui
     b.bits = 0;
     b.nbits = 0;
     b.bad = false;
-    huff_refill<DW>(b);
+    huff_refill<RD>(b);
     huff_consume(b, bit_pos & 31u);
 }
 __device__ __forceinline__ uint32_t huff_bit_pos(const DevBits &b) { return b.wpos * 32u - b.nbits; }
@@ -152,11 +158,18 @@ __device__ __forceinline__ void huff_flush_blocks(JP_LDS HuffWriteBuf &W, bool f
 template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
 __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                              uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad,
-                                             JP_LDS HuffWriteBuf *W = nullptr, bool participate = true) {
+                                             JP_LDS HuffWriteBuf *W = nullptr, bool participate = true, JP_LDS uint32_t *ring = nullptr,
+                                             uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
-    constexpr bool DW = !(WRITE && BY_BITS);  // (huff_core.hpp: the chunk decoder's write pass keeps the 16-byte reader)
+    // (huff_core.hpp) kernels that store decode from the LDS ring when they are given one; the sync passes fetch dwords ahead
+#ifdef JPGPU_HOST_EMULATION
+    constexpr int RD = HUFF_READ_DW;
+#else
+    constexpr int RD = WRITE ? HUFF_READ_RING : HUFF_READ_DW;
+#endif
     DevBits b;
-    huff_open_at<DW>(b, data, pos);
+    huff_open_at<RD>(b, data, pos, ring, ring_stride);
+    uint32_t steps = 0;
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
@@ -182,7 +195,8 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
         bool flush = false;
         uint64_t flush_addr = 0;
         if (active) {
-        huff_refill<DW>(b);
+        if (RD == HUFF_READ_RING && (++steps % HUFF_RING_PERIOD) == 0u) huff_ring_topup(b);
+        huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
         const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> 8;
@@ -272,7 +286,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 // counts those per job: one atomic per workgroup, not per lane — a quarter of a million lanes adding to a few hundred
 // neighbouring counters took 18 ms per pass); WRITE = true: the write pass.
 template <bool WRITE>
-__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass) {
+__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     uint32_t pos, q, k;
@@ -324,7 +338,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         dc[2] = w1 & 0xffffu;
         dc[3] = w1 >> 16;
     }
-    if (pos < limit) pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad);
+    if (pos < limit) pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, nullptr, true, ring, ring_stride);
     if (!WRITE && dc_sums) {
         job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);
         job.dc_sum[2u * i + 1u] = (dc[2] & 0xffffu) | (dc[3] << 16);
@@ -348,7 +362,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
 
 // The write pass with block assembly (HuffWriteBuf): every lane of the workgroup calls it, `valid` = the lane has a chunk;
 // lanes without work still take part in the cooperative stores.  Same decisions as huff_sync_chunk<true>.
-__device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid) {
+__device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid, JP_LDS uint32_t *ring, uint32_t ring_stride) {
     const JP_LDS HuffSyncJob &job = L.job;
     uint32_t pos = 0, q = 0, k = 0;
     bool participate = valid;
@@ -379,7 +393,7 @@ __device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L,
         dc[3] = w1 >> 16;
     }
     participate = participate && pos < limit;
-    const uint32_t end = huff_run<true, true, true>(L, job.data, participate ? pos : 0u, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, &W, participate);
+    const uint32_t end = huff_run<true, true, true>(L, job.data, participate ? pos : 0u, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, &W, participate, ring, ring_stride);
     if (participate) pos = end;
     if (!valid) return;
     if (bad) atomicOr_status(job.status, 1u | 2u);
@@ -389,14 +403,14 @@ __device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L,
 // ---- streams WITH restart markers: one lane per restart segment (src/decoder.rs:920-956: the predictors and the bit
 // reader start afresh after every RSTn, so segments are independent).  The job record says where the segments lie
 // (seg_off, staged by huff_stage_segment one slot each) and how many MCUs one holds (ri); the decoding loop is huff_run.
-__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint32_t seg) {
+__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint32_t seg, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     const uint8_t *data = job.data + job.seg_off[2u * seg];
     const uint32_t seg_bits = job.seg_off[2u * seg + 1u] * 8u;
     const uint32_t m0 = seg * job.ri, m1 = min(m0 + job.ri, job.n_mcu);
     uint32_t q = 0, k = 0, nblk = 0, blkno = m0 * job.bpm;
     bool bad = false;
-    const uint32_t pos = huff_run<true, false>(L, data, 0u, 0u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad);
+    const uint32_t pos = huff_run<true, false>(L, data, 0u, 0u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, nullptr, true, ring, ring_stride);
     // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it keeps reading until it
     // meets the marker, which works iff the unread rest of the segment fits its 64-bit buffer; left-over bits are
     // dropped.  A segment that ran dry (bits taken from beyond its end — the reference would have fed zeros as well) is
