@@ -568,6 +568,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const uint8_t *src;  // the scan's entropy-coded bytes
         const host::PlannedScan *ps;
         HuffSyncJob *sync;   // scan without restart markers: its job record (the unstuffed length goes there)
+        uint32_t *h_status;  // the image's status word in the pinned block (set here if the staging pass refuses the stream)
     };
     std::vector<CopyTask> copies;
     std::vector<std::pair<size_t, size_t>> zero_ranges;  // coefficient planes of the listed images
@@ -580,7 +581,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         for (const host::PlannedScan &ps : *images[k].scans) {
             // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
             HuffSyncJob *sj = ps.ri == 0 ? &sjobs[si] : nullptr;
-            copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps, sj});
+            copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps, sj,
+                                      reinterpret_cast<uint32_t *>(h + off_status) + k});
             size_t scan_bytes = 0, stuffed = 0;
             for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
                 scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
@@ -658,13 +660,16 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             uint32_t o = 0;
             for (size_t sg = 0; sg + 1 < ct.ps->seg_off.size(); sg += 2) {
                 const uint32_t first = ct.ps->seg_off[sg], n = ct.ps->seg_off[sg + 1] - first;
+                bool clean = true;
                 ct.seg_table[sg] = ct.dst_off + o;
-                ct.seg_table[sg + 1] = huff_stage_segment(ct.dst + o, ct.src + first, n);
+                ct.seg_table[sg + 1] = huff_stage_segment(ct.dst + o, ct.src + first, n, ct.ps->check_at_staging ? &clean : nullptr);
                 o += huff_slot_bytes(n);
+                if (!clean) *ct.h_status |= 1u | 16u;  // something other than 0xFF00 pairs inside the scan: the host decodes this image
             }
             if (ct.sync) {
-                ct.sync->n_bits = ct.seg_table[1] * 8u;
-                ct.sync->n_chunks = huff_sync_chunks(ct.seg_table[1], ct.sync->chunk_shift);
+                const bool refused = (*ct.h_status & 1u) != 0u;
+                ct.sync->n_bits = refused ? 0u : ct.seg_table[1] * 8u;
+                ct.sync->n_chunks = refused ? 0u : huff_sync_chunks(ct.seg_table[1], ct.sync->chunk_shift);
             }
         };
         if (par && copies.size() > 1) (*par)((uint32_t)copies.size(), body);

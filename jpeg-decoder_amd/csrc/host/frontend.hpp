@@ -59,6 +59,8 @@ struct PlannedScan {
     size_t data_off = 0;            // offset of the scan's entropy-coded bytes in the stream given to the Frontend
     std::vector<uint32_t> seg_off;  // 2 * n_seg offsets relative to data_off: segment s = [seg_off[2s], seg_off[2s+1]), no markers
     uint32_t ri = 0, cols = 0, n_mcu = 0, ncomp = 0;  // ri == 0: no restart interval (one segment)
+    bool check_at_staging = false;  // ri == 0: the segment was taken to run up to the last EOI of the stream without looking inside:
+                                    // huff_stage_segment must find nothing but 0xFF00 pairs in it, else the image is the host's
     struct Comp {
         uint32_t frame_index, block_w, h, v, dc, ac;
     } comp[4];

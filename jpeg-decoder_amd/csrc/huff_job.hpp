@@ -27,7 +27,9 @@ struct HuffScanComp {
 // zeros, then zero bytes up to the next 16-byte boundary plus 144 (the device reader fetches aligned 16-byte chunks ahead
 // and treats what follows a segment as zero bits).  Returns the unstuffed length.  Slot size: huff_slot_bytes(n).
 inline uint32_t huff_slot_bytes(uint32_t stuffed_bytes) { return ((stuffed_bytes + 15u) & ~15u) + 144u; }  // (the LDS ring reads up to 8 pieces ahead)
-inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n) {
+// `clean` (optional) is cleared if a 0xFF inside the segment is not followed by its stuffing zero — a marker or a fill byte: the
+// planner that takes the short way for scans without restart markers leaves that check to this pass over the same bytes.
+inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n, bool *clean = nullptr) {
     // runs between 0xFF bytes (one per ~256 bytes of entropy-coded data) go through memcpy: ~5x a byte loop
     uint32_t o = 0, i = 0;
     while (i < n) {
@@ -36,7 +38,10 @@ inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n)
         memcpy(dst + o, src + i, run);
         o += run;
         i += run;
-        if (ff && i < n && src[i] == 0) i++;  // its stuffing zero
+        if (ff) {
+            if (i < n && src[i] == 0) i++;  // its stuffing zero
+            else if (clean) *clean = false;
+        }
     }
     const uint32_t slot = huff_slot_bytes(n);
     memset(dst + o, 0, slot - o);

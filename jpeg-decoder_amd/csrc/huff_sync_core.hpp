@@ -411,14 +411,15 @@ __device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint3
     uint32_t q = 0, k = 0, nblk = 0, blkno = m0 * job.bpm;
     bool bad = false;
     const uint32_t pos = huff_run<true, false>(L, data, 0u, 0u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, nullptr, true, ring, ring_stride);
-    // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it keeps reading until it
-    // meets the marker, which works iff the unread rest of the segment fits its 64-bit buffer; left-over bits are
-    // dropped.  A segment that ran dry (bits taken from beyond its end — the reference would have fed zeros as well) is
-    // left to the host to be safe.
+    // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it tops up its 64-bit buffer —
+    // bytes are appended while it holds at most 56 bits (src/huffman.rs:123-160) — and must MEET the marker doing so, which
+    // happens iff the unread rest of the segment is at most 56 bits ("no marker found where RSTn was expected" otherwise);
+    // left-over bits are dropped.  A segment that ran dry (bits taken from beyond its end — the reference would have fed
+    // zeros as well) is left to the host to be safe.
     const int64_t left = (int64_t)seg_bits - (int64_t)pos;
-    if (bad || left < 0 || left > 64) {
+    if (bad || left < 0 || left > 56) {
         // bit 0 = re-decode on the host; bits 1..3 say why (diagnostics)
-        atomicOr_status(job.status, 1u | (bad ? 2u : 0u) | (left > 64 ? 4u : 0u) | (left < 0 ? 8u : 0u));
+        atomicOr_status(job.status, 1u | (bad ? 2u : 0u) | (left > 56 ? 4u : 0u) | (left < 0 ? 8u : 0u));
         return false;
     }
     return true;

@@ -434,6 +434,24 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             d.out_w = fe.output_width();
             d.out_h = fe.output_height();
             d.color_transform = fe.color_transform();
+            {
+                // A block costs at least two bits.  A header that announces far more blocks than the file can hold (truncated or
+                // hostile: 65535 x 65535 in 200 bytes) would have the sub-batch allocate gigabytes of arenas and pinned staging
+                // — 2.5 s for one such file — before the entropy decoder finds out: let it find out first, into a sink that
+                // keeps nothing.  (A stream that decodes after all goes on as usual.)
+                uint64_t blocks = 0;
+                for (uint32_t c = 0; c < d.ncomp; c++) blocks += (uint64_t)d.components[c].block_width * d.components[c].block_height;
+                if ((uint64_t)len[i] * 8u < blocks * 2u) {
+                    struct Nothing : RowSink {
+                        void start(uint32_t, const jpgpu_component &, const uint16_t *) override {}
+                        void append_row(uint32_t, const int16_t *, size_t) override {}
+                        void finish(uint32_t, uint32_t) override {}
+                    } nothing;
+                    Frontend probe(data[i], len[i], Frontend::Borrowed{});
+                    probe.read_info();
+                    probe.decode_to(nothing);  // throws what the image's decode() would throw
+                }
+            }
             cand[i] = d;
             if (device_entropy) {  // eligible for the device entropy decoder?  (the planning pass spends the object)
                 if (fe.plan_device_scans(p->plans[i])) {

@@ -24,6 +24,8 @@ def lib():
         L.emu_huff_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.emu_stage_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.emu_stage_segment.restype = C.c_uint32
+        L.emu_stage_segment_clean.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.emu_stage_segment_clean.restype = C.c_int
         L.emu_slot_bytes.argtypes = [C.c_uint32]
         L.emu_slot_bytes.restype = C.c_uint32
         L.emu_chunk_shift.argtypes = [C.c_uint32, C.c_uint32]

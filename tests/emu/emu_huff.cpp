@@ -19,6 +19,11 @@ extern "C" {
 // huff_stage_segment / huff_sync_chunk_shift as the product uses them (host-side helpers of csrc/huff_job.hpp)
 uint32_t emu_stage_segment(uint8_t* dst, const uint8_t* src, uint32_t n) { return huff_stage_segment(dst, src, n); }
 uint32_t emu_slot_bytes(uint32_t n) { return huff_slot_bytes(n); }
+int emu_stage_segment_clean(uint8_t* dst, const uint8_t* src, uint32_t n) {
+    bool clean = true;
+    huff_stage_segment(dst, src, n, &clean);
+    return clean ? 1 : 0;
+}
 uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return huff_sync_chunk_shift(stuffed_bytes, total_blocks); }
 
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
@@ -68,10 +73,13 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
         uint32_t o = 0;
         for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
             const uint32_t first = ps.seg_off[sg], n = ps.seg_off[sg + 1] - first;
+            bool clean = true;
             table[sg] = o;
-            table[sg + 1] = huff_stage_segment(stage + o, data + ps.data_off + first, n);
+            table[sg + 1] = huff_stage_segment(stage + o, data + ps.data_off + first, n, ps.check_at_staging ? &clean : nullptr);
             o += huff_slot_bytes(n);
+            if (!clean) status |= 1u | 16u;  // (batch.cpp: the staging pass refuses the stream)
         }
+        if (status & 1u) continue;
         if (ps.ri == 0) {  // no restart markers: the self-synchronising chunk decoder, passes run one after the other
             HuffSyncLds* S = new HuffSyncLds;
             HuffSyncJob& sj = S->job;

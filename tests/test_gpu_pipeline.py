@@ -191,7 +191,11 @@ def test_pipeline_device_entropy_decoder_streams_without_restart_markers(monkeyp
     _check(names, files, out)
     t = p.timings()
     assert t["images_device_entropy"] >= 12, t  # the plain sequential files did go to the device ...
-    assert t["images_device_rejected"] <= 4, t  # ... and (nearly) all stayed there
+    assert t["total_ms"] < 1500, t              # (hostile headers announcing 65535 x 65535 pixels do not make the call allocate for them)
+    good = [f for n, f in zip(names, files) if "crashtest" not in n]
+    p.decode(good, device_entropy=True)
+    t = p.timings()
+    assert t["images_device_entropy"] >= 12 and t["images_device_rejected"] <= 2, t  # ... and the well-formed ones stayed there
     names, files = [], []
     for (w, h, sub, gray) in [(64, 48, "4:2:0", False), (250, 130, "4:2:0", False), (129, 257, "4:2:2", False), (200, 120, "4:4:4", False),
                               (300, 200, "4:4:4", True), (1920, 1080, "4:2:0", False), (1, 1, "4:2:0", False), (17, 3000, "4:4:4", False),
