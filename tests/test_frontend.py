@@ -137,7 +137,8 @@ def test_max_decoding_buffer_size():
 
 
 FUZZ_SEEDS = ["reftest/mozilla/jpg-size-33x33.jpg", "reftest/mozilla/jpg-progressive.jpg", "reftest/restarts.jpg",
-              "reftest/non-interleaved-mcu.jpg", "reftest/mozilla/jpg-gray.jpg", "reftest/16bit-qtables.jpg", "benches/tower.jpg"]
+              "reftest/non-interleaved-mcu.jpg", "reftest/mozilla/jpg-gray.jpg", "reftest/16bit-qtables.jpg", "benches/tower.jpg",
+              "benches/tower_progressive.jpg", "reftest/progressive3.jpg"]  # (refinement scans through the non-zero bitmaps)
 
 
 @pytest.mark.parametrize("rel", FUZZ_SEEDS)
