@@ -310,6 +310,27 @@ int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len
                 int rc = jpgpu_worker_create(d->device, &d->worker);
                 if (rc) throw DecodeError{rc, "no usable MI355X device: the pixel pipeline has no CPU fallback"};
             }
+            {
+                // A header that announces far more blocks than the stream can hold (two bits per block at the very least):
+                // let the entropy decoder fail into a sink that keeps nothing before planes are allocated for it (a 200-byte
+                // file claiming 65535 x 65535 pixels cost 2.5 s of allocations otherwise).  A stream that decodes goes on.
+                d->fe->read_info();
+                uint64_t blocks = 0;
+                for (uint32_t c = 0; c < d->fe->ncomp(); c++) blocks += (uint64_t)d->fe->components()[c].block_width * d->fe->components()[c].block_height;
+                size_t n = 0;
+                const uint8_t *bytes = d->fe->stream_bytes(&n);
+                if ((uint64_t)n * 8u < blocks * 2u) {
+                    struct Nothing : RowSink {
+                        void start(uint32_t, const jpgpu_component &, const uint16_t *) override {}
+                        void append_row(uint32_t, const int16_t *, size_t) override {}
+                        void finish(uint32_t, uint32_t) override {}
+                    } nothing;
+                    Frontend probe(bytes, n, Frontend::Borrowed{});
+                    probe.set_max_decoding_buffer_size(d->fe->max_decoding_buffer_size());
+                    probe.read_info();
+                    probe.decode_to(nothing);
+                }
+            }
             const bool trace = getenv("JPGPU_DECODER_TRACE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
             auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
