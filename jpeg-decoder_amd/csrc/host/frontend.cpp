@@ -458,8 +458,19 @@ struct Frontend::Impl {
     uint64_t *nz = nullptr;  // the current block's bitmap (null outside progressive frames)
     std::vector<ScanDelta> *rec = nullptr;
     const int16_t *rec_base = nullptr;  // start of the plane the current block belongs to
+    // A scan reports a coefficient at most once: on damaged streams the refinement pass can correct the last coefficient of a
+    // band and overwrite it right away (src/decoder.rs:1241-1252 with nothing left to skip) — the two changes are merged.
+    inline void record(const int16_t &c, int32_t delta) {
+        const uint32_t index = (uint32_t)(&c - rec_base);
+        if (!rec->empty() && rec->back().index == index) {
+            rec->back().delta += delta;
+            if (rec->back().delta == 0) rec->pop_back();
+        } else {
+            rec->push_back(ScanDelta{index, delta});
+        }
+    }
     inline void put(int16_t &c, int16_t v, uint8_t zz) {  // zz: the coefficient's zig-zag position
-        if (rec && v != c) rec->push_back(ScanDelta{(uint32_t)(&c - rec_base), (int32_t)v - (int32_t)c});
+        if (rec && v != c) record(c, (int32_t)v - (int32_t)c);
         if (nz) *nz = v ? (*nz | (1ull << zz)) : (*nz & ~(1ull << zz));
         c = v;
     }
@@ -790,7 +801,7 @@ struct Frontend::Impl {
             const int32_t apply = (int32_t)br.get_bits(src, 1) & (int32_t)((c & bit) == 0);
             const int32_t v = (int32_t)c + (((int32_t)c >> 31) | 1) * (int32_t)bit * apply;
             if (v > 32767 || v < -32768) fail(JPGPU_ERR_FORMAT, "Coefficient overflow");
-            if (rec && apply) rec->push_back(ScanDelta{(uint32_t)(&c - rec_base), v - (int32_t)c});
+            if (rec && apply) record(c, v - (int32_t)c);
             c = (int16_t)v;
         }
         return hit ? stop : (uint8_t)(end - 1);

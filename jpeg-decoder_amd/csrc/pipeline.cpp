@@ -196,8 +196,13 @@ public:
         }
     }
     bool wants_scan_deltas() override { return true; }
+    // The reference hands a component's plane to the worker when a scan completes it (and again if a later scan completes it
+    // again); what scans change AFTER the last such hand-over never reaches the pixels (only damaged or unusual streams have
+    // such scans).  So: changes to a component that has been handed over once wait here until its next hand-over, if any.
     void scan_deltas(uint32_t slot, const jpgpu::host::ScanDelta *d, size_t n) override {
-        if (n) ship_(slot, std::vector<jpgpu::host::ScanDelta>(d, d + n));
+        if (!n) return;
+        if (done_[slot]) late_[slot].emplace_back(d, d + n);
+        else ship_(slot, std::vector<jpgpu::host::ScanDelta>(d, d + n));
     }
     void frame_slot_hint(uint32_t index, uint32_t slot) override { slot_of_[index] = slot; }
     void start(uint32_t index, const jpgpu_component &, const uint16_t qt[64]) override { memcpy(qt_[index], qt, 128); }
@@ -205,6 +210,8 @@ public:
     void finish(uint32_t index, uint32_t slot) override {
         if (slot != slot_of_[index]) throw DecodeError{JPGPU_ERR_INTERNAL, "pipeline: plane finished under another frame slot"};
         memcpy(slot_qt_[slot], qt_[index], 128);
+        for (auto &v : late_[slot]) ship_(slot, std::move(v));
+        late_[slot].clear();
         done_[slot] = true;
     }
     bool done(uint32_t slot) const { return done_[slot]; }
@@ -212,6 +219,7 @@ public:
 
 private:
     std::function<void(uint32_t, std::vector<jpgpu::host::ScanDelta> &&)> ship_;
+    std::vector<std::vector<jpgpu::host::ScanDelta>> late_[4];
     uint32_t slot_of_[4];
     uint16_t qt_[4][64], slot_qt_[4][64];
     bool done_[4];

@@ -240,7 +240,16 @@ public:
         }
     }
     bool wants_scan_deltas() override { return true; }
+    std::vector<std::vector<ScanDelta>> late[4];  // (pipeline.cpp, DeltaSink: changes after a hand-over wait for the next one)
     void scan_deltas(uint32_t slot, const ScanDelta* d, size_t n) override {
+        if (delivered[slot]) {
+            late[slot].emplace_back(d, d + n);
+            scans++;
+            return;
+        }
+        apply(slot, d, n);
+    }
+    void apply(uint32_t slot, const ScanDelta* d, size_t n) {
         scans++;
         for (size_t i = 0; i < n; i++) {
             if (d[i].index >= acc[slot].size()) {
@@ -259,6 +268,8 @@ public:
         std::vector<int16_t> taken;
         taken.swap(work[index]);
         rows[slot].swap(taken);
+        for (auto& v : late[slot]) apply(slot, v.data(), v.size());
+        late[slot].clear();
         delivered[slot] = true;
     }
 };
