@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,12 @@ struct jpgpu_batch {
     size_t entropy_out_cap = 0;
     hipEvent_t entropy_uploaded = nullptr;
     uint8_t *h_bounce = nullptr;  // pinned: jpgpu_batch_download into pageable memory
+    struct DeltaScratch {          // jpgpu_batch_add_deltas: device copy of the entries, one per stream in use
+        hipStream_t stream;
+        uint8_t *d;
+        size_t cap;
+    };
+    std::deque<DeltaScratch> delta_scratch;
     size_t h_bounce_cap = 0;
     std::vector<uint32_t> entropy_images;  // images of the launch in flight
     size_t entropy_out_off = 0;            // offset of the status / stats words inside d_entropy
@@ -256,6 +263,8 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->h_entropy_out) hipHostFree(b->h_entropy_out);
         if (b->entropy_uploaded) hipEventDestroy(b->entropy_uploaded);
         if (b->h_bounce) hipHostFree(b->h_bounce);
+        for (auto &x : b->delta_scratch)
+            if (x.d) hipFree(x.d);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
         if (b->d_image_jobs) hipFree(b->d_image_jobs);
         for (FusedPlan &fp : b->fused) fused_free(fp);
@@ -341,13 +350,31 @@ int jpgpu::batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const
     }
     if (n == 0) return JPGPU_OK;
     hipStream_t s = (hipStream_t)hip_stream;
-    jpgpu_coef_delta *d = nullptr;
-    B_HIP(hipMallocAsync((void **)&d, n * sizeof(jpgpu_coef_delta), s));
-    hipError_t e = hipMemcpyAsync(d, entries, n * sizeof(jpgpu_coef_delta), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = launch_delta_add(d, (uint32_t)n, reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]), (uint32_t)plane, s);
-    const hipError_t f = hipFreeAsync(d, s);
-    if (e == hipSuccess) e = f;
-    if (e != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "add_deltas: %s", hipGetErrorString(e));
+    // One device buffer per stream the caller uses, reused call after call: the stream orders "kernel k has read it" before
+    // "copy k+1 overwrites it".  (The stream-ordered allocator was the first choice — hipMallocAsync / hipFreeAsync per call —
+    // and lost the entries of the very first call of a process now and then.)
+    jpgpu_batch::DeltaScratch *sc = nullptr;
+    {
+        std::lock_guard<std::mutex> g(b->compact_mutex);
+        for (auto &x : b->delta_scratch)
+            if (x.stream == s) sc = &x;
+        if (!sc) {
+            b->delta_scratch.push_back(jpgpu_batch::DeltaScratch{s, nullptr, 0});
+            sc = &b->delta_scratch.back();
+        }
+    }
+    const size_t bytes = n * sizeof(jpgpu_coef_delta);
+    if (sc->cap < bytes) {
+        B_HIP(hipStreamSynchronize(s));  // (the buffer about to go may still be read)
+        if (sc->d) B_HIP(hipFree(sc->d));
+        sc->d = nullptr;
+        sc->cap = 0;
+        B_HIP(hipMalloc((void **)&sc->d, bytes + bytes / 2));
+        sc->cap = bytes + bytes / 2;
+    }
+    B_HIP(hipMemcpyAsync(sc->d, entries, bytes, hipMemcpyHostToDevice, s));
+    B_HIP(launch_delta_add(reinterpret_cast<const jpgpu_coef_delta *>(sc->d), (uint32_t)n, reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]),
+                           (uint32_t)plane, s));
     return JPGPU_OK;
 }
 
