@@ -400,6 +400,56 @@ void jpgpu_pipeline_destroy(jpgpu_pipeline *p) {
 
 const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p) { return p ? p->err.c_str() : ""; }
 
+// Which of the planned streams are better off with the host decoder after all (decided once the headers of a call are read).
+static void back_to_the_host(jpgpu_pipeline *p, uint32_t i, const uint8_t *const *data, const size_t *len) {
+    p->plans[i].clear();  // (the planning pass spent the front-end: a fresh one for the host path)
+    try {
+        p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
+        p->fes[i]->read_info();
+    } catch (const DecodeError &e) {
+        p->status[i] = e.code;
+        p->errors[i] = e.message;
+    }
+}
+
+static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
+    if (getenv("JPGPU_PIPE_FORCE_DEVICE")) return;  // (tests, A/B runs)
+    // Restart-marker streams on the device cost the time of their LONGEST segment (one lane walks it: ≈2.4 µs per byte,
+    // measured with 6 kB segments: 14.7 ms per launch, however many images), on the host the time of ALL their bytes
+    // (≈12 ns per byte and thread).  A few images, or segments of many MCU rows, are better off on the host.
+    size_t max_seg = 0, bytes = 0;
+    uint32_t n_seg_images = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
+            n_seg_images++;
+            for (const jpgpu::host::PlannedScan &ps : p->plans[i])
+                for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+                    max_seg = std::max<size_t>(max_seg, ps.seg_off[sg + 1] - ps.seg_off[sg]);
+                    bytes += ps.seg_off[sg + 1] - ps.seg_off[sg];
+                }
+        }
+    const double device_ms = 1.0 + (double)max_seg * 2.4e-3, host_ms = (double)bytes * 12e-6 / std::max<uint32_t>(1u, p->pool->size() / 2u);
+    if (n_seg_images && device_ms > host_ms) {
+        if (getenv("JPGPU_PIPE_TRACE"))
+            fprintf(stderr, "pipeline trace: %u restart-marker stream(s) stay on the host (longest segment %zu B: device ~%.1f ms, host ~%.1f ms)\n",
+                    n_seg_images, max_seg, device_ms, host_ms);
+        for (uint32_t i = 0; i < n; i++)
+            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) back_to_the_host(p, i, data, len);
+    }
+    // Streams without restart markers whose blocks are very long (noise at quality >= 98: no end-of-block symbols at all) keep
+    // the chunk decoder re-synchronising for dozens of passes (measured: beyond ~350 bits per block more launches than it is
+    // given) — it would flag them in the end; the host decodes them right away instead.
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri == 0) {
+            const jpgpu::host::PlannedScan &ps = p->plans[i][0];
+            uint64_t blocks = 0;
+            for (uint32_t c = 0; c < ps.ncomp; c++) blocks += (uint64_t)ps.comp[c].h * ps.comp[c].v;
+            blocks *= ps.n_mcu;
+            const uint64_t bits = ps.seg_off.size() >= 2 ? (uint64_t)(ps.seg_off[1] - ps.seg_off[0]) * 8u : 0u;
+            if (blocks && bits / blocks > 384u) back_to_the_host(p, i, data, len);
+        }
+}
+
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
     if (!p || !p->pool || (n && (!data || !len))) return JPGPU_ERR_FORMAT;
     int rc = jpgpu::use_device(p->device, p->err);
@@ -479,61 +529,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             p->errors[i] = e.what();
         }
     });
-    // Restart-marker streams on the device cost the time of their LONGEST segment (one lane walks it: ≈2.4 µs per byte,
-    // measured with 6 kB segments: 14.7 ms per launch, however many images), on the host the time of ALL their bytes
-    // (≈12 ns per byte and thread).  A few images, or segments of many MCU rows, are better off on the host.
-    if (device_entropy) {
-        size_t max_seg = 0, bytes = 0;
-        uint32_t n_seg_images = 0;
-        for (uint32_t i = 0; i < n; i++)
-            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
-                n_seg_images++;
-                for (const jpgpu::host::PlannedScan &ps : p->plans[i])
-                    for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
-                        max_seg = std::max<size_t>(max_seg, ps.seg_off[sg + 1] - ps.seg_off[sg]);
-                        bytes += ps.seg_off[sg + 1] - ps.seg_off[sg];
-                    }
-            }
-        const double device_ms = 1.0 + (double)max_seg * 2.4e-3, host_ms = (double)bytes * 12e-6 / std::max<uint32_t>(1u, p->pool->size() / 2u);
-        if (n_seg_images && device_ms > host_ms && !getenv("JPGPU_PIPE_FORCE_DEVICE")) {
-            if (getenv("JPGPU_PIPE_TRACE"))
-                fprintf(stderr, "pipeline trace: %u restart-marker stream(s) stay on the host (longest segment %zu B: device ~%.1f ms, host ~%.1f ms)\n",
-                        n_seg_images, max_seg, device_ms, host_ms);
-            for (uint32_t i = 0; i < n; i++)
-                if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
-                    p->plans[i].clear();
-                    try {
-                        p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
-                        p->fes[i]->read_info();
-                    } catch (const DecodeError &e) {
-                        p->status[i] = e.code;
-                        p->errors[i] = e.message;
-                    }
-                }
-        }
-    }
-    // Streams without restart markers whose blocks are very long (noise at quality >= 98: no end-of-block symbols at all) keep
-    // the chunk decoder re-synchronising for dozens of passes (measured: beyond ~350 bits per block more launches than it is
-    // given) — it would flag them in the end; the host decodes them right away instead.
-    if (device_entropy && !getenv("JPGPU_PIPE_FORCE_DEVICE"))
-        for (uint32_t i = 0; i < n; i++)
-            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri == 0) {
-                const jpgpu::host::PlannedScan &ps = p->plans[i][0];
-                uint64_t blocks = 0;
-                for (uint32_t c = 0; c < ps.ncomp; c++) blocks += (uint64_t)ps.comp[c].h * ps.comp[c].v;
-                blocks *= ps.n_mcu;
-                const uint64_t bits = ps.seg_off.size() >= 2 ? (uint64_t)(ps.seg_off[1] - ps.seg_off[0]) * 8u : 0u;
-                if (blocks && bits / blocks > 384u) {
-                    p->plans[i].clear();
-                    try {
-                        p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
-                        p->fes[i]->read_info();
-                    } catch (const DecodeError &e) {
-                        p->status[i] = e.code;
-                        p->errors[i] = e.message;
-                    }
-                }
-            }
+    if (device_entropy) keep_on_host_what_the_device_would_decode_slower(p, data, len, n);
     const double t1 = now_ms();
 
     // 2. sub-batches of the images that have a frame (each kept while its geometry sequence repeats)
