@@ -299,19 +299,25 @@ struct F420 {
             const TPrime &q = t[comp];
             uint32_t m[4] = {pk_mad3(q.tE1, q.tOm), pk_mad3(q.tE1, q.tO1), pk_mad3(q.tO1, q.tE1), pk_mad3(q.tO1, q.tEp)};
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++) pk[comp][i] = pk_shr(H2V1 ? pk_add(m[i], 0x00020002u) : m[i], SH);
+            for (uint32_t i = 0; i < 4; i++) {
+                // Cb stays unshifted: its two values are taken apart with one v_bfe / v_lshrrev each, which do the shift as
+                // well (Cr is taken apart for free by the sub-dword operand selects of its two multiplications)
+                const uint32_t mi = H2V1 ? pk_add(m[i], 0x00020002u) : m[i];
+                pk[comp][i] = comp == 0u ? mi : pk_shr(mi, SH);
+            }
         }
         const uint32_t last_x = 2u * g.cw - 1u;
         if (ox0 == 0u || last_x - ox0 < 8u) {  // rare: first / last image column
 #pragma unroll
             for (uint32_t comp = 0; comp < 2; comp++) {
+                const uint32_t up = comp == 0u ? SH : 0u;  // (Cb: see above)
                 if (ox0 == 0u)  // src/upsampler.rs:213-214: px0 = t'(s0) >> 2
-                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | ((t[comp].tE1 & 0xffffu) >> ESH);
+                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | (((t[comp].tE1 & 0xffffu) >> ESH) << up);
                 if (last_x - ox0 < 8u) {  // src/upsampler.rs:226: last column (odd k): t'(s_(k>>1)) >> 2
                     const uint32_t k = last_x - ox0;
                     const uint32_t tm = k == 1u ? (t[comp].tE1 & 0xffffu) : k == 3u ? (t[comp].tO1 & 0xffffu)
                                         : k == 5u ? (t[comp].tE1 >> 16) : (t[comp].tO1 >> 16);
-                    const uint32_t v = tm >> ESH;
+                    const uint32_t v = (tm >> ESH) << up;
                     if (k == 1u) pk[comp][1] = (pk[comp][1] & 0xffff0000u) | v;
                     if (k == 3u) pk[comp][3] = (pk[comp][3] & 0xffff0000u) | v;
                     if (k == 5u) pk[comp][1] = (pk[comp][1] & 0x0000ffffu) | (v << 16);
@@ -324,7 +330,7 @@ struct F420 {
                            byte_shl20<0>(yy.y), byte_shl20<1>(yy.y), byte_shl20<2>(yy.y), byte_shl20<3>(yy.y)};
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t cb = (k < 4) ? (pk[0][k & 3u] & 0xffffu) : (pk[0][k & 3u] >> 16);
+            const uint32_t cb = (k < 4) ? ((pk[0][k & 3u] >> SH) & (0xffffu >> SH)) : (pk[0][k & 3u] >> (16u + SH));
             const uint32_t cr = (k < 4) ? (pk[1][k & 3u] & 0xffffu) : (pk[1][k & 3u] >> 16);
             p[k] = ycbcr_raw_yb(yb[k], cb, cr);
         }
@@ -374,26 +380,38 @@ struct F420 {
             const size_t pitch = (size_t)g.out_w * 3u;
             JP_GLOBAL uint8_t *rowa = out + (size_t)oya * pitch, *rowb = out + (size_t)oyb * pitch;
             const bool al4a = (((size_t)oya * pitch) & 3u) == 0, al4b = (((size_t)oyb * pitch) & 3u) == 0;
-#pragma unroll 1
-            for (uint32_t chk = lane; chk < nch; chk += 64u) {
+            // The lane's six LDS rows as finished, opaque addresses (chunk `lane`; LDS column of plane column j0 - 4 is
+            // 4*chk + 4): left to itself the compiler keeps offsets in the loop's registers and adds the start of the
+            // dynamic LDS segment at every use (`v_add_u32 v, 0, v`, six per unit).  A clamped chroma row is never staged:
+            // its partner stands in (uniform per slot).
+            const uint8_t *pu[2], *pl[2];
+#pragma unroll
+            for (uint32_t comp = 0; comp < 2; comp++) {
+                pu[comp] = opaque_lds(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * lds.cpitch + 4u * lane + 4u]);
+                pl[comp] = opaque_lds(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * lds.cpitch + 4u * lane + 4u]);
+            }
+            const uint8_t *pya = opaque_lds(&lds.coef[(uint32_t)(va ? ra : rb) * ypitch + 8u * lane]);
+            const uint8_t *pyb = opaque_lds(&lds.coef[(uint32_t)(vb ? rb : ra) * ypitch + 8u * lane]);
+            static_assert(F420_TX_MAX <= 64u, "a lane takes at most two chunks of a row");
+#pragma unroll  // both chunks spelled out: the second one's addresses are immediate offsets of the first one's
+            for (uint32_t it = 0; it < 2u; it++) {
+                const uint32_t chk = lane + 64u * it;
                 const uint32_t ox0 = 16u * x0m + 8u * chk;
-                if (ox0 >= g.out_w) continue;
-                const uint32_t coff = 4u * chk + 4u;  // LDS column of plane column j0 - 4
+                if (chk >= nch || ox0 >= g.out_w) continue;
                 ChromaEO eu[2], el[2];
 #pragma unroll
                 for (uint32_t comp = 0; comp < 2; comp++) {
-                    // a clamped row is never staged: substitute its partner (uniform per slot)
-                    eu[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * lds.cpitch + coff]);
-                    el[comp] = load_eo(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * lds.cpitch + coff]);
+                    eu[comp] = load_eo(pu[comp] + 256u * it);
+                    el[comp] = load_eo(pl[comp] + 256u * it);
                 }
                 if (va) {
                     const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};
-                    const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)ra * ypitch + 8u * chk]);
+                    const v2u yy = *reinterpret_cast<const v2u *>(pya + 512u * it);
                     row_pixels(g, rowa, al4a, t, yy, ox0);
                 }
                 if (vb) {
                     const TPrime t[2] = {tprime(el[0], eu[0]), tprime(el[1], eu[1])};
-                    const v2u yy = *reinterpret_cast<const v2u *>(&lds.coef[(uint32_t)rb * ypitch + 8u * chk]);
+                    const v2u yy = *reinterpret_cast<const v2u *>(pyb + 512u * it);
                     row_pixels(g, rowb, al4b, t, yy, ox0);
                 }
             }

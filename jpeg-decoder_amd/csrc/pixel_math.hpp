@@ -29,6 +29,19 @@
 #define JP_LDS __attribute__((address_space(3)))  // ds_* instead of flat_* when a pointer to LDS crosses a function boundary
 #endif
 
+// A pointer into LDS as a value the compiler cannot look into (it stays an LDS pointer: ds_* instructions).  For addresses
+// that are used inside a loop: a known one is kept as offset + segment start and put together at every use.
+template <class T>
+__device__ __forceinline__ T *opaque_lds(T *p) {
+#ifdef JPGPU_HOST_EMULATION
+    return p;
+#else
+    JP_LDS T *q = (JP_LDS T *)p;
+    asm volatile("" : "+v"(q));
+    return (T *)q;
+#endif
+}
+
 namespace jpgpu {
 
 // Plain vector types for memory access (the HIP uint2/uint4 classes cannot be assigned through
