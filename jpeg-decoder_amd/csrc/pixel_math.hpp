@@ -292,6 +292,9 @@ constexpr uint32_t pk_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((
 // Inputs arrive as signed 16-bit pairs p02 = (s0,s2), p46 = (s4,s6), p13 = (s1,s3), p57 = (s5,s7), so each
 // row of the maps is two v_dot2_i32_i16 (2 MACs per instruction, full rate): 16 dot2 + 8 add/sub per
 // pass instead of 12 multiplies + 29 adds.  Valid whenever every input fits i16.
+// PLUS_SHL: o[0..3] (the sums) come out shifted left by that much — (a + b) << n is one instruction (v_add_lshl_u32),
+// (a - b) << n is not.
+template <int PLUS_SHL = 0>
 __device__ __forceinline__ void idct_pass8_dot2(uint32_t p02, uint32_t p46, uint32_t p13, uint32_t p57, w32 x_scale,
                                                 w32 (&o)[8]) {
     const w32 x0 = dot2_i16(p02, pk_i16(4096, 5352), dot2_i16_sc(p46, pk_i16(4096, 2217), x_scale));
@@ -302,13 +305,13 @@ __device__ __forceinline__ void idct_pass8_dot2(uint32_t p02, uint32_t p46, uint
     const w32 u1 = dot2_i16(p13, pk_i16(3219, -5681), dot2_i16_sc(p57, pk_i16(1132, 4816), 0u));
     const w32 u2 = dot2_i16(p13, pk_i16(4816, -1129), dot2_i16_sc(p57, pk_i16(-5681, -3218), 0u));
     const w32 u3 = dot2_i16(p13, pk_i16(5683, 4816), dot2_i16_sc(p57, pk_i16(3219, 1131), 0u));
-    o[0] = x0 + u3;
+    o[0] = (x0 + u3) << PLUS_SHL;
     o[7] = x0 - u3;
-    o[1] = x1 + u2;
+    o[1] = (x1 + u2) << PLUS_SHL;
     o[6] = x1 - u2;
-    o[2] = x2 + u1;
+    o[2] = (x2 + u1) << PLUS_SHL;
     o[5] = x2 - u1;
-    o[3] = x3 + u0;
+    o[3] = (x3 + u0) << PLUS_SHL;
     o[4] = x3 - u0;
 }
 
@@ -375,18 +378,26 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint32_t
             const uint32_t p02 = perm_b32(d[2 * 4 + j], d[0 * 4 + j], sel), p46 = perm_b32(d[6 * 4 + j], d[4 * 4 + j], sel);
             const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
             w32 o[8];
-            idct_pass8_dot2(p02, p46, p13, p57, 512u, o);
+            if constexpr (ARITH == ARITH_TIGHT) {
+                // The row pass wants bits 10..25 of these as 16-bit halves: rows 0..3 (sums) leave the pass shifted left by 6
+                // and the pairing below takes their HIGH halves (32 shifts less per block); rows 4..7 are shifted here.
+                idct_pass8_dot2<6>(p02, p46, p13, p57, 512u, o);
 #pragma unroll
-            for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
+                for (int k = 0; k < 8; k++) t[k * 8 + i] = k < 4 ? o[k] : sar(o[k], 10);
+            } else {
+                idct_pass8_dot2(p02, p46, p13, p57, 512u, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             w32 o[8];
             if constexpr (ARITH == ARITH_TIGHT) {
                 // the row's eight values fit i16: pair them (0,2) (4,6) (1,3) (5,7) and use dot2 again
-                const uint32_t lo16 = 0x05040100u;
-                idct_pass8_dot2(perm_b32(t[r * 8 + 2], t[r * 8 + 0], lo16), perm_b32(t[r * 8 + 6], t[r * 8 + 4], lo16),
-                                perm_b32(t[r * 8 + 3], t[r * 8 + 1], lo16), perm_b32(t[r * 8 + 7], t[r * 8 + 5], lo16), X_SCALE, o);
+                const uint32_t h16 = r < 4 ? 0x07060302u : 0x05040100u;  // (see the column pass)
+                idct_pass8_dot2(perm_b32(t[r * 8 + 2], t[r * 8 + 0], h16), perm_b32(t[r * 8 + 6], t[r * 8 + 4], h16),
+                                perm_b32(t[r * 8 + 3], t[r * 8 + 1], h16), perm_b32(t[r * 8 + 7], t[r * 8 + 5], h16), X_SCALE, o);
             } else {
                 w32 s[8];
 #pragma unroll
