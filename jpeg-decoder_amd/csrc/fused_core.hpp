@@ -262,13 +262,15 @@ struct F420 {
         c.E2 = d[2] & 0x00ff00ffu;
         return c;
     }
-    // t' = 3*near + far + 2 (src/upsampler.rs:209,217):
+    // t' = 3*near + far + 2 (src/upsampler.rs:209,217), kept as t'' = t' - 512 (mod 2^16): the horizontal step then yields
+    // 3*t''main + t''other = (3*t'main + t'other) - 2048, whose arithmetic shift by 4 is the chroma sample MINUS 128 — the
+    // form the colour conversion wants (src/decoder.rs:1489-1491), for the price of another constant in the same addition.
     //   tE1 = (s2, s0)  tO1 = (s3, s1)  tOm = (s1, s_-1)  tEp = (s4, s2)
     struct TPrime {
         uint32_t tE1, tO1, tOm, tEp;
     };
     static __device__ __forceinline__ TPrime tprime(const ChromaEO &n, const ChromaEO &f) {
-        const uint32_t two = 0x00020002u;
+        const uint32_t two = 0xfe02fe02u;  // 2 - 512 per lane
         const uint32_t tO0 = pk_add(pk_mad3(n.O0, f.O0), two);
         const uint32_t tE1 = pk_add(pk_mad3(n.E1, f.E1), two);
         const uint32_t tO1 = pk_add(pk_mad3(n.O1, f.O1), two);
@@ -288,36 +290,34 @@ struct F420 {
     // that scanline starts 4-byte aligned (then every 8-pixel chunk does: 24*chk is a multiple of 4)
     // H2V1 = true: `t` holds raw samples and only the horizontal step of UpsamplerH2V1 is applied
     // (src/upsampler.rs:134-163): c = (3*s_main + s_other + 2) >> 2, first / last column c = s_main.
+    // Either way a 16-bit lane of pk[][] ends up holding (c - 128) << SH (plus fraction bits below SH): the two values of
+    // a dword are taken apart, shifted and sign-extended by one v_bfe_i32 / v_ashrrev_i32 each.
     template <bool H2V1 = false>
     static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *rowp, bool row_al4,
                                                       const TPrime (&t)[2], v2u yy, uint32_t ox0) {
         // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
-        constexpr uint32_t SH = H2V1 ? 2u : 4u, ESH = H2V1 ? 0u : 2u;
+        constexpr uint32_t SH = H2V1 ? 2u : 4u;
         uint32_t pk[2][4];
 #pragma unroll
         for (uint32_t comp = 0; comp < 2; comp++) {
             const TPrime &q = t[comp];
             uint32_t m[4] = {pk_mad3(q.tE1, q.tOm), pk_mad3(q.tE1, q.tO1), pk_mad3(q.tO1, q.tE1), pk_mad3(q.tO1, q.tEp)};
 #pragma unroll
-            for (uint32_t i = 0; i < 4; i++) {
-                // Cb stays unshifted: its two values are taken apart with one v_bfe / v_lshrrev each, which do the shift as
-                // well (Cr is taken apart for free by the sub-dword operand selects of its two multiplications)
-                const uint32_t mi = H2V1 ? pk_add(m[i], 0x00020002u) : m[i];
-                pk[comp][i] = comp == 0u ? mi : pk_shr(mi, SH);
-            }
+            for (uint32_t i = 0; i < 4; i++) pk[comp][i] = H2V1 ? pk_add(m[i], 0xfe02fe02u) : m[i];
         }
         const uint32_t last_x = 2u * g.cw - 1u;
         if (ox0 == 0u || last_x - ox0 < 8u) {  // rare: first / last image column
+            // the lane of c = t'main >> 2 (tm = t''main as 16 bits), of c = s_main (tm = the sample) with H2V1
+            auto edge_lane = [](uint32_t tm) -> uint32_t { return H2V1 ? ((tm << 2) - 512u) & 0xffffu : (tm << 2) & 0xfff0u; };
 #pragma unroll
             for (uint32_t comp = 0; comp < 2; comp++) {
-                const uint32_t up = comp == 0u ? SH : 0u;  // (Cb: see above)
                 if (ox0 == 0u)  // src/upsampler.rs:213-214: px0 = t'(s0) >> 2
-                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | (((t[comp].tE1 & 0xffffu) >> ESH) << up);
+                    pk[comp][0] = (pk[comp][0] & 0xffff0000u) | edge_lane(t[comp].tE1 & 0xffffu);
                 if (last_x - ox0 < 8u) {  // src/upsampler.rs:226: last column (odd k): t'(s_(k>>1)) >> 2
                     const uint32_t k = last_x - ox0;
                     const uint32_t tm = k == 1u ? (t[comp].tE1 & 0xffffu) : k == 3u ? (t[comp].tO1 & 0xffffu)
                                         : k == 5u ? (t[comp].tE1 >> 16) : (t[comp].tO1 >> 16);
-                    const uint32_t v = (tm >> ESH) << up;
+                    const uint32_t v = edge_lane(tm);
                     if (k == 1u) pk[comp][1] = (pk[comp][1] & 0xffff0000u) | v;
                     if (k == 3u) pk[comp][3] = (pk[comp][3] & 0xffff0000u) | v;
                     if (k == 5u) pk[comp][1] = (pk[comp][1] & 0x0000ffffu) | (v << 16);
@@ -330,9 +330,9 @@ struct F420 {
                            byte_shl20<0>(yy.y), byte_shl20<1>(yy.y), byte_shl20<2>(yy.y), byte_shl20<3>(yy.y)};
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t cb = (k < 4) ? ((pk[0][k & 3u] >> SH) & (0xffffu >> SH)) : (pk[0][k & 3u] >> (16u + SH));
-            const uint32_t cr = (k < 4) ? (pk[1][k & 3u] & 0xffffu) : (pk[1][k & 3u] >> 16);
-            p[k] = ycbcr_raw_yb(yb[k], cb, cr);
+            const int32_t cb = (k < 4) ? ((int32_t)(pk[0][k & 3u] << 16) >> (16u + SH)) : ((int32_t)pk[0][k & 3u] >> (16u + SH));
+            const int32_t cr = (k < 4) ? ((int32_t)(pk[1][k & 3u] << 16) >> (16u + SH)) : ((int32_t)pk[1][k & 3u] >> (16u + SH));
+            p[k] = ycbcr_raw_centred(yb[k], cb, cr);
         }
         JP_GLOBAL uint8_t *o = rowp + ox0 * 3u;
         const uint32_t n = min(8u, g.out_w - ox0);

@@ -510,6 +510,27 @@ __device__ __forceinline__ RawRgb ycbcr_raw_yb(w32 yb, uint32_t cb, uint32_t cr)
     o.b = yb + (mul24(cb, CB_B) + (w32)KB);
     return o;
 }
+// The same values from chroma samples that already had their 128 taken off (src/decoder.rs:1489-1491 as written): one
+// rounding term for all three channels, so each channel is a chain of v_mad_i32_i24 that starts from it.
+// (as an instruction: left to itself the compiler turns the two-step chain of the green channel into two multiplications
+// and a three-operand addition)
+__device__ __forceinline__ w32 mad24(w32 a, int32_t c_uniform, w32 acc) {
+#ifdef JPGPU_HOST_EMULATION
+    return mul24(a, c_uniform) + acc;
+#else
+    w32 r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c_uniform), "v"(acc));
+    return r;
+#endif
+}
+__device__ __forceinline__ RawRgb ycbcr_raw_centred(w32 yb, int32_t cb, int32_t cr) {
+    const w32 yh = yb + (1u << 19);
+    RawRgb o;
+    o.r = mad24((w32)cr, CR_R, yh);
+    o.g = mad24((w32)cb, -CB_G, mad24((w32)cr, -CR_G, yh));
+    o.b = mad24((w32)cb, CB_B, yh);
+    return o;
+}
 __device__ __forceinline__ RawRgb ycbcr_raw(uint32_t y, uint32_t cb, uint32_t cr) {
     const w32 yb = y << 20;
     RawRgb o;
