@@ -248,18 +248,21 @@ struct F420 {
     }
 
     // Chroma columns of one 8-pixel chunk as packed 16-bit lane pairs (hi, lo).  Plane column
-    // j0 + i (j0 = ox0/2) is sample s_i; an output row needs s_-1 .. s_4.
-    //   O0 = (s_-1, s_-3)   E1 = (s2, s0)   O1 = (s3, s1)   E2 = (s6, s4)
+    // j0 + i (j0 = ox0/2) is sample s_i; an output row needs s_-1 .. s_4, as the main samples of the even / odd pixel
+    // pairs and their outer neighbours:
+    //   E1 = (s2, s0)   O1 = (s3, s1)   Om = (s1, s_-1)   Ep = (s4, s2)
+    // (the two shifted pairs are byte permutes of the loaded dwords: cheaper here, once per chroma row, than as funnel
+    // shifts of the t' values, once per output row)
     struct ChromaEO {
-        uint32_t O0, E1, O1, E2;
+        uint32_t E1, O1, Om, Ep;
     };
     static __device__ __forceinline__ ChromaEO load_eo(const uint8_t *row) {
         const uint32_t *d = reinterpret_cast<const uint32_t *>(row);  // dwords: cols j0-4.., j0.., j0+4..
         ChromaEO c;
-        c.O0 = pk_shr(d[0], 8);
         c.E1 = d[1] & 0x00ff00ffu;
         c.O1 = pk_shr(d[1], 8);
-        c.E2 = d[2] & 0x00ff00ffu;
+        c.Om = perm_b32(d[1], d[0], 0x0c050c03u);  // (d1.byte1, d0.byte3)
+        c.Ep = perm_b32(d[2], d[1], 0x0c040c02u);  // (d2.byte0, d1.byte2)
         return c;
     }
     // t' = 3*near + far + 2 (src/upsampler.rs:209,217), kept as t'' = t' - 512 (mod 2^16): the horizontal step then yields
@@ -271,15 +274,11 @@ struct F420 {
     };
     static __device__ __forceinline__ TPrime tprime(const ChromaEO &n, const ChromaEO &f) {
         const uint32_t two = 0xfe02fe02u;  // 2 - 512 per lane
-        const uint32_t tO0 = pk_add(pk_mad3(n.O0, f.O0), two);
-        const uint32_t tE1 = pk_add(pk_mad3(n.E1, f.E1), two);
-        const uint32_t tO1 = pk_add(pk_mad3(n.O1, f.O1), two);
-        const uint32_t tE2 = pk_add(pk_mad3(n.E2, f.E2), two);
         TPrime t;
-        t.tE1 = tE1;
-        t.tO1 = tO1;
-        t.tOm = alignbit(tO1, tO0, 16);  // (tO1.lo, tO0.hi) = (s1, s_-1)
-        t.tEp = alignbit(tE2, tE1, 16);  // (tE2.lo, tE1.hi) = (s4, s2)
+        t.tE1 = pk_add(pk_mad3(n.E1, f.E1), two);
+        t.tO1 = pk_add(pk_mad3(n.O1, f.O1), two);
+        t.tOm = pk_add(pk_mad3(n.Om, f.Om), two);
+        t.tEp = pk_add(pk_mad3(n.Ep, f.Ep), two);
         return t;
     }
 
@@ -737,8 +736,8 @@ struct F422 {
                 const typename P::ChromaEO e = P::load_eo(ctile + (comp * 8u + row) * cp + 4u * chk + 4u);
                 t[comp].tE1 = e.E1;
                 t[comp].tO1 = e.O1;
-                t[comp].tOm = alignbit(e.O1, e.O0, 16);  // (s1, s_-1)
-                t[comp].tEp = alignbit(e.E2, e.E1, 16);  // (s4, s2)
+                t[comp].tOm = e.Om;
+                t[comp].tEp = e.Ep;
             }
             const v2u yy = *reinterpret_cast<const v2u *>(lds.coef + row * ypitch + 8u * chk);
             const size_t ro = (size_t)oy * pitch;
