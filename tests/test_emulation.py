@@ -136,6 +136,8 @@ GEOMS = [
     (1025, 40, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1920, 24, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (2050, 18, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (672, 65, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (673, 79, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (30, 160, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (36, 20, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (38, 10, [(2, 2), (1, 1), (1, 1)], "YCbCr"),  # last column in pixel 3 / 5 of a chunk
+    (36, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (38, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (45, 29, [(1, 1), (1, 1), (1, 1)], "RGB"),
     (650, 20, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (1, 1, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
     (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2, 1, [(2, 1), (1, 1), (1, 1)], "YCbCr"),

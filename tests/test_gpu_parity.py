@@ -361,10 +361,10 @@ def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
 
 
 MIXED_SIZES = {
-    "420": ([(2, 2), (1, 1), (1, 1)], "YCbCr", "fused420", [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (1920, 64), (17, 1080), (640, 480)]),
+    "420": ([(2, 2), (1, 1), (1, 1)], "YCbCr", "fused420", [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (1920, 64), (17, 1080), (640, 480), (36, 20), (38, 20), (3, 5), (30, 40)]),
     "444": ([(1, 1), (1, 1), (1, 1)], "YCbCr", "fused444", [(45, 29), (200, 120), (1, 1), (513, 8), (9, 300), (640, 480)]),
     "444rgb": ([(1, 1), (1, 1), (1, 1)], "RGB", "fused444", [(45, 29), (8, 8), (700, 33)]),
-    "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr", "fused422", [(64, 24), (33, 17), (2, 1), (1000, 9), (17, 300), (1984, 8), (1985, 8), (640, 480)]),
+    "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr", "fused422", [(64, 24), (33, 17), (2, 1), (1000, 9), (17, 300), (1984, 8), (1985, 8), (640, 480), (36, 9), (38, 9), (3, 9), (30, 17)]),
     "gray": ([(1, 1)], "Grayscale", "fusedgray", [(37, 21), (300, 200), (1, 1000), (2056, 9), (8, 8)]),
 }
 
