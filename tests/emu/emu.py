@@ -16,6 +16,8 @@ def lib():
         L.emu_idct_small.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.emu_ycbcr.argtypes = [C.c_uint32] * 3
         L.emu_ycbcr.restype = C.c_uint32
+        L.emu_ycbcr_centred_mismatches.argtypes = []
+        L.emu_ycbcr_centred_mismatches.restype = C.c_uint32
         L.emu_fused_decode.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]
         L.emu_fused_decode.restype = C.c_int
         L.emu_compute_image.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint16, C.c_uint16, C.c_int, C.c_void_p,

@@ -19,4 +19,20 @@ void emu_idct_small(int scale, const int16_t* c, const uint16_t* q, uint8_t* out
     }
 }
 uint32_t emu_ycbcr(uint32_t y, uint32_t cb, uint32_t cr) { return jpgpu::ycbcr_to_rgb24(y, cb, cr); }
+// every (y, cb, cr): the form the fused 4:2:0 / 4:2:2 passes use (chroma with its 128 already taken off, one rounding term)
+// against src/decoder.rs:1486-1508 written out; returns the number of inputs that differ
+uint32_t emu_ycbcr_centred_mismatches(void) {
+    uint32_t bad = 0;
+    for (int y = 0; y < 256; y++)
+        for (int cb = 0; cb < 256; cb++)
+            for (int cr = 0; cr < 256; cr++) {
+                const jpgpu::RawRgb p = jpgpu::ycbcr_raw_centred((uint32_t)y << 20, cb - 128, cr - 128);
+                const uint32_t got = jpgpu::sar_sat_u8x2(p.r, p.g, 20) | (jpgpu::sar_sat_u8x2(p.b, 0u, 20) << 16);
+                const int64_t Y = (int64_t)y * (1 << 20) + (1 << 19);
+                int64_t r = (Y + 1470104ll * (cr - 128)) >> 20, g = (Y - 360857ll * (cb - 128) - 748830ll * (cr - 128)) >> 20, b = (Y + 1858077ll * (cb - 128)) >> 20;
+                r = r < 0 ? 0 : r > 255 ? 255 : r; g = g < 0 ? 0 : g > 255 ? 255 : g; b = b < 0 ? 0 : b > 255 ? 255 : b;
+                bad += got != (uint32_t)(r | (g << 8) | (b << 16));
+            }
+    return bad;
+}
 }

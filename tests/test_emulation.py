@@ -107,6 +107,12 @@ def test_device_ycbcr_all_inputs():
         assert emu.lib().emu_ycbcr(int(y[i, j, k]), int(cb[i, j, k]), int(cr[i, j, k])) == int(want[i, j, k])
 
 
+def test_device_ycbcr_on_centred_chroma_all_inputs():
+    """The colour conversion of the fused 4:2:0 / 4:2:2 passes (chroma arrives minus 128, v_mad chains from one rounding
+    term) gives src/decoder.rs:1486-1508 for all 2^24 inputs."""
+    assert emu.lib().emu_ycbcr_centred_mismatches() == 0
+
+
 def _to_j(ocomps):
     out = (J.Component * len(ocomps))()
     for i, c in enumerate(ocomps):
