@@ -24,7 +24,17 @@ namespace jpgpu {
 // start of every workgroup (measured: 2 % on the 4:2:0 bench).
 __device__ __forceinline__ FusedWork locate(const FusedWork *__restrict__ work) {
     if (work) return work[blockIdx.x];
+#ifdef JPGPU_XCD_SWIZZLE
+    // Experiment: workgroups are handed to the 8 XCDs round-robin in launch order; renumber them so that each
+    // XCD walks one contiguous eighth of the (tile, MCU row, image) space — neighbours in x and y then share an L2.
+    const uint32_t gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    uint32_t l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if ((n & 7u) == 0u) l = (l & 7u) * (n >> 3) + (l >> 3);
+    const uint32_t t = l / gx;
+    return FusedWork{t / gy, l - t * gx, t - (t / gy) * gy, 0u};
+#else
     return FusedWork{blockIdx.z, blockIdx.x, blockIdx.y, 0u};
+#endif
 }
 
 // work item of the chroma pass: a = component (0 Cb, 1 Cr), b = 256-block group within the plane
