@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
     ap.add_argument("--generic", action="store_true", help="force the two-kernel generic path")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--settle", type=int, default=-1,
+                    help="untimed launches BEFORE the warm-up steps that let the GPU leave its clock transient after an idle "
+                         "period (DESIGN.md §5: the first ~25 launches run up to 50 %% slower); default: enough to make "
+                         "settle + warm-up = 50 launches, i.e. none for the default warm-up; 0 switches it off")
     return ap.parse_args()
 
 
@@ -167,7 +171,8 @@ def main():
         batch.set_range_hint(i, variants[i % nv]["sane"])
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    for _ in range(max(args.warmup, 0)):
+    settle = max(0, 50 - max(args.warmup, 0)) if args.settle < 0 else args.settle
+    for _ in range(settle + max(args.warmup, 0)):
         batch.decode(stream)
     torch.cuda.synchronize(dev)
     if dist:
@@ -230,7 +235,7 @@ def main():
         achieved = alg_bytes / (gpu_ms_per_step * 1e-3) / 1e9
         line = {
             "metric": "megapixels/s decoded (batch, whole node)", "value": round(value, 1), "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_launches_before_warmup": settle,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32 fixed-point (i16 coefficients -> u8 pixels)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} baseline " + " + ".join('x'.join(str(hh) + str(vv) for hh, vv in v["sampling"]) + " " + v["ct"]
