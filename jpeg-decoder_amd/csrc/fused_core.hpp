@@ -649,7 +649,7 @@ struct S420 {
 // wave 2 the te+2 Cb blocks and wave 3 the te+2 Cr blocks under them — one halo block either side, because
 // UpsamplerH2V1 (src/upsampler.rs:134-163) reads the sample left / right of each chroma sample; there is no vertical
 // neighbourhood, so nothing has to come from other MCU rows.  Every wave works on one component: its quantization
-// table stays in SGPRs.  The pixel phase deals the 8 rows x 2*te chunks over all lanes.
+// table stays in SGPRs.  In the pixel phase wave w takes tile rows w and w + 4 and its lanes walk the row's 2*te chunks.
 // =============================================================================================
 template <int ARITH>
 struct F422 {
@@ -718,30 +718,39 @@ struct F422 {
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLdsSmall &lds) {
         const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t nch = 2u * te, nunits = 8u * nch;
-        const uint32_t magic = 0xffffffffu / nch + 1u;  // mul_hi(u, magic) == u / nch for u < 65536
+        const uint32_t nch = 2u * te;
         const uint32_t ypitch = 16u * g.tx, cp = cpitch(g);
         const uint8_t *ctile = lds.coef + 8u * ypitch;
         JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
         const size_t pitch = (size_t)g.out_w * 3u;
+        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
+        // Wave w takes tile rows w and w + 4, its lanes walk the row's chunks (at most two each: tx <= 62): the scanline is
+        // wave-uniform (scalar address math), the lane's LDS addresses are finished before the chunks (see F420::phase3).
+        static_assert(F422_TX_MAX <= 64u, "a lane takes at most two chunks of a row");
 #pragma unroll 1
-        for (uint32_t u = tid; u < nunits; u += NT) {
-            const uint32_t row = __umulhi(u, magic), chk = u - row * nch;
-            const uint32_t oy = 8u * my + row, ox0 = 16u * x0m + 8u * chk;
-            if (oy >= g.out_h || ox0 >= g.out_w) continue;
-            typename P::TPrime t[2];
-#pragma unroll
-            for (uint32_t comp = 0; comp < 2; comp++) {
-                // tile column of plane column j0 - 4 (j0 = ox0 / 2): 4*chk + 4, as in the 4:2:0 kernels
-                const typename P::ChromaEO e = P::load_eo(ctile + (comp * 8u + row) * cp + 4u * chk + 4u);
-                t[comp].tE1 = e.E1;
-                t[comp].tO1 = e.O1;
-                t[comp].tOm = e.Om;
-                t[comp].tEp = e.Ep;
-            }
-            const v2u yy = *reinterpret_cast<const v2u *>(lds.coef + row * ypitch + 8u * chk);
+        for (uint32_t row = wave; row < 8u; row += NT / 64u) {
+            const uint32_t oy = 8u * my + row;
+            if (oy >= g.out_h) continue;
             const size_t ro = (size_t)oy * pitch;
-            P::template row_pixels<true>(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
+            const uint8_t *pc[2] = {opaque_lds(ctile + row * cp + 4u * lane + 4u), opaque_lds(ctile + (8u + row) * cp + 4u * lane + 4u)};
+            const uint8_t *py = opaque_lds(lds.coef + row * ypitch + 8u * lane);
+#pragma unroll
+            for (uint32_t it = 0; it < 2u; it++) {
+                const uint32_t chk = lane + 64u * it, ox0 = 16u * x0m + 8u * chk;
+                if (chk >= nch || ox0 >= g.out_w) continue;
+                typename P::TPrime t[2];
+#pragma unroll
+                for (uint32_t comp = 0; comp < 2; comp++) {
+                    // tile column of plane column j0 - 4 (j0 = ox0 / 2): 4*chk + 4, as in the 4:2:0 kernels
+                    const typename P::ChromaEO e = P::load_eo(pc[comp] + 256u * it);
+                    t[comp].tE1 = e.E1;
+                    t[comp].tO1 = e.O1;
+                    t[comp].tOm = e.Om;
+                    t[comp].tEp = e.Ep;
+                }
+                const v2u yy = *reinterpret_cast<const v2u *>(py + 512u * it);
+                P::template row_pixels<true>(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
+            }
         }
     }
 };
