@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+"""bench.py — BASELINE.json's metric on BASELINE.json's configs.
 
   metric : megapixels/s decoded (batch, whole node); % of HBM roofline for the pixel kernels
-  N=1 workload (configs[1]): 1920x1080 baseline 4:2:0 YCbCr, batch of 256 images, 1 MI355X.
-  A "step" = one pass of the hot path (dequantize + IDCT + upsample + YCbCr->RGB) over the whole
-  batch, coefficients already resident in HBM, RGB left resident in HBM.
-  N>1: one process per GPU (torch.distributed / RCCL), the batch shards one-image-per-task with
-  NO data-path collective (weak scaling: 256 images per GPU); the final RCCL gather of the
-  pixels to rank 0 that north_star mentions runs after the timed region and is reported apart.
+  A "step" = one pass of the hot path (dequantize + IDCT + upsample + YCbCr->RGB) over the rank's whole shard,
+  coefficients already resident in HBM, RGB left resident in HBM.
+
+  N = 1 (configs[1]): 1920x1080 baseline 4:2:0 YCbCr, batch of 256 images, one launch group per step.
+  N > 1 (configs[2]): 3840x2160 baseline 4:2:0, 4096 images in total, sharded by image with
+          jpeg_decoder_amd.distributed.shard() (512 per GPU at N = 8; STRONG scaling: the total stays 4096), decoded
+          in sub-batches; `value` has no collective in it (there is no data-path collective), `value_with_gather`
+          is the same job with north_star's final RCCL gather of the pixels to rank 0 inside the timed region,
+          issued per sub-batch so that it overlaps the decode of the next one (peer -> root point-to-point
+          transfers, one xGMI link each, no ring).
+
+  Launch: `python bench.py --gpus N` spawns the N ranks itself (torch.distributed.run, 127.0.0.1) when it is not
+  already running under a launcher; under torchrun (RANK / WORLD_SIZE in the environment) it is one rank.  A
+  mismatch between --gpus and WORLD_SIZE, or fewer visible GPUs than N, is an error — never a silent 1-GPU run.
+  `--dry-run` walks the same launcher / sharding / gather / JSON code on CPU (gloo) without touching a GPU; it
+  is what the CPU tests use and measures nothing.
 
 Prints ONE JSON line on rank 0."""
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,35 +39,80 @@ import numpy as np
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 WORKLOADS = {
-    # name: (width, height, sampling, mode, colour transform, default batch)
+    # name: (width, height, sampling, mode, colour transform, default images per GPU at N = 1)
     "1080p-420": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "2160p-420": (3840, 2160, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 64),
     "1080p-444": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-422": (1920, 1080, [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
+    "1080p-440": (1920, 1080, [(1, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
     # 4:4:4 and grayscale images interleaved in one batch (two fused launch groups, path "mixed")
     "1080p-444+gray": (1920, 1080, None, "mixed", None, 512),
 }
+CONFIG3_WORKLOAD, CONFIG3_IMAGES_TOTAL = "2160p-420", 4096
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="1080p-420", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 500 at N = 1, 40 at N > 1)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default: 50 at N = 1, 5 at N > 1)")
+    ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS),
+                    help="default: 1080p-420 at N = 1 (configs[1]), 2160p-420 at N > 1 (configs[2])")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (weak scaling; default: the workload's at N = 1)")
+    ap.add_argument("--images-total", type=int, default=0,
+                    help="images in the whole job, sharded over the ranks (strong scaling; default at N > 1: 4096)")
+    ap.add_argument("--sub-batches", type=int, default=0, help="launch groups per step (default: 1 at N = 1, 8 at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
     ap.add_argument("--generic", action="store_true", help="force the two-kernel generic path")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-steps", type=int, default=3, help="timed steps of the decode + gather region (N > 1)")
+    ap.add_argument("--no-classes", action="store_true", help="skip the per-arithmetic-class timings (N = 1)")
+    ap.add_argument("--class-steps", type=int, default=60)
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo walk through launcher, sharding, gather and the JSON line")
     ap.add_argument("--settle", type=int, default=-1,
                     help="untimed launches BEFORE the warm-up steps that let the GPU leave its clock transient after an idle "
-                         "period (DESIGN.md §5: the first ~25 launches run up to 50 %% slower); default: enough to make "
-                         "settle + warm-up = 50 launches, i.e. none for the default warm-up; 0 switches it off")
-    return ap.parse_args()
+                         "period (DESIGN.md §5); default: enough to make settle + warm-up = 50 launches at N = 1")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(n, argv, port=None):
+    """The command `python bench.py --gpus n ...` re-executes itself as (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def launch_ranks(args, argv):
+    if not args.dry_run:
+        have = visible_gpus()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible — refusing to run a smaller job under that label")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(launcher_command(args.gpus, argv), env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------------
 def algorithmic_bytes_per_image(comps, out_bytes):
     """coefficient bytes in (int16) + pixel bytes out; q-tables ignored."""
     return sum(c.block_width * c.block_height * 64 * 2 for c in comps) + out_bytes
@@ -86,57 +143,122 @@ def effective_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(O, ocomps, qts, coefs, w, h, ct, target_seconds):
-    """Oracle ("port" of the reference's scalar path) on the CPUs the process may use, bounded sample."""
+    """Oracle ("port" of the reference's scalar path) on the CPUs the process may use, bounded sample.  The comparator is
+    built on this box with -O3 -march=native and every task in flight has its own coefficient buffers."""
     cores = effective_cpus()
+    flags = O.use_native_build()  # compiles oracle/liboracle_native.so here; falls back to the portable -O2 build
+    distinct = max(4 * cores, 16)
+    pool = [[np.array(c, copy=True) for c in coefs] for _ in range(distinct)]
     n0 = max(cores, 4)
     t0 = time.perf_counter()
-    O.batch_pixels(ocomps, qts, [coefs] * n0, w, h, ct.upper(), cores, keep_outputs=False)
+    O.batch_pixels(ocomps, qts, [pool[i % distinct] for i in range(n0)], w, h, ct.upper(), cores, keep_outputs=False)
     dt = time.perf_counter() - t0
     n = int(max(n0, min(65536, n0 * target_seconds / max(dt, 1e-3))))
     n = (n // cores) * cores or cores
     t0 = time.perf_counter()
-    O.batch_pixels(ocomps, qts, [coefs] * n, w, h, ct.upper(), cores, keep_outputs=False)
+    O.batch_pixels(ocomps, qts, [pool[i % distinct] for i in range(n)], w, h, ct.upper(), cores, keep_outputs=False)
     dt = time.perf_counter() - t0
     return {"value": round(n * w * h / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-            "sample": f"{n} images {w}x{h} of the same workload, pixel pipeline only (coefficients -> pixels), "
-                      f"{cores} threads one image per task, {dt:.1f} s"}
+            "sample": f"{n} images {w}x{h} of the same workload ({distinct} distinct coefficient sets, none shared by tasks in flight), "
+                      f"pixel pipeline only (coefficients -> pixels), {cores} threads one image per task, {dt:.1f} s; "
+                      f"gcc {flags}; {cpu_model()}; the crate's own x86 build would add SSSE3 IDCT / colour kernels (not bit-compatible with its scalar path)"}
 
 
 def measured_traffic(workload, path):
-    """HBM bytes per decode from the committed rocprofv3 PMC passes (profiles/round1/pmc_traffic.json,
+    """HBM bytes per decode from the committed rocprofv3 PMC passes (profiles/roundN/pmc_traffic.json,
     FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc runs); None if not measured."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")))
-        e = t.get(f"{workload}:{path}")
-        return e["hbm_bytes_per_decode"] if e else None
-    except (OSError, ValueError, KeyError):
-        return None
+    for rnd in ("round2", "round1"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
+            e = t.get(f"{workload}:{path}")
+            if e:
+                return e["hbm_bytes_per_decode"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
-def main():
-    args = parse_args()
-    import torch
+class Shard:
+    """One rank's images as `n_sub` launch groups (jpgpu batches) over one pair of device arenas."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(args.gpus, 1) and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    import jpeg_decoder_amd as J
-    import jpeg_decoder_amd.distributed as D
-    import synth
+    def __init__(self, J, torch, variants, n_img, n_sub, device_index, generic=False):
+        self.J, self.torch, self.variants, self.n_img = J, torch, variants, n_img
+        nv = len(variants)
+        n_sub = max(1, min(n_sub, n_img))
+        self.bounds = [(n_img * s // n_sub, n_img * (s + 1) // n_sub) for s in range(n_sub)]
+        flags = J._native.BATCH_EXTERNAL_BUFFERS | (J._native.BATCH_FORCE_GENERIC if generic else 0)
+        self.batches = [J.Batch([variants[i % nv]["desc"] for i in range(a, b)], device=device_index, flags=flags) for a, b in self.bounds]
+        self.coef_base, self.out_base = [], []
+        co = oo = 0
+        for b in self.batches:
+            self.coef_base.append(co)
+            self.out_base.append(oo)
+            co += -(-b.coef_arena_bytes() // 256) * 256
+            oo += -(-b.out_arena_bytes() // 256) * 256
+        self.dev = torch.device("cuda", device_index)
+        self.coef_arena = torch.zeros(co, dtype=torch.uint8, device=self.dev)
+        self.out_arena = torch.zeros(oo, dtype=torch.uint8, device=self.dev)
+        # N distinct coefficient buffers in HBM (no aliasing): upload each variant once, replicate on the device
+        for k, v in enumerate(variants):
+            srcs = [torch.from_numpy(c.view(np.uint8)).to(self.dev) for c in v["coefs"]]
+            for s, (a, b) in enumerate(self.bounds):
+                for i in range(a, b):
+                    if i % nv != k:
+                        continue
+                    for c, src in enumerate(srcs):
+                        off = self.coef_base[s] + self.batches[s].coef_offset(i - a, c)
+                        self.coef_arena[off: off + src.numel()] = src
+        for s, b in enumerate(self.batches):
+            b.bind(self.coef_arena.data_ptr() + self.coef_base[s], self.out_arena.data_ptr() + self.out_base[s])
+        self.set_classes(None)
 
-    dist = D.init(backend="nccl") if world > 1 else None
+    def set_classes(self, cap):
+        """Hand the host-side classification of the coefficients to the batches (what jpgpu_batch_upload computes
+        when it stages the data itself); `cap` limits the class (A/B of the arithmetic variants)."""
+        nv = len(self.variants)
+        for (a, b), batch in zip(self.bounds, self.batches):
+            for i in range(a, b):
+                cls = self.variants[i % nv]["sane"]
+                batch.set_range_hint(i - a, cls if cap is None else min(cls, cap))
 
-    w, h, sampling, mode, ct, default_batch = WORKLOADS[args.workload]
-    n_img = args.batch or default_batch
+    def pixel_slice(self, s):
+        b = self.batches[s]
+        n = b.n_images
+        return self.out_arena[self.out_base[s]: self.out_base[s] + b.out_offset(n - 1) + b.out_bytes(n - 1)]
+
+    def image_pixels(self, i):
+        s = next(k for k, (a, b) in enumerate(self.bounds) if a <= i < b)
+        b = self.batches[s]
+        off = self.out_base[s] + b.out_offset(i - self.bounds[s][0])
+        return self.out_arena[off: off + b.out_bytes(i - self.bounds[s][0])]
+
+    def decode(self, stream):
+        for b in self.batches:
+            b.decode(stream)
+
+    @property
+    def path(self):
+        return self.batches[0].path
+
+    def close(self):
+        for b in self.batches:
+            b.close()
+
+
+def build_variants(J, synth, w, h, sampling, mode, ct):
     lum, chr_ = synth.quality_tables(85)
     rgb = synth.synthetic_rgb(w, h)
-    # image i of the batch is variant i % len(variants); one variant except for the interleaved workload
     specs = [([(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr"), ([(1, 1)], "gray", "Grayscale")] if mode == "mixed" else [(sampling, mode, ct)]
     variants = []
     for v_sampling, v_mode, v_ct in specs:
@@ -150,30 +272,95 @@ def main():
             sane = 3 if all((p.sum(axis=1) <= 5900).all() for p in prod) else 1
         variants.append({"sampling": v_sampling, "ct": v_ct, "comps": comps, "qts": qts, "coefs": coefs, "sane": sane,
                          "desc": J.image_desc(list(comps), qts, w, h, v_ct)})
-    sampling, ct = variants[0]["sampling"], variants[0]["ct"]
-    comps, qts, coefs, sane = (variants[0][k] for k in ("comps", "qts", "coefs", "sane"))
-    nv = len(variants)
+    return variants
 
-    flags = J._native.BATCH_EXTERNAL_BUFFERS | (J._native.BATCH_FORCE_GENERIC if args.generic else 0)
-    batch = J.Batch([variants[i % nv]["desc"] for i in range(n_img)], device=local_rank, flags=flags)
-    dev = torch.device("cuda", local_rank)
-    coef_arena = torch.zeros(batch.coef_arena_bytes(), dtype=torch.uint8, device=dev)
-    out_arena = torch.zeros(batch.out_arena_bytes(), dtype=torch.uint8, device=dev)
-    # N distinct coefficient buffers in HBM (no aliasing): upload each variant once, replicate on device
-    for k, v in enumerate(variants):
-        for c in range(len(v["comps"])):
-            src = torch.from_numpy(v["coefs"][c].view(np.uint8)).to(dev)
-            for i in range(k, n_img, nv):
-                off = batch.coef_offset(i, c)
-                coef_arena[off: off + src.numel()] = src
-    batch.bind(coef_arena.data_ptr(), out_arena.data_ptr())
-    for i in range(n_img):
-        batch.set_range_hint(i, variants[i % nv]["sane"])
-    stream = torch.cuda.current_stream(dev).cuda_stream
 
-    settle = max(0, 50 - max(args.warmup, 0)) if args.settle < 0 else args.settle
-    for _ in range(settle + max(args.warmup, 0)):
-        batch.decode(stream)
+class PixelGather:
+    """north_star's only collective: the pixels of every rank end on rank 0.  Point-to-point form: each
+    peer sends its sub-batch to the root over its own xGMI link while it decodes the next one; nothing to reduce, no ring."""
+
+    def __init__(self, dist, torch, rank, world, slices, device):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.slices = slices
+        # shards may differ by one image: every rank tells the others how many bytes its sub-batches hold
+        mine = torch.tensor([sl.numel() for sl in slices], dtype=torch.int64, device=device)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        self.sizes = [[int(x) for x in t.cpu()] for t in every]
+        if any(len(t) != len(slices) for t in self.sizes):
+            raise SystemExit("bench.py: ranks disagree on the number of sub-batches")
+        self.recv = None
+        if rank == 0:
+            self.recv = [[torch.empty(n, dtype=torch.uint8, device=device) for n in self.sizes[r]] for r in range(1, world)]
+        self.pending = []
+
+    def post(self, s):
+        """Enqueue the transfers of sub-batch `s` behind what the current stream has been given so far."""
+        P = self.dist.P2POp
+        if self.rank == 0:
+            ops = [P(self.dist.irecv, self.recv[r - 1][s], r) for r in range(1, self.world)]
+        else:
+            ops = [P(self.dist.isend, self.slices[s], 0)]
+        if ops:
+            self.pending += self.dist.batch_isend_irecv(ops)
+
+    def wait(self):
+        for wk in self.pending:
+            wk.wait()
+        self.pending = []
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def dry_run(args, rank, world, workload, images_total, n_img, n_sub):
+    """No GPU: the N>1 bookkeeping on CPU tensors over gloo — shard sizes, per-sub-batch gather to rank 0, max over
+    ranks, and the JSON contract.  Measures nothing (value is null)."""
+    import torch
+    import jpeg_decoder_amd.distributed as D
+
+    dist = D.init(backend="gloo") if world > 1 else None
+    mine = D.shard(images_total, rank, world) if images_total else range(rank * n_img, (rank + 1) * n_img)
+    n_sub = max(1, min(n_sub, len(mine)))
+    bounds = [(len(mine) * s // n_sub, len(mine) * (s + 1) // n_sub) for s in range(n_sub)]
+    tag = 5  # bytes standing in for one image's pixels: the image's global index
+    slices = []
+    for a, b in bounds:
+        t = torch.zeros((b - a) * tag, dtype=torch.uint8)
+        for k in range(a, b):
+            t[(k - a) * tag:(k - a + 1) * tag] = mine[k] % 251
+        slices.append(t)
+    ok = True
+    if dist:
+        g = PixelGather(dist, torch, rank, world, slices, "cpu")
+        for s in range(n_sub):
+            g.post(s)
+        g.wait()
+        dist.barrier()
+        if rank == 0:
+            for r in range(1, world):
+                theirs = D.shard(images_total, r, world) if images_total else range(r * n_img, (r + 1) * n_img)
+                tb = [(len(theirs) * s // n_sub, len(theirs) * (s + 1) // n_sub) for s in range(n_sub)]
+                for s, (a, b) in enumerate(tb):
+                    ok = ok and g.recv[r - 1][s].numel() == (b - a) * tag
+                    for k in range(a, b):
+                        ok = ok and bool((g.recv[r - 1][s][(k - a) * tag:(k - a + 1) * tag] == theirs[k] % 251).all())
+        t = D.max_over_ranks([float(rank)])
+        ok = ok and t == [float(world - 1)]
+    if rank == 0:
+        w, h = WORKLOADS[workload][0], WORKLOADS[workload][1]
+        print(json.dumps({"metric": "megapixels/s decoded (batch, whole node)", "value": None, "unit": "MP/s", "n_gpus": world,
+                          "dry_run": True, "scaling": "strong" if images_total else "weak",
+                          "config": {"workload": f"{w}x{h}", "name": workload, "images_total": images_total or world * n_img,
+                                     "images_per_gpu": len(mine), "sub_batches": n_sub},
+                          "gather_checked": ok, "value_with_gather": None, "gather_ms": None}), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def time_steps(torch, dev, dist, stream, steps, body):
+    """`steps` calls of body() between barrier + synchronize on both sides; (wall seconds, GPU ms per step from events
+    on the stream the kernels are launched on)."""
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -181,22 +368,67 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream the kernels are launched on
-    for _ in range(args.steps):
-        batch.decode(stream)
+    for _ in range(steps):
+        body()
     ev1.record()
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+
+    workload = args.workload or ("1080p-420" if world == 1 else CONFIG3_WORKLOAD)
+    w, h, sampling, mode, ct, default_batch = WORKLOADS[workload]
+    images_total = args.images_total or (CONFIG3_IMAGES_TOTAL if world > 1 and not args.batch else 0)
+    import jpeg_decoder_amd.distributed as D
+    n_img = len(D.shard(images_total, rank, world)) if images_total else (args.batch or default_batch)
+    n_sub = args.sub_batches or (1 if world == 1 else 8)
+    steps = args.steps or (500 if world == 1 else 40)
+    warmup = args.warmup if args.warmup >= 0 else (50 if world == 1 else 5)
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world, workload, images_total, n_img, n_sub))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible")
+    torch.cuda.set_device(local_rank)
+    import jpeg_decoder_amd as J
+    import synth
+
+    dist = D.init(backend="nccl") if world > 1 else None
+    variants = build_variants(J, synth, w, h, sampling, mode, ct)
+    sampling, ct = variants[0]["sampling"], variants[0]["ct"]
+    comps, qts, coefs = (variants[0][k] for k in ("comps", "qts", "coefs"))
+    nv = len(variants)
+    dev = torch.device("cuda", local_rank)
+    shard = Shard(J, torch, variants, n_img, n_sub, local_rank, generic=args.generic)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    settle = (max(0, 50 - warmup) if world == 1 else 0) if args.settle < 0 else args.settle
+    for _ in range(settle + warmup):
+        shard.decode(stream)
+    elapsed, gpu_ms_per_step = time_steps(torch, dev, dist, stream, steps, lambda: shard.decode(stream))
     if dist:
         elapsed, gpu_ms_per_step = D.max_over_ranks([elapsed, gpu_ms_per_step], device=dev)
 
     # parity spot check inside the bench (oracle = checker only, never the thing measured)
     verified = None
-    gather_ms = None
-    out_bytes = batch.out_bytes(0)
     if rank == 0:
         import oracle as O
         verified = True
@@ -208,54 +440,104 @@ def main():
             for i in sorted({k, ((n_img // 2) // nv) * nv + k, last}):
                 if i >= n_img:
                     continue
-                off = batch.out_offset(i)
-                got = out_arena[off: off + batch.out_bytes(i)].cpu().numpy()
+                got = shard.image_pixels(i).cpu().numpy()
                 verified = verified and hashlib.sha256(got.tobytes()).hexdigest() == digest
         ocomps, _ = O.make_components(w, h, sampling)
-    if dist and not args.no_gather:
-        try:  # north_star's "RCCL over xGMI only for the final gather", outside the timed region
-            pix = out_arena[: batch.out_offset(n_img - 1) + batch.out_bytes(n_img - 1)]
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            g0 = time.perf_counter()
-            gl = D.gather_pixels(pix, dst=0)
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            del gl
-        except Exception as e:  # the gather is informational; never lose the bench line to it
-            gather_ms = None
-            if rank == 0:
-                print(f"# gather skipped: {e}", file=sys.stderr)
 
+    total_images = images_total or world * n_img
+    mp_per_step = total_images * w * h / 1e6
+    line = None
     if rank == 0:
-        mp_per_step = world * n_img * w * h / 1e6
-        value = mp_per_step * args.steps / elapsed
-        alg_bytes = sum(algorithmic_bytes_per_image(variants[i % nv]["comps"], batch.out_bytes(i)) for i in range(n_img))  # per launch (one GPU's batch)
+        value = mp_per_step * steps / elapsed
+        alg_bytes = sum(algorithmic_bytes_per_image(v["comps"], shard.image_pixels(k).numel()) * len(range(k, n_img, nv))
+                        for k, v in enumerate(variants) if k < n_img)  # per step of this rank's shard
         achieved = alg_bytes / (gpu_ms_per_step * 1e-3) / 1e9
         line = {
             "metric": "megapixels/s decoded (batch, whole node)", "value": round(value, 1), "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_launches_before_warmup": settle,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "settle_launches_before_warmup": settle,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if images_total else "weak",
             "vs_baseline": None, "dtype": "i32 fixed-point (i16 coefficients -> u8 pixels)", "data": "synthetic",
             "config": {"workload": f"{w}x{h} baseline " + " + ".join('x'.join(str(hh) + str(vv) for hh, vv in v["sampling"]) + " " + v["ct"]
                                                                      for v in variants) +
                                    (" interleaved" if nv > 1 else "") +
-                                   f", batch of {n_img} images per GPU (coefficients resident in HBM -> RGB in HBM)",
-                       "name": args.workload, "images_per_gpu": n_img, "kernel_path": batch.path, "range_class": min(v["sane"] for v in variants),
+                                   (f", {total_images} images in the job, {n_img} per GPU" if images_total else f", batch of {n_img} images per GPU") +
+                                   " (coefficients resident in HBM -> RGB in HBM)",
+                       "name": workload, "images_total": total_images, "images_per_gpu": n_img, "sub_batches": len(shard.batches),
+                       "kernel_path": shard.path, "range_class": min(v["sane"] for v in variants),
+                       "range_class_source": "host scan at staging time, outside the timed region (see roofline_by_class.with_device_range_scan)",
                        "parallelism": f"images sharded {n_img}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic(args.workload, batch.path) if n_img == default_batch else None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": round(gpu_ms_per_step, 4)},
+                         "traffic": measured_traffic(workload, shard.path) if (n_img == default_batch and world == 1) else None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": round(gpu_ms_per_step, 4),
+                         "launch": "one step of this rank's shard" + (f" = {len(shard.batches)} launch groups" if len(shard.batches) > 1 else "")},
             "verified_vs_oracle": verified,
         }
-        if gather_ms is not None:
-            line["gather_ms_after_timed_region"] = round(gather_ms, 2)
+
+    # ---- N > 1: the same job with the final gather inside the timed region, overlapped per sub-batch ----
+    if dist and not args.no_gather:
+        gather = PixelGather(dist, torch, rank, world, [shard.pixel_slice(s) for s in range(len(shard.batches))], dev)
+
+        def step_with_gather():
+            for s, b in enumerate(shard.batches):
+                b.decode(stream)
+                gather.post(s)  # behind sub-batch s on the stream; sub-batch s + 1 decodes while it moves
+            gather.wait()
+
+        def gather_only():
+            for s in range(len(shard.batches)):
+                gather.post(s)
+            gather.wait()
+
+        step_with_gather()  # warm-up (communicator set-up)
+        g_elapsed, _ = time_steps(torch, dev, dist, stream, args.gather_steps, step_with_gather)
+        o_elapsed, _ = time_steps(torch, dev, dist, stream, 1, gather_only)
+        g_elapsed, o_elapsed = D.max_over_ranks([g_elapsed, o_elapsed], device=dev)
+        if rank == 0:
+            # the root holds every peer's pixels now: spot-check one image of the last rank
+            chk = gather.recv[world - 2][0][: shard.image_pixels(0).numel()].cpu().numpy()
+            line["gather_verified"] = bool(hashlib.sha256(chk.tobytes()).hexdigest() == hashlib.sha256(shard.image_pixels(0).cpu().numpy().tobytes()).hexdigest()) if nv == 1 else None
+            line["value_with_gather"] = round(mp_per_step * args.gather_steps / g_elapsed, 1)
+            line["ms_per_step_with_gather"] = round(g_elapsed / args.gather_steps * 1e3, 3)
+            line["gather_ms"] = round(o_elapsed * 1e3, 3)
+            line["gather"] = {"bytes_into_root": int(sum(sum(t) for t in gather.sizes[1:])),
+                              "form": "per sub-batch isend/irecv peer -> rank 0 (RCCL), overlapped with the next sub-batch's decode",
+                              "steps": args.gather_steps}
+        del gather
+
+    # ---- N = 1: what the arithmetic class is worth, and what finding it out on the device costs ----
+    if rank == 0 and world == 1 and not args.no_classes and not args.generic:
+        by_class = {}
+        top = min(v["sane"] for v in variants)
+        for cap in (0, 1, 3):
+            if cap > top:
+                continue
+            shard.set_classes(cap)
+            for _ in range(10):
+                shard.decode(stream)
+            _, ms = time_steps(torch, dev, None, stream, args.class_steps, lambda: shard.decode(stream))
+            by_class[f"class{cap}"] = {"kernel_ms_per_launch": round(ms, 4), "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        shard.set_classes(None)
+        if hasattr(shard.batches[0], "classify_on_device"):
+            for b in shard.batches:
+                b.classify_on_device(True)
+            for _ in range(10):
+                shard.decode(stream)
+            _, ms = time_steps(torch, dev, None, stream, args.class_steps, lambda: shard.decode(stream))
+            by_class["with_device_range_scan"] = {"kernel_ms_per_launch": round(ms, 4), "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                  "note": "range_scan_kernel inside every step; the pixel kernels take each image's class from its result on the device"}
+            for b in shard.batches:
+                b.classify_on_device(False)
+        by_class["note"] = ("class 3 = every |c*q| < 2^15 and every block column sum <= 5900 (legal 8-bit JPEG data), class 1 = the first only, "
+                            "class 0 = arbitrary i16 coefficients (wrap-exact kernels)")
+        line["roofline_by_class"] = by_class
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1 and nv == 1:
             line["cpu_baseline"] = cpu_baseline(O, ocomps, qts, coefs, w, h, ct, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    batch.close()
+    shard.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

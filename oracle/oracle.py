@@ -69,10 +69,30 @@ def build(force=False):
     return so
 
 
-def lib():
+NATIVE_CFLAGS = "-O3 -march=native -fPIC -std=c11 -fwrapv -fno-strict-aliasing"
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg only: rebuild the comparator ON THIS BOX with -O3 -march=native as
+    oracle/liboracle_native.so and bind it in place of the portable -O2 library the tests use.  Returns the flags in
+    effect (the portable ones if the native build is not possible here)."""
+    global _LIB
+    so = os.path.join(_HERE, "liboracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _LIB = None
+        lib(so)
+        return NATIVE_CFLAGS
+    except (subprocess.CalledProcessError, OSError):
+        _LIB = None
+        lib()
+        return "-O2 (portable build; native rebuild failed)"
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(path or build())
         L.orc_dequantize_and_idct_block.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_dequantize_and_idct_block.restype = None
         L.orc_choose_idct_size.argtypes = [C.c_uint16] * 4

@@ -1,0 +1,76 @@
+"""bench.py's multi-GPU entry point, exercised without a GPU: `python bench.py --gpus N` must either run N ranks or
+fail loudly — never report a 1-GPU run under an N-GPU label.  `--dry-run` walks the launcher, the
+sharding of BASELINE configs[2] (4096 images of 3840x2160), the per-sub-batch gather to rank 0 (gloo here, RCCL on
+the GPUs) and the JSON contract on CPU tensors."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_n_without_n_gpus_is_an_error():
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    r = _run(["--gpus", "8"])
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and "--gpus 8" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # and no bench line under a false label
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--dry-run"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_launcher_command_is_one_rank_per_gpu_on_loopback():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "3"], port=12345)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert cmd[-5:] == [BENCH, "--gpus", "4", "--steps", "3"]
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_dry_run_shards_config3_and_gathers():
+    r = _run(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["scaling"] == "strong"
+    assert line["config"]["name"] == "2160p-420" and line["config"]["images_total"] == 4096
+    assert line["config"]["images_per_gpu"] == 2048 and line["config"]["sub_batches"] == 8
+    assert line["gather_checked"] is True
+    for key in ("value", "value_with_gather", "gather_ms"):
+        assert key in line
+
+
+@pytest.mark.timeout(300)
+def test_three_ranks_dry_run_uneven_total_and_weak_mode():
+    r = _run(["--gpus", "3", "--dry-run", "--images-total", "100", "--sub-batches", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 3 and line["config"]["images_total"] == 100 and line["config"]["images_per_gpu"] == 34
+    assert line["gather_checked"] is True
+    r = _run(["--gpus", "2", "--dry-run", "--batch", "16", "--workload", "1080p-420"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["scaling"] == "weak" and line["config"]["images_per_gpu"] == 16 and line["config"]["images_total"] == 32

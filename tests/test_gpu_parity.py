@@ -338,6 +338,34 @@ def test_batch_1080p_420_full_size_properties():
     assert err.mean() < 6.0
 
 
+def test_batch_2160p_420_full_size_properties():
+    """BASELINE configs[2] geometry (3840x2160 4:2:0, the per-GPU shard of the 4096-image job) at full size: the
+    oracle on two distinct images, then identical inputs -> identical outputs over the rest of the batch."""
+    rng = np.random.default_rng(2160)
+    w_, h_ = 3840, 2160
+    ocomps, _ = O.make_components(w_, h_, [(2, 2), (1, 1), (1, 1)])
+    jc = to_j(ocomps)
+    lum, chr_ = synth.quality_tables(85)
+    qts = [lum, chr_, chr_]
+    rgb = synth.synthetic_rgb(w_, h_)
+    base = synth.coefficients_from_rgb(rgb, jc, "ycbcr", qts)
+    other = [synth.sparse_coefficients(rng, c.block_w * c.block_h) for c in ocomps]
+    n = 6
+    cases = [(ocomps, qts, other if i == 3 else base, "YCbCr", w_, h_) for i in range(n)]
+    outs, path = _run_batch(cases)
+    assert path.startswith("fused420"), path
+    want_base = O.pixels_from_coefficients(ocomps, qts, base, w_, h_, "YCBCR")
+    want_other = O.pixels_from_coefficients(ocomps, qts, other, w_, h_, "YCBCR")
+    digest = hashlib.sha256(want_base.tobytes()).hexdigest()
+    for i, got in enumerate(outs):
+        if i == 3:
+            assert np.array_equal(got, want_other)
+        else:
+            assert hashlib.sha256(got.tobytes()).hexdigest() == digest, (i, path)
+    err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
+    assert err.mean() < 6.0
+
+
 STRIP_GEOMETRY = [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (673, 79), (1920, 64), (30, 160)]
 
 
