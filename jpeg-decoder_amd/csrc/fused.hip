@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const 
     K::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
 
-// 4:2:0 in one launch (opt-in): a = strip, b = row segment; see S420 in fused_core.hpp
+// 4:2:0 in one launch: a = strip, b = row segment; see S420 in fused_core.hpp
 template <int ARITH, uint32_t NT>
 __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                      const FusedWork *__restrict__ work) {
@@ -90,30 +90,44 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict
     const uint32_t k0 = w.b * g.seg_rows, k1 = min(k0 + g.seg_rows, g.mcu_h);
     S420Regs r;
     K::init(img, tid, lds);
-    if (k0 > 0) {  // carry rows of the MCU row above this segment
-        K::stage(g, img, strip, k0 - 1, tid, lds);
+    if (k0 > 0 || k1 < g.mcu_h) {  // seam rows of the segments above / below
+        K::seam_stage(g, img, strip, k0, k1, tid, lds);
         __syncthreads();
-        K::read_block(g, strip, tid, lds, r);
-        K::transform(g, strip, k0 - 1, tid, lds, r, true);
+        K::seam_transform(g, strip, k0, k1, tid, lds);
         __syncthreads();
     }
+    {
+        typename K::Pre pre;
+        K::stage_load(g, img, strip, k0, tid, pre);
+        K::stage_store(g, strip, tid, lds, pre);
+    }
+    __syncthreads();
     for (uint32_t k = k0; k < k1; k++) {
+        typename K::Pre pre;  // (declared per iteration: not live around the loop)
         // A fresh, opaque copy of the lane id per phase: otherwise every per-lane address of every phase is hoisted
         // out of the loop and kept live across it (~100 VGPRs), which spills the coefficient block at 4 waves/SIMD.
         uint32_t t0 = tid, t1 = tid, t2 = tid;
-        asm volatile("" : "+v"(t0));
-        K::stage(g, img, strip, k, t0, lds);
-        __syncthreads();
         asm volatile("" : "+v"(t1));
         K::read_block(g, strip, t1, lds, r);
         __syncthreads();  // the tiles alias the staging area
-        K::transform(g, strip, k, t1, lds, r, false);
+        K::transform(g, strip, t1, lds, r);
         __syncthreads();
+        const bool more = k + 1u < k1;
         asm volatile("" : "+v"(t2));
-        K::colour(g, img, strip, k, t2, lds);
+        K::colour(g, img, strip, k, 16u * k0, false, t2, lds);
         __syncthreads();
+        if (more) {
+            asm volatile("" : "+v"(t0));
+            K::stage_load(g, img, strip, k + 1u, t0, pre);
+            K::stage_store(g, strip, t0, lds, pre);
+            __syncthreads();
+        }
     }
-    if (k1 == g.mcu_h) K::colour(g, img, strip, g.mcu_h, tid, lds);  // the image's last row (far chroma row clamped onto the near one)
+    if (16u * k1 - 1u < g.out_h) {  // the segment's last output row: its far chroma row is the seam row below (or itself at the image's end)
+        K::closing_tiles(tid, lds);
+        __syncthreads();
+        K::colour(g, img, strip, k1, 16u * k0, true, tid, lds);
+    }
 }
 
 template <int ARITH>
@@ -177,14 +191,14 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     plan.uniform = false;
     if (descs.empty() || descs.size() > 65535u || ids.size() != descs.size()) return false;
     plan.ids = ids;
-    // Tuning knobs (A/B experiments, profiles/round1/04_strip_walk_experiments.md):
-    //   JPGPU_F420_TX    MCUs per tile of the 4:2:0 main pass (<= 32 selects 128-thread workgroups)
-    //   JPGPU_420_STRIP  1 = the single-launch strip walk (S420) for 4:2:0 — uniform batches only; off by default: on
-    //                    MI355X it moves 15 % fewer bytes but runs 10 % slower (0.79 vs 0.72 ms per 256 x 1080p)
-    //   JPGPU_S420_TX / JPGPU_S420_SEG  its strip width and MCU rows per workgroup
+    // Knobs (A/B experiments, profiles/round2/02_single_launch_420.md):
+    //   JPGPU_420_STRIP  0 = 4:2:0 as chroma pass + main pass (F420, round 1's default); default 1 = the single-launch
+    //                    strip walk (S420): chroma never goes through HBM (3.3 instead of 4.1 GB per 256 x 1080p)
+    //   JPGPU_F420_TX    MCUs per tile of the two-pass main kernel (<= 32 selects 128-thread workgroups)
+    //   JPGPU_S420_TX / JPGPU_S420_SEG  strip width and MCU rows per workgroup of the strip walk
     const char *txenv = getenv("JPGPU_F420_TX"), *tp = getenv("JPGPU_420_STRIP"), *stx = getenv("JPGPU_S420_TX");
     const uint32_t f420_tx = txenv ? (uint32_t)atoi(txenv) : 64u;
-    bool strip420 = tp && atoi(tp) != 0;
+    const bool strip420 = !(tp && atoi(tp) == 0);
     const uint32_t n = (uint32_t)descs.size();
     bool uniform = true;
     for (uint32_t i = 1; i < n && uniform; i++) {
@@ -192,7 +206,6 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
         uniform = d.ncomp == d0.ncomp && d.out_w == d0.out_w && d.out_h == d0.out_h && d.color_transform == d0.color_transform;
         for (uint32_t c = 0; uniform && c < d.ncomp; c++) uniform = fused_same_component(d.components[c], d0.components[c]);
     }
-    if (!uniform) strip420 = false;
     plan.uniform = uniform;
     plan.geoms.resize(n);
     const char *name = "";
@@ -224,8 +237,9 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     uint32_t tx_max = 0;
     for (const auto &g : plan.geoms) tx_max = std::max(tx_max, g.tx);
     plan.nt = 256;
-    if (plan.kind == FUSED_420) plan.nt = plan.strip ? (tx_max <= 20u ? 128u : 256u) : (tx_max <= 32u ? 128u : 256u);
+    if (plan.kind == FUSED_420) plan.nt = plan.strip ? 256u : (tx_max <= 32u ? 128u : 256u);
     plan.lds_bytes = plan.kind != FUSED_420 ? 0 : (plan.strip ? S420Lds::total_bytes(tx_max) : F420Lds::total_bytes(tx_max));
+    if (const char *pad = getenv("JPGPU_LDS_PAD")) plan.lds_bytes += (size_t)atoi(pad);  // occupancy experiments: claim more LDS than needed
     plan.scratch_off.assign(n, 0);
     size_t so = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -319,8 +333,7 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
     switch (plan.kind) {
     case FUSED_420:
         if (plan.strip) {
-            if (plan.nt == 128) ARITH_SWITCH(s420_kernel, 128);
-            else ARITH_SWITCH(s420_kernel, 256);
+            ARITH_SWITCH(s420_kernel, 256);
             break;
         }
         if (plan.uniform)  // (component, 256-block group, image)

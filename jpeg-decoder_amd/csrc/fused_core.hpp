@@ -285,14 +285,20 @@ struct F420 {
     // One output row of one 8-pixel chunk (src/upsampler.rs:191-228 + src/decoder.rs:1406-1437).
     //   pixel k: main sample s_(k>>1), other tap s_(k>>1)+-1:  c = (3*t'main + t'other) >> 4
     //   first / last column of the image: c = t'main >> 2
-    // `rowp` = first byte of the output scanline (wave-uniform -> scalar address math), `row_al4` =
-    // that scanline starts 4-byte aligned (then every 8-pixel chunk does: 24*chk is a multiple of 4)
+    // `o` = address of the chunk's first output byte (scanline start + 3*ox0; callers keep the scanline start wave-uniform
+    // where they can -> scalar address math), `row_al4` = it is 4-byte aligned
     // H2V1 = true: `t` holds raw samples and only the horizontal step of UpsamplerH2V1 is applied
     // (src/upsampler.rs:134-163): c = (3*s_main + s_other + 2) >> 2, first / last column c = s_main.
     // Either way a 16-bit lane of pk[][] ends up holding (c - 128) << SH (plus fraction bits below SH): the two values of
     // a dword are taken apart, shifted and sign-extended by one v_bfe_i32 / v_ashrrev_i32 each.
-    template <bool H2V1 = false>
-    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *rowp, bool row_al4,
+    // EDGES = false: the caller's chroma tile already holds the first / last sample of a row once more in the column
+    // outside the image; then the general formula IS the edge formula — (3*t + t) >> 4 == t >> 2, (3*s + s + 2) >> 2 == s —
+    // and no lane needs the fix-up below.
+    // FULL = true: the caller knows the chunk has all 8 pixels and a 4-byte aligned address (no byte-wise store path).
+    // NTS: non-temporal stores — they pay in the two-pass kernels, whose chroma planes want the L2 for themselves, and cost
+    // in the single-launch one (partial lines: pixel_math.hpp stream_store).
+    template <bool H2V1 = false, bool EDGES = true, bool FULL = false, bool NTS = true>
+    static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *o, bool row_al4,
                                                       const TPrime (&t)[2], v2u yy, uint32_t ox0) {
         // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
         constexpr uint32_t SH = H2V1 ? 2u : 4u;
@@ -305,7 +311,7 @@ struct F420 {
             for (uint32_t i = 0; i < 4; i++) pk[comp][i] = H2V1 ? pk_add(m[i], 0xfe02fe02u) : m[i];
         }
         const uint32_t last_x = 2u * g.cw - 1u;
-        if (ox0 == 0u || last_x - ox0 < 8u) {  // rare: first / last image column
+        if (EDGES && (ox0 == 0u || last_x - ox0 < 8u)) {  // rare: first / last image column
             // the lane of c = t'main >> 2 (tm = t''main as 16 bits), of c = s_main (tm = the sample) with H2V1
             auto edge_lane = [](uint32_t tm) -> uint32_t { return H2V1 ? ((tm << 2) - 512u) & 0xffffu : (tm << 2) & 0xfff0u; };
 #pragma unroll
@@ -333,14 +339,20 @@ struct F420 {
             const int32_t cr = (k < 4) ? ((int32_t)(pk[1][k & 3u] << 16) >> (16u + SH)) : ((int32_t)pk[1][k & 3u] >> (16u + SH));
             p[k] = ycbcr_raw_centred(yb[k], cb, cr);
         }
-        JP_GLOBAL uint8_t *o = rowp + ox0 * 3u;
-        const uint32_t n = min(8u, g.out_w - ox0);
-        if (n == 8u && row_al4) {
+        const uint32_t n = FULL ? 8u : min(8u, g.out_w - ox0);
+        if (FULL || (n == 8u && row_al4)) {
             uint32_t d0, d1, d2, d3, d4, d5;
             rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
             rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
-            stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o), v3u{d0, d1, d2});
-            stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12), v3u{d3, d4, d5});
+            {
+                if constexpr (NTS) {
+                    stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o), v3u{d0, d1, d2});
+                    stream_store(reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12), v3u{d3, d4, d5});
+                } else {
+                    *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{d0, d1, d2};
+                    *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{d3, d4, d5};
+                }
+            }
         } else {
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++)  // unrolled + predicated: a runtime-indexed p[] would live in scratch
@@ -406,12 +418,12 @@ struct F420 {
                 if (va) {
                     const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};
                     const v2u yy = *reinterpret_cast<const v2u *>(pya + 512u * it);
-                    row_pixels(g, rowa, al4a, t, yy, ox0);
+                    row_pixels(g, rowa + ox0 * 3u, al4a, t, yy, ox0);
                 }
                 if (vb) {
                     const TPrime t[2] = {tprime(el[0], eu[0]), tprime(el[1], eu[1])};
                     const v2u yy = *reinterpret_cast<const v2u *>(pyb + 512u * it);
-                    row_pixels(g, rowb, al4b, t, yy, ox0);
+                    row_pixels(g, rowb + ox0 * 3u, al4b, t, yy, ox0);
                 }
             }
         }
@@ -419,54 +431,56 @@ struct F420 {
 };
 
 // =============================================================================================
-// FUSED_420, single launch ("strip walk"): a workgroup owns a strip of `tx` (<= 42) MCU columns and walks
-// `seg_rows` MCU rows of it top to bottom.  Per MCU row it stages the 4*te luma blocks AND the 2*(te+2) chroma
-// blocks under them (one halo block each side: the fancy upsampler reads +-1 chroma sample) in LDS, transforms
-// all of them (one lane per block), and keeps the chroma samples in LDS next to the luma tile: chroma never
-// makes the round trip through HBM that the two-pass form needs (0.8 of its 4.0 GB per 256 x 1080p).
-// The vertical +-1 chroma row comes from the previous MCU row, whose last chroma row and last luma row are
-// carried in LDS (two carry buffers, alternating by MCU row parity): step k emits output rows 16k-1 .. 16k+14
-// (eight slots of two rows, every slot uses two adjacent chroma rows); the last row of the image is emitted after
-// the last step.  A workgroup that does not start at MCU row 0 first transforms MCU row k0-1 only to fill the
-// carry rows.  The sample tiles alias the coefficient staging area (consumed before they are written).
+// FUSED_420, single launch ("strip walk"): a workgroup owns a strip of `tx` (<= 42) MCU columns and walks the MCU rows
+// [k0, k1) of it top to bottom.  Per MCU row it stages the 4*te luma blocks AND the 2*(te+2) chroma blocks under them
+// (one halo block each side: the fancy upsampler reads +-1 chroma sample) in LDS, transforms all of them (one lane
+// per block), and keeps the samples in LDS tiles: chroma never makes the round trip through HBM that the two-pass
+// form needs (0.8 of its 4.1 GB per 256 x 1080p).
+//   * Vertical neighbours.  Output row y reads chroma rows y/2 and y/2 -+ 1 (src/upsampler.rs:200-206), so step k emits
+//     output rows 16k-1 .. 16k+14: the tiles have a row 0 in front of the step's own rows — luma row 16k-1 and chroma row
+//     8k-1, carried over from step k-1 through a small LDS buffer — and row 16k+15 waits for step k+1.
+//   * Segment seams.  A workgroup that starts below the top of the image needs chroma row 8*k0-1, one that ends above the
+//     bottom needs chroma row 8*k1 for its last output row 16*k1-1: ONE extra transform round per workgroup (the chroma
+//     blocks of block rows k0-1 and k1, of which a single sample row each is kept) supplies both.  Nobody emits
+//     another workgroup's rows, so there is no luma warm-up.
+//   * Quantization tables sit in LDS (lanes of one wave hold blocks of different components); for the classes whose
+//     products fit i16 the block is multiplied row by row while it is copied out of the staging area, so table and raw
+//     coefficients never occupy registers together.
+//   * Pixel phase: the 8*nch (slot, 8-pixel chunk) units of a step — a slot = two output rows that share two chroma
+//     rows — are dealt to the lanes in order; waves without a unit in the last round go straight to the barrier and leave
+//     their SIMD to other workgroups, so only the remainder of ONE wave idles (tx = 40: none at all).
+// The sample tiles alias the coefficient staging area (consumed into registers before they are written).
 // =============================================================================================
 struct S420Lds {
-    uint8_t *stage;   // (6*tx + 4) blocks x 128 B coefficient staging; later luma rows 1..15 and chroma rows 1..7
-    uint8_t *ctile;   // inside `stage`: 2 comps x 7 rows x cpitch; column lc <-> plane column 8*(x0m-1) + lc
-    uint8_t *carry;   // 2 buffers x (ypitch + 2*cpitch): luma row 16 / chroma rows 8 of an MCU row = rows 0 of the next
-    uint8_t *qtab;    // 3 x 128 B packed quantization tables (lanes of one wave may use different ones)
+    uint8_t *stage;   // (6*tx + 4) blocks x 128 B coefficient staging; later the tiles:
+    uint8_t *ytile;   //   17 rows x ypitch : row 0 = luma row 16k-1 (carry), rows 1..16 = the step's own rows
+    uint8_t *ctile;   //   2 comps x 9 rows x cpitch : row 0 = chroma row 8k-1 (carry), rows 1..8 the step's own; column lc <-> plane column 8*(x0m-1) + lc
+    uint8_t *carry;   // ypitch + 2*cpitch: last luma / chroma rows of the step before (chroma part: the seam row at a segment start)
+    uint8_t *bnd;     // 2*cpitch: chroma row 8*k1 (seam below the segment)
+    uint8_t *qtab;    // 3 x 128 B packed quantization tables
     uint32_t ypitch, cpitch;
     static __device__ __host__ __forceinline__ uint32_t stage_bytes(uint32_t tx) { return (6u * tx + 4u) * 128u; }
     static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx) {
-        return stage_bytes(tx) + 2u * (16u * tx + 16u * (tx + 2u)) + 384u;
+        return stage_bytes(tx) + (16u * tx + 16u * (tx + 2u)) + 16u * (tx + 2u) + 384u;
     }
     static __device__ __forceinline__ S420Lds make(uint8_t *base, uint32_t tx) {
         S420Lds l;
         l.ypitch = 16u * tx;
         l.cpitch = 8u * (tx + 2u);
         l.stage = base;
-        l.ctile = base + 15u * l.ypitch;  // 15*16*tx + 14*8*(tx+2) <= (6*tx+4)*128
+        l.ytile = base;
+        l.ctile = base + 17u * l.ypitch;  // 17*16*tx + 18*8*(tx+2) = 416*tx + 288 <= (6*tx+4)*128
         l.carry = base + stage_bytes(tx);
-        l.qtab = l.carry + 2u * (l.ypitch + 2u * l.cpitch);
+        l.bnd = l.carry + l.ypitch + 2u * l.cpitch;
+        l.qtab = l.bnd + 2u * l.cpitch;
         return l;
-    }
-    // luma tile row r (0..16) / chroma tile row r (0..8) of component c during step k
-    __device__ __forceinline__ uint8_t *yrow(uint32_t k, uint32_t r) const {
-        if (r == 0u) return carry + (k & 1u) * (ypitch + 2u * cpitch);
-        if (r == 16u) return carry + ((k + 1u) & 1u) * (ypitch + 2u * cpitch);
-        return stage + (r - 1u) * ypitch;
-    }
-    __device__ __forceinline__ uint8_t *crow(uint32_t k, uint32_t c, uint32_t r) const {
-        if (r == 0u) return carry + (k & 1u) * (ypitch + 2u * cpitch) + ypitch + c * cpitch;
-        if (r == 8u) return carry + ((k + 1u) & 1u) * (ypitch + 2u * cpitch) + ypitch + c * cpitch;
-        return ctile + (c * 7u + r - 1u) * cpitch;
     }
 };
 constexpr uint32_t S420_TX_MAX = 42;  // 4*tx luma + 2*(tx+2) chroma blocks <= 256 lanes (<= 20 with 128-thread workgroups)
 
 struct S420Regs {
-    uint32_t cw[32];   // the lane's coefficient block (between read_block and transform)
-    uint32_t out[16];  // ... transformed
+    uint32_t cw[32];  // the lane's block between read_block and transform: dequantized (packed products) or, for the exact class, raw
+    v2u carry;        // 8 bytes of the carry rows on their way into row 0 of the tiles
 };
 
 template <int ARITH, uint32_t NTHREADS = 256>
@@ -493,8 +507,15 @@ struct S420 {
     // from one run — wave-uniform base, the lane's chunk index as 32-bit offset — so the address math stays
     // scalar; the price is 3+3+2+2 = 10 loads with idle lanes in the last load of each run.
     // Staging block index = lane that transforms it: [0,2te) luma row 0, [2te,4te) luma row 1, then Cb, Cr.
-    static __device__ __forceinline__ void stage(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
-                                                 uint32_t tid, const Lds &lds) {
+    // Two halves: stage_load issues the loads (into registers), stage_store puts them into LDS — the kernel issues the
+    // loads of step k+1 before the pixel phase of step k, so their latency is spent computing.
+    static constexpr uint32_t LY = (16u * (NT == 256 ? S420_TX_MAX : 20u) + NT - 1u) / NT;        // 3
+    static constexpr uint32_t LC = (8u * ((NT == 256 ? S420_TX_MAX : 20u) + 2u) + NT - 1u) / NT;  // 2
+    struct Pre {
+        v4u y0[LY], y1[LY], cb[LC], cr[LC];
+    };
+    static __device__ __forceinline__ void stage_load(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
+                                                      uint32_t tid, Pre &pre) {
         const uint32_t x0m = strip * g.tx, te = txe(g, strip);
         const uint32_t nl = 16u * te, ncc = 8u * (te + 2u);
         const JP_GLOBAL v4u *y0 = (const JP_GLOBAL v4u *)img.coefs[0] + ((size_t)(2u * k) * g.bw0 + 2u * x0m) * 8u;
@@ -503,32 +524,35 @@ struct S420 {
         const JP_GLOBAL v4u *cr = (const JP_GLOBAL v4u *)img.coefs[2] + (size_t)k * g.bwc * 8u;
         // halo blocks outside the plane (image edges) are never transformed: clamp them onto valid chunks
         const int32_t cfirst = ((int32_t)x0m - 1) * 8, cmax = (int32_t)(g.bwc * 8u) - 1;
-        v4u pre[10];
 #pragma unroll
-        for (uint32_t i = 0; i < 3; i++) {
+        for (uint32_t i = 0; i < LY; i++) {
             const uint32_t j = min(tid + NT * i, nl - 1u);  // clamped: unconditional loads
-            pre[i] = stream_load(y0 + j);
-            pre[3 + i] = stream_load(y1 + j);
+            pre.y0[i] = stream_load(y0 + j);
+            pre.y1[i] = stream_load(y1 + j);
         }
 #pragma unroll
-        for (uint32_t i = 0; i < 2; i++) {
+        for (uint32_t i = 0; i < LC; i++) {
             const uint32_t e = (uint32_t)min(max(cfirst + (int32_t)min(tid + NT * i, ncc - 1u), 0), cmax);
-            pre[6 + i] = stream_load(cb + e);
-            pre[8 + i] = stream_load(cr + e);
+            pre.cb[i] = stream_load(cb + e);
+            pre.cr[i] = stream_load(cr + e);
         }
+    }
+    static __device__ __forceinline__ void stage_store(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds, const Pre &pre) {
+        const uint32_t te = txe(g, strip);
+        const uint32_t nl = 16u * te, ncc = 8u * (te + 2u);
         v4u *dst = reinterpret_cast<v4u *>(lds.stage);
         const uint32_t row = tid & 7u, b = tid >> 3;
 #pragma unroll
-        for (uint32_t i = 0; i < 3; i++)
+        for (uint32_t i = 0; i < LY; i++)
             if (tid + NT * i < nl) {
-                dst[coef_slot(b + (NT / 8u) * i, row)] = pre[i];
-                dst[coef_slot(2u * te + b + (NT / 8u) * i, row)] = pre[3 + i];
+                dst[coef_slot(b + (NT / 8u) * i, row)] = pre.y0[i];
+                dst[coef_slot(2u * te + b + (NT / 8u) * i, row)] = pre.y1[i];
             }
 #pragma unroll
-        for (uint32_t i = 0; i < 2; i++)
+        for (uint32_t i = 0; i < LC; i++)
             if (tid + NT * i < ncc) {
-                dst[coef_slot(4u * te + b + (NT / 8u) * i, row)] = pre[6 + i];
-                dst[coef_slot(5u * te + 2u + b + (NT / 8u) * i, row)] = pre[8 + i];
+                dst[coef_slot(4u * te + b + (NT / 8u) * i, row)] = pre.cb[i];
+                dst[coef_slot(5u * te + 2u + b + (NT / 8u) * i, row)] = pre.cr[i];
             }
     }
 
@@ -554,66 +578,215 @@ struct S420 {
         return bx >= 0 && bx < (int32_t)g.bwc;
     }
 
-    // staging -> registers (a barrier follows: the tiles written by put_tiles alias the staging area)
-    static __device__ __forceinline__ void read_block(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds,
-                                                      S420Regs &r) {
-        uint32_t comp, ry, cx;
-        if (!lane_block(g, strip, tid, comp, ry, cx)) return;
-        load_block_from_lds(lds.stage, tid, r.cw);
-    }
-
-    // transform the lane's block and write the samples to the tiles.  carry_only: just the rows the next MCU row
-    // needs (luma row 16, chroma rows 8) — the warm-up step of a workgroup that starts below MCU row 0.
-    static __device__ __forceinline__ void transform(const FusedGeom &g, uint32_t strip, uint32_t k, uint32_t tid,
-                                                     const Lds &lds, S420Regs &r, bool carry_only) {
-        uint32_t comp, ry, cx;
-        if (!lane_block(g, strip, tid, comp, ry, cx)) return;
-        if (carry_only && comp == 0u && ry == 0u) return;
-        uint32_t qw[32];
+    // block `lb` of the staging area -> registers, dequantized on the way for the classes whose products fit i16
+    static __device__ __forceinline__ void fetch_block(const Lds &lds, uint32_t lb, uint32_t comp, uint32_t (&cw)[32]) {
+        const v4u *p = reinterpret_cast<const v4u *>(lds.stage);
         const v4u *q = reinterpret_cast<const v4u *>(lds.qtab) + comp * 8u;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const v4u v = q[i];
-            qw[4 * i] = v.x;
-            qw[4 * i + 1] = v.y;
-            qw[4 * i + 2] = v.z;
-            qw[4 * i + 3] = v.w;
+        for (uint32_t k = 0; k < 8; k++) {
+            const v4u v = p[coef_slot(lb, k)];
+            if constexpr (ARITH == ARITH_EXACT) {
+                cw[4 * k] = v.x, cw[4 * k + 1] = v.y, cw[4 * k + 2] = v.z, cw[4 * k + 3] = v.w;
+            } else {
+                const v4u qq = q[k];
+                cw[4 * k] = pk_mul_lo_u16(v.x, qq.x), cw[4 * k + 1] = pk_mul_lo_u16(v.y, qq.y);
+                cw[4 * k + 2] = pk_mul_lo_u16(v.z, qq.z), cw[4 * k + 3] = pk_mul_lo_u16(v.w, qq.w);
+            }
         }
-        idct8x8<ARITH>(r.cw, qw, r.out);
-        // rows 1..: luma tile row ry*8 + 1 + row, chroma tile row 1 + row
-        const uint32_t c = comp == 0u ? 0u : comp - 1u;
-        uint8_t *last = comp == 0u ? lds.yrow(k, 16u) : lds.crow(k, c, 8u);
-        if (!carry_only) {
-            uint8_t *base = comp == 0u ? lds.stage + (ry * 8u) * lds.ypitch : lds.ctile + (c * 7u) * lds.cpitch;
-            const uint32_t pitch = comp == 0u ? lds.ypitch : lds.cpitch;
+    }
+    static __device__ __forceinline__ void transform_block(const Lds &lds, uint32_t comp, const uint32_t (&cw)[32], uint32_t (&out)[16]) {
+        if constexpr (ARITH == ARITH_EXACT) {
+            uint32_t qw[32];
+            const v4u *q = reinterpret_cast<const v4u *>(lds.qtab) + comp * 8u;
 #pragma unroll
-            for (int row = 0; row < 7; row++)
-                *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch + cx * 8u) = v2u{r.out[2 * row], r.out[2 * row + 1]};
-            if (comp == 0u && ry == 0u) last = base + 7u * pitch;  // luma tile row 8 is an ordinary row
+            for (int i = 0; i < 8; i++) {
+                const v4u v = q[i];
+                qw[4 * i] = v.x, qw[4 * i + 1] = v.y, qw[4 * i + 2] = v.z, qw[4 * i + 3] = v.w;
+            }
+            idct8x8<ARITH_EXACT>(cw, qw, out);
+        } else {
+            idct8x8_products<ARITH>(cw, out);
         }
-        *reinterpret_cast<v2u *>(last + cx * 8u) = v2u{r.out[14], r.out[15]};
     }
 
-    // output rows 16k-1 .. 16k+14: slot p (0..7) pairs chroma tile rows (p, p+1) = plane rows 8k-1+p, 8k+p and
-    // emits luma tile rows 2p (near = upper chroma row) and 2p+1 (near = lower chroma row).
-    // The 8*nch (slot, chunk) units are dealt to the 256 lanes in order, so consecutive lanes write consecutive
-    // 24-B runs of a scanline; with nch = 80 that is 2.5 rounds: the waves that sit out the last round rotate
-    // with k (waves map to SIMDs round-robin: a fixed assignment would load two SIMDs more than the others).
-    // k == mcu_h is the closing call: only the very last image row (slot 0, first row) is in range.
-    static __device__ __forceinline__ void colour(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k,
-                                                  uint32_t tid, const Lds &lds) {
+    // staging -> registers (a barrier follows: the tiles written by transform alias the staging area); the first lanes
+    // also pick up 8 bytes each of the carry rows, which transform() puts into row 0 of the tiles
+    static __device__ __forceinline__ void read_block(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds,
+                                                      S420Regs &r) {
+        if (tid * 8u < lds.ypitch + 2u * lds.cpitch) r.carry = *reinterpret_cast<const v2u *>(lds.carry + tid * 8u);
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, strip, tid, comp, ry, cx)) return;
+        fetch_block(lds, tid, comp, r.cw);
+    }
+
+    // transform the lane's block and write the samples to the tiles (rows 1..) and its last row to the carry buffer as well
+    static __device__ __forceinline__ void transform(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds, S420Regs &r) {
+        if (tid * 8u < lds.ypitch + 2u * lds.cpitch) {  // carry rows -> row 0 of the tiles
+            const uint32_t o = tid * 8u;
+            uint8_t *dst = o < lds.ypitch ? lds.ytile + o
+                                          : (o - lds.ypitch < lds.cpitch ? lds.ctile + (o - lds.ypitch) : lds.ctile + 9u * lds.cpitch + (o - lds.ypitch - lds.cpitch));
+            *reinterpret_cast<v2u *>(dst) = r.carry;
+        }
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, strip, tid, comp, ry, cx)) return;
+        uint32_t out[16];
+        transform_block(lds, comp, r.cw, out);
+        const uint32_t c = comp == 0u ? 0u : comp - 1u;
+        uint8_t *base = comp == 0u ? lds.ytile + (1u + ry * 8u) * lds.ypitch + cx * 8u : lds.ctile + (c * 9u + 1u) * lds.cpitch + cx * 8u;
+        const uint32_t pitch = comp == 0u ? lds.ypitch : lds.cpitch;
+        const EdgeFix ef = comp == 0u ? EdgeFix{false, false} : edge_fix(g, strip * g.tx, cx, out);
+#pragma unroll
+        for (int row = 0; row < 8; row++) *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch) = v2u{out[2 * row], out[2 * row + 1]};
+        uint8_t *cy = comp == 0u ? lds.carry + cx * 8u : lds.carry + lds.ypitch + c * lds.cpitch + cx * 8u;
+        if (comp != 0u || ry == 1u) *reinterpret_cast<v2u *>(cy) = v2u{out[14], out[15]};  // what the next step finds in front of its own rows
+        // the sample next to the image, in the (untransformed) neighbour block's columns: one lane per chroma component at most
+        if (ef.before) {
+#pragma unroll
+            for (int row = 0; row < 8; row++) (base + (uint32_t)row * pitch)[-1] = (uint8_t)out[2 * row];
+            cy[-1] = (uint8_t)out[14];
+        }
+        if (ef.after) {
+#pragma unroll
+            for (int row = 0; row < 8; row++) (base + (uint32_t)row * pitch)[8] = (uint8_t)(out[2 * row + 1] >> 24);
+            cy[8] = (uint8_t)(out[15] >> 24);
+        }
+    }
+
+    // Chroma columns just outside the image repeat the first / last sample of their row (see F420::row_pixels<.., EDGES = false>).
+    // Plane column cw (= size.width: the upsampler's "last column" is pixel 2*cw-1, src/upsampler.rs:226) lies in the block
+    // of column cw-1 unless that one ends the block: then, like column -1, it is a byte of the neighbouring block, which is
+    // outside the plane and never transformed.  bx = plane block of the lane (x0m - 1 + cx).
+    struct EdgeFix {
+        bool before, after;  // write byte 0 of a row to column -1 / byte 7 to column +8 of the block
+    };
+    static __device__ __forceinline__ EdgeFix edge_fix(const FusedGeom &g, uint32_t x0m, uint32_t cx, uint32_t (&out)[16]) {
+        const uint32_t bx = x0m - 1u + cx, last = g.cw - 1u;
+        // (a halo block's own neighbour column is not part of the tile — nobody reads it, and the byte would land in
+        // the next row or past the buffer: only the strip's own blocks, cx in [1, te], write outside themselves)
+        const bool own = cx >= 1u && cx <= min(g.tx, g.mcu_w - x0m);
+        EdgeFix ef{bx == 0u && own, false};
+        if (bx == (last >> 3)) {
+            const uint32_t r = last & 7u;
+            if (r == 7u) ef.after = own;
+            else {
+#pragma unroll
+                for (int row = 0; row < 8; row++) {
+                    const uint64_t v = (uint64_t)out[2 * row] | ((uint64_t)out[2 * row + 1] << 32);
+                    const uint64_t b = (v >> (8u * r)) & 0xffull, m = 0xffull << (8u * (r + 1u));
+                    const uint64_t w = (v & ~m) | (b << (8u * (r + 1u)));
+                    out[2 * row] = (uint32_t)w, out[2 * row + 1] = (uint32_t)(w >> 32);
+                }
+            }
+        }
+        return ef;
+    }
+    static __device__ __forceinline__ void edge_bytes(const EdgeFix &ef, uint8_t *row8, uint32_t lo, uint32_t hi) {
+        if (ef.before) row8[-1] = (uint8_t)lo;
+        if (ef.after) row8[8] = (uint8_t)(hi >> 24);
+    }
+
+    // ---- segment seams: the chroma blocks of block rows k0-1 (their last sample row -> carry) and k1 (their first
+    // sample row -> bnd).  Staging block index = lane: [0,te+2) Cb above, then Cr above, Cb below, Cr below.
+    static __device__ __forceinline__ void seam_stage(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k0, uint32_t k1,
+                                                      uint32_t tid, const Lds &lds) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip), ncc = 8u * (te + 2u);
+        const bool above = k0 > 0u, below = k1 < g.mcu_h;
+        const size_t ra = (size_t)(above ? k0 - 1u : 0u) * g.bwc * 8u, rb = (size_t)(below ? k1 : 0u) * g.bwc * 8u;
+        const JP_GLOBAL v4u *run[4] = {(const JP_GLOBAL v4u *)img.coefs[1] + ra, (const JP_GLOBAL v4u *)img.coefs[2] + ra,
+                                       (const JP_GLOBAL v4u *)img.coefs[1] + rb, (const JP_GLOBAL v4u *)img.coefs[2] + rb};
+        const int32_t cfirst = ((int32_t)x0m - 1) * 8, cmax = (int32_t)(g.bwc * 8u) - 1;
+        v4u v[4][LC];
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++)
+#pragma unroll
+            for (uint32_t i = 0; i < LC; i++) {
+                const uint32_t e = (uint32_t)min(max(cfirst + (int32_t)min(tid + NT * i, ncc - 1u), 0), cmax);
+                v[w][i] = run[w][e];  // (re-read by the neighbouring segment: no streaming hint)
+            }
+        v4u *dst = reinterpret_cast<v4u *>(lds.stage);
+        const uint32_t row = tid & 7u, b = tid >> 3;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++)
+#pragma unroll
+            for (uint32_t i = 0; i < LC; i++)
+                if (tid + NT * i < ncc) dst[coef_slot(w * (te + 2u) + b + (NT / 8u) * i, row)] = v[w][i];
+    }
+    static __device__ __forceinline__ void seam_transform(const FusedGeom &g, uint32_t strip, uint32_t k0, uint32_t k1, uint32_t tid,
+                                                          const Lds &lds) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip), nb = te + 2u;
+        if (tid >= 4u * nb) return;
+        const uint32_t which = (tid >= nb ? 1u : 0u) + (tid >= 2u * nb ? 1u : 0u) + (tid >= 3u * nb ? 1u : 0u);
+        const uint32_t cx = tid - which * nb, c = which & 1u;
+        const bool below = which >= 2u;
+        if (below ? !(k1 < g.mcu_h) : !(k0 > 0u)) return;
+        const int32_t bx = (int32_t)x0m - 1 + (int32_t)cx;
+        if (bx < 0 || bx >= (int32_t)g.bwc) return;
+        uint32_t cw[32], out[16];
+        fetch_block(lds, tid, 1u + c, cw);
+        transform_block(lds, 1u + c, cw, out);
+        const EdgeFix ef = edge_fix(g, x0m, cx, out);
+        uint8_t *dst = below ? lds.bnd + c * lds.cpitch + cx * 8u : lds.carry + lds.ypitch + c * lds.cpitch + cx * 8u;
+        const uint32_t lo = below ? out[0] : out[14], hi = below ? out[1] : out[15];
+        *reinterpret_cast<v2u *>(dst) = v2u{lo, hi};
+        edge_bytes(ef, dst, lo, hi);
+    }
+    // after the last step: the carry rows and the seam row below become rows 0 / 1 of the tiles for the closing call
+    static __device__ __forceinline__ void closing_tiles(uint32_t tid, const Lds &lds) {
+        const uint32_t o = tid * 8u;
+        if (o < lds.ypitch) *reinterpret_cast<v2u *>(lds.ytile + o) = *reinterpret_cast<const v2u *>(lds.carry + o);
+        if (o < 2u * lds.cpitch) {
+            const uint32_t c = o >= lds.cpitch ? 1u : 0u, x = o - c * lds.cpitch;
+            *reinterpret_cast<v2u *>(lds.ctile + c * 9u * lds.cpitch + x) = *reinterpret_cast<const v2u *>(lds.carry + lds.ypitch + o);
+            *reinterpret_cast<v2u *>(lds.ctile + (c * 9u + 1u) * lds.cpitch + x) = *reinterpret_cast<const v2u *>(lds.bnd + o);
+        }
+    }
+
+    // output rows 16k-1 .. 16k+14 of the strip: slot p (0..7) pairs chroma tile rows (p, p+1) = plane rows 8k-1+p, 8k+p and
+    // emits luma tile rows 2p (near = upper chroma row) and 2p+1 (near = lower chroma row).  Rows above `row_lo` belong
+    // to the workgroup of the segment above.  closing: only slot 0 (the segment's last output row, k = k1).
+    static __device__ __forceinline__ void colour(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k, uint32_t row_lo,
+                                                  bool closing, uint32_t tid, const Lds &lds) {
         const uint32_t x0m = strip * g.tx, te = txe(g, strip);
-        const uint32_t nch = 2u * te, nunits = 8u * nch;
+        const uint32_t nch = 2u * te, nunits = (closing ? 1u : 8u) * nch;
         const uint32_t magic = 0xffffffffu / nch + 1u;  // mul_hi(u, magic) == u / nch for u < 65536
-        const uint32_t vt = (tid + 64u * (k & (NT / 64u - 1u))) & (NT - 1u);
-        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
-        const size_t pitch = (size_t)g.out_w * 3u;
+        const uint32_t pitch = g.out_w * 3u;
+        // first byte of output row 16k-1 (may lie before the image for k = 0: never dereferenced)
+        JP_GLOBAL uint8_t *base = (JP_GLOBAL uint8_t *)img.out + ((ptrdiff_t)(16 * (int64_t)k - 1)) * (ptrdiff_t)pitch;
+        const uint32_t base_lo = (uint32_t)((16 * (int64_t)k - 1) * (int64_t)pitch) & 3u;  // its alignment
+        // Interior steps — every one of the 16 rows inside the segment and the image, no vertical clamp, the strip's chunks
+        // complete and 4-byte aligned (widths that are multiples of 8) — run a loop without any per-unit predicate.
+        const bool interior = !closing && 16u * k >= row_lo + 1u && 16u * k + 15u <= g.out_h && k > 0u && 8u * k + 8u <= g.ch &&
+                              (g.out_w & 7u) == 0u && 16u * x0m + 8u * nch <= g.out_w;
+        if (interior) {
 #pragma unroll 1
-        for (uint32_t u = vt; u < nunits; u += NT) {
+            for (uint32_t u = tid; u < nunits; u += NT) {
+                const uint32_t slot = __umulhi(u, magic), chk = u - slot * nch;
+                const uint8_t *pc = lds.ctile + slot * lds.cpitch + 4u * chk + 4u;  // upper chroma row of the slot, Cb; lower: + cpitch; Cr: + 9 * cpitch
+                typename P::ChromaEO eu[2], el[2];
+#pragma unroll
+                for (uint32_t comp = 0; comp < 2; comp++) {
+                    eu[comp] = P::load_eo(pc + comp * 9u * lds.cpitch);
+                    el[comp] = P::load_eo(pc + (comp * 9u + 1u) * lds.cpitch);
+                }
+                const uint32_t ox0 = 16u * x0m + 8u * chk, offa = 2u * slot * pitch + ox0 * 3u;
+                const uint8_t *py = lds.ytile + 2u * slot * lds.ypitch + 8u * chk;
+                {
+                    const typename P::TPrime t[2] = {P::tprime(eu[0], el[0]), P::tprime(eu[1], el[1])};
+                    P::template row_pixels<false, false, true, false>(g, base + offa, true, t, *reinterpret_cast<const v2u *>(py), ox0);
+                }
+                {
+                    const typename P::TPrime t[2] = {P::tprime(el[0], eu[0]), P::tprime(el[1], eu[1])};
+                    P::template row_pixels<false, false, true, false>(g, base + (offa + pitch), true, t, *reinterpret_cast<const v2u *>(py + lds.ypitch), ox0);
+                }
+            }
+            return;
+        }
+#pragma unroll 1
+        for (uint32_t u = tid; u < nunits; u += NT) {
             const uint32_t slot = __umulhi(u, magic), chk = u - slot * nch;
             const int32_t oya = 16 * (int32_t)k - 1 + 2 * (int32_t)slot;
             const uint32_t oyb = (uint32_t)(oya + 1);
-            const bool va = oya >= 0 && (uint32_t)oya < g.out_h, vb = oyb < g.out_h;
+            const bool va = oya >= (int32_t)row_lo && (uint32_t)oya < g.out_h, vb = !closing && oyb < g.out_h;
             const uint32_t ox0 = 16u * x0m + 8u * chk;
             if ((!va && !vb) || ox0 >= g.out_w) continue;
             const int32_t cu = 8 * (int32_t)k - 1 + (int32_t)slot;  // plane row of the slot's upper chroma row
@@ -624,20 +797,20 @@ struct S420 {
             typename P::ChromaEO eu[2], el[2];
 #pragma unroll
             for (uint32_t comp = 0; comp < 2; comp++) {
-                eu[comp] = P::load_eo(lds.crow(k, comp, U) + coff);
-                el[comp] = P::load_eo(lds.crow(k, comp, L) + coff);
+                eu[comp] = P::load_eo(lds.ctile + (comp * 9u + U) * lds.cpitch + coff);
+                el[comp] = P::load_eo(lds.ctile + (comp * 9u + L) * lds.cpitch + coff);
             }
+            const uint32_t offa = 2u * slot * pitch + ox0 * 3u;  // < 17 rows: fits 32 bits
+            const uint8_t *py = lds.ytile + 2u * slot * lds.ypitch + 8u * chk;
             if (va) {
                 const typename P::TPrime t[2] = {P::tprime(eu[0], el[0]), P::tprime(eu[1], el[1])};
-                const v2u yy = *reinterpret_cast<const v2u *>(lds.yrow(k, 2u * slot) + 8u * chk);
-                const size_t ro = (size_t)oya * pitch;
-                P::row_pixels(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
+                const v2u yy = *reinterpret_cast<const v2u *>(py);
+                P::template row_pixels<false, false, false, false>(g, base + offa, ((base_lo + offa) & 3u) == 0, t, yy, ox0);
             }
             if (vb) {
                 const typename P::TPrime t[2] = {P::tprime(el[0], eu[0]), P::tprime(el[1], eu[1])};
-                const v2u yy = *reinterpret_cast<const v2u *>(lds.yrow(k, 2u * slot + 1u) + 8u * chk);
-                const size_t ro = (size_t)oyb * pitch;
-                P::row_pixels(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
+                const v2u yy = *reinterpret_cast<const v2u *>(py + lds.ypitch);
+                P::template row_pixels<false, false, false, false>(g, base + (offa + pitch), ((base_lo + offa + pitch) & 3u) == 0, t, yy, ox0);
             }
         }
     }
@@ -749,7 +922,7 @@ struct F422 {
                     t[comp].tEp = e.Ep;
                 }
                 const v2u yy = *reinterpret_cast<const v2u *>(py + 512u * it);
-                P::template row_pixels<true>(g, out + ro, (ro & 3u) == 0, t, yy, ox0);
+                P::template row_pixels<true>(g, out + ro + ox0 * 3u, (ro & 3u) == 0, t, yy, ox0);
             }
         }
     }

@@ -20,7 +20,7 @@ inline bool fused_same_component(const jpgpu_component &a, const jpgpu_component
 // MI355X, 1080p x256: 0.899 ms with 64 vs 0.941 ms with 32 — profiles/round1)
 // strip420: 4:2:0 as the single-launch strip walk (S420) instead of chroma pass + main pass.
 inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why,
-                                uint32_t f420_tx_max = 64, bool strip420 = false, uint32_t s420_tx_max = S420_TX_MAX) {
+                                uint32_t f420_tx_max = 64, bool strip420 = true, uint32_t s420_tx_max = S420_TX_MAX) {
     g = FusedGeom{};
     for (uint32_t c = 0; c < d0.ncomp; c++)
         if (d0.components[c].dct_scale != 8) {
@@ -40,7 +40,7 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
         // choose_upsampler (src/upsampler.rs:80-81): an output width/height of 1 overrides H2V2,
         // such frames stay on the generic path
         kind = FUSED_420;
-        name = "fused420";
+        name = "fused420-2pass";
         g.mcu_w = d0.components[1].block_width;
         g.mcu_h = d0.components[1].block_height;
         g.bwc = d0.components[1].block_width;
@@ -54,7 +54,7 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
         }
         tx_max = strip420 ? (s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max)) : (f420_tx_max <= 32u ? 32u : (f420_tx_max < F420_TX_MAX ? f420_tx_max : F420_TX_MAX));
         g.strip = strip420 ? 1u : 0u;
-        if (strip420) name = "fused420s";
+        if (strip420) name = "fused420";
     } else if (d0.ncomp == 3 && hv(0, 2, 1) && hv(1, 1, 1) && hv(2, 1, 1) && d0.color_transform == JPGPU_CT_YCBCR && d0.out_w > 1 &&
                fused_same_component(d0.components[1], d0.components[2])) {
         // (an output width of 1 overrides H2V1 with H1V1, src/upsampler.rs:80: generic path)
@@ -115,19 +115,21 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
     return kind;
 }
 
-// S420: split the MCU rows of a strip between workgroups.  Every workgroup but the first re-transforms one
-// MCU row for its carry rows, so segments are as long as the machine allows: enough workgroups to fill
-// 256 CUs x 3 resident workgroups a few times over, and no more.
+// S420: split the MCU rows of a strip between workgroups.  A seam costs one extra transform round (the chroma blocks
+// above and below, 35 % of a step) and re-reads two chroma block rows, so segments are as long as the machine allows:
+// about 2300 workgroups per launch for the 1024 the chip holds at once (measured on 256 x 1080p, 768 strips: 3 segments
+// of 23 rows 0.650 ms, 4 of 17 0.667, 8 of 9 0.663, 2 of 34 0.687 — profiles/round2/02_single_launch_420.md), never
+// fewer than the strips themselves; a lone image is cut down to single rows for the sake of parallelism.
 inline void s420_set_segments(FusedGeom &g, uint32_t n_images, uint32_t seg_rows_override = 0) {
     uint32_t seg = seg_rows_override;
     if (seg == 0) {
-        const uint32_t target = g.tx <= 20u ? 6144u : 3072u;  // workgroups (128-thread ones are half the size)
+        const uint32_t target = 2304u;
         const uint32_t per_seg = g.tiles_x * (n_images ? n_images : 1u);
-        uint32_t n_seg = (target + per_seg - 1) / per_seg;
+        uint32_t n_seg = (target + per_seg / 2u) / per_seg;
         n_seg = n_seg < 1u ? 1u : n_seg;
         seg = (g.mcu_h + n_seg - 1) / n_seg;
-        if (seg < 4u) seg = 4u;
     }
+    if (seg < 1u) seg = 1u;
     if (seg > g.mcu_h) seg = g.mcu_h;
     g.seg_rows = seg;
     g.n_seg = (g.mcu_h + seg - 1) / seg;

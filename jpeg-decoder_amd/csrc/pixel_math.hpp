@@ -65,11 +65,17 @@ typedef uint32_t w32;
 // (macros, not templates: template argument deduction would drop the 4-byte alignment of v3u_a4)
 #if !defined(JPGPU_NO_STREAM_NT) && !defined(JPGPU_HOST_EMULATION)
 #define stream_load(p) __builtin_nontemporal_load(p)
-#define stream_store(p, ...) __builtin_nontemporal_store((__VA_ARGS__), (p))
 #else
 #define stream_load(p) (*(p))
+#endif
+#if !defined(JPGPU_NO_STREAM_NT) && !defined(JPGPU_HOST_EMULATION)
+#define stream_store(p, ...) __builtin_nontemporal_store((__VA_ARGS__), (p))
+#else
 #define stream_store(p, ...) (*(p) = (__VA_ARGS__))
 #endif
+// (What the hint does to PARTIAL lines — a lane writing 12-byte pieces 24 bytes apart fills half of each line per
+// instruction: tools/ubench_store.hip, profiles/round2/01_store_patterns.txt — alone 2.5 TB/s against 5.3 TB/s for plain
+// stores.  The single-launch 4:2:0 kernel therefore stores plainly, F420::row_pixels<.., NTS = false>.)
 
 typedef const JP_CONST uint32_t *qtab_t;  // 64 u16 quantization values packed two per dword, 4-B aligned
 
@@ -212,10 +218,20 @@ __device__ __forceinline__ uint32_t sar_sat_u8x2_raw(w32 a, w32 b) {
     return r;
 #endif
 }
-// four values -> one dword, byte 0 = a
+// four values -> one dword, byte 0 = a.  The instruction writes ONE 16-bit half of its destination and leaves the other
+// alone (that is what the "undefined" upper half above is: the register's previous content); op_sel[3] selects the
+// upper half.  So the second pair goes straight into the upper half of the first pair's register — no v_perm_b32 to
+// merge them (probe: profiles/round2/00_valu_issue_cost_ubench.txt; the instruction alone costs two issue slots).
 template <int N>
 __device__ __forceinline__ uint32_t sar_sat_u8x4(w32 a, w32 b, w32 c, w32 d) {
-    return perm_b32(sar_sat_u8x2_raw<N>(c, d), sar_sat_u8x2_raw<N>(a, b), 0x05040100u);  // bytes: lo.0 lo.1 hi.0 hi.1
+#ifdef JPGPU_HOST_EMULATION
+    return (sar_sat_u8x2(a, b, N) & 0xffffu) | (sar_sat_u8x2(c, d, N) << 16);
+#else
+    uint32_t r;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(N));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(c), "v"(d), "n"(N));
+    return r;
+#endif
 }
 __device__ __forceinline__ uint32_t clamp_u8(w32 x) {  // stbi_clamp, src/idct.rs:568-570
     return sar_sat_u8x2(x, 0u, 0) & 0xffu;
@@ -289,18 +305,21 @@ constexpr uint32_t pk_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((
 //        [4096  2217 -4096 -5350]        [3219 -5681  1132  4816]
 //        [4096 -2217 -4096  5350]        [4816 -1129 -5681 -3218]
 //        [4096 -5352  4096 -2217]        [5683  4816  3219  1131]
-// Inputs arrive as signed 16-bit pairs p02 = (s0,s2), p46 = (s4,s6), p13 = (s1,s3), p57 = (s5,s7), so each
-// row of the maps is two v_dot2_i32_i16 (2 MACs per instruction, full rate): 16 dot2 + 8 add/sub per
-// pass instead of 12 multiplies + 29 adds.  Valid whenever every input fits i16.
+// Inputs arrive as signed 16-bit pairs p04 = (s0,s4), p26 = (s2,s6), p13 = (s1,s3), p57 = (s5,s7).  The odd half is the
+// 4x4 map Ou: two v_dot2_i32_i16 per row (2 MACs per instruction).  The even half keeps one butterfly level of
+// kernel_x — e0/e1 = 4096*(s0 +- s4) + x_scale and t3/t2 = the (s2,s6) rotation, one dot2 each, then x0,x3 = e0 +- t3 and
+// x1,x2 = e1 +- t2 — because additions issue at twice the rate of dot2 on gfx950 (profiles/round2/00_*): 12 dot2 +
+// 12 add/sub per pass instead of 16 + 8.  The same integer linear map mod 2^32 either way.  Valid whenever every input fits i16.
 // PLUS_SHL: o[0..3] (the sums) come out shifted left by that much — (a + b) << n is one instruction (v_add_lshl_u32),
 // (a - b) << n is not.
 template <int PLUS_SHL = 0>
-__device__ __forceinline__ void idct_pass8_dot2(uint32_t p02, uint32_t p46, uint32_t p13, uint32_t p57, w32 x_scale,
+__device__ __forceinline__ void idct_pass8_dot2(uint32_t p04, uint32_t p26, uint32_t p13, uint32_t p57, w32 x_scale,
                                                 w32 (&o)[8]) {
-    const w32 x0 = dot2_i16(p02, pk_i16(4096, 5352), dot2_i16_sc(p46, pk_i16(4096, 2217), x_scale));
-    const w32 x1 = dot2_i16(p02, pk_i16(4096, 2217), dot2_i16_sc(p46, pk_i16(-4096, -5350), x_scale));
-    const w32 x2 = dot2_i16(p02, pk_i16(4096, -2217), dot2_i16_sc(p46, pk_i16(-4096, 5350), x_scale));
-    const w32 x3 = dot2_i16(p02, pk_i16(4096, -5352), dot2_i16_sc(p46, pk_i16(4096, -2217), x_scale));
+    const w32 e0 = dot2_i16_sc(p04, pk_i16(4096, 4096), x_scale);
+    const w32 e1 = dot2_i16_sc(p04, pk_i16(4096, -4096), x_scale);
+    const w32 t3 = dot2_i16_sc(p26, pk_i16(5352, 2217), 0u);
+    const w32 t2 = dot2_i16_sc(p26, pk_i16(2217, -5350), 0u);
+    const w32 x0 = e0 + t3, x3 = e0 - t3, x1 = e1 + t2, x2 = e1 - t2;
     const w32 u0 = dot2_i16(p13, pk_i16(1131, -3218), dot2_i16_sc(p57, pk_i16(4816, -5680), 0u));
     const w32 u1 = dot2_i16(p13, pk_i16(3219, -5681), dot2_i16_sc(p57, pk_i16(1132, 4816), 0u));
     const w32 u2 = dot2_i16(p13, pk_i16(4816, -1129), dot2_i16_sc(p57, pk_i16(-5681, -3218), 0u));
@@ -322,6 +341,83 @@ enum : int {
     ARITH_TIGHT = 2,  // additionally every column of every block has sum_k |c*q| <= 5900, so the column-pass
                       // outputs (<= (5683*5900 + 512) >> 10 < 2^15) fit i16 and the row pass runs on dot2 too
 };
+
+// The two passes on DEQUANTIZED coefficients that fit i16 (classes ARITH_SANE / ARITH_TIGHT): d[k*4+j] = (s[k][2j], s[k][2j+1]).
+// Split from the dequantization so that a kernel may multiply while it copies a block out of LDS (S420::read_block).
+template <int ARITH>
+__device__ __forceinline__ void idct8x8_products(const uint32_t (&d)[32], uint32_t (&out)[16]) {
+    static_assert(ARITH == ARITH_SANE || ARITH == ARITH_TIGHT, "the exact class works on 32-bit products");
+    const w32 X_SCALE = 65536u + (128u << 17);
+#ifdef JPGPU_IDCT_LATE_PACK  // A/B: the row pass pairs the 64 column-pass outputs as it goes (more registers, same instructions)
+    if constexpr (false) {
+#else
+    if constexpr (ARITH == ARITH_TIGHT) {
+#endif
+        // Column-pass outputs fit i16: they are paired for the row pass — (0,4) (2,6) (1,3) (5,7) — as soon as both columns
+        // of a pair exist, so 32 packed dwords are kept instead of 64 values (registers: one more wave per SIMD).
+        // The row pass wants bits 10..25 of the sums as 16-bit halves: rows 0..3 leave the pass shifted left by 6 and the
+        // pairing takes their HIGH halves (32 shifts less per block); rows 4..7 are shifted here.
+        uint32_t tp[32];  // tp[r*4 + m]: row r, pair m of (0,4) (2,6) (1,3) (5,7)
+        constexpr int PAIR[4][2] = {{0, 4}, {2, 6}, {1, 3}, {5, 7}};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            w32 o[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = PAIR[m][h], j = i >> 1;
+                const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
+                const uint32_t p04 = perm_b32(d[4 * 4 + j], d[0 * 4 + j], sel), p26 = perm_b32(d[6 * 4 + j], d[2 * 4 + j], sel);
+                const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
+                idct_pass8_dot2<6>(p04, p26, p13, p57, 512u, o[h]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                tp[r * 4 + m] = r < 4 ? perm_b32(o[1][r], o[0][r], 0x07060302u) : perm_b32(sar(o[1][r], 10), sar(o[0][r], 10), 0x05040100u);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            w32 o[8];
+            idct_pass8_dot2(tp[r * 4 + 0], tp[r * 4 + 1], tp[r * 4 + 2], tp[r * 4 + 3], X_SCALE, o);
+            out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
+            out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
+        }
+    } else {
+        w32 t[64];  // t[k*8+i] = column-pass output (row k, column i)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int j = i >> 1;
+            const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
+            const uint32_t p04 = perm_b32(d[4 * 4 + j], d[0 * 4 + j], sel), p26 = perm_b32(d[6 * 4 + j], d[2 * 4 + j], sel);
+            const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
+            w32 o[8];
+            if constexpr (ARITH == ARITH_TIGHT) {
+                idct_pass8_dot2<6>(p04, p26, p13, p57, 512u, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++) t[k * 8 + i] = k < 4 ? o[k] : sar(o[k], 10);
+            } else {
+                idct_pass8_dot2(p04, p26, p13, p57, 512u, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            w32 o[8];
+            if constexpr (ARITH == ARITH_TIGHT) {
+                const uint32_t h16 = r < 4 ? 0x07060302u : 0x05040100u;
+                idct_pass8_dot2(perm_b32(t[r * 8 + 4], t[r * 8 + 0], h16), perm_b32(t[r * 8 + 6], t[r * 8 + 2], h16),
+                                perm_b32(t[r * 8 + 3], t[r * 8 + 1], h16), perm_b32(t[r * 8 + 7], t[r * 8 + 5], h16), X_SCALE, o);
+            } else {
+                w32 s[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
+                idct_pass8<true>(s, X_SCALE, o);
+            }
+            out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
+            out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
 
 // qw: the 64 quantization values packed two per dword (natural order), as VALUES — in SGPRs when they
 // were loaded through a wave-uniform table pointer, in VGPRs when lanes of a wave use different tables.
@@ -370,43 +466,7 @@ __device__ __forceinline__ void idct8x8(const uint32_t (&cw)[32], const uint32_t
         uint32_t d[32];  // d[k*4+j] = (s[k][2j], s[k][2j+1])
 #pragma unroll
         for (int i = 0; i < 32; i++) d[i] = pk_mul_lo_u16(cw[i], qw[i]);
-        w32 t[64];  // t[k*8+i] = column-pass output (row k, column i)
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int j = i >> 1;
-            const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
-            const uint32_t p02 = perm_b32(d[2 * 4 + j], d[0 * 4 + j], sel), p46 = perm_b32(d[6 * 4 + j], d[4 * 4 + j], sel);
-            const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
-            w32 o[8];
-            if constexpr (ARITH == ARITH_TIGHT) {
-                // The row pass wants bits 10..25 of these as 16-bit halves: rows 0..3 (sums) leave the pass shifted left by 6
-                // and the pairing below takes their HIGH halves (32 shifts less per block); rows 4..7 are shifted here.
-                idct_pass8_dot2<6>(p02, p46, p13, p57, 512u, o);
-#pragma unroll
-                for (int k = 0; k < 8; k++) t[k * 8 + i] = k < 4 ? o[k] : sar(o[k], 10);
-            } else {
-                idct_pass8_dot2(p02, p46, p13, p57, 512u, o);
-#pragma unroll
-                for (int k = 0; k < 8; k++) t[k * 8 + i] = sar(o[k], 10);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            w32 o[8];
-            if constexpr (ARITH == ARITH_TIGHT) {
-                // the row's eight values fit i16: pair them (0,2) (4,6) (1,3) (5,7) and use dot2 again
-                const uint32_t h16 = r < 4 ? 0x07060302u : 0x05040100u;  // (see the column pass)
-                idct_pass8_dot2(perm_b32(t[r * 8 + 2], t[r * 8 + 0], h16), perm_b32(t[r * 8 + 6], t[r * 8 + 4], h16),
-                                perm_b32(t[r * 8 + 3], t[r * 8 + 1], h16), perm_b32(t[r * 8 + 7], t[r * 8 + 5], h16), X_SCALE, o);
-            } else {
-                w32 s[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) s[k] = t[r * 8 + k];
-                idct_pass8<true>(s, X_SCALE, o);
-            }
-            out[r * 2] = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
-            out[r * 2 + 1] = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
-        }
+        idct8x8_products<ARITH>(d, out);
     }
 }
 
@@ -541,15 +601,12 @@ __device__ __forceinline__ RawRgb ycbcr_raw(uint32_t y, uint32_t cb, uint32_t cr
 }
 // Four pixels -> the 12 output bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3.  The shift-saturate-
 // pack instruction takes two values at a time, so the pairs are chosen in output byte order and
-// each dword is then one byte permute of two pairs.
+// each dword is two of them, one per half (sar_sat_u8x4).
 __device__ __forceinline__ void rgb4_to_12bytes(const RawRgb &p0, const RawRgb &p1, const RawRgb &p2, const RawRgb &p3,
                                                 uint32_t &d0, uint32_t &d1, uint32_t &d2) {
-    const uint32_t a = sar_sat_u8x2_raw<20>(p0.r, p0.g), b = sar_sat_u8x2_raw<20>(p0.b, p1.r);
-    const uint32_t c = sar_sat_u8x2_raw<20>(p1.g, p1.b), d = sar_sat_u8x2_raw<20>(p2.r, p2.g);
-    const uint32_t e = sar_sat_u8x2_raw<20>(p2.b, p3.r), f = sar_sat_u8x2_raw<20>(p3.g, p3.b);
-    d0 = perm_b32(b, a, 0x05040100u);
-    d1 = perm_b32(d, c, 0x05040100u);
-    d2 = perm_b32(f, e, 0x05040100u);
+    d0 = sar_sat_u8x4<20>(p0.r, p0.g, p0.b, p1.r);
+    d1 = sar_sat_u8x4<20>(p1.g, p1.b, p2.r, p2.g);
+    d2 = sar_sat_u8x4<20>(p2.b, p3.r, p3.g, p3.b);
 }
 
 __device__ __forceinline__ uint32_t ycbcr_to_rgb24(uint32_t y, uint32_t cb, uint32_t cr) {

@@ -22,18 +22,24 @@ static void run_s420(const FusedGeom& g, const FusedImage& img) {
             const S420Lds lds = S420Lds::make(mem.data(), g.tx);
             const uint32_t k0 = seg * g.seg_rows, k1 = std::min(k0 + g.seg_rows, g.mcu_h);
             LANES(K::init(img, t, lds))
-            if (k0 > 0) {
-                LANES(K::stage(g, img, strip, k0 - 1, t, lds))
-                LANES(K::read_block(g, strip, t, lds, regs[t]))
-                LANES(K::transform(g, strip, k0 - 1, t, lds, regs[t], true))
+            if (k0 > 0 || k1 < g.mcu_h) {
+                LANES(K::seam_stage(g, img, strip, k0, k1, t, lds))
+                LANES(K::seam_transform(g, strip, k0, k1, t, lds))
             }
+            std::vector<typename K::Pre> pre(NT);
+            LANES(K::stage_load(g, img, strip, k0, t, pre[t]))
+            LANES(K::stage_store(g, strip, t, lds, pre[t]))
             for (uint32_t k = k0; k < k1; k++) {
-                LANES(K::stage(g, img, strip, k, t, lds))
                 LANES(K::read_block(g, strip, t, lds, regs[t]))
-                LANES(K::transform(g, strip, k, t, lds, regs[t], false))
-                LANES(K::colour(g, img, strip, k, t, lds))
+                LANES(K::transform(g, strip, t, lds, regs[t]))
+                if (k + 1 < k1) LANES(K::stage_load(g, img, strip, k + 1, t, pre[t]))
+                LANES(K::colour(g, img, strip, k, 16u * k0, false, t, lds))
+                if (k + 1 < k1) LANES(K::stage_store(g, strip, t, lds, pre[t]))
             }
-            if (k1 == g.mcu_h) LANES(K::colour(g, img, strip, g.mcu_h, t, lds))
+            if (16u * k1 - 1u < g.out_h) {
+                LANES(K::closing_tiles(t, lds))
+                LANES(K::colour(g, img, strip, k1, 16u * k0, true, t, lds))
+            }
         }
 #undef LANES
 }
@@ -56,15 +62,9 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         }
         im.out = out;
         if (tx_out) *tx_out = g.tx;
-        if (g.tx <= 20u) {
-            if (sane == 2) run_s420<ARITH_TIGHT, 128>(g, im);
-            else if (sane) run_s420<ARITH_SANE, 128>(g, im);
-            else run_s420<ARITH_EXACT, 128>(g, im);
-        } else {
-            if (sane == 2) run_s420<ARITH_TIGHT, 256>(g, im);
-            else if (sane) run_s420<ARITH_SANE, 256>(g, im);
-            else run_s420<ARITH_EXACT, 256>(g, im);
-        }
+        if (sane == 2) run_s420<ARITH_TIGHT, 256>(g, im);
+        else if (sane) run_s420<ARITH_SANE, 256>(g, im);
+        else run_s420<ARITH_EXACT, 256>(g, im);
         return kind;
     }
     if (tx_out) *tx_out = g.tx;

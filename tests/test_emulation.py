@@ -139,7 +139,7 @@ GEOMS = [
     (64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (2, 2, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (3, 5, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (16, 16, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (17, 33, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
-    (1025, 40, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1920, 24, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (1025, 40, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1920, 24, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1920, 72, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1920, 64, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (2050, 18, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (672, 65, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (673, 79, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (30, 160, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (36, 20, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (38, 10, [(2, 2), (1, 1), (1, 1)], "YCbCr"),  # last column in pixel 3 / 5 of a chunk
@@ -156,7 +156,7 @@ GEOMS = [
 
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
 @pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
-@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7"])
+@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7", "strip-tx7-seg1"])
 def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     if f420_tx != 64 and not (len(geom[2]) == 3 and geom[2][0] == (2, 2)):
         pytest.skip("variant knob only affects the 4:2:0 kernels")
@@ -164,7 +164,7 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     if isinstance(f420_tx, str):  # single-launch strip walk: (MCU rows per workgroup, widest strip)
         strip = 1
         seg_rows, s420_tx = {"strip": (1000, 0), "strip-seg1": (1, 0), "strip-seg3": (3, 0), "strip-tx20": (1000, 20),
-                             "strip-tx20-seg2": (2, 20), "strip-tx7": (5, 7)}[f420_tx]
+                             "strip-tx20-seg2": (2, 20), "strip-tx7": (5, 7), "strip-tx7-seg1": (1, 7)}[f420_tx]
         f420_tx = 64
     w_, h_, samp, ct = geom
     rng = np.random.default_rng(w_ * 131 + h_)

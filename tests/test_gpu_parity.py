@@ -374,7 +374,7 @@ STRIP_GEOMETRY = [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (673, 79),
                          ids=["default", "seg1", "seg3-tx20", "tx7"])
 @pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
 def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
-    """The opt-in single-launch 4:2:0 kernel (JPGPU_420_STRIP=1): strip / segment seams, carry rows, image edges."""
+    """The single-launch 4:2:0 kernel (the default since round 2): strip / segment seams, carry rows, image edges."""
     monkeypatch.setenv("JPGPU_420_STRIP", "1")
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
@@ -382,10 +382,24 @@ def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
     rng = np.random.default_rng(w_ * 77 + h_)
     cases = [_batch_case(rng, w_, h_, [(2, 2), (1, 1), (1, 1)], "YCbCr", kind=kind) for _ in range(3)]
     outs, path = _run_batch(cases)
-    assert path == "fused420s"
+    assert path == "fused420"
     for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
         want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("size", STRIP_GEOMETRY, ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
+def test_batch_420_two_pass_variant_bit_exact(size, kind, monkeypatch):
+    """Round 1's 4:2:0 form (chroma pass + main pass), kept behind JPGPU_420_STRIP=0 as the A/B partner."""
+    monkeypatch.setenv("JPGPU_420_STRIP", "0")
+    w_, h_ = size
+    rng = np.random.default_rng(w_ * 79 + h_)
+    cases = [_batch_case(rng, w_, h_, [(2, 2), (1, 1), (1, 1)], "YCbCr", kind=kind) for _ in range(3)]
+    outs, path = _run_batch(cases)
+    assert path == "fused420-2pass"
+    for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
+        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
 
 
 MIXED_SIZES = {
