@@ -215,6 +215,11 @@ int jpgpu_batch_download(jpgpu_batch *b, uint32_t image, uint8_t *dst, size_t ca
 int jpgpu_batch_time(jpgpu_batch *b, void *hip_stream, uint32_t iters, float *ms_per_decode);
 /* Name of the kernel path the batch resolved to ("fused420", "generic", ...). */
 const char *jpgpu_batch_path(const jpgpu_batch *b);
+/* How many images of the batch's fused launch groups run in each arithmetic variant (counts[0]: wrap-exact, counts[1]:
+ * range class 1, counts[2]: range class 3) with the range classes as they stand: images of different classes get
+ * separate launches, so an image with hostile coefficients costs only itself. Images on the generic path are not
+ * counted (they carry their class per component). */
+int jpgpu_batch_class_counts(jpgpu_batch *b, uint32_t counts[3]);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,7 @@ _PROTOS = {
     "jpgpu_batch_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "jpgpu_batch_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     "jpgpu_batch_path": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_batch_class_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     # include/jpgpu_decoder.h
     "jpgpu_decoder_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "jpgpu_decoder_destroy": (None, [C.c_void_p]),

@@ -111,6 +111,12 @@ class Batch:
         self._check(N.lib().jpgpu_batch_scan_ranges(self._h, stream, out.ctypes.data))
         return out
 
+    def class_counts(self):
+        """Images of the fused launch groups per arithmetic variant: (wrap-exact, range class 1, range class 3)."""
+        c = (C.c_uint32 * 3)()
+        self._check(N.lib().jpgpu_batch_class_counts(self._h, c))
+        return tuple(int(x) for x in c)
+
     def decode(self, stream=None):
         self._check(N.lib().jpgpu_batch_decode(self._h, stream))
 

@@ -68,6 +68,10 @@ struct jpgpu_batch {
     uint32_t *h_entropy_out = nullptr;  // pinned read-back: status per listed image, then 2 range stats per (image, comp)
     size_t entropy_out_cap = 0;
     hipEvent_t entropy_uploaded = nullptr;
+    uint8_t *d_scan = nullptr;     // jpgpu_batch_scan_ranges: stats + job table on the device, kept between calls
+    uint32_t *h_scan = nullptr;    // pinned read-back of the stats
+    size_t scan_cap = 0;
+    bool scan_jobs_valid = false;  // the job table on the device matches the bound arena and the current q-tables
     uint8_t *h_bounce = nullptr;  // pinned: jpgpu_batch_download into pageable memory
     struct DeltaScratch {          // jpgpu_batch_add_deltas: device copy of the entries, one per stream in use
         hipStream_t stream;
@@ -263,6 +267,8 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->h_entropy_out) hipHostFree(b->h_entropy_out);
         if (b->entropy_uploaded) hipEventDestroy(b->entropy_uploaded);
         if (b->h_bounce) hipHostFree(b->h_bounce);
+        if (b->d_scan) hipFree(b->d_scan);
+        if (b->h_scan) hipHostFree(b->h_scan);
         for (auto &x : b->delta_scratch)
             if (x.d) hipFree(x.d);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
@@ -276,6 +282,17 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
 
 const char *jpgpu_batch_last_error(const jpgpu_batch *b) { return b ? b->err.c_str() : ""; }
 const char *jpgpu_batch_path(const jpgpu_batch *b) { return b ? b->path.c_str() : ""; }
+int jpgpu_batch_class_counts(jpgpu_batch *b, uint32_t counts[3]) {
+    if (!b || !counts) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    rc = batch_refresh_jobs(b);
+    if (rc) return rc;
+    counts[0] = counts[1] = counts[2] = 0;
+    for (const FusedPlan &fp : b->fused)
+        for (int c = 0; c < 3; c++) counts[c] += fp.class_images[c];
+    return JPGPU_OK;
+}
 size_t jpgpu_batch_coef_arena_bytes(const jpgpu_batch *b) { return b ? b->coef_bytes : 0; }
 size_t jpgpu_batch_out_arena_bytes(const jpgpu_batch *b) { return b ? b->out_bytes : 0; }
 size_t jpgpu_batch_coef_offset(const jpgpu_batch *b, uint32_t image, uint32_t comp) {
@@ -301,6 +318,7 @@ int jpgpu_batch_bind(jpgpu_batch *b, void *device_coef_arena, void *device_out_a
     b->d_coef = (uint8_t *)device_coef_arena;
     b->d_out = (uint8_t *)device_out_arena;
     b->jobs_dirty = true;
+    b->scan_jobs_valid = false;
     return JPGPU_OK;
 }
 
@@ -386,30 +404,40 @@ int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) 
     if (rc) return rc;
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
     hipStream_t s = (hipStream_t)hip_stream;
-    std::vector<RangeJob> jobs;
-    uint32_t max_blocks = 0;
+    // stats and job table live on the device between calls (a call per decode must not allocate: bench.py times it)
+    const size_t n_jobs_max = b->descs.size() * 4;
+    const size_t stats_bytes = b->descs.size() * 4 * 2 * sizeof(uint32_t), jobs_off = align_up(stats_bytes, 256);
+    if (!b->d_scan) {
+        B_HIP(hipMalloc((void **)&b->d_scan, jobs_off + n_jobs_max * sizeof(RangeJob)));
+        B_HIP(hipHostMalloc((void **)&b->h_scan, stats_bytes, hipHostMallocDefault));
+        b->scan_jobs_valid = false;
+    }
+    uint32_t max_blocks = 0, n_jobs = 0;
     for (size_t i = 0; i < b->descs.size(); i++)
         for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
-            RangeJob r;
-            r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
-            r.n_blocks = (uint32_t)(b->coef_len[i * 4 + c] / 128);
-            r.slot = (uint32_t)(i * 4 + c);
-            memcpy(r.q, b->descs[i].quantization_tables[c], 128);
-            max_blocks = std::max(max_blocks, r.n_blocks);
-            jobs.push_back(r);
+            max_blocks = std::max(max_blocks, (uint32_t)(b->coef_len[i * 4 + c] / 128));
+            n_jobs++;
         }
-    const size_t stats_bytes = b->descs.size() * 4 * 2 * sizeof(uint32_t), jobs_bytes = jobs.size() * sizeof(RangeJob);
-    uint8_t *d = nullptr;
-    B_HIP(hipMalloc((void **)&d, align_up(stats_bytes, 256) + jobs_bytes));
-    std::vector<uint32_t> stats(b->descs.size() * 8, 0);
-    hipError_t e = hipMemsetAsync(d, 0, stats_bytes, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d + align_up(stats_bytes, 256), jobs.data(), jobs_bytes, hipMemcpyHostToDevice, s);
+    if (!b->scan_jobs_valid) {
+        std::vector<RangeJob> jobs;
+        for (size_t i = 0; i < b->descs.size(); i++)
+            for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
+                RangeJob r;
+                r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
+                r.n_blocks = (uint32_t)(b->coef_len[i * 4 + c] / 128);
+                r.slot = (uint32_t)(i * 4 + c);
+                memcpy(r.q, b->descs[i].quantization_tables[c], 128);
+                jobs.push_back(r);
+            }
+        B_HIP(hipMemcpy(b->d_scan + jobs_off, jobs.data(), jobs.size() * sizeof(RangeJob), hipMemcpyHostToDevice));
+        b->scan_jobs_valid = true;
+    }
+    uint32_t *stats = b->h_scan;
+    hipError_t e = hipMemsetAsync(b->d_scan, 0, stats_bytes, s);
     if (e == hipSuccess)
-        e = launch_range_scan(reinterpret_cast<const RangeJob *>(d + align_up(stats_bytes, 256)), (uint32_t)jobs.size(), max_blocks,
-                              reinterpret_cast<uint32_t *>(d), s);
-    if (e == hipSuccess) e = hipMemcpyAsync(stats.data(), d, stats_bytes, hipMemcpyDeviceToHost, s);
+        e = launch_range_scan(reinterpret_cast<const RangeJob *>(b->d_scan + jobs_off), n_jobs, max_blocks, reinterpret_cast<uint32_t *>(b->d_scan), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, b->d_scan, stats_bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
     if (e != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "scan_ranges: %s", hipGetErrorString(e));
     for (size_t i = 0; i < b->descs.size(); i++)
         for (uint32_t c = 0; c < 4; c++) {
@@ -430,6 +458,7 @@ int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) 
 int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t q[64]) {
     if (!b || !q || image >= b->descs.size() || comp >= b->descs[image].ncomp) return JPGPU_ERR_FORMAT;
     memcpy(b->descs[image].quantization_tables[comp], q, 128);
+    b->scan_jobs_valid = false;
     b->qt_dirty = true;
     b->jobs_dirty = true;
     return JPGPU_OK;

@@ -95,7 +95,7 @@ struct CompactWriter {
                 for (uint64_t m = bm; m; m &= m - 1) values[n_values++] = p[__builtin_ctzll(m)];
                 continue;
             }
-            int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int64_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (64-bit: eight products of up to 2^31 each)
             for (uint64_t m = bm; m; m &= m - 1) {
                 const int k = __builtin_ctzll(m);
                 values[n_values++] = p[k];
@@ -104,7 +104,7 @@ struct CompactWriter {
                 max_abs = v > max_abs ? v : max_abs;
                 col[k & 7] += v;
             }
-            for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? col[i] : max_col;
+            for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? (int32_t)(col[i] > 0x7fffffff ? 0x7fffffff : col[i]) : max_col;
         }
     }
     size_t finish(int *range_class) {

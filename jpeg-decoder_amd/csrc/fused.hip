@@ -287,7 +287,10 @@ int fused_alloc(FusedPlan &plan, std::string &err) {
 int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt, const std::vector<size_t> &coef_off,
                const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
-    uint32_t common = 3u;  // AND of the per-image flags: one hostile image sends the whole batch down the wrap-exact kernels
+    std::vector<uint8_t> cls(plan.n_images, 0);
+    int cap = (int)ARITH_TIGHT;
+    if (const char *ae = getenv("JPGPU_ARITH")) cap = std::min(cap, atoi(ae));  // tuning/testing knob: cap the variant
+    plan.class_images[0] = plan.class_images[1] = plan.class_images[2] = 0;
     for (uint32_t i = 0; i < plan.n_images; i++) {
         FusedImage &im = plan.images[i];
         uint32_t fl = 3u;
@@ -301,12 +304,38 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
         im.scratch = plan.d_scratch ? plan.d_scratch + plan.scratch_off[i] : nullptr;
         if (!(fl & 1u)) fl = 0u;  // tight implies sane
         im.flags = fl;
-        common &= fl;
+        cls[i] = (uint8_t)std::min(cap, (fl & 2u) ? (int)ARITH_TIGHT : ((fl & 1u) ? (int)ARITH_SANE : (int)ARITH_EXACT));
+        plan.class_images[cls[i]]++;
     }
-    plan.arith = (common & 2u) ? ARITH_TIGHT : ((common & 1u) ? ARITH_SANE : ARITH_EXACT);
-    if (const char *ae = getenv("JPGPU_ARITH")) plan.arith = std::min(plan.arith, atoi(ae));  // tuning/testing knob: cap the variant
+    const int present = (plan.class_images[0] != 0) + (plan.class_images[1] != 0) + (plan.class_images[2] != 0);
+    plan.arith = plan.class_images[2] ? ARITH_TIGHT : (plan.class_images[1] ? ARITH_SANE : ARITH_EXACT);
+    plan.by_class = present > 1;
     hipError_t e = hipMemcpy(plan.d_images, plan.images.data(), sizeof(FusedImage) * plan.n_images, hipMemcpyHostToDevice);
     if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMemcpy(images): %s", hipGetErrorString(e));
+    if (plan.by_class) {
+        // the plan's work tables, split by the class of the image each entry belongs to
+        std::vector<FusedWork> all;
+        for (int c = 0; c < 3; c++) {
+            plan.n_main_cls[c] = 0;
+            for (const FusedWork &w : plan.work_main)
+                if (cls[w.image] == c) all.push_back(w), plan.n_main_cls[c]++;
+        }
+        for (int c = 0; c < 3; c++) {
+            plan.n_pre_cls[c] = 0;
+            for (const FusedWork &w : plan.work_pre)
+                if (cls[w.image] == c) all.push_back(w), plan.n_pre_cls[c]++;
+        }
+        if (all.size() > plan.work_cls_cap) {
+            if (plan.d_work_cls) (void)hipFree(plan.d_work_cls);
+            plan.d_work_cls = nullptr;
+            plan.work_cls_cap = 0;
+            e = hipMalloc((void **)&plan.d_work_cls, sizeof(FusedWork) * all.size());
+            if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMalloc(class work tables): %s", hipGetErrorString(e));
+            plan.work_cls_cap = all.size();
+        }
+        e = hipMemcpy(plan.d_work_cls, all.data(), sizeof(FusedWork) * all.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMemcpy(class work tables): %s", hipGetErrorString(e));
+    }
     return JPGPU_OK;
 }
 
@@ -314,16 +343,14 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
 // chunk's chroma planes stay in the 256 MiB Infinity Cache, and alternating chunks between two streams so that the
 // HBM-bound chroma pass overlaps the VALU-bound main pass, were both measured on MI355X and did not pay: chunks of
 // 16/32/64/128 images were 23/9/4/1 % slower, two streams 3 % slower — profiles/round1.)
-hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
+static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, const FusedWork *W, uint32_t n_main, const FusedWork *Wpre,
+                                   uint32_t n_pre) {
     const FusedGeom *G = plan.d_geoms;
     const FusedImage *I = plan.d_images;
     const FusedGeom &g0 = plan.geoms[0];
-    const FusedWork *W = plan.uniform ? nullptr : plan.d_work_main;
-    const dim3 grid = plan.uniform ? dim3(g0.tiles_x, plan.strip ? g0.n_seg : g0.mcu_h, plan.n_images)
-                                   : dim3((uint32_t)plan.work_main.size());
+    const dim3 grid = W ? dim3(n_main) : dim3(g0.tiles_x, plan.strip ? g0.n_seg : g0.mcu_h, plan.n_images);
     const dim3 block(plan.nt);
     const size_t shm = plan.lds_bytes;
-    const int ar = plan.arith;
 #define ARITH_SWITCH(KERNEL, ...)                                                                      \
     do {                                                                                               \
         if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);  \
@@ -336,10 +363,10 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
             ARITH_SWITCH(s420_kernel, 256);
             break;
         }
-        if (plan.uniform)  // (component, 256-block group, image)
+        if (!Wpre)  // (component, 256-block group, image)
             f420_chroma_kernel<<<dim3(2, (g0.bwc * g0.mcu_h + 255u) / 256u, plan.n_images), dim3(256), 0, stream>>>(G, I, nullptr);
         else
-            f420_chroma_kernel<<<dim3((uint32_t)plan.work_pre.size()), dim3(256), 0, stream>>>(G, I, plan.d_work_pre);
+            f420_chroma_kernel<<<dim3(n_pre), dim3(256), 0, stream>>>(G, I, Wpre);
         if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, 128);
         else ARITH_SWITCH(f420_main_kernel, 256);
         break;
@@ -352,12 +379,37 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// One batch = the chroma pass (two-pass 4:2:0 only) and the main launch — per arithmetic class when the images disagree.
+// (Walking the batch in chunks so that a chunk's chroma planes stay in the 256 MiB Infinity Cache, and alternating chunks
+// between two streams so that the HBM-bound chroma pass overlaps the VALU-bound main pass, were both measured on MI355X and
+// did not pay: chunks of 16/32/64/128 images were 23/9/4/1 % slower, two streams 3 % slower — profiles/round1.)
+hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
+    if (!plan.by_class) {
+        const bool table = !plan.uniform;
+        return fused_launch_one(plan, stream, plan.arith, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
+                                table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
+    }
+    const FusedWork *w = plan.d_work_cls, *wp = plan.d_work_cls + plan.n_main_cls[0] + plan.n_main_cls[1] + plan.n_main_cls[2];
+    for (int c = 0; c < 3; c++) {
+        if (plan.n_main_cls[c]) {
+            hipError_t e = fused_launch_one(plan, stream, c, w, plan.n_main_cls[c], plan.n_pre_cls[c] ? wp : nullptr, plan.n_pre_cls[c]);
+            if (e != hipSuccess) return e;
+        }
+        w += plan.n_main_cls[c];
+        wp += plan.n_pre_cls[c];
+    }
+    return hipSuccess;
+}
+
 void fused_free(FusedPlan &plan) {
     if (plan.d_scratch) (void)hipFree(plan.d_scratch);
     if (plan.d_images) (void)hipFree(plan.d_images);
     if (plan.d_geoms) (void)hipFree(plan.d_geoms);
     if (plan.d_work_main) (void)hipFree(plan.d_work_main);
     if (plan.d_work_pre) (void)hipFree(plan.d_work_pre);
+    if (plan.d_work_cls) (void)hipFree(plan.d_work_cls);
+    plan.d_work_cls = nullptr;
+    plan.work_cls_cap = 0;
     plan.d_scratch = nullptr;
     plan.d_images = nullptr;
     plan.d_geoms = nullptr;

@@ -29,7 +29,14 @@ struct FusedPlan {
     FusedGeom *d_geoms = nullptr;
     FusedWork *d_work_main = nullptr, *d_work_pre = nullptr;
     std::vector<FusedImage> images;
-    int arith = 0;  // ARITH_* variant every image of the batch qualifies for
+    int arith = 0;  // ARITH_* variant every image of the plan qualifies for (when they all agree)
+    // Images of different arithmetic classes in one plan: one launch per class present, each over its own work table
+    // (an image that needs the wrap-exact kernels costs only itself).  Built by fused_bind.
+    bool by_class = false;
+    uint32_t class_images[3] = {0, 0, 0};      // images per ARITH_* class (statistics: jpgpu_batch_class_counts)
+    FusedWork *d_work_cls = nullptr;           // main tables of the three classes, back to back, then the chroma-pass tables
+    size_t work_cls_cap = 0;
+    uint32_t n_main_cls[3] = {0, 0, 0}, n_pre_cls[3] = {0, 0, 0};
 };
 
 // descs: the images of ONE kind (fused_kind_key); ids: their indices in the batch (for fused_bind's offset tables)

@@ -986,9 +986,16 @@ struct Frontend::Impl {
         {
             std::vector<uint32_t> se;
             se.reserve(2u * n_seg);
+            uint64_t bpm = 0;  // blocks per MCU
+            for (int i = 0; i < nc; i++) bpm += interleaved ? (uint64_t)comps[i].horizontal_sampling_factor * comps[i].vertical_sampling_factor : 1u;
             for (uint32_t s = 0; s < n_seg; s++) {
-                se.push_back(s == 0 ? 0u : seg_start_after[s - 1]);
-                se.push_back(ps.seg_off[s + 1]);
+                const uint32_t first = s == 0 ? 0u : seg_start_after[s - 1], last = ps.seg_off[s + 1];
+                // as for scans without restart markers: a block costs at least two bits, and a segment that cannot hold its
+                // MCUs would send a lane of the segment decoder through the padding behind it
+                const uint64_t mcus = std::min<uint64_t>(ps.ri, (uint64_t)ps.n_mcu - (uint64_t)s * ps.ri);
+                if (last < first || (uint64_t)(last - first) * 8u < mcus * bpm * 2u) throw NotEligible{15};
+                se.push_back(first);
+                se.push_back(last);
             }
             ps.seg_off.swap(se);
             seg_start_after.clear();

@@ -190,7 +190,11 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
     bool own = k == 0u;
     JP_LDS uint16_t *mine = ASSEMBLE ? W->blk[threadIdx_x_of_lane()] : nullptr;
     for (;;) {
-        const bool active = participate && !bad && (!BY_BITS || huff_bit_pos(b) < limit) && !(WRITE && blkno >= end_blk);
+        // !BY_BITS (restart segments): `limit`, if not 0, is a hard stop a little beyond the segment's data — a segment far
+        // shorter than its MCUs need would otherwise be decoded on through the zero padding into the neighbouring slots and past
+        // the staging block; the caller flags such a segment (bits taken from beyond its end) for the host.
+        const bool active = participate && !bad && (BY_BITS ? huff_bit_pos(b) < limit : (limit == 0u || huff_bit_pos(b) <= limit)) &&
+                            !(WRITE && blkno >= end_blk);
         if (ASSEMBLE ? !huff_wave_any(active) : !active) break;  // (ASSEMBLE: the wave stays together for the cooperative stores)
         bool flush = false;
         uint64_t flush_addr = 0;
@@ -410,7 +414,7 @@ __device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint3
     const uint32_t m0 = seg * job.ri, m1 = min(m0 + job.ri, job.n_mcu);
     uint32_t q = 0, k = 0, nblk = 0, blkno = m0 * job.bpm;
     bool bad = false;
-    const uint32_t pos = huff_run<true, false>(L, data, 0u, 0u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, nullptr, true, ring, ring_stride);
+    const uint32_t pos = huff_run<true, false>(L, data, 0u, seg_bits + 64u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, nullptr, true, ring, ring_stride);
     // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it tops up its 64-bit buffer —
     // bytes are appended while it holds at most 56 bits (src/huffman.rs:123-160) — and must MEET the marker doing so, which
     // happens iff the unread rest of the segment is at most 56 bits ("no marker found where RSTn was expected" otherwise);

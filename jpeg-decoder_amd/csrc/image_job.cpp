@@ -166,14 +166,14 @@ int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t q[
     const size_t nblk = len / 64;
     for (size_t blk = 0; blk < nblk; blk++) {
         const int16_t *p = coefficients + blk * 64;
-        int32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (eight products of up to 2^31 each: 64-bit sums)
         for (int k = 0; k < 64; k++) {
-            int32_t v = (int32_t)p[k] * qq[k];
+            int32_t v = (int32_t)p[k] * qq[k];  // |i16 x u16| <= 2^31 - 2^15: fits
             v = v < 0 ? -v : v;
             max_abs = v > max_abs ? v : max_abs;
             col[k & 7] += v;
         }
-        for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? col[i] : max_col;
+        for (int i = 0; i < 8; i++) max_col = col[i] > max_col ? (int32_t)std::min<int64_t>(col[i], INT32_MAX) : max_col;
     }
     if (max_abs < (1 << 15)) return (max_col <= 5900) ? 3 : 1;
     return 0;

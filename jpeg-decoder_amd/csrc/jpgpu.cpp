@@ -122,6 +122,11 @@ static int worker_send_rows(jpgpu_worker *w, uint32_t index) {
     W_HIP(hipMemcpyAsync(s.d_coefs + s.sent_rows * per_row, s.h_pinned + s.sent_rows * per_row, (s.rows - s.sent_rows) * per_row * sizeof(int16_t),
                          hipMemcpyHostToDevice, w->stream));
     s.sent_rows = s.rows;
+    // every copy out of the pinned staging memory leaves its mark: a scan that is abandoned half-way never reaches
+    // finish_plane, and the next start() of the slot must not overwrite (or free) memory a copy is still reading
+    if (!s.uploaded) W_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    W_HIP(hipEventRecord(s.uploaded, w->stream));
+    s.upload_pending = true;
     return JPGPU_OK;
 }
 

@@ -66,12 +66,16 @@ public:
     uint32_t size() const { return (uint32_t)workers_.size(); }
     void run(uint32_t n, const std::function<void(uint32_t)> &fn) {
         if (n == 0) return;
+        std::lock_guard<std::mutex> one_at_a_time(run_m_);
         std::unique_lock<std::mutex> g(m_);
         fn_ = &fn;
         n_ = n;
-        next_.store(0);
         pending_ = n;
         generation_++;
+        // the claim counter carries the generation it belongs to: a worker that read (fn, n) of an earlier run and only
+        // now gets to claim an index finds another generation in the counter and backs off — it can neither take an item of
+        // this run with the old n nor call the old, by now destroyed, function (use-after-free + a lost item)
+        next_.store((uint64_t)(uint32_t)generation_ << 32);
         cv_work_.notify_all();
         cv_done_.wait(g, [this] { return pending_ == 0; });
         fn_ = nullptr;
@@ -91,12 +95,17 @@ private:
                 fn = fn_;
                 n = n_;
             }
+            if (!fn) continue;  // that run is over already
             uint32_t done = 0;
+            uint64_t cur = next_.load();
             for (;;) {
-                const uint32_t i = next_.fetch_add(1);
+                if ((uint32_t)(cur >> 32) != (uint32_t)seen) break;  // a later run owns the counter
+                const uint32_t i = (uint32_t)cur;
                 if (i >= n) break;
+                if (!next_.compare_exchange_weak(cur, cur + 1)) continue;  // (cur reloaded)
                 (*fn)(i);
                 done++;
+                cur = next_.load();
             }
             if (done) {
                 std::lock_guard<std::mutex> g(m_);
@@ -106,11 +115,11 @@ private:
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex m_;
+    std::mutex m_, run_m_;
     std::condition_variable cv_work_, cv_done_;
     const std::function<void(uint32_t)> *fn_ = nullptr;
     uint32_t n_ = 0, pending_ = 0;
-    std::atomic<uint32_t> next_{0};
+    std::atomic<uint64_t> next_{0};
     uint64_t generation_ = 0;
     bool stop_ = false;
 };

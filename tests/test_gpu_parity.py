@@ -601,3 +601,36 @@ def test_batch_scan_ranges_on_device_equals_host_classification():
     for i, (oc, qts, coefs, ct_, w_, h_) in enumerate(cases):
         assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
     b.close()
+
+
+@pytest.mark.parametrize("strip", ["1", "0"], ids=["single-launch", "two-pass"])
+@pytest.mark.parametrize("samp,ct", [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1), (1, 1), (1, 1)], "YCbCr"), ([(2, 1), (1, 1), (1, 1)], "YCbCr"),
+                                     ([(1, 1)], "Grayscale")], ids=["420", "444", "422", "gray"])
+def test_one_hostile_image_costs_only_itself(samp, ct, strip, monkeypatch):
+    """A launch group whose images disagree on the arithmetic class is split per class: one image with
+    wrap-range coefficients and one of class 1 among 64 leave the other 62 on the class-3 kernels, and every image —
+    whichever kernel took it — equals the oracle."""
+    monkeypatch.setenv("JPGPU_420_STRIP", strip)
+    rng = np.random.default_rng(len(samp) * 1000 + samp[0][0] * 10 + samp[0][1])
+    w_, h_ = 200, 120
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind="tight") for _ in range(64)]
+    cases[17] = _batch_case(rng, w_, h_, samp, ct, kind="full")
+    cases[40] = _batch_case(rng, w_, h_, samp, ct, kind="sane")
+    descs = [J.image_desc(list(to_j(oc)), qts, w, h, ct_) for oc, qts, _c, ct_, w, h in cases]
+    b = J.Batch(descs)
+    try:
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            for c in range(len(coefs)):
+                b.upload(i, c, coefs[c])
+        exact, sane, tight = b.class_counts()
+        assert exact == 1 and tight >= 62 and exact + sane + tight == 64, (exact, sane, tight)
+        b.decode()
+        b.synchronize()
+        assert b.path.startswith("fused")
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
+        # the device-side scan arrives at the same split
+        b.scan_ranges()
+        assert b.class_counts() == (exact, sane, tight)
+    finally:
+        b.close()
