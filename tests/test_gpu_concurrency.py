@@ -1,0 +1,74 @@
+"""Many decodes on many threads: the reference pins that with tests/rayon-2.rs:14-20 (1024 threads, each decoding the same
+image on the global rayon pool).  Here: 64 Python threads x Decoder(data).decode() (ctypes releases the GIL inside the
+library: the worker / pipeline pools behind their mutexes in csrc/host/decoder_api.cpp are really entered concurrently),
+next to 4 Pipelines decoding batches on the same device, every result byte-exact against the oracle."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as O
+import refimages as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _images():
+    names = [os.path.join(R.REFTEST, "mozilla", "jpg-size-33x33.jpg"), os.path.join(R.REFTEST, "mjpeg.jpg"),
+             os.path.join(R.REFTEST, "progressive3.jpg"), os.path.join(R.REFTEST, "rgb.jpg"),
+             os.path.join(R.GOLDEN, "benches", "tower.jpg"), os.path.join(R.GOLDEN, "benches", "tower_grayscale.jpg"),
+             os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), os.path.join(R.REFTEST, "mozilla", "jpg-cmyk-2.jpg")]
+    out = []
+    for n in names:
+        data = open(n, "rb").read()
+        out.append((os.path.basename(n), data, O.decode(data).pixels))
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_64_decoder_threads_and_4_pipelines_on_one_device():
+    import jpeg_decoder_amd as J
+    assert J.device_count() >= 1
+    imgs = _images()
+    # a big sequential image as well: it takes the one-image pipeline route inside Decoder.decode (pooled pipelines)
+    big = open(os.path.join(R.GOLDEN, "benches", "large_image.jpg"), "rb").read()
+    imgs.append(("large_image.jpg", big, O.decode(big).pixels))
+    errors, lock = [], threading.Lock()
+    start = threading.Barrier(64 + 4)
+
+    def decoder_thread(t):
+        try:
+            start.wait()
+            for rep in range(6):
+                name, data, want = imgs[(t + rep) % len(imgs)]
+                got = J.Decoder(data).decode()
+                if not np.array_equal(got, want):
+                    raise AssertionError(f"thread {t} rep {rep}: {name} differs from the oracle")
+        except Exception as e:  # noqa: BLE001 - collected and re-raised in the main thread
+            with lock:
+                errors.append(repr(e))
+
+    def pipeline_thread(t):
+        try:
+            p = J.Pipeline(threads=4)
+            start.wait()
+            for rep in range(3):
+                batch = [imgs[(t + rep + k) % len(imgs)] for k in range(12)]
+                outs = p.decode([b[1] for b in batch], device_entropy=(t % 2 == 0))
+                for (name, _d, want), got in zip(batch, outs):
+                    if isinstance(got, Exception) or not np.array_equal(got, want):
+                        raise AssertionError(f"pipeline {t} rep {rep}: {name}: {got!r}")
+            p.close()
+        except Exception as e:  # noqa: BLE001
+            with lock:
+                errors.append(repr(e))
+
+    threads = [threading.Thread(target=decoder_thread, args=(t,)) for t in range(64)] + \
+              [threading.Thread(target=pipeline_thread, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(500)
+        assert not th.is_alive(), "a decoding thread hung"
+    assert not errors, errors[:5]
