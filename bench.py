@@ -46,6 +46,7 @@ WORKLOADS = {
     "1080p-422": (1920, 1080, [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-440": (1920, 1080, [(1, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
+    "1080p-cmyk": (1920, 1080, [(1, 1)] * 4, "cmyk", "CMYK", 192),
     # 4:4:4 and grayscale images interleaved in one batch (two fused launch groups, path "mixed")
     "1080p-444+gray": (1920, 1080, None, "mixed", None, 512),
 }
@@ -263,7 +264,7 @@ def build_variants(J, synth, w, h, sampling, mode, ct):
     variants = []
     for v_sampling, v_mode, v_ct in specs:
         comps, _mcu = J.make_components(w, h, v_sampling)
-        qts = [lum, chr_, chr_][: len(v_sampling)]
+        qts = [lum] * 4 if v_mode == "cmyk" else [lum, chr_, chr_][: len(v_sampling)]
         coefs = synth.coefficients_from_rgb(rgb, comps, v_mode, qts)
         # range class of the dequantized coefficients (what jpgpu_batch_upload computes when it stages data itself)
         prod = [np.abs(c.astype(np.int64).reshape(-1, 8, 8) * q.astype(np.int64).reshape(8, 8)) for c, q in zip(coefs, qts)]

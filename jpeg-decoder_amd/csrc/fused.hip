@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__
     FusedRegs r;
     F444<ARITH>::phase0(g, img, w.a, w.b, threadIdx.x, lds);
     __syncthreads();
-    const uint32_t wcomp = min((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), 2u);
+    const uint32_t wcomp = min((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), F444<ARITH>::ncomp(g) - 1u);
     F444<ARITH>::phase1(g, imgs[w.image].qt[wcomp], w.a, threadIdx.x, lds, r);
     __syncthreads();
     F444<ARITH>::phase2(g, w.a, threadIdx.x, lds, r);
@@ -183,7 +183,7 @@ uint32_t fused_kind_key(const jpgpu_image_desc &d) {
     FusedGeom g;
     const char *nm = "", *w = "";
     const int kind = fused_geom_from_desc(d, g, nm, w);
-    return kind == FUSED_NONE ? 0u : (uint32_t)kind * 4u + g.color;
+    return kind == FUSED_NONE ? 0u : (uint32_t)kind * 8u + g.color;
 }
 
 bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<uint32_t> &ids, FusedPlan &plan, std::string &why) {

@@ -30,7 +30,7 @@ constexpr uint32_t F422_TX_MAX = 62;     // 2 luma waves (124 blocks), one wave 
 constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
 
-enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1 };
+enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1, FCOLOR_CMYK = 2, FCOLOR_YCCK = 3 };  // the last two: four components
 enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4 };
 
 struct FusedGeom {
@@ -929,15 +929,16 @@ struct F422 {
 };
 
 // =============================================================================================
-// FUSED_444: MCU = one 8x8 block per component.  Wave c (0..2) transforms component c (so the
-// quantization table stays wave-uniform in SGPRs), lane = block; wave 3 only helps staging and
-// the pixel phase.
+// FUSED_444: MCU = one 8x8 block per component; three components (YCbCr / RGB -> RGB24) or four (CMYK / YCCK -> 32-bit
+// pixels, src/decoder.rs:1439-1474).  Wave c transforms component c (so the quantization table stays wave-uniform in
+// SGPRs), lane = block; with three components wave 3 only helps staging and the pixel phase.
 // =============================================================================================
 template <int ARITH>
 struct F444 {
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.mcu_w - tile_x * g.tx);
     }
+    static __device__ __forceinline__ uint32_t ncomp(const FusedGeom &g) { return g.color >= FCOLOR_CMYK ? 4u : 3u; }
     // LDS block index of (component, block) = comp*64 + cx
     static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, FusedLdsSmall &lds) {
@@ -947,13 +948,16 @@ struct F444 {
         const JP_GLOBAL v4u *c1 = (const JP_GLOBAL v4u *)img.coefs[1] + base;
         const JP_GLOBAL v4u *c2 = (const JP_GLOBAL v4u *)img.coefs[2] + base;
         const uint32_t te8 = te * 8u;  // <= 512 chunks per component: two loads each
-        v4u v0[2], v1[2], v2[2];
+        v4u v0[2], v1[2], v2[2], v3[2];
         load_run<FUSED_NT, 2>(v0, c0, te8, tid);
         load_run<FUSED_NT, 2>(v1, c1, te8, tid);
         load_run<FUSED_NT, 2>(v2, c2, te8, tid);
+        const bool four = ncomp(g) == 4u;  // (uniform)
+        if (four) load_run<FUSED_NT, 2>(v3, (const JP_GLOBAL v4u *)img.coefs[3] + base, te8, tid);
         store_run<FUSED_NT, 2>(lds.coef, v0, te8, 0u, tid);  // LDS block of (component, block) = comp*64 + cx
         store_run<FUSED_NT, 2>(lds.coef, v1, te8, 64u, tid);
         store_run<FUSED_NT, 2>(lds.coef, v2, te8, 128u, tid);
+        if (four) store_run<FUSED_NT, 2>(lds.coef, v3, te8, 192u, tid);
     }
     // qt_of_wave: quantization table of component (tid >> 6), fetched by the caller from the image array in memory
     // (a runtime index — or a chain of selects, which the compiler turns into one — into the by-value image struct
@@ -962,17 +966,17 @@ struct F444 {
                                                   const FusedLdsSmall &lds, FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
         const uint32_t comp = uniform(tid >> 6), cx = tid & 63u;
-        if (comp >= 3u || cx >= te) return;
+        if (comp >= ncomp(g) || cx >= te) return;
         uint32_t cw[32];
         load_block_from_lds(lds.coef, comp * 64u + cx, cw);
         idct8x8<ARITH>(cw, as_qtab(qt_of_wave), r.out);
     }
-    // sample tiles: [3 comps][8 rows][pitch 8*tx]
+    // sample tiles: [ncomp][8 rows][pitch 8*tx]
     static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, FusedLdsSmall &lds,
                                                   const FusedRegs &r) {
         const uint32_t te = txe(g, tile_x);
         const uint32_t comp = tid >> 6, cx = tid & 63u;
-        if (comp >= 3u || cx >= te) return;
+        if (comp >= ncomp(g) || cx >= te) return;
         const uint32_t pitch = 8u * g.tx;
 #pragma unroll
         for (int row = 0; row < 8; row++)
@@ -989,6 +993,42 @@ struct F444 {
         const uint32_t ox0 = 8u * (x0m + chk);
         if (ox0 >= g.out_w) return;
         const uint32_t npx = min(8u, g.out_w - ox0);
+        if (ncomp(g) == 4u) {  // (uniform) 32-bit pixels: a lane's 8 pixels are 32 contiguous, 4-byte aligned bytes
+            for (uint32_t row = wave; row < 8u; row += 4u) {
+                const uint32_t oy = 8u * my + row;
+                if (oy >= g.out_h) continue;
+                v2u s[4];
+#pragma unroll
+                for (uint32_t comp = 0; comp < 4; comp++)
+                    s[comp] = *reinterpret_cast<const v2u *>(&lds.coef[(comp * 8u + row) * pitch + chk * 8u]);
+                uint32_t px[8];
+                if (g.color == FCOLOR_CMYK) {  // src/decoder.rs:1456-1474: 255 - x, four times
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t v = byte_of(k < 4 ? s[0].x : s[0].y, k & 3u) | (byte_of(k < 4 ? s[1].x : s[1].y, k & 3u) << 8) |
+                                           (byte_of(k < 4 ? s[2].x : s[2].y, k & 3u) << 16) | (byte_of(k < 4 ? s[3].x : s[3].y, k & 3u) << 24);
+                        px[k] = ~v;
+                    }
+                } else {  // YCCK, src/decoder.rs:1439-1454: YCbCr -> RGB on the first three, 255 - k
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t rgb = ycbcr_to_rgb24(byte_of(k < 4 ? s[0].x : s[0].y, k & 3u), byte_of(k < 4 ? s[1].x : s[1].y, k & 3u),
+                                                            byte_of(k < 4 ? s[2].x : s[2].y, k & 3u));
+                        px[k] = rgb | ((255u - byte_of(k < 4 ? s[3].x : s[3].y, k & 3u)) << 24);
+                    }
+                }
+                JP_GLOBAL uint8_t *o = out + ((size_t)oy * g.out_w + ox0) * 4u;
+                if (npx == 8u) {
+                    stream_store(reinterpret_cast<JP_GLOBAL v4u *>(o), v4u{px[0], px[1], px[2], px[3]});  // (an arena offset is 256-byte aligned, a pixel 4 bytes)
+                    stream_store(reinterpret_cast<JP_GLOBAL v4u *>(o + 16), v4u{px[4], px[5], px[6], px[7]});
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (k < npx) reinterpret_cast<JP_GLOBAL uint32_t *>(o)[k] = px[k];
+                }
+            }
+            return;
+        }
         for (uint32_t row = wave; row < 8u; row += 4u) {
             const uint32_t oy = 8u * my + row;
             if (oy >= g.out_h) continue;

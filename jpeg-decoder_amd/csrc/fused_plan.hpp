@@ -86,6 +86,21 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             return FUSED_NONE;
         }
         tx_max = F444_TX_MAX;
+    } else if (d0.ncomp == 4 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) && hv(3, 1, 1) &&
+               (d0.color_transform == JPGPU_CT_CMYK || d0.color_transform == JPGPU_CT_YCCK) &&
+               fused_same_component(d0.components[0], d0.components[1]) && fused_same_component(d0.components[1], d0.components[2]) &&
+               fused_same_component(d0.components[2], d0.components[3])) {
+        kind = FUSED_444;
+        name = "fused444x4";
+        g.mcu_w = d0.components[0].block_width;
+        g.mcu_h = d0.components[0].block_height;
+        g.bwc = d0.components[0].block_width;
+        g.color = d0.color_transform == JPGPU_CT_CMYK ? FCOLOR_CMYK : FCOLOR_YCCK;
+        if (d0.out_w > 8u * g.mcu_w || d0.out_h > 8u * g.mcu_h) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = F444_TX_MAX;
     } else if (d0.ncomp == 1 && hv(0, 1, 1)) {
         kind = FUSED_GRAY;
         name = "fusedgray";

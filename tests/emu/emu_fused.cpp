@@ -115,13 +115,13 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
                 if (sane == 2) { RUN422(ARITH_TIGHT) } else if (sane) { RUN422(ARITH_SANE) } else { RUN422(ARITH_EXACT) }
 #undef RUN422
             } else if (kind == FUSED_444 && sane == 2) {
-                RUN(256, F444<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_TIGHT>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_TIGHT>::phase1(g, img.qt[std::min(t >> 6, desc->ncomp - 1u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_TIGHT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_TIGHT>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444 && sane) {
-                RUN(256, F444<ARITH_SANE>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_SANE>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_SANE>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_SANE>::phase1(g, img.qt[std::min(t >> 6, desc->ncomp - 1u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_SANE>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_SANE>::phase3(g, img, tile, my, t, *lds_s))
             } else if (kind == FUSED_444) {
-                RUN(256, F444<ARITH_EXACT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_EXACT>::phase1(g, img.qt[std::min(t >> 6, 2u)], tile, t, *lds_s, regs[t]))
+                RUN(256, F444<ARITH_EXACT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F444<ARITH_EXACT>::phase1(g, img.qt[std::min(t >> 6, desc->ncomp - 1u)], tile, t, *lds_s, regs[t]))
                 RUN(256, F444<ARITH_EXACT>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F444<ARITH_EXACT>::phase3(g, img, tile, my, t, *lds_s))
             } else if (sane == 2) {
                 RUN(256, FGray<ARITH_TIGHT>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, FGray<ARITH_TIGHT>::phase1(g, img, tile, my, t, *lds_s))

@@ -47,11 +47,13 @@ def _fdct_quantize(plane, block_w, block_h, qt):
 def coefficients_from_rgb(rgb, comps, mode, qts):
     """Forward path of a baseline encoder (colour transform, box subsampling, FDCT, quantise)
     producing per-component coefficient planes in the Worker layout.
-    mode: 'ycbcr' (3 comps, subsampled per comps' sampling factors) or 'gray'."""
+    mode: 'ycbcr' (3 comps, subsampled per comps' sampling factors), 'gray', or 'cmyk' (4 full-resolution planes)."""
     r, g, b = [rgb[..., i].astype(np.float64) for i in range(3)]
     y = 0.299 * r + 0.587 * g + 0.114 * b
     if mode == "gray":
         return [_fdct_quantize(y - 128.0, comps[0].block_width, comps[0].block_height, qts[0])]
+    if mode == "cmyk":  # Adobe-style inverted CMYK planes (the decoder returns 255 - x): C, M, Y from the primaries, K from luma
+        return [_fdct_quantize(p - 128.0, c.block_width, c.block_height, q) for c, p, q in zip(comps, (r, g, b, y), qts)]
     cb = -0.168736 * r - 0.331264 * g + 0.5 * b + 128.0
     cr = 0.5 * r - 0.418688 * g - 0.081312 * b + 128.0
     h_max = max(c.horizontal_sampling_factor for c in comps)

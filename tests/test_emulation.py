@@ -127,7 +127,7 @@ def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64, strip=0, seg_rows=0
     desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
     n = len(samp)
     ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in coefs])
-    out_len = w_ * h_ * (1 if n == 1 else 3)
+    out_len = w_ * h_ * (1 if n == 1 else n)
     out = np.full(out_len + 64, 0x5A, np.uint8)  # guard band: the kernels must not write past the image
     tx = C.c_uint32(0)
     kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, int(sane), out.ctypes.data, C.byref(tx), f420_tx, strip, seg_rows, s420_tx)
@@ -149,6 +149,7 @@ GEOMS = [
     (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2, 1, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (3, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (16, 8, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (17, 8, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (993, 10, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (1920, 16, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2017, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (45, 29, [(1, 1)] * 4, "CMYK"), (45, 29, [(1, 1)] * 4, "YCCK"), (650, 20, [(1, 1)] * 4, "YCCK"), (513, 9, [(1, 1)] * 4, "CMYK"), (1, 1, [(1, 1)] * 4, "CMYK"),
     (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
     (1000, 1, [(1, 1)], "Grayscale"),
 ]
@@ -191,7 +192,7 @@ def test_planner_keeps_odd_geometries_on_the_generic_path():
     for (w_, h_, samp, ct) in [(1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
                                (1, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
                                (64, 64, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 1), (1, 1), (1, 1)], "RGB"), (64, 64, [(2, 2)], "Grayscale"),
-                               (64, 64, [(1, 1)] * 4, "CMYK")]:
+                               (64, 64, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (64, 64, [(1, 1)] * 4, "None")]:
         rng = np.random.default_rng(0)
         ocomps, _ = O.make_components(w_, h_, samp)
         qts = [np.ones(64, np.uint16) for _ in ocomps]

@@ -263,11 +263,12 @@ def test_batch_heterogeneous_mixed_paths():
         _batch_case(rng, 50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
     ]
     outs, path = _run_batch(cases)
-    assert path == "mixed"  # 4:2:0, 4:2:2, 4:4:4 RGB and gray each get their fused launch; CMYK, 4:1:1 and 4:4:0 the generic kernels
+    assert path == "mixed"  # every fusable kind gets its own launch; 4:1:1 (and whatever else has no fused kernel) the generic kernels
     outs_g, path_g = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
     assert path_g == "generic"
     outs_2, path_2 = _run_batch(cases[4:])
-    assert path_2 == "generic"
+    assert path_2 == "mixed"
+    assert _run_batch(cases[5:6])[1] == "generic"
     for (oc, qts, coefs, ct, w_, h_), got, gen in zip(cases, outs, outs_g):
         want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper())
         assert np.array_equal(got, want)
@@ -408,6 +409,8 @@ MIXED_SIZES = {
     "444rgb": ([(1, 1), (1, 1), (1, 1)], "RGB", "fused444", [(45, 29), (8, 8), (700, 33)]),
     "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr", "fused422", [(64, 24), (33, 17), (2, 1), (1000, 9), (17, 300), (1984, 8), (1985, 8), (640, 480), (36, 9), (38, 9), (3, 9), (30, 17)]),
     "gray": ([(1, 1)], "Grayscale", "fusedgray", [(37, 21), (300, 200), (1, 1000), (2056, 9), (8, 8)]),
+    "cmyk": ([(1, 1)] * 4, "CMYK", "fused444x4", [(45, 29), (200, 120), (1, 1), (513, 8), (9, 300), (640, 480)]),
+    "ycck": ([(1, 1)] * 4, "YCCK", "fused444x4", [(45, 29), (8, 8), (700, 33), (500, 333)]),
 }
 
 
@@ -513,7 +516,7 @@ def test_batch_compact_upload_rejects_inconsistent_buffers():
 
 @pytest.mark.parametrize("name,samp,mode,ct,path", [
     ("422", [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused422"), ("444", [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused444"),
-    ("gray", [(1, 1)], "gray", "Grayscale", "fusedgray")])
+    ("gray", [(1, 1)], "gray", "Grayscale", "fusedgray"), ("cmyk", [(1, 1)] * 4, "cmyk", "CMYK", "fused444x4")])
 def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
     """BASELINE geometry at full size for the other fused kinds: oracle on the decoded synthetic image, identical
     inputs -> identical outputs across the batch, and the decode is close to its source."""
@@ -521,7 +524,7 @@ def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
     ocomps, _ = O.make_components(w_, h_, samp)
     jc = to_j(ocomps)
     lum, chr_ = synth.quality_tables(85)
-    qts = [lum, chr_, chr_][: len(samp)]
+    qts = [lum] * 4 if mode == "cmyk" else [lum, chr_, chr_][: len(samp)]
     rgb = synth.synthetic_rgb(w_, h_)
     base = synth.coefficients_from_rgb(rgb, jc, mode, qts)
     cases = [(ocomps, qts, base, ct, w_, h_)] * 5
@@ -533,6 +536,8 @@ def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
     if mode == "gray":
         y = 0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2]
         err = np.abs(outs[0].reshape(h_, w_).astype(float) - y)
+    elif mode == "cmyk":  # the planes were the primaries themselves: 255 - decoded = source
+        err = np.abs(255 - outs[0].reshape(h_, w_, 4)[..., :3].astype(int) - rgb.astype(int))
     else:
         err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
     assert err.mean() < 6.0
