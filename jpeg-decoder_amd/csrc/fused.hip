@@ -76,16 +76,14 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const 
     K::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
 
-// 4:2:0 in one launch: a = strip, b = row segment; see S420 in fused_core.hpp
-template <int ARITH, uint32_t NT>
-__global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                     const FusedWork *__restrict__ work) {
-    typedef S420<ARITH, NT> K;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+// Strip walks (4:2:0: S420, 4:4:0: S440 in fused_core.hpp): a = strip, b = row segment
+template <class K>
+__device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
+                                          uint8_t *lds_raw) {
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
-    const S420Lds lds = S420Lds::make(lds_raw, g.tx);
+    const typename K::Lds lds = K::Lds::make(lds_raw, g.tx);
     const uint32_t strip = w.a, tid = threadIdx.x;
     const uint32_t k0 = w.b * g.seg_rows, k1 = min(k0 + g.seg_rows, g.mcu_h);
     S420Regs r;
@@ -128,6 +126,20 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict
         __syncthreads();
         K::colour(g, img, strip, k1, 16u * k0, true, tid, lds);
     }
+}
+
+template <int ARITH, uint32_t NT>
+__global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                     const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    walk_body<S420<ARITH, NT>>(geoms, imgs, work, lds_raw);
+}
+
+template <int ARITH>
+__global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                      const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    walk_body<S440<ARITH>>(geoms, imgs, work, lds_raw);
 }
 
 template <int ARITH>
@@ -228,7 +240,7 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     plan.name = name;
     plan.n_images = n;
     plan.ncomp = descs[0].ncomp;
-    plan.strip = plan.kind == FUSED_420 && plan.geoms[0].strip != 0;
+    plan.strip = (plan.kind == FUSED_420 || plan.kind == FUSED_440) && plan.geoms[0].strip != 0;
     if (plan.strip) {
         const char *sr = getenv("JPGPU_S420_SEG");
         for (auto &g : plan.geoms) s420_set_segments(g, n, sr ? (uint32_t)atoi(sr) : 0u);
@@ -238,7 +250,8 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     for (const auto &g : plan.geoms) tx_max = std::max(tx_max, g.tx);
     plan.nt = 256;
     if (plan.kind == FUSED_420) plan.nt = plan.strip ? 256u : (tx_max <= 32u ? 128u : 256u);
-    plan.lds_bytes = plan.kind != FUSED_420 ? 0 : (plan.strip ? S420Lds::total_bytes(tx_max) : F420Lds::total_bytes(tx_max));
+    plan.lds_bytes = plan.kind == FUSED_440 ? S440Lds::total_bytes(tx_max)
+                     : plan.kind != FUSED_420 ? 0 : (plan.strip ? S420Lds::total_bytes(tx_max) : F420Lds::total_bytes(tx_max));
     if (const char *pad = getenv("JPGPU_LDS_PAD")) plan.lds_bytes += (size_t)atoi(pad);  // occupancy experiments: claim more LDS than needed
     plan.scratch_off.assign(n, 0);
     size_t so = 0;
@@ -370,6 +383,7 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, 128);
         else ARITH_SWITCH(f420_main_kernel, 256);
         break;
+    case FUSED_440: ARITH_SWITCH(s440_kernel); break;
     case FUSED_444: ARITH_SWITCH(f444_kernel); break;
     case FUSED_422: ARITH_SWITCH(f422_kernel); break;
     case FUSED_GRAY: ARITH_SWITCH(fgray_kernel); break;

@@ -31,7 +31,7 @@ constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
 
 enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1, FCOLOR_CMYK = 2, FCOLOR_YCCK = 3 };  // the last two: four components
-enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4 };
+enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4, FUSED_440 = 5 };
 
 struct FusedGeom {
     uint32_t kind;
@@ -579,7 +579,8 @@ struct S420 {
     }
 
     // block `lb` of the staging area -> registers, dequantized on the way for the classes whose products fit i16
-    static __device__ __forceinline__ void fetch_block(const Lds &lds, uint32_t lb, uint32_t comp, uint32_t (&cw)[32]) {
+    template <class L>
+    static __device__ __forceinline__ void fetch_block(const L &lds, uint32_t lb, uint32_t comp, uint32_t (&cw)[32]) {
         const v4u *p = reinterpret_cast<const v4u *>(lds.stage);
         const v4u *q = reinterpret_cast<const v4u *>(lds.qtab) + comp * 8u;
 #pragma unroll
@@ -594,7 +595,8 @@ struct S420 {
             }
         }
     }
-    static __device__ __forceinline__ void transform_block(const Lds &lds, uint32_t comp, const uint32_t (&cw)[32], uint32_t (&out)[16]) {
+    template <class L>
+    static __device__ __forceinline__ void transform_block(const L &lds, uint32_t comp, const uint32_t (&cw)[32], uint32_t (&out)[16]) {
         if constexpr (ARITH == ARITH_EXACT) {
             uint32_t qw[32];
             const v4u *q = reinterpret_cast<const v4u *>(lds.qtab) + comp * 8u;
@@ -812,6 +814,230 @@ struct S420 {
                 const v2u yy = *reinterpret_cast<const v2u *>(py + lds.ypitch);
                 P::template row_pixels<false, false, false, false>(g, base + (offa + pitch), ((base_lo + offa + pitch) & 3u) == 0, t, yy, ox0);
             }
+        }
+    }
+};
+
+// =============================================================================================
+// FUSED_440: 4:4:0 YCbCr (H1V1 luma, chroma at half the height: UpsamplerH1V2, src/upsampler.rs:165-189) -> RGB24 in one
+// launch, as a strip walk like S420: MCU = 8 x 16 pixels = two luma blocks one above the other + one Cb + one Cr block; a
+// workgroup walks MCU rows [k0, k1) of a strip of tx <= 64 MCUs, four blocks per MCU = one lane each.  The vertical
+// filter reads chroma rows y/2 and y/2 -+ 1 exactly as H2V2 does, so the tiles, the carry rows and the seam round are those
+// of S420 (without its horizontal halo: there is no horizontal filter); a unit of the pixel phase is one 8-pixel block
+// column x two output rows.
+// =============================================================================================
+struct S440Lds {
+    uint8_t *stage;   // 4*tx blocks x 128 B coefficient staging; later the tiles:
+    uint8_t *ytile;   //   17 rows x pitch : row 0 = luma row 16k-1 (carry), rows 1..16 the step's own
+    uint8_t *ctile;   //   2 comps x 9 rows x pitch : row 0 = chroma row 8k-1 (carry), rows 1..8 the step's own
+    uint8_t *carry;   // 3 x pitch: last luma / Cb / Cr rows of the step before (chroma: the seam row at a segment start)
+    uint8_t *bnd;     // 2 x pitch: chroma row 8*k1 (seam below the segment)
+    uint8_t *qtab;    // 3 x 128 B
+    uint32_t pitch;   // 8*tx
+    static __device__ __host__ __forceinline__ uint32_t stage_bytes(uint32_t tx) { return 4u * tx * 128u; }
+    static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx) { return stage_bytes(tx) + 5u * 8u * tx + 384u; }
+    static __device__ __forceinline__ S440Lds make(uint8_t *base, uint32_t tx) {
+        S440Lds l;
+        l.pitch = 8u * tx;
+        l.stage = base;
+        l.ytile = base;
+        l.ctile = base + 17u * l.pitch;  // (17 + 18) * 8 * tx = 280 * tx <= 512 * tx
+        l.carry = base + stage_bytes(tx);
+        l.bnd = l.carry + 3u * l.pitch;
+        l.qtab = l.bnd + 2u * l.pitch;
+        return l;
+    }
+};
+constexpr uint32_t S440_TX_MAX = 64;
+
+template <int ARITH>
+struct S440 {
+    typedef S440Lds Lds;
+    typedef S420<ARITH, 256> W;  // block fetch / transform helpers (they only look at lds.stage and lds.qtab)
+    static constexpr uint32_t NT = 256;
+    static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t strip) { return min(g.tx, g.mcu_w - strip * g.tx); }
+    static __device__ __forceinline__ void init(const FusedImage &img, uint32_t tid, const Lds &lds) {
+        if (tid < 32u) {
+            uint32_t *d = reinterpret_cast<uint32_t *>(lds.qtab);
+            d[tid] = ((const JP_GLOBAL uint32_t *)img.qt[0])[tid];
+            d[32u + tid] = ((const JP_GLOBAL uint32_t *)img.qt[1])[tid];
+            d[64u + tid] = ((const JP_GLOBAL uint32_t *)img.qt[2])[tid];
+        }
+    }
+    // lane -> block: [0,te) luma row 0, [te,2te) luma row 1, [2te,3te) Cb, [3te,4te) Cr
+    static __device__ __forceinline__ bool lane_block(uint32_t te, uint32_t tid, uint32_t &comp, uint32_t &ry, uint32_t &cx) {
+        const uint32_t q = (tid >= te ? 1u : 0u) + (tid >= 2u * te ? 1u : 0u) + (tid >= 3u * te ? 1u : 0u);
+        cx = tid - q * te;
+        ry = q == 1u ? 1u : 0u;
+        comp = q < 2u ? 0u : q - 1u;
+        return tid < 4u * te;
+    }
+    // four runs of 8*te chunks (<= 512: two loads per lane and run); staging block index = lane that transforms it
+    struct Pre {
+        v4u v[4][2];
+    };
+    static __device__ __forceinline__ void stage_load(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k, uint32_t tid, Pre &pre) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip), nc = 8u * te;
+        const JP_GLOBAL v4u *y0 = (const JP_GLOBAL v4u *)img.coefs[0] + ((size_t)(2u * k) * g.bw0 + x0m) * 8u;
+        const JP_GLOBAL v4u *run[4] = {y0, y0 + (size_t)g.bw0 * 8u, (const JP_GLOBAL v4u *)img.coefs[1] + ((size_t)k * g.bwc + x0m) * 8u,
+                                       (const JP_GLOBAL v4u *)img.coefs[2] + ((size_t)k * g.bwc + x0m) * 8u};
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++)
+#pragma unroll
+            for (uint32_t i = 0; i < 2; i++) pre.v[w][i] = run[w][min(tid + NT * i, nc - 1u)];
+    }
+    static __device__ __forceinline__ void stage_store(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds, const Pre &pre) {
+        const uint32_t te = txe(g, strip), nc = 8u * te;
+        v4u *dst = reinterpret_cast<v4u *>(lds.stage);
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++)
+#pragma unroll
+            for (uint32_t i = 0; i < 2; i++)
+                if (tid + NT * i < nc) dst[coef_slot(w * te + (tid >> 3) + (NT / 8u) * i, tid & 7u)] = pre.v[w][i];
+    }
+    static __device__ __forceinline__ void read_block(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds, S420Regs &r) {
+        if (tid * 8u < 3u * lds.pitch) r.carry = *reinterpret_cast<const v2u *>(lds.carry + tid * 8u);
+        uint32_t comp, ry, cx;
+        if (!lane_block(txe(g, strip), tid, comp, ry, cx)) return;
+        W::fetch_block(lds, tid, comp, r.cw);
+    }
+    static __device__ __forceinline__ void transform(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds, S420Regs &r) {
+        if (tid * 8u < 3u * lds.pitch) {  // carry rows -> row 0 of the tiles
+            const uint32_t o = tid * 8u;
+            uint8_t *dst = o < lds.pitch ? lds.ytile + o : (o < 2u * lds.pitch ? lds.ctile + (o - lds.pitch) : lds.ctile + 9u * lds.pitch + (o - 2u * lds.pitch));
+            *reinterpret_cast<v2u *>(dst) = r.carry;
+        }
+        uint32_t comp, ry, cx;
+        if (!lane_block(txe(g, strip), tid, comp, ry, cx)) return;
+        uint32_t out[16];
+        W::transform_block(lds, comp, r.cw, out);
+        uint8_t *base = comp == 0u ? lds.ytile + (1u + ry * 8u) * lds.pitch + cx * 8u : lds.ctile + ((comp - 1u) * 9u + 1u) * lds.pitch + cx * 8u;
+#pragma unroll
+        for (int row = 0; row < 8; row++) *reinterpret_cast<v2u *>(base + (uint32_t)row * lds.pitch) = v2u{out[2 * row], out[2 * row + 1]};
+        if (comp != 0u || ry == 1u) *reinterpret_cast<v2u *>(lds.carry + comp * lds.pitch + cx * 8u) = v2u{out[14], out[15]};
+    }
+    // seams: chroma blocks of block rows k0-1 (last sample row -> carry) and k1 (first sample row -> bnd); staging block
+    // index = lane: [0,te) Cb above, Cr above, Cb below, Cr below
+    static __device__ __forceinline__ void seam_stage(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k0, uint32_t k1, uint32_t tid, const Lds &lds) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip), nc = 8u * te;
+        const size_t ra = ((size_t)(k0 > 0u ? k0 - 1u : 0u) * g.bwc + x0m) * 8u, rb = ((size_t)(k1 < g.mcu_h ? k1 : 0u) * g.bwc + x0m) * 8u;
+        const JP_GLOBAL v4u *run[4] = {(const JP_GLOBAL v4u *)img.coefs[1] + ra, (const JP_GLOBAL v4u *)img.coefs[2] + ra,
+                                       (const JP_GLOBAL v4u *)img.coefs[1] + rb, (const JP_GLOBAL v4u *)img.coefs[2] + rb};
+        Pre pre;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++)
+#pragma unroll
+            for (uint32_t i = 0; i < 2; i++) pre.v[w][i] = run[w][min(tid + NT * i, nc - 1u)];
+        stage_store(g, strip, tid, lds, pre);
+    }
+    static __device__ __forceinline__ void seam_transform(const FusedGeom &g, uint32_t strip, uint32_t k0, uint32_t k1, uint32_t tid, const Lds &lds) {
+        const uint32_t te = txe(g, strip);
+        if (tid >= 4u * te) return;
+        const uint32_t which = (tid >= te ? 1u : 0u) + (tid >= 2u * te ? 1u : 0u) + (tid >= 3u * te ? 1u : 0u);
+        const uint32_t cx = tid - which * te, c = which & 1u;
+        const bool below = which >= 2u;
+        if (below ? !(k1 < g.mcu_h) : !(k0 > 0u)) return;
+        uint32_t cw[32], out[16];
+        W::fetch_block(lds, tid, 1u + c, cw);
+        W::transform_block(lds, 1u + c, cw, out);
+        if (below) *reinterpret_cast<v2u *>(lds.bnd + c * lds.pitch + cx * 8u) = v2u{out[0], out[1]};
+        else *reinterpret_cast<v2u *>(lds.carry + (1u + c) * lds.pitch + cx * 8u) = v2u{out[14], out[15]};
+    }
+    static __device__ __forceinline__ void closing_tiles(uint32_t tid, const Lds &lds) {
+        const uint32_t o = tid * 8u;
+        if (o < lds.pitch) {
+            *reinterpret_cast<v2u *>(lds.ytile + o) = *reinterpret_cast<const v2u *>(lds.carry + o);
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++) {
+                *reinterpret_cast<v2u *>(lds.ctile + c * 9u * lds.pitch + o) = *reinterpret_cast<const v2u *>(lds.carry + (1u + c) * lds.pitch + o);
+                *reinterpret_cast<v2u *>(lds.ctile + (c * 9u + 1u) * lds.pitch + o) = *reinterpret_cast<const v2u *>(lds.bnd + c * lds.pitch + o);
+            }
+        }
+    }
+
+    // Eight chroma samples of one output row, centred: (3*near + far + 2) >> 2 - 128 (src/upsampler.rs:186) per sample, on
+    // 16-bit lane pairs — even bytes (s0,s2)(s4,s6) and odd bytes (s1,s3)(s5,s7) of the two dwords.
+    struct C8 {
+        uint32_t e0, o0, e1, o1;  // lanes hold c - 128 as i16
+    };
+    static __device__ __forceinline__ C8 vfilter(v2u n, v2u f) {
+        const uint32_t m = 0x00ff00ffu, bias = 0xfe02fe02u;  // 2 - 512 per lane: ((3n + f + 2 - 512) >> 2) == ((3n + f + 2) >> 2) - 128
+        C8 c;
+        c.e0 = pk_sar2(pk_add(pk_mad3(n.x & m, f.x & m), bias));
+        c.o0 = pk_sar2(pk_add(pk_mad3(pk_shr(n.x, 8), pk_shr(f.x, 8)), bias));
+        c.e1 = pk_sar2(pk_add(pk_mad3(n.y & m, f.y & m), bias));
+        c.o1 = pk_sar2(pk_add(pk_mad3(pk_shr(n.y, 8), pk_shr(f.y, 8)), bias));
+        return c;
+    }
+    static __device__ __forceinline__ int32_t lane_lo(uint32_t x) { return (int32_t)(x << 16) >> 16; }
+    static __device__ __forceinline__ int32_t lane_hi(uint32_t x) { return (int32_t)x >> 16; }
+    // one 8-pixel chunk of one row; n = pixels inside the image (8 unless the image ends in the chunk), al4 = 4-byte aligned
+    template <bool FULL>
+    static __device__ __forceinline__ void row8(JP_GLOBAL uint8_t *o, v2u yy, const C8 &cb, const C8 &cr, uint32_t n, bool al4) {
+        const w32 yb[8] = {byte_shl20<0>(yy.x), byte_shl20<1>(yy.x), byte_shl20<2>(yy.x), byte_shl20<3>(yy.x),
+                           byte_shl20<0>(yy.y), byte_shl20<1>(yy.y), byte_shl20<2>(yy.y), byte_shl20<3>(yy.y)};
+        const int32_t b[8] = {lane_lo(cb.e0), lane_lo(cb.o0), lane_hi(cb.e0), lane_hi(cb.o0), lane_lo(cb.e1), lane_lo(cb.o1), lane_hi(cb.e1), lane_hi(cb.o1)};
+        const int32_t r[8] = {lane_lo(cr.e0), lane_lo(cr.o0), lane_hi(cr.e0), lane_hi(cr.o0), lane_lo(cr.e1), lane_lo(cr.o1), lane_hi(cr.e1), lane_hi(cr.o1)};
+        RawRgb p[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) p[k] = ycbcr_raw_centred(yb[k], b[k], r[k]);
+        if (FULL || (n == 8u && al4)) {
+            uint32_t d0, d1, d2, d3, d4, d5;
+            rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
+            rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{d0, d1, d2};
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{d3, d4, d5};
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++)
+                if (k < n) {
+                    o[3 * k] = (uint8_t)sar_sat_u8x2(p[k].r, 0u, 20);
+                    o[3 * k + 1] = (uint8_t)sar_sat_u8x2(p[k].g, 0u, 20);
+                    o[3 * k + 2] = (uint8_t)sar_sat_u8x2(p[k].b, 0u, 20);
+                }
+        }
+    }
+    // output rows 16k-1 .. 16k+14 of the strip (see S420::colour); closing: the segment's last row only
+    static __device__ __forceinline__ void colour(const FusedGeom &g, const FusedImage &img, uint32_t strip, uint32_t k, uint32_t row_lo, bool closing,
+                                                  uint32_t tid, const Lds &lds) {
+        const uint32_t x0m = strip * g.tx, te = txe(g, strip);
+        const uint32_t nunits = (closing ? 1u : 8u) * te;
+        const uint32_t magic = te > 1u ? 0xffffffffu / te + 1u : 0u;  // mul_hi(u, magic) == u / te for u < 65536 (te == 1: u itself)
+        const uint32_t pitch = g.out_w * 3u;
+        JP_GLOBAL uint8_t *base = (JP_GLOBAL uint8_t *)img.out + ((ptrdiff_t)(16 * (int64_t)k - 1)) * (ptrdiff_t)pitch;
+        const uint32_t base_lo = (uint32_t)((16 * (int64_t)k - 1) * (int64_t)pitch) & 3u;
+        const bool interior = !closing && 16u * k >= row_lo + 1u && 16u * k + 15u <= g.out_h && k > 0u && 8u * k + 8u <= g.ch &&
+                              (g.out_w & 7u) == 0u && 8u * (x0m + te) <= g.out_w;
+        if (interior) {
+#pragma unroll 1
+            for (uint32_t u = tid; u < nunits; u += NT) {
+                const uint32_t slot = te > 1u ? __umulhi(u, magic) : u, chk = u - slot * te;
+                const uint8_t *pc = lds.ctile + slot * lds.pitch + 8u * chk, *py = lds.ytile + 2u * slot * lds.pitch + 8u * chk;
+                const v2u bu = *reinterpret_cast<const v2u *>(pc), bl = *reinterpret_cast<const v2u *>(pc + lds.pitch);
+                const v2u ru = *reinterpret_cast<const v2u *>(pc + 9u * lds.pitch), rl = *reinterpret_cast<const v2u *>(pc + 10u * lds.pitch);
+                const uint32_t offa = 2u * slot * pitch + 8u * (x0m + chk) * 3u;
+                row8<true>(base + offa, *reinterpret_cast<const v2u *>(py), vfilter(bu, bl), vfilter(ru, rl), 8u, true);
+                row8<true>(base + (offa + pitch), *reinterpret_cast<const v2u *>(py + lds.pitch), vfilter(bl, bu), vfilter(rl, ru), 8u, true);
+            }
+            return;
+        }
+#pragma unroll 1
+        for (uint32_t u = tid; u < nunits; u += NT) {
+            const uint32_t slot = te > 1u ? __umulhi(u, magic) : u, chk = u - slot * te;
+            const int32_t oya = 16 * (int32_t)k - 1 + 2 * (int32_t)slot;
+            const uint32_t oyb = (uint32_t)(oya + 1);
+            const bool va = oya >= (int32_t)row_lo && (uint32_t)oya < g.out_h, vb = !closing && oyb < g.out_h;
+            const uint32_t ox0 = 8u * (x0m + chk);
+            if ((!va && !vb) || ox0 >= g.out_w) continue;
+            const int32_t cu = 8 * (int32_t)k - 1 + (int32_t)slot;
+            const bool clamp_a = cu + 1 > (int32_t)g.ch - 1, clamp_b = cu < 0;
+            const uint32_t U = clamp_b ? slot + 1u : slot, L = clamp_a ? slot : slot + 1u;
+            const uint8_t *pc = lds.ctile + 8u * chk, *py = lds.ytile + 2u * slot * lds.pitch + 8u * chk;
+            const v2u bu = *reinterpret_cast<const v2u *>(pc + U * lds.pitch), bl = *reinterpret_cast<const v2u *>(pc + L * lds.pitch);
+            const v2u ru = *reinterpret_cast<const v2u *>(pc + (9u + U) * lds.pitch), rl = *reinterpret_cast<const v2u *>(pc + (9u + L) * lds.pitch);
+            const uint32_t offa = 2u * slot * pitch + ox0 * 3u, n = min(8u, g.out_w - ox0);
+            if (va) row8<false>(base + offa, *reinterpret_cast<const v2u *>(py), vfilter(bu, bl), vfilter(ru, rl), n, ((base_lo + offa) & 3u) == 0);
+            if (vb) row8<false>(base + (offa + pitch), *reinterpret_cast<const v2u *>(py + lds.pitch), vfilter(bl, bu), vfilter(rl, ru), n, ((base_lo + offa + pitch) & 3u) == 0);
         }
     }
 };

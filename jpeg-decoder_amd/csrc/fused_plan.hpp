@@ -71,6 +71,23 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             return FUSED_NONE;
         }
         tx_max = F422_TX_MAX;
+    } else if (d0.ncomp == 3 && hv(0, 1, 2) && hv(1, 1, 1) && hv(2, 1, 1) && d0.color_transform == JPGPU_CT_YCBCR && d0.out_h > 1 &&
+               fused_same_component(d0.components[1], d0.components[2])) {
+        // (an output height of 1 overrides H1V2 with H1V1, src/upsampler.rs:81: generic path)
+        kind = FUSED_440;
+        name = "fused440";
+        g.mcu_w = d0.components[1].block_width;
+        g.mcu_h = d0.components[1].block_height;
+        g.bwc = d0.components[1].block_width;
+        g.cw = d0.components[1].size_width;
+        g.ch = d0.components[1].size_height;
+        if (d0.components[0].block_width != g.mcu_w || d0.components[0].block_height != 2u * g.mcu_h || d0.out_w > g.cw ||
+            d0.out_w > 8u * g.mcu_w || d0.out_h > 2u * g.ch) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = S440_TX_MAX;
+        g.strip = 1u;
     } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&
                (d0.color_transform == JPGPU_CT_YCBCR || d0.color_transform == JPGPU_CT_RGB) &&
                fused_same_component(d0.components[0], d0.components[1]) &&

@@ -117,6 +117,9 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return (((a & 0xffffu) + (b & 0xffffu)) & 0xffffu) | ((((a >> 16) + (b >> 16)) & 0xffffu) << 16);
 }
 __device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return ((a & 0xffffu) >> n) | (((a >> 16) >> n) << 16); }
+__device__ __forceinline__ uint32_t pk_sar2(uint32_t a) {  // per 16-bit lane: arithmetic shift right by 2
+    return ((uint32_t)((int32_t)(int16_t)(a & 0xffffu) >> 2) & 0xffffu) | ((uint32_t)((int32_t)(int16_t)(a >> 16) >> 2) << 16);
+}
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int n) {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> n);
 }
@@ -150,6 +153,10 @@ __device__ __forceinline__ uint32_t pk_mad3(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return us2_bits(as_us2(a) + as_us2(b)); }
 __device__ __forceinline__ uint32_t pk_shr(uint32_t a, int n) { return us2_bits(as_us2(a) >> (unsigned short)n); }
+__device__ __forceinline__ uint32_t pk_sar2(uint32_t a) {  // v_pk_ashrrev_i16
+    typedef short ss2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ss2_t, a) >> (short)2);
+}
 __device__ __forceinline__ uint32_t pk_mul_lo_u16(uint32_t a, uint32_t b) { return us2_bits(as_us2(a) * as_us2(b)); }
 typedef short s2_t __attribute__((ext_vector_type(2)));
 // v_dot2_i32_i16 in its three-operand (VOP3P) form.  Through the builtin hipcc picks the accumulating

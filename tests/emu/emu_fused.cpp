@@ -9,17 +9,17 @@
 
 using namespace jpgpu;
 
-// strip420 != 0: 4:2:0 through the strip-walk kernel (S420) with `seg_rows` MCU rows per workgroup (0 = planner's choice)
-template <int A, uint32_t NT>
-static void run_s420(const FusedGeom& g, const FusedImage& img) {
-    typedef S420<A, NT> K;
-    std::vector<uint8_t> mem(S420Lds::total_bytes(g.tx) + 64);
+// the strip-walk kernels (S420, S440): fused.hip's walk_body, phase by phase, `seg_rows` MCU rows per workgroup
+template <class K>
+static void run_walk(const FusedGeom& g, const FusedImage& img) {
+    constexpr uint32_t NT = K::NT;
+    std::vector<uint8_t> mem(K::Lds::total_bytes(g.tx) + 64);
     std::vector<S420Regs> regs(NT);
 #define LANES(BODY) for (uint32_t t = 0; t < NT; t++) { BODY; }
     for (uint32_t seg = 0; seg < g.n_seg; seg++)
         for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
             memset(mem.data(), 0xCD, mem.size());  // garbage, like real LDS
-            const S420Lds lds = S420Lds::make(mem.data(), g.tx);
+            const typename K::Lds lds = K::Lds::make(mem.data(), g.tx);
             const uint32_t k0 = seg * g.seg_rows, k1 = std::min(k0 + g.seg_rows, g.mcu_h);
             LANES(K::init(img, t, lds))
             if (k0 > 0 || k1 < g.mcu_h) {
@@ -53,7 +53,7 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
     const char *name = "", *why = "";
     int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max, strip420 != 0, s420_tx_max ? s420_tx_max : S420_TX_MAX);
     if (kind == FUSED_NONE) return 0;
-    if (kind == FUSED_420 && g.strip) {
+    if ((kind == FUSED_420 || kind == FUSED_440) && g.strip) {
         s420_set_segments(g, 1, seg_rows);
         FusedImage im{};
         for (uint32_t c = 0; c < desc->ncomp; c++) {
@@ -62,9 +62,14 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         }
         im.out = out;
         if (tx_out) *tx_out = g.tx;
-        if (sane == 2) run_s420<ARITH_TIGHT, 256>(g, im);
-        else if (sane) run_s420<ARITH_SANE, 256>(g, im);
-        else run_s420<ARITH_EXACT, 256>(g, im);
+        im.flags = sane == 2 ? 3u : (sane ? 1u : 0u);
+        if (kind == FUSED_440) {
+            if (sane == 2) run_walk<S440<ARITH_TIGHT>>(g, im);
+            else if (sane) run_walk<S440<ARITH_SANE>>(g, im);
+            else run_walk<S440<ARITH_EXACT>>(g, im);
+        } else if (sane == 2) run_walk<S420<ARITH_TIGHT, 256>>(g, im);
+        else if (sane) run_walk<S420<ARITH_SANE, 256>>(g, im);
+        else run_walk<S420<ARITH_EXACT, 256>>(g, im);
         return kind;
     }
     if (tx_out) *tx_out = g.tx;

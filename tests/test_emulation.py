@@ -149,6 +149,8 @@ GEOMS = [
     (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2, 1, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (3, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (16, 8, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (17, 8, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (993, 10, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (1920, 16, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2017, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (64, 48, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (8, 2, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+    (3, 5, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (520, 80, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (1032, 33, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (17, 160, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1)] * 4, "CMYK"), (45, 29, [(1, 1)] * 4, "YCCK"), (650, 20, [(1, 1)] * 4, "YCCK"), (513, 9, [(1, 1)] * 4, "CMYK"), (1, 1, [(1, 1)] * 4, "CMYK"),
     (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
     (1000, 1, [(1, 1)], "Grayscale"),
@@ -159,8 +161,9 @@ GEOMS = [
 @pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
 @pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7", "strip-tx7-seg1"])
 def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
-    if f420_tx != 64 and not (len(geom[2]) == 3 and geom[2][0] == (2, 2)):
-        pytest.skip("variant knob only affects the 4:2:0 kernels")
+    walk = len(geom[2]) == 3 and geom[2][0] in ((2, 2), (1, 2))
+    if f420_tx != 64 and not walk or (f420_tx == 32 and geom[2][0] != (2, 2)):
+        pytest.skip("variant knob only affects the 4:2:0 / 4:4:0 kernels")
     strip, seg_rows, s420_tx = 0, 0, 0
     if isinstance(f420_tx, str):  # single-launch strip walk: (MCU rows per workgroup, widest strip)
         strip = 1
@@ -190,7 +193,7 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
 
 def test_planner_keeps_odd_geometries_on_the_generic_path():
     for (w_, h_, samp, ct) in [(1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
-                               (1, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+                               (1, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 1, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
                                (64, 64, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 1), (1, 1), (1, 1)], "RGB"), (64, 64, [(2, 2)], "Grayscale"),
                                (64, 64, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (64, 64, [(1, 1)] * 4, "None")]:
         rng = np.random.default_rng(0)

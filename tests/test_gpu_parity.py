@@ -409,6 +409,7 @@ MIXED_SIZES = {
     "444rgb": ([(1, 1), (1, 1), (1, 1)], "RGB", "fused444", [(45, 29), (8, 8), (700, 33)]),
     "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr", "fused422", [(64, 24), (33, 17), (2, 1), (1000, 9), (17, 300), (1984, 8), (1985, 8), (640, 480), (36, 9), (38, 9), (3, 9), (30, 17)]),
     "gray": ([(1, 1)], "Grayscale", "fusedgray", [(37, 21), (300, 200), (1, 1000), (2056, 9), (8, 8)]),
+    "440": ([(1, 2), (1, 1), (1, 1)], "YCbCr", "fused440", [(64, 48), (50, 61), (8, 2), (3, 5), (520, 80), (17, 1080), (640, 480), (1032, 33)]),
     "cmyk": ([(1, 1)] * 4, "CMYK", "fused444x4", [(45, 29), (200, 120), (1, 1), (513, 8), (9, 300), (640, 480)]),
     "ycck": ([(1, 1)] * 4, "YCCK", "fused444x4", [(45, 29), (8, 8), (700, 33), (500, 333)]),
 }
@@ -516,7 +517,8 @@ def test_batch_compact_upload_rejects_inconsistent_buffers():
 
 @pytest.mark.parametrize("name,samp,mode,ct,path", [
     ("422", [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused422"), ("444", [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused444"),
-    ("gray", [(1, 1)], "gray", "Grayscale", "fusedgray"), ("cmyk", [(1, 1)] * 4, "cmyk", "CMYK", "fused444x4")])
+    ("gray", [(1, 1)], "gray", "Grayscale", "fusedgray"), ("cmyk", [(1, 1)] * 4, "cmyk", "CMYK", "fused444x4"),
+    ("440", [(1, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", "fused440")])
 def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
     """BASELINE geometry at full size for the other fused kinds: oracle on the decoded synthetic image, identical
     inputs -> identical outputs across the batch, and the decode is close to its source."""
@@ -610,7 +612,8 @@ def test_batch_scan_ranges_on_device_equals_host_classification():
 
 @pytest.mark.parametrize("strip", ["1", "0"], ids=["single-launch", "two-pass"])
 @pytest.mark.parametrize("samp,ct", [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1), (1, 1), (1, 1)], "YCbCr"), ([(2, 1), (1, 1), (1, 1)], "YCbCr"),
-                                     ([(1, 1)], "Grayscale")], ids=["420", "444", "422", "gray"])
+                                     ([(1, 1)], "Grayscale"), ([(1, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)] * 4, "YCCK")],
+                         ids=["420", "444", "422", "gray", "440", "ycck"])
 def test_one_hostile_image_costs_only_itself(samp, ct, strip, monkeypatch):
     """A launch group whose images disagree on the arithmetic class is split per class: one image with
     wrap-range coefficients and one of class 1 among 64 leave the other 62 on the class-3 kernels, and every image —
