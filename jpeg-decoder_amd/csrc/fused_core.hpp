@@ -524,17 +524,22 @@ struct S420 {
         const JP_GLOBAL v4u *cr = (const JP_GLOBAL v4u *)img.coefs[2] + (size_t)k * g.bwc * 8u;
         // halo blocks outside the plane (image edges) are never transformed: clamp them onto valid chunks
         const int32_t cfirst = ((int32_t)x0m - 1) * 8, cmax = (int32_t)(g.bwc * 8u) - 1;
+        // (byte offsets as 32-bit values next to wave-uniform bases: global_load with an SGPR base and a VGPR offset, no
+        // 64-bit address arithmetic per lane)
+        auto at = [](const JP_GLOBAL v4u *base, uint32_t chunk) -> v4u {
+            return *reinterpret_cast<const JP_GLOBAL v4u *>(reinterpret_cast<const JP_GLOBAL uint8_t *>(base) + chunk * 16u);
+        };
 #pragma unroll
         for (uint32_t i = 0; i < LY; i++) {
             const uint32_t j = min(tid + NT * i, nl - 1u);  // clamped: unconditional loads
-            pre.y0[i] = y0[j];  // (plain loads and stores in this kernel: measured 1.5 % better than the streaming hint)
-            pre.y1[i] = y1[j];
+            pre.y0[i] = at(y0, j);  // (plain loads and stores in this kernel: measured 1.5 % better than the streaming hint)
+            pre.y1[i] = at(y1, j);
         }
 #pragma unroll
         for (uint32_t i = 0; i < LC; i++) {
             const uint32_t e = (uint32_t)min(max(cfirst + (int32_t)min(tid + NT * i, ncc - 1u), 0), cmax);
-            pre.cb[i] = cb[e];
-            pre.cr[i] = cr[e];
+            pre.cb[i] = at(cb, e);
+            pre.cr[i] = at(cr, e);
         }
     }
     static __device__ __forceinline__ void stage_store(const FusedGeom &g, uint32_t strip, uint32_t tid, const Lds &lds, const Pre &pre) {
@@ -667,17 +672,16 @@ struct S420 {
         // the next row or past the buffer: only the strip's own blocks, cx in [1, te], write outside themselves)
         const bool own = cx >= 1u && cx <= min(g.tx, g.mcu_w - x0m);
         EdgeFix ef{bx == 0u && own, false};
-        if (bx == (last >> 3)) {
-            const uint32_t r = last & 7u;
-            if (r == 7u) ef.after = own;
-            else {
+        const uint32_t r = last & 7u;  // (uniform: a property of the image)
+        if (r == 7u) {
+            ef.after = own && bx == (last >> 3);
+        } else if (bx == (last >> 3)) {  // widths whose chroma plane ends inside a block: the copy stays in the block
 #pragma unroll
-                for (int row = 0; row < 8; row++) {
-                    const uint64_t v = (uint64_t)out[2 * row] | ((uint64_t)out[2 * row + 1] << 32);
-                    const uint64_t b = (v >> (8u * r)) & 0xffull, m = 0xffull << (8u * (r + 1u));
-                    const uint64_t w = (v & ~m) | (b << (8u * (r + 1u)));
-                    out[2 * row] = (uint32_t)w, out[2 * row + 1] = (uint32_t)(w >> 32);
-                }
+            for (int row = 0; row < 8; row++) {
+                const uint64_t v = (uint64_t)out[2 * row] | ((uint64_t)out[2 * row + 1] << 32);
+                const uint64_t b = (v >> (8u * r)) & 0xffull, m = 0xffull << (8u * (r + 1u));
+                const uint64_t w = (v & ~m) | (b << (8u * (r + 1u)));
+                out[2 * row] = (uint32_t)w, out[2 * row + 1] = (uint32_t)(w >> 32);
             }
         }
         return ef;
@@ -743,6 +747,33 @@ struct S420 {
         }
     }
 
+    // SKIP_A0: slot 0 emits its lower row only
+    template <bool SKIP_A0>
+    static __device__ __forceinline__ void interior_loop(const FusedGeom &g, const Lds &lds, JP_GLOBAL uint8_t *base, uint32_t pitch, uint32_t x0m,
+                                                         uint32_t nch, uint32_t nunits, uint32_t magic, uint32_t tid) {
+#pragma unroll 1
+        for (uint32_t u = tid; u < nunits; u += NT) {
+            const uint32_t slot = __umulhi(u, magic), chk = u - slot * nch;
+            const uint8_t *pc = lds.ctile + slot * lds.cpitch + 4u * chk + 4u;  // upper chroma row of the slot, Cb; lower: + cpitch; Cr: + 9 * cpitch
+            typename P::ChromaEO eu[2], el[2];
+#pragma unroll
+            for (uint32_t comp = 0; comp < 2; comp++) {
+                eu[comp] = P::load_eo(pc + comp * 9u * lds.cpitch);
+                el[comp] = P::load_eo(pc + (comp * 9u + 1u) * lds.cpitch);
+            }
+            const uint32_t ox0 = 16u * x0m + 8u * chk, offa = 2u * slot * pitch + ox0 * 3u;
+            const uint8_t *py = lds.ytile + 2u * slot * lds.ypitch + 8u * chk;
+            if (!SKIP_A0 || slot != 0u) {
+                const typename P::TPrime t[2] = {P::tprime(eu[0], el[0]), P::tprime(eu[1], el[1])};
+                P::template row_pixels<false, false, true, false>(g, base + offa, true, t, *reinterpret_cast<const v2u *>(py), ox0);
+            }
+            {
+                const typename P::TPrime t[2] = {P::tprime(el[0], eu[0]), P::tprime(el[1], eu[1])};
+                P::template row_pixels<false, false, true, false>(g, base + (offa + pitch), true, t, *reinterpret_cast<const v2u *>(py + lds.ypitch), ox0);
+            }
+        }
+    }
+
     // output rows 16k-1 .. 16k+14 of the strip: slot p (0..7) pairs chroma tile rows (p, p+1) = plane rows 8k-1+p, 8k+p and
     // emits luma tile rows 2p (near = upper chroma row) and 2p+1 (near = lower chroma row).  Rows above `row_lo` belong
     // to the workgroup of the segment above.  closing: only slot 0 (the segment's last output row, k = k1).
@@ -755,32 +786,15 @@ struct S420 {
         // first byte of output row 16k-1 (may lie before the image for k = 0: never dereferenced)
         JP_GLOBAL uint8_t *base = (JP_GLOBAL uint8_t *)img.out + ((ptrdiff_t)(16 * (int64_t)k - 1)) * (ptrdiff_t)pitch;
         const uint32_t base_lo = (uint32_t)((16 * (int64_t)k - 1) * (int64_t)pitch) & 3u;  // its alignment
-        // Interior steps — every one of the 16 rows inside the segment and the image, no vertical clamp, the strip's chunks
-        // complete and 4-byte aligned (widths that are multiples of 8) — run a loop without any per-unit predicate.
-        const bool interior = !closing && 16u * k >= row_lo + 1u && 16u * k + 15u <= g.out_h && k > 0u && 8u * k + 8u <= g.ch &&
-                              (g.out_w & 7u) == 0u && 16u * x0m + 8u * nch <= g.out_w;
+        // Interior steps — every one of the 16 rows inside the image, no vertical clamp, the strip's chunks complete and
+        // 4-byte aligned (widths that are multiples of 8) — run a loop without per-unit predicates; the first step of a
+        // segment below the top one is such a step too, except that its row 16k-1 belongs to the workgroup above.
+        const bool first_of_segment = 16u * k == row_lo;
+        const bool interior = !closing && 16u * k + 15u <= g.out_h && k > 0u && 8u * k + 8u <= g.ch && (g.out_w & 7u) == 0u &&
+                              16u * x0m + 8u * nch <= g.out_w;
         if (interior) {
-#pragma unroll 1
-            for (uint32_t u = tid; u < nunits; u += NT) {
-                const uint32_t slot = __umulhi(u, magic), chk = u - slot * nch;
-                const uint8_t *pc = lds.ctile + slot * lds.cpitch + 4u * chk + 4u;  // upper chroma row of the slot, Cb; lower: + cpitch; Cr: + 9 * cpitch
-                typename P::ChromaEO eu[2], el[2];
-#pragma unroll
-                for (uint32_t comp = 0; comp < 2; comp++) {
-                    eu[comp] = P::load_eo(pc + comp * 9u * lds.cpitch);
-                    el[comp] = P::load_eo(pc + (comp * 9u + 1u) * lds.cpitch);
-                }
-                const uint32_t ox0 = 16u * x0m + 8u * chk, offa = 2u * slot * pitch + ox0 * 3u;
-                const uint8_t *py = lds.ytile + 2u * slot * lds.ypitch + 8u * chk;
-                {
-                    const typename P::TPrime t[2] = {P::tprime(eu[0], el[0]), P::tprime(eu[1], el[1])};
-                    P::template row_pixels<false, false, true, false>(g, base + offa, true, t, *reinterpret_cast<const v2u *>(py), ox0);
-                }
-                {
-                    const typename P::TPrime t[2] = {P::tprime(el[0], eu[0]), P::tprime(el[1], eu[1])};
-                    P::template row_pixels<false, false, true, false>(g, base + (offa + pitch), true, t, *reinterpret_cast<const v2u *>(py + lds.ypitch), ox0);
-                }
-            }
+            if (first_of_segment) interior_loop<true>(g, lds, base, pitch, x0m, nch, nunits, magic, tid);
+            else interior_loop<false>(g, lds, base, pitch, x0m, nch, nunits, magic, tid);
             return;
         }
 #pragma unroll 1

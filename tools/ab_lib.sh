@@ -6,8 +6,8 @@ B="python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-classes $@"
 for rep in 1 2; do
   $B > $O/main_$rep.json 2>>$O/err.txt
   JPGPU_LIBRARY=$PWD/jpeg-decoder_amd/libjpgpu_alt.so $B > $O/alt_$rep.json 2>>$O/err.txt
-  JPGPU_420_STRIP=1 JPGPU_S420_SEG=23 $B > $O/main_strip_$rep.json 2>>$O/err.txt
-  JPGPU_420_STRIP=1 JPGPU_S420_SEG=23 JPGPU_LIBRARY=$PWD/jpeg-decoder_amd/libjpgpu_alt.so $B > $O/alt_strip_$rep.json 2>>$O/err.txt
+  $B > $O/main_strip_$rep.json 2>>$O/err.txt
+  JPGPU_LIBRARY=$PWD/jpeg-decoder_amd/libjpgpu_alt.so $B > $O/alt_strip_$rep.json 2>>$O/err.txt
 done
 for f in $O/*.json; do python -c "
 import json,sys
