@@ -816,6 +816,7 @@ static int batch_expand_pending(jpgpu_batch *b, hipStream_t s) {
 
 int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     if (!b) return JPGPU_ERR_FORMAT;
+    jpgpu::TraceRange roctx_range("jpgpu_batch_decode");
     int rc = use_device(b->device, b->err);
     if (rc) return rc;
     rc = batch_refresh_jobs(b);

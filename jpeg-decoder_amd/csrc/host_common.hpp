@@ -21,6 +21,17 @@ int build_image_job(const jpgpu_component *comps, uint32_t ncomp, uint8_t *const
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// roctx range around a host-side phase (the reference has no tracing hooks; rocprofv3 --marker-trace shows these
+// next to the kernels).  Costs two calls into libroctx64 when no tool listens.
+extern "C" int roctxRangePushA(const char *message);
+extern "C" int roctxRangePop();
+struct TraceRange {
+    explicit TraceRange(const char *name) { (void)roctxRangePushA(name); }
+    ~TraceRange() { (void)roctxRangePop(); }
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+};
+
 // jpgpu_batch_upload_compact for buffers written by CompactWriter inside this library (no consistency pass)
 int batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes, int range_class,
                          void *hip_stream, bool trusted);

@@ -394,6 +394,7 @@ int jpgpu_compute_image(jpgpu_worker *w, const jpgpu_component *components, uint
                         const uint8_t *const *host_planes, uint16_t out_w, uint16_t out_h, int color_transform,
                         uint8_t *dst, size_t cap, size_t *len) {
     if (!w) return JPGPU_ERR_FORMAT;
+    jpgpu::TraceRange roctx_range("jpgpu_compute_image");
     if (!components || ncomp == 0 || ncomp > JPGPU_MAX_COMPONENTS)
         return set_err(w->err, JPGPU_ERR_FORMAT, "not all components have data");  // src/decoder.rs:1306-1308
     int rc = use_device(w->device, w->err);

@@ -460,6 +460,7 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
 }
 
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
+    jpgpu::TraceRange roctx_range("jpgpu_pipeline_decode");
     if (!p || !p->pool || (n && (!data || !len))) return JPGPU_ERR_FORMAT;
     int rc = jpgpu::use_device(p->device, p->err);
     if (rc) return rc;
