@@ -73,6 +73,10 @@ typedef struct jpgpu_worker jpgpu_worker;
 int jpgpu_worker_create(int device, jpgpu_worker **out); /* WorkerScopeInner::Hip(Default) */
 void jpgpu_worker_destroy(jpgpu_worker *w);
 const char *jpgpu_worker_last_error(const jpgpu_worker *w);
+/* Name of the kernels the last jpgpu_compute_image of this worker ran: "generic" (planes -> pixels) or the fused kernel
+ * of the frame's kind ("fused420", ... — coefficients -> pixels in one launch, taken when every component reached the
+ * frame as a complete plane of coefficients at full scale through finish_plane). Diagnostics / tests. */
+const char *jpgpu_worker_last_path(const jpgpu_worker *w);
 
 /* Worker::start(RowData{index, component, quantization_table}) — src/worker/mod.rs:25,
  * src/worker/rayon.rs:40-49.  `quantization_table` is in natural (un-zigzagged) order. */

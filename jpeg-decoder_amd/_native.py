@@ -86,6 +86,7 @@ _PROTOS = {
     "jpgpu_worker_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "jpgpu_worker_destroy": (None, [C.c_void_p]),
     "jpgpu_worker_last_error": (C.c_char_p, [C.c_void_p]),
+    "jpgpu_worker_last_path": (C.c_char_p, [C.c_void_p]),
     "jpgpu_worker_start": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Component), C.c_void_p]),
     "jpgpu_worker_append_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "jpgpu_worker_append_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "fused.hpp"
 #include "host_common.hpp"
 #include "kernels.hpp"
 
@@ -88,7 +89,20 @@ struct jpgpu_worker {
     struct Frame {
         uint8_t *d_plane = nullptr;
         size_t len = 0, cap = 0;
+        // deferred: the plane has not been transformed — its coefficients (a complete plane at dct_scale 8) wait in d_coefs,
+        // and compute_image runs the fused kernel of the frame's kind on them (coefficients -> pixels in one launch, as in a
+        // batch) if every component came this way; anything else that needs the samples transforms them first (materialise)
+        bool deferred = false;
+        int16_t *d_coefs = nullptr;
+        size_t coef_cap = 0;
+        jpgpu_component c{};
     } frame[JPGPU_MAX_COMPONENTS];
+    std::vector<std::pair<int16_t *, size_t>> spare_coefs;  // coefficient buffers between uses, like spare_planes
+    uint16_t *d_frame_qt = nullptr;                          // 4 x 64: the tables of the deferred planes, by frame slot
+    jpgpu::FusedPlan fplan;                                  // one-image plan of the last geometry that took the fused route
+    bool fplan_valid = false;
+    jpgpu_image_desc fplan_desc{};
+    std::string last_path = "generic";
     // planes that went out of use (a frame slot was overwritten): start() takes them back instead of allocating —
     // a worker that decodes image after image reaches a state without any hipMalloc / hipFree (each a device-wide sync)
     std::vector<std::pair<uint8_t *, size_t>> spare_planes;
@@ -184,8 +198,11 @@ void jpgpu::worker_recycle(jpgpu_worker *w) {
     if (!w) return;
     for (auto &f : w->frame) {
         if (f.d_plane) w->spare_planes.emplace_back(f.d_plane, f.cap);
+        if (f.d_coefs) w->spare_coefs.emplace_back(f.d_coefs, f.coef_cap);
         f.d_plane = nullptr;
-        f.len = f.cap = 0;
+        f.d_coefs = nullptr;
+        f.deferred = false;
+        f.len = f.cap = f.coef_cap = 0;
     }
     for (auto &s : w->slot) s.started = false;
     w->err.clear();
@@ -223,8 +240,13 @@ void jpgpu_worker_destroy(jpgpu_worker *w) {
             if (s.d_plane) hipFree(s.d_plane);
         }
         for (auto &sp : w->spare_planes) hipFree(sp.first);
-        for (auto &f : w->frame)
+        for (auto &f : w->frame) {
             if (f.d_plane) hipFree(f.d_plane);
+            if (f.d_coefs) hipFree(f.d_coefs);
+        }
+        for (auto &sp : w->spare_coefs) hipFree(sp.first);
+        if (w->d_frame_qt) hipFree(w->d_frame_qt);
+        if (w->fplan_valid) jpgpu::fused_free(w->fplan);
         for (auto &t : w->d_tmp)
             if (t) hipFree(t);
         if (w->d_out) hipFree(w->d_out);
@@ -235,6 +257,7 @@ void jpgpu_worker_destroy(jpgpu_worker *w) {
 }
 
 const char *jpgpu_worker_last_error(const jpgpu_worker *w) { return w ? w->err.c_str() : ""; }
+const char *jpgpu_worker_last_path(const jpgpu_worker *w) { return w ? w->last_path.c_str() : ""; }
 
 int jpgpu_worker_start(jpgpu_worker *w, uint32_t index, const jpgpu_component *component,
                        const uint16_t quantization_table[64]) {
@@ -271,11 +294,24 @@ int jpgpu_worker_start(jpgpu_worker *w, uint32_t index, const jpgpu_component *c
     memcpy(hq, quantization_table, 128);
     W_HIP(hipMemcpyAsync(s.d_qt, hq, 128, hipMemcpyHostToDevice, w->stream));
     if (s.coef_cap < cbytes) {
-        if (s.d_coefs) W_HIP(hipFree(s.d_coefs));
+        if (s.d_coefs) w->spare_coefs.emplace_back(s.d_coefs, s.coef_cap);
         s.d_coefs = nullptr;
         s.coef_cap = 0;
-        W_HIP(hipMalloc((void **)&s.d_coefs, std::max<size_t>(cbytes, 256)));
-        s.coef_cap = std::max<size_t>(cbytes, 256);
+        for (size_t k = 0; k < w->spare_coefs.size(); k++)
+            if (w->spare_coefs[k].second >= cbytes && w->spare_coefs[k].second <= 2 * std::max<size_t>(cbytes, 256)) {
+                s.d_coefs = w->spare_coefs[k].first;
+                s.coef_cap = w->spare_coefs[k].second;
+                w->spare_coefs.erase(w->spare_coefs.begin() + (long)k);
+                break;
+            }
+        if (!s.d_coefs) {
+            while (w->spare_coefs.size() > 8) {
+                W_HIP(hipFree(w->spare_coefs.front().first));
+                w->spare_coefs.erase(w->spare_coefs.begin());
+            }
+            W_HIP(hipMalloc((void **)&s.d_coefs, std::max<size_t>(cbytes, 256)));
+            s.coef_cap = std::max<size_t>(cbytes, 256);
+        }
     }
     if (s.pinned_cap < cbytes) {
         if (s.h_pinned) W_HIP(hipHostFree(s.h_pinned));
@@ -348,27 +384,61 @@ int jpgpu_worker_finish_plane(jpgpu_worker *w, uint32_t index, uint32_t plane_sl
         return set_err(w->err, JPGPU_ERR_INTERNAL, "get_result on a component that was not started");
     int rc = use_device(w->device, w->err);
     if (rc) return rc;
-    rc = worker_run_idct(w, index);
-    if (rc) return rc;
     auto &s = w->slot[index];
-    if (s.rows) {
-        if (!s.uploaded) W_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
-        W_HIP(hipEventRecord(s.uploaded, w->stream));
-        s.upload_pending = true;
-    }
-    {
+    auto &f = w->frame[plane_slot];
+    if (f.d_plane) w->spare_planes.emplace_back(f.d_plane, f.cap);
+    if (f.d_coefs) w->spare_coefs.emplace_back(f.d_coefs, f.coef_cap);
+    f.d_coefs = nullptr;
+    f.coef_cap = 0;
+    f.deferred = false;
+    static const bool defer_ok = getenv("JPGPU_WORKER_NO_DEFER") == nullptr;  // (A/B and test knob)
+    if (defer_ok && s.c.dct_scale == 8 && s.rows * s.c.vertical_sampling_factor == s.c.block_height && s.rows > 0 && s.idct_rows == 0) {
+        // a complete plane: keep the coefficients, transform later (or never: compute_image's fused route)
+        rc = worker_send_rows(w, index);
+        if (rc) return rc;
+        if (!w->d_frame_qt) W_HIP(hipMalloc((void **)&w->d_frame_qt, JPGPU_MAX_COMPONENTS * 128));
+        W_HIP(hipMemcpyAsync(w->d_frame_qt + plane_slot * 64, s.d_qt, 128, hipMemcpyDeviceToDevice, w->stream));
+        f.deferred = true;
+        f.d_coefs = s.d_coefs;
+        f.coef_cap = s.coef_cap;
+        f.c = s.c;
+        s.d_coefs = nullptr;
+        s.coef_cap = 0;
+    } else {
+        rc = worker_run_idct(w, index);
+        if (rc) return rc;
+        if (s.rows) {
+            if (!s.uploaded) W_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+            W_HIP(hipEventRecord(s.uploaded, w->stream));
+            s.upload_pending = true;
+        }
         const size_t row_bytes = (size_t)s.c.block_width * s.c.vertical_sampling_factor * s.c.dct_scale * s.c.dct_scale, done = s.rows * row_bytes;
         const size_t pbytes = plane_bytes(s.c);
         if (done < pbytes) W_HIP(hipMemsetAsync(s.d_plane + done, 0, pbytes - done, w->stream));
     }
-    auto &f = w->frame[plane_slot];
-    if (f.d_plane) w->spare_planes.emplace_back(f.d_plane, f.cap);
     f.d_plane = s.d_plane;  // mem::take
     f.len = plane_bytes(s.c);
     f.cap = s.plane_cap;
     s.d_plane = nullptr;
     s.plane_cap = 0;
     s.started = false;
+    return JPGPU_OK;
+}
+
+// A deferred plane after all: transform its coefficients into the plane the frame slot holds.
+static int worker_materialise(jpgpu_worker *w, uint32_t plane_slot) {
+    auto &f = w->frame[plane_slot];
+    if (!f.deferred) return JPGPU_OK;
+    PlaneJob job{};
+    job.coefs = f.d_coefs;
+    job.plane = f.d_plane;
+    job.qt = w->d_frame_qt + plane_slot * 64;
+    job.block_w = f.c.block_width;
+    job.n_blocks = (uint32_t)f.c.block_width * f.c.block_height;
+    job.scale = 8;
+    job.flags = 0;
+    W_HIP(launch_idct_plane_one(job, w->stream));
+    f.deferred = false;
     return JPGPU_OK;
 }
 
@@ -383,6 +453,8 @@ int jpgpu_worker_get_result(jpgpu_worker *w, uint32_t index, uint8_t *dst, size_
     if (len) *len = n;
     if (!dst || cap < n) return set_err(w->err, JPGPU_ERR_FORMAT, "get_result: destination too small (%zu < %zu)", cap, n);
     int rc = jpgpu_worker_finish_plane(w, index, index);
+    if (rc) return rc;
+    rc = worker_materialise(w, index);
     if (rc) return rc;
     rc = worker_download(w, dst, w->frame[index].d_plane, n);
     if (rc) return rc;
@@ -436,8 +508,50 @@ int jpgpu_compute_image(jpgpu_worker *w, const jpgpu_component *components, uint
         W_HIP(hipMalloc((void **)&w->d_out, out_len));
         w->out_cap = out_len;
     }
-    job.out = w->d_out;
-    W_HIP(launch_upsample_color_one(job, w->stream));
+    // Every component still as coefficients and the frame of a kind the batch path has a fused kernel for: that kernel, on
+    // this one image (coefficients -> pixels in one launch; wrap-exact arithmetic: nobody classified these coefficients).
+    bool fused = !host_planes;
+    for (uint32_t i = 0; fused && i < ncomp; i++)
+        fused = w->frame[i].deferred && memcmp(&w->frame[i].c, &components[i], sizeof(jpgpu_component)) == 0;
+    if (fused) {
+        jpgpu_image_desc d{};
+        d.ncomp = ncomp;
+        for (uint32_t i = 0; i < ncomp; i++) d.components[i] = components[i];
+        d.out_w = out_w;
+        d.out_h = out_h;
+        d.color_transform = color_transform;
+        fused = fused_kind_key(d) != 0;
+        if (fused && !(w->fplan_valid && memcmp(&w->fplan_desc, &d, sizeof(d)) == 0)) {
+            if (w->fplan_valid) fused_free(w->fplan);
+            w->fplan_valid = false;
+            std::string why;
+            if (!fused_plan(std::vector<jpgpu_image_desc>{d}, std::vector<uint32_t>{0u}, w->fplan, why)) fused = false;
+            else {
+                rc = fused_alloc(w->fplan, w->err);
+                if (rc) return rc;
+                w->fplan_desc = d;
+                w->fplan_valid = true;
+            }
+        }
+        if (fused) {
+            std::vector<size_t> coef_off(4, 0), out_off(1, 0);
+            for (uint32_t i = 0; i < ncomp; i++) coef_off[i] = (size_t)(uintptr_t)w->frame[i].d_coefs;  // absolute: the base is null
+            rc = fused_bind(w->fplan, nullptr, w->d_out, w->d_frame_qt, coef_off, out_off, std::vector<uint8_t>(4, 0), w->err);
+            if (rc) return rc;
+            W_HIP(fused_launch(w->fplan, w->stream));
+            w->last_path = w->fplan.name;
+        }
+    }
+    if (!fused) {
+        w->last_path = "generic";
+        if (!host_planes)
+            for (uint32_t i = 0; i < ncomp; i++) {
+                rc = worker_materialise(w, i);
+                if (rc) return rc;
+            }
+        job.out = w->d_out;
+        W_HIP(launch_upsample_color_one(job, w->stream));
+    }
     rc = worker_download(w, dst, w->d_out, out_len);
     if (rc) return rc;
     for (auto &sl : w->slot) sl.qt_unsynced = 0, sl.upload_pending = false;

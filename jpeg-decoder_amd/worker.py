@@ -90,6 +90,11 @@ class HipWorker:
         """Device-resident get_result: keep the plane in HBM as frame component `plane_slot`."""
         self._check(N.lib().jpgpu_worker_finish_plane(self._h, index, plane_slot))
 
+    @property
+    def last_path(self):
+        """Kernels of the last compute_image: "generic" or the fused kernel of the frame's kind."""
+        return N.lib().jpgpu_worker_last_path(self._h).decode()
+
     def compute_image(self, components, data, output_size, color_transform):
         """compute_image (src/decoder.rs:1300-1336) incl. compute_image_parallel
         (src/worker/mod.rs:97-128).  data: list of planes (np.uint8) or None to use the planes
