@@ -478,34 +478,43 @@ def main(argv=None):
 
     # ---- N > 1: the same job with the final gather inside the timed region, overlapped per sub-batch ----
     if dist and not args.no_gather:
-        gather = PixelGather(dist, torch, rank, world, [shard.pixel_slice(s) for s in range(len(shard.batches))], dev)
+        # (never lose the bench line to the collective: whatever goes wrong in here is reported in the line instead)
+        gather_error = None
+        try:
+            gather = PixelGather(dist, torch, rank, world, [shard.pixel_slice(s) for s in range(len(shard.batches))], dev)
 
-        def step_with_gather():
-            for s, b in enumerate(shard.batches):
-                b.decode(stream)
-                gather.post(s)  # behind sub-batch s on the stream; sub-batch s + 1 decodes while it moves
-            gather.wait()
+            def step_with_gather():
+                for s, b in enumerate(shard.batches):
+                    b.decode(stream)
+                    gather.post(s)  # behind sub-batch s on the stream; sub-batch s + 1 decodes while it moves
+                gather.wait()
 
-        def gather_only():
-            for s in range(len(shard.batches)):
-                gather.post(s)
-            gather.wait()
+            def gather_only():
+                for s in range(len(shard.batches)):
+                    gather.post(s)
+                gather.wait()
 
-        step_with_gather()  # warm-up (communicator set-up)
-        g_elapsed, _ = time_steps(torch, dev, dist, stream, args.gather_steps, step_with_gather)
-        o_elapsed, _ = time_steps(torch, dev, dist, stream, 1, gather_only)
-        g_elapsed, o_elapsed = D.max_over_ranks([g_elapsed, o_elapsed], device=dev)
-        if rank == 0:
-            # the root holds every peer's pixels now: spot-check one image of the last rank
-            chk = gather.recv[world - 2][0][: shard.image_pixels(0).numel()].cpu().numpy()
-            line["gather_verified"] = bool(hashlib.sha256(chk.tobytes()).hexdigest() == hashlib.sha256(shard.image_pixels(0).cpu().numpy().tobytes()).hexdigest()) if nv == 1 else None
-            line["value_with_gather"] = round(mp_per_step * args.gather_steps / g_elapsed, 1)
-            line["ms_per_step_with_gather"] = round(g_elapsed / args.gather_steps * 1e3, 3)
-            line["gather_ms"] = round(o_elapsed * 1e3, 3)
-            line["gather"] = {"bytes_into_root": int(sum(sum(t) for t in gather.sizes[1:])),
-                              "form": "per sub-batch isend/irecv peer -> rank 0 (RCCL), overlapped with the next sub-batch's decode",
-                              "steps": args.gather_steps}
-        del gather
+            step_with_gather()  # warm-up (communicator set-up)
+            g_elapsed, _ = time_steps(torch, dev, dist, stream, args.gather_steps, step_with_gather)
+            o_elapsed, _ = time_steps(torch, dev, dist, stream, 1, gather_only)
+            g_elapsed, o_elapsed = D.max_over_ranks([g_elapsed, o_elapsed], device=dev)
+            if rank == 0:
+                # the root holds every peer's pixels now: spot-check one image of the last rank
+                chk = gather.recv[world - 2][0][: shard.image_pixels(0).numel()].cpu().numpy()
+                line["gather_verified"] = bool(hashlib.sha256(chk.tobytes()).hexdigest() == hashlib.sha256(shard.image_pixels(0).cpu().numpy().tobytes()).hexdigest()) if nv == 1 else None
+                line["value_with_gather"] = round(mp_per_step * args.gather_steps / g_elapsed, 1)
+                line["ms_per_step_with_gather"] = round(g_elapsed / args.gather_steps * 1e3, 3)
+                line["gather_ms"] = round(o_elapsed * 1e3, 3)
+                line["gather"] = {"bytes_into_root": int(sum(sum(t) for t in gather.sizes[1:])),
+                                  "form": "per sub-batch isend/irecv peer -> rank 0 (RCCL), overlapped with the next sub-batch's decode",
+                                  "steps": args.gather_steps}
+            del gather
+        except Exception as e:  # noqa: BLE001
+            gather_error = f"{type(e).__name__}: {e}"[:300]
+        if rank == 0 and gather_error:
+            line["value_with_gather"] = None
+            line["gather_ms"] = None
+            line["gather_error"] = gather_error
 
     # ---- N = 1: what the arithmetic class is worth, and what finding it out on the device costs ----
     if rank == 0 and world == 1 and not args.no_classes and not args.generic:
