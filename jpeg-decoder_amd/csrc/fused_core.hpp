@@ -1124,9 +1124,24 @@ struct F422 {
         const uint32_t ypitch = 16u * g.tx, cp = cpitch(g);
         uint8_t *base = comp == 0u ? lds.coef + cx * 8u : lds.coef + 8u * ypitch + (comp - 1u) * 8u * cp + cx * 8u;
         const uint32_t pitch = comp == 0u ? ypitch : cp;
+        // chroma rows repeat their first / last sample in the column outside the image, so that the pixel phase needs no
+        // edge formula ((3 s + s + 2) >> 2 == s; see F420::row_pixels<.., EDGES = false> and S420::edge_fix)
+        uint32_t out[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) out[i] = r.out[i];
+        typedef typename S420<ARITH, 256>::EdgeFix EdgeFix;
+        const EdgeFix ef = comp == 0u ? EdgeFix{false, false} : S420<ARITH, 256>::edge_fix(g, tile_x * g.tx, cx, out);
 #pragma unroll
         for (int row = 0; row < 8; row++)
-            *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch) = v2u{r.out[2 * row], r.out[2 * row + 1]};
+            *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch) = v2u{out[2 * row], out[2 * row + 1]};
+        if (ef.before) {
+#pragma unroll
+            for (int row = 0; row < 8; row++) (base + (uint32_t)row * pitch)[-1] = (uint8_t)out[2 * row];
+        }
+        if (ef.after) {
+#pragma unroll
+            for (int row = 0; row < 8; row++) (base + (uint32_t)row * pitch)[8] = (uint8_t)(out[2 * row + 1] >> 24);
+        }
     }
     static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
                                                   uint32_t tid, const FusedLdsSmall &lds) {
@@ -1134,6 +1149,8 @@ struct F422 {
         const uint32_t nch = 2u * te;
         const uint32_t ypitch = 16u * g.tx, cp = cpitch(g);
         const uint8_t *ctile = lds.coef + 8u * ypitch;
+        // tiles whose chunks are complete and 4-byte aligned (widths that are multiples of 8): no per-lane store predicate
+        const bool full = (g.out_w & 7u) == 0u && 16u * x0m + 8u * nch <= g.out_w;
         JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
         const size_t pitch = (size_t)g.out_w * 3u;
         const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
@@ -1162,7 +1179,8 @@ struct F422 {
                     t[comp].tEp = e.Ep;
                 }
                 const v2u yy = *reinterpret_cast<const v2u *>(py + 512u * it);
-                P::template row_pixels<true>(g, out + ro + ox0 * 3u, (ro & 3u) == 0, t, yy, ox0);
+                if (full) P::template row_pixels<true, false, true>(g, out + ro + ox0 * 3u, true, t, yy, ox0);
+                else P::template row_pixels<true, false, false>(g, out + ro + ox0 * 3u, (ro & 3u) == 0, t, yy, ox0);
             }
         }
     }
@@ -1233,6 +1251,7 @@ struct F444 {
         const uint32_t ox0 = 8u * (x0m + chk);
         if (ox0 >= g.out_w) return;
         const uint32_t npx = min(8u, g.out_w - ox0);
+        const bool full = (g.out_w & 7u) == 0u && 8u * (x0m + te) <= g.out_w;  // (uniform) every chunk of the tile complete and aligned
         if (ncomp(g) == 4u) {  // (uniform) 32-bit pixels: a lane's 8 pixels are 32 contiguous, 4-byte aligned bytes
             for (uint32_t row = wave; row < 8u; row += 4u) {
                 const uint32_t oy = 8u * my + row;
@@ -1290,7 +1309,7 @@ struct F444 {
                 for (uint32_t k = 0; k < 8; k++)
                     p[k] = ycbcr_raw(byte_of(k < 4 ? s[0].x : s[0].y, k & 3u), byte_of(k < 4 ? s[1].x : s[1].y, k & 3u),
                                      byte_of(k < 4 ? s[2].x : s[2].y, k & 3u));
-                if (npx == 8u && (off & 3u) == 0) {
+                if (full || (npx == 8u && (off & 3u) == 0)) {
                     uint32_t d0, d1, d2, d3, d4, d5;
                     rgb4_to_12bytes(p[0], p[1], p[2], p[3], d0, d1, d2);
                     rgb4_to_12bytes(p[4], p[5], p[6], p[7], d3, d4, d5);
