@@ -76,10 +76,40 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const 
     K::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
 
+// Phase clocks (a diagnostic build: -DJPGPU_PHASE_CLOCKS, tools/gpu_phase_clocks.sh): every wave sums, per phase of the
+// walk, the shader-clock time from the barrier that opened the phase to the end of its own work and from there to the
+// release of the barrier that closes it; jpgpu_debug_phase_clocks() reads the totals.
+#ifdef JPGPU_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clocks[16];
+struct PhaseClock {
+    unsigned long long last, acc[10];
+    __device__ __forceinline__ PhaseClock() : last(__builtin_readcyclecounter()) {
+        for (auto &a : acc) a = 0;
+    }
+    __device__ __forceinline__ void mark(int slot) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        acc[slot] += t - last;
+        last = t;
+    }
+    __device__ __forceinline__ void flush() {
+        if ((threadIdx.x & 63u) == 0u) {
+            for (int i = 0; i < 10; i++) atomicAdd(&g_phase_clocks[i], acc[i]);
+            atomicAdd(&g_phase_clocks[15], 1ull);
+        }
+    }
+};
+#define PHASE_MARK(slot) pc.mark(slot)
+#else
+#define PHASE_MARK(slot) (void)0
+#endif
+
 // Strip walks (4:2:0: S420, 4:4:0: S440 in fused_core.hpp): a = strip, b = row segment
 template <class K>
 __device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
                                           uint8_t *lds_raw) {
+#ifdef JPGPU_PHASE_CLOCKS
+    PhaseClock pc;
+#endif
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
@@ -100,6 +130,7 @@ __device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, c
         K::stage_store(g, strip, tid, lds, pre);
     }
     __syncthreads();
+    PHASE_MARK(8);  // prologue: set-up, seam round, first stage
     for (uint32_t k = k0; k < k1; k++) {
         typename K::Pre pre;  // (declared per iteration: not live around the loop)
         // A fresh, opaque copy of the lane id per phase: otherwise every per-lane address of every phase is hoisted
@@ -107,18 +138,26 @@ __device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, c
         uint32_t t0 = tid, t1 = tid, t2 = tid;
         asm volatile("" : "+v"(t1));
         K::read_block(g, strip, t1, lds, r);
+        PHASE_MARK(0);
         __syncthreads();  // the tiles alias the staging area
+        PHASE_MARK(1);
         K::transform(g, strip, t1, lds, r);
+        PHASE_MARK(2);
         __syncthreads();
+        PHASE_MARK(3);
         const bool more = k + 1u < k1;
         asm volatile("" : "+v"(t2));
         K::colour(g, img, strip, k, 16u * k0, false, t2, lds);
+        PHASE_MARK(4);
         __syncthreads();
+        PHASE_MARK(5);
         if (more) {
             asm volatile("" : "+v"(t0));
             K::stage_load(g, img, strip, k + 1u, t0, pre);
             K::stage_store(g, strip, t0, lds, pre);
+            PHASE_MARK(6);
             __syncthreads();
+            PHASE_MARK(7);
         }
     }
     if (16u * k1 - 1u < g.out_h) {  // the segment's last output row: its far chroma row is the seam row below (or itself at the image's end)
@@ -126,6 +165,10 @@ __device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, c
         __syncthreads();
         K::colour(g, img, strip, k1, 16u * k0, true, tid, lds);
     }
+    PHASE_MARK(9);  // epilogue
+#ifdef JPGPU_PHASE_CLOCKS
+    pc.flush();
+#endif
 }
 
 template <int ARITH, uint32_t NT>
@@ -431,3 +474,14 @@ void fused_free(FusedPlan &plan) {
 }
 
 }  // namespace jpgpu
+
+#ifdef JPGPU_PHASE_CLOCKS
+extern "C" int jpgpu_debug_phase_clocks(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(jpgpu::g_phase_clocks), sizeof(unsigned long long) * 16) != hipSuccess) return 4;
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(jpgpu::g_phase_clocks), zero, sizeof(zero)) != hipSuccess) return 4;
+    }
+    return 0;
+}
+#endif

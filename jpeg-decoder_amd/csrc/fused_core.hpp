@@ -507,8 +507,10 @@ struct S420 {
     // from one run — wave-uniform base, the lane's chunk index as 32-bit offset — so the address math stays
     // scalar; the price is 3+3+2+2 = 10 loads with idle lanes in the last load of each run.
     // Staging block index = lane that transforms it: [0,2te) luma row 0, [2te,4te) luma row 1, then Cb, Cr.
-    // Two halves: stage_load issues the loads (into registers), stage_store puts them into LDS — the kernel issues the
-    // loads of step k+1 before the pixel phase of step k, so their latency is spent computing.
+    // Two halves: stage_load issues the loads (into registers), stage_store puts them into LDS.  (Issuing the loads of
+    // step k+1 before the pixel phase of step k needs 40 more live VGPRs: spills at 4 workgroups per CU, and at 3 — 166
+    // VGPRs, no spills — it measured 0.8 % better, the waves of the other workgroups cover the latency as it is:
+    // profiles/round2/02b_phase_clocks.md.)
     static constexpr uint32_t LY = (16u * (NT == 256 ? S420_TX_MAX : 20u) + NT - 1u) / NT;        // 3
     static constexpr uint32_t LC = (8u * ((NT == 256 ? S420_TX_MAX : 20u) + 2u) + NT - 1u) / NT;  // 2
     struct Pre {
