@@ -452,14 +452,15 @@ struct F420 {
 // The sample tiles alias the coefficient staging area (consumed into registers before they are written).
 // =============================================================================================
 struct S420Lds {
-    uint8_t *stage;   // (6*tx + 4) blocks x 128 B coefficient staging; later the tiles:
+    uint8_t *stage;   // max(6*tx + 4, 4*(tx + 2)) blocks x 128 B coefficient staging; later the tiles:
     uint8_t *ytile;   //   17 rows x ypitch : row 0 = luma row 16k-1 (carry), rows 1..16 = the step's own rows
     uint8_t *ctile;   //   2 comps x 9 rows x cpitch : row 0 = chroma row 8k-1 (carry), rows 1..8 the step's own; column lc <-> plane column 8*(x0m-1) + lc
     uint8_t *carry;   // ypitch + 2*cpitch: last luma / chroma rows of the step before (chroma part: the seam row at a segment start)
     uint8_t *bnd;     // 2*cpitch: chroma row 8*k1 (seam below the segment)
     uint8_t *qtab;    // 3 x 128 B packed quantization tables
     uint32_t ypitch, cpitch;
-    static __device__ __host__ __forceinline__ uint32_t stage_bytes(uint32_t tx) { return (6u * tx + 4u) * 128u; }
+    // (the seam round stages 4*(tx+2) chroma blocks: more than a step's 6*tx+4 when the strip is one MCU wide)
+    static __device__ __host__ __forceinline__ uint32_t stage_bytes(uint32_t tx) { return (tx < 2u ? 4u * (tx + 2u) : 6u * tx + 4u) * 128u; }
     static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx) {
         return stage_bytes(tx) + (16u * tx + 16u * (tx + 2u)) + 16u * (tx + 2u) + 384u;
     }

@@ -143,6 +143,8 @@ GEOMS = [
     (2050, 18, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (672, 65, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (673, 79, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (30, 160, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (36, 20, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (38, 10, [(2, 2), (1, 1), (1, 1)], "YCbCr"),  # last column in pixel 3 / 5 of a chunk
+    (13, 29, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (4, 355, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (14, 38, [(2, 2), (1, 1), (1, 1)], "YCbCr"),  # one MCU wide, several rows (tools/fuzz_gpu_geometry.py)
+    (5, 40, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (8, 100, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (5, 40, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (7, 50, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
     (36, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (38, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (45, 29, [(1, 1), (1, 1), (1, 1)], "RGB"),
     (650, 20, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (1, 1, [(1, 1), (1, 1), (1, 1)], "YCbCr"),

@@ -1,0 +1,24 @@
+"""A short run of the geometry fuzzer (tools/fuzz_gpu_geometry.py) under -m gpu: random sizes x sampling kinds x colour
+transforms x coefficient classes through the batch kernels, one kind per batch and mixed, byte for byte against the oracle.
+(The fuzzer found the one-MCU-wide 4:2:0 seam staging overflow in round 2; longer runs: tools/gpu_fuzz_geometry.sh.)"""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fuzzer():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu_geometry.py")
+    spec = importlib.util.spec_from_file_location("fuzz_gpu_geometry", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("seed", [2026, 2027])
+def test_geometry_fuzz_bit_exact(seed):
+    bad, total, paths = _fuzzer().run(seed, 80, verbose=False)
+    assert total > 200 and bad == 0, (bad, total, paths)
+    assert any(p.startswith("fused") for p in paths) and "mixed" in paths

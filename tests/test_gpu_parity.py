@@ -283,6 +283,9 @@ SAME_GEOMETRY = [
     (1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
     (129, 257, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (13, 29, [(2, 2), (1, 1), (1, 1)], "YCbCr"),  # one MCU wide, several segments: the seam round needs more staging than a step
+    (4, 355, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (5, 100, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
     (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
     (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
