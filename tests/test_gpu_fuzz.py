@@ -9,9 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _fuzzer():
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu_geometry.py")
-    spec = importlib.util.spec_from_file_location("fuzz_gpu_geometry", path)
+def _fuzzer(name="fuzz_gpu_geometry"):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -22,3 +22,10 @@ def test_geometry_fuzz_bit_exact(seed):
     bad, total, paths = _fuzzer().run(seed, 80, verbose=False)
     assert total > 200 and bad == 0, (bad, total, paths)
     assert any(p.startswith("fused") for p in paths) and "mixed" in paths
+
+
+def test_valid_stream_fuzz_bit_exact():
+    """tools/fuzz_gpu_files.py: PIL-encoded streams of random size / sampling / quality / progressive / restart interval through
+    Decoder (Worker route, also with scale()) and Pipeline (host and device entropy decoding) against the oracle's decode."""
+    pytest.importorskip("PIL")
+    assert _fuzzer("fuzz_gpu_files").run(77, 48, verbose=False) == 0
