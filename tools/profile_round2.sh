@@ -34,6 +34,7 @@ JPGPU_420_STRIP=0 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/tf
 JPGPU_420_STRIP=0 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/tw_2p -o p -- $PCMD > /dev/null 2>&1
 cd $R/tools && python make_pmc_traffic.py 1080p-420:fused420-2pass $O/tf_2p $O/tw_2p $O/pmc_traffic.json f420_
 cd $R
+find $O/trace -name '*kernel_stats.csv' -exec cp {} $O/rocprofv3_kernel_stats.csv \;
 rm -rf $O/trace $O/pmc1 $O/pmc2 $O/tf_* $O/tw_*
 cat $O/bench_default.json; cut -c1-40,330-420 $O/bench_other.jsonl | head -0; python - <<PY
 import json
