@@ -271,6 +271,11 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
             why = w;
             return false;
         }
+        if (const char *t = getenv("JPGPU_TX"); t && kind != FUSED_420) {  // experiment: tile / strip width of the other kinds (<= the kind's maximum)
+            FusedGeom &g = plan.geoms[i];
+            g.tx = std::min<uint32_t>(std::max(1, atoi(t)), g.tx * g.tiles_x);
+            g.tiles_x = (g.mcu_w + g.tx - 1) / g.tx;
+        }
         if (i == 0) {
             plan.kind = kind;
             name = nm;

@@ -300,6 +300,13 @@ struct F420 {
     template <bool H2V1 = false, bool EDGES = true, bool FULL = false, bool NTS = true>
     static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *o, bool row_al4,
                                                       const TPrime (&t)[2], v2u yy, uint32_t ox0) {
+#ifdef JPGPU_STUB_COLOUR  // experiment: the stores without the upsampling / conversion arithmetic
+        if (FULL) {
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{yy.x ^ t[0].tE1, yy.y ^ t[1].tO1, t[0].tOm};
+            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{yy.y ^ t[1].tE1, yy.x ^ t[0].tO1, t[1].tEp};
+            return;
+        }
+#endif
         // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
         constexpr uint32_t SH = H2V1 ? 2u : 4u;
         uint32_t pk[2][4];
@@ -532,6 +539,13 @@ struct S420 {
         auto at = [](const JP_GLOBAL v4u *base, uint32_t chunk) -> v4u {
             return *reinterpret_cast<const JP_GLOBAL v4u *>(reinterpret_cast<const JP_GLOBAL uint8_t *>(base) + chunk * 16u);
         };
+#ifdef JPGPU_STUB_LOADS  // experiment: no coefficient loads
+#pragma unroll
+        for (uint32_t i = 0; i < LY; i++) pre.y0[i] = pre.y1[i] = v4u{tid, k, i, 1u};
+#pragma unroll
+        for (uint32_t i = 0; i < LC; i++) pre.cb[i] = pre.cr[i] = v4u{tid, k, i, 2u};
+        return;
+#endif
 #pragma unroll
         for (uint32_t i = 0; i < LY; i++) {
             const uint32_t j = min(tid + NT * i, nl - 1u);  // clamped: unconditional loads
@@ -615,7 +629,12 @@ struct S420 {
             }
             idct8x8<ARITH_EXACT>(cw, qw, out);
         } else {
+#ifdef JPGPU_STUB_IDCT  // experiment: what the launch costs without the transform's arithmetic
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = cw[i] ^ cw[i + 16];
+#else
             idct8x8_products<ARITH>(cw, out);
+#endif
         }
     }
 
