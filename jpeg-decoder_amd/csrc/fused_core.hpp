@@ -742,6 +742,9 @@ struct S420 {
     static __device__ __forceinline__ void seam_transform(const FusedGeom &g, uint32_t strip, uint32_t k0, uint32_t k1, uint32_t tid,
                                                           const Lds &lds) {
         const uint32_t x0m = strip * g.tx, te = txe(g, strip), nb = te + 2u;
+#ifdef JPGPU_STUB_SEAM  // experiment: what shorter segments would cost if the seam round were free
+        return;
+#endif
         if (tid >= 4u * nb) return;
         const uint32_t which = (tid >= nb ? 1u : 0u) + (tid >= 2u * nb ? 1u : 0u) + (tid >= 3u * nb ? 1u : 0u);
         const uint32_t cx = tid - which * nb, c = which & 1u;

@@ -165,6 +165,12 @@ int main() {
         snprintf(nm, sizeof nm, "V4 registers only, %u segments per strip (%u workgroups)", ns, IMGS * 3 * ns);
         run<4>(nm, c, d, 0, ns);
     }
+    for (uint32_t ns : {3u, 68u})
+        for (size_t shm : {(size_t)0, (size_t)20480, (size_t)33792, (size_t)54272}) {  // occupancy of the register-only variant: 8 / 7 / 4 / 2 workgroups per CU
+            char nm[96];
+            snprintf(nm, sizeof nm, "V4 registers only, %u segments, claiming %zu B of LDS", ns, shm);
+            run<4>(nm, c, d, shm, ns);
+        }
     for (uint32_t ns : {4u, 17u, 68u}) {
         char nm[96];
         snprintf(nm, sizeof nm, "V6 full rows per workgroup (3 strips in turn), %u segments (%u wgs)", ns, IMGS * ns);
