@@ -545,6 +545,21 @@ def main(argv=None):
                             "class 0 = arbitrary i16 coefficients (wrap-exact kernels)")
         line["roofline_by_class"] = by_class
 
+    if world == 1 and not args.no_classes:
+        # What the memory system gives an address-ordered stream of the same size and read/write mix, on this box, in this
+        # run: an elementwise add from the coefficient arena into the pixel arena (the pixels are verified by now).  Context
+        # for roofline.frac, which is quoted against the 8 TB/s peak: DESIGN.md 5.0.
+        n4 = min(shard.coef_arena.numel(), shard.out_arena.numel()) // 4 * 4
+        src, dst = shard.coef_arena[:n4].view(torch.int32), shard.out_arena[:n4].view(torch.int32)
+        for _ in range(3):
+            torch.add(src, 1, out=dst)
+        _, ms = time_steps(torch, dev, None, stream, 20, lambda: torch.add(src, 1, out=dst))
+        ref = 2.0 * n4 / (ms * 1e-3) / 1e9
+        line["roofline"]["stream_reference"] = {
+            "achieved": round(ref, 1), "unit": "GB/s", "ms": round(ms, 4), "frac_of_peak": round(ref / HBM_PEAK_GBPS, 4),
+            "kernel_vs_reference": round(line["roofline"]["achieved"] / ref, 4),
+            "what": "torch.add over this workload's own arenas (as many bytes read as written, address order), same box, same run"}
+
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and nv == 1:
             line["cpu_baseline"] = cpu_baseline(O, ocomps, qts, coefs, w, h, ct, args.cpu_seconds)
