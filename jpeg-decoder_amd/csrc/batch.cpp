@@ -556,7 +556,29 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     if (rc) return rc;
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
     hipStream_t s = (hipStream_t)hip_stream;
-    static const uint32_t sync_blocks = env_u32("JPGPU_SYNC_BLOCKS", 48, 4, 1024);  // tuning knob: blocks per chunk aimed at
+    // Chunk size of the chunk decoder: ~48 blocks per chunk settle in the fewest passes and give the best throughput when a
+    // call fills the device (256 x 1080p: 270 k lanes).  A call with few streams is latency-bound instead — three passes in
+    // which every lane walks its whole chunk, ~2.4 us per symbol: one 1080p image is 1,055 lanes and 2.3 ms — so small calls
+    // get smaller chunks and more (cheap once settled) passes: 1080p 3.07 -> 1.68 ms, 2160p 4.82 -> 3.02, 512^2 2.25 -> 1.30
+    // through jpgpu_pipeline_decode (profiles/round2/09_decoder_latency.txt).  The environment knobs pin the values (A/B).
+    static const bool sync_pinned = getenv("JPGPU_SYNC_BLOCKS") || getenv("JPGPU_SYNC_MIN_SHIFT") || getenv("JPGPU_SYNC_LAUNCHES");
+    static const uint32_t env_sync_blocks = env_u32("JPGPU_SYNC_BLOCKS", 48, 1, 1024);      // blocks per chunk aimed at
+    static const uint32_t env_sync_min_shift = env_u32("JPGPU_SYNC_MIN_SHIFT", 10, 7, 15);  // smallest chunk: 1 << this many bits
+    static const uint32_t env_sync_launches = env_u32("JPGPU_SYNC_LAUNCHES", 10, 1, 64);
+    uint32_t sync_blocks = env_sync_blocks, sync_min_shift = env_sync_min_shift, sync_launches = env_sync_launches;
+    if (!sync_pinned) {
+        uint64_t lanes = 0;  // at the throughput setting
+        for (uint32_t k = 0; k < n && images[k].scans; k++)
+            for (const host::PlannedScan &ps : *images[k].scans)
+                if (ps.ri == 0 && ps.seg_off.size() == 2) {
+                    uint32_t blocks = 0;
+                    for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
+                    const uint32_t bytes = (uint32_t)(ps.seg_off[1] - ps.seg_off[0]);
+                    lanes += huff_sync_chunks(bytes, huff_sync_chunk_shift(bytes, blocks * ps.n_mcu, 48u, 10u));
+                }
+        if (lanes < 16384u) sync_blocks = 12u, sync_min_shift = 9u, sync_launches = 16u;
+        else if (lanes < 65536u) sync_blocks = 24u, sync_launches = 12u;
+    }
     size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, n_range = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
@@ -574,7 +596,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 n_sync_jobs++;
                 uint32_t blocks = 0;
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
-                const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks);
+                const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
                 scratch_bytes += align_up((size_t)huff_sync_chunks((uint32_t)stuffed, shift) * 7 * 4, 16);
             } else {
                 n_seg_jobs++;
@@ -663,7 +685,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 memcpy(sj->comp, comp, sizeof(comp));
                 sj->ncomp = ps.ncomp;
                 huff_sync_finish_job(*sj);
-                sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks);
+                sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
                 const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
                 uint32_t *st = reinterpret_cast<uint32_t *>(d + xcur);
                 sj->data = d + dcur;
@@ -752,8 +774,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     }
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
-        static const uint32_t launches = env_u32("JPGPU_SYNC_LAUNCHES", 10, 1, 64), iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
-        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, launches, iters, s));
+        static const uint32_t iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
+        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s));
     }
     B_HIP(launch_range_scan(reinterpret_cast<const RangeJob *>(d + off_range), (uint32_t)n_range, max_blocks,
                             reinterpret_cast<uint32_t *>(d + off_stats), s));

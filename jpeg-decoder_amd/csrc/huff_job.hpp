@@ -81,9 +81,9 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
 // so what matters is the number of BLOCKS in a chunk: ~48 of them (measured: 15 blocks per chunk settle 63 % of the lanes per
 // pass, 60 blocks 98 %), between 1,024 and 32,768 bits, from the stream's average (the stuffed length serves: an upper bound
 // taken before the staging copy).
-inline uint32_t huff_sync_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks, uint32_t blocks_per_chunk = 48u) {
+inline uint32_t huff_sync_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks, uint32_t blocks_per_chunk = 48u, uint32_t min_shift = 10u) {
     const uint64_t target = (uint64_t)stuffed_bytes * 8u * blocks_per_chunk / (total_blocks ? total_blocks : 1u);
-    uint32_t shift = 10;
+    uint32_t shift = min_shift;
     while (shift < 15u && (1ull << shift) * 1414u / 1000u < target) shift++;  // nearest power of two (in the log domain)
     return shift;
 }

@@ -63,6 +63,9 @@ class Decoder:
         """decode() -> Vec<u8> (a numpy uint8 array)."""
         n = C.c_size_t(0)
         cap = N.lib().jpgpu_decoder_output_bytes(self._h)
+        if cap == 0:  # size the buffer from the frame header first: otherwise a large image is decoded into the library's
+            N.lib().jpgpu_decoder_read_info(self._h)  # own buffer and copied twice (an error here is decode()'s too: it raises it)
+            cap = N.lib().jpgpu_decoder_output_bytes(self._h)
         out = np.empty(max(cap, 1), dtype=np.uint8)
         st = N.lib().jpgpu_decoder_decode(self._h, out.ctypes.data, cap, C.byref(n))
         if st and n.value > cap:  # size only known after the frame header was parsed
