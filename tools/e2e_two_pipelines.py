@@ -1,0 +1,24 @@
+"""Two (or N) Pipeline objects driven from as many threads, each decoding batches of 256 x 1080p back to back with device
+entropy decoding: the upload of one call overlaps the kernels of the other.  python tools/e2e_two_pipelines.py [n_pipelines]"""
+import io, os, sys, threading, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import jpeg_decoder_amd as J, synth
+from PIL import Image
+files = []
+for i in range(8):
+    buf = io.BytesIO(); Image.fromarray(synth.synthetic_rgb(1920, 1080, seed=i)).save(buf, format="JPEG", quality=85, subsampling="4:2:0"); files.append(buf.getvalue())
+files = [files[i % 8] for i in range(256)]
+for npipes in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 2, 3]):
+    pipes = [J.Pipeline(threads=max(4, 32 // npipes)) for _ in range(npipes)]
+    for p in pipes: p.decode(files, device_entropy=True, download=False)
+    calls = 8
+    def work(p):
+        for _ in range(calls): p.decode(files, device_entropy=True, download=False)
+    ts = [threading.Thread(target=work, args=(p,)) for p in pipes]
+    t0 = time.perf_counter()
+    for t in ts: t.start()
+    for t in ts: t.join()
+    dt = time.perf_counter() - t0
+    print(f"{npipes} pipeline(s): {npipes * calls * 256 / dt:,.0f} images/s  ({dt / calls * 1e3:.2f} ms per round of {npipes} x 256)", flush=True)
+    for p in pipes: p.close()
