@@ -36,7 +36,12 @@ namespace jpgpu {
 //                   wave waits for memory once per 16 steps and the per-step reads are LDS reads.
 // Measured (256 1080p images): sync passes 2.53 ms with 16-byte pieces, 2.14 ms with dwords; write pass: see DESIGN.md §5.
 enum HuffReader { HUFF_READ_16 = 0, HUFF_READ_DW = 1, HUFF_READ_RING = 2 };
-constexpr uint32_t HUFF_RING_DWORDS = 32, HUFF_RING_AHEAD = 24, HUFF_RING_PERIOD = 16;
+#ifndef JPGPU_RING_DWORDS  // (A/B builds: -DJPGPU_RING_DWORDS=16 -DJPGPU_RING_AHEAD=12 -DJPGPU_RING_PERIOD=8)
+#define JPGPU_RING_DWORDS 32
+#define JPGPU_RING_AHEAD 24
+#define JPGPU_RING_PERIOD 16
+#endif
+constexpr uint32_t HUFF_RING_DWORDS = JPGPU_RING_DWORDS, HUFF_RING_AHEAD = JPGPU_RING_AHEAD, HUFF_RING_PERIOD = JPGPU_RING_PERIOD;
 
 struct DevBits {
     uint64_t bits;   // unread bits, left-aligned

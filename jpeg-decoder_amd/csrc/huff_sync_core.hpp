@@ -165,7 +165,11 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 #ifdef JPGPU_HOST_EMULATION
     constexpr int RD = HUFF_READ_DW;
 #else
+#ifdef JPGPU_WRITE_DW  // (A/B build: the write pass fetches dwords ahead like the sync passes, no LDS ring)
+    constexpr int RD = HUFF_READ_DW;
+#else
     constexpr int RD = WRITE ? HUFF_READ_RING : HUFF_READ_DW;
+#endif
 #endif
     DevBits b;
     huff_open_at<RD>(b, data, pos, ring, ring_stride);

@@ -29,3 +29,9 @@ def test_valid_stream_fuzz_bit_exact():
     Decoder (Worker route, also with scale()) and Pipeline (host and device entropy decoding) against the oracle's decode."""
     pytest.importorskip("PIL")
     assert _fuzzer("fuzz_gpu_files").run(77, 48, verbose=False) == 0
+
+
+def test_extreme_geometries_bit_exact():
+    """tools/extreme_sizes.py: 65535-wide, 65535-tall, one-pixel and 8191x4097 images of every fused kind through the batch path
+    (maximum sizes of SOF0: src/parser.rs:292-298)."""
+    assert _fuzzer("extreme_sizes").run(verbose=False) == []
