@@ -30,7 +30,9 @@ class Decoder:
 
     def close(self):
         if getattr(self, "_h", None):
-            N.lib().jpgpu_decoder_destroy(self._h)
+            lib = N.lib() if N is not None and getattr(N, "lib", None) else None  # (interpreter shutdown: module globals may be gone)
+            if lib is not None:
+                lib.jpgpu_decoder_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

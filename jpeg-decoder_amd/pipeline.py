@@ -24,7 +24,9 @@ class Pipeline:
 
     def close(self):
         if getattr(self, "_h", None):
-            N.lib().jpgpu_pipeline_destroy(self._h)
+            lib = N.lib() if N is not None and getattr(N, "lib", None) else None  # (interpreter shutdown: module globals may be gone)
+            if lib is not None:
+                lib.jpgpu_pipeline_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

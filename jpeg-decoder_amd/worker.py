@@ -37,7 +37,9 @@ class HipWorker:
 
     def close(self):
         if self._h:
-            N.lib().jpgpu_worker_destroy(self._h)
+            lib = N.lib() if N is not None and getattr(N, "lib", None) else None  # (interpreter shutdown: module globals may be gone)
+            if lib is not None:
+                lib.jpgpu_worker_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
