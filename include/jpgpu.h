@@ -191,7 +191,9 @@ int jpgpu_batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const 
  * jpgpu_batch_upload would have given it. If `classes` is not NULL it receives 4 entries per image. */
 int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes);
 /* Replace the quantization table given in the image descriptor (RowData.quantization_table of Worker::start,
- * src/worker/mod.rs:18-22): feeders learn it only while parsing the stream. Takes effect at the next decode. */
+ * src/worker/mod.rs:18-22): feeders learn it only while parsing the stream. Takes effect at the next decode.  If the table
+ * differs from the one in place, the component's range class goes back to 0 (unknown: wrap-exact kernels) — the class of
+ * coefficients uploaded earlier was computed with the old table; upload (or jpgpu_batch_set_range_class / scan_ranges) afterwards. */
 int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t quantization_table[64]);
 
 /* Compact coefficient transport: PCIe carries, per component,

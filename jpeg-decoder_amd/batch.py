@@ -77,6 +77,13 @@ class Batch:
     def out_arena(self):
         return N.lib().jpgpu_batch_out_arena(self._h)
 
+    def set_quantization_table(self, image, comp, table):
+        """jpgpu_batch_set_quantization_table: replace the descriptor's table (the component's range class becomes 0 if it changes)."""
+        q = np.ascontiguousarray(table, dtype=np.uint16).reshape(64)
+        self._check(N.lib().jpgpu_batch_set_quantization_table(self._h, image, comp, q.ctypes.data))
+        for k in range(64):
+            self.descs[image].quantization_tables[comp][k] = int(q[k])
+
     def upload(self, image, comp, coefficients):
         a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
         self._check(N.lib().jpgpu_batch_upload(self._h, image, comp, a.ctypes.data, a.size))

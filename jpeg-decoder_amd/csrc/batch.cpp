@@ -457,7 +457,10 @@ int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) 
 
 int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t comp, const uint16_t q[64]) {
     if (!b || !q || image >= b->descs.size() || comp >= b->descs[image].ncomp) return JPGPU_ERR_FORMAT;
+    if (memcmp(b->descs[image].quantization_tables[comp], q, 128) == 0) return JPGPU_OK;
     memcpy(b->descs[image].quantization_tables[comp], q, 128);
+    // the range class of coefficients already uploaded was computed with the old table (|c*q| bounds): unknown again
+    b->sane[(size_t)image * 4 + comp] = 0;
     b->scan_jobs_valid = false;
     b->qt_dirty = true;
     b->jobs_dirty = true;

@@ -687,3 +687,31 @@ def test_worker_device_resident_flow_takes_the_fused_kernels(case, path, kind):
             assert w.last_path == "generic"
             planes = [O.idct_plane(oc[i], qts[i], coefs[i], n_mcu_rows=(rows0 - 1 if i == 0 else None)) for i in range(len(samp))]
             assert np.array_equal(got, O.compute_image(oc, planes, w_, h_, ct.upper()))
+
+
+def test_batch_quantization_table_replaced_after_upload():
+    """jpgpu_batch_set_quantization_table after the coefficients went up: the class computed at upload time (with the old,
+    small table: tight) must not survive a table under which the products leave the 16-bit range — the decode has to equal
+    the oracle's with the NEW table (wrap-exact arithmetic), for the strip walk and for a tile kernel."""
+    rng = np.random.default_rng(404)
+    for samp in ([(2, 2), (1, 1), (1, 1)], [(1, 1), (1, 1), (1, 1)]):
+        w_, h_ = 80, 48
+        ocomps, _ = O.make_components(w_, h_, samp)
+        small = [np.full(64, 1, np.uint16) for _ in ocomps]
+        big = [rng.integers(2000, 65536, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [rng.integers(-300, 301, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
+        desc = J.image_desc(list(to_j(ocomps)), small, w_, h_, "YCbCr")
+        b = J.Batch([desc, desc])
+        for i in range(2):
+            for c in range(3):
+                b.upload(i, c, coefs[c])
+        assert b.class_counts()[2] == 2  # both images tight under the table of ones
+        for c in range(3):
+            b.set_quantization_table(1, c, big[c])  # image 1 only
+        b.decode()
+        b.synchronize()
+        got0, got1 = b.download(0), b.download(1)
+        assert b.class_counts()[0] == 1 and b.class_counts()[2] == 1
+        b.close()
+        assert np.array_equal(got0, O.pixels_from_coefficients(ocomps, small, coefs, w_, h_, "YCBCR"))
+        assert np.array_equal(got1, O.pixels_from_coefficients(ocomps, big, coefs, w_, h_, "YCBCR"))
