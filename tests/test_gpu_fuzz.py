@@ -35,3 +35,9 @@ def test_extreme_geometries_bit_exact():
     """tools/extreme_sizes.py: 65535-wide, 65535-tall, one-pixel and 8191x4097 images of every fused kind through the batch path
     (maximum sizes of SOF0: src/parser.rs:292-298)."""
     assert _fuzzer("extreme_sizes").run(verbose=False) == []
+
+
+def test_worker_sequence_fuzz_bit_exact():
+    """tools/fuzz_gpu_worker.py: random call sequences over the Worker boundary (prefixes of the rows, get_result / finish_plane,
+    rows one by one / several at once, reduced IDCTs, the worker reused) — planes and pixels against the oracle."""
+    assert _fuzzer("fuzz_gpu_worker").run(5, 120, verbose=False) == 0
