@@ -129,7 +129,7 @@ PipelinePool &pipeline_pool() {
     static PipelinePool *p = new PipelinePool;
     return *p;
 }
-constexpr uint64_t kDeviceEntropyMinPixels = 1500000;  // below, the Worker path is as fast (measured: 1080p 3.5 vs 3.1 ms)
+constexpr uint64_t kDeviceEntropyMinPixels = 900000;  // below, the Worker path is as fast (round 2, q85 4:2:0: 1024x768 1.32-1.48 vs 1.53 ms, 1280x720 1.49 vs 1.33, 1600x900 2.25 vs 1.72)
 }  // namespace
 
 struct jpgpu_decoder {

@@ -29,7 +29,8 @@ def main():
     if not datas:
         import synth
         from PIL import Image
-        for (w, h) in [(512, 512), (1920, 1080), (3840, 2160)]:
+        sizes = [tuple(int(v) for v in t.split('x')) for t in os.environ['SIZES'].split(',')] if os.environ.get('SIZES') else [(512, 512), (1920, 1080), (3840, 2160)]
+        for (w, h) in sizes:
             buf = io.BytesIO()
             Image.fromarray(synth.synthetic_rgb(w, h, seed=1)).save(buf, format="JPEG", quality=85, subsampling="4:2:0")
             datas.append((f"synthetic {w}x{h} 4:2:0 q85", buf.getvalue()))
