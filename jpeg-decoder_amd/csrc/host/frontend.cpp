@@ -904,8 +904,13 @@ struct Frontend::Impl {
             DevHuffTable &d = ps.tables[t];
             memset(&d, 0, sizeof(d));
             if (!h.present) continue;
-            static_assert(sizeof(d.lut) / sizeof(d.lut[0]) == sizeof(h.lut_value) && sizeof(d.values) == sizeof(h.values), "table layouts");
-            for (int i = 0; i < kLutSize; i++) d.lut[i] = (uint16_t)(h.lut_value[i] | (h.lut_size[i] << 8));
+            static_assert(HUFF_LUT_BITS >= 8 && HUFF_LUT_BITS <= kLutBits && sizeof(d.values) == sizeof(h.values), "table layouts");
+            // the device table is the host's wide table cut to HUFF_LUT_BITS: a code that fits has the same entry under every
+            // longer prefix; one that does not is left to the walk (which starts at 9 bits like the reference's, src/huffman.rs:31-58)
+            for (int i = 0; i < (1 << HUFF_LUT_BITS); i++) {
+                const int w = i << (kLutBits - HUFF_LUT_BITS);
+                d.lut[i] = h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS ? (uint16_t)(h.lut_value[w] | (h.lut_size[w] << 8)) : (uint16_t)0;
+            }
             memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode));
             memcpy(d.delta, h.delta, sizeof(d.delta));
             memcpy(d.values, h.values, sizeof(d.values));

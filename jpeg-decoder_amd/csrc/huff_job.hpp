@@ -6,7 +6,10 @@
 
 namespace jpgpu {
 
-constexpr int HUFF_LUT_BITS = 10;  // == kLutBits of the host front-end
+#ifndef JPGPU_DEV_LUT_BITS  // (A/B builds: -DJPGPU_DEV_LUT_BITS=9 — half the LDS per table, more symbols through the bit-serial walk)
+#define JPGPU_DEV_LUT_BITS 10
+#endif
+constexpr int HUFF_LUT_BITS = JPGPU_DEV_LUT_BITS;  // <= kLutBits of the host front-end (10), whose table the device table is cut from
 
 struct alignas(16) DevHuffTable {  // (maxcode[8..15] are read as two 16-byte words)
     uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: symbol | code length << 8 (length 0: not resolved within the lookahead)
