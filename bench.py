@@ -45,6 +45,7 @@ WORKLOADS = {
     "1080p-444": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-422": (1920, 1080, [(2, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "1080p-440": (1920, 1080, [(1, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
+    "1080p-411": (1920, 1080, [(4, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),  # UpsamplerGeneric layout (fusedgen)
     "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
     "1080p-cmyk": (1920, 1080, [(1, 1)] * 4, "cmyk", "CMYK", 192),
     # 4:4:4 and grayscale images interleaved in one batch (two fused launch groups, path "mixed")

@@ -185,6 +185,32 @@ __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restric
     walk_body<S440<ARITH>>(geoms, imgs, work, lds_raw);
 }
 
+// a = tile, b = MCU row
+template <int ARITH>
+__global__ __launch_bounds__(256, 4) void fgen_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                      const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    typedef FGen<ARITH> K;
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
+    const FGenLds lds = FGenLds::make(lds_raw, g.tx, g.hs, g.vs);
+    const uint32_t tid = threadIdx.x;
+    S420Regs r;
+    K::init(img, tid, lds);
+    {
+        typename K::Pre pre;
+        K::stage_load(g, img, w.a, w.b, tid, pre);
+        K::stage_store(g, w.a, tid, lds, pre);
+    }
+    __syncthreads();
+    K::read_block(g, w.a, tid, lds, r);
+    __syncthreads();  // the tiles alias the staging area
+    K::transform(g, w.a, tid, lds, r);
+    __syncthreads();
+    K::colour(g, img, w.a, w.b, tid, lds);
+}
+
 template <int ARITH>
 __global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                    const FusedWork *__restrict__ work) {
@@ -300,6 +326,10 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     if (plan.kind == FUSED_420) plan.nt = plan.strip ? 256u : (tx_max <= 32u ? 128u : 256u);
     plan.lds_bytes = plan.kind == FUSED_440 ? S440Lds::total_bytes(tx_max)
                      : plan.kind != FUSED_420 ? 0 : (plan.strip ? S420Lds::total_bytes(tx_max) : F420Lds::total_bytes(tx_max));
+    if (plan.kind == FUSED_GEN) {  // (images of one launch group may differ in H x V: the largest claim)
+        plan.lds_bytes = 0;
+        for (const auto &g : plan.geoms) plan.lds_bytes = std::max<size_t>(plan.lds_bytes, FGenLds::total_bytes(g.tx, g.hs, g.vs));
+    }
     if (const char *pad = getenv("JPGPU_LDS_PAD")) plan.lds_bytes += (size_t)atoi(pad);  // occupancy experiments: claim more LDS than needed
     plan.scratch_off.assign(n, 0);
     size_t so = 0;
@@ -432,6 +462,7 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         else ARITH_SWITCH(f420_main_kernel, 256);
         break;
     case FUSED_440: ARITH_SWITCH(s440_kernel); break;
+    case FUSED_GEN: ARITH_SWITCH(fgen_kernel); break;
     case FUSED_444: ARITH_SWITCH(f444_kernel); break;
     case FUSED_422: ARITH_SWITCH(f422_kernel); break;
     case FUSED_GRAY: ARITH_SWITCH(fgray_kernel); break;

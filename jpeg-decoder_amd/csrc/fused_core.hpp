@@ -31,7 +31,7 @@ constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
 
 enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1, FCOLOR_CMYK = 2, FCOLOR_YCCK = 3 };  // the last two: four components
-enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4, FUSED_440 = 5 };
+enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4, FUSED_440 = 5, FUSED_GEN = 6 };
 
 struct FusedGeom {
     uint32_t kind;
@@ -47,6 +47,7 @@ struct FusedGeom {
     uint32_t strip;    // 420: 1 = single-launch strip walk (S420), 0 = chroma pass + main pass (F420)
     uint32_t seg_rows; // S420: MCU rows per workgroup
     uint32_t n_seg;    // S420: ceil(mcu_h / seg_rows)
+    uint32_t hs, vs;   // FGen: log2 of the luma sampling factors (H x V luma blocks per MCU)
 };
 
 // One workgroup of a fused launch: which image, and which of its tiles (meaning of a/b per kernel, fused.hip).
@@ -1077,6 +1078,158 @@ struct S440 {
             const uint32_t offa = 2u * slot * pitch + ox0 * 3u, n = min(8u, g.out_w - ox0);
             if (va) row8<false>(base + offa, *reinterpret_cast<const v2u *>(py), vfilter(bu, bl), vfilter(ru, rl), n, ((base_lo + offa) & 3u) == 0);
             if (vb) row8<false>(base + (offa + pitch), *reinterpret_cast<const v2u *>(py + lds.pitch), vfilter(bl, bu), vfilter(rl, ru), n, ((base_lo + offa + pitch) & 3u) == 0);
+        }
+    }
+};
+
+// =============================================================================================
+// FUSED_GEN (round 2): the layouts that fall to UpsamplerGeneric (src/upsampler.rs:230-250) — luma H x V blocks per MCU
+// with H, V in {1, 2, 4} and none of the four fancy-upsampled shapes (4:1:1 = 4x1, 4:1:0 = 4x2, 1x4, 2x4, 4x4), Cb and
+// Cr one block each.  Chroma is replicated: pixel (x, y) takes sample (x / H, y / V); luma is H1V1.  No neighbourhood at
+// all, so a workgroup owns tx MCUs of one MCU row: (H*V + 2) * tx <= 256 blocks, one per lane, staged and transformed like
+// the strip walks' (quantization tables in LDS, multiplied during the fetch), then the pixel phase walks the tile's 8V rows
+// in 8-pixel chunks and reuses the 4:4:0 kernel's row arithmetic on the replicated samples.
+// =============================================================================================
+struct FGenLds {
+    uint8_t *stage;  // tx*(H*V+2) blocks x 128 B coefficient staging; later the tiles:
+    uint8_t *ytile;  //   8V rows x ypitch (8*H*tx)
+    uint8_t *ctile;  //   2 components x 8 rows x cpitch (8*tx)
+    uint8_t *qtab;   // 3 x 128 B
+    uint32_t ypitch, cpitch;
+    static __device__ __host__ __forceinline__ uint32_t stage_bytes(uint32_t tx, uint32_t hs, uint32_t vs) { return tx * ((1u << (hs + vs)) + 2u) * 128u; }
+    static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx, uint32_t hs, uint32_t vs) { return stage_bytes(tx, hs, vs) + 384u; }
+    static __device__ __forceinline__ FGenLds make(uint8_t *base, uint32_t tx, uint32_t hs, uint32_t vs) {
+        FGenLds l;
+        l.ypitch = (8u << hs) * tx;
+        l.cpitch = 8u * tx;
+        l.stage = base;
+        l.ytile = base;
+        l.ctile = base + (8u << vs) * l.ypitch;  // tiles: 64*tx*(H*V + 2) bytes, half the staging area
+        l.qtab = base + stage_bytes(tx, hs, vs);
+        return l;
+    }
+};
+inline __device__ __host__ uint32_t fgen_tx_max(uint32_t hs, uint32_t vs) { return 256u / ((1u << (hs + vs)) + 2u); }
+
+template <int ARITH>
+struct FGen {
+    typedef FGenLds Lds;
+    typedef S420<ARITH, 256> W;  // block fetch / transform helpers (they only look at lds.stage and lds.qtab)
+    typedef S440<ARITH> R;       // row8: eight pixels from eight luma bytes and centred chroma lanes
+    static constexpr uint32_t NT = 256;
+    struct Pre {
+        v4u v[8];  // (H*V + 2) * tx * 8 <= 2048 chunks: eight per lane
+    };
+    static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) { return min(g.tx, g.mcu_w - tile_x * g.tx); }
+    static __device__ __forceinline__ void init(const FusedImage &img, uint32_t tid, const Lds &lds) {
+        if (tid < 32u) {
+            uint32_t *d = reinterpret_cast<uint32_t *>(lds.qtab);
+            d[tid] = ((const JP_GLOBAL uint32_t *)img.qt[0])[tid];
+            d[32u + tid] = ((const JP_GLOBAL uint32_t *)img.qt[1])[tid];
+            d[64u + tid] = ((const JP_GLOBAL uint32_t *)img.qt[2])[tid];
+        }
+    }
+    // Chunk c of the tile (16 bytes): the V luma block rows first (8*te*H chunks each, contiguous in the plane), then Cb, Cr
+    // (8*te each).  Staging block index = lane that transforms it: luma row r block j -> r*te*H + j, Cb -> te*H*V + j, Cr after.
+    static __device__ __forceinline__ void stage_load(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my, uint32_t tid, Pre &pre) {
+        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
+        const uint32_t nly = (8u << g.hs) * te, ncl = nly << g.vs, ncc = 8u * te, total = ncl + 2u * ncc;
+        const JP_GLOBAL v4u *y = (const JP_GLOBAL v4u *)img.coefs[0] + (((size_t)my << g.vs) * g.bw0 + ((size_t)x0m << g.hs)) * 8u;
+        const JP_GLOBAL v4u *cb = (const JP_GLOBAL v4u *)img.coefs[1] + ((size_t)my * g.bwc + x0m) * 8u;
+        const JP_GLOBAL v4u *cr = (const JP_GLOBAL v4u *)img.coefs[2] + ((size_t)my * g.bwc + x0m) * 8u;
+        const uint32_t row_chunks = g.bw0 * 8u;  // chunks between luma block rows
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t c = min(tid + NT * i, total - 1u);  // clamped: unconditional loads
+            if (c < ncl) {
+                const uint32_t r = (c >= nly ? 1u : 0u) + (c >= 2u * nly ? 1u : 0u) + (c >= 3u * nly ? 1u : 0u);
+                pre.v[i] = y[r * row_chunks + (c - r * nly)];
+            } else {
+                const uint32_t d = c - ncl;
+                pre.v[i] = d >= ncc ? cr[d - ncc] : cb[d];
+            }
+        }
+    }
+    static __device__ __forceinline__ void stage_store(const FusedGeom &g, uint32_t tile_x, uint32_t tid, const Lds &lds, const Pre &pre) {
+        const uint32_t te = txe(g, tile_x);
+        const uint32_t total = ((8u << (g.hs + g.vs)) + 16u) * te;
+        v4u *dst = reinterpret_cast<v4u *>(lds.stage);
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t c = tid + NT * i;  // (runs are whole blocks: chunk c belongs to staging block c >> 3, row c & 7)
+            if (c < total) dst[coef_slot(c >> 3, c & 7u)] = pre.v[i];
+        }
+    }
+    // lane -> its block: component and position in the tiles
+    static __device__ __forceinline__ bool lane_block(const FusedGeom &g, uint32_t te, uint32_t tid, uint32_t &comp, uint32_t &ry, uint32_t &cx) {
+        const uint32_t nl = te << (g.hs + g.vs);
+        if (tid < nl) {
+            const uint32_t per_row = te << g.hs;  // luma blocks per block row of the tile
+            comp = 0u;
+            ry = (tid >= per_row ? 1u : 0u) + (tid >= 2u * per_row ? 1u : 0u) + (tid >= 3u * per_row ? 1u : 0u);
+            cx = tid - ry * per_row;
+            return true;
+        }
+        const uint32_t t = tid - nl;
+        comp = t >= te ? 2u : 1u;
+        ry = 0u;
+        cx = t - (comp - 1u) * te;
+        return t < 2u * te;
+    }
+    static __device__ __forceinline__ void read_block(const FusedGeom &g, uint32_t tile_x, uint32_t tid, const Lds &lds, S420Regs &r) {
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, txe(g, tile_x), tid, comp, ry, cx)) return;
+        W::fetch_block(lds, tid, comp, r.cw);
+    }
+    static __device__ __forceinline__ void transform(const FusedGeom &g, uint32_t tile_x, uint32_t tid, const Lds &lds, S420Regs &r) {
+        uint32_t comp, ry, cx;
+        if (!lane_block(g, txe(g, tile_x), tid, comp, ry, cx)) return;
+        uint32_t out[16];
+        W::transform_block(lds, comp, r.cw, out);
+        const uint32_t pitch = comp == 0u ? lds.ypitch : lds.cpitch;
+        uint8_t *base = comp == 0u ? lds.ytile + ry * 8u * lds.ypitch + cx * 8u : lds.ctile + (comp - 1u) * 8u * lds.cpitch + cx * 8u;
+#pragma unroll
+        for (int row = 0; row < 8; row++) *reinterpret_cast<v2u *>(base + (uint32_t)row * pitch) = v2u{out[2 * row], out[2 * row + 1]};
+    }
+    // eight replicated chroma samples of one component as centred 16-bit lanes (S440::C8: (s0,s2) (s1,s3) (s4,s6) (s5,s7))
+    static __device__ __forceinline__ typename R::C8 replicate(const uint8_t *crow, uint32_t chk, uint32_t hs) {
+        typename R::C8 c;
+        const uint32_t m = 0x00ff00ffu, centre = 0xff80ff80u;  // - 128 per lane
+        if (hs == 0u) {  // eight samples
+            const v2u w = *reinterpret_cast<const v2u *>(crow + 8u * chk);
+            c.e0 = w.x & m, c.o0 = (w.x >> 8) & m, c.e1 = w.y & m, c.o1 = (w.y >> 8) & m;
+        } else if (hs == 1u) {  // four samples, each twice: (t0,t0,t1,t1,t2,t2,t3,t3)
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(crow + 4u * chk);
+            c.e0 = c.o0 = (d & 0xffu) | ((d & 0xff00u) << 8);
+            c.e1 = c.o1 = ((d >> 16) & 0xffu) | ((d >> 24) << 16);
+        } else {  // two samples, each four times
+            const uint32_t d = *reinterpret_cast<const uint16_t *>(crow + 2u * chk);
+            c.e0 = c.o0 = (d & 0xffu) * 0x00010001u;
+            c.e1 = c.o1 = (d >> 8) * 0x00010001u;
+        }
+        c.e0 = pk_add(c.e0, centre), c.o0 = pk_add(c.o0, centre), c.e1 = pk_add(c.e1, centre), c.o1 = pk_add(c.o1, centre);
+        return c;
+    }
+    static __device__ __forceinline__ void colour(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my, uint32_t tid, const Lds &lds) {
+        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
+        const uint32_t nchk = te << g.hs, nunits = nchk << (3u + g.vs);  // rows x chunks: <= 2048
+        const uint32_t magic = nchk > 1u ? 0xffffffffu / nchk + 1u : 0u;  // mul_hi(u, magic) == u / nchk for u < 65536
+        const uint32_t pitch = g.out_w * 3u;
+        const uint32_t oy0 = (my << g.vs) * 8u, ox_tile = (x0m << g.hs) * 8u;
+        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
+        const bool full = (g.out_w & 7u) == 0u && ox_tile + 8u * nchk <= g.out_w;  // (uniform) every chunk complete and 4-byte aligned
+#pragma unroll 1
+        for (uint32_t u = tid; u < nunits; u += NT) {
+            const uint32_t row = nchk > 1u ? __umulhi(u, magic) : u, chk = u - row * nchk;
+            const uint32_t oy = oy0 + row, ox0 = ox_tile + 8u * chk;
+            if (oy >= g.out_h || ox0 >= g.out_w) continue;
+            const v2u yy = *reinterpret_cast<const v2u *>(lds.ytile + row * lds.ypitch + 8u * chk);
+            const uint32_t crow = row >> g.vs;
+            const typename R::C8 cb = replicate(lds.ctile + crow * lds.cpitch, chk, g.hs);
+            const typename R::C8 cr = replicate(lds.ctile + (8u + crow) * lds.cpitch, chk, g.hs);
+            const size_t off = (size_t)oy * pitch + ox0 * 3u;
+            if (full) R::template row8<true>(out + off, yy, cb, cr, 8u, true);
+            else R::template row8<false>(out + off, yy, cb, cr, min(8u, g.out_w - ox0), (off & 3u) == 0u);
         }
     }
 };

@@ -91,6 +91,28 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
         // is bound by the memory system — 0.834 ms with 60, 0.809 with 64/64/64/48, 0.757 with five strips of 48 (256 x 1080p).
         tx_max = 48u;
         g.strip = 1u;
+    } else if (d0.ncomp == 3 && hv(1, 1, 1) && hv(2, 1, 1) && d0.color_transform == JPGPU_CT_YCBCR && d0.out_w > 1 && d0.out_h > 1 &&
+               fused_same_component(d0.components[1], d0.components[2]) &&
+               (hv(0, 4, 1) || hv(0, 4, 2) || hv(0, 1, 4) || hv(0, 2, 4) || hv(0, 4, 4))) {
+        // 4:1:1, 4:1:0 and their transposes: neither factor pair is one of the fancy upsamplers' (choose_upsampler,
+        // src/upsampler.rs:80-105), the chroma components get UpsamplerGeneric.  (An output width / height of 1 would turn
+        // the choice into H1V1: generic path.)
+        kind = FUSED_GEN;
+        name = "fusedgen";
+        const uint32_t H = d0.components[0].horizontal_sampling_factor, V = d0.components[0].vertical_sampling_factor;
+        g.hs = H == 4 ? 2u : (H == 2 ? 1u : 0u);
+        g.vs = V == 4 ? 2u : (V == 2 ? 1u : 0u);
+        g.mcu_w = d0.components[1].block_width;
+        g.mcu_h = d0.components[1].block_height;
+        g.bwc = d0.components[1].block_width;
+        g.cw = d0.components[1].size_width;
+        g.ch = d0.components[1].size_height;
+        if (d0.components[0].block_width != H * g.mcu_w || d0.components[0].block_height != V * g.mcu_h || d0.out_w > H * g.cw ||
+            d0.out_h > V * g.ch || d0.out_w > 8u * H * g.mcu_w || d0.out_h > 8u * V * g.mcu_h) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = fgen_tx_max(g.hs, g.vs);
     } else if (d0.ncomp == 3 && hv(0, 1, 1) && hv(1, 1, 1) && hv(2, 1, 1) &&
                (d0.color_transform == JPGPU_CT_YCBCR || d0.color_transform == JPGPU_CT_RGB) &&
                fused_same_component(d0.components[0], d0.components[1]) &&

@@ -72,6 +72,36 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         else run_walk<S420<ARITH_EXACT, 256>>(g, im);
         return kind;
     }
+    if (kind == FUSED_GEN) {  // fgen_kernel, phase by phase
+        FusedImage im{};
+        for (uint32_t c = 0; c < desc->ncomp; c++) {
+            im.coefs[c] = coefs[c];
+            im.qt[c] = desc->quantization_tables[c];
+        }
+        im.out = out;
+        if (tx_out) *tx_out = g.tx;
+        std::vector<uint8_t> mem(FGenLds::total_bytes(g.tx, g.hs, g.vs) + 64);
+        std::vector<S420Regs> regs(256);
+        auto run = [&](auto K) {
+            typedef decltype(K) KK;
+            std::vector<typename KK::Pre> pre(256);
+            for (uint32_t my = 0; my < g.mcu_h; my++)
+                for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
+                    memset(mem.data(), 0xCD, mem.size());
+                    const FGenLds lds = FGenLds::make(mem.data(), g.tx, g.hs, g.vs);
+                    for (uint32_t t = 0; t < 256; t++) KK::init(im, t, lds);
+                    for (uint32_t t = 0; t < 256; t++) KK::stage_load(g, im, tile, my, t, pre[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::stage_store(g, tile, t, lds, pre[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::read_block(g, tile, t, lds, regs[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::transform(g, tile, t, lds, regs[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::colour(g, im, tile, my, t, lds);
+                }
+        };
+        if (sane == 2) run(FGen<ARITH_TIGHT>{});
+        else if (sane) run(FGen<ARITH_SANE>{});
+        else run(FGen<ARITH_EXACT>{});
+        return kind;
+    }
     if (tx_out) *tx_out = g.tx;
     FusedImage img{};
     for (uint32_t c = 0; c < desc->ncomp; c++) {

@@ -153,6 +153,9 @@ GEOMS = [
     (993, 10, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (1920, 16, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (2017, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (64, 48, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (8, 2, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
     (3, 5, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (520, 80, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (1032, 33, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (17, 160, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+    (64, 24, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (333, 21, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (3, 9, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (1400, 9, [(4, 1), (1, 1), (1, 1)], "YCbCr"),
+    (70, 40, [(4, 2), (1, 1), (1, 1)], "YCbCr"), (821, 17, [(4, 2), (1, 1), (1, 1)], "YCbCr"), (40, 70, [(1, 4), (1, 1), (1, 1)], "YCbCr"), (345, 33, [(1, 4), (1, 1), (1, 1)], "YCbCr"),
+    (50, 61, [(2, 4), (1, 1), (1, 1)], "YCbCr"), (417, 35, [(2, 4), (1, 1), (1, 1)], "YCbCr"), (50, 61, [(4, 4), (1, 1), (1, 1)], "YCbCr"), (460, 33, [(4, 4), (1, 1), (1, 1)], "YCbCr"), (2, 2, [(4, 4), (1, 1), (1, 1)], "YCbCr"),
     (45, 29, [(1, 1)] * 4, "CMYK"), (45, 29, [(1, 1)] * 4, "YCCK"), (650, 20, [(1, 1)] * 4, "YCCK"), (513, 9, [(1, 1)] * 4, "CMYK"), (1, 1, [(1, 1)] * 4, "CMYK"),
     (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
     (1000, 1, [(1, 1)], "Grayscale"),
@@ -196,7 +199,7 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
 def test_planner_keeps_odd_geometries_on_the_generic_path():
     for (w_, h_, samp, ct) in [(1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
                                (1, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 1, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
-                               (64, 64, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 1), (1, 1), (1, 1)], "RGB"), (64, 64, [(2, 2)], "Grayscale"),
+                               (64, 64, [(3, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(4, 1), (2, 1), (1, 1)], "YCbCr"), (64, 1, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 1), (1, 1), (1, 1)], "RGB"), (64, 64, [(2, 2)], "Grayscale"),
                                (64, 64, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (64, 64, [(1, 1)] * 4, "None")]:
         rng = np.random.default_rng(0)
         ocomps, _ = O.make_components(w_, h_, samp)

@@ -259,11 +259,13 @@ def test_batch_heterogeneous_mixed_paths():
         _batch_case(rng, 100, 9, [(1, 1)], "Grayscale"),
         _batch_case(rng, 31, 70, [(2, 1), (1, 1), (1, 1)], "YCbCr", kind="full"),
         _batch_case(rng, 16, 16, [(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"),
-        _batch_case(rng, 70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"),
+        _batch_case(rng, 70, 40, [(3, 1), (1, 1), (1, 1)], "YCbCr"),
         _batch_case(rng, 50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+        _batch_case(rng, 70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"),
+        _batch_case(rng, 90, 50, [(4, 2), (1, 1), (1, 1)], "YCbCr"),
     ]
     outs, path = _run_batch(cases)
-    assert path == "mixed"  # every fusable kind gets its own launch; 4:1:1 (and whatever else has no fused kernel) the generic kernels
+    assert path == "mixed"  # every fusable kind gets its own launch; 3:1:1 (and whatever else has no fused kernel) the generic kernels
     outs_g, path_g = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
     assert path_g == "generic"
     outs_2, path_2 = _run_batch(cases[4:])
@@ -293,6 +295,11 @@ SAME_GEOMETRY = [
     (2, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
     (37, 21, [(1, 1)], "Grayscale"),
     (300, 200, [(1, 1)], "Grayscale"),
+    (333, 45, [(4, 1), (1, 1), (1, 1)], "YCbCr"),  # UpsamplerGeneric layouts: fusedgen
+    (150, 70, [(4, 2), (1, 1), (1, 1)], "YCbCr"),
+    (61, 150, [(1, 4), (1, 1), (1, 1)], "YCbCr"),
+    (130, 97, [(2, 4), (1, 1), (1, 1)], "YCbCr"),
+    (200, 129, [(4, 4), (1, 1), (1, 1)], "YCbCr"),
 ]
 
 
@@ -650,8 +657,9 @@ def test_one_hostile_image_costs_only_itself(samp, ct, strip, monkeypatch):
 @pytest.mark.parametrize("case,path", [((250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"), "fused420"), ((200, 120, [(1, 1)] * 3, "YCbCr"), "fused444"),
                                        ((64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), "fused422"), ((50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"), "fused440"),
                                        ((37, 21, [(1, 1)], "Grayscale"), "fusedgray"), ((45, 29, [(1, 1)] * 4, "CMYK"), "fused444x4"),
-                                       ((70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"), "generic")],
-                         ids=["420", "444", "422", "440", "gray", "cmyk", "411"])
+                                       ((70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"), "fusedgen"),
+                                       ((70, 40, [(3, 1), (1, 1), (1, 1)], "YCbCr"), "generic")],
+                         ids=["420", "444", "422", "440", "gray", "cmyk", "411", "311"])
 @pytest.mark.parametrize("kind", ["sparse", "full"])
 def test_worker_device_resident_flow_takes_the_fused_kernels(case, path, kind):
     """The drop-in surface (start / append_row / finish_plane / compute_image, what rust/src/worker/hip.rs calls): complete

@@ -9,7 +9,7 @@ import jpeg_decoder_amd as J
 import test_gpu_parity as T
 T.J = J
 KINDS = {"420": ([(2, 2), (1, 1), (1, 1)], "YCbCr"), "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr"), "444": ([(1, 1)] * 3, "YCbCr"),
-         "440": ([(1, 2), (1, 1), (1, 1)], "YCbCr"), "gray": ([(1, 1)], "Grayscale"), "cmyk": ([(1, 1)] * 4, "CMYK")}
+         "440": ([(1, 2), (1, 1), (1, 1)], "YCbCr"), "411": ([(4, 1), (1, 1), (1, 1)], "YCbCr"), "44x": ([(4, 4), (1, 1), (1, 1)], "YCbCr"), "gray": ([(1, 1)], "Grayscale"), "cmyk": ([(1, 1)] * 4, "CMYK")}
 SIZES = [(65535, 17), (17, 65535), (65500, 40), (8191, 4097), (1, 65535), (65535, 1), (2, 2), (65535, 2), (3, 65534)]
 
 
