@@ -8,7 +8,7 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 : > $O/bench_other.jsonl
-for wl in 1080p-444 1080p-422 1080p-440 1080p-gray 1080p-cmyk 1080p-444+gray 2160p-420; do
+for wl in 1080p-444 1080p-422 1080p-440 1080p-411 1080p-gray 1080p-cmyk 1080p-444+gray 2160p-420; do
   timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-classes >> $O/bench_other.jsonl 2>> $O/bench_other.err
 done
 JPGPU_420_STRIP=0 timeout 300 python bench.py --no-cpu-baseline --no-classes >> $O/bench_other.jsonl 2>> $O/bench_other.err   # round 1's two-pass 4:2:0 on the same box
@@ -22,7 +22,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLE
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/pmc2 -o p -- $PCMD > $O/pmc2.log 2>&1
 cd $R
 python tools/prof_summary.py $O/pmc1 $O/pmc2 $O/trace > $O/kernel_trace_stats_and_pmc.json 2> $O/summary.err
-for spec in "1080p-420:fused420:s420_" "1080p-444:fused444:f444_" "1080p-422:fused422:f422_" "1080p-440:fused440:s440_" "1080p-gray:fusedgray:fgray_" "1080p-cmyk:fused444x4:f444_" "2160p-420:fused420:s420_"; do
+for spec in "1080p-420:fused420:s420_" "1080p-411:fusedgen:fgen_" "1080p-444:fused444:f444_" "1080p-422:fused422:f422_" "1080p-440:fused440:s440_" "1080p-gray:fusedgray:fgray_" "1080p-cmyk:fused444x4:f444_" "2160p-420:fused420:s420_"; do
   IFS=: read wl path pat <<< "$spec"
   cd /tmp
   timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/tf_$wl -o p -- python $R/bench.py --workload $wl --steps 40 --warmup 10 --no-cpu-baseline --no-classes > /dev/null 2>&1
