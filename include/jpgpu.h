@@ -77,6 +77,10 @@ const char *jpgpu_worker_last_error(const jpgpu_worker *w);
  * of the frame's kind ("fused420", ... — coefficients -> pixels in one launch, taken when every component reached the
  * frame as a complete plane of coefficients at full scale through finish_plane). Diagnostics / tests. */
 const char *jpgpu_worker_last_path(const jpgpu_worker *w);
+/* Range class (0, 1 or 3: see jpgpu_batch_set_range_hint) the fused kernel of the last jpgpu_compute_image ran with; -1 if
+ * that call took the generic kernels.  The class is worked out on the device from the frame's coefficients (one scan at HBM
+ * speed in front of the kernel, nothing read back); this call reads it back (blocking).  Diagnostics / tests. */
+int jpgpu_worker_last_class(jpgpu_worker *w);
 
 /* Worker::start(RowData{index, component, quantization_table}) — src/worker/mod.rs:25,
  * src/worker/rayon.rs:40-49.  `quantization_table` is in natural (un-zigzagged) order. */
@@ -177,7 +181,9 @@ int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t qu
  *   jpgpu_batch_add_deltas: coefficient[entries[k].index] += entries[k].delta (i16 wrapping) in component `comp` of
  *   `image`; index = block number in raster order * 64 + position in natural order.  An index must not occur twice in
  *   one call; calls on the same stream are applied in order.  `entries` is host memory and must stay valid until the
- *   stream has been synchronised.  The image's range class becomes 0 (unknown) — see jpgpu_batch_scan_ranges. */
+ *   stream has been synchronised.  The image's range class is worked out on the device from what the kernel adds up
+ *   (every value a coefficient takes is ranged with the component's quantization table as the device holds it; see
+ *   jpgpu_batch_classify_on_device). */
 typedef struct jpgpu_coef_delta {
     uint32_t index;
     int32_t delta;
@@ -190,6 +196,14 @@ int jpgpu_batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const 
  * one pass over the arena at HBM speed on `hip_stream`, blocking; afterwards every component has the range class
  * jpgpu_batch_upload would have given it. If `classes` is not NULL it receives 4 entries per image. */
 int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes);
+/* The classification WITHOUT the host: one pass over the arena on `hip_stream` (asynchronous, nothing is read back) leaves
+ * per-image range statistics on the device, and from then on every jpgpu_batch_decode turns them into the images' classes
+ * there (a few-microsecond kernel in front of the pixel kernels, which pick their arithmetic per workgroup) — no host
+ * synchronisation between whoever wrote the coefficients and the pixel kernels.  The library's own writers leave the same
+ * statistics as a by-product and need no pass at all: the device entropy decoder (jpgpu_pipeline_decode with
+ * JPGPU_PIPELINE_DEVICE_ENTROPY), jpgpu_batch_upload_compact with range_class < 0, jpgpu_batch_add_deltas.  A class set from
+ * the host afterwards (upload, set_range_hint / set_range_class, scan_ranges) takes over again for that component. */
+int jpgpu_batch_classify_on_device(jpgpu_batch *b, void *hip_stream);
 /* Replace the quantization table given in the image descriptor (RowData.quantization_table of Worker::start,
  * src/worker/mod.rs:18-22): feeders learn it only while parsing the stream. Takes effect at the next decode.  If the table
  * differs from the one in place, the component's range class goes back to 0 (unknown: wrap-exact kernels) — the class of
@@ -204,7 +218,8 @@ int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t 
  * (<= jpgpu_compact_max_bytes) and, if asked, the range class of jpgpu_batch_set_range_hint.
  * jpgpu_batch_upload_compact validates the buffer, copies it asynchronously on `hip_stream` (the buffer must stay
  * valid until that stream reaches the copy; use pinned memory for real overlap) and marks the component for expansion;
- * it also sets the component's range class when `range_class` >= 0. */
+ * it also sets the component's range class when `range_class` >= 0; with `range_class` < 0 (the sender did not classify)
+ * the expansion kernel ranges the values on the device while it has them in registers (jpgpu_batch_classify_on_device). */
 size_t jpgpu_compact_max_bytes(size_t n_blocks);
 size_t jpgpu_compact_encode(const int16_t *coefficients, size_t n_blocks, const uint16_t quantization_table[64], void *dst,
                             int *range_class);

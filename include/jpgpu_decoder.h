@@ -95,6 +95,15 @@ typedef struct jpgpu_pipeline_timings {
     uint64_t jpeg_bytes, coefficient_bytes, pixel_bytes;
     uint32_t images_device_entropy;  /* entropy-decoded on the device (JPGPU_PIPELINE_DEVICE_ENTROPY) ... */
     uint32_t images_device_rejected; /* ... of which the device decoder handed this many back to the host */
+    /* Kernel time of the device entropy route, by phase, from events on each sub-batch's own stream and summed over the
+     * sub-batches (they overlap one another and the host: a breakdown of GPU work, not of the call's wall time).  Recorded only
+     * when the environment variable JPGPU_BATCH_KERNEL_TIMES is set (the events cost a few microseconds per sub-batch):
+     *   dev_fill_ms   zero fill of the coefficient planes and statistics
+     *   dev_sync_ms   restart-segment decoder + the chunk decoder's sync passes + block numbering
+     *   dev_write_ms  write pass (coefficients and, as a by-product, their range statistics) + DC sums
+     *   dev_pixel_ms  class finalize + pixel kernels (dequantize, IDCT, upsampling, colour conversion) */
+    uint32_t dev_times_valid, _pad;
+    double dev_fill_ms, dev_sync_ms, dev_write_ms, dev_pixel_ms;
 } jpgpu_pipeline_timings;
 
 enum {

@@ -54,7 +54,9 @@ class ImageDesc(C.Structure):
 class PipelineTimings(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "kernels_ms", "download_ms", "total_ms")] + \
                [("threads", C.c_uint32), ("images_ok", C.c_uint32), ("jpeg_bytes", C.c_uint64), ("coefficient_bytes", C.c_uint64),
-                ("pixel_bytes", C.c_uint64), ("images_device_entropy", C.c_uint32), ("images_device_rejected", C.c_uint32)]
+                ("pixel_bytes", C.c_uint64), ("images_device_entropy", C.c_uint32), ("images_device_rejected", C.c_uint32),
+                ("dev_times_valid", C.c_uint32), ("_pad", C.c_uint32)] + \
+               [(n, C.c_double) for n in ("dev_fill_ms", "dev_sync_ms", "dev_write_ms", "dev_pixel_ms")]
 
 
 PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_PROGRESSIVE_DELTAS = 1, 2, 4, 8
@@ -92,6 +94,7 @@ _PROTOS = {
     "jpgpu_worker_append_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "jpgpu_worker_get_result": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "jpgpu_worker_finish_plane": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "jpgpu_worker_last_class": (C.c_int, [C.c_void_p]),
     "jpgpu_compute_image": (C.c_int, [C.c_void_p, C.POINTER(Component), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint16,
                                       C.c_uint16, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "jpgpu_batch_create": (C.c_int, [C.c_int, C.POINTER(ImageDesc), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
@@ -110,6 +113,7 @@ _PROTOS = {
     "jpgpu_batch_set_range_hint": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
     "jpgpu_batch_set_range_class": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "jpgpu_batch_scan_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jpgpu_batch_classify_on_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jpgpu_batch_clear_coefficients": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "jpgpu_batch_add_deltas": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_range_class": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -88,15 +88,16 @@ class Batch:
         a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
         self._check(N.lib().jpgpu_batch_upload(self._h, image, comp, a.ctypes.data, a.size))
 
-    def upload_compact(self, image, comp, coefficients, stream=None):
+    def upload_compact(self, image, comp, coefficients, stream=None, classify=True):
         """Same result as upload(), but PCIe carries only the non-zero coefficients (bitmap + index + values per block,
-        include/jpgpu.h); a kernel expands them into the arena at the start of the next decode()."""
+        include/jpgpu.h); a kernel expands them into the arena at the start of the next decode().  classify=False sends
+        range_class = -1: the expansion kernel ranges the values on the device instead of the host encoder."""
         a = np.ascontiguousarray(coefficients, dtype=np.int16).reshape(-1)
         q = np.ascontiguousarray(np.ctypeslib.as_array(self.descs[image].quantization_tables[comp]), dtype=np.uint16)
         buf = np.empty(N.lib().jpgpu_compact_max_bytes(a.size // 64), np.uint8)
         rc = C.c_int(0)
         n = N.lib().jpgpu_compact_encode(a.ctypes.data, a.size // 64, q.ctypes.data, buf.ctypes.data, C.byref(rc))
-        self._check(N.lib().jpgpu_batch_upload_compact(self._h, image, comp, buf.ctypes.data, n, rc.value, stream))
+        self._check(N.lib().jpgpu_batch_upload_compact(self._h, image, comp, buf.ctypes.data, n, rc.value if classify else -1, stream))
         self.synchronize(stream)  # the host buffer is pageable and about to go away
         return n
 
@@ -119,6 +120,12 @@ class Batch:
         out = np.zeros((self.n_images, 4), np.uint8)
         self._check(N.lib().jpgpu_batch_scan_ranges(self._h, stream, out.ctypes.data))
         return out
+
+    def classify_on_device(self, stream=None):
+        """jpgpu_batch_classify_on_device: range statistics of the arena's coefficients gathered and kept ON THE DEVICE
+        (asynchronous, no read-back); decode() then takes the classes from them there.  The device entropy decoder,
+        upload_compact(..., classify=False) and add_deltas leave the same statistics as a by-product."""
+        self._check(N.lib().jpgpu_batch_classify_on_device(self._h, stream))
 
     def class_counts(self):
         """Images of the fused launch groups per arithmetic variant: (wrap-exact, range class 1, range class 3)."""

@@ -24,6 +24,7 @@
 #include "fused.hpp"
 #include "host_common.hpp"
 #include "kernels.hpp"
+#include "range_stats.hpp"
 
 using namespace jpgpu;
 
@@ -82,6 +83,23 @@ struct jpgpu_batch {
     size_t h_bounce_cap = 0;
     std::vector<uint32_t> entropy_images;  // images of the launch in flight
     size_t entropy_out_off = 0;            // offset of the status / stats words inside d_entropy
+    // Classes decided ON THE DEVICE (range_stats.hpp): statistics raised by the kernels that write the coefficients, turned
+    // into class bits by class_finalize_* in front of the pixel kernels.  cls_src[image * 4 + comp] = 1: that component's
+    // class comes from the image's statistics; 0: from `sane` (what the host knows).  dev_classes: some component does, so
+    // decodes run the finalize kernels and the `_dyn` pixel kernels instead of one launch per class.
+    uint32_t *d_stats = nullptr;        // RS_WORDS per image
+    uint8_t *d_host_cls = nullptr;      // per image * 4 + comp: 0 / 1 / 3 or CLS_FROM_DEVICE
+    static constexpr int kClsRing = 4;
+    uint8_t *h_host_cls = nullptr;      // pinned, kClsRing copies (the upload is asynchronous on the decode stream)
+    hipEvent_t cls_sent[kClsRing] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t cls_next = 0;
+    uint32_t *d_plane_job_slot = nullptr;  // generic path: plane job -> image * 4 + comp
+    std::vector<uint8_t> cls_src;
+    bool dev_classes = false;
+    bool cls_dirty = true;              // class knowledge changed since the tables / the class table were last sent
+    // JPGPU_BATCH_KERNEL_TIMES (diagnostics, jpgpu_pipeline_timings): events around the phases of the device entropy path
+    hipEvent_t ev_phase[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool phase_events_valid = false;
 };
 
 #define B_HIP(call)                                                                                     \
@@ -90,9 +108,53 @@ struct jpgpu_batch {
         if (_e != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(_e)); \
     } while (0)
 
-static int batch_refresh_jobs(jpgpu_batch *b) {
-    if (!b->jobs_dirty) return JPGPU_OK;
+// first use of the device-side classes: statistics (zeroed), class table, pinned staging
+static int batch_enable_dev_classes(jpgpu_batch *b) {
+    if (b->d_stats) return JPGPU_OK;
+    const size_t n = b->descs.size();
+    B_HIP(hipMalloc((void **)&b->d_stats, n * RS_WORDS * sizeof(uint32_t)));
+    B_HIP(hipMemset(b->d_stats, 0, n * RS_WORDS * sizeof(uint32_t)));
+    B_HIP(hipMalloc((void **)&b->d_host_cls, n * 4));
+    B_HIP(hipHostMalloc((void **)&b->h_host_cls, n * 4 * jpgpu_batch::kClsRing, hipHostMallocDefault));
+    for (auto &e : b->cls_sent) B_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!b->generic_ids.empty()) B_HIP(hipMalloc((void **)&b->d_plane_job_slot, n * 4 * sizeof(uint32_t)));
+    b->jobs_dirty = true;  // (the plane-job slot table goes up with the jobs)
+    return JPGPU_OK;
+}
+
+// mark component `idx` = image * 4 + comp as classified by the device statistics / by the host (`sane[idx]`)
+static void batch_class_source(jpgpu_batch *b, size_t idx, bool from_device) {
+    if (b->cls_src[idx] != (from_device ? 1 : 0)) {
+        b->cls_src[idx] = from_device ? 1 : 0;
+        b->cls_dirty = true;
+    }
+    if (from_device) b->dev_classes = true;
+}
+static void batch_set_host_class(jpgpu_batch *b, size_t idx, uint8_t cls) {
+    if (b->sane[idx] != cls) {
+        b->sane[idx] = cls;
+        b->cls_dirty = true;
+    }
+    batch_class_source(b, idx, false);
+}
+
+static int batch_refresh_jobs(jpgpu_batch *b, hipStream_t stream = nullptr) {
+    // host-side classes are part of the launch tables (one launch per class: fused_bind); with device-side classes they
+    // travel in a small table of their own, asynchronously, and the launch tables stay as they are
+    const bool need_bind = b->jobs_dirty || (b->cls_dirty && !b->dev_classes);
+    if (!need_bind && !b->cls_dirty) return JPGPU_OK;
     if (!b->d_coef || !b->d_out) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    if (b->dev_classes) {
+        const size_t n4 = b->descs.size() * 4;
+        const uint32_t k = b->cls_next++ % jpgpu_batch::kClsRing;
+        uint8_t *h = b->h_host_cls + (size_t)k * n4;
+        B_HIP(hipEventSynchronize(b->cls_sent[k]));  // (its previous copy, four refreshes ago: long gone)
+        for (size_t i = 0; i < n4; i++) h[i] = b->cls_src[i] ? CLS_FROM_DEVICE : b->sane[i];
+        B_HIP(hipMemcpyAsync(b->d_host_cls, h, n4, hipMemcpyHostToDevice, stream));
+        B_HIP(hipEventRecord(b->cls_sent[k], stream));
+    }
+    b->cls_dirty = false;
+    if (!need_bind) return JPGPU_OK;
     const uint32_t n = (uint32_t)b->descs.size();
     b->plane_jobs.clear();
     b->image_jobs.clear();
@@ -121,6 +183,12 @@ static int batch_refresh_jobs(jpgpu_batch *b) {
     }
     if (!b->plane_jobs.empty())
         B_HIP(hipMemcpy(b->d_plane_jobs, b->plane_jobs.data(), b->plane_jobs.size() * sizeof(PlaneJob), hipMemcpyHostToDevice));
+    if (!b->plane_jobs.empty() && b->d_plane_job_slot) {
+        std::vector<uint32_t> slots;
+        for (uint32_t i : b->generic_ids)
+            for (uint32_t c = 0; c < b->descs[i].ncomp; c++) slots.push_back(i * 4 + c);
+        B_HIP(hipMemcpy(b->d_plane_job_slot, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (!b->image_jobs.empty())
         B_HIP(hipMemcpy(b->d_image_jobs, b->image_jobs.data(), b->image_jobs.size() * sizeof(ImageJob), hipMemcpyHostToDevice));
     for (FusedPlan &fp : b->fused) {
@@ -159,6 +227,7 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
     b->out_off.assign(n_images, 0);
     b->out_len.assign(n_images, 0);
     b->sane.assign((size_t)n_images * 4, 0);
+    b->cls_src.assign((size_t)n_images * 4, 0);
     // path resolution: group the images that can share a fused launch, the rest is generic
     std::vector<uint32_t> kind_key(n_images, 0);
     if (!(flags & JPGPU_BATCH_FORCE_GENERIC))
@@ -269,6 +338,14 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->h_bounce) hipHostFree(b->h_bounce);
         if (b->d_scan) hipFree(b->d_scan);
         if (b->h_scan) hipHostFree(b->h_scan);
+        if (b->d_stats) hipFree(b->d_stats);
+        if (b->d_host_cls) hipFree(b->d_host_cls);
+        if (b->h_host_cls) hipHostFree(b->h_host_cls);
+        if (b->d_plane_job_slot) hipFree(b->d_plane_job_slot);
+        for (auto &e : b->cls_sent)
+            if (e) hipEventDestroy(e);
+        for (auto &e : b->ev_phase)
+            if (e) hipEventDestroy(e);
         for (auto &x : b->delta_scratch)
             if (x.d) hipFree(x.d);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
@@ -289,6 +366,17 @@ int jpgpu_batch_class_counts(jpgpu_batch *b, uint32_t counts[3]) {
     rc = batch_refresh_jobs(b);
     if (rc) return rc;
     counts[0] = counts[1] = counts[2] = 0;
+    if (b->dev_classes) {  // the classes live on the device: have them worked out there and read the image tables back
+        B_HIP(hipDeviceSynchronize());
+        for (FusedPlan &fp : b->fused) {
+            B_HIP(fused_finalize_classes(fp, nullptr, b->d_stats, b->d_host_cls));
+            std::vector<uint8_t> bits;
+            rc = fused_read_classes(fp, bits, b->err);
+            if (rc) return rc;
+            for (uint8_t f : bits) counts[(f & 2u) ? 2 : ((f & 1u) ? 1 : 0)]++;
+        }
+        return JPGPU_OK;
+    }
     for (const FusedPlan &fp : b->fused)
         for (int c = 0; c < 3; c++) counts[c] += fp.class_images[c];
     return JPGPU_OK;
@@ -324,15 +412,13 @@ int jpgpu_batch_bind(jpgpu_batch *b, void *device_coef_arena, void *device_out_a
 
 int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane) {
     if (!b || image >= b->descs.size()) return JPGPU_ERR_FORMAT;
-    for (uint32_t c = 0; c < 4; c++) b->sane[image * 4 + c] = (uint8_t)(sane & 3);
-    b->jobs_dirty = true;
+    for (uint32_t c = 0; c < 4; c++) batch_set_host_class(b, (size_t)image * 4 + c, (uint8_t)(sane & 3));
     return JPGPU_OK;
 }
 
 int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, int range_class) {
     if (!b || image >= b->descs.size() || comp >= 4) return JPGPU_ERR_FORMAT;
-    b->sane[image * 4 + comp] = (uint8_t)(range_class & 3);
-    b->jobs_dirty = true;
+    batch_set_host_class(b, (size_t)image * 4 + comp, (uint8_t)(range_class & 3));
     return JPGPU_OK;
 }
 
@@ -344,6 +430,10 @@ int jpgpu_batch_clear_coefficients(jpgpu_batch *b, uint32_t image, void *hip_str
     const uint32_t nc = b->descs[image].ncomp;
     const size_t first = b->coef_off[(size_t)image * 4], last = b->coef_off[(size_t)image * 4 + nc - 1] + b->coef_len[(size_t)image * 4 + nc - 1];
     B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, (hipStream_t)hip_stream));
+    // an accumulation starts: so do the image's range statistics (jpgpu_batch_add_deltas raises them)
+    rc = batch_enable_dev_classes(b);
+    if (rc) return rc;
+    B_HIP(hipMemsetAsync(b->d_stats + (size_t)image * RS_WORDS, 0, RS_WORDS * sizeof(uint32_t), (hipStream_t)hip_stream));
     return JPGPU_OK;
 }
 
@@ -362,10 +452,16 @@ int jpgpu::batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const
     if (n > 0xFFFFFFFFu) return set_err(b->err, JPGPU_ERR_FORMAT, "add_deltas: too many entries");
     for (size_t k = 0; !trusted && k < n; k++)
         if (entries[k].index >= plane) return set_err(b->err, JPGPU_ERR_FORMAT, "add_deltas: index outside the component's plane");
-    if (b->sane[idx] != 0) {
-        b->sane[idx] = 0;
-        b->jobs_dirty = true;
-    }
+    // the finished plane's class comes from the statistics the kernel raises while it adds (every value a coefficient takes is
+    // ranged; a caller that never cleared the image keeps whatever the statistics held: they only grow)
+    // The kernel ranges with the table the device holds (the descriptor's, or the last one a decode sent): while a changed
+    // table is waiting to be sent, the statistics cannot be trusted and the component stays "unknown" (wrap-exact kernels);
+    // jpgpu_batch_set_quantization_table with a different table resets the class as well.
+    rc = batch_enable_dev_classes(b);
+    if (rc) return rc;
+    b->sane[idx] = 0;
+    const bool ranged = !b->qt_dirty;
+    batch_class_source(b, idx, ranged);
     if (n == 0) return JPGPU_OK;
     hipStream_t s = (hipStream_t)hip_stream;
     // One device buffer per stream the caller uses, reused call after call: the stream orders "kernel k has read it" before
@@ -392,11 +488,47 @@ int jpgpu::batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const
     }
     B_HIP(hipMemcpyAsync(sc->d, entries, bytes, hipMemcpyHostToDevice, s));
     B_HIP(launch_delta_add(reinterpret_cast<const jpgpu_coef_delta *>(sc->d), (uint32_t)n, reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]),
-                           (uint32_t)plane, s));
+                           (uint32_t)plane, b->d_qt + idx * 64, ranged ? b->d_stats + (size_t)image * RS_WORDS : nullptr, s));
     return JPGPU_OK;
 }
 
 extern "C" {
+
+// the range-scan job table on the device (d_scan: [ stats of the blocking scan | RangeJob[] ]); slot = image * 4 + comp
+static int batch_scan_jobs(jpgpu_batch *b, uint32_t &n_jobs, uint32_t &max_blocks, size_t &jobs_off) {
+    const size_t n_jobs_max = b->descs.size() * 4;
+    const size_t stats_bytes = b->descs.size() * 4 * RS_WORDS * sizeof(uint32_t);
+    jobs_off = align_up(stats_bytes, 256);
+    if (!b->d_scan) {
+        B_HIP(hipMalloc((void **)&b->d_scan, jobs_off + 2 * n_jobs_max * sizeof(RangeJob)));
+        B_HIP(hipHostMalloc((void **)&b->h_scan, stats_bytes, hipHostMallocDefault));
+        b->scan_jobs_valid = false;
+    }
+    max_blocks = 0, n_jobs = 0;
+    for (size_t i = 0; i < b->descs.size(); i++)
+        for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
+            max_blocks = std::max(max_blocks, (uint32_t)(b->coef_len[i * 4 + c] / 128));
+            n_jobs++;
+        }
+    if (!b->scan_jobs_valid) {
+        // two tables back to back: slots per component (the blocking scan's per-component classes) and per image (the
+        // device-side statistics are kept per image: range_stats.hpp)
+        std::vector<RangeJob> jobs;
+        for (int per_image = 0; per_image < 2; per_image++)
+            for (size_t i = 0; i < b->descs.size(); i++)
+                for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
+                    RangeJob r;
+                    r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
+                    r.n_blocks = (uint32_t)(b->coef_len[i * 4 + c] / 128);
+                    r.slot = per_image ? (uint32_t)i : (uint32_t)(i * 4 + c);
+                    memcpy(r.q, b->descs[i].quantization_tables[c], 128);
+                    jobs.push_back(r);
+                }
+        B_HIP(hipMemcpy(b->d_scan + jobs_off, jobs.data(), jobs.size() * sizeof(RangeJob), hipMemcpyHostToDevice));
+        b->scan_jobs_valid = true;
+    }
+    return JPGPU_OK;
+}
 
 int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) {
     if (!b) return JPGPU_ERR_FORMAT;
@@ -405,33 +537,11 @@ int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) 
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
     hipStream_t s = (hipStream_t)hip_stream;
     // stats and job table live on the device between calls (a call per decode must not allocate: bench.py times it)
-    const size_t n_jobs_max = b->descs.size() * 4;
-    const size_t stats_bytes = b->descs.size() * 4 * 2 * sizeof(uint32_t), jobs_off = align_up(stats_bytes, 256);
-    if (!b->d_scan) {
-        B_HIP(hipMalloc((void **)&b->d_scan, jobs_off + n_jobs_max * sizeof(RangeJob)));
-        B_HIP(hipHostMalloc((void **)&b->h_scan, stats_bytes, hipHostMallocDefault));
-        b->scan_jobs_valid = false;
-    }
     uint32_t max_blocks = 0, n_jobs = 0;
-    for (size_t i = 0; i < b->descs.size(); i++)
-        for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
-            max_blocks = std::max(max_blocks, (uint32_t)(b->coef_len[i * 4 + c] / 128));
-            n_jobs++;
-        }
-    if (!b->scan_jobs_valid) {
-        std::vector<RangeJob> jobs;
-        for (size_t i = 0; i < b->descs.size(); i++)
-            for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
-                RangeJob r;
-                r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
-                r.n_blocks = (uint32_t)(b->coef_len[i * 4 + c] / 128);
-                r.slot = (uint32_t)(i * 4 + c);
-                memcpy(r.q, b->descs[i].quantization_tables[c], 128);
-                jobs.push_back(r);
-            }
-        B_HIP(hipMemcpy(b->d_scan + jobs_off, jobs.data(), jobs.size() * sizeof(RangeJob), hipMemcpyHostToDevice));
-        b->scan_jobs_valid = true;
-    }
+    size_t jobs_off = 0;
+    rc = batch_scan_jobs(b, n_jobs, max_blocks, jobs_off);
+    if (rc) return rc;
+    const size_t stats_bytes = b->descs.size() * 4 * RS_WORDS * sizeof(uint32_t);
     uint32_t *stats = b->h_scan;
     hipError_t e = hipMemsetAsync(b->d_scan, 0, stats_bytes, s);
     if (e == hipSuccess)
@@ -443,14 +553,34 @@ int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes) 
         for (uint32_t c = 0; c < 4; c++) {
             uint8_t cls = 0;
             if (c < b->descs[i].ncomp) {
-                const uint32_t max_abs = stats[(i * 4 + c) * 2], max_col = stats[(i * 4 + c) * 2 + 1];
-                cls = max_abs < (1u << 15) ? (max_col <= 5900u ? 3 : 1) : 0;
-                if (b->sane[i * 4 + c] != cls) {
-                    b->sane[i * 4 + c] = cls;
-                    b->jobs_dirty = true;
-                }
+                const uint32_t *st = stats + (i * 4 + c) * RS_WORDS;
+                cls = (uint8_t)range_class_from_stats(st[RS_MAX_DC], st[RS_MAX_AC], st[RS_MAX_COL], 1u);
+                batch_set_host_class(b, i * 4 + c, cls);
             }
             if (classes) classes[i * 4 + c] = cls;
+        }
+    return JPGPU_OK;
+}
+
+int jpgpu_batch_classify_on_device(jpgpu_batch *b, void *hip_stream) {
+    if (!b) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    hipStream_t s = (hipStream_t)hip_stream;
+    rc = batch_enable_dev_classes(b);
+    if (rc) return rc;
+    uint32_t max_blocks = 0, n_jobs = 0;
+    size_t jobs_off = 0;
+    rc = batch_scan_jobs(b, n_jobs, max_blocks, jobs_off);
+    if (rc) return rc;
+    // zero, then the scan (which also marks the column maxima as exact: RS_COL_EXACT)
+    B_HIP(hipMemsetAsync(b->d_stats, 0, b->descs.size() * RS_WORDS * sizeof(uint32_t), s));
+    B_HIP(launch_range_scan(reinterpret_cast<const RangeJob *>(b->d_scan + jobs_off) + n_jobs, n_jobs, max_blocks, b->d_stats, s));
+    for (size_t i = 0; i < b->descs.size(); i++)
+        for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
+            b->sane[i * 4 + c] = 0;  // (the host does not know)
+            batch_class_source(b, i * 4 + c, true);
         }
     return JPGPU_OK;
 }
@@ -460,7 +590,8 @@ int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t 
     if (memcmp(b->descs[image].quantization_tables[comp], q, 128) == 0) return JPGPU_OK;
     memcpy(b->descs[image].quantization_tables[comp], q, 128);
     // the range class of coefficients already uploaded was computed with the old table (|c*q| bounds): unknown again
-    b->sane[(size_t)image * 4 + comp] = 0;
+    // (statistics the device gathered with the old table included)
+    batch_set_host_class(b, (size_t)image * 4 + comp, 0);
     b->scan_jobs_valid = false;
     b->qt_dirty = true;
     b->jobs_dirty = true;
@@ -482,10 +613,7 @@ int jpgpu_batch_upload(jpgpu_batch *b, uint32_t image, uint32_t comp, const int1
     uint8_t sane = 0;  // bit0: every |c*q| < 2^15; bit1: additionally every column sum of |c*q| <= 5900
     if (!(b->flags & JPGPU_BATCH_ASSUME_HOSTILE))
         sane = (uint8_t)jpgpu_range_class(coefficients, len, b->descs[image].quantization_tables[comp]);
-    if (b->sane[image * 4 + comp] != sane) {
-        b->sane[image * 4 + comp] = sane;
-        b->jobs_dirty = true;
-    }
+    batch_set_host_class(b, (size_t)image * 4 + comp, sane);
     B_HIP(hipMemcpy(b->d_coef + b->coef_off[image * 4 + comp], coefficients, len * sizeof(int16_t), hipMemcpyHostToDevice));
     return JPGPU_OK;
 }
@@ -530,12 +658,17 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
             B_HIP(hipMalloc((void **)&b->d_compact, std::max<size_t>(off, 256)));
             B_HIP(hipMalloc((void **)&b->d_expand_jobs, n * 4 * sizeof(ExpandJob)));
         }
-        b->compact_pending[idx] = 1;
+        // range_class < 0: the sender did not classify — expand_compact_kernel ranges the values while it expands them
+        b->compact_pending[idx] = range_class >= 0 ? 1 : 2;
         b->any_compact_pending = true;
-    }
-    if (range_class >= 0 && b->sane[idx] != (uint8_t)(range_class & 3)) {
-        b->sane[idx] = (uint8_t)(range_class & 3);
-        b->jobs_dirty = true;
+        if (range_class >= 0) {
+            batch_set_host_class(b, idx, (uint8_t)(range_class & 3));
+        } else {
+            rc = batch_enable_dev_classes(b);
+            if (rc) return rc;
+            b->sane[idx] = 0;
+            batch_class_source(b, idx, true);
+        }
     }
     B_HIP(hipMemcpyAsync(b->d_compact + b->compact_off[idx], compact, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     return JPGPU_OK;
@@ -550,8 +683,10 @@ static uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t h
 }
 
 // Staging block layout (same offsets in the pinned and the device copy):
-//   [ status: n x u32 | stats: n x 4 x 2 x u32 | settle counters: 4 x u32 per sync job | HuffSyncJob[] (segment jobs) | HuffSyncJob[] (chunk jobs) | RangeJob[] |
+//   [ status: n x u32 | settle counters: 4 x u32 per sync job | HuffSyncJob[] (segment jobs) | HuffSyncJob[] (chunk jobs) |
 //     DevHuffTable[8] per scan | segment offsets | scan bytes ]   + device only: per-chunk state of the sync jobs
+// The range statistics of the decoded coefficients are a by-product of the kernels that write them (HuffSyncJob::stats ->
+// the batch's d_stats; round 2 ran range_scan_kernel over the arena afterwards and read the result back).
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
@@ -582,10 +717,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         if (lanes < 16384u) sync_blocks = 12u, sync_min_shift = 9u, sync_launches = 16u;
         else if (lanes < 65536u) sync_blocks = 24u, sync_launches = 12u;
     }
-    size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, n_range = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
+    rc = batch_enable_dev_classes(b);
+    if (rc) return rc;
+    size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
-        n_range += b->descs[images[k].image].ncomp;
         for (const host::PlannedScan &ps : *images[k].scans) {
             n_scans++;
             seg_words += ps.seg_off.size();
@@ -606,9 +742,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             }
         }
     }
-    const size_t off_status = 0, off_stats = align_up(off_status + (size_t)n * 4, 16), off_cnt = align_up(off_stats + (size_t)n * 32, 16);
+    const size_t off_status = 0, off_cnt = align_up(off_status + (size_t)n * 4, 16);
     const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = align_up(off_jobs + n_seg_jobs * sizeof(HuffSyncJob), 16);
-    const size_t off_range = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16), off_tables = align_up(off_range + n_range * sizeof(RangeJob), 16);
+    const size_t off_tables = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
     const size_t off_seg = align_up(off_tables + n_scans * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
     const size_t off_scratch = align_up(total, 256), total_dev = off_scratch + scratch_bytes;
@@ -628,7 +764,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipHostMalloc((void **)&b->h_entropy, cap, hipHostMallocDefault));
         b->entropy_host_cap = cap;
     }
-    const size_t out_words = (size_t)n * 9;
+    const size_t out_words = (size_t)n;
     if (out_words > b->entropy_out_cap) {
         if (b->h_entropy_out) (void)hipHostFree(b->h_entropy_out);
         b->h_entropy_out = nullptr;
@@ -636,12 +772,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         b->entropy_out_cap = out_words + 64;
     }
     uint8_t *h = b->h_entropy, *d = b->d_entropy;
-    memset(h, 0, off_jobs);  // status and stats start at zero
+    memset(h, 0, off_jobs);  // status words and settle counters start at zero
     HuffSyncJob *jobs = reinterpret_cast<HuffSyncJob *>(h + off_jobs);
     HuffSyncJob *sjobs = reinterpret_cast<HuffSyncJob *>(h + off_sjobs);
-    RangeJob *rjobs = reinterpret_cast<RangeJob *>(h + off_range);
-    size_t ji = 0, si = 0, ri = 0, tcur = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
-    uint32_t max_seg = 0, max_blocks = 0, max_chunks = 0;
+    size_t ji = 0, si = 0, tcur = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
+    uint32_t max_seg = 0, max_chunks = 0;
+    std::vector<uint32_t> stat_images;  // listed images, for the fills that zero their statistics
     struct CopyTask {
         uint8_t *dst;        // first slot of the scan in the pinned block
         uint32_t *seg_table; // its 2 * n_seg words
@@ -659,6 +795,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         b->entropy_images.push_back(img);
         const jpgpu_image_desc &desc = b->descs[img];
         zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
+        stat_images.push_back(img);
+        for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the write passes leave in d_stats
+            b->sane[(size_t)img * 4 + c] = 0;
+            batch_class_source(b, (size_t)img * 4 + c, true);
+        }
         for (const host::PlannedScan &ps : *images[k].scans) {
             // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
             HuffSyncJob *sj = ps.ri == 0 ? &sjobs[si] : nullptr;
@@ -672,10 +813,13 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             memcpy(h + tcur, ps.tables, sizeof(ps.tables));
             HuffScanComp comp[4];
             memset(comp, 0, sizeof(comp));
+            uint16_t scan_q[4][64];
+            memset(scan_q, 0, sizeof(scan_q));
             for (uint32_t c = 0; c < ps.ncomp; c++) {
                 const uint32_t fi = ps.comp[c].frame_index;
                 if (fi >= desc.ncomp || ps.comp[c].block_w != desc.components[fi].block_width)
                     return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: plan does not match the image descriptor");
+                memcpy(scan_q[c], desc.quantization_tables[fi], 128);
                 comp[c].dst = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
                 comp[c].block_w = ps.comp[c].block_w;
                 comp[c].h = ps.comp[c].h;
@@ -687,6 +831,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 memset(sj, 0, sizeof(*sj));
                 memcpy(sj->comp, comp, sizeof(comp));
                 sj->ncomp = ps.ncomp;
+                memcpy(sj->q, scan_q, sizeof(scan_q));
+                sj->stats = b->d_stats + (size_t)img * RS_WORDS;
                 huff_sync_finish_job(*sj);
                 sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
                 const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
@@ -719,20 +865,14 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 j.n_mcu = ps.n_mcu;
                 j.ncomp = ps.ncomp;
                 memcpy(j.comp, comp, sizeof(comp));
+                memcpy(j.q, scan_q, sizeof(scan_q));
+                j.stats = b->d_stats + (size_t)img * RS_WORDS;
                 huff_sync_finish_job(j);
                 max_seg = std::max(max_seg, j.n_seg);
             }
             dcur += scan_bytes;
             scur += ps.seg_off.size() * 4;
             tcur += 8 * sizeof(DevHuffTable);
-        }
-        for (uint32_t c = 0; c < desc.ncomp; c++) {
-            RangeJob &r = rjobs[ri++];
-            r.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + c]);
-            r.n_blocks = (uint32_t)(b->coef_len[(size_t)img * 4 + c] / 128);
-            r.slot = k * 4 + c;
-            memcpy(r.q, desc.quantization_tables[c], 128);
-            max_blocks = std::max(max_blocks, r.n_blocks);
         }
     }
     {
@@ -767,42 +907,65 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     } else {
         B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
     }
+    // JPGPU_BATCH_KERNEL_TIMES: events between the phases (fills | sync passes | write pass + DC sums | pixel kernels)
+    static const bool phase_times = getenv("JPGPU_BATCH_KERNEL_TIMES") != nullptr;
+    b->phase_events_valid = false;
+    if (phase_times) {
+        for (auto &e : b->ev_phase)
+            if (!e) B_HIP(hipEventCreate(&e));
+        B_HIP(hipEventRecord(b->ev_phase[0], s));
+    }
     // the planes start as zeros (the Worker's zero-initialised plane): only non-zero coefficients are written.  Neighbouring
-    // images are cleared with one fill (a fill per image was 1,024 tiny launches = 28 ms per 1,024 images).
+    // images are cleared with one fill (a fill per image was 1,024 tiny launches = 28 ms per 1,024 images).  The same for
+    // their range statistics.
+    std::sort(stat_images.begin(), stat_images.end());
+    for (size_t z = 0; z < stat_images.size();) {
+        const size_t first = stat_images[z];
+        size_t last = first;
+        for (z++; z < stat_images.size() && stat_images[z] <= last + 1; z++) last = stat_images[z];
+        B_HIP(hipMemsetAsync(b->d_stats + first * RS_WORDS, 0, (last - first + 1) * RS_WORDS * sizeof(uint32_t), s));
+    }
     std::sort(zero_ranges.begin(), zero_ranges.end());
     for (size_t z = 0; z < zero_ranges.size();) {
         size_t first = zero_ranges[z].first, last = zero_ranges[z].second;
         for (z++; z < zero_ranges.size() && zero_ranges[z].first <= last + 256; z++) last = std::max(last, zero_ranges[z].second);
         B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, s));
     }
+    if (phase_times) B_HIP(hipEventRecord(b->ev_phase[1], s));
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
         static const uint32_t iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
-        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s));
+        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s,
+                               phase_times ? b->ev_phase[2] : nullptr));
     }
-    B_HIP(launch_range_scan(reinterpret_cast<const RangeJob *>(d + off_range), (uint32_t)n_range, max_blocks,
-                            reinterpret_cast<uint32_t *>(d + off_stats), s));
-    // status words, then the stats (8 per image), into pinned memory
+    if (phase_times) {
+        B_HIP(hipEventRecord(b->ev_phase[3], s));
+        b->phase_events_valid = true;
+    }
+    // the status words into pinned memory (the only thing the host needs to look at: which images it has to decode itself)
     B_HIP(hipMemcpyAsync(b->h_entropy_out, d + off_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    B_HIP(hipMemcpyAsync(b->h_entropy_out + n, d + off_stats, (size_t)n * 32, hipMemcpyDeviceToHost, s));
     return JPGPU_OK;
+}
+
+// JPGPU_BATCH_KERNEL_TIMES: milliseconds of the phases of the last device entropy launch and of the decode that followed it on
+// the same stream ([0] fills, [1] restart-segment decoder + sync passes + block numbering, [2] write pass + DC sums,
+// [3] class finalize + pixel kernels); false if they were not recorded.  The stream must have been synchronised.
+bool jpgpu::batch_phase_times(jpgpu_batch *b, float ms[4]) {
+    if (!b || !b->phase_events_valid) return false;
+    for (int i = 0; i < 4; i++) ms[i] = 0.f;
+    bool ok = hipEventElapsedTime(&ms[0], b->ev_phase[0], b->ev_phase[1]) == hipSuccess;
+    ok = ok && hipEventElapsedTime(&ms[1], b->ev_phase[1], b->ev_phase[2]) == hipSuccess;
+    ok = ok && hipEventElapsedTime(&ms[2], b->ev_phase[2], b->ev_phase[3]) == hipSuccess;
+    if (ok && hipEventQuery(b->ev_phase[5]) == hipSuccess) ok = hipEventElapsedTime(&ms[3], b->ev_phase[4], b->ev_phase[5]) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
 }
 
 int jpgpu::batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n) {
     if (!b || !status || n != b->entropy_images.size()) return JPGPU_ERR_FORMAT;
-    for (uint32_t k = 0; k < n; k++) {
-        status[k] = b->h_entropy_out[k];
-        if (status[k]) continue;
-        const uint32_t img = b->entropy_images[k];
-        for (uint32_t c = 0; c < b->descs[img].ncomp; c++) {
-            const uint32_t max_abs = b->h_entropy_out[n + (size_t)k * 8 + 2 * c], max_col = b->h_entropy_out[n + (size_t)k * 8 + 2 * c + 1];
-            const uint8_t cls = max_abs < (1u << 15) ? (max_col <= 5900u ? 3 : 1) : 0;
-            if (b->sane[(size_t)img * 4 + c] != cls) {
-                b->sane[(size_t)img * 4 + c] = cls;
-                b->jobs_dirty = true;
-            }
-        }
-    }
+    // (the classes of the accepted images stay on the device: d_stats; an image the host decodes instead gets its class with
+    // its upload)
+    for (uint32_t k = 0; k < n; k++) status[k] = b->h_entropy_out[k];
     b->entropy_images.clear();
     return JPGPU_OK;
 }
@@ -817,16 +980,32 @@ int jpgpu_batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, co
 // compact uploads since the last decode -> dense coefficient arena, on the decode stream
 static int batch_expand_pending(jpgpu_batch *b, hipStream_t s) {
     std::vector<ExpandJob> jobs;
+    std::vector<uint32_t> stat_fresh;
     uint32_t max_blocks = 0;
     {
         std::lock_guard<std::mutex> g(b->compact_mutex);
         if (!b->any_compact_pending) return JPGPU_OK;
+        // An image's statistics start afresh when every component they stand for is being re-sent now; otherwise they only
+        // grow (sound, possibly pessimistic).
+        for (size_t img = 0; img < b->descs.size(); img++) {
+            bool any = false, all = true;
+            for (uint32_t c = 0; c < b->descs[img].ncomp; c++) {
+                const size_t idx = img * 4 + c;
+                if (b->compact_pending[idx] == 2 && b->cls_src[idx]) any = true;
+                else if (b->cls_src[idx]) all = false;
+            }
+            if (any && all) stat_fresh.push_back((uint32_t)img);
+        }
         for (size_t idx = 0; idx < b->compact_pending.size(); idx++)
             if (b->compact_pending[idx]) {
                 ExpandJob j{};
                 j.compact = b->d_compact + b->compact_off[idx];
                 j.dense = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]);
                 j.n_blocks = (uint32_t)(b->coef_len[idx] / 128);
+                if (b->compact_pending[idx] == 2 && b->cls_src[idx]) {  // unclassified by the sender: ranged on the way
+                    j.qt = b->d_qt + idx * 64;
+                    j.stats = b->d_stats + (idx / 4) * RS_WORDS;
+                }
                 max_blocks = std::max(max_blocks, j.n_blocks);
                 jobs.push_back(j);
                 b->compact_pending[idx] = 0;
@@ -834,6 +1013,7 @@ static int batch_expand_pending(jpgpu_batch *b, hipStream_t s) {
         b->any_compact_pending = false;
     }
     if (jobs.empty()) return JPGPU_OK;
+    for (uint32_t img : stat_fresh) B_HIP(hipMemsetAsync(b->d_stats + (size_t)img * RS_WORDS, 0, RS_WORDS * sizeof(uint32_t), s));
     B_HIP(hipMemcpy(b->d_expand_jobs, jobs.data(), jobs.size() * sizeof(ExpandJob), hipMemcpyHostToDevice));
     B_HIP(launch_expand_compact(b->d_expand_jobs, (uint32_t)jobs.size(), max_blocks, s));
     return JPGPU_OK;
@@ -844,18 +1024,25 @@ int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     jpgpu::TraceRange roctx_range("jpgpu_batch_decode");
     int rc = use_device(b->device, b->err);
     if (rc) return rc;
-    rc = batch_refresh_jobs(b);
-    if (rc) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
+    rc = batch_refresh_jobs(b, s);
+    if (rc) return rc;
     rc = batch_expand_pending(b, s);
     if (rc) return rc;
-    for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s));
-    if (b->generic_ids.empty()) return JPGPU_OK;
-    const uint32_t n = (uint32_t)b->image_jobs.size();
-    static const uint32_t kScales[4] = {8, 4, 2, 1};
-    for (uint32_t sc : kScales)
-        if (b->scales[sc]) B_HIP(launch_idct_planes(b->d_plane_jobs, (uint32_t)b->plane_jobs.size(), b->max_blocks, sc, s));
-    B_HIP(launch_upsample_color(b->d_image_jobs, n, b->max_w, b->max_h, s));
+    if (b->phase_events_valid) B_HIP(hipEventRecord(b->ev_phase[4], s));
+    // device-side classes: statistics -> class bits in the launch tables (class_finalize_*), then the `_dyn` kernels
+    const uint32_t *st = b->dev_classes ? b->d_stats : nullptr;
+    const uint8_t *hc = b->dev_classes ? b->d_host_cls : nullptr;
+    for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s, st, hc));
+    if (!b->generic_ids.empty()) {
+        const uint32_t n = (uint32_t)b->image_jobs.size();
+        if (b->dev_classes) B_HIP(launch_class_finalize_planes(b->d_plane_jobs, b->d_plane_job_slot, (uint32_t)b->plane_jobs.size(), st, hc, s));
+        static const uint32_t kScales[4] = {8, 4, 2, 1};
+        for (uint32_t sc : kScales)
+            if (b->scales[sc]) B_HIP(launch_idct_planes(b->d_plane_jobs, (uint32_t)b->plane_jobs.size(), b->max_blocks, sc, s));
+        B_HIP(launch_upsample_color(b->d_image_jobs, n, b->max_w, b->max_h, s));
+    }
+    if (b->phase_events_valid) B_HIP(hipEventRecord(b->ev_phase[5], s));
     return JPGPU_OK;
 }
 

@@ -18,6 +18,9 @@ struct ExpandJob {
     int16_t *dense;          // device: n_blocks * 64 i16 (the coefficient arena)
     uint32_t n_blocks;
     uint32_t _pad;
+    const uint16_t *qt;      // device: the component's quantization table, natural order (only read when `stats` is set)
+    uint32_t *stats;         // device, or null: the image's RangeStats words (range_stats.hpp) — raised on the way when the
+                             // sender did not classify the coefficients itself (jpgpu_batch_upload_compact, range_class < 0)
 };
 
 // Incremental host encoder: blocks arrive in order (MCU row by MCU row); finish() pads the blocks never delivered

@@ -16,6 +16,7 @@
 #include "fused_plan.hpp"
 #include "host_common.hpp"
 #include "idct_plane_body.hpp"
+#include "range_stats.hpp"
 
 namespace jpgpu {
 
@@ -55,13 +56,27 @@ __global__ __launch_bounds__(256) void f420_chroma_kernel(const FusedGeom *__res
     idct_planes_body<8>(job, w.b, lds);
 }
 
+// Every pixel kernel exists in four forms: one per arithmetic class (the host knows the classes of a launch's images and has
+// split the work tables accordingly: fused_bind) and `_dyn`, which reads the class of its workgroup's image from the image
+// table ON THE DEVICE and branches to the body of that class (workgroup-uniform) — for batches whose classes come from
+// statistics the device gathered itself (range_stats.hpp, class_finalize_fused_kernel): no host in between.  The three
+// bodies share registers and LDS (allocation = the largest, which the wrap-exact body already set under the same launch bounds).
+#define JP_DYN_DISPATCH(FLAGS, CALL)                \
+    do {                                            \
+        const uint32_t _fl = (FLAGS);               \
+        if (_fl & 2u) { CALL(ARITH_TIGHT); }        \
+        else if (_fl & 1u) { CALL(ARITH_SANE); }    \
+        else { CALL(ARITH_EXACT); }                 \
+    } while (0)
+__device__ __forceinline__ uint32_t image_flags(const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[locate(work).image].flags);
+}
+
 // main pass / 4:4:4 / gray: a = tile within the MCU row, b = MCU row
 template <int ARITH, uint32_t NT>
-__global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const FusedGeom *__restrict__ geoms,
-                                                                           const FusedImage *__restrict__ imgs,
-                                                                           const FusedWork *__restrict__ work) {
+__device__ __forceinline__ void f420_main_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                               const FusedWork *__restrict__ work, uint8_t *lds_raw) {
     typedef F420<ARITH, NT> K;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
@@ -74,6 +89,22 @@ __global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const 
     K::phase2(g, w.a, threadIdx.x, lds, r);
     __syncthreads();
     K::phase3(g, img, w.a, w.b, threadIdx.x, lds);
+}
+template <int ARITH, uint32_t NT>
+__global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel(const FusedGeom *__restrict__ geoms,
+                                                                           const FusedImage *__restrict__ imgs,
+                                                                           const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    f420_main_body<ARITH, NT>(geoms, imgs, work, lds_raw);
+}
+template <uint32_t NT>
+__global__ __launch_bounds__(NT, NT == 128 ? 4 : 3) void f420_main_kernel_dyn(const FusedGeom *__restrict__ geoms,
+                                                                               const FusedImage *__restrict__ imgs,
+                                                                               const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+#define JP_CALL(A) f420_main_body<A, NT>(geoms, imgs, work, lds_raw)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
 }
 
 // Phase clocks (a diagnostic build: -DJPGPU_PHASE_CLOCKS, tools/gpu_phase_clocks.sh): every wave sums, per phase of the
@@ -177,6 +208,14 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     walk_body<S420<ARITH, NT>>(geoms, imgs, work, lds_raw);
 }
+template <uint32_t NT>
+__global__ __launch_bounds__(NT, 4) void s420_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                         const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+#define JP_CALL(A) walk_body<S420<A, NT>>(geoms, imgs, work, lds_raw)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
 
 template <int ARITH>
 __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
@@ -184,12 +223,18 @@ __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restric
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     walk_body<S440<ARITH>>(geoms, imgs, work, lds_raw);
 }
+__global__ __launch_bounds__(256, 4) void s440_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                          const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+#define JP_CALL(A) walk_body<S440<A>>(geoms, imgs, work, lds_raw)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
 
 // a = tile, b = MCU row
 template <int ARITH>
-__global__ __launch_bounds__(256, 4) void fgen_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                      const FusedWork *__restrict__ work) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+__device__ __forceinline__ void fgen_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
+                                          uint8_t *lds_raw) {
     typedef FGen<ARITH> K;
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
@@ -210,11 +255,23 @@ __global__ __launch_bounds__(256, 4) void fgen_kernel(const FusedGeom *__restric
     __syncthreads();
     K::colour(g, img, w.a, w.b, tid, lds);
 }
+template <int ARITH>
+__global__ __launch_bounds__(256, 4) void fgen_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                      const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    fgen_body<ARITH>(geoms, imgs, work, lds_raw);
+}
+__global__ __launch_bounds__(256, 4) void fgen_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                          const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+#define JP_CALL(A) fgen_body<A>(geoms, imgs, work, lds_raw)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
 
 template <int ARITH>
-__global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                   const FusedWork *__restrict__ work) {
-    __shared__ FusedLdsSmall lds;
+__device__ __forceinline__ void f444_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
+                                          FusedLdsSmall &lds) {
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
@@ -228,11 +285,23 @@ __global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__
     __syncthreads();
     F444<ARITH>::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
-
 template <int ARITH>
-__global__ __launch_bounds__(256) void f422_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(256) void f444_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                    const FusedWork *__restrict__ work) {
     __shared__ FusedLdsSmall lds;
+    f444_body<ARITH>(geoms, imgs, work, lds);
+}
+__global__ __launch_bounds__(256) void f444_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                       const FusedWork *__restrict__ work) {
+    __shared__ FusedLdsSmall lds;
+#define JP_CALL(A) f444_body<A>(geoms, imgs, work, lds)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
+
+template <int ARITH>
+__device__ __forceinline__ void f422_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
+                                          FusedLdsSmall &lds) {
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
@@ -246,11 +315,23 @@ __global__ __launch_bounds__(256) void f422_kernel(const FusedGeom *__restrict__
     __syncthreads();
     F422<ARITH>::phase3(g, img, w.a, w.b, threadIdx.x, lds);
 }
+template <int ARITH>
+__global__ __launch_bounds__(256) void f422_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                   const FusedWork *__restrict__ work) {
+    __shared__ FusedLdsSmall lds;
+    f422_body<ARITH>(geoms, imgs, work, lds);
+}
+__global__ __launch_bounds__(256) void f422_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                       const FusedWork *__restrict__ work) {
+    __shared__ FusedLdsSmall lds;
+#define JP_CALL(A) f422_body<A>(geoms, imgs, work, lds)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
 
 template <int ARITH>
-__global__ __launch_bounds__(256) void fgray_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                    const FusedWork *__restrict__ work) {
-    __shared__ FusedLdsSmall lds;
+__device__ __forceinline__ void fgray_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
+                                           FusedLdsSmall &lds) {
     const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
@@ -258,8 +339,46 @@ __global__ __launch_bounds__(256) void fgray_kernel(const FusedGeom *__restrict_
     __syncthreads();
     FGray<ARITH>::phase1(g, img, w.a, w.b, threadIdx.x, lds);
 }
+template <int ARITH>
+__global__ __launch_bounds__(256) void fgray_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                    const FusedWork *__restrict__ work) {
+    __shared__ FusedLdsSmall lds;
+    fgray_body<ARITH>(geoms, imgs, work, lds);
+}
+__global__ __launch_bounds__(256) void fgray_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                        const FusedWork *__restrict__ work) {
+    __shared__ FusedLdsSmall lds;
+#define JP_CALL(A) fgray_body<A>(geoms, imgs, work, lds)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
+
+// Statistics -> class bits of every image of a plan, in its image table, right in front of the `_dyn` launch (range_stats.hpp).
+// host_cls[image * 4 + comp]: the class the host knows (0, 1, 3) or CLS_FROM_DEVICE; stats: RS_WORDS per batch image.
+__global__ __launch_bounds__(256) void class_finalize_fused_kernel(FusedImage *__restrict__ imgs, const uint32_t *__restrict__ ids, uint32_t n,
+                                                                   uint32_t ncomp, const uint32_t *__restrict__ stats,
+                                                                   const uint8_t *__restrict__ host_cls, uint32_t cap_bits) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t gi = ids[i];
+    const uint32_t *st = stats + (size_t)gi * RS_WORDS;
+    const uint32_t dev = range_class_from_stats(st[RS_MAX_DC], st[RS_MAX_AC], st[RS_MAX_COL], st[RS_COL_EXACT]);
+    uint32_t fl = 3u;
+    for (uint32_t c = 0; c < ncomp; c++) {
+        const uint32_t h = host_cls[gi * 4u + c];
+        fl &= h == CLS_FROM_DEVICE ? dev : h;
+    }
+    if (!(fl & 1u)) fl = 0u;  // tight implies sane
+    imgs[i].flags = fl & cap_bits;
+}
 
 // ---- host side ------------------------------------------------------------------------------
+// JPGPU_ARITH (tuning / testing knob): cap the arithmetic variant — 0 wrap-exact, 1 sane, 2 (default) tight
+static int arith_cap() {
+    int cap = (int)ARITH_TIGHT;
+    if (const char *ae = getenv("JPGPU_ARITH")) cap = std::max(0, std::min(cap, atoi(ae)));
+    return cap;
+}
 uint32_t fused_kind_key(const jpgpu_image_desc &d) {
     FusedGeom g;
     const char *nm = "", *w = "";
@@ -365,6 +484,9 @@ int fused_alloc(FusedPlan &plan, std::string &err) {
     F_HIP(hipMalloc((void **)&plan.d_images, sizeof(FusedImage) * plan.n_images));
     F_HIP(hipMalloc((void **)&plan.d_geoms, sizeof(FusedGeom) * plan.n_images));
     F_HIP(hipMemcpy(plan.d_geoms, plan.geoms.data(), sizeof(FusedGeom) * plan.n_images, hipMemcpyHostToDevice));
+    F_HIP(hipMalloc((void **)&plan.d_ids, sizeof(uint32_t) * plan.n_images));
+    F_HIP(hipMemcpy(plan.d_ids, plan.ids.data(), sizeof(uint32_t) * plan.n_images, hipMemcpyHostToDevice));
+    F_HIP(hipEventCreateWithFlags(&plan.launched, hipEventDisableTiming));
     F_HIP(hipMalloc((void **)&plan.d_work_main, sizeof(FusedWork) * std::max<size_t>(plan.work_main.size(), 1)));
     F_HIP(hipMemcpy(plan.d_work_main, plan.work_main.data(), sizeof(FusedWork) * plan.work_main.size(), hipMemcpyHostToDevice));
     if (!plan.work_pre.empty()) {
@@ -379,8 +501,13 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
                const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err) {
     if (plan.kind == FUSED_NONE) return JPGPU_OK;
     std::vector<uint8_t> cls(plan.n_images, 0);
-    int cap = (int)ARITH_TIGHT;
-    if (const char *ae = getenv("JPGPU_ARITH")) cap = std::min(cap, atoi(ae));  // tuning/testing knob: cap the variant
+    const int cap = arith_cap();
+    // The previous launch of this plan may still be reading the tables rewritten below (decodes are asynchronous on the
+    // caller's stream, possibly a non-blocking one that the copies on the null stream do not order against)
+    if (plan.launched && plan.launch_pending) {
+        (void)hipEventSynchronize(plan.launched);
+        plan.launch_pending = false;
+    }
     plan.class_images[0] = plan.class_images[1] = plan.class_images[2] = 0;
     for (uint32_t i = 0; i < plan.n_images; i++) {
         FusedImage &im = plan.images[i];
@@ -442,30 +569,32 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
     const dim3 grid = W ? dim3(n_main) : dim3(g0.tiles_x, plan.strip ? g0.n_seg : g0.mcu_h, plan.n_images);
     const dim3 block(plan.nt);
     const size_t shm = plan.lds_bytes;
-#define ARITH_SWITCH(KERNEL, ...)                                                                      \
+    // ar < 0: the `_dyn` form (class per image from the image table on the device)
+#define ARITH_SWITCH(KERNEL, DYN, ...)                                                                 \
     do {                                                                                               \
-        if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);  \
+        if (ar < 0) DYN<<<grid, block, shm, stream>>>(G, I, W);                                        \
+        else if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);  \
         else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W); \
         else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);                  \
     } while (0)
     switch (plan.kind) {
     case FUSED_420:
         if (plan.strip) {
-            ARITH_SWITCH(s420_kernel, 256);
+            ARITH_SWITCH(s420_kernel, s420_kernel_dyn<256>, 256);
             break;
         }
         if (!Wpre)  // (component, 256-block group, image)
             f420_chroma_kernel<<<dim3(2, (g0.bwc * g0.mcu_h + 255u) / 256u, plan.n_images), dim3(256), 0, stream>>>(G, I, nullptr);
         else
             f420_chroma_kernel<<<dim3(n_pre), dim3(256), 0, stream>>>(G, I, Wpre);
-        if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, 128);
-        else ARITH_SWITCH(f420_main_kernel, 256);
+        if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, f420_main_kernel_dyn<128>, 128);
+        else ARITH_SWITCH(f420_main_kernel, f420_main_kernel_dyn<256>, 256);
         break;
-    case FUSED_440: ARITH_SWITCH(s440_kernel); break;
-    case FUSED_GEN: ARITH_SWITCH(fgen_kernel); break;
-    case FUSED_444: ARITH_SWITCH(f444_kernel); break;
-    case FUSED_422: ARITH_SWITCH(f422_kernel); break;
-    case FUSED_GRAY: ARITH_SWITCH(fgray_kernel); break;
+    case FUSED_440: ARITH_SWITCH(s440_kernel, s440_kernel_dyn); break;
+    case FUSED_GEN: ARITH_SWITCH(fgen_kernel, fgen_kernel_dyn); break;
+    case FUSED_444: ARITH_SWITCH(f444_kernel, f444_kernel_dyn); break;
+    case FUSED_422: ARITH_SWITCH(f422_kernel, f422_kernel_dyn); break;
+    case FUSED_GRAY: ARITH_SWITCH(fgray_kernel, fgray_kernel_dyn); break;
     default: return hipErrorInvalidValue;
     }
 #undef ARITH_SWITCH
@@ -476,22 +605,51 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
 // (Walking the batch in chunks so that a chunk's chroma planes stay in the 256 MiB Infinity Cache, and alternating chunks
 // between two streams so that the HBM-bound chroma pass overlaps the VALU-bound main pass, were both measured on MI355X and
 // did not pay: chunks of 16/32/64/128 images were 23/9/4/1 % slower, two streams 3 % slower — profiles/round1.)
-hipError_t fused_launch(FusedPlan &plan, hipStream_t stream) {
-    if (!plan.by_class) {
-        const bool table = !plan.uniform;
-        return fused_launch_one(plan, stream, plan.arith, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
-                                table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
-    }
-    const FusedWork *w = plan.d_work_cls, *wp = plan.d_work_cls + plan.n_main_cls[0] + plan.n_main_cls[1] + plan.n_main_cls[2];
-    for (int c = 0; c < 3; c++) {
-        if (plan.n_main_cls[c]) {
-            hipError_t e = fused_launch_one(plan, stream, c, w, plan.n_main_cls[c], plan.n_pre_cls[c] ? wp : nullptr, plan.n_pre_cls[c]);
-            if (e != hipSuccess) return e;
+// d_stats / d_host_cls != null: the classes are decided on the device — class_finalize_fused_kernel writes them into the image
+// table from the statistics there (and the classes the host does know), then ONE `_dyn` launch over the whole work table.
+hipError_t fused_finalize_classes(FusedPlan &plan, hipStream_t stream, const uint32_t *d_stats, const uint8_t *d_host_cls) {
+    if (plan.kind == FUSED_NONE || !d_stats || !d_host_cls) return hipSuccess;
+    const int cap = arith_cap();
+    class_finalize_fused_kernel<<<dim3((plan.n_images + 255u) / 256u), dim3(256), 0, stream>>>(
+        plan.d_images, plan.d_ids, plan.n_images, plan.ncomp, d_stats, d_host_cls, cap >= (int)ARITH_TIGHT ? 3u : (cap == (int)ARITH_SANE ? 1u : 0u));
+    return hipGetLastError();
+}
+
+hipError_t fused_launch(FusedPlan &plan, hipStream_t stream, const uint32_t *d_stats, const uint8_t *d_host_cls) {
+    hipError_t e = hipSuccess;
+    const bool table = !plan.uniform;
+    if (d_stats && d_host_cls) {
+        e = fused_finalize_classes(plan, stream, d_stats, d_host_cls);
+        if (e == hipSuccess)
+            e = fused_launch_one(plan, stream, -1, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
+                                 table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
+    } else if (!plan.by_class) {
+        e = fused_launch_one(plan, stream, plan.arith, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
+                             table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
+    } else {
+        const FusedWork *w = plan.d_work_cls, *wp = plan.d_work_cls + plan.n_main_cls[0] + plan.n_main_cls[1] + plan.n_main_cls[2];
+        for (int c = 0; c < 3 && e == hipSuccess; c++) {
+            if (plan.n_main_cls[c]) e = fused_launch_one(plan, stream, c, w, plan.n_main_cls[c], plan.n_pre_cls[c] ? wp : nullptr, plan.n_pre_cls[c]);
+            w += plan.n_main_cls[c];
+            wp += plan.n_pre_cls[c];
         }
-        w += plan.n_main_cls[c];
-        wp += plan.n_pre_cls[c];
     }
-    return hipSuccess;
+    if (e == hipSuccess && plan.launched && hipEventRecord(plan.launched, stream) == hipSuccess) plan.launch_pending = true;
+    return e;
+}
+
+int fused_read_classes(FusedPlan &plan, std::vector<uint8_t> &bits, std::string &err) {
+    bits.assign(plan.n_images, 0);
+    if (plan.kind == FUSED_NONE || !plan.d_images) return JPGPU_OK;
+    if (plan.launched && plan.launch_pending) {
+        (void)hipEventSynchronize(plan.launched);
+        plan.launch_pending = false;
+    }
+    std::vector<FusedImage> imgs(plan.n_images);
+    hipError_t e = hipMemcpy(imgs.data(), plan.d_images, sizeof(FusedImage) * plan.n_images, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return set_err(err, JPGPU_ERR_IO, "hipMemcpy(image table): %s", hipGetErrorString(e));
+    for (uint32_t i = 0; i < plan.n_images; i++) bits[i] = (uint8_t)(imgs[i].flags & 3u);
+    return JPGPU_OK;
 }
 
 void fused_free(FusedPlan &plan) {
@@ -501,6 +659,11 @@ void fused_free(FusedPlan &plan) {
     if (plan.d_work_main) (void)hipFree(plan.d_work_main);
     if (plan.d_work_pre) (void)hipFree(plan.d_work_pre);
     if (plan.d_work_cls) (void)hipFree(plan.d_work_cls);
+    if (plan.d_ids) (void)hipFree(plan.d_ids);
+    if (plan.launched) (void)hipEventDestroy(plan.launched);
+    plan.d_ids = nullptr;
+    plan.launched = nullptr;
+    plan.launch_pending = false;
     plan.d_work_cls = nullptr;
     plan.work_cls_cap = 0;
     plan.d_scratch = nullptr;

@@ -28,6 +28,9 @@ struct FusedPlan {
     FusedImage *d_images = nullptr;
     FusedGeom *d_geoms = nullptr;
     FusedWork *d_work_main = nullptr, *d_work_pre = nullptr;
+    uint32_t *d_ids = nullptr;       // `ids` on the device (class_finalize_fused_kernel)
+    hipEvent_t launched = nullptr;   // recorded behind every launch of the plan: fused_bind waits for it before it rewrites the
+    bool launch_pending = false;     // tables a launch in flight may still be reading
     std::vector<FusedImage> images;
     int arith = 0;  // ARITH_* variant every image of the plan qualifies for (when they all agree)
     // Images of different arithmetic classes in one plan: one launch per class present, each over its own work table
@@ -46,7 +49,14 @@ uint32_t fused_kind_key(const jpgpu_image_desc &d);
 int fused_alloc(FusedPlan &plan, std::string &err);
 int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt, const std::vector<size_t> &coef_off,
                const std::vector<size_t> &out_off, const std::vector<uint8_t> &sane, std::string &err);
-hipError_t fused_launch(FusedPlan &plan, hipStream_t stream);
+// d_stats (RS_WORDS per batch image, range_stats.hpp) and d_host_cls (per batch image * 4 + component: 0 / 1 / 3 or
+// CLS_FROM_DEVICE) given: the classes are taken from the device's own statistics and the `_dyn` kernels run; else the
+// classes fused_bind was given (one launch per class present).
+hipError_t fused_launch(FusedPlan &plan, hipStream_t stream, const uint32_t *d_stats = nullptr, const uint8_t *d_host_cls = nullptr);
+// the finalize step alone (jpgpu_batch_class_counts)
+hipError_t fused_finalize_classes(FusedPlan &plan, hipStream_t stream, const uint32_t *d_stats, const uint8_t *d_host_cls);
+// class bits (bit 0 sane, bit 1 tight) of the plan's images as the last launch saw them (blocking read-back; diagnostics)
+int fused_read_classes(FusedPlan &plan, std::vector<uint8_t> &bits, std::string &err);
 void fused_free(FusedPlan &plan);
 
 }  // namespace jpgpu

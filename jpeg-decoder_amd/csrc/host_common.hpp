@@ -22,12 +22,21 @@ int build_image_job(const jpgpu_component *comps, uint32_t ncomp, uint8_t *const
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // roctx range around a host-side phase (the reference has no tracing hooks; rocprofv3 --marker-trace shows these
-// next to the kernels).  Costs two calls into libroctx64 when no tool listens.
-extern "C" int roctxRangePushA(const char *message);
-extern "C" int roctxRangePop();
+// next to the kernels).  libroctx64 is looked up at run time (dlopen, once): the library neither links against it nor fails
+// to load where ROCm's tracing library is absent or lives elsewhere — the ranges are then no-ops.
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi &roctx_api();  // jpgpu.cpp
 struct TraceRange {
-    explicit TraceRange(const char *name) { (void)roctxRangePushA(name); }
-    ~TraceRange() { (void)roctxRangePop(); }
+    bool on;
+    explicit TraceRange(const char *name) : on(roctx_api().push != nullptr) {
+        if (on) (void)roctx_api().push(name);
+    }
+    ~TraceRange() {
+        if (on) (void)roctx_api().pop();
+    }
     TraceRange(const TraceRange &) = delete;
     TraceRange &operator=(const TraceRange &) = delete;
 };
@@ -60,5 +69,6 @@ int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images
                                 const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
                                 void *copy_stream = nullptr);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
+bool batch_phase_times(jpgpu_batch *b, float ms[4]);  // JPGPU_BATCH_KERNEL_TIMES, batch.cpp
 
 }  // namespace jpgpu

@@ -6,16 +6,25 @@
 #include "huff.hpp"
 #include "huff_core.hpp"
 #include "huff_sync_core.hpp"
+#include "range_stats.hpp"
 
 namespace jpgpu {
+
+// the lanes' range by-product -> the image's statistics
+__device__ __forceinline__ void publish_range(uint32_t *stats, HuffRange rg) { stat_publish_wave(stats, rg.dc, rg.ac); }
 
 // max |c*q| and the largest block-column sum of |c*q| per plane (the two quantities behind the range classes of
 // include/jpgpu.h).  Eight lanes per block, one 16-byte row each: a wave reads 1 KB of consecutive coefficients per load
 // (one lane per block — every lane on its own cache line — ran at 1.2 TB/s).  The column sums are folded across the
 // eight lanes by halving (4 + 2 + 1 exchanges), the maxima per wave, then atomicMax.
-__global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restrict__ jobs, uint32_t *__restrict__ stats) {
-    const RangeJob &job = jobs[blockIdx.y];
+struct RangeView {  // what the scan needs of a RangeJob (the table through a pointer: the job's own copy, or device memory)
+    const int16_t *coefs;
+    uint32_t n_blocks, slot;
+    const uint16_t *q;
+};
+__device__ __forceinline__ void range_scan_body(const RangeView job, uint32_t *__restrict__ stats) {
     const uint32_t row = threadIdx.x & 7u, first = blockIdx.x * 256u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) stats[RS_WORDS * job.slot + RS_COL_EXACT] = 1u;  // whole blocks in view: exact column sums
     if (first >= job.n_blocks) return;
     uint32_t q[8];
     {
@@ -79,10 +88,19 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restr
         wg_max[1][threadIdx.x >> 6] = max_col;
     }
     __syncthreads();
-    if (threadIdx.x < 2u) {
+    if (threadIdx.x < 2u) {  // (exact column sums: the image's RS_COL_EXACT word is set by the launcher's fill)
         const uint32_t v = max(max(wg_max[threadIdx.x][0], wg_max[threadIdx.x][1]), max(wg_max[threadIdx.x][2], wg_max[threadIdx.x][3]));
-        if (v) atomicMax(&stats[2u * job.slot + threadIdx.x], v);
+        stat_raise(&stats[RS_WORDS * job.slot + (threadIdx.x ? RS_MAX_COL : RS_MAX_AC)], v);
     }
+}
+__global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restrict__ jobs, uint32_t *__restrict__ stats) {
+    const RangeJob &job = jobs[blockIdx.y];
+    range_scan_body(RangeView{job.coefs, job.n_blocks, job.slot, job.q}, stats);
+}
+// one plane, its table in device memory (the Worker's fused route: jpgpu.cpp)
+__global__ __launch_bounds__(256) void range_scan_one_kernel(const int16_t *__restrict__ coefs, uint32_t n_blocks, const uint16_t *__restrict__ q,
+                                                             uint32_t *__restrict__ stats) {
+    range_scan_body(RangeView{coefs, n_blocks, 0u, q}, stats);
 }
 
 // ---- scans without restart markers: the self-synchronising chunk decoder (huff_sync_core.hpp) -------------------------
@@ -118,7 +136,9 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__
     sync_load_lds<64>(*(JP_LDS HuffSyncLds *)&L, gj);
     __shared__ uint32_t ring[HUFF_RING_DWORDS][64];
     const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
-    if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], 64u);
+    HuffRange rg;
+    if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], 64u);
+    publish_range(L.job.stats, rg);
 }
 
 // does chunk i have a start state it has not decoded from yet?  (what huff_sync_chunk decides itself, ahead of the call)
@@ -164,8 +184,9 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
         }
         if (need) todo[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
         __syncthreads();
+        HuffRange unused;
         if (threadIdx.x < total)
-            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it);
+            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);
         __syncthreads();
     }
     const uint32_t n_pub = (uint32_t)__syncthreads_count(published);
@@ -251,7 +272,9 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSync
     sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
     __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
     const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
-    if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
+    HuffRange rg;
+    if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
+    publish_range(L.job.stats, rg);
 }
 
 // The same with whole blocks assembled in LDS and written as 128-byte lines (HuffWriteBuf; two workgroups per CU by its size)
@@ -269,7 +292,9 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(cons
     __syncthreads();
     const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
     __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
-    huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
+    HuffRange rg;
+    huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
+    publish_range(L.job.stats, rg);
 }
 
 // DC differences -> DC values: a running sum (i16 wrapping, src/decoder.rs:1095-1099) per component over its blocks in
@@ -285,7 +310,8 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
     if (c >= job.ncomp || *job.status != 0u || !job.uniform) return;  // (other scans: the write pass stored DC values)
     const HuffScanComp sc = job.comp[c];
     const uint32_t hv = sc.h * sc.v, n = job.n_mcu * hv, cols = job.cols;
-    uint32_t carry = 0;
+    const uint32_t q0 = job.q[c][0];
+    uint32_t carry = 0, max_dc = 0;  // (the write pass of such a scan left the DC coefficients out of its range statistics)
     for (uint32_t base = 0; base < n; base += DC_NT * DC_E) {
         const uint32_t s0 = base + threadIdx.x * DC_E;
         JP_GLOBAL int16_t *addr[DC_E];
@@ -331,15 +357,26 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
         const uint32_t off = carry + before + incl - d[DC_E - 1u];
 #pragma unroll
         for (uint32_t e = 0; e < DC_E; e++)
-            if (addr[e]) *addr[e] = (int16_t)(uint16_t)(d[e] + off);
+            if (addr[e]) {
+                const int32_t v = (int16_t)(uint16_t)(d[e] + off);
+                *addr[e] = (int16_t)v;
+                max_dc = max(max_dc, (uint32_t)(v < 0 ? -v : v) * q0);
+            }
         carry += total;
         __syncthreads();
     }
+    publish_range(job.stats, HuffRange{max_dc, 0u});
 }
 
 hipError_t launch_huff_segments(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream) {
     if (n_jobs == 0 || max_segments == 0) return hipSuccess;
     huff_segments_kernel<<<dim3((max_segments + 63u) / 64u, n_jobs), dim3(64), 0, stream>>>(d_jobs);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream) {
+    if (n_blocks == 0) return hipSuccess;
+    range_scan_one_kernel<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, stream>>>(d_coefs, n_blocks, d_q, d_stats);
     return hipGetLastError();
 }
 
@@ -351,11 +388,16 @@ hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t m
 
 // Everything for the jobs without restart markers, enqueued blind: a fixed number of sync launches (settled jobs cost an
 // empty workgroup each), block numbering, the write pass and the DC sums.
-hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream) {
-    if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) return hipSuccess;
+hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
+                            hipEvent_t after_sync) {
+    if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) {
+        if (after_sync) (void)hipEventRecord(after_sync, stream);
+        return hipSuccess;
+    }
     const dim3 grid((max_chunks + SYNC_NT - 1u) / SYNC_NT, n_jobs);
     for (uint32_t l = 0; l < launches; l++) huff_sync_pass_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);
+    if (after_sync) (void)hipEventRecord(after_sync, stream);
     // The write pass runs best with TWO workgroups per CU: every lane keeps a cache line of the arena open for its 2-byte
     // stores, and fewer lanes in flight means fewer open lines (measured, 256 1080p images: 6 workgroups per CU 2.19 ms,
     // 4: 2.26, 2: 1.89, 1: 3.2).  Unused dynamic LDS is the occupancy limiter.

@@ -10,12 +10,17 @@ namespace jpgpu {
 struct RangeJob {  // one component plane to classify
     const int16_t *coefs;
     uint32_t n_blocks;
-    uint32_t slot;    // stats[2*slot] = max |c*q|, stats[2*slot+1] = max block-column sum of |c*q|
+    uint32_t slot;    // stats[RS_WORDS*slot + RS_MAX_AC] = max |c*q|, [.. + RS_MAX_COL] = max block-column sum of |c*q| (range_stats.hpp);
+                      // several jobs may share a slot (the planes of one image)
     uint16_t q[64];
 };
 
 hipError_t launch_huff_segments(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream);
-hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream);
+// after_sync (optional): recorded between the sync passes + block numbering and the write pass (phase timing)
+hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
+                            hipEvent_t after_sync = nullptr);
 hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t *d_stats, hipStream_t stream);
+// one plane whose quantization table sits in device memory; raises the RS_WORDS statistics words at d_stats
+hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream);
 
 }  // namespace jpgpu

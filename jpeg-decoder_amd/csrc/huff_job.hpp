@@ -77,6 +77,11 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
                                  // per pass: a lane synchronised in position but one block off would hand the error on forever)
     HuffScanComp comp[4];
     uint8_t q_comp[16], q_sub[16];  // block-within-MCU -> component of the scan, block inside that component's part of the MCU
+    // Range statistics as a by-product of the passes that write coefficients (the write pass, the restart-segment decoder, the
+    // DC sums of `uniform` scans): the image's RangeStats words (range_stats.hpp) in device memory, and the quantization
+    // tables of the scan's components in natural order — the writer sees every non-zero coefficient and its position anyway.
+    uint32_t *stats;
+    uint16_t q[4][64];
 };
 
 // Chunk size.  A lane that starts at a wrong place finds the symbol boundaries within a few symbols, the block boundaries at

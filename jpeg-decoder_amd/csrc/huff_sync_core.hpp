@@ -155,11 +155,17 @@ __device__ __forceinline__ void huff_flush_blocks(JP_LDS HuffWriteBuf &W, bool f
 //   WRITE:   store coefficients; `blkno` = number of the block being decoded (-> its MCU and address)
 //   dc_sums: dc[component] accumulates DC differences (WRITE: they are predictors, and the stored DC values are finished)
 // Returns the bit position reached; q, k, nblk (blocks completed), blkno, bad are updated.
+// Largest |coefficient * quantization value| among the DC / the AC coefficients a lane has written (range_stats.hpp): the
+// writer's by-product that spares the pixel kernels' feeder a second pass over the arena.
+struct HuffRange {
+    uint32_t dc = 0, ac = 0;
+};
+
 template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
 __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                              uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad,
-                                             JP_LDS HuffWriteBuf *W = nullptr, bool participate = true, JP_LDS uint32_t *ring = nullptr,
-                                             uint32_t ring_stride = 0) {
+                                             HuffRange &rg, JP_LDS HuffWriteBuf *W = nullptr, bool participate = true,
+                                             JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     // (huff_core.hpp) kernels that store decode from the LDS ring when they are given one; the sync passes fetch dwords ahead
 #ifdef JPGPU_HOST_EMULATION
@@ -177,6 +183,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
+    const JP_LDS uint16_t *qrow = L.job.q[c];  // quantization table of block q's component (WRITE: range statistics)
     JP_GLOBAL int16_t *blk = nullptr;
     uint32_t mx = 0, my = 0;  // the MCU of block `blkno` (write pass), kept by counting: no divisions per block
     if (WRITE) {
@@ -244,9 +251,14 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
                     if (ASSEMBLE && own) mine[0] = (uint16_t)val;
                     else blk[0] = (int16_t)val;
                 }
+                // (finished DC values only: the differences of a uniform scan are summed — and ranged — by huff_dc_prefix_kernel)
+                if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * qrow[0]);
             } else if (WRITE && (info & SYM_COEF)) {
-                if (ASSEMBLE && own) mine[L.unzig[k - 1u]] = (uint16_t)huff_extend(raw, nread);
-                else blk[L.unzig[k - 1u]] = (int16_t)huff_extend(raw, nread);
+                const uint32_t z = L.unzig[k - 1u];
+                const int32_t x = huff_extend(raw, nread);
+                if (ASSEMBLE && own) mine[z] = (uint16_t)x;
+                else blk[z] = (int16_t)x;
+                rg.ac = max(rg.ac, (uint32_t)(x < 0 ? -x : x) * qrow[z]);  // |x| <= 2^15, q <= 2^16 - 1
             }
         }
         if (k >= 64u && !bad) {  // end of the block
@@ -263,6 +275,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
             }
             qt = L.q_tables[q];
             c = job.q_comp[q];
+            if (WRITE) qrow = L.job.q[c];
             if (WRITE) {
                 if (ASSEMBLE && own) {
                     flush = true;
@@ -294,7 +307,8 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 // counts those per job: one atomic per workgroup, not per lane — a quarter of a million lanes adding to a few hundred
 // neighbouring counters took 18 ms per pass); WRITE = true: the write pass.
 template <bool WRITE>
-__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
+__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
+                                                uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     uint32_t pos, q, k;
@@ -346,7 +360,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         dc[2] = w1 & 0xffffu;
         dc[3] = w1 >> 16;
     }
-    if (pos < limit) pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, nullptr, true, ring, ring_stride);
+    if (pos < limit) pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
     if (!WRITE && dc_sums) {
         job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);
         job.dc_sum[2u * i + 1u] = (dc[2] & 0xffffu) | (dc[3] << 16);
@@ -370,7 +384,8 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
 
 // The write pass with block assembly (HuffWriteBuf): every lane of the workgroup calls it, `valid` = the lane has a chunk;
 // lanes without work still take part in the cooperative stores.  Same decisions as huff_sync_chunk<true>.
-__device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid, JP_LDS uint32_t *ring, uint32_t ring_stride) {
+__device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid, HuffRange &rg,
+                                                          JP_LDS uint32_t *ring, uint32_t ring_stride) {
     const JP_LDS HuffSyncJob &job = L.job;
     uint32_t pos = 0, q = 0, k = 0;
     bool participate = valid;
@@ -401,7 +416,7 @@ __device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L,
         dc[3] = w1 >> 16;
     }
     participate = participate && pos < limit;
-    const uint32_t end = huff_run<true, true, true>(L, job.data, participate ? pos : 0u, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, &W, participate, ring, ring_stride);
+    const uint32_t end = huff_run<true, true, true>(L, job.data, participate ? pos : 0u, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, &W, participate, ring, ring_stride);
     if (participate) pos = end;
     if (!valid) return;
     if (bad) atomicOr_status(job.status, 1u | 2u);
@@ -411,14 +426,15 @@ __device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L,
 // ---- streams WITH restart markers: one lane per restart segment (src/decoder.rs:920-956: the predictors and the bit
 // reader start afresh after every RSTn, so segments are independent).  The job record says where the segments lie
 // (seg_off, staged by huff_stage_segment one slot each) and how many MCUs one holds (ri); the decoding loop is huff_run.
-__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint32_t seg, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
+__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint32_t seg, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
+                                                    uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     const uint8_t *data = job.data + job.seg_off[2u * seg];
     const uint32_t seg_bits = job.seg_off[2u * seg + 1u] * 8u;
     const uint32_t m0 = seg * job.ri, m1 = min(m0 + job.ri, job.n_mcu);
     uint32_t q = 0, k = 0, nblk = 0, blkno = m0 * job.bpm;
     bool bad = false;
-    const uint32_t pos = huff_run<true, false>(L, data, 0u, seg_bits + 64u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, nullptr, true, ring, ring_stride);
+    const uint32_t pos = huff_run<true, false>(L, data, 0u, seg_bits + 64u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, rg, nullptr, true, ring, ring_stride);
     // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it tops up its 64-bit buffer —
     // bytes are appended while it holds at most 56 bits (src/huffman.rs:123-160) — and must MEET the marker doing so, which
     // happens iff the unread rest of the segment is at most 56 bits ("no marker found where RSTn was expected" otherwise);

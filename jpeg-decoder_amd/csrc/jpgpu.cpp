@@ -5,6 +5,7 @@
 // every compute entry point fails with JPGPU_ERR_NO_DEVICE.
 #include "../../include/jpgpu.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,7 +19,9 @@
 
 #include "fused.hpp"
 #include "host_common.hpp"
+#include "huff.hpp"
 #include "kernels.hpp"
+#include "range_stats.hpp"
 
 using namespace jpgpu;
 
@@ -48,6 +51,22 @@ const char *jpgpu_status_string(int status) {
 }  // extern "C"
 
 namespace jpgpu {
+
+const RoctxApi &roctx_api() {
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        if (getenv("JPGPU_NO_ROCTX")) return a;
+        void *h = nullptr;
+        for (const char *name : {"libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+        if (!h) return a;
+        a.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+        return a;
+    }();
+    return api;
+}
 
 int use_device(int device, std::string &err) {
     int n = 0;
@@ -101,6 +120,8 @@ struct jpgpu_worker {
     uint16_t *d_frame_qt = nullptr;                          // 4 x 64: the tables of the deferred planes, by frame slot
     jpgpu::FusedPlan fplan;                                  // one-image plan of the last geometry that took the fused route
     bool fplan_valid = false;
+    uint64_t fplan_bound[6] = {0, 0, 0, 0, 0, 0};            // what the plan's tables were last bound to (coefficients x 4, pixels, tables)
+    uint32_t *d_cls = nullptr;                               // RS_WORDS statistics words + 4 class-source bytes (all CLS_FROM_DEVICE)
     jpgpu_image_desc fplan_desc{};
     std::string last_path = "generic";
     // planes that went out of use (a frame slot was overwritten): start() takes them back instead of allocating —
@@ -246,6 +267,7 @@ void jpgpu_worker_destroy(jpgpu_worker *w) {
         }
         for (auto &sp : w->spare_coefs) hipFree(sp.first);
         if (w->d_frame_qt) hipFree(w->d_frame_qt);
+        if (w->d_cls) hipFree(w->d_cls);
         if (w->fplan_valid) jpgpu::fused_free(w->fplan);
         for (auto &t : w->d_tmp)
             if (t) hipFree(t);
@@ -258,6 +280,13 @@ void jpgpu_worker_destroy(jpgpu_worker *w) {
 
 const char *jpgpu_worker_last_error(const jpgpu_worker *w) { return w ? w->err.c_str() : ""; }
 const char *jpgpu_worker_last_path(const jpgpu_worker *w) { return w ? w->last_path.c_str() : ""; }
+int jpgpu_worker_last_class(jpgpu_worker *w) {
+    if (!w || !w->fplan_valid || w->last_path == "generic") return -1;
+    if (use_device(w->device, w->err) != JPGPU_OK) return -1;
+    std::vector<uint8_t> bits;
+    if (fused_read_classes(w->fplan, bits, w->err) != JPGPU_OK || bits.empty()) return -1;
+    return (bits[0] & 2u) ? 3 : ((bits[0] & 1u) ? 1 : 0);
+}
 
 int jpgpu_worker_start(jpgpu_worker *w, uint32_t index, const jpgpu_component *component,
                        const uint16_t quantization_table[64]) {
@@ -386,8 +415,12 @@ int jpgpu_worker_finish_plane(jpgpu_worker *w, uint32_t index, uint32_t plane_sl
     if (rc) return rc;
     auto &s = w->slot[index];
     auto &f = w->frame[plane_slot];
+    // what the frame slot held goes back to the spare lists; the slot forgets it right away — a failing call below must not
+    // leave a pointer owned twice (a later start() would hand the buffer out while the frame still names it)
     if (f.d_plane) w->spare_planes.emplace_back(f.d_plane, f.cap);
     if (f.d_coefs) w->spare_coefs.emplace_back(f.d_coefs, f.coef_cap);
+    f.d_plane = nullptr;
+    f.len = f.cap = 0;
     f.d_coefs = nullptr;
     f.coef_cap = 0;
     f.deferred = false;
@@ -531,14 +564,33 @@ int jpgpu_compute_image(jpgpu_worker *w, const jpgpu_component *components, uint
                 if (rc) return rc;
                 w->fplan_desc = d;
                 w->fplan_valid = true;
+                memset(w->fplan_bound, 0, sizeof(w->fplan_bound));
             }
         }
         if (fused) {
-            std::vector<size_t> coef_off(4, 0), out_off(1, 0);
-            for (uint32_t i = 0; i < ncomp; i++) coef_off[i] = (size_t)(uintptr_t)w->frame[i].d_coefs;  // absolute: the base is null
-            rc = fused_bind(w->fplan, nullptr, w->d_out, w->d_frame_qt, coef_off, out_off, std::vector<uint8_t>(4, 0), w->err);
-            if (rc) return rc;
-            W_HIP(fused_launch(w->fplan, w->stream));
+            // the plan's tables are rewritten (a blocking copy) only when the buffers behind them changed; a worker that decodes
+            // frame after frame of one geometry keeps its buffers
+            uint64_t key[6] = {0, 0, 0, 0, (uint64_t)(uintptr_t)w->d_out, (uint64_t)(uintptr_t)w->d_frame_qt};
+            for (uint32_t i = 0; i < ncomp; i++) key[i] = (uint64_t)(uintptr_t)w->frame[i].d_coefs;
+            if (memcmp(key, w->fplan_bound, sizeof(key)) != 0) {
+                std::vector<size_t> coef_off(4, 0), out_off(1, 0);
+                for (uint32_t i = 0; i < ncomp; i++) coef_off[i] = (size_t)key[i];  // absolute: the base is null
+                rc = fused_bind(w->fplan, nullptr, w->d_out, w->d_frame_qt, coef_off, out_off, std::vector<uint8_t>(4, 0), w->err);
+                if (rc) return rc;
+                memcpy(w->fplan_bound, key, sizeof(key));
+            }
+            // Nobody classified these coefficients on the way (that would be a pass over them on the host, 0.2-0.5 ms per 1080p
+            // frame): the device ranges them where they lie — a scan at HBM speed, microseconds for one frame — and the `_dyn`
+            // kernel takes the class from those statistics (range_stats.hpp).
+            if (!w->d_cls) {
+                W_HIP(hipMalloc((void **)&w->d_cls, (RS_WORDS + 1) * sizeof(uint32_t)));
+                W_HIP(hipMemset(w->d_cls + RS_WORDS, 0xff, sizeof(uint32_t)));
+            }
+            W_HIP(hipMemsetAsync(w->d_cls, 0, RS_WORDS * sizeof(uint32_t), w->stream));
+            for (uint32_t i = 0; i < ncomp; i++)
+                W_HIP(launch_range_scan_one(w->frame[i].d_coefs, (uint32_t)components[i].block_width * components[i].block_height,
+                                            w->d_frame_qt + i * 64, w->d_cls, w->stream));
+            W_HIP(fused_launch(w->fplan, w->stream, w->d_cls, reinterpret_cast<const uint8_t *>(w->d_cls + RS_WORDS)));
             w->last_path = w->fplan.name;
         }
     }

@@ -15,6 +15,7 @@
 #include "pixel_math.hpp"
 #include "idct_plane_body.hpp"
 #include "upsample_color_body.hpp"
+#include "range_stats.hpp"
 
 namespace jpgpu {
 
@@ -59,40 +60,86 @@ __global__ __launch_bounds__(256) void upsample_color_one_kernel(ImageJob job) {
 __global__ __launch_bounds__(256) void expand_compact_kernel(const ExpandJob *__restrict__ jobs) {
     const ExpandJob job = jobs[blockIdx.y];
     const uint32_t t = blockIdx.x * 256u + threadIdx.x, b = t >> 3, r = t & 7u;
-    if (b >= job.n_blocks) return;
-    const JP_GLOBAL uint64_t *bitmaps = (const JP_GLOBAL uint64_t *)job.compact;
-    const JP_GLOBAL uint32_t *first = (const JP_GLOBAL uint32_t *)(job.compact + (size_t)job.n_blocks * 8u);
-    const JP_GLOBAL int16_t *values = (const JP_GLOBAL int16_t *)(job.compact + (size_t)job.n_blocks * 12u);
-    const uint64_t bm = bitmaps[b];
-    const uint32_t bits = (uint32_t)(bm >> (8u * r)) & 0xffu;
-    uint32_t idx = first[b] + (uint32_t)__popcll(bm & ((1ull << (8u * r)) - 1ull));
-    uint32_t v[8];
+    if (blockIdx.x * 32u >= job.n_blocks) return;  // (whole workgroup beyond the plane)
+    const bool valid = b < job.n_blocks;            // (lanes beyond it stay for the wave reduction of the statistics)
+    uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        const JP_GLOBAL uint64_t *bitmaps = (const JP_GLOBAL uint64_t *)job.compact;
+        const JP_GLOBAL uint32_t *first = (const JP_GLOBAL uint32_t *)(job.compact + (size_t)job.n_blocks * 8u);
+        const JP_GLOBAL int16_t *values = (const JP_GLOBAL int16_t *)(job.compact + (size_t)job.n_blocks * 12u);
+        const uint64_t bm = bitmaps[b];
+        const uint32_t bits = (uint32_t)(bm >> (8u * r)) & 0xffu;
+        uint32_t idx = first[b] + (uint32_t)__popcll(bm & ((1ull << (8u * r)) - 1ull));
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        v[k] = 0u;
-        if (bits & (1u << k)) v[k] = (uint16_t)values[idx++];
+        for (uint32_t k = 0; k < 8; k++)
+            if (bits & (1u << k)) v[k] = (uint16_t)values[idx++];
+        const v4u row = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+        *reinterpret_cast<JP_GLOBAL v4u *>((JP_GLOBAL uint8_t *)job.dense + (size_t)b * 128u + r * 16u) = row;
     }
-    const v4u row = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
-    *reinterpret_cast<JP_GLOBAL v4u *>((JP_GLOBAL uint8_t *)job.dense + (size_t)b * 128u + r * 16u) = row;
+    if (job.stats) {  // (uniform per job) nobody classified these coefficients: their range, while they are in registers
+        const v4u qv = ((const JP_GLOBAL v4u *)job.qt)[r];
+        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+        uint32_t max_dc = 0, max_ac = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const int32_t c = (int16_t)(uint16_t)v[k];
+            const uint32_t p = (uint32_t)(c < 0 ? -c : c) * ((qw[k >> 1] >> (16u * (k & 1u))) & 0xffffu);
+            if (k == 0u && r == 0u) max_dc = p;
+            else max_ac = max(max_ac, p);
+        }
+        stat_publish_wave(job.stats, max_dc, max_ac);
+    }
 }
 
 // Progressive accumulation on the device: coefficient[index] += delta for the changes one scan made to
 // one component plane.  One lane per entry; a scan touches a coefficient at most once (host front-end, RowSink::scan_deltas),
 // so no atomics — launches of consecutive scans are ordered by their stream.  i16 wrapping add: the sum of all deltas is the
 // coefficient the host accumulated, which fits.
+// Range statistics on the way (range_stats.hpp): every value a coefficient takes is ranged, its final one among them, so the
+// maxima bound the finished plane from above.
 __global__ __launch_bounds__(256) void delta_add_kernel(const jpgpu_coef_delta *__restrict__ d, uint32_t n, int16_t *__restrict__ plane,
-                                                        uint32_t plane_coefficients) {
+                                                        uint32_t plane_coefficients, const uint16_t *__restrict__ qt, uint32_t *__restrict__ stats) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const jpgpu_coef_delta e = d[i];
-    if (e.index >= plane_coefficients) return;  // (checked on the host as well)
-    plane[e.index] = (int16_t)(uint16_t)((uint32_t)(uint16_t)plane[e.index] + (uint32_t)e.delta);
+    uint32_t max_dc = 0, max_ac = 0;
+    if (i < n) {
+        const jpgpu_coef_delta e = d[i];
+        if (e.index < plane_coefficients) {  // (checked on the host as well)
+            const int32_t v = (int16_t)(uint16_t)((uint32_t)(uint16_t)plane[e.index] + (uint32_t)e.delta);
+            plane[e.index] = (int16_t)v;
+            if (stats) {
+                const uint32_t z = e.index & 63u, p = (uint32_t)(v < 0 ? -v : v) * qt[z];
+                if (z == 0u) max_dc = p;
+                else max_ac = p;
+            }
+        }
+    }
+    if (stats) stat_publish_wave(stats, max_dc, max_ac);
+}
+
+// Device-side classes for the generic path: a plane job's class bits from the device statistics of its image (kept per image)
+// or from the class the host knows (fused kernels: class_finalize_fused_kernel, fused.hip).
+__global__ __launch_bounds__(256) void class_finalize_planes_kernel(PlaneJob *__restrict__ jobs, const uint32_t *__restrict__ slot, uint32_t n,
+                                                                    const uint32_t *__restrict__ stats, const uint8_t *__restrict__ host_cls) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t sl = slot[j], h = host_cls[sl];
+    const uint32_t *st = stats + (size_t)(sl >> 2) * RS_WORDS;
+    const uint32_t cls = h == CLS_FROM_DEVICE ? range_class_from_stats(st[RS_MAX_DC], st[RS_MAX_AC], st[RS_MAX_COL], st[RS_COL_EXACT]) : h;
+    jobs[j].flags = (cls & 1u) ? (cls & 3u) : 0u;
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, hipStream_t stream) {
+hipError_t launch_class_finalize_planes(PlaneJob *d_jobs, const uint32_t *d_slot, uint32_t n_jobs, const uint32_t *d_stats, const uint8_t *d_host_cls,
+                                        hipStream_t stream) {
+    if (n_jobs == 0 || !d_jobs || !d_slot || !d_stats || !d_host_cls) return hipSuccess;
+    class_finalize_planes_kernel<<<dim3((n_jobs + 255u) / 256u), dim3(256), 0, stream>>>(d_jobs, d_slot, n_jobs, d_stats, d_host_cls);
+    return hipGetLastError();
+}
+
+hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, const uint16_t *d_qt,
+                            uint32_t *d_stats, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    delta_add_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, stream>>>(d_entries, n, d_plane, plane_coefficients);
+    delta_add_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, stream>>>(d_entries, n, d_plane, plane_coefficients, d_qt, d_stats);
     return hipGetLastError();
 }
 

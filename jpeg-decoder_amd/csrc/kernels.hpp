@@ -10,11 +10,16 @@
 namespace jpgpu {
 
 struct ExpandJob;
-hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, hipStream_t stream);
+// d_qt / d_stats: the plane's quantization table and the image's RangeStats words (range_stats.hpp) on the device; null = no statistics
+hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, const uint16_t *d_qt,
+                            uint32_t *d_stats, hipStream_t stream);
 hipError_t launch_expand_compact(const ExpandJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, hipStream_t stream);
 hipError_t launch_idct_planes(const PlaneJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t scale,
                               hipStream_t stream);
 hipError_t launch_idct_plane_one(const PlaneJob &job, hipStream_t stream);
+// device-side classes (range_stats.hpp): d_jobs[j].flags from the statistics of image d_slot[j] / 4 and the host's class table
+hipError_t launch_class_finalize_planes(PlaneJob *d_jobs, const uint32_t *d_slot, uint32_t n_jobs, const uint32_t *d_stats, const uint8_t *d_host_cls,
+                                        hipStream_t stream);
 hipError_t launch_upsample_color(const ImageJob *d_jobs, uint32_t n_jobs, uint32_t max_w, uint32_t max_h,
                                  hipStream_t stream);
 hipError_t launch_upsample_color_one(const ImageJob &job, hipStream_t stream);

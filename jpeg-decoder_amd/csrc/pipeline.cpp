@@ -3,6 +3,7 @@
 // one image per task, rows staged in pinned memory, per-image async H2D, then the batch kernels (batch.cpp).
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -644,6 +645,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0;
     uint32_t device_rejected = 0, device_images = 0;
+    double dev_ms[4] = {0, 0, 0, 0};  // JPGPU_BATCH_KERNEL_TIMES: phases of the device entropy path, summed over the sub-batches
+    bool dev_ms_valid = false;
     // JPGPU_PIPELINE_PROGRESSIVE_DELTAS: per image the scans' deltas in the order they were decoded (workers push, the uploader
     // pops); the uploader keeps the entry lists alive until the streams have drained (hipMemcpyAsync reads them later)
     struct DeltaItem {
@@ -653,6 +656,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::vector<std::vector<DeltaItem>> delta_q(progressive_deltas ? n : 0);
     std::vector<size_t> delta_next(progressive_deltas ? n : 0, 0);
     std::vector<uint8_t> is_delta(n, 0), delta_cleared(n, 0);
+    // final quantization tables of the delta images: handed to the batch by the uploader thread, which is also the one that
+    // calls jpgpu_batch_add_deltas for them (the class bookkeeping of a component is touched by one thread only)
+    std::vector<std::array<uint16_t, 4 * 64>> delta_qt(progressive_deltas ? n : 0);
     std::mutex delta_m;
     // the pool is idle while device-entropy images are staged (its tasks for them return at once): lend it to the copy
     std::mutex par_m;
@@ -718,6 +724,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         if (jpgpu_batch_clear_coefficients(sb.batch, (uint32_t)p->slot[i], p->copy_streams[i % kCopyStreams]) != JPGPU_OK) hip_failed.store(1);
                         delta_cleared[i] = 1;
                     }
+                    // the tables its planes were finished with: if one differs from the table the deltas were ranged with
+                    // (the header's), that component's class goes back to "unknown" (jpgpu_batch_set_quantization_table)
+                    for (uint32_t c = 0; c < sb.descs[(uint32_t)p->slot[i]].ncomp; c++)
+                        jpgpu_batch_set_quantization_table(sb.batch, (uint32_t)p->slot[i], c, delta_qt[i].data() + 64 * c);
                 } else
                 if (it.second == 1 && !hip_failed.load()) {
                     hipStream_t cps = p->copy_streams[k++ % kCopyStreams];
@@ -753,6 +763,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
                                                                  p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams]) == JPGPU_OK;
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
+                        // The pixel kernels follow at once on the same stream: the classes of the decoded coefficients are a
+                        // by-product of the write pass and stay on the device (range_stats.hpp), so nothing has to come
+                        // back to the host in between.  What does come back, later, is the status word per image: an image
+                        // the device decoder refused is decoded here and the sub-batch's kernels run once more.
+                        if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) okk = false;
                         if (!okk) launch_err = jpgpu_batch_last_error(sb.batch);
                         else pending_subs.push_back((uint32_t)p->sub_of[i]);
                         if (!okk) hip_failed.store(1);
@@ -788,15 +803,22 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                             redo.emplace_back();
                             redo.back().image = dv[k2];
                         }
+                    {
+                        float ms[4];
+                        if (okk && jpgpu::batch_phase_times(sb.batch, ms)) {  // JPGPU_BATCH_KERNEL_TIMES
+                            dev_ms[0] += ms[0], dev_ms[1] += ms[1], dev_ms[2] += ms[2], dev_ms[3] += ms[3];
+                            dev_ms_valid = true;
+                        }
+                    }
                     if (!redo.empty()) {
                         const std::function<void(uint32_t)> body = [&](uint32_t r) { host_redecode_stage(p, sb, redo[r], data[redo[r].image], len[redo[r].image]); };
                         if (redo.size() > 1) par_for((uint32_t)redo.size(), body);
                         else body(0);
                         for (Redecode &r : redo) host_redecode_upload(p, sb, r);
-                    }
-                    if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {
-                        launch_err = jpgpu_batch_last_error(sb.batch);
-                        okk = false;
+                        if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {  // (the whole sub-batch once more: rare)
+                            launch_err = jpgpu_batch_last_error(sb.batch);
+                            okk = false;
+                        }
                     }
                     if (okk && download)
                         okk = hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, cs) == hipSuccess;
@@ -843,9 +865,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 for (uint32_t c = 0; c < nc; c++)
                     if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
                 for (uint32_t c = 0; c < nc; c++) {
-                    jpgpu_batch_set_quantization_table(sb.batch, bi, c, sink.qt(c));
-                    jpgpu_batch_set_range_class(sb.batch, bi, c, 0);  // the host never saw the finished planes: wrap-exact kernels
-                    cbytes[(size_t)i * 4 + c] = 0;
+                    memcpy(delta_qt[i].data() + 64 * c, sink.qt(c), 128);  // (the uploader passes them on; the class of the
+                    cbytes[(size_t)i * 4 + c] = 0;                        //  finished planes comes from the device's statistics)
                 }
                 jpeg_bytes += len[i];
                 coef_bytes += sent;
@@ -912,6 +933,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.download_ms = t4 - t3;
     p->t.total_ms = t4 - t0;
     p->t.images_ok = okc;
+    p->t.dev_times_valid = dev_ms_valid ? 1u : 0u;
+    p->t.dev_fill_ms = dev_ms[0];
+    p->t.dev_sync_ms = dev_ms[1];
+    p->t.dev_write_ms = dev_ms[2];
+    p->t.dev_pixel_ms = dev_ms[3];
     p->t.jpeg_bytes = jpeg_bytes.load();
     p->t.coefficient_bytes = coef_bytes.load();
     p->t.pixel_bytes = pixel_bytes;

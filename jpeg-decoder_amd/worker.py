@@ -97,6 +97,11 @@ class HipWorker:
         """Kernels of the last compute_image: "generic" or the fused kernel of the frame's kind."""
         return N.lib().jpgpu_worker_last_path(self._h).decode()
 
+    @property
+    def last_class(self):
+        """jpgpu_worker_last_class: range class (0 / 1 / 3) the last fused compute_image ran with, -1 after the generic kernels."""
+        return N.lib().jpgpu_worker_last_class(self._h)
+
     def compute_image(self, components, data, output_size, color_transform):
         """compute_image (src/decoder.rs:1300-1336) incl. compute_image_parallel
         (src/worker/mod.rs:97-128).  data: list of planes (np.uint8) or None to use the planes

@@ -14,6 +14,7 @@ using jpgpu::host::Frontend;
 using jpgpu::host::PlannedScan;
 
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
+static uint32_t g_range[2] = {0, 0};  // by-product of the last emu_huff_decode: largest |DC * q| / |AC * q| written (range_stats.hpp)
 
 extern "C" {
 // huff_stage_segment / huff_sync_chunk_shift as the product uses them (host-side helpers of csrc/huff_job.hpp)
@@ -26,6 +27,7 @@ int emu_stage_segment_clean(uint8_t* dst, const uint8_t* src, uint32_t n) {
 }
 uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return huff_sync_chunk_shift(stuffed_bytes, total_blocks); }
 
+void emu_huff_last_range(uint32_t out[2]) { out[0] = g_range[0], out[1] = g_range[1]; }
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
     g_sync_stale = stale;
     g_sync_iters = iters ? iters : 1u;
@@ -63,6 +65,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
     if (!fe.plan_device_scans(scans)) return -1;
     uint32_t status = 0;
     HuffSyncLds* L = new HuffSyncLds;
+    HuffRange rg;  // what the kernels fold per wave and raise in the image's statistics words
     for (const PlannedScan& ps : scans) {
         // staging as batch.cpp does it: every segment unstuffed into its own 16-byte aligned, zero padded slot
         size_t total = 0;
@@ -100,6 +103,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 sj.comp[c].v = ps.comp[c].v;
                 sj.comp[c].dc = ps.comp[c].dc;
                 sj.comp[c].ac = ps.comp[c].ac;
+                memcpy(sj.q[c], fe.qtable_of_component(ps.comp[c].frame_index), 128);
             }
             huff_sync_finish_job(sj);
             sj.chunk_shift = huff_sync_chunk_shift(ps.seg_off[1] - ps.seg_off[0], sj.bpm * ps.n_mcu);
@@ -140,7 +144,8 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                         for (uint32_t i = lo; i < hi; i++) {
                             std::copy(prev_pos.begin(), prev_pos.end(), sj.out_pos + first);
                             std::copy(prev_qk.begin(), prev_qk.end(), sj.out_qk + first);
-                            changed += huff_sync_chunk<false>(*S, i, launch * iters + it) ? 1u : 0u;
+                            HuffRange unused;
+                            changed += huff_sync_chunk<false>(*S, i, launch * iters + it, unused) ? 1u : 0u;
                             new_pos[i - first] = sj.out_pos[i];
                             new_qk[i - first] = sj.out_qk[i];
                         }
@@ -169,7 +174,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     for (int f = 0; f < 4; f++) acc[f] += v[f];
                 }
             }
-            for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0);
+            for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0, rg);
             // (huff_dc_prefix_kernel, uniform scans only) DC differences -> values, per component in stream order (i16 wrapping)
             for (uint32_t c = 0; sj.uniform && c < ps.ncomp; c++) {
                 const HuffScanComp& sc = sj.comp[c];
@@ -181,6 +186,8 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                         int16_t* blk = sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u;
                         acc = (uint16_t)(acc + (uint16_t)blk[0]);
                         blk[0] = (int16_t)acc;
+                        const int32_t v = (int16_t)acc;  // (the kernel ranges the finished DC values of such a scan)
+                        rg.dc = std::max(rg.dc, (uint32_t)(v < 0 ? -v : v) * sj.q[c][0]);
                     }
             }
             if (n_passes) *n_passes = pass;
@@ -205,14 +212,16 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             job.comp[c].v = ps.comp[c].v;
             job.comp[c].dc = ps.comp[c].dc;
             job.comp[c].ac = ps.comp[c].ac;
+            memcpy(job.q[c], fe.qtable_of_component(ps.comp[c].frame_index), 128);
         }
         huff_sync_finish_job(job);
         memcpy(L->tables, ps.tables, sizeof(L->tables));
         for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(L->unzig, t);
         for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*L, t);
-        for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s);
+        for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s, rg);
     }
     delete L;
+    g_range[0] = rg.dc, g_range[1] = rg.ac;
     return (int)status;
 }
 }

@@ -158,3 +158,17 @@ def test_compact_encoder_range_class_on_hostile_and_16bit_tables():
     assert both(edge, ones) == (1, 1)
     edge[8] = 5163  # column 0 sum exactly 5900, block total far above: the exact path must still say 3
     assert both(edge, ones) == (3, 3)
+
+
+def test_library_does_not_need_the_tracing_library_to_load():
+    """roctx ranges are resolved at run time (dlopen) and are no-ops where libroctx64 is absent: the library
+    must not carry a load-time dependency on it."""
+    import shutil
+    import subprocess
+    J.build()
+    tool = shutil.which("readelf") or shutil.which("objdump")
+    if not tool:
+        pytest.skip("no readelf / objdump")
+    args = [tool, "-d", J._native.LIB_PATH] if tool.endswith("readelf") else [tool, "-p", J._native.LIB_PATH]
+    out = subprocess.run(args, capture_output=True, text=True).stdout
+    assert "NEEDED" in out and "roctx" not in out, [l for l in out.splitlines() if "roctx" in l]

@@ -39,6 +39,43 @@ def _device(data):
     return st, desc, planes, ns.value, nseg.value
 
 
+def _range_by_product():
+    """(max |DC * q|, max |AC * q|) the write passes of the last _device() call folded (csrc/range_stats.hpp)."""
+    out = (C.c_uint32 * 2)()
+    emu.lib().emu_huff_last_range(out)
+    return int(out[0]), int(out[1])
+
+
+def _exact_ranges(desc, planes):
+    """The same two maxima, and the exact class of include/jpgpu.h, from the finished planes."""
+    max_dc = max_ac = 0
+    cls = 3
+    for c in range(desc.ncomp):
+        q = np.array(list(desc.quantization_tables[c]), np.int64).reshape(8, 8)
+        s = np.abs(planes[c].astype(np.int64).reshape(-1, 8, 8) * q)
+        max_dc = max(max_dc, int(s[:, 0, 0].max()))
+        ac = s.copy()
+        ac[:, 0, 0] = 0
+        max_ac = max(max_ac, int(ac.max()))
+        cls = min(cls, N.lib().jpgpu_range_class(planes[c].ctypes.data, planes[c].size, np.array(list(desc.quantization_tables[c]), np.uint16).ctypes.data))
+    return max_dc, max_ac, cls
+
+
+def _class_from_by_product(max_dc, max_ac):
+    """range_class_from_stats without exact column sums (csrc/range_stats.hpp)."""
+    if max(max_dc, max_ac) >= 1 << 15:
+        return 0
+    return 3 if max(max_dc + 7 * max_ac, 8 * max_ac) <= 5900 else 1
+
+
+def _check_range_by_product(desc, planes):
+    got = _range_by_product()
+    max_dc, max_ac, exact_cls = _exact_ranges(desc, planes)
+    assert got == (max_dc, max_ac), (got, max_dc, max_ac)  # the writer sees every non-zero coefficient exactly once
+    assert _class_from_by_product(*got) <= exact_cls       # and the class drawn from the two maxima never overstates
+    return _class_from_by_product(*got), exact_cls
+
+
 def _pil_jpeg(w, h, subsampling, restart_blocks=0, restart_rows=0, gray=False, quality=85, seed=1):
     from PIL import Image
     rgb = synth.synthetic_rgb(w, h, seed=seed)
@@ -64,6 +101,7 @@ def test_reference_fixtures_with_restart_markers(rel):
     for c in range(desc.ncomp):
         assert np.array_equal(planes[c], hcoefs[c]), c
         assert list(desc.quantization_tables[c]) == list(hdesc.quantization_tables[c])
+    _check_range_by_product(desc, planes)
 
 
 @pytest.mark.parametrize("case", [(64, 48, "4:2:0", 0, 1), (250, 130, "4:2:0", 3, 0), (129, 257, "4:2:2", 0, 2), (200, 120, "4:4:4", 1, 0),
@@ -80,6 +118,8 @@ def test_encoder_written_restart_streams(case):
     hdesc, hcoefs = _host(data)
     for c in range(desc.ncomp):
         assert np.array_equal(planes[c], hcoefs[c]), c
+    got_cls, exact_cls = _check_range_by_product(desc, planes)
+    assert got_cls == exact_cls == 3, (got_cls, exact_cls)  # the bench's synthetic image at quality 85: the tight class either way
 
 
 def test_only_plain_sequential_streams_are_planned():
@@ -126,6 +166,7 @@ def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_
     assert _device.last_passes <= 6, _device.last_passes  # launches until one changed nothing
     for c in range(desc.ncomp):
         assert np.array_equal(planes[c], hcoefs[c]), c
+    _check_range_by_product(desc, planes)  # (uniform scans — rgb.jpg, the CMYK files — range their DC values in the DC-sum step)
 
 
 @pytest.mark.parametrize("case", [(64, 48, "4:2:0"), (250, 130, "4:2:0"), (129, 257, "4:2:2"), (200, 120, "4:4:4"), (300, 200, None),

@@ -723,3 +723,170 @@ def test_batch_quantization_table_replaced_after_upload():
         b.close()
         assert np.array_equal(got0, O.pixels_from_coefficients(ocomps, small, coefs, w_, h_, "YCBCR"))
         assert np.array_equal(got1, O.pixels_from_coefficients(ocomps, big, coefs, w_, h_, "YCBCR"))
+
+
+# ---- classes decided ON THE DEVICE (csrc/range_stats.hpp): no host between the writer of the coefficients and the pixel kernels ----
+def _exact_image_class(qts, coefs):
+    import ctypes as C  # noqa: F401
+    from jpeg_decoder_amd import _native as N
+    cls = 3
+    for q, c in zip(qts, coefs):
+        a = np.ascontiguousarray(c, np.int16).reshape(-1)
+        qq = np.ascontiguousarray(q, np.uint16).reshape(64)
+        cls = min(cls, N.lib().jpgpu_range_class(a.ctypes.data, a.size, qq.ctypes.data))
+    return cls
+
+
+def _by_product_image_class(qts, coefs):
+    """Class drawn from max |DC*q| and max |AC*q| alone (what writers that see one coefficient at a time leave behind)."""
+    max_dc = max_ac = 0
+    for q, c in zip(qts, coefs):
+        s = np.abs(np.asarray(c, np.int64).reshape(-1, 64) * np.asarray(q, np.int64).reshape(64))
+        max_dc = max(max_dc, int(s[:, 0].max()))
+        max_ac = max(max_ac, int(s[:, 1:].max()))
+    if max(max_dc, max_ac) >= 1 << 15:
+        return 0
+    return 3 if max(max_dc + 7 * max_ac, 8 * max_ac) <= 5900 else 1
+
+
+DYN_KINDS = [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1), (1, 1), (1, 1)], "YCbCr"), ([(2, 1), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)], "Grayscale"),
+             ([(1, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)] * 4, "YCCK"), ([(4, 1), (1, 1), (1, 1)], "YCbCr"), ([(3, 1), (1, 1), (1, 1)], "YCbCr")]
+DYN_IDS = ["420", "444", "422", "gray", "440", "ycck", "411", "311-generic"]
+
+
+@pytest.mark.parametrize("strip", ["1", "0"], ids=["single-launch", "two-pass"])
+@pytest.mark.parametrize("samp,ct", DYN_KINDS, ids=DYN_IDS)
+def test_classes_decided_on_the_device_every_kernel(samp, ct, strip, monkeypatch):
+    """jpgpu_batch_classify_on_device: the range statistics stay in HBM, a finalize kernel turns them into the images' classes
+    in front of the pixel kernels, and ONE `_dyn` launch per kind branches per workgroup — 64 images of all three classes, every
+    one equal to the oracle, and the split the device arrives at equal to the host's exact classification (VERDICT r2 next #2)."""
+    if strip == "0" and samp[0] != (2, 2):
+        pytest.skip("the two-pass form exists for 4:2:0 only")
+    monkeypatch.setenv("JPGPU_420_STRIP", strip)
+    rng = np.random.default_rng(len(samp) * 100 + samp[0][0] * 10 + samp[0][1] + 5)
+    w_, h_ = 200, 120
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind="tight") for _ in range(64)]
+    for i in (3, 17, 63):
+        cases[i] = _batch_case(rng, w_, h_, samp, ct, kind="full")
+    for i in (0, 40):
+        cases[i] = _batch_case(rng, w_, h_, samp, ct, kind="sane")
+    descs = [J.image_desc(list(to_j(oc)), qts, w, h, ct_) for oc, qts, _c, ct_, w, h in cases]
+    b = J.Batch(descs)
+    try:
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            for c in range(len(coefs)):
+                b.upload(i, c, coefs[c])
+                b._check(J._native.lib().jpgpu_batch_set_range_class(b._h, i, c, 0))  # forget what upload() found out
+        b.classify_on_device()
+        for rep in range(2):  # (the second decode reuses statistics and tables)
+            b.decode()
+        b.synchronize()
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
+        if b.path.startswith("fused"):
+            want = [0, 0, 0]
+            for oc, qts, coefs, *_ in cases:
+                want[{0: 0, 1: 1, 3: 2}[_exact_image_class(qts, coefs)]] += 1
+            assert b.class_counts() == tuple(want), (b.class_counts(), want)
+            assert want[0] >= 3 and want[2] >= 50
+        # a class set from the host afterwards takes over for that image: everything hostile -> still the oracle's pixels
+        for i in range(len(cases)):
+            b.set_range_hint(i, 0)
+        b.decode()
+        b.synchronize()
+        if b.path.startswith("fused"):
+            assert b.class_counts() == (64, 0, 0)
+        for i in (0, 1, 17):
+            oc, qts, coefs, ct_, _w, _h = cases[i]
+            assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("samp,ct", [DYN_KINDS[0], DYN_KINDS[1], DYN_KINDS[3], DYN_KINDS[7]], ids=["420", "444", "gray", "311-generic"])
+def test_compact_upload_ranged_by_the_expansion_kernel(samp, ct):
+    """jpgpu_batch_upload_compact with range_class = -1: expand_compact_kernel ranges the values while it has them in registers;
+    the class drawn from its two maxima never overstates the exact one, and the pixels are the oracle's."""
+    rng = np.random.default_rng(99 + len(samp))
+    w_, h_ = 136, 72
+    kinds = ["tight", "sparse", "full", "sane", "tight", "sparse"]
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind=k) for k in kinds]
+    descs = [J.image_desc(list(to_j(oc)), qts, w, h, ct_) for oc, qts, _c, ct_, w, h in cases]
+    b = J.Batch(descs)
+    try:
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            for c in range(len(coefs)):
+                b.upload_compact(i, c, coefs[c], classify=(i == 1))  # image 1: the host encoder's class next to the device's
+        b.decode()
+        b.synchronize()
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
+        if b.path.startswith("fused"):
+            want = [0, 0, 0]
+            for i, (oc, qts, coefs, *_r) in enumerate(cases):
+                cls = _exact_image_class(qts, coefs) if i == 1 else _by_product_image_class(qts, coefs)
+                assert cls <= _exact_image_class(qts, coefs)
+                want[{0: 0, 1: 1, 3: 2}[cls]] += 1
+            assert b.class_counts() == tuple(want), (b.class_counts(), want)
+        # the same components sent again with other data: the statistics start afresh (a hostile image becomes a tame one)
+        oc, qts, coefs, ct_, _w, _h = cases[0]
+        for c in range(len(coefs)):
+            b.upload_compact(2, c, coefs[c], classify=False)
+            b.set_quantization_table(2, c, qts[c])
+        for c in range(len(coefs)):  # (the table change reset the class to "unknown": send once more under the new table)
+            b.upload_compact(2, c, coefs[c], classify=False)
+        b.decode()
+        b.synchronize()
+        assert np.array_equal(b.download(2), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
+        if b.path.startswith("fused"):
+            assert b.class_counts()[0] == 0 or _by_product_image_class(qts, coefs) == 0
+    finally:
+        b.close()
+
+
+def test_deltas_ranged_by_the_accumulation_kernel():
+    """jpgpu_batch_add_deltas: the kernel ranges every value a coefficient takes; the finished plane's class comes from those
+    statistics on the device (round 2 ran such images wrap-exact)."""
+    rng = np.random.default_rng(4242)
+    w_, h_ = 96, 64
+    samp, ct = [(2, 2), (1, 1), (1, 1)], "YCbCr"
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind=k) for k in ("tight", "full", "tight")]
+    descs = [J.image_desc(list(to_j(oc)), qts, w, h, ct_) for oc, qts, _c, ct_, w, h in cases]
+    b = J.Batch(descs)
+    try:
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            b.clear_coefficients(i)
+            for c in range(len(coefs)):
+                final = np.asarray(coefs[c], np.int64)
+                idx = np.flatnonzero(final)
+                first = rng.integers(-2, 3, idx.size)  # two "scans": a first value, then the correction to the final one
+                b.add_deltas(i, c, idx.astype(np.uint32), first.astype(np.int32))
+                b.add_deltas(i, c, idx.astype(np.uint32), (final[idx] - first).astype(np.int32))
+        b.decode()
+        b.synchronize()
+        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
+            assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
+        counts = b.class_counts()
+        assert counts[0] == 1 and sum(counts) == 3, counts  # the hostile image runs wrap-exact, the tame ones do not
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("kind,want_cls", [("tight", 3), ("sane", 1), ("full", 0)])
+def test_worker_fused_route_classifies_on_the_device(kind, want_cls):
+    """The drop-in surface's fused route ranges the frame's coefficients on the device (a scan in front of the kernel, nothing
+    read back) instead of running every frame wrap-exact."""
+    w_, h_, samp, ct = 250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"
+    rng = np.random.default_rng(31 + want_cls)
+    oc, qts, coefs, _ct, _w, _h = _batch_case(rng, w_, h_, samp, ct, kind=kind)
+    comps = to_j(oc)
+    want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct.upper())
+    with J.HipWorker() as w:
+        for rep in range(3):
+            for i in range(3):
+                w.start(J.RowData(i, comps[i], qts[i]))
+                w.append_rows_contiguous(i, coefs[i], comps[i].block_height // comps[i].vertical_sampling_factor)
+                w.finish_plane(i, i)
+            got = w.compute_image(list(comps), None, (w_, h_), ct)
+            assert w.last_path == "fused420" and np.array_equal(got, want)
+            assert w.last_class == _exact_image_class(qts, coefs) == want_cls
