@@ -136,6 +136,9 @@ int jpgpu_pipeline_image_info(const jpgpu_pipeline *p, uint32_t image, jpgpu_ima
 size_t jpgpu_pipeline_pixel_bytes(const jpgpu_pipeline *p, uint32_t image);
 const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t image); /* HBM, NULL if the image failed */
 const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t image); /* only with JPGPU_PIPELINE_DOWNLOAD */
+/* One image's pixels of the last decode call, HBM -> `dst` (blocking): for calls that left the pixels on the device and want
+ * to look at a few of them.  `*len` receives the byte count even when `cap` is too small (then JPGPU_ERR_FORMAT). */
+int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t image, uint8_t *dst, size_t cap, size_t *len);
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p);                   /* "fused420", "generic", ... */
 int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t);
 

@@ -560,6 +560,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         return JPGPU_OK;
     }
     std::vector<uint32_t> bounds{0u};  // sub-batch j = ok[bounds[j] .. bounds[j+1])
+    uint32_t n_dev_subs = 0;           // the first sub-batches hold the images whose entropy data goes to the device
     {
         // streams with restart markers: one lane per restart segment, ~1,000 images fill the machine; without: one lane
         // per chunk of the scan, 256 images do, and smaller sub-batches let staging, upload and kernels of neighbours overlap
@@ -570,6 +571,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_chunked * 2u >= n_dev ? 4u : 16u) * kSubBatchImages;
         const uint32_t dev_subs = n_dev ? std::min<uint32_t>(kMaxSubBatches / 2u, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;
         for (uint32_t j = 1; j <= dev_subs; j++) bounds.push_back((uint32_t)((uint64_t)n_dev * j / dev_subs));
+        n_dev_subs = dev_subs;
         const uint32_t n_host = (uint32_t)ok.size() - n_dev;
         const uint32_t host_subs = n_host ? std::min<uint32_t>(kMaxSubBatches - dev_subs, (n_host + kSubBatchImages - 1u) / kSubBatchImages) : 0u;
         for (uint32_t j = 1; j <= host_subs; j++) bounds.push_back(n_dev + (uint32_t)((uint64_t)n_host * j / host_subs));
@@ -586,7 +588,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             descs.push_back(cand[ok[k]]);
         }
         sb.remaining = last - first;
-        bool reuse = sb.batch && descs.size() == sb.descs.size() && sb.compact == compact;
+        // Sub-batches of device-entropy images need no pinned staging for coefficients (their entropy-coded bytes are staged by
+        // the batch itself; an image the device decoder hands back is decoded into memory of its own): for 4096 x 1080p that
+        // would have been 28 GB of pinned host memory.
+        const bool staged = j >= n_dev_subs;
+        bool reuse = sb.batch && descs.size() == sb.descs.size() && sb.compact == compact && (sb.h_coef != nullptr) == staged;
         for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], sb.descs[k]);
         if (!reuse) {
             sb.drop();
@@ -617,7 +623,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     }
                 sb.h_coef_bytes = std::max<size_t>(so, 256);
             }
-            P_HIP(hipHostMalloc((void **)&sb.h_coef, sb.h_coef_bytes, hipHostMallocDefault));
+            if (staged) P_HIP(hipHostMalloc((void **)&sb.h_coef, sb.h_coef_bytes, hipHostMallocDefault));
+            else sb.h_coef_bytes = 0;
         }
         if (download && !sb.h_out) {
             sb.h_out_bytes = jpgpu_batch_out_arena_bytes(sb.batch);
@@ -971,6 +978,14 @@ const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t i) {
 const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t i) {
     const SubBatch *sb = sub_of(p, i);
     return (sb && sb->h_out && p->downloaded) ? sb->h_out + jpgpu_batch_out_offset(sb->batch, (uint32_t)p->slot[i]) : nullptr;
+}
+int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t i, uint8_t *dst, size_t cap, size_t *len) {
+    if (!p) return JPGPU_ERR_FORMAT;
+    const SubBatch *sb = sub_of(p, i);
+    if (!sb) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "download: image %u has no pixels", i);
+    const int rc = jpgpu_batch_download(sb->batch, (uint32_t)p->slot[i], dst, cap, len);
+    if (rc) p->err = jpgpu_batch_last_error(sb->batch);
+    return rc;
 }
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return p ? p->path.c_str() : ""; }
 int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t) {

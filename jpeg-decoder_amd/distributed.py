@@ -15,16 +15,22 @@ def shard(n_items, rank, world):
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def init(backend=None):
-    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+def init(backend=None, force=False):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1 unless `force`:
+    a one-rank group — the collective library's set-up and collectives exercised on a single GPU)."""
     import torch
     import torch.distributed as dist
 
     rank, local_rank, world = env_rank_world()
-    if world == 1:
+    if world == 1 and not force:
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1]) if world == 1 else "29511"
+        s.close()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
@@ -41,9 +47,20 @@ def max_over_ranks(values, device="cpu"):
     import torch.distributed as dist
 
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():  # (a one-rank group too: bench.py --force-dist runs the collective on the device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(x) for x in t]
+
+
+def min_over_ranks(value, device="cpu"):
+    """MIN of one float over all ranks (e.g. the job size every rank can hold)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t[0])
 
 
 def gather_pixels(local, dst=0):

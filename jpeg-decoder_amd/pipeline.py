@@ -67,6 +67,15 @@ class Pipeline:
             return None
         return ImageInfo(i.width, i.height, PIXEL_FORMATS[i.pixel_format], CODING_PROCESSES[i.coding_process])
 
+    def download(self, image):
+        """jpgpu_pipeline_download: one image's pixels of the last call from HBM (for calls made with download=False)."""
+        n = N.lib().jpgpu_pipeline_pixel_bytes(self._h, image)
+        out = np.empty(max(n, 1), np.uint8)
+        got = C.c_size_t(0)
+        st = N.lib().jpgpu_pipeline_download(self._h, image, out.ctypes.data, out.size, C.byref(got))
+        check(st, N.lib().jpgpu_pipeline_last_error(self._h) if st else b"")
+        return out[: got.value]
+
     def device_pointer(self, image):
         return N.lib().jpgpu_pipeline_pixels_device(self._h, image)
 

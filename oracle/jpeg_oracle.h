@@ -133,6 +133,9 @@ void orc_decode(const uint8_t *data, size_t len, uint16_t req_w, uint16_t req_h,
                 int color_transform_override, int keep_intermediates, orc_result *res);
 void orc_free_result(orc_result *res);
 
+/* bench.py's cpu_baseline_e2e: orc_decode of n streams, one stream per task over nthreads host threads (oracle_batch.c) */
+int orc_batch_decode(const uint8_t *const *data, const size_t *len, int n, int nthreads, int *ok, unsigned long long *pixels);
+
 #ifdef __cplusplus
 }
 #endif

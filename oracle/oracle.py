@@ -116,6 +116,8 @@ def lib(path=None):
         L.orc_batch_pixels.argtypes = [C.POINTER(Component), C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_int,
                                        C.c_uint16, C.c_uint16, C.c_int, C.POINTER(C.c_void_p), C.c_int]
         L.orc_batch_pixels.restype = C.c_int
+        L.orc_batch_decode.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        L.orc_batch_decode.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -250,3 +252,15 @@ def batch_pixels(comps, qts, coefs_per_image, out_w, out_h, color_transform, nth
     if rc:
         raise OracleError(rc, "batch")
     return outs
+
+
+def batch_decode(streams, nthreads):
+    """CPU baseline leg (end to end): Decoder::new(bytes).decode() of every stream, one stream per task over `nthreads`
+    threads (oracle_batch.c).  -> (streams decoded, pixel bytes produced); the pixels themselves are dropped."""
+    bufs = [bytes(s) for s in streams]
+    n = len(bufs)
+    ptrs = (C.c_char_p * max(n, 1))(*bufs)
+    lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+    ok, px = C.c_int(0), C.c_ulonglong(0)
+    lib().orc_batch_decode(ptrs, lens, n, nthreads, C.byref(ok), C.byref(px))
+    return ok.value, px.value

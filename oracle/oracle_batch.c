@@ -83,3 +83,57 @@ int orc_batch_pixels(const orc_component *comps, int ncomp, const uint16_t *qts,
     pthread_mutex_destroy(&b.mu);
     return b.status;
 }
+
+/* ---- whole decodes (bench.py's `cpu_baseline_e2e`): Decoder::new(bytes).decode() for every stream, one stream per task over
+ * `nthreads` host threads — what a rayon user of the reference gets with par_iter over files (per image a serial
+ * parse + Huffman + IDCT, src/decoder.rs:297-1298, then upsampling and colour conversion).  The pixels are dropped; `ok`
+ * receives the number of streams that decoded, `pixels` the pixel bytes they produced. ---- */
+typedef struct {
+    const uint8_t *const *data;
+    const size_t *len;
+    int n, next, ok;
+    unsigned long long pixels;
+    pthread_mutex_t mu;
+} decode_batch_t;
+
+static void *decode_worker(void *arg) {
+    decode_batch_t *b = (decode_batch_t *)arg;
+    int ok = 0;
+    unsigned long long pixels = 0;
+    for (;;) {
+        pthread_mutex_lock(&b->mu);
+        int i = b->next++;
+        pthread_mutex_unlock(&b->mu);
+        if (i >= b->n) break;
+        orc_result res;
+        orc_decode(b->data[i], b->len[i], 0, 0, -1 /* determine_color_transform */, 0, &res);
+        if (res.status == 0) {
+            ok++;
+            pixels += res.pixels_len;
+        }
+        orc_free_result(&res);
+    }
+    pthread_mutex_lock(&b->mu);
+    b->ok += ok;
+    b->pixels += pixels;
+    pthread_mutex_unlock(&b->mu);
+    return NULL;
+}
+
+int orc_batch_decode(const uint8_t *const *data, const size_t *len, int n, int nthreads, int *ok, unsigned long long *pixels) {
+    decode_batch_t b;
+    memset(&b, 0, sizeof(b));
+    b.data = data;
+    b.len = len;
+    b.n = n;
+    pthread_mutex_init(&b.mu, NULL);
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, decode_worker, &b);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&b.mu);
+    if (ok) *ok = b.ok;
+    if (pixels) *pixels = b.pixels;
+    return 0;
+}

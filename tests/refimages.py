@@ -69,3 +69,12 @@ def max_diff_vs_png(pixels, ncomp, png_path):
     got = cmyk_to_rgb(pixels) if ncomp == 4 else np.asarray(pixels, dtype=np.uint8).reshape(-1)
     assert ref.size == got.size, (ref.size, got.size)
     return int(np.abs(ref.astype(np.int32) - got.astype(np.int32)).max())
+
+
+ANCHOR = os.path.join(GOLDEN, "anchor")
+
+
+def anchor_files():
+    """4:4:0 / 4:1:1 files with libjpeg-turbo's decodes beside them (tests/golden/anchor/README.md): the external anchor for
+    the two upsamplers the reference holds no fixture for."""
+    return sorted(os.path.basename(f) for f in glob.glob(os.path.join(ANCHOR, "*.jpg")))

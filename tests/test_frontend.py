@@ -14,7 +14,7 @@ import refimages as R
 import jpeg_decoder_amd as J
 
 ALL_GOOD = sorted(glob.glob(os.path.join(R.REFTEST, "*.jpg")) + glob.glob(os.path.join(R.REFTEST, "mozilla", "*.jpg")) +
-                  glob.glob(os.path.join(R.GOLDEN, "benches", "*.jpg")))
+                  glob.glob(os.path.join(R.GOLDEN, "benches", "*.jpg")) + glob.glob(os.path.join(R.ANCHOR, "*.jpg")))
 HOSTILE = sorted(glob.glob(os.path.join(R.GOLDEN, "crashtest", "*.jpg")) +
                  glob.glob(os.path.join(R.GOLDEN, "crashtest", "imagetestsuite", "*.jpg")))
 

@@ -157,3 +157,30 @@ def test_trim_caches_between_decodes():
     assert np.array_equal(J.Decoder(prog).decode(), O.decode(prog).pixels)
     N.lib().jpgpu_trim_caches()
     assert np.array_equal(J.Decoder(prog).decode(), O.decode(prog).pixels)
+
+
+@pytest.mark.parametrize("name", R.anchor_files())
+def test_anchor_440_411_bit_exact_and_within_tolerance_of_libjpeg_turbo(name):
+    """The 4:4:0 / 4:1:1 anchor files (tests/golden/anchor: decoded by libjpeg-turbo): GPU == oracle byte for byte, through the
+    Decoder (Worker route: fused440 / fusedgen kernels) and through a batch of all of them at once, and within 3 of the
+    external decode."""
+    path = os.path.join(R.ANCHOR, name)
+    data = open(path, "rb").read()
+    od = O.decode(data)
+    got = J.Decoder(data).decode()
+    assert np.array_equal(got, od.pixels)
+    assert R.max_diff_vs_png(got, od.ncomp, os.path.splitext(path)[0] + ".png") <= 3
+
+
+def test_anchor_files_through_the_pipeline():
+    files = [open(os.path.join(R.ANCHOR, n), "rb").read() for n in R.anchor_files()]
+    assert len(files) >= 6
+    p = J.Pipeline()
+    try:
+        for dev in (True, False):
+            out = p.decode(files, download=True, device_entropy=dev)
+            for data, got in zip(files, out):
+                assert not isinstance(got, Exception), got
+                assert np.array_equal(got, O.decode(data).pixels)
+    finally:
+        p.close()

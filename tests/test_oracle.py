@@ -156,3 +156,43 @@ def test_batch_driver_matches_single():
     outs = O.batch_pixels(comps, qts, imgs, 48, 40, "YCBCR", 3)
     for im, out in zip(imgs, outs):
         assert np.array_equal(out, O.pixels_from_coefficients(comps, qts, im, 48, 40, "YCBCR"))
+
+
+@pytest.mark.parametrize("name", R.anchor_files())
+def test_anchor_440_411_within_reference_tolerance_of_libjpeg_turbo(name):
+    """UpsamplerH1V2 (4:4:0) and UpsamplerGeneric (4:1:1) have no fixture in the reference's reftest suite; these files were
+    decoded by libjpeg-turbo (an implementation independent of the reference and of this oracle) and the oracle is held to
+    the reference's own rule against that: every sample within 3 (tests/reftest/mod.rs:93-120).  The files really exercise
+    those upsamplers (sampling factors checked)."""
+    path = os.path.join(R.ANCHOR, name)
+    d = O.decode(open(path, "rb").read(), keep_intermediates=True)
+    hv = (d.components[0].h, d.components[0].v)
+    assert hv == ((1, 2) if "-440-" in name else (4, 1)) and (d.components[1].h, d.components[1].v) == (1, 1)
+    md = R.max_diff_vs_png(d.pixels, d.ncomp, os.path.splitext(path)[0] + ".png")
+    assert md <= 3, (name, md)
+
+
+def test_builtin_encoder_round_trips_through_the_oracle():
+    """tools/baseline_encoder.py (writes the anchor files and, where Pillow is absent, the bench's e2e inputs): the oracle's
+    entropy decoder returns exactly the coefficients that went in, for every sampling and with restart intervals."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import baseline_encoder as E
+    import synth
+    for (w, h, s, ri) in [(64, 48, "420", 0), (250, 130, "420", 5), (129, 57, "422", 0), (100, 60, "444", 3), (33, 17, "gray", 0), (70, 40, "411", 0),
+                          (50, 61, "440", 2), (8, 8, "420", 1)]:
+        data = E.synthetic_jpeg(w, h, 85, s, restart_interval=ri)
+        d = O.decode(data, keep_intermediates=True)
+        comps, _ = O.make_components(w, h, E.SAMPLINGS[s])
+        assert (d.width, d.height, d.ncomp) == (w, h, len(comps))
+
+        class _C:  # (synth wants the product's field names)
+            def __init__(self, c):
+                self.horizontal_sampling_factor, self.vertical_sampling_factor = c.h, c.v
+                self.block_width, self.block_height, self.size_width, self.size_height = c.block_w, c.block_h, c.size_w, c.size_h
+        lum, chr_ = synth.quality_tables(85)
+        qts = [lum, chr_, chr_][: len(comps)]
+        coefs = synth.coefficients_from_rgb(synth.synthetic_rgb(w, h), [_C(c) for c in comps], "gray" if s == "gray" else "ycbcr", qts)
+        for c in range(len(comps)):
+            assert np.array_equal(np.asarray(coefs[c]), d.coefs[c]), (w, h, s, ri, c)
+            assert np.array_equal(d.qtables[c], qts[c])
