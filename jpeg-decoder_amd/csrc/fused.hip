@@ -134,19 +134,38 @@ struct PhaseClock {
 #define PHASE_MARK(slot) (void)0
 #endif
 
-// Strip walks (4:2:0: S420, 4:4:0: S440 in fused_core.hpp): a = strip, b = row segment
+// Strip walks (4:2:0: S420, 4:4:0: S440 in fused_core.hpp).  One work item = MCU rows [k0, k1) of one strip of one image.
+// Which items a workgroup owns (walk_items_of): with `wg_first` (balanced launches: walk_balanced_items, fused_plan.hpp) items
+// wg_first[blockIdx.x] .. wg_first[blockIdx.x + 1] of the table, a contiguous share of the launch's steps; with a table alone the
+// one item work[blockIdx.x]; without a table (uniform batch, fixed segments) strip blockIdx.x, segment blockIdx.y of image
+// blockIdx.z.
+struct WalkItems {
+    uint32_t first, end;  // table indices (table forms); first = 0, end = 1 for the 3-D grid form
+};
+__device__ __forceinline__ WalkItems walk_items_of(const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
+    if (wg_first) return WalkItems{wg_first[blockIdx.x], wg_first[blockIdx.x + 1u]};
+    if (work) return WalkItems{blockIdx.x, blockIdx.x + 1u};
+    return WalkItems{0u, 1u};
+}
+__device__ __forceinline__ FusedWork walk_item_at(const FusedGeom *__restrict__ geoms, const FusedWork *__restrict__ work, uint32_t it) {
+    if (work) return work[it];
+    FusedWork w = locate(nullptr);  // (strip, segment, image) from the grid
+    const uint32_t seg = geoms[w.image].seg_rows, k0 = w.b * seg;
+    w.b = k0;
+    w.c = min(k0 + seg, geoms[w.image].mcu_h);
+    return w;
+}
+
 template <class K>
-__device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
-                                          uint8_t *lds_raw) {
+__device__ __forceinline__ void walk_item(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork w, uint8_t *lds_raw) {
 #ifdef JPGPU_PHASE_CLOCKS
     PhaseClock pc;
 #endif
-    const FusedWork w = locate(work);
     const FusedGeom g = geoms[w.image];
     const FusedImage img = imgs[w.image];
     const typename K::Lds lds = K::Lds::make(lds_raw, g.tx);
     const uint32_t strip = w.a, tid = threadIdx.x;
-    const uint32_t k0 = w.b * g.seg_rows, k1 = min(k0 + g.seg_rows, g.mcu_h);
+    const uint32_t k0 = w.b, k1 = w.c;
     S420Regs r;
     K::init(img, tid, lds);
     if (k0 > 0 || k1 < g.mcu_h) {  // seam rows of the segments above / below
@@ -202,33 +221,52 @@ __device__ __forceinline__ void walk_body(const FusedGeom *__restrict__ geoms, c
 #endif
 }
 
+// (a barrier between the items of a workgroup: the closing phase of one reads the tiles the next one's staging overwrites)
 template <int ARITH, uint32_t NT>
 __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                     const FusedWork *__restrict__ work) {
+                                                     const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    walk_body<S420<ARITH, NT>>(geoms, imgs, work, lds_raw);
+    const WalkItems its = walk_items_of(work, wg_first);
+    for (uint32_t it = its.first; it < its.end; it++) {
+        walk_item<S420<ARITH, NT>>(geoms, imgs, walk_item_at(geoms, work, it), lds_raw);
+        if (it + 1u < its.end) __syncthreads();
+    }
 }
 template <uint32_t NT>
 __global__ __launch_bounds__(NT, 4) void s420_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                         const FusedWork *__restrict__ work) {
+                                                         const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-#define JP_CALL(A) walk_body<S420<A, NT>>(geoms, imgs, work, lds_raw)
-    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+    const WalkItems its = walk_items_of(work, wg_first);
+    for (uint32_t it = its.first; it < its.end; it++) {  // (the items of a workgroup may belong to images of different classes)
+        const FusedWork w = walk_item_at(geoms, work, it);
+#define JP_CALL(A) walk_item<S420<A, NT>>(geoms, imgs, w, lds_raw)
+        JP_DYN_DISPATCH((uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags), JP_CALL);
 #undef JP_CALL
+        if (it + 1u < its.end) __syncthreads();
+    }
 }
 
 template <int ARITH>
 __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                      const FusedWork *__restrict__ work) {
+                                                      const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    walk_body<S440<ARITH>>(geoms, imgs, work, lds_raw);
+    const WalkItems its = walk_items_of(work, wg_first);
+    for (uint32_t it = its.first; it < its.end; it++) {
+        walk_item<S440<ARITH>>(geoms, imgs, walk_item_at(geoms, work, it), lds_raw);
+        if (it + 1u < its.end) __syncthreads();
+    }
 }
 __global__ __launch_bounds__(256, 4) void s440_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                          const FusedWork *__restrict__ work) {
+                                                          const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-#define JP_CALL(A) walk_body<S440<A>>(geoms, imgs, work, lds_raw)
-    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+    const WalkItems its = walk_items_of(work, wg_first);
+    for (uint32_t it = its.first; it < its.end; it++) {
+        const FusedWork w = walk_item_at(geoms, work, it);
+#define JP_CALL(A) walk_item<S440<A>>(geoms, imgs, w, lds_raw)
+        JP_DYN_DISPATCH((uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags), JP_CALL);
 #undef JP_CALL
+        if (it + 1u < its.end) __syncthreads();
+    }
 }
 
 // a = tile, b = MCU row
@@ -435,8 +473,27 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     plan.ncomp = descs[0].ncomp;
     plan.strip = (plan.kind == FUSED_420 || plan.kind == FUSED_440) && plan.geoms[0].strip != 0;
     if (plan.strip) {
-        const char *sr = getenv("JPGPU_S420_SEG");
+        // Default: segments per strip by the heuristic of s420_set_segments, one (strip, segment) per workgroup.
+        // JPGPU_S420_SEG = n: fixed segments of n MCU rows (A/B and test knob).
+        // JPGPU_WALK_BALANCE=1 (round 3 experiment, kept as the A/B partner): balanced shares of the launch's steps, one share
+        // per workgroup the device holds at once (walk_balanced_items), JPGPU_WALK_ROUNDS = r: r times as many, shorter shares.
+        // Measured SLOWER (256 x 1080p, same box, profiles/round3/03_balanced_walk.txt): segments 0.654 ms; one share per
+        // resident workgroup 0.685-0.708; two 0.687-0.702; three 0.649-0.671 — workgroups that all start together stay in step
+        // (all loading, then all computing), and it is the spread of phases across the workgroups of a CU that overlaps the
+        // memory phases of one with the arithmetic of another.
+        const char *sr = getenv("JPGPU_S420_SEG"), *wb = getenv("JPGPU_WALK_BALANCE"), *wr = getenv("JPGPU_WALK_ROUNDS");
         for (auto &g : plan.geoms) s420_set_segments(g, n, sr ? (uint32_t)atoi(sr) : 0u);
+        plan.balanced = !sr && wb && atoi(wb) != 0;
+        if (plan.balanced) {
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            else
+                (void)hipGetLastError();
+            const uint32_t per_cu = 4u;  // workgroups per CU: 33.6 KB of LDS and <= 128 VGPRs (s420_kernel / s440_kernel launch bounds)
+            plan.walk_wgs = (uint32_t)cus * per_cu * (wr ? (uint32_t)std::max(1, atoi(wr)) : 1u);
+        }
     }
     // workgroup size, LDS claim, scratch layout, work tables
     uint32_t tx_max = 0;
@@ -461,14 +518,18 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
             for (uint32_t comp = 0; comp < 2; comp++)
                 for (uint32_t wg = 0; wg < groups; wg++) plan.work_pre.push_back(FusedWork{i, comp, wg, 0u});
         }
+        if (plan.strip && plan.balanced) continue;  // (the items of a balanced walk: below, over all images)
         const uint32_t ny = plan.strip ? g.n_seg : g.mcu_h;
         for (uint32_t y = 0; y < ny; y++)
-            for (uint32_t x = 0; x < g.tiles_x; x++) plan.work_main.push_back(FusedWork{i, x, y, 0u});
+            for (uint32_t x = 0; x < g.tiles_x; x++)
+                plan.work_main.push_back(plan.strip ? FusedWork{i, x, y * g.seg_rows, std::min((y + 1u) * g.seg_rows, g.mcu_h)} : FusedWork{i, x, y, 0u});
     }
+    if (plan.strip && plan.balanced) walk_balanced_items(plan.geoms.data(), nullptr, n, plan.walk_wgs, plan.work_main, plan.wg_first);
     plan.scratch_bytes = so;
     // the 3-D grid needs its y extent within 65535; JPGPU_FUSED_TABLE=1 forces the table form (test knob)
     if (plan.kind == FUSED_420 && !plan.strip && (plan.geoms[0].bwc * plan.geoms[0].mcu_h + 255u) / 256u > 65535u) plan.uniform = false;
     if (const char *ft = getenv("JPGPU_FUSED_TABLE")) if (atoi(ft) != 0) plan.uniform = false;
+    if (plan.strip && plan.balanced) plan.uniform = false;  // (always through the item table)
     plan.images.assign(n, FusedImage{});
     return true;
 }
@@ -489,6 +550,10 @@ int fused_alloc(FusedPlan &plan, std::string &err) {
     F_HIP(hipEventCreateWithFlags(&plan.launched, hipEventDisableTiming));
     F_HIP(hipMalloc((void **)&plan.d_work_main, sizeof(FusedWork) * std::max<size_t>(plan.work_main.size(), 1)));
     F_HIP(hipMemcpy(plan.d_work_main, plan.work_main.data(), sizeof(FusedWork) * plan.work_main.size(), hipMemcpyHostToDevice));
+    if (!plan.wg_first.empty()) {
+        F_HIP(hipMalloc((void **)&plan.d_wg_first, sizeof(uint32_t) * plan.wg_first.size()));
+        F_HIP(hipMemcpy(plan.d_wg_first, plan.wg_first.data(), sizeof(uint32_t) * plan.wg_first.size(), hipMemcpyHostToDevice));
+    }
     if (!plan.work_pre.empty()) {
         F_HIP(hipMalloc((void **)&plan.d_work_pre, sizeof(FusedWork) * plan.work_pre.size()));
         F_HIP(hipMemcpy(plan.d_work_pre, plan.work_pre.data(), sizeof(FusedWork) * plan.work_pre.size(), hipMemcpyHostToDevice));
@@ -561,12 +626,13 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
 // chunk's chroma planes stay in the 256 MiB Infinity Cache, and alternating chunks between two streams so that the
 // HBM-bound chroma pass overlaps the VALU-bound main pass, were both measured on MI355X and did not pay: chunks of
 // 16/32/64/128 images were 23/9/4/1 % slower, two streams 3 % slower — profiles/round1.)
+// wg_first (strip walks): the workgroups' shares of the item table W (balanced launches); null: one item per workgroup
 static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, const FusedWork *W, uint32_t n_main, const FusedWork *Wpre,
-                                   uint32_t n_pre) {
+                                   uint32_t n_pre, const uint32_t *wg_first = nullptr, uint32_t n_wg = 0) {
     const FusedGeom *G = plan.d_geoms;
     const FusedImage *I = plan.d_images;
     const FusedGeom &g0 = plan.geoms[0];
-    const dim3 grid = W ? dim3(n_main) : dim3(g0.tiles_x, plan.strip ? g0.n_seg : g0.mcu_h, plan.n_images);
+    const dim3 grid = wg_first ? dim3(n_wg) : (W ? dim3(n_main) : dim3(g0.tiles_x, plan.strip ? g0.n_seg : g0.mcu_h, plan.n_images));
     const dim3 block(plan.nt);
     const size_t shm = plan.lds_bytes;
     // ar < 0: the `_dyn` form (class per image from the image table on the device)
@@ -577,10 +643,17 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W); \
         else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);                  \
     } while (0)
+#define WALK_SWITCH(KERNEL, DYN, ...)                                                                              \
+    do {                                                                                                            \
+        if (ar < 0) DYN<<<grid, block, shm, stream>>>(G, I, W, wg_first);                                           \
+        else if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first); \
+        else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first);   \
+        else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first);                   \
+    } while (0)
     switch (plan.kind) {
     case FUSED_420:
         if (plan.strip) {
-            ARITH_SWITCH(s420_kernel, s420_kernel_dyn<256>, 256);
+            WALK_SWITCH(s420_kernel, s420_kernel_dyn<256>, 256);
             break;
         }
         if (!Wpre)  // (component, 256-block group, image)
@@ -590,7 +663,7 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, f420_main_kernel_dyn<128>, 128);
         else ARITH_SWITCH(f420_main_kernel, f420_main_kernel_dyn<256>, 256);
         break;
-    case FUSED_440: ARITH_SWITCH(s440_kernel, s440_kernel_dyn); break;
+    case FUSED_440: WALK_SWITCH(s440_kernel, s440_kernel_dyn); break;
     case FUSED_GEN: ARITH_SWITCH(fgen_kernel, fgen_kernel_dyn); break;
     case FUSED_444: ARITH_SWITCH(f444_kernel, f444_kernel_dyn); break;
     case FUSED_422: ARITH_SWITCH(f422_kernel, f422_kernel_dyn); break;
@@ -598,6 +671,7 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
     default: return hipErrorInvalidValue;
     }
 #undef ARITH_SWITCH
+#undef WALK_SWITCH
     return hipGetLastError();
 }
 
@@ -622,11 +696,13 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream, const uint32_t *d_s
         e = fused_finalize_classes(plan, stream, d_stats, d_host_cls);
         if (e == hipSuccess)
             e = fused_launch_one(plan, stream, -1, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
-                                 table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
+                                 table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size(), plan.d_wg_first,
+                                 plan.wg_first.empty() ? 0u : (uint32_t)plan.wg_first.size() - 1u);
     } else if (!plan.by_class) {
         e = fused_launch_one(plan, stream, plan.arith, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
-                             table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
-    } else {
+                             table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size(), plan.d_wg_first,
+                             plan.wg_first.empty() ? 0u : (uint32_t)plan.wg_first.size() - 1u);
+    } else {  // (per class: one item per workgroup — the shares of a balanced walk were cut over all images)
         const FusedWork *w = plan.d_work_cls, *wp = plan.d_work_cls + plan.n_main_cls[0] + plan.n_main_cls[1] + plan.n_main_cls[2];
         for (int c = 0; c < 3 && e == hipSuccess; c++) {
             if (plan.n_main_cls[c]) e = fused_launch_one(plan, stream, c, w, plan.n_main_cls[c], plan.n_pre_cls[c] ? wp : nullptr, plan.n_pre_cls[c]);
@@ -659,6 +735,8 @@ void fused_free(FusedPlan &plan) {
     if (plan.d_work_main) (void)hipFree(plan.d_work_main);
     if (plan.d_work_pre) (void)hipFree(plan.d_work_pre);
     if (plan.d_work_cls) (void)hipFree(plan.d_work_cls);
+    if (plan.d_wg_first) (void)hipFree(plan.d_wg_first);
+    plan.d_wg_first = nullptr;
     if (plan.d_ids) (void)hipFree(plan.d_ids);
     if (plan.launched) (void)hipEventDestroy(plan.launched);
     plan.d_ids = nullptr;

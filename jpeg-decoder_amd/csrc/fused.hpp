@@ -17,6 +17,10 @@ struct FusedPlan {
     uint32_t n_images = 0, ncomp = 0;
     std::vector<uint32_t> ids;       // batch-level index of each image of this plan (a batch may hold several plans)
     bool strip = false;              // 4:2:0 through the single-launch strip walk
+    bool balanced = false;           // strip walks: work_main holds items {image, strip, [k0, k1)}, workgroup w owns items
+    uint32_t walk_wgs = 0;           //   wg_first[w] .. wg_first[w + 1] (walk_balanced_items, fused_plan.hpp); walk_wgs = workgroups aimed at
+    std::vector<uint32_t> wg_first;
+    uint32_t *d_wg_first = nullptr;
     bool uniform = false;            // every image has the same geometry: 3-D grid, no work table
     uint32_t nt = 256;               // threads per workgroup of the main launch
     size_t lds_bytes = 0;            // dynamic LDS of the main launch (largest tile of the batch)

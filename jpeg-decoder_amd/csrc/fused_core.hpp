@@ -50,9 +50,10 @@ struct FusedGeom {
     uint32_t hs, vs;   // FGen: log2 of the luma sampling factors (H x V luma blocks per MCU)
 };
 
-// One workgroup of a fused launch: which image, and which of its tiles (meaning of a/b per kernel, fused.hip).
+// One work item of a fused launch: which image, and which of its tiles (meaning of a / b / c per kernel, fused.hip).
+// Tile kernels: a = tile within the MCU row, b = MCU row.  Strip walks: a = strip, MCU rows [b, c) of it.
 struct alignas(16) FusedWork {
-    uint32_t image, a, b, _pad;
+    uint32_t image, a, b, c;
 };
 
 struct FusedImage {

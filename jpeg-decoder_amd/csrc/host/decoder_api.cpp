@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,6 +64,49 @@ public:
     }
 };
 
+}  // namespace
+
+// How many decodes may hold a device context (a worker, or a one-image pipeline: streams, pinned staging, device buffers) at the
+// same time.  The reference's rayon-2 test spawns 1,024 decoding threads (tests/rayon-2.rs:14-20); its workers are CPU threads
+// of one global pool, so 1,024 decodes queue up behind the machine's cores.  Here the resource is the device: decode() calls
+// beyond the cap wait for a context to come back instead of creating a thousand streams and a thousand sets of buffers.
+// JPGPU_MAX_CONCURRENT_DECODES overrides the default of 64.  A context is held only inside jpgpu_decoder_decode (it goes back
+// on the failure paths as well), so waiting cannot deadlock.
+namespace {
+struct DeviceSlots {
+    std::mutex m;
+    std::condition_variable cv;
+    int in_use = 0, cap = 64;
+    DeviceSlots() {
+        if (const char *e = getenv("JPGPU_MAX_CONCURRENT_DECODES")) cap = std::max(1, atoi(e));
+    }
+    void acquire() {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return in_use < cap; });
+        in_use++;
+    }
+    void release() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            in_use--;
+        }
+        cv.notify_one();
+    }
+};
+DeviceSlots &device_slots() {
+    static DeviceSlots *s = new DeviceSlots;
+    return *s;
+}
+struct SlotHold {  // scope guard
+    bool held = false;
+    void take() {
+        if (!held) device_slots().acquire(), held = true;
+    }
+    void drop() {
+        if (held) device_slots().release(), held = false;
+    }
+    ~SlotHold() { drop(); }
+};
 }  // namespace
 
 // Idle workers per device: a Decoder borrows one for its decode() and hands it back with its streams, pinned staging and
@@ -267,6 +311,8 @@ int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len
                 const uint8_t *bytes = d->fe->stream_bytes(&n);
                 bool done = false;
                 if (eligible) {
+                    SlotHold slot;
+                    slot.take();
                     jpgpu_pipeline *p = pipeline_pool().take(d->device);
                     if (!p && jpgpu_pipeline_create(d->device, 2, &p) != JPGPU_OK) p = nullptr;
                     if (p) {
@@ -303,8 +349,10 @@ int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len
         }
     }
     if (!d->decoded) {
+        SlotHold slot;
         try {
             if (d->device < 0) throw DecodeError{JPGPU_ERR_NO_DEVICE, "decoder was created without a device (host-only)"};
+            slot.take();
             if (!d->worker) d->worker = worker_pool().take(d->device);
             if (!d->worker) {
                 int rc = jpgpu_worker_create(d->device, &d->worker);
@@ -355,6 +403,11 @@ int jpgpu_decoder_decode(jpgpu_decoder *d, uint8_t *dst, size_t cap, size_t *len
             worker_pool().give(d->device, d->worker);  // the pixels are on the host: the next Decoder may have the worker
             d->worker = nullptr;
         } catch (const DecodeError &e) {
+            if (d->worker) {  // the context goes back with the failed decode (a decoder decodes once): nothing is held between calls
+                jpgpu::worker_recycle(d->worker);
+                worker_pool().give(d->device, d->worker);
+                d->worker = nullptr;
+            }
             return fail(d, e);
         }
     }

@@ -9,18 +9,32 @@
 
 using namespace jpgpu;
 
-// the strip-walk kernels (S420, S440): fused.hip's walk_body, phase by phase, `seg_rows` MCU rows per workgroup
+// the strip-walk kernels (S420, S440): fused.hip's walk_item, phase by phase, for every work item of the launch — fixed
+// segments of `seg_rows` MCU rows, or (balanced_wgs != 0) the shares walk_balanced_items cuts for that many workgroups, the
+// items of one workgroup run one after the other on the same LDS as on the device
 template <class K>
-static void run_walk(const FusedGeom& g, const FusedImage& img) {
+static void run_walk(const FusedGeom& g, const FusedImage& img, uint32_t balanced_wgs) {
     constexpr uint32_t NT = K::NT;
     std::vector<uint8_t> mem(K::Lds::total_bytes(g.tx) + 64);
     std::vector<S420Regs> regs(NT);
+    std::vector<FusedWork> items;
+    std::vector<uint32_t> wg_first;
+    if (balanced_wgs) {
+        walk_balanced_items(&g, nullptr, 1u, balanced_wgs, items, wg_first);
+    } else {
+        for (uint32_t seg = 0; seg < g.n_seg; seg++)
+            for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
+                wg_first.push_back((uint32_t)items.size());
+                items.push_back(FusedWork{0u, strip, seg * g.seg_rows, std::min((seg + 1u) * g.seg_rows, g.mcu_h)});
+            }
+        wg_first.push_back((uint32_t)items.size());
+    }
 #define LANES(BODY) for (uint32_t t = 0; t < NT; t++) { BODY; }
-    for (uint32_t seg = 0; seg < g.n_seg; seg++)
-        for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
-            memset(mem.data(), 0xCD, mem.size());  // garbage, like real LDS
+    for (size_t wg = 0; wg + 1 < wg_first.size(); wg++) {
+        memset(mem.data(), 0xCD, mem.size());  // garbage, like real LDS
+        for (uint32_t it = wg_first[wg]; it < wg_first[wg + 1]; it++) {
             const typename K::Lds lds = K::Lds::make(mem.data(), g.tx);
-            const uint32_t k0 = seg * g.seg_rows, k1 = std::min(k0 + g.seg_rows, g.mcu_h);
+            const uint32_t strip = items[it].a, k0 = items[it].b, k1 = items[it].c;
             LANES(K::init(img, t, lds))
             if (k0 > 0 || k1 < g.mcu_h) {
                 LANES(K::seam_stage(g, img, strip, k0, k1, t, lds))
@@ -41,6 +55,7 @@ static void run_walk(const FusedGeom& g, const FusedImage& img) {
                 LANES(K::colour(g, img, strip, k1, 16u * k0, true, t, lds))
             }
         }
+    }
 #undef LANES
 }
 
@@ -54,7 +69,8 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
     int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max, strip420 != 0, s420_tx_max ? s420_tx_max : S420_TX_MAX);
     if (kind == FUSED_NONE) return 0;
     if ((kind == FUSED_420 || kind == FUSED_440) && g.strip) {
-        s420_set_segments(g, 1, seg_rows);
+        const uint32_t balanced_wgs = seg_rows >= 0x10000u ? (seg_rows & 0xffffu) : 0u;  // (test hook: 0x10000 | workgroups -> balanced shares)
+        s420_set_segments(g, 1, balanced_wgs ? 0u : seg_rows);
         FusedImage im{};
         for (uint32_t c = 0; c < desc->ncomp; c++) {
             im.coefs[c] = coefs[c];
@@ -64,12 +80,12 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         if (tx_out) *tx_out = g.tx;
         im.flags = sane == 2 ? 3u : (sane ? 1u : 0u);
         if (kind == FUSED_440) {
-            if (sane == 2) run_walk<S440<ARITH_TIGHT>>(g, im);
-            else if (sane) run_walk<S440<ARITH_SANE>>(g, im);
-            else run_walk<S440<ARITH_EXACT>>(g, im);
-        } else if (sane == 2) run_walk<S420<ARITH_TIGHT, 256>>(g, im);
-        else if (sane) run_walk<S420<ARITH_SANE, 256>>(g, im);
-        else run_walk<S420<ARITH_EXACT, 256>>(g, im);
+            if (sane == 2) run_walk<S440<ARITH_TIGHT>>(g, im, balanced_wgs);
+            else if (sane) run_walk<S440<ARITH_SANE>>(g, im, balanced_wgs);
+            else run_walk<S440<ARITH_EXACT>>(g, im, balanced_wgs);
+        } else if (sane == 2) run_walk<S420<ARITH_TIGHT, 256>>(g, im, balanced_wgs);
+        else if (sane) run_walk<S420<ARITH_SANE, 256>>(g, im, balanced_wgs);
+        else run_walk<S420<ARITH_EXACT, 256>>(g, im, balanced_wgs);
         return kind;
     }
     if (kind == FUSED_GEN) {  // fgen_kernel, phase by phase

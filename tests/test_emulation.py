@@ -164,7 +164,8 @@ GEOMS = [
 
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
 @pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
-@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7", "strip-tx7-seg1"])
+@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7", "strip-tx7-seg1",
+                                     "strip-bal2", "strip-bal3", "strip-bal7", "strip-tx7-bal5"])
 def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     walk = len(geom[2]) == 3 and geom[2][0] in ((2, 2), (1, 2))
     if f420_tx != 64 and not walk or (f420_tx == 32 and geom[2][0] != (2, 2)):
@@ -173,7 +174,11 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     if isinstance(f420_tx, str):  # single-launch strip walk: (MCU rows per workgroup, widest strip)
         strip = 1
         seg_rows, s420_tx = {"strip": (1000, 0), "strip-seg1": (1, 0), "strip-seg3": (3, 0), "strip-tx20": (1000, 20),
-                             "strip-tx20-seg2": (2, 20), "strip-tx7": (5, 7), "strip-tx7-seg1": (1, 7)}[f420_tx]
+                             "strip-tx20-seg2": (2, 20), "strip-tx7": (5, 7), "strip-tx7-seg1": (1, 7),
+                             # balanced shares (fused_plan.hpp walk_balanced_items) for 2 / 3 / 7 / 5 workgroups: items that start and
+                             # end anywhere in a strip, several items of different strips run by one workgroup on the same LDS
+                             "strip-bal2": (0x10000 | 2, 0), "strip-bal3": (0x10000 | 3, 0), "strip-bal7": (0x10000 | 7, 0),
+                             "strip-tx7-bal5": (0x10000 | 5, 7)}[f420_tx]
         f420_tx = 64
     w_, h_, samp, ct = geom
     rng = np.random.default_rng(w_ * 131 + h_)

@@ -1,7 +1,8 @@
 """Many decodes on many threads: the reference pins that with tests/rayon-2.rs:14-20 (1024 threads, each decoding the same
 image on the global rayon pool).  Here: 64 Python threads x Decoder(data).decode() (ctypes releases the GIL inside the
 library: the worker / pipeline pools behind their mutexes in csrc/host/decoder_api.cpp are really entered concurrently),
-next to 4 Pipelines decoding batches on the same device, every result byte-exact against the oracle."""
+next to 4 Pipelines decoding batches on the same device, every result byte-exact against the oracle; and the reference's test
+at its own size (1,024 threads) against the library's cap on concurrently held device contexts."""
 import os
 import threading
 
@@ -72,3 +73,41 @@ def test_64_decoder_threads_and_4_pipelines_on_one_device():
         th.join(500)
         assert not th.is_alive(), "a decoding thread hung"
     assert not errors, errors[:5]
+
+
+@pytest.mark.timeout(900)
+def test_1024_decoding_threads_like_the_reference_rayon_2_test():
+    """tests/rayon-2.rs:14-20 at its own size: 1,024 threads, each `Decoder::new(progressive3.jpg).decode()`.  The reference's
+    threads queue up behind a two-thread rayon pool; here they queue up behind the library's cap on concurrently held device
+    contexts (64 by default, JPGPU_MAX_CONCURRENT_DECODES) — a thousand decodes do not mean a thousand streams and buffer
+    sets on the device.  Every result is checked (the reference only unwraps).  JPGPU_TEST_RAYON2_THREADS scales the test."""
+    import jpeg_decoder_amd as J
+    n_threads = int(os.environ.get("JPGPU_TEST_RAYON2_THREADS", "1024"))
+    data = open(os.path.join(R.REFTEST, "progressive3.jpg"), "rb").read()
+    want = O.decode(data).pixels
+    errors, lock = [], threading.Lock()
+    done = [0]
+
+    def body(t):
+        try:
+            got = J.Decoder(data).decode()
+            if not np.array_equal(got, want):
+                raise AssertionError(f"thread {t}: differs from the oracle")
+            with lock:
+                done[0] += 1
+        except Exception as e:  # noqa: BLE001
+            with lock:
+                errors.append(repr(e))
+
+    old = threading.stack_size(256 * 1024)  # (a thousand default-sized stacks are 8 GB of address space)
+    try:
+        threads = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(800)
+            assert not th.is_alive(), "a decoding thread hung"
+    finally:
+        threading.stack_size(old)
+    assert not errors, errors[:5]
+    assert done[0] == n_threads
