@@ -55,6 +55,14 @@ WORKLOADS = {
     "1080p-411": (1920, 1080, [(4, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),  # UpsamplerGeneric layout (fusedgen)
     "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
     "1080p-cmyk": (1920, 1080, [(1, 1)] * 4, "cmyk", "CMYK", 192),
+    # layouts the reference's own fixtures have (jpg-cmyk-2.jpg: one full-size and three half-size components; YCCK as Photoshop
+    # writes it: K at full size) and reduced-size decodes (Decoder::scale, src/idct.rs:456-565: dct_scale 4 / 2 / 1)
+    "1080p-cmyk-2211": (1920, 1080, [(2, 2), (1, 1), (1, 1), (1, 1)], "cmyk", "CMYK", 192),
+    "1080p-ycck-2212": (1920, 1080, [(2, 2), (1, 1), (1, 1), (2, 2)], "ycck", "YCCK", 192),
+    "1080p-420-scale4": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 4),
+    "1080p-420-scale2": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 2),
+    "1080p-420-scale1": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 1),
+    "1080p-444-scale4": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 4),
     # 4:4:4 and grayscale images interleaved in one batch (two fused launch groups, path "mixed")
     "1080p-444+gray": (1920, 1080, None, "mixed", None, 1024),  # BASELINE configs[4]: batch 1024 (512 + 512)
 }
@@ -433,14 +441,15 @@ class Shard:
             b.close()
 
 
-def build_variants(J, synth, w, h, sampling, mode, ct):
+def build_variants(J, synth, w, h, sampling, mode, ct, dct_scale=8):
     lum, chr_ = synth.quality_tables(85)
     rgb = synth.synthetic_rgb(w, h)
+    ow, oh = (w, h) if dct_scale == 8 else J.scaled_output_size(w, h, dct_scale)
     specs = [([(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr"), ([(1, 1)], "gray", "Grayscale")] if mode == "mixed" else [(sampling, mode, ct)]
     variants = []
     for v_sampling, v_mode, v_ct in specs:
-        comps, _mcu = J.make_components(w, h, v_sampling)
-        qts = [lum] * 4 if v_mode == "cmyk" else [lum, chr_, chr_][: len(v_sampling)]
+        comps, _mcu = J.make_components(w, h, v_sampling, dct_scale=dct_scale)
+        qts = [lum] * 4 if v_mode == "cmyk" else ([lum, chr_, chr_, lum] if v_mode == "ycck" else [lum, chr_, chr_][: len(v_sampling)])
         coefs = synth.coefficients_from_rgb(rgb, comps, v_mode, qts)
         # range class of the dequantized coefficients (what jpgpu_batch_upload computes when it stages data itself)
         prod = [np.abs(c.astype(np.int64).reshape(-1, 8, 8) * q.astype(np.int64).reshape(8, 8)) for c, q in zip(coefs, qts)]
@@ -448,7 +457,7 @@ def build_variants(J, synth, w, h, sampling, mode, ct):
         if all((p < (1 << 15)).all() for p in prod):
             sane = 3 if all((p.sum(axis=1) <= 5900).all() for p in prod) else 1
         variants.append({"sampling": v_sampling, "ct": v_ct, "comps": comps, "qts": qts, "coefs": coefs, "sane": sane,
-                         "desc": J.image_desc(list(comps), qts, w, h, v_ct)})
+                         "dct_scale": dct_scale, "desc": J.image_desc(list(comps), qts, ow, oh, v_ct)})
     return variants
 
 
@@ -569,7 +578,8 @@ def main(argv=None):
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     workload = args.workload or ("1080p-420" if world == 1 else CONFIG3_WORKLOAD)
-    w, h, sampling, mode, ct, default_batch = WORKLOADS[workload]
+    w, h, sampling, mode, ct, default_batch = WORKLOADS[workload][:6]
+    dct_scale = WORKLOADS[workload][6] if len(WORKLOADS[workload]) > 6 else 8
     images_total = args.images_total or (CONFIG3_IMAGES_TOTAL if world > 1 and not args.batch else 0)
     import jpeg_decoder_amd.distributed as D
     n_img = len(D.shard(images_total, rank, world)) if images_total else (args.batch or default_batch)
@@ -589,7 +599,10 @@ def main(argv=None):
     import synth
 
     dist = D.init(backend="nccl", force=args.force_dist) if (world > 1 or args.force_dist) else None
-    variants = build_variants(J, synth, w, h, sampling, mode, ct)
+    variants = build_variants(J, synth, w, h, sampling, mode, ct, dct_scale)
+    full_w, full_h = w, h
+    if dct_scale != 8:  # a reduced-size decode produces ceil(W * scale / 8) x ceil(H * scale / 8) pixels (src/parser.rs:127-130)
+        w, h = J.scaled_output_size(full_w, full_h, dct_scale)
     sampling, ct = variants[0]["sampling"], variants[0]["ct"]
     comps, qts, coefs = (variants[0][k] for k in ("comps", "qts", "coefs"))
     nv = len(variants)
@@ -650,7 +663,7 @@ def main(argv=None):
         import oracle as O
         verified = True
         for k, v in enumerate(variants):
-            ocomps, _ = O.make_components(w, h, v["sampling"])
+            ocomps, _ = O.make_components(full_w, full_h, v["sampling"], dct_scale=dct_scale)
             want = O.pixels_from_coefficients(ocomps, v["qts"], v["coefs"], w, h, v["ct"].upper())
             digest = hashlib.sha256(want.tobytes()).hexdigest()
             last = ((n_img - 1 - k) // nv) * nv + k
@@ -659,7 +672,7 @@ def main(argv=None):
                     continue
                 got = shard.image_pixels(i).cpu().numpy()
                 verified = verified and hashlib.sha256(got.tobytes()).hexdigest() == digest
-        ocomps, _ = O.make_components(w, h, sampling)
+        ocomps, _ = O.make_components(full_w, full_h, sampling, dct_scale=dct_scale)
 
     total_images = images_total or world * n_img
     mp_per_step = total_images * w * h / 1e6
@@ -677,7 +690,7 @@ def main(argv=None):
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if images_total else "weak",
             "vs_baseline": None, "dtype": "i32 fixed-point (i16 coefficients -> u8 pixels)", "data": "synthetic",
-            "config": {"workload": f"{w}x{h} baseline " + " + ".join('x'.join(str(hh) + str(vv) for hh, vv in v["sampling"]) + " " + v["ct"]
+            "config": {"workload": f"{full_w}x{full_h} baseline " + (f"decoded at {dct_scale}/8 ({w}x{h}) " if dct_scale != 8 else "") + " + ".join('x'.join(str(hh) + str(vv) for hh, vv in v["sampling"]) + " " + v["ct"]
                                                                      for v in variants) +
                                    (" interleaved" if nv > 1 else "") +
                                    (f", {total_images} images in the job, {n_img} per GPU" if images_total else f", batch of {n_img} images per GPU") +

@@ -68,7 +68,7 @@ struct jpgpu_batch {
     size_t entropy_cap = 0, entropy_host_cap = 0;
     uint32_t *h_entropy_out = nullptr;  // pinned read-back: status per listed image, then 2 range stats per (image, comp)
     size_t entropy_out_cap = 0;
-    hipEvent_t entropy_uploaded = nullptr;
+    hipEvent_t entropy_uploaded = nullptr, entropy_filled = nullptr;
     uint8_t *d_scan = nullptr;     // jpgpu_batch_scan_ranges: stats + job table on the device, kept between calls
     uint32_t *h_scan = nullptr;    // pinned read-back of the stats
     size_t scan_cap = 0;
@@ -335,6 +335,7 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
         if (b->h_entropy) hipHostFree(b->h_entropy);
         if (b->h_entropy_out) hipHostFree(b->h_entropy_out);
         if (b->entropy_uploaded) hipEventDestroy(b->entropy_uploaded);
+        if (b->entropy_filled) hipEventDestroy(b->entropy_filled);
         if (b->h_bounce) hipHostFree(b->h_bounce);
         if (b->d_scan) hipFree(b->d_scan);
         if (b->h_scan) hipHostFree(b->h_scan);
@@ -899,13 +900,16 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     }
     // The upload first: it is a DMA transfer and overlaps the kernels another sub-batch has in flight on its own stream; behind
     // a fill kernel it waited for the machine to drain (measured: 2 of 7.5 ms per sub-batch of 256 images).
-    if (copy_stream && copy_stream != hip_stream) {
-        if (!b->entropy_uploaded) B_HIP(hipEventCreateWithFlags(&b->entropy_uploaded, hipEventDisableTiming));
-        B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, (hipStream_t)copy_stream));
-        B_HIP(hipEventRecord(b->entropy_uploaded, (hipStream_t)copy_stream));
+    const bool two_streams = copy_stream && copy_stream != hip_stream;
+    hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
+    if (two_streams && !b->entropy_uploaded) {
+        B_HIP(hipEventCreateWithFlags(&b->entropy_uploaded, hipEventDisableTiming));
+        B_HIP(hipEventCreateWithFlags(&b->entropy_filled, hipEventDisableTiming));
+    }
+    B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, cps));
+    if (two_streams) {
+        B_HIP(hipEventRecord(b->entropy_uploaded, cps));
         B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));
-    } else {
-        B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
     }
     // JPGPU_BATCH_KERNEL_TIMES: events between the phases (fills | sync passes | write pass + DC sums | pixel kernels)
     static const bool phase_times = getenv("JPGPU_BATCH_KERNEL_TIMES") != nullptr;
@@ -915,28 +919,34 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             if (!e) B_HIP(hipEventCreate(&e));
         B_HIP(hipEventRecord(b->ev_phase[0], s));
     }
-    // the planes start as zeros (the Worker's zero-initialised plane): only non-zero coefficients are written.  Neighbouring
+    // The planes start as zeros (the Worker's zero-initialised plane): only non-zero coefficients are written.  Neighbouring
     // images are cleared with one fill (a fill per image was 1,024 tiny launches = 28 ms per 1,024 images).  The same for
-    // their range statistics.
+    // their range statistics.  With a second stream the fills run THERE, behind the upload and next to the sync passes: those
+    // are bound by instruction issue and never touch the arena, the fills by bandwidth — only the write pass waits for them
+    // (round 3: the fills were 0.23 of the 5.2 ms of kernels per 256 x 1080p on the stream of the passes).
     std::sort(stat_images.begin(), stat_images.end());
     for (size_t z = 0; z < stat_images.size();) {
         const size_t first = stat_images[z];
         size_t last = first;
         for (z++; z < stat_images.size() && stat_images[z] <= last + 1; z++) last = stat_images[z];
-        B_HIP(hipMemsetAsync(b->d_stats + first * RS_WORDS, 0, (last - first + 1) * RS_WORDS * sizeof(uint32_t), s));
+        B_HIP(hipMemsetAsync(b->d_stats + first * RS_WORDS, 0, (last - first + 1) * RS_WORDS * sizeof(uint32_t), cps));
     }
     std::sort(zero_ranges.begin(), zero_ranges.end());
     for (size_t z = 0; z < zero_ranges.size();) {
         size_t first = zero_ranges[z].first, last = zero_ranges[z].second;
         for (z++; z < zero_ranges.size() && zero_ranges[z].first <= last + 256; z++) last = std::max(last, zero_ranges[z].second);
-        B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, s));
+        B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, cps));
     }
+    if (two_streams) B_HIP(hipEventRecord(b->entropy_filled, cps));
     if (phase_times) B_HIP(hipEventRecord(b->ev_phase[1], s));
+    // (the restart-segment decoder writes coefficients: it waits for the fills; the chunk decoder's write pass does — its sync
+    // passes do not)
+    if (two_streams && n_seg_jobs) B_HIP(hipStreamWaitEvent(s, b->entropy_filled, 0));
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
         static const uint32_t iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
         B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s,
-                               phase_times ? b->ev_phase[2] : nullptr));
+                               phase_times ? b->ev_phase[2] : nullptr, two_streams ? b->entropy_filled : nullptr));
     }
     if (phase_times) {
         B_HIP(hipEventRecord(b->ev_phase[3], s));

@@ -690,6 +690,7 @@ struct S420 {
     struct EdgeFix {
         bool before, after;  // write byte 0 of a row to column -1 / byte 7 to column +8 of the block
     };
+    template <int ROWS = 8>  // rows of `out` in use (seam rounds: the one row that is kept)
     static __device__ __forceinline__ EdgeFix edge_fix(const FusedGeom &g, uint32_t x0m, uint32_t cx, uint32_t (&out)[16]) {
         const uint32_t bx = x0m - 1u + cx, last = g.cw - 1u;
         // (a halo block's own neighbour column is not part of the tile — nobody reads it, and the byte would land in
@@ -701,7 +702,7 @@ struct S420 {
             ef.after = own && bx == (last >> 3);
         } else if (bx == (last >> 3)) {  // widths whose chroma plane ends inside a block: the copy stays in the block
 #pragma unroll
-            for (int row = 0; row < 8; row++) {
+            for (int row = 0; row < ROWS; row++) {
                 const uint64_t v = (uint64_t)out[2 * row] | ((uint64_t)out[2 * row + 1] << 32);
                 const uint64_t b = (v >> (8u * r)) & 0xffull, m = 0xffull << (8u * (r + 1u));
                 const uint64_t w = (v & ~m) | (b << (8u * (r + 1u)));
@@ -754,12 +755,27 @@ struct S420 {
         if (below ? !(k1 < g.mcu_h) : !(k0 > 0u)) return;
         const int32_t bx = (int32_t)x0m - 1 + (int32_t)cx;
         if (bx < 0 || bx >= (int32_t)g.bwc) return;
-        uint32_t cw[32], out[16];
+        uint32_t cw[32];
         fetch_block(lds, tid, 1u + c, cw);
-        transform_block(lds, 1u + c, cw, out);
-        const EdgeFix ef = edge_fix(g, x0m, cx, out);
         uint8_t *dst = below ? lds.bnd + c * lds.cpitch + cx * 8u : lds.carry + lds.ypitch + c * lds.cpitch + cx * 8u;
-        const uint32_t lo = below ? out[0] : out[14], hi = below ? out[1] : out[15];
+        uint32_t lo, hi;
+        EdgeFix ef;
+#ifndef JPGPU_SEAM_FULL  // (A/B: -DJPGPU_SEAM_FULL = round 2's full transform of the seam blocks)
+        if constexpr (ARITH != ARITH_EXACT) {
+            // only ONE sample row of a seam block is ever used: its first (block row k1, below) or its last (block row k0 - 1)
+            if (below) idct8x8_products_row<ARITH, 0>(cw, lo, hi);
+            else idct8x8_products_row<ARITH, 7>(cw, lo, hi);
+            uint32_t row[16] = {lo, hi, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            ef = edge_fix<1>(g, x0m, cx, row);
+            lo = row[0], hi = row[1];
+        } else
+#endif
+        {
+            uint32_t out[16];
+            transform_block(lds, 1u + c, cw, out);
+            ef = edge_fix(g, x0m, cx, out);
+            lo = below ? out[0] : out[14], hi = below ? out[1] : out[15];
+        }
         *reinterpret_cast<v2u *>(dst) = v2u{lo, hi};
         edge_bytes(ef, dst, lo, hi);
     }
@@ -978,11 +994,21 @@ struct S440 {
         const uint32_t cx = tid - which * te, c = which & 1u;
         const bool below = which >= 2u;
         if (below ? !(k1 < g.mcu_h) : !(k0 > 0u)) return;
-        uint32_t cw[32], out[16];
+        uint32_t cw[32], lo, hi;
         W::fetch_block(lds, tid, 1u + c, cw);
-        W::transform_block(lds, 1u + c, cw, out);
-        if (below) *reinterpret_cast<v2u *>(lds.bnd + c * lds.pitch + cx * 8u) = v2u{out[0], out[1]};
-        else *reinterpret_cast<v2u *>(lds.carry + (1u + c) * lds.pitch + cx * 8u) = v2u{out[14], out[15]};
+#ifndef JPGPU_SEAM_FULL
+        if constexpr (ARITH != ARITH_EXACT) {  // the one sample row that is kept (pixel_math.hpp idct8x8_products_row)
+            if (below) idct8x8_products_row<ARITH, 0>(cw, lo, hi);
+            else idct8x8_products_row<ARITH, 7>(cw, lo, hi);
+        } else
+#endif
+        {
+            uint32_t out[16];
+            W::transform_block(lds, 1u + c, cw, out);
+            lo = below ? out[0] : out[14], hi = below ? out[1] : out[15];
+        }
+        if (below) *reinterpret_cast<v2u *>(lds.bnd + c * lds.pitch + cx * 8u) = v2u{lo, hi};
+        else *reinterpret_cast<v2u *>(lds.carry + (1u + c) * lds.pitch + cx * 8u) = v2u{lo, hi};
     }
     static __device__ __forceinline__ void closing_tiles(uint32_t tid, const Lds &lds) {
         const uint32_t o = tid * 8u;

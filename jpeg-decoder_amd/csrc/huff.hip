@@ -389,7 +389,7 @@ hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t m
 // Everything for the jobs without restart markers, enqueued blind: a fixed number of sync launches (settled jobs cost an
 // empty workgroup each), block numbering, the write pass and the DC sums.
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync) {
+                            hipEvent_t after_sync, hipEvent_t before_write) {
     if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) {
         if (after_sync) (void)hipEventRecord(after_sync, stream);
         return hipSuccess;
@@ -398,6 +398,7 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     for (uint32_t l = 0; l < launches; l++) huff_sync_pass_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);
     if (after_sync) (void)hipEventRecord(after_sync, stream);
+    if (before_write) (void)hipStreamWaitEvent(stream, before_write, 0);  // (the zero fill of the planes, enqueued on another stream)
     // The write pass runs best with TWO workgroups per CU: every lane keeps a cache line of the arena open for its 2-byte
     // stores, and fewer lanes in flight means fewer open lines (measured, 256 1080p images: 6 workgroups per CU 2.19 ms,
     // 4: 2.26, 2: 1.89, 1: 3.2).  Unused dynamic LDS is the occupancy limiter.

@@ -53,11 +53,17 @@ struct HuffSyncLds {
     } q_dst[16];
     uint32_t dc[256][4];        // per lane and component: sum of DC differences (sync passes) / DC predictor (write pass)
     uint8_t unzig[64];
+    uint32_t unzq[4][64];       // per scan component and zig-zag index k: natural position | quantization value there << 16 — the
+                                // write pass needs both for every coefficient (store address, range statistics): one LDS read
 };
 constexpr uint32_t HUFF_SYNC_LANES = 256;  // lanes per workgroup (dc[] slots)
 // after job and tables are in place; every lane of the workgroup calls it (lane < 512 does something), then a barrier
 __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32_t lane) {
     if (lane < 512u) L.sym_info[lane >> 8][lane & 255u] = (uint16_t)huff_sym_info(lane >> 8, lane & 255u);
+    if (lane < 256u) {
+        const uint32_t z = L.unzig[lane & 63u];
+        L.unzq[lane >> 6][lane & 63u] = z | ((uint32_t)L.job.q[lane >> 6][z] << 16);
+    }
     if (lane < 16u) {
         const uint32_t c = L.job.q_comp[lane < L.job.bpm ? lane : 0u];
         L.q_tables[lane] = (uint32_t)(L.job.comp[c].dc * sizeof(DevHuffTable)) | ((uint32_t)((4u + L.job.comp[c].ac) * sizeof(DevHuffTable)) << 16);
@@ -183,7 +189,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
-    const JP_LDS uint16_t *qrow = L.job.q[c];  // quantization table of block q's component (WRITE: range statistics)
+    const JP_LDS uint32_t *zq = L.unzq[c];  // zig-zag index -> (natural position, quantization value) of block q's component
     JP_GLOBAL int16_t *blk = nullptr;
     uint32_t mx = 0, my = 0;  // the MCU of block `blkno` (write pass), kept by counting: no divisions per block
     if (WRITE) {
@@ -252,13 +258,13 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
                     else blk[0] = (int16_t)val;
                 }
                 // (finished DC values only: the differences of a uniform scan are summed — and ranged — by huff_dc_prefix_kernel)
-                if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * qrow[0]);
+                if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * (zq[0] >> 16));
             } else if (WRITE && (info & SYM_COEF)) {
-                const uint32_t z = L.unzig[k - 1u];
+                const uint32_t e = zq[k - 1u], z = e & 0xffffu;
                 const int32_t x = huff_extend(raw, nread);
                 if (ASSEMBLE && own) mine[z] = (uint16_t)x;
                 else blk[z] = (int16_t)x;
-                rg.ac = max(rg.ac, (uint32_t)(x < 0 ? -x : x) * qrow[z]);  // |x| <= 2^15, q <= 2^16 - 1
+                rg.ac = max(rg.ac, (uint32_t)(x < 0 ? -x : x) * (e >> 16));  // |x| <= 2^15, q <= 2^16 - 1
             }
         }
         if (k >= 64u && !bad) {  // end of the block
@@ -275,7 +281,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
             }
             qt = L.q_tables[q];
             c = job.q_comp[q];
-            if (WRITE) qrow = L.job.q[c];
+            if (WRITE) zq = L.unzq[c];
             if (WRITE) {
                 if (ASSEMBLE && own) {
                     flush = true;

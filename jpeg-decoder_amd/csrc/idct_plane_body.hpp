@@ -17,6 +17,8 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
     if (first >= job.n_blocks) return;  // whole workgroup out of range (uniform)
     const uint32_t nb = min(256u, job.n_blocks - first);
     const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)(job.coefs + (size_t)first * 64);
+    uint32_t cw[32];
+    if constexpr (SCALE == 8) {
     // All eight 16-B loads are issued before the first LDS store (one exposed memory latency, not
     // eight).  Named scalars + clamped indices on purpose: a predicated `v4u v[8]` array is
     // kept in scratch memory by hipcc (ROCm 7.2) instead of VGPRs.
@@ -33,7 +35,6 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
 #undef JP_ST
     __syncthreads();
     if (tid >= nb) return;
-    uint32_t cw[32];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         v4u v = lds[tid * 8u + ((uint32_t)k ^ ((tid >> 1) & 7u))];
@@ -41,6 +42,36 @@ __device__ __forceinline__ void idct_planes_body(const PlaneJob &job, uint32_t w
         cw[k * 4 + 1] = v.y;
         cw[k * 4 + 2] = v.z;
         cw[k * 4 + 3] = v.w;
+    }
+    } else {
+        // Reduced IDCTs use the top-left SCALE x SCALE coefficients only (src/idct.rs:456-565): rows 0 .. SCALE-1 of a block,
+        // i.e. its first SCALE 16-byte pieces — half, a quarter, an eighth of the arena's bytes (round 3: the kernel fetched
+        // all eight).  Piece j of the workgroup = row j % R of block j / R, R = SCALE (scale 1: the one piece with the DC).
+        constexpr uint32_t R = SCALE == 4 ? 4u : (SCALE == 2 ? 2u : 1u);
+        const uint32_t lastp = nb * R - 1u;
+        v4u v[R];
+#pragma unroll
+        for (uint32_t i = 0; i < R; i++) {
+            const uint32_t j = min(i * 256u + tid, lastp);
+            v[i] = src[(j / R) * 8u + (j % R)];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < R; i++) {
+            const uint32_t j = i * 256u + tid;
+            if (j <= lastp) lds[(j / R) * 8u + ((j % R) ^ (((j / R) >> 1) & 7u))] = v[i];
+        }
+        __syncthreads();
+        if (tid >= nb) return;
+#pragma unroll
+        for (int k = 0; k < 32; k++) cw[k] = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < R; k++) {
+            const v4u w = lds[tid * 8u + (k ^ ((tid >> 1) & 7u))];
+            cw[k * 4 + 0] = w.x;
+            cw[k * 4 + 1] = w.y;
+            cw[k * 4 + 2] = w.z;
+            cw[k * 4 + 3] = w.w;
+        }
     }
     const uint32_t b = first + tid;
     const uint32_t bx = b % job.block_w, by = b / job.block_w;

@@ -119,11 +119,17 @@ int build_image_job(const jpgpu_component *comps, uint32_t ncomp, uint8_t *const
     if (fn == CC_NONE && (size_t)ncomp * line_buffer_size > (size_t)out_w * ncomp)
         return set_err(err, JPGPU_ERR_INTERNAL, "reference would panic: color_no_convert overruns the row");
     if (out_h == 0 || out_w == 0) return JPGPU_OK;
-    // dword path of the kernel (upsample_color_body.hpp): interleaved output, every plane at dct_scale 8 (stride % 8 == 0)
-    // under one of the four fixed upsamplers, planes 8-byte aligned
+    // dword path of the kernel (upsample_color_body.hpp): interleaved output, every plane under one of the four fixed
+    // upsamplers, 8-byte aligned, and its rows as well where a lane reads eight samples at once (H1V1 / H1V2: stride % 8 == 0)
+    // or aligned dwords around column x / 2 (H2V1 / H2V2: stride % 4 == 0).  Planes at dct_scale 8 always qualify; reduced-size
+    // planes (Decoder::scale, stride = block_width * dct_scale) when their block count makes the stride so — 1080p does at
+    // every scale (round 3: such frames ran the byte-granular path, 1.15 of the 1.5 ms of a 256 x 1080p decode at scale 4).
     job.fast8 = (fn == CC_RGB || fn == CC_YCBCR || fn == CC_CMYK || fn == CC_YCCK) ? 1u : 0u;
-    for (uint32_t i = 0; i < ncomp; i++)
-        if (comps[i].dct_scale != 8 || job.comp[i].kind > UP_H2V2 || ((uintptr_t)job.comp[i].plane & 7u)) job.fast8 = 0u;
+    for (uint32_t i = 0; i < ncomp; i++) {
+        const UpComp &u = job.comp[i];
+        const uint32_t align = (u.kind == UP_H1V1 || u.kind == UP_H1V2) ? 8u : 4u;
+        if (u.kind > UP_H2V2 || ((uintptr_t)u.plane & 7u) || (u.stride % align) != 0u || u.stride < 8u) job.fast8 = 0u;
+    }
     for (uint32_t i = 0; i < ncomp; i++) {
         const UpComp &u = job.comp[i];
         const size_t len = plane_bytes(comps[i]);

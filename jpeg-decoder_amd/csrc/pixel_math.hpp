@@ -426,6 +426,37 @@ __device__ __forceinline__ void idct8x8_products(const uint32_t (&d)[32], uint32
     }
 }
 
+// ONE output row (ROW = 0 or 7) of idct8x8_products, the same values at about a fifth of the instructions: the column pass
+// needs a single output per column — o[0] = x0 + u3 or o[7] = x0 - u3: four dot2 — and the row pass runs once.  For the seam
+// rounds of the strip walks (fused_core.hpp): of the chroma blocks above and below a workgroup's rows only the sample row that
+// touches them enters the fancy upsampler (src/upsampler.rs:200-206).
+template <int ARITH, int ROW>
+__device__ __forceinline__ void idct8x8_products_row(const uint32_t (&d)[32], uint32_t &lo, uint32_t &hi) {
+    static_assert(ARITH == ARITH_SANE || ARITH == ARITH_TIGHT, "the exact class works on 32-bit products");
+    static_assert(ROW == 0 || ROW == 7, "first or last sample row");
+    const w32 X_SCALE = 65536u + (128u << 17);
+    w32 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int j = i >> 1;
+        const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;  // (lo.half, hi.half) of column i
+        const uint32_t p04 = perm_b32(d[4 * 4 + j], d[0 * 4 + j], sel), p26 = perm_b32(d[6 * 4 + j], d[2 * 4 + j], sel);
+        const uint32_t p13 = perm_b32(d[3 * 4 + j], d[1 * 4 + j], sel), p57 = perm_b32(d[7 * 4 + j], d[5 * 4 + j], sel);
+        const w32 x0 = dot2_i16_sc(p04, pk_i16(4096, 4096), 512u) + dot2_i16_sc(p26, pk_i16(5352, 2217), 0u);
+        const w32 u3 = dot2_i16(p13, pk_i16(5683, 4816), dot2_i16_sc(p57, pk_i16(3219, 1131), 0u));
+        t[i] = sar(ROW == 0 ? x0 + u3 : x0 - u3, 10);
+    }
+    w32 o[8];
+    if constexpr (ARITH == ARITH_TIGHT) {  // (the column-pass outputs fit i16: the row pass on dot2, as in the full transform)
+        idct_pass8_dot2(perm_b32(t[4], t[0], 0x05040100u), perm_b32(t[6], t[2], 0x05040100u), perm_b32(t[3], t[1], 0x05040100u),
+                        perm_b32(t[7], t[5], 0x05040100u), X_SCALE, o);
+    } else {
+        idct_pass8<true>(t, X_SCALE, o);
+    }
+    lo = sar_sat_u8x4<17>(o[0], o[1], o[2], o[3]);
+    hi = sar_sat_u8x4<17>(o[4], o[5], o[6], o[7]);
+}
+
 // qw: the 64 quantization values packed two per dword (natural order), as VALUES — in SGPRs when they
 // were loaded through a wave-uniform table pointer, in VGPRs when lanes of a wave use different tables.
 template <int ARITH>

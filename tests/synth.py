@@ -47,26 +47,28 @@ def _fdct_quantize(plane, block_w, block_h, qt):
 def coefficients_from_rgb(rgb, comps, mode, qts):
     """Forward path of a baseline encoder (colour transform, box subsampling, FDCT, quantise)
     producing per-component coefficient planes in the Worker layout.
-    mode: 'ycbcr' (3 comps, subsampled per comps' sampling factors), 'gray', or 'cmyk' (4 full-resolution planes)."""
+    mode: 'ycbcr' (3 comps), 'gray', 'cmyk' (Adobe-style inverted C, M, Y from the primaries, K from luma) or 'ycck' (Y, Cb, Cr
+    and K = luma); every component is box-subsampled by its own sampling factors against the frame's largest ones.  The
+    planes are those of the FULL-size frame whatever the components' dct_scale (a scaled decode reads the same coefficients)."""
     r, g, b = [rgb[..., i].astype(np.float64) for i in range(3)]
     y = 0.299 * r + 0.587 * g + 0.114 * b
-    if mode == "gray":
-        return [_fdct_quantize(y - 128.0, comps[0].block_width, comps[0].block_height, qts[0])]
-    if mode == "cmyk":  # Adobe-style inverted CMYK planes (the decoder returns 255 - x): C, M, Y from the primaries, K from luma
-        return [_fdct_quantize(p - 128.0, c.block_width, c.block_height, q) for c, p, q in zip(comps, (r, g, b, y), qts)]
     cb = -0.168736 * r - 0.331264 * g + 0.5 * b + 128.0
     cr = 0.5 * r - 0.418688 * g - 0.081312 * b + 128.0
+    planes = {"gray": (y,), "cmyk": (r, g, b, y), "ycck": (y, cb, cr, y), "ycbcr": (y, cb, cr)}[mode]
     h_max = max(c.horizontal_sampling_factor for c in comps)
     v_max = max(c.vertical_sampling_factor for c in comps)
+    height, width = rgb.shape[:2]
     out = []
-    for c, plane in zip(comps, (y, cb, cr)):
+    for c, plane in zip(comps, planes):
         fx, fy = h_max // c.horizontal_sampling_factor, v_max // c.vertical_sampling_factor
         p = plane
-        if fx > 1 or fy > 1:
+        if len(comps) > 1 and (fx > 1 or fy > 1):
             hh, ww = p.shape
             p = np.pad(p, ((0, (-hh) % fy), (0, (-ww) % fx)), mode="edge")
             p = p.reshape(p.shape[0] // fy, fy, p.shape[1] // fx, fx).mean(axis=(1, 3))
-        p = p[: c.size_height, : c.size_width]
+        if len(comps) > 1:  # ceil(W * h / h_max) x ceil(H * v / v_max): component.size at dct_scale 8 (src/parser.rs:292-310)
+            p = p[: -(-height * c.vertical_sampling_factor // v_max), : -(-width * c.horizontal_sampling_factor // h_max)]
+        p = p[: c.block_height * 8, : c.block_width * 8]
         out.append(_fdct_quantize(p - 128.0, c.block_width, c.block_height, qts[len(out)]))
     return out
 
