@@ -307,6 +307,45 @@ __global__ __launch_bounds__(256, 4) void fgen_kernel_dyn(const FusedGeom *__res
 #undef JP_CALL
 }
 
+// four components, some at half size: a = tile, b = MCU row (fused_x4.hpp)
+template <int ARITH, bool K_FULL>
+__device__ __forceinline__ void r4_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
+                                        uint8_t *lds_raw) {
+    typedef R4<ARITH, K_FULL> K;
+    const FusedWork w = locate(work);
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
+    const R4Lds lds = R4Lds::make(lds_raw, g.tx, K::NL, K::NH);
+    const uint32_t tid = threadIdx.x;
+    S420Regs r;
+    K::init(img, tid, lds);
+    {
+        typename K::Pre pre;
+        K::stage_load(g, img, w.a, w.b, tid, pre);
+        K::stage_store(g, w.a, tid, lds, pre);
+    }
+    __syncthreads();
+    K::read_block(g, w.a, w.b, tid, lds, r);
+    __syncthreads();  // the tiles alias the staging area
+    K::transform(g, w.a, w.b, tid, lds, r);
+    __syncthreads();
+    K::colour(g, img, w.a, w.b, tid, lds);
+}
+template <int ARITH, bool K_FULL>
+__global__ __launch_bounds__(256, 4) void r4_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                    const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    r4_body<ARITH, K_FULL>(geoms, imgs, work, lds_raw);
+}
+template <bool K_FULL>
+__global__ __launch_bounds__(256, 4) void r4_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                        const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+#define JP_CALL(A) r4_body<A, K_FULL>(geoms, imgs, work, lds_raw)
+    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
+#undef JP_CALL
+}
+
 template <int ARITH>
 __device__ __forceinline__ void f444_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
                                           FusedLdsSmall &lds) {
@@ -421,7 +460,7 @@ uint32_t fused_kind_key(const jpgpu_image_desc &d) {
     FusedGeom g;
     const char *nm = "", *w = "";
     const int kind = fused_geom_from_desc(d, g, nm, w);
-    return kind == FUSED_NONE ? 0u : (uint32_t)kind * 8u + g.color;
+    return kind == FUSED_NONE ? 0u : (uint32_t)kind * 8u + g.color + 4u * g.k_full;  // (color < 4; k_full only with CMYK / YCCK frames)
 }
 
 bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<uint32_t> &ids, FusedPlan &plan, std::string &why) {
@@ -462,7 +501,7 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
         if (i == 0) {
             plan.kind = kind;
             name = nm;
-        } else if (kind != plan.kind || plan.geoms[i].color != plan.geoms[0].color) {
+        } else if (kind != plan.kind || plan.geoms[i].color != plan.geoms[0].color || plan.geoms[i].k_full != plan.geoms[0].k_full) {
             why = "images of different kinds";  // e.g. gray next to 4:2:0: the generic path takes the batch
             plan.kind = FUSED_NONE;
             return false;
@@ -502,6 +541,7 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     if (plan.kind == FUSED_420) plan.nt = plan.strip ? 256u : (tx_max <= 32u ? 128u : 256u);
     plan.lds_bytes = plan.kind == FUSED_440 ? S440Lds::total_bytes(tx_max)
                      : plan.kind != FUSED_420 ? 0 : (plan.strip ? S420Lds::total_bytes(tx_max) : F420Lds::total_bytes(tx_max));
+    if (plan.kind == FUSED_420X4) plan.lds_bytes = R4Lds::total_bytes(tx_max, plan.geoms[0].k_full ? 2u : 1u, plan.geoms[0].k_full ? 2u : 3u);
     if (plan.kind == FUSED_GEN) {  // (images of one launch group may differ in H x V: the largest claim)
         plan.lds_bytes = 0;
         for (const auto &g : plan.geoms) plan.lds_bytes = std::max<size_t>(plan.lds_bytes, FGenLds::total_bytes(g.tx, g.hs, g.vs));
@@ -665,6 +705,10 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         break;
     case FUSED_440: WALK_SWITCH(s440_kernel, s440_kernel_dyn); break;
     case FUSED_GEN: ARITH_SWITCH(fgen_kernel, fgen_kernel_dyn); break;
+    case FUSED_420X4:
+        if (g0.k_full) ARITH_SWITCH(r4_kernel, r4_kernel_dyn<true>, true);
+        else ARITH_SWITCH(r4_kernel, r4_kernel_dyn<false>, false);
+        break;
     case FUSED_444: ARITH_SWITCH(f444_kernel, f444_kernel_dyn); break;
     case FUSED_422: ARITH_SWITCH(f422_kernel, f422_kernel_dyn); break;
     case FUSED_GRAY: ARITH_SWITCH(fgray_kernel, fgray_kernel_dyn); break;

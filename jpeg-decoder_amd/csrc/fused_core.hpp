@@ -31,7 +31,8 @@ constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
 constexpr uint32_t FUSED_COEF_LDS = 256 * 128;          // staging area (bytes), aliased by the sample tiles
 
 enum : uint32_t { FCOLOR_YCBCR = 0, FCOLOR_RGB = 1, FCOLOR_CMYK = 2, FCOLOR_YCCK = 3 };  // the last two: four components
-enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4, FUSED_440 = 5, FUSED_GEN = 6 };
+enum FusedKind : int { FUSED_NONE = 0, FUSED_420 = 1, FUSED_444 = 2, FUSED_GRAY = 3, FUSED_422 = 4, FUSED_440 = 5, FUSED_GEN = 6,
+                       FUSED_420X4 = 7 };  // four components, some of them at half size (fused_x4.hpp)
 
 struct FusedGeom {
     uint32_t kind;
@@ -48,6 +49,7 @@ struct FusedGeom {
     uint32_t seg_rows; // S420: MCU rows per workgroup
     uint32_t n_seg;    // S420: ceil(mcu_h / seg_rows)
     uint32_t hs, vs;   // FGen: log2 of the luma sampling factors (H x V luma blocks per MCU)
+    uint32_t k_full;   // R4 (fused_x4.hpp): component 3 is at full size (sampling 22 11 11 22) instead of half size (22 11 11 11)
 };
 
 // One work item of a fused launch: which image, and which of its tiles (meaning of a / b / c per kernel, fused.hip).

@@ -5,6 +5,7 @@
 
 #include "../../include/jpgpu.h"
 #include "fused_core.hpp"
+#include "fused_x4.hpp"
 
 namespace jpgpu {
 
@@ -143,6 +144,27 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             return FUSED_NONE;
         }
         tx_max = F444_TX_MAX;
+    } else if (d0.ncomp == 4 && hv(0, 2, 2) && hv(1, 1, 1) && hv(2, 1, 1) && (hv(3, 1, 1) || hv(3, 2, 2)) &&
+               (d0.color_transform == JPGPU_CT_CMYK || d0.color_transform == JPGPU_CT_YCCK) && d0.out_w > 1 && d0.out_h > 1 &&
+               fused_same_component(d0.components[1], d0.components[2]) &&
+               fused_same_component(d0.components[3], d0.components[hv(3, 2, 2) ? 0 : 1])) {
+        // jpg-cmyk-2.jpg (22 11 11 11: M, Y, K through UpsamplerH2V2) and YCCK with K at full size (22 11 11 22): fused_x4.hpp.
+        // (An output width / height of 1 overrides H2V2, src/upsampler.rs:80-81: generic path.)
+        kind = FUSED_420X4;
+        g.k_full = hv(3, 2, 2) ? 1u : 0u;
+        name = g.k_full ? "fused420x4-2212" : "fused420x4-2211";
+        g.mcu_w = d0.components[1].block_width;
+        g.mcu_h = d0.components[1].block_height;
+        g.bwc = d0.components[1].block_width;
+        g.cw = d0.components[1].size_width;
+        g.ch = d0.components[1].size_height;
+        g.color = d0.color_transform == JPGPU_CT_CMYK ? FCOLOR_CMYK : FCOLOR_YCCK;
+        if (d0.components[0].block_width != 2u * g.mcu_w || d0.components[0].block_height != 2u * g.mcu_h || d0.out_w > 2u * g.cw ||
+            d0.out_h > 2u * g.ch) {
+            why = "inconsistent block grid";
+            return FUSED_NONE;
+        }
+        tx_max = r4_tx_max(g.k_full != 0u);
     } else if (d0.ncomp == 1 && hv(0, 1, 1)) {
         kind = FUSED_GRAY;
         name = "fusedgray";

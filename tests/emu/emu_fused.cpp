@@ -88,6 +88,46 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         else run_walk<S420<ARITH_EXACT, 256>>(g, im, balanced_wgs);
         return kind;
     }
+    if (kind == FUSED_420X4) {  // r4_kernel (fused_x4.hpp), phase by phase
+        FusedImage im{};
+        for (uint32_t c = 0; c < desc->ncomp; c++) {
+            im.coefs[c] = coefs[c];
+            im.qt[c] = desc->quantization_tables[c];
+        }
+        im.out = out;
+        if (tx_out) *tx_out = g.tx;
+        if (s420_tx_max) {  // (test hook: narrower tiles)
+            g.tx = std::min(g.tx, s420_tx_max);
+            g.tiles_x = (g.mcu_w + g.tx - 1) / g.tx;
+        }
+        std::vector<S420Regs> regs(256);
+        auto run = [&](auto K) {
+            typedef decltype(K) KK;
+            std::vector<uint8_t> mem(R4Lds::total_bytes(g.tx, KK::NL, KK::NH) + 64);
+            std::vector<typename KK::Pre> pre(256);
+            for (uint32_t my = 0; my < g.mcu_h; my++)
+                for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
+                    memset(mem.data(), 0xCD, mem.size());
+                    const R4Lds lds = R4Lds::make(mem.data(), g.tx, KK::NL, KK::NH);
+                    for (uint32_t t = 0; t < 256; t++) KK::init(im, t, lds);
+                    for (uint32_t t = 0; t < 256; t++) KK::stage_load(g, im, tile, my, t, pre[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::stage_store(g, tile, t, lds, pre[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::read_block(g, tile, my, t, lds, regs[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::transform(g, tile, my, t, lds, regs[t]);
+                    for (uint32_t t = 0; t < 256; t++) KK::colour(g, im, tile, my, t, lds);
+                }
+        };
+        if (g.k_full) {
+            if (sane == 2) run(R4<ARITH_TIGHT, true>{});
+            else if (sane) run(R4<ARITH_SANE, true>{});
+            else run(R4<ARITH_EXACT, true>{});
+        } else {
+            if (sane == 2) run(R4<ARITH_TIGHT, false>{});
+            else if (sane) run(R4<ARITH_SANE, false>{});
+            else run(R4<ARITH_EXACT, false>{});
+        }
+        return kind;
+    }
     if (kind == FUSED_GEN) {  // fgen_kernel, phase by phase
         FusedImage im{};
         for (uint32_t c = 0; c < desc->ncomp; c++) {

@@ -159,6 +159,13 @@ GEOMS = [
     (45, 29, [(1, 1)] * 4, "CMYK"), (45, 29, [(1, 1)] * 4, "YCCK"), (650, 20, [(1, 1)] * 4, "YCCK"), (513, 9, [(1, 1)] * 4, "CMYK"), (1, 1, [(1, 1)] * 4, "CMYK"),
     (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
     (1000, 1, [(1, 1)], "Grayscale"),
+    # four components with half-size ones (fused_x4.hpp): jpg-cmyk-2.jpg's layout and YCCK with K at full size, both colour
+    # functions on both; several tiles and MCU rows, widths / heights that end inside a block, an MCU, a tile; one MCU
+    (65, 47, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
+    (65, 47, [(2, 2), (1, 1), (1, 1), (1, 1)], "YCCK"), (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "CMYK"),
+    (600, 40, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (577, 33, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
+    (16, 16, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (2, 2, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
+    (13, 90, [(2, 2), (1, 1), (1, 1), (1, 1)], "YCCK"), (38, 10, [(2, 2), (1, 1), (1, 1), (2, 2)], "CMYK"), (290, 18, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"),
 ]
 
 

@@ -471,7 +471,8 @@ def test_batch_of_different_kinds_runs_one_fused_launch_per_kind():
 
 @pytest.mark.parametrize("case", [(250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
                                   (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (300, 200, [(1, 1)], "Grayscale"),
-                                  (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK")], ids=["420", "444", "422", "gray", "ycck-generic"])
+                                  (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"), (70, 40, [(3, 1), (1, 1), (1, 1)], "YCbCr")],
+                         ids=["420", "444", "422", "gray", "ycck-x4", "311-generic"])
 @pytest.mark.parametrize("kind", ["sparse", "full"])
 def test_batch_compact_upload_equals_dense_upload(case, kind):
     """Compact coefficient transport (bitmap + index + values over PCIe, expand kernel on the device): same pixels as
@@ -553,6 +554,25 @@ def test_batch_1080p_other_kinds_full_size(name, samp, mode, ct, path):
     else:
         err = np.abs(outs[0].reshape(h_, w_, 3).astype(int) - rgb.astype(int))
     assert err.mean() < 6.0
+
+
+def test_batch_1080p_444_and_gray_interleaved_full_size():
+    """BASELINE configs[4] at full size: 1920x1080 4:4:4 and grayscale images interleaved in ONE batch (two fused launch groups,
+    path "mixed"), every image equal to the oracle, whichever group it sits in and wherever in the batch."""
+    w_, h_ = 1920, 1080
+    lum, chr_ = synth.quality_tables(85)
+    rgb = synth.synthetic_rgb(w_, h_)
+    oc444, _ = O.make_components(w_, h_, [(1, 1)] * 3)
+    ocg, _ = O.make_components(w_, h_, [(1, 1)])
+    c444 = synth.coefficients_from_rgb(rgb, to_j(oc444), "ycbcr", [lum, chr_, chr_])
+    cg = synth.coefficients_from_rgb(rgb, to_j(ocg), "gray", [lum])
+    cases = [(oc444, [lum, chr_, chr_], c444, "YCbCr", w_, h_) if i % 2 == 0 else (ocg, [lum], cg, "Grayscale", w_, h_) for i in range(12)]
+    outs, path = _run_batch(cases)
+    assert path == "mixed"
+    want444 = O.pixels_from_coefficients(oc444, [lum, chr_, chr_], c444, w_, h_, "YCBCR")
+    wantg = O.pixels_from_coefficients(ocg, [lum], cg, w_, h_, "GRAYSCALE")
+    for i, got in enumerate(outs):
+        assert np.array_equal(got, want444 if i % 2 == 0 else wantg), i
 
 
 def test_batch_scan_ranges_on_device_equals_host_classification():
@@ -658,8 +678,10 @@ def test_one_hostile_image_costs_only_itself(samp, ct, strip, monkeypatch):
                                        ((64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), "fused422"), ((50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"), "fused440"),
                                        ((37, 21, [(1, 1)], "Grayscale"), "fusedgray"), ((45, 29, [(1, 1)] * 4, "CMYK"), "fused444x4"),
                                        ((70, 40, [(4, 1), (1, 1), (1, 1)], "YCbCr"), "fusedgen"),
-                                       ((70, 40, [(3, 1), (1, 1), (1, 1)], "YCbCr"), "generic")],
-                         ids=["420", "444", "422", "440", "gray", "cmyk", "411", "311"])
+                                       ((70, 40, [(3, 1), (1, 1), (1, 1)], "YCbCr"), "generic"),
+                                       ((65, 47, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), "fused420x4-2211"),
+                                       ((65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"), "fused420x4-2212")],
+                         ids=["420", "444", "422", "440", "gray", "cmyk", "411", "311", "cmyk-2211", "ycck-2212"])
 @pytest.mark.parametrize("kind", ["sparse", "full"])
 def test_worker_device_resident_flow_takes_the_fused_kernels(case, path, kind):
     """The drop-in surface (start / append_row / finish_plane / compute_image, what rust/src/worker/hip.rs calls): complete
@@ -750,8 +772,9 @@ def _by_product_image_class(qts, coefs):
 
 
 DYN_KINDS = [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1), (1, 1), (1, 1)], "YCbCr"), ([(2, 1), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)], "Grayscale"),
-             ([(1, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)] * 4, "YCCK"), ([(4, 1), (1, 1), (1, 1)], "YCbCr"), ([(3, 1), (1, 1), (1, 1)], "YCbCr")]
-DYN_IDS = ["420", "444", "422", "gray", "440", "ycck", "411", "311-generic"]
+             ([(1, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)] * 4, "YCCK"), ([(4, 1), (1, 1), (1, 1)], "YCbCr"), ([(3, 1), (1, 1), (1, 1)], "YCbCr"),
+             ([(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), ([(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK")]
+DYN_IDS = ["420", "444", "422", "gray", "440", "ycck", "411", "311-generic", "cmyk-2211", "ycck-2212"]
 
 
 @pytest.mark.parametrize("strip", ["1", "0"], ids=["single-launch", "two-pass"])
@@ -894,3 +917,43 @@ def test_worker_fused_route_classifies_on_the_device(kind, want_cls):
             got = w.compute_image(list(comps), None, (w_, h_), ct)
             assert w.last_path == "fused420" and np.array_equal(got, want)
             assert w.last_class == _exact_image_class(qts, coefs) == want_cls
+
+
+# ---- four components with half-size ones: the row kernel of csrc/fused_x4.hpp ----
+X4_LAYOUTS = [([(2, 2), (1, 1), (1, 1), (1, 1)], "fused420x4-2211"), ([(2, 2), (1, 1), (1, 1), (2, 2)], "fused420x4-2212")]
+
+
+@pytest.mark.parametrize("size", [(65, 47), (600, 40), (16, 16), (2, 2), (13, 90), (290, 18), (577, 33), (1920, 64)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("ct", ["CMYK", "YCCK"])
+@pytest.mark.parametrize("samp,path", X4_LAYOUTS, ids=["2211", "2212"])
+@pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
+def test_batch_four_components_with_half_size_ones_fused(samp, path, ct, size, kind):
+    """jpg-cmyk-2.jpg's layout (22 11 11 11) and YCCK with K at full size (22 11 11 22), both colour functions: the fused row
+    kernel (own blocks in full, of the rows above and below the one sample row the upsampler touches) equals the oracle and the
+    generic kernel pair, for every arithmetic class, several tiles / MCU rows and sizes that end inside a block / an MCU / a tile."""
+    w_, h_ = size
+    rng = np.random.default_rng(w_ * 13 + h_ + len(kind))
+    cases = [_batch_case(rng, w_, h_, samp, ct, kind=kind) for _ in range(3)]
+    outs, got_path = _run_batch(cases)
+    assert got_path == path
+    gen, gen_path = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
+    assert gen_path == "generic"
+    for (oc, qts, coefs, ct_, _w, _h), got, g2 in zip(cases, outs, gen):
+        want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
+        assert np.array_equal(got, want)
+        assert np.array_equal(g2, want)
+
+
+@pytest.mark.parametrize("samp,mode,ct,path", [([(2, 2), (1, 1), (1, 1), (1, 1)], "cmyk", "CMYK", "fused420x4-2211"),
+                                               ([(2, 2), (1, 1), (1, 1), (2, 2)], "ycck", "YCCK", "fused420x4-2212")], ids=["cmyk-2211", "ycck-2212"])
+def test_batch_1080p_four_components_full_size(samp, mode, ct, path):
+    w_, h_ = 1920, 1080
+    ocomps, _ = O.make_components(w_, h_, samp)
+    lum, chr_ = synth.quality_tables(85)
+    qts = [lum] * 4 if mode == "cmyk" else [lum, chr_, chr_, lum]
+    base = synth.coefficients_from_rgb(synth.synthetic_rgb(w_, h_), to_j(ocomps), mode, qts)
+    outs, got_path = _run_batch([(ocomps, qts, base, ct, w_, h_)] * 4)
+    assert got_path == path
+    want = O.pixels_from_coefficients(ocomps, qts, base, w_, h_, ct.upper())
+    for got in outs:
+        assert np.array_equal(got, want)
