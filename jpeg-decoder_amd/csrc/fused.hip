@@ -221,10 +221,20 @@ __device__ __forceinline__ void walk_item(const FusedGeom *__restrict__ geoms, c
 #endif
 }
 
-// (a barrier between the items of a workgroup: the closing phase of one reads the tiles the next one's staging overwrites)
+// The default form: ONE work item per workgroup (work[blockIdx.x], or strip / segment / image from the grid).  Kept free of the
+// item loop below: with it the tight 4:2:0 kernel needed 128 VGPRs, 32 spilled SGPRs and scratch memory where it takes 119
+// VGPRs and none on its own.
 template <int ARITH, uint32_t NT>
 __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                     const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
+                                                     const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    walk_item<S420<ARITH, NT>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
+}
+// Balanced shares (JPGPU_WALK_BALANCE=1, the A/B partner): workgroup w runs items wg_first[w] .. wg_first[w + 1], with a barrier
+// between them (the closing phase of one reads the tiles the next one's staging overwrites)
+template <int ARITH, uint32_t NT>
+__global__ __launch_bounds__(NT, 4) void s420_kernel_items(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                           const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WalkItems its = walk_items_of(work, wg_first);
     for (uint32_t it = its.first; it < its.end; it++) {
@@ -232,23 +242,34 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict
         if (it + 1u < its.end) __syncthreads();
     }
 }
-template <uint32_t NT>
+// Classes from the device (one item per workgroup), as TWO launches: the first runs the images whose coefficients are in range
+// (tight / sane bodies), the second the others (wrap-exact body); a workgroup whose image belongs to the other launch leaves at
+// once.  One kernel with all three bodies inherits the scratch memory of the wrap-exact one (it spills at 128 VGPRs), and a
+// kernel with scratch is dispatched more slowly even where no wave touches it: measured 0.737 ms against 0.676 for the tight
+// kernel on the same box (profiles/round3/10_kernel_trace_stats_and_pmc.json).
+template <uint32_t NT, bool EXACT_PASS>
 __global__ __launch_bounds__(NT, 4) void s420_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                         const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
+                                                         const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const WalkItems its = walk_items_of(work, wg_first);
-    for (uint32_t it = its.first; it < its.end; it++) {  // (the items of a workgroup may belong to images of different classes)
-        const FusedWork w = walk_item_at(geoms, work, it);
-#define JP_CALL(A) walk_item<S420<A, NT>>(geoms, imgs, w, lds_raw)
-        JP_DYN_DISPATCH((uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags), JP_CALL);
-#undef JP_CALL
-        if (it + 1u < its.end) __syncthreads();
+    const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
+    const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags);
+    if constexpr (EXACT_PASS) {
+        if (!(fl & 1u)) walk_item<S420<ARITH_EXACT, NT>>(geoms, imgs, w, lds_raw);
+    } else {
+        if (fl & 2u) walk_item<S420<ARITH_TIGHT, NT>>(geoms, imgs, w, lds_raw);
+        else if (fl & 1u) walk_item<S420<ARITH_SANE, NT>>(geoms, imgs, w, lds_raw);
     }
 }
 
 template <int ARITH>
 __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                      const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
+                                                      const FusedWork *__restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    walk_item<S440<ARITH>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
+}
+template <int ARITH>
+__global__ __launch_bounds__(256, 4) void s440_kernel_items(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                            const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const WalkItems its = walk_items_of(work, wg_first);
     for (uint32_t it = its.first; it < its.end; it++) {
@@ -256,16 +277,17 @@ __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restric
         if (it + 1u < its.end) __syncthreads();
     }
 }
+template <bool EXACT_PASS>
 __global__ __launch_bounds__(256, 4) void s440_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
-                                                          const FusedWork *__restrict__ work, const uint32_t *__restrict__ wg_first) {
+                                                          const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const WalkItems its = walk_items_of(work, wg_first);
-    for (uint32_t it = its.first; it < its.end; it++) {
-        const FusedWork w = walk_item_at(geoms, work, it);
-#define JP_CALL(A) walk_item<S440<A>>(geoms, imgs, w, lds_raw)
-        JP_DYN_DISPATCH((uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags), JP_CALL);
-#undef JP_CALL
-        if (it + 1u < its.end) __syncthreads();
+    const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
+    const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags);
+    if constexpr (EXACT_PASS) {
+        if (!(fl & 1u)) walk_item<S440<ARITH_EXACT>>(geoms, imgs, w, lds_raw);
+    } else {
+        if (fl & 2u) walk_item<S440<ARITH_TIGHT>>(geoms, imgs, w, lds_raw);
+        else if (fl & 1u) walk_item<S440<ARITH_SANE>>(geoms, imgs, w, lds_raw);
     }
 }
 
@@ -325,9 +347,15 @@ __device__ __forceinline__ void r4_body(const FusedGeom *__restrict__ geoms, con
         K::stage_store(g, w.a, tid, lds, pre);
     }
     __syncthreads();
-    K::read_block(g, w.a, w.b, tid, lds, r);
+    // Which wave transforms which blocks rotates from workgroup to workgroup: the first waves hold the blocks that are
+    // transformed in full (660 instructions), the last ones only one-row transforms (150), and wave i of every workgroup runs
+    // on SIMD i of its CU — unrotated, one SIMD did most of every workgroup's arithmetic while two idled.
+    const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t rot = (lin ^ (lin >> 2) ^ (lin >> 5) ^ (lin >> 8) ^ (lin >> 11)) & 3u;
+    const uint32_t role = ((((tid >> 6) + rot) & 3u) << 6) | (tid & 63u);  // the lane whose block this lane takes
+    K::read_block(g, w.a, w.b, role, lds, r);
     __syncthreads();  // the tiles alias the staging area
-    K::transform(g, w.a, w.b, tid, lds, r);
+    K::transform(g, w.a, w.b, role, lds, r);
     __syncthreads();
     K::colour(g, img, w.a, w.b, tid, lds);
 }
@@ -337,13 +365,17 @@ __global__ __launch_bounds__(256, 4) void r4_kernel(const FusedGeom *__restrict_
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     r4_body<ARITH, K_FULL>(geoms, imgs, work, lds_raw);
 }
-template <bool K_FULL>
+template <bool K_FULL, bool EXACT_PASS>  // (two launches, like the walks: the wrap-exact body spills)
 __global__ __launch_bounds__(256, 4) void r4_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                         const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-#define JP_CALL(A) r4_body<A, K_FULL>(geoms, imgs, work, lds_raw)
-    JP_DYN_DISPATCH(image_flags(imgs, work), JP_CALL);
-#undef JP_CALL
+    const uint32_t fl = image_flags(imgs, work);
+    if constexpr (EXACT_PASS) {
+        if (!(fl & 1u)) r4_body<ARITH_EXACT, K_FULL>(geoms, imgs, work, lds_raw);
+    } else {
+        if (fl & 2u) r4_body<ARITH_TIGHT, K_FULL>(geoms, imgs, work, lds_raw);
+        else if (fl & 1u) r4_body<ARITH_SANE, K_FULL>(geoms, imgs, work, lds_raw);
+    }
 }
 
 template <int ARITH>
@@ -683,17 +715,24 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W); \
         else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);                  \
     } while (0)
-#define WALK_SWITCH(KERNEL, DYN, ...)                                                                              \
+    // strip walks: one item per workgroup (KERNEL) or balanced shares (ITEMS, with wg_first); ar < 0: the two `_dyn` passes
+#define WALK_SWITCH(KERNEL, ITEMS, DYN_FAST, DYN_EXACT, ...)                                                        \
     do {                                                                                                            \
-        if (ar < 0) DYN<<<grid, block, shm, stream>>>(G, I, W, wg_first);                                           \
-        else if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first); \
-        else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first);   \
-        else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first);                   \
+        if (ar < 0) {                                                                                               \
+            DYN_FAST<<<grid, block, shm, stream>>>(G, I, W);                                                        \
+            DYN_EXACT<<<grid, block, shm, stream>>>(G, I, W);                                                       \
+        } else if (wg_first) {                                                                                      \
+            if (ar == ARITH_TIGHT) ITEMS<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first);  \
+            else if (ar == ARITH_SANE) ITEMS<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first); \
+            else ITEMS<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W, wg_first);                \
+        } else if (ar == ARITH_TIGHT) KERNEL<ARITH_TIGHT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);    \
+        else if (ar == ARITH_SANE) KERNEL<ARITH_SANE, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);        \
+        else KERNEL<ARITH_EXACT, ##__VA_ARGS__><<<grid, block, shm, stream>>>(G, I, W);                             \
     } while (0)
     switch (plan.kind) {
     case FUSED_420:
         if (plan.strip) {
-            WALK_SWITCH(s420_kernel, s420_kernel_dyn<256>, 256);
+            WALK_SWITCH(s420_kernel, s420_kernel_items, (s420_kernel_dyn<256, false>), (s420_kernel_dyn<256, true>), 256);
             break;
         }
         if (!Wpre)  // (component, 256-block group, image)
@@ -703,11 +742,26 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
         if (plan.nt == 128) ARITH_SWITCH(f420_main_kernel, f420_main_kernel_dyn<128>, 128);
         else ARITH_SWITCH(f420_main_kernel, f420_main_kernel_dyn<256>, 256);
         break;
-    case FUSED_440: WALK_SWITCH(s440_kernel, s440_kernel_dyn); break;
+    case FUSED_440: WALK_SWITCH(s440_kernel, s440_kernel_items, s440_kernel_dyn<false>, s440_kernel_dyn<true>); break;
     case FUSED_GEN: ARITH_SWITCH(fgen_kernel, fgen_kernel_dyn); break;
     case FUSED_420X4:
-        if (g0.k_full) ARITH_SWITCH(r4_kernel, r4_kernel_dyn<true>, true);
-        else ARITH_SWITCH(r4_kernel, r4_kernel_dyn<false>, false);
+        if (ar < 0) {
+            if (g0.k_full) {
+                r4_kernel_dyn<true, false><<<grid, block, shm, stream>>>(G, I, W);
+                r4_kernel_dyn<true, true><<<grid, block, shm, stream>>>(G, I, W);
+            } else {
+                r4_kernel_dyn<false, false><<<grid, block, shm, stream>>>(G, I, W);
+                r4_kernel_dyn<false, true><<<grid, block, shm, stream>>>(G, I, W);
+            }
+        } else if (g0.k_full) {
+            if (ar == ARITH_TIGHT) r4_kernel<ARITH_TIGHT, true><<<grid, block, shm, stream>>>(G, I, W);
+            else if (ar == ARITH_SANE) r4_kernel<ARITH_SANE, true><<<grid, block, shm, stream>>>(G, I, W);
+            else r4_kernel<ARITH_EXACT, true><<<grid, block, shm, stream>>>(G, I, W);
+        } else {
+            if (ar == ARITH_TIGHT) r4_kernel<ARITH_TIGHT, false><<<grid, block, shm, stream>>>(G, I, W);
+            else if (ar == ARITH_SANE) r4_kernel<ARITH_SANE, false><<<grid, block, shm, stream>>>(G, I, W);
+            else r4_kernel<ARITH_EXACT, false><<<grid, block, shm, stream>>>(G, I, W);
+        }
         break;
     case FUSED_444: ARITH_SWITCH(f444_kernel, f444_kernel_dyn); break;
     case FUSED_422: ARITH_SWITCH(f422_kernel, f422_kernel_dyn); break;
@@ -738,10 +792,9 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream, const uint32_t *d_s
     const bool table = !plan.uniform;
     if (d_stats && d_host_cls) {
         e = fused_finalize_classes(plan, stream, d_stats, d_host_cls);
-        if (e == hipSuccess)
+        if (e == hipSuccess)  // (a balanced plan: one item per workgroup here — the `_dyn` kernels have no item loop)
             e = fused_launch_one(plan, stream, -1, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
-                                 table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size(), plan.d_wg_first,
-                                 plan.wg_first.empty() ? 0u : (uint32_t)plan.wg_first.size() - 1u);
+                                 table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size());
     } else if (!plan.by_class) {
         e = fused_launch_one(plan, stream, plan.arith, table ? plan.d_work_main : nullptr, (uint32_t)plan.work_main.size(),
                              table && !plan.work_pre.empty() ? plan.d_work_pre : nullptr, (uint32_t)plan.work_pre.size(), plan.d_wg_first,

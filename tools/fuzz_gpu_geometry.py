@@ -17,6 +17,7 @@ KINDS = [  # sampling factors, colour transform
     ([(1, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)], "Grayscale"), ([(1, 1), (1, 1), (1, 1)], "RGB"),
     ([(1, 1), (1, 1), (1, 1), (1, 1)], "CMYK"), ([(1, 1), (1, 1), (1, 1), (1, 1)], "YCCK"),
     ([(4, 1), (1, 1), (1, 1)], "YCbCr"), ([(4, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 4), (1, 1), (1, 1)], "YCbCr"), ([(2, 4), (1, 1), (1, 1)], "YCbCr"), ([(4, 4), (1, 1), (1, 1)], "YCbCr"),  # UpsamplerGeneric layouts: fusedgen
+    ([(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), ([(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"), ([(2, 2), (1, 1), (1, 1), (1, 1)], "YCCK"), ([(2, 2), (1, 1), (1, 1), (2, 2)], "CMYK"),  # four components with half-size ones: fused420x4 (round 3)
     ([(3, 1), (1, 1), (1, 1)], "YCbCr"), ([(2, 2), (2, 1), (1, 1)], "YCbCr"),  # no fused kernel: the generic path
 ]
 COEF = ["sparse", "tight", "sane", "full"]
