@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -894,22 +895,65 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 ct.sync->n_chunks = refused ? 0u : huff_sync_chunks(ct.seg_table[1], ct.sync->chunk_shift);
             }
         };
-        if (par && copies.size() > 1) (*par)((uint32_t)copies.size(), body);
+        // Staging and upload in slices: while the host threads unstuff the scans of one slice into the pinned block, the
+        // DMA engine carries the slice before (round 3: the whole block was staged, 2.5 ms for 256 x 1080p on the 16 CPUs the
+        // box grants, and only then uploaded, 2 ms).  In front of the uploads, on the same stream, the fills: the planes start
+        // as zeros (the Worker's zero-initialised plane: only non-zero coefficients are written; neighbouring images are
+        // cleared with one fill — a fill per image was 1,024 tiny launches = 28 ms per 1,024 images) and so do the images' range
+        // statistics.  They run while the host stages the first slice, next to nothing else of this sub-batch; on a second
+        // stream (`copy_stream`) they and the uploads also stay clear of the kernels other sub-batches have in flight — behind
+        // a fill on the kernels' own stream an upload waited for the machine to drain (2 of 7.5 ms per sub-batch).
+        const bool two_streams = copy_stream && copy_stream != hip_stream;
+        hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
+        if (two_streams && !b->entropy_uploaded) B_HIP(hipEventCreateWithFlags(&b->entropy_uploaded, hipEventDisableTiming));
+        std::sort(stat_images.begin(), stat_images.end());
+        for (size_t z = 0; z < stat_images.size();) {
+            const size_t first = stat_images[z];
+            size_t last = first;
+            for (z++; z < stat_images.size() && stat_images[z] <= last + 1; z++) last = stat_images[z];
+            B_HIP(hipMemsetAsync(b->d_stats + first * RS_WORDS, 0, (last - first + 1) * RS_WORDS * sizeof(uint32_t), cps));
+        }
+        std::sort(zero_ranges.begin(), zero_ranges.end());
+        for (size_t z = 0; z < zero_ranges.size();) {
+            size_t first = zero_ranges[z].first, last = zero_ranges[z].second;
+            for (z++; z < zero_ranges.size() && zero_ranges[z].first <= last + 256; z++) last = std::max(last, zero_ranges[z].second);
+            B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, cps));
+        }
+        // One parallel-for over all staging tasks; whoever finishes the last task of a slice (~8 MB of the data area) sends
+        // that slice on its way.  (A parallel-for per slice spent more on starting threads than the overlap gave back.)
+        const uint32_t n_tasks = (uint32_t)copies.size();
+        const uint32_t n_slices = std::max<uint32_t>(1u, std::min<uint32_t>({16u, n_tasks, (uint32_t)(data_bytes >> 23) + 1u}));
+        std::vector<std::atomic<uint32_t>> left(n_slices);
+        auto slice_first = [&](uint32_t g) { return (uint32_t)((uint64_t)n_tasks * g / n_slices); };
+        auto slice_of = [&](uint32_t t) {
+            uint32_t g = (uint32_t)(((uint64_t)t * n_slices) / n_tasks);
+            while (g + 1u < n_slices && slice_first(g + 1u) <= t) g++;
+            while (g > 0u && slice_first(g) > t) g--;
+            return g;
+        };
+        for (uint32_t g = 0; g < n_slices; g++) left[g].store(slice_first(g + 1u) - slice_first(g));
+        std::atomic<int> copy_failed{0};
+        const int device = b->device;
+        const std::function<void(uint32_t)> staged = [&](uint32_t t) {
+            body(t);
+            const uint32_t g = slice_of(t);
+            if (left[g].fetch_sub(1u) == 1u) {  // the slice is complete
+                const uint32_t t0 = slice_first(g), t1 = slice_first(g + 1u);
+                const size_t lo = off_data + copies[t0].dst_off, hi = t1 < n_tasks ? off_data + copies[t1].dst_off : total;
+                if (hipSetDevice(device) != hipSuccess || hipMemcpyAsync(d + lo, h + lo, hi - lo, hipMemcpyHostToDevice, cps) != hipSuccess)
+                    copy_failed.store(1);
+            }
+        };
+        if (par && n_tasks > 1) (*par)(n_tasks, staged);
         else
-            for (uint32_t t = 0; t < copies.size(); t++) body(t);
-    }
-    // The upload first: it is a DMA transfer and overlaps the kernels another sub-batch has in flight on its own stream; behind
-    // a fill kernel it waited for the machine to drain (measured: 2 of 7.5 ms per sub-batch of 256 images).
-    const bool two_streams = copy_stream && copy_stream != hip_stream;
-    hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
-    if (two_streams && !b->entropy_uploaded) {
-        B_HIP(hipEventCreateWithFlags(&b->entropy_uploaded, hipEventDisableTiming));
-        B_HIP(hipEventCreateWithFlags(&b->entropy_filled, hipEventDisableTiming));
-    }
-    B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, cps));
-    if (two_streams) {
-        B_HIP(hipEventRecord(b->entropy_uploaded, cps));
-        B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));
+            for (uint32_t t = 0; t < n_tasks; t++) staged(t);
+        if (copy_failed.load()) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
+        // the head of the block last: the staging tasks wrote into its job records (unstuffed lengths, chunk counts, status)
+        B_HIP(hipMemcpyAsync(d, h, off_data, hipMemcpyHostToDevice, cps));
+        if (two_streams) {
+            B_HIP(hipEventRecord(b->entropy_uploaded, cps));
+            B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));
+        }
     }
     // JPGPU_BATCH_KERNEL_TIMES: events between the phases (fills | sync passes | write pass + DC sums | pixel kernels)
     static const bool phase_times = getenv("JPGPU_BATCH_KERNEL_TIMES") != nullptr;
@@ -919,34 +963,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             if (!e) B_HIP(hipEventCreate(&e));
         B_HIP(hipEventRecord(b->ev_phase[0], s));
     }
-    // The planes start as zeros (the Worker's zero-initialised plane): only non-zero coefficients are written.  Neighbouring
-    // images are cleared with one fill (a fill per image was 1,024 tiny launches = 28 ms per 1,024 images).  The same for
-    // their range statistics.  With a second stream the fills run THERE, behind the upload and next to the sync passes: those
-    // are bound by instruction issue and never touch the arena, the fills by bandwidth — only the write pass waits for them
-    // (round 3: the fills were 0.23 of the 5.2 ms of kernels per 256 x 1080p on the stream of the passes).
-    std::sort(stat_images.begin(), stat_images.end());
-    for (size_t z = 0; z < stat_images.size();) {
-        const size_t first = stat_images[z];
-        size_t last = first;
-        for (z++; z < stat_images.size() && stat_images[z] <= last + 1; z++) last = stat_images[z];
-        B_HIP(hipMemsetAsync(b->d_stats + first * RS_WORDS, 0, (last - first + 1) * RS_WORDS * sizeof(uint32_t), cps));
-    }
-    std::sort(zero_ranges.begin(), zero_ranges.end());
-    for (size_t z = 0; z < zero_ranges.size();) {
-        size_t first = zero_ranges[z].first, last = zero_ranges[z].second;
-        for (z++; z < zero_ranges.size() && zero_ranges[z].first <= last + 256; z++) last = std::max(last, zero_ranges[z].second);
-        B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, cps));
-    }
-    if (two_streams) B_HIP(hipEventRecord(b->entropy_filled, cps));
     if (phase_times) B_HIP(hipEventRecord(b->ev_phase[1], s));
-    // (the restart-segment decoder writes coefficients: it waits for the fills; the chunk decoder's write pass does — its sync
-    // passes do not)
-    if (two_streams && n_seg_jobs) B_HIP(hipStreamWaitEvent(s, b->entropy_filled, 0));
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
         static const uint32_t iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
         B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s,
-                               phase_times ? b->ev_phase[2] : nullptr, two_streams ? b->entropy_filled : nullptr));
+                               phase_times ? b->ev_phase[2] : nullptr));
     }
     if (phase_times) {
         B_HIP(hipEventRecord(b->ev_phase[3], s));

@@ -43,13 +43,17 @@ __global__ __launch_bounds__(256) void idct_plane_one_kernel(PlaneJob job) {
     idct_planes_body<SCALE>(job, blockIdx.x, lds);
 }
 
-// Upsample + colour convert: upsample_color_body.hpp (one lane per 8 consecutive output pixels of one row)
-__global__ __launch_bounds__(256) void upsample_color_kernel(const ImageJob *__restrict__ jobs) {
+// Upsample + colour convert: upsample_color_body.hpp (one lane per 8 consecutive output pixels of one row).  The lanes of a
+// launch walk the (row, chunk) pairs of an image in row-major order, `cpr` chunks per row: a workgroup spans several rows of a
+// narrow image (round 3: one workgroup per row left 136 of 256 lanes idle on the 960-pixel rows of a 1080p decode at scale 4).
+__global__ __launch_bounds__(256) void upsample_color_kernel(const ImageJob *__restrict__ jobs, uint32_t cpr, uint32_t rows) {
     const ImageJob &job = jobs[blockIdx.z];
-    upsample_color_lane(job, (blockIdx.x * 256u + threadIdx.x) * 8u, blockIdx.y);
+    const uint32_t l = blockIdx.x * 256u + threadIdx.x, row = l / cpr;
+    if (row < rows) upsample_color_lane(job, (l - row * cpr) * 8u, row);
 }
-__global__ __launch_bounds__(256) void upsample_color_one_kernel(ImageJob job) {
-    upsample_color_lane(job, (blockIdx.x * 256u + threadIdx.x) * 8u, blockIdx.y);
+__global__ __launch_bounds__(256) void upsample_color_one_kernel(ImageJob job, uint32_t cpr, uint32_t rows) {
+    const uint32_t l = blockIdx.x * 256u + threadIdx.x, row = l / cpr;
+    if (row < rows) upsample_color_lane(job, (l - row * cpr) * 8u, row);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,8 +184,10 @@ hipError_t launch_idct_plane_one(const PlaneJob &job, hipStream_t stream) {
 hipError_t launch_upsample_color(const ImageJob *d_jobs, uint32_t n_jobs, uint32_t max_w, uint32_t max_h,
                                  hipStream_t stream) {
     if (n_jobs == 0 || max_w == 0 || max_h == 0) return hipSuccess;
-    dim3 grid(((max_w + 7u) / 8u + 255u) / 256u, max_h, n_jobs), block(256);
-    upsample_color_kernel<<<grid, block, 0, stream>>>(d_jobs);
+    const uint32_t cpr = (max_w + 7u) / 8u;
+    const uint64_t lanes = (uint64_t)cpr * max_h;  // <= 8192 * 65535
+    dim3 grid((uint32_t)((lanes + 255u) / 256u), 1, n_jobs), block(256);
+    upsample_color_kernel<<<grid, block, 0, stream>>>(d_jobs, cpr, max_h);
     return hipGetLastError();
 }
 
@@ -189,8 +195,9 @@ hipError_t launch_upsample_color_one(const ImageJob &job, hipStream_t stream) {
     uint32_t w = job.color_fn == CC_GRAY ? job.comp[0].width : job.out_w;
     uint32_t h = job.color_fn == CC_GRAY ? job.comp[0].height : job.out_h;
     if (w == 0 || h == 0) return hipSuccess;
-    dim3 grid(((w + 7u) / 8u + 255u) / 256u, h), block(256);
-    upsample_color_one_kernel<<<grid, block, 0, stream>>>(job);
+    const uint32_t cpr = (w + 7u) / 8u;
+    dim3 grid((uint32_t)(((uint64_t)cpr * h + 255u) / 256u)), block(256);
+    upsample_color_one_kernel<<<grid, block, 0, stream>>>(job, cpr, h);
     return hipGetLastError();
 }
 

@@ -284,7 +284,11 @@ struct SubBatch {
     }
 };
 
-constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 8, kComputeStreams = 8;  // one compute stream per sub-batch
+// Up to 32 sub-batches per call (half of them at most for the device-entropy route, 256 images each by default), eight compute
+// streams shared round robin.  Round 3: with 8 sub-batches a call of 4,096 files made four device sub-batches of 1,024, whose
+// write pass took 11 us per image against 7 us in sub-batches of 256 (a 6.4 GB arena per sub-batch instead of 1.6 GB:
+// profiles/round3/08_subbatch_size.txt).
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 32, kComputeStreams = 8;
 
 }  // namespace
 
