@@ -697,7 +697,7 @@ def main(argv=None):
                                    " (coefficients resident in HBM -> RGB in HBM)",
                        "name": workload, "images_total": total_images, "images_per_gpu": n_img, "sub_batches": len(shard.batches),
                        "kernel_path": shard.path, "range_class": min(v["sane"] for v in variants),
-                       "range_class_source": "host scan at staging time, outside the timed region (see roofline_by_class.with_device_range_scan)",
+                       "range_class_source": "host scan at staging time, outside the timed region (roofline_by_class.classes_on_device: the same launch with the classes decided on the device, inside the timed region)",
                        "parallelism": f"images sharded {n_img}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
