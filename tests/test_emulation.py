@@ -212,7 +212,7 @@ def test_planner_keeps_odd_geometries_on_the_generic_path():
     for (w_, h_, samp, ct) in [(1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 9, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
                                (1, 64, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (64, 1, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
                                (64, 64, [(3, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(4, 1), (2, 1), (1, 1)], "YCbCr"), (64, 1, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (64, 64, [(2, 1), (1, 1), (1, 1)], "RGB"), (64, 64, [(2, 2)], "Grayscale"),
-                               (64, 64, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (64, 64, [(1, 1)] * 4, "None")]:
+                               (64, 64, [(2, 1), (1, 1), (1, 1), (1, 1)], "CMYK"), (64, 64, [(2, 2), (2, 1), (1, 1), (1, 1)], "CMYK"), (64, 64, [(1, 1)] * 4, "None")]:
         rng = np.random.default_rng(0)
         ocomps, _ = O.make_components(w_, h_, samp)
         qts = [np.ones(64, np.uint16) for _ in ocomps]
