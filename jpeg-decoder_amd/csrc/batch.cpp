@@ -719,6 +719,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         if (lanes < 16384u) sync_blocks = 12u, sync_min_shift = 9u, sync_launches = 16u;
         else if (lanes < 65536u) sync_blocks = 24u, sync_launches = 12u;
     }
+    // Speculative emission ("one pass less", huff_job.hpp): the sync passes leave entry lists, huff_expand_kernel writes whole
+    // blocks — no write pass, and no zero fill for images whose scans cover their planes.  JPGPU_SYNC_EMIT=0: the write pass.
+    static const bool emitting = env_u32("JPGPU_SYNC_EMIT", 1, 0, 1) != 0;
+    static const uint32_t sync_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
     size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
@@ -738,7 +742,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 uint32_t blocks = 0;
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
                 const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
-                scratch_bytes += align_up((size_t)huff_sync_chunks((uint32_t)stuffed, shift) * 7 * 4, 16);
+                const size_t chunks = huff_sync_chunks((uint32_t)stuffed, shift);
+                scratch_bytes += align_up(chunks * 7 * 4, 16);
+                if (emitting) scratch_bytes += align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16);
             } else {
                 n_seg_jobs++;
             }
@@ -796,7 +802,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const uint32_t img = images[k].image;
         b->entropy_images.push_back(img);
         const jpgpu_image_desc &desc = b->descs[img];
-        zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
+        bool needs_zeros = !emitting;  // (the write pass and the restart-segment decoder store non-zero coefficients only)
         stat_images.push_back(img);
         for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the write passes leave in d_stats
             b->sane[(size_t)img * 4 + c] = 0;
@@ -837,6 +843,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->stats = b->d_stats + (size_t)img * RS_WORDS;
                 huff_sync_finish_job(*sj);
                 sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
+                sj->pass0_skip = ((1u << sj->chunk_shift) >> 3) * (8u - sync_tail);
                 const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
                 uint32_t *st = reinterpret_cast<uint32_t *>(d + xcur);
                 sj->data = d + dcur;
@@ -853,6 +860,16 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->n_mcu = ps.n_mcu;
                 max_chunks = std::max(max_chunks, chunks);
                 xcur += align_up((size_t)chunks * 7 * 4, 16);
+                if (emitting) {
+                    sj->emit_stride = huff_emit_stride(sj->chunk_shift);
+                    sj->emit_cnt = reinterpret_cast<uint32_t *>(d + xcur);
+                    xcur += align_up((size_t)chunks * 4, 16);
+                    sj->emit = reinterpret_cast<uint32_t *>(d + xcur);
+                    xcur += align_up((size_t)chunks * sj->emit_stride * 4, 16);
+                    uint32_t block_h[4] = {0, 0, 0, 0};
+                    for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
+                    if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;
+                }
                 si++;
             } else {
                 HuffSyncJob &j = jobs[ji++];
@@ -871,11 +888,14 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 j.stats = b->d_stats + (size_t)img * RS_WORDS;
                 huff_sync_finish_job(j);
                 max_seg = std::max(max_seg, j.n_seg);
+                needs_zeros = true;
             }
             dcur += scan_bytes;
             scur += ps.seg_off.size() * 4;
             tcur += 8 * sizeof(DevHuffTable);
         }
+        if (needs_zeros)
+            zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
     }
     {
         const std::function<void(uint32_t)> body = [&](uint32_t t) {
@@ -968,7 +988,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     {
         static const uint32_t iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
         B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s,
-                               phase_times ? b->ev_phase[2] : nullptr));
+                               phase_times ? b->ev_phase[2] : nullptr, nullptr, emitting));
     }
     if (phase_times) {
         B_HIP(hipEventRecord(b->ev_phase[3], s));

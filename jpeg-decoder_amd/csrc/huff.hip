@@ -145,12 +145,16 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__
 __device__ __forceinline__ bool sync_chunk_has_work(const HuffSyncJob *gj, uint32_t i, uint32_t pass) {
     if (i >= gj->n_chunks) return false;
     if (pass == 0u) return true;
-    if (i == 0u) return false;  // the first chunk decoded from the truth in pass 0
-    const uint32_t p = huff_load_shared(gj->out_pos + (i - 1u));
-    uint32_t qk = huff_load_shared(gj->out_qk + (i - 1u));
+    uint32_t p = 0u, qk = 0u;  // (the first chunk: the start of the scan)
+    if (i > 0u) {
+        p = huff_load_shared(gj->out_pos + (i - 1u));
+        qk = huff_load_shared(gj->out_qk + (i - 1u));
+    }
     if (gj->uniform) qk &= 0xffu;
     const uint32_t first = i << gj->chunk_shift;  // (huff_sync_state_plausible)
-    return p >= first && p - first <= 32u && (qk >> 8) < gj->bpm && (qk & 0xffu) < 64u && (p != gj->in_pos[i] || qk != gj->in_qk[i]);
+    if (i > 0u && !(p >= first && p - first <= 32u && (qk >> 8) < gj->bpm && (qk & 0xffu) < 64u)) return false;
+    if (gj->emit != nullptr) qk |= QK_EMITTED;  // (a state decoded from in pass 0, without emission, is work again)
+    return p != gj->in_pos[i] || qk != gj->in_qk[i];
 }
 
 __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
@@ -185,8 +189,15 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
         if (need) todo[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
         __syncthreads();
         HuffRange unused;
+#if JPGPU_EMIT_MODE == 3
+        __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
+        if (threadIdx.x < total)
+            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused,
+                                                (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
+#else
         if (threadIdx.x < total)
             published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);
+#endif
         __syncthreads();
     }
     const uint32_t n_pub = (uint32_t)__syncthreads_count(published);
@@ -201,7 +212,8 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
         if (threadIdx.x == 0) atomicOr(job.status, 1u | 64u);
         return;
     }
-    uint32_t carry = 0;
+    uint32_t carry = 0, bad = 0;
+    const bool emits = job.emit != nullptr;
     for (uint32_t base = 0; base < job.n_chunks; base += SYNC_NT) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < job.n_chunks ? job.n_blocks[i] : 0u;
@@ -221,8 +233,13 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
             total += t;
         }
         if (i < job.n_chunks) job.n_blocks[i] = carry + before + incl - v;
+        if (emits && i < job.n_chunks) bad |= huff_emit_chunk_status(job, i, carry + before + incl);
         carry += total;
         __syncthreads();
+    }
+    if (emits) {  // (jobs with a write pass: that pass raises these)
+        if (threadIdx.x == 0) bad |= huff_emit_final_status(job, carry);
+        if (bad) atomicOr(job.status, bad);
     }
     if (job.uniform) return;
     // sums of DC differences per chunk and component -> the predictors every chunk starts from (mod 2^16)
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
 __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSyncJob *__restrict__ jobs) {
     __shared__ HuffSyncLds L;
     const HuffSyncJob *gj = &jobs[blockIdx.y];
-    if (blockIdx.x * SYNC_NT >= gj->n_chunks) return;
+    if (blockIdx.x * SYNC_NT >= gj->n_chunks || gj->emit != nullptr) return;  // (emitting jobs: huff_expand_kernel)
     if (*gj->status != 0u) return;
     sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
     __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
@@ -282,7 +299,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(cons
     __shared__ HuffSyncLds L;
     __shared__ HuffWriteBuf W;
     const HuffSyncJob *gj = &jobs[blockIdx.y];
-    if (blockIdx.x * SYNC_NT >= gj->n_chunks) return;
+    if (blockIdx.x * SYNC_NT >= gj->n_chunks || gj->emit != nullptr) return;
     if (*gj->status != 0u) return;
     sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
     {
@@ -295,6 +312,179 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(cons
     HuffRange rg;
     huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
     publish_range(L.job.stats, rg);
+}
+
+// ---- speculative emission -> whole blocks (HuffSyncJob::emit) ----------------------------------------------------------
+// One WAVE per chunk (no workgroup barriers inside): it reads the chunk's entries 64 at a time, numbers the blocks they belong
+// to (a ballot of the "first of a block" bits), scatters the values into a ring of block images in LDS and writes every block
+// that is complete as one 128-byte line, eight lanes each — the arena gets every block of the scan exactly once, zeros
+// included, so nobody has to clear it first, and the 2-byte stores of the write pass happen in LDS instead of HBM.  A block
+// belongs to the chunk it STARTS in; the wave follows it through the leading entries of the chunks after.
+// All of a chunk's entries are requested before the first is used (up to EXP_LOADS x 64 per round): a wave that waits for
+// every 256 bytes in turn would leave the memory system idle.
+constexpr uint32_t EXP_WAVES = 4, EXP_CHUNKS = 4, EXP_SLOT = 68, EXP_SLOTS = 66, EXP_LOADS = 8;
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+struct ExpandLds {
+    HuffSyncJob job;
+    HuffBlockDst q_dst[16];
+    uint32_t wg_rg[2][EXP_WAVES];
+    alignas(16) uint16_t ring[EXP_WAVES][EXP_SLOTS * EXP_SLOT];  // per wave: block images of 136 bytes (8 more than a block: the DC
+                                                                 // entries of a run of flat blocks do not all meet in one bank)
+};
+static_assert(sizeof(HuffSyncJob) % 4 == 0, "copied by dwords");
+
+// Block numbers -> MCU coordinates without a division per block: the wave knows where block S, the first one that starts in
+// its chunk, lies (real divisions, once per chunk), every other block is S + d with d < 2^16, and n / x for small n is a
+// multiplication by 2^32 / x + 1 (exact while n * x < 2^32).
+struct ExpandAt {
+    uint64_t inv_bpm, inv_cols;
+    uint32_t bpm, cols, q0, mx0, my0;  // block S = block q0 of MCU (mx0, my0)
+};
+__device__ __forceinline__ uint32_t small_div(uint32_t n, uint64_t inv) { return (uint32_t)(((uint64_t)n * inv) >> 32); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// slots [0, n) of the wave's ring hold blocks S + d0 .. S + d0 + n - 1: written out and cleared, eight lanes per block
+__device__ __forceinline__ void expand_store_blocks(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, const ExpandAt &at, uint32_t S, uint32_t d0, uint32_t n,
+                                                    uint32_t total) {
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, grp = lane >> 3;
+    for (uint32_t s0 = 0; s0 < n; s0 += 8u) {
+        const uint32_t s = s0 + grp;
+        if (s < n) {
+            JP_LDS v2u *row = (JP_LDS v2u *)(ring + s * EXP_SLOT + sub * 8u);
+            const v2u a = row[0], b = row[1];
+            row[0] = v2u{0u, 0u};
+            row[1] = v2u{0u, 0u};
+            if (S + d0 + s < total) {
+                const uint32_t t = at.q0 + d0 + s, dm = small_div(t, at.inv_bpm), q = (t - dm * at.bpm) & 15u;
+                const uint32_t x = at.mx0 + dm, dy = small_div(x, at.inv_cols), mx = x - dy * at.cols, my = at.my0 + dy;
+                const uint64_t dst = E.q_dst[q].base + (uint64_t)my * E.q_dst[q].row_stride + (uint64_t)mx * E.q_dst[q].mcu_stride;
+                ((JP_GLOBAL v4u *)(uintptr_t)dst)[sub] = v4u{a.x, a.y, b.x, b.y};
+            }
+        }
+    }
+}
+
+// one entry of block S + d into image `slot` of the ring; returns |value * quantization value| (0 for lanes without an entry)
+__device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, const ExpandAt &at, bool valid, uint32_t ent, uint32_t d, uint32_t slot,
+                                               uint32_t w0, uint32_t w1) {
+    const uint32_t t = at.q0 + d, c = E.job.q_comp[(t - small_div(t, at.inv_bpm) * at.bpm) & 15u] & 3u, z = (ent >> 16) & 63u;
+    uint32_t v = ent & 0xffffu;
+    if (ent & HUFF_EMIT_DC) {  // the chunk's running sum + what the chunks before it add up to (zeros in a `uniform` scan)
+        const uint32_t w = c < 2u ? w0 : w1;
+        v = (v + ((c & 1u) ? w >> 16 : w)) & 0xffffu;
+    }
+    if (!valid || slot >= EXP_SLOTS) return 0u;  // (the second condition never holds for lists the sync passes wrote)
+    ring[slot * EXP_SLOT + z] = (uint16_t)v;
+    const int32_t sv = (int16_t)(uint16_t)v;
+    return (uint32_t)(sv < 0 ? -sv : sv) * E.job.q[c][z];
+}
+
+__global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffSyncJob *__restrict__ jobs) {
+    __shared__ ExpandLds E_;
+    JP_LDS ExpandLds &E = *(JP_LDS ExpandLds *)&E_;
+    const HuffSyncJob *gj = &jobs[blockIdx.y];
+    const uint32_t first_chunk = blockIdx.x * (EXP_WAVES * EXP_CHUNKS);
+    if (first_chunk >= gj->n_chunks || gj->emit == nullptr || *gj->status != 0u) return;  // (flagged: the host decodes the image)
+    {
+        const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj;
+        JP_LDS uint32_t *dst = (JP_LDS uint32_t *)&E.job;
+        for (uint32_t t = threadIdx.x; t < sizeof(HuffSyncJob) / 4u; t += EXP_WAVES * 64u) dst[t] = src[t];
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl(threadIdx.x >> 6);
+    JP_LDS uint16_t *ring = E.ring[wave];
+    for (uint32_t t = lane; t < EXP_SLOTS * EXP_SLOT / 2u; t += 64u) ((JP_LDS uint32_t *)ring)[t] = 0u;
+    __syncthreads();
+    if (threadIdx.x < 16u) huff_fill_block_dst(E.job, E.q_dst, threadIdx.x);
+    __syncthreads();
+    const JP_LDS HuffSyncJob &job = E.job;
+    // (what steers the wave is the same in all its lanes: kept in scalar registers, branches instead of lane masks)
+    const uint32_t bpm = rfl(job.bpm), cols = rfl(job.cols), n_chunks = rfl(job.n_chunks), uniform = rfl(job.uniform);
+    const uint32_t total = rfl(job.n_mcu) * bpm, stride = rfl(job.emit_stride);
+    ExpandAt at;
+    at.bpm = bpm;
+    at.cols = cols;
+    at.inv_bpm = (1ull << 32) / bpm + 1ull;
+    at.inv_cols = (1ull << 32) / cols + 1ull;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t rg_dc = 0, rg_ac = 0;
+    for (uint32_t ci = 0; ci < EXP_CHUNKS; ci++) {
+        const uint32_t i = first_chunk + wave * EXP_CHUNKS + ci;
+        if (i >= n_chunks) break;
+        const uint32_t cw = rfl(job.emit_cnt[i]), cnt = min(cw & 0xffffu, stride), lead = min(cw >> 16, cnt);
+        if (lead >= cnt) continue;  // no block starts in this chunk
+        const uint32_t k_i = i ? rfl(job.out_qk[i - 1u]) & 0xffu : 0u;
+        const uint32_t S = rfl(job.n_blocks[i]) + (k_i ? 1u : 0u);  // number of the first block that starts here
+        if (S >= total) continue;  // (what a stream holds after its last block)
+        {
+            const uint32_t m = S / bpm;
+            at.q0 = S - m * bpm;
+            at.my0 = m / cols;
+            at.mx0 = m - at.my0 * cols;
+        }
+        const uint32_t w0 = uniform ? 0u : rfl(job.dc_sum[2u * i]), w1 = uniform ? 0u : rfl(job.dc_sum[2u * i + 1u]);
+        const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
+        uint32_t started = 0, base = 0;  // blocks started so far; which of them sits in slot 0 (the open one, once there is one)
+        for (uint32_t e0 = lead; e0 < cnt; e0 += 64u * EXP_LOADS) {
+            uint32_t ent[EXP_LOADS];
+#pragma unroll
+            for (uint32_t r = 0; r < EXP_LOADS; r++) {
+                const uint32_t e = e0 + 64u * r + lane;
+                ent[r] = e < cnt ? stream_load(buf + e) : 0u;
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < EXP_LOADS; r++) {
+                if (e0 + 64u * r >= cnt) break;
+                const bool valid = e0 + 64u * r + lane < cnt, flag = valid && (ent[r] & HUFF_EMIT_DC) != 0u;
+                const uint64_t m = __ballot(flag);
+                const uint32_t local = started + (uint32_t)__popcll(m & lt) + (flag ? 1u : 0u) - 1u;  // the entry's block, counted from S
+                const uint32_t a = expand_put(E, ring, at, valid, ent[r], local, local - base, w0, w1);
+                if (S + local < total) {
+                    if (flag) rg_dc = uniform ? rg_dc : max(rg_dc, a);  // (uniform scans: huff_dc_prefix_kernel ranges the finished values)
+                    else rg_ac = max(rg_ac, a);
+                }
+                started += (uint32_t)__popcll(m);
+                const uint32_t done = started ? started - 1u - base : 0u;  // every block but the last one started is complete
+                __builtin_amdgcn_wave_barrier();
+                expand_store_blocks(E, ring, at, S, base, done, total);
+                if (done && lane < 8u) {  // the open block moves to slot 0
+                    JP_LDS v2u *from = (JP_LDS v2u *)(ring + done * EXP_SLOT + lane * 8u), *to = (JP_LDS v2u *)(ring + lane * 8u);
+                    const v2u x = from[0], y = from[1];
+                    from[0] = v2u{0u, 0u};
+                    from[1] = v2u{0u, 0u};
+                    to[0] = x;
+                    to[1] = y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                base += done;
+            }
+        }
+        // the last block: its remaining entries lead the lists of the chunks that follow
+        const uint32_t last = started ? started - 1u : total;  // (counted from S)
+        for (uint32_t j = i + 1u; S + last < total && j < n_chunks; j++) {
+            const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj);
+            const JP_GLOBAL uint32_t *bj = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)j * stride);
+            for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put(E, ring, at, true, stream_load(bj + e) & ~HUFF_EMIT_DC, last, 0u, 0u, 0u));
+            if (leadj < cntj) break;  // a block starts in chunk j: ours ended there
+        }
+        __builtin_amdgcn_wave_barrier();
+        expand_store_blocks(E, ring, at, S, last, started ? 1u : 0u, total);
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        rg_dc = max(rg_dc, (uint32_t)__shfl_xor((int)rg_dc, off));
+        rg_ac = max(rg_ac, (uint32_t)__shfl_xor((int)rg_ac, off));
+    }
+    if (lane == 0u) {
+        E.wg_rg[0][wave] = rg_dc;
+        E.wg_rg[1][wave] = rg_ac;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint32_t v = 0;
+        for (uint32_t w = 0; w < EXP_WAVES; w++) v = max(v, E.wg_rg[threadIdx.x][w]);
+        stat_raise(job.stats + (threadIdx.x ? RS_MAX_AC : RS_MAX_DC), v);
+    }
 }
 
 // DC differences -> DC values: a running sum (i16 wrapping, src/decoder.rs:1095-1099) per component over its blocks in
@@ -389,7 +579,7 @@ hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t m
 // Everything for the jobs without restart markers, enqueued blind: a fixed number of sync launches (settled jobs cost an
 // empty workgroup each), block numbering, the write pass and the DC sums.
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync, hipEvent_t before_write) {
+                            hipEvent_t after_sync, hipEvent_t before_write, bool emitting) {
     if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) {
         if (after_sync) (void)hipEventRecord(after_sync, stream);
         return hipSuccess;
@@ -411,7 +601,9 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     // the extra ~35 instructions per step of the cooperative stores cost more than the 2-byte stores they replace.
     const char *asm_env = getenv("JPGPU_SYNC_WRITE_ASSEMBLE");
     const bool assembled = asm_env && atoi(asm_env) != 0;
-    if (assembled) huff_sync_write_assembled_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs);
+    if (emitting)  // (every job of the call carries emission buffers: the lists the sync passes left -> whole blocks)
+        huff_expand_kernel<<<dim3((max_chunks + EXP_WAVES * EXP_CHUNKS - 1u) / (EXP_WAVES * EXP_CHUNKS), n_jobs), dim3(EXP_WAVES * 64u), 0, stream>>>(d_jobs);
+    else if (assembled) huff_sync_write_assembled_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs);
     else huff_sync_write_kernel<<<grid, dim3(SYNC_NT), write_lds, stream>>>(d_jobs);
     huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(DC_NT), 0, stream>>>(d_jobs);
     return hipGetLastError();

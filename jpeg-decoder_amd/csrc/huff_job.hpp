@@ -82,7 +82,31 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     // tables of the scan's components in natural order — the writer sees every non-zero coefficient and its position anyway.
     uint32_t *stats;
     uint16_t q[4][64];
+    // Speculative emission (huff_sync_core.hpp, "one pass less"): from the second sync pass on every lane leaves what it decodes
+    // as a list of entries in stream order in its chunk's own buffer; once the segmentation has settled the lists ARE the
+    // scan, and huff_expand_kernel turns them into whole blocks (no write pass, no zero fill).  nullptr: write pass instead.
+    uint32_t *emit;         // n_chunks buffers of emit_stride entries: value & 0xffff | natural position << 16 | first of a block << 31
+    uint32_t *emit_cnt;     // per chunk: entries | entries before the first block start << 16 (HUFF_EMIT_OVERFLOW: see there)
+    uint32_t emit_stride;
+    uint32_t pass0_skip;    // bits of its chunk every lane but the first leaves out in sync pass 0 (huff_sync_chunk)
 };
+// Does the scan write every block of its components' planes?  (An interleaved scan does; a scan of one component of several
+// leaves out the blocks that pad the plane to whole MCUs of the frame.)  block_h[c]: rows of blocks of scan component c's plane.
+inline bool huff_scan_covers_planes(const HuffSyncJob &j, const uint32_t block_h[4]) {
+    if (j.cols == 0 || j.n_mcu % j.cols != 0) return false;
+    const uint32_t rows = j.n_mcu / j.cols;
+    for (uint32_t c = 0; c < j.ncomp; c++)
+        if (j.cols * j.comp[c].h != j.comp[c].block_w || rows * j.comp[c].v != block_h[c]) return false;
+    return true;
+}
+constexpr uint32_t HUFF_EMIT_DC = 0x80000000u, HUFF_EMIT_OVERFLOW = 0xffffffffu;
+// Entries a chunk can produce: a DC entry takes at least 1 bit and is followed by an end-of-block code (>= 1 bit) or 63
+// coefficients, an AC entry at least 2 bits (code + magnitude) — at most 64 entries per 127 bits — and the symbols a lane decodes
+// start inside its chunk (the last one may end up to 31 bits beyond it).  Multiple of 4 entries: buffers stay 16-byte aligned.
+inline uint32_t huff_emit_stride(uint32_t chunk_shift) {
+    const uint32_t bits = 1u << chunk_shift;
+    return (bits / 2u + bits / 128u + 24u + 3u) & ~3u;
+}
 
 // Chunk size.  A lane that starts at a wrong place finds the symbol boundaries within a few symbols, the block boundaries at
 // the next end-of-block — and the position inside the MCU (which tables apply) only by luck, one try per re-synchronisation,

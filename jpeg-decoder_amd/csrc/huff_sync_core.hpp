@@ -42,15 +42,25 @@ __device__ __forceinline__ uint32_t huff_sym_info(uint32_t ac, uint32_t sym) {
     return r == 0u ? (64u << 4) : SYM_BAD;                             // EOB; an EOBn run is for the host
 }
 
+struct alignas(16) HuffBlockDst {  // block-within-MCU -> where its coefficients go: base + my * row_stride + mx * mcu_stride (bytes)
+    uint64_t base;
+    uint32_t row_stride, mcu_stride;
+};
+__device__ __forceinline__ void huff_fill_block_dst(const JP_LDS HuffSyncJob &job, JP_LDS HuffBlockDst *q_dst, uint32_t lane) {  // lane < 16
+    const uint32_t c = job.q_comp[lane < job.bpm ? lane : 0u];
+    const JP_LDS HuffScanComp &sc = job.comp[c];
+    const uint32_t sub = job.q_sub[lane < job.bpm ? lane : 0u], h = sc.h ? sc.h : 1u, vp = sub / h, hp = sub - vp * h;
+    q_dst[lane].base = (uint64_t)(uintptr_t)sc.dst + ((uint64_t)vp * sc.block_w + hp) * 128u;
+    q_dst[lane].row_stride = sc.v * sc.block_w * 128u;
+    q_dst[lane].mcu_stride = sc.h * 128u;
+}
+
 struct HuffSyncLds {
     DevHuffTable tables[8];
     HuffSyncJob job;
     uint16_t sym_info[2][256];  // [DC | AC][symbol]
     uint32_t q_tables[16];      // block-within-MCU -> byte offset of its DC table in `tables` | its AC table << 16
-    struct alignas(16) Dst {    // block-within-MCU -> where its coefficients go: base + my * row_stride + mx * mcu_stride (bytes)
-        uint64_t base;
-        uint32_t row_stride, mcu_stride;
-    } q_dst[16];
+    HuffBlockDst q_dst[16];
     uint32_t dc[256][4];        // per lane and component: sum of DC differences (sync passes) / DC predictor (write pass)
     uint8_t unzig[64];
     uint32_t unzq[4][64];       // per scan component and zig-zag index k: natural position | quantization value there << 16 — the
@@ -67,11 +77,7 @@ __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32
     if (lane < 16u) {
         const uint32_t c = L.job.q_comp[lane < L.job.bpm ? lane : 0u];
         L.q_tables[lane] = (uint32_t)(L.job.comp[c].dc * sizeof(DevHuffTable)) | ((uint32_t)((4u + L.job.comp[c].ac) * sizeof(DevHuffTable)) << 16);
-        const JP_LDS HuffScanComp &sc = L.job.comp[c];
-        const uint32_t sub = L.job.q_sub[lane < L.job.bpm ? lane : 0u], h = sc.h ? sc.h : 1u, vp = sub / h, hp = sub - vp * h;
-        L.q_dst[lane].base = (uint64_t)(uintptr_t)sc.dst + ((uint64_t)vp * sc.block_w + hp) * 128u;
-        L.q_dst[lane].row_stride = sc.v * sc.block_w * 128u;
-        L.q_dst[lane].mcu_stride = sc.h * 128u;
+        huff_fill_block_dst(L.job, L.q_dst, lane);
     }
 }
 
@@ -166,12 +172,52 @@ __device__ __forceinline__ void huff_flush_blocks(JP_LDS HuffWriteBuf &W, bool f
 struct HuffRange {
     uint32_t dc = 0, ac = 0;
 };
+// Speculative emission of a sync pass (HuffSyncJob::emit): the lane's chunk buffer and what it has put there.  An entry per DC
+// value (always, zero or not: it marks the start of a block; the value is the running sum of the chunk's differences for its
+// component — the chunk's predictor is added by the expansion — or the difference itself in a `uniform` scan) and per
+// non-zero AC coefficient, in stream order.
+#ifndef JPGPU_EMIT_MODE  // A/B builds: 0 one 4-byte store per entry; 1 no stores at all (what the bookkeeping alone costs: wrong
+#define JPGPU_EMIT_MODE 2  //  output); 2 four entries gathered in registers, one 16-byte store; 3 = 0 with the stream read through the LDS ring
+#endif
+struct HuffEmit {
+    JP_GLOBAL uint32_t *buf = nullptr;  // nullptr: this run emits nothing
+    uint32_t n = 0, cap = 0, lead = 0xffffffffu;  // entries so far (counts on past `cap`: overflow), capacity (a multiple of 4), entries before the first DC
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // the last entries, youngest in s3, not yet stored
+};
+__device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
+#if JPGPU_EMIT_MODE == 2
+    em.s0 = em.s1;
+    em.s1 = em.s2;
+    em.s2 = em.s3;
+    em.s3 = e;
+    if ((em.n & 3u) == 3u && em.n < em.cap) *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
+#elif JPGPU_EMIT_MODE == 1
+    em.s3 ^= e;
+#else
+    if (em.n < em.cap) em.buf[em.n] = e;
+#endif
+    em.n++;
+}
+// the entries of an incomplete group of four, at the end of a run
+__device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
+#if JPGPU_EMIT_MODE == 2
+    const uint32_t r = em.n & 3u, first = em.n - r;
+    if (em.buf && r && em.n <= em.cap) {
+        const uint32_t a = r == 3u ? em.s1 : (r == 2u ? em.s2 : em.s3), b = r == 3u ? em.s2 : em.s3;
+        em.buf[first] = a;
+        if (r >= 2u) em.buf[first + 1u] = b;
+        if (r == 3u) em.buf[first + 2u] = em.s3;
+    }
+#elif JPGPU_EMIT_MODE == 1
+    if (em.buf && em.s3 == 0x12345678u) em.buf[0] = em.s3;  // (keeps the bookkeeping alive)
+#endif
+}
 
 template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
 __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                              uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad,
                                              HuffRange &rg, JP_LDS HuffWriteBuf *W = nullptr, bool participate = true,
-                                             JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
+                                             JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0, HuffEmit *em = nullptr) {
     const JP_LDS HuffSyncJob &job = L.job;
     // (huff_core.hpp) kernels that store decode from the LDS ring when they are given one; the sync passes fetch dwords ahead
 #ifdef JPGPU_HOST_EMULATION
@@ -180,7 +226,11 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 #ifdef JPGPU_WRITE_DW  // (A/B build: the write pass fetches dwords ahead like the sync passes, no LDS ring)
     constexpr int RD = HUFF_READ_DW;
 #else
+#if JPGPU_EMIT_MODE == 3
+    constexpr int RD = HUFF_READ_RING;
+#else
     constexpr int RD = WRITE ? HUFF_READ_RING : HUFF_READ_DW;
+#endif
 #endif
 #endif
     DevBits b;
@@ -259,6 +309,15 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
                 }
                 // (finished DC values only: the differences of a uniform scan are summed — and ranged — by huff_dc_prefix_kernel)
                 if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * (zq[0] >> 16));
+                if (!WRITE && BY_BITS && em && em->buf) {
+                    if (em->lead == 0xffffffffu) em->lead = em->n;
+                    huff_emit_entry(*em, HUFF_EMIT_DC | (uint32_t)(uint16_t)val);
+                }
+            } else if (!WRITE && BY_BITS && (info & SYM_COEF)) {
+                if (em && em->buf) {
+                    const uint32_t z = L.unzig[k - 1u];
+                    huff_emit_entry(*em, (z << 16) | (uint32_t)(uint16_t)huff_extend(raw, nread));
+                }
             } else if (WRITE && (info & SYM_COEF)) {
                 const uint32_t e = zq[k - 1u], z = e & 0xffffu;
                 const int32_t x = huff_extend(raw, nread);
@@ -312,18 +371,28 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 // One chunk.  WRITE = false: a sync pass (`pass` = its number), returns whether the lane published a new state (the caller
 // counts those per job: one atomic per workgroup, not per lane — a quarter of a million lanes adding to a few hundred
 // neighbouring counters took 18 ms per pass); WRITE = true: the write pass.
+// Jobs with speculative emission (job.emit): a sync pass also leaves the chunk's entries — every pass but the first, whose
+// start states are guesses.  A lane that has decoded from a state WITHOUT emitting still has work when the same state comes
+// round again (QK_EMITTED in in_qk tells).
+constexpr uint32_t QK_EMITTED = 0x80000000u;
+__device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t pass) { return job.emit != nullptr && pass > 0u; }
+
 template <bool WRITE>
 __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
                                                 uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     uint32_t pos, q, k;
-    if (i == 0u) {
-        pos = 0u;
+    if (!WRITE && pass == 0u) {
+        // The first pass is there to find where the chunks END, from guessed start states; a lane that starts at a guess
+        // finds the true segmentation within ~15 blocks on average (the misses decay exponentially): it need not walk the
+        // whole chunk for that.  Every lane decodes its chunk again from a real state in pass 1 anyway — the first lane too,
+        // whose true start is known (one lane walking a whole chunk would keep the launch waiting for it).
+        pos = (i << job.chunk_shift) + job.pass0_skip;
         q = 0u;
         k = 0u;
-    } else if (!WRITE && pass == 0u) {
-        pos = i << job.chunk_shift;
+    } else if (i == 0u) {
+        pos = 0u;
         q = 0u;
         k = 0u;
     } else {
@@ -337,12 +406,14 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     // which is the start of ours.  Anything else is not a state of this launch sequence — that lane belongs to a workgroup
     // which has not run yet, and the words are what an earlier batch left there — and must not be decoded from (it could
     // mean walking half the scan) nor handed on (it would travel down the scan, one lane per pass, keeping the job unsettled).
-    if (i > 0u && !huff_sync_state_plausible(job, i, pos, q, k)) pos = HUFF_POS_INVALID;
+    if (i > 0u && !(!WRITE && pass == 0u) && !huff_sync_state_plausible(job, i, pos, q, k)) pos = HUFF_POS_INVALID;
+    const bool emit = !WRITE && huff_emit_in_pass(job, i, pass);
     if (!WRITE) {
         if (pos == HUFF_POS_INVALID) return false;  // the predecessor has nothing to offer yet: keep what we have
-        if (pass > 0u && pos == job.in_pos[i] && ((q << 8) | k) == job.in_qk[i]) return false;  // same start as last time
+        const uint32_t qk_in = (q << 8) | k | (emit ? QK_EMITTED : 0u);
+        if (pass > 0u && pos == job.in_pos[i] && qk_in == job.in_qk[i]) return false;  // same start as last time
         job.in_pos[i] = pos;
-        job.in_qk[i] = (q << 8) | k;
+        job.in_qk[i] = qk_in;
     } else if (pos == HUFF_POS_INVALID) {
         atomicOr_status(job.status, 1u | 32u);
         return false;
@@ -366,7 +437,16 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         dc[2] = w1 & 0xffffu;
         dc[3] = w1 >> 16;
     }
-    if (pos < limit) pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
+    HuffEmit em;
+    if (emit) {
+        em.buf = (JP_GLOBAL uint32_t *)(job.emit + (size_t)i * job.emit_stride);
+        em.cap = job.emit_stride;
+    }
+    if (pos < limit)
+        pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride, &em);
+    if (!WRITE) huff_emit_finish(em);
+    if (!WRITE && job.emit != nullptr)  // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
+        job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
     if (!WRITE && dc_sums) {
         job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);
         job.dc_sum[2u * i + 1u] = (dc[2] & 0xffffu) | (dc[3] << 16);
@@ -386,6 +466,25 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         if (i + 1u == job.n_chunks && (blkno < total_blocks || pos > job.n_bits)) atomicOr_status(job.status, 1u | 8u);
     }
     return false;
+}
+
+// What the write pass would have noticed, for jobs with speculative emission (block numbering, huff_sync_scan_kernel): a chunk
+// whose last run met an impossible code (or overran its buffer) before the scan's last block was complete ...
+__device__ __forceinline__ uint32_t huff_emit_chunk_status(const HuffSyncJob &job, uint32_t i, uint32_t blocks_through_chunk) {
+    const uint32_t total_blocks = job.n_mcu * job.bpm;
+    if (blocks_through_chunk >= total_blocks) return 0u;  // (what follows the last block is nobody's business: src/decoder.rs stops there)
+    if (job.emit_cnt[i] == HUFF_EMIT_OVERFLOW) return 1u | 128u;
+    return job.out_pos[i] == HUFF_POS_INVALID ? (1u | 2u) : 0u;
+}
+// ... and data that ends before the last block does (`blocks` = what all chunks completed), or whose last block took bits from
+// beyond the end: only symbols that start inside the data are decoded, so that is the last symbol of the last chunk completing
+// block number total - 1.
+__device__ __forceinline__ uint32_t huff_emit_final_status(const HuffSyncJob &job, uint32_t blocks) {
+    const uint32_t total_blocks = job.n_mcu * job.bpm;
+    if (blocks < total_blocks || job.n_chunks == 0u) return 1u | 8u;
+    const uint32_t p = job.out_pos[job.n_chunks - 1u];
+    if (blocks == total_blocks && p != HUFF_POS_INVALID && p > job.n_bits && (job.out_qk[job.n_chunks - 1u] & 0xffu) == 0u) return 1u | 8u;
+    return 0u;
 }
 
 // The write pass with block assembly (HuffWriteBuf): every lane of the workgroup calls it, `valid` = the lane has a chunk;

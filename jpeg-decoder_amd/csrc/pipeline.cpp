@@ -288,7 +288,7 @@ struct SubBatch {
 // streams shared round robin.  Round 3: with 8 sub-batches a call of 4,096 files made four device sub-batches of 1,024, whose
 // write pass took 11 us per image against 7 us in sub-batches of 256 (a 6.4 GB arena per sub-batch instead of 1.6 GB:
 // profiles/round3/08_subbatch_size.txt).
-constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 32, kComputeStreams = 8;
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 8;
 
 }  // namespace
 
@@ -310,6 +310,7 @@ struct jpgpu_pipeline {
     bool downloaded = false;  // the last call copied the pixels to host memory
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t compute[kComputeStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t n_compute = kComputeStreams;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob)
     jpgpu_pipeline_timings t{};
 };
 
@@ -389,6 +390,7 @@ int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) 
     p->subs.resize(kMaxSubBatches);
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
     for (uint32_t k = 0; k < kComputeStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->compute[k], hipStreamNonBlocking));
+    if (const char *e = getenv("JPGPU_PIPE_STREAMS")) p->n_compute = (uint32_t)std::min<long>(std::max<long>(atol(e), 1), kComputeStreams);
     for (SubBatch &sb : p->subs)
         for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipEventCreateWithFlags(&sb.ready[k], hipEventDisableTiming));
     return JPGPU_OK;
@@ -567,13 +569,18 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     uint32_t n_dev_subs = 0;           // the first sub-batches hold the images whose entropy data goes to the device
     {
         // streams with restart markers: one lane per restart segment, ~1,000 images fill the machine; without: one lane
-        // per chunk of the scan, 256 images do, and smaller sub-batches let staging, upload and kernels of neighbours overlap
-        static const long dev_sub_env = getenv("JPGPU_PIPE_DEV_SUB") ? atol(getenv("JPGPU_PIPE_DEV_SUB")) : 0;  // tuning knob
+        // per chunk of the scan, 256 images do — but several sub-batches are in flight at a time (one compute stream each, and
+        // a hardware queue each when GPU_MAX_HW_QUEUES allows: jpgpu.cpp), the latency-bound late sync passes of one run next to
+        // the full passes of another, and staging, upload and kernels of neighbours overlap: 128 images per sub-batch, up to 32
+        // of them (256 files per call 8.6 -> 7.5 ms, 1,024: 21.1 -> 18.8 ms, 4,096: 68.7 -> 63.5 ms against 256 x 16)
+        const long dev_sub_env = getenv("JPGPU_PIPE_DEV_SUB") ? atol(getenv("JPGPU_PIPE_DEV_SUB")) : 0;  // tuning knob (read per call)
         uint32_t n_chunked = 0;
         for (uint32_t k = 0; k < n_dev; k++)
             if (!p->plans[ok[k]].empty() && p->plans[ok[k]][0].ri == 0) n_chunked++;
-        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_chunked * 2u >= n_dev ? 4u : 16u) * kSubBatchImages;
-        const uint32_t dev_subs = n_dev ? std::min<uint32_t>(kMaxSubBatches / 2u, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;
+        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_chunked * 2u >= n_dev ? 2u : 16u) * kSubBatchImages;
+        const long dev_cap_env = getenv("JPGPU_PIPE_MAX_DEV_SUBS") ? atol(getenv("JPGPU_PIPE_MAX_DEV_SUBS")) : 0;  // tuning knob (read per call)
+        const uint32_t dev_cap = dev_cap_env > 0 ? (uint32_t)std::min<long>(dev_cap_env, kMaxSubBatches / 2u) : kMaxSubBatches / 2u;
+        const uint32_t dev_subs = n_dev ? std::min<uint32_t>(dev_cap, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;
         for (uint32_t j = 1; j <= dev_subs; j++) bounds.push_back((uint32_t)((uint64_t)n_dev * j / dev_subs));
         n_dev_subs = dev_subs;
         const uint32_t n_host = (uint32_t)ok.size() - n_dev;
@@ -758,7 +765,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 }
                 handled++;
                 if (--sb.remaining == 0 && !hip_failed.load()) {  // sub-batch complete: kernels + download behind its uploads
-                    hipStream_t cs = p->compute[(uint32_t)p->sub_of[i] % kComputeStreams];
+                    hipStream_t cs = p->compute[(uint32_t)p->sub_of[i] % p->n_compute];
                     bool okk = true;
                     for (uint32_t c = 0; c < kCopyStreams && okk; c++)
                         okk = hipEventRecord(sb.ready[c], p->copy_streams[c]) == hipSuccess &&
@@ -799,7 +806,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             if (handled >= n_jobs && !pending_subs.empty() && !hip_failed.load()) {
                 for (uint32_t sj : pending_subs) {
                     SubBatch &sb = p->subs[sj];
-                    hipStream_t cs = p->compute[sj % kComputeStreams];
+                    hipStream_t cs = p->compute[sj % p->n_compute];
                     std::vector<uint32_t> &dv = dev_images[sj];
                     std::vector<uint32_t> st(dv.size(), 0);
                     const double s0 = now_ms();

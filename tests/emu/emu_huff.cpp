@@ -14,7 +14,67 @@ using jpgpu::host::Frontend;
 using jpgpu::host::PlannedScan;
 
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
+static uint32_t g_tail = 8;  // eighths of its chunk a lane walks in sync pass 0 (HuffSyncJob::pass0_skip)
+static uint32_t g_emit = 0;  // 1: speculative emission + expansion instead of the write pass (emu_huff_set_emit)
 static uint32_t g_range[2] = {0, 0};  // by-product of the last emu_huff_decode: largest |DC * q| / |AC * q| written (range_stats.hpp)
+
+// What huff_expand_kernel (csrc/huff.hip) does with the settled emission lists, one entry after the other: a block belongs to
+// the chunk it starts in; its entries may run on through the leading entries of the chunks that follow.  Every block below the
+// scan's total is written whole (the planes are NOT zero-filled on this path: the caller fills them with a pattern).
+static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
+    const uint32_t total = sj.n_mcu * sj.bpm;
+    for (uint32_t i = 0; i < sj.n_chunks; i++) {
+        const uint32_t cw = sj.emit_cnt[i], cnt = std::min(cw & 0xffffu, sj.emit_stride), lead = std::min(cw >> 16, cnt);
+        if (lead >= cnt) continue;
+        const uint32_t k_i = i ? sj.out_qk[i - 1] & 0xffu : 0u;
+        uint32_t blk = sj.n_blocks[i] + (k_i ? 1u : 0u);  // the first block that starts here
+        const uint32_t w0 = sj.uniform ? 0u : sj.dc_sum[2 * i], w1 = sj.uniform ? 0u : sj.dc_sum[2 * i + 1];
+        const uint32_t pred[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+        int16_t cur[64];
+        bool open = false;
+        auto flush = [&]() {
+            if (open && blk < total) {
+                const uint32_t m = blk / sj.bpm, q = blk - m * sj.bpm, my = m / sj.cols, mx = m - my * sj.cols;
+                const HuffScanComp& sc = sj.comp[sj.q_comp[q]];
+                const uint32_t sub = sj.q_sub[q], vp = sub / sc.h, hp = sub - vp * sc.h;
+                memcpy(sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u, cur, 128);
+            }
+            if (open) blk++;
+            open = false;
+        };
+        auto put = [&](uint32_t ent) {
+            const uint32_t c = sj.q_comp[blk % sj.bpm], z = (ent >> 16) & 63u;
+            uint32_t v = ent & 0xffffu;
+            if ((ent & HUFF_EMIT_DC) && !sj.uniform) v = (v + pred[c]) & 0xffffu;
+            cur[z] = (int16_t)(uint16_t)v;
+            const int32_t sv = (int16_t)(uint16_t)v;
+            const uint32_t a = (uint32_t)(sv < 0 ? -sv : sv) * sj.q[c][z];
+            if (blk < total) {
+                if (ent & HUFF_EMIT_DC) {
+                    if (!sj.uniform) rg.dc = std::max(rg.dc, a);
+                } else {
+                    rg.ac = std::max(rg.ac, a);
+                }
+            }
+        };
+        const uint32_t* buf = sj.emit + (size_t)i * sj.emit_stride;
+        for (uint32_t e = lead; e < cnt; e++) {
+            if (buf[e] & HUFF_EMIT_DC) {
+                flush();
+                memset(cur, 0, sizeof(cur));
+                open = true;
+            }
+            put(buf[e]);
+        }
+        for (uint32_t j = i + 1; open && j < sj.n_chunks; j++) {  // the rest of the last block
+            const uint32_t cj = sj.emit_cnt[j], cntj = std::min(cj & 0xffffu, sj.emit_stride), leadj = std::min(cj >> 16, cntj);
+            const uint32_t* bj = sj.emit + (size_t)j * sj.emit_stride;
+            for (uint32_t e = 0; e < leadj; e++) put(bj[e]);
+            if (leadj < cntj) break;
+        }
+        flush();
+    }
+}
 
 extern "C" {
 // huff_stage_segment / huff_sync_chunk_shift as the product uses them (host-side helpers of csrc/huff_job.hpp)
@@ -27,6 +87,8 @@ int emu_stage_segment_clean(uint8_t* dst, const uint8_t* src, uint32_t n) {
 }
 uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return huff_sync_chunk_shift(stuffed_bytes, total_blocks); }
 
+void emu_huff_set_emit(uint32_t on) { g_emit = on; }
+void emu_huff_set_tail(uint32_t eighths) { g_tail = eighths >= 1 && eighths <= 8 ? eighths : 8; }
 void emu_huff_last_range(uint32_t out[2]) { out[0] = g_range[0], out[1] = g_range[1]; }
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
     g_sync_stale = stale;
@@ -57,6 +119,27 @@ int emu_huff_plan(const uint8_t* data, size_t len, jpgpu_image_desc* desc, uint3
     *n_segments = 0;
     for (auto& s : scans) *n_segments += (uint32_t)(s.seg_off.size() / 2);
     return 0;
+}
+// 1: every scan is one without restart markers that writes all blocks of its planes (huff_scan_covers_planes: batch.cpp skips
+// the zero fill for such images when the sync passes emit)
+int emu_huff_covered(const uint8_t* data, size_t len) {
+    Frontend fe(data, len);
+    std::vector<PlannedScan> scans;
+    fe.read_info();
+    if (!fe.plan_device_scans(scans)) return -1;
+    for (const PlannedScan& ps : scans) {
+        if (ps.ri != 0) return 0;
+        HuffSyncJob sj;
+        memset(&sj, 0, sizeof(sj));
+        sj.cols = ps.cols, sj.n_mcu = ps.n_mcu, sj.ncomp = ps.ncomp;
+        uint32_t bh[4] = {0, 0, 0, 0};
+        for (uint32_t c = 0; c < ps.ncomp; c++) {
+            sj.comp[c].block_w = ps.comp[c].block_w, sj.comp[c].h = ps.comp[c].h, sj.comp[c].v = ps.comp[c].v;
+            bh[c] = fe.components()[ps.comp[c].frame_index].block_height;
+        }
+        if (!huff_scan_covers_planes(sj, bh)) return 0;
+    }
+    return 1;
 }
 int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint32_t* n_passes) {
     Frontend fe(data, len);
@@ -108,6 +191,15 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             huff_sync_finish_job(sj);
             sj.chunk_shift = huff_sync_chunk_shift(ps.seg_off[1] - ps.seg_off[0], sj.bpm * ps.n_mcu);
             sj.n_chunks = huff_sync_chunks(table[1], sj.chunk_shift);
+            sj.pass0_skip = ((1u << sj.chunk_shift) >> 3) * (8u - g_tail);
+            std::vector<uint32_t> emit_buf, emit_cnt;
+            if (g_emit) {
+                sj.emit_stride = huff_emit_stride(sj.chunk_shift);
+                emit_buf.assign((size_t)sj.n_chunks * sj.emit_stride + 1, 0xABABABABu);  // (+1: a canary behind the last buffer)
+                emit_cnt.assign(sj.n_chunks, 0xCDCDCDCDu);
+                sj.emit = emit_buf.data();
+                sj.emit_cnt = emit_cnt.data();
+            }
             std::vector<uint32_t> arr(7 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
             sj.in_pos = arr.data();
             sj.in_qk = arr.data() + sj.n_chunks;
@@ -163,6 +255,11 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 const uint32_t nb = sj.n_blocks[i];
                 sj.n_blocks[i] = run;
                 run += nb;
+                if (g_emit) status |= huff_emit_chunk_status(sj, i, run);
+            }
+            if (g_emit) {
+                status |= huff_emit_final_status(sj, run);
+                if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;  // a lane wrote past its buffer
             }
             if (!sj.uniform) {  // (huff_sync_scan_kernel) sums of DC differences -> predictors at the start of every chunk
                 uint32_t acc[4] = {0, 0, 0, 0};
@@ -174,7 +271,11 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     for (int f = 0; f < 4; f++) acc[f] += v[f];
                 }
             }
-            for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0, rg);
+            if (g_emit) {
+                if (status == 0) emu_expand(sj, rg);
+            } else {
+                for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0, rg);
+            }
             // (huff_dc_prefix_kernel, uniform scans only) DC differences -> values, per component in stream order (i16 wrapping)
             for (uint32_t c = 0; sj.uniform && c < ps.ncomp; c++) {
                 const HuffScanComp& sc = sj.comp[c];

@@ -31,12 +31,32 @@ def _device(data):
     ns, nseg = C.c_uint32(0), C.c_uint32(0)
     if L.emu_huff_plan(buf, len(data), C.byref(desc), C.byref(ns), C.byref(nseg)) != 0:
         return None
-    planes = [np.zeros(desc.components[c].block_width * desc.components[c].block_height * 64, np.int16) for c in range(desc.ncomp)]
+    # speculative emission (emission fixture): the expansion writes every block of the scan whole, so the planes of a stream with
+    # scans that cover their planes and have no restart markers may start as anything — a pattern here — where the write pass needs zeros
+    fill = 0x5A5A if (_device.emit and L.emu_huff_covered(buf, len(data)) == 1) else 0
+    planes = [np.full(desc.components[c].block_width * desc.components[c].block_height * 64, fill, np.int16) for c in range(desc.ncomp)]
     ptrs = (C.c_void_p * 4)(*([p.ctypes.data for p in planes] + [None] * (4 - len(planes))))
     npass = C.c_uint32(0)
     st = L.emu_huff_decode(buf, len(data), ptrs, C.byref(npass))
     _device.last_passes = npass.value
     return st, desc, planes, ns.value, nseg.value
+
+
+_device.emit = False
+
+
+@pytest.fixture(params=[(0, 8), (1, 8), (1, 3), (0, 2)], ids=["write-pass", "emission", "emission-tail3", "write-pass-tail2"])
+def emission(request):
+    """The chunk decoder's two ways to the arena: a write pass after the sync passes, or entries emitted by the sync passes
+    themselves and expanded into whole blocks (HuffSyncJob::emit); and how much of its chunk a lane walks in the first
+    sync pass (eighths: HuffSyncJob::pass0_skip)."""
+    emu.lib().emu_huff_set_emit(request.param[0])
+    emu.lib().emu_huff_set_tail(request.param[1])
+    _device.emit = bool(request.param[0])
+    yield request.param
+    emu.lib().emu_huff_set_emit(0)
+    emu.lib().emu_huff_set_tail(8)
+    _device.emit = False
 
 
 def _range_by_product():
@@ -153,7 +173,7 @@ def launch_shape(request):
 
 
 @pytest.mark.parametrize("rel", NO_RST)
-def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_shape):
+def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_shape, emission):
     """Baseline files as encoders write them by default (no DRI): chunked decoding with state hand-over until the
     segmentation settles, block numbering, write pass, DC accumulation — all device code, run on the CPU."""
     data = open(os.path.join(R.GOLDEN, rel), "rb").read()
@@ -171,7 +191,7 @@ def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_
 
 @pytest.mark.parametrize("case", [(64, 48, "4:2:0"), (250, 130, "4:2:0"), (129, 257, "4:2:2"), (200, 120, "4:4:4"), (300, 200, None),
                                   (1920, 1080, "4:2:0"), (1, 1, "4:2:0"), (17, 3000, "4:4:4")], ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}")
-def test_encoder_written_streams_without_restart_markers(case, launch_shape):
+def test_encoder_written_streams_without_restart_markers(case, launch_shape, emission):
     pytest.importorskip("PIL")
     import io
     from PIL import Image
@@ -190,7 +210,7 @@ def test_encoder_written_streams_without_restart_markers(case, launch_shape):
     assert _device.last_passes <= 8, _device.last_passes
 
 
-def test_damaged_restart_streams_never_disagree_silently():
+def test_damaged_restart_streams_never_disagree_silently(emission):
     """Mutations inside the entropy data of DRI streams: not eligible, or flagged, or identical to the host."""
     pytest.importorskip("PIL")
     seeds = [open(os.path.join(R.GOLDEN, "reftest/restarts.jpg"), "rb").read(), _pil_jpeg(96, 64, "4:2:0", 2, 0),
