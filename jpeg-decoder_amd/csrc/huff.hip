@@ -322,7 +322,17 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(cons
 // belongs to the chunk it STARTS in; the wave follows it through the leading entries of the chunks after.
 // All of a chunk's entries are requested before the first is used (up to EXP_LOADS x 64 per round): a wave that waits for
 // every 256 bytes in turn would leave the memory system idle.
-constexpr uint32_t EXP_WAVES = 4, EXP_CHUNKS = 4, EXP_SLOT = 68, EXP_SLOTS = 66, EXP_LOADS = 8;
+#ifndef JPGPU_EXP_THR  // A/B builds: complete blocks waiting in the ring before a store round (8: full rounds only; 1: right away)
+#define JPGPU_EXP_THR 8
+#endif
+#ifndef JPGPU_EXP_CHUNKS
+#define JPGPU_EXP_CHUNKS 8
+#endif
+#ifndef JPGPU_EXP_LOADS
+#define JPGPU_EXP_LOADS 16
+#endif
+constexpr uint32_t EXP_WAVES = 4, EXP_CHUNKS = JPGPU_EXP_CHUNKS, EXP_SLOT = 68, EXP_THR = JPGPU_EXP_THR, EXP_LOADS = JPGPU_EXP_LOADS;
+constexpr uint32_t EXP_SLOTS = EXP_THR + 65u;  // complete blocks that may wait + 1 open + 64 new
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 struct ExpandLds {
     HuffSyncJob job;
@@ -334,16 +344,16 @@ struct ExpandLds {
 static_assert(sizeof(HuffSyncJob) % 4 == 0, "copied by dwords");
 
 // Block numbers -> MCU coordinates without a division per block: the wave knows where block S, the first one that starts in
-// its chunk, lies (real divisions, once per chunk), every other block is S + d with d < 2^16, and n / x for small n is a
-// multiplication by 2^32 / x + 1 (exact while n * x < 2^32).
+// its chunk, lies (real divisions, once per chunk), every other block is S + d with d < 2^16, and n / x for small n is the
+// high half of n * (2^32 / x + 1) (exact while n * x < 2^32; x = 1 has no such factor in 32 bits and is tested for).
 struct ExpandAt {
-    uint64_t inv_bpm, inv_cols;
+    uint32_t inv_bpm, inv_cols;
     uint32_t bpm, cols, q0, mx0, my0;  // block S = block q0 of MCU (mx0, my0)
 };
-__device__ __forceinline__ uint32_t small_div(uint32_t n, uint64_t inv) { return (uint32_t)(((uint64_t)n * inv) >> 32); }
+__device__ __forceinline__ uint32_t small_div(uint32_t n, uint32_t x, uint32_t inv) { return x == 1u ? n : __umulhi(n, inv); }
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// slots [0, n) of the wave's ring hold blocks S + d0 .. S + d0 + n - 1: written out and cleared, eight lanes per block
+// slots [s_first, s_first + n) of the wave's ring hold blocks S + d0 .. S + d0 + n - 1: written out and cleared, eight lanes per block
 __device__ __forceinline__ void expand_store_blocks(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, const ExpandAt &at, uint32_t S, uint32_t d0, uint32_t n,
                                                     uint32_t total) {
     const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, grp = lane >> 3;
@@ -355,8 +365,8 @@ __device__ __forceinline__ void expand_store_blocks(JP_LDS ExpandLds &E, JP_LDS 
             row[0] = v2u{0u, 0u};
             row[1] = v2u{0u, 0u};
             if (S + d0 + s < total) {
-                const uint32_t t = at.q0 + d0 + s, dm = small_div(t, at.inv_bpm), q = (t - dm * at.bpm) & 15u;
-                const uint32_t x = at.mx0 + dm, dy = small_div(x, at.inv_cols), mx = x - dy * at.cols, my = at.my0 + dy;
+                const uint32_t t = at.q0 + d0 + s, dm = small_div(t, at.bpm, at.inv_bpm), q = (t - dm * at.bpm) & 15u;
+                const uint32_t x = at.mx0 + dm, dy = small_div(x, at.cols, at.inv_cols), mx = x - dy * at.cols, my = at.my0 + dy;
                 const uint64_t dst = E.q_dst[q].base + (uint64_t)my * E.q_dst[q].row_stride + (uint64_t)mx * E.q_dst[q].mcu_stride;
                 ((JP_GLOBAL v4u *)(uintptr_t)dst)[sub] = v4u{a.x, a.y, b.x, b.y};
             }
@@ -364,12 +374,19 @@ __device__ __forceinline__ void expand_store_blocks(JP_LDS ExpandLds &E, JP_LDS 
     }
 }
 
-// one entry of block S + d into image `slot` of the ring; returns |value * quantization value| (0 for lanes without an entry)
+// one entry of block S + d into image `slot` of the ring; returns |value * quantization value| (0 for lanes without an entry).
+// UNIFORM: the entry does not say which component its block belongs to (the lane that wrote it could not know)
+template <bool UNIFORM>
 __device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, const ExpandAt &at, bool valid, uint32_t ent, uint32_t d, uint32_t slot,
                                                uint32_t w0, uint32_t w1) {
-    const uint32_t t = at.q0 + d, c = E.job.q_comp[(t - small_div(t, at.inv_bpm) * at.bpm) & 15u] & 3u, z = (ent >> 16) & 63u;
+    uint32_t c = (ent >> 22) & 3u;
+    if (UNIFORM) {
+        const uint32_t t = at.q0 + d;
+        c = E.job.q_comp[(t - small_div(t, at.bpm, at.inv_bpm) * at.bpm) & 15u] & 3u;
+    }
+    const uint32_t z = (ent >> 16) & 63u;
     uint32_t v = ent & 0xffffu;
-    if (ent & HUFF_EMIT_DC) {  // the chunk's running sum + what the chunks before it add up to (zeros in a `uniform` scan)
+    if (!UNIFORM && (ent & HUFF_EMIT_DC)) {  // the chunk's running sum + what the chunks before it add up to
         const uint32_t w = c < 2u ? w0 : w1;
         v = (v + ((c & 1u) ? w >> 16 : w)) & 0xffffu;
     }
@@ -377,6 +394,79 @@ __device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint1
     ring[slot * EXP_SLOT + z] = (uint16_t)v;
     const int32_t sv = (int16_t)(uint16_t)v;
     return (uint32_t)(sv < 0 ? -sv : sv) * E.job.q[c][z];
+}
+
+// One chunk of the scan -> its blocks in the arena.  Complete blocks wait in the ring until eight of them can go out together
+// (eight lanes per block: a store instruction for fewer leaves lanes idle, and the kernel is bound by instruction issue).
+template <bool UNIFORM>
+__device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, ExpandAt &at, uint32_t i, uint32_t n_chunks, uint32_t total, uint32_t stride,
+                                             uint32_t &rg_dc, uint32_t &rg_ac) {
+    const JP_LDS HuffSyncJob &job = E.job;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t cw = rfl(job.emit_cnt[i]), cnt = min(cw & 0xffffu, stride), lead = min(cw >> 16, cnt);
+    if (lead >= cnt) return;  // no block starts in this chunk
+    const uint32_t k_i = i ? rfl(job.out_qk[i - 1u]) & 0xffu : 0u;
+    const uint32_t S = rfl(job.n_blocks[i]) + (k_i ? 1u : 0u);  // number of the first block that starts here
+    if (S >= total) return;  // (what a stream holds after its last block)
+    {
+        const uint32_t m = S / at.bpm;
+        at.q0 = S - m * at.bpm;
+        at.my0 = m / at.cols;
+        at.mx0 = m - at.my0 * at.cols;
+    }
+    const uint32_t w0 = UNIFORM ? 0u : rfl(job.dc_sum[2u * i]), w1 = UNIFORM ? 0u : rfl(job.dc_sum[2u * i + 1u]);
+    const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
+    uint32_t started = 0, base = 0;  // blocks started so far; which of them sits in slot 0
+    for (uint32_t e0 = lead; e0 < cnt; e0 += 64u * EXP_LOADS) {
+        uint32_t ent[EXP_LOADS];
+#pragma unroll
+        for (uint32_t r = 0; r < EXP_LOADS; r++) {
+            const uint32_t e = e0 + 64u * r + lane;
+            ent[r] = e < cnt ? stream_load(buf + e) : 0u;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < EXP_LOADS; r++) {
+            if (e0 + 64u * r >= cnt) break;
+            const bool valid = e0 + 64u * r + lane < cnt, flag = valid && (ent[r] & HUFF_EMIT_DC) != 0u;
+            const uint64_t m = __ballot(flag);
+            const uint32_t local = started + (uint32_t)__popcll(m & lt) + (flag ? 1u : 0u) - 1u;  // the entry's block, counted from S
+            const uint32_t a = expand_put<UNIFORM>(E, ring, at, valid, ent[r], local, local - base, w0, w1);
+            if (S + local < total) {
+                if (flag) rg_dc = UNIFORM ? rg_dc : max(rg_dc, a);  // (uniform scans: huff_dc_prefix_kernel ranges the finished values)
+                else rg_ac = max(rg_ac, a);
+            }
+            started += (uint32_t)__popcll(m);
+            const uint32_t pending = started ? started - 1u - base : 0u;  // every block but the last one started is complete
+            if (pending >= EXP_THR) {
+                const uint32_t out = EXP_THR >= 8u ? pending & ~7u : pending, keep = pending - out + 1u;  // the rest, and the open block, move to the front
+                __builtin_amdgcn_wave_barrier();
+                expand_store_blocks(E, ring, at, S, base, out, total);
+                if ((lane >> 3) < keep) {
+                    JP_LDS v2u *from = (JP_LDS v2u *)(ring + (out + (lane >> 3)) * EXP_SLOT + (lane & 7u) * 8u), *to = (JP_LDS v2u *)(ring + lane * 8u + (lane >> 3) * (EXP_SLOT - 64u));
+                    const v2u x = from[0], y = from[1];
+                    from[0] = v2u{0u, 0u};
+                    from[1] = v2u{0u, 0u};
+                    to[0] = x;
+                    to[1] = y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                base += out;
+            }
+        }
+    }
+    if (!started) return;
+    // the last block: its remaining entries lead the lists of the chunks that follow
+    const uint32_t last = started - 1u;  // (counted from S)
+    for (uint32_t j = i + 1u; S + last < total && j < n_chunks; j++) {
+        const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj);
+        const JP_GLOBAL uint32_t *bj = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)j * stride);
+        for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put<UNIFORM>(E, ring, at, true, stream_load(bj + e) & ~HUFF_EMIT_DC, last, last - base, 0u, 0u));
+        if (leadj < cntj) break;  // a block starts in chunk j: ours ended there
+    }
+    __builtin_amdgcn_wave_barrier();
+    expand_store_blocks(E, ring, at, S, base, started - base, total);
+    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffSyncJob *__restrict__ jobs) {
@@ -403,72 +493,15 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
     ExpandAt at;
     at.bpm = bpm;
     at.cols = cols;
-    at.inv_bpm = (1ull << 32) / bpm + 1ull;
-    at.inv_cols = (1ull << 32) / cols + 1ull;
-    const uint64_t lt = (1ull << lane) - 1ull;
+    at.inv_bpm = bpm > 1u ? 0xffffffffu / bpm + 1u : 0u;
+    at.inv_cols = cols > 1u ? 0xffffffffu / cols + 1u : 0u;
+    at.q0 = at.mx0 = at.my0 = 0u;
     uint32_t rg_dc = 0, rg_ac = 0;
     for (uint32_t ci = 0; ci < EXP_CHUNKS; ci++) {
         const uint32_t i = first_chunk + wave * EXP_CHUNKS + ci;
         if (i >= n_chunks) break;
-        const uint32_t cw = rfl(job.emit_cnt[i]), cnt = min(cw & 0xffffu, stride), lead = min(cw >> 16, cnt);
-        if (lead >= cnt) continue;  // no block starts in this chunk
-        const uint32_t k_i = i ? rfl(job.out_qk[i - 1u]) & 0xffu : 0u;
-        const uint32_t S = rfl(job.n_blocks[i]) + (k_i ? 1u : 0u);  // number of the first block that starts here
-        if (S >= total) continue;  // (what a stream holds after its last block)
-        {
-            const uint32_t m = S / bpm;
-            at.q0 = S - m * bpm;
-            at.my0 = m / cols;
-            at.mx0 = m - at.my0 * cols;
-        }
-        const uint32_t w0 = uniform ? 0u : rfl(job.dc_sum[2u * i]), w1 = uniform ? 0u : rfl(job.dc_sum[2u * i + 1u]);
-        const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
-        uint32_t started = 0, base = 0;  // blocks started so far; which of them sits in slot 0 (the open one, once there is one)
-        for (uint32_t e0 = lead; e0 < cnt; e0 += 64u * EXP_LOADS) {
-            uint32_t ent[EXP_LOADS];
-#pragma unroll
-            for (uint32_t r = 0; r < EXP_LOADS; r++) {
-                const uint32_t e = e0 + 64u * r + lane;
-                ent[r] = e < cnt ? stream_load(buf + e) : 0u;
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < EXP_LOADS; r++) {
-                if (e0 + 64u * r >= cnt) break;
-                const bool valid = e0 + 64u * r + lane < cnt, flag = valid && (ent[r] & HUFF_EMIT_DC) != 0u;
-                const uint64_t m = __ballot(flag);
-                const uint32_t local = started + (uint32_t)__popcll(m & lt) + (flag ? 1u : 0u) - 1u;  // the entry's block, counted from S
-                const uint32_t a = expand_put(E, ring, at, valid, ent[r], local, local - base, w0, w1);
-                if (S + local < total) {
-                    if (flag) rg_dc = uniform ? rg_dc : max(rg_dc, a);  // (uniform scans: huff_dc_prefix_kernel ranges the finished values)
-                    else rg_ac = max(rg_ac, a);
-                }
-                started += (uint32_t)__popcll(m);
-                const uint32_t done = started ? started - 1u - base : 0u;  // every block but the last one started is complete
-                __builtin_amdgcn_wave_barrier();
-                expand_store_blocks(E, ring, at, S, base, done, total);
-                if (done && lane < 8u) {  // the open block moves to slot 0
-                    JP_LDS v2u *from = (JP_LDS v2u *)(ring + done * EXP_SLOT + lane * 8u), *to = (JP_LDS v2u *)(ring + lane * 8u);
-                    const v2u x = from[0], y = from[1];
-                    from[0] = v2u{0u, 0u};
-                    from[1] = v2u{0u, 0u};
-                    to[0] = x;
-                    to[1] = y;
-                }
-                __builtin_amdgcn_wave_barrier();
-                base += done;
-            }
-        }
-        // the last block: its remaining entries lead the lists of the chunks that follow
-        const uint32_t last = started ? started - 1u : total;  // (counted from S)
-        for (uint32_t j = i + 1u; S + last < total && j < n_chunks; j++) {
-            const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj);
-            const JP_GLOBAL uint32_t *bj = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)j * stride);
-            for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put(E, ring, at, true, stream_load(bj + e) & ~HUFF_EMIT_DC, last, 0u, 0u, 0u));
-            if (leadj < cntj) break;  // a block starts in chunk j: ours ended there
-        }
-        __builtin_amdgcn_wave_barrier();
-        expand_store_blocks(E, ring, at, S, last, started ? 1u : 0u, total);
-        __builtin_amdgcn_wave_barrier();
+        if (uniform) expand_chunk<true>(E, ring, at, i, n_chunks, total, stride, rg_dc, rg_ac);
+        else expand_chunk<false>(E, ring, at, i, n_chunks, total, stride, rg_dc, rg_ac);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

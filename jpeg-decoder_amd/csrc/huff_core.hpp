@@ -47,7 +47,9 @@ struct DevBits {
     uint64_t bits;   // unread bits, left-aligned
     uint32_t nbits;
     uint32_t wpos;   // dwords taken from the slot so far
-    const v4u *g;    // the slot (16-byte aligned, zero padded: huff_stage_segment)
+    const JP_GLOBAL v4u *g;  // the slot (16-byte aligned, zero padded: huff_stage_segment).  An address-space-1 pointer: through a generic
+                             // one the fetches are flat_load instructions, which count as LDS operations too — every wait for an LDS
+                             // read behind one (and the loop is full of them) then waits for the stream fetch as well
     v4u cur, nxt;    // HUFF_READ_16: 16-byte piece wpos / 4 and the one after it
     uint32_t ahead;  // HUFF_READ_DW: dword wpos
     JP_LDS uint32_t *ring;  // HUFF_READ_RING: this lane's column of the ring (dword d of the stream at ring[(d % 32) * ring_stride])
@@ -93,7 +95,7 @@ __device__ __forceinline__ void huff_refill(DevBits &b) {
 #ifndef JPGPU_HOST_EMULATION
             asm volatile("" : "+v"(b.bits) : : "memory");  // the old `ahead` is dead from here on
 #endif
-            b.ahead = reinterpret_cast<const uint32_t *>(b.g)[b.wpos];
+            b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
         } else {
             const uint32_t w = b.wpos & 3u;
             const uint32_t x = w == 0u ? b.cur.x : (w == 1u ? b.cur.y : (w == 2u ? b.cur.z : b.cur.w));

@@ -83,7 +83,7 @@ __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32
 
 template <int RD>
 __device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
-    b.g = reinterpret_cast<const v4u *>(slot);
+    b.g = (const JP_GLOBAL v4u *)(uintptr_t)slot;
     b.wpos = bit_pos >> 5;
     if (RD == HUFF_READ_RING) {
         b.ring = ring;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, ui
         huff_ring_topup(b);  // (twice: up to 7 pieces until HUFF_RING_AHEAD dwords lie ahead of a reader that starts mid-piece)
         huff_ring_topup(b);
     } else if (RD == HUFF_READ_DW) {
-        b.ahead = reinterpret_cast<const uint32_t *>(slot)[b.wpos];
+        b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
     } else {
         b.cur = b.g[b.wpos >> 2];
         b.nxt = b.g[(b.wpos >> 2) + 1u];
@@ -175,7 +175,8 @@ struct HuffRange {
 // Speculative emission of a sync pass (HuffSyncJob::emit): the lane's chunk buffer and what it has put there.  An entry per DC
 // value (always, zero or not: it marks the start of a block; the value is the running sum of the chunk's differences for its
 // component — the chunk's predictor is added by the expansion — or the difference itself in a `uniform` scan) and per
-// non-zero AC coefficient, in stream order.
+// non-zero AC coefficient, in stream order.  Bits 22-23: the component of the scan the block belongs to — as far as the lane knows
+// it: in a `uniform` scan it does not (the expansion derives it from the block number there).
 #ifndef JPGPU_EMIT_MODE  // A/B builds: 0 one 4-byte store per entry; 1 no stores at all (what the bookkeeping alone costs: wrong
 #define JPGPU_EMIT_MODE 2  //  output); 2 four entries gathered in registers, one 16-byte store; 3 = 0 with the stream read through the LDS ring
 #endif
@@ -311,12 +312,12 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
                 if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * (zq[0] >> 16));
                 if (!WRITE && BY_BITS && em && em->buf) {
                     if (em->lead == 0xffffffffu) em->lead = em->n;
-                    huff_emit_entry(*em, HUFF_EMIT_DC | (uint32_t)(uint16_t)val);
+                    huff_emit_entry(*em, HUFF_EMIT_DC | (c << 22) | (uint32_t)(uint16_t)val);
                 }
             } else if (!WRITE && BY_BITS && (info & SYM_COEF)) {
                 if (em && em->buf) {
                     const uint32_t z = L.unzig[k - 1u];
-                    huff_emit_entry(*em, (z << 16) | (uint32_t)(uint16_t)huff_extend(raw, nread));
+                    huff_emit_entry(*em, (z << 16) | (c << 22) | (uint32_t)(uint16_t)huff_extend(raw, nread));
                 }
             } else if (WRITE && (info & SYM_COEF)) {
                 const uint32_t e = zq[k - 1u], z = e & 0xffffu;

@@ -15,6 +15,7 @@ using jpgpu::host::PlannedScan;
 
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
 static uint32_t g_tail = 8;  // eighths of its chunk a lane walks in sync pass 0 (HuffSyncJob::pass0_skip)
+static uint32_t g_emit_mismatch = 0;
 static uint32_t g_emit = 0;  // 1: speculative emission + expansion instead of the write pass (emu_huff_set_emit)
 static uint32_t g_range[2] = {0, 0};  // by-product of the last emu_huff_decode: largest |DC * q| / |AC * q| written (range_stats.hpp)
 
@@ -44,6 +45,7 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
         };
         auto put = [&](uint32_t ent) {
             const uint32_t c = sj.q_comp[blk % sj.bpm], z = (ent >> 16) & 63u;
+            if (!sj.uniform && c != ((ent >> 22) & 3u)) g_emit_mismatch++;  // (the component the lane wrote into the entry)
             uint32_t v = ent & 0xffffu;
             if ((ent & HUFF_EMIT_DC) && !sj.uniform) v = (v + pred[c]) & 0xffffu;
             cur[z] = (int16_t)(uint16_t)v;
@@ -272,7 +274,11 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 }
             }
             if (g_emit) {
-                if (status == 0) emu_expand(sj, rg);
+                if (status == 0) {
+                    g_emit_mismatch = 0;
+                    emu_expand(sj, rg);
+                    if (g_emit_mismatch) status |= 0x4000u;  // entries that name another component than the block numbering does
+                }
             } else {
                 for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0, rg);
             }
