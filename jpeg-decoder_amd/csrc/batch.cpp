@@ -725,11 +725,16 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     static const uint32_t sync_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
-    size_t n_scans = 0, n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
+    size_t n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
+    // Files of one encoder repeat the same Huffman tables (27 kB per scan in device form): a scan whose tables equal those of
+    // the scan before it shares that copy — one in the staging block, one upload, one set of lines in the L2.
+    const DevHuffTable *prev_tables = nullptr;
+    size_t n_table_sets = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
         for (const host::PlannedScan &ps : *images[k].scans) {
-            n_scans++;
+            if (!prev_tables || memcmp(prev_tables, ps.tables, sizeof(ps.tables)) != 0) n_table_sets++;
+            prev_tables = ps.tables;
             seg_words += ps.seg_off.size();
             size_t stuffed = 0;
             for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
@@ -753,7 +758,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const size_t off_status = 0, off_cnt = align_up(off_status + (size_t)n * 4, 16);
     const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = align_up(off_jobs + n_seg_jobs * sizeof(HuffSyncJob), 16);
     const size_t off_tables = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
-    const size_t off_seg = align_up(off_tables + n_scans * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
+    const size_t off_seg = align_up(off_tables + n_table_sets * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
     const size_t off_scratch = align_up(total, 256), total_dev = off_scratch + scratch_bytes;
     if (total_dev > b->entropy_cap) {
@@ -783,7 +788,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     memset(h, 0, off_jobs);  // status words and settle counters start at zero
     HuffSyncJob *jobs = reinterpret_cast<HuffSyncJob *>(h + off_jobs);
     HuffSyncJob *sjobs = reinterpret_cast<HuffSyncJob *>(h + off_sjobs);
-    size_t ji = 0, si = 0, tcur = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
+    size_t ji = 0, si = 0, tcur = off_tables, tnext = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
+    prev_tables = nullptr;
     uint32_t max_seg = 0, max_chunks = 0;
     std::vector<uint32_t> stat_images;  // listed images, for the fills that zero their statistics
     struct CopyTask {
@@ -818,7 +824,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
                 stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
             }
-            memcpy(h + tcur, ps.tables, sizeof(ps.tables));
+            if (!prev_tables || memcmp(prev_tables, ps.tables, sizeof(ps.tables)) != 0) {
+                tcur = tnext;
+                tnext += 8 * sizeof(DevHuffTable);
+                memcpy(h + tcur, ps.tables, sizeof(ps.tables));
+            }
+            prev_tables = ps.tables;
             HuffScanComp comp[4];
             memset(comp, 0, sizeof(comp));
             uint16_t scan_q[4][64];
@@ -892,7 +903,6 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             }
             dcur += scan_bytes;
             scur += ps.seg_off.size() * 4;
-            tcur += 8 * sizeof(DevHuffTable);
         }
         if (needs_zeros)
             zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
