@@ -728,13 +728,14 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     size_t n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     // Files of one encoder repeat the same Huffman tables (27 kB per scan in device form): a scan whose tables equal those of
     // the scan before it shares that copy — one in the staging block, one upload, one set of lines in the L2.
-    const DevHuffTable *prev_tables = nullptr;
+    const host::PlannedScan::TableSet *prev_tables = nullptr;
     size_t n_table_sets = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
         for (const host::PlannedScan &ps : *images[k].scans) {
-            if (!prev_tables || memcmp(prev_tables, ps.tables, sizeof(ps.tables)) != 0) n_table_sets++;
-            prev_tables = ps.tables;
+            if (!ps.tables) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: scan without tables");
+            if (!prev_tables || (prev_tables != ps.tables.get() && memcmp(prev_tables, ps.tables.get(), sizeof(*prev_tables)) != 0)) n_table_sets++;
+            prev_tables = ps.tables.get();
             seg_words += ps.seg_off.size();
             size_t stuffed = 0;
             for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
@@ -824,12 +825,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
                 stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
             }
-            if (!prev_tables || memcmp(prev_tables, ps.tables, sizeof(ps.tables)) != 0) {
+            if (!prev_tables || (prev_tables != ps.tables.get() && memcmp(prev_tables, ps.tables.get(), sizeof(*prev_tables)) != 0)) {
                 tcur = tnext;
                 tnext += 8 * sizeof(DevHuffTable);
-                memcpy(h + tcur, ps.tables, sizeof(ps.tables));
+                memcpy(h + tcur, ps.tables->t, sizeof(ps.tables->t));
             }
-            prev_tables = ps.tables;
+            prev_tables = ps.tables.get();
             HuffScanComp comp[4];
             memset(comp, 0, sizeof(comp));
             uint16_t scan_q[4][64];

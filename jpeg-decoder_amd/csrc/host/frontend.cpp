@@ -669,7 +669,12 @@ struct Frontend::Impl {
 
     void parse_dht() {  // src/parser.rs:536-589, merge of src/decoder.rs:501-518
         size_t length = read_length();
-        std::unique_ptr<HuffTable[]> ndc(new HuffTable[4]), nac(new HuffTable[4]);
+        // (per thread, not per call: two 23 kB heap blocks per DHT segment, allocated and freed by every pool thread at once, had the
+        // threads queue up inside the allocator)
+        thread_local std::unique_ptr<HuffTable[]> tl_dc, tl_ac;
+        if (!tl_dc) tl_dc.reset(new HuffTable[4]), tl_ac.reset(new HuffTable[4]);
+        HuffTable *ndc = tl_dc.get(), *nac = tl_ac.get();
+        for (int i = 0; i < 4; i++) ndc[i].present = nac[i].present = false;
         while (length > 17) {
             const uint8_t tc = src.u8(), cls = tc >> 4;
             const size_t index = tc & 15;
@@ -925,46 +930,48 @@ struct Frontend::Impl {
             ps.comp[i].dc = (uint32_t)scan.dc_tables[i];
             ps.comp[i].ac = (uint32_t)scan.ac_tables[i];
         }
-        for (int t = 0; t < 8; t++) {
-            const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
-            DevHuffTable &d = ps.tables[t];
-            memset(&d, 0, sizeof(d));
-            if (!h.present) continue;
-            static_assert(HUFF_LUT_BITS >= 8 && HUFF_LUT_BITS <= kLutBits && sizeof(d.values) == sizeof(h.values), "table layouts");
-            // (like the host tables: the device form of the tables this thread met last is kept, keyed by their definition)
-            constexpr int kSlots = 8;
-            struct DevEntry {
-                HuffTable key;  // only bits / values / nvalues / is_ac / present are filled in
-                DevHuffTable dev;
+        {
+            // The device form of the eight tables: the set this thread built last is kept with the definitions it came from
+            // (code counts, values, class: everything else in a table is a function of them) and handed out again as it is.
+            struct Last {
+                HuffTable key[8];  // only present / is_ac / nvalues / bits / values are filled in
+                std::shared_ptr<const PlannedScan::TableSet> set;
             };
-            thread_local std::unique_ptr<DevEntry[]> cache;
-            thread_local int next = 0;
-            if (!cache) cache.reset(new DevEntry[kSlots]);
-            bool hit = false;
-            for (int i = 0; i < kSlots && !hit; i++)
-                if (same_definition(cache[i].key, h.bits, h.values, h.nvalues, h.is_ac)) {
-                    d = cache[i].dev;
-                    hit = true;
-                }
-            if (hit) continue;
-            // the device table is the host's wide table cut to HUFF_LUT_BITS: a code that fits has the same entry under every
-            // longer prefix; one that does not is left to the walk (which starts at 9 bits like the reference's, src/huffman.rs:31-58)
-            for (int i = 0; i < (1 << HUFF_LUT_BITS); i++) {
-                const int w = i << (kLutBits - HUFF_LUT_BITS);
-                d.lut[i] = h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS ? (uint16_t)(h.lut_value[w] | (h.lut_size[w] << 8)) : (uint16_t)0;
+            thread_local std::unique_ptr<Last> last;
+            if (!last) last.reset(new Last);
+            bool same = last->set != nullptr;
+            for (int t = 0; t < 8 && same; t++) {
+                const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
+                same = h.present ? same_definition(last->key[t], h.bits, h.values, h.nvalues, h.is_ac) : !last->key[t].present;
             }
-            memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode));
-            memcpy(d.delta, h.delta, sizeof(d.delta));
-            memcpy(d.values, h.values, sizeof(d.values));
-            d.nvalues = h.nvalues;
-            DevEntry &e = cache[next];
-            next = (next + 1) % kSlots;
-            e.key.present = true;
-            e.key.is_ac = h.is_ac;
-            e.key.nvalues = h.nvalues;
-            memcpy(e.key.bits, h.bits, 16);
-            memcpy(e.key.values, h.values, sizeof(h.values));
-            e.dev = d;
+            if (!same) {
+                auto set = std::make_shared<PlannedScan::TableSet>();
+                memset(set.get(), 0, sizeof(*set));
+                for (int t = 0; t < 8; t++) {
+                    const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
+                    DevHuffTable &d = set->t[t];
+                    HuffTable &k = last->key[t];
+                    k.present = h.present;
+                    if (!h.present) continue;
+                    static_assert(HUFF_LUT_BITS >= 8 && HUFF_LUT_BITS <= kLutBits && sizeof(d.values) == sizeof(h.values), "table layouts");
+                    // the device table is the host's wide table cut to HUFF_LUT_BITS: a code that fits has the same entry under every
+                    // longer prefix; one that does not is left to the walk (which starts at 9 bits like the reference's, src/huffman.rs:31-58)
+                    for (int i = 0; i < (1 << HUFF_LUT_BITS); i++) {
+                        const int w = i << (kLutBits - HUFF_LUT_BITS);
+                        d.lut[i] = h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS ? (uint16_t)(h.lut_value[w] | (h.lut_size[w] << 8)) : (uint16_t)0;
+                    }
+                    memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode));
+                    memcpy(d.delta, h.delta, sizeof(d.delta));
+                    memcpy(d.values, h.values, sizeof(d.values));
+                    d.nvalues = h.nvalues;
+                    k.is_ac = h.is_ac;
+                    k.nvalues = h.nvalues;
+                    memcpy(k.bits, h.bits, 16);
+                    memcpy(k.values, h.values, sizeof(h.values));
+                }
+                last->set = std::move(set);
+            }
+            ps.tables = last->set;
         }
         // cut the entropy-coded data at the RSTn markers: exactly one every `ri` MCUs, numbered 0..7 cyclically
         // (src/decoder.rs:920-956), 0xFF00 pairs inside, one other marker right after the last segment

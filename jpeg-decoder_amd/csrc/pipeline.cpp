@@ -299,6 +299,7 @@ struct jpgpu_pipeline {
     // results of the last call
     uint32_t n = 0;
     std::vector<std::unique_ptr<Frontend>> fes;
+    std::vector<uint8_t> has_frame;  // per image: a frame header was parsed (jpgpu_pipeline_image_info)
     std::vector<int> status;
     std::vector<std::string> errors;
     std::vector<jpgpu_image_info> infos;
@@ -478,6 +479,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->n = n;
     p->fes.clear();
     p->fes.resize(n);
+    p->has_frame.assign(n, 0);
     p->status.assign(n, JPGPU_ERR_INTERNAL);
     p->errors.assign(n, std::string());
     p->infos.assign(n, jpgpu_image_info{});
@@ -531,16 +533,22 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             if (device_entropy) {  // eligible for the device entropy decoder?  (the planning pass spends the object)
                 if (fe.plan_device_scans(p->plans[i])) {
                     for (uint32_t c = 0; c < d.ncomp; c++) memcpy(cand[i].quantization_tables[c], fe.qtable_of_component(c), 128);
+                    // The plan holds all the device route needs: the front-end (45 kB of table space) goes back to the allocator of
+                    // this thread right away — 4,096 of them alive until the next call were 180 MB of fresh pages per call.
+                    p->has_frame[i] = 1;
+                    p->fes[i].reset();
                 } else {
                     p->plans[i].clear();
                     p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
                     p->fes[i]->read_info();
                 }
             }
+            if (p->fes[i]) p->has_frame[i] = p->fes[i]->has_frame() ? 1 : 0;
             p->status[i] = JPGPU_OK;
         } catch (const DecodeError &e) {
             p->status[i] = e.code;
             p->errors[i] = e.message;
+            if (p->fes[i]) p->has_frame[i] = p->fes[i]->has_frame() ? 1 : 0;
         } catch (const std::exception &e) {
             p->status[i] = JPGPU_ERR_INTERNAL;
             p->errors[i] = e.what();
@@ -851,9 +859,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         if (p->status[i] != JPGPU_OK) return;
         SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
         const uint32_t bi = (uint32_t)p->slot[i];
-        Frontend &fe0 = *p->fes[i];  // (re-created below if the device planner spends it)
         size_t off[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
-        const uint32_t nc = fe0.ncomp();
+        const uint32_t nc = cand[i].ncomp;  // (images planned for the device have no front-end any more)
         for (uint32_t c = 0; c < nc; c++) {
             off[c] = sb.compact ? sb.stage_off[(size_t)bi * 4 + c] : jpgpu_batch_coef_offset(sb.batch, bi, c);
             ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
@@ -974,7 +981,7 @@ static const SubBatch *sub_of(const jpgpu_pipeline *p, uint32_t i) {
 int jpgpu_pipeline_image_status(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->status[i] : JPGPU_ERR_FORMAT; }
 const char *jpgpu_pipeline_image_error(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->errors[i].c_str() : ""; }
 int jpgpu_pipeline_image_info(const jpgpu_pipeline *p, uint32_t i, jpgpu_image_info *info) {
-    if (!p || i >= p->n || !info || !p->fes[i] || !p->fes[i]->has_frame()) return JPGPU_ERR_FORMAT;
+    if (!p || i >= p->n || !info || i >= p->has_frame.size() || !p->has_frame[i]) return JPGPU_ERR_FORMAT;
     *info = p->infos[i];
     return JPGPU_OK;
 }

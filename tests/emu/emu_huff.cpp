@@ -174,7 +174,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             memset(&sj, 0, sizeof(sj));
             uint32_t changed = 0;
             sj.data = stage;
-            sj.tables = ps.tables;
+            sj.tables = ps.tables->t;
             sj.status = &status;
             sj.changed = &changed;
             sj.n_bits = table[1] * 8u;
@@ -217,7 +217,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     sj.in_qk[i] = sj.out_qk[i ? i - 1 : 0];
                     sj.n_blocks[i] = i % 9u;
                 }
-            memcpy(S->tables, ps.tables, sizeof(S->tables));
+            memcpy(S->tables, ps.tables->t, sizeof(S->tables));
             for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(S->unzig, t);
             for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*S, t);
             // Launches as huff.hip runs them: workgroups of 256 lanes, `iters` iterations each with a barrier in between.
@@ -305,7 +305,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
         memset(&job, 0, sizeof(job));
         job.data = stage;
         job.seg_off = table.data();
-        job.tables = ps.tables;
+        job.tables = ps.tables->t;
         job.status = &status;
         job.n_seg = (uint32_t)(ps.seg_off.size() / 2);
         job.ri = ps.ri;
@@ -322,7 +322,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             memcpy(job.q[c], fe.qtable_of_component(ps.comp[c].frame_index), 128);
         }
         huff_sync_finish_job(job);
-        memcpy(L->tables, ps.tables, sizeof(L->tables));
+        memcpy(L->tables, ps.tables->t, sizeof(L->tables));
         for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(L->unzig, t);
         for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*L, t);
         for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s, rg);
