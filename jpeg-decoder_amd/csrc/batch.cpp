@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -689,9 +690,29 @@ static uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t h
 //     DevHuffTable[8] per scan | segment offsets | scan bytes ]   + device only: per-chunk state of the sync jobs
 // The range statistics of the decoded coefficients are a by-product of the kernels that write them (HuffSyncJob::stats ->
 // the batch's d_stats; round 2 ran range_scan_kernel over the arena afterwards and read the result back).
+namespace {
+struct LaunchClock {  // JPGPU_PIPE_TRACE: where a slow launch spent its time (host)
+    bool on = getenv("JPGPU_PIPE_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    char text[512];
+    size_t used = 0;
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        used += (size_t)snprintf(text + used, used < sizeof(text) ? sizeof(text) - used : 0, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - last).count());
+        if (used >= sizeof(text)) used = sizeof(text) - 1;
+        last = now;
+    }
+    ~LaunchClock() {
+        if (on && std::chrono::duration<double, std::milli>(last - t0).count() > 3.0) fprintf(stderr, "pipeline trace: slow device entropy launch (ms):%s\n", text);
+    }
+};
+}  // namespace
+
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
+    LaunchClock clk;
     int rc = use_device(b->device, b->err);
     if (rc) return rc;
     if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
@@ -785,6 +806,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipHostMalloc((void **)&b->h_entropy_out, (out_words + 64) * 4, hipHostMallocDefault));
         b->entropy_out_cap = out_words + 64;
     }
+    clk.mark("buffers");
     uint8_t *h = b->h_entropy, *d = b->d_entropy;
     memset(h, 0, off_jobs);  // status words and settle counters start at zero
     HuffSyncJob *jobs = reinterpret_cast<HuffSyncJob *>(h + off_jobs);
@@ -934,6 +956,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         // statistics.  They run while the host stages the first slice, next to nothing else of this sub-batch; on a second
         // stream (`copy_stream`) they and the uploads also stay clear of the kernels other sub-batches have in flight — behind
         // a fill on the kernels' own stream an upload waited for the machine to drain (2 of 7.5 ms per sub-batch).
+        clk.mark("jobs");
         const bool two_streams = copy_stream && copy_stream != hip_stream;
         hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
         if (two_streams && !b->entropy_uploaded) B_HIP(hipEventCreateWithFlags(&b->entropy_uploaded, hipEventDisableTiming));
@@ -950,10 +973,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             for (z++; z < zero_ranges.size() && zero_ranges[z].first <= last + 256; z++) last = std::max(last, zero_ranges[z].second);
             B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, cps));
         }
+        clk.mark("fills");
         // One parallel-for over all staging tasks; whoever finishes the last task of a slice (~8 MB of the data area) sends
         // that slice on its way.  (A parallel-for per slice spent more on starting threads than the overlap gave back.)
         const uint32_t n_tasks = (uint32_t)copies.size();
-        const uint32_t n_slices = std::max<uint32_t>(1u, std::min<uint32_t>({16u, n_tasks, (uint32_t)(data_bytes >> 23) + 1u}));
+        static const uint32_t slice_shift = env_u32("JPGPU_STAGE_SLICE_SHIFT", 23, 20, 31);  // tuning knob: bytes per slice = 1 << this
+        const uint32_t n_slices = std::max<uint32_t>(1u, std::min<uint32_t>({16u, n_tasks, (uint32_t)(data_bytes >> slice_shift) + 1u}));
         std::vector<std::atomic<uint32_t>> left(n_slices);
         auto slice_first = [&](uint32_t g) { return (uint32_t)((uint64_t)n_tasks * g / n_slices); };
         auto slice_of = [&](uint32_t t) {
@@ -964,20 +989,35 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         };
         for (uint32_t g = 0; g < n_slices; g++) left[g].store(slice_first(g + 1u) - slice_first(g));
         std::atomic<int> copy_failed{0};
+        std::atomic<uint32_t> max_copy_us{0}, max_task_us{0};
         const int device = b->device;
         const std::function<void(uint32_t)> staged = [&](uint32_t t) {
+            const auto b0 = std::chrono::steady_clock::now();
             body(t);
+            if (clk.on) {
+                const uint32_t us = (uint32_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - b0).count();
+                uint32_t cur = max_task_us.load();
+                while (us > cur && !max_task_us.compare_exchange_weak(cur, us)) {}
+            }
             const uint32_t g = slice_of(t);
             if (left[g].fetch_sub(1u) == 1u) {  // the slice is complete
                 const uint32_t t0 = slice_first(g), t1 = slice_first(g + 1u);
                 const size_t lo = off_data + copies[t0].dst_off, hi = t1 < n_tasks ? off_data + copies[t1].dst_off : total;
+                const auto c0 = std::chrono::steady_clock::now();
                 if (hipSetDevice(device) != hipSuccess || hipMemcpyAsync(d + lo, h + lo, hi - lo, hipMemcpyHostToDevice, cps) != hipSuccess)
                     copy_failed.store(1);
+                if (clk.on) {
+                    const uint32_t us = (uint32_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+                    uint32_t cur = max_copy_us.load();
+                    while (us > cur && !max_copy_us.compare_exchange_weak(cur, us)) {}
+                }
             }
         };
         if (par && n_tasks > 1) (*par)(n_tasks, staged);
         else
             for (uint32_t t = 0; t < n_tasks; t++) staged(t);
+        clk.mark("staging+uploads");
+        if (clk.on) clk.used += (size_t)snprintf(clk.text + clk.used, clk.used < sizeof(clk.text) ? sizeof(clk.text) - clk.used : 0, " (slowest staging task %.2f, slowest hipMemcpyAsync call %.2f)", max_task_us.load() / 1e3, max_copy_us.load() / 1e3);
         if (copy_failed.load()) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
         // the head of the block last: the staging tasks wrote into its job records (unstuffed lengths, chunk counts, status)
         B_HIP(hipMemcpyAsync(d, h, off_data, hipMemcpyHostToDevice, cps));
@@ -986,6 +1026,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));
         }
     }
+    clk.mark("head");
     // JPGPU_BATCH_KERNEL_TIMES: events between the phases (fills | sync passes | write pass + DC sums | pixel kernels)
     static const bool phase_times = getenv("JPGPU_BATCH_KERNEL_TIMES") != nullptr;
     b->phase_events_valid = false;
@@ -1005,8 +1046,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipEventRecord(b->ev_phase[3], s));
         b->phase_events_valid = true;
     }
+    clk.mark("kernels");
     // the status words into pinned memory (the only thing the host needs to look at: which images it has to decode itself)
     B_HIP(hipMemcpyAsync(b->h_entropy_out, d + off_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    clk.mark("status copy");
     return JPGPU_OK;
 }
 
@@ -1020,6 +1063,18 @@ bool jpgpu::batch_phase_times(jpgpu_batch *b, float ms[4]) {
     ok = ok && hipEventElapsedTime(&ms[1], b->ev_phase[1], b->ev_phase[2]) == hipSuccess;
     ok = ok && hipEventElapsedTime(&ms[2], b->ev_phase[2], b->ev_phase[3]) == hipSuccess;
     if (ok && hipEventQuery(b->ev_phase[5]) == hipSuccess) ok = hipEventElapsedTime(&ms[3], b->ev_phase[4], b->ev_phase[5]) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+// JPGPU_PIPE_TRACE: when the phase events of `b` fired, in milliseconds after `ref`'s first one (both recorded, streams synchronised)
+bool jpgpu::batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]) {
+    if (!ref || !b || !ref->phase_events_valid || !b->phase_events_valid) return false;
+    bool ok = true;
+    for (int i = 0; i < 6 && ok; i++) {
+        ms[i] = -1.f;
+        if (hipEventQuery(b->ev_phase[i]) == hipSuccess) ok = hipEventElapsedTime(&ms[i], ref->ev_phase[0], b->ev_phase[i]) == hipSuccess;
+    }
     if (!ok) (void)hipGetLastError();
     return ok;
 }

@@ -70,5 +70,6 @@ int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images
                                 void *copy_stream = nullptr);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 bool batch_phase_times(jpgpu_batch *b, float ms[4]);  // JPGPU_BATCH_KERNEL_TIMES, batch.cpp
+bool batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]);  // (+ JPGPU_PIPE_TRACE) event times relative to ref's first event
 
 }  // namespace jpgpu

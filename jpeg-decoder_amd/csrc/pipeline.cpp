@@ -296,6 +296,7 @@ struct jpgpu_pipeline {
     int device = 0;
     std::string err;
     std::unique_ptr<Pool> pool;
+    std::unique_ptr<Pool> stage_pool;  // the staging copies of the device entropy route (the uploader thread's parallel-for)
     // results of the last call
     uint32_t n = 0;
     std::vector<std::unique_ptr<Frontend>> fes;
@@ -388,6 +389,7 @@ int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) 
     if (rc) return rc;  // no usable MI355X: there is no CPU fallback for the pixel work
     if (n_threads == 0) n_threads = default_threads();
     p->pool.reset(new Pool(n_threads));
+    p->stage_pool.reset(new Pool(std::max<uint32_t>(2u, n_threads / 2u)));
     p->subs.resize(kMaxSubBatches);
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
     for (uint32_t k = 0; k < kComputeStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->compute[k], hipStreamNonBlocking));
@@ -688,15 +690,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::mutex delta_m;
     // the pool is idle while device-entropy images are staged (its tasks for them return at once): lend it to the copy
     std::mutex par_m;
+    // (a team of its own, kept between calls: the pool proper may still be inside its run() of step 3 when the uploader thread gets
+    // here, and sixteen fresh threads per launch — 512 thread starts per 4,096-file call — were half of a launch's host time)
     const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> par_for = [&](uint32_t cnt, const std::function<void(uint32_t)> &fn) {
-        std::vector<std::thread> ts;
-        std::atomic<uint32_t> next{0};
-        const uint32_t nt = std::min<uint32_t>(cnt, std::max<uint32_t>(2u, p->pool->size() / 2u));
-        for (uint32_t t = 0; t < nt; t++)
-            ts.emplace_back([&] {
-                for (uint32_t k = next.fetch_add(1); k < cnt; k = next.fetch_add(1)) fn(k);
-            });
-        for (auto &t : ts) t.join();
+        p->stage_pool->run(cnt, fn);
     };
     (void)par_m;
     std::thread uploader([&] {
@@ -831,6 +828,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         }
                     {
                         float ms[4];
+                        float stamp[6];
+                        if (okk && trace && jpgpu::batch_phase_stamps(p->subs[pending_subs[0]].batch, sb.batch, stamp))
+                            fprintf(stderr, "pipeline trace: sub-batch %u on the device: entropy launch +%.2f, sync passes %.2f .. %.2f, expansion .. %.2f, pixel kernels %.2f .. %.2f ms\n",
+                                    sj, stamp[0], stamp[1], stamp[2], stamp[3], stamp[4], stamp[5]);
                         if (okk && jpgpu::batch_phase_times(sb.batch, ms)) {  // JPGPU_BATCH_KERNEL_TIMES
                             dev_ms[0] += ms[0], dev_ms[1] += ms[1], dev_ms[2] += ms[2], dev_ms[3] += ms[3];
                             dev_ms_valid = true;
