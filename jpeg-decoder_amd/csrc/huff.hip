@@ -194,6 +194,11 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
         if (threadIdx.x < total)
             published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused,
                                                 (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
+#elif JPGPU_EMIT_MODE == 4
+        __shared__ uint32_t emit_stage[HUFF_EMIT_ROUND][SYNC_NT];
+        if (threadIdx.x < total)
+            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused, nullptr, 0u,
+                                                (JP_LDS uint32_t *)&emit_stage[0][threadIdx.x], SYNC_NT);
 #else
         if (threadIdx.x < total)
             published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);

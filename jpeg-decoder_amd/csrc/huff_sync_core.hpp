@@ -177,16 +177,53 @@ struct HuffRange {
 // component — the chunk's predictor is added by the expansion — or the difference itself in a `uniform` scan) and per
 // non-zero AC coefficient, in stream order.  Bits 22-23: the component of the scan the block belongs to — as far as the lane knows
 // it: in a `uniform` scan it does not (the expansion derives it from the block number there).
-#ifndef JPGPU_EMIT_MODE  // A/B builds: 0 one 4-byte store per entry; 1 no stores at all (what the bookkeeping alone costs: wrong
-#define JPGPU_EMIT_MODE 2  //  output); 2 four entries gathered in registers, one 16-byte store; 3 = 0 with the stream read through the LDS ring
+// How the entries reach the buffer (A/B builds: -DJPGPU_EMIT_MODE=...).  On gfx9 a wait for a load is a wait for every store issued
+// before it, and the loop waits for its stream fetch in nearly every step:
+//   0  one 4-byte store per entry (sync passes 3.85 ms per 256 1080p images; 2.72 without emission)
+//   1  no stores at all: what the bookkeeping alone costs (2.87 ms; wrong output)
+//   2  four entries gathered in registers, one 16-byte store (3.20 ms): still a store instruction in nearly every step of the wave,
+//      some lane's group is always full
+//   3  = 0 with the stream read through the LDS ring (5.16 ms: 60 kB of LDS, two workgroups per CU)
+//   4  entries collected in LDS (eight per lane) and written every eighth step by ALL lanes at once, 32 bytes each whatever
+//      they hold (what lies beyond a lane's entries is overwritten by its next round): one step in eight has stores in front of
+//      its wait — measured 3.48-3.54 ms, no better than 2 (the stores' cost is not the waits behind them); kept as an A/B build
+#ifndef JPGPU_EMIT_MODE
+#define JPGPU_EMIT_MODE 2
 #endif
+constexpr uint32_t HUFF_EMIT_ROUND = 8;  // steps between two flushes = entries a lane can collect (a step emits at most one)
+typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));  // (a list position is a multiple of 4 bytes, not of 16)
 struct HuffEmit {
     JP_GLOBAL uint32_t *buf = nullptr;  // nullptr: this run emits nothing
     uint32_t n = 0, cap = 0, lead = 0xffffffffu;  // entries so far (counts on past `cap`: overflow), capacity (a multiple of 4), entries before the first DC
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // the last entries, youngest in s3, not yet stored
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // mode 2: the last entries, youngest in s3, not yet stored
+    JP_LDS uint32_t *stage = nullptr;             // mode 4: this lane's HUFF_EMIT_ROUND words in LDS, `stage_stride` words apart (entry-major:
+    uint32_t stage_stride = 1;                    //   lane-major rows of 32 bytes put every fourth lane on the same bank) ...
+    uint32_t stored = 0;                          // ... hold entries stored .. n - 1
+    bool overflow = false;
 };
+// mode 4: what the lane has collected -> its buffer.  Called by all lanes of the wave in the same step (and once at the end of a run).
+__device__ __forceinline__ void huff_emit_flush(HuffEmit &em) {
+#if JPGPU_EMIT_MODE == 4
+    if (!em.buf || em.n == em.stored) return;
+    if (em.stored + HUFF_EMIT_ROUND <= em.cap) {
+#ifdef JPGPU_HOST_EMULATION
+        for (uint32_t j = 0; j < HUFF_EMIT_ROUND; j++) em.buf[em.stored + j] = em.stage[j * em.stage_stride];
+#else
+        const JP_LDS uint32_t *src = em.stage;
+        const uint32_t st = em.stage_stride;
+        *(JP_GLOBAL v4u_a4 *)(em.buf + em.stored) = v4u{src[0], src[st], src[2u * st], src[3u * st]};
+        if (em.n - em.stored > 4u) *(JP_GLOBAL v4u_a4 *)(em.buf + em.stored + 4u) = v4u{src[4u * st], src[5u * st], src[6u * st], src[7u * st]};
+#endif
+    } else {
+        em.overflow = true;
+    }
+    em.stored = em.n;
+#endif
+}
 __device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
-#if JPGPU_EMIT_MODE == 2
+#if JPGPU_EMIT_MODE == 4
+    em.stage[((em.n - em.stored) & (HUFF_EMIT_ROUND - 1u)) * em.stage_stride] = e;
+#elif JPGPU_EMIT_MODE == 2
     em.s0 = em.s1;
     em.s1 = em.s2;
     em.s2 = em.s3;
@@ -201,7 +238,10 @@ __device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
 }
 // the entries of an incomplete group of four, at the end of a run
 __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
-#if JPGPU_EMIT_MODE == 2
+#if JPGPU_EMIT_MODE == 4
+    huff_emit_flush(em);
+    if (em.overflow) em.n = em.cap + 1u;
+#elif JPGPU_EMIT_MODE == 2
     const uint32_t r = em.n & 3u, first = em.n - r;
     if (em.buf && r && em.n <= em.cap) {
         const uint32_t a = r == 3u ? em.s1 : (r == 2u ? em.s2 : em.s3), b = r == 3u ? em.s2 : em.s3;
@@ -236,7 +276,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 #endif
     DevBits b;
     huff_open_at<RD>(b, data, pos, ring, ring_stride);
-    uint32_t steps = 0;
+    uint32_t steps = 0, emit_steps = 0;
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
@@ -267,6 +307,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
         bool flush = false;
         uint64_t flush_addr = 0;
         if (active) {
+        if (!WRITE && BY_BITS && JPGPU_EMIT_MODE == 4 && em && (++emit_steps & (HUFF_EMIT_ROUND - 1u)) == 0u) huff_emit_flush(*em);
         if (RD == HUFF_READ_RING && (++steps % HUFF_RING_PERIOD) == 0u) huff_ring_topup(b);
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
@@ -380,7 +421,7 @@ __device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job,
 
 template <bool WRITE>
 __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
-                                                uint32_t ring_stride = 0) {
+                                                uint32_t ring_stride = 0, JP_LDS uint32_t *emit_stage = nullptr, uint32_t emit_stage_stride = 1) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     uint32_t pos, q, k;
@@ -442,6 +483,8 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     if (emit) {
         em.buf = (JP_GLOBAL uint32_t *)(job.emit + (size_t)i * job.emit_stride);
         em.cap = job.emit_stride;
+        em.stage = emit_stage;  // (JPGPU_EMIT_MODE 4: HUFF_EMIT_ROUND words of LDS, this lane's own)
+        em.stage_stride = emit_stage_stride;
     }
     if (pos < limit)
         pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride, &em);

@@ -298,3 +298,52 @@ def test_chunk_size_follows_the_bits_per_block():
         sh = L.emu_chunk_shift(kb * 1000, 48_960)
         assert sh >= prev
         prev = sh
+
+
+def _unary_table(symbols):
+    """A Huffman table whose k-th symbol has the code 1^k 0 (lengths 1, 2, 3, ...): the shortest codes a table can have."""
+    bits = [0] * 16
+    for k in range(len(symbols)):
+        bits[k] = 1
+    return bits, list(symbols)
+
+
+@pytest.mark.parametrize("kind", ["flat", "all-ones", "mixed"])
+def test_emission_buffers_hold_the_densest_streams(kind, emission):
+    """huff_emit_stride (csrc/huff_job.hpp): a chunk's entry list never outgrows its buffer — also when the tables give the most
+    frequent symbols 1-bit codes: blocks of a DC difference of 0 and an end-of-block code (2 bits, one entry) and blocks of 63
+    coefficients of +-1 (127 bits, 64 entries) are the densest a scan can be.  (The harness has a canary behind the buffers.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("baseline_encoder", os.path.join(R.ROOT if hasattr(R, "ROOT") else os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "baseline_encoder.py"))
+    enc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(enc)
+    import oracle as O
+    w, h = 400, 296
+    comps, _ = O.make_components(w, h, [(1, 1)])
+    n = comps[0].block_w * comps[0].block_h
+    rng = np.random.default_rng(5)
+    co = np.zeros((n, 64), np.int16)
+    if kind in ("all-ones", "mixed"):
+        co[:, 1:] = rng.choice([-1, 1], (n, 63))
+        co[:, 0] = 0
+        if kind == "mixed":
+            co[rng.random(n) < 0.5, 1:] = 0
+    dc = _unary_table(range(12))
+    ac_syms = [0x01, 0x00] if kind == "all-ones" else [0x00, 0x01]  # the 1-bit code goes to what the stream is made of
+    ac = _unary_table(ac_syms + [0xF0, 0x11, 0x02, 0x21, 0x12, 0x31])
+    class Cm:  # (the encoder's view of a component)
+        pass
+    cm = Cm()
+    cm.horizontal_sampling_factor = cm.vertical_sampling_factor = 1
+    cm.block_width, cm.block_height = comps[0].block_w, comps[0].block_h
+    data = enc.encode_from_coefficients([cm], [np.ones(64, np.int64)], [co.reshape(-1)], w, h, huffman={"dc": [dc, dc], "ac": [ac, ac]})
+    got = _device(data)
+    assert got is not None
+    st, desc, planes, _ns, _nseg = got
+    assert (st & 0xC000) == 0, hex(st)  # never past a buffer (canary), never an entry for the wrong component
+    if kind != "mixed":
+        assert st == 0, st
+    if st:  # (1-bit codes re-synchronise badly: such a scan may not settle in the launches it is given — flagged, the host's then)
+        return
+    hdesc, hcoefs = _host(data)
+    assert np.array_equal(planes[0], hcoefs[0])

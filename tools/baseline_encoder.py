@@ -95,9 +95,10 @@ def _pack_bits(values, lengths):
     return np.insert(out, ff + 1, 0).tobytes()
 
 
-def _entropy_segment(blocks, tab, comp_of, pred):
+def _entropy_segment(blocks, tab, comp_of, pred, tables=None):
     """blocks: (n, 64) zig-zag order int, in stream order; tab: (n,) 0 luma / 1 chroma tables; comp_of: (n,) component (DC
     predictors); pred: dict component -> predictor at the start of the segment.  -> entropy-coded bytes."""
+    _T = tables or _TABLES
     n = blocks.shape[0]
     dc = blocks[:, 0].astype(np.int64)
     diff = np.zeros(n, np.int64)
@@ -113,7 +114,7 @@ def _entropy_segment(blocks, tab, comp_of, pred):
     cat = _category(diff)
     for t in (0, 1):
         m = tab == t
-        code, ln = _TABLES["dc"][t]
+        code, ln = _T["dc"][t]
         keys.append(blk[m] * KEY + 3)
         vals.append((code[cat[m]] << cat[m]) | _amplitude_bits(diff[m], cat[m]))
         lens.append(ln[cat[m]] + cat[m])
@@ -129,7 +130,7 @@ def _entropy_segment(blocks, tab, comp_of, pred):
     tt = tab[bi]
     for t in (0, 1):
         m = tt == t
-        code, ln = _TABLES["ac"][t]
+        code, ln = _T["ac"][t]
         sym = ((run[m] & 15) << 4) | cat[m]
         keys.append(bi[m] * KEY + pos[m] * 4 + 3)
         vals.append((code[sym] << cat[m]) | _amplitude_bits(v[m], cat[m]))
@@ -144,7 +145,7 @@ def _entropy_segment(blocks, tab, comp_of, pred):
     np.maximum.at(last, bi, pos)
     for t in (0, 1):
         m = (tab == t) & (last < 63)
-        code, ln = _TABLES["ac"][t]
+        code, ln = _T["ac"][t]
         keys.append(blk[m] * KEY + 64 * 4)
         vals.append(np.full(int(m.sum()), code[0]))
         lens.append(np.full(int(m.sum()), ln[0]))
@@ -157,11 +158,15 @@ def _marker(m, payload=b""):
     return bytes([0xFF, m]) + (len(payload) + 2).to_bytes(2, "big") + bytes(payload)
 
 
-def encode_from_coefficients(comps, qts, coefs, width, height, restart_interval=0, identifiers=None):
+def encode_from_coefficients(comps, qts, coefs, width, height, restart_interval=0, identifiers=None, huffman=None):
     """comps: components with horizontal_sampling_factor / vertical_sampling_factor / block_width / block_height (the geometry of
     src/parser.rs:282-310, e.g. jpeg_decoder_amd.make_components); qts: per component, 64 values <= 255 in natural order;
     coefs: per component, block-raster natural-order int16 (the Worker layout).  1 component -> grayscale, 3 -> YCbCr (JFIF).
-    Components whose table equals the first one's share DQT 0 and the luminance Huffman tables; the others use the second set."""
+    Components whose table equals the first one's share DQT 0 and the luminance Huffman tables; the others use the second set.
+    huffman: optional {"dc": [(BITS, HUFFVAL), (BITS, HUFFVAL)], "ac": [...]} instead of Annex K's tables (every symbol the data needs
+    must have a code; tests use it for streams with the shortest codes a table can have)."""
+    specs = huffman or {"dc": [_DC_L, _DC_C], "ac": [_AC_L, _AC_C]}
+    tables = {k: [_code_table(sp) for sp in v] for k, v in specs.items()}
     ncomp = len(comps)
     assert ncomp in (1, 3)
     H = [int(c.horizontal_sampling_factor) for c in comps]
@@ -198,7 +203,7 @@ def encode_from_coefficients(comps, qts, coefs, width, height, restart_interval=
         comp_of = np.tile(comp_of_q, m1 - m0)
         if ri:
             pred = {}
-        parts.append(_entropy_segment(blocks, np.array(tq)[comp_of], comp_of, pred))
+        parts.append(_entropy_segment(blocks, np.array(tq)[comp_of], comp_of, pred, tables))
         if ri and m1 < n_mcu:
             parts.append(bytes([0xFF, 0xD0 + (k & 7)]))
     ids = list(identifiers) if identifiers else [1, 2, 3][:ncomp]
@@ -209,7 +214,7 @@ def encode_from_coefficients(comps, qts, coefs, width, height, restart_interval=
     out.append(_marker(0xC0, bytes([8]) + int(height).to_bytes(2, "big") + int(width).to_bytes(2, "big") + bytes([ncomp]) +
                        b"".join(bytes([ids[c], (int(comps[c].horizontal_sampling_factor) << 4) | int(comps[c].vertical_sampling_factor), tq[c]]) for c in range(ncomp))))
     for t in sorted(set(tq)):
-        for cls, spec in ((0, (_DC_L, _DC_C)[t]), (1, (_AC_L, _AC_C)[t])):
+        for cls, spec in ((0, specs["dc"][t]), (1, specs["ac"][t])):
             out.append(_marker(0xC4, bytes([(cls << 4) | t]) + bytes(spec[0]) + bytes(spec[1])))
     if ri:
         out.append(_marker(0xDD, ri.to_bytes(2, "big")))
