@@ -710,7 +710,8 @@ struct LaunchClock {  // JPGPU_PIPE_TRACE: where a slow launch spent its time (h
 }  // namespace
 
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
-                                       const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream) {
+                                       const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream,
+                                       DeviceScratch *scratch) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
     LaunchClock clk;
     int rc = use_device(b->device, b->err);
@@ -782,7 +783,15 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const size_t off_tables = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
     const size_t off_seg = align_up(off_tables + n_table_sets * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
-    const size_t off_scratch = align_up(total, 256), total_dev = off_scratch + scratch_bytes;
+    const size_t off_scratch = align_up(total, 256), total_dev = scratch ? total : off_scratch + scratch_bytes;
+    if (scratch && scratch_bytes > scratch->cap) {  // (hipFree waits for whatever still uses the block)
+        if (scratch->d) (void)hipFree(scratch->d);
+        scratch->d = nullptr;
+        scratch->cap = 0;
+        const size_t cap = scratch_bytes + scratch_bytes / 4;
+        B_HIP(hipMalloc((void **)&scratch->d, cap));
+        scratch->cap = cap;
+    }
     if (total_dev > b->entropy_cap) {
         if (b->d_entropy) (void)hipFree(b->d_entropy);
         b->d_entropy = nullptr;
@@ -811,7 +820,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     memset(h, 0, off_jobs);  // status words and settle counters start at zero
     HuffSyncJob *jobs = reinterpret_cast<HuffSyncJob *>(h + off_jobs);
     HuffSyncJob *sjobs = reinterpret_cast<HuffSyncJob *>(h + off_sjobs);
-    size_t ji = 0, si = 0, tcur = off_tables, tnext = off_tables, scur = off_seg, dcur = off_data, xcur = off_scratch;
+    uint8_t *xs = scratch ? scratch->d : d;  // base of the device-only work space
+    size_t ji = 0, si = 0, tcur = off_tables, tnext = off_tables, scur = off_seg, dcur = off_data, xcur = scratch ? 0 : off_scratch;
     prev_tables = nullptr;
     uint32_t max_seg = 0, max_chunks = 0;
     std::vector<uint32_t> stat_images;  // listed images, for the fills that zero their statistics
@@ -879,7 +889,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
                 sj->pass0_skip = ((1u << sj->chunk_shift) >> 3) * (8u - sync_tail);
                 const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
-                uint32_t *st = reinterpret_cast<uint32_t *>(d + xcur);
+                uint32_t *st = reinterpret_cast<uint32_t *>(xs + xcur);
                 sj->data = d + dcur;
                 sj->tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
                 sj->status = reinterpret_cast<uint32_t *>(d + off_status) + k;
@@ -896,9 +906,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 xcur += align_up((size_t)chunks * 7 * 4, 16);
                 if (emitting) {
                     sj->emit_stride = huff_emit_stride(sj->chunk_shift);
-                    sj->emit_cnt = reinterpret_cast<uint32_t *>(d + xcur);
+                    sj->emit_cnt = reinterpret_cast<uint32_t *>(xs + xcur);
                     xcur += align_up((size_t)chunks * 4, 16);
-                    sj->emit = reinterpret_cast<uint32_t *>(d + xcur);
+                    sj->emit = reinterpret_cast<uint32_t *>(xs + xcur);
                     xcur += align_up((size_t)chunks * sj->emit_stride * 4, 16);
                     uint32_t block_h[4] = {0, 0, 0, 0};
                     for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;

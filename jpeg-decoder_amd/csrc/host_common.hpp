@@ -65,9 +65,16 @@ struct DeviceEntropyImage {
 // means image k of the list must be decoded on the host instead; the others have their range classes set.
 // `par`: optional parallel-for (count, body) used for the staging copies of the scans' bytes.
 // `copy_stream`: optional second stream for the upload (the kernels on `hip_stream` wait for it through an event).
+// `scratch`: optional device-only work space of the chunk decoder (per-chunk states, emission buffers: ~16 bytes per byte of
+// entropy-coded data) owned by the caller and shared by all launches it enqueues on the SAME stream — they run one after the
+// other there; without it every batch keeps its own (32 sub-batches of a 4,096-file call: 27 GB instead of 7).
+struct DeviceScratch {
+    uint8_t *d = nullptr;
+    size_t cap = 0;
+};
 int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                 const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
-                                void *copy_stream = nullptr);
+                                void *copy_stream = nullptr, DeviceScratch *scratch = nullptr);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 bool batch_phase_times(jpgpu_batch *b, float ms[4]);  // JPGPU_BATCH_KERNEL_TIMES, batch.cpp
 bool batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]);  // (+ JPGPU_PIPE_TRACE) event times relative to ref's first event

@@ -313,6 +313,7 @@ struct jpgpu_pipeline {
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t compute[kComputeStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t n_compute = kComputeStreams;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob)
+    jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
 };
 
@@ -413,6 +414,8 @@ void jpgpu_pipeline_destroy(jpgpu_pipeline *p) {
             if (p->copy_streams[k]) (void)hipStreamDestroy(p->copy_streams[k]);
         for (uint32_t k = 0; k < kComputeStreams; k++)
             if (p->compute[k]) (void)hipStreamDestroy(p->compute[k]);
+        for (auto &sc : p->scratch)
+            if (sc.d) (void)hipFree(sc.d);
     }
     delete p;
 }
@@ -784,7 +787,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
                         const double l0 = now_ms();
                         okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
-                                                                 p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams]) == JPGPU_OK;
+                                                                 p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
+                                                                 &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute]) == JPGPU_OK;
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         // The pixel kernels follow at once on the same stream: the classes of the decoded coefficients are a
                         // by-product of the write pass and stay on the device (range_stats.hpp), so nothing has to come
