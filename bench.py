@@ -22,7 +22,8 @@
   At N = 1 the line also carries, OUTSIDE `value` (each verified against the oracle):
     k_4096            the same kernel-only figure on north_star's 4096-image batch (51 GB of arenas on one GPU);
     e2e               what the metric's words say — JPEG bytes in host memory -> RGB in HBM through jpgpu_pipeline_decode
-                      (entropy decoding on the device), 256 and 4096 files, best of 3 warm calls, with the kernel time per phase;
+                      (entropy decoding on the device), 256, 1024 and 4096 files, best of 3 warm calls; the kernel time per phase
+                      from one sub-batch of 256 files alone on the device (kernels_256_one_sub_batch);
     cpu_baseline_e2e  the oracle's whole Decoder::decode() on the same files, one file per task on every granted core;
     sustained         the timed step repeated for --min-seconds (an independent look at `value`, long enough for a sampler).
 
@@ -37,9 +38,9 @@ import sys
 import time
 
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a
-# queue run one after the other: jpgpu_pipeline_decode keeps up to 8 sub-batches in flight on 8 compute + 4 copy streams.
+# queue run one after the other: jpgpu_pipeline_decode keeps up to 16 sub-batches in flight on 16 compute + 4 copy streams.
 # Read once when the runtime initialises, so it is set before anything touches HIP (jpeg_decoder_amd._native does the same).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -97,7 +98,7 @@ def parse_args(argv=None):
                     help="after the K timed steps: repeat the step for at least this long and report it as `sustained` (0 = off)")
     ap.add_argument("--no-k4096", action="store_true", help="skip the 4096-image kernel-only figure (N = 1, default workload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the JPEG-bytes -> RGB figures and their CPU comparator (N = 1, default workload)")
-    ap.add_argument("--e2e-images", default="256,4096", help="files per jpgpu_pipeline_decode call of the e2e block")
+    ap.add_argument("--e2e-images", default="256,1024,4096", help="files per jpgpu_pipeline_decode call of the e2e block")
     ap.add_argument("--e2e-encoder", default="auto", choices=["auto", "pillow", "builtin"],
                     help="who writes the e2e block's JPEG files: Pillow (libjpeg-turbo) or tools/baseline_encoder.py; auto = Pillow if importable")
     ap.add_argument("--force-dist", action="store_true",

@@ -52,11 +52,11 @@ const char *jpgpu_status_string(int status) {
 
 namespace jpgpu {
 
-// jpgpu_pipeline_decode keeps several sub-batches in flight on 8 compute + 4 copy streams; the HIP runtime maps a process's streams
+// jpgpu_pipeline_decode keeps several sub-batches in flight on 16 compute + 4 copy streams; the HIP runtime maps a process's streams
 // onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise (4,096 1080p files per call: 91 ms
 // with 4 queues, 64 ms with 16).  The runtime reads the variable when it initialises — at the first HIP call of the process —
 // so this helps a host that loads the library before it touches HIP; others export the variable themselves.
-__attribute__((constructor)) static void jpgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor)) static void jpgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 const RoctxApi &roctx_api() {
     static const RoctxApi api = [] {

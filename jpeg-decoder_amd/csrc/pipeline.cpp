@@ -288,7 +288,7 @@ struct SubBatch {
 // streams shared round robin.  Round 3: with 8 sub-batches a call of 4,096 files made four device sub-batches of 1,024, whose
 // write pass took 11 us per image against 7 us in sub-batches of 256 (a 6.4 GB arena per sub-batch instead of 1.6 GB:
 // profiles/round3/08_subbatch_size.txt).
-constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 8;
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 16, kComputeStreamsDefault = 16;
 
 }  // namespace
 
@@ -311,8 +311,8 @@ struct jpgpu_pipeline {
     std::string path;
     bool downloaded = false;  // the last call copied the pixels to host memory
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t compute[kComputeStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t n_compute = kComputeStreams;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob)
+    hipStream_t compute[kComputeStreams] = {};
+    uint32_t n_compute = kComputeStreamsDefault;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob, up to kComputeStreams)
     jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
 };

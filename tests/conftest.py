@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # (jpeg_decoder_amd/_native.py: before the HIP runtime initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # (jpeg_decoder_amd/_native.py: before the HIP runtime initialises)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
