@@ -958,7 +958,9 @@ struct Frontend::Impl {
                     // longer prefix; one that does not is left to the walk (which starts at 9 bits like the reference's, src/huffman.rs:31-58)
                     for (int i = 0; i < (1 << HUFF_LUT_BITS); i++) {
                         const int w = i << (kLutBits - HUFF_LUT_BITS);
-                        d.lut[i] = h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS ? (uint16_t)(h.lut_value[w] | (h.lut_size[w] << 8)) : (uint16_t)0;
+                        d.lut[i] = h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS
+                                       ? (uint16_t)(huff_sym_info(h.is_ac ? 1u : 0u, h.lut_value[w]) | ((uint32_t)h.lut_size[w] << SYM_LEN_SHIFT))
+                                       : (uint16_t)0;
                     }
                     memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode));
                     memcpy(d.delta, h.delta, sizeof(d.delta));

@@ -11,8 +11,28 @@ namespace jpgpu {
 #endif
 constexpr int HUFF_LUT_BITS = JPGPU_DEV_LUT_BITS;  // <= kLutBits of the host front-end (10), whose table the device table is cut from
 
+// What a Huffman symbol means to the decoding loop, 12 bits: how many magnitude bits follow, how far the coefficient index moves
+// (DC: to 1; AC coefficient: run + 1; ZRL: 16; EOB: to 64, which ends the block), whether it is a coefficient, whether it cannot
+// occur in a sequential scan.  The wide table holds it per prefix together with the code length, so that the loop's one table
+// read per symbol says everything (round 3: symbol from the table, then its class from a second table — a dependent LDS round
+// trip per step in a loop that is a chain of them).
+constexpr uint32_t SYM_NREAD = 0x000fu, SYM_ADV_SHIFT = 4, SYM_ADV_MASK = 0x3fu /* advance - 1 */, SYM_COEF = 0x0400u, SYM_BAD = 0x0800u;
+constexpr uint32_t SYM_LEN_SHIFT = 12;  // table entries: code length here (0: the prefix is not resolved within the lookahead)
+inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t
+    huff_sym_info(uint32_t ac, uint32_t sym) {
+    const uint32_t r = sym >> 4, sz = sym & 15u;
+    if (!ac) return sym > 11u ? SYM_BAD : ((0u << SYM_ADV_SHIFT) | sym);  // "invalid DC difference magnitude category"
+    if (sz) return SYM_COEF | (r << SYM_ADV_SHIFT) | sz;
+    if (r == 15u) return 15u << SYM_ADV_SHIFT;                             // ZRL
+    return r == 0u ? (63u << SYM_ADV_SHIFT) : SYM_BAD;                     // EOB; an EOBn run is for the host
+}
+
 struct alignas(16) DevHuffTable {  // (maxcode[8..15] are read as two 16-byte words)
-    uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: symbol | code length << 8 (length 0: not resolved within the lookahead)
+    uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: huff_sym_info of the symbol | code length << 12 (0: not resolved within the lookahead)
     int32_t maxcode[16], delta[16];
     uint8_t values[256];
     int32_t nvalues;

@@ -29,19 +29,8 @@ namespace jpgpu {
 
 constexpr uint32_t HUFF_POS_INVALID = 0xffffffffu;  // published by a lane whose speculative decode hit an impossible code
 
-// Per symbol the decoder needs: how many magnitude bits follow, how far the coefficient index moves (DC: to 1; AC
-// coefficient: run + 1; ZRL: 16; EOB: to 64, which ends the block) and whether the symbol is a coefficient or cannot
-// occur in a sequential scan.  One 16-bit word per (class, symbol) in LDS instead of a dozen compares and selects per
-// step — the loop is bound by instruction issue (one lane = one chunk: every wave executes every path).
-constexpr uint32_t SYM_BAD = 0x8000u, SYM_COEF = 0x4000u;  // | advance << 4 | magnitude bits
-__device__ __forceinline__ uint32_t huff_sym_info(uint32_t ac, uint32_t sym) {
-    const uint32_t r = sym >> 4, sz = sym & 15u;
-    if (!ac) return sym > 11u ? SYM_BAD : ((1u << 4) | sym);          // "invalid DC difference magnitude category"
-    if (sz) return SYM_COEF | ((r + 1u) << 4) | sz;
-    if (r == 15u) return 16u << 4;                                     // ZRL
-    return r == 0u ? (64u << 4) : SYM_BAD;                             // EOB; an EOBn run is for the host
-}
-
+// (what a symbol means to the loop: huff_sym_info, huff_job.hpp — in the wide tables next to the code length, and in a 512-entry
+// LDS table for the symbols the slow path finds)
 struct alignas(16) HuffBlockDst {  // block-within-MCU -> where its coefficients go: base + my * row_stride + mx * mcu_stride (bytes)
     uint64_t base;
     uint32_t row_stride, mcu_stride;
@@ -312,21 +301,24 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
-        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> 8;
-        uint32_t sym = e & 0xffu;
-        if (csz) {
-            huff_consume(b, csz);
+        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> SYM_LEN_SHIFT;
+        uint32_t info = e, raw;
+        if (csz) {  // code and magnitude bits leave the reader together
+            const uint32_t nread = e & SYM_NREAD;
+            raw = huff_peek(b, csz + nread) & ((1u << nread) - 1u);
+            huff_consume(b, csz + nread);
         } else {
-            sym = huff_walk(b, t);
+            const uint32_t sym = huff_walk(b, t);
             bad = b.bad;
+            // chunk decoder (several waves per SIMD, bound by instruction issue) from the LDS table; restart segments (one wave
+            // per SIMD at best: every dependent LDS round trip is paid in full) by a dozen selects
+            info = BY_BITS ? (uint32_t)L.sym_info[ac][sym] : huff_sym_info(ac, sym);
+            raw = huff_peek(b, info & SYM_NREAD);
+            huff_consume(b, info & SYM_NREAD);
         }
-        // what the symbol means: chunk decoder (several waves per SIMD, bound by instruction issue) from the LDS table; restart
-        // segments (one wave per SIMD at best: every dependent LDS round trip is paid in full) by a dozen selects
-        const uint32_t info = BY_BITS ? (uint32_t)L.sym_info[ac][sym] : huff_sym_info(ac, sym), nread = info & 15u;
-        const uint32_t raw = huff_peek(b, nread);
-        huff_consume(b, nread);
+        const uint32_t nread = info & SYM_NREAD;
         const uint32_t k0 = k;
-        k += (info >> 4) & 127u;
+        k += ((info >> SYM_ADV_SHIFT) & SYM_ADV_MASK) + 1u;
         // a coefficient beyond index 63: the reference breaks out of the block in a way that depends on its own table
         // layout (src/decoder.rs:1045-1075) — only broken streams have it, the host decides
         bad = bad || (info & SYM_BAD) != 0u || ((info & SYM_COEF) != 0u && k > 64u);
