@@ -956,11 +956,37 @@ struct Frontend::Impl {
                     static_assert(HUFF_LUT_BITS >= 8 && HUFF_LUT_BITS <= kLutBits && sizeof(d.values) == sizeof(h.values), "table layouts");
                     // the device table is the host's wide table cut to HUFF_LUT_BITS: a code that fits has the same entry under every
                     // longer prefix; one that does not is left to the walk (which starts at 9 bits like the reference's, src/huffman.rs:31-58)
+                    int n_sub = 0;
                     for (int i = 0; i < (1 << HUFF_LUT_BITS); i++) {
                         const int w = i << (kLutBits - HUFF_LUT_BITS);
-                        d.lut[i] = h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS
-                                       ? (uint16_t)(huff_sym_info(h.is_ac ? 1u : 0u, h.lut_value[w]) | ((uint32_t)h.lut_size[w] << SYM_LEN_SHIFT))
-                                       : (uint16_t)0;
+                        if (h.lut_size[w] && h.lut_size[w] <= HUFF_LUT_BITS) {
+                            d.lut[i] = (uint16_t)(huff_sym_info(h.is_ac ? 1u : 0u, h.lut_value[w]) | ((uint32_t)h.lut_size[w] << SYM_LEN_SHIFT));
+                            continue;
+                        }
+                        // not resolved within the lookahead: the reference's maxcode walk (src/huffman.rs:31-58, from length 9 as
+                        // huff_walk does it) evaluated for the 64 continuations of this prefix — if any of them is a code
+                        d.lut[i] = (uint16_t)HUFF_SUB_NONE;
+                        if (n_sub >= HUFF_SUB_TABLES) continue;
+                        uint16_t sub[1 << HUFF_SUB_BITS];
+                        bool any = false;
+                        for (int x = 0; x < (1 << HUFF_SUB_BITS); x++) {
+                            const uint32_t b16 = ((uint32_t)i << HUFF_SUB_BITS) | (uint32_t)x;
+                            sub[x] = (uint16_t)SYM_BAD;
+                            for (int len = 9; len <= 16; len++) {
+                                const int32_t code = (int32_t)(b16 >> (16 - len));
+                                if (code <= h.maxcode[len - 1]) {
+                                    const int32_t index = code + h.delta[len - 1];
+                                    if (index >= 0 && index < h.nvalues) {
+                                        sub[x] = (uint16_t)(huff_sym_info(h.is_ac ? 1u : 0u, h.values[index]) | ((uint32_t)(len - 1) << SYM_LEN_SHIFT));
+                                        any = true;
+                                    }
+                                    break;
+                                }
+                            }
+                        }
+                        if (!any) continue;  // (nothing but rejections under this prefix: the walk says so at decode time)
+                        memcpy(d.lut2[n_sub], sub, sizeof(sub));
+                        d.lut[i] = (uint16_t)n_sub++;
                     }
                     memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode));
                     memcpy(d.delta, h.delta, sizeof(d.delta));

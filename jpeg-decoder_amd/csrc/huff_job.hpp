@@ -31,8 +31,18 @@ inline
     return r == 0u ? (63u << SYM_ADV_SHIFT) : SYM_BAD;                     // EOB; an EOBn run is for the host
 }
 
+// Codes longer than the lookahead: a second table per unresolved prefix, indexed by the six bits that follow it (a code has at
+// most 16).  Its entries hold the code length minus one.  Up to HUFF_SUB_TABLES prefixes per table get one (Annex K's AC tables have
+// 7-8 such prefixes); the others — and the prefixes of malformed tables that the reference's procedure rejects — say
+// HUFF_SUB_NONE and the maxcode walk decides at decode time, as in rounds 1-3 (≈45 instructions that some lane of a wave needed
+// in a quarter of the steps).
+constexpr int HUFF_SUB_TABLES = 12, HUFF_SUB_BITS = 16 - HUFF_LUT_BITS;
+constexpr uint32_t HUFF_SUB_NONE = 0x0fffu;
+
 struct alignas(16) DevHuffTable {  // (maxcode[8..15] are read as two 16-byte words)
-    uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: huff_sym_info of the symbol | code length << 12 (0: not resolved within the lookahead)
+    uint16_t lut[1 << HUFF_LUT_BITS];  // per prefix: huff_sym_info of the symbol | code length << 12; length 0: not resolved within the
+                                       // lookahead — the entry is the number of the prefix's second-level table, or HUFF_SUB_NONE
+    uint16_t lut2[HUFF_SUB_TABLES][1 << HUFF_SUB_BITS];  // huff_sym_info | (code length - 1) << 12
     int32_t maxcode[16], delta[16];
     uint8_t values[256];
     int32_t nvalues;

@@ -232,11 +232,17 @@ __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
     if (em.overflow) em.n = em.cap + 1u;
 #elif JPGPU_EMIT_MODE == 2
     const uint32_t r = em.n & 3u, first = em.n - r;
-    if (em.buf && r && em.n <= em.cap) {
-        const uint32_t a = r == 3u ? em.s1 : (r == 2u ? em.s2 : em.s3), b = r == 3u ? em.s2 : em.s3;
-        em.buf[first] = a;
-        if (r >= 2u) em.buf[first + 1u] = b;
-        if (r == 3u) em.buf[first + 2u] = em.s3;
+    if (em.buf && r && em.n <= em.cap) {  // (branches, not selects: the compiler turned the selects into a table in scratch memory)
+        if (r == 1u) {
+            em.buf[first] = em.s3;
+        } else if (r == 2u) {
+            em.buf[first] = em.s2;
+            em.buf[first + 1u] = em.s3;
+        } else {
+            em.buf[first] = em.s1;
+            em.buf[first + 1u] = em.s2;
+            em.buf[first + 2u] = em.s3;
+        }
     }
 #elif JPGPU_EMIT_MODE == 1
     if (em.buf && em.s3 == 0x12345678u) em.buf[0] = em.s3;  // (keeps the bookkeeping alive)
@@ -301,12 +307,16 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
-        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)], csz = e >> SYM_LEN_SHIFT;
-        uint32_t info = e, raw;
-        if (csz) {  // code and magnitude bits leave the reader together
-            const uint32_t nread = e & SYM_NREAD;
-            raw = huff_peek(b, csz + nread) & ((1u << nread) - 1u);
-            huff_consume(b, csz + nread);
+        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)];
+        uint32_t info = e, csz = e >> SYM_LEN_SHIFT, raw;
+        if (csz == 0u && e != HUFF_SUB_NONE) {  // a code longer than the lookahead: the prefix's second-level table
+            info = t.lut2[0][e * (1u << HUFF_SUB_BITS) + (huff_peek(b, 16) & ((1u << HUFF_SUB_BITS) - 1u))];
+            csz = (info >> SYM_LEN_SHIFT) + 1u;
+        }
+        if (csz) {  // code and magnitude bits leave the reader together (<= 16 + 15 of the > 32 bits it holds)
+            const uint32_t nr = info & SYM_NREAD;
+            raw = huff_peek(b, csz + nr) & ((1u << nr) - 1u);
+            huff_consume(b, csz + nr);
         } else {
             const uint32_t sym = huff_walk(b, t);
             bad = b.bad;
