@@ -173,18 +173,22 @@ struct HuffRange {
 //   2  four entries gathered in registers, one 16-byte store (3.20 ms): still a store instruction in nearly every step of the wave,
 //      some lane's group is always full
 //   3  = 0 with the stream read through the LDS ring (5.16 ms: 60 kB of LDS, two workgroups per CU)
+//   5  = 2 with two groups of four per store round (the first waits in registers for the second): half as many partial-line
+//      writes meet a line that has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds:
+//      the counters show 2.9 GB fetched and 1.4 GB written per 256 images for 0.44 GB of entries)
 //   4  entries collected in LDS (eight per lane) and written every eighth step by ALL lanes at once, 32 bytes each whatever
 //      they hold (what lies beyond a lane's entries is overwritten by its next round): one step in eight has stores in front of
 //      its wait — measured 3.48-3.54 ms, no better than 2 (the stores' cost is not the waits behind them); kept as an A/B build
 #ifndef JPGPU_EMIT_MODE
-#define JPGPU_EMIT_MODE 2
+#define JPGPU_EMIT_MODE 5
 #endif
 constexpr uint32_t HUFF_EMIT_ROUND = 8;  // steps between two flushes = entries a lane can collect (a step emits at most one)
 typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));  // (a list position is a multiple of 4 bytes, not of 16)
 struct HuffEmit {
     JP_GLOBAL uint32_t *buf = nullptr;  // nullptr: this run emits nothing
     uint32_t n = 0, cap = 0, lead = 0xffffffffu;  // entries so far (counts on past `cap`: overflow), capacity (a multiple of 4), entries before the first DC
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // mode 2: the last entries, youngest in s3, not yet stored
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // modes 2, 5: the last entries, youngest in s3, not yet stored
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;      // mode 5: the complete group of four before them, waiting for its neighbour
     JP_LDS uint32_t *stage = nullptr;             // mode 4: this lane's HUFF_EMIT_ROUND words in LDS, `stage_stride` words apart (entry-major:
     uint32_t stage_stride = 1;                    //   lane-major rows of 32 bytes put every fourth lane on the same bank) ...
     uint32_t stored = 0;                          // ... hold entries stored .. n - 1
@@ -212,6 +216,19 @@ __device__ __forceinline__ void huff_emit_flush(HuffEmit &em) {
 __device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
 #if JPGPU_EMIT_MODE == 4
     em.stage[((em.n - em.stored) & (HUFF_EMIT_ROUND - 1u)) * em.stage_stride] = e;
+#elif JPGPU_EMIT_MODE == 5
+    em.s0 = em.s1;
+    em.s1 = em.s2;
+    em.s2 = em.s3;
+    em.s3 = e;
+    if ((em.n & 3u) == 3u) {
+        if ((em.n & 4u) == 0u) {
+            em.t0 = em.s0, em.t1 = em.s1, em.t2 = em.s2, em.t3 = em.s3;
+        } else if (em.n < em.cap) {  // two groups, one after the other: the second store finds the line where the first left it
+            *(JP_GLOBAL v4u *)(em.buf + (em.n - 7u)) = v4u{em.t0, em.t1, em.t2, em.t3};
+            *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
+        }
+    }
 #elif JPGPU_EMIT_MODE == 2
     em.s0 = em.s1;
     em.s1 = em.s2;
@@ -230,6 +247,25 @@ __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
 #if JPGPU_EMIT_MODE == 4
     huff_emit_flush(em);
     if (em.overflow) em.n = em.cap + 1u;
+#elif JPGPU_EMIT_MODE == 5
+    if (em.buf && em.n <= em.cap) {
+        uint32_t first = em.n & ~7u;
+        if (em.n & 4u) {  // a complete group waits in t
+            *(JP_GLOBAL v4u *)(em.buf + first) = v4u{em.t0, em.t1, em.t2, em.t3};
+            first += 4u;
+        }
+        const uint32_t r = em.n & 3u;
+        if (r == 1u) {
+            em.buf[first] = em.s3;
+        } else if (r == 2u) {
+            em.buf[first] = em.s2;
+            em.buf[first + 1u] = em.s3;
+        } else if (r == 3u) {
+            em.buf[first] = em.s1;
+            em.buf[first + 1u] = em.s2;
+            em.buf[first + 2u] = em.s3;
+        }
+    }
 #elif JPGPU_EMIT_MODE == 2
     const uint32_t r = em.n & 3u, first = em.n - r;
     if (em.buf && r && em.n <= em.cap) {  // (branches, not selects: the compiler turned the selects into a table in scratch memory)
