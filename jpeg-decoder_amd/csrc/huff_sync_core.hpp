@@ -448,6 +448,75 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
     return huff_bit_pos(b);
 }
 
+// The decoding loop of a sync pass, on its own (round 3): the same symbol step as huff_run, arranged for the instruction streams
+// the compiler makes of it — a wave's step is as many SCALAR instructions (lane-mask bookkeeping around every divergent region) as
+// vector ones, and the two issue at the same rate, so regions count.  DC and AC entries leave through ONE emission site; whether
+// a pass emits is a template parameter (it is the same for every lane of a launch's iteration), `bad` is a number in a vector
+// register, not a lane mask carried round the loop.  From (pos, q, k) until the bit position reaches `limit`; returns the
+// position reached, q, k, nblk (blocks completed) updated.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
+                                                  uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em) {
+    const JP_LDS HuffSyncJob &job = L.job;
+    constexpr int RD = HUFF_READ_DW;
+    DevBits b;
+    huff_open_at<RD>(b, data, pos);
+    uint32_t c = job.q_comp[q];  // component of block q
+    const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
+    uint32_t qt = L.q_tables[q];  // table offsets of block q
+    uint32_t badv = 0;
+    while (badv == 0u && huff_bit_pos(b) < limit) {
+        huff_refill<RD>(b);
+        const uint32_t ac = k != 0u ? 1u : 0u;
+        const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
+        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)];
+        uint32_t info = e, csz = e >> SYM_LEN_SHIFT, raw;
+        if (csz == 0u && e != HUFF_SUB_NONE) {  // a code longer than the lookahead: the prefix's second-level table
+            info = t.lut2[0][e * (1u << HUFF_SUB_BITS) + (huff_peek(b, 16) & ((1u << HUFF_SUB_BITS) - 1u))];
+            csz = (info >> SYM_LEN_SHIFT) + 1u;
+        }
+        if (csz) {  // code and magnitude bits leave the reader together (<= 16 + 15 of the > 32 bits it holds)
+            const uint32_t nr = info & SYM_NREAD;
+            raw = huff_peek(b, csz + nr) & ((1u << nr) - 1u);
+            huff_consume(b, csz + nr);
+        } else {
+            const uint32_t sym = huff_walk(b, t);
+            badv |= b.bad ? 1u : 0u;
+            info = (uint32_t)L.sym_info[ac][sym];
+            raw = huff_peek(b, info & SYM_NREAD);
+            huff_consume(b, info & SYM_NREAD);
+        }
+        const uint32_t nread = info & SYM_NREAD, k0 = k;
+        k += ((info >> SYM_ADV_SHIFT) & SYM_ADV_MASK) + 1u;
+        // (a coefficient beyond index 63: only broken streams have it, the host decides — huff_run)
+        badv |= (info & SYM_BAD) | (((info & SYM_COEF) != 0u && k > 64u) ? 1u : 0u);
+        if (badv == 0u) {
+            const bool isdc = k0 == 0u;
+            if (isdc || (EMIT && (info & SYM_COEF) != 0u)) {
+                int32_t val = huff_extend(raw, nread);
+                if (isdc && dc_sums) {  // the chunk's sum of differences so far, per component
+                    dc[c] += (uint32_t)val;
+                    val = (int16_t)(uint16_t)dc[c];
+                }
+                if (EMIT) {
+                    const uint32_t z = L.unzig[isdc ? 0u : k - 1u];  // (unzig[0] = 0)
+                    em.lead = (isdc && em.lead == 0xffffffffu) ? em.n : em.lead;
+                    huff_emit_entry(em, (isdc ? HUFF_EMIT_DC : 0u) | (z << 16) | (c << 22) | (uint32_t)(uint16_t)val);
+                }
+            }
+            if (k >= 64u) {  // end of the block
+                k = 0u;
+                nblk++;
+                q = q + 1u == job.bpm ? 0u : q + 1u;
+                qt = L.q_tables[q];
+                c = job.q_comp[q];
+            }
+        }
+    }
+    bad_out = badv != 0u;
+    return huff_bit_pos(b);
+}
+
 // One chunk.  WRITE = false: a sync pass (`pass` = its number), returns whether the lane published a new state (the caller
 // counts those per job: one atomic per workgroup, not per lane — a quarter of a million lanes adding to a few hundred
 // neighbouring counters took 18 ms per pass); WRITE = true: the write pass.
@@ -524,8 +593,11 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         em.stage = emit_stage;  // (JPGPU_EMIT_MODE 4: HUFF_EMIT_ROUND words of LDS, this lane's own)
         em.stage_stride = emit_stage_stride;
     }
-    if (pos < limit)
-        pos = huff_run<WRITE, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride, &em);
+    if (pos < limit) {
+        if (WRITE) pos = huff_run<true, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
+        else if (emit) pos = huff_sync_run<true>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em);
+        else pos = huff_sync_run<false>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em);
+    }
     if (!WRITE) huff_emit_finish(em);
     if (!WRITE && job.emit != nullptr)  // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
         job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
