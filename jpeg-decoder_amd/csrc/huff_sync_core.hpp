@@ -172,7 +172,7 @@ struct HuffRange {
 //   1  no stores at all: what the bookkeeping alone costs (2.87 ms; wrong output)
 //   2  four entries gathered in registers, one 16-byte store (3.20 ms): still a store instruction in nearly every step of the wave,
 //      some lane's group is always full
-//   3  = 0 with the stream read through the LDS ring (5.16 ms: 60 kB of LDS, two workgroups per CU)
+//   3  (removed) = 0 with the stream read through the LDS ring: 5.16 ms — 60 kB of LDS, two workgroups per CU
 //   5  = 2 with two groups of four per store round (the first waits in registers for the second): half as many partial-line
 //      writes meet a line that has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds:
 //      the counters show 2.9 GB fetched and 1.4 GB written per 256 images for 0.44 GB of entries)
@@ -289,7 +289,7 @@ template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
 __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                              uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad,
                                              HuffRange &rg, JP_LDS HuffWriteBuf *W = nullptr, bool participate = true,
-                                             JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0, HuffEmit *em = nullptr) {
+                                             JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     // (huff_core.hpp) kernels that store decode from the LDS ring when they are given one; the sync passes fetch dwords ahead
 #ifdef JPGPU_HOST_EMULATION
@@ -298,16 +298,12 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 #ifdef JPGPU_WRITE_DW  // (A/B build: the write pass fetches dwords ahead like the sync passes, no LDS ring)
     constexpr int RD = HUFF_READ_DW;
 #else
-#if JPGPU_EMIT_MODE == 3
-    constexpr int RD = HUFF_READ_RING;
-#else
     constexpr int RD = WRITE ? HUFF_READ_RING : HUFF_READ_DW;
-#endif
 #endif
 #endif
     DevBits b;
     huff_open_at<RD>(b, data, pos, ring, ring_stride);
-    uint32_t steps = 0, emit_steps = 0;
+    uint32_t steps = 0;
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
@@ -338,7 +334,6 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
         bool flush = false;
         uint64_t flush_addr = 0;
         if (active) {
-        if (!WRITE && BY_BITS && JPGPU_EMIT_MODE == 4 && em && (++emit_steps & (HUFF_EMIT_ROUND - 1u)) == 0u) huff_emit_flush(*em);
         if (RD == HUFF_READ_RING && (++steps % HUFF_RING_PERIOD) == 0u) huff_ring_topup(b);
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
@@ -389,15 +384,6 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
                 }
                 // (finished DC values only: the differences of a uniform scan are summed — and ranged — by huff_dc_prefix_kernel)
                 if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * (zq[0] >> 16));
-                if (!WRITE && BY_BITS && em && em->buf) {
-                    if (em->lead == 0xffffffffu) em->lead = em->n;
-                    huff_emit_entry(*em, HUFF_EMIT_DC | (c << 22) | (uint32_t)(uint16_t)val);
-                }
-            } else if (!WRITE && BY_BITS && (info & SYM_COEF)) {
-                if (em && em->buf) {
-                    const uint32_t z = L.unzig[k - 1u];
-                    huff_emit_entry(*em, (z << 16) | (c << 22) | (uint32_t)(uint16_t)huff_extend(raw, nread));
-                }
             } else if (WRITE && (info & SYM_COEF)) {
                 const uint32_t e = zq[k - 1u], z = e & 0xffffu;
                 const int32_t x = huff_extend(raw, nread);
@@ -465,7 +451,13 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
     uint32_t badv = 0;
+#if JPGPU_EMIT_MODE == 4
+    uint32_t emit_steps = 0;
+#endif
     while (badv == 0u && huff_bit_pos(b) < limit) {
+#if JPGPU_EMIT_MODE == 4
+        if (EMIT && (++emit_steps & (HUFF_EMIT_ROUND - 1u)) == 0u) huff_emit_flush(em);
+#endif
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
