@@ -347,3 +347,72 @@ def test_emission_buffers_hold_the_densest_streams(kind, emission):
         return
     hdesc, hcoefs = _host(data)
     assert np.array_equal(planes[0], hcoefs[0])
+
+
+@pytest.mark.parametrize("case", [(320, 200, "4:2:0", 95, False), (257, 129, "4:4:4", 60, False), (400, 300, "4:2:2", 98, False), (200, 200, None, 90, False),
+                                  (320, 240, "4:2:0", 92, True)], ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}-q{c[3]}{'-dri' if c[4] else ''}")
+def test_encoder_optimised_tables_take_the_second_level_tables(case, emission):
+    """Tables an encoder fits to the image (Pillow's optimize=True) have other code lengths than Annex K's — long codes for rare
+    symbols, whose prefixes get second-level tables (DevHuffTable::lut2, built from the reference's maxcode walk) or fall back to
+    the walk: every symbol class must come out as the host decoder's."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    w, h, sub, q, dri = case
+    rgb = synth.synthetic_rgb(w, h, seed=w * 3 + h)
+    buf = io.BytesIO()
+    kw = {"restart_marker_rows": 1} if dri else {}
+    Image.fromarray(rgb[..., 0] if sub is None else rgb).save(buf, format="JPEG", quality=q, optimize=True, subsampling=sub or "4:4:4", **kw)
+    data = buf.getvalue()
+    got = _device(data)
+    assert got is not None
+    st, desc, planes, _ns, _nseg = got
+    assert st == 0, st
+    hdesc, hcoefs = _host(data)
+    for c in range(desc.ncomp):
+        assert np.array_equal(planes[c], hcoefs[c]), c
+
+
+def test_more_long_code_prefixes_than_second_level_tables(emission):
+    """41 symbols with 11-bit codes are 21 prefixes of the 10-bit lookahead: twelve get second-level tables (HUFF_SUB_TABLES), the
+    rest must take the maxcode walk — both in one stream, against the host decoder."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("baseline_encoder", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "baseline_encoder.py"))
+    enc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(enc)
+    import oracle as O
+    w, h = 256, 192
+    comps, _ = O.make_components(w, h, [(1, 1)])
+    n = comps[0].block_w * comps[0].block_h
+    rng = np.random.default_rng(11)
+    co = np.zeros((n, 64), np.int64)
+    for b in range(n):  # a few coefficients per block at random zig-zag positions: runs 0..15 (and beyond: ZRL), sizes 1..3
+        pos = np.sort(rng.choice(np.arange(1, 64), int(rng.integers(0, 9)), replace=False))
+        nat = enc.UNZIGZAG[pos]
+        co[b, nat] = rng.integers(1, 8, pos.size) * rng.choice([-1, 1], pos.size)
+    co[:, 0] = rng.integers(-60, 61, n)
+    syms = [(r << 4) | s for s in (1, 2, 3) for r in range(16)]
+    order = [0x00, 0x01, 0x02, 0x11, 0x03, 0x21, 0x12, 0x31, 0x41] + [s for s in syms if s not in (0x01, 0x02, 0x11, 0x03, 0x21, 0x12, 0x31, 0x41)] + [0xF0]
+    bits = [0] * 16
+    for ln in range(2, 11):
+        bits[ln - 1] = 1
+    bits[10] = len(order) - 9  # everything else: 11 bits
+    ac = (bits, order)
+    dc_bits = [0] * 16
+    for k in range(12):
+        dc_bits[k + 1] = 1  # lengths 2..13
+    dc = (dc_bits, list(range(12)))
+    class Cm:
+        pass
+    cm = Cm()
+    cm.horizontal_sampling_factor = cm.vertical_sampling_factor = 1
+    cm.block_width, cm.block_height = comps[0].block_w, comps[0].block_h
+    data = enc.encode_from_coefficients([cm], [np.ones(64, np.int64)], [co.astype(np.int16).reshape(-1)], w, h, huffman={"dc": [dc, dc], "ac": [ac, ac]})
+    got = _device(data)
+    assert got is not None
+    st, desc, planes, _ns, _nseg = got
+    hdesc, hcoefs = _host(data)
+    assert np.array_equal(hcoefs[0].reshape(-1, 64)[:, :], hcoefs[0].reshape(-1, 64))  # (the host decodes it)
+    assert (st & 0xC000) == 0, hex(st)
+    assert st == 0, st
+        assert np.array_equal(planes[0], hcoefs[0])
