@@ -412,7 +412,5 @@ def test_more_long_code_prefixes_than_second_level_tables(emission):
     assert got is not None
     st, desc, planes, _ns, _nseg = got
     hdesc, hcoefs = _host(data)
-    assert np.array_equal(hcoefs[0].reshape(-1, 64)[:, :], hcoefs[0].reshape(-1, 64))  # (the host decodes it)
-    assert (st & 0xC000) == 0, hex(st)
-    assert st == 0, st
-        assert np.array_equal(planes[0], hcoefs[0])
+    assert st == 0, hex(st)
+    assert np.array_equal(planes[0], hcoefs[0])
