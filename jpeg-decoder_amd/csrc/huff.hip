@@ -396,18 +396,34 @@ __device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint1
     return (uint32_t)(sv < 0 ? -sv : sv) * E.job.q[c][z];
 }
 
+// What the wave needs to know of a chunk before it can ask for its entries (scalar registers; huff_expand_kernel reads these for all of
+// a wave's chunks at once, so that the entries of chunk i + 1 are on their way while chunk i is being assembled)
+struct ExpandMeta {
+    uint32_t cw, nblk, qk_before, w0, w1;  // emit_cnt[i], n_blocks[i], out_qk[i - 1] (0 for the first chunk), dc_sum[2i], dc_sum[2i + 1]
+};
+// the first EXP_LOADS x 64 entries of chunk i behind its leading ones (all there is of an ordinary chunk): requested, not waited for
+__device__ __forceinline__ void expand_request(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t stride, const ExpandMeta &m, uint32_t (&ent)[EXP_LOADS]) {
+    const uint32_t lane = threadIdx.x & 63u, cnt = min(m.cw & 0xffffu, stride), lead = min(m.cw >> 16, cnt);
+    const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
+#pragma unroll
+    for (uint32_t r = 0; r < EXP_LOADS; r++) {
+        const uint32_t e = lead + 64u * r + lane;
+        ent[r] = e < cnt ? stream_load(buf + e) : 0u;
+    }
+}
+
 // One chunk of the scan -> its blocks in the arena.  Complete blocks wait in the ring until eight of them can go out together
-// (eight lanes per block: a store instruction for fewer leaves lanes idle, and the kernel is bound by instruction issue).
+// (eight lanes per block: a store instruction for fewer leaves lanes idle).  `first`: the chunk's first round of entries
+// (expand_request); longer lists are fetched round by round here.
 template <bool UNIFORM>
-__device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, ExpandAt &at, uint32_t i, uint32_t n_chunks, uint32_t total, uint32_t stride,
-                                             uint32_t &rg_dc, uint32_t &rg_ac) {
+__device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_t *ring, ExpandAt &at, uint32_t i, const ExpandMeta &meta, uint32_t (&first)[EXP_LOADS],
+                                             uint32_t n_chunks, uint32_t total, uint32_t stride, uint32_t &rg_dc, uint32_t &rg_ac) {
     const JP_LDS HuffSyncJob &job = E.job;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t cw = rfl(job.emit_cnt[i]), cnt = min(cw & 0xffffu, stride), lead = min(cw >> 16, cnt);
+    const uint32_t cnt = min(meta.cw & 0xffffu, stride), lead = min(meta.cw >> 16, cnt);
     if (lead >= cnt) return;  // no block starts in this chunk
-    const uint32_t k_i = i ? rfl(job.out_qk[i - 1u]) & 0xffu : 0u;
-    const uint32_t S = rfl(job.n_blocks[i]) + (k_i ? 1u : 0u);  // number of the first block that starts here
+    const uint32_t S = meta.nblk + ((meta.qk_before & 0xffu) ? 1u : 0u);  // number of the first block that starts here
     if (S >= total) return;  // (what a stream holds after its last block)
     {
         const uint32_t m = S / at.bpm;
@@ -415,15 +431,19 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
         at.my0 = m / at.cols;
         at.mx0 = m - at.my0 * at.cols;
     }
-    const uint32_t w0 = UNIFORM ? 0u : rfl(job.dc_sum[2u * i]), w1 = UNIFORM ? 0u : rfl(job.dc_sum[2u * i + 1u]);
+    const uint32_t w0 = UNIFORM ? 0u : meta.w0, w1 = UNIFORM ? 0u : meta.w1;
     const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
     uint32_t started = 0, base = 0;  // blocks started so far; which of them sits in slot 0
     for (uint32_t e0 = lead; e0 < cnt; e0 += 64u * EXP_LOADS) {
         uint32_t ent[EXP_LOADS];
 #pragma unroll
         for (uint32_t r = 0; r < EXP_LOADS; r++) {
-            const uint32_t e = e0 + 64u * r + lane;
-            ent[r] = e < cnt ? stream_load(buf + e) : 0u;
+            if (e0 == lead) {
+                ent[r] = first[r];
+            } else {
+                const uint32_t e = e0 + 64u * r + lane;
+                ent[r] = e < cnt ? stream_load(buf + e) : 0u;
+            }
         }
 #pragma unroll
         for (uint32_t r = 0; r < EXP_LOADS; r++) {
@@ -497,11 +517,41 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
     at.inv_cols = cols > 1u ? 0xffffffffu / cols + 1u : 0u;
     at.q0 = at.mx0 = at.my0 = 0u;
     uint32_t rg_dc = 0, rg_ac = 0;
+    // lanes 0 .. EXP_CHUNKS - 1 fetch what the wave has to know of its chunks (one wait for all of them) ...
+    const uint32_t i0 = first_chunk + wave * EXP_CHUNKS;
+    uint32_t v_cw = 0, v_nblk = 0, v_qk = 0, v_w0 = 0, v_w1 = 0;
+    {
+        const uint32_t mine = i0 + (lane % EXP_CHUNKS);
+        if (mine < n_chunks) {
+            v_cw = job.emit_cnt[mine];
+            v_nblk = job.n_blocks[mine];
+            v_qk = mine ? job.out_qk[mine - 1u] : 0u;
+            if (!uniform) {
+                v_w0 = job.dc_sum[2u * mine];
+                v_w1 = job.dc_sum[2u * mine + 1u];
+            }
+        }
+    }
+    auto meta_of = [&](uint32_t ci) {
+        return ExpandMeta{(uint32_t)__builtin_amdgcn_readlane((int)v_cw, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)v_nblk, (int)ci),
+                          (uint32_t)__builtin_amdgcn_readlane((int)v_qk, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)v_w0, (int)ci),
+                          (uint32_t)__builtin_amdgcn_readlane((int)v_w1, (int)ci)};
+    };
+    // ... and the entries of chunk ci + 1 are requested before chunk ci is assembled
+    uint32_t cur[EXP_LOADS], nxt[EXP_LOADS];
+    if (i0 < n_chunks) expand_request(job, i0, stride, meta_of(0u), cur);
     for (uint32_t ci = 0; ci < EXP_CHUNKS; ci++) {
-        const uint32_t i = first_chunk + wave * EXP_CHUNKS + ci;
+        const uint32_t i = i0 + ci;
         if (i >= n_chunks) break;
-        if (uniform) expand_chunk<true>(E, ring, at, i, n_chunks, total, stride, rg_dc, rg_ac);
-        else expand_chunk<false>(E, ring, at, i, n_chunks, total, stride, rg_dc, rg_ac);
+        const ExpandMeta m = meta_of(ci);
+        const bool more = ci + 1u < EXP_CHUNKS && i + 1u < n_chunks;
+        if (more) expand_request(job, i + 1u, stride, meta_of(ci + 1u), nxt);
+        if (uniform) expand_chunk<true>(E, ring, at, i, m, cur, n_chunks, total, stride, rg_dc, rg_ac);
+        else expand_chunk<false>(E, ring, at, i, m, cur, n_chunks, total, stride, rg_dc, rg_ac);
+        if (more) {
+#pragma unroll
+            for (uint32_t r = 0; r < EXP_LOADS; r++) cur[r] = nxt[r];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
