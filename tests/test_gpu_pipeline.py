@@ -366,3 +366,56 @@ def test_pipeline_device_entropy_randomised_encoder_settings(monkeypatch):
     out = p.decode(files, device_entropy=True)  # with the cost models deciding
     _check(names, files, out)
     p.close()
+
+
+_OTHER_SETTINGS_SCRIPT = r'''
+import io, os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import oracle as O, synth
+import jpeg_decoder_amd as J
+from PIL import Image
+files = []
+for k, (w, h, sub, gray) in enumerate([(640, 480, "4:2:0", False), (321, 243, "4:2:2", False), (200, 120, "4:4:4", False), (300, 200, "4:4:4", True),
+                                       (1280, 720, "4:2:0", False), (64, 48, "4:2:0", False)] * 4):
+    rgb = synth.synthetic_rgb(w, h, seed=100 + k)
+    buf = io.BytesIO()
+    Image.fromarray(rgb[..., 0] if gray else rgb).save(buf, format="JPEG", quality=70 + k, subsampling=sub)
+    files.append(buf.getvalue())
+base = files[4]
+cut = bytearray(base)
+del cut[len(cut) // 2:]
+files.append(bytes(cut))                      # data that ends before the last block: the device hands it back
+p = J.Pipeline(threads=4)
+for rep in range(2):
+    out = p.decode(files, device_entropy=True)
+    for f, got in zip(files, out):
+        try:
+            want = O.decode(f).pixels
+        except O.OracleError as e:
+            assert isinstance(got, J.Error) and got.kind == e.kind, (got, e)
+            continue
+        assert not isinstance(got, Exception), got
+        assert np.array_equal(got, want)
+t = p.timings()
+assert t["images_device_entropy"] >= len(files) - 1, t
+p.close()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{"JPGPU_SYNC_EMIT": "0"}, {"GPU_MAX_HW_QUEUES": "4"}, {"JPGPU_SYNC_TAIL": "8"}, {"JPGPU_SYNC_TAIL": "1", "JPGPU_SYNC_ITERS": "1"},
+                                 {"JPGPU_PIPE_DEV_SUB": "3", "JPGPU_PIPE_MAX_DEV_SUBS": "32"}, {"JPGPU_PIPE_STREAMS": "1"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_pipeline_device_entropy_under_other_settings(env):
+    """Settings a process reads once — the write pass instead of emission + expansion, the HIP runtime's default queue count, the
+    first sync pass over whole chunks or an eighth of them, tiny sub-batches, one compute stream: the device-entropy route of a
+    process of its own must give the oracle's pixels (and the oracle's error for a truncated file) under each."""
+    pytest.importorskip("PIL")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _OTHER_SETTINGS_SCRIPT, root], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
