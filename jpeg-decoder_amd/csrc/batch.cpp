@@ -745,6 +745,40 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     // blocks — no write pass, and no zero fill for images whose scans cover their planes.  JPGPU_SYNC_EMIT=0: the write pass.
     static const bool emitting = env_u32("JPGPU_SYNC_EMIT", 1, 0, 1) != 0;
     static const uint32_t sync_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
+    // Restart-marker streams through the chunk decoder (huff_job.hpp, HuffSyncJob::seg_chunks): every segment gets chunk slots of
+    // its own.  Not for `uniform` scans (their DC sums run over whole planes), not without emission.  JPGPU_DRI_CHUNKS=0: one lane
+    // per segment as in rounds 1-3 (huff_segments_kernel).
+    static const bool dri_chunks = env_u32("JPGPU_DRI_CHUNKS", 1, 0, 1) != 0;
+    struct DriGeom {
+        bool chunked;
+        uint32_t shift, seg_chunks;
+    };
+    uint64_t all_slots = 0;  // (bit positions inside the staging block's data area are 32-bit numbers)
+    for (uint32_t k = 0; k < n && images[k].scans; k++)
+        for (const host::PlannedScan &ps : *images[k].scans)
+            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) all_slots += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
+    auto dri_geom = [&](const host::PlannedScan &ps) {
+        DriGeom g{false, 0u, 0u};
+        if (ps.ri == 0 || !emitting || !dri_chunks || ps.seg_off.size() < 4 || all_slots >= (1u << 29)) return g;
+        bool uniform = true;
+        uint32_t blocks = 0;
+        for (uint32_t c = 0; c < ps.ncomp; c++) {
+            blocks += ps.comp[c].h * ps.comp[c].v;
+            if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) uniform = false;
+        }
+        if (uniform) return g;
+        uint64_t stuffed = 0;
+        uint32_t longest = 0;
+        for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+            stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
+            longest = std::max<uint32_t>(longest, ps.seg_off[sg + 1] - ps.seg_off[sg]);
+        }
+        if (stuffed >= (1u << 28)) return g;
+        g.shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
+        g.seg_chunks = huff_sync_chunks(longest, g.shift);
+        g.chunked = true;
+        return g;
+    };
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
     size_t n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
@@ -771,8 +805,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
                 const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
                 const size_t chunks = huff_sync_chunks((uint32_t)stuffed, shift);
-                scratch_bytes += align_up(chunks * 7 * 4, 16);
+                scratch_bytes += align_up(chunks * 8 * 4, 16);
                 if (emitting) scratch_bytes += align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16);
+            } else if (const DriGeom g = dri_geom(ps); g.chunked) {
+                n_sync_jobs++;
+                const size_t chunks = (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16);
             } else {
                 n_seg_jobs++;
             }
@@ -849,7 +887,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         }
         for (const host::PlannedScan &ps : *images[k].scans) {
             // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
-            HuffSyncJob *sj = ps.ri == 0 ? &sjobs[si] : nullptr;
+            const DriGeom dg = dri_geom(ps);
+            HuffSyncJob *sj = (ps.ri == 0 || dg.chunked) ? &sjobs[si] : nullptr;
             copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps, sj,
                                       reinterpret_cast<uint32_t *>(h + off_status) + k});
             size_t scan_bytes = 0, stuffed = 0;
@@ -886,11 +925,19 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 memcpy(sj->q, scan_q, sizeof(scan_q));
                 sj->stats = b->d_stats + (size_t)img * RS_WORDS;
                 huff_sync_finish_job(*sj);
-                sj->chunk_shift = huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
+                sj->chunk_shift = dg.chunked ? dg.shift : huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
                 sj->pass0_skip = ((1u << sj->chunk_shift) >> 3) * (8u - sync_tail);
-                const uint32_t chunks = huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);  // upper bound; the staging task sets the real count
+                // (no restart markers: an upper bound, the staging task sets the real count; restart segments: slots per segment x segments)
+                const uint32_t chunks = dg.chunked ? (uint32_t)(ps.seg_off.size() / 2) * dg.seg_chunks : huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);
                 uint32_t *st = reinterpret_cast<uint32_t *>(xs + xcur);
-                sj->data = d + dcur;
+                sj->data = dg.chunked ? d + off_data : d + dcur;  // (segment offsets are relative to the start of the data area)
+                if (dg.chunked) {
+                    sj->seg_off = reinterpret_cast<const uint32_t *>(d + scur);
+                    sj->n_seg = (uint32_t)(ps.seg_off.size() / 2);
+                    sj->ri = ps.ri;
+                    sj->seg_chunks = dg.seg_chunks;
+                    sj->n_chunks = chunks;
+                }
                 sj->tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
                 sj->status = reinterpret_cast<uint32_t *>(d + off_status) + k;
                 sj->changed = reinterpret_cast<uint32_t *>(d + off_cnt) + si * 4;
@@ -900,10 +947,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->out_qk = st + 3 * (size_t)chunks;
                 sj->n_blocks = st + 4 * (size_t)chunks;
                 sj->dc_sum = st + 5 * (size_t)chunks;
+                sj->blk_end = st + 7 * (size_t)chunks;
                 sj->cols = ps.cols;
                 sj->n_mcu = ps.n_mcu;
                 max_chunks = std::max(max_chunks, chunks);
-                xcur += align_up((size_t)chunks * 7 * 4, 16);
+                xcur += align_up((size_t)chunks * 8 * 4, 16);
                 if (emitting) {
                     sj->emit_stride = huff_emit_stride(sj->chunk_shift);
                     sj->emit_cnt = reinterpret_cast<uint32_t *>(xs + xcur);
@@ -954,8 +1002,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             }
             if (ct.sync) {
                 const bool refused = (*ct.h_status & 1u) != 0u;
-                ct.sync->n_bits = refused ? 0u : ct.seg_table[1] * 8u;
-                ct.sync->n_chunks = refused ? 0u : huff_sync_chunks(ct.seg_table[1], ct.sync->chunk_shift);
+                if (ct.sync->n_seg > 1u) {  // restart segments in chunk slots: the slots are where they are, the segment table says what they hold
+                    if (refused) ct.sync->n_chunks = 0u;
+                } else {
+                    ct.sync->n_bits = refused ? 0u : ct.seg_table[1] * 8u;
+                    ct.sync->n_chunks = refused ? 0u : huff_sync_chunks(ct.seg_table[1], ct.sync->chunk_shift);
+                }
             }
         };
         // Staging and upload in slices: while the host threads unstuff the scans of one slice into the pinned block, the

@@ -145,14 +145,15 @@ __global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__
 __device__ __forceinline__ bool sync_chunk_has_work(const HuffSyncJob *gj, uint32_t i, uint32_t pass) {
     if (i >= gj->n_chunks) return false;
     if (pass == 0u) return true;
-    uint32_t p = 0u, qk = 0u;  // (the first chunk: the start of the scan)
-    if (i > 0u) {
+    const HuffChunkSpan span = huff_chunk_span(*gj, i);
+    uint32_t p = span.start, qk = 0u;  // (a chunk at the start of the scan or of a restart segment: the truth)
+    if (!span.first) {
         p = huff_load_shared(gj->out_pos + (i - 1u));
         qk = huff_load_shared(gj->out_qk + (i - 1u));
     }
     if (gj->uniform) qk &= 0xffu;
-    const uint32_t first = i << gj->chunk_shift;  // (huff_sync_state_plausible)
-    if (i > 0u && !(p >= first && p - first <= 32u && (qk >> 8) < gj->bpm && (qk & 0xffu) < 64u)) return false;
+    const uint32_t first = span.start;  // (huff_sync_state_plausible)
+    if (!span.first && !(p >= first && p - first <= 32u && (qk >> 8) < gj->bpm && (qk & 0xffu) < 64u)) return false;
     if (gj->emit != nullptr) qk |= QK_EMITTED;  // (a state decoded from in pass 0, without emission, is work again)
     return p != gj->in_pos[i] || qk != gj->in_qk[i];
 }
@@ -214,6 +215,11 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
     }
     uint32_t carry = 0, bad = 0;
     const bool emits = job.emit != nullptr;
+    if (job.n_seg > 1u) {  // restart segments: each is numbered on its own, by one thread (huff_emit_segment_scan)
+        for (uint32_t seg = threadIdx.x; seg < job.n_seg; seg += SYNC_NT) bad |= huff_emit_segment_scan(job, seg);
+        if (bad) atomicOr(job.status, bad);
+        return;
+    }
     for (uint32_t base = 0; base < job.n_chunks; base += SYNC_NT) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < job.n_chunks ? job.n_blocks[i] : 0u;
@@ -424,6 +430,14 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
     const uint32_t cnt = min(meta.cw & 0xffffu, stride), lead = min(meta.cw >> 16, cnt);
     if (lead >= cnt) return;  // no block starts in this chunk
     const uint32_t S = meta.nblk + ((meta.qk_before & 0xffu) ? 1u : 0u);  // number of the first block that starts here
+    uint32_t seg_end_chunk = n_chunks;  // blocks and lists end with the restart segment, if there are any
+    if (job.n_seg > 1u) {
+        const uint32_t seg = i / job.seg_chunks;
+        uint32_t fb, nb;
+        huff_segment_blocks(job, seg, fb, nb);
+        total = rfl(fb + nb);
+        seg_end_chunk = rfl((seg + 1u) * job.seg_chunks);
+    }
     if (S >= total) return;  // (what a stream holds after its last block)
     {
         const uint32_t m = S / at.bpm;
@@ -478,7 +492,7 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
     if (!started) return;
     // the last block: its remaining entries lead the lists of the chunks that follow
     const uint32_t last = started - 1u;  // (counted from S)
-    for (uint32_t j = i + 1u; S + last < total && j < n_chunks; j++) {
+    for (uint32_t j = i + 1u; S + last < total && j < seg_end_chunk; j++) {
         const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj);
         const JP_GLOBAL uint32_t *bj = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)j * stride);
         for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put<UNIFORM>(E, ring, at, true, stream_load(bj + e) & ~HUFF_EMIT_DC, last, last - base, 0u, 0u));
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
         if (mine < n_chunks) {
             v_cw = job.emit_cnt[mine];
             v_nblk = job.n_blocks[mine];
-            v_qk = mine ? job.out_qk[mine - 1u] : 0u;
+            v_qk = huff_chunk_span(job, mine).first ? 0u : job.out_qk[mine - 1u];
             if (!uniform) {
                 v_w0 = job.dc_sum[2u * mine];
                 v_w1 = job.dc_sum[2u * mine + 1u];

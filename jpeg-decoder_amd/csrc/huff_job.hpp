@@ -96,6 +96,7 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     uint32_t *in_pos, *in_qk;    // start state last decoded from          (qk = block-within-MCU << 8 | coefficient index)
     uint32_t *out_pos, *out_qk;  // published end state
     uint32_t *n_blocks;          // blocks completed by the chunk; after the scan: number of its first block
+    uint32_t *blk_end;           // bit position at which the last block the chunk completed ended (emitting jobs; 0: none completed)
     uint32_t *dc_sum;            // 2 words per chunk: the sums of its DC differences per component, 16 bits each (component 0 in the
                                  // low half of word 0); after the scan: the DC predictors its first block starts from.  Unused
                                  // when `uniform` (which component a block belongs to is unknown until the blocks are numbered)
@@ -119,7 +120,60 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     uint32_t *emit_cnt;     // per chunk: entries | entries before the first block start << 16 (HUFF_EMIT_OVERFLOW: see there)
     uint32_t emit_stride;
     uint32_t pass0_skip;    // bits of its chunk every lane but the first leaves out in sync pass 0 (huff_sync_chunk)
+    // Restart-marker streams through the chunk decoder (round 3): the segments are independent scans in miniature — every one
+    // starts at a byte boundary with the predictors at zero — so each gets `seg_chunks` chunk slots of its own (chunk i = slot
+    // i % seg_chunks of segment i / seg_chunks; slots behind a segment's data stay empty), its first lane starts from the truth,
+    // block numbers and DC sums restart per segment.  n_seg <= 1: the one-slot scan of a stream without restart markers.
+    uint32_t seg_chunks, _pad_seg;
 };
+// Where chunk i lies: bits [start, end) of the job's data, whether a segment starts there, which segment it belongs to.
+struct HuffChunkSpan {
+    uint32_t start, end, seg;
+    bool first;
+};
+template <class Job>
+inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    HuffChunkSpan
+    huff_chunk_span(const Job &job, uint32_t i) {
+    HuffChunkSpan sp;
+    if (job.n_seg <= 1u) {
+        sp.seg = 0u;
+        sp.first = i == 0u;
+        sp.start = i << job.chunk_shift;
+        const uint32_t e = (i + 1u) << job.chunk_shift;
+        sp.end = e < job.n_bits ? e : job.n_bits;
+        if (sp.end < sp.start) sp.end = sp.start;
+        return sp;
+    }
+    sp.seg = i / job.seg_chunks;
+    const uint32_t j = i - sp.seg * job.seg_chunks, seg_start = job.seg_off[2u * sp.seg] * 8u, seg_bits = job.seg_off[2u * sp.seg + 1u] * 8u;
+    const uint32_t lo = j << job.chunk_shift, hi = (j + 1u) << job.chunk_shift;
+    sp.first = j == 0u;
+    sp.start = seg_start + (lo < seg_bits ? lo : seg_bits);
+    sp.end = seg_start + (hi < seg_bits ? hi : seg_bits);
+    return sp;
+}
+// blocks segment `seg` must hold, and the number of its first block
+template <class Job>
+inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    void
+    huff_segment_blocks(const Job &job, uint32_t seg, uint32_t &first_block, uint32_t &n_blocks) {
+    const uint32_t total = job.n_mcu * job.bpm;
+    if (job.n_seg <= 1u) {
+        first_block = 0u;
+        n_blocks = total;
+        return;
+    }
+    const uint32_t per = job.ri * job.bpm;
+    first_block = seg * per < total ? seg * per : total;
+    n_blocks = total - first_block < per ? total - first_block : per;
+}
 // Does the scan write every block of its components' planes?  (An interleaved scan does; a scan of one component of several
 // leaves out the blocks that pad the plane to whole MCUs of the frame.)  block_h[c]: rows of blocks of scan component c's plane.
 inline bool huff_scan_covers_planes(const HuffSyncJob &j, const uint32_t block_h[4]) {

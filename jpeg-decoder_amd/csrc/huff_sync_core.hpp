@@ -94,8 +94,7 @@ __device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, ui
 }
 __device__ __forceinline__ uint32_t huff_bit_pos(const DevBits &b) { return b.wpos * 32u - b.nbits; }
 
-__device__ __forceinline__ bool huff_sync_state_plausible(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t pos, uint32_t q, uint32_t k) {
-    const uint32_t first = i << job.chunk_shift;
+__device__ __forceinline__ bool huff_sync_state_plausible(const JP_LDS HuffSyncJob &job, uint32_t first, uint32_t pos, uint32_t q, uint32_t k) {
     return pos >= first && pos - first <= 32u && q < job.bpm && k < 64u;
 }
 
@@ -442,7 +441,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 // position reached, q, k, nblk (blocks completed) updated.
 template <bool EMIT>
 __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
-                                                  uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em) {
+                                                  uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em, uint32_t &last_block_end) {
     const JP_LDS HuffSyncJob &job = L.job;
     constexpr int RD = HUFF_READ_DW;
     DevBits b;
@@ -499,6 +498,7 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
             if (k >= 64u) {  // end of the block
                 k = 0u;
                 nblk++;
+                last_block_end = huff_bit_pos(b);
                 q = q + 1u == job.bpm ? 0u : q + 1u;
                 qt = L.q_tables[q];
                 c = job.q_comp[q];
@@ -523,17 +523,18 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
                                                 uint32_t ring_stride = 0, JP_LDS uint32_t *emit_stage = nullptr, uint32_t emit_stage_stride = 1) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
+    const HuffChunkSpan span = huff_chunk_span(job, i);
     uint32_t pos, q, k;
     if (!WRITE && pass == 0u) {
         // The first pass is there to find where the chunks END, from guessed start states; a lane that starts at a guess
         // finds the true segmentation within ~15 blocks on average (the misses decay exponentially): it need not walk the
         // whole chunk for that.  Every lane decodes its chunk again from a real state in pass 1 anyway — the first lane too,
         // whose true start is known (one lane walking a whole chunk would keep the launch waiting for it).
-        pos = (i << job.chunk_shift) + job.pass0_skip;
+        pos = span.start + job.pass0_skip;
         q = 0u;
         k = 0u;
-    } else if (i == 0u) {
-        pos = 0u;
+    } else if (span.first) {  // the start of the scan, or of a restart segment: the truth
+        pos = span.start;
         q = 0u;
         k = 0u;
     } else {
@@ -547,7 +548,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     // which is the start of ours.  Anything else is not a state of this launch sequence — that lane belongs to a workgroup
     // which has not run yet, and the words are what an earlier batch left there — and must not be decoded from (it could
     // mean walking half the scan) nor handed on (it would travel down the scan, one lane per pass, keeping the job unsettled).
-    if (i > 0u && !(!WRITE && pass == 0u) && !huff_sync_state_plausible(job, i, pos, q, k)) pos = HUFF_POS_INVALID;
+    if (!span.first && !(!WRITE && pass == 0u) && !huff_sync_state_plausible(job, span.start, pos, q, k)) pos = HUFF_POS_INVALID;
     const bool emit = !WRITE && huff_emit_in_pass(job, i, pass);
     if (!WRITE) {
         if (pos == HUFF_POS_INVALID) return false;  // the predecessor has nothing to offer yet: keep what we have
@@ -559,7 +560,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         atomicOr_status(job.status, 1u | 32u);
         return false;
     }
-    const uint32_t limit = min((i + 1u) << job.chunk_shift, job.n_bits);
+    const uint32_t limit = span.end;
     uint32_t nblk = 0;
     const uint32_t total_blocks = job.n_mcu * job.bpm;
     uint32_t blkno = WRITE ? job.n_blocks[i] : 0u;  // number of the block being decoded (write pass)
@@ -578,6 +579,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         dc[2] = w1 & 0xffffu;
         dc[3] = w1 >> 16;
     }
+    uint32_t last_block_end = 0;
     HuffEmit em;
     if (emit) {
         em.buf = (JP_GLOBAL uint32_t *)(job.emit + (size_t)i * job.emit_stride);
@@ -587,9 +589,10 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     }
     if (pos < limit) {
         if (WRITE) pos = huff_run<true, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
-        else if (emit) pos = huff_sync_run<true>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em);
-        else pos = huff_sync_run<false>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em);
+        else if (emit) pos = huff_sync_run<true>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else pos = huff_sync_run<false>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
     }
+    if (!WRITE && job.emit != nullptr) job.blk_end[i] = last_block_end;
     if (!WRITE) huff_emit_finish(em);
     if (!WRITE && job.emit != nullptr)  // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
         job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
@@ -633,6 +636,42 @@ __device__ __forceinline__ uint32_t huff_emit_final_status(const HuffSyncJob &jo
     return 0u;
 }
 
+// The same for a job with restart markers (HuffSyncJob::seg_chunks), one segment at a time — by one thread, a segment has a
+// handful of chunks: number its chunks' first blocks from the segment's own first block, turn their sums of DC differences
+// into the predictors they start from (zero at the segment start, src/decoder.rs:928-931), and return what the restart-segment
+// decoder (huff_decode_segment) would have flagged: an impossible code or a full buffer before the segment's blocks are
+// complete, fewer or more blocks than the restart interval holds, a last block that took bits from beyond the segment, or more
+// than 56 bits between its end and the marker (the reference would not find the marker there: src/huffman.rs:103-160).
+__device__ __forceinline__ uint32_t huff_emit_segment_scan(const HuffSyncJob &job, uint32_t seg) {
+    uint32_t first_block, expected;
+    huff_segment_blocks(job, seg, first_block, expected);
+    const uint32_t c0 = seg * job.seg_chunks, seg_bits = job.seg_off[2u * seg + 1u] * 8u, seg_end = job.seg_off[2u * seg] * 8u + seg_bits;
+    uint32_t run = 0, status = 0, end_pos = 0, acc[4] = {0, 0, 0, 0};
+    for (uint32_t j = 0; j < job.seg_chunks; j++) {
+        const uint32_t i = c0 + j, nb = job.n_blocks[i];
+        job.n_blocks[i] = first_block + run;
+        if (!job.uniform) {
+            const uint32_t w0 = job.dc_sum[2u * i], w1 = job.dc_sum[2u * i + 1u];
+            job.dc_sum[2u * i] = (acc[0] & 0xffffu) | ((acc[1] & 0xffffu) << 16);
+            job.dc_sum[2u * i + 1u] = (acc[2] & 0xffffu) | ((acc[3] & 0xffffu) << 16);
+            acc[0] += w0 & 0xffffu, acc[1] += w0 >> 16, acc[2] += w1 & 0xffffu, acc[3] += w1 >> 16;
+        }
+        if (run < expected) {  // (what a chunk does once the segment's blocks are complete is nobody's business)
+            if (job.emit_cnt[i] == HUFF_EMIT_OVERFLOW) status |= 1u | 128u;
+            if (run + nb < expected && (j << job.chunk_shift) < seg_bits && job.out_pos[i] == HUFF_POS_INVALID) status |= 1u | 2u;
+            if (run + nb == expected) end_pos = job.blk_end[i];
+        }
+        run += nb;
+    }
+    if (run < expected) return status | 1u | 8u;
+    if (run > expected) return status | 1u | 4u;
+    if (expected) {
+        if (end_pos > seg_end) status |= 1u | 8u;
+        else if (seg_end - end_pos > 56u) status |= 1u | 4u;
+    }
+    return status;
+}
+
 // The write pass with block assembly (HuffWriteBuf): every lane of the workgroup calls it, `valid` = the lane has a chunk;
 // lanes without work still take part in the cooperative stores.  Same decisions as huff_sync_chunk<true>.
 __device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid, HuffRange &rg,
@@ -646,7 +685,7 @@ __device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L,
         q = qk >> 8;
         k = qk & 0xffu;
         if (job.uniform) q = 0u;
-        if (!huff_sync_state_plausible(job, i, pos, q, k)) {
+        if (!huff_sync_state_plausible(job, i << job.chunk_shift, pos, q, k)) {
             atomicOr_status(job.status, 1u | 32u);
             participate = false;
             pos = q = k = 0u;

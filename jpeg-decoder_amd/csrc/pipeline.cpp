@@ -434,6 +434,17 @@ static void back_to_the_host(jpgpu_pipeline *p, uint32_t i, const uint8_t *const
     }
 }
 
+// Restart-marker scans that still take one lane per segment (huff_segments_kernel): scans whose components all share their tables,
+// single-segment scans, and everything when the chunk slots or the emission are switched off (batch.cpp, dri_geom).
+static bool one_lane_per_segment(const jpgpu::host::PlannedScan &ps) {
+    if (ps.ri == 0) return false;
+    const char *e_dri = getenv("JPGPU_DRI_CHUNKS"), *e_emit = getenv("JPGPU_SYNC_EMIT");
+    if ((e_dri && atoi(e_dri) == 0) || (e_emit && atoi(e_emit) == 0) || ps.seg_off.size() < 4) return true;
+    for (uint32_t c = 1; c < ps.ncomp; c++)
+        if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) return false;
+    return true;
+}
+
 static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
     if (getenv("JPGPU_PIPE_FORCE_DEVICE")) return;  // (tests, A/B runs)
     // Restart-marker streams on the device cost the time of their LONGEST segment (one lane walks it: ≈2.4 µs per byte,
@@ -441,8 +452,10 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
     // (≈12 ns per byte and thread).  A few images, or segments of many MCU rows, are better off on the host.
     size_t max_seg = 0, bytes = 0;
     uint32_t n_seg_images = 0;
+    // (since round 3 restart segments go through the chunk decoder, each in chunk slots of its own, unless the scan's components
+    // all share their tables — batch.cpp, dri_geom: those cost what streams without restart markers cost and stay on the device)
     for (uint32_t i = 0; i < n; i++)
-        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) {
+        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && one_lane_per_segment(p->plans[i][0])) {
             n_seg_images++;
             for (const jpgpu::host::PlannedScan &ps : p->plans[i])
                 for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
@@ -456,7 +469,7 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
             fprintf(stderr, "pipeline trace: %u restart-marker stream(s) stay on the host (longest segment %zu B: device ~%.1f ms, host ~%.1f ms)\n",
                     n_seg_images, max_seg, device_ms, host_ms);
         for (uint32_t i = 0; i < n; i++)
-            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri != 0) back_to_the_host(p, i, data, len);
+            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && one_lane_per_segment(p->plans[i][0])) back_to_the_host(p, i, data, len);
     }
     // Streams without restart markers whose blocks are very long (noise at quality >= 98: no end-of-block symbols at all) keep
     // the chunk decoder re-synchronising for dozens of passes (measured: beyond ~350 bits per block more launches than it is
@@ -589,7 +602,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         const long dev_sub_env = getenv("JPGPU_PIPE_DEV_SUB") ? atol(getenv("JPGPU_PIPE_DEV_SUB")) : 0;  // tuning knob (read per call)
         uint32_t n_chunked = 0;
         for (uint32_t k = 0; k < n_dev; k++)
-            if (!p->plans[ok[k]].empty() && p->plans[ok[k]][0].ri == 0) n_chunked++;
+            if (!p->plans[ok[k]].empty() && !one_lane_per_segment(p->plans[ok[k]][0])) n_chunked++;
         const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_chunked * 2u >= n_dev ? 2u : 16u) * kSubBatchImages;
         const long dev_cap_env = getenv("JPGPU_PIPE_MAX_DEV_SUBS") ? atol(getenv("JPGPU_PIPE_MAX_DEV_SUBS")) : 0;  // tuning knob (read per call)
         const uint32_t dev_cap = dev_cap_env > 0 ? (uint32_t)std::min<long>(dev_cap_env, kMaxSubBatches / 2u) : kMaxSubBatches / 2u;

@@ -15,6 +15,7 @@ using jpgpu::host::PlannedScan;
 
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
 static uint32_t g_tail = 8;  // eighths of its chunk a lane walks in sync pass 0 (HuffSyncJob::pass0_skip)
+static uint32_t g_dri_chunks = 1, g_dri_shift = 0;  // restart segments in chunk slots (emu_huff_set_dri: on/off, forced chunk size)
 static uint32_t g_emit_mismatch = 0;
 static uint32_t g_emit = 0;  // 1: speculative emission + expansion instead of the write pass (emu_huff_set_emit)
 static uint32_t g_range[2] = {0, 0};  // by-product of the last emu_huff_decode: largest |DC * q| / |AC * q| written (range_stats.hpp)
@@ -23,11 +24,15 @@ static uint32_t g_range[2] = {0, 0};  // by-product of the last emu_huff_decode:
 // the chunk it starts in; its entries may run on through the leading entries of the chunks that follow.  Every block below the
 // scan's total is written whole (the planes are NOT zero-filled on this path: the caller fills them with a pattern).
 static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
-    const uint32_t total = sj.n_mcu * sj.bpm;
     for (uint32_t i = 0; i < sj.n_chunks; i++) {
         const uint32_t cw = sj.emit_cnt[i], cnt = std::min(cw & 0xffffu, sj.emit_stride), lead = std::min(cw >> 16, cnt);
         if (lead >= cnt) continue;
-        const uint32_t k_i = i ? sj.out_qk[i - 1] & 0xffu : 0u;
+        const HuffChunkSpan span = huff_chunk_span(sj, i);
+        uint32_t seg_first, seg_blocks;
+        huff_segment_blocks(sj, span.seg, seg_first, seg_blocks);
+        const uint32_t total = seg_first + seg_blocks;  // blocks (and lists) end with the restart segment, if there are any
+        const uint32_t seg_end_chunk = sj.n_seg > 1u ? (span.seg + 1u) * sj.seg_chunks : sj.n_chunks;
+        const uint32_t k_i = span.first ? 0u : sj.out_qk[i - 1] & 0xffu;
         uint32_t blk = sj.n_blocks[i] + (k_i ? 1u : 0u);  // the first block that starts here
         const uint32_t w0 = sj.uniform ? 0u : sj.dc_sum[2 * i], w1 = sj.uniform ? 0u : sj.dc_sum[2 * i + 1];
         const uint32_t pred[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
@@ -68,7 +73,7 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
             }
             put(buf[e]);
         }
-        for (uint32_t j = i + 1; open && j < sj.n_chunks; j++) {  // the rest of the last block
+        for (uint32_t j = i + 1; open && j < seg_end_chunk; j++) {  // the rest of the last block
             const uint32_t cj = sj.emit_cnt[j], cntj = std::min(cj & 0xffffu, sj.emit_stride), leadj = std::min(cj >> 16, cntj);
             const uint32_t* bj = sj.emit + (size_t)j * sj.emit_stride;
             for (uint32_t e = 0; e < leadj; e++) put(bj[e]);
@@ -90,6 +95,7 @@ int emu_stage_segment_clean(uint8_t* dst, const uint8_t* src, uint32_t n) {
 uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return huff_sync_chunk_shift(stuffed_bytes, total_blocks); }
 
 void emu_huff_set_emit(uint32_t on) { g_emit = on; }
+void emu_huff_set_dri(uint32_t chunks, uint32_t shift) { g_dri_chunks = chunks, g_dri_shift = shift; }
 void emu_huff_set_tail(uint32_t eighths) { g_tail = eighths >= 1 && eighths <= 8 ? eighths : 8; }
 void emu_huff_last_range(uint32_t out[2]) { out[0] = g_range[0], out[1] = g_range[1]; }
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
@@ -130,7 +136,12 @@ int emu_huff_covered(const uint8_t* data, size_t len) {
     fe.read_info();
     if (!fe.plan_device_scans(scans)) return -1;
     for (const PlannedScan& ps : scans) {
-        if (ps.ri != 0) return 0;
+        if (ps.ri != 0) {  // restart segments: only when they go through the chunk decoder (emission on: not uniform, two segments or more)
+            bool mixed_tables = false;
+            for (uint32_t c = 1; c < ps.ncomp; c++)
+                if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) mixed_tables = true;
+            if (!mixed_tables || !g_dri_chunks || ps.seg_off.size() < 4) return 0;
+        }
         HuffSyncJob sj;
         memset(&sj, 0, sizeof(sj));
         sj.cols = ps.cols, sj.n_mcu = ps.n_mcu, sj.ncomp = ps.ncomp;
@@ -168,7 +179,12 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             if (!clean) status |= 1u | 16u;  // (batch.cpp: the staging pass refuses the stream)
         }
         if (status & 1u) continue;
-        if (ps.ri == 0) {  // no restart markers: the self-synchronising chunk decoder, passes run one after the other
+        // restart-marker streams through the chunk decoder (batch.cpp, dri_geom): with emission, not for uniform scans, >= 2 segments
+        bool dri_chunked = false;
+        if (ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4)
+            for (uint32_t c = 1; c < ps.ncomp; c++)
+                if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) dri_chunked = true;
+        if (ps.ri == 0 || dri_chunked) {  // the self-synchronising chunk decoder, passes run one after the other
             HuffSyncLds* S = new HuffSyncLds;
             HuffSyncJob& sj = S->job;
             memset(&sj, 0, sizeof(sj));
@@ -191,8 +207,23 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 memcpy(sj.q[c], fe.qtable_of_component(ps.comp[c].frame_index), 128);
             }
             huff_sync_finish_job(sj);
-            sj.chunk_shift = huff_sync_chunk_shift(ps.seg_off[1] - ps.seg_off[0], sj.bpm * ps.n_mcu);
-            sj.n_chunks = huff_sync_chunks(table[1], sj.chunk_shift);
+            if (dri_chunked) {
+                uint32_t stuffed = 0, longest = 0;
+                for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
+                    stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
+                    longest = std::max<uint32_t>(longest, ps.seg_off[sg + 1] - ps.seg_off[sg]);
+                }
+                sj.chunk_shift = g_dri_shift ? g_dri_shift : huff_sync_chunk_shift(stuffed, sj.bpm * ps.n_mcu);
+                sj.seg_off = table.data();
+                sj.n_seg = (uint32_t)(ps.seg_off.size() / 2);
+                sj.ri = ps.ri;
+                sj.seg_chunks = huff_sync_chunks(longest, sj.chunk_shift);
+                sj.n_chunks = sj.n_seg * sj.seg_chunks;
+                sj.n_bits = 0;
+            } else {
+                sj.chunk_shift = huff_sync_chunk_shift(ps.seg_off[1] - ps.seg_off[0], sj.bpm * ps.n_mcu);
+                sj.n_chunks = huff_sync_chunks(table[1], sj.chunk_shift);
+            }
             sj.pass0_skip = ((1u << sj.chunk_shift) >> 3) * (8u - g_tail);
             std::vector<uint32_t> emit_buf, emit_cnt;
             if (g_emit) {
@@ -202,7 +233,8 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 sj.emit = emit_buf.data();
                 sj.emit_cnt = emit_cnt.data();
             }
-            std::vector<uint32_t> arr(7 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
+            std::vector<uint32_t> arr(8 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
+            sj.blk_end = arr.data() + 7 * (size_t)sj.n_chunks;
             sj.in_pos = arr.data();
             sj.in_qk = arr.data() + sj.n_chunks;
             sj.out_pos = arr.data() + 2 * (size_t)sj.n_chunks;
@@ -253,25 +285,30 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             }
             pass = launch;
             if (pass == 32) status |= 1u | 64u;
-            uint32_t run = 0;
-            for (uint32_t i = 0; i < sj.n_chunks; i++) {  // exclusive scan
-                const uint32_t nb = sj.n_blocks[i];
-                sj.n_blocks[i] = run;
-                run += nb;
-                if (g_emit) status |= huff_emit_chunk_status(sj, i, run);
-            }
-            if (g_emit) {
-                status |= huff_emit_final_status(sj, run);
-                if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;  // a lane wrote past its buffer
-            }
-            if (!sj.uniform) {  // (huff_sync_scan_kernel) sums of DC differences -> predictors at the start of every chunk
-                uint32_t acc[4] = {0, 0, 0, 0};
-                for (uint32_t i = 0; i < sj.n_chunks; i++) {
-                    const uint32_t w0 = sj.dc_sum[2 * i], w1 = sj.dc_sum[2 * i + 1];
-                    const uint32_t v[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
-                    sj.dc_sum[2 * i] = (acc[0] & 0xffffu) | ((acc[1] & 0xffffu) << 16);
-                    sj.dc_sum[2 * i + 1] = (acc[2] & 0xffffu) | ((acc[3] & 0xffffu) << 16);
-                    for (int f = 0; f < 4; f++) acc[f] += v[f];
+            if (sj.n_seg > 1u) {  // (huff_sync_scan_kernel, restart segments: one thread per segment)
+                for (uint32_t seg = 0; seg < sj.n_seg; seg++) status |= huff_emit_segment_scan(sj, seg);
+                if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;
+            } else {
+                uint32_t run = 0;
+                for (uint32_t i = 0; i < sj.n_chunks; i++) {  // exclusive scan
+                    const uint32_t nb = sj.n_blocks[i];
+                    sj.n_blocks[i] = run;
+                    run += nb;
+                    if (g_emit) status |= huff_emit_chunk_status(sj, i, run);
+                }
+                if (g_emit) {
+                    status |= huff_emit_final_status(sj, run);
+                    if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;  // a lane wrote past its buffer
+                }
+                if (!sj.uniform) {  // (huff_sync_scan_kernel) sums of DC differences -> predictors at the start of every chunk
+                    uint32_t acc[4] = {0, 0, 0, 0};
+                    for (uint32_t i = 0; i < sj.n_chunks; i++) {
+                        const uint32_t w0 = sj.dc_sum[2 * i], w1 = sj.dc_sum[2 * i + 1];
+                        const uint32_t v[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+                        sj.dc_sum[2 * i] = (acc[0] & 0xffffu) | ((acc[1] & 0xffffu) << 16);
+                        sj.dc_sum[2 * i + 1] = (acc[2] & 0xffffu) | ((acc[3] & 0xffffu) << 16);
+                        for (int f = 0; f < 4; f++) acc[f] += v[f];
+                    }
                 }
             }
             if (g_emit) {

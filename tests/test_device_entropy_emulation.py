@@ -110,7 +110,7 @@ FIXTURES = ["reftest/restarts.jpg", "reftest/mjpeg.jpg"]
 
 
 @pytest.mark.parametrize("rel", FIXTURES)
-def test_reference_fixtures_with_restart_markers(rel):
+def test_reference_fixtures_with_restart_markers(rel, emission):
     data = open(os.path.join(R.GOLDEN, rel), "rb").read()
     got = _device(data)
     assert got is not None, "planner refused a plain DRI stream"
@@ -127,7 +127,7 @@ def test_reference_fixtures_with_restart_markers(rel):
 @pytest.mark.parametrize("case", [(64, 48, "4:2:0", 0, 1), (250, 130, "4:2:0", 3, 0), (129, 257, "4:2:2", 0, 2), (200, 120, "4:4:4", 1, 0),
                                   (33, 17, "4:2:0", 5, 0), (300, 200, None, 0, 1), (1920, 64, "4:2:0", 0, 1), (17, 1080, "4:4:4", 7, 0)],
                          ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}-b{c[3]}r{c[4]}")
-def test_encoder_written_restart_streams(case):
+def test_encoder_written_restart_streams(case, emission):
     pytest.importorskip("PIL")
     w, h, sub, rb, rr = case
     data = _pil_jpeg(w, h, sub or "4:4:4", rb, rr, gray=sub is None)
