@@ -100,7 +100,8 @@ typedef struct jpgpu_pipeline_timings {
      * when the environment variable JPGPU_BATCH_KERNEL_TIMES is set (the events cost a few microseconds per sub-batch):
      *   dev_fill_ms   zero fill of the coefficient planes and statistics
      *   dev_sync_ms   restart-segment decoder + the chunk decoder's sync passes + block numbering
-     *   dev_write_ms  write pass (coefficients and, as a by-product, their range statistics) + DC sums
+     *   dev_write_ms  expansion of the sync passes' entry lists into coefficient blocks (and, as a by-product, their range statistics;
+     *                 the write pass with JPGPU_SYNC_EMIT=0) + DC sums of scans whose components share their tables
      *   dev_pixel_ms  class finalize + pixel kernels (dequantize, IDCT, upsampling, colour conversion) */
     uint32_t dev_times_valid, _pad;
     double dev_fill_ms, dev_sync_ms, dev_write_ms, dev_pixel_ms;
