@@ -728,18 +728,26 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     static const uint32_t env_sync_min_shift = env_u32("JPGPU_SYNC_MIN_SHIFT", 10, 7, 15);  // smallest chunk: 1 << this many bits
     static const uint32_t env_sync_launches = env_u32("JPGPU_SYNC_LAUNCHES", 10, 1, 64);
     uint32_t sync_blocks = env_sync_blocks, sync_min_shift = env_sync_min_shift, sync_launches = env_sync_launches;
+    // Passes per launch: a call that fills the device runs one pass per launch — launches cost 5 us once a job has settled, and passes
+    // that begin with everything the one before published need fewer of them (4,096 files: 53 ms against 55-57 with two passes per
+    // launch) —; small calls, which wait for every launch, keep two.
+    static const bool iters_pinned = getenv("JPGPU_SYNC_ITERS") != nullptr;
+    static const uint32_t env_iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
+    uint32_t sync_iters = env_iters;
     if (!sync_pinned) {
         uint64_t lanes = 0;  // at the throughput setting
         for (uint32_t k = 0; k < n && images[k].scans; k++)
             for (const host::PlannedScan &ps : *images[k].scans)
-                if (ps.ri == 0 && ps.seg_off.size() == 2) {
+                if (ps.seg_off.size() >= 2) {  // (restart segments go through the chunk decoder too: about as many lanes for the same bytes)
                     uint32_t blocks = 0;
                     for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
-                    const uint32_t bytes = (uint32_t)(ps.seg_off[1] - ps.seg_off[0]);
-                    lanes += huff_sync_chunks(bytes, huff_sync_chunk_shift(bytes, blocks * ps.n_mcu, 48u, 10u));
+                    uint64_t bytes = 0;
+                    for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) bytes += ps.seg_off[sg + 1] - ps.seg_off[sg];
+                    if (bytes < (1u << 28)) lanes += huff_sync_chunks((uint32_t)bytes, huff_sync_chunk_shift((uint32_t)bytes, blocks * ps.n_mcu, 48u, 10u));
                 }
         if (lanes < 16384u) sync_blocks = 12u, sync_min_shift = 9u, sync_launches = 16u;
         else if (lanes < 65536u) sync_blocks = 24u, sync_launches = 12u;
+        else if (!iters_pinned) sync_iters = 1u, sync_launches = 16u;
     }
     // Speculative emission ("one pass less", huff_job.hpp): the sync passes leave entry lists, huff_expand_kernel writes whole
     // blocks — no write pass, and no zero fill for images whose scans cover their planes.  JPGPU_SYNC_EMIT=0: the write pass.
@@ -1100,8 +1108,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     if (phase_times) B_HIP(hipEventRecord(b->ev_phase[1], s));
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
-        static const uint32_t iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
-        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, iters, s,
+        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, sync_iters, s,
                                phase_times ? b->ev_phase[2] : nullptr, nullptr, emitting));
     }
     if (phase_times) {
