@@ -768,7 +768,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     auto dri_geom = [&](const host::PlannedScan &ps) {
         DriGeom g{false, 0u, 0u};
         if (ps.ri == 0 || !emitting || !dri_chunks || ps.seg_off.size() < 4 || all_slots >= (1u << 29)) return g;
-        bool uniform = true;
+        bool uniform = ps.ncomp > 1;
         uint32_t blocks = 0;
         for (uint32_t c = 0; c < ps.ncomp; c++) {
             blocks += ps.comp[c].h * ps.comp[c].v;

@@ -217,7 +217,7 @@ inline void huff_sync_finish_job(HuffSyncJob &j) {
             bpm++;
         }
     j.bpm = bpm;
-    j.uniform = 1;
+    j.uniform = j.ncomp > 1u ? 1u : 0u;  // (one component: every block is its block — nothing to be unsure about)
     for (uint32_t c = 1; c < j.ncomp; c++)
         if (j.comp[c].dc != j.comp[0].dc || j.comp[c].ac != j.comp[0].ac) j.uniform = 0;
 }

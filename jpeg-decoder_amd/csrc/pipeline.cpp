@@ -440,6 +440,7 @@ static bool one_lane_per_segment(const jpgpu::host::PlannedScan &ps) {
     if (ps.ri == 0) return false;
     const char *e_dri = getenv("JPGPU_DRI_CHUNKS"), *e_emit = getenv("JPGPU_SYNC_EMIT");
     if ((e_dri && atoi(e_dri) == 0) || (e_emit && atoi(e_emit) == 0) || ps.seg_off.size() < 4) return true;
+    if (ps.ncomp == 1) return false;
     for (uint32_t c = 1; c < ps.ncomp; c++)
         if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) return false;
     return true;

@@ -137,7 +137,7 @@ int emu_huff_covered(const uint8_t* data, size_t len) {
     if (!fe.plan_device_scans(scans)) return -1;
     for (const PlannedScan& ps : scans) {
         if (ps.ri != 0) {  // restart segments: only when they go through the chunk decoder (emission on: not uniform, two segments or more)
-            bool mixed_tables = false;
+            bool mixed_tables = ps.ncomp == 1;
             for (uint32_t c = 1; c < ps.ncomp; c++)
                 if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) mixed_tables = true;
             if (!mixed_tables || !g_dri_chunks || ps.seg_off.size() < 4) return 0;
@@ -180,7 +180,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
         }
         if (status & 1u) continue;
         // restart-marker streams through the chunk decoder (batch.cpp, dri_geom): with emission, not for uniform scans, >= 2 segments
-        bool dri_chunked = false;
+        bool dri_chunked = ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4 && ps.ncomp == 1;
         if (ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4)
             for (uint32_t c = 1; c < ps.ncomp; c++)
                 if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) dri_chunked = true;
