@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3prof2; rm -rf $O; mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -n 2 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -n 2 | tee $O/smoke.txt
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python bench.py --force-dist --no-e2e --no-k4096 --no-cpu-baseline --no-classes > $O/bench_force_dist.json 2> $O/bench_force_dist.err
@@ -39,6 +40,7 @@ python tools/prof_summary.py $O/pipe256_pmc1 $O/pipe256_fetch $O/pipe256_write $
 # the same call as the pipeline splits it by default (two sub-batches of 128) and 4096 files: per-sub-batch device timeline
 JPGPU_PIPE_TRACE=1 JPGPU_BATCH_KERNEL_TIMES=1 timeout 300 python tools/e2e_bench.py --images 4096 --device-entropy --no-download --rounds 3 > $O/trace4096.txt 2>&1
 # other sampling kinds through the same route
+for r in 1 4; do timeout 300 python tools/e2e_bench.py --images 1024 --device-entropy --no-download --rounds 4 --restart-rows $r 2>/dev/null | tail -1 >> $O/e2e_other_kinds.jsonl; done
 for s in 4:4:4 4:2:2; do timeout 200 python tools/e2e_bench.py --images 1024 --device-entropy --no-download --rounds 4 --subsampling $s 2>/dev/null | tail -1 >> $O/e2e_other_kinds.jsonl; done
 timeout 200 python tools/e2e_bench.py --images 1024 --device-entropy --no-download --rounds 4 --file tests/golden/benches/tower_grayscale.jpg 2>/dev/null | tail -1 >> $O/e2e_other_kinds.jsonl
 timeout 200 python tools/e2e_bench.py --images 1024 --device-entropy --no-download --rounds 4 --file tests/golden/reftest/rgb.jpg 2>/dev/null | tail -1 >> $O/e2e_other_kinds.jsonl
