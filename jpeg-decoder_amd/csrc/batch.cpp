@@ -711,7 +711,7 @@ struct LaunchClock {  // JPGPU_PIPE_TRACE: where a slow launch spent its time (h
 
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream,
-                                       DeviceScratch *scratch) {
+                                       DeviceScratch *scratch, bool alone) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
     LaunchClock clk;
     int rc = use_device(b->device, b->err);
@@ -752,7 +752,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     // Speculative emission ("one pass less", huff_job.hpp): the sync passes leave entry lists, huff_expand_kernel writes whole
     // blocks — no write pass, and no zero fill for images whose scans cover their planes.  JPGPU_SYNC_EMIT=0: the write pass.
     static const bool emitting = env_u32("JPGPU_SYNC_EMIT", 1, 0, 1) != 0;
-    static const uint32_t sync_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
+    static const bool tail_pinned = getenv("JPGPU_SYNC_TAIL") != nullptr;
+    static const uint32_t env_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
+    const uint32_t sync_tail = (alone && !tail_pinned) ? 8u : env_tail;
+    if (alone && !iters_pinned) sync_iters = env_iters;
     // Restart-marker streams through the chunk decoder (huff_job.hpp, HuffSyncJob::seg_chunks): every segment gets chunk slots of
     // its own.  Not for `uniform` scans (their DC sums run over whole planes), not without emission.  JPGPU_DRI_CHUNKS=0: one lane
     // per segment as in rounds 1-3 (huff_segments_kernel).

@@ -68,13 +68,16 @@ struct DeviceEntropyImage {
 // `scratch`: optional device-only work space of the chunk decoder (per-chunk states, emission buffers: ~16 bytes per byte of
 // entropy-coded data) owned by the caller and shared by all launches it enqueues on the SAME stream — they run one after the
 // other there; without it every batch keeps its own (32 sub-batches of a 4,096-file call: 27 GB instead of 7).
+// `alone`: the launch has the device to itself (a call with one or two sub-batches): what counts is how long its passes take one
+// after the other, not how much work they are — the first sync pass walks whole chunks (fewer lanes re-run in the later,
+// chain-bound passes: sync passes of 256 files 2.9 -> 2.5 ms) and launches keep two passes each.
 struct DeviceScratch {
     uint8_t *d = nullptr;
     size_t cap = 0;
 };
 int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                 const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
-                                void *copy_stream = nullptr, DeviceScratch *scratch = nullptr);
+                                void *copy_stream = nullptr, DeviceScratch *scratch = nullptr, bool alone = false);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 bool batch_phase_times(jpgpu_batch *b, float ms[4]);  // JPGPU_BATCH_KERNEL_TIMES, batch.cpp
 bool batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]);  // (+ JPGPU_PIPE_TRACE) event times relative to ref's first event

@@ -802,7 +802,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         const double l0 = now_ms();
                         okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
                                                                  p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
-                                                                 &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute]) == JPGPU_OK;
+                                                                 &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u) == JPGPU_OK;
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         // The pixel kernels follow at once on the same stream: the classes of the decoded coefficients are a
                         // by-product of the write pass and stay on the device (range_stats.hpp), so nothing has to come
