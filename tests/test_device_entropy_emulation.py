@@ -213,7 +213,8 @@ def test_encoder_written_streams_without_restart_markers(case, launch_shape, emi
 def test_damaged_restart_streams_never_disagree_silently(emission):
     """Mutations inside the entropy data of DRI streams: not eligible, or flagged, or identical to the host."""
     pytest.importorskip("PIL")
-    seeds = [open(os.path.join(R.GOLDEN, "reftest/restarts.jpg"), "rb").read(), _pil_jpeg(96, 64, "4:2:0", 2, 0),
+    seeds = [open(os.path.join(R.GOLDEN, "reftest/restarts.jpg"), "rb").read(), _pil_jpeg(96, 64, "4:2:0", 2, 0), _pil_jpeg(320, 240, "4:2:0", 0, 1),
+             _pil_jpeg(200, 150, "4:4:4", 0, 2, gray=True),
              open(os.path.join(R.GOLDEN, "reftest/mozilla/jpg-size-33x33.jpg"), "rb").read(), open(os.path.join(R.GOLDEN, "benches/tower.jpg"), "rb").read()]
     rng = np.random.default_rng(9)
     outcomes = {"host": 0, "flag": 0, "same": 0}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzzing on the GPU: damaged variants of eight base streams (with / without restart markers, gray, RGB,
+"""Differential fuzzing on the GPU: damaged variants of twelve base streams (with / without restart markers, gray, RGB,
 optimised tables) in ONE pipeline call with the entropy decoding forced onto the device; every result — pixels or the kind of
 error — must equal the oracle's.  python tools/fuzz_gpu.py <seed> <variants per base>  (run on the GPU box; prints "bad 0")."""
 import sys, os, io
@@ -10,7 +10,9 @@ import jpeg_decoder_amd as J
 from PIL import Image
 def pil(w,h,sub,gray=False,q=85,**kw):
     buf=io.BytesIO(); rgb=synth.synthetic_rgb(w,h,seed=w+h); Image.fromarray(rgb[...,0] if gray else rgb).save(buf,format="JPEG",quality=q,subsampling=sub,**kw); return buf.getvalue()
-bases=[open(os.path.join(R.GOLDEN,"benches/tower.jpg"),"rb").read(), pil(96,64,"4:2:0"), pil(200,120,"4:4:4",q=95), pil(150,90,"4:2:0",gray=True), open(os.path.join(R.GOLDEN,"reftest/rgb.jpg"),"rb").read(), pil(96,64,"4:2:0",restart_marker_blocks=5), pil(320,240,"4:2:2",restart_marker_rows=1), pil(640,480,"4:2:0",optimize=True)]
+bases=[open(os.path.join(R.GOLDEN,"benches/tower.jpg"),"rb").read(), pil(96,64,"4:2:0"), pil(200,120,"4:4:4",q=95), pil(150,90,"4:2:0",gray=True), open(os.path.join(R.GOLDEN,"reftest/rgb.jpg"),"rb").read(), pil(96,64,"4:2:0",restart_marker_blocks=5), pil(320,240,"4:2:2",restart_marker_rows=1), pil(640,480,"4:2:0",optimize=True),
+       # restart streams whose segments span several chunks of the chunk decoder (round 3: every segment in chunk slots of its own), gray ones too
+       pil(640,480,"4:2:0",restart_marker_rows=1), pil(640,480,"4:2:0",restart_marker_rows=4), pil(400,300,"4:4:4",gray=True,restart_marker_rows=1), pil(1280,720,"4:2:0",restart_marker_blocks=20)]
 rng=np.random.default_rng(int(sys.argv[1])); per=int(sys.argv[2])
 files=[]
 for base in bases:
