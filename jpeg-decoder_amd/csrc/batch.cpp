@@ -757,7 +757,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const uint32_t sync_tail = (alone && !tail_pinned) ? 8u : env_tail;
     if (alone && !iters_pinned) sync_iters = env_iters;
     // Restart-marker streams through the chunk decoder (huff_job.hpp, HuffSyncJob::seg_chunks): every segment gets chunk slots of
-    // its own.  Not for `uniform` scans (their DC sums run over whole planes), not without emission.  JPGPU_DRI_CHUNKS=0: one lane
+    // its own (`uniform` scans too: huff_dc_prefix_kernel starts its sums again at every segment).  Not without emission.  JPGPU_DRI_CHUNKS=0: one lane
     // per segment as in rounds 1-3 (huff_segments_kernel).
     static const bool dri_chunks = env_u32("JPGPU_DRI_CHUNKS", 1, 0, 1) != 0;
     struct DriGeom {
@@ -771,13 +771,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     auto dri_geom = [&](const host::PlannedScan &ps) {
         DriGeom g{false, 0u, 0u};
         if (ps.ri == 0 || !emitting || !dri_chunks || ps.seg_off.size() < 4 || all_slots >= (1u << 29)) return g;
-        bool uniform = ps.ncomp > 1;
         uint32_t blocks = 0;
-        for (uint32_t c = 0; c < ps.ncomp; c++) {
-            blocks += ps.comp[c].h * ps.comp[c].v;
-            if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) uniform = false;
-        }
-        if (uniform) return g;
+        for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
         uint64_t stuffed = 0;
         uint32_t longest = 0;
         for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {

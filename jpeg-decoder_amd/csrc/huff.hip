@@ -592,13 +592,18 @@ constexpr uint32_t DC_NT = 1024, DC_E = 8;
 
 __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob *__restrict__ jobs) {
     __shared__ uint32_t wave_tot[DC_NT / 64u];
+    __shared__ uint32_t s_all[DC_NT * DC_E];  // restart intervals: the tile's running sums, for the value just before a segment's first block
     const HuffSyncJob &job = jobs[blockIdx.y];
     const uint32_t c = blockIdx.x;
     if (c >= job.ncomp || *job.status != 0u || !job.uniform) return;  // (other scans: the write pass stored DC values)
     const HuffScanComp sc = job.comp[c];
     const uint32_t hv = sc.h * sc.v, n = job.n_mcu * hv, cols = job.cols;
     const uint32_t q0 = job.q[c][0];
-    uint32_t carry = 0, max_dc = 0;  // (the write pass of such a scan left the DC coefficients out of its range statistics)
+    // With restart markers the predictor starts again at every segment (src/decoder.rs:928-931): element x of the component's
+    // blocks in stream order belongs to the segment that starts at element (x / P) * P, P = blocks of this component per
+    // restart interval, and its value is the running sum minus the running sum just before that element.
+    const uint32_t P = job.n_seg > 1u ? job.ri * hv : 0u;
+    uint32_t carry = 0, carry_b = 0, max_dc = 0;  // carry_b: the running sum just before the segment that holds the tile's first element
     for (uint32_t base = 0; base < n; base += DC_NT * DC_E) {
         const uint32_t s0 = base + threadIdx.x * DC_E;
         JP_GLOBAL int16_t *addr[DC_E];
@@ -642,13 +647,28 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
             total += t;
         }
         const uint32_t off = carry + before + incl - d[DC_E - 1u];
+        if (P) {
+#pragma unroll
+            for (uint32_t e = 0; e < DC_E; e++) s_all[threadIdx.x * DC_E + e] = d[e] + off;
+            __syncthreads();
+        }
 #pragma unroll
         for (uint32_t e = 0; e < DC_E; e++)
             if (addr[e]) {
-                const int32_t v = (int16_t)(uint16_t)(d[e] + off);
+                uint32_t sum = d[e] + off;
+                if (P) {
+                    const uint32_t first = ((s0 + e) / P) * P;  // the segment's first element
+                    sum -= first == 0u ? 0u : (first > base ? s_all[first - 1u - base] : (first == base ? carry : carry_b));
+                }
+                const int32_t v = (int16_t)(uint16_t)sum;
                 *addr[e] = (int16_t)v;
                 max_dc = max(max_dc, (uint32_t)(v < 0 ? -v : v) * q0);
             }
+        if (P) {  // for the next tile: the running sum just before the segment its first element lies in
+            const uint32_t next = base + DC_NT * DC_E, first = (next / P) * P;
+            if (first > base && first < next) carry_b = s_all[first - 1u - base];
+            else if (first == base) carry_b = carry;
+        }
         carry += total;
         __syncthreads();
     }

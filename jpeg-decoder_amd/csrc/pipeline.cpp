@@ -434,16 +434,12 @@ static void back_to_the_host(jpgpu_pipeline *p, uint32_t i, const uint8_t *const
     }
 }
 
-// Restart-marker scans that still take one lane per segment (huff_segments_kernel): scans whose components all share their tables,
-// single-segment scans, and everything when the chunk slots or the emission are switched off (batch.cpp, dri_geom).
+// Restart-marker scans that still take one lane per segment (huff_segments_kernel): single-segment scans, and everything when the
+// chunk slots or the emission are switched off (batch.cpp, dri_geom).
 static bool one_lane_per_segment(const jpgpu::host::PlannedScan &ps) {
     if (ps.ri == 0) return false;
     const char *e_dri = getenv("JPGPU_DRI_CHUNKS"), *e_emit = getenv("JPGPU_SYNC_EMIT");
-    if ((e_dri && atoi(e_dri) == 0) || (e_emit && atoi(e_emit) == 0) || ps.seg_off.size() < 4) return true;
-    if (ps.ncomp == 1) return false;
-    for (uint32_t c = 1; c < ps.ncomp; c++)
-        if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) return false;
-    return true;
+    return (e_dri && atoi(e_dri) == 0) || (e_emit && atoi(e_emit) == 0) || ps.seg_off.size() < 4;
 }
 
 static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {

@@ -137,10 +137,7 @@ int emu_huff_covered(const uint8_t* data, size_t len) {
     if (!fe.plan_device_scans(scans)) return -1;
     for (const PlannedScan& ps : scans) {
         if (ps.ri != 0) {  // restart segments: only when they go through the chunk decoder (emission on: not uniform, two segments or more)
-            bool mixed_tables = ps.ncomp == 1;
-            for (uint32_t c = 1; c < ps.ncomp; c++)
-                if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) mixed_tables = true;
-            if (!mixed_tables || !g_dri_chunks || ps.seg_off.size() < 4) return 0;
+            if (!g_dri_chunks || ps.seg_off.size() < 4) return 0;
         }
         HuffSyncJob sj;
         memset(&sj, 0, sizeof(sj));
@@ -180,10 +177,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
         }
         if (status & 1u) continue;
         // restart-marker streams through the chunk decoder (batch.cpp, dri_geom): with emission, not for uniform scans, >= 2 segments
-        bool dri_chunked = ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4 && ps.ncomp == 1;
-        if (ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4)
-            for (uint32_t c = 1; c < ps.ncomp; c++)
-                if (ps.comp[c].dc != ps.comp[0].dc || ps.comp[c].ac != ps.comp[0].ac) dri_chunked = true;
+        const bool dri_chunked = ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4;
         if (ps.ri == 0 || dri_chunked) {  // the self-synchronising chunk decoder, passes run one after the other
             HuffSyncLds* S = new HuffSyncLds;
             HuffSyncJob& sj = S->job;
@@ -327,6 +321,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 uint16_t acc = 0;
                 for (uint32_t m = 0; m < sj.n_mcu; m++)
                     for (uint32_t sub = 0; sub < hv; sub++) {
+                        if (sj.n_seg > 1u && sub == 0 && m % sj.ri == 0) acc = 0;  // (a restart: the predictor starts again)
                         const uint32_t my = m / sj.cols, mx = m - my * sj.cols, vp = sub / sc.h, hp = sub - vp * sc.h;
                         int16_t* blk = sc.dst + ((size_t)(my * sc.v + vp) * sc.block_w + (mx * sc.h + hp)) * 64u;
                         acc = (uint16_t)(acc + (uint16_t)blk[0]);

@@ -415,3 +415,27 @@ def test_more_long_code_prefixes_than_second_level_tables(emission):
     hdesc, hcoefs = _host(data)
     assert st == 0, hex(st)
     assert np.array_equal(planes[0], hcoefs[0])
+
+
+@pytest.mark.parametrize("case", [(160, 120, {"restart_marker_rows": 1}), (97, 61, {"restart_marker_blocks": 7}), (320, 200, {"restart_marker_rows": 2})],
+                         ids=lambda c: f"{c[0]}x{c[1]}-" + "-".join(f"{k[15:]}{v}" for k, v in c[2].items()))
+def test_restart_streams_whose_components_share_their_tables(case, emission):
+    """CMYK as Pillow writes it: four components, one pair of Huffman tables — a `uniform` scan (the chunk decoder cannot tell
+    the blocks of an MCU apart, DC values are summed per plane afterwards) — with restart markers: the sums start again at
+    every segment (huff_dc_prefix_kernel's restart intervals; the one-lane-per-segment decoder when emission is off)."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    w, h, kw = case
+    rgb = synth.synthetic_rgb(w, h, seed=w + 7 * h)
+    buf = io.BytesIO()
+    Image.fromarray(np.concatenate([rgb, rgb[..., :1]], axis=2), mode="CMYK").save(buf, format="JPEG", quality=88, **kw)
+    data = buf.getvalue()
+    got = _device(data)
+    assert got is not None
+    st, desc, planes, _ns, n_seg = got
+    assert st == 0 and n_seg > 1 and desc.ncomp == 4
+    hdesc, hcoefs = _host(data)
+    for c in range(desc.ncomp):
+        assert np.array_equal(planes[c], hcoefs[c]), c
+    _check_range_by_product(desc, planes)

@@ -158,10 +158,9 @@ def test_pipeline_device_entropy_decoder_matches_host_path(monkeypatch):
     assert p.kernel_path == "fused420"
     _check([f"same-{i}" for i in range(9)], same, out)
     assert p.timings()["images_device_entropy"] == 9
-    # without the override: restart streams whose components have tables of their own — and gray ones — go through the chunk decoder
-    # (every segment in chunk slots of its own) and cost what plain streams cost: they stay on the device; a few small CMYK restart
-    # streams (four components sharing one pair of tables: the scan is `uniform`, one lane per segment, which pays off with many images
-    # only) are kept on the host by the cost model
+    # without the override: restart streams go through the chunk decoder (every segment in chunk slots of its own) and cost what
+    # plain streams cost — they stay on the device, gray ones and those whose components share their tables (CMYK as Pillow writes
+    # it: `uniform` scans, DC values summed per plane and per segment afterwards) included
     monkeypatch.delenv("JPGPU_PIPE_FORCE_DEVICE")
     gray = [_pil_restart(320, 240, "4:4:4", 1, 0, gray=True, seed=s) for s in range(3)]
     mixed = same + [_pil_plain(320, 240, "4:2:0", seed=s) for s in range(3)] + gray
@@ -173,13 +172,13 @@ def test_pipeline_device_entropy_decoder_matches_host_path(monkeypatch):
     import synth
     cmyk = []
     for sd in range(9):
-        rgb = synth.synthetic_rgb(320, 240, seed=40 + sd)
+        rgb = synth.synthetic_rgb(320 + 8 * sd, 240, seed=40 + sd)
         buf = io.BytesIO()
-        Image.fromarray(np.concatenate([rgb, rgb[..., :1]], axis=2), mode="CMYK").save(buf, format="JPEG", quality=85, restart_marker_rows=1)
+        Image.fromarray(np.concatenate([rgb, rgb[..., :1]], axis=2), mode="CMYK").save(buf, format="JPEG", quality=85, **({"restart_marker_rows": 1 + sd % 3} if sd % 2 else {"restart_marker_blocks": 5 + sd}))
         cmyk.append(buf.getvalue())
     out = p.decode(cmyk + mixed[9:12], device_entropy=True)
     _check([f"cmyk-{i}" for i in range(12)], cmyk + mixed[9:12], out)
-    assert p.timings()["images_device_entropy"] == 3, p.timings()
+    assert p.timings()["images_device_entropy"] == 12 and p.timings()["images_device_rejected"] == 0, p.timings()
     p.close()
 
 
