@@ -126,6 +126,11 @@ enum {
 int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out);
 void jpgpu_pipeline_destroy(jpgpu_pipeline *p);
 const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p);
+/* Decoder::scale (src/decoder.rs:278-290) for every image of the calls that follow: each image is decoded at the smallest of the
+ * DCT scales 1/8, 1/4, 1/2, 1 whose output is at least requested_width x requested_height (choose_idct_size, src/idct.rs:14-28) —
+ * per image, as N decoders on which scale() was called would; jpgpu_pipeline_image_info then reports the scaled size.
+ * 0 x 0: full size again (the default). */
+int jpgpu_pipeline_set_scale(jpgpu_pipeline *p, uint16_t requested_width, uint16_t requested_height);
 /* The streams must stay valid during the call only.  Returns JPGPU_OK if the machinery worked, even
  * when individual images failed. */
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n_images,

@@ -312,6 +312,7 @@ struct jpgpu_pipeline {
     bool downloaded = false;  // the last call copied the pixels to host memory
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t compute[kComputeStreams] = {};
+    uint16_t req_w = 0, req_h = 0;  // jpgpu_pipeline_set_scale (0 x 0: full size)
     uint32_t n_compute = kComputeStreamsDefault;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob, up to kComputeStreams)
     jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
@@ -515,6 +516,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
             Frontend &fe = *p->fes[i];
             fe.read_info();
+            if (p->req_w | p->req_h) {  // Decoder::scale: the IDCT size of this image (the coefficients are the same at every scale)
+                uint16_t ow, oh;
+                fe.scale(p->req_w, p->req_h, ow, oh);
+            }
             p->infos[i] = fe.info();
             jpgpu_image_desc d;
             memset(&d, 0, sizeof(d));
@@ -1021,6 +1026,12 @@ int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t i, uint8_t *dst, size_t 
     return rc;
 }
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return p ? p->path.c_str() : ""; }
+int jpgpu_pipeline_set_scale(jpgpu_pipeline *p, uint16_t requested_width, uint16_t requested_height) {
+    if (!p) return JPGPU_ERR_FORMAT;
+    p->req_w = requested_width;
+    p->req_h = requested_height;
+    return JPGPU_OK;
+}
 int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t) {
     if (!p || !t) return JPGPU_ERR_FORMAT;
     *t = p->t;

@@ -31,14 +31,16 @@ class Pipeline:
 
     __del__ = close
 
-    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False):
+    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False, scale=None):
         """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
         ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``); dense=True sends all
         64 coefficients of every block over PCIe instead of the compact form (same pixels, A/B switch); device_entropy=True
         (the default here; JPGPU_PIPELINE_DEVICE_ENTROPY in the C API) decodes 8-bit sequential Huffman streams (one scan with all components; with or without restart markers) on the
         GPU, all other streams — and any the device decoder flags — on the host as usual; progressive_deltas=True accumulates
-        the coefficients of progressive streams on the device, scan by scan (same pixels; A/B switch)."""
+        the coefficients of progressive streams on the device, scan by scan (same pixels; A/B switch); scale=(w, h): every image as
+        after ``Decoder.scale(w, h)`` (the smallest DCT scale whose output is at least w x h; ``info(i)`` gives the scaled size)."""
         L = N.lib()
+        check(L.jpgpu_pipeline_set_scale(self._h, *((int(scale[0]), int(scale[1])) if scale else (0, 0))), b"set_scale")
         bufs = [bytes(s.read() if hasattr(s, "read") else s) for s in streams]
         n = len(bufs)
         ptrs = (C.c_char_p * max(n, 1))(*bufs)  # the bytes objects' own buffers (alive in `bufs` during the call): no copies

@@ -433,3 +433,27 @@ def test_pipeline_device_entropy_under_other_settings(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _OTHER_SETTINGS_SCRIPT, root], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_pipeline_scaled_decodes():
+    """Decoder::scale for a whole call (jpgpu_pipeline_set_scale): every image at the DCT scale its own size and the requested one give
+    (choose_idct_size, src/idct.rs:14-28) — mixed sizes, samplings and routes (device entropy, restart markers, progressive on the
+    host) in one call, against the oracle's scale() + decode(); and full size again afterwards."""
+    pytest.importorskip("PIL")
+    names = ["benches/tower.jpg", "reftest/rgb.jpg", "benches/tower_grayscale.jpg", "benches/tower_progressive.jpg", "reftest/restarts.jpg",
+             "reftest/mozilla/jpg-cmyk-1.jpg", "reftest/mozilla/jpg-size-33x33.jpg"]
+    files = [open(os.path.join(R.GOLDEN, n), "rb").read() for n in names]
+    files += [_pil_plain(640, 480, "4:2:0", seed=1), _pil_plain(641, 479, "4:2:2", seed=2), _pil_plain(320, 200, "4:4:4", seed=3), _pil_restart(400, 304, "4:2:0", 1, 0)]
+    names += ["pil-640x480-420", "pil-641x479-422", "pil-320x200-444", "pil-restart"]
+    p = J.Pipeline(threads=8)
+    for req in [(100, 75), (250, 167), (63, 42), (1, 1), (2000, 2000)]:
+        out = p.decode(files, device_entropy=True, scale=req)
+        for i, (n, f, got) in enumerate(zip(names, files, out)):
+            want = O.decode(f, scale_to=req)
+            assert not isinstance(got, Exception), (n, req, got)
+            assert np.array_equal(got, want.pixels), (n, req)
+            inf = p.info(i)
+            assert (inf.width, inf.height) == (want.width, want.height), (n, req, inf)
+    out = p.decode(files, device_entropy=True)  # (the request does not stick: scale=None is full size)
+    _check(names, files, out)
+    p.close()

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--sleep", type=float, default=0.0, help="seconds to idle between rounds")
     ap.add_argument("--progressive-deltas", action="store_true", help="accumulate progressive streams on the device, scan by scan (JPGPU_PIPELINE_PROGRESSIVE_DELTAS)")
     ap.add_argument("--dense", action="store_true", help="send dense coefficient planes (A/B against the compact transport)")
+    ap.add_argument("--scale", default=None, help="WxH: Decoder::scale for every image (jpgpu_pipeline_set_scale)")
     ap.add_argument("--file", default=None, help="use this JPEG (replicated) instead of the synthetic images")
     args = ap.parse_args()
     from PIL import Image
@@ -52,7 +53,8 @@ def main():
     import time
     for r in range(args.rounds):
         time.sleep(args.sleep)
-        out = p.decode(files, download=not args.no_download, dense=args.dense, device_entropy=args.device_entropy, progressive_deltas=args.progressive_deltas)
+        out = p.decode(files, download=not args.no_download, dense=args.dense, device_entropy=args.device_entropy, progressive_deltas=args.progressive_deltas,
+                       scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None)
         bad = [o for o in out if isinstance(o, Exception)]
         assert not bad, bad[:1]
         t = p.timings()
@@ -65,7 +67,8 @@ def main():
     t0 = time.perf_counter()
     reps = 6
     for _ in range(reps):
-        p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy, progressive_deltas=args.progressive_deltas)
+        p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy, progressive_deltas=args.progressive_deltas,
+                 scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None)
     wall = time.perf_counter() - t0
     r1 = resource.getrusage(resource.RUSAGE_SELF)
     sustained = reps * args.images / wall
