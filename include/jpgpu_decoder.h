@@ -131,6 +131,9 @@ const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p);
  * per image, as N decoders on which scale() was called would; jpgpu_pipeline_image_info then reports the scaled size.
  * 0 x 0: full size again (the default). */
 int jpgpu_pipeline_set_scale(jpgpu_pipeline *p, uint16_t requested_width, uint16_t requested_height);
+/* Decoder::set_color_transform (src/decoder.rs:158-161) for every image of the calls that follow: one of the JPGPU_CT_* values of
+ * jpgpu.h instead of what determine_color_transform finds per image; a negative value: per image again (the default). */
+int jpgpu_pipeline_set_color_transform(jpgpu_pipeline *p, int color_transform);
 /* The streams must stay valid during the call only.  Returns JPGPU_OK if the machinery worked, even
  * when individual images failed. */
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n_images,

@@ -313,6 +313,7 @@ struct jpgpu_pipeline {
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t compute[kComputeStreams] = {};
     uint16_t req_w = 0, req_h = 0;  // jpgpu_pipeline_set_scale (0 x 0: full size)
+    int color_transform = -1;       // jpgpu_pipeline_set_color_transform (< 0: what every image says itself)
     uint32_t n_compute = kComputeStreamsDefault;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob, up to kComputeStreams)
     jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
@@ -516,6 +517,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
             Frontend &fe = *p->fes[i];
             fe.read_info();
+            if (p->color_transform >= 0) fe.set_color_transform(p->color_transform);
             if (p->req_w | p->req_h) {  // Decoder::scale: the IDCT size of this image (the coefficients are the same at every scale)
                 uint16_t ow, oh;
                 fe.scale(p->req_w, p->req_h, ow, oh);
@@ -547,6 +549,28 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     Frontend probe(data[i], len[i], Frontend::Borrowed{});
                     probe.read_info();
                     probe.decode_to(nothing);  // throws what the image's decode() would throw
+                }
+            }
+            {
+                // what compute_image would refuse for this frame (an impossible sampling combination, a colour function whose row
+                // copy would overrun: src/decoder.rs:1300-1336, src/upsampler.rs:20-45) fails THIS image here — a sub-batch is
+                // created from frames the pixel backend takes, one refused frame must not fail its neighbours
+                jpgpu::ImageJob probe;
+                uint8_t *no_planes[4] = {nullptr, nullptr, nullptr, nullptr};
+                size_t out_len = 0;
+                std::string why;
+                const int v = jpgpu::build_image_job(d.components, d.ncomp, no_planes, d.out_w, d.out_h, d.color_transform, nullptr, probe, out_len, why);
+                if (v != JPGPU_OK) {
+                    // (the reference decodes the entropy data before it gets to compute_image: a stream that is broken as well reports that)
+                    struct Nothing : RowSink {
+                        void start(uint32_t, const jpgpu_component &, const uint16_t *) override {}
+                        void append_row(uint32_t, const int16_t *, size_t) override {}
+                        void finish(uint32_t, uint32_t) override {}
+                    } nothing;
+                    Frontend whole(data[i], len[i], Frontend::Borrowed{});
+                    whole.read_info();
+                    whole.decode_to(nothing);
+                    throw DecodeError{v, why};
                 }
             }
             cand[i] = d;
@@ -1026,6 +1050,11 @@ int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t i, uint8_t *dst, size_t 
     return rc;
 }
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return p ? p->path.c_str() : ""; }
+int jpgpu_pipeline_set_color_transform(jpgpu_pipeline *p, int color_transform) {
+    if (!p) return JPGPU_ERR_FORMAT;
+    p->color_transform = color_transform;
+    return JPGPU_OK;
+}
 int jpgpu_pipeline_set_scale(jpgpu_pipeline *p, uint16_t requested_width, uint16_t requested_height) {
     if (!p) return JPGPU_ERR_FORMAT;
     p->req_w = requested_width;

@@ -457,3 +457,23 @@ def test_pipeline_scaled_decodes():
     out = p.decode(files, device_entropy=True)  # (the request does not stick: scale=None is full size)
     _check(names, files, out)
     p.close()
+
+
+def test_pipeline_color_transform_override():
+    """Decoder::set_color_transform for a whole call (jpgpu_pipeline_set_color_transform): three-component files read as RGB or left
+    untransformed, against the oracle's decodes with the same override; per image again afterwards."""
+    pytest.importorskip("PIL")
+    files = [open(os.path.join(R.GOLDEN, n), "rb").read() for n in ["benches/tower.jpg", "reftest/rgb.jpg"]] + [_pil_plain(320, 200, "4:4:4", seed=3), _pil_plain(640, 480, "4:2:0", seed=1)]
+    p = J.Pipeline(threads=4)
+    for ct in ["RGB", "None", "YCbCr"]:
+        out = p.decode(files, device_entropy=True, color_transform=ct)
+        for k, (f, got) in enumerate(zip(files, out)):
+            try:
+                want = O.decode(f, color_transform=ct.upper())
+            except O.OracleError as e:  # ("None" on a subsampled frame: the reference's row copy would overrun — that image fails, alone)
+                assert isinstance(got, J.Error) and got.kind == e.kind, (k, ct, got, e)
+                continue
+            assert not isinstance(got, Exception), (k, ct, got)
+            assert np.array_equal(got, want.pixels), (k, ct)
+    _check([str(k) for k in range(len(files))], files, p.decode(files, device_entropy=True))
+    p.close()
