@@ -134,6 +134,9 @@ int jpgpu_pipeline_set_scale(jpgpu_pipeline *p, uint16_t requested_width, uint16
 /* Decoder::set_color_transform (src/decoder.rs:158-161) for every image of the calls that follow: one of the JPGPU_CT_* values of
  * jpgpu.h instead of what determine_color_transform finds per image; a negative value: per image again (the default). */
 int jpgpu_pipeline_set_color_transform(jpgpu_pipeline *p, int color_transform);
+/* Decoder::set_max_decoding_buffer_size (src/decoder.rs:162-165): an image whose decoded size exceeds max_bytes fails with the
+ * reference's error; SIZE_MAX: no limit (the default). */
+int jpgpu_pipeline_set_max_decoding_buffer_size(jpgpu_pipeline *p, size_t max_bytes);
 /* The streams must stay valid during the call only.  Returns JPGPU_OK if the machinery worked, even
  * when individual images failed. */
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n_images,

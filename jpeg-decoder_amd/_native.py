@@ -161,6 +161,7 @@ _PROTOS = {
     "jpgpu_pipeline_kernel_path": (C.c_char_p, [C.c_void_p]),
     "jpgpu_pipeline_set_scale": (C.c_int, [C.c_void_p, C.c_uint16, C.c_uint16]),
     "jpgpu_pipeline_set_color_transform": (C.c_int, [C.c_void_p, C.c_int]),
+    "jpgpu_pipeline_set_max_decoding_buffer_size": (C.c_int, [C.c_void_p, C.c_size_t]),
     "jpgpu_pipeline_download": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "jpgpu_pipeline_last_timings": (C.c_int, [C.c_void_p, C.POINTER(PipelineTimings)]),
 }

@@ -314,6 +314,7 @@ struct jpgpu_pipeline {
     hipStream_t compute[kComputeStreams] = {};
     uint16_t req_w = 0, req_h = 0;  // jpgpu_pipeline_set_scale (0 x 0: full size)
     int color_transform = -1;       // jpgpu_pipeline_set_color_transform (< 0: what every image says itself)
+    size_t max_bytes = SIZE_MAX;    // jpgpu_pipeline_set_max_decoding_buffer_size
     uint32_t n_compute = kComputeStreamsDefault;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob, up to kComputeStreams)
     jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
@@ -332,11 +333,13 @@ struct Redecode {
     std::string error;
 };
 
+static void read_info_with_options(const jpgpu_pipeline *p, Frontend &fe);
+
 static void host_redecode_stage(jpgpu_pipeline *p, SubBatch &sb, Redecode &r, const uint8_t *data, size_t len) {
     const uint32_t bi = (uint32_t)p->slot[r.image];
     try {
         Frontend fe(data, len, Frontend::Borrowed{});
-        fe.read_info();
+        read_info_with_options(p, fe);
         r.nc = fe.ncomp();
         size_t total = 0;
         for (uint32_t c = 0; c < r.nc; c++) {
@@ -429,10 +432,22 @@ static void back_to_the_host(jpgpu_pipeline *p, uint32_t i, const uint8_t *const
     p->plans[i].clear();  // (the planning pass spent the front-end: a fresh one for the host path)
     try {
         p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
-        p->fes[i]->read_info();
+        read_info_with_options(p, *p->fes[i]);
     } catch (const DecodeError &e) {
         p->status[i] = e.code;
         p->errors[i] = e.message;
+    }
+}
+
+// Decoder options of the pipeline (jpgpu_pipeline_set_*), for every front-end it creates: what read_info() + the setters + scale()
+// leave in a reference Decoder
+static void read_info_with_options(const jpgpu_pipeline *p, Frontend &fe) {
+    fe.read_info();
+    if (p->max_bytes != SIZE_MAX) fe.set_max_decoding_buffer_size(p->max_bytes);
+    if (p->color_transform >= 0) fe.set_color_transform(p->color_transform);
+    if (p->req_w | p->req_h) {  // Decoder::scale: the IDCT size of this image (the coefficients are the same at every scale)
+        uint16_t ow, oh;
+        fe.scale(p->req_w, p->req_h, ow, oh);
     }
 }
 
@@ -516,12 +531,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         try {
             p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
             Frontend &fe = *p->fes[i];
-            fe.read_info();
-            if (p->color_transform >= 0) fe.set_color_transform(p->color_transform);
-            if (p->req_w | p->req_h) {  // Decoder::scale: the IDCT size of this image (the coefficients are the same at every scale)
-                uint16_t ow, oh;
-                fe.scale(p->req_w, p->req_h, ow, oh);
-            }
+            read_info_with_options(p, fe);
             p->infos[i] = fe.info();
             jpgpu_image_desc d;
             memset(&d, 0, sizeof(d));
@@ -547,7 +557,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         void finish(uint32_t, uint32_t) override {}
                     } nothing;
                     Frontend probe(data[i], len[i], Frontend::Borrowed{});
-                    probe.read_info();
+                    read_info_with_options(p, probe);
                     probe.decode_to(nothing);  // throws what the image's decode() would throw
                 }
             }
@@ -568,7 +578,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         void finish(uint32_t, uint32_t) override {}
                     } nothing;
                     Frontend whole(data[i], len[i], Frontend::Borrowed{});
-                    whole.read_info();
+                    read_info_with_options(p, whole);
                     whole.decode_to(nothing);
                     throw DecodeError{v, why};
                 }
@@ -584,7 +594,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 } else {
                     p->plans[i].clear();
                     p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
-                    p->fes[i]->read_info();
+                    read_info_with_options(p, *p->fes[i]);
                 }
             }
             if (p->fes[i]) p->has_frame[i] = p->fes[i]->has_frame() ? 1 : 0;
@@ -1050,6 +1060,11 @@ int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t i, uint8_t *dst, size_t 
     return rc;
 }
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return p ? p->path.c_str() : ""; }
+int jpgpu_pipeline_set_max_decoding_buffer_size(jpgpu_pipeline *p, size_t max_bytes) {
+    if (!p) return JPGPU_ERR_FORMAT;
+    p->max_bytes = max_bytes;
+    return JPGPU_OK;
+}
 int jpgpu_pipeline_set_color_transform(jpgpu_pipeline *p, int color_transform) {
     if (!p) return JPGPU_ERR_FORMAT;
     p->color_transform = color_transform;

@@ -32,7 +32,7 @@ class Pipeline:
 
     __del__ = close
 
-    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False, scale=None, color_transform=None):
+    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False, scale=None, color_transform=None, max_decoding_buffer_size=None):
         """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
         ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``); dense=True sends all
         64 coefficients of every block over PCIe instead of the compact form (same pixels, A/B switch); device_entropy=True
@@ -40,8 +40,10 @@ class Pipeline:
         GPU, all other streams — and any the device decoder flags — on the host as usual; progressive_deltas=True accumulates
         the coefficients of progressive streams on the device, scan by scan (same pixels; A/B switch); scale=(w, h): every image as
         after ``Decoder.scale(w, h)`` (the smallest DCT scale whose output is at least w x h; ``info(i)`` gives the scaled size);
-        color_transform: every image as after ``Decoder.set_color_transform(...)`` ("None", "Grayscale", "RGB", "YCbCr", "CMYK", "YCCK")."""
+        color_transform: every image as after ``Decoder.set_color_transform(...)`` ("None", "Grayscale", "RGB", "YCbCr", "CMYK", "YCCK");
+        max_decoding_buffer_size: ``Decoder.set_max_decoding_buffer_size`` (images that would need more fail with the reference's error)."""
         L = N.lib()
+        check(L.jpgpu_pipeline_set_max_decoding_buffer_size(self._h, (1 << 64) - 1 if max_decoding_buffer_size is None else int(max_decoding_buffer_size)), b"set_max")
         check(L.jpgpu_pipeline_set_color_transform(self._h, color_transform_id(color_transform) if color_transform is not None else -1), b"set_color_transform")
         check(L.jpgpu_pipeline_set_scale(self._h, *((int(scale[0]), int(scale[1])) if scale else (0, 0))), b"set_scale")
         bufs = [bytes(s.read() if hasattr(s, "read") else s) for s in streams]

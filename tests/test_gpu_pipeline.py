@@ -477,3 +477,22 @@ def test_pipeline_color_transform_override():
             assert np.array_equal(got, want.pixels), (k, ct)
     _check([str(k) for k in range(len(files))], files, p.decode(files, device_entropy=True))
     p.close()
+
+
+def test_pipeline_max_decoding_buffer_size():
+    """Decoder::set_max_decoding_buffer_size for a whole call: images whose decoded bytes exceed the limit fail with the reference's
+    message (src/decoder.rs: "size of decoded image exceeds maximum allowed size"), their neighbours decode — on both entropy routes."""
+    pytest.importorskip("PIL")
+    files = [_pil_plain(64, 48, "4:2:0", seed=1), _pil_plain(640, 480, "4:2:0", seed=2), _pil_plain(100, 100, "4:4:4", gray=True, seed=3), _pil_plain(320, 200, "4:4:4", seed=4)]
+    sizes = [64 * 48 * 3, 640 * 480 * 3, 100 * 100, 320 * 200 * 3]
+    p = J.Pipeline(threads=4)
+    for de in (True, False):
+        for limit in (64 * 48 * 3, 100 * 100, 320 * 200 * 3, 640 * 480 * 3 - 1):
+            out = p.decode(files, device_entropy=de, max_decoding_buffer_size=limit)
+            for f, sz, got in zip(files, sizes, out):
+                if sz > limit:
+                    assert isinstance(got, J.Error) and "exceeds maximum allowed size" in str(got), (de, limit, sz, got)
+                else:
+                    assert np.array_equal(got, O.decode(f).pixels), (de, limit, sz)
+    _check([str(k) for k in range(4)], files, p.decode(files, device_entropy=True))
+    p.close()
