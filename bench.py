@@ -243,9 +243,11 @@ def k_4096(J, torch, O, variants, device_index, dev, stream, w, h, digest, n_img
         sh.close()
 
 
-def e2e_files(synth, w, h, encoder, distinct=4):
-    """`distinct` baseline 4:2:0 q85 files of the bench's synthetic image (seeds 0x5EED + k); -> (files, who wrote them)."""
+def e2e_files(synth, w, h, encoder, distinct=4, restart_rows=0):
+    """`distinct` baseline 4:2:0 q85 files of the bench's synthetic image (seeds 0x5EED + k); -> (files, who wrote them).
+    restart_rows: a restart marker every that many MCU rows (DRI)."""
     rgbs = [synth.synthetic_rgb(w, h, seed=0x5EED + k) for k in range(distinct)]
+    rst = f"a restart marker every {restart_rows} MCU row(s)" if restart_rows else "no restart markers"
     if encoder in ("auto", "pillow"):
         try:
             import io
@@ -254,15 +256,18 @@ def e2e_files(synth, w, h, encoder, distinct=4):
             out = []
             for rgb in rgbs:
                 buf = io.BytesIO()
-                Image.fromarray(rgb).save(buf, format="JPEG", quality=85, subsampling="4:2:0")
+                Image.fromarray(rgb).save(buf, format="JPEG", quality=85, subsampling="4:2:0",
+                                          **({"restart_marker_rows": restart_rows} if restart_rows else {}))
                 out.append(buf.getvalue())
-            return out, f"Pillow {PIL.__version__} (libjpeg-turbo), quality 85, 4:2:0, default (Annex K) Huffman tables, no restart markers"
+            if not restart_rows or all(b"\xff\xdd\x00\x04" in d[:1024] for d in out):  # (an older Pillow ignores the keyword)
+                return out, f"Pillow {PIL.__version__} (libjpeg-turbo), quality 85, 4:2:0, default (Annex K) Huffman tables, {rst}"
         except ImportError:
             if encoder == "pillow":
                 raise
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import baseline_encoder as E
-    return [E.encode_rgb(rgb, 85, "420") for rgb in rgbs], "tools/baseline_encoder.py (this repo), quality 85, 4:2:0, Annex K Huffman tables, no restart markers"
+    ri = restart_rows * ((w + 15) // 16)
+    return [E.encode_rgb(rgb, 85, "420", ri) for rgb in rgbs], f"tools/baseline_encoder.py (this repo), quality 85, 4:2:0, Annex K Huffman tables, {rst}"
 
 
 def e2e_block(J, O, synth, w, h, sizes, encoder):
@@ -320,6 +325,32 @@ def e2e_block(J, O, synth, w, h, sizes, encoder):
         finally:
             del os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"]
         files_for_cpu = [distinct[i % len(distinct)] for i in range(256)]
+        # The same images written with a restart marker after every MCU row (DRI): the chunk decoder takes each restart interval as
+        # its own run of chunks (csrc/huff_job.hpp huff_chunk_span) — same kernels, no host entropy decoding either.
+        if sizes and max(sizes) >= 1024:
+            try:
+                rfiles, rwho = e2e_files(synth, w, h, encoder, restart_rows=1)
+                rwant = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in rfiles]
+                n = 1024
+                files = [rfiles[i % len(rfiles)] for i in range(n)]
+                best = None
+                for r in range(4):
+                    res = p.decode(files, download=False, device_entropy=True)
+                    bad = [x for x in res if isinstance(x, Exception)]
+                    if bad:
+                        raise bad[0]
+                    t = p.timings()
+                    if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
+                        best = t
+                okr = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == rwant[i % len(rfiles)] for i in (0, 1, n // 2, n - 1))
+                out["restart_every_mcu_row_1024"] = {
+                    "images": n, "input": f"{len(rfiles)} distinct {w}x{h} files, repeated; written by {rwho}",
+                    "total_ms": round(best["total_ms"], 3), "images_per_s": round(n / best["total_ms"] * 1e3, 1),
+                    "value": round(n * w * h / 1e6 / best["total_ms"] * 1e3, 1), "unit": "MP/s",
+                    "images_device_entropy": int(best["images_device_entropy"]), "images_device_rejected": int(best["images_device_rejected"]),
+                    "threads": int(best["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(okr)}
+            except Exception as e:  # noqa: BLE001 (this entry only)
+                out["restart_every_mcu_row_1024"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # BASELINE configs[3]: benches/tower_progressive.jpg (512 x 512 progressive, 10 scans) x 256.  Progressive scans are
         # entropy-decoded on the HOST (refinement scans depend on the accumulated coefficients: DESIGN.md 7), the finished
         # planes go up in the compact form and the device does the pixel work: this figure is bound by the host's cores.

@@ -288,7 +288,7 @@ struct SubBatch {
 // streams shared round robin.  Round 3: with 8 sub-batches a call of 4,096 files made four device sub-batches of 1,024, whose
 // write pass took 11 us per image against 7 us in sub-batches of 256 (a 6.4 GB arena per sub-batch instead of 1.6 GB:
 // profiles/round3/08_subbatch_size.txt).
-constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 16, kComputeStreamsDefault = 16;
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 32, kComputeStreamsDefault = 16;  // (more than 16 in use is slower: 24 streams 109 ms, 32 streams 75 ms per 4,096 files against 53-60, whatever GPU_MAX_HW_QUEUES says — tools/gpu_streams.sh)
 
 }  // namespace
 
@@ -398,8 +398,8 @@ int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) 
     p->stage_pool.reset(new Pool(std::max<uint32_t>(2u, n_threads / 2u)));
     p->subs.resize(kMaxSubBatches);
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
-    for (uint32_t k = 0; k < kComputeStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->compute[k], hipStreamNonBlocking));
     if (const char *e = getenv("JPGPU_PIPE_STREAMS")) p->n_compute = (uint32_t)std::min<long>(std::max<long>(atol(e), 1), kComputeStreams);
+    for (uint32_t k = 0; k < p->n_compute; k++) P_HIP(hipStreamCreateWithFlags(&p->compute[k], hipStreamNonBlocking));
     for (SubBatch &sb : p->subs)
         for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipEventCreateWithFlags(&sb.ready[k], hipEventDisableTiming));
     return JPGPU_OK;
@@ -996,7 +996,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
 
     // 4. drain: whatever kernels and downloads are still in flight
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamSynchronize(p->copy_streams[k]));
-    for (uint32_t k = 0; k < kComputeStreams; k++) P_HIP(hipStreamSynchronize(p->compute[k]));
+    for (uint32_t k = 0; k < p->n_compute; k++) P_HIP(hipStreamSynchronize(p->compute[k]));
     const double t4 = now_ms();
     uint64_t pixel_bytes = 0;
     uint32_t okc = 0;
