@@ -190,15 +190,8 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
         if (need) todo[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
         __syncthreads();
         HuffRange unused;
-#if JPGPU_EMIT_MODE == 4
-        __shared__ uint32_t emit_stage[HUFF_EMIT_ROUND][SYNC_NT];
-        if (threadIdx.x < total)
-            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused, nullptr, 0u,
-                                                (JP_LDS uint32_t *)&emit_stage[0][threadIdx.x], SYNC_NT);
-#else
         if (threadIdx.x < total)
             published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);
-#endif
         __syncthreads();
     }
     const uint32_t n_pub = (uint32_t)__syncthreads_count(published);

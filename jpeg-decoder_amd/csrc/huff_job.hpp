@@ -189,7 +189,7 @@ constexpr uint32_t HUFF_EMIT_DC = 0x80000000u, HUFF_EMIT_OVERFLOW = 0xffffffffu;
 // start inside its chunk (the last one may end up to 31 bits beyond it).  Multiple of 4 entries: buffers stay 16-byte aligned.
 inline uint32_t huff_emit_stride(uint32_t chunk_shift) {
     const uint32_t bits = 1u << chunk_shift;
-    return (bits / 2u + bits / 128u + 32u + 3u) & ~3u;  // (+ 8: a lane writes whole rounds of eight entries, huff_emit_flush)
+    return (bits / 2u + bits / 128u + 32u + 3u) & ~3u;  // (a multiple of 4: the lists are written 16 bytes at a time, huff_emit_entry)
 }
 
 // Chunk size.  A lane that starts at a wrong place finds the symbol boundaries within a few symbols, the block boundaries at

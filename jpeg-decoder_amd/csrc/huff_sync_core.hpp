@@ -165,57 +165,24 @@ struct HuffRange {
 // component — the chunk's predictor is added by the expansion — or the difference itself in a `uniform` scan) and per
 // non-zero AC coefficient, in stream order.  Bits 22-23: the component of the scan the block belongs to — as far as the lane knows
 // it: in a `uniform` scan it does not (the expansion derives it from the block number there).
-// How the entries reach the buffer (A/B builds: -DJPGPU_EMIT_MODE=...).  On gfx9 a wait for a load is a wait for every store issued
-// before it, and the loop waits for its stream fetch in nearly every step:
-//   0  one 4-byte store per entry (sync passes 3.85 ms per 256 1080p images; 2.72 without emission)
-//   1  no stores at all: what the bookkeeping alone costs (2.87 ms; wrong output)
-//   2  four entries gathered in registers, one 16-byte store (3.20 ms): still a store instruction in nearly every step of the wave,
-//      some lane's group is always full
-//   3  (removed) = 0 with the stream read through the LDS ring: 5.16 ms — 60 kB of LDS, two workgroups per CU
-//   5  = 2 with two groups of four per store round (the first waits in registers for the second): half as many partial-line
-//      writes meet a line that has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds:
-//      the counters show 2.9 GB fetched and 1.4 GB written per 256 images for 0.44 GB of entries)
-//   4  entries collected in LDS (eight per lane) and written every eighth step by ALL lanes at once, 32 bytes each whatever
-//      they hold (what lies beyond a lane's entries is overwritten by its next round): one step in eight has stores in front of
-//      its wait — measured 3.48-3.54 ms, no better than 2 (the stores' cost is not the waits behind them); kept as an A/B build
-#ifndef JPGPU_EMIT_MODE
-#define JPGPU_EMIT_MODE 5
-#endif
-constexpr uint32_t HUFF_EMIT_ROUND = 8;  // steps between two flushes = entries a lane can collect (a step emits at most one)
-typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));  // (a list position is a multiple of 4 bytes, not of 16)
+// How the entries reach the buffer: four gathered in registers, two such groups per store round (the first waits in registers for
+// the second), two 16-byte stores one after the other.  On gfx9 a wait for a load is a wait for every store issued before it, and
+// the loop waits for its stream fetch in nearly every step; what was measured before settling on this (sync passes per 256 1080p
+// images; 2.72 ms without emission; profiles/round3/14_emission_path.txt, tools/gpu_r3m.sh):
+//   one 4-byte store per entry                                   3.85 ms
+//   no stores at all (what the bookkeeping alone costs)          2.87 ms
+//   one 16-byte store per four entries                           3.20 ms
+//   two groups of four per store round (this)                    3.20 ms, fabric traffic -25 %: half as many partial-line writes meet
+//       a line that has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds)
+//   the stream read through an LDS ring                          5.16 ms (60 kB of LDS: two workgroups per CU)
+//   entries collected in LDS, written every eighth step by all lanes at once   3.48-3.54 ms (the stores' cost is not the waits behind them)
 struct HuffEmit {
     JP_GLOBAL uint32_t *buf = nullptr;  // nullptr: this run emits nothing
     uint32_t n = 0, cap = 0, lead = 0xffffffffu;  // entries so far (counts on past `cap`: overflow), capacity (a multiple of 4), entries before the first DC
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // modes 2, 5: the last entries, youngest in s3, not yet stored
-    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;      // mode 5: the complete group of four before them, waiting for its neighbour
-    JP_LDS uint32_t *stage = nullptr;             // mode 4: this lane's HUFF_EMIT_ROUND words in LDS, `stage_stride` words apart (entry-major:
-    uint32_t stage_stride = 1;                    //   lane-major rows of 32 bytes put every fourth lane on the same bank) ...
-    uint32_t stored = 0;                          // ... hold entries stored .. n - 1
-    bool overflow = false;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // the last entries, youngest in s3, not yet stored
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;      // the complete group of four before them, waiting for its neighbour
 };
-// mode 4: what the lane has collected -> its buffer.  Called by all lanes of the wave in the same step (and once at the end of a run).
-__device__ __forceinline__ void huff_emit_flush(HuffEmit &em) {
-#if JPGPU_EMIT_MODE == 4
-    if (!em.buf || em.n == em.stored) return;
-    if (em.stored + HUFF_EMIT_ROUND <= em.cap) {
-#ifdef JPGPU_HOST_EMULATION
-        for (uint32_t j = 0; j < HUFF_EMIT_ROUND; j++) em.buf[em.stored + j] = em.stage[j * em.stage_stride];
-#else
-        const JP_LDS uint32_t *src = em.stage;
-        const uint32_t st = em.stage_stride;
-        *(JP_GLOBAL v4u_a4 *)(em.buf + em.stored) = v4u{src[0], src[st], src[2u * st], src[3u * st]};
-        if (em.n - em.stored > 4u) *(JP_GLOBAL v4u_a4 *)(em.buf + em.stored + 4u) = v4u{src[4u * st], src[5u * st], src[6u * st], src[7u * st]};
-#endif
-    } else {
-        em.overflow = true;
-    }
-    em.stored = em.n;
-#endif
-}
 __device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
-#if JPGPU_EMIT_MODE == 4
-    em.stage[((em.n - em.stored) & (HUFF_EMIT_ROUND - 1u)) * em.stage_stride] = e;
-#elif JPGPU_EMIT_MODE == 5
     em.s0 = em.s1;
     em.s1 = em.s2;
     em.s2 = em.s3;
@@ -228,32 +195,17 @@ __device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
             *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
         }
     }
-#elif JPGPU_EMIT_MODE == 2
-    em.s0 = em.s1;
-    em.s1 = em.s2;
-    em.s2 = em.s3;
-    em.s3 = e;
-    if ((em.n & 3u) == 3u && em.n < em.cap) *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
-#elif JPGPU_EMIT_MODE == 1
-    em.s3 ^= e;
-#else
-    if (em.n < em.cap) em.buf[em.n] = e;
-#endif
     em.n++;
 }
-// the entries of an incomplete group of four, at the end of a run
+// the entries of an incomplete round, at the end of a run
 __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
-#if JPGPU_EMIT_MODE == 4
-    huff_emit_flush(em);
-    if (em.overflow) em.n = em.cap + 1u;
-#elif JPGPU_EMIT_MODE == 5
     if (em.buf && em.n <= em.cap) {
         uint32_t first = em.n & ~7u;
         if (em.n & 4u) {  // a complete group waits in t
             *(JP_GLOBAL v4u *)(em.buf + first) = v4u{em.t0, em.t1, em.t2, em.t3};
             first += 4u;
         }
-        const uint32_t r = em.n & 3u;
+        const uint32_t r = em.n & 3u;  // (branches, not selects: the compiler turned selects into a table in scratch memory)
         if (r == 1u) {
             em.buf[first] = em.s3;
         } else if (r == 2u) {
@@ -265,23 +217,6 @@ __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
             em.buf[first + 2u] = em.s3;
         }
     }
-#elif JPGPU_EMIT_MODE == 2
-    const uint32_t r = em.n & 3u, first = em.n - r;
-    if (em.buf && r && em.n <= em.cap) {  // (branches, not selects: the compiler turned the selects into a table in scratch memory)
-        if (r == 1u) {
-            em.buf[first] = em.s3;
-        } else if (r == 2u) {
-            em.buf[first] = em.s2;
-            em.buf[first + 1u] = em.s3;
-        } else {
-            em.buf[first] = em.s1;
-            em.buf[first + 1u] = em.s2;
-            em.buf[first + 2u] = em.s3;
-        }
-    }
-#elif JPGPU_EMIT_MODE == 1
-    if (em.buf && em.s3 == 0x12345678u) em.buf[0] = em.s3;  // (keeps the bookkeeping alive)
-#endif
 }
 
 template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
@@ -450,13 +385,7 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
     uint32_t badv = 0;
-#if JPGPU_EMIT_MODE == 4
-    uint32_t emit_steps = 0;
-#endif
     while (badv == 0u && huff_bit_pos(b) < limit) {
-#if JPGPU_EMIT_MODE == 4
-        if (EMIT && (++emit_steps & (HUFF_EMIT_ROUND - 1u)) == 0u) huff_emit_flush(em);
-#endif
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
@@ -520,7 +449,7 @@ __device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job,
 
 template <bool WRITE>
 __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
-                                                uint32_t ring_stride = 0, JP_LDS uint32_t *emit_stage = nullptr, uint32_t emit_stage_stride = 1) {
+                                                uint32_t ring_stride = 0) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     const HuffChunkSpan span = huff_chunk_span(job, i);
@@ -584,8 +513,6 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     if (emit) {
         em.buf = (JP_GLOBAL uint32_t *)(job.emit + (size_t)i * job.emit_stride);
         em.cap = job.emit_stride;
-        em.stage = emit_stage;  // (JPGPU_EMIT_MODE 4: HUFF_EMIT_ROUND words of LDS, this lane's own)
-        em.stage_stride = emit_stage_stride;
     }
     if (pos < limit) {
         if (WRITE) pos = huff_run<true, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);

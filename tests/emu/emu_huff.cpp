@@ -265,8 +265,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                             std::copy(prev_pos.begin(), prev_pos.end(), sj.out_pos + first);
                             std::copy(prev_qk.begin(), prev_qk.end(), sj.out_qk + first);
                             HuffRange unused;
-                            alignas(16) uint32_t stage[HUFF_EMIT_ROUND];  // (the lane's LDS words of JPGPU_EMIT_MODE 4)
-                            changed += huff_sync_chunk<false>(*S, i, launch * iters + it, unused, nullptr, 0u, stage, 1u) ? 1u : 0u;
+                            changed += huff_sync_chunk<false>(*S, i, launch * iters + it, unused) ? 1u : 0u;
                             new_pos[i - first] = sj.out_pos[i];
                             new_qk[i - first] = sj.out_qk[i];
                         }
