@@ -337,6 +337,7 @@ struct ExpandLds {
     HuffSyncJob job;
     HuffBlockDst q_dst[16];
     uint32_t wg_rg[2][EXP_WAVES];
+    uint8_t unzig[64];  // an entry carries its coefficient's zig-zag index (one table read less per symbol in the sync passes' chain)
     alignas(16) uint16_t ring[EXP_WAVES][EXP_SLOTS * EXP_SLOT];  // per wave: block images of 136 bytes (8 more than a block: the DC
                                                                  // entries of a run of flat blocks do not all meet in one bank)
 };
@@ -383,7 +384,7 @@ __device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint1
         const uint32_t t = at.q0 + d;
         c = E.job.q_comp[(t - small_div(t, at.bpm, at.inv_bpm) * at.bpm) & 15u] & 3u;
     }
-    const uint32_t z = (ent >> 16) & 63u;
+    const uint32_t z = E.unzig[(ent >> 16) & 63u];
     uint32_t v = ent & 0xffffu;
     if (!UNIFORM && (ent & HUFF_EMIT_DC)) {  // the chunk's running sum + what the chunks before it add up to
         const uint32_t w = c < 2u ? w0 : w1;
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
     for (uint32_t t = lane; t < EXP_SLOTS * EXP_SLOT / 2u; t += 64u) ((JP_LDS uint32_t *)ring)[t] = 0u;
     __syncthreads();
     if (threadIdx.x < 16u) huff_fill_block_dst(E.job, E.q_dst, threadIdx.x);
+    huff_fill_unzigzag((JP_LDS uint8_t *)E.unzig, threadIdx.x);
     __syncthreads();
     const JP_LDS HuffSyncJob &job = E.job;
     // (what steers the wave is the same in all its lanes: kept in scalar registers, branches instead of lane masks)

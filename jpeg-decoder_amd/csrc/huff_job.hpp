@@ -116,7 +116,7 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     // Speculative emission (huff_sync_core.hpp, "one pass less"): from the second sync pass on every lane leaves what it decodes
     // as a list of entries in stream order in its chunk's own buffer; once the segmentation has settled the lists ARE the
     // scan, and huff_expand_kernel turns them into whole blocks (no write pass, no zero fill).  nullptr: write pass instead.
-    uint32_t *emit;         // n_chunks buffers of emit_stride entries: value & 0xffff | natural position << 16 | scan component << 22 | first of a block << 31
+    uint32_t *emit;         // n_chunks buffers of emit_stride entries: value & 0xffff | zig-zag index << 16 | scan component << 22 | first of a block << 31
     uint32_t *emit_cnt;     // per chunk: entries | entries before the first block start << 16 (HUFF_EMIT_OVERFLOW: see there)
     uint32_t emit_stride;
     uint32_t pass0_skip;    // bits of its chunk every lane but the first leaves out in sync pass 0 (huff_sync_chunk)

@@ -197,6 +197,23 @@ __device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
     }
     em.n++;
 }
+// the same for a step that may or may not have an entry (`put`): register selects instead of a divergent region
+__device__ __forceinline__ void huff_emit_entry_if(HuffEmit &em, uint32_t e, bool put) {
+    em.s0 = put ? em.s1 : em.s0;
+    em.s1 = put ? em.s2 : em.s1;
+    em.s2 = put ? em.s3 : em.s2;
+    em.s3 = put ? e : em.s3;
+    const bool first_full = put && (em.n & 7u) == 3u;
+    em.t0 = first_full ? em.s0 : em.t0;
+    em.t1 = first_full ? em.s1 : em.t1;
+    em.t2 = first_full ? em.s2 : em.t2;
+    em.t3 = first_full ? em.s3 : em.t3;
+    if (put && (em.n & 7u) == 7u && em.n < em.cap) {  // two groups, one after the other: the second store finds the line where the first left it
+        *(JP_GLOBAL v4u *)(em.buf + (em.n - 7u)) = v4u{em.t0, em.t1, em.t2, em.t3};
+        *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
+    }
+    em.n += put ? 1u : 0u;
+}
 // the entries of an incomplete round, at the end of a run
 __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
     if (em.buf && em.n <= em.cap) {
@@ -385,7 +402,8 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
     uint32_t badv = 0;
-    while (badv == 0u && huff_bit_pos(b) < limit) {
+    const uint32_t bpm = job.bpm;  // (in a register: the loop's LDS writes keep the compiler from hoisting the read itself)
+    do {  // (the caller has checked pos < limit; one exit, at the bottom: the compiler keeps one set of registers for the loop's values)
         huff_refill<RD>(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
@@ -406,34 +424,33 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
             raw = huff_peek(b, info & SYM_NREAD);
             huff_consume(b, info & SYM_NREAD);
         }
-        const uint32_t nread = info & SYM_NREAD, k0 = k;
+        const uint32_t nread = info & SYM_NREAD;
+        const bool isdc = k == 0u, coef = (info & SYM_COEF) != 0u;
         k += ((info >> SYM_ADV_SHIFT) & SYM_ADV_MASK) + 1u;
         // (a coefficient beyond index 63: only broken streams have it, the host decides — huff_run)
-        badv |= (info & SYM_BAD) | (((info & SYM_COEF) != 0u && k > 64u) ? 1u : 0u);
-        if (badv == 0u) {
-            const bool isdc = k0 == 0u;
-            if (isdc || (EMIT && (info & SYM_COEF) != 0u)) {
-                int32_t val = huff_extend(raw, nread);
-                if (isdc && dc_sums) {  // the chunk's sum of differences so far, per component
-                    dc[c] += (uint32_t)val;
-                    val = (int16_t)(uint16_t)dc[c];
-                }
-                if (EMIT) {
-                    const uint32_t z = L.unzig[isdc ? 0u : k - 1u];  // (unzig[0] = 0)
-                    em.lead = (isdc && em.lead == 0xffffffffu) ? em.n : em.lead;
-                    huff_emit_entry(em, (isdc ? HUFF_EMIT_DC : 0u) | (z << 16) | (c << 22) | (uint32_t)(uint16_t)val);
-                }
-            }
-            if (k >= 64u) {  // end of the block
-                k = 0u;
-                nblk++;
-                last_block_end = huff_bit_pos(b);
-                q = q + 1u == job.bpm ? 0u : q + 1u;
-                qt = L.q_tables[q];
-                c = job.q_comp[q];
-            }
+        badv |= (info & SYM_BAD) | ((coef && k > 64u) ? 1u : 0u);
+        // From here on: selects, not regions (every divergent region is three scalar instructions and a set of register copies
+        // where it joins; the only regions left are the rare ones — DC sums, the store of a full round, the end of a block).
+        int32_t val = huff_extend(raw, nread);
+        if (isdc && dc_sums && badv == 0u) {  // the chunk's sum of differences so far, per component
+            dc[c] += (uint32_t)val;
+            val = (int16_t)(uint16_t)dc[c];
         }
-    }
+        if (EMIT) {
+            const bool put = (isdc || coef) && badv == 0u;
+            em.lead = (put && isdc && em.lead == 0xffffffffu) ? em.n : em.lead;
+            // (k - 1: the zig-zag index of the coefficient just read, 0 for a DC value; the expansion turns it into the natural position)
+            huff_emit_entry_if(em, (isdc ? HUFF_EMIT_DC : 0u) | (((k - 1u) & 63u) << 16) | (c << 22) | (uint32_t)(uint16_t)val, put);
+        }
+        if (k >= 64u && badv == 0u) {  // end of the block
+            k = 0u;
+            nblk++;
+            last_block_end = huff_bit_pos(b);
+            q = q + 1u == bpm ? 0u : q + 1u;
+            qt = L.q_tables[q];
+            c = job.q_comp[q];
+        }
+    } while (badv == 0u && huff_bit_pos(b) < limit);
     bad_out = badv != 0u;
     return huff_bit_pos(b);
 }

@@ -49,7 +49,9 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
             open = false;
         };
         auto put = [&](uint32_t ent) {
-            const uint32_t c = sj.q_comp[blk % sj.bpm], z = (ent >> 16) & 63u;
+            static const uint8_t kUnzig[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                               35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+            const uint32_t c = sj.q_comp[blk % sj.bpm], z = kUnzig[(ent >> 16) & 63u];  // (an entry carries the zig-zag index)
             if (!sj.uniform && c != ((ent >> 22) & 3u)) g_emit_mismatch++;  // (the component the lane wrote into the entry)
             uint32_t v = ent & 0xffffu;
             if ((ent & HUFF_EMIT_DC) && !sj.uniform) v = (v + pred[c]) & 0xffffu;
