@@ -386,7 +386,7 @@ __device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint1
     }
     const uint32_t z = E.unzig[(ent >> 16) & 63u];
     uint32_t v = ent & 0xffffu;
-    if (!UNIFORM && (ent & HUFF_EMIT_DC)) {  // the chunk's running sum + what the chunks before it add up to
+    if (!UNIFORM && huff_entry_is_dc(ent)) {  // the chunk's running sum + what the chunks before it add up to
         const uint32_t w = c < 2u ? w0 : w1;
         v = (v + ((c & 1u) ? w >> 16 : w)) & 0xffffu;
     }
@@ -456,7 +456,7 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
 #pragma unroll
         for (uint32_t r = 0; r < EXP_LOADS; r++) {
             if (e0 + 64u * r >= cnt) break;
-            const bool valid = e0 + 64u * r + lane < cnt, flag = valid && (ent[r] & HUFF_EMIT_DC) != 0u;
+            const bool valid = e0 + 64u * r + lane < cnt, flag = valid && huff_entry_is_dc(ent[r]);
             const uint64_t m = __ballot(flag);
             const uint32_t local = started + (uint32_t)__popcll(m & lt) + (flag ? 1u : 0u) - 1u;  // the entry's block, counted from S
             const uint32_t a = expand_put<UNIFORM>(E, ring, at, valid, ent[r], local, local - base, w0, w1);
@@ -489,7 +489,7 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
     for (uint32_t j = i + 1u; S + last < total && j < seg_end_chunk; j++) {
         const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj);
         const JP_GLOBAL uint32_t *bj = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)j * stride);
-        for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put<UNIFORM>(E, ring, at, true, stream_load(bj + e) & ~HUFF_EMIT_DC, last, last - base, 0u, 0u));
+        for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put<UNIFORM>(E, ring, at, true, stream_load(bj + e), last, last - base, 0u, 0u));
         if (leadj < cntj) break;  // a block starts in chunk j: ours ended there
     }
     __builtin_amdgcn_wave_barrier();

@@ -116,7 +116,7 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     // Speculative emission (huff_sync_core.hpp, "one pass less"): from the second sync pass on every lane leaves what it decodes
     // as a list of entries in stream order in its chunk's own buffer; once the segmentation has settled the lists ARE the
     // scan, and huff_expand_kernel turns them into whole blocks (no write pass, no zero fill).  nullptr: write pass instead.
-    uint32_t *emit;         // n_chunks buffers of emit_stride entries: value & 0xffff | zig-zag index << 16 | scan component << 22 | first of a block << 31
+    uint32_t *emit;         // n_chunks buffers of emit_stride entries: value & 0xffff | zig-zag index << 16 (0: a DC value, the first entry of a block) | scan component << 22
     uint32_t *emit_cnt;     // per chunk: entries | entries before the first block start << 16 (HUFF_EMIT_OVERFLOW: see there)
     uint32_t emit_stride;
     uint32_t pass0_skip;    // bits of its chunk every lane but the first leaves out in sync pass 0 (huff_sync_chunk)
@@ -183,7 +183,12 @@ inline bool huff_scan_covers_planes(const HuffSyncJob &j, const uint32_t block_h
         if (j.cols * j.comp[c].h != j.comp[c].block_w || rows * j.comp[c].v != block_h[c]) return false;
     return true;
 }
-constexpr uint32_t HUFF_EMIT_DC = 0x80000000u, HUFF_EMIT_OVERFLOW = 0xffffffffu;
+constexpr uint32_t HUFF_EMIT_OVERFLOW = 0xffffffffu;
+// An entry with zig-zag index 0 is a DC value — the first entry of its block (AC entries have indices 1..63).
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline bool huff_entry_is_dc(uint32_t ent) { return (ent & 0x3f0000u) == 0u; }
 // Entries a chunk can produce: a DC entry takes at least 1 bit and is followed by an end-of-block code (>= 1 bit) or 63
 // coefficients, an AC entry at least 2 bits (code + magnitude) — at most 64 entries per 127 bits — and the symbols a lane decodes
 // start inside its chunk (the last one may end up to 31 bits beyond it).  Multiple of 4 entries: buffers stay 16-byte aligned.

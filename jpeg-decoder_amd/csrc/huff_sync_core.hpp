@@ -172,7 +172,7 @@ struct HuffRange {
 //   one 4-byte store per entry                                   3.85 ms
 //   no stores at all (what the bookkeeping alone costs)          2.87 ms
 //   one 16-byte store per four entries                           3.20 ms
-//   two groups of four per store round (this)                    3.20 ms, fabric traffic -25 %: half as many partial-line writes meet
+//   two groups of four per store round (this)                    3.20 ms (with the select-only loop of the round's end: 2.25 against 2.35 for one group per store), fabric traffic -25 %: half as many partial-line writes meet
 //       a line that has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds)
 //   the stream read through an LDS ring                          5.16 ms (60 kB of LDS: two workgroups per CU)
 //   entries collected in LDS, written every eighth step by all lanes at once   3.48-3.54 ms (the stores' cost is not the waits behind them)
@@ -430,7 +430,9 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
         // (a coefficient beyond index 63: only broken streams have it, the host decides — huff_run)
         badv |= (info & SYM_BAD) | ((coef && k > 64u) ? 1u : 0u);
         // From here on: selects, not regions (every divergent region is three scalar instructions and a set of register copies
-        // where it joins; the only regions left are the rare ones — DC sums, the store of a full round, the end of a block).
+        // where it joins); the regions left are the DC sums, the store of a full round and the end of a block — turning those into
+        // selects as well (sums as packed 16-bit adds in two registers, table offsets re-read in every step) costs more vector
+        // instructions than it saves scalar ones: sync passes of 256 files 2.44 ms against 2.28.
         int32_t val = huff_extend(raw, nread);
         if (isdc && dc_sums && badv == 0u) {  // the chunk's sum of differences so far, per component
             dc[c] += (uint32_t)val;
@@ -440,7 +442,7 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
             const bool put = (isdc || coef) && badv == 0u;
             em.lead = (put && isdc && em.lead == 0xffffffffu) ? em.n : em.lead;
             // (k - 1: the zig-zag index of the coefficient just read, 0 for a DC value; the expansion turns it into the natural position)
-            huff_emit_entry_if(em, (isdc ? HUFF_EMIT_DC : 0u) | (((k - 1u) & 63u) << 16) | (c << 22) | (uint32_t)(uint16_t)val, put);
+            huff_emit_entry_if(em, (((k - 1u) & 63u) << 16) | (c << 22) | (uint32_t)(uint16_t)val, put);
         }
         if (k >= 64u && badv == 0u) {  // end of the block
             k = 0u;

@@ -54,12 +54,12 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
             const uint32_t c = sj.q_comp[blk % sj.bpm], z = kUnzig[(ent >> 16) & 63u];  // (an entry carries the zig-zag index)
             if (!sj.uniform && c != ((ent >> 22) & 3u)) g_emit_mismatch++;  // (the component the lane wrote into the entry)
             uint32_t v = ent & 0xffffu;
-            if ((ent & HUFF_EMIT_DC) && !sj.uniform) v = (v + pred[c]) & 0xffffu;
+            if (huff_entry_is_dc(ent) && !sj.uniform) v = (v + pred[c]) & 0xffffu;
             cur[z] = (int16_t)(uint16_t)v;
             const int32_t sv = (int16_t)(uint16_t)v;
             const uint32_t a = (uint32_t)(sv < 0 ? -sv : sv) * sj.q[c][z];
             if (blk < total) {
-                if (ent & HUFF_EMIT_DC) {
+                if (huff_entry_is_dc(ent)) {
                     if (!sj.uniform) rg.dc = std::max(rg.dc, a);
                 } else {
                     rg.ac = std::max(rg.ac, a);
@@ -68,7 +68,7 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
         };
         const uint32_t* buf = sj.emit + (size_t)i * sj.emit_stride;
         for (uint32_t e = lead; e < cnt; e++) {
-            if (buf[e] & HUFF_EMIT_DC) {
+            if (huff_entry_is_dc(buf[e])) {
                 flush();
                 memset(cur, 0, sizeof(cur));
                 open = true;
