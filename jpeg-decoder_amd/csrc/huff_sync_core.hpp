@@ -391,7 +391,7 @@ __device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_
 // a pass emits is a template parameter (it is the same for every lane of a launch's iteration), `bad` is a number in a vector
 // register, not a lane mask carried round the loop.  From (pos, q, k) until the bit position reaches `limit`; returns the
 // position reached, q, k, nblk (blocks completed) updated.
-template <bool EMIT>
+template <int EMIT>  // 0: no entries; 1: entries in rounds of eight (a pass of every lane); 2: entry by entry (a late pass: few lanes, the wave's step is what counts)
 __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                                   uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em, uint32_t &last_block_end) {
     const JP_LDS HuffSyncJob &job = L.job;
@@ -442,7 +442,13 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
             const bool put = (isdc || coef) && badv == 0u;
             em.lead = (put && isdc && em.lead == 0xffffffffu) ? em.n : em.lead;
             // (k - 1: the zig-zag index of the coefficient just read, 0 for a DC value; the expansion turns it into the natural position)
-            huff_emit_entry_if(em, (((k - 1u) & 63u) << 16) | (c << 22) | (uint32_t)(uint16_t)val, put);
+            const uint32_t ent = (((k - 1u) & 63u) << 16) | (c << 22) | (uint32_t)(uint16_t)val;
+            if (EMIT == 2) {
+                if (put && em.n < em.cap) em.buf[em.n] = ent;
+                em.n += put ? 1u : 0u;
+            } else {
+                huff_emit_entry_if(em, ent, put);
+            }
         }
         if (k >= 64u && badv == 0u) {  // end of the block
             k = 0u;
@@ -464,6 +470,10 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
 // start states are guesses.  A lane that has decoded from a state WITHOUT emitting still has work when the same state comes
 // round again (QK_EMITTED in in_qk tells).
 constexpr uint32_t QK_EMITTED = 0x80000000u;
+// From this pass on a lane stores its entries one by one (huff_sync_run<2>): few lanes are left, what a late pass costs is the
+// wave's step — 16 vector instructions shorter without the rounds' register shuffling — times the symbols of a chunk (sync passes
+// of 256 files alone 2.24 -> 2.15-2.18 ms; from pass 3 on: 2.19).
+constexpr uint32_t HUFF_LATE_PASS = 2u;
 __device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t pass) { return job.emit != nullptr && pass > 0u; }
 
 template <bool WRITE>
@@ -535,11 +545,12 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     }
     if (pos < limit) {
         if (WRITE) pos = huff_run<true, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
-        else if (emit) pos = huff_sync_run<true>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
-        else pos = huff_sync_run<false>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else if (emit && pass >= HUFF_LATE_PASS) pos = huff_sync_run<2>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else if (emit) pos = huff_sync_run<1>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else pos = huff_sync_run<0>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
     }
     if (!WRITE && job.emit != nullptr) job.blk_end[i] = last_block_end;
-    if (!WRITE) huff_emit_finish(em);
+    if (!WRITE && !(emit && pass >= HUFF_LATE_PASS)) huff_emit_finish(em);  // (a late pass has stored every entry already)
     if (!WRITE && job.emit != nullptr)  // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
         job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
     if (!WRITE && dc_sums) {
