@@ -734,6 +734,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     static const bool iters_pinned = getenv("JPGPU_SYNC_ITERS") != nullptr;
     static const uint32_t env_iters = env_u32("JPGPU_SYNC_ITERS", 2, 1, 8);
     uint32_t sync_iters = env_iters;
+    static const uint32_t env_late = env_u32("JPGPU_SYNC_LATE_PASS", 0, 0, 64);  // (0: chosen here)
+    uint32_t late_pass = env_late ? env_late : HUFF_LATE_PASS;
     if (!sync_pinned) {
         uint64_t lanes = 0;  // at the throughput setting
         for (uint32_t k = 0; k < n && images[k].scans; k++)
@@ -939,6 +941,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 huff_sync_finish_job(*sj);
                 sj->chunk_shift = dg.chunked ? dg.shift : huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
                 sj->pass0_skip = ((1u << sj->chunk_shift) >> 3) * (8u - sync_tail);
+                sj->late_pass = late_pass;
                 // (no restart markers: an upper bound, the staging task sets the real count; restart segments: slots per segment x segments)
                 const uint32_t chunks = dg.chunked ? (uint32_t)(ps.seg_off.size() / 2) * dg.seg_chunks : huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);
                 uint32_t *st = reinterpret_cast<uint32_t *>(xs + xcur);

@@ -124,7 +124,8 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     // starts at a byte boundary with the predictors at zero — so each gets `seg_chunks` chunk slots of its own (chunk i = slot
     // i % seg_chunks of segment i / seg_chunks; slots behind a segment's data stay empty), its first lane starts from the truth,
     // block numbers and DC sums restart per segment.  n_seg <= 1: the one-slot scan of a stream without restart markers.
-    uint32_t seg_chunks, _pad_seg;
+    uint32_t seg_chunks;
+    uint32_t late_pass;     // from this sync pass on a lane stores its entries one by one (huff_sync_core.hpp, huff_sync_run<2>)
 };
 // Where chunk i lies: bits [start, end) of the job's data, whether a segment starts there, which segment it belongs to.
 struct HuffChunkSpan {
@@ -183,7 +184,7 @@ inline bool huff_scan_covers_planes(const HuffSyncJob &j, const uint32_t block_h
         if (j.cols * j.comp[c].h != j.comp[c].block_w || rows * j.comp[c].v != block_h[c]) return false;
     return true;
 }
-constexpr uint32_t HUFF_EMIT_OVERFLOW = 0xffffffffu;
+constexpr uint32_t HUFF_EMIT_OVERFLOW = 0xffffffffu, HUFF_LATE_PASS = 2u;  // (HuffSyncJob::late_pass by default)
 // An entry with zig-zag index 0 is a DC value — the first entry of its block (AC entries have indices 1..63).
 #ifdef __HIPCC__
 __host__ __device__

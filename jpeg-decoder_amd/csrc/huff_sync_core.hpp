@@ -470,10 +470,10 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
 // start states are guesses.  A lane that has decoded from a state WITHOUT emitting still has work when the same state comes
 // round again (QK_EMITTED in in_qk tells).
 constexpr uint32_t QK_EMITTED = 0x80000000u;
-// From this pass on a lane stores its entries one by one (huff_sync_run<2>): few lanes are left, what a late pass costs is the
-// wave's step — 16 vector instructions shorter without the rounds' register shuffling — times the symbols of a chunk (sync passes
-// of 256 files alone 2.24 -> 2.15-2.18 ms; from pass 3 on: 2.19).
-constexpr uint32_t HUFF_LATE_PASS = 2u;
+// From pass HuffSyncJob::late_pass on a lane stores its entries one by one (huff_sync_run<2>): few lanes are left, what a late pass
+// costs is the wave's step — 16 vector instructions shorter without the rounds' register shuffling — times the symbols of a chunk
+// (sync passes of 256 files alone 2.24 -> 2.15-2.18 ms with 2; from pass 3 on: 2.19).  One image through Decoder.decode() measures the
+// same with 1 and with 2 (1080p 1.40-1.50 ms): 2 everywhere (HUFF_LATE_PASS, huff_job.hpp; JPGPU_SYNC_LATE_PASS pins another).
 __device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t pass) { return job.emit != nullptr && pass > 0u; }
 
 template <bool WRITE>
@@ -545,12 +545,12 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     }
     if (pos < limit) {
         if (WRITE) pos = huff_run<true, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
-        else if (emit && pass >= HUFF_LATE_PASS) pos = huff_sync_run<2>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else if (emit && pass >= job.late_pass) pos = huff_sync_run<2>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
         else if (emit) pos = huff_sync_run<1>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
         else pos = huff_sync_run<0>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
     }
     if (!WRITE && job.emit != nullptr) job.blk_end[i] = last_block_end;
-    if (!WRITE && !(emit && pass >= HUFF_LATE_PASS)) huff_emit_finish(em);  // (a late pass has stored every entry already)
+    if (!WRITE && !(emit && pass >= job.late_pass)) huff_emit_finish(em);  // (a late pass has stored every entry already)
     if (!WRITE && job.emit != nullptr)  // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
         job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
     if (!WRITE && dc_sums) {

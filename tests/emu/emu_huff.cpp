@@ -14,6 +14,7 @@ using jpgpu::host::Frontend;
 using jpgpu::host::PlannedScan;
 
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
+static uint32_t g_late = 2;  // HuffSyncJob::late_pass (emu_huff_set_late)
 static uint32_t g_tail = 8;  // eighths of its chunk a lane walks in sync pass 0 (HuffSyncJob::pass0_skip)
 static uint32_t g_dri_chunks = 1, g_dri_shift = 0;  // restart segments in chunk slots (emu_huff_set_dri: on/off, forced chunk size)
 static uint32_t g_emit_mismatch = 0;
@@ -98,6 +99,7 @@ uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return
 
 void emu_huff_set_emit(uint32_t on) { g_emit = on; }
 void emu_huff_set_dri(uint32_t chunks, uint32_t shift) { g_dri_chunks = chunks, g_dri_shift = shift; }
+void emu_huff_set_late(uint32_t pass) { g_late = pass; }
 void emu_huff_set_tail(uint32_t eighths) { g_tail = eighths >= 1 && eighths <= 8 ? eighths : 8; }
 void emu_huff_last_range(uint32_t out[2]) { out[0] = g_range[0], out[1] = g_range[1]; }
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
@@ -221,6 +223,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 sj.n_chunks = huff_sync_chunks(table[1], sj.chunk_shift);
             }
             sj.pass0_skip = ((1u << sj.chunk_shift) >> 3) * (8u - g_tail);
+            sj.late_pass = g_late;
             std::vector<uint32_t> emit_buf, emit_cnt;
             if (g_emit) {
                 sj.emit_stride = huff_emit_stride(sj.chunk_shift);

@@ -45,17 +45,20 @@ def _device(data):
 _device.emit = False
 
 
-@pytest.fixture(params=[(0, 8), (1, 8), (1, 3), (0, 2)], ids=["write-pass", "emission", "emission-tail3", "write-pass-tail2"])
+@pytest.fixture(params=[(0, 8, 2), (1, 8, 2), (1, 3, 2), (0, 2, 2), (1, 3, 1), (1, 8, 1000)],
+                ids=["write-pass", "emission", "emission-tail3", "write-pass-tail2", "emission-tail3-stores-one-by-one", "emission-rounds-of-eight-only"])
 def emission(request):
     """The chunk decoder's two ways to the arena: a write pass after the sync passes, or entries emitted by the sync passes
     themselves and expanded into whole blocks (HuffSyncJob::emit); and how much of its chunk a lane walks in the first
-    sync pass (eighths: HuffSyncJob::pass0_skip)."""
+    sync pass (eighths: HuffSyncJob::pass0_skip); from which pass on a lane stores its entries one by one (HuffSyncJob::late_pass)."""
     emu.lib().emu_huff_set_emit(request.param[0])
     emu.lib().emu_huff_set_tail(request.param[1])
+    emu.lib().emu_huff_set_late(request.param[2])
     _device.emit = bool(request.param[0])
     yield request.param
     emu.lib().emu_huff_set_emit(0)
     emu.lib().emu_huff_set_tail(8)
+    emu.lib().emu_huff_set_late(2)
     _device.emit = False
 
 
