@@ -209,8 +209,9 @@ __device__ __forceinline__ void huff_emit_entry_if(HuffEmit &em, uint32_t e, boo
     em.t2 = first_full ? em.s2 : em.t2;
     em.t3 = first_full ? em.s3 : em.t3;
     if (put && (em.n & 7u) == 7u && em.n < em.cap) {  // two groups, one after the other: the second store finds the line where the first left it
-        *(JP_GLOBAL v4u *)(em.buf + (em.n - 7u)) = v4u{em.t0, em.t1, em.t2, em.t3};
-        *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
+        JP_GLOBAL v4u *dst = (JP_GLOBAL v4u *)(em.buf + (em.n - 7u));  // (one address, the second store at offset 16)
+        dst[0] = v4u{em.t0, em.t1, em.t2, em.t3};
+        dst[1] = v4u{em.s0, em.s1, em.s2, em.s3};
     }
     em.n += put ? 1u : 0u;
 }
