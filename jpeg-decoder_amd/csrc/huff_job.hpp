@@ -195,7 +195,7 @@ inline bool huff_entry_is_dc(uint32_t ent) { return (ent & 0x3f0000u) == 0u; }
 // start inside its chunk (the last one may end up to 31 bits beyond it).  Multiple of 4 entries: buffers stay 16-byte aligned.
 inline uint32_t huff_emit_stride(uint32_t chunk_shift) {
     const uint32_t bits = 1u << chunk_shift;
-    return (bits / 2u + bits / 128u + 32u + 3u) & ~3u;  // (a multiple of 4: the lists are written 16 bytes at a time, huff_emit_entry)
+    return (bits / 2u + bits / 128u + 32u + 3u) & ~3u;  // (a multiple of 4: the lists are written 16 bytes at a time, huff_emit_entry_if)
 }
 
 // Chunk size.  A lane that starts at a wrong place finds the symbol boundaries within a few symbols, the block boundaries at

@@ -172,8 +172,9 @@ struct HuffRange {
 //   one 4-byte store per entry                                   3.85 ms
 //   no stores at all (what the bookkeeping alone costs)          2.87 ms
 //   one 16-byte store per four entries                           3.20 ms
-//   two groups of four per store round (this)                    3.20 ms (with the select-only loop of the round's end: 2.25 against 2.35 for one group per store), fabric traffic -25 %: half as many partial-line writes meet
-//       a line that has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds)
+//   two groups of four per store round (this)                    3.20 ms, fabric traffic -25 %: half as many partial-line writes meet a line that
+//       has left the L2 in between (200 k lanes x one open 128-byte line each is more than the L2 holds); with the select-only loop
+//       of the round's end 2.25 ms against 2.35 for one group per store
 //   the stream read through an LDS ring                          5.16 ms (60 kB of LDS: two workgroups per CU)
 //   entries collected in LDS, written every eighth step by all lanes at once   3.48-3.54 ms (the stores' cost is not the waits behind them)
 struct HuffEmit {
@@ -182,22 +183,7 @@ struct HuffEmit {
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // the last entries, youngest in s3, not yet stored
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;      // the complete group of four before them, waiting for its neighbour
 };
-__device__ __forceinline__ void huff_emit_entry(HuffEmit &em, uint32_t e) {
-    em.s0 = em.s1;
-    em.s1 = em.s2;
-    em.s2 = em.s3;
-    em.s3 = e;
-    if ((em.n & 3u) == 3u) {
-        if ((em.n & 4u) == 0u) {
-            em.t0 = em.s0, em.t1 = em.s1, em.t2 = em.s2, em.t3 = em.s3;
-        } else if (em.n < em.cap) {  // two groups, one after the other: the second store finds the line where the first left it
-            *(JP_GLOBAL v4u *)(em.buf + (em.n - 7u)) = v4u{em.t0, em.t1, em.t2, em.t3};
-            *(JP_GLOBAL v4u *)(em.buf + (em.n - 3u)) = v4u{em.s0, em.s1, em.s2, em.s3};
-        }
-    }
-    em.n++;
-}
-// the same for a step that may or may not have an entry (`put`): register selects instead of a divergent region
+// One step of a lane: an entry, or none (`put`) — register selects, not a divergent region (a wave would enter it in every step).
 __device__ __forceinline__ void huff_emit_entry_if(HuffEmit &em, uint32_t e, bool put) {
     em.s0 = put ? em.s1 : em.s0;
     em.s1 = put ? em.s2 : em.s1;
