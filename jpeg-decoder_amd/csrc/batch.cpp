@@ -760,6 +760,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     // Speculative emission ("one pass less", huff_job.hpp): the sync passes leave entry lists, huff_expand_kernel writes whole
     // blocks — no write pass, and no zero fill for images whose scans cover their planes.  JPGPU_SYNC_EMIT=0: the write pass.
     static const bool emitting = env_u32("JPGPU_SYNC_EMIT", 1, 0, 1) != 0;
+    bool low_table_ids = env_u32("JPGPU_SYNC_COMPACT_TABLES", 1, 0, 1) != 0;  // until a scan uses a Huffman table id above 1 (huff_sync_pass_kernel<4>)
     static const bool tail_pinned = getenv("JPGPU_SYNC_TAIL") != nullptr;
     static const uint32_t env_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
     const uint32_t sync_tail = (alone && !tail_pinned) ? 8u : env_tail;
@@ -931,6 +932,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 comp[c].v = ps.comp[c].v;
                 comp[c].dc = ps.comp[c].dc;
                 comp[c].ac = ps.comp[c].ac;
+                if (ps.comp[c].dc > 1u || ps.comp[c].ac > 1u) low_table_ids = false;
             }
             if (sj) {
                 memset(sj, 0, sizeof(*sj));
@@ -1116,7 +1118,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
     {
         B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, sync_iters, s,
-                               phase_times ? b->ev_phase[2] : nullptr, nullptr, emitting));
+                               phase_times ? b->ev_phase[2] : nullptr, nullptr, emitting, low_table_ids));
     }
     if (phase_times) {
         B_HIP(hipEventRecord(b->ev_phase[3], s));

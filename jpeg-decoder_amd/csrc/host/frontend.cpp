@@ -949,7 +949,7 @@ struct Frontend::Impl {
                 memset(set.get(), 0, sizeof(*set));
                 for (int t = 0; t < 8; t++) {
                     const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
-                    DevHuffTable &d = set->t[t];
+                    DevHuffTable &d = set->t[huff_table_slot(t < 4 ? 0u : 1u, (uint32_t)(t & 3))];
                     HuffTable &k = last->key[t];
                     k.present = h.present;
                     if (!h.present) continue;

@@ -64,7 +64,7 @@ struct PlannedScan {
     struct Comp {
         uint32_t frame_index, block_w, h, v, dc, ac;
     } comp[4];
-    // dc 0..3, ac 0..3 as they stand at this scan, in device form.  Shared and immutable: files of one encoder repeat their tables,
+    // dc 0..3, ac 0..3 as they stand at this scan, in device form (slot of a table: huff_table_slot).  Shared and immutable: files of one encoder repeat their tables,
     // the planner hands every scan that uses the set it built last the same object (equal pointers = equal tables; 27 kB not
     // copied per file), and the staging code uploads a set once per run of scans that share it.
     struct TableSet {

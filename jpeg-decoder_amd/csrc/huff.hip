@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void range_scan_one_kernel(const int16_t *__re
 // and clears slot (t+1) % 3, so the host can enqueue a fixed number of launches without looking at the device in between.
 constexpr uint32_t SYNC_NT = HUFF_SYNC_LANES;
 
-template <uint32_t NT>
+template <uint32_t NT, uint32_t TABLES = 8u>
 __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffSyncJob *gj) {
     {
         const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffS
     {
         const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj->tables;
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)L.tables;
-        for (uint32_t i = threadIdx.x; i < 8u * sizeof(DevHuffTable) / 4u; i += NT) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < TABLES * sizeof(DevHuffTable) / 4u; i += NT) dst[i] = src[i];
     }
     __syncthreads();
     for (uint32_t l = threadIdx.x; l < 512u; l += NT) huff_sync_fill_lds(L, l);
@@ -158,9 +158,17 @@ __device__ __forceinline__ bool sync_chunk_has_work(const HuffSyncJob *gj, uint3
     return p != gj->in_pos[i] || qk != gj->in_qk[i];
 }
 
-__global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
-                                                                uint32_t iters) {
-    __shared__ HuffSyncLds L;
+// TABLES = 4: every job of the launch uses Huffman table ids 0 and 1 only — the LDS image ends behind their four slots
+// (HUFF_SYNC_LDS_COMPACT_BYTES: 24 kB, six workgroups per CU where the full 40 kB allow four).
+#ifndef JPGPU_SYNC_WAVES_PER_EU
+#define JPGPU_SYNC_WAVES_PER_EU 4  // (A/B builds: registers for this many waves per SIMD)
+#endif
+template <uint32_t TABLES>
+__global__ __launch_bounds__(SYNC_NT, JPGPU_SYNC_WAVES_PER_EU) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
+                                                                                          uint32_t iters) {
+    static_assert(TABLES == 4u || TABLES == 8u, "");
+    __shared__ alignas(16) uint8_t L_raw[TABLES == 8u ? sizeof(HuffSyncLds) : HUFF_SYNC_LDS_COMPACT_BYTES];
+    JP_LDS HuffSyncLds &L = *(JP_LDS HuffSyncLds *)L_raw;
     __shared__ uint16_t todo[SYNC_NT];              // chunks (relative to the workgroup's first) with work, packed to the front
     __shared__ uint32_t wave_cnt[SYNC_NT / 64u];
     const HuffSyncJob *gj = &jobs[blockIdx.y];
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
     const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // does any lane of this workgroup have a new start state?  (after the first launches most do not: skip the table load)
     if (!__syncthreads_or(sync_chunk_has_work(gj, i, first_pass))) return;
-    sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
+    sync_load_lds<SYNC_NT, TABLES>(L, gj);
     bool published = false;
     for (uint32_t it = 0; it < iters; it++) {
         // Lanes with work are packed into as few waves as possible: a wave costs the same with one busy lane as with 64, and
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_pass_kernel(const HuffSyncJ
         __syncthreads();
         HuffRange unused;
         if (threadIdx.x < total)
-            published |= huff_sync_chunk<false>(*(JP_LDS HuffSyncLds *)&L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);
+            published |= huff_sync_chunk<false>(L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);
         __syncthreads();
     }
     const uint32_t n_pub = (uint32_t)__syncthreads_count(published);
@@ -691,13 +699,16 @@ hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t m
 // Everything for the jobs without restart markers, enqueued blind: a fixed number of sync launches (settled jobs cost an
 // empty workgroup each), block numbering, the write pass and the DC sums.
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync, hipEvent_t before_write, bool emitting) {
+                            hipEvent_t after_sync, hipEvent_t before_write, bool emitting, bool low_table_ids) {
     if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) {
         if (after_sync) (void)hipEventRecord(after_sync, stream);
         return hipSuccess;
     }
     const dim3 grid((max_chunks + SYNC_NT - 1u) / SYNC_NT, n_jobs);
-    for (uint32_t l = 0; l < launches; l++) huff_sync_pass_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
+    for (uint32_t l = 0; l < launches; l++) {
+        if (low_table_ids) huff_sync_pass_kernel<4u><<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
+        else huff_sync_pass_kernel<8u><<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
+    }
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);
     if (after_sync) (void)hipEventRecord(after_sync, stream);
     if (before_write) (void)hipStreamWaitEvent(stream, before_write, 0);  // (the zero fill of the planes, enqueued on another stream)

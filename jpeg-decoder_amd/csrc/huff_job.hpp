@@ -49,11 +49,17 @@ struct alignas(16) DevHuffTable {  // (maxcode[8..15] are read as two 16-byte wo
 };
 static_assert(sizeof(DevHuffTable) % 16 == 0 && (sizeof(uint16_t) << HUFF_LUT_BITS) % 16 == 0, "16-byte reads of maxcode");
 
+// Where table `id` (0..3) of class `ac` (0: DC, 1: AC) sits among a scan's eight device tables: ids 0 and 1 — all that most files use —
+// in the first four slots.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint32_t huff_table_slot(uint32_t ac, uint32_t id) { return 2u * id + ac; }
 struct HuffScanComp {
     int16_t *dst;       // the component's coefficient plane in the arena (zero-filled before the launch)
     uint32_t block_w;   // blocks per plane row
     uint32_t h, v;      // blocks per MCU (1, 1 in a single-component scan)
-    uint32_t dc, ac;    // table slots: dc in tables[0..3], ac in tables[4..7]
+    uint32_t dc, ac;    // table ids 0..3 of the scan's DC / AC table (slot in `tables`: huff_table_slot)
 };
 
 // Host side of the staging: copy one restart segment (markers excluded, 0xFF00 pairs inside) without its stuffing
@@ -89,7 +95,7 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     const uint8_t *data;         // staged scan: unstuffed, 16-byte aligned, zero padded (ri > 0: base of the batch's data area)
     const uint32_t *seg_off;     // ri > 0: 2 * n_seg words, segment s starts at data + seg_off[2s] and has seg_off[2s+1] unstuffed bytes
     uint32_t n_seg, ri;          // restart interval in MCUs
-    const DevHuffTable *tables;  // 8 tables of this scan
+    const DevHuffTable *tables;  // 8 tables of this scan (slots: huff_table_slot)
     uint32_t *status;            // the image's status word (bit 0: decode on the host instead)
     uint32_t *changed;           // per job: 3 counters of published states, used in rotation by consecutive launches (huff.hip)
     // per chunk (n_chunks entries each)

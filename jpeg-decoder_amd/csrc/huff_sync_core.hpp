@@ -45,7 +45,6 @@ __device__ __forceinline__ void huff_fill_block_dst(const JP_LDS HuffSyncJob &jo
 }
 
 struct HuffSyncLds {
-    DevHuffTable tables[8];
     HuffSyncJob job;
     uint16_t sym_info[2][256];  // [DC | AC][symbol]
     uint32_t q_tables[16];      // block-within-MCU -> byte offset of its DC table in `tables` | its AC table << 16
@@ -54,7 +53,13 @@ struct HuffSyncLds {
     uint8_t unzig[64];
     uint32_t unzq[4][64];       // per scan component and zig-zag index k: natural position | quantization value there << 16 — the
                                 // write pass needs both for every coefficient (store address, range statistics): one LDS read
+    // Last, so that a kernel whose jobs use table ids 0 and 1 only can do with the first four slots (HuffSyncLdsCompact below): slot
+    // 2 * id is DC table id, slot 2 * id + 1 AC table id (huff_table_slot).
+    DevHuffTable tables[8];
 };
+// The same without the slots of table ids 2 and 3: the sync pass kernel of calls whose scans all use ids 0 and 1 (what encoders write
+// for YCbCr and gray) — 24 kB of LDS instead of 40, six workgroups per CU instead of four.  Never touch tables[4..7] through it.
+constexpr uint32_t HUFF_SYNC_LDS_COMPACT_BYTES = (uint32_t)(sizeof(HuffSyncLds) - 4u * sizeof(DevHuffTable));
 constexpr uint32_t HUFF_SYNC_LANES = 256;  // lanes per workgroup (dc[] slots)
 // after job and tables are in place; every lane of the workgroup calls it (lane < 512 does something), then a barrier
 __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32_t lane) {
@@ -65,7 +70,7 @@ __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32
     }
     if (lane < 16u) {
         const uint32_t c = L.job.q_comp[lane < L.job.bpm ? lane : 0u];
-        L.q_tables[lane] = (uint32_t)(L.job.comp[c].dc * sizeof(DevHuffTable)) | ((uint32_t)((4u + L.job.comp[c].ac) * sizeof(DevHuffTable)) << 16);
+        L.q_tables[lane] = (uint32_t)(huff_table_slot(0u, L.job.comp[c].dc) * sizeof(DevHuffTable)) | ((uint32_t)(huff_table_slot(1u, L.job.comp[c].ac) * sizeof(DevHuffTable)) << 16);
         huff_fill_block_dst(L.job, L.q_dst, lane);
     }
 }

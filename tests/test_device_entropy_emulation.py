@@ -192,6 +192,26 @@ def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_
     _check_range_by_product(desc, planes)  # (uniform scans — rgb.jpg, the CMYK files — range their DC values in the DC-sum step)
 
 
+@pytest.mark.parametrize("maps", [({0: 2, 1: 3}, {0: 3, 1: 2}), ({1: 3}, {0: 2}), ({0: 3}, {1: 2}), ({}, {1: 3})], ids=lambda m: f"dc{m[0]}-ac{m[1]}".replace(" ", ""))
+def test_huffman_table_ids_above_one(maps, emission):
+    """Extended sequential frames may keep their tables under ids 2 and 3 (baseline: 0 and 1 only); the device tables sit in slots
+    2 * id + class (huff_table_slot) and the sync pass kernel has a four-slot build for the common case."""
+    pytest.importorskip("PIL")
+    import jpegedit
+    for (w, h, sub, rows) in [(250, 130, "4:2:0", 0), (200, 120, "4:4:4", 0), (320, 240, "4:2:0", 1)]:
+        base = _pil_jpeg(w, h, sub, restart_rows=rows)
+        data = jpegedit.retarget_huffman_tables(base, *maps)
+        got = _device(data)
+        assert got is not None
+        st, desc, planes, _ns, _nseg = got
+        assert st == 0
+        hdesc, hcoefs = _host(data)
+        bdesc, bcoefs = _host(base)
+        for c in range(desc.ncomp):
+            assert np.array_equal(planes[c], hcoefs[c]) and np.array_equal(planes[c], bcoefs[c]), c
+        _check_range_by_product(desc, planes)
+
+
 @pytest.mark.parametrize("case", [(64, 48, "4:2:0"), (250, 130, "4:2:0"), (129, 257, "4:2:2"), (200, 120, "4:4:4"), (300, 200, None),
                                   (1920, 1080, "4:2:0"), (1, 1, "4:2:0"), (17, 3000, "4:4:4")], ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}")
 def test_encoder_written_streams_without_restart_markers(case, launch_shape, emission):

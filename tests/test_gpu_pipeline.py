@@ -435,6 +435,30 @@ def test_pipeline_device_entropy_under_other_settings(env):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_pipeline_huffman_table_ids_above_one():
+    """Extended sequential frames with their Huffman tables under ids 2 and 3 (the sync passes' eight-slot kernel; files that
+    use ids 0 and 1 only run its four-slot build), alone and mixed with ordinary files in one call."""
+    pytest.importorskip("PIL")
+    import jpegedit
+    names, files = [], []
+    for k, (w, h, sub, rows) in enumerate([(250, 130, "4:2:0", 0), (1920, 1080, "4:2:0", 0), (640, 480, "4:4:4", 0), (640, 480, "4:2:0", 1)]):
+        base = _pil_restart(w, h, sub, rows=rows) if rows else _pil_plain(w, h, sub)
+        for j, (dm, am) in enumerate([({0: 2, 1: 3}, {0: 3, 1: 2}), ({1: 3}, {0: 2})]):
+            names.append(f"ids-{w}x{h}-{sub}-r{rows}-{j}")
+            files.append(jpegedit.retarget_huffman_tables(base, dm, am))
+    p = J.Pipeline(threads=8)
+    out = p.decode(files, device_entropy=True)
+    _check(names, files, out)
+    t = p.timings()
+    assert t["images_device_entropy"] == len(files) and t["images_device_rejected"] == 0, t
+    plain = [_pil_plain(300, 200, "4:2:0"), _pil_plain(1280, 720, "4:2:0")]
+    out = p.decode(files[:3] + plain, device_entropy=True)
+    _check(names[:3] + ["plain-a", "plain-b"], files[:3] + plain, out)
+    out = p.decode(plain, device_entropy=True)
+    _check(["plain-a", "plain-b"], plain, out)
+    p.close()
+
+
 def test_pipeline_scaled_decodes():
     """Decoder::scale for a whole call (jpgpu_pipeline_set_scale): every image at the DCT scale its own size and the requested one give
     (choose_idct_size, src/idct.rs:14-28) — mixed sizes, samplings and routes (device entropy, restart markers, progressive on the
