@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, call M: how the sync passes emit (JPGPU_EMIT_MODE builds: 2 = 16-byte stores from registers (default), 0 = 4-byte stores,
+# round 3, call M: how the sync passes emit (JPGPU_EMIT_MODE builds: 2 = 16-byte stores from registers (default), 0 = 4-byte stores, (historical: those -D switches are gone, huff_sync_core.hpp keeps the table of results)
 # 1 = no stores (cost of the bookkeeping; wrong output), 3 = 4-byte stores + LDS ring reader), and the expansion kernel with scalar control
 O=gpurun_out/r3m; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q -x -k "pipeline or decoder or entropy or anchor" > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log
