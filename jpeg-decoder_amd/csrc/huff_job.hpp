@@ -68,9 +68,8 @@ struct HuffScanComp {
 inline uint32_t huff_slot_bytes(uint32_t stuffed_bytes) { return ((stuffed_bytes + 15u) & ~15u) + 144u; }  // (the LDS ring reads up to 8 pieces ahead)
 // `clean` (optional) is cleared if a 0xFF inside the segment is not followed by its stuffing zero — a marker or a fill byte: the
 // planner that takes the short way for scans without restart markers leaves that check to this pass over the same bytes.
-inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n, bool *clean = nullptr) {
-    // runs between 0xFF bytes (one per ~256 bytes of entropy-coded data) go through memcpy: ~5x a byte loop
-    uint32_t o = 0, i = 0;
+// The portable form: runs between 0xFF bytes (one per ~256 bytes of entropy-coded data) go through memchr + memcpy, ~5x a byte loop.
+inline uint32_t huff_unstuff_portable(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t o, uint32_t i, bool *clean) {
     while (i < n) {
         const uint8_t *ff = static_cast<const uint8_t *>(memchr(src + i, 0xFF, n - i));
         const uint32_t run = ff ? (uint32_t)(ff - (src + i)) + 1u : n - i;  // up to and including the 0xFF
@@ -82,6 +81,42 @@ inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n,
             else if (clean) *clean = false;
         }
     }
+    return o;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// 32 bytes at a time where the host has AVX2 (checked once at run time): a vector without a 0xFF — seven of eight — is one load, one
+// compare and one store; one with a 0xFF is stored whole as well (what lies behind the 0xFF is overwritten by the next store: the
+// slot is at least 144 bytes longer than the data) and the walk goes on behind its stuffing zero.  Per thread 2-3 x the portable form
+// (tools/host_stage_bench.cpp), which matters where a call waits for its first sub-batch to be staged.
+__attribute__((target("avx2"))) inline uint32_t huff_unstuff_avx2(uint8_t *dst, const uint8_t *src, uint32_t n, bool *clean, uint32_t &i_out) {
+    typedef char v32c __attribute__((vector_size(32), aligned(1), may_alias));
+    uint32_t o = 0, i = 0;
+    while (i + 32u <= n) {
+        const v32c v = *reinterpret_cast<const v32c *>(src + i);
+        const uint32_t m = (uint32_t)__builtin_ia32_pmovmskb256((v32c)(v == (char)0xFF));
+        *reinterpret_cast<v32c *>(dst + o) = v;
+        if (m == 0u) {
+            o += 32u;
+            i += 32u;
+            continue;
+        }
+        const uint32_t t = (uint32_t)__builtin_ctz(m) + 1u;  // up to and including the first 0xFF
+        o += t;
+        i += t;
+        if (i < n && src[i] == 0) i++;  // its stuffing zero
+        else if (clean) *clean = false;
+    }
+    i_out = i;
+    return o;
+}
+#endif
+inline uint32_t huff_stage_segment(uint8_t *dst, const uint8_t *src, uint32_t n, bool *clean = nullptr) {
+    uint32_t o = 0, i = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    static const bool avx2 = __builtin_cpu_supports("avx2") > 0;
+    if (avx2) o = huff_unstuff_avx2(dst, src, n, clean, i);
+#endif
+    o = huff_unstuff_portable(dst, src, n, o, i, clean);
     const uint32_t slot = huff_slot_bytes(n);
     memset(dst + o, 0, slot - o);
     return o;
