@@ -74,3 +74,25 @@ def test_three_ranks_dry_run_uneven_total_and_weak_mode():
     assert r.returncode == 0, r.stderr[-2000:]
     line = _json_line(r.stdout)
     assert line["scaling"] == "weak" and line["config"]["images_per_gpu"] == 16 and line["config"]["images_total"] == 32
+
+
+@pytest.mark.parametrize("encoder", ["auto", "baseline"])
+def test_e2e_input_files_with_and_without_restart_markers(encoder):
+    """bench.py's e2e inputs (the 256 / 1,024 / 4,096-file lines and the restart-marker line): written by Pillow where it is installed,
+    by tools/baseline_encoder.py otherwise; the restart variant really carries a DRI segment and RSTn markers, and the oracle decodes
+    all of them (same picture with and without markers when the encoder is the same)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import bench
+    import oracle as O
+    import synth
+    if encoder == "auto":
+        pytest.importorskip("PIL")
+    plain, who = bench.e2e_files(synth, 160, 96, encoder, distinct=2)
+    rst, who_r = bench.e2e_files(synth, 160, 96, encoder, distinct=2, restart_rows=1)
+    assert "no restart markers" in who and "restart marker every 1 MCU row" in who_r
+    for a, b in zip(plain, rst):
+        assert b"\xff\xdd\x00\x04" not in a and b"\xff\xdd\x00\x04" in b and b.count(b"\xff\xd0") >= 1
+        pa, pb = O.decode(a).pixels, O.decode(b).pixels
+        assert pa.size == 96 * 160 * 3 and np.array_equal(pa, pb)
