@@ -65,6 +65,11 @@ typedef struct jpgpu_component {
 const char *jpgpu_version(void);
 int jpgpu_device_count(int *count);            /* number of visible HIP devices */
 const char *jpgpu_status_string(int status);
+/* Opt-in, once, BEFORE the process's first HIP call (the HIP runtime reads its environment when it initialises): sets
+ * GPU_MAX_HW_QUEUES=24 unless the variable is set already — jpgpu_pipeline_decode runs its sub-batches side by side on ~20 streams,
+ * which the runtime otherwise folds onto 4 hardware queues.  Returns 1 if it set the variable, 0 if not.
+ * Loading the library has no such side effect. */
+int jpgpu_process_init(void);
 
 /* ---- Worker: trait Worker, src/worker/mod.rs:24-35 ----------------------------------- */
 /* One worker per decode() (WorkerScope, src/worker/mod.rs:44-95).  Planes live in HBM. */

@@ -4,7 +4,7 @@ Python face of the C ABI in include/jpgpu.h: the Worker boundary (HipWorker,
 compute_image_parallel), the batch driver and the Decoder front-end.  The product path is
 HIP-only: nothing here falls back to a CPU implementation."""
 from . import _native
-from ._native import Component, ImageDesc, build, device_count, lib
+from ._native import Component, ImageDesc, build, device_count, lib, process_init
 from .batch import Batch, image_desc
 from .decoder import CODING_PROCESSES, PIXEL_FORMATS, Decoder, ImageInfo, decode_batch
 from .error import Error, FormatError, InternalError, IoError, NoDeviceError, UnsupportedError

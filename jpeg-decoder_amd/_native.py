@@ -9,11 +9,17 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-# jpgpu_pipeline_decode keeps several sub-batches in flight on 16 compute + 4 copy streams; the HIP runtime maps a process's
-# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: streams that share one serialise — 4,096 1080p files per call
-# 91 ms with 4 queues, 64 ms with 16).  The runtime reads the variable once, when it initialises: set it before the first
-# HIP call of the process (importing this module early is enough; a C host exports it).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
+
+def process_init():
+    """Opt-in (jpgpu_process_init of include/jpgpu.h, done here without loading the library): GPU_MAX_HW_QUEUES=24 unless set.
+    jpgpu_pipeline_decode keeps several sub-batches in flight on 16 compute + 4 copy streams; the HIP runtime maps a process's
+    streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: streams that share one serialise — 4,096 1080p files per call
+    91 ms with 4 queues, 64 ms with 16).  The runtime reads the variable once, when it initialises: call this before the first
+    HIP call of the process.  Importing the package no longer does it (bench.py, tools/ and tests/conftest.py call it)."""
+    return os.environ.setdefault("GPU_MAX_HW_QUEUES", "24") == "24"
+
+
 # JPGPU_LIBRARY: development knob for A/B builds of the same ABI (e.g. libjpgpu_alt.so built with other -D flags)
 LIB_PATH = os.environ.get("JPGPU_LIBRARY") or os.path.join(_HERE, "libjpgpu.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "jpgpu.h")
@@ -90,6 +96,7 @@ _PROTOS = {
     "jpgpu_version": (C.c_char_p, []),
     "jpgpu_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "jpgpu_status_string": (C.c_char_p, [C.c_int]),
+    "jpgpu_process_init": (C.c_int, []),
     "jpgpu_worker_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "jpgpu_worker_destroy": (None, [C.c_void_p]),
     "jpgpu_worker_last_error": (C.c_char_p, [C.c_void_p]),

@@ -97,6 +97,10 @@ struct jpgpu_batch {
     uint32_t cls_next = 0;
     uint32_t *d_plane_job_slot = nullptr;  // generic path: plane job -> image * 4 + comp
     std::vector<uint8_t> cls_src;
+    // per image * 4 + comp: the device statistics miss some of this component's coefficients (an add_deltas while a changed
+    // quantization table was waiting to be sent, or values ranged with a table that has been replaced since): the component stays
+    // host-sourced at class 0 until the image's coefficients are cleared, re-scanned or written anew as a whole
+    std::vector<uint8_t> stats_incomplete;
     bool dev_classes = false;
     bool cls_dirty = true;              // class knowledge changed since the tables / the class table were last sent
     // JPGPU_BATCH_KERNEL_TIMES (diagnostics, jpgpu_pipeline_timings): events around the phases of the device entropy path
@@ -230,6 +234,7 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
     b->out_len.assign(n_images, 0);
     b->sane.assign((size_t)n_images * 4, 0);
     b->cls_src.assign((size_t)n_images * 4, 0);
+    b->stats_incomplete.assign((size_t)n_images * 4, 0);
     // path resolution: group the images that can share a fused launch, the rest is generic
     std::vector<uint32_t> kind_key(n_images, 0);
     if (!(flags & JPGPU_BATCH_FORCE_GENERIC))
@@ -437,6 +442,7 @@ int jpgpu_batch_clear_coefficients(jpgpu_batch *b, uint32_t image, void *hip_str
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
     B_HIP(hipMemsetAsync(b->d_stats + (size_t)image * RS_WORDS, 0, RS_WORDS * sizeof(uint32_t), (hipStream_t)hip_stream));
+    for (uint32_t c = 0; c < 4; c++) b->stats_incomplete[(size_t)image * 4 + c] = 0;
     return JPGPU_OK;
 }
 
@@ -463,7 +469,10 @@ int jpgpu::batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
     b->sane[idx] = 0;
-    const bool ranged = !b->qt_dirty;
+    // Once a call could not be ranged the statistics under-estimate this component for good: it stays "unknown" (host class 0)
+    // whatever later calls range, until jpgpu_batch_clear_coefficients / jpgpu_batch_classify_on_device start them afresh.
+    if (b->qt_dirty) b->stats_incomplete[idx] = 1;
+    const bool ranged = !b->stats_incomplete[idx];
     batch_class_source(b, idx, ranged);
     if (n == 0) return JPGPU_OK;
     hipStream_t s = (hipStream_t)hip_stream;
@@ -583,6 +592,7 @@ int jpgpu_batch_classify_on_device(jpgpu_batch *b, void *hip_stream) {
     for (size_t i = 0; i < b->descs.size(); i++)
         for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
             b->sane[i * 4 + c] = 0;  // (the host does not know)
+            b->stats_incomplete[i * 4 + c] = 0;  // (a full scan with the current tables)
             batch_class_source(b, i * 4 + c, true);
         }
     return JPGPU_OK;
@@ -595,6 +605,7 @@ int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t 
     // the range class of coefficients already uploaded was computed with the old table (|c*q| bounds): unknown again
     // (statistics the device gathered with the old table included)
     batch_set_host_class(b, (size_t)image * 4 + comp, 0);
+    b->stats_incomplete[(size_t)image * 4 + comp] = 1;  // (what the device ranged so far was ranged with the old table)
     b->scan_jobs_valid = false;
     b->qt_dirty = true;
     b->jobs_dirty = true;
@@ -670,6 +681,9 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
             rc = batch_enable_dev_classes(b);
             if (rc) return rc;
             b->sane[idx] = 0;
+            // (the whole plane is replaced and ranged, at expansion time, with the table the device then holds — batch_refresh_jobs
+            // runs first: whatever was missing of this component's statistics no longer matters; older maxima only over-estimate)
+            b->stats_incomplete[idx] = 0;
             batch_class_source(b, idx, true);
         }
     }
@@ -898,6 +912,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         stat_images.push_back(img);
         for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the write passes leave in d_stats
             b->sane[(size_t)img * 4 + c] = 0;
+            b->stats_incomplete[(size_t)img * 4 + c] = 0;  // (statistics zeroed by this launch's fills, every block written anew)
             batch_class_source(b, (size_t)img * 4 + c, true);
         }
         for (const host::PlannedScan &ps : *images[k].scans) {

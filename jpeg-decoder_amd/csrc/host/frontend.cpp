@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 
 namespace jpgpu {
 namespace host {
@@ -203,20 +204,63 @@ struct HuffTable {
 inline bool same_definition(const HuffTable &t, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
     return t.present && t.is_ac == ac && t.nvalues == n && memcmp(t.bits, bits, 16) == 0 && memcmp(t.values, vals, (size_t)n) == 0;
 }
+// The cache is ONE per process (round 4; rounds 2-3 kept eight 5.5 kB slots per calling thread: the C API is driven by a thousand
+// decoding threads in tests/test_gpu_concurrency.py, and whatever a thread-local holds stays until its thread ends — ADVICE r3):
+// readers copy out under a shared lock (a microsecond, 4 times per file), a new definition takes the exclusive one.
 inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
     constexpr int kSlots = 8;
-    thread_local std::unique_ptr<HuffTable[]> cache;
-    thread_local int next = 0;
-    if (!cache) cache.reset(new HuffTable[kSlots]);
-    for (int i = 0; i < kSlots; i++)
-        if (n > 0 && n <= 256 && same_definition(cache[i], bits, vals, n, ac)) {
-            dst = cache[i];
-            return;
-        }
+    static std::shared_mutex m;
+    static HuffTable cache[kSlots];
+    static int next = 0;
+    if (n > 0 && n <= 256) {
+        std::shared_lock<std::shared_mutex> g(m);
+        for (int i = 0; i < kSlots; i++)
+            if (same_definition(cache[i], bits, vals, n, ac)) {
+                dst = cache[i];
+                return;
+            }
+    }
     dst.build(bits, vals, n, ac);
+    std::unique_lock<std::shared_mutex> g(m);
     cache[next] = dst;
     next = (next + 1) % kSlots;
 }
+
+// Scratch objects that would otherwise be thread-locals (44 kB of Huffman tables per thread that ever parsed a DHT segment) or
+// per-call heap blocks (every pool thread inside the allocator at once): a process-wide free list bounded at `kKeep` objects —
+// a thread borrows one for the duration of a call; more concurrent callers than that allocate, and free, their own.
+template <class T, int kKeep = 64>
+class ScratchPool {
+public:
+    struct Lease {
+        ScratchPool *pool;
+        std::unique_ptr<T> obj;
+        T *operator->() { return obj.get(); }
+        ~Lease() { pool->give(std::move(obj)); }
+    };
+    Lease take() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (!free_.empty()) {
+                std::unique_ptr<T> o = std::move(free_.back());
+                free_.pop_back();
+                return Lease{this, std::move(o)};
+            }
+        }
+        return Lease{this, std::unique_ptr<T>(new T)};
+    }
+
+private:
+    void give(std::unique_ptr<T> o) {
+        std::lock_guard<std::mutex> g(m_);
+        if ((int)free_.size() < kKeep) free_.push_back(std::move(o));
+    }
+    std::mutex m_;
+    std::vector<std::unique_ptr<T>> free_;
+};
+struct DhtScratch {
+    HuffTable dc[4], ac[4];
+};
 
 // Annex K default tables for MJPEG (src/huffman.rs:295-346)
 const uint8_t kK3Bits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
@@ -669,11 +713,11 @@ struct Frontend::Impl {
 
     void parse_dht() {  // src/parser.rs:536-589, merge of src/decoder.rs:501-518
         size_t length = read_length();
-        // (per thread, not per call: two 23 kB heap blocks per DHT segment, allocated and freed by every pool thread at once, had the
-        // threads queue up inside the allocator)
-        thread_local std::unique_ptr<HuffTable[]> tl_dc, tl_ac;
-        if (!tl_dc) tl_dc.reset(new HuffTable[4]), tl_ac.reset(new HuffTable[4]);
-        HuffTable *ndc = tl_dc.get(), *nac = tl_ac.get();
+        // (borrowed, not allocated per call: two heap blocks per DHT segment, allocated and freed by every pool thread at once, had
+        // the threads queue up inside the allocator — and not thread-local either: ScratchPool)
+        static ScratchPool<DhtScratch> scratch_pool;
+        auto scratch = scratch_pool.take();
+        HuffTable *ndc = scratch->dc, *nac = scratch->ac;
         for (int i = 0; i < 4; i++) ndc[i].present = nac[i].present = false;
         while (length > 17) {
             const uint8_t tc = src.u8(), cls = tc >> 4;
@@ -931,26 +975,46 @@ struct Frontend::Impl {
             ps.comp[i].ac = (uint32_t)scan.ac_tables[i];
         }
         {
-            // The device form of the eight tables: the set this thread built last is kept with the definitions it came from
-            // (code counts, values, class: everything else in a table is a function of them) and handed out again as it is.
+            // The device form of the eight tables: the sets built last are kept with the definitions they came from (code counts,
+            // values, class: everything else in a table is a function of them) and handed out again as they are.
+            // (four per PROCESS since round 4, looked up under a mutex, built outside it — a batch's files come from a few encoders
+            // and share their sets; the key holds the definitions only, 280 bytes per table.  Rounds 2-3: one per thread, each
+            // with eight whole host tables as its key.)
+            struct Key {
+                bool present = false, is_ac = false;
+                int nvalues = 0;
+                uint8_t bits[16], values[256];
+                bool matches(const HuffTable &h) const {
+                    return h.present ? (present && is_ac == h.is_ac && nvalues == h.nvalues && memcmp(bits, h.bits, 16) == 0 &&
+                                        memcmp(values, h.values, (size_t)h.nvalues) == 0)
+                                     : !present;
+                }
+            };
             struct Last {
-                HuffTable key[8];  // only present / is_ac / nvalues / bits / values are filled in
+                Key key[8];
                 std::shared_ptr<const PlannedScan::TableSet> set;
             };
-            thread_local std::unique_ptr<Last> last;
-            if (!last) last.reset(new Last);
-            bool same = last->set != nullptr;
-            for (int t = 0; t < 8 && same; t++) {
-                const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
-                same = h.present ? same_definition(last->key[t], h.bits, h.values, h.nvalues, h.is_ac) : !last->key[t].present;
+            constexpr int kSets = 4;
+            static std::mutex last_m;
+            static Last last_sets[kSets];
+            static int last_next = 0;
+            std::shared_ptr<const PlannedScan::TableSet> found;
+            {
+                std::lock_guard<std::mutex> last_lock(last_m);
+                for (int e = 0; e < kSets && !found; e++) {
+                    bool same = last_sets[e].set != nullptr;
+                    for (int t = 0; t < 8 && same; t++) same = last_sets[e].key[t].matches(t < 4 ? dc[t] : ac[t - 4]);
+                    if (same) found = last_sets[e].set;
+                }
             }
-            if (!same) {
+            if (!found) {
+                Last fresh, *last = &fresh;
                 auto set = std::make_shared<PlannedScan::TableSet>();
                 memset(set.get(), 0, sizeof(*set));
                 for (int t = 0; t < 8; t++) {
                     const HuffTable &h = t < 4 ? dc[t] : ac[t - 4];
                     DevHuffTable &d = set->t[huff_table_slot(t < 4 ? 0u : 1u, (uint32_t)(t & 3))];
-                    HuffTable &k = last->key[t];
+                    Key &k = last->key[t];
                     k.present = h.present;
                     if (!h.present) continue;
                     static_assert(HUFF_LUT_BITS >= 8 && HUFF_LUT_BITS <= kLutBits && sizeof(d.values) == sizeof(h.values), "table layouts");
@@ -998,8 +1062,12 @@ struct Frontend::Impl {
                     memcpy(k.values, h.values, sizeof(h.values));
                 }
                 last->set = std::move(set);
+                found = last->set;
+                std::lock_guard<std::mutex> last_lock(last_m);
+                last_sets[last_next] = std::move(fresh);
+                last_next = (last_next + 1) % kSets;
             }
-            ps.tables = last->set;
+            ps.tables = found;
         }
         // cut the entropy-coded data at the RSTn markers: exactly one every `ri` MCUs, numbered 0..7 cyclically
         // (src/decoder.rs:920-956), 0xFF00 pairs inside, one other marker right after the last segment

@@ -583,6 +583,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
     if (threadIdx.x < 2u) {
         uint32_t v = 0;
         for (uint32_t w = 0; w < EXP_WAVES; w++) v = max(v, E.wg_rg[threadIdx.x][w]);
+        if (threadIdx.x == 0u) stat_mark_inexact(job.stats);
         stat_raise(job.stats + (threadIdx.x ? RS_MAX_AC : RS_MAX_DC), v);
     }
 }

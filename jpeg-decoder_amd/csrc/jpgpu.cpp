@@ -36,6 +36,16 @@ int jpgpu_device_count(int *count) {
     return e == hipSuccess ? JPGPU_OK : JPGPU_ERR_NO_DEVICE;
 }
 
+// Opt-in process set-up (include/jpgpu.h).  jpgpu_pipeline_decode keeps several sub-batches in flight on 16 compute + 4 copy
+// streams; the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a
+// queue serialise (4,096 1080p files per call: 91 ms with 4 queues, 64 ms with 16, 58 with 24).  The runtime reads the variable
+// when it initialises — at the first HIP call of the process — so a host calls this before it touches HIP, or exports the
+// variable itself.  (Rounds 1-3 did this from a load-time constructor: a silent side effect on every HIP user of the process.)
+int jpgpu_process_init(void) {
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+    return setenv("GPU_MAX_HW_QUEUES", "24", 0) == 0 ? 1 : 0;
+}
+
 const char *jpgpu_status_string(int status) {
     switch (status) {
     case JPGPU_OK: return "Ok";
@@ -51,12 +61,6 @@ const char *jpgpu_status_string(int status) {
 }  // extern "C"
 
 namespace jpgpu {
-
-// jpgpu_pipeline_decode keeps several sub-batches in flight on 16 compute + 4 copy streams; the HIP runtime maps a process's streams
-// onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise (4,096 1080p files per call: 91 ms
-// with 4 queues, 64 ms with 16).  The runtime reads the variable when it initialises — at the first HIP call of the process —
-// so this helps a host that loads the library before it touches HIP; others export the variable themselves.
-__attribute__((constructor)) static void jpgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 const RoctxApi &roctx_api() {
     static const RoctxApi api = [] {
@@ -590,7 +594,9 @@ int jpgpu_compute_image(jpgpu_worker *w, const jpgpu_component *components, uint
             // kernel takes the class from those statistics (range_stats.hpp).
             if (!w->d_cls) {
                 W_HIP(hipMalloc((void **)&w->d_cls, (RS_WORDS + 1) * sizeof(uint32_t)));
-                W_HIP(hipMemset(w->d_cls + RS_WORDS, 0xff, sizeof(uint32_t)));
+                // (on the worker's own stream: it is non-blocking, i.e. NOT ordered behind the null stream a plain hipMemset uses,
+                // and the finalize kernel below is the first reader — ADVICE r3)
+                W_HIP(hipMemsetAsync(w->d_cls + RS_WORDS, 0xff, sizeof(uint32_t), w->stream));
             }
             W_HIP(hipMemsetAsync(w->d_cls, 0, RS_WORDS * sizeof(uint32_t), w->stream));
             for (uint32_t i = 0; i < ncomp; i++)

@@ -16,7 +16,8 @@
 //   max column sum <= max(max_dc + 7 * max_ac, 8 * max_ac)
 // is a sound bound (legal 8-bit data: |DC * q| <= 1024, so class 3 is granted up to max_ac = 696; images with harder edges
 // than that run class 1, measured 1.5 % slower).  range_scan_kernel has whole blocks in front of it and stores the exact
-// column maximum instead (RS_COL_EXACT set).
+// column maximum instead (RS_COL_EXACT set); every other writer clears that word again (stat_mark_inexact), and the bound
+// then also covers what the scan had seen: it leaves max |s| of ALL coefficients in RS_MAX_AC, and 8 * max_ac bounds any column.
 #pragma once
 #include <stdint.h>
 
@@ -47,7 +48,16 @@ inline
 __device__ __forceinline__ void stat_raise(uint32_t *p, uint32_t v) {
     if (v && __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(p, v);
 }
+// A writer that does not keep block-column sums has touched the image's coefficients: whatever exact column maximum an earlier
+// range scan stored (RS_COL_EXACT) no longer describes them — a value added to a column raises its sum without raising any
+// per-coefficient maximum — so the class falls back to the bound from max_dc / max_ac until the next scan.
+// A look first: most waves of a launch find the word cleared already.
+__device__ __forceinline__ void stat_mark_inexact(uint32_t *stats) {
+    if (__hip_atomic_load(stats + RS_COL_EXACT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        __hip_atomic_store(stats + RS_COL_EXACT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // per-lane maxima -> the image's statistics: one pair of atomics per wave at most.  Every lane of the wave calls it.
+// (the by-product writers' publisher: column sums are unknown to them, stat_mark_inexact)
 __device__ __forceinline__ void stat_publish_wave(uint32_t *stats, uint32_t max_dc, uint32_t max_ac) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -55,6 +65,7 @@ __device__ __forceinline__ void stat_publish_wave(uint32_t *stats, uint32_t max_
         max_ac = max(max_ac, (uint32_t)__shfl_xor((int)max_ac, off));
     }
     if ((threadIdx.x & 63u) == 0u && stats) {
+        stat_mark_inexact(stats);
         stat_raise(stats + RS_MAX_DC, max_dc);
         stat_raise(stats + RS_MAX_AC, max_ac);
     }

@@ -8,6 +8,16 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now (the launcher hands it to every rank of a job)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def shard(n_items, rank, world):
     """Contiguous shard of `n_items` images for `rank`: sizes differ by at most one, order preserved."""
     base, extra = divmod(n_items, world)
@@ -26,11 +36,13 @@ def init(backend=None, force=False):
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if "MASTER_PORT" not in os.environ:
-        import socket
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        os.environ["MASTER_PORT"] = str(s.getsockname()[1]) if world == 1 else "29511"
-        s.close()
+        # One rank can pick any free port for itself.  Several ranks must AGREE on one, and only their launcher can tell them
+        # (bench.py's launcher_command passes --master-port free_port(); torchrun exports MASTER_PORT): a constant here would
+        # make two jobs on one node collide, so a multi-rank start without a port is refused.
+        if world > 1:
+            raise RuntimeError("jpeg_decoder_amd.distributed.init: WORLD_SIZE > 1 but MASTER_PORT is not set — launch the ranks through "
+                               "torch.distributed.run (--master-port P) or bench.py --gpus N, which pick a free port for the whole job")
+        os.environ["MASTER_PORT"] = str(free_port())
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}

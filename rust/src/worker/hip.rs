@@ -15,7 +15,8 @@ use crate::parser::{Component, Dimensions};
 use alloc::boxed::Box;
 use alloc::string::String;
 use alloc::vec::Vec;
-use core::ffi::{c_char, c_int, c_void};
+use core::ffi::c_void;
+use std::os::raw::{c_char, c_int}; // (core::ffi::{c_char, c_int} need Rust 1.64; the crate's rust-version is 1.61)
 
 /// `jpgpu_component` (include/jpgpu.h) == `parser::Component` (src/parser.rs:76-89), field for field.
 #[repr(C)]

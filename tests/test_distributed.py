@@ -61,6 +61,22 @@ def test_shard_covers_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_multi_rank_init_refuses_to_guess_a_port(monkeypatch):
+    """VERDICT r3: no constant rendezvous port (two jobs on one node would collide).  One rank picks a free port for itself;
+    several ranks without MASTER_PORT are a launcher error, not something to paper over."""
+    sys.path.insert(0, ROOT)
+    import jpeg_decoder_amd.distributed as D
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        D.init(backend="gloo")
+    a, b = D.free_port(), D.free_port()
+    assert 1024 < a < 65536 and 1024 < b < 65536
+    assert "29511" not in open(D.__file__).read()
+
+
 @pytest.mark.timeout(120)
 def test_two_ranks_gloo_shard_gather():
     import torch.multiprocessing as mp
