@@ -99,9 +99,9 @@ typedef struct jpgpu_pipeline_timings {
      * sub-batches (they overlap one another and the host: a breakdown of GPU work, not of the call's wall time).  Recorded only
      * when the environment variable JPGPU_BATCH_KERNEL_TIMES is set (the events cost a few microseconds per sub-batch):
      *   dev_fill_ms   zero fill of the coefficient planes and statistics
-     *   dev_sync_ms   restart-segment decoder + the chunk decoder's sync passes + block numbering
-     *   dev_write_ms  expansion of the sync passes' entry lists into coefficient blocks (and, as a by-product, their range statistics;
-     *                 the write pass with JPGPU_SYNC_EMIT=0) + DC sums of scans whose components share their tables
+     *   dev_sync_ms   the chunk decoder's sync passes (with speculative emission) + block numbering
+     *   dev_write_ms  expansion of the sync passes' entry lists into coefficient blocks (and, as a by-product, their range statistics)
+     *                 + DC sums of scans whose components share their tables
      *   dev_pixel_ms  class finalize + pixel kernels (dequantize, IDCT, upsampling, colour conversion) */
     uint32_t dev_times_valid, _pad;
     double dev_fill_ms, dev_sync_ms, dev_write_ms, dev_pixel_ms;
@@ -112,9 +112,9 @@ enum {
     JPGPU_PIPELINE_DENSE = 2u,    /* send all 64 coefficients of every block over PCIe instead of the compact form
                                    * (bitmap + index + non-zero values, jpgpu.h) — A/B switch, same pixels */
     JPGPU_PIPELINE_DEVICE_ENTROPY = 4u /* 8-bit sequential Huffman streams with one all-component scan: send the entropy-coded
-                                   * bytes and decode them on the device — with restart markers (DRI) one lane per restart
-                                   * segment (src/decoder.rs:920-956: segments are independent), without them the
-                                   * self-synchronising chunk decoder (one lane per 128 bytes, csrc/huff_sync_core.hpp); every
+                                   * bytes and decode them on the device with the self-synchronising chunk decoder (one lane
+                                   * per chunk of 64 bytes to 4 kB, csrc/huff_sync_core.hpp; a restart segment — src/decoder.rs:920-956:
+                                   * segments are independent — is a scan in miniature with chunk slots of its own); every
                                    * other stream, and any stream the device decoder flags, takes the host path */
     , JPGPU_PIPELINE_PROGRESSIVE_DELTAS = 8u /* progressive streams (host-decoded): accumulate the coefficients ON THE DEVICE —
                                    * after every scan the host sends what the scan changed (jpgpu_batch_add_deltas) instead of

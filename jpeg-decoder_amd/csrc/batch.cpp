@@ -771,46 +771,45 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             if (!alone) sync_blocks = 64u;
         }
     }
-    // Speculative emission ("one pass less", huff_job.hpp): the sync passes leave entry lists, huff_expand_kernel writes whole
-    // blocks — no write pass, and no zero fill for images whose scans cover their planes.  JPGPU_SYNC_EMIT=0: the write pass.
-    static const bool emitting = env_u32("JPGPU_SYNC_EMIT", 1, 0, 1) != 0;
+    // Speculative emission (huff_job.hpp): the sync passes leave entry lists, huff_expand_kernel writes whole blocks — no write
+    // pass, and no zero fill for images whose scans cover their planes.
     bool low_table_ids = env_u32("JPGPU_SYNC_COMPACT_TABLES", 1, 0, 1) != 0;  // until a scan uses a Huffman table id above 1 (huff_sync_pass_kernel<4>)
     static const bool tail_pinned = getenv("JPGPU_SYNC_TAIL") != nullptr;
     static const uint32_t env_tail = env_u32("JPGPU_SYNC_TAIL", 3, 1, 8);  // eighths of its chunk a lane walks in the first sync pass
     const uint32_t sync_tail = (alone && !tail_pinned) ? 8u : env_tail;
     if (alone && !iters_pinned) sync_iters = env_iters;
-    // Restart-marker streams through the chunk decoder (huff_job.hpp, HuffSyncJob::seg_chunks): every segment gets chunk slots of
-    // its own (`uniform` scans too: huff_dc_prefix_kernel starts its sums again at every segment).  Not without emission.  JPGPU_DRI_CHUNKS=0: one lane
-    // per segment as in rounds 1-3 (huff_segments_kernel).
-    static const bool dri_chunks = env_u32("JPGPU_DRI_CHUNKS", 1, 0, 1) != 0;
+    // Restart-marker streams (huff_job.hpp, HuffSyncJob::seg_chunks): every segment gets chunk slots of its own (`uniform` scans
+    // too: huff_dc_prefix_kernel starts its sums again at every segment); a scan whose restart interval covers all its MCUs is ONE
+    // segment, i.e. a scan without restart markers.  Bit positions are 32-bit numbers relative to the scan's first slot: a scan
+    // whose slots exceed 2^29 bytes is handed back to the host (status bit 8).
     struct DriGeom {
-        bool chunked;
+        bool chunked, too_large;
         uint32_t shift, seg_chunks;
     };
-    uint64_t all_slots = 0;  // (bit positions inside the staging block's data area are 32-bit numbers)
-    for (uint32_t k = 0; k < n && images[k].scans; k++)
-        for (const host::PlannedScan &ps : *images[k].scans)
-            for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) all_slots += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
     auto dri_geom = [&](const host::PlannedScan &ps) {
-        DriGeom g{false, 0u, 0u};
-        if (ps.ri == 0 || !emitting || !dri_chunks || ps.seg_off.size() < 4 || all_slots >= (1u << 29)) return g;
+        DriGeom g{false, false, 0u, 0u};
+        if (ps.ri == 0 || ps.seg_off.size() < 4) return g;
         uint32_t blocks = 0;
         for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
-        uint64_t stuffed = 0;
+        uint64_t stuffed = 0, slots = 0;
         uint32_t longest = 0;
         for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
             stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
+            slots += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
             longest = std::max<uint32_t>(longest, ps.seg_off[sg + 1] - ps.seg_off[sg]);
         }
-        if (stuffed >= (1u << 28)) return g;
+        g.chunked = true;
+        if (stuffed >= (1u << 28) || slots >= (1u << 29)) {
+            g.too_large = true;
+            return g;
+        }
         g.shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
         g.seg_chunks = huff_sync_chunks(longest, g.shift);
-        g.chunked = true;
         return g;
     };
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
-    size_t n_seg_jobs = 0, n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
+    size_t n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     // Files of one encoder repeat the same Huffman tables (27 kB per scan in device form): a scan whose tables equal those of
     // the scan before it shares that copy — one in the staging block, one upload, one set of lines in the L2.
     const host::PlannedScan::TableSet *prev_tables = nullptr;
@@ -827,26 +826,22 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 data_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
                 stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
             }
-            if (ps.ri == 0) {  // no restart markers: the chunk decoder and its per-chunk state (device only)
+            n_sync_jobs++;  // every scan is a job of the chunk decoder, with its per-chunk state and entry buffers (device only)
+            if (const DriGeom g = dri_geom(ps); g.chunked) {
+                const size_t chunks = g.too_large ? 0 : (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16);
+            } else {  // one segment: a scan without restart markers (or one whose restart interval covers it)
                 if (ps.seg_off.size() != 2 || stuffed >= (1u << 28)) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad plan");
-                n_sync_jobs++;
                 uint32_t blocks = 0;
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
                 const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
                 const size_t chunks = huff_sync_chunks((uint32_t)stuffed, shift);
-                scratch_bytes += align_up(chunks * 8 * 4, 16);
-                if (emitting) scratch_bytes += align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16);
-            } else if (const DriGeom g = dri_geom(ps); g.chunked) {
-                n_sync_jobs++;
-                const size_t chunks = (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
-                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16);
-            } else {
-                n_seg_jobs++;
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16);
             }
         }
     }
     const size_t off_status = 0, off_cnt = align_up(off_status + (size_t)n * 4, 16);
-    const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = align_up(off_jobs + n_seg_jobs * sizeof(HuffSyncJob), 16);
+    const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = off_jobs;
     const size_t off_tables = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
     const size_t off_seg = align_up(off_tables + n_table_sets * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
@@ -885,20 +880,19 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     clk.mark("buffers");
     uint8_t *h = b->h_entropy, *d = b->d_entropy;
     memset(h, 0, off_jobs);  // status words and settle counters start at zero
-    HuffSyncJob *jobs = reinterpret_cast<HuffSyncJob *>(h + off_jobs);
     HuffSyncJob *sjobs = reinterpret_cast<HuffSyncJob *>(h + off_sjobs);
     uint8_t *xs = scratch ? scratch->d : d;  // base of the device-only work space
-    size_t ji = 0, si = 0, tcur = off_tables, tnext = off_tables, scur = off_seg, dcur = off_data, xcur = scratch ? 0 : off_scratch;
+    size_t si = 0, tcur = off_tables, tnext = off_tables, scur = off_seg, dcur = off_data, xcur = scratch ? 0 : off_scratch;
     prev_tables = nullptr;
-    uint32_t max_seg = 0, max_chunks = 0;
+    uint32_t max_chunks = 0;
     std::vector<uint32_t> stat_images;  // listed images, for the fills that zero their statistics
     struct CopyTask {
         uint8_t *dst;        // first slot of the scan in the pinned block
         uint32_t *seg_table; // its 2 * n_seg words
-        uint32_t dst_off;    // offset of dst inside the data area
+        uint32_t dst_off;    // offset of dst inside the data area (which slice of the upload the scan belongs to)
         const uint8_t *src;  // the scan's entropy-coded bytes
         const host::PlannedScan *ps;
-        HuffSyncJob *sync;   // scan without restart markers: its job record (the unstuffed length goes there)
+        HuffSyncJob *sync;   // its job record (a scan of one segment: the unstuffed length goes there)
         uint32_t *h_status;  // the image's status word in the pinned block (set here if the staging pass refuses the stream)
     };
     std::vector<CopyTask> copies;
@@ -908,9 +902,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const uint32_t img = images[k].image;
         b->entropy_images.push_back(img);
         const jpgpu_image_desc &desc = b->descs[img];
-        bool needs_zeros = !emitting;  // (the write pass and the restart-segment decoder store non-zero coefficients only)
+        bool needs_zeros = false;  // (the expansion writes every block of a scan, zeros included; planes a scan does not cover: below)
         stat_images.push_back(img);
-        for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the write passes leave in d_stats
+        for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the expansion leaves in d_stats
             b->sane[(size_t)img * 4 + c] = 0;
             b->stats_incomplete[(size_t)img * 4 + c] = 0;  // (statistics zeroed by this launch's fills, every block written anew)
             batch_class_source(b, (size_t)img * 4 + c, true);
@@ -918,7 +912,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         for (const host::PlannedScan &ps : *images[k].scans) {
             // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
             const DriGeom dg = dri_geom(ps);
-            HuffSyncJob *sj = (ps.ri == 0 || dg.chunked) ? &sjobs[si] : nullptr;
+            HuffSyncJob *sj = &sjobs[si];
             copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps, sj,
                                       reinterpret_cast<uint32_t *>(h + off_status) + k});
             size_t scan_bytes = 0, stuffed = 0;
@@ -949,7 +943,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 comp[c].ac = ps.comp[c].ac;
                 if (ps.comp[c].dc > 1u || ps.comp[c].ac > 1u) low_table_ids = false;
             }
-            if (sj) {
+            {
                 memset(sj, 0, sizeof(*sj));
                 memcpy(sj->comp, comp, sizeof(comp));
                 sj->ncomp = ps.ncomp;
@@ -959,16 +953,18 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->chunk_shift = dg.chunked ? dg.shift : huff_sync_chunk_shift((uint32_t)stuffed, sj->bpm * ps.n_mcu, sync_blocks, sync_min_shift);
                 sj->pass0_skip = ((1u << sj->chunk_shift) >> 3) * (8u - sync_tail);
                 sj->late_pass = late_pass;
-                // (no restart markers: an upper bound, the staging task sets the real count; restart segments: slots per segment x segments)
-                const uint32_t chunks = dg.chunked ? (uint32_t)(ps.seg_off.size() / 2) * dg.seg_chunks : huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);
+                // (one segment: an upper bound, the staging task sets the real count; restart segments: slots per segment x segments)
+                const uint32_t chunks = dg.chunked ? (dg.too_large ? 0u : (uint32_t)(ps.seg_off.size() / 2) * dg.seg_chunks)
+                                                   : huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);
                 uint32_t *st = reinterpret_cast<uint32_t *>(xs + xcur);
-                sj->data = dg.chunked ? d + off_data : d + dcur;  // (segment offsets are relative to the start of the data area)
+                sj->data = d + dcur;  // (bit positions and segment offsets are relative to the scan's first slot)
                 if (dg.chunked) {
                     sj->seg_off = reinterpret_cast<const uint32_t *>(d + scur);
                     sj->n_seg = (uint32_t)(ps.seg_off.size() / 2);
                     sj->ri = ps.ri;
                     sj->seg_chunks = dg.seg_chunks;
                     sj->n_chunks = chunks;
+                    if (dg.too_large) reinterpret_cast<uint32_t *>(h + off_status)[k] |= 1u | 256u;  // the host decodes this image
                 }
                 sj->tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
                 sj->status = reinterpret_cast<uint32_t *>(d + off_status) + k;
@@ -984,35 +980,15 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->n_mcu = ps.n_mcu;
                 max_chunks = std::max(max_chunks, chunks);
                 xcur += align_up((size_t)chunks * 8 * 4, 16);
-                if (emitting) {
-                    sj->emit_stride = huff_emit_stride(sj->chunk_shift);
-                    sj->emit_cnt = reinterpret_cast<uint32_t *>(xs + xcur);
-                    xcur += align_up((size_t)chunks * 4, 16);
-                    sj->emit = reinterpret_cast<uint32_t *>(xs + xcur);
-                    xcur += align_up((size_t)chunks * sj->emit_stride * 4, 16);
-                    uint32_t block_h[4] = {0, 0, 0, 0};
-                    for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
-                    if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;
-                }
+                sj->emit_stride = huff_emit_stride(sj->chunk_shift);
+                sj->emit_cnt = reinterpret_cast<uint32_t *>(xs + xcur);
+                xcur += align_up((size_t)chunks * 4, 16);
+                sj->emit = reinterpret_cast<uint32_t *>(xs + xcur);
+                xcur += align_up((size_t)chunks * sj->emit_stride * 4, 16);
+                uint32_t block_h[4] = {0, 0, 0, 0};
+                for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
+                if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;
                 si++;
-            } else {
-                HuffSyncJob &j = jobs[ji++];
-                memset(&j, 0, sizeof(j));
-                j.data = d + off_data;  // (segment offsets are relative to the start of the data area)
-                j.seg_off = reinterpret_cast<const uint32_t *>(d + scur);
-                j.tables = reinterpret_cast<const DevHuffTable *>(d + tcur);
-                j.status = reinterpret_cast<uint32_t *>(d + off_status) + k;
-                j.n_seg = (uint32_t)(ps.seg_off.size() / 2);
-                j.ri = ps.ri;
-                j.cols = ps.cols;
-                j.n_mcu = ps.n_mcu;
-                j.ncomp = ps.ncomp;
-                memcpy(j.comp, comp, sizeof(comp));
-                memcpy(j.q, scan_q, sizeof(scan_q));
-                j.stats = b->d_stats + (size_t)img * RS_WORDS;
-                huff_sync_finish_job(j);
-                max_seg = std::max(max_seg, j.n_seg);
-                needs_zeros = true;
             }
             dcur += scan_bytes;
             scur += ps.seg_off.size() * 4;
@@ -1027,7 +1003,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             for (size_t sg = 0; sg + 1 < ct.ps->seg_off.size(); sg += 2) {
                 const uint32_t first = ct.ps->seg_off[sg], n = ct.ps->seg_off[sg + 1] - first;
                 bool clean = true;
-                ct.seg_table[sg] = ct.dst_off + o;
+                ct.seg_table[sg] = o;  // (relative to the scan's first slot)
                 ct.seg_table[sg + 1] = huff_stage_segment(ct.dst + o, ct.src + first, n, ct.ps->check_at_staging ? &clean : nullptr);
                 o += huff_slot_bytes(n);
                 if (!clean) *ct.h_status |= 1u | 16u;  // something other than 0xFF00 pairs inside the scan: the host decodes this image
@@ -1130,11 +1106,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipEventRecord(b->ev_phase[0], s));
     }
     if (phase_times) B_HIP(hipEventRecord(b->ev_phase[1], s));
-    B_HIP(launch_huff_segments(reinterpret_cast<const HuffSyncJob *>(d + off_jobs), (uint32_t)n_seg_jobs, max_seg, s));
-    {
-        B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, sync_iters, s,
-                               phase_times ? b->ev_phase[2] : nullptr, nullptr, emitting, low_table_ids));
-    }
+    B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, sync_iters, s,
+                           phase_times ? b->ev_phase[2] : nullptr, low_table_ids));
     if (phase_times) {
         B_HIP(hipEventRecord(b->ev_phase[3], s));
         b->phase_events_valid = true;

@@ -16,22 +16,15 @@ struct FusedPlan {
     int kind = FUSED_NONE;
     uint32_t n_images = 0, ncomp = 0;
     std::vector<uint32_t> ids;       // batch-level index of each image of this plan (a batch may hold several plans)
-    bool strip = false;              // 4:2:0 through the single-launch strip walk
-    bool balanced = false;           // strip walks: work_main holds items {image, strip, [k0, k1)}, workgroup w owns items
-    uint32_t walk_wgs = 0;           //   wg_first[w] .. wg_first[w + 1] (walk_balanced_items, fused_plan.hpp); walk_wgs = workgroups aimed at
-    std::vector<uint32_t> wg_first;
-    uint32_t *d_wg_first = nullptr;
+    bool strip = false;              // a strip walk (4:2:0, 4:4:0): work items are {image, strip, MCU rows [k0, k1)}
     bool uniform = false;            // every image has the same geometry: 3-D grid, no work table
     uint32_t nt = 256;               // threads per workgroup of the main launch
     size_t lds_bytes = 0;            // dynamic LDS of the main launch (largest tile of the batch)
     std::vector<FusedGeom> geoms;    // per image
-    std::vector<FusedWork> work_main, work_pre;  // one entry per workgroup: main launch / 4:2:0 chroma pass
-    std::vector<size_t> scratch_off; // per image: its Cb|Cr planes in d_scratch
-    size_t scratch_bytes = 0;
-    uint8_t *d_scratch = nullptr;
+    std::vector<FusedWork> work_main;  // one entry per workgroup
     FusedImage *d_images = nullptr;
     FusedGeom *d_geoms = nullptr;
-    FusedWork *d_work_main = nullptr, *d_work_pre = nullptr;
+    FusedWork *d_work_main = nullptr;
     uint32_t *d_ids = nullptr;       // `ids` on the device (class_finalize_fused_kernel)
     hipEvent_t launched = nullptr;   // recorded behind every launch of the plan: fused_bind waits for it before it rewrites the
     bool launch_pending = false;     // tables a launch in flight may still be reading
@@ -41,9 +34,9 @@ struct FusedPlan {
     // (an image that needs the wrap-exact kernels costs only itself).  Built by fused_bind.
     bool by_class = false;
     uint32_t class_images[3] = {0, 0, 0};      // images per ARITH_* class (statistics: jpgpu_batch_class_counts)
-    FusedWork *d_work_cls = nullptr;           // main tables of the three classes, back to back, then the chroma-pass tables
+    FusedWork *d_work_cls = nullptr;           // work tables of the three classes, back to back
     size_t work_cls_cap = 0;
-    uint32_t n_main_cls[3] = {0, 0, 0}, n_pre_cls[3] = {0, 0, 0};
+    uint32_t n_main_cls[3] = {0, 0, 0};
 };
 
 // descs: the images of ONE kind (fused_kind_key); ids: their indices in the batch (for fused_bind's offset tables)

@@ -1,18 +1,18 @@
-// fused_core.hpp — bodies of the fused fast-path kernels (same-geometry batches, dct_scale 8).
+// fused_core.hpp — bodies of the fused fast-path kernels (dct_scale 8): coefficients in, interleaved pixels out, ONE launch per
+// kind, nothing but those two arenas in HBM.
 //
-//   FUSED_420  : 4:2:0 YCbCr (H2V2 / H1V1 / H1V1) -> RGB24.  Two launches per batch:
-//                  chroma pass : Cb, Cr coefficient planes -> u8 planes in a scratch arena
-//                                (same body as the generic IDCT kernel);
-//                  main pass   : per tile of TX MCUs x 1 MCU row: stage Y coefficients and the
-//                                chroma neighbourhood (+-1 sample halo) in LDS, IDCT the 4*TX luma
-//                                blocks (one lane per block), exchange through an LDS tile, then
-//                                fancy-upsample (src/upsampler.rs:191-228), colour convert
-//                                (src/decoder.rs:1486-1508) and store 24-B pixel runs, lanes
-//                                walking consecutive 8-pixel chunks of one scanline.
-//   FUSED_444  : 4:4:4 YCbCr or RGB -> RGB24, one launch, no halo.
-//   FUSED_GRAY : 1 component -> L8, one launch, IDCT written straight to the output rows
-//                (compute_image's stride compaction, src/decoder.rs:1310-1332, is just the
-//                output pitch).
+//   S420  (FUSED_420) : 4:2:0 YCbCr (H2V2 / H1V1 / H1V1) -> RGB24, a strip walk (below).
+//   S440  (FUSED_440) : 4:4:0 YCbCr (UpsamplerH1V2), the same walk without a horizontal halo.
+//   FGen  (FUSED_GEN) : the UpsamplerGeneric layouts (4:1:1, 4:1:0, 1x4, 2x4, 4x4), tile = tx MCUs of one MCU row.
+//   F422  (FUSED_422) : 4:2:2 YCbCr (UpsamplerH2V1), tile kernel, one halo block either side.
+//   F444  (FUSED_444) : 4:4:4 YCbCr or RGB -> RGB24, CMYK / YCCK at 4:4:4 -> 32-bit pixels; no halo.
+//   FGray (FUSED_GRAY): 1 component -> L8, IDCT written straight to the output rows (compute_image's stride compaction,
+//                       src/decoder.rs:1310-1332, is just the output pitch).
+//   (fused_x4.hpp: four components with half-size ones; fused_scaled.hpp: reduced-size decodes.)
+//   PixelOps<ARITH>   : upsample + colour + store helpers shared by the 4:2:0 and 4:2:2 kernels (src/upsampler.rs:134-228,
+//                       src/decoder.rs:1406-1437).
+// (Round 1's 4:2:0 was two launches — a chroma pass into u8 planes and a main pass that read their neighbourhood back, 4.11 GB
+// of traffic against 3.26 — kept through round 3 as the A/B partner of the walk and deleted in round 4.)
 //
 // Each kernel is a sequence of barrier-separated phases written as plain functions of
 // (geometry, image, tile, tid, LDS, per-lane registers) so that tests/emu can run the very same
@@ -24,7 +24,6 @@
 namespace jpgpu {
 
 constexpr uint32_t FUSED_NT = 256;       // threads per workgroup
-constexpr uint32_t F420_TX_MAX = 64;     // 4 luma blocks per MCU -> <= 256 lanes
 constexpr uint32_t F444_TX_MAX = 64;     // one wave per component, one lane per block
 constexpr uint32_t F422_TX_MAX = 62;     // 2 luma waves (124 blocks), one wave per chroma component (62 + 2 halo blocks)
 constexpr uint32_t FGRAY_TX_MAX = 256;   // 1 block per MCU
@@ -44,8 +43,7 @@ struct FusedGeom {
     uint32_t bwc;      // block_width of the chroma components (420) / all components (444)
     uint32_t cw, ch;   // chroma component size (420)
     uint32_t color;    // FCOLOR_* (444)
-    uint32_t chroma_plane_bytes;  // 420 scratch: bytes of one chroma plane (bwc*8 * bhc*8)
-    uint32_t strip;    // 420: 1 = single-launch strip walk (S420), 0 = chroma pass + main pass (F420)
+    uint32_t strip;    // 1: a strip walk (S420, S440): work items are (strip, MCU rows [k0, k1))
     uint32_t seg_rows; // S420: MCU rows per workgroup
     uint32_t n_seg;    // S420: ceil(mcu_h / seg_rows)
     uint32_t hs, vs;   // FGen: log2 of the luma sampling factors (H x V luma blocks per MCU)
@@ -62,29 +60,10 @@ struct FusedImage {
     const int16_t *coefs[4];
     const uint16_t *qt[4];
     uint8_t *out;
-    uint8_t *scratch;  // 4:2:0: Cb plane followed by Cr plane
     uint32_t flags;    // bit0: every component "sane" (|c*q| < 2^15), bit1: "tight" (column sums <= 5900) — pixel_math.hpp
     uint32_t _pad;
 };
 
-// 4:2:0 main pass LDS, sized at launch from the tile width (dynamic shared memory):
-//   coef   : 4*tx luma blocks x 128 B of coefficient staging, later the 16-row luma tile
-//   chroma : 2 components x 10 rows x cpitch, cpitch = 8 halo + 8*tx + 8 halo bytes
-// 1080p (tx = 60): 40,640 B -> four workgroups per CU instead of three with a fixed-size struct.
-struct F420Lds {
-    uint8_t *coef;
-    uint8_t *chroma;
-    uint32_t cpitch;
-    static __device__ __host__ __forceinline__ uint32_t coef_bytes(uint32_t tx) { return 4u * tx * 128u; }
-    static __device__ __host__ __forceinline__ uint32_t total_bytes(uint32_t tx) { return coef_bytes(tx) + 20u * (8u * tx + 16u); }
-    static __device__ __forceinline__ F420Lds make(uint8_t *base, uint32_t tx) {
-        F420Lds l;
-        l.coef = base;
-        l.chroma = base + coef_bytes(tx);
-        l.cpitch = 8u * tx + 16u;
-        return l;
-    }
-};
 struct alignas(16) FusedLdsSmall {          // kernels without a chroma neighbourhood
     uint8_t coef[FUSED_COEF_LDS];
 };
@@ -158,7 +137,7 @@ __device__ __forceinline__ void store_run(uint8_t *coef_lds, const v4u (&v)[LOAD
 }
 
 // =============================================================================================
-// FUSED_420 main pass
+// Pixel helpers of the kernels with horizontally subsampled chroma (4:2:0, 4:2:2)
 // =============================================================================================
 // SWAR helpers: two 16-bit lanes per dword (values stay below 2^12, so plain 32-bit adds and
 // shifts never carry between lanes).
@@ -166,91 +145,8 @@ __device__ __forceinline__ uint32_t swar_even(uint32_t d) { return d & 0x00ff00f
 __device__ __forceinline__ uint32_t swar_odd(uint32_t d) { return (d >> 8) & 0x00ff00ffu; }    // bytes 1,3
 __device__ __forceinline__ uint32_t swar_3a_b(uint32_t a, uint32_t b) { return (a << 1) + a + b; }
 
-template <int ARITH, uint32_t NT>
-struct F420 {
-    typedef F420Lds Lds;
-    static constexpr uint32_t TX_MAX = NT / 4;
-    static constexpr uint32_t NWAVES = NT / 64;
-    static constexpr uint32_t CITEMS = 20 / NWAVES;  // (component,row) chroma items per wave
-    static constexpr bool HAS_CB = TX_MAX + 2 > 64;  // a chroma row has more than 64 8-B granules
-    // effective MCUs of tile `tile_x`
-    static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
-        return min(g.tx, g.mcu_w - tile_x * g.tx);
-    }
-
-    // phase 0: stage luma coefficients (two block rows of the MCU row) and the chroma
-    // neighbourhood [8*my-1, 8*my+8] x [8*x0-8, 8*(x0+txe)+8) of both chroma planes into LDS.
-    static __device__ __forceinline__ void phase0(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, const Lds &lds) {
-        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t run8 = 2u * te * 8u;  // 16-B chunks per luma block row of the tile
-        const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)img.coefs[0];
-        const JP_GLOBAL v4u *row0 = src + ((size_t)(2u * my) * g.bw0 + 2u * x0m) * 8u;
-        const JP_GLOBAL v4u *row1 = row0 + (size_t)g.bw0 * 8u;
-        // chroma loads are issued first, the (larger) coefficient staging overlaps their latency.
-        // 8-B granules; LDS column lc <-> plane column 8*x0m - 8 + lc.  Wave w takes
-        // (component, row) items w, w+4, ... < 20; lanes walk the granules of a row.
-        const uint32_t stride = g.bwc * 8u, gran_per_row = te + 2u;
-        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
-        const int32_t col0 = (int32_t)(8u * x0m) - 8 + (int32_t)(8u * lane), col1 = col0 + 512;
-        const bool okc0 = lane < gran_per_row && col0 >= 0 && col0 < (int32_t)stride;
-        const bool okc1 = lane + 64u < gran_per_row && col1 >= 0 && col1 < (int32_t)stride;
-        const uint32_t colc0 = (uint32_t)min(max(col0, 0), (int32_t)stride - 8);
-        const uint32_t colc1 = (uint32_t)min(max(col1, 0), (int32_t)stride - 8);
-        const JP_GLOBAL uint8_t *planes = (const JP_GLOBAL uint8_t *)img.scratch;
-        v2u ca[CITEMS], cb[HAS_CB ? CITEMS : 1];
-        bool rok[CITEMS];
-#pragma unroll
-        for (uint32_t i = 0; i < CITEMS; i++) {
-            const uint32_t item = wave + NWAVES * i;  // < 20
-            const uint32_t comp = item >= 10u ? 1u : 0u;
-            const int32_t crow = (int32_t)(8u * my) - 1 + (int32_t)(item - comp * 10u);
-            const int32_t crowc = min(max(crow, 0), (int32_t)g.ch - 1);
-            rok[i] = crow == crowc;
-            const JP_GLOBAL uint8_t *prow = planes + (size_t)comp * g.chroma_plane_bytes + (size_t)crowc * stride;
-            ca[i] = *reinterpret_cast<const JP_GLOBAL v2u *>(prow + colc0);  // clamped address: unconditional
-            if constexpr (HAS_CB) cb[i] = *reinterpret_cast<const JP_GLOBAL v2u *>(prow + colc1);
-        }
-        v4u c0[4], c1[4];  // run8 <= 16 * TX_MAX = 4 * NT chunks per block row
-        load_run<NT, 4>(c0, row0, run8, tid);
-        load_run<NT, 4>(c1, row1, run8, tid);
-        store_run<NT, 4>(lds.coef, c0, run8, 0u, tid);
-        store_run<NT, 4>(lds.coef, c1, run8, 2u * te, tid);
-#pragma unroll
-        for (uint32_t i = 0; i < CITEMS; i++) {
-            const uint32_t item = wave + NWAVES * i;
-            if (rok[i]) {
-                if (okc0) *reinterpret_cast<v2u *>(&lds.chroma[item * lds.cpitch + 8u * lane]) = ca[i];
-                if constexpr (HAS_CB)
-                    if (okc1) *reinterpret_cast<v2u *>(&lds.chroma[item * lds.cpitch + 8u * (lane + 64u)]) = cb[i];
-            }
-        }
-    }
-
-    // phase 1: one lane per luma block: LDS -> registers -> IDCT
-    static __device__ __forceinline__ void phase1(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t tid,
-                                                  const Lds &lds, FusedRegs &r) {
-        const uint32_t te = txe(g, tile_x);
-        if (tid >= 4u * te) return;
-        uint32_t cw[32];
-        load_block_from_lds(lds.coef, tid, cw);
-        idct8x8<ARITH>(cw, as_qtab(img.qt[0]), r.out);
-    }
-
-    // phase 2: luma samples into the LDS tile (16 rows x 16*te bytes, pitch 16*tx), which
-    // aliases the (now consumed) coefficient staging area
-    static __device__ __forceinline__ void phase2(const FusedGeom &g, uint32_t tile_x, uint32_t tid, const Lds &lds,
-                                                  const FusedRegs &r) {
-        const uint32_t te = txe(g, tile_x);
-        if (tid >= 4u * te) return;
-        const uint32_t run = 2u * te, ypitch = 16u * g.tx;
-        const uint32_t ry = tid >= run ? 1u : 0u, cx = tid - ry * run;
-#pragma unroll
-        for (int row = 0; row < 8; row++)
-            *reinterpret_cast<v2u *>(&lds.coef[(ry * 8u + (uint32_t)row) * ypitch + cx * 8u]) =
-                v2u{r.out[2 * row], r.out[2 * row + 1]};
-    }
-
+template <int ARITH>
+struct PixelOps {
     // Chroma columns of one 8-pixel chunk as packed 16-bit lane pairs (hi, lo).  Plane column
     // j0 + i (j0 = ox0/2) is sample s_i; an output row needs s_-1 .. s_4, as the main samples of the even / odd pixel
     // pairs and their outer neighbours:
@@ -304,13 +200,6 @@ struct F420 {
     template <bool H2V1 = false, bool EDGES = true, bool FULL = false, bool NTS = true>
     static __device__ __forceinline__ void row_pixels(const FusedGeom &g, JP_GLOBAL uint8_t *o, bool row_al4,
                                                       const TPrime (&t)[2], v2u yy, uint32_t ox0) {
-#ifdef JPGPU_STUB_COLOUR  // experiment: the stores without the upsampling / conversion arithmetic
-        if (FULL) {
-            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{yy.x ^ t[0].tE1, yy.y ^ t[1].tO1, t[0].tOm};
-            *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{yy.y ^ t[1].tE1, yy.x ^ t[0].tO1, t[1].tEp};
-            return;
-        }
-#endif
         // pk[comp][0..3] = (px4,px0) (px5,px1) (px6,px2) (px7,px3) as (hi, lo) lanes
         constexpr uint32_t SH = H2V1 ? 2u : 4u;
         uint32_t pk[2][4];
@@ -374,79 +263,14 @@ struct F420 {
                 }
         }
     }
-
-    // phase 3: upsample + colour convert + store.
-    // Work unit = "slot" p (0..8) x 8-pixel chunk: slot p reads chroma LDS rows (p, p+1) and
-    // produces tile rows 2p-1 (near = row p) and 2p (near = row p+1), sharing the unpacking of the
-    // two chroma rows.  Wave w takes slots w, w+4, w+8 (slots 0 and 8 are half slots, so every wave
-    // does two slots' worth); lanes walk consecutive chunks, i.e. 24-B pixel runs next to each
-    // other on one scanline.
-    static __device__ __forceinline__ void phase3(const FusedGeom &g, const FusedImage &img, uint32_t tile_x, uint32_t my,
-                                                  uint32_t tid, const Lds &lds) {
-        const uint32_t x0m = tile_x * g.tx, te = txe(g, tile_x);
-        const uint32_t nch = 2u * te, ypitch = 16u * g.tx;
-        const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
-        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)img.out;
-#pragma unroll 1
-        for (uint32_t slot = wave; slot < 9u; slot += NWAVES) {
-            // output rows of the slot
-            const int32_t ra = 2 * (int32_t)slot - 1, rb = 2 * (int32_t)slot;  // tile rows
-            const uint32_t oya = 16u * my + (uint32_t)ra, oyb = 16u * my + (uint32_t)rb;
-            const bool va = slot >= 1u && oya < g.out_h, vb = slot <= 7u && oyb < g.out_h;
-            if (!va && !vb) continue;
-            // chroma rows (src/upsampler.rs:200-206): LDS row r <-> plane row 8*my - 1 + r
-            const int32_t cu = (int32_t)(8u * my) - 1 + (int32_t)slot;  // plane row of LDS row `slot`
-            const uint32_t U = slot, L = slot + 1u;
-            // row a: near U, far min(near+1, ch-1);  row b: near L, far max(near-1, 0)
-            const bool clamp_a = !(cu + 1 <= (int32_t)g.ch - 1), clamp_b = !(cu >= 0);
-            const size_t pitch = (size_t)g.out_w * 3u;
-            JP_GLOBAL uint8_t *rowa = out + (size_t)oya * pitch, *rowb = out + (size_t)oyb * pitch;
-            const bool al4a = (((size_t)oya * pitch) & 3u) == 0, al4b = (((size_t)oyb * pitch) & 3u) == 0;
-            // The lane's six LDS rows as finished, opaque addresses (chunk `lane`; LDS column of plane column j0 - 4 is
-            // 4*chk + 4): left to itself the compiler keeps offsets in the loop's registers and adds the start of the
-            // dynamic LDS segment at every use (`v_add_u32 v, 0, v`, six per unit).  A clamped chroma row is never staged:
-            // its partner stands in (uniform per slot).
-            const uint8_t *pu[2], *pl[2];
-#pragma unroll
-            for (uint32_t comp = 0; comp < 2; comp++) {
-                pu[comp] = opaque_lds(&lds.chroma[(comp * 10u + (clamp_b ? L : U)) * lds.cpitch + 4u * lane + 4u]);
-                pl[comp] = opaque_lds(&lds.chroma[(comp * 10u + (clamp_a ? U : L)) * lds.cpitch + 4u * lane + 4u]);
-            }
-            const uint8_t *pya = opaque_lds(&lds.coef[(uint32_t)(va ? ra : rb) * ypitch + 8u * lane]);
-            const uint8_t *pyb = opaque_lds(&lds.coef[(uint32_t)(vb ? rb : ra) * ypitch + 8u * lane]);
-            static_assert(F420_TX_MAX <= 64u, "a lane takes at most two chunks of a row");
-#pragma unroll  // both chunks spelled out: the second one's addresses are immediate offsets of the first one's
-            for (uint32_t it = 0; it < 2u; it++) {
-                const uint32_t chk = lane + 64u * it;
-                const uint32_t ox0 = 16u * x0m + 8u * chk;
-                if (chk >= nch || ox0 >= g.out_w) continue;
-                ChromaEO eu[2], el[2];
-#pragma unroll
-                for (uint32_t comp = 0; comp < 2; comp++) {
-                    eu[comp] = load_eo(pu[comp] + 256u * it);
-                    el[comp] = load_eo(pl[comp] + 256u * it);
-                }
-                if (va) {
-                    const TPrime t[2] = {tprime(eu[0], el[0]), tprime(eu[1], el[1])};
-                    const v2u yy = *reinterpret_cast<const v2u *>(pya + 512u * it);
-                    row_pixels(g, rowa + ox0 * 3u, al4a, t, yy, ox0);
-                }
-                if (vb) {
-                    const TPrime t[2] = {tprime(el[0], eu[0]), tprime(el[1], eu[1])};
-                    const v2u yy = *reinterpret_cast<const v2u *>(pyb + 512u * it);
-                    row_pixels(g, rowb + ox0 * 3u, al4b, t, yy, ox0);
-                }
-            }
-        }
-    }
 };
 
 // =============================================================================================
-// FUSED_420, single launch ("strip walk"): a workgroup owns a strip of `tx` (<= 42) MCU columns and walks the MCU rows
+// FUSED_420 ("strip walk"): a workgroup owns a strip of `tx` (<= 42) MCU columns and walks the MCU rows
 // [k0, k1) of it top to bottom.  Per MCU row it stages the 4*te luma blocks AND the 2*(te+2) chroma blocks under them
 // (one halo block each side: the fancy upsampler reads +-1 chroma sample) in LDS, transforms all of them (one lane
-// per block), and keeps the samples in LDS tiles: chroma never makes the round trip through HBM that the two-pass
-// form needs (0.8 of its 4.1 GB per 256 x 1080p).
+// per block), and keeps the samples in LDS tiles: chroma never makes a round trip through HBM (round 1's two-pass form
+// paid 0.8 of its 4.1 GB per 256 x 1080p for it).
 //   * Vertical neighbours.  Output row y reads chroma rows y/2 and y/2 -+ 1 (src/upsampler.rs:200-206), so step k emits
 //     output rows 16k-1 .. 16k+14: the tiles have a row 0 in front of the step's own rows — luma row 16k-1 and chroma row
 //     8k-1, carried over from step k-1 through a small LDS buffer — and row 16k+15 waits for step k+1.
@@ -498,7 +322,7 @@ struct S420Regs {
 template <int ARITH, uint32_t NTHREADS = 256>
 struct S420 {
     typedef S420Lds Lds;
-    typedef F420<ARITH, 256> P;  // pixel helpers (upsample + colour + store)
+    typedef PixelOps<ARITH> P;  // pixel helpers (upsample + colour + store)
     static constexpr uint32_t NT = NTHREADS;  // 256: strips of <= 42 MCUs; 128: <= 20
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t strip) {
         return min(g.tx, g.mcu_w - strip * g.tx);
@@ -543,13 +367,6 @@ struct S420 {
         auto at = [](const JP_GLOBAL v4u *base, uint32_t chunk) -> v4u {
             return *reinterpret_cast<const JP_GLOBAL v4u *>(reinterpret_cast<const JP_GLOBAL uint8_t *>(base) + chunk * 16u);
         };
-#ifdef JPGPU_STUB_LOADS  // experiment: no coefficient loads
-#pragma unroll
-        for (uint32_t i = 0; i < LY; i++) pre.y0[i] = pre.y1[i] = v4u{tid, k, i, 1u};
-#pragma unroll
-        for (uint32_t i = 0; i < LC; i++) pre.cb[i] = pre.cr[i] = v4u{tid, k, i, 2u};
-        return;
-#endif
 #pragma unroll
         for (uint32_t i = 0; i < LY; i++) {
             const uint32_t j = min(tid + NT * i, nl - 1u);  // clamped: unconditional loads
@@ -633,12 +450,7 @@ struct S420 {
             }
             idct8x8<ARITH_EXACT>(cw, qw, out);
         } else {
-#ifdef JPGPU_STUB_IDCT  // experiment: what the launch costs without the transform's arithmetic
-#pragma unroll
-            for (int i = 0; i < 16; i++) out[i] = cw[i] ^ cw[i + 16];
-#else
             idct8x8_products<ARITH>(cw, out);
-#endif
         }
     }
 
@@ -685,7 +497,7 @@ struct S420 {
         }
     }
 
-    // Chroma columns just outside the image repeat the first / last sample of their row (see F420::row_pixels<.., EDGES = false>).
+    // Chroma columns just outside the image repeat the first / last sample of their row (see PixelOps::row_pixels<.., EDGES = false>).
     // Plane column cw (= size.width: the upsampler's "last column" is pixel 2*cw-1, src/upsampler.rs:226) lies in the block
     // of column cw-1 unless that one ends the block: then, like column -1, it is a byte of the neighbouring block, which is
     // outside the plane and never transformed.  bx = plane block of the lane (x0m - 1 + cx).
@@ -747,9 +559,6 @@ struct S420 {
     static __device__ __forceinline__ void seam_transform(const FusedGeom &g, uint32_t strip, uint32_t k0, uint32_t k1, uint32_t tid,
                                                           const Lds &lds) {
         const uint32_t x0m = strip * g.tx, te = txe(g, strip), nb = te + 2u;
-#ifdef JPGPU_STUB_SEAM  // experiment: what shorter segments would cost if the seam round were free
-        return;
-#endif
         if (tid >= 4u * nb) return;
         const uint32_t which = (tid >= nb ? 1u : 0u) + (tid >= 2u * nb ? 1u : 0u) + (tid >= 3u * nb ? 1u : 0u);
         const uint32_t cx = tid - which * nb, c = which & 1u;
@@ -762,17 +571,14 @@ struct S420 {
         uint8_t *dst = below ? lds.bnd + c * lds.cpitch + cx * 8u : lds.carry + lds.ypitch + c * lds.cpitch + cx * 8u;
         uint32_t lo, hi;
         EdgeFix ef;
-#ifndef JPGPU_SEAM_FULL  // (A/B: -DJPGPU_SEAM_FULL = round 2's full transform of the seam blocks)
-        if constexpr (ARITH != ARITH_EXACT) {
+        if constexpr (ARITH != ARITH_EXACT) {  // (round 2 transformed the seam blocks in full: < 1 % either way, profiles/round3/04_seam_row_transform.txt)
             // only ONE sample row of a seam block is ever used: its first (block row k1, below) or its last (block row k0 - 1)
             if (below) idct8x8_products_row<ARITH, 0>(cw, lo, hi);
             else idct8x8_products_row<ARITH, 7>(cw, lo, hi);
             uint32_t row[16] = {lo, hi, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             ef = edge_fix<1>(g, x0m, cx, row);
             lo = row[0], hi = row[1];
-        } else
-#endif
-        {
+        } else {
             uint32_t out[16];
             transform_block(lds, 1u + c, cw, out);
             ef = edge_fix(g, x0m, cx, out);
@@ -998,13 +804,10 @@ struct S440 {
         if (below ? !(k1 < g.mcu_h) : !(k0 > 0u)) return;
         uint32_t cw[32], lo, hi;
         W::fetch_block(lds, tid, 1u + c, cw);
-#ifndef JPGPU_SEAM_FULL
         if constexpr (ARITH != ARITH_EXACT) {  // the one sample row that is kept (pixel_math.hpp idct8x8_products_row)
             if (below) idct8x8_products_row<ARITH, 0>(cw, lo, hi);
             else idct8x8_products_row<ARITH, 7>(cw, lo, hi);
-        } else
-#endif
-        {
+        } else {
             uint32_t out[16];
             W::transform_block(lds, 1u + c, cw, out);
             lo = below ? out[0] : out[14], hi = below ? out[1] : out[15];
@@ -1273,7 +1076,7 @@ struct FGen {
 // =============================================================================================
 template <int ARITH>
 struct F422 {
-    typedef F420<ARITH, 256> P;  // pixel helpers
+    typedef PixelOps<ARITH> P;  // pixel helpers
     static constexpr uint32_t NT = 256;
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile_x) {
         return min(g.tx, g.mcu_w - tile_x * g.tx);
@@ -1332,7 +1135,7 @@ struct F422 {
         uint8_t *base = comp == 0u ? lds.coef + cx * 8u : lds.coef + 8u * ypitch + (comp - 1u) * 8u * cp + cx * 8u;
         const uint32_t pitch = comp == 0u ? ypitch : cp;
         // chroma rows repeat their first / last sample in the column outside the image, so that the pixel phase needs no
-        // edge formula ((3 s + s + 2) >> 2 == s; see F420::row_pixels<.., EDGES = false> and S420::edge_fix)
+        // edge formula ((3 s + s + 2) >> 2 == s; see PixelOps::row_pixels<.., EDGES = false> and S420::edge_fix)
         uint32_t out[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) out[i] = r.out[i];
@@ -1362,7 +1165,7 @@ struct F422 {
         const size_t pitch = (size_t)g.out_w * 3u;
         const uint32_t wave = uniform(tid >> 6), lane = tid & 63u;
         // Wave w takes tile rows w and w + 4, its lanes walk the row's chunks (at most two each: tx <= 62): the scanline is
-        // wave-uniform (scalar address math), the lane's LDS addresses are finished before the chunks (see F420::phase3).
+        // wave-uniform (scalar address math), the lane's LDS addresses are finished before the chunks (as in the walks' pixel phase).
         static_assert(F422_TX_MAX <= 64u, "a lane takes at most two chunks of a row");
 #pragma unroll 1
         for (uint32_t row = wave; row < 8u; row += NT / 64u) {

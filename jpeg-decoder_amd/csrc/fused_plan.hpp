@@ -17,11 +17,8 @@ inline bool fused_same_component(const jpgpu_component &a, const jpgpu_component
 }
 
 // Returns FUSED_* and fills `g`; FUSED_NONE (with `why`) sends the batch down the generic path.
-// f420_tx_max: MCUs per 4:2:0 tile (32 -> 128-thread workgroups, 64 -> 256-thread workgroups; measured on
-// MI355X, 1080p x256: 0.899 ms with 64 vs 0.941 ms with 32 — profiles/round1)
-// strip420: 4:2:0 as the single-launch strip walk (S420) instead of chroma pass + main pass.
-inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why,
-                                uint32_t f420_tx_max = 64, bool strip420 = true, uint32_t s420_tx_max = S420_TX_MAX) {
+// s420_tx_max: widest strip of the 4:2:0 walk (test knob JPGPU_S420_TX: narrow strips exercise halos and seams on small images)
+inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const char *&name, const char *&why, uint32_t s420_tx_max = S420_TX_MAX) {
     g = FusedGeom{};
     for (uint32_t c = 0; c < d0.ncomp; c++)
         if (d0.components[c].dct_scale != 8) {
@@ -41,21 +38,19 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
         // choose_upsampler (src/upsampler.rs:80-81): an output width/height of 1 overrides H2V2,
         // such frames stay on the generic path
         kind = FUSED_420;
-        name = "fused420-2pass";
+        name = "fused420";
         g.mcu_w = d0.components[1].block_width;
         g.mcu_h = d0.components[1].block_height;
         g.bwc = d0.components[1].block_width;
         g.cw = d0.components[1].size_width;
         g.ch = d0.components[1].size_height;
-        g.chroma_plane_bytes = (uint32_t)d0.components[1].block_width * d0.components[1].block_height * 64u;
         if (d0.components[0].block_width != 2u * g.mcu_w || d0.components[0].block_height != 2u * g.mcu_h ||
             d0.out_w > 2u * g.cw || d0.out_h > 2u * g.ch) {
             why = "inconsistent block grid";
             return FUSED_NONE;
         }
-        tx_max = strip420 ? (s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max)) : (f420_tx_max <= 32u ? 32u : (f420_tx_max < F420_TX_MAX ? f420_tx_max : F420_TX_MAX));
-        g.strip = strip420 ? 1u : 0u;
-        if (strip420) name = "fused420";
+        tx_max = s420_tx_max < 1u ? 1u : (s420_tx_max > S420_TX_MAX ? S420_TX_MAX : s420_tx_max);
+        g.strip = 1u;
     } else if (d0.ncomp == 3 && hv(0, 2, 1) && hv(1, 1, 1) && hv(2, 1, 1) && d0.color_transform == JPGPU_CT_YCBCR && d0.out_w > 1 &&
                fused_same_component(d0.components[1], d0.components[2])) {
         // (an output width of 1 overrides H2V1 with H1V1, src/upsampler.rs:80: generic path)
@@ -217,51 +212,6 @@ inline void s420_set_segments(FusedGeom &g, uint32_t n_images, uint32_t seg_rows
     if (seg > g.mcu_h) seg = g.mcu_h;
     g.seg_rows = seg;
     g.n_seg = (g.mcu_h + seg - 1) / seg;
-}
-
-// Strip walks, balanced: the launch's steps (one step = one MCU row of one strip) are dealt to `n_wg` workgroups in equal
-// contiguous shares of the sequence (image, strip, MCU row) — address order.  A share that crosses the end of a strip continues
-// at the top of the next one: a workgroup owns a list of work items {image, strip, [k0, k1)}, `wg_first[w]` .. `wg_first[w + 1]`.
-// With n_wg = the number of workgroups the device holds at once, every workgroup is resident from the first cycle to the last
-// and all of them finish together; with one (strip, segment) per workgroup the 2304 workgroups of 256 x 1080p ran as two full
-// rounds and a quarter-full third one (measured: 0.596 of the roofline there against 0.638 for 4096 images, whose 12288
-// workgroups happen to be twelve full rounds).  Seams: one per item that starts below the top / ends above the bottom of its strip.
-template <class Vec32, class VecWork>
-inline void walk_balanced_items(const FusedGeom *geoms, const uint32_t *image_ids, uint32_t n_images, uint32_t n_wg, VecWork &items, Vec32 &wg_first) {
-    items.clear();
-    wg_first.clear();
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n_images; i++) total += (uint64_t)geoms[image_ids ? image_ids[i] : i].tiles_x * geoms[image_ids ? image_ids[i] : i].mcu_h;
-    if (total == 0) {
-        wg_first.push_back(0u);
-        return;
-    }
-    if (n_wg < 1u) n_wg = 1u;
-    if ((uint64_t)n_wg > total) n_wg = (uint32_t)total;
-    uint64_t done = 0;  // steps handed out so far
-    uint32_t w = 0;     // workgroup being filled: it ends at step (w + 1) * total / n_wg
-    wg_first.push_back(0u);
-    for (uint32_t i = 0; i < n_images; i++) {
-        const uint32_t img = image_ids ? image_ids[i] : i;
-        const FusedGeom &g = geoms[img];
-        for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
-            uint32_t k = 0;
-            while (k < g.mcu_h) {
-                const uint64_t end = (uint64_t)(w + 1u) * total / n_wg;  // first step of the next workgroup
-                const uint32_t take = (uint32_t)(end - done < (uint64_t)(g.mcu_h - k) ? end - done : g.mcu_h - k);
-                FusedWork it;
-                it.image = img, it.a = strip, it.b = k, it.c = k + take;
-                items.push_back(it);
-                k += take;
-                done += take;
-                if (done == end && w + 1u < n_wg) {
-                    w++;
-                    wg_first.push_back((uint32_t)items.size());
-                }
-            }
-        }
-    }
-    while (wg_first.size() < (size_t)n_wg + 1u) wg_first.push_back((uint32_t)items.size());
 }
 
 }  // namespace jpgpu

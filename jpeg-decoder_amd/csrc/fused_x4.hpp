@@ -57,7 +57,7 @@ template <int ARITH, bool K_FULL>
 struct R4 {
     typedef R4Lds Lds;
     typedef S420<ARITH, 256> W;        // fetch_block / transform_block (they look at lds.stage and lds.qtab only)
-    typedef F420<ARITH, 256> P;        // ChromaEO / load_eo
+    typedef PixelOps<ARITH> P;        // ChromaEO / load_eo
     static constexpr uint32_t NT = 256, NL = K_FULL ? 2u : 1u, NH = K_FULL ? 2u : 3u;
     static constexpr uint32_t LY = 1u;  // 16*tx <= 256 chunks per full-size block row: one load per lane and run
     static __device__ __forceinline__ uint32_t txe(const FusedGeom &g, uint32_t tile) { return min(g.tx, g.mcu_w - tile * g.tx); }
@@ -207,7 +207,7 @@ struct R4 {
     }
 
     // t' = 3*near + far + 2 per 16-bit lane (src/upsampler.rs:209,217).  CENTRED = false: as it is (the sample is wanted);
-    // true: minus 512, so that the horizontal step yields the sample minus 128 (what the colour conversion wants: F420::tprime)
+    // true: minus 512, so that the horizontal step yields the sample minus 128 (what the colour conversion wants: PixelOps::tprime)
     template <bool CENTRED>
     static __device__ __forceinline__ typename P::TPrime tprime(const typename P::ChromaEO &n, const typename P::ChromaEO &f) {
         const uint32_t two = CENTRED ? 0xfe02fe02u : 0x00020002u;

@@ -1,5 +1,6 @@
-// huff.hip — device entropy decoding of restart-marker streams (huff_core.hpp) and the range scan that classifies the
-// coefficients it produced (the host never sees them).
+// huff.hip — kernels of the device entropy decoder (huff_sync_core.hpp: sync passes with speculative emission, block numbering,
+// expansion of the entry lists into whole blocks, DC sums of scans whose components share their tables) and the range scan for
+// coefficients a caller's own kernels put into an arena (jpgpu_batch_classify_on_device / _scan_ranges, the Worker's fused route).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
@@ -116,7 +117,6 @@ __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffS
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)&L.job;
         for (uint32_t i = threadIdx.x; i < sizeof(HuffSyncJob) / 4u; i += NT) dst[i] = src[i];
     }
-    huff_fill_unzigzag((JP_LDS uint8_t *)L.unzig, threadIdx.x & 63u);
     {
         const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj->tables;
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)L.tables;
@@ -125,20 +125,6 @@ __device__ __forceinline__ void sync_load_lds(JP_LDS HuffSyncLds &L, const HuffS
     __syncthreads();
     for (uint32_t l = threadIdx.x; l < 512u; l += NT) huff_sync_fill_lds(L, l);
     __syncthreads();
-}
-
-// Restart-segment decoder: grid = (ceil(max segments / 64), segment jobs), one wave per workgroup — lanes diverge (every
-// lane walks its own bit stream), so small workgroups spread the segments over as many SIMDs as possible.
-__global__ __launch_bounds__(64) void huff_segments_kernel(const HuffSyncJob *__restrict__ jobs) {
-    __shared__ HuffSyncLds L;
-    const HuffSyncJob *gj = &jobs[blockIdx.y];
-    if (blockIdx.x * 64u >= gj->n_seg) return;
-    sync_load_lds<64>(*(JP_LDS HuffSyncLds *)&L, gj);
-    __shared__ uint32_t ring[HUFF_RING_DWORDS][64];
-    const uint32_t seg = blockIdx.x * 64u + threadIdx.x;
-    HuffRange rg;
-    if (seg < L.job.n_seg) huff_decode_segment(*(JP_LDS HuffSyncLds *)&L, seg, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], 64u);
-    publish_range(L.job.stats, rg);
 }
 
 // does chunk i have a start state it has not decoded from yet?  (what huff_sync_chunk decides itself, ahead of the call)
@@ -160,11 +146,8 @@ __device__ __forceinline__ bool sync_chunk_has_work(const HuffSyncJob *gj, uint3
 
 // TABLES = 4: every job of the launch uses Huffman table ids 0 and 1 only — the LDS image ends behind their four slots
 // (HUFF_SYNC_LDS_COMPACT_BYTES: 24 kB, six workgroups per CU where the full 40 kB allow four).
-#ifndef JPGPU_SYNC_WAVES_PER_EU
-#define JPGPU_SYNC_WAVES_PER_EU 4  // (A/B builds: registers for this many waves per SIMD)
-#endif
 template <uint32_t TABLES>
-__global__ __launch_bounds__(SYNC_NT, JPGPU_SYNC_WAVES_PER_EU) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
+__global__ __launch_bounds__(SYNC_NT, 4) void huff_sync_pass_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass,
                                                                                           uint32_t iters) {
     static_assert(TABLES == 4u || TABLES == 8u, "");
     __shared__ alignas(16) uint8_t L_raw[TABLES == 8u ? sizeof(HuffSyncLds) : HUFF_SYNC_LDS_COMPACT_BYTES];
@@ -197,9 +180,7 @@ __global__ __launch_bounds__(SYNC_NT, JPGPU_SYNC_WAVES_PER_EU) void huff_sync_pa
         }
         if (need) todo[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
         __syncthreads();
-        HuffRange unused;
-        if (threadIdx.x < total)
-            published |= huff_sync_chunk<false>(L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it, unused);
+        if (threadIdx.x < total) published |= huff_sync_chunk(L, blockIdx.x * SYNC_NT + todo[threadIdx.x], first_pass + it);
         __syncthreads();
     }
     const uint32_t n_pub = (uint32_t)__syncthreads_count(published);
@@ -244,7 +225,7 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
         carry += total;
         __syncthreads();
     }
-    if (emits) {  // (jobs with a write pass: that pass raises these)
+    if (emits) {
         if (threadIdx.x == 0) bad |= huff_emit_final_status(job, carry);
         if (bad) atomicOr(job.status, bad);
     }
@@ -288,57 +269,18 @@ __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJ
     }
 }
 
-__global__ __launch_bounds__(SYNC_NT) void huff_sync_write_kernel(const HuffSyncJob *__restrict__ jobs) {
-    __shared__ HuffSyncLds L;
-    const HuffSyncJob *gj = &jobs[blockIdx.y];
-    if (blockIdx.x * SYNC_NT >= gj->n_chunks || gj->emit != nullptr) return;  // (emitting jobs: huff_expand_kernel)
-    if (*gj->status != 0u) return;
-    sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
-    __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
-    const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
-    HuffRange rg;
-    if (i < L.job.n_chunks) huff_sync_chunk<true>(*(JP_LDS HuffSyncLds *)&L, i, 0u, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
-    publish_range(L.job.stats, rg);
-}
-
-// The same with whole blocks assembled in LDS and written as 128-byte lines (HuffWriteBuf; two workgroups per CU by its size)
-__global__ __launch_bounds__(SYNC_NT) void huff_sync_write_assembled_kernel(const HuffSyncJob *__restrict__ jobs) {
-    __shared__ HuffSyncLds L;
-    __shared__ HuffWriteBuf W;
-    const HuffSyncJob *gj = &jobs[blockIdx.y];
-    if (blockIdx.x * SYNC_NT >= gj->n_chunks || gj->emit != nullptr) return;
-    if (*gj->status != 0u) return;
-    sync_load_lds<SYNC_NT>(*(JP_LDS HuffSyncLds *)&L, gj);
-    {
-        JP_LDS uint32_t *z = (JP_LDS uint32_t *)&W.blk[0][0];
-        for (uint32_t t = threadIdx.x; t < sizeof(W.blk) / 4u; t += SYNC_NT) z[t] = 0u;
-    }
-    __syncthreads();
-    const uint32_t i = blockIdx.x * SYNC_NT + threadIdx.x;
-    __shared__ uint32_t ring[HUFF_RING_DWORDS][SYNC_NT];
-    HuffRange rg;
-    huff_sync_write_assembled(*(JP_LDS HuffSyncLds *)&L, *(JP_LDS HuffWriteBuf *)&W, i, i < L.job.n_chunks, rg, (JP_LDS uint32_t *)&ring[0][threadIdx.x], SYNC_NT);
-    publish_range(L.job.stats, rg);
-}
-
 // ---- speculative emission -> whole blocks (HuffSyncJob::emit) ----------------------------------------------------------
 // One WAVE per chunk (no workgroup barriers inside): it reads the chunk's entries 64 at a time, numbers the blocks they belong
 // to (a ballot of the "first of a block" bits), scatters the values into a ring of block images in LDS and writes every block
 // that is complete as one 128-byte line, eight lanes each — the arena gets every block of the scan exactly once, zeros
-// included, so nobody has to clear it first, and the 2-byte stores of the write pass happen in LDS instead of HBM.  A block
+// included, so nobody has to clear it first, and the 2-byte scatter happens in LDS instead of HBM.  A block
 // belongs to the chunk it STARTS in; the wave follows it through the leading entries of the chunks after.
 // All of a chunk's entries are requested before the first is used (up to EXP_LOADS x 64 per round): a wave that waits for
 // every 256 bytes in turn would leave the memory system idle.
-#ifndef JPGPU_EXP_THR  // A/B builds: complete blocks waiting in the ring before a store round (8: full rounds only; 1: right away)
-#define JPGPU_EXP_THR 8
-#endif
-#ifndef JPGPU_EXP_CHUNKS
-#define JPGPU_EXP_CHUNKS 8
-#endif
-#ifndef JPGPU_EXP_LOADS
-#define JPGPU_EXP_LOADS 16
-#endif
-constexpr uint32_t EXP_WAVES = 4, EXP_CHUNKS = JPGPU_EXP_CHUNKS, EXP_SLOT = 68, EXP_THR = JPGPU_EXP_THR, EXP_LOADS = JPGPU_EXP_LOADS;
+// EXP_THR: complete blocks waiting in the ring before a store round (8: full rounds only — store rounds after every batch of
+// entries measured 0.67 ms against 0.61); EXP_CHUNKS: chunks per wave; EXP_LOADS x 64: entries requested ahead per chunk
+// (profiles/round3/14_emission_path.txt).
+constexpr uint32_t EXP_WAVES = 4, EXP_CHUNKS = 8, EXP_SLOT = 68, EXP_THR = 8, EXP_LOADS = 16;
 constexpr uint32_t EXP_SLOTS = EXP_THR + 65u;  // complete blocks that may wait + 1 open + 64 new
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 struct ExpandLds {
@@ -679,12 +621,6 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
     publish_range(job.stats, HuffRange{max_dc, 0u});
 }
 
-hipError_t launch_huff_segments(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream) {
-    if (n_jobs == 0 || max_segments == 0) return hipSuccess;
-    huff_segments_kernel<<<dim3((max_segments + 63u) / 64u, n_jobs), dim3(64), 0, stream>>>(d_jobs);
-    return hipGetLastError();
-}
-
 hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream) {
     if (n_blocks == 0) return hipSuccess;
     range_scan_one_kernel<<<dim3((n_blocks + 255u) / 256u), dim3(256), 0, stream>>>(d_coefs, n_blocks, d_q, d_stats);
@@ -697,10 +633,10 @@ hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t m
     return hipGetLastError();
 }
 
-// Everything for the jobs without restart markers, enqueued blind: a fixed number of sync launches (settled jobs cost an
-// empty workgroup each), block numbering, the write pass and the DC sums.
+// Everything for a sub-batch's scans, enqueued blind: a fixed number of sync launches (settled jobs cost an empty workgroup
+// each), block numbering, the expansion of the entry lists and the DC sums of `uniform` scans.
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync, hipEvent_t before_write, bool emitting, bool low_table_ids) {
+                            hipEvent_t after_sync, bool low_table_ids) {
     if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) {
         if (after_sync) (void)hipEventRecord(after_sync, stream);
         return hipSuccess;
@@ -712,23 +648,7 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     }
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);
     if (after_sync) (void)hipEventRecord(after_sync, stream);
-    if (before_write) (void)hipStreamWaitEvent(stream, before_write, 0);  // (the zero fill of the planes, enqueued on another stream)
-    // The write pass runs best with TWO workgroups per CU: every lane keeps a cache line of the arena open for its 2-byte
-    // stores, and fewer lanes in flight means fewer open lines (measured, 256 1080p images: 6 workgroups per CU 2.19 ms,
-    // 4: 2.26, 2: 1.89, 1: 3.2).  Unused dynamic LDS is the occupancy limiter.
-    static const uint32_t write_lds = [] {
-        const char *e = getenv("JPGPU_SYNC_WRITE_LDS");  // tuning knob: bytes of dynamic LDS added to the write kernel
-        return e ? (uint32_t)atoi(e) : 0u;  // (the kernel's own 57 kB — tables, ring — already mean two workgroups per CU)
-    }();
-    // A/B switch, off by default: whole blocks assembled in LDS and written as 128-byte lines by eight lanes each
-    // (huff_sync_write_assembled_kernel) measured 2.26 ms against 2.14 ms for the plain kernel at two workgroups per CU —
-    // the extra ~35 instructions per step of the cooperative stores cost more than the 2-byte stores they replace.
-    const char *asm_env = getenv("JPGPU_SYNC_WRITE_ASSEMBLE");
-    const bool assembled = asm_env && atoi(asm_env) != 0;
-    if (emitting)  // (every job of the call carries emission buffers: the lists the sync passes left -> whole blocks)
-        huff_expand_kernel<<<dim3((max_chunks + EXP_WAVES * EXP_CHUNKS - 1u) / (EXP_WAVES * EXP_CHUNKS), n_jobs), dim3(EXP_WAVES * 64u), 0, stream>>>(d_jobs);
-    else if (assembled) huff_sync_write_assembled_kernel<<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs);
-    else huff_sync_write_kernel<<<grid, dim3(SYNC_NT), write_lds, stream>>>(d_jobs);
+    huff_expand_kernel<<<dim3((max_chunks + EXP_WAVES * EXP_CHUNKS - 1u) / (EXP_WAVES * EXP_CHUNKS), n_jobs), dim3(EXP_WAVES * 64u), 0, stream>>>(d_jobs);
     huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(DC_NT), 0, stream>>>(d_jobs);
     return hipGetLastError();
 }

@@ -15,13 +15,11 @@ struct RangeJob {  // one component plane to classify
     uint16_t q[64];
 };
 
-hipError_t launch_huff_segments(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_segments, hipStream_t stream);
-// after_sync (optional): recorded between the sync passes + block numbering and the write pass (phase timing)
-// before_write (optional): the write pass (the first kernel that touches the coefficient planes) waits for it
-// emitting: the jobs carry emission buffers (HuffSyncJob::emit) — huff_expand_kernel instead of the write pass
+// Sync passes (with speculative emission) + block numbering | expansion of the entry lists + DC sums of `uniform` scans.
+// after_sync (optional): recorded between the two (phase timing)
 // low_table_ids: every job's components use Huffman table ids 0 and 1 only — the sync passes run with four table slots in LDS
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync = nullptr, hipEvent_t before_write = nullptr, bool emitting = false, bool low_table_ids = false);
+                            hipEvent_t after_sync = nullptr, bool low_table_ids = false);
 hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t *d_stats, hipStream_t stream);
 // one plane whose quantization table sits in device memory; raises the RS_WORDS statistics words at d_stats
 hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream);

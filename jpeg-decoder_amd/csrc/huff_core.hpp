@@ -1,6 +1,6 @@
-// huff_core.hpp — bit reader and Huffman symbol lookup of the device entropy decoders (huff_sync_core.hpp: restart
-// segments, SURVEY §8f n1 "DRI segments are independently decodable", src/decoder.rs:920-956, and the chunk decoder for
-// scans without restart markers).  The decoding procedure is the reference's (src/huffman.rs:31-96) on the same wide tables
+// huff_core.hpp — bit reader and Huffman symbol lookup of the device entropy decoder (huff_sync_core.hpp: the self-synchronising
+// chunk decoder; restart segments — SURVEY §8f n1 "DRI segments are independently decodable", src/decoder.rs:920-956 — are scans
+// in miniature with chunk slots of their own).  The decoding procedure is the reference's (src/huffman.rs:31-96) on the same wide tables
 // the host front-end uses (csrc/host/frontend.cpp: an exact cache of the 8-bit LUT + maxcode walk).  Compiled by hipcc for
 // the kernels (huff.hip) and by g++ for tests/emu.
 //
@@ -23,26 +23,11 @@
 
 namespace jpgpu {
 
-// Three ways to fetch the stream (template parameter of huff_refill / huff_open_at; the fields of the others are dead):
-//   HUFF_READ_16:   two 16-byte pieces in registers, one reloaded every fourth refill.  Few memory instructions, but the
-//                   compiler waits for the load right behind it (the value has to be copied into the loop-carried
-//                   registers), and with 64 lanes per wave some lane reloads in nearly every step.
-//   HUFF_READ_DW:   one dword per refill, fetched one refill AHEAD into the register the previous one just left (the empty
-//                   asm keeps the load behind the last use of the old value, so no copy and no wait until the next refill).
-//   HUFF_READ_RING: a ring of 32 dwords per lane in LDS, topped up every 16 steps (a step takes at most 31 bits, the ring
-//                   then holds at least 96 bytes ahead).  For the kernels that also STORE: on gfx9 a wait for a load
-//                   (vmcnt) is a wait for every store issued before it as well, and with a stream load in nearly every step
-//                   the write pass spent its life in such waits (SQ_WAIT_ANY 56 % of the wave cycles); with the ring the
-//                   wave waits for memory once per 16 steps and the per-step reads are LDS reads.
-// Measured (256 1080p images): sync passes 2.53 ms with 16-byte pieces, 2.14 ms with dwords; write pass: see DESIGN.md §5.
-enum HuffReader { HUFF_READ_16 = 0, HUFF_READ_DW = 1, HUFF_READ_RING = 2 };
-#ifndef JPGPU_RING_DWORDS  // (A/B builds: -DJPGPU_RING_DWORDS=16 -DJPGPU_RING_AHEAD=12 -DJPGPU_RING_PERIOD=8)
-#define JPGPU_RING_DWORDS 32
-#define JPGPU_RING_AHEAD 24
-#define JPGPU_RING_PERIOD 16
-#endif
-constexpr uint32_t HUFF_RING_DWORDS = JPGPU_RING_DWORDS, HUFF_RING_AHEAD = JPGPU_RING_AHEAD, HUFF_RING_PERIOD = JPGPU_RING_PERIOD;
-
+// How the stream is fetched: one aligned dword per refill, requested one refill AHEAD into the register the previous one just
+// left (the empty asm keeps the load behind the last use of the old value, so no copy and no wait until the next refill).
+// Rounds 1-3 also carried a reader of 16-byte pieces (sync passes of 256 1080p images 2.53 ms against 2.14 with dwords) and an LDS
+// ring for the kernels that stored coefficients themselves (the write pass and the one-lane-per-restart-segment decoder, both
+// replaced by speculative emission + huff_expand_kernel and deleted in round 4: profiles/round3/14_emission_path.txt).
 struct DevBits {
     uint64_t bits;   // unread bits, left-aligned
     uint32_t nbits;
@@ -50,63 +35,20 @@ struct DevBits {
     const JP_GLOBAL v4u *g;  // the slot (16-byte aligned, zero padded: huff_stage_segment).  An address-space-1 pointer: through a generic
                              // one the fetches are flat_load instructions, which count as LDS operations too — every wait for an LDS
                              // read behind one (and the loop is full of them) then waits for the stream fetch as well
-    v4u cur, nxt;    // HUFF_READ_16: 16-byte piece wpos / 4 and the one after it
-    uint32_t ahead;  // HUFF_READ_DW: dword wpos
-    JP_LDS uint32_t *ring;  // HUFF_READ_RING: this lane's column of the ring (dword d of the stream at ring[(d % 32) * ring_stride])
-    uint32_t ring_stride;   //   lanes of the workgroup (the ring is stored dword-major: no bank conflicts between lanes)
-    uint32_t fetched;       //   dwords of the stream in the ring so far (a multiple of 4)
+    uint32_t ahead;  // dword wpos
     bool bad;
 };
 
-// HUFF_READ_RING: bring the ring to at least HUFF_RING_AHEAD dwords ahead of the reader (at most 4 pieces of 16 bytes: all
-// requested, then one wait)
-__device__ __forceinline__ void huff_ring_topup(DevBits &b) {
-    const uint32_t have = b.fetched - b.wpos;
-    const uint32_t need = have >= HUFF_RING_AHEAD ? 0u : min(4u, (HUFF_RING_AHEAD - have + 3u) >> 2);
-    v4u c[4];
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; j++)
-        if (j < need) c[j] = b.g[(b.fetched >> 2) + j];
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; j++)
-        if (j < need) {
-            const uint32_t d = b.fetched + 4u * j;
-            b.ring[((d + 0u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].x;
-            b.ring[((d + 1u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].y;
-            b.ring[((d + 2u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].z;
-            b.ring[((d + 3u) % HUFF_RING_DWORDS) * b.ring_stride] = c[j].w;
-        }
-    b.fetched += 4u * need;
-}
-
 // at most once per step: afterwards more than 32 bits are available (a step reads <= 16 + 15)
-template <int RD>
 __device__ __forceinline__ void huff_refill(DevBits &b) {
     if (b.nbits <= 32u) {
-        if (RD == HUFF_READ_RING) {
-            const uint32_t x = b.ring[(b.wpos % HUFF_RING_DWORDS) * b.ring_stride];
-            b.bits |= (uint64_t)__builtin_bswap32(x) << (32u - b.nbits);
-            b.nbits += 32u;
-            b.wpos++;
-        } else if (RD == HUFF_READ_DW) {
-            b.bits |= (uint64_t)__builtin_bswap32(b.ahead) << (32u - b.nbits);
-            b.nbits += 32u;
-            b.wpos++;
+        b.bits |= (uint64_t)__builtin_bswap32(b.ahead) << (32u - b.nbits);
+        b.nbits += 32u;
+        b.wpos++;
 #ifndef JPGPU_HOST_EMULATION
-            asm volatile("" : "+v"(b.bits) : : "memory");  // the old `ahead` is dead from here on
+        asm volatile("" : "+v"(b.bits) : : "memory");  // the old `ahead` is dead from here on
 #endif
-            b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
-        } else {
-            const uint32_t w = b.wpos & 3u;
-            const uint32_t x = w == 0u ? b.cur.x : (w == 1u ? b.cur.y : (w == 2u ? b.cur.z : b.cur.w));
-            b.bits |= (uint64_t)__builtin_bswap32(x) << (32u - b.nbits);
-            b.nbits += 32u;
-            b.wpos++;
-            if ((b.wpos & 3u) == 0u) {
-                b.cur = b.nxt;
-                b.nxt = b.g[(b.wpos >> 2) + 1u];
-            }
-        }
+        b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
     }
 }
 __device__ __forceinline__ uint32_t huff_peek(const DevBits &b, uint32_t n) { return n ? (uint32_t)(b.bits >> (64u - n)) : 0u; }

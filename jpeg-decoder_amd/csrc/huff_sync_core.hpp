@@ -1,27 +1,28 @@
-// huff_sync_core.hpp — entropy decoding ON THE DEVICE for sequential Huffman scans WITHOUT restart markers: the
-// self-synchronising chunked decoder (Klein & Wiseman 2003; Weissenberger & Schmidt 2018/2021 for JPEG).
+// huff_sync_core.hpp — entropy decoding ON THE DEVICE for sequential Huffman scans: the self-synchronising chunked decoder
+// (Klein & Wiseman 2003; Weissenberger & Schmidt 2018/2021 for JPEG) with speculative emission.
 //
 // A Huffman bit stream decoded from a wrong position re-synchronises with the true symbol boundaries after a few
-// symbols with high probability.  The scan (unstuffed by the host, huff_stage_segment) is cut into chunks of 1,024 to 32,768
-// bits (huff_sync_chunk_shift), one lane per chunk:
-//   1. sync passes (huff_sync_chunk<false>): lane i decodes from its current start state to the first symbol boundary at
-//      or beyond the end of its chunk and publishes that state for lane i+1.  State = (bit position, block-within-MCU,
-//      coefficient index) — which tables apply and where a block ends; DC predictors and absolute block numbers are
-//      additive and come later.  Pass 0 starts every lane but the first at its chunk boundary with state (block 0,
-//      DC next); pass t > 0 re-decodes the lanes whose predecessor published something new.  Lane 0 always starts from the
-//      truth, so a pass that changes nothing has reached the unique consistent — the true — segmentation.
-//   2. an exclusive scan of the blocks completed per chunk gives every chunk its first block number;
-//   3. the write pass (huff_sync_chunk<true>) decodes every chunk once more from its final start state and writes
-//      coefficients into the zero-filled arena;
-//   4. DC values are running sums of differences per component (i16 wrapping adds, src/decoder.rs:1095-1099): every
-//      sync pass also leaves the chunk's sum of DC differences per component, the scan of step 2 turns them into the
-//      predictors each chunk starts from, and the write pass stores finished DC values.  (Scans whose components all share
-//      their tables — `uniform` — do not know the component of a block before step 2: their write pass stores the
-//      differences and huff_dc_prefix_kernel runs the sums afterwards, one scattered read-modify-write per block.)
-// Speculative decoding may run into impossible codes; only what the write pass sees counts: an undecodable code, an
-// EOBn run (legal only in progressive scans), data that ends before the last block — and a segmentation that has not
+// symbols with high probability.  The scan (unstuffed by the host, huff_stage_segment) is cut into chunks of 512 to 32,768
+// bits (huff_sync_chunk_shift), one lane per chunk; a restart segment is a scan in miniature with chunk slots of its own:
+//   1. sync passes (huff_sync_chunk): lane i decodes from its current start state to the first symbol boundary at or beyond
+//      the end of its chunk and publishes that state for lane i+1.  State = (bit position, block-within-MCU, coefficient
+//      index) — which tables apply and where a block ends; DC predictors and absolute block numbers are additive and come
+//      later.  Pass 0 starts every lane at a guess inside its chunk with state (block 0, DC next); pass t > 0 re-decodes the
+//      lanes whose predecessor published something new.  The first lane of a scan / segment always starts from the truth,
+//      so a pass that changes nothing has reached the unique consistent — the true — segmentation.  Every pass but the first
+//      leaves what it decodes as a list of entries per chunk (HuffEmit): once nothing changes, the lists ARE the scan;
+//   2. an exclusive scan of the blocks completed per chunk gives every chunk its first block number, and the sums of DC
+//      differences per chunk and component (i16 wrapping adds, src/decoder.rs:1095-1099) become the predictors each chunk
+//      starts from (huff_sync_scan_kernel; per restart segment: huff_emit_segment_scan);
+//   3. huff_expand_kernel turns the lists into whole 128-byte blocks.  (Scans whose components all share their tables —
+//      `uniform` — do not know the component of a block before step 2: their entries hold the differences and
+//      huff_dc_prefix_kernel runs the sums afterwards, one scattered read-modify-write per block.)
+// Speculative decoding may run into impossible codes; only what the settled segmentation says counts: an undecodable code,
+// an EOBn run (legal only in progressive scans), data that ends before the last block — and a segmentation that has not
 // settled after the allotted passes — raise the image's status word and the host decodes that image.
 // The per-symbol step is decode_block (src/decoder.rs:1020-1107) as a table-driven state machine (huff_sym_info).
+// (Rounds 1-3 had a write pass — every chunk decoded once more, coefficients stored one by one into a zero-filled arena — and a
+// one-lane-per-restart-segment decoder; both lost to emission + expansion and were deleted in round 4.)
 #pragma once
 #include "huff_core.hpp"
 
@@ -48,11 +49,7 @@ struct HuffSyncLds {
     HuffSyncJob job;
     uint16_t sym_info[2][256];  // [DC | AC][symbol]
     uint32_t q_tables[16];      // block-within-MCU -> byte offset of its DC table in `tables` | its AC table << 16
-    HuffBlockDst q_dst[16];
-    uint32_t dc[256][4];        // per lane and component: sum of DC differences (sync passes) / DC predictor (write pass)
-    uint8_t unzig[64];
-    uint32_t unzq[4][64];       // per scan component and zig-zag index k: natural position | quantization value there << 16 — the
-                                // write pass needs both for every coefficient (store address, range statistics): one LDS read
+    uint32_t dc[256][4];        // per lane and component: sum of DC differences
     // Last, so that a kernel whose jobs use table ids 0 and 1 only can do with the first four slots (HuffSyncLdsCompact below): slot
     // 2 * id is DC table id, slot 2 * id + 1 AC table id (huff_table_slot).
     DevHuffTable tables[8];
@@ -64,37 +61,20 @@ constexpr uint32_t HUFF_SYNC_LANES = 256;  // lanes per workgroup (dc[] slots)
 // after job and tables are in place; every lane of the workgroup calls it (lane < 512 does something), then a barrier
 __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32_t lane) {
     if (lane < 512u) L.sym_info[lane >> 8][lane & 255u] = (uint16_t)huff_sym_info(lane >> 8, lane & 255u);
-    if (lane < 256u) {
-        const uint32_t z = L.unzig[lane & 63u];
-        L.unzq[lane >> 6][lane & 63u] = z | ((uint32_t)L.job.q[lane >> 6][z] << 16);
-    }
     if (lane < 16u) {
         const uint32_t c = L.job.q_comp[lane < L.job.bpm ? lane : 0u];
         L.q_tables[lane] = (uint32_t)(huff_table_slot(0u, L.job.comp[c].dc) * sizeof(DevHuffTable)) | ((uint32_t)(huff_table_slot(1u, L.job.comp[c].ac) * sizeof(DevHuffTable)) << 16);
-        huff_fill_block_dst(L.job, L.q_dst, lane);
     }
 }
 
-template <int RD>
-__device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos, JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
+__device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos) {
     b.g = (const JP_GLOBAL v4u *)(uintptr_t)slot;
     b.wpos = bit_pos >> 5;
-    if (RD == HUFF_READ_RING) {
-        b.ring = ring;
-        b.ring_stride = ring_stride;
-        b.fetched = b.wpos & ~3u;
-        huff_ring_topup(b);  // (twice: up to 7 pieces until HUFF_RING_AHEAD dwords lie ahead of a reader that starts mid-piece)
-        huff_ring_topup(b);
-    } else if (RD == HUFF_READ_DW) {
-        b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
-    } else {
-        b.cur = b.g[b.wpos >> 2];
-        b.nxt = b.g[(b.wpos >> 2) + 1u];
-    }
+    b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
     b.bits = 0;
     b.nbits = 0;
     b.bad = false;
-    huff_refill<RD>(b);
+    huff_refill(b);
     huff_consume(b, bit_pos & 31u);
 }
 __device__ __forceinline__ uint32_t huff_bit_pos(const DevBits &b) { return b.wpos * 32u - b.nbits; }
@@ -103,63 +83,6 @@ __device__ __forceinline__ bool huff_sync_state_plausible(const JP_LDS HuffSyncJ
     return pos >= first && pos - first <= 32u && q < job.bpm && k < 64u;
 }
 
-// The write pass of the chunk decoder assembles every block its lane decodes completely in LDS and lets eight lanes write
-// it as one 128-byte line (huff_flush_blocks): 2-byte stores scattered over as many cache lines as there are lanes were
-// what bound that pass.  Blocks a lane shares with a neighbour (the first and the last of a chunk) still go out coefficient
-// by coefficient into the zero-filled arena.
-__device__ __forceinline__ bool huff_wave_any(bool x) {
-#ifdef JPGPU_HOST_EMULATION
-    return x;
-#else
-    return __ballot(x) != 0ull;
-#endif
-}
-__device__ __forceinline__ uint32_t threadIdx_x_of_lane() {
-#ifdef JPGPU_HOST_EMULATION
-    return 0u;
-#else
-    return threadIdx.x;
-#endif
-}
-
-struct HuffWriteBuf {
-    uint16_t blk[HUFF_SYNC_LANES][72];           // one block per lane, rows of 144 bytes (16-byte aligned, banks spread)
-    uint64_t done_ptr[HUFF_SYNC_LANES / 64][64];  // per wave: arena addresses of the blocks finished in this step ...
-    uint8_t done_lane[HUFF_SYNC_LANES / 64][64];  // ... and the lanes whose buffers hold them
-};
-
-#ifndef JPGPU_HOST_EMULATION
-// All 64 lanes of the wave: `flush` lanes have a finished block in their buffer, to be stored at `addr`.
-__device__ __forceinline__ void huff_flush_blocks(JP_LDS HuffWriteBuf &W, bool flush, uint64_t addr) {
-    const uint64_t m = __ballot(flush);
-    if (m == 0) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (flush) {
-        const uint32_t r = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        W.done_lane[wave][r] = (uint8_t)lane;
-        W.done_ptr[wave][r] = addr;
-    }
-    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order; this keeps the compiler from reordering them)
-    const uint32_t n = (uint32_t)__popcll(m), sub = lane & 7u;
-    for (uint32_t base = 0; base < n; base += 8u) {
-        const uint32_t g = base + (lane >> 3);
-        if (g < n) {
-            const uint32_t src = W.done_lane[wave][g];
-            JP_LDS v4u *b = (JP_LDS v4u *)&W.blk[wave * 64u + src][sub * 8u];
-            const v4u v = *b;
-            *((JP_GLOBAL v4u *)(uintptr_t)W.done_ptr[wave][g] + sub) = v;
-            *b = v4u{0u, 0u, 0u, 0u};
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-#endif
-
-// The decoding loop shared by the chunk decoder and the restart-segment decoder: from state (pos, q, k) of the staged bit
-// stream `data` until the bit position reaches `limit` (BY_BITS) and/or `end_blk` blocks are complete (WRITE).
-//   WRITE:   store coefficients; `blkno` = number of the block being decoded (-> its MCU and address)
-//   dc_sums: dc[component] accumulates DC differences (WRITE: they are predictors, and the stored DC values are finished)
-// Returns the bit position reached; q, k, nblk (blocks completed), blkno, bad are updated.
 // Largest |coefficient * quantization value| among the DC / the AC coefficients a lane has written (range_stats.hpp): the
 // writer's by-product that spares the pixel kernels' feeder a second pass over the arena.
 struct HuffRange {
@@ -228,156 +151,7 @@ __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
     }
 }
 
-template <bool WRITE, bool BY_BITS, bool ASSEMBLE = false>
-__device__ __forceinline__ uint32_t huff_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
-                                             uint32_t &nblk, uint32_t &blkno, uint32_t end_blk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad,
-                                             HuffRange &rg, JP_LDS HuffWriteBuf *W = nullptr, bool participate = true,
-                                             JP_LDS uint32_t *ring = nullptr, uint32_t ring_stride = 0) {
-    const JP_LDS HuffSyncJob &job = L.job;
-    // (huff_core.hpp) kernels that store decode from the LDS ring when they are given one; the sync passes fetch dwords ahead
-#ifdef JPGPU_HOST_EMULATION
-    constexpr int RD = HUFF_READ_DW;
-#else
-#ifdef JPGPU_WRITE_DW  // (A/B build: the write pass fetches dwords ahead like the sync passes, no LDS ring)
-    constexpr int RD = HUFF_READ_DW;
-#else
-    constexpr int RD = WRITE ? HUFF_READ_RING : HUFF_READ_DW;
-#endif
-#endif
-    DevBits b;
-    huff_open_at<RD>(b, data, pos, ring, ring_stride);
-    uint32_t steps = 0;
-    uint32_t c = job.q_comp[q];  // component of block q
-    const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
-    uint32_t qt = L.q_tables[q];  // table offsets of block q
-    const JP_LDS uint32_t *zq = L.unzq[c];  // zig-zag index -> (natural position, quantization value) of block q's component
-    JP_GLOBAL int16_t *blk = nullptr;
-    uint32_t mx = 0, my = 0;  // the MCU of block `blkno` (write pass), kept by counting: no divisions per block
-    if (WRITE) {
-        const uint32_t m = blkno / job.bpm;
-        my = m / job.cols;
-        mx = m - my * job.cols;
-    }
-    auto locate = [&]() {  // arena address of block `blkno` = block q of MCU (mx, my)
-        const uint64_t base = L.q_dst[q].base;
-        blk = (JP_GLOBAL int16_t *)(uintptr_t)(base + (uint64_t)my * L.q_dst[q].row_stride + mx * L.q_dst[q].mcu_stride);
-    };
-    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;  // DC predictors of a restart segment (start at 0, src/decoder.rs:928-931)
-    if (WRITE && blkno < end_blk) locate();
-    // ASSEMBLE: `own` — the block being decoded started in this lane (it will be written as a whole); mine = this lane's buffer
-    bool own = k == 0u;
-    JP_LDS uint16_t *mine = ASSEMBLE ? W->blk[threadIdx_x_of_lane()] : nullptr;
-    for (;;) {
-        // !BY_BITS (restart segments): `limit`, if not 0, is a hard stop a little beyond the segment's data — a segment far
-        // shorter than its MCUs need would otherwise be decoded on through the zero padding into the neighbouring slots and past
-        // the staging block; the caller flags such a segment (bits taken from beyond its end) for the host.
-        const bool active = participate && !bad && (BY_BITS ? huff_bit_pos(b) < limit : (limit == 0u || huff_bit_pos(b) <= limit)) &&
-                            !(WRITE && blkno >= end_blk);
-        if (ASSEMBLE ? !huff_wave_any(active) : !active) break;  // (ASSEMBLE: the wave stays together for the cooperative stores)
-        bool flush = false;
-        uint64_t flush_addr = 0;
-        if (active) {
-        if (RD == HUFF_READ_RING && (++steps % HUFF_RING_PERIOD) == 0u) huff_ring_topup(b);
-        huff_refill<RD>(b);
-        const uint32_t ac = k != 0u ? 1u : 0u;
-        const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
-        const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)];
-        uint32_t info = e, csz = e >> SYM_LEN_SHIFT, raw;
-        if (csz == 0u && e != HUFF_SUB_NONE) {  // a code longer than the lookahead: the prefix's second-level table
-            info = t.lut2[0][e * (1u << HUFF_SUB_BITS) + (huff_peek(b, 16) & ((1u << HUFF_SUB_BITS) - 1u))];
-            csz = (info >> SYM_LEN_SHIFT) + 1u;
-        }
-        if (csz) {  // code and magnitude bits leave the reader together (<= 16 + 15 of the > 32 bits it holds)
-            const uint32_t nr = info & SYM_NREAD;
-            raw = huff_peek(b, csz + nr) & ((1u << nr) - 1u);
-            huff_consume(b, csz + nr);
-        } else {
-            const uint32_t sym = huff_walk(b, t);
-            bad = b.bad;
-            // chunk decoder (several waves per SIMD, bound by instruction issue) from the LDS table; restart segments (one wave
-            // per SIMD at best: every dependent LDS round trip is paid in full) by a dozen selects
-            info = BY_BITS ? (uint32_t)L.sym_info[ac][sym] : huff_sym_info(ac, sym);
-            raw = huff_peek(b, info & SYM_NREAD);
-            huff_consume(b, info & SYM_NREAD);
-        }
-        const uint32_t nread = info & SYM_NREAD;
-        const uint32_t k0 = k;
-        k += ((info >> SYM_ADV_SHIFT) & SYM_ADV_MASK) + 1u;
-        // a coefficient beyond index 63: the reference breaks out of the block in a way that depends on its own table
-        // layout (src/decoder.rs:1045-1075) — only broken streams have it, the host decides
-        bad = bad || (info & SYM_BAD) != 0u || ((info & SYM_COEF) != 0u && k > 64u);
-        if (!bad) {
-            if (k0 == 0u) {
-                int32_t val = huff_extend(raw, nread);
-                if (!BY_BITS) {  // restart segments: a wave on its own pays every LDS round trip in full — registers and selects
-                    uint32_t pr = c == 0u ? d0 : (c == 1u ? d1 : (c == 2u ? d2 : d3));
-                    pr += (uint32_t)val;
-                    d0 = c == 0u ? pr : d0;
-                    d1 = c == 1u ? pr : d1;
-                    d2 = c == 2u ? pr : d2;
-                    d3 = c == 3u ? pr : d3;
-                    val = (int16_t)(uint16_t)pr;
-                } else if (dc_sums) {  // sync pass: sum of differences; write pass: the predictor -> the DC value
-                    dc[c] += (uint32_t)val;
-                    val = (int16_t)(uint16_t)dc[c];
-                }
-                if (WRITE && val) {  // (uniform scans: the difference; huff_dc_prefix_kernel sums up)
-                    if (ASSEMBLE && own) mine[0] = (uint16_t)val;
-                    else blk[0] = (int16_t)val;
-                }
-                // (finished DC values only: the differences of a uniform scan are summed — and ranged — by huff_dc_prefix_kernel)
-                if (WRITE && (!BY_BITS || dc_sums)) rg.dc = max(rg.dc, (uint32_t)(val < 0 ? -val : val) * (zq[0] >> 16));
-            } else if (WRITE && (info & SYM_COEF)) {
-                const uint32_t e = zq[k - 1u], z = e & 0xffffu;
-                const int32_t x = huff_extend(raw, nread);
-                if (ASSEMBLE && own) mine[z] = (uint16_t)x;
-                else blk[z] = (int16_t)x;
-                rg.ac = max(rg.ac, (uint32_t)(x < 0 ? -x : x) * (e >> 16));  // |x| <= 2^15, q <= 2^16 - 1
-            }
-        }
-        if (k >= 64u && !bad) {  // end of the block
-            k = 0u;
-            nblk++;
-            q++;
-            if (q == job.bpm) {
-                q = 0u;
-                mx++;
-                if (mx == job.cols) {
-                    mx = 0u;
-                    my++;
-                }
-            }
-            qt = L.q_tables[q];
-            c = job.q_comp[q];
-            if (WRITE) zq = L.unzq[c];
-            if (WRITE) {
-                if (ASSEMBLE && own) {
-                    flush = true;
-                    flush_addr = (uint64_t)(uintptr_t)blk;
-                }
-                own = true;
-                blkno++;
-                if (blkno < end_blk) locate();
-            }
-        }
-        }  // if (active)
-#ifndef JPGPU_HOST_EMULATION
-        if (ASSEMBLE) huff_flush_blocks(*W, flush, flush_addr);
-#endif
-    }
-    if (ASSEMBLE && participate && own && blkno < end_blk && !bad) {
-        // the chunk ended inside a block this lane began: the lane to the right writes the rest coefficient by coefficient
-        // into the zero-filled line, so what sits in the buffer goes out the same way
-        for (uint32_t z = 0; z < 64u; z++) {
-            const uint16_t v = mine[z];
-            if (v) blk[z] = (int16_t)v;
-            mine[z] = 0;
-        }
-    }
-    return huff_bit_pos(b);
-}
-
-// The decoding loop of a sync pass, on its own (round 3): the same symbol step as huff_run, arranged for the instruction streams
+// The decoding loop of a sync pass: one step per Huffman symbol, arranged for the instruction streams
 // the compiler makes of it — a wave's step is as many SCALAR instructions (lane-mask bookkeeping around every divergent region) as
 // vector ones, and the two issue at the same rate, so regions count.  DC and AC entries leave through ONE emission site; whether
 // a pass emits is a template parameter (it is the same for every lane of a launch's iteration), `bad` is a number in a vector
@@ -387,16 +161,15 @@ template <int EMIT>  // 0: no entries; 1: entries in rounds of eight (a pass of 
 __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                                   uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em, uint32_t &last_block_end) {
     const JP_LDS HuffSyncJob &job = L.job;
-    constexpr int RD = HUFF_READ_DW;
     DevBits b;
-    huff_open_at<RD>(b, data, pos);
+    huff_open_at(b, data, pos);
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
     uint32_t badv = 0;
     const uint32_t bpm = job.bpm;  // (in a register: the loop's LDS writes keep the compiler from hoisting the read itself)
     do {  // (the caller has checked pos < limit; one exit, at the bottom: the compiler keeps one set of registers for the loop's values)
-        huff_refill<RD>(b);
+        huff_refill(b);
         const uint32_t ac = k != 0u ? 1u : 0u;
         const JP_LDS DevHuffTable &t = *(const JP_LDS DevHuffTable *)(tbase + (ac ? qt >> 16 : qt & 0xffffu));
         const uint32_t e = t.lut[huff_peek(b, HUFF_LUT_BITS)];
@@ -419,7 +192,8 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
         const uint32_t nread = info & SYM_NREAD;
         const bool isdc = k == 0u, coef = (info & SYM_COEF) != 0u;
         k += ((info >> SYM_ADV_SHIFT) & SYM_ADV_MASK) + 1u;
-        // (a coefficient beyond index 63: only broken streams have it, the host decides — huff_run)
+        // (a coefficient beyond index 63: the reference breaks out of the block in a way that depends on its own table layout,
+        // src/decoder.rs:1045-1075 — only broken streams have it, the host decides)
         badv |= (info & SYM_BAD) | ((coef && k > 64u) ? 1u : 0u);
         // From here on: selects, not regions (every divergent region is three scalar instructions and a set of register copies
         // where it joins); the regions left are the DC sums, the store of a full round and the end of a block — turning those into
@@ -455,27 +229,23 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
     return huff_bit_pos(b);
 }
 
-// One chunk.  WRITE = false: a sync pass (`pass` = its number), returns whether the lane published a new state (the caller
-// counts those per job: one atomic per workgroup, not per lane — a quarter of a million lanes adding to a few hundred
-// neighbouring counters took 18 ms per pass); WRITE = true: the write pass.
-// Jobs with speculative emission (job.emit): a sync pass also leaves the chunk's entries — every pass but the first, whose
-// start states are guesses.  A lane that has decoded from a state WITHOUT emitting still has work when the same state comes
-// round again (QK_EMITTED in in_qk tells).
+// One chunk in one sync pass (`pass` = its number); returns whether the lane published a new state (the caller counts those per
+// job: one atomic per workgroup, not per lane — a quarter of a million lanes adding to a few hundred neighbouring counters took
+// 18 ms per pass).  The pass also leaves the chunk's entries — every pass but the first, whose start states are guesses.  A lane
+// that has decoded from a state WITHOUT emitting still has work when the same state comes round again (QK_EMITTED in in_qk tells).
 constexpr uint32_t QK_EMITTED = 0x80000000u;
 // From pass HuffSyncJob::late_pass on a lane stores its entries one by one (huff_sync_run<2>): few lanes are left, what a late pass
 // costs is the wave's step — 16 vector instructions shorter without the rounds' register shuffling — times the symbols of a chunk
 // (sync passes of 256 files alone 2.24 -> 2.15-2.18 ms with 2; from pass 3 on: 2.19).  One image through Decoder.decode() measures the
 // same with 1 and with 2 (1080p 1.40-1.50 ms): 2 everywhere (HUFF_LATE_PASS, huff_job.hpp; JPGPU_SYNC_LATE_PASS pins another).
-__device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t pass) { return job.emit != nullptr && pass > 0u; }
+__device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job, uint32_t pass) { return job.emit != nullptr && pass > 0u; }
 
-template <bool WRITE>
-__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
-                                                uint32_t ring_stride = 0) {
+__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     const HuffChunkSpan span = huff_chunk_span(job, i);
     uint32_t pos, q, k;
-    if (!WRITE && pass == 0u) {
+    if (pass == 0u) {
         // The first pass is there to find where the chunks END, from guessed start states; a lane that starts at a guess
         // finds the true segmentation within ~15 blocks on average (the misses decay exponentially): it need not walk the
         // whole chunk for that.  Every lane decodes its chunk again from a real state in pass 1 anyway — the first lane too,
@@ -498,75 +268,51 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     // which is the start of ours.  Anything else is not a state of this launch sequence — that lane belongs to a workgroup
     // which has not run yet, and the words are what an earlier batch left there — and must not be decoded from (it could
     // mean walking half the scan) nor handed on (it would travel down the scan, one lane per pass, keeping the job unsettled).
-    if (!span.first && !(!WRITE && pass == 0u) && !huff_sync_state_plausible(job, span.start, pos, q, k)) pos = HUFF_POS_INVALID;
-    const bool emit = !WRITE && huff_emit_in_pass(job, i, pass);
-    if (!WRITE) {
-        if (pos == HUFF_POS_INVALID) return false;  // the predecessor has nothing to offer yet: keep what we have
-        const uint32_t qk_in = (q << 8) | k | (emit ? QK_EMITTED : 0u);
-        if (pass > 0u && pos == job.in_pos[i] && qk_in == job.in_qk[i]) return false;  // same start as last time
-        job.in_pos[i] = pos;
-        job.in_qk[i] = qk_in;
-    } else if (pos == HUFF_POS_INVALID) {
-        atomicOr_status(job.status, 1u | 32u);
-        return false;
-    }
+    if (!span.first && pass != 0u && !huff_sync_state_plausible(job, span.start, pos, q, k)) return false;  // nothing to offer yet: keep what we have
+    const bool emit = huff_emit_in_pass(job, pass);
+    const uint32_t qk_in = (q << 8) | k | (emit ? QK_EMITTED : 0u);
+    if (pass > 0u && pos == job.in_pos[i] && qk_in == job.in_qk[i]) return false;  // same start as last time
+    job.in_pos[i] = pos;
+    job.in_qk[i] = qk_in;
     const uint32_t limit = span.end;
     uint32_t nblk = 0;
-    const uint32_t total_blocks = job.n_mcu * job.bpm;
-    uint32_t blkno = WRITE ? job.n_blocks[i] : 0u;  // number of the block being decoded (write pass)
-    if (WRITE) q = blkno % job.bpm;                 // (what the settled state says anyway; the only source when `uniform`)
     bool bad = false;
     const bool dc_sums = !job.uniform;
     JP_LDS uint32_t *dc = L.dc[i % HUFF_SYNC_LANES];
-    if (dc_sums) {
-        uint32_t w0 = 0, w1 = 0;
-        if (WRITE) {
-            w0 = job.dc_sum[2u * i];
-            w1 = job.dc_sum[2u * i + 1u];
-        }
-        dc[0] = w0 & 0xffffu;
-        dc[1] = w0 >> 16;
-        dc[2] = w1 & 0xffffu;
-        dc[3] = w1 >> 16;
-    }
+    if (dc_sums) dc[0] = dc[1] = dc[2] = dc[3] = 0u;
     uint32_t last_block_end = 0;
     HuffEmit em;
     if (emit) {
         em.buf = (JP_GLOBAL uint32_t *)(job.emit + (size_t)i * job.emit_stride);
         em.cap = job.emit_stride;
     }
+    const bool late = emit && pass >= job.late_pass;
     if (pos < limit) {
-        if (WRITE) pos = huff_run<true, true>(L, job.data, pos, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, nullptr, true, ring, ring_stride);
-        else if (emit && pass >= job.late_pass) pos = huff_sync_run<2>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        if (late) pos = huff_sync_run<2>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
         else if (emit) pos = huff_sync_run<1>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
         else pos = huff_sync_run<0>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
     }
-    if (!WRITE && job.emit != nullptr) job.blk_end[i] = last_block_end;
-    if (!WRITE && !(emit && pass >= job.late_pass)) huff_emit_finish(em);  // (a late pass has stored every entry already)
-    if (!WRITE && job.emit != nullptr)  // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
+    if (job.emit != nullptr) {
+        job.blk_end[i] = last_block_end;
+        if (!late) huff_emit_finish(em);  // (a late pass has stored every entry already)
+        // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
         job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
-    if (!WRITE && dc_sums) {
+    }
+    if (dc_sums) {
         job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);
         job.dc_sum[2u * i + 1u] = (dc[2] & 0xffffu) | (dc[3] << 16);
     }
-    if (!WRITE) {
-        const uint32_t np = bad ? HUFF_POS_INVALID : pos, nqk = bad ? 0u : (((job.uniform ? 0u : q) << 8) | k);
-        if (pass == 0u || np != job.out_pos[i] || nqk != job.out_qk[i] || nblk != job.n_blocks[i]) {
-            huff_store_shared(job.out_qk + i, nqk);
-            huff_store_shared(job.out_pos + i, np);
-            job.n_blocks[i] = nblk;
-            return true;
-        }
-    } else {
-        if (bad) atomicOr_status(job.status, 1u | 2u);
-        // the last chunk: every block must be complete before the data runs out, and none may have used bits from beyond
-        // its end (the reference would decode zero bits there: the host decides)
-        if (i + 1u == job.n_chunks && (blkno < total_blocks || pos > job.n_bits)) atomicOr_status(job.status, 1u | 8u);
+    const uint32_t np = bad ? HUFF_POS_INVALID : pos, nqk = bad ? 0u : (((job.uniform ? 0u : q) << 8) | k);
+    if (pass == 0u || np != job.out_pos[i] || nqk != job.out_qk[i] || nblk != job.n_blocks[i]) {
+        huff_store_shared(job.out_qk + i, nqk);
+        huff_store_shared(job.out_pos + i, np);
+        job.n_blocks[i] = nblk;
+        return true;
     }
     return false;
 }
 
-// What the write pass would have noticed, for jobs with speculative emission (block numbering, huff_sync_scan_kernel): a chunk
+// What only the settled segmentation can say (block numbering, huff_sync_scan_kernel): a chunk
 // whose last run met an impossible code (or overran its buffer) before the scan's last block was complete ...
 __device__ __forceinline__ uint32_t huff_emit_chunk_status(const HuffSyncJob &job, uint32_t i, uint32_t blocks_through_chunk) {
     const uint32_t total_blocks = job.n_mcu * job.bpm;
@@ -587,8 +333,8 @@ __device__ __forceinline__ uint32_t huff_emit_final_status(const HuffSyncJob &jo
 
 // The same for a job with restart markers (HuffSyncJob::seg_chunks), one segment at a time — by one thread, a segment has a
 // handful of chunks: number its chunks' first blocks from the segment's own first block, turn their sums of DC differences
-// into the predictors they start from (zero at the segment start, src/decoder.rs:928-931), and return what the restart-segment
-// decoder (huff_decode_segment) would have flagged: an impossible code or a full buffer before the segment's blocks are
+// into the predictors they start from (zero at the segment start, src/decoder.rs:928-931), and return what a decoder that walks
+// the segment from its start would flag: an impossible code or a full buffer before the segment's blocks are
 // complete, fewer or more blocks than the restart interval holds, a last block that took bits from beyond the segment, or more
 // than 56 bits between its end and the marker (the reference would not find the marker there: src/huffman.rs:103-160).
 __device__ __forceinline__ uint32_t huff_emit_segment_scan(const HuffSyncJob &job, uint32_t seg) {
@@ -619,73 +365,6 @@ __device__ __forceinline__ uint32_t huff_emit_segment_scan(const HuffSyncJob &jo
         else if (seg_end - end_pos > 56u) status |= 1u | 4u;
     }
     return status;
-}
-
-// The write pass with block assembly (HuffWriteBuf): every lane of the workgroup calls it, `valid` = the lane has a chunk;
-// lanes without work still take part in the cooperative stores.  Same decisions as huff_sync_chunk<true>.
-__device__ __forceinline__ void huff_sync_write_assembled(JP_LDS HuffSyncLds &L, JP_LDS HuffWriteBuf &W, uint32_t i, bool valid, HuffRange &rg,
-                                                          JP_LDS uint32_t *ring, uint32_t ring_stride) {
-    const JP_LDS HuffSyncJob &job = L.job;
-    uint32_t pos = 0, q = 0, k = 0;
-    bool participate = valid;
-    if (valid && i > 0u) {
-        pos = huff_load_shared(job.out_pos + (i - 1u));
-        const uint32_t qk = huff_load_shared(job.out_qk + (i - 1u));
-        q = qk >> 8;
-        k = qk & 0xffu;
-        if (job.uniform) q = 0u;
-        if (!huff_sync_state_plausible(job, i << job.chunk_shift, pos, q, k)) {
-            atomicOr_status(job.status, 1u | 32u);
-            participate = false;
-            pos = q = k = 0u;
-        }
-    }
-    const uint32_t limit = valid ? min((i + 1u) << job.chunk_shift, job.n_bits) : 0u;
-    const uint32_t total_blocks = job.n_mcu * job.bpm;
-    uint32_t nblk = 0, blkno = participate ? job.n_blocks[i] : 0u;
-    if (participate) q = blkno % job.bpm;
-    bool bad = false;
-    const bool dc_sums = !job.uniform;
-    JP_LDS uint32_t *dc = L.dc[threadIdx_x_of_lane() % HUFF_SYNC_LANES];
-    if (dc_sums) {
-        const uint32_t w0 = participate ? job.dc_sum[2u * i] : 0u, w1 = participate ? job.dc_sum[2u * i + 1u] : 0u;
-        dc[0] = w0 & 0xffffu;
-        dc[1] = w0 >> 16;
-        dc[2] = w1 & 0xffffu;
-        dc[3] = w1 >> 16;
-    }
-    participate = participate && pos < limit;
-    const uint32_t end = huff_run<true, true, true>(L, job.data, participate ? pos : 0u, limit, q, k, nblk, blkno, total_blocks, dc, dc_sums, bad, rg, &W, participate, ring, ring_stride);
-    if (participate) pos = end;
-    if (!valid) return;
-    if (bad) atomicOr_status(job.status, 1u | 2u);
-    if (i + 1u == job.n_chunks && (blkno < total_blocks || pos > job.n_bits)) atomicOr_status(job.status, 1u | 8u);
-}
-
-// ---- streams WITH restart markers: one lane per restart segment (src/decoder.rs:920-956: the predictors and the bit
-// reader start afresh after every RSTn, so segments are independent).  The job record says where the segments lie
-// (seg_off, staged by huff_stage_segment one slot each) and how many MCUs one holds (ri); the decoding loop is huff_run.
-__device__ __forceinline__ bool huff_decode_segment(JP_LDS HuffSyncLds &L, uint32_t seg, HuffRange &rg, JP_LDS uint32_t *ring = nullptr,
-                                                    uint32_t ring_stride = 0) {
-    const JP_LDS HuffSyncJob &job = L.job;
-    const uint8_t *data = job.data + job.seg_off[2u * seg];
-    const uint32_t seg_bits = job.seg_off[2u * seg + 1u] * 8u;
-    const uint32_t m0 = seg * job.ri, m1 = min(m0 + job.ri, job.n_mcu);
-    uint32_t q = 0, k = 0, nblk = 0, blkno = m0 * job.bpm;
-    bool bad = false;
-    const uint32_t pos = huff_run<true, false>(L, data, 0u, seg_bits + 64u, q, k, nblk, blkno, m1 * job.bpm, nullptr, true, bad, rg, nullptr, true, ring, ring_stride);
-    // What the reference does at a restart (take_marker, src/huffman.rs:103-105, then reset): it tops up its 64-bit buffer —
-    // bytes are appended while it holds at most 56 bits (src/huffman.rs:123-160) — and must MEET the marker doing so, which
-    // happens iff the unread rest of the segment is at most 56 bits ("no marker found where RSTn was expected" otherwise);
-    // left-over bits are dropped.  A segment that ran dry (bits taken from beyond its end — the reference would have fed
-    // zeros as well) is left to the host to be safe.
-    const int64_t left = (int64_t)seg_bits - (int64_t)pos;
-    if (bad || left < 0 || left > 56) {
-        // bit 0 = re-decode on the host; bits 1..3 say why (diagnostics)
-        atomicOr_status(job.status, 1u | (bad ? 2u : 0u) | (left > 56 ? 4u : 0u) | (left < 0 ? 8u : 0u));
-        return false;
-    }
-    return true;
 }
 
 }  // namespace jpgpu

@@ -451,45 +451,15 @@ static void read_info_with_options(const jpgpu_pipeline *p, Frontend &fe) {
     }
 }
 
-// Restart-marker scans that still take one lane per segment (huff_segments_kernel): single-segment scans, and everything when the
-// chunk slots or the emission are switched off (batch.cpp, dri_geom).
-static bool one_lane_per_segment(const jpgpu::host::PlannedScan &ps) {
-    if (ps.ri == 0) return false;
-    const char *e_dri = getenv("JPGPU_DRI_CHUNKS"), *e_emit = getenv("JPGPU_SYNC_EMIT");
-    return (e_dri && atoi(e_dri) == 0) || (e_emit && atoi(e_emit) == 0) || ps.seg_off.size() < 4;
-}
-
 static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
     if (getenv("JPGPU_PIPE_FORCE_DEVICE")) return;  // (tests, A/B runs)
-    // Restart-marker streams on the device cost the time of their LONGEST segment (one lane walks it: ≈2.4 µs per byte,
-    // measured with 6 kB segments: 14.7 ms per launch, however many images), on the host the time of ALL their bytes
-    // (≈12 ns per byte and thread).  A few images, or segments of many MCU rows, are better off on the host.
-    size_t max_seg = 0, bytes = 0;
-    uint32_t n_seg_images = 0;
-    // (since round 3 restart segments go through the chunk decoder, each in chunk slots of its own, unless the scan's components
-    // all share their tables — batch.cpp, dri_geom: those cost what streams without restart markers cost and stay on the device)
-    for (uint32_t i = 0; i < n; i++)
-        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && one_lane_per_segment(p->plans[i][0])) {
-            n_seg_images++;
-            for (const jpgpu::host::PlannedScan &ps : p->plans[i])
-                for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
-                    max_seg = std::max<size_t>(max_seg, ps.seg_off[sg + 1] - ps.seg_off[sg]);
-                    bytes += ps.seg_off[sg + 1] - ps.seg_off[sg];
-                }
-        }
-    const double device_ms = 1.0 + (double)max_seg * 2.4e-3, host_ms = (double)bytes * 12e-6 / std::max<uint32_t>(1u, p->pool->size() / 2u);
-    if (n_seg_images && device_ms > host_ms) {
-        if (getenv("JPGPU_PIPE_TRACE"))
-            fprintf(stderr, "pipeline trace: %u restart-marker stream(s) stay on the host (longest segment %zu B: device ~%.1f ms, host ~%.1f ms)\n",
-                    n_seg_images, max_seg, device_ms, host_ms);
-        for (uint32_t i = 0; i < n; i++)
-            if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && one_lane_per_segment(p->plans[i][0])) back_to_the_host(p, i, data, len);
-    }
+    // (restart-marker streams cost what streams without markers cost since round 3 — every segment in chunk slots of its own —
+    // and stay on the device; rounds 1-3 weighed one lane per segment against the host's cores here)
     // Streams without restart markers whose blocks are very long (noise at quality >= 98: no end-of-block symbols at all) keep
     // the chunk decoder re-synchronising for dozens of passes (measured: beyond ~350 bits per block more launches than it is
     // given) — it would flag them in the end; the host decodes them right away instead.
     for (uint32_t i = 0; i < n; i++)
-        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].ri == 0) {
+        if (p->status[i] == JPGPU_OK && !p->plans[i].empty() && p->plans[i][0].seg_off.size() == 2) {
             const jpgpu::host::PlannedScan &ps = p->plans[i][0];
             uint64_t blocks = 0;
             for (uint32_t c = 0; c < ps.ncomp; c++) blocks += (uint64_t)ps.comp[c].h * ps.comp[c].v;
@@ -630,16 +600,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::vector<uint32_t> bounds{0u};  // sub-batch j = ok[bounds[j] .. bounds[j+1])
     uint32_t n_dev_subs = 0;           // the first sub-batches hold the images whose entropy data goes to the device
     {
-        // streams with restart markers: one lane per restart segment, ~1,000 images fill the machine; without: one lane
-        // per chunk of the scan, 256 images do — but several sub-batches are in flight at a time (one compute stream each, and
-        // a hardware queue each when GPU_MAX_HW_QUEUES allows: jpgpu.cpp), the latency-bound late sync passes of one run next to
-        // the full passes of another, and staging, upload and kernels of neighbours overlap: 128 images per sub-batch, up to 32
-        // of them (256 files per call 8.6 -> 7.5 ms, 1,024: 21.1 -> 18.8 ms, 4,096: 68.7 -> 63.5 ms against 256 x 16)
+        // one lane per chunk of a scan: 256 images fill the machine — but several sub-batches are in flight at a time (one compute
+        // stream each, and a hardware queue each when GPU_MAX_HW_QUEUES allows: jpgpu_process_init), the latency-bound late sync
+        // passes of one run next to the full passes of another, and staging, upload and kernels of neighbours overlap: 128 images
+        // per sub-batch, up to 32 of them (256 files per call 8.6 -> 7.5 ms, 1,024: 21.1 -> 18.8 ms, 4,096: 68.7 -> 63.5 ms against 256 x 16)
         const long dev_sub_env = getenv("JPGPU_PIPE_DEV_SUB") ? atol(getenv("JPGPU_PIPE_DEV_SUB")) : 0;  // tuning knob (read per call)
-        uint32_t n_chunked = 0;
-        for (uint32_t k = 0; k < n_dev; k++)
-            if (!p->plans[ok[k]].empty() && !one_lane_per_segment(p->plans[ok[k]][0])) n_chunked++;
-        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_chunked * 2u >= n_dev ? 2u : 16u) * kSubBatchImages;
+        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : 2u * kSubBatchImages;
         const long dev_cap_env = getenv("JPGPU_PIPE_MAX_DEV_SUBS") ? atol(getenv("JPGPU_PIPE_MAX_DEV_SUBS")) : 0;  // tuning knob (read per call)
         const uint32_t dev_cap = dev_cap_env > 0 ? (uint32_t)std::min<long>(dev_cap_env, kMaxSubBatches / 2u) : kMaxSubBatches / 2u;
         const uint32_t dev_subs = n_dev ? std::min<uint32_t>(dev_cap, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;

@@ -75,7 +75,7 @@ typedef uint32_t w32;
 #endif
 // (What the hint does to PARTIAL lines — a lane writing 12-byte pieces 24 bytes apart fills half of each line per
 // instruction: tools/ubench_store.hip, profiles/round2/01_store_patterns.txt — alone 2.5 TB/s against 5.3 TB/s for plain
-// stores.  The single-launch 4:2:0 kernel therefore stores plainly, F420::row_pixels<.., NTS = false>.)
+// stores.  The single-launch 4:2:0 kernel therefore stores plainly, PixelOps::row_pixels<.., NTS = false>.)
 
 typedef const JP_CONST uint32_t *qtab_t;  // 64 u16 quantization values packed two per dword, 4-B aligned
 
@@ -355,11 +355,7 @@ template <int ARITH>
 __device__ __forceinline__ void idct8x8_products(const uint32_t (&d)[32], uint32_t (&out)[16]) {
     static_assert(ARITH == ARITH_SANE || ARITH == ARITH_TIGHT, "the exact class works on 32-bit products");
     const w32 X_SCALE = 65536u + (128u << 17);
-#ifdef JPGPU_IDCT_LATE_PACK  // A/B: the row pass pairs the 64 column-pass outputs as it goes (more registers, same instructions)
-    if constexpr (false) {
-#else
     if constexpr (ARITH == ARITH_TIGHT) {
-#endif
         // Column-pass outputs fit i16: they are paired for the row pass — (0,4) (2,6) (1,3) (5,7) — as soon as both columns
         // of a pair exist, so 32 packed dwords are kept instead of 64 values (registers: one more wave per SIMD).
         // The row pass wants bits 10..25 of the sums as 16-bit halves: rows 0..3 leave the pass shifted left by 6 and the

@@ -18,14 +18,14 @@ def lib():
         L.emu_ycbcr.restype = C.c_uint32
         L.emu_ycbcr_centred_mismatches.argtypes = []
         L.emu_ycbcr_centred_mismatches.restype = C.c_uint32
-        L.emu_fused_decode.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]
+        L.emu_fused_decode.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
         L.emu_fused_decode.restype = C.c_int
         L.emu_compute_image.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint16, C.c_uint16, C.c_int, C.c_void_p,
                                         C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]
         L.emu_compute_image.restype = C.c_int
         L.emu_huff_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.emu_huff_covered.argtypes = [C.c_void_p, C.c_size_t]
-        L.emu_huff_set_dri.argtypes = [C.c_uint32, C.c_uint32]
+        L.emu_huff_set_dri.argtypes = [C.c_uint32]
         L.emu_stage_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.emu_stage_segment.restype = C.c_uint32
         L.emu_stage_segment_clean.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]

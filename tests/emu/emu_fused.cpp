@@ -9,26 +9,21 @@
 
 using namespace jpgpu;
 
-// the strip-walk kernels (S420, S440): fused.hip's walk_item, phase by phase, for every work item of the launch — fixed
-// segments of `seg_rows` MCU rows, or (balanced_wgs != 0) the shares walk_balanced_items cuts for that many workgroups, the
-// items of one workgroup run one after the other on the same LDS as on the device
+// the strip-walk kernels (S420, S440): fused.hip's walk_item, phase by phase, for every work item of the launch — segments of
+// `seg_rows` MCU rows, one item per workgroup
 template <class K>
-static void run_walk(const FusedGeom& g, const FusedImage& img, uint32_t balanced_wgs) {
+static void run_walk(const FusedGeom& g, const FusedImage& img) {
     constexpr uint32_t NT = K::NT;
     std::vector<uint8_t> mem(K::Lds::total_bytes(g.tx) + 64);
     std::vector<S420Regs> regs(NT);
     std::vector<FusedWork> items;
     std::vector<uint32_t> wg_first;
-    if (balanced_wgs) {
-        walk_balanced_items(&g, nullptr, 1u, balanced_wgs, items, wg_first);
-    } else {
-        for (uint32_t seg = 0; seg < g.n_seg; seg++)
-            for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
-                wg_first.push_back((uint32_t)items.size());
-                items.push_back(FusedWork{0u, strip, seg * g.seg_rows, std::min((seg + 1u) * g.seg_rows, g.mcu_h)});
-            }
-        wg_first.push_back((uint32_t)items.size());
-    }
+    for (uint32_t seg = 0; seg < g.n_seg; seg++)
+        for (uint32_t strip = 0; strip < g.tiles_x; strip++) {
+            wg_first.push_back((uint32_t)items.size());
+            items.push_back(FusedWork{0u, strip, seg * g.seg_rows, std::min((seg + 1u) * g.seg_rows, g.mcu_h)});
+        }
+    wg_first.push_back((uint32_t)items.size());
 #define LANES(BODY) for (uint32_t t = 0; t < NT; t++) { BODY; }
     for (size_t wg = 0; wg + 1 < wg_first.size(); wg++) {
         memset(mem.data(), 0xCD, mem.size());  // garbage, like real LDS
@@ -63,14 +58,13 @@ extern "C" {
 
 // returns the fused kind the planner picked (0 = none -> generic path on the GPU)
 int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, int sane, uint8_t* out,
-                     uint32_t* tx_out, uint32_t f420_tx_max, int strip420, uint32_t seg_rows, uint32_t s420_tx_max) {
+                     uint32_t* tx_out, uint32_t seg_rows, uint32_t s420_tx_max) {
     FusedGeom g;
     const char *name = "", *why = "";
-    int kind = fused_geom_from_desc(*desc, g, name, why, f420_tx_max, strip420 != 0, s420_tx_max ? s420_tx_max : S420_TX_MAX);
+    int kind = fused_geom_from_desc(*desc, g, name, why, s420_tx_max ? s420_tx_max : S420_TX_MAX);
     if (kind == FUSED_NONE) return 0;
     if ((kind == FUSED_420 || kind == FUSED_440) && g.strip) {
-        const uint32_t balanced_wgs = seg_rows >= 0x10000u ? (seg_rows & 0xffffu) : 0u;  // (test hook: 0x10000 | workgroups -> balanced shares)
-        s420_set_segments(g, 1, balanced_wgs ? 0u : seg_rows);
+        s420_set_segments(g, 1, seg_rows);
         FusedImage im{};
         for (uint32_t c = 0; c < desc->ncomp; c++) {
             im.coefs[c] = coefs[c];
@@ -80,12 +74,12 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         if (tx_out) *tx_out = g.tx;
         im.flags = sane == 2 ? 3u : (sane ? 1u : 0u);
         if (kind == FUSED_440) {
-            if (sane == 2) run_walk<S440<ARITH_TIGHT>>(g, im, balanced_wgs);
-            else if (sane) run_walk<S440<ARITH_SANE>>(g, im, balanced_wgs);
-            else run_walk<S440<ARITH_EXACT>>(g, im, balanced_wgs);
-        } else if (sane == 2) run_walk<S420<ARITH_TIGHT, 256>>(g, im, balanced_wgs);
-        else if (sane) run_walk<S420<ARITH_SANE, 256>>(g, im, balanced_wgs);
-        else run_walk<S420<ARITH_EXACT, 256>>(g, im, balanced_wgs);
+            if (sane == 2) run_walk<S440<ARITH_TIGHT>>(g, im);
+            else if (sane) run_walk<S440<ARITH_SANE>>(g, im);
+            else run_walk<S440<ARITH_EXACT>>(g, im);
+        } else if (sane == 2) run_walk<S420<ARITH_TIGHT, 256>>(g, im);
+        else if (sane) run_walk<S420<ARITH_SANE, 256>>(g, im);
+        else run_walk<S420<ARITH_EXACT, 256>>(g, im);
         return kind;
     }
     if (kind == FUSED_420X4) {  // r4_kernel (fused_x4.hpp), phase by phase
@@ -166,41 +160,13 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
     }
     img.out = out;
     img.flags = sane == 2 ? 3u : (sane ? 1u : 0u);
-    std::vector<uint8_t> scratch;
-    if (kind == FUSED_420) {
-        scratch.assign(2 * (size_t)g.chroma_plane_bytes, 0xAB);
-        img.scratch = scratch.data();
-        // chroma pass (f420_chroma_kernel): one block per lane, plane stride bwc*8
-        for (uint32_t comp = 0; comp < 2; comp++) {
-            uint8_t* plane = scratch.data() + (size_t)comp * g.chroma_plane_bytes;
-            const uint32_t stride = g.bwc * 8u, nblk = g.bwc * g.mcu_h;
-            for (uint32_t b = 0; b < nblk; b++) {
-                uint32_t cw[32], o[16];
-                memcpy(cw, coefs[1 + comp] + (size_t)b * 64, 128);
-                if (sane == 2) idct8x8<ARITH_TIGHT>(cw, as_qtab(img.qt[1 + comp]), o);
-                else if (sane) idct8x8<ARITH_SANE>(cw, as_qtab(img.qt[1 + comp]), o);
-                else idct8x8<ARITH_EXACT>(cw, as_qtab(img.qt[1 + comp]), o);
-                uint32_t bx = b % g.bwc, by = b / g.bwc;
-                for (int r = 0; r < 8; r++) memcpy(plane + (size_t)(by * 8 + r) * stride + bx * 8, &o[2 * r], 8);
-            }
-        }
-    }
-    std::vector<uint8_t> lds420(F420Lds::total_bytes(g.tx ? g.tx : 1) + 64);
-    F420Lds ldsv = F420Lds::make(lds420.data(), g.tx), *lds = &ldsv, *lds128 = &ldsv;
     FusedLdsSmall* lds_s = new FusedLdsSmall;
     std::vector<FusedRegs> regs(FUSED_NT);
 #define RUN(NTH, BODY) for (uint32_t t = 0; t < NTH; t++) { BODY; }
-#define RUN420(S, NTH, L) \
-    RUN(NTH, (F420<S, NTH>::phase0(g, img, tile, my, t, *L))) RUN(NTH, (F420<S, NTH>::phase1(g, img, tile, t, *L, regs[t]))) \
-    RUN(NTH, (F420<S, NTH>::phase2(g, tile, t, *L, regs[t]))) RUN(NTH, (F420<S, NTH>::phase3(g, img, tile, my, t, *L)))
     for (uint32_t my = 0; my < g.mcu_h; my++)
         for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
-            memset(lds420.data(), 0xCD, lds420.size());  // garbage, like real LDS
             memset(lds_s, 0xCD, sizeof(FusedLdsSmall));
-            if (kind == FUSED_420) {
-                if (g.tx <= 32u) { if (sane == 2) { RUN420(ARITH_TIGHT, 128, lds128) } else if (sane) { RUN420(ARITH_SANE, 128, lds128) } else { RUN420(ARITH_EXACT, 128, lds128) } }
-                else { if (sane == 2) { RUN420(ARITH_TIGHT, 256, lds) } else if (sane) { RUN420(ARITH_SANE, 256, lds) } else { RUN420(ARITH_EXACT, 256, lds) } }
-            } else if (kind == FUSED_422) {
+            if (kind == FUSED_422) {
 #define RUN422(S) RUN(256, F422<S>::phase0(g, img, tile, my, t, *lds_s)) RUN(256, F422<S>::phase1(g, img.qt[(t >> 6) < 2 ? 0 : (t >> 6) - 1], tile, t, *lds_s, regs[t])) \
     RUN(256, F422<S>::phase2(g, tile, t, *lds_s, regs[t])) RUN(256, F422<S>::phase3(g, img, tile, my, t, *lds_s))
                 if (sane == 2) { RUN422(ARITH_TIGHT) } else if (sane) { RUN422(ARITH_SANE) } else { RUN422(ARITH_EXACT) }
@@ -223,7 +189,6 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
             }
         }
 #undef RUN
-#undef RUN420
     delete lds_s;
     return kind;
 }

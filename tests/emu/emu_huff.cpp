@@ -1,5 +1,5 @@
-// emu_huff.cpp — TEST-ONLY CPU run of the device entropy decoder (csrc/huff_core.hpp) on the plan the host front-end
-// makes (Frontend::plan_device_scans): every restart segment decoded by the device code, into zero-filled planes.
+// emu_huff.cpp — TEST-ONLY CPU run of the device entropy decoder (csrc/huff_sync_core.hpp: sync passes with speculative emission,
+// block numbering, expansion) on the plan the host front-end makes (Frontend::plan_device_scans).
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
@@ -16,9 +16,8 @@ using jpgpu::host::PlannedScan;
 static uint32_t g_sync_iters = 1, g_sync_wg = 256, g_sync_stale = 0;  // launch shape of the sync passes (emu_huff_set_launch)
 static uint32_t g_late = 2;  // HuffSyncJob::late_pass (emu_huff_set_late)
 static uint32_t g_tail = 8;  // eighths of its chunk a lane walks in sync pass 0 (HuffSyncJob::pass0_skip)
-static uint32_t g_dri_chunks = 1, g_dri_shift = 0;  // restart segments in chunk slots (emu_huff_set_dri: on/off, forced chunk size)
+static uint32_t g_dri_shift = 0;  // restart segments in chunk slots: forced chunk size (emu_huff_set_dri; 0: the product's choice)
 static uint32_t g_emit_mismatch = 0;
-static uint32_t g_emit = 0;  // 1: speculative emission + expansion instead of the write pass (emu_huff_set_emit)
 static uint32_t g_range[2] = {0, 0};  // by-product of the last emu_huff_decode: largest |DC * q| / |AC * q| written (range_stats.hpp)
 
 // What huff_expand_kernel (csrc/huff.hip) does with the settled emission lists, one entry after the other: a block belongs to
@@ -97,8 +96,7 @@ int emu_stage_segment_clean(uint8_t* dst, const uint8_t* src, uint32_t n) {
 }
 uint32_t emu_chunk_shift(uint32_t stuffed_bytes, uint32_t total_blocks) { return huff_sync_chunk_shift(stuffed_bytes, total_blocks); }
 
-void emu_huff_set_emit(uint32_t on) { g_emit = on; }
-void emu_huff_set_dri(uint32_t chunks, uint32_t shift) { g_dri_chunks = chunks, g_dri_shift = shift; }
+void emu_huff_set_dri(uint32_t shift) { g_dri_shift = shift; }
 void emu_huff_set_late(uint32_t pass) { g_late = pass; }
 void emu_huff_set_tail(uint32_t eighths) { g_tail = eighths >= 1 && eighths <= 8 ? eighths : 8; }
 void emu_huff_last_range(uint32_t out[2]) { out[0] = g_range[0], out[1] = g_range[1]; }
@@ -132,17 +130,13 @@ int emu_huff_plan(const uint8_t* data, size_t len, jpgpu_image_desc* desc, uint3
     for (auto& s : scans) *n_segments += (uint32_t)(s.seg_off.size() / 2);
     return 0;
 }
-// 1: every scan is one without restart markers that writes all blocks of its planes (huff_scan_covers_planes: batch.cpp skips
-// the zero fill for such images when the sync passes emit)
+// 1: every scan writes all blocks of its planes (huff_scan_covers_planes: batch.cpp skips the zero fill for such images)
 int emu_huff_covered(const uint8_t* data, size_t len) {
     Frontend fe(data, len);
     std::vector<PlannedScan> scans;
     fe.read_info();
     if (!fe.plan_device_scans(scans)) return -1;
     for (const PlannedScan& ps : scans) {
-        if (ps.ri != 0) {  // restart segments: only when they go through the chunk decoder (emission on: not uniform, two segments or more)
-            if (!g_dri_chunks || ps.seg_off.size() < 4) return 0;
-        }
         HuffSyncJob sj;
         memset(&sj, 0, sizeof(sj));
         sj.cols = ps.cols, sj.n_mcu = ps.n_mcu, sj.ncomp = ps.ncomp;
@@ -161,7 +155,6 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
     fe.read_info();
     if (!fe.plan_device_scans(scans)) return -1;
     uint32_t status = 0;
-    HuffSyncLds* L = new HuffSyncLds;
     HuffRange rg;  // what the kernels fold per wave and raise in the image's statistics words
     for (const PlannedScan& ps : scans) {
         // staging as batch.cpp does it: every segment unstuffed into its own 16-byte aligned, zero padded slot
@@ -180,9 +173,9 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             if (!clean) status |= 1u | 16u;  // (batch.cpp: the staging pass refuses the stream)
         }
         if (status & 1u) continue;
-        // restart-marker streams through the chunk decoder (batch.cpp, dri_geom): with emission, not for uniform scans, >= 2 segments
-        const bool dri_chunked = ps.ri != 0 && g_emit && g_dri_chunks && ps.seg_off.size() >= 4;
-        if (ps.ri == 0 || dri_chunked) {  // the self-synchronising chunk decoder, passes run one after the other
+        // restart-marker streams (batch.cpp, dri_geom): every segment in chunk slots of its own; one segment = a scan without markers
+        const bool dri_chunked = ps.ri != 0 && ps.seg_off.size() >= 4;
+        {  // the self-synchronising chunk decoder, passes run one after the other
             HuffSyncLds* S = new HuffSyncLds;
             HuffSyncJob& sj = S->job;
             memset(&sj, 0, sizeof(sj));
@@ -225,13 +218,11 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             sj.pass0_skip = ((1u << sj.chunk_shift) >> 3) * (8u - g_tail);
             sj.late_pass = g_late;
             std::vector<uint32_t> emit_buf, emit_cnt;
-            if (g_emit) {
-                sj.emit_stride = huff_emit_stride(sj.chunk_shift);
-                emit_buf.assign((size_t)sj.n_chunks * sj.emit_stride + 1, 0xABABABABu);  // (+1: a canary behind the last buffer)
-                emit_cnt.assign(sj.n_chunks, 0xCDCDCDCDu);
-                sj.emit = emit_buf.data();
-                sj.emit_cnt = emit_cnt.data();
-            }
+            sj.emit_stride = huff_emit_stride(sj.chunk_shift);
+            emit_buf.assign((size_t)sj.n_chunks * sj.emit_stride + 1, 0xABABABABu);  // (+1: a canary behind the last buffer)
+            emit_cnt.assign(sj.n_chunks, 0xCDCDCDCDu);
+            sj.emit = emit_buf.data();
+            sj.emit_cnt = emit_cnt.data();
             std::vector<uint32_t> arr(8 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
             sj.blk_end = arr.data() + 7 * (size_t)sj.n_chunks;
             sj.in_pos = arr.data();
@@ -249,7 +240,6 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     sj.n_blocks[i] = i % 9u;
                 }
             memcpy(S->tables, ps.tables->t, sizeof(S->tables));
-            for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(S->unzig, t);
             for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*S, t);
             // Launches as huff.hip runs them: workgroups of 256 lanes, `iters` iterations each with a barrier in between.
             // Lanes of a workgroup run concurrently (every lane sees the states its neighbours had before the iteration);
@@ -269,8 +259,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                         for (uint32_t i = lo; i < hi; i++) {
                             std::copy(prev_pos.begin(), prev_pos.end(), sj.out_pos + first);
                             std::copy(prev_qk.begin(), prev_qk.end(), sj.out_qk + first);
-                            HuffRange unused;
-                            changed += huff_sync_chunk<false>(*S, i, launch * iters + it, unused) ? 1u : 0u;
+                            changed += huff_sync_chunk(*S, i, launch * iters + it) ? 1u : 0u;
                             new_pos[i - first] = sj.out_pos[i];
                             new_qk[i - first] = sj.out_qk[i];
                         }
@@ -292,12 +281,10 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     const uint32_t nb = sj.n_blocks[i];
                     sj.n_blocks[i] = run;
                     run += nb;
-                    if (g_emit) status |= huff_emit_chunk_status(sj, i, run);
+                    status |= huff_emit_chunk_status(sj, i, run);
                 }
-                if (g_emit) {
-                    status |= huff_emit_final_status(sj, run);
-                    if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;  // a lane wrote past its buffer
-                }
+                status |= huff_emit_final_status(sj, run);
+                if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;  // a lane wrote past its buffer
                 if (!sj.uniform) {  // (huff_sync_scan_kernel) sums of DC differences -> predictors at the start of every chunk
                     uint32_t acc[4] = {0, 0, 0, 0};
                     for (uint32_t i = 0; i < sj.n_chunks; i++) {
@@ -309,14 +296,10 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     }
                 }
             }
-            if (g_emit) {
-                if (status == 0) {
-                    g_emit_mismatch = 0;
-                    emu_expand(sj, rg);
-                    if (g_emit_mismatch) status |= 0x4000u;  // entries that name another component than the block numbering does
-                }
-            } else {
-                for (uint32_t i = 0; i < sj.n_chunks; i++) huff_sync_chunk<true>(*S, i, 0, rg);
+            if (status == 0) {
+                g_emit_mismatch = 0;
+                emu_expand(sj, rg);
+                if (g_emit_mismatch) status |= 0x4000u;  // entries that name another component than the block numbering does
             }
             // (huff_dc_prefix_kernel, uniform scans only) DC differences -> values, per component in stream order (i16 wrapping)
             for (uint32_t c = 0; sj.uniform && c < ps.ncomp; c++) {
@@ -336,35 +319,8 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             }
             if (n_passes) *n_passes = pass;
             delete S;
-            continue;
         }
-        HuffSyncJob& job = L->job;
-        memset(&job, 0, sizeof(job));
-        job.data = stage;
-        job.seg_off = table.data();
-        job.tables = ps.tables->t;
-        job.status = &status;
-        job.n_seg = (uint32_t)(ps.seg_off.size() / 2);
-        job.ri = ps.ri;
-        job.cols = ps.cols;
-        job.n_mcu = ps.n_mcu;
-        job.ncomp = ps.ncomp;
-        for (uint32_t c = 0; c < ps.ncomp; c++) {
-            job.comp[c].dst = coefs[ps.comp[c].frame_index];
-            job.comp[c].block_w = ps.comp[c].block_w;
-            job.comp[c].h = ps.comp[c].h;
-            job.comp[c].v = ps.comp[c].v;
-            job.comp[c].dc = ps.comp[c].dc;
-            job.comp[c].ac = ps.comp[c].ac;
-            memcpy(job.q[c], fe.qtable_of_component(ps.comp[c].frame_index), 128);
-        }
-        huff_sync_finish_job(job);
-        memcpy(L->tables, ps.tables->t, sizeof(L->tables));
-        for (uint32_t t = 0; t < 64; t++) huff_fill_unzigzag(L->unzig, t);
-        for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*L, t);
-        for (uint32_t s = 0; s < job.n_seg; s++) huff_decode_segment(*L, s, rg);
     }
-    delete L;
     g_range[0] = rg.dc, g_range[1] = rg.ac;
     return (int)status;
 }

@@ -1,5 +1,5 @@
-"""Device entropy decoder (csrc/huff_core.hpp: one lane per restart segment) run on the CPU by tests/emu against the host
-front-end: same coefficients for every stream the planner declares eligible; damaged streams either stay with the host
+"""Device entropy decoder (csrc/huff_sync_core.hpp: self-synchronising chunk decoder with speculative emission; restart segments
+in chunk slots of their own) run on the CPU by tests/emu against the host front-end: same coefficients for every stream the planner declares eligible; damaged streams either stay with the host
 (not eligible), raise the status flag, or decode to exactly what the host decodes."""
 import ctypes as C
 import io
@@ -31,9 +31,9 @@ def _device(data):
     ns, nseg = C.c_uint32(0), C.c_uint32(0)
     if L.emu_huff_plan(buf, len(data), C.byref(desc), C.byref(ns), C.byref(nseg)) != 0:
         return None
-    # speculative emission (emission fixture): the expansion writes every block of the scan whole, so the planes of a stream with
-    # scans that cover their planes and have no restart markers may start as anything — a pattern here — where the write pass needs zeros
-    fill = 0x5A5A if (_device.emit and L.emu_huff_covered(buf, len(data)) == 1) else 0
+    # the expansion writes every block of a scan whole, so the planes of a stream whose scans cover their planes may start as
+    # anything — a pattern here; other planes start as zeros (batch.cpp's fill)
+    fill = 0x5A5A if L.emu_huff_covered(buf, len(data)) == 1 else 0
     planes = [np.full(desc.components[c].block_width * desc.components[c].block_height * 64, fill, np.int16) for c in range(desc.ncomp)]
     ptrs = (C.c_void_p * 4)(*([p.ctypes.data for p in planes] + [None] * (4 - len(planes))))
     npass = C.c_uint32(0)
@@ -42,28 +42,21 @@ def _device(data):
     return st, desc, planes, ns.value, nseg.value
 
 
-_device.emit = False
-
-
-@pytest.fixture(params=[(0, 8, 2), (1, 8, 2), (1, 3, 2), (0, 2, 2), (1, 3, 1), (1, 8, 1000)],
-                ids=["write-pass", "emission", "emission-tail3", "write-pass-tail2", "emission-tail3-stores-one-by-one", "emission-rounds-of-eight-only"])
+@pytest.fixture(params=[(1, 8, 2), (1, 3, 2), (1, 2, 2), (1, 3, 1), (1, 8, 1000)],
+                ids=["emission", "emission-tail3", "emission-tail2", "emission-tail3-stores-one-by-one", "emission-rounds-of-eight-only"])
 def emission(request):
-    """The chunk decoder's two ways to the arena: a write pass after the sync passes, or entries emitted by the sync passes
-    themselves and expanded into whole blocks (HuffSyncJob::emit); and how much of its chunk a lane walks in the first
-    sync pass (eighths: HuffSyncJob::pass0_skip); from which pass on a lane stores its entries one by one (HuffSyncJob::late_pass)."""
-    emu.lib().emu_huff_set_emit(request.param[0])
+    """Entries emitted by the sync passes and expanded into whole blocks (HuffSyncJob::emit): how much of its chunk a lane walks in
+    the first sync pass (eighths: HuffSyncJob::pass0_skip), and from which pass on a lane stores its entries one by one
+    (HuffSyncJob::late_pass).  (Rounds 1-3 also had a write pass after the sync passes; deleted in round 4.)"""
     emu.lib().emu_huff_set_tail(request.param[1])
     emu.lib().emu_huff_set_late(request.param[2])
-    _device.emit = bool(request.param[0])
     yield request.param
-    emu.lib().emu_huff_set_emit(0)
     emu.lib().emu_huff_set_tail(8)
     emu.lib().emu_huff_set_late(2)
-    _device.emit = False
 
 
 def _range_by_product():
-    """(max |DC * q|, max |AC * q|) the write passes of the last _device() call folded (csrc/range_stats.hpp)."""
+    """(max |DC * q|, max |AC * q|) the expansion of the last _device() call folded (csrc/range_stats.hpp)."""
     out = (C.c_uint32 * 2)()
     emu.lib().emu_huff_last_range(out)
     return int(out[0]), int(out[1])
@@ -128,7 +121,9 @@ def test_reference_fixtures_with_restart_markers(rel, emission):
 
 
 @pytest.mark.parametrize("case", [(64, 48, "4:2:0", 0, 1), (250, 130, "4:2:0", 3, 0), (129, 257, "4:2:2", 0, 2), (200, 120, "4:4:4", 1, 0),
-                                  (33, 17, "4:2:0", 5, 0), (300, 200, None, 0, 1), (1920, 64, "4:2:0", 0, 1), (17, 1080, "4:4:4", 7, 0)],
+                                  (33, 17, "4:2:0", 5, 0), (300, 200, None, 0, 1), (1920, 64, "4:2:0", 0, 1), (17, 1080, "4:4:4", 7, 0),
+                                  # a restart interval that covers the whole scan: ONE segment, decoded as a scan without markers (round 4)
+                                  (96, 64, "4:2:0", 0, 50), (40, 24, "4:4:4", 500, 0)],
                          ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}-b{c[3]}r{c[4]}")
 def test_encoder_written_restart_streams(case, emission):
     pytest.importorskip("PIL")
@@ -178,7 +173,7 @@ def launch_shape(request):
 @pytest.mark.parametrize("rel", NO_RST)
 def test_streams_without_restart_markers_self_synchronising_decoder(rel, launch_shape, emission):
     """Baseline files as encoders write them by default (no DRI): chunked decoding with state hand-over until the
-    segmentation settles, block numbering, write pass, DC accumulation — all device code, run on the CPU."""
+    segmentation settles, block numbering, expansion, DC accumulation — all device code, run on the CPU."""
     data = open(os.path.join(R.GOLDEN, rel), "rb").read()
     got = _device(data)
     if got is None:
@@ -445,7 +440,7 @@ def test_more_long_code_prefixes_than_second_level_tables(emission):
 def test_restart_streams_whose_components_share_their_tables(case, emission):
     """CMYK as Pillow writes it: four components, one pair of Huffman tables — a `uniform` scan (the chunk decoder cannot tell
     the blocks of an MCU apart, DC values are summed per plane afterwards) — with restart markers: the sums start again at
-    every segment (huff_dc_prefix_kernel's restart intervals; the one-lane-per-segment decoder when emission is off)."""
+    every segment (huff_dc_prefix_kernel's restart intervals)."""
     pytest.importorskip("PIL")
     import io
     from PIL import Image

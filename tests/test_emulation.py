@@ -122,7 +122,7 @@ def _to_j(ocomps):
     return out
 
 
-def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64, strip=0, seg_rows=0, s420_tx=0):
+def _emulate(w_, h_, samp, ct, coefs, qts, sane, seg_rows=0, s420_tx=0):
     ocomps, _ = O.make_components(w_, h_, samp)
     desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
     n = len(samp)
@@ -130,7 +130,7 @@ def _emulate(w_, h_, samp, ct, coefs, qts, sane, f420_tx=64, strip=0, seg_rows=0
     out_len = w_ * h_ * (1 if n == 1 else n)
     out = np.full(out_len + 64, 0x5A, np.uint8)  # guard band: the kernels must not write past the image
     tx = C.c_uint32(0)
-    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, int(sane), out.ctypes.data, C.byref(tx), f420_tx, strip, seg_rows, s420_tx)
+    kind = emu.lib().emu_fused_decode(C.byref(desc), ptrs, int(sane), out.ctypes.data, C.byref(tx), seg_rows, s420_tx)
     assert (out[out_len:] == 0x5A).all(), "emulated kernel wrote past the output"
     return kind, out[:out_len], tx.value
 
@@ -171,22 +171,14 @@ GEOMS = [
 
 @pytest.mark.parametrize("geom", GEOMS, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
 @pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
-@pytest.mark.parametrize("f420_tx", [64, 32, "strip", "strip-seg1", "strip-seg3", "strip-tx20", "strip-tx20-seg2", "strip-tx7", "strip-tx7-seg1",
-                                     "strip-bal2", "strip-bal3", "strip-bal7", "strip-tx7-bal5"])
-def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
+@pytest.mark.parametrize("walk_shape", ["default", "seg1", "seg3", "tx20", "tx20-seg2", "tx7", "tx7-seg1"])
+def test_fused_kernel_logic_matches_oracle(geom, kind, walk_shape):
     walk = len(geom[2]) == 3 and geom[2][0] in ((2, 2), (1, 2))
-    if f420_tx != 64 and not walk or (f420_tx == 32 and geom[2][0] != (2, 2)):
-        pytest.skip("variant knob only affects the 4:2:0 / 4:4:0 kernels")
-    strip, seg_rows, s420_tx = 0, 0, 0
-    if isinstance(f420_tx, str):  # single-launch strip walk: (MCU rows per workgroup, widest strip)
-        strip = 1
-        seg_rows, s420_tx = {"strip": (1000, 0), "strip-seg1": (1, 0), "strip-seg3": (3, 0), "strip-tx20": (1000, 20),
-                             "strip-tx20-seg2": (2, 20), "strip-tx7": (5, 7), "strip-tx7-seg1": (1, 7),
-                             # balanced shares (fused_plan.hpp walk_balanced_items) for 2 / 3 / 7 / 5 workgroups: items that start and
-                             # end anywhere in a strip, several items of different strips run by one workgroup on the same LDS
-                             "strip-bal2": (0x10000 | 2, 0), "strip-bal3": (0x10000 | 3, 0), "strip-bal7": (0x10000 | 7, 0),
-                             "strip-tx7-bal5": (0x10000 | 5, 7)}[f420_tx]
-        f420_tx = 64
+    if walk_shape != "default" and not walk:
+        pytest.skip("the shape knobs only affect the strip walks (4:2:0 / 4:4:0)")
+    # strip walks: (MCU rows per workgroup, widest strip) — short segments and narrow strips exercise seams and halos
+    seg_rows, s420_tx = {"default": (1000, 0), "seg1": (1, 0), "seg3": (3, 0), "tx20": (1000, 20), "tx20-seg2": (2, 20), "tx7": (5, 7),
+                         "tx7-seg1": (1, 7)}[walk_shape]
     w_, h_, samp, ct = geom
     rng = np.random.default_rng(w_ * 131 + h_)
     ocomps, _ = O.make_components(w_, h_, samp)
@@ -200,7 +192,7 @@ def test_fused_kernel_logic_matches_oracle(geom, kind, f420_tx):
     else:
         qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
         coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
-    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, {"hostile": 0, "sane": 1, "tight": 2}[kind], f420_tx, strip, seg_rows, s420_tx)
+    got_kind, got, tx = _emulate(w_, h_, samp, ct, coefs, qts, {"hostile": 0, "sane": 1, "tight": 2}[kind], seg_rows, s420_tx)
     assert got_kind != 0, "planner refused a geometry the fused kernels are meant to cover"
     want = O.pixels_from_coefficients(ocomps, qts, coefs, w_, h_, ct.upper())
     assert got.size == want.size
@@ -221,7 +213,7 @@ def test_planner_keeps_odd_geometries_on_the_generic_path():
         desc = J.image_desc(list(_to_j(ocomps)), qts, w_, h_, ct)
         ptrs = (C.c_void_p * len(samp))(*[c.ctypes.data for c in coefs])
         out = np.zeros(w_ * h_ * 4 + 64, np.uint8)
-        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None, 32, 0, 0, 0) == 0
+        assert emu.lib().emu_fused_decode(C.byref(desc), ptrs, 0, out.ctypes.data, None, 0, 0) == 0
 
 
 # ---- generic upsample + colour kernel (csrc/upsample_color_body.hpp + csrc/image_job.cpp) ----------------------------

@@ -385,8 +385,7 @@ STRIP_GEOMETRY = [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (673, 79),
                          ids=["default", "seg1", "seg3-tx20", "tx7"])
 @pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
 def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
-    """The single-launch 4:2:0 kernel (the default since round 2): strip / segment seams, carry rows, image edges."""
-    monkeypatch.setenv("JPGPU_420_STRIP", "1")
+    """The 4:2:0 strip walk: strip / segment seams, carry rows, image edges."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     w_, h_ = size
@@ -397,20 +396,6 @@ def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
     for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
         want = O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())
         assert np.array_equal(got, want)
-
-
-@pytest.mark.parametrize("size", STRIP_GEOMETRY, ids=lambda s: f"{s[0]}x{s[1]}")
-@pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
-def test_batch_420_two_pass_variant_bit_exact(size, kind, monkeypatch):
-    """Round 1's 4:2:0 form (chroma pass + main pass), kept behind JPGPU_420_STRIP=0 as the A/B partner."""
-    monkeypatch.setenv("JPGPU_420_STRIP", "0")
-    w_, h_ = size
-    rng = np.random.default_rng(w_ * 79 + h_)
-    cases = [_batch_case(rng, w_, h_, [(2, 2), (1, 1), (1, 1)], "YCbCr", kind=kind) for _ in range(3)]
-    outs, path = _run_batch(cases)
-    assert path == "fused420-2pass"
-    for (oc, qts, coefs, ct_, _w, _h), got in zip(cases, outs):
-        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper()))
 
 
 MIXED_SIZES = {
@@ -441,11 +426,9 @@ def test_batch_mixed_sizes_of_one_kind_take_the_fused_path(key, kind):
 
 @pytest.mark.parametrize("case", [(250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (200, 120, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
                                   (300, 200, [(1, 1)], "Grayscale")], ids=["420", "444", "gray"])
-@pytest.mark.parametrize("strip", ["0", "1"])
-def test_uniform_batch_through_the_work_table_form(case, strip, monkeypatch):
+def test_uniform_batch_through_the_work_table_form(case, monkeypatch):
     """Uniform batches normally use the 3-D grid; JPGPU_FUSED_TABLE=1 sends them through the work tables as well."""
     monkeypatch.setenv("JPGPU_FUSED_TABLE", "1")
-    monkeypatch.setenv("JPGPU_420_STRIP", strip)
     w_, h_, samp, ct = case
     rng = np.random.default_rng(w_ + h_)
     cases = [_batch_case(rng, w_, h_, samp, ct) for _ in range(4)]
@@ -640,15 +623,13 @@ def test_batch_scan_ranges_on_device_equals_host_classification():
     b.close()
 
 
-@pytest.mark.parametrize("strip", ["1", "0"], ids=["single-launch", "two-pass"])
 @pytest.mark.parametrize("samp,ct", [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1), (1, 1), (1, 1)], "YCbCr"), ([(2, 1), (1, 1), (1, 1)], "YCbCr"),
                                      ([(1, 1)], "Grayscale"), ([(1, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)] * 4, "YCCK")],
                          ids=["420", "444", "422", "gray", "440", "ycck"])
-def test_one_hostile_image_costs_only_itself(samp, ct, strip, monkeypatch):
+def test_one_hostile_image_costs_only_itself(samp, ct):
     """A launch group whose images disagree on the arithmetic class is split per class: one image with
     wrap-range coefficients and one of class 1 among 64 leave the other 62 on the class-3 kernels, and every image —
     whichever kernel took it — equals the oracle."""
-    monkeypatch.setenv("JPGPU_420_STRIP", strip)
     rng = np.random.default_rng(len(samp) * 1000 + samp[0][0] * 10 + samp[0][1])
     w_, h_ = 200, 120
     cases = [_batch_case(rng, w_, h_, samp, ct, kind="tight") for _ in range(64)]
@@ -777,15 +758,11 @@ DYN_KINDS = [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(1, 1), (1, 1), (1, 1)], "YC
 DYN_IDS = ["420", "444", "422", "gray", "440", "ycck", "411", "311-generic", "cmyk-2211", "ycck-2212"]
 
 
-@pytest.mark.parametrize("strip", ["1", "0"], ids=["single-launch", "two-pass"])
 @pytest.mark.parametrize("samp,ct", DYN_KINDS, ids=DYN_IDS)
-def test_classes_decided_on_the_device_every_kernel(samp, ct, strip, monkeypatch):
+def test_classes_decided_on_the_device_every_kernel(samp, ct):
     """jpgpu_batch_classify_on_device: the range statistics stay in HBM, a finalize kernel turns them into the images' classes
     in front of the pixel kernels, and ONE `_dyn` launch per kind branches per workgroup — 64 images of all three classes, every
     one equal to the oracle, and the split the device arrives at equal to the host's exact classification (VERDICT r2 next #2)."""
-    if strip == "0" and samp[0] != (2, 2):
-        pytest.skip("the two-pass form exists for 4:2:0 only")
-    monkeypatch.setenv("JPGPU_420_STRIP", strip)
     rng = np.random.default_rng(len(samp) * 100 + samp[0][0] * 10 + samp[0][1] + 5)
     w_, h_ = 200, 120
     cases = [_batch_case(rng, w_, h_, samp, ct, kind="tight") for _ in range(64)]

@@ -118,7 +118,7 @@ def _pil_restart(w, h, subsampling, rows=0, blocks=0, gray=False, seed=3):
 
 
 def test_pipeline_device_entropy_decoder_matches_host_path(monkeypatch):
-    """Restart-marker streams decoded on the GPU (one lane per restart segment) next to streams that must stay on the host
+    """Restart-marker streams decoded on the GPU (every restart segment in chunk slots of its own) next to streams that must stay on the host
     and damaged restart streams the device decoder has to hand back: every result equals the per-image oracle outcome."""
     pytest.importorskip("PIL")
     monkeypatch.setenv("JPGPU_PIPE_FORCE_DEVICE", "1")  # (a handful of small files: the pipeline's cost model would keep them on the host)
@@ -371,11 +371,9 @@ def test_pipeline_device_entropy_randomised_encoder_settings(monkeypatch):
     _check(names, files, out)
     t = p.timings()
     assert t["images_device_entropy"] == len(files), t
-    monkeypatch.setenv("JPGPU_SYNC_WRITE_ASSEMBLE", "1")  # the write pass that assembles whole blocks in LDS (A/B variant)
-    out = p.decode(files, device_entropy=True)
+    out = p.decode(files, device_entropy=True)  # (a second call: buffers, work space and statistics of the first are reused)
     _check(names, files, out)
     assert p.timings()["images_device_entropy"] == len(files)
-    monkeypatch.delenv("JPGPU_SYNC_WRITE_ASSEMBLE")
     monkeypatch.delenv("JPGPU_PIPE_FORCE_DEVICE")
     out = p.decode(files, device_entropy=True)  # with the cost models deciding
     _check(names, files, out)
@@ -420,11 +418,11 @@ print("ok")
 '''
 
 
-@pytest.mark.parametrize("env", [{"JPGPU_SYNC_EMIT": "0"}, {"GPU_MAX_HW_QUEUES": "4"}, {"JPGPU_SYNC_TAIL": "8"}, {"JPGPU_SYNC_TAIL": "1", "JPGPU_SYNC_ITERS": "1"},
+@pytest.mark.parametrize("env", [{"GPU_MAX_HW_QUEUES": "4"}, {"JPGPU_SYNC_TAIL": "8"}, {"JPGPU_SYNC_TAIL": "1", "JPGPU_SYNC_ITERS": "1"},
                                  {"JPGPU_PIPE_DEV_SUB": "3", "JPGPU_PIPE_MAX_DEV_SUBS": "32"}, {"JPGPU_PIPE_STREAMS": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_pipeline_device_entropy_under_other_settings(env):
-    """Settings a process reads once — the write pass instead of emission + expansion, the HIP runtime's default queue count, the
+    """Settings a process reads once — the HIP runtime's default queue count, the
     first sync pass over whole chunks or an eighth of them, tiny sub-batches, one compute stream: the device-entropy route of a
     process of its own must give the oracle's pixels (and the oracle's error for a truncated file) under each."""
     pytest.importorskip("PIL")
