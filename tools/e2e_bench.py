@@ -34,6 +34,7 @@ def main():
     from PIL import Image
     import synth
     import jpeg_decoder_amd as J
+    J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
     distinct = []
     if args.file:
         data = open(args.file, "rb").read()

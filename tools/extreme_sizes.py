@@ -6,6 +6,7 @@ for sub in ("oracle", "", "tests"):
 import numpy as np
 import oracle as O, synth
 import jpeg_decoder_amd as J
+J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
 import test_gpu_parity as T
 T.J = J
 KINDS = {"420": ([(2, 2), (1, 1), (1, 1)], "YCbCr"), "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr"), "444": ([(1, 1)] * 3, "YCbCr"),

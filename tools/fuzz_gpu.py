@@ -7,6 +7,7 @@ sys.path.insert(0,'tests'); sys.path.insert(0,'.'); sys.path.insert(0,'oracle')
 import numpy as np
 import oracle as O, refimages as R, synth
 import jpeg_decoder_amd as J
+J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
 from PIL import Image
 def pil(w,h,sub,gray=False,q=85,**kw):
     buf=io.BytesIO(); rgb=synth.synthetic_rgb(w,h,seed=w+h); Image.fromarray(rgb[...,0] if gray else rgb).save(buf,format="JPEG",quality=q,subsampling=sub,**kw); return buf.getvalue()

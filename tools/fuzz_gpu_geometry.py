@@ -10,6 +10,7 @@ for sub in ("oracle", "", "tests"):
 import numpy as np
 import oracle as O, synth
 import jpeg_decoder_amd as J
+J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
 import test_gpu_parity as T
 
 KINDS = [  # sampling factors, colour transform

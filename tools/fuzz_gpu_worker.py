@@ -12,6 +12,7 @@ for sub in ("oracle", "", "tests"):
 import numpy as np
 import oracle as O, synth
 import jpeg_decoder_amd as J
+J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
 import test_gpu_parity as T
 
 KINDS = [([(2, 2), (1, 1), (1, 1)], "YCbCr"), ([(2, 1), (1, 1), (1, 1)], "YCbCr"), ([(1, 1)] * 3, "YCbCr"), ([(1, 2), (1, 1), (1, 1)], "YCbCr"),

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import jpeg_decoder_amd as J
+J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
 import synth
 from PIL import Image
 p = J.Pipeline(threads=int(os.environ.get("THREADS", "1")))

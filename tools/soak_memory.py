@@ -6,6 +6,7 @@ for sub in ("oracle", "", "tests"):
     sys.path.insert(0, os.path.join(ROOT, sub))
 import numpy as np, torch
 import jpeg_decoder_amd as J, synth
+J.process_init()  # GPU_MAX_HW_QUEUES before the HIP runtime starts (opt-in since round 4)
 from PIL import Image
 
 def jpeg(w, h, sub="4:2:0", **kw):
