@@ -266,6 +266,10 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         b->out_off[i] = oo;
         b->out_len[i] = out_len;
         oo += align_up(out_len, 256);
+        // JPGPU_ARENA_SKEW = s (experiment, round 4): s * ((7 i) mod 16) bytes of padding behind image i in both arenas — images of one
+        // geometry then no longer lie at one stride (1080p 4:2:0: 8 kB x 765 for coefficients, 1 kB x 6075 for pixels) from each other
+        static const size_t skew = getenv("JPGPU_ARENA_SKEW") ? (size_t)std::max(0l, atol(getenv("JPGPU_ARENA_SKEW"))) / 256 * 256 : 0;
+        if (skew) co += skew * ((7u * i) % 16u), oo += skew * ((7u * i) % 16u);
         if (kind_key[i] == 0) {
             b->generic_ids.push_back(i);
             b->max_w = std::max<uint32_t>(b->max_w, d.ncomp == 1 ? d.components[0].size_width : d.out_w);
