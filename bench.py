@@ -73,6 +73,7 @@ WORKLOADS = {
     "1080p-444+gray": (1920, 1080, None, "mixed", None, 1024),  # BASELINE configs[4]: batch 1024 (512 + 512)
 }
 CONFIG3_WORKLOAD, CONFIG3_IMAGES_TOTAL = "2160p-420", 4096
+E2E_SHARDED_TOTAL = 4096  # files of the e2e leg at N > 1 (north_star's batch), sharded over the ranks
 
 
 def parse_args(argv=None):
@@ -99,6 +100,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-k4096", action="store_true", help="skip the 4096-image kernel-only figure (N = 1, default workload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the JPEG-bytes -> RGB figures and their CPU comparator (N = 1, default workload)")
     ap.add_argument("--e2e-images", default="256,1024,4096", help="files per jpgpu_pipeline_decode call of the e2e block")
+    ap.add_argument("--e2e-total", type=int, default=E2E_SHARDED_TOTAL, help="files of the e2e leg at N > 1 / --force-dist, sharded over the ranks")
     ap.add_argument("--e2e-encoder", default="auto", choices=["auto", "pillow", "builtin"],
                     help="who writes the e2e block's JPEG files: Pillow (libjpeg-turbo) or tools/baseline_encoder.py; auto = Pillow if importable")
     ap.add_argument("--force-dist", action="store_true",
@@ -174,6 +176,68 @@ def effective_cpus():
         except (OSError, ValueError, IndexError):
             continue
     return n
+
+
+def rank_cpu_share(rank, world):
+    """Host CPUs rank `rank` of `world` keeps its feeder threads on: a contiguous share of the CPUs this process may run on (on a
+    two-socket host the first ranks then sit on the first socket), and the thread budget that goes with it — the CPUs the cgroup
+    GRANTS, divided by the ranks (one pipeline keeps ~8 CPUs busy; `world` ranks that each started the default of one thread per
+    physical core would oversubscribe the host `world`-fold: VERDICT r3).  -> (cpu list, threads for jpgpu_pipeline_create)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(os.cpu_count() or 1))
+    a, b = len(allowed) * rank // world, len(allowed) * (rank + 1) // world
+    share = allowed[a:b] or allowed
+    return share, max(2, effective_cpus() // world)
+
+
+def pin_to(share):
+    try:
+        os.sched_setaffinity(0, share)
+        return True
+    except (AttributeError, OSError):
+        return False
+
+
+def h2d_rate_gbps(torch, dev, nbytes=1 << 30):
+    """What the host link gives ONE pinned copy of 1 GB, in this run (the floor of an E call is its entropy-coded bytes at this rate)."""
+    src = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    return nbytes / (best * 1e-3) / 1e9
+
+
+def huffman_symbols(J, data):
+    """Huffman symbols of a baseline file's scan(s), from the coefficients the host front-end decodes: per block one DC symbol,
+    one symbol per non-zero AC coefficient, a ZRL per 16 zeros inside a run, an EOB unless the last coefficient is non-zero."""
+    _desc, planes = J.Decoder(data, device=-1).decode_coefficients()
+    zz = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+                   57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+    total = 0
+    for pl in planes:
+        b = np.asarray(pl, np.int16).reshape(-1, 64)[:, zz]  # zig-zag order
+        nz = b[:, 1:] != 0
+        total += b.shape[0] + int(nz.sum())                   # DC symbols + coefficient symbols
+        last = np.where(nz.any(axis=1), 62 - np.argmax(nz[:, ::-1], axis=1), -1)  # index (0..62) of the last non-zero AC coefficient
+        total += int((last < 62).sum())                        # EOB
+        # ZRL: one per 16 zeros in front of a non-zero coefficient
+        idx = np.arange(63)
+        pos_idx = np.where(nz, idx[None, :], -1)
+        prev = np.maximum.accumulate(np.concatenate([np.full((b.shape[0], 1), -1), pos_idx[:, :-1]], axis=1), axis=1)
+        total += int((np.where(nz, idx[None, :] - prev - 1, 0) // 16).sum())
+    return total
 
 
 def cpu_model():
@@ -270,7 +334,44 @@ def e2e_files(synth, w, h, encoder, distinct=4, restart_rows=0):
     return [E.encode_rgb(rgb, 85, "420", ri) for rgb in rgbs], f"tools/baseline_encoder.py (this repo), quality 85, 4:2:0, Annex K Huffman tables, {rst}"
 
 
-def e2e_block(J, O, synth, w, h, sizes, encoder):
+def sync_pass_instructions(symbols_per_call):
+    """Vector instructions of the chunk decoder's sync passes per Huffman symbol, from the committed counter passes of a 256-file
+    call as one sub-batch (profiles/roundN/*pipeline_256*pmc*.json: SQ_INSTS_VALU per dispatch x dispatches, all sync launches of
+    the call): wave-instructions per symbol, and x 64 = lane slots per symbol (a scalar decoder's step is ~100 instructions)."""
+    import glob
+    for rnd in ("round4", "round3"):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", rnd, "*pipeline_256*pmc*.json")) + glob.glob(os.path.join(ROOT, "profiles", rnd, "*pipe256*stats*.json"))):
+            try:
+                doc = json.load(open(f))
+            except (OSError, ValueError):
+                continue
+            wave_instr = 0.0
+            for name, e in doc.items():
+                if "huff_sync_pass_kernel" in name and "pmc" in e and "SQ_INSTS_VALU" in e["pmc"]:
+                    wave_instr += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
+            calls = doc.get("_calls_of_the_pipeline") or 6  # (tools/pipe_calls.py / round 3's script: six calls per profiled process)
+            if wave_instr:
+                per_call = wave_instr / calls
+                return {"wave_instructions_per_symbol": round(per_call / symbols_per_call, 2), "lane_slots_per_symbol": round(64 * per_call / symbols_per_call, 1),
+                        "source": os.path.relpath(f, ROOT) + " (SQ_INSTS_VALU of every huff_sync_pass_kernel dispatch of one 256-file call; read from the file, not measured in this run)"}
+    return None
+
+
+def e2e_floor_fields(e, best, h2d_gbps, alone_ms_per_image):
+    """An E entry on its own roofline: the link floor (entropy-coded bytes that cross PCIe at the H2D rate one pinned 1-GB copy
+    reached in this run), the device-work floor (the kernels' time per image with the device to itself — sync passes, expansion,
+    pixel kernels of one sub-batch of 256 alone — times the images), and how close the call's wall clock is to the larger one."""
+    link = best["coefficient_bytes"] / (h2d_gbps * 1e9) * 1e3 if h2d_gbps else None
+    work = alone_ms_per_image * e["images"] if alone_ms_per_image else None
+    floors = [x for x in (link, work) if x]
+    e["pcie_bytes"] = int(best["coefficient_bytes"])
+    e["link_floor_ms"] = round(link, 3) if link else None
+    e["device_work_ms"] = round(work, 3) if work else None
+    e["frac_of_floor"] = round(max(floors) / e["total_ms"], 4) if floors else None
+    e["bound"] = None if not floors else ("link" if link and link >= (work or 0) else "device work")
+
+
+def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
     """What the metric's words say: JPEG bytes in host memory -> RGB in HBM, through jpgpu_pipeline_decode with the entropy
     decoding on the device (no host Huffman decoding, no range scan, no host synchronisation in front of the pixel kernels).
     Per batch size: best of 3 warm calls (wall clock of the call, everything included: header parsing, staging, H2D, kernels) and a
@@ -284,6 +385,7 @@ def e2e_block(J, O, synth, w, h, sizes, encoder):
                    "(self-synchronising chunk decoder with speculative emission), classes from its statistics, pixel kernels right behind it; "
                    "best of 3 warm calls; wall clock of the whole call"}
     p = J.Pipeline()
+    bests = {}
     try:
         for n in sizes:
             files = [distinct[i % len(distinct)] for i in range(n)]
@@ -303,6 +405,7 @@ def e2e_block(J, O, synth, w, h, sizes, encoder):
                  "images_device_entropy": int(best["images_device_entropy"]), "images_device_rejected": int(best["images_device_rejected"]),
                  "threads": int(best["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(ok)}
             out[str(n)] = e
+            bests[str(n)] = best
         # The kernels alone: the same 256 files as ONE sub-batch with the device to itself (the pipeline's default splits a call into
         # sub-batches of 128 that run side by side on their own streams: their phase times overlap and do not add up to anything).
         os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"] = "256", "1"
@@ -322,6 +425,20 @@ def e2e_block(J, O, synth, w, h, sizes, encoder):
                             "uniform scans | class finalize + pixel kernels.  No zero fill, no range scan, no write pass.",
                     "kernel_ms": {**{k: round(v, 3) for k, v in km.items()}, "sum": round(sum(km.values()), 3)},
                     "kernels_only_images_per_s": round(256 / sum(km.values()) * 1e3, 1), "total_ms": round(best["total_ms"], 3)}
+                # every E entry against its own floors (VERDICT r3 next #1a)
+                symbols = sum(huffman_symbols(J, d) for d in distinct) / len(distinct)
+                for key, b in bests.items():
+                    e2e_floor_fields(out[key], b, h2d_gbps, sum(km.values()) / 256.0)
+                out["roofline"] = {
+                    "h2d_gbps": round(h2d_gbps, 2) if h2d_gbps else None,
+                    "h2d_what": "one pinned 1-GB host-to-device copy, best of 3, this run",
+                    "device_work_ms_per_image": round(sum(km.values()) / 256.0, 5),
+                    "device_work_what": "kernels_256_one_sub_batch.kernel_ms.sum / 256: sync passes + block numbering + expansion + pixel kernels with the device to themselves "
+                                        "(the late sync passes' chains included: an upper estimate of the work, a lower one of a lone sub-batch's latency)",
+                    "huffman_symbols_per_image": int(symbols), "bits_per_symbol": round(out["jpeg_bytes_per_image"] * 8 / symbols, 2),
+                    "sync_ns_per_symbol": round(km["sync_ms"] * 1e6 / (256 * symbols), 4),
+                    "sync_pass_vector_instructions": sync_pass_instructions(256 * symbols),
+                    "frac_of_floor": "max(link_floor_ms, device_work_ms) / total_ms per entry: 1.0 = the call takes what its larger floor takes"}
         finally:
             del os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"]
         files_for_cpu = [distinct[i % len(distinct)] for i in range(256)]
@@ -411,6 +528,57 @@ def _cpu_e2e_sample(O, files, w, h, target_seconds):
             "sample": f"{n} decodes of the e2e block's {w}x{h} files ({ok} ok, {px} pixel bytes), JPEG bytes -> RGB in host memory, whole decode "
                       f"(parse + Huffman + IDCT + upsampling + colour), {cores} threads one file per task, {dt:.1f} s; gcc {flags}; {cpu_model()}; "
                       f"the crate's own x86 build would add SSSE3 IDCT / colour kernels (not bit-compatible with its scalar path)"}
+
+
+def e2e_sharded(J, O, synth, D, dist, torch, dev, rank, local_rank, world, w, h, total, encoder, share, threads, pinned):
+    """E at N ranks (north_star: "throughput on synthetic 4:2:0 baseline JPEGs is reported at 1, 2, 4 and 8 GPUs"): `total` files, rank r
+    decodes D.shard(total, r, world) of them through a pipeline of its own on ITS GPU with ITS share of the host (CPU affinity set,
+    threads = granted CPUs / ranks); every call starts behind a barrier, so the ranks contend for the host at the same moment; the
+    job's time is the slowest rank's best warm call (MAX over ranks).  No collective on the data path; pixels stay in each rank's HBM."""
+    distinct, who = e2e_files(synth, w, h, encoder)
+    mine = D.shard(total, rank, world)
+    files = [distinct[i % len(distinct)] for i in mine]
+    p = J.Pipeline(device=local_rank, threads=threads)
+    try:
+        best = None
+        for r in range(4):  # the first call allocates arenas and staging: not counted
+            torch.cuda.synchronize(dev)
+            if dist:
+                dist.barrier()
+            res = p.decode(files, download=False, device_entropy=True)
+            bad = [x for x in res if isinstance(x, Exception)]
+            if bad:
+                raise bad[0]
+            t = p.timings()
+            if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
+                best = t
+        ok = 1.0
+        if files:
+            want = {k: hashlib.sha256(O.decode(distinct[k]).pixels.tobytes()).hexdigest() for k in {mine[0] % len(distinct), mine[len(mine) - 1] % len(distinct)}}
+            for j in (0, len(files) - 1):
+                ok = min(ok, 1.0 if hashlib.sha256(p.download(j).tobytes()).hexdigest() == want[mine[j] % len(distinct)] else 0.0)
+        mine_ms = best["total_ms"] if best else 0.0
+        slowest, = D.max_over_ranks([mine_ms], device=dev)
+        all_ok = D.min_over_ranks(ok, device=dev)
+        kernel_path = p.kernel_path
+    finally:
+        p.close()
+    return {"images": total, "images_per_rank": len(files), "ranks": world, "total_ms": round(slowest, 3),
+            "images_per_s": round(total / slowest * 1e3, 1) if slowest else None,
+            "value": round(total * w * h / 1e6 / slowest * 1e3, 1) if slowest else None, "unit": "MP/s",
+            "rank0_ms": round(mine_ms, 3), "threads_per_rank": threads, "cpus_per_rank": len(share), "cpu_affinity_set": bool(pinned),
+            "host_cpus_granted": effective_cpus_unpinned(), "kernel_path": kernel_path, "verified_vs_oracle": bool(all_ok >= 1.0),
+            "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}",
+            "what": "jpgpu_pipeline_decode per rank on its shard of the file list (entropy decoding on the device), every call behind a barrier; "
+                    "MAX over ranks of the best of 3 warm calls; pixels stay in each rank's HBM"}
+
+
+_UNPINNED_CPUS = None
+
+
+def effective_cpus_unpinned():
+    """effective_cpus() as it was before this process narrowed its own affinity mask (rank_cpu_share / pin_to)."""
+    return _UNPINNED_CPUS if _UNPINNED_CPUS is not None else effective_cpus()
 
 
 class Shard:
@@ -551,11 +719,24 @@ class PixelGather:
 # ---------------------------------------------------------------------------------------------------------------
 def dry_run(args, rank, world, workload, images_total, n_img, n_sub):
     """No GPU: the N>1 bookkeeping on CPU tensors over gloo — shard sizes, per-sub-batch gather to rank 0, max over
-    ranks, and the JSON contract.  Measures nothing (value is null)."""
+    ranks, the per-rank host budget of the e2e leg (CPU share, thread count, its shard of the file list) and the JSON contract.
+    Measures nothing (value is null)."""
     import torch
     import jpeg_decoder_amd.distributed as D
 
     dist = D.init(backend="gloo") if world > 1 else None
+    # the e2e leg's host budget, exactly as the GPU run sets it up (rank_cpu_share + pin_to), checked across ranks below
+    global _UNPINNED_CPUS
+    _UNPINNED_CPUS = effective_cpus()
+    share, threads = rank_cpu_share(rank, world)
+    pinned = pin_to(share)
+    e2e_mine = D.shard(E2E_SHARDED_TOTAL, rank, world)
+    budget = torch.tensor([float(threads), float(len(share)), float(min(share)), float(max(share)), float(len(e2e_mine)), 1.0 if pinned else 0.0], dtype=torch.float64)
+    budgets = [torch.zeros_like(budget) for _ in range(world)]
+    if dist:
+        dist.all_gather(budgets, budget)
+    else:
+        budgets = [budget]
     mine = D.shard(images_total, rank, world) if images_total else range(rank * n_img, (rank + 1) * n_img)
     n_sub = max(1, min(n_sub, len(mine)))
     bounds = [(len(mine) * s // n_sub, len(mine) * (s + 1) // n_sub) for s in range(n_sub)]
@@ -585,11 +766,17 @@ def dry_run(args, rank, world, workload, images_total, n_img, n_sub):
         ok = ok and t == [float(world - 1)]
     if rank == 0:
         w, h = WORKLOADS[workload][0], WORKLOADS[workload][1]
+        rows = [[float(x) for x in b] for b in budgets]
+        disjoint = all(rows[i][3] < rows[i + 1][2] for i in range(len(rows) - 1)) or len(sorted(os.sched_getaffinity(0))) < world
         print(json.dumps({"metric": "megapixels/s decoded (batch, whole node)", "value": None, "unit": "MP/s", "n_gpus": world,
                           "dry_run": True, "scaling": "strong" if images_total else "weak",
                           "config": {"workload": f"{w}x{h}", "name": workload, "images_total": images_total or world * n_img,
                                      "images_per_gpu": len(mine), "sub_batches": n_sub},
-                          "gather_checked": ok, "value_with_gather": None, "gather_ms": None}), flush=True)
+                          "gather_checked": ok, "value_with_gather": None, "gather_ms": None,
+                          "e2e": {"sharded": {"images": E2E_SHARDED_TOTAL, "ranks": world, "images_per_rank": [int(r[4]) for r in rows],
+                                              "threads_per_rank": [int(r[0]) for r in rows], "cpus_per_rank": [int(r[1]) for r in rows],
+                                              "cpu_shares_disjoint": bool(disjoint), "cpu_affinity_set": [bool(r[5]) for r in rows],
+                                              "host_cpus_granted": _UNPINNED_CPUS, "total_ms": None}}}), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -887,17 +1074,36 @@ def main(argv=None):
         except Exception as e:  # noqa: BLE001
             line["k_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
+    if dist and not args.no_e2e and not args.generic:
+        # ---- N > 1 (and --force-dist): E per rank on its shard of the file list, with a per-rank host budget ----
+        if shard is not None:
+            shard.close()
+            shard = None
+        torch.cuda.empty_cache()
+        e2e_error, sharded = None, None
+        try:
+            global _UNPINNED_CPUS
+            _UNPINNED_CPUS = effective_cpus()
+            share, threads = rank_cpu_share(rank, world)
+            pinned = pin_to(share)
+            import oracle as O_all  # (every rank checks two of its own images: the oracle as checker)
+            w1, h1 = WORKLOADS["1080p-420"][0], WORKLOADS["1080p-420"][1]
+            sharded = e2e_sharded(J, O_all, synth, D, dist, torch, dev, rank, local_rank, world, w1, h1, args.e2e_total, args.e2e_encoder, share, threads, pinned)
+        except Exception as e:  # noqa: BLE001 (never lose the line to this leg; the other ranks' collectives are bounded by their own try)
+            e2e_error = f"{type(e).__name__}: {e}"[:300]
+        if rank == 0:
+            line.setdefault("e2e", {})["sharded"] = sharded if sharded else {"error": e2e_error}
     if rank == 0 and default_run and not args.no_e2e:
         if shard is not None:
             shard.close()
             shard = None
         try:
-            e2e, files = e2e_block(J, O, synth, w, h, [int(x) for x in args.e2e_images.split(",") if x], args.e2e_encoder)
-            line["e2e"] = e2e
+            e2e, files = e2e_block(J, O, synth, w, h, [int(x) for x in args.e2e_images.split(",") if x], args.e2e_encoder, h2d_rate_gbps(torch, dev))
+            line.setdefault("e2e", {}).update(e2e)
             if not args.no_cpu_baseline:
                 line["cpu_baseline_e2e"] = cpu_baseline_e2e(O, files, w, h, args.cpu_seconds)
         except Exception as e:  # noqa: BLE001
-            line["e2e"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            line.setdefault("e2e", {})["error"] = f"{type(e).__name__}: {e}"[:300]
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and nv == 1:
             line["cpu_baseline"] = cpu_baseline(O, ocomps, qts, coefs, w, h, ct, args.cpu_seconds)

@@ -105,6 +105,11 @@ typedef struct jpgpu_pipeline_timings {
      *   dev_pixel_ms  class finalize + pixel kernels (dequantize, IDCT, upsampling, colour conversion) */
     uint32_t dev_times_valid, _pad;
     double dev_fill_ms, dev_sync_ms, dev_write_ms, dev_pixel_ms;
+    /* pipelines over several devices (jpgpu_pipeline_create_multi): wall clock until every device had decoded its share, then of the
+     * gather to the first device (JPGPU_PIPELINE_GATHER; 0 without) and the bytes it moved.  The other wall-clock fields are then the
+     * MAXIMUM over the devices, the counts and byte totals the SUM; total_ms is always the whole call. */
+    double decode_ms, gather_ms;
+    uint64_t gather_bytes;
 } jpgpu_pipeline_timings;
 
 enum {
@@ -120,10 +125,27 @@ enum {
                                    * after every scan the host sends what the scan changed (jpgpu_batch_add_deltas) instead of
                                    * the finished planes at the end; same pixels (A/B switch, off by default:
                                    * more PCIe bytes than the compact planes and nothing off the critical path) */
+    , JPGPU_PIPELINE_GATHER = 16u /* pipelines over several devices: after the decode copy every device's pixels to the FIRST device of
+                                   * the list (peer-to-peer, one xGMI link per peer; SURVEY 8e, north_star's final gather);
+                                   * jpgpu_pipeline_pixels_device then points into that copy */
+};
+/* flags of jpgpu_pipeline_create_multi */
+enum {
+    JPGPU_PIPELINE_MULTI_PIN_CPUS = 1u /* give every device's host threads their own contiguous share of the CPUs the calling thread
+                                   * may run on (sched_setaffinity) */
 };
 
 /* n_threads 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if there is one. */
 int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out);
+/* The same object over SEVERAL devices (the reference has one Decoder per stream, src/decoder.rs:134-154 — images are
+ * independent, so a batch shards by image and nothing crosses devices while it decodes): `devices` = n_devices HIP ordinals (an
+ * ordinal may appear more than once: that many sub-pipelines share the device).  Image i of a call goes to devices[i mod n_devices];
+ * every per-image accessor below takes the call's own image index.  n_threads = host threads for ALL devices together (0: what ONE
+ * pipeline takes by default), split evenly — the host's cores are the shared resource, not the devices. */
+int jpgpu_pipeline_create_multi(const int *devices, uint32_t n_devices, uint32_t n_threads, uint32_t flags, jpgpu_pipeline **out);
+uint32_t jpgpu_pipeline_device_count(const jpgpu_pipeline *p);                    /* 1 for jpgpu_pipeline_create */
+int jpgpu_pipeline_image_device(const jpgpu_pipeline *p, uint32_t image);          /* HIP ordinal of the device that decoded it; -1 */
+int jpgpu_pipeline_pixels_device_ordinal(const jpgpu_pipeline *p, uint32_t image); /* ... whose memory jpgpu_pipeline_pixels_device points into */
 void jpgpu_pipeline_destroy(jpgpu_pipeline *p);
 const char *jpgpu_pipeline_last_error(const jpgpu_pipeline *p);
 /* Decoder::scale (src/decoder.rs:278-290) for every image of the calls that follow: each image is decoded at the smallest of the

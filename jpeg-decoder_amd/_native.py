@@ -67,10 +67,12 @@ class PipelineTimings(C.Structure):
                [("threads", C.c_uint32), ("images_ok", C.c_uint32), ("jpeg_bytes", C.c_uint64), ("coefficient_bytes", C.c_uint64),
                 ("pixel_bytes", C.c_uint64), ("images_device_entropy", C.c_uint32), ("images_device_rejected", C.c_uint32),
                 ("dev_times_valid", C.c_uint32), ("_pad", C.c_uint32)] + \
-               [(n, C.c_double) for n in ("dev_fill_ms", "dev_sync_ms", "dev_write_ms", "dev_pixel_ms")]
+               [(n, C.c_double) for n in ("dev_fill_ms", "dev_sync_ms", "dev_write_ms", "dev_pixel_ms", "decode_ms", "gather_ms")] + \
+               [("gather_bytes", C.c_uint64)]
 
 
-PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_PROGRESSIVE_DELTAS = 1, 2, 4, 8
+PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_PROGRESSIVE_DELTAS, PIPELINE_GATHER = 1, 2, 4, 8, 16
+PIPELINE_MULTI_PIN_CPUS = 1
 
 
 class ImageInfoStruct(C.Structure):
@@ -155,6 +157,10 @@ _PROTOS = {
     "jpgpu_decoder_icc_profile": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "jpgpu_decoder_decode_coefficients": (C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "jpgpu_pipeline_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "jpgpu_pipeline_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "jpgpu_pipeline_device_count": (C.c_uint32, [C.c_void_p]),
+    "jpgpu_pipeline_image_device": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "jpgpu_pipeline_pixels_device_ordinal": (C.c_int, [C.c_void_p, C.c_uint32]),
     "jpgpu_pipeline_destroy": (None, [C.c_void_p]),
     "jpgpu_pipeline_last_error": (C.c_char_p, [C.c_void_p]),
     "jpgpu_trim_caches": (None, []),

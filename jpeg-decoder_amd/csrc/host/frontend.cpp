@@ -8,7 +8,6 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
-#include <shared_mutex>
 
 namespace jpgpu {
 namespace host {
@@ -204,63 +203,43 @@ struct HuffTable {
 inline bool same_definition(const HuffTable &t, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
     return t.present && t.is_ac == ac && t.nvalues == n && memcmp(t.bits, bits, 16) == 0 && memcmp(t.values, vals, (size_t)n) == 0;
 }
-// The cache is ONE per process (round 4; rounds 2-3 kept eight 5.5 kB slots per calling thread: the C API is driven by a thousand
-// decoding threads in tests/test_gpu_concurrency.py, and whatever a thread-local holds stays until its thread ends — ADVICE r3):
-// readers copy out under a shared lock (a microsecond, 4 times per file), a new definition takes the exclusive one.
+// Where the tables live (round 4; rounds 2-3 kept eight 5.5 kB copies per calling thread — the C API is driven by a thousand
+// decoding threads in tests/test_gpu_concurrency.py, and whatever a thread-local holds stays until its thread ends):
+// ONE immutable copy per definition in a process-wide registry (a mutex, taken only when a thread meets a definition for the
+// first time), and per thread eight POINTERS to the tables it used last — the hit path takes no lock (a first version with a
+// reader-writer lock around the registry made the header phase of 4,096 files 18 ms instead of 1.8: 32 threads x 16 k lock
+// operations on one cache line).
 inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
-    constexpr int kSlots = 8;
-    static std::shared_mutex m;
-    static HuffTable cache[kSlots];
-    static int next = 0;
-    if (n > 0 && n <= 256) {
-        std::shared_lock<std::shared_mutex> g(m);
+    constexpr int kSlots = 8, kShared = 32;
+    thread_local std::shared_ptr<const HuffTable> mine[kSlots];
+    thread_local int next = 0;
+    if (n > 0 && n <= 256)
         for (int i = 0; i < kSlots; i++)
-            if (same_definition(cache[i], bits, vals, n, ac)) {
-                dst = cache[i];
+            if (mine[i] && same_definition(*mine[i], bits, vals, n, ac)) {
+                dst = *mine[i];
                 return;
             }
+    static std::mutex m;
+    static std::shared_ptr<const HuffTable> shared[kShared];
+    static int shared_next = 0;
+    std::shared_ptr<const HuffTable> found;
+    if (n > 0 && n <= 256) {
+        std::lock_guard<std::mutex> g(m);
+        for (int i = 0; i < kShared && !found; i++)
+            if (shared[i] && same_definition(*shared[i], bits, vals, n, ac)) found = shared[i];
     }
-    dst.build(bits, vals, n, ac);
-    std::unique_lock<std::shared_mutex> g(m);
-    cache[next] = dst;
+    if (!found) {
+        auto fresh = std::make_shared<HuffTable>();
+        fresh->build(bits, vals, n, ac);  // (throws on a malformed definition: nothing is cached)
+        found = fresh;
+        std::lock_guard<std::mutex> g(m);
+        shared[shared_next] = found;
+        shared_next = (shared_next + 1) % kShared;
+    }
+    dst = *found;
+    mine[next] = std::move(found);
     next = (next + 1) % kSlots;
 }
-
-// Scratch objects that would otherwise be thread-locals (44 kB of Huffman tables per thread that ever parsed a DHT segment) or
-// per-call heap blocks (every pool thread inside the allocator at once): a process-wide free list bounded at `kKeep` objects —
-// a thread borrows one for the duration of a call; more concurrent callers than that allocate, and free, their own.
-template <class T, int kKeep = 64>
-class ScratchPool {
-public:
-    struct Lease {
-        ScratchPool *pool;
-        std::unique_ptr<T> obj;
-        T *operator->() { return obj.get(); }
-        ~Lease() { pool->give(std::move(obj)); }
-    };
-    Lease take() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            if (!free_.empty()) {
-                std::unique_ptr<T> o = std::move(free_.back());
-                free_.pop_back();
-                return Lease{this, std::move(o)};
-            }
-        }
-        return Lease{this, std::unique_ptr<T>(new T)};
-    }
-
-private:
-    void give(std::unique_ptr<T> o) {
-        std::lock_guard<std::mutex> g(m_);
-        if ((int)free_.size() < kKeep) free_.push_back(std::move(o));
-    }
-    std::mutex m_;
-    std::vector<std::unique_ptr<T>> free_;
-};
-struct DhtScratch {
-    HuffTable dc[4], ac[4];
-};
 
 // Annex K default tables for MJPEG (src/huffman.rs:295-346)
 const uint8_t kK3Bits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
@@ -713,11 +692,9 @@ struct Frontend::Impl {
 
     void parse_dht() {  // src/parser.rs:536-589, merge of src/decoder.rs:501-518
         size_t length = read_length();
-        // (borrowed, not allocated per call: two heap blocks per DHT segment, allocated and freed by every pool thread at once, had
-        // the threads queue up inside the allocator — and not thread-local either: ScratchPool)
-        static ScratchPool<DhtScratch> scratch_pool;
-        auto scratch = scratch_pool.take();
-        HuffTable *ndc = scratch->dc, *nac = scratch->ac;
+        // (on the stack, 44 kB: two heap blocks per DHT segment, allocated and freed by every pool thread at once, had the threads
+        // queue up inside the allocator; rounds 2-3 kept them per thread for good)
+        HuffTable ndc[4], nac[4];
         for (int i = 0; i < 4; i++) ndc[i].present = nac[i].present = false;
         while (length > 17) {
             const uint8_t tc = src.u8(), cls = tc >> 4;
@@ -977,9 +954,8 @@ struct Frontend::Impl {
         {
             // The device form of the eight tables: the sets built last are kept with the definitions they came from (code counts,
             // values, class: everything else in a table is a function of them) and handed out again as they are.
-            // (four per PROCESS since round 4, looked up under a mutex, built outside it — a batch's files come from a few encoders
-            // and share their sets; the key holds the definitions only, 280 bytes per table.  Rounds 2-3: one per thread, each
-            // with eight whole host tables as its key.)
+            // (shared by the PROCESS since round 4 — a batch's files come from a few encoders and share their sets; the key holds the
+            // definitions only, 280 bytes per table.  Rounds 2-3: one set per thread, each with eight whole host tables as its key.)
             struct Key {
                 bool present = false, is_ac = false;
                 int nvalues = 0;
@@ -994,21 +970,31 @@ struct Frontend::Impl {
                 Key key[8];
                 std::shared_ptr<const PlannedScan::TableSet> set;
             };
-            constexpr int kSets = 4;
+            // (per thread: a POINTER to the set it used last — compared without a lock; the sets themselves are shared, immutable,
+            // and registered under a mutex that only a thread's first file of an encoder takes)
+            constexpr int kSets = 8;
             static std::mutex last_m;
-            static Last last_sets[kSets];
+            static std::shared_ptr<const Last> last_sets[kSets];
             static int last_next = 0;
+            thread_local std::shared_ptr<const Last> mine;
+            auto matches = [&](const Last &l) {
+                bool same = l.set != nullptr;
+                for (int t = 0; t < 8 && same; t++) same = l.key[t].matches(t < 4 ? dc[t] : ac[t - 4]);
+                return same;
+            };
             std::shared_ptr<const PlannedScan::TableSet> found;
-            {
+            if (mine && matches(*mine)) found = mine->set;
+            if (!found) {
                 std::lock_guard<std::mutex> last_lock(last_m);
-                for (int e = 0; e < kSets && !found; e++) {
-                    bool same = last_sets[e].set != nullptr;
-                    for (int t = 0; t < 8 && same; t++) same = last_sets[e].key[t].matches(t < 4 ? dc[t] : ac[t - 4]);
-                    if (same) found = last_sets[e].set;
-                }
+                for (int e = 0; e < kSets && !found; e++)
+                    if (last_sets[e] && matches(*last_sets[e])) {
+                        mine = last_sets[e];
+                        found = mine->set;
+                    }
             }
             if (!found) {
-                Last fresh, *last = &fresh;
+                auto fresh_p = std::make_shared<Last>();
+                Last *last = fresh_p.get();
                 auto set = std::make_shared<PlannedScan::TableSet>();
                 memset(set.get(), 0, sizeof(*set));
                 for (int t = 0; t < 8; t++) {
@@ -1063,8 +1049,9 @@ struct Frontend::Impl {
                 }
                 last->set = std::move(set);
                 found = last->set;
+                mine = fresh_p;
                 std::lock_guard<std::mutex> last_lock(last_m);
-                last_sets[last_next] = std::move(fresh);
+                last_sets[last_next] = std::move(fresh_p);
                 last_next = (last_next + 1) % kSets;
             }
             ps.tables = found;

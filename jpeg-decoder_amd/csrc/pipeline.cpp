@@ -2,6 +2,7 @@
 // Host entropy decoding (csrc/host/frontend.cpp, the restatement of src/decoder.rs:794-1298) on a thread pool,
 // one image per task, rows staged in pinned memory, per-image async H2D, then the batch kernels (batch.cpp).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <array>
 #include <atomic>
@@ -318,7 +319,33 @@ struct jpgpu_pipeline {
     uint32_t n_compute = kComputeStreamsDefault;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob, up to kComputeStreams)
     jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
+    // ---- several devices behind one object (jpgpu_pipeline_create_multi): this pipeline only deals the images of a call to its
+    // children (one ordinary pipeline per listed device, image i -> child i mod n) and maps the per-image accessors back
+    std::vector<jpgpu_pipeline *> children;
+    std::vector<std::vector<int>> child_cpus;  // CPUs of each child's share (empty: no pinning)
+    uint32_t multi_n = 0;                      // images of the last call
+    uint8_t *d_gather = nullptr;               // JPGPU_PIPELINE_GATHER: the children's pixel arenas, copied to devices[0]
+    size_t gather_cap = 0;
+    std::vector<std::vector<size_t>> gather_base;  // [child][sub-batch] -> offset of its arena in d_gather
+    bool gathered = false;
+    hipStream_t gather_stream = nullptr;
 };
+
+static const jpgpu_pipeline *child_of(const jpgpu_pipeline *p, uint32_t &image) {
+    const uint32_t n = (uint32_t)p->children.size();
+    const jpgpu_pipeline *c = p->children[image % n];
+    image /= n;
+    return c;
+}
+static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags);
+static void pin_to(const std::vector<int> &cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus)
+        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof(set), &set);  // (best effort: a refused mask leaves the thread where it was)
+}
 
 // An image the device entropy decoder handed back: the pinned behaviour is the host decoder's — decode it here (uploader
 // thread; rare) and upload it densely, or record the error it raises.
@@ -408,6 +435,16 @@ int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) 
 void jpgpu_pipeline_destroy(jpgpu_pipeline *p) {
     if (!p) return;
     std::string e;
+    if (!p->children.empty()) {
+        if (jpgpu::use_device(p->device, e) == JPGPU_OK) {
+            (void)hipDeviceSynchronize();
+            if (p->d_gather) (void)hipFree(p->d_gather);
+            if (p->gather_stream) (void)hipStreamDestroy(p->gather_stream);
+        }
+        for (jpgpu_pipeline *c : p->children) jpgpu_pipeline_destroy(c);
+        delete p;
+        return;
+    }
     if (jpgpu::use_device(p->device, e) == JPGPU_OK) {
         (void)hipDeviceSynchronize();
         for (SubBatch &sb : p->subs) {
@@ -471,6 +508,7 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
 
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
     jpgpu::TraceRange roctx_range("jpgpu_pipeline_decode");
+    if (p && !p->children.empty()) return (n && (!data || !len)) ? JPGPU_ERR_FORMAT : multi_decode(p, data, len, n, flags);
     if (!p || !p->pool || (n && (!data || !len))) return JPGPU_ERR_FORMAT;
     int rc = jpgpu::use_device(p->device, p->err);
     if (rc) return rc;
@@ -977,6 +1015,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.kernels_ms = 0.0;  // overlapped: see drain_ms
     p->t.download_ms = t4 - t3;
     p->t.total_ms = t4 - t0;
+    p->t.decode_ms = t4 - t0;
     p->t.images_ok = okc;
     p->t.dev_times_valid = dev_ms_valid ? 1u : 0u;
     p->t.dev_fill_ms = dev_ms[0];
@@ -998,27 +1037,60 @@ static const SubBatch *sub_of(const jpgpu_pipeline *p, uint32_t i) {
     return sb.batch ? &sb : nullptr;
 }
 
-int jpgpu_pipeline_image_status(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->status[i] : JPGPU_ERR_FORMAT; }
-const char *jpgpu_pipeline_image_error(const jpgpu_pipeline *p, uint32_t i) { return (p && i < p->n) ? p->errors[i].c_str() : ""; }
+// (a pipeline over several devices: image i of the call is image i / n of child i mod n)
+#define MULTI(P, I, CALL, NONE)                                   \
+    if ((P) && !(P)->children.empty()) {                          \
+        if ((I) >= (P)->multi_n) return NONE;                     \
+        uint32_t ci = (I);                                        \
+        const jpgpu_pipeline *c = child_of((P), ci);              \
+        return CALL;                                              \
+    }
+int jpgpu_pipeline_image_status(const jpgpu_pipeline *p, uint32_t i) {
+    MULTI(p, i, jpgpu_pipeline_image_status(c, ci), JPGPU_ERR_FORMAT)
+    return (p && i < p->n) ? p->status[i] : JPGPU_ERR_FORMAT;
+}
+const char *jpgpu_pipeline_image_error(const jpgpu_pipeline *p, uint32_t i) {
+    MULTI(p, i, jpgpu_pipeline_image_error(c, ci), "")
+    return (p && i < p->n) ? p->errors[i].c_str() : "";
+}
 int jpgpu_pipeline_image_info(const jpgpu_pipeline *p, uint32_t i, jpgpu_image_info *info) {
+    MULTI(p, i, jpgpu_pipeline_image_info(c, ci, info), JPGPU_ERR_FORMAT)
     if (!p || i >= p->n || !info || i >= p->has_frame.size() || !p->has_frame[i]) return JPGPU_ERR_FORMAT;
     *info = p->infos[i];
     return JPGPU_OK;
 }
 size_t jpgpu_pipeline_pixel_bytes(const jpgpu_pipeline *p, uint32_t i) {
+    MULTI(p, i, jpgpu_pipeline_pixel_bytes(c, ci), 0)
     const SubBatch *sb = sub_of(p, i);
     return sb ? jpgpu_batch_out_bytes(sb->batch, (uint32_t)p->slot[i]) : 0;
 }
 const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t i) {
+    if (p && !p->children.empty()) {
+        if (i >= p->multi_n) return nullptr;
+        uint32_t ci = i;
+        const jpgpu_pipeline *c = child_of(p, ci);
+        if (!p->gathered) return jpgpu_pipeline_pixels_device(c, ci);
+        const SubBatch *sb = sub_of(c, ci);  // the copy on the first device
+        if (!sb) return nullptr;
+        return p->d_gather + p->gather_base[i % p->children.size()][(uint32_t)c->sub_of[ci]] + jpgpu_batch_out_offset(sb->batch, (uint32_t)c->slot[ci]);
+    }
     const SubBatch *sb = sub_of(p, i);
     return sb ? (const uint8_t *)jpgpu_batch_out_arena(sb->batch) + jpgpu_batch_out_offset(sb->batch, (uint32_t)p->slot[i]) : nullptr;
 }
 const uint8_t *jpgpu_pipeline_pixels_host(const jpgpu_pipeline *p, uint32_t i) {
+    MULTI(p, i, jpgpu_pipeline_pixels_host(c, ci), nullptr)
     const SubBatch *sb = sub_of(p, i);
     return (sb && sb->h_out && p->downloaded) ? sb->h_out + jpgpu_batch_out_offset(sb->batch, (uint32_t)p->slot[i]) : nullptr;
 }
 int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t i, uint8_t *dst, size_t cap, size_t *len) {
     if (!p) return JPGPU_ERR_FORMAT;
+    if (!p->children.empty()) {  // (from the device that decoded the image: the gathered copy is the same bytes)
+        if (i >= p->multi_n) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "download: image %u has no pixels", i);
+        jpgpu_pipeline *c = p->children[i % p->children.size()];
+        const int rc = jpgpu_pipeline_download(c, i / (uint32_t)p->children.size(), dst, cap, len);
+        if (rc) p->err = c->err;
+        return rc;
+    }
     const SubBatch *sb = sub_of(p, i);
     if (!sb) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "download: image %u has no pixels", i);
     const int rc = jpgpu_batch_download(sb->batch, (uint32_t)p->slot[i], dst, cap, len);
@@ -1028,20 +1100,82 @@ int jpgpu_pipeline_download(jpgpu_pipeline *p, uint32_t i, uint8_t *dst, size_t 
 const char *jpgpu_pipeline_kernel_path(const jpgpu_pipeline *p) { return p ? p->path.c_str() : ""; }
 int jpgpu_pipeline_set_max_decoding_buffer_size(jpgpu_pipeline *p, size_t max_bytes) {
     if (!p) return JPGPU_ERR_FORMAT;
+    for (jpgpu_pipeline *c : p->children) jpgpu_pipeline_set_max_decoding_buffer_size(c, max_bytes);
     p->max_bytes = max_bytes;
     return JPGPU_OK;
 }
 int jpgpu_pipeline_set_color_transform(jpgpu_pipeline *p, int color_transform) {
     if (!p) return JPGPU_ERR_FORMAT;
+    for (jpgpu_pipeline *c : p->children) jpgpu_pipeline_set_color_transform(c, color_transform);
     p->color_transform = color_transform;
     return JPGPU_OK;
 }
 int jpgpu_pipeline_set_scale(jpgpu_pipeline *p, uint16_t requested_width, uint16_t requested_height) {
     if (!p) return JPGPU_ERR_FORMAT;
+    for (jpgpu_pipeline *c : p->children) jpgpu_pipeline_set_scale(c, requested_width, requested_height);
     p->req_w = requested_width;
     p->req_h = requested_height;
     return JPGPU_OK;
 }
+uint32_t jpgpu_pipeline_device_count(const jpgpu_pipeline *p) { return !p ? 0u : (p->children.empty() ? 1u : (uint32_t)p->children.size()); }
+int jpgpu_pipeline_image_device(const jpgpu_pipeline *p, uint32_t i) {
+    if (!p) return -1;
+    if (p->children.empty()) return i < p->n ? p->device : -1;
+    return i < p->multi_n ? p->children[i % p->children.size()]->device : -1;
+}
+int jpgpu_pipeline_pixels_device_ordinal(const jpgpu_pipeline *p, uint32_t i) {
+    if (!p) return -1;
+    if (!p->children.empty() && p->gathered) return i < p->multi_n ? p->device : -1;
+    return jpgpu_pipeline_image_device(p, i);
+}
+// CPUs the calling thread may run on, in order (the shares of a multi-device pipeline are contiguous pieces of this list: on a
+// two-socket host the first devices' feeders then sit on the first socket)
+static std::vector<int> allowed_cpus() {
+    std::vector<int> v;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &set)) v.push_back(c);
+    return v;
+}
+
+int jpgpu_pipeline_create_multi(const int *devices, uint32_t n_devices, uint32_t n_threads, uint32_t flags, jpgpu_pipeline **out) {
+    if (!out) return JPGPU_ERR_FORMAT;
+    jpgpu_pipeline *p = new jpgpu_pipeline();
+    *out = p;  // returned even on failure so that last_error can be read
+    if (!devices || n_devices == 0 || n_devices > 64) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "create_multi: 1..64 devices, got %u", n_devices);
+    p->device = devices[0];
+    // Thread budget: `n_threads` host threads IN ALL (0: what one pipeline would take by default — one per physical core, capped by
+    // a cgroup CPU quota), dealt evenly; every child keeps at least two.  One pipeline keeps ~8 CPUs busy at 45-50 k 1080p images/s:
+    // N children that each started the default would oversubscribe the host N-fold.
+    const uint32_t budget = n_threads ? n_threads : default_threads();
+    const uint32_t per_child = std::max<uint32_t>(2u, budget / n_devices);
+    const std::vector<int> cpus = (flags & JPGPU_PIPELINE_MULTI_PIN_CPUS) ? allowed_cpus() : std::vector<int>();
+    p->child_cpus.assign(n_devices, std::vector<int>());
+    for (uint32_t k = 0; k < n_devices; k++) {
+        if (cpus.size() >= n_devices) {
+            const size_t a = cpus.size() * k / n_devices, b = cpus.size() * (k + 1) / n_devices;
+            p->child_cpus[k].assign(cpus.begin() + (long)a, cpus.begin() + (long)b);
+        }
+        jpgpu_pipeline *c = nullptr;
+        int rc = JPGPU_OK;
+        // (created on a thread of its own that has moved to the child's CPUs first: the pool threads inherit the mask)
+        std::thread maker([&] {
+            pin_to(p->child_cpus[k]);
+            rc = jpgpu_pipeline_create(devices[k], per_child, &c);
+        });
+        maker.join();
+        if (c) p->children.push_back(c);
+        if (rc) {
+            p->err = c ? c->err : "create_multi: out of memory";
+            return rc;
+        }
+    }
+    p->t.threads = per_child * n_devices;
+    return JPGPU_OK;
+}
+
 int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings *t) {
     if (!p || !t) return JPGPU_ERR_FORMAT;
     *t = p->t;
@@ -1049,3 +1183,88 @@ int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings 
 }
 
 }  // extern "C"
+
+// One call over several devices: image i goes to child i mod n (north_star: "a batch of independent images shards one-image-per-GPU");
+// the children decode side by side, each on a thread that sits on the child's CPUs; there is no data-path exchange between
+// devices.  JPGPU_PIPELINE_GATHER: afterwards every child's pixel arenas are copied to the first device (hipMemcpyPeerAsync: one
+// xGMI link per peer, nothing to reduce — SURVEY 8e), where jpgpu_pipeline_pixels_device then points.
+static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
+    const double t0 = now_ms();
+    const uint32_t nc = (uint32_t)p->children.size();
+    const bool gather = (flags & JPGPU_PIPELINE_GATHER) != 0;
+    const uint32_t child_flags = flags & ~(uint32_t)JPGPU_PIPELINE_GATHER;
+    p->multi_n = n;
+    p->gathered = false;
+    std::vector<std::vector<const uint8_t *>> cd(nc);
+    std::vector<std::vector<size_t>> cl(nc);
+    for (uint32_t i = 0; i < n; i++) {
+        cd[i % nc].push_back(data[i]);
+        cl[i % nc].push_back(len[i]);
+    }
+    std::vector<int> rcs(nc, JPGPU_OK);
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < nc; k++)
+        th.emplace_back([&, k] {
+            pin_to(p->child_cpus[k]);  // (the call's uploader thread starts from here and inherits the mask)
+            rcs[k] = jpgpu_pipeline_decode(p->children[k], cd[k].data(), cl[k].data(), (uint32_t)cd[k].size(), child_flags);
+        });
+    for (auto &t : th) t.join();
+    const double t1 = now_ms();
+    p->path.clear();
+    p->t = jpgpu_pipeline_timings{};
+    for (uint32_t k = 0; k < nc; k++) {
+        const jpgpu_pipeline *c = p->children[k];
+        if (rcs[k]) {
+            p->err = c->err;
+            return rcs[k];
+        }
+        if (cd[k].empty()) continue;
+        if (p->path.empty()) p->path = c->path;
+        else if (p->path != c->path) p->path = "mixed";
+        p->t.headers_ms = std::max(p->t.headers_ms, c->t.headers_ms);
+        p->t.setup_ms = std::max(p->t.setup_ms, c->t.setup_ms);
+        p->t.entropy_and_upload_ms = std::max(p->t.entropy_and_upload_ms, c->t.entropy_and_upload_ms);
+        p->t.download_ms = std::max(p->t.download_ms, c->t.download_ms);
+        p->t.threads += c->t.threads;
+        p->t.images_ok += c->t.images_ok;
+        p->t.jpeg_bytes += c->t.jpeg_bytes;
+        p->t.coefficient_bytes += c->t.coefficient_bytes;
+        p->t.pixel_bytes += c->t.pixel_bytes;
+        p->t.images_device_entropy += c->t.images_device_entropy;
+        p->t.images_device_rejected += c->t.images_device_rejected;
+    }
+    p->t.decode_ms = t1 - t0;
+    if (gather) {
+        int rc = jpgpu::use_device(p->device, p->err);
+        if (rc) return rc;
+        size_t total = 0;
+        p->gather_base.assign(nc, std::vector<size_t>());
+        for (uint32_t k = 0; k < nc; k++)
+            for (uint32_t j = 0; j < p->children[k]->n_subs; j++) {
+                const SubBatch &sb = p->children[k]->subs[j];
+                p->gather_base[k].push_back(total);
+                total += sb.batch ? jpgpu::align_up(jpgpu_batch_out_arena_bytes(sb.batch), 256) : 0;
+            }
+        if (total > p->gather_cap) {
+            if (p->d_gather) P_HIP(hipFree(p->d_gather));
+            p->d_gather = nullptr;
+            p->gather_cap = 0;
+            P_HIP(hipMalloc((void **)&p->d_gather, total + total / 8));
+            p->gather_cap = total + total / 8;
+        }
+        if (!p->gather_stream) P_HIP(hipStreamCreateWithFlags(&p->gather_stream, hipStreamNonBlocking));
+        for (uint32_t k = 0; k < nc; k++)
+            for (uint32_t j = 0; j < p->children[k]->n_subs; j++) {
+                const SubBatch &sb = p->children[k]->subs[j];
+                if (!sb.batch) continue;
+                P_HIP(hipMemcpyPeerAsync(p->d_gather + p->gather_base[k][j], p->device, jpgpu_batch_out_arena(sb.batch), p->children[k]->device,
+                                         jpgpu_batch_out_arena_bytes(sb.batch), p->gather_stream));
+                p->t.gather_bytes += jpgpu_batch_out_arena_bytes(sb.batch);
+            }
+        P_HIP(hipStreamSynchronize(p->gather_stream));
+        p->gathered = true;
+    }
+    p->t.gather_ms = now_ms() - t1;
+    p->t.total_ms = now_ms() - t0;
+    return JPGPU_OK;
+}

@@ -15,9 +15,16 @@ from .worker import color_transform_id
 
 
 class Pipeline:
-    def __init__(self, device=0, threads=0):
+    def __init__(self, device=0, threads=0, devices=None, pin_cpus=False):
+        """device: one HIP ordinal; devices=[...]: jpgpu_pipeline_create_multi — image i of a call goes to devices[i mod n] (an ordinal
+        may appear more than once), `threads` is then the host-thread budget of ALL devices together; pin_cpus: every device's
+        threads on their own share of the CPUs this process may use."""
         self._h = C.c_void_p()
-        st = N.lib().jpgpu_pipeline_create(device, threads, C.byref(self._h))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            st = N.lib().jpgpu_pipeline_create_multi(arr, len(devices), threads, N.PIPELINE_MULTI_PIN_CPUS if pin_cpus else 0, C.byref(self._h))
+        else:
+            st = N.lib().jpgpu_pipeline_create(device, threads, C.byref(self._h))
         if st:
             msg = N.lib().jpgpu_pipeline_last_error(self._h) if self._h else b"jpgpu_pipeline_create"
             self.close()
@@ -32,7 +39,8 @@ class Pipeline:
 
     __del__ = close
 
-    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False, scale=None, color_transform=None, max_decoding_buffer_size=None):
+    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False, scale=None, color_transform=None, max_decoding_buffer_size=None,
+               gather=False):
         """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
         ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``); dense=True sends all
         64 coefficients of every block over PCIe instead of the compact form (same pixels, A/B switch); device_entropy=True
@@ -41,7 +49,8 @@ class Pipeline:
         the coefficients of progressive streams on the device, scan by scan (same pixels; A/B switch); scale=(w, h): every image as
         after ``Decoder.scale(w, h)`` (the smallest DCT scale whose output is at least w x h; ``info(i)`` gives the scaled size);
         color_transform: every image as after ``Decoder.set_color_transform(...)`` ("None", "Grayscale", "RGB", "YCbCr", "CMYK", "YCCK");
-        max_decoding_buffer_size: ``Decoder.set_max_decoding_buffer_size`` (images that would need more fail with the reference's error)."""
+        max_decoding_buffer_size: ``Decoder.set_max_decoding_buffer_size`` (images that would need more fail with the reference's error);
+        gather=True (pipelines over several devices): copy every device's pixels to the first device afterwards (JPGPU_PIPELINE_GATHER)."""
         L = N.lib()
         check(L.jpgpu_pipeline_set_max_decoding_buffer_size(self._h, (1 << 64) - 1 if max_decoding_buffer_size is None else int(max_decoding_buffer_size)), b"set_max")
         check(L.jpgpu_pipeline_set_color_transform(self._h, color_transform_id(color_transform) if color_transform is not None else -1), b"set_color_transform")
@@ -51,7 +60,7 @@ class Pipeline:
         ptrs = (C.c_char_p * max(n, 1))(*bufs)  # the bytes objects' own buffers (alive in `bufs` during the call): no copies
         lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
         st = L.jpgpu_pipeline_decode(self._h, C.cast(ptrs, C.POINTER(C.c_void_p)), lens, n, (N.PIPELINE_DOWNLOAD if download else 0) | (N.PIPELINE_DENSE if dense else 0) |
-                                     (N.PIPELINE_DEVICE_ENTROPY if device_entropy else 0) | (N.PIPELINE_PROGRESSIVE_DELTAS if progressive_deltas else 0))
+                                     (N.PIPELINE_DEVICE_ENTROPY if device_entropy else 0) | (N.PIPELINE_PROGRESSIVE_DELTAS if progressive_deltas else 0) | (N.PIPELINE_GATHER if gather else 0))
         check(st, L.jpgpu_pipeline_last_error(self._h) if st else b"")
         out = []
         for i in range(n):
@@ -85,6 +94,14 @@ class Pipeline:
 
     def device_pointer(self, image):
         return N.lib().jpgpu_pipeline_pixels_device(self._h, image)
+
+    def device_of(self, image):
+        """(device that decoded the image, device whose memory device_pointer(image) points into) — the same unless gathered."""
+        return N.lib().jpgpu_pipeline_image_device(self._h, image), N.lib().jpgpu_pipeline_pixels_device_ordinal(self._h, image)
+
+    @property
+    def n_devices(self):
+        return N.lib().jpgpu_pipeline_device_count(self._h)
 
     @property
     def kernel_path(self):

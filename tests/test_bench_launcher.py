@@ -61,6 +61,17 @@ def test_two_ranks_dry_run_shards_config3_and_gathers():
     assert line["gather_checked"] is True
     for key in ("value", "value_with_gather", "gather_ms"):
         assert key in line
+    # the e2e leg's per-rank host budget (VERDICT r3 next #2a/c): the file list sharded, the granted CPUs DIVIDED between the ranks
+    # (never the one-pipeline default in every rank), every rank's feeder threads on a share of its own
+    sys.path.insert(0, ROOT)
+    import bench
+    sh = line["e2e"]["sharded"]
+    assert sh["images"] == 4096 and sh["ranks"] == 2 and sh["images_per_rank"] == [2048, 2048]
+    granted = sh["host_cpus_granted"]
+    assert granted == bench.effective_cpus()
+    assert sh["threads_per_rank"] == [max(2, granted // 2)] * 2
+    assert sum(sh["threads_per_rank"]) <= max(4, granted)
+    assert sh["cpu_shares_disjoint"] is True and sum(sh["cpus_per_rank"]) <= len(os.sched_getaffinity(0))
 
 
 @pytest.mark.timeout(300)
@@ -70,6 +81,7 @@ def test_three_ranks_dry_run_uneven_total_and_weak_mode():
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 3 and line["config"]["images_total"] == 100 and line["config"]["images_per_gpu"] == 34
     assert line["gather_checked"] is True
+    assert line["e2e"]["sharded"]["images_per_rank"] == [1366, 1365, 1365] and len(set(line["e2e"]["sharded"]["threads_per_rank"])) == 1
     r = _run(["--gpus", "2", "--dry-run", "--batch", "16", "--workload", "1080p-420"])
     assert r.returncode == 0, r.stderr[-2000:]
     line = _json_line(r.stdout)

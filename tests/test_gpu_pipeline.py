@@ -518,3 +518,88 @@ def test_pipeline_max_decoding_buffer_size():
                     assert np.array_equal(got, O.decode(f).pixels), (de, limit, sz)
     _check([str(k) for k in range(4)], files, p.decode(files, device_entropy=True))
     p.close()
+
+
+def _device_bytes(ptr, n, device):
+    """n bytes at device address `ptr` (memory of HIP device `device`) through the runtime's own copy — no torch."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipSetDevice.argtypes = [C.c_int]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipSetDevice(device) == 0
+    out = np.empty(n, np.uint8)
+    assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), n, 2) == 0  # hipMemcpyDeviceToHost
+    return out
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]], ids=["two-children", "three-children"])
+def test_pipeline_over_several_devices_one_gpu_listed_more_than_once(devices):
+    """jpgpu_pipeline_create_multi (VERDICT r3 next #2d): image i of a call goes to devices[i mod n], the children decode
+    side by side on their own thread budgets, every per-image accessor takes the call's own index, and JPGPU_PIPELINE_GATHER leaves
+    a copy of every image's pixels on the first device.  One GPU listed two / three times is the N-device code path on this box."""
+    names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
+    files = [open(n, "rb").read() for n in names]
+    p = J.Pipeline(devices=devices, threads=12, pin_cpus=True)
+    assert p.n_devices == len(devices)
+    out = p.decode(files)
+    _check(names, files, out)
+    t = p.timings()
+    assert t["threads"] == len(devices) * max(2, 12 // len(devices))  # the budget is split, not multiplied
+    assert t["images_ok"] == sum(not isinstance(o, Exception) for o in out)
+    assert t["decode_ms"] > 0 and t["gather_bytes"] == 0
+    # pixels left on the devices, then gathered to the first one: same bytes through the device pointers
+    good = [i for i, o in enumerate(out) if not isinstance(o, Exception)][:24]
+    sizes = p.decode(files, download=False, gather=True)
+    t = p.timings()
+    assert t["gather_bytes"] > 0 and t["gather_ms"] >= 0 and t["total_ms"] >= t["decode_ms"]
+    for i in good:
+        assert sizes[i] == out[i].size
+        assert p.device_of(i) == (devices[i % len(devices)], devices[0])
+        assert np.array_equal(_device_bytes(p.device_pointer(i), out[i].size, devices[0]), out[i]), names[i]
+        assert np.array_equal(p.download(i), out[i])
+    # without the gather the pointer is the child's own arena (and the ordinal says so)
+    p.decode(files[:7], download=False)
+    for i in range(7):
+        if not isinstance(out[i], Exception):
+            assert p.device_of(i) == (devices[i % len(devices)], devices[i % len(devices)])
+            assert np.array_equal(_device_bytes(p.device_pointer(i), out[i].size, devices[i % len(devices)]), out[i])
+    # options reach every child: a reduced-size decode of a call that spans all of them
+    rgb = open(os.path.join(R.GOLDEN, "reftest", "rgb.jpg"), "rb").read()
+    got = p.decode([rgb] * 5, scale=(125, 84))
+    want = O.decode(rgb, scale_to=(125, 84)).pixels
+    assert all(np.array_equal(g, want) for g in got) and (p.info(4).width, p.info(4).height) == (125, 84)
+    assert p.decode([]) == []
+    p.close()
+
+
+def test_pipeline_multi_refuses_nonsense():
+    with pytest.raises(J.Error):
+        J.Pipeline(devices=[], threads=4)
+    with pytest.raises(J.Error):
+        J.Pipeline(devices=[0, 99], threads=4)  # no such device: the error of the child that could not be created
+
+
+@pytest.mark.timeout(600)
+def test_pipeline_4096_files_every_image_checked():
+    """The e2e block of bench.py looks at four images of its 4,096-file call; here EVERY image of such a call is hashed on the host
+    (four distinct files repeated: four distinct digests, each 1,024 times) — VERDICT r3 next #8."""
+    pytest.importorskip("PIL")
+    import bench
+    import synth
+    distinct, _who = bench.e2e_files(synth, 1920, 1080, "auto")
+    want = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in distinct]
+    assert len(set(want)) == 4
+    n = 4096
+    files = [distinct[i % 4] for i in range(n)]
+    p = J.Pipeline()
+    sizes = p.decode(files, download=False, device_entropy=True)
+    assert sizes == [1920 * 1080 * 3] * n
+    t = p.timings()
+    assert t["images_device_entropy"] == n and t["images_device_rejected"] == 0
+    counts = [0, 0, 0, 0]
+    for i in range(n):
+        h = hashlib.sha256(_device_bytes(p.device_pointer(i), sizes[i], 0).tobytes()).hexdigest()
+        assert h == want[i % 4], i
+        counts[i % 4] += 1
+    assert counts == [1024] * 4
+    p.close()
