@@ -24,6 +24,7 @@
 #include "host/frontend.hpp"
 #include "huff.hpp"
 #include "fused.hpp"
+#include "fused_scaled.hpp"
 #include "host_common.hpp"
 #include "kernels.hpp"
 #include "range_stats.hpp"
@@ -57,6 +58,18 @@ struct jpgpu_batch {
     bool qt_dirty = false;
     std::vector<FusedPlan> fused;       // one per fusable kind present in the batch
     std::vector<uint32_t> generic_ids;  // images on the generic path
+    // Reduced-size decodes in one launch (fused_scaled.hpp): images whose components all sit at one dct_scale < 8 — their own job
+    // tables (PlaneJobs carry the coefficient / table pointers, ImageJobs the upsampler kinds and the output), no u8 planes in HBM
+    std::vector<uint32_t> scaled_ids;
+    std::vector<ScaledGeom> scaled_geoms;
+    std::vector<PlaneJob> s_plane_jobs;
+    std::vector<ImageJob> s_image_jobs;
+    ScaledGeom *d_scaled_geoms = nullptr;
+    PlaneJob *d_s_plane_jobs = nullptr;
+    ImageJob *d_s_image_jobs = nullptr;
+    uint32_t s_max_tiles_x = 0, s_max_mcu_h = 0, s_lds_bytes = 0;
+    bool s_scales[9] = {false, false, false, false, false, false, false, false, false};
+    std::string scaled_name;            // path name of the scaled launch group ("fused420-s4", ...; "fusedscaled-mixed")
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // compact transport (compact.hpp): staging area in HBM, allocated at the first jpgpu_batch_upload_compact
     std::mutex compact_mutex;
@@ -197,6 +210,30 @@ static int batch_refresh_jobs(jpgpu_batch *b, hipStream_t stream = nullptr) {
     }
     if (!b->image_jobs.empty())
         B_HIP(hipMemcpy(b->d_image_jobs, b->image_jobs.data(), b->image_jobs.size() * sizeof(ImageJob), hipMemcpyHostToDevice));
+    b->s_plane_jobs.clear();
+    b->s_image_jobs.clear();
+    for (uint32_t i : b->scaled_ids) {  // (planes: none — the kernel keeps them in LDS; the reduced IDCTs are exact at any class)
+        const jpgpu_image_desc &d = b->descs[i];
+        uint8_t *no_planes[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (uint32_t c = 0; c < d.ncomp; c++) {
+            PlaneJob j{};
+            j.coefs = reinterpret_cast<const int16_t *>(b->d_coef + b->coef_off[i * 4 + c]);
+            j.qt = b->d_qt + ((size_t)i * 4 + c) * 64;
+            j.block_w = d.components[c].block_width;
+            j.n_blocks = (uint32_t)d.components[c].block_width * d.components[c].block_height;
+            j.scale = d.components[c].dct_scale;
+            b->s_plane_jobs.push_back(j);
+        }
+        ImageJob ij;
+        size_t out_len = 0;
+        int rc = build_image_job(d.components, d.ncomp, no_planes, d.out_w, d.out_h, d.color_transform, b->d_out + b->out_off[i], ij, out_len, b->err);
+        if (rc) return rc;
+        b->s_image_jobs.push_back(ij);
+    }
+    if (!b->s_plane_jobs.empty()) {
+        B_HIP(hipMemcpy(b->d_s_plane_jobs, b->s_plane_jobs.data(), b->s_plane_jobs.size() * sizeof(PlaneJob), hipMemcpyHostToDevice));
+        B_HIP(hipMemcpy(b->d_s_image_jobs, b->s_image_jobs.data(), b->s_image_jobs.size() * sizeof(ImageJob), hipMemcpyHostToDevice));
+    }
     for (FusedPlan &fp : b->fused) {
         int rc = fused_bind(fp, b->d_coef, b->d_out, b->d_qt, b->coef_off, b->out_off, b->sane, b->err);
         if (rc) return rc;
@@ -250,13 +287,27 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         size_t out_len = 0;
         rc = build_image_job(d.components, d.ncomp, dummy, d.out_w, d.out_h, d.color_transform, nullptr, ij, out_len, b->err);
         if (rc) return rc;
+        // reduced-size decodes (every component at one dct_scale < 8): one launch, planes in LDS (fused_scaled.hpp)
+        ScaledGeom sg;
+        const bool scaled = kind_key[i] == 0 && !(flags & JPGPU_BATCH_FORCE_GENERIC) && scaled_geom_from_job(d.components, d.ncomp, ij, sg);
+        if (scaled) {
+            b->scaled_ids.push_back(i);
+            b->scaled_geoms.push_back(sg);
+            b->s_max_tiles_x = std::max(b->s_max_tiles_x, sg.tiles_x);
+            b->s_max_mcu_h = std::max(b->s_max_mcu_h, sg.mcu_h);
+            b->s_lds_bytes = std::max(b->s_lds_bytes, sg.lds_bytes);
+            b->s_scales[sg.scale] = true;
+            const char *nm = scaled_path_name(sg);
+            if (b->scaled_name.empty()) b->scaled_name = nm;
+            else if (b->scaled_name != nm) b->scaled_name = "fusedscaled-mixed";
+        }
         for (uint32_t c = 0; c < d.ncomp; c++) {
             const jpgpu_component &cc = d.components[c];
             size_t cb = (size_t)cc.block_width * cc.block_height * 64 * sizeof(int16_t);
             b->coef_off[i * 4 + c] = co;
             b->coef_len[i * 4 + c] = cb;
             co += align_up(cb, 256);
-            if (kind_key[i] == 0) {  // generic path: intermediate u8 plane, launch extents
+            if (kind_key[i] == 0 && !scaled) {  // generic path: intermediate u8 plane, launch extents
                 b->plane_off[i * 4 + c] = po;
                 po += align_up(plane_bytes(cc), 256);
                 b->max_blocks = std::max<uint32_t>(b->max_blocks, (uint32_t)cc.block_width * cc.block_height);
@@ -270,7 +321,7 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         // geometry then no longer lie at one stride (1080p 4:2:0: 8 kB x 765 for coefficients, 1 kB x 6075 for pixels) from each other
         static const size_t skew = getenv("JPGPU_ARENA_SKEW") ? (size_t)std::max(0l, atol(getenv("JPGPU_ARENA_SKEW"))) / 256 * 256 : 0;
         if (skew) co += skew * ((7u * i) % 16u), oo += skew * ((7u * i) % 16u);
-        if (kind_key[i] == 0) {
+        if (kind_key[i] == 0 && !scaled) {
             b->generic_ids.push_back(i);
             b->max_w = std::max<uint32_t>(b->max_w, d.ncomp == 1 ? d.components[0].size_width : d.out_w);
             b->max_h = std::max<uint32_t>(b->max_h, d.ncomp == 1 ? d.components[0].size_height : d.out_h);
@@ -301,6 +352,7 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         else if (b->fused.size() == 1 && b->generic_ids.empty()) b->path = b->fused[0].name;
         else b->path = "mixed";
     }
+    if (!b->scaled_ids.empty()) b->path = (b->fused.empty() && b->generic_ids.empty()) ? b->scaled_name : "mixed";
     hipError_t e;
 #define C_HIP(call)                                                                        \
     if ((e = (call)) != hipSuccess) return set_err(b->err, JPGPU_ERR_IO, "%s: %s", #call, hipGetErrorString(e))
@@ -325,6 +377,18 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
     }
     C_HIP(hipMalloc((void **)&b->d_plane_jobs, (size_t)n_images * 4 * sizeof(PlaneJob)));
     C_HIP(hipMalloc((void **)&b->d_image_jobs, (size_t)n_images * sizeof(ImageJob)));
+    if (!b->scaled_ids.empty()) {
+        const size_t ns = b->scaled_ids.size();
+        uint32_t pj = 0;
+        for (size_t k = 0; k < ns; k++) {
+            b->scaled_geoms[k].first_plane_job = pj;
+            pj += b->descs[b->scaled_ids[k]].ncomp;
+        }
+        C_HIP(hipMalloc((void **)&b->d_scaled_geoms, ns * sizeof(ScaledGeom)));
+        C_HIP(hipMemcpy(b->d_scaled_geoms, b->scaled_geoms.data(), ns * sizeof(ScaledGeom), hipMemcpyHostToDevice));
+        C_HIP(hipMalloc((void **)&b->d_s_plane_jobs, ns * 4 * sizeof(PlaneJob)));
+        C_HIP(hipMalloc((void **)&b->d_s_image_jobs, ns * sizeof(ImageJob)));
+    }
     C_HIP(hipEventCreate(&b->ev0));
     C_HIP(hipEventCreate(&b->ev1));
 #undef C_HIP
@@ -362,6 +426,9 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
             if (x.d) hipFree(x.d);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
         if (b->d_image_jobs) hipFree(b->d_image_jobs);
+        if (b->d_scaled_geoms) hipFree(b->d_scaled_geoms);
+        if (b->d_s_plane_jobs) hipFree(b->d_s_plane_jobs);
+        if (b->d_s_image_jobs) hipFree(b->d_s_image_jobs);
         for (FusedPlan &fp : b->fused) fused_free(fp);
         if (b->ev0) hipEventDestroy(b->ev0);
         if (b->ev1) hipEventDestroy(b->ev1);
@@ -1222,6 +1289,9 @@ int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     const uint32_t *st = b->dev_classes ? b->d_stats : nullptr;
     const uint8_t *hc = b->dev_classes ? b->d_host_cls : nullptr;
     for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s, st, hc));
+    if (!b->scaled_ids.empty())
+        B_HIP(launch_scaled_fused(b->d_scaled_geoms, b->d_s_image_jobs, b->d_s_plane_jobs, (uint32_t)b->scaled_ids.size(), b->s_max_tiles_x, b->s_max_mcu_h,
+                                  b->s_lds_bytes, b->s_scales, s));
     if (!b->generic_ids.empty()) {
         const uint32_t n = (uint32_t)b->image_jobs.size();
         if (b->dev_classes) B_HIP(launch_class_finalize_planes(b->d_plane_jobs, b->d_plane_job_slot, (uint32_t)b->plane_jobs.size(), st, hc, s));

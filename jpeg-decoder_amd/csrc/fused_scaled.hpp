@@ -1,0 +1,275 @@
+// fused_scaled.hpp — reduced-size decodes (Decoder::scale, src/decoder.rs:278-290: dct_scale 4 / 2 / 1, src/idct.rs:456-565) in ONE
+// launch: coefficients in, interleaved pixels out, the reduced sample planes never leave LDS.  Rounds 1-3 ran such images on the
+// generic pair of kernels (idct_planes_kernel<4|2|1> -> u8 planes in HBM -> upsample_color_kernel): 2.64 GB moved for 2.00 GB
+// algorithmic at scale 4, 0.36-0.40 of the roofline (profiles/round3/pmc_traffic.json).
+//
+// A ROW kernel in address order (what R4 is for full-size four-component frames, fused_x4.hpp): a workgroup owns `tx` MCUs of one
+// MCU row of one image.
+//   1. transform: one lane per block (up to FS_BLOCKS_PER_LANE rounds) — the tile's own blocks of every component and, for the
+//      components under one of the fancy upsamplers (UpsamplerH2V1 / H1V2 / H2V2, src/upsampler.rs:134-228: they read one sample
+//      beyond a block), the ring of blocks around them: at a reduced size a whole neighbour block is 16 / 4 / 1 samples and a
+//      fraction of a full transform, and its coefficients are what the neighbouring workgroups read at about the same time (L2 /
+//      infinity cache, not HBM).  A lane fetches the `SCALE` 16-byte pieces of its block that the reduced IDCT reads (rows
+//      0 .. SCALE-1), all of its blocks' pieces before the first use, and writes SCALE x SCALE samples into the component's LDS
+//      plane — the reference's plane (stride = blocks x dct_scale, src/worker/immediate.rs:39-60) cut to the tile and its ring;
+//   2. pixels: the reference's row functions on those planes — every upsampler and colour function in the forms of the generic
+//      path's lane body (upsample_color_body.hpp), with ABSOLUTE plane coordinates (near / far rows, first / last column) mapped
+//      into the tile's copy by one offset per component.  Four pixels per unit, units dealt to the lanes in row-major order.
+// Every sampling layout, colour function and component count build_image_job accepts takes this kernel when all components are at
+// one reduced scale; images of different sizes and kinds share a launch (per-image geometry table).
+// No HIP dependency in the planner (tests/emu runs the same phases on the CPU).
+#pragma once
+#include <stdint.h>
+
+#include "jobs.hpp"
+#include "pixel_math.hpp"
+#include "upsample_color_body.hpp"
+
+namespace jpgpu {
+
+constexpr uint32_t FS_NT = 256, FS_BLOCKS_PER_LANE = 4;
+
+struct ScaledGeom {
+    uint32_t scale, ncomp;
+    uint32_t mcu_w, mcu_h;          // MCUs across / down
+    uint32_t tx, tiles_x;           // MCUs per tile (a multiple of 4: tiles then begin at multiples of four pixels at every scale)
+    uint32_t hmax, vmax;
+    uint32_t h[4], v[4];            // blocks of component c per MCU
+    uint32_t halo[4];               // 1: the ring of neighbour blocks is transformed as well (fancy upsamplers)
+    uint32_t block_w[4], block_h[4];
+    uint32_t lds_off[4], pitch[4];  // the component's LDS plane: (v + 2 halo) * scale rows of `pitch` bytes
+    uint32_t lds_bytes;
+    uint32_t first_plane_job;       // index of component 0's PlaneJob in the launch's table (the others follow)
+};
+
+// Which images take the kernel, and their tiling.  `job` = what build_image_job made of the frame (upsampler kinds).
+inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g) {
+    g = ScaledGeom{};
+    if (ncomp == 0 || ncomp > 4) return false;
+    const uint32_t scale = comps[0].dct_scale;
+    if (scale != 4u && scale != 2u && scale != 1u) return false;
+    uint32_t hmax = 0, vmax = 0;
+    for (uint32_t c = 0; c < ncomp; c++) {
+        if (comps[c].dct_scale != scale) return false;
+        hmax = hmax > comps[c].horizontal_sampling_factor ? hmax : comps[c].horizontal_sampling_factor;
+        vmax = vmax > comps[c].vertical_sampling_factor ? vmax : comps[c].vertical_sampling_factor;
+    }
+    if (hmax == 0 || vmax == 0 || hmax > 4 || vmax > 4) return false;
+    g.scale = scale, g.ncomp = ncomp, g.hmax = hmax, g.vmax = vmax;
+    g.mcu_w = comps[0].block_width / comps[0].horizontal_sampling_factor;
+    g.mcu_h = comps[0].block_height / comps[0].vertical_sampling_factor;
+    if (g.mcu_w == 0 || g.mcu_h == 0 || g.mcu_h > 65535u) return false;
+    uint32_t per_mcu = 0, ring = 0;  // blocks per MCU of the tile; blocks of the rings that do not grow with the tile
+    for (uint32_t c = 0; c < ncomp; c++) {
+        g.h[c] = comps[c].horizontal_sampling_factor, g.v[c] = comps[c].vertical_sampling_factor;
+        g.block_w[c] = comps[c].block_width, g.block_h[c] = comps[c].block_height;
+        if (g.block_w[c] != g.mcu_w * g.h[c] || g.block_h[c] != g.mcu_h * g.v[c]) return false;  // (not a grid update_component_sizes makes)
+        const uint32_t k = job.comp[c].kind;
+        g.halo[c] = (job.color_fn != CC_GRAY && (k == UP_H2V1 || k == UP_H1V2 || k == UP_H2V2)) ? 1u : 0u;
+        per_mcu += g.h[c] * (g.v[c] + 2u * g.halo[c]);
+        ring += 2u * g.halo[c] * (g.v[c] + 2u * g.halo[c]);
+    }
+    const uint32_t cap = FS_NT * FS_BLOCKS_PER_LANE;
+    if (ring + 4u * per_mcu > cap) return false;
+    uint32_t tx_max = ((cap - ring) / per_mcu) & ~3u;
+    if (tx_max > 64u) tx_max = 64u;
+    const uint32_t n_tiles = (g.mcu_w + tx_max - 1u) / tx_max;
+    g.tx = (((g.mcu_w + n_tiles - 1u) / n_tiles) + 3u) & ~3u;  // balanced, rounded up to a multiple of 4 (<= tx_max: that is one)
+    g.tiles_x = (g.mcu_w + g.tx - 1u) / g.tx;
+    uint32_t off = 0;
+    for (uint32_t c = 0; c < ncomp; c++) {
+        g.pitch[c] = ((g.tx * g.h[c] + 2u * g.halo[c]) * scale + 3u) & ~3u;
+        g.lds_off[c] = off;
+        off += g.pitch[c] * (g.v[c] + 2u * g.halo[c]) * scale;
+        off = (off + 15u) & ~15u;
+    }
+    g.lds_bytes = off;
+    return true;
+}
+// name of the path for jpgpu_batch_path: "fused420-s4", "fused444-s2", "fusedgray-s1", ... ("fusedscaled-sN" for the other layouts)
+inline const char *scaled_path_name(const ScaledGeom &g) {
+    static const char *names[5][3] = {{"fused420-s4", "fused420-s2", "fused420-s1"}, {"fused444-s4", "fused444-s2", "fused444-s1"},
+                                      {"fusedgray-s4", "fusedgray-s2", "fusedgray-s1"}, {"fused422-s4", "fused422-s2", "fused422-s1"},
+                                      {"fusedscaled-s4", "fusedscaled-s2", "fusedscaled-s1"}};
+    const uint32_t si = g.scale == 4u ? 0u : (g.scale == 2u ? 1u : 2u);
+    auto is = [&](uint32_t c, uint32_t h, uint32_t v) { return g.h[c] == h && g.v[c] == v; };
+    uint32_t kind = 4;
+    if (g.ncomp == 1) kind = 2;
+    else if (g.ncomp == 3 && is(1, 1, 1) && is(2, 1, 1)) kind = is(0, 2, 2) ? 0u : (is(0, 1, 1) ? 1u : (is(0, 2, 1) ? 3u : 4u));
+    return names[kind][si];
+}
+
+template <int SCALE>
+struct FScaled {
+    static constexpr uint32_t R = SCALE == 4 ? 4u : (SCALE == 2 ? 2u : 1u);  // 16-byte pieces of a block the reduced IDCT reads
+
+    static __device__ __forceinline__ uint32_t txe(const ScaledGeom &g, uint32_t tile) { return min(g.tx, g.mcu_w - tile * g.tx); }
+    static __device__ __forceinline__ uint32_t tile_blocks(const ScaledGeom &g, uint32_t te) {
+        uint32_t n = 0;
+        for (uint32_t c = 0; c < g.ncomp; c++) n += (te * g.h[c] + 2u * g.halo[c]) * (g.v[c] + 2u * g.halo[c]);
+        return n;
+    }
+
+    // phase 1: blocks -> samples in the LDS planes
+    static __device__ __forceinline__ void transform(const ScaledGeom &g, const PlaneJob *__restrict__ pj, uint32_t tile, uint32_t my, uint32_t tid,
+                                                     uint8_t *lds) {
+        const uint32_t te = txe(g, tile), x0m = tile * g.tx, total = tile_blocks(g, te);
+        v4u pc[FS_BLOCKS_PER_LANE][R];
+        uint32_t comp[FS_BLOCKS_PER_LANE], at[FS_BLOCKS_PER_LANE];  // component; LDS byte offset of the block's first sample (~0: no block)
+#pragma unroll
+        for (uint32_t i = 0; i < FS_BLOCKS_PER_LANE; i++) {
+            uint32_t b = tid + FS_NT * i, c = 0;
+            at[i] = 0xffffffffu;
+            comp[i] = 0;
+            if (b >= total) continue;
+            uint32_t nbx = te * g.h[0] + 2u * g.halo[0], cnt = nbx * (g.v[0] + 2u * g.halo[0]);
+            while (b >= cnt) {  // (<= 3 steps)
+                b -= cnt;
+                c++;
+                nbx = te * g.h[c] + 2u * g.halo[c];
+                cnt = nbx * (g.v[c] + 2u * g.halo[c]);
+            }
+            const uint32_t by = b / nbx, bx = b - by * nbx;
+            const int32_t gbx = (int32_t)(x0m * g.h[c] + bx) - (int32_t)g.halo[c], gby = (int32_t)(my * g.v[c] + by) - (int32_t)g.halo[c];
+            if (gbx < 0 || gby < 0 || gbx >= (int32_t)g.block_w[c] || gby >= (int32_t)g.block_h[c]) continue;  // outside the plane: never read
+            comp[i] = c;
+            at[i] = g.lds_off[c] + by * (uint32_t)SCALE * g.pitch[c] + bx * (uint32_t)SCALE;
+            const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)(pj[c].coefs + ((size_t)gby * g.block_w[c] + (size_t)gbx) * 64u);
+#pragma unroll
+            for (uint32_t r = 0; r < R; r++) pc[i][r] = stream_load(src + r);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < FS_BLOCKS_PER_LANE; i++) {
+            if (at[i] == 0xffffffffu) continue;
+            const uint32_t c = comp[i];
+            uint32_t cw[32];
+#pragma unroll
+            for (uint32_t k = 0; k < 32; k++) cw[k] = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < R; r++) cw[4 * r] = pc[i][r].x, cw[4 * r + 1] = pc[i][r].y, cw[4 * r + 2] = pc[i][r].z, cw[4 * r + 3] = pc[i][r].w;
+            const qtab_t q = as_qtab(pj[c].qt);
+            uint8_t *dst = lds + at[i];
+            if constexpr (SCALE == 4) {
+                uint32_t out[4];
+                idct4x4_exact(cw, q, out);
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) *reinterpret_cast<uint32_t *>(dst + r * g.pitch[c]) = out[r];
+            } else if constexpr (SCALE == 2) {
+                const uint32_t o = idct2x2_exact(cw, q);
+                *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(o & 0xffffu);
+                *reinterpret_cast<uint16_t *>(dst + g.pitch[c]) = (uint16_t)(o >> 16);
+            } else {
+                dst[0] = (uint8_t)idct1x1_exact(cw[0], q);
+            }
+        }
+    }
+
+    // One component's view of its LDS plane for the pixel phase: `off0` is the plane's LDS offset minus the position of the tile's
+    // first sample (mod 2^32), so that lds[off0 + row * pitch + x] with ABSOLUTE plane coordinates (what the reference's row functions
+    // compute with: near / far rows, first / last column) addresses the tile's copy.
+    struct View {
+        uint32_t off0, pitch, kind, hf, vf, width, height;
+    };
+    static __device__ __forceinline__ View view_of(const ScaledGeom &g, const ImageJob &job, uint32_t c, uint32_t tile, uint32_t my) {
+        const uint32_t col0 = (tile * g.tx * g.h[c] - g.halo[c]) * (uint32_t)SCALE, row0 = (my * g.v[c] - g.halo[c]) * (uint32_t)SCALE;  // (wrapping)
+        const UpComp &u = job.comp[c];
+        return View{g.lds_off[c] - (row0 * g.pitch[c] + col0), g.pitch[c], u.kind, u.hf, u.vf, u.width, u.height};
+    }
+    // UpsamplerXxx::upsample_row for ONE output sample (src/upsampler.rs:119-250 — the same forms as up_sample of
+    // upsample_color_body.hpp, on the LDS plane)
+    static __device__ __forceinline__ uint32_t sample(const uint8_t *lds, const View &u, uint32_t x, uint32_t row) {
+        auto at = [&](uint32_t r, uint32_t col) -> uint32_t { return lds[u.off0 + r * u.pitch + col]; };
+        switch (u.kind) {
+        case UP_H1V1: return at(row, x);  // :119-132
+        case UP_H2V1: {                    // :134-163
+            const uint32_t W = u.width, i = x >> 1;
+            if (x == 0u) return at(row, 0u);
+            if (x == 2u * W - 1u) return at(row, W - 1u);
+            return (3u * at(row, i) + at(row, (x & 1u) ? i + 1u : i - 1u) + 2u) >> 2;
+        }
+        case UP_H1V2: {  // :165-189
+            uint32_t near, far;
+            near_far(row, u.height, near, far);
+            return (3u * at(near, x) + at(far, x) + 2u) >> 2;
+        }
+        case UP_H2V2: {  // :191-228
+            uint32_t near, far;
+            near_far(row, u.height, near, far);
+            const uint32_t W = u.width, j = x >> 1, tj = 3u * at(near, j) + at(far, j);
+            if (x == 0u || x == 2u * W - 1u) return (tj + 2u) >> 2;
+            const uint32_t o = (x & 1u) ? j + 1u : j - 1u;
+            return (3u * tj + 3u * at(near, o) + at(far, o) + 8u) >> 4;
+        }
+        default: return at(row / u.vf, x / u.hf);  // Generic :230-250
+        }
+    }
+
+    // phase 2: the tile's output pixels, four per unit (Upsampler::upsample_and_interleave_row + the colour functions,
+    // src/upsampler.rs:47-63, src/decoder.rs:1391-1484; the 1-component copy of compute_image, :1310-1332)
+    static __device__ __forceinline__ void pixels(const ScaledGeom &g, const ImageJob &job, uint32_t tile, uint32_t my, uint32_t tid, const uint8_t *lds) {
+        const uint32_t te = txe(g, tile), nc = g.ncomp, fn = job.color_fn;
+        const uint32_t x0 = tile * g.tx * g.hmax * (uint32_t)SCALE, y0 = my * g.vmax * (uint32_t)SCALE;
+        const uint32_t width = te * g.hmax * (uint32_t)SCALE, rows = g.vmax * (uint32_t)SCALE;
+        const uint32_t upr = (width + 3u) / 4u, units = upr * rows;
+        const View v0 = view_of(g, job, 0u, tile, my), v1 = view_of(g, job, nc > 1u ? 1u : 0u, tile, my), v2 = view_of(g, job, nc > 2u ? 2u : 0u, tile, my),
+                   v3 = view_of(g, job, nc > 3u ? 3u : 0u, tile, my);
+        const uint32_t out_w = fn == CC_GRAY ? v0.width : job.out_w, out_h = fn == CC_GRAY ? v0.height : job.out_h;
+        JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)job.out;
+        for (uint32_t un = tid; un < units; un += FS_NT) {
+            const uint32_t r = un / upr, x = x0 + 4u * (un - r * upr), row = y0 + r;
+            if (row >= out_h || x >= out_w) continue;
+            const uint32_t n = min(4u, out_w - x);
+            uint32_t s[4][4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t xk = x + min(k, n - 1u);  // (pixels past the image repeat the last one: never stored)
+                s[0][k] = sample(lds, v0, xk, row);
+                s[1][k] = nc > 1u ? sample(lds, v1, xk, row) : 0u;
+                s[2][k] = nc > 2u ? sample(lds, v2, xk, row) : 0u;
+                s[3][k] = nc > 3u ? sample(lds, v3, xk, row) : 0u;
+            }
+            if (fn == CC_GRAY) {
+                JP_GLOBAL uint8_t *o = out + (size_t)row * out_w + x;
+                if (n == 4u && (((size_t)row * out_w) & 3u) == 0u) *reinterpret_cast<JP_GLOBAL uint32_t *>(o) = s[0][0] | (s[0][1] << 8) | (s[0][2] << 16) | (s[0][3] << 24);
+                else
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (k < n) o[k] = (uint8_t)s[0][k];
+                continue;
+            }
+            if (fn == CC_NONE) {  // color_no_convert: planar within the row
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++)
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (c < nc && k < n) out[(size_t)row * out_w * nc + (size_t)c * out_w + x + k] = (uint8_t)s[c][k];
+                continue;
+            }
+            uint32_t px[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (fn == CC_RGB) px[k] = s[0][k] | (s[1][k] << 8) | (s[2][k] << 16);
+                else if (fn == CC_YCBCR) px[k] = ycbcr_to_rgb24(s[0][k], s[1][k], s[2][k]);
+                else if (fn == CC_YCCK) px[k] = ycbcr_to_rgb24(s[0][k], s[1][k], s[2][k]) | ((255u - s[3][k]) << 24);
+                else px[k] = (255u - s[0][k]) | ((255u - s[1][k]) << 8) | ((255u - s[2][k]) << 16) | ((255u - s[3][k]) << 24);
+            }
+            const size_t off = ((size_t)row * out_w + x) * nc;
+            JP_GLOBAL uint8_t *o = out + off;
+            if (nc == 4u) {
+                if (n == 4u) *reinterpret_cast<JP_GLOBAL v4u *>(o) = v4u{px[0], px[1], px[2], px[3]};  // (x % 4 == 0: 16-byte aligned)
+                else
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (k < n) reinterpret_cast<JP_GLOBAL uint32_t *>(o)[k] = px[k];
+            } else if (n == 4u && (off & 3u) == 0u) {
+                *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (k < n) o[3 * k] = (uint8_t)px[k], o[3 * k + 1] = (uint8_t)(px[k] >> 8), o[3 * k + 2] = (uint8_t)(px[k] >> 16);
+            }
+        }
+    }
+};
+
+}  // namespace jpgpu

@@ -15,6 +15,7 @@
 #include "pixel_math.hpp"
 #include "idct_plane_body.hpp"
 #include "upsample_color_body.hpp"
+#include "fused_scaled.hpp"
 #include "range_stats.hpp"
 
 namespace jpgpu {
@@ -54,6 +55,20 @@ __global__ __launch_bounds__(256) void upsample_color_kernel(const ImageJob *__r
 __global__ __launch_bounds__(256) void upsample_color_one_kernel(ImageJob job, uint32_t cpr, uint32_t rows) {
     const uint32_t l = blockIdx.x * 256u + threadIdx.x, row = l / cpr;
     if (row < rows) upsample_color_lane(job, (l - row * cpr) * 8u, row);
+}
+
+// Reduced-size decodes in one launch (fused_scaled.hpp): grid = (tiles across, MCU rows, images) of the largest image; a workgroup
+// beyond its own image's grid leaves at once.
+template <int SCALE>
+__global__ __launch_bounds__(FS_NT) void scaled_fused_kernel(const ScaledGeom *__restrict__ geoms, const ImageJob *__restrict__ jobs,
+                                                             const PlaneJob *__restrict__ planes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const ScaledGeom &g = geoms[blockIdx.z];
+    if (g.scale != (uint32_t)SCALE || blockIdx.x >= g.tiles_x || blockIdx.y >= g.mcu_h) return;  // (uniform)
+    typedef FScaled<SCALE> K;
+    K::transform(g, planes + g.first_plane_job, blockIdx.x, blockIdx.y, threadIdx.x, lds_raw);
+    __syncthreads();
+    K::pixels(g, jobs[blockIdx.z], blockIdx.x, blockIdx.y, threadIdx.x, lds_raw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -188,6 +203,16 @@ hipError_t launch_upsample_color(const ImageJob *d_jobs, uint32_t n_jobs, uint32
     const uint64_t lanes = (uint64_t)cpr * max_h;  // <= 8192 * 65535
     dim3 grid((uint32_t)((lanes + 255u) / 256u), 1, n_jobs), block(256);
     upsample_color_kernel<<<grid, block, 0, stream>>>(d_jobs, cpr, max_h);
+    return hipGetLastError();
+}
+
+hipError_t launch_scaled_fused(const ScaledGeom *d_geoms, const ImageJob *d_jobs, const PlaneJob *d_planes, uint32_t n_images, uint32_t max_tiles_x,
+                               uint32_t max_mcu_h, uint32_t lds_bytes, const bool (&scales)[9], hipStream_t stream) {
+    if (n_images == 0 || max_tiles_x == 0 || max_mcu_h == 0) return hipSuccess;
+    const dim3 grid(max_tiles_x, max_mcu_h, n_images), block(FS_NT);
+    if (scales[4]) scaled_fused_kernel<4><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes);
+    if (scales[2]) scaled_fused_kernel<2><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes);
+    if (scales[1]) scaled_fused_kernel<1><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes);
     return hipGetLastError();
 }
 

@@ -23,5 +23,10 @@ hipError_t launch_class_finalize_planes(PlaneJob *d_jobs, const uint32_t *d_slot
 hipError_t launch_upsample_color(const ImageJob *d_jobs, uint32_t n_jobs, uint32_t max_w, uint32_t max_h,
                                  hipStream_t stream);
 hipError_t launch_upsample_color_one(const ImageJob &job, hipStream_t stream);
+// reduced-size decodes in one launch (fused_scaled.hpp): n_images geometries / jobs, PlaneJobs indexed by ScaledGeom::first_plane_job;
+// scales[s]: some image of the launch decodes at dct_scale s (one launch per scale present)
+struct ScaledGeom;
+hipError_t launch_scaled_fused(const ScaledGeom *d_geoms, const ImageJob *d_jobs, const PlaneJob *d_planes, uint32_t n_images, uint32_t max_tiles_x,
+                               uint32_t max_mcu_h, uint32_t lds_bytes, const bool (&scales)[9], hipStream_t stream);
 
 }  // namespace jpgpu

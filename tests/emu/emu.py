@@ -23,6 +23,8 @@ def lib():
         L.emu_compute_image.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint16, C.c_uint16, C.c_int, C.c_void_p,
                                         C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]
         L.emu_compute_image.restype = C.c_int
+        L.emu_scaled_fused.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.emu_scaled_fused.restype = C.c_int
         L.emu_huff_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.emu_huff_covered.argtypes = [C.c_void_p, C.c_size_t]
         L.emu_huff_set_dri.argtypes = [C.c_uint32]

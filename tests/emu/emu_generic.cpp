@@ -37,3 +37,44 @@ int emu_compute_image(const jpgpu_component* comps, uint32_t ncomp, const uint8_
     return 0;
 }
 }
+
+// ---- reduced-size decodes in one launch (csrc/fused_scaled.hpp): every workgroup of the launch grid, phase by phase ----------
+#include "../../jpeg-decoder_amd/csrc/fused_scaled.hpp"
+extern "C" {
+// Returns -1 if the planner keeps the image on the generic pair of kernels, else the status of build_image_job (0: `out` holds the image).
+int emu_scaled_fused(const jpgpu_image_desc* desc, const int16_t* const* coefs, uint8_t* out, size_t* len, uint32_t* tx_out, uint32_t* tiles_out) {
+    ImageJob job;
+    size_t out_len = 0;
+    std::string err;
+    uint8_t* no_planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = build_image_job(desc->components, desc->ncomp, no_planes, desc->out_w, desc->out_h, desc->color_transform, out, job, out_len, err);
+    if (rc) return rc;
+    ScaledGeom g;
+    if (!scaled_geom_from_job(desc->components, desc->ncomp, job, g)) return -1;
+    if (len) *len = out_len;
+    if (tx_out) *tx_out = g.tx;
+    if (tiles_out) *tiles_out = g.tiles_x;
+    PlaneJob pj[4];
+    memset(pj, 0, sizeof(pj));
+    for (uint32_t c = 0; c < desc->ncomp; c++) {
+        pj[c].coefs = coefs[c];
+        pj[c].qt = desc->quantization_tables[c];
+        pj[c].block_w = desc->components[c].block_width;
+        pj[c].n_blocks = (uint32_t)desc->components[c].block_width * desc->components[c].block_height;
+        pj[c].scale = desc->components[c].dct_scale;
+    }
+    std::vector<uint8_t> lds(g.lds_bytes + 64);
+    for (uint32_t my = 0; my < g.mcu_h; my++)
+        for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
+            memset(lds.data(), 0xCD, lds.size());  // garbage, like real LDS
+#define RUNS(S)                                                                                            \
+    {                                                                                                      \
+        for (uint32_t t = 0; t < FS_NT; t++) FScaled<S>::transform(g, pj, tile, my, t, lds.data());         \
+        for (uint32_t t = 0; t < FS_NT; t++) FScaled<S>::pixels(g, job, tile, my, t, lds.data());           \
+    }
+            if (g.scale == 4) RUNS(4) else if (g.scale == 2) RUNS(2) else RUNS(1)
+#undef RUNS
+        }
+    return 0;
+}
+}

@@ -258,3 +258,66 @@ def test_generic_upsample_color_kernel_logic_matches_oracle(case, scale, force_s
     assert np.array_equal(out[:out_len], want)
     if scale == 8 and not force_slow and ct not in ("None", "Grayscale") and all(max(s[0] for s in samp) // h in (1, 2) and max(s[1] for s in samp) // v in (1, 2) for h, v in samp):
         assert fast.value == 1, "planner did not take the dword path for a geometry it is meant to cover"
+
+
+# ---- reduced-size decodes in one launch (csrc/fused_scaled.hpp): every tile of the launch against the oracle -------------------
+SCALED_CASES = [
+    (64, 48, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (33, 17, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (2, 2, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (3, 5, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (17, 33, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (1930, 40, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1025, 24, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (250, 130, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (9, 300, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (1, 40, [(2, 2), (1, 1), (1, 1)], "YCbCr"), (40, 1, [(2, 2), (1, 1), (1, 1)], "YCbCr"),
+    (500, 333, [(1, 1), (1, 1), (1, 1)], "RGB"), (45, 29, [(1, 1), (1, 1), (1, 1)], "YCbCr"), (1040, 9, [(1, 1), (1, 1), (1, 1)], "YCbCr"),
+    (64, 24, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (333, 21, [(2, 1), (1, 1), (1, 1)], "YCbCr"), (3, 9, [(2, 1), (1, 1), (1, 1)], "YCbCr"),
+    (50, 61, [(1, 2), (1, 1), (1, 1)], "YCbCr"), (520, 33, [(1, 2), (1, 1), (1, 1)], "YCbCr"),
+    (333, 21, [(4, 1), (1, 1), (1, 1)], "YCbCr"), (70, 40, [(4, 2), (1, 1), (1, 1)], "YCbCr"), (50, 61, [(1, 4), (1, 1), (1, 1)], "YCbCr"),
+    (64, 64, [(3, 1), (1, 1), (1, 1)], "YCbCr"), (70, 33, [(2, 2), (2, 1), (1, 1)], "YCbCr"),
+    (45, 29, [(1, 1)] * 4, "CMYK"), (45, 29, [(1, 1)] * 4, "YCCK"), (65, 47, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (65, 47, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
+    (64, 40, [(1, 1)] * 3, "None"), (37, 21, [(1, 1)], "Grayscale"), (2056, 9, [(1, 1)], "Grayscale"), (300, 200, [(2, 2)], "Grayscale"), (1, 1000, [(1, 1)], "Grayscale"),
+]
+
+
+@pytest.mark.parametrize("case", SCALED_CASES, ids=lambda g: f"{g[0]}x{g[1]}-{len(g[2])}c{g[2][0][0]}{g[2][0][1]}-{g[3]}")
+@pytest.mark.parametrize("scale", [4, 2, 1])
+@pytest.mark.parametrize("kind", ["sparse", "full"])
+def test_scaled_fused_kernel_logic_matches_oracle(case, scale, kind):
+    """fused_scaled.hpp on the CPU: tiles with their rings of neighbour blocks, every upsampler on the LDS planes through absolute
+    coordinates, every colour function — against the oracle's reduced-size decode (src/idct.rs:456-565, src/upsampler.rs, Decoder::scale)."""
+    w_, h_, samp, ct = case
+    rng = np.random.default_rng(w_ * 17 + h_ * 3 + scale)
+    ocomps, _ = O.make_components(w_, h_, samp, dct_scale=scale)
+    ow, oh = J.scaled_output_size(w_, h_, scale)
+    if kind == "sparse":
+        qts = [rng.integers(1, 64, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h, amp=64, dc_amp=500) for c in ocomps]
+    else:  # wrap-range data: the reduced IDCTs are exact in Wrapping<i32> whatever the coefficients
+        qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
+    try:
+        want = O.pixels_from_coefficients(ocomps, qts, coefs, ow, oh, ct.upper())
+    except O.OracleError:
+        want = None
+    desc = J.image_desc(list(_to_j(ocomps)), qts, ow, oh, ct)
+    n = len(samp)
+    ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in coefs])
+    cap = ow * oh * max(n, 1) + 64
+    out = np.full(cap, 0x5A, np.uint8)
+    ln, tx, tiles = C.c_size_t(0), C.c_uint32(0), C.c_uint32(0)
+    rc = emu.lib().emu_scaled_fused(C.byref(desc), ptrs, out.ctypes.data, C.byref(ln), C.byref(tx), C.byref(tiles))
+    if want is None:
+        assert rc > 0  # the frame the reference refuses, refused the same way (build_image_job)
+        return
+    assert rc == 0, rc
+    assert ln.value == want.size and (out[ln.value:] == 0x5A).all(), "emulated kernel wrote past the output"
+    bad = np.nonzero(out[:ln.value] != want)[0]
+    assert bad.size == 0, (f"tx={tx.value} tiles={tiles.value}", bad[:10], out[bad[:10]], want[bad[:10]])
+    assert tx.value % 4 == 0 and tiles.value >= 1
+
+
+def test_scaled_fused_planner_leaves_full_size_and_mixed_scales_alone():
+    ocomps, _ = O.make_components(64, 48, [(2, 2), (1, 1), (1, 1)], dct_scale=8)
+    qts = [np.ones(64, np.uint16)] * 3
+    desc = J.image_desc(list(_to_j(ocomps)), qts, 64, 48, "YCbCr")
+    coefs = [np.zeros(c.block_w * c.block_h * 64, np.int16) for c in ocomps]
+    ptrs = (C.c_void_p * 3)(*[c.ctypes.data for c in coefs])
+    out = np.zeros(64 * 48 * 3 + 64, np.uint8)
+    assert emu.lib().emu_scaled_fused(C.byref(desc), ptrs, out.ctypes.data, None, None, None) == -1

@@ -1029,3 +1029,88 @@ def test_batch_1080p_four_components_full_size(samp, mode, ct, path):
     want = O.pixels_from_coefficients(ocomps, qts, base, w_, h_, ct.upper())
     for got in outs:
         assert np.array_equal(got, want)
+
+
+# ---- reduced-size decodes in one launch (csrc/fused_scaled.hpp) -------------------------------------------
+def _scaled_case(rng, w_, h_, samp, ct, scale, kind="sparse"):
+    ocomps, _ = O.make_components(w_, h_, samp, dct_scale=scale)
+    if kind == "sparse":
+        qts = [rng.integers(1, 64, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [synth.sparse_coefficients(rng, c.block_w * c.block_h, amp=64, dc_amp=500) for c in ocomps]
+    else:
+        qts = [rng.integers(1, 65536, 64).astype(np.uint16) for _ in ocomps]
+        coefs = [rng.integers(-32768, 32768, c.block_w * c.block_h * 64).astype(np.int16) for c in ocomps]
+    ow, oh = J.scaled_output_size(w_, h_, scale)
+    return ocomps, qts, coefs, ct, ow, oh
+
+
+SCALED_KINDS = {
+    "420": ([(2, 2), (1, 1), (1, 1)], "YCbCr", "fused420-s%d"), "444": ([(1, 1), (1, 1), (1, 1)], "YCbCr", "fused444-s%d"),
+    "444rgb": ([(1, 1), (1, 1), (1, 1)], "RGB", "fused444-s%d"), "422": ([(2, 1), (1, 1), (1, 1)], "YCbCr", "fused422-s%d"),
+    "440": ([(1, 2), (1, 1), (1, 1)], "YCbCr", "fusedscaled-s%d"), "411": ([(4, 1), (1, 1), (1, 1)], "YCbCr", "fusedscaled-s%d"),
+    "311": ([(3, 1), (1, 1), (1, 1)], "YCbCr", "fusedscaled-s%d"), "gray": ([(1, 1)], "Grayscale", "fusedgray-s%d"),
+    "cmyk": ([(1, 1)] * 4, "CMYK", "fusedscaled-s%d"), "cmyk2211": ([(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK", "fusedscaled-s%d"),
+    "ycck2212": ([(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK", "fusedscaled-s%d"), "none": ([(1, 1)] * 3, "None", "fusedscaled-s%d"),
+}
+SCALED_SIZES = [(64, 48), (33, 17), (1, 1), (3, 5), (250, 130), (1930, 40), (9, 300), (640, 480), (1025, 24)]
+
+
+@pytest.mark.parametrize("key", sorted(SCALED_KINDS))
+@pytest.mark.parametrize("scale", [4, 2, 1])
+@pytest.mark.parametrize("kind", ["sparse", "full"])
+def test_batch_reduced_size_decodes_take_the_fused_scaled_kernel(key, scale, kind):
+    """Images of one layout but different sizes at one reduced scale: ONE launch (coefficients -> pixels, planes in LDS), bit-exact
+    against the oracle's Decoder::scale decode and against the generic pair of kernels (JPGPU_BATCH_FORCE_GENERIC)."""
+    samp, ct, path = SCALED_KINDS[key]
+    rng = np.random.default_rng(len(key) * 313 + scale * 7 + len(kind))
+    cases = [_scaled_case(rng, w_, h_, samp, ct, scale, kind) for (w_, h_) in SCALED_SIZES]
+    outs, got_path = _run_batch(cases)
+    assert got_path == path % scale
+    gen, gen_path = _run_batch(cases, flags=J._native.BATCH_FORCE_GENERIC)
+    assert gen_path == "generic"
+    for (oc, qts, coefs, ct_, ow, oh), got, g2 in zip(cases, outs, gen):
+        want = O.pixels_from_coefficients(oc, qts, coefs, ow, oh, ct_.upper())
+        assert np.array_equal(got, want), (ow, oh)
+        assert np.array_equal(g2, want), (ow, oh)
+
+
+def test_batch_reduced_and_full_size_images_of_many_kinds_in_one_batch():
+    """Scales 8 / 4 / 2 / 1, several layouts, one batch: fused launch groups for the full-size images, ONE fused-scaled launch per
+    reduced scale present, nothing left for the generic pair — path "mixed", every image the oracle's."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    for i, (w_, h_) in enumerate([(250, 130), (64, 48), (1000, 70), (33, 17), (500, 333), (17, 1080)]):
+        for scale in (8, 4, 2, 1):
+            samp, ct, _p = list(SCALED_KINDS.values())[(i + scale) % len(SCALED_KINDS)]
+            cases.append(_scaled_case(rng, w_, h_, samp, ct, scale))
+    outs, path = _run_batch(cases)
+    assert path == "mixed"
+    for (oc, qts, coefs, ct_, ow, oh), got in zip(cases, outs):
+        assert np.array_equal(got, O.pixels_from_coefficients(oc, qts, coefs, ow, oh, ct_.upper())), (ow, oh, ct_)
+
+
+@pytest.mark.parametrize("scale", [4, 2, 1])
+def test_batch_1080p_420_reduced_size_full_batch(scale):
+    """The bench's reduced-size workloads at their own size: 1920x1080 4:2:0 at 4/8, 2/8, 1/8 (bench.py 1080p-420-scaleN)."""
+    w_, h_ = 1920, 1080
+    samp = [(2, 2), (1, 1), (1, 1)]
+    ocomps, _ = O.make_components(w_, h_, samp, dct_scale=scale)
+    lum, chr_ = synth.quality_tables(85)
+    qts = [lum, chr_, chr_]
+    comps_full, _ = O.make_components(w_, h_, samp)
+    coefs = synth.coefficients_from_rgb(synth.synthetic_rgb(w_, h_), to_j(comps_full), "ycbcr", qts)
+    ow, oh = J.scaled_output_size(w_, h_, scale)
+    want = O.pixels_from_coefficients(ocomps, qts, coefs, ow, oh, "YCBCR")
+    desc = J.image_desc(list(to_j(ocomps)), qts, ow, oh, "YCbCr")
+    b = J.Batch([desc] * 6)
+    try:
+        for i in range(6):
+            for c in range(3):
+                b.upload(i, c, coefs[c])
+        b.decode()
+        b.synchronize()
+        assert b.path == "fused420-s%d" % scale
+        for i in range(6):
+            assert np.array_equal(b.download(i), want), i
+    finally:
+        b.close()
