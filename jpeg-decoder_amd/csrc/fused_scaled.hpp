@@ -32,12 +32,14 @@ constexpr uint32_t FS_NT = 256, FS_BLOCKS_PER_LANE = 4;
 struct ScaledGeom {
     uint32_t scale, ncomp;
     uint32_t mcu_w, mcu_h;          // MCUs across / down
-    uint32_t tx, tiles_x;           // MCUs per tile (a multiple of 4: tiles then begin at multiples of four pixels at every scale)
+    uint32_t tx, tiles_x;           // MCUs per tile (a multiple of 8: tiles then begin at multiples of eight pixels at every scale)
     uint32_t hmax, vmax;
     uint32_t h[4], v[4];            // blocks of component c per MCU
     uint32_t halo[4];               // 1: the ring of neighbour blocks is transformed as well (fancy upsamplers)
     uint32_t block_w[4], block_h[4];
-    uint32_t lds_off[4], pitch[4];  // the component's LDS plane: (v + 2 halo) * scale rows of `pitch` bytes
+    uint32_t lds_off[4], pitch[4];  // the component's LDS plane: (v + 2 halo) * scale rows of `pitch` = tx * h * scale + 8 bytes — four bytes
+                                    // of margin either side of the tile's own samples (the ring's columns are the inner ones of them):
+                                    // sample columns that are multiples of 4 in the plane are so in LDS (aligned dword reads)
     uint32_t lds_bytes;
     uint32_t first_plane_job;       // index of component 0's PlaneJob in the launch's table (the others follow)
 };
@@ -70,15 +72,15 @@ inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, c
         ring += 2u * g.halo[c] * (g.v[c] + 2u * g.halo[c]);
     }
     const uint32_t cap = FS_NT * FS_BLOCKS_PER_LANE;
-    if (ring + 4u * per_mcu > cap) return false;
-    uint32_t tx_max = ((cap - ring) / per_mcu) & ~3u;
+    if (ring + 8u * per_mcu > cap) return false;
+    uint32_t tx_max = ((cap - ring) / per_mcu) & ~7u;
     if (tx_max > 64u) tx_max = 64u;
     const uint32_t n_tiles = (g.mcu_w + tx_max - 1u) / tx_max;
-    g.tx = (((g.mcu_w + n_tiles - 1u) / n_tiles) + 3u) & ~3u;  // balanced, rounded up to a multiple of 4 (<= tx_max: that is one)
+    g.tx = (((g.mcu_w + n_tiles - 1u) / n_tiles) + 7u) & ~7u;  // balanced, rounded up to a multiple of 8 (<= tx_max: that is one)
     g.tiles_x = (g.mcu_w + g.tx - 1u) / g.tx;
     uint32_t off = 0;
     for (uint32_t c = 0; c < ncomp; c++) {
-        g.pitch[c] = ((g.tx * g.h[c] + 2u * g.halo[c]) * scale + 3u) & ~3u;
+        g.pitch[c] = g.tx * g.h[c] * scale + 8u;
         g.lds_off[c] = off;
         off += g.pitch[c] * (g.v[c] + 2u * g.halo[c]) * scale;
         off = (off + 15u) & ~15u;
@@ -133,10 +135,14 @@ struct FScaled {
             const int32_t gbx = (int32_t)(x0m * g.h[c] + bx) - (int32_t)g.halo[c], gby = (int32_t)(my * g.v[c] + by) - (int32_t)g.halo[c];
             if (gbx < 0 || gby < 0 || gbx >= (int32_t)g.block_w[c] || gby >= (int32_t)g.block_h[c]) continue;  // outside the plane: never read
             comp[i] = c;
-            at[i] = g.lds_off[c] + by * (uint32_t)SCALE * g.pitch[c] + bx * (uint32_t)SCALE;
+            // (block column bx of the tile's row: its own blocks start at LDS column 4, the left ring block ends there)
+            at[i] = g.lds_off[c] + by * (uint32_t)SCALE * g.pitch[c] + 4u + (bx - g.halo[c]) * (uint32_t)SCALE;
             const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)(pj[c].coefs + ((size_t)gby * g.block_w[c] + (size_t)gbx) * 64u);
+            // (components with a ring are read again by the workgroups of the neighbouring tiles and rows, at about the same
+            // time: plain loads, so that those find them in the L2 / infinity cache; the others are touched once — first version:
+            // streaming loads everywhere, 3.37 GB of HBM traffic for 2.00 algorithmic)
 #pragma unroll
-            for (uint32_t r = 0; r < R; r++) pc[i][r] = stream_load(src + r);
+            for (uint32_t r = 0; r < R; r++) pc[i][r] = g.halo[c] ? src[r] : stream_load(src + r);
         }
 #pragma unroll
         for (uint32_t i = 0; i < FS_BLOCKS_PER_LANE; i++) {
@@ -166,107 +172,130 @@ struct FScaled {
 
     // One component's view of its LDS plane for the pixel phase: `off0` is the plane's LDS offset minus the position of the tile's
     // first sample (mod 2^32), so that lds[off0 + row * pitch + x] with ABSOLUTE plane coordinates (what the reference's row functions
-    // compute with: near / far rows, first / last column) addresses the tile's copy.
+    // compute with: near / far rows, first / last column) addresses the tile's copy; off0 and pitch are multiples of 4.
     struct View {
         uint32_t off0, pitch, kind, hf, vf, width, height;
     };
     static __device__ __forceinline__ View view_of(const ScaledGeom &g, const ImageJob &job, uint32_t c, uint32_t tile, uint32_t my) {
-        const uint32_t col0 = (tile * g.tx * g.h[c] - g.halo[c]) * (uint32_t)SCALE, row0 = (my * g.v[c] - g.halo[c]) * (uint32_t)SCALE;  // (wrapping)
+        const uint32_t col0 = tile * g.tx * g.h[c] * (uint32_t)SCALE - 4u, row0 = (my * g.v[c] - g.halo[c]) * (uint32_t)SCALE;  // (wrapping)
         const UpComp &u = job.comp[c];
         return View{g.lds_off[c] - (row0 * g.pitch[c] + col0), g.pitch[c], u.kind, u.hf, u.vf, u.width, u.height};
     }
-    // UpsamplerXxx::upsample_row for ONE output sample (src/upsampler.rs:119-250 — the same forms as up_sample of
-    // upsample_color_body.hpp, on the LDS plane)
-    static __device__ __forceinline__ uint32_t sample(const uint8_t *lds, const View &u, uint32_t x, uint32_t row) {
-        auto at = [&](uint32_t r, uint32_t col) -> uint32_t { return lds[u.off0 + r * u.pitch + col]; };
-        switch (u.kind) {
-        case UP_H1V1: return at(row, x);  // :119-132
-        case UP_H2V1: {                    // :134-163
-            const uint32_t W = u.width, i = x >> 1;
-            if (x == 0u) return at(row, 0u);
-            if (x == 2u * W - 1u) return at(row, W - 1u);
-            return (3u * at(row, i) + at(row, (x & 1u) ? i + 1u : i - 1u) + 2u) >> 2;
-        }
-        case UP_H1V2: {  // :165-189
-            uint32_t near, far;
+    static __device__ __forceinline__ uint32_t dword_at(const uint8_t *lds, uint32_t off) { return *reinterpret_cast<const uint32_t *>(lds + off); }
+    // samples s[-1 .. 4] around column j0 (a multiple of 4) of the row at `base`: s[0] = column j0 - 1
+    static __device__ __forceinline__ void fetch6(const uint8_t *lds, uint32_t base, uint32_t j0, uint32_t (&s)[6]) {
+        const uint32_t a = dword_at(lds, base + j0 - 4u), b = dword_at(lds, base + j0), c = dword_at(lds, base + j0 + 4u);
+        s[0] = a >> 24, s[1] = b & 0xffu, s[2] = (b >> 8) & 0xffu, s[3] = (b >> 16) & 0xffu, s[4] = b >> 24, s[5] = c & 0xffu;
+    }
+    static __device__ __forceinline__ void fetch8(const uint8_t *lds, uint32_t base, uint32_t x0, uint32_t (&s)[8]) {
+        const uint32_t a = dword_at(lds, base + x0), b = dword_at(lds, base + x0 + 4u);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) s[k] = ((k < 4 ? a : b) >> (8u * (k & 3u))) & 0xffu;
+    }
+    // UpsamplerXxx::upsample_row (src/upsampler.rs:119-250) for the eight output samples x0 .. x0 + 7 (x0 a multiple of 8) of
+    // output row `row` — up_sample8 of upsample_color_body.hpp on the LDS plane.  Samples past the image are computed from
+    // whatever the margins hold and never stored.
+    static __device__ __forceinline__ void sample8(const uint8_t *lds, const View &u, uint32_t x0, uint32_t row, uint32_t (&out)[8]) {
+        const uint32_t W = u.width;
+        if (u.kind == UP_H1V1) {  // :119-132
+            fetch8(lds, u.off0 + row * u.pitch, x0, out);
+        } else if (u.kind == UP_H1V2) {  // :165-189
+            uint32_t near, far, n[8], f[8];
             near_far(row, u.height, near, far);
-            return (3u * at(near, x) + at(far, x) + 2u) >> 2;
-        }
-        case UP_H2V2: {  // :191-228
-            uint32_t near, far;
+            fetch8(lds, u.off0 + near * u.pitch, x0, n);
+            fetch8(lds, u.off0 + far * u.pitch, x0, f);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) out[k] = (3u * n[k] + f[k] + 2u) >> 2;
+        } else if (u.kind == UP_H2V1) {  // :134-163
+            uint32_t s[6];
+            fetch6(lds, u.off0 + row * u.pitch, x0 >> 1, s);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t x = x0 + k, m = s[1u + (k >> 1)], o = (k & 1u) ? s[2u + (k >> 1)] : s[k >> 1];
+                out[k] = (x == 0u || x == 2u * W - 1u) ? m : (3u * m + o + 2u) >> 2;
+            }
+        } else if (u.kind == UP_H2V2) {  // :191-228
+            uint32_t near, far, n[6], f[6], t[6];
             near_far(row, u.height, near, far);
-            const uint32_t W = u.width, j = x >> 1, tj = 3u * at(near, j) + at(far, j);
-            if (x == 0u || x == 2u * W - 1u) return (tj + 2u) >> 2;
-            const uint32_t o = (x & 1u) ? j + 1u : j - 1u;
-            return (3u * tj + 3u * at(near, o) + at(far, o) + 8u) >> 4;
-        }
-        default: return at(row / u.vf, x / u.hf);  // Generic :230-250
+            fetch6(lds, u.off0 + near * u.pitch, x0 >> 1, n);
+            fetch6(lds, u.off0 + far * u.pitch, x0 >> 1, f);
+#pragma unroll
+            for (uint32_t m = 0; m < 6; m++) t[m] = 3u * n[m] + f[m];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t x = x0 + k, tm = t[1u + (k >> 1)], to = (k & 1u) ? t[2u + (k >> 1)] : t[k >> 1];
+                out[k] = (x == 0u || x == 2u * W - 1u) ? (tm + 2u) >> 2 : (3u * tm + to + 8u) >> 4;
+            }
+        } else {  // Generic :230-250 (sample (row / vf, x / hf); columns past the plane's last one read the last)
+            const uint32_t base = u.off0 + (row / u.vf) * u.pitch;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) out[k] = lds[base + min((x0 + k) / u.hf, W - 1u)];
         }
     }
 
-    // phase 2: the tile's output pixels, four per unit (Upsampler::upsample_and_interleave_row + the colour functions,
-    // src/upsampler.rs:47-63, src/decoder.rs:1391-1484; the 1-component copy of compute_image, :1310-1332)
+    // phase 2: the tile's output pixels, eight per unit (Upsampler::upsample_and_interleave_row + the colour functions,
+    // src/upsampler.rs:47-63, src/decoder.rs:1391-1484; the 1-component copy of compute_image, :1310-1332).  First version: four per
+    // unit, byte reads, one switch per sample — 600 vector instructions per unit, the launch bound by them (0.91 ms per 256 x 1080p
+    // at scale 4 where the generic pair of kernels took 0.62).
     static __device__ __forceinline__ void pixels(const ScaledGeom &g, const ImageJob &job, uint32_t tile, uint32_t my, uint32_t tid, const uint8_t *lds) {
         const uint32_t te = txe(g, tile), nc = g.ncomp, fn = job.color_fn;
         const uint32_t x0 = tile * g.tx * g.hmax * (uint32_t)SCALE, y0 = my * g.vmax * (uint32_t)SCALE;
         const uint32_t width = te * g.hmax * (uint32_t)SCALE, rows = g.vmax * (uint32_t)SCALE;
-        const uint32_t upr = (width + 3u) / 4u, units = upr * rows;
+        const uint32_t upr = (width + 7u) / 8u, units = upr * rows;
         const View v0 = view_of(g, job, 0u, tile, my), v1 = view_of(g, job, nc > 1u ? 1u : 0u, tile, my), v2 = view_of(g, job, nc > 2u ? 2u : 0u, tile, my),
                    v3 = view_of(g, job, nc > 3u ? 3u : 0u, tile, my);
         const uint32_t out_w = fn == CC_GRAY ? v0.width : job.out_w, out_h = fn == CC_GRAY ? v0.height : job.out_h;
         JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)job.out;
         for (uint32_t un = tid; un < units; un += FS_NT) {
-            const uint32_t r = un / upr, x = x0 + 4u * (un - r * upr), row = y0 + r;
+            const uint32_t r = un / upr, x = x0 + 8u * (un - r * upr), row = y0 + r;
             if (row >= out_h || x >= out_w) continue;
-            const uint32_t n = min(4u, out_w - x);
-            uint32_t s[4][4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t xk = x + min(k, n - 1u);  // (pixels past the image repeat the last one: never stored)
-                s[0][k] = sample(lds, v0, xk, row);
-                s[1][k] = nc > 1u ? sample(lds, v1, xk, row) : 0u;
-                s[2][k] = nc > 2u ? sample(lds, v2, xk, row) : 0u;
-                s[3][k] = nc > 3u ? sample(lds, v3, xk, row) : 0u;
-            }
+            const uint32_t n = min(8u, out_w - x);
+            uint32_t s[4][8];
+            sample8(lds, v0, x, row, s[0]);
+            if (nc > 1u) sample8(lds, v1, x, row, s[1]);
+            if (nc > 2u) sample8(lds, v2, x, row, s[2]);
+            if (nc > 3u) sample8(lds, v3, x, row, s[3]);
             if (fn == CC_GRAY) {
                 JP_GLOBAL uint8_t *o = out + (size_t)row * out_w + x;
-                if (n == 4u && (((size_t)row * out_w) & 3u) == 0u) *reinterpret_cast<JP_GLOBAL uint32_t *>(o) = s[0][0] | (s[0][1] << 8) | (s[0][2] << 16) | (s[0][3] << 24);
-                else
+                if (n == 8u && (((size_t)row * out_w) & 3u) == 0u) {
+                    reinterpret_cast<JP_GLOBAL uint32_t *>(o)[0] = s[0][0] | (s[0][1] << 8) | (s[0][2] << 16) | (s[0][3] << 24);
+                    reinterpret_cast<JP_GLOBAL uint32_t *>(o)[1] = s[0][4] | (s[0][5] << 8) | (s[0][6] << 16) | (s[0][7] << 24);
+                } else {
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++)
+                    for (uint32_t k = 0; k < 8; k++)
                         if (k < n) o[k] = (uint8_t)s[0][k];
+                }
                 continue;
             }
             if (fn == CC_NONE) {  // color_no_convert: planar within the row
 #pragma unroll
                 for (uint32_t c = 0; c < 4; c++)
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++)
+                    for (uint32_t k = 0; k < 8; k++)
                         if (c < nc && k < n) out[(size_t)row * out_w * nc + (size_t)c * out_w + x + k] = (uint8_t)s[c][k];
                 continue;
             }
-            uint32_t px[4];
+            uint32_t px[8];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
+            for (uint32_t k = 0; k < 8; k++) {
                 if (fn == CC_RGB) px[k] = s[0][k] | (s[1][k] << 8) | (s[2][k] << 16);
                 else if (fn == CC_YCBCR) px[k] = ycbcr_to_rgb24(s[0][k], s[1][k], s[2][k]);
                 else if (fn == CC_YCCK) px[k] = ycbcr_to_rgb24(s[0][k], s[1][k], s[2][k]) | ((255u - s[3][k]) << 24);
                 else px[k] = (255u - s[0][k]) | ((255u - s[1][k]) << 8) | ((255u - s[2][k]) << 16) | ((255u - s[3][k]) << 24);
             }
             const size_t off = ((size_t)row * out_w + x) * nc;
-            JP_GLOBAL uint8_t *o = out + off;
             if (nc == 4u) {
-                if (n == 4u) *reinterpret_cast<JP_GLOBAL v4u *>(o) = v4u{px[0], px[1], px[2], px[3]};  // (x % 4 == 0: 16-byte aligned)
-                else
+                JP_GLOBAL uint8_t *o = out + off;
+                if (n == 8u) {  // (4-byte aligned whatever the image's width)
+                    *reinterpret_cast<JP_GLOBAL v4u_a4 *>(o) = v4u{px[0], px[1], px[2], px[3]};
+                    *reinterpret_cast<JP_GLOBAL v4u_a4 *>(o + 16) = v4u{px[4], px[5], px[6], px[7]};
+                } else {
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++)
+                    for (uint32_t k = 0; k < 8; k++)
                         if (k < n) reinterpret_cast<JP_GLOBAL uint32_t *>(o)[k] = px[k];
-            } else if (n == 4u && (off & 3u) == 0u) {
-                *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+                }
             } else {
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++)
-                    if (k < n) o[3 * k] = (uint8_t)px[k], o[3 * k + 1] = (uint8_t)(px[k] >> 8), o[3 * k + 2] = (uint8_t)(px[k] >> 16);
+                store_rgb_run(out, off, px, n);
             }
         }
     }

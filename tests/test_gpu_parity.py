@@ -1050,7 +1050,7 @@ SCALED_KINDS = {
     "440": ([(1, 2), (1, 1), (1, 1)], "YCbCr", "fusedscaled-s%d"), "411": ([(4, 1), (1, 1), (1, 1)], "YCbCr", "fusedscaled-s%d"),
     "311": ([(3, 1), (1, 1), (1, 1)], "YCbCr", "fusedscaled-s%d"), "gray": ([(1, 1)], "Grayscale", "fusedgray-s%d"),
     "cmyk": ([(1, 1)] * 4, "CMYK", "fusedscaled-s%d"), "cmyk2211": ([(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK", "fusedscaled-s%d"),
-    "ycck2212": ([(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK", "fusedscaled-s%d"), "none": ([(1, 1)] * 3, "None", "fusedscaled-s%d"),
+    "ycck2212": ([(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK", "fusedscaled-s%d"), "none": ([(1, 1)] * 3, "None", "fused444-s%d"),
 }
 SCALED_SIZES = [(64, 48), (33, 17), (1, 1), (3, 5), (250, 130), (1930, 40), (9, 300), (640, 480), (1025, 24)]
 

@@ -23,6 +23,7 @@
 #   fuzz[:n]                      the differential fuzzers, n cases each (default 200)
 #   latency                       one image through Decoder / a one-image pipeline (tools/decoder_latency.py)
 #   forcedist                     bench.py --force-dist (the N > 1 code path with one rank on RCCL), e2e included
+#   hostbench:<file>[:reps]       tools/host_bench.cpp on the box's CPU: host entropy decoding of one file, scan by scan for progressive ones
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd "$R" || exit 1
@@ -146,6 +147,9 @@ for step in "$@"; do
     forcedist)
       timeout 900 python bench.py --force-dist --no-k4096 --no-cpu-baseline --no-classes --e2e-images 256,1024 > $O/bench_force_dist.json 2> $O/bench_force_dist.err
       summary_line $O/bench_force_dist.json force_dist ;;
+    hostbench)
+      g++ -O3 -march=native -std=c++17 -I. tools/host_bench.cpp jpeg-decoder_amd/csrc/host/frontend.cpp jpeg-decoder_amd/csrc/image_job.cpp -o /tmp/host_bench 2> $O/host_bench_build.err
+      (grep -m1 "model name" /proc/cpuinfo; /tmp/host_bench $a1 ${a2:-60}) > $O/host_bench_$(basename $a1).txt 2>&1; cat $O/host_bench_$(basename $a1).txt ;;
     *) echo "unknown step $what" ;;
   esac
 done

@@ -1,7 +1,9 @@
 // host_bench.cpp — single-thread cost of the host half of the pipeline on one JPEG file:
 //   g++ -O3 -std=c++17 -I. tools/host_bench.cpp jpeg-decoder_amd/csrc/host/frontend.cpp jpeg-decoder_amd/csrc/image_job.cpp -o /tmp/host_bench
 //   /tmp/host_bench file.jpg [repeats]
-// Prints ms per image for: entropy decoding alone (rows dropped), + dense staging (memcpy + range scan), + compact staging.
+// Prints ms per image for: entropy decoding alone (rows dropped), + dense staging (memcpy + range scan), + compact staging; and, for a
+// progressive file, where the entropy decoding time goes scan by scan (the clock read whenever the front-end reports what a scan changed).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -54,6 +56,19 @@ struct CompactSink : RowSink {
     }
 };
 
+// progressive files: a sink that asks for the per-scan change lists only to read the clock when each one arrives
+struct ScanClockSink : NullSink {
+    std::vector<double> at;
+    std::vector<size_t> entries;
+    std::vector<uint32_t> comp;
+    bool wants_scan_deltas() override { return true; }
+    void scan_deltas(uint32_t slot, const ScanDelta *, size_t n) override {
+        at.push_back(now_ms());
+        entries.push_back(n);
+        comp.push_back(slot);
+    }
+};
+
 int main(int argc, char **argv) {
     if (argc < 2) return 1;
     FILE *f = fopen(argv[1], "rb");
@@ -81,5 +96,36 @@ int main(int argc, char **argv) {
         printf("%s: %.3f ms\n", mode == 0 ? "entropy only" : mode == 1 ? "entropy + dense staging + range scan" : "entropy + compact staging", best);
     }
     printf("compact bytes %zu\n", cs.bytes);
+    {  // scan by scan (median of `reps` runs per interval); sequential files report nothing here
+        std::vector<std::vector<double>> dt;
+        std::vector<size_t> entries;
+        std::vector<uint32_t> comp;
+        double total = 0;
+        for (int r = 0; r < reps; r++) {
+            ScanClockSink sc;
+            const double t0 = now_ms();
+            Frontend fe(data.data(), data.size());
+            fe.decode_to(sc);
+            const double t1 = now_ms();
+            if (sc.at.empty()) break;
+            if (dt.empty()) dt.resize(sc.at.size() + 1), entries = sc.entries, comp = sc.comp;
+            if (sc.at.size() + 1 != dt.size()) break;
+            for (size_t k = 0; k < sc.at.size(); k++) dt[k].push_back(sc.at[k] - (k ? sc.at[k - 1] : t0));
+            dt.back().push_back(t1 - sc.at.back());
+            total += t1 - t0;
+        }
+        if (!dt.empty() && !dt[0].empty()) {
+            printf("progressive, change lists on: %.3f ms per image (mean); per reported scan x component (median ms, coefficients changed):\n", total / (double)dt[0].size());
+            double sum = 0;
+            for (size_t k = 0; k < dt.size(); k++) {
+                std::sort(dt[k].begin(), dt[k].end());
+                const double m = dt[k][dt[k].size() / 2];
+                sum += m;
+                if (k + 1 < dt.size()) printf("  report %2zu  component %u  %8.4f ms  %7zu changes\n", k, comp[k], m, entries[k]);
+                else printf("  after the last report (finishing rows)  %8.4f ms\n", m);
+            }
+            printf("  sum of medians %.3f ms\n", sum);
+        }
+    }
     return 0;
 }
