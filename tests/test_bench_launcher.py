@@ -69,8 +69,8 @@ def test_two_ranks_dry_run_shards_config3_and_gathers():
     assert sh["images"] == 4096 and sh["ranks"] == 2 and sh["images_per_rank"] == [2048, 2048]
     granted = sh["host_cpus_granted"]
     assert granted == bench.effective_cpus()
-    assert sh["threads_per_rank"] == [max(2, granted // 2)] * 2
-    assert sum(sh["threads_per_rank"]) <= max(4, granted)
+    assert sh["threads_per_rank"] == [max(2, 2 * granted // 2)] * 2   # one pipeline's default (twice the granted CPUs) DIVIDED by the ranks
+    assert sum(sh["threads_per_rank"]) <= max(4, 2 * granted)
     assert sh["cpu_shares_disjoint"] is True and sum(sh["cpus_per_rank"]) <= len(os.sched_getaffinity(0))
 
 

@@ -72,7 +72,7 @@ for step in "$@"; do
   echo "=== $step"
   case $what in
     tests)
-      if [ -n "$a1" ]; then timeout 2400 python -m pytest tests -m gpu -q -x -k "$a1" > $O/pytest_gpu.log 2>&1
+      if [ -n "$a1" ]; then timeout 2400 python -m pytest tests -m gpu -q -x -k "$(envs "$a1")" > $O/pytest_gpu.log 2>&1
       else timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; fi
       echo "pytest exit $?" >> $O/pytest_gpu.log; tail -n 6 $O/pytest_gpu.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 2 | tee $O/smoke.txt ;;
