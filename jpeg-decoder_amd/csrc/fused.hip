@@ -112,9 +112,7 @@ template <int ARITH, uint32_t NT>
 __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                      const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
-    if (w.image == FUSED_NO_WORK) return;  // (a slot of the XCD-ordered table that no segment fills)
-    walk_item<S420<ARITH, NT>>(geoms, imgs, w, lds_raw);
+    walk_item<S420<ARITH, NT>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
 }
 // Classes from the device (one item per workgroup), as TWO launches: the first runs the images whose coefficients are in range
 // (tight / sane bodies), the second the others (wrap-exact body); a workgroup whose image belongs to the other launch leaves at
@@ -126,7 +124,6 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel_dyn(const FusedGeom *__rest
                                                          const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
-    if (w.image == FUSED_NO_WORK) return;
     const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags);
     if constexpr (EXACT_PASS) {
         if (!(fl & 1u)) walk_item<S420<ARITH_EXACT, NT>>(geoms, imgs, w, lds_raw);
@@ -140,16 +137,13 @@ template <int ARITH>
 __global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                       const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
-    if (w.image == FUSED_NO_WORK) return;
-    walk_item<S440<ARITH>>(geoms, imgs, w, lds_raw);
+    walk_item<S440<ARITH>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
 }
 template <bool EXACT_PASS>
 __global__ __launch_bounds__(256, 4) void s440_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                           const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
-    if (w.image == FUSED_NO_WORK) return;
     const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags);
     if constexpr (EXACT_PASS) {
         if (!(fl & 1u)) walk_item<S440<ARITH_EXACT>>(geoms, imgs, w, lds_raw);
@@ -432,29 +426,6 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     }
     // JPGPU_FUSED_TABLE=1 forces the table form (test knob)
     if (const char *ft = getenv("JPGPU_FUSED_TABLE")) if (atoi(ft) != 0) plan.uniform = false;
-    // Strip walks, XCD order (JPGPU_WALK_XCD=1; round 4 experiment): workgroups are handed to the 8 XCDs round-robin in launch order
-    // and every XCD has an L2 of its own.  Column s = (image, strip) goes to XCD s mod 8 and its segments to consecutive slots of
-    // that XCD — table index 8 * j + xcd —, so the segments of a column run one after the other on ONE XCD: a segment's seam blocks
-    // (the chroma block rows its neighbours stage in full) come out of that L2, and with short segments (JPGPU_S420_SEG) every XCD
-    // sweeps its columns top to bottom in address order.  Slots no segment fills hold FUSED_NO_WORK.
-    if (plan.strip)
-        if (const char *wx = getenv("JPGPU_WALK_XCD"); wx && atoi(wx) != 0) {
-            std::vector<std::vector<FusedWork>> per_xcd(8);
-            uint32_t col = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                const FusedGeom &g = plan.geoms[i];
-                for (uint32_t x = 0; x < g.tiles_x; x++, col++)
-                    for (uint32_t y = 0; y < g.n_seg; y++)
-                        per_xcd[col & 7u].push_back(FusedWork{i, x, y * g.seg_rows, std::min((y + 1u) * g.seg_rows, g.mcu_h)});
-            }
-            size_t longest = 0;
-            for (const auto &l : per_xcd) longest = std::max(longest, l.size());
-            plan.work_main.clear();
-            for (size_t j = 0; j < longest; j++)
-                for (uint32_t xcd = 0; xcd < 8; xcd++)
-                    plan.work_main.push_back(j < per_xcd[xcd].size() ? per_xcd[xcd][j] : FusedWork{FUSED_NO_WORK, 0u, 0u, 0u});
-            plan.uniform = false;
-        }
     plan.images.assign(n, FusedImage{});
     return true;
 }
@@ -516,7 +487,7 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
         for (int c = 0; c < 3; c++) {
             plan.n_main_cls[c] = 0;
             for (const FusedWork &w : plan.work_main)
-                if (w.image != FUSED_NO_WORK && cls[w.image] == c) all.push_back(w), plan.n_main_cls[c]++;
+                if (cls[w.image] == c) all.push_back(w), plan.n_main_cls[c]++;
         }
         if (all.size() > plan.work_cls_cap) {
             if (plan.d_work_cls) (void)hipFree(plan.d_work_cls);

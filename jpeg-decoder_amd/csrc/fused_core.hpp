@@ -55,7 +55,6 @@ struct FusedGeom {
 struct alignas(16) FusedWork {
     uint32_t image, a, b, c;
 };
-constexpr uint32_t FUSED_NO_WORK = 0xffffffffu;  // FusedWork::image of a table slot without work (XCD-ordered tables of the strip walks)
 
 struct FusedImage {
     const int16_t *coefs[4];
