@@ -915,7 +915,11 @@ def main(argv=None):
                 if i >= n_img:
                     continue
                 got = shard.image_pixels(i).cpu().numpy()
-                verified = verified and hashlib.sha256(got.tobytes()).hexdigest() == digest
+                same = hashlib.sha256(got.tobytes()).hexdigest() == digest
+                if not same:  # (say where: a line on stderr, the JSON line keeps its one boolean)
+                    bad = np.nonzero(got != want)[0]
+                    print(f"bench.py: image {i} differs from the oracle in {bad.size} bytes, first at {bad[:8].tolist()}: got {got[bad[:8]].tolist()} want {want[bad[:8]].tolist()}", file=sys.stderr)
+                verified = verified and same
         ocomps, _ = O.make_components(full_w, full_h, sampling, dct_scale=dct_scale)
 
     total_images = images_total or world * n_img
