@@ -289,7 +289,8 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         if (rc) return rc;
         // reduced-size decodes (every component at one dct_scale < 8): one launch, planes in LDS (fused_scaled.hpp)
         ScaledGeom sg;
-        const bool scaled = kind_key[i] == 0 && !(flags & JPGPU_BATCH_FORCE_GENERIC) && scaled_geom_from_job(d.components, d.ncomp, ij, sg);
+        static const uint32_t scaled_tx = getenv("JPGPU_SCALED_TX") ? (uint32_t)std::max(8, atoi(getenv("JPGPU_SCALED_TX"))) : 64u;  // (tuning / test knob)
+        const bool scaled = kind_key[i] == 0 && !(flags & JPGPU_BATCH_FORCE_GENERIC) && scaled_geom_from_job(d.components, d.ncomp, ij, sg, scaled_tx);
         if (scaled) {
             b->scaled_ids.push_back(i);
             b->scaled_geoms.push_back(sg);
@@ -317,10 +318,6 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         b->out_off[i] = oo;
         b->out_len[i] = out_len;
         oo += align_up(out_len, 256);
-        // JPGPU_ARENA_SKEW = s (experiment, round 4): s * ((7 i) mod 16) bytes of padding behind image i in both arenas — images of one
-        // geometry then no longer lie at one stride (1080p 4:2:0: 8 kB x 765 for coefficients, 1 kB x 6075 for pixels) from each other
-        static const size_t skew = getenv("JPGPU_ARENA_SKEW") ? (size_t)std::max(0l, atol(getenv("JPGPU_ARENA_SKEW"))) / 256 * 256 : 0;
-        if (skew) co += skew * ((7u * i) % 16u), oo += skew * ((7u * i) % 16u);
         if (kind_key[i] == 0 && !scaled) {
             b->generic_ids.push_back(i);
             b->max_w = std::max<uint32_t>(b->max_w, d.ncomp == 1 ? d.components[0].size_width : d.out_w);

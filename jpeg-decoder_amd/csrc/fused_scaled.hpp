@@ -45,7 +45,8 @@ struct ScaledGeom {
 };
 
 // Which images take the kernel, and their tiling.  `job` = what build_image_job made of the frame (upsampler kinds).
-inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g) {
+// tx_cap: widest tile in MCUs (test / tuning knob JPGPU_SCALED_TX; 64 by default)
+inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g, uint32_t tx_cap = 64u) {
     g = ScaledGeom{};
     if (ncomp == 0 || ncomp > 4) return false;
     const uint32_t scale = comps[0].dct_scale;
@@ -74,7 +75,8 @@ inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, c
     const uint32_t cap = FS_NT * FS_BLOCKS_PER_LANE;
     if (ring + 8u * per_mcu > cap) return false;
     uint32_t tx_max = ((cap - ring) / per_mcu) & ~7u;
-    if (tx_max > 64u) tx_max = 64u;
+    tx_cap = (tx_cap < 8u ? 8u : (tx_cap > 64u ? 64u : tx_cap)) & ~7u;
+    if (tx_max > tx_cap) tx_max = tx_cap;
     const uint32_t n_tiles = (g.mcu_w + tx_max - 1u) / tx_max;
     g.tx = (((g.mcu_w + n_tiles - 1u) / n_tiles) + 7u) & ~7u;  // balanced, rounded up to a multiple of 8 (<= tx_max: that is one)
     g.tiles_x = (g.mcu_w + g.tx - 1u) / g.tx;

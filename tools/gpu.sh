@@ -12,7 +12,7 @@
 #   e:<name>[:ENV=VAL+...]        the E figures (256 / 1,024 / 4,096 files) + kernel phases of one sub-batch alone
 #   ab:<reps>                     K of libjpgpu.so against every jpeg-decoder_amd/libjpgpu_alt*.so, interleaved <reps> times
 #   abe:<reps>                    the same for the E figures
-#   wl:<workload>[:batch[:subs]]  K of another workload (bench.py --workload)
+#   wl:<workload>[:batch[:subs[:ENV=VAL+...]]]  K of another workload (bench.py --workload)
 #   trace:<name>:<cmd with + for spaces>     rocprofv3 --kernel-trace --stats of a command -> <name>_kernel_stats.json
 #   pmc:<name>:<cmd>              instruction / wait / LDS counters of a command (two passes of eight counters) -> <name>_pmc.json
 #   lanes:<name>:<cmd>            SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU per kernel -> <name>_lanes.json
@@ -95,8 +95,9 @@ for step in "$@"; do
       done ;;
     wl)
       extra=""; [ -n "$a2" ] && extra="--batch $a2"; [ -n "$a3" ] && extra="$extra --sub-batches $a3"
-      timeout 600 python bench.py --workload $a1 $extra --steps 300 --warmup 50 --no-cpu-baseline --no-classes --min-seconds 0 > $O/wl_$a1${a2:+_$a2}${a3:+_$a3}.json 2>> $O/wl.err
-      summary_line $O/wl_$a1${a2:+_$a2}${a3:+_$a3}.json "wl_$a1${a2:+_$a2}${a3:+_$a3}" ;;
+      tag=$a1${a2:+_$a2}${a3:+_$a3}${a4:+_${a4//[^A-Za-z0-9]/_}}
+      env $(envs "$a4") timeout 600 python bench.py --workload $a1 $extra --steps 300 --warmup 50 --no-cpu-baseline --no-classes --min-seconds 0 > $O/wl_$tag.json 2>> $O/wl.err
+      summary_line $O/wl_$tag.json "wl_$tag" ;;
     trace)
       cmd=$(envs "$a2"); rm -rf $O/trace_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_$a1 -o t -- $cmd > $O/trace_$a1.log 2>&1)
