@@ -33,6 +33,7 @@ PIPE_CMD="python $R/tools/pipe_calls.py --images 256 --calls 6 --one-sub-batch"
 KARGS="--steps 500 --warmup 50 --no-cpu-baseline --no-classes --no-k4096 --no-e2e --min-seconds 0"
 
 envs() { echo "${1//+/ }"; }   # "A=1+B=2" -> "A=1 B=2"
+cmdline() { local c="${1//+/ }"; c="${c// bench.py/ $R/bench.py}"; echo "${c// tools\// $R/tools/}"; }  # the same for a command run from /tmp (rocprofv3): repo paths made absolute
 
 summary_line() {  # <file> <label>
 python - "$1" "$2" <<'PY'
@@ -99,16 +100,16 @@ for step in "$@"; do
       env $(envs "$a4") timeout 600 python bench.py --workload $a1 $extra --steps 300 --warmup 50 --no-cpu-baseline --no-classes --min-seconds 0 > $O/wl_$tag.json 2>> $O/wl.err
       summary_line $O/wl_$tag.json "wl_$tag" ;;
     trace)
-      cmd=$(envs "$a2"); rm -rf $O/trace_$a1
+      cmd=$(cmdline "$a2"); rm -rf $O/trace_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_$a1 -o t -- $cmd > $O/trace_$a1.log 2>&1)
       python tools/prof_summary.py $O/trace_$a1 > $O/${a1}_kernel_stats.json 2>> $O/summary.err; kernel_table $O/trace_$a1 ;;
     pmc)
-      cmd=$(envs "$a2"); rm -rf $O/pmc1_$a1 $O/pmc2_$a1
+      cmd=$(cmdline "$a2"); rm -rf $O/pmc1_$a1 $O/pmc2_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD -d $O/pmc1_$a1 -o p -- $cmd > $O/pmc1_$a1.log 2>&1)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAIT_ANY -d $O/pmc2_$a1 -o p -- $cmd > $O/pmc2_$a1.log 2>&1)
       python tools/prof_summary.py $O/pmc1_$a1 $O/pmc2_$a1 > $O/${a1}_pmc.json 2>> $O/summary.err; head -c 3000 $O/${a1}_pmc.json ;;
     lanes)
-      cmd=$(envs "$a2"); rm -rf $O/lanes_$a1
+      cmd=$(cmdline "$a2"); rm -rf $O/lanes_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES -d $O/lanes_$a1 -o p -- $cmd > $O/lanes_$a1.log 2>&1)
       python tools/prof_summary.py $O/lanes_$a1 > $O/${a1}_lanes.json 2>> $O/summary.err; head -c 3000 $O/${a1}_lanes.json ;;
     traffic)
