@@ -21,6 +21,7 @@
 #pragma once
 #include <stdint.h>
 
+#include "fused_core.hpp"
 #include "jobs.hpp"
 #include "pixel_math.hpp"
 #include "upsample_color_body.hpp"
@@ -267,6 +268,29 @@ struct FScaled {
                    v3 = view_of(g, job, nc > 3u ? 3u : 0u, tile, my);
         const uint32_t out_w = fn == CC_GRAY ? v0.width : job.out_w, out_h = fn == CC_GRAY ? v0.height : job.out_h;
         JP_GLOBAL uint8_t *out = (JP_GLOBAL uint8_t *)job.out;
+        if (fn == CC_YCBCR && nc == 3u && v0.kind == UP_H1V1 && v1.kind == UP_H2V2 && v2.kind == UP_H2V2 && v1.width == v2.width && v1.height == v2.height) {
+            // 4:2:0 YCbCr (uniform per image): the packed 16-bit row arithmetic of the full-size walk (PixelOps::tprime / row_pixels,
+            // fused_core.hpp: H2V2 + colour conversion for 8 pixels in ~120 vector instructions, the first / last column of the
+            // image fixed up inside) on the rows of the LDS planes — the general loop below spends ~290 on the same eight pixels,
+            // and at 158 M vector wave-instructions per 256 x 1080p launch at scale 4 the kernel was bound by them (profiles/round4).
+            typedef PixelOps<ARITH_EXACT> P;
+            FusedGeom fg{};
+            fg.cw = v1.width, fg.out_w = out_w;
+            for (uint32_t un = tid; un < units; un += FS_NT) {
+                const uint32_t r = un / upr, x = x0 + 8u * (un - r * upr), row = y0 + r;
+                if (row >= out_h || x >= out_w) continue;
+                uint32_t near, far;
+                near_far(row, v1.height, near, far);
+                const uint32_t jn = near * v1.pitch + (x >> 1) - 4u, jf = far * v1.pitch + (x >> 1) - 4u;  // (the row functions read columns j0 - 4 .. j0 + 7)
+                const typename P::TPrime t[2] = {P::tprime(P::load_eo(lds + (v1.off0 + jn)), P::load_eo(lds + (v1.off0 + jf))),
+                                                 P::tprime(P::load_eo(lds + (v2.off0 + jn)), P::load_eo(lds + (v2.off0 + jf)))};
+                const uint32_t yo = v0.off0 + row * v0.pitch + x;
+                const v2u yy = {dword_at(lds, yo), dword_at(lds, yo + 4u)};
+                const size_t off = ((size_t)row * out_w + x) * 3u;
+                P::template row_pixels<false, true, false, true>(fg, out + off, (off & 3u) == 0u, t, yy, x);
+            }
+            return;
+        }
         for (uint32_t un = tid; un < units; un += FS_NT) {
             const uint32_t r = un / upr, x = x0 + 8u * (un - r * upr), row = y0 + r;
             if (row >= out_h || x >= out_w) continue;
