@@ -287,7 +287,9 @@ struct FScaled {
                 const uint32_t yo = v0.off0 + row * v0.pitch + x;
                 const v2u yy = {dword_at(lds, yo), dword_at(lds, yo + 4u)};
                 const size_t off = ((size_t)row * out_w + x) * 3u;
-                P::template row_pixels<false, true, false, true>(fg, out + off, (off & 3u) == 0u, t, yy, x);
+                // (plain stores: a lane's two 12-byte pieces fill half of every line an instruction touches, and with the non-temporal
+                // hint such partial lines leave one by one — profiles/round2/01_store_patterns.txt)
+                P::template row_pixels<false, true, false, false>(fg, out + off, (off & 3u) == 0u, t, yy, x);
             }
             return;
         }
@@ -339,6 +341,10 @@ struct FScaled {
                     for (uint32_t k = 0; k < 8; k++)
                         if (k < n) reinterpret_cast<JP_GLOBAL uint32_t *>(o)[k] = px[k];
                 }
+            } else if (n == 8u && (off & 3u) == 0u) {  // (store_rgb_run with plain stores)
+                JP_GLOBAL uint8_t *o = out + off;
+                *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o) = v3u{px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8)};
+                *reinterpret_cast<JP_GLOBAL v3u_a4 *>(o + 12) = v3u{px[4] | (px[5] << 24), (px[5] >> 8) | (px[6] << 16), (px[6] >> 16) | (px[7] << 8)};
             } else {
                 store_rgb_run(out, off, px, n);
             }

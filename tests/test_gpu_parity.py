@@ -1115,3 +1115,56 @@ def test_batch_1080p_420_reduced_size_full_batch(scale):
             assert np.array_equal(b.download(i), want), i
     finally:
         b.close()
+
+
+def _hip():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip
+
+
+@pytest.mark.parametrize("scale", [8, 4, 2, 1])
+def test_every_output_byte_is_written_whatever_the_arena_held(scale):
+    """Kernels that write a pixel arena in pieces (tiles, strips, rings) must cover it exactly: the batch decodes into a caller's
+    arena pre-filled with one pattern, then another — bytes a kernel forgets keep the pattern and show up against the oracle, bytes
+    between the images (and behind the last one) must keep it.  Mixed layouts and sizes in one batch, every reduced scale."""
+    import ctypes as C
+    hip = _hip()
+    rng = np.random.default_rng(900 + scale)
+    layouts = [SCALED_KINDS[k] for k in ("420", "444", "422", "440", "gray", "cmyk2211", "411")]
+    sizes = [(250, 130), (1930, 40), (33, 17), (640, 480), (9, 300), (1025, 24), (64, 48)]
+    cases = [_scaled_case(rng, w_, h_, samp, ct, scale) for (samp, ct, _p), (w_, h_) in zip(layouts, sizes)]
+    descs = [J.image_desc(list(to_j(oc)), qts, ow, oh, ct_) for oc, qts, _c, ct_, ow, oh in cases]
+    b = J.Batch(descs, flags=J._native.BATCH_EXTERNAL_BUFFERS)
+    coef, out = C.c_void_p(), C.c_void_p()
+    nco, nout = b.coef_arena_bytes(), b.out_arena_bytes()
+    assert hip.hipMalloc(C.byref(coef), nco) == 0 and hip.hipMalloc(C.byref(out), nout + 4096) == 0
+    try:
+        b.bind(coef.value, out.value)
+        for i, (oc, qts, coefs, ct_, ow, oh) in enumerate(cases):
+            for c in range(len(oc)):
+                b.upload(i, c, coefs[c])
+        for pattern in (0xA5, 0x3C):
+            assert hip.hipMemset(out, pattern, nout + 4096) == 0
+            b.decode()
+            b.synchronize()
+            host = np.empty(nout + 4096, np.uint8)
+            assert hip.hipMemcpy(host.ctypes.data, out, nout + 4096, 2) == 0
+            covered = np.zeros(nout + 4096, bool)
+            for i, (oc, qts, coefs, ct_, ow, oh) in enumerate(cases):
+                want = O.pixels_from_coefficients(oc, qts, coefs, ow, oh, ct_.upper())
+                off = b.out_offset(i)
+                assert b.out_bytes(i) == want.size
+                got = host[off: off + want.size]
+                bad = np.nonzero(got != want)[0]
+                assert bad.size == 0, (scale, hex(pattern), i, ow, oh, bad.size, bad[:16].tolist(), got[bad[:16]].tolist(), want[bad[:16]].tolist())
+                covered[off: off + want.size] = True
+            assert (host[~covered] == pattern).all(), "a kernel wrote outside the images"
+    finally:
+        b.close()
+        hip.hipFree(coef)
+        hip.hipFree(out)
