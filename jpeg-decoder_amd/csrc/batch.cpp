@@ -897,14 +897,16 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             n_sync_jobs++;  // every scan is a job of the chunk decoder, with its per-chunk state and entry buffers (device only)
             if (const DriGeom g = dri_geom(ps); g.chunked) {
                 const size_t chunks = g.too_large ? 0 : (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
-                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16);
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16) +
+                                 align_up(huff_weave_dwords((uint32_t)chunks, g.shift) * 4, 256) + 256;
             } else {  // one segment: a scan without restart markers (or one whose restart interval covers it)
                 if (ps.seg_off.size() != 2 || stuffed >= (1u << 28)) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad plan");
                 uint32_t blocks = 0;
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
                 const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
                 const size_t chunks = huff_sync_chunks((uint32_t)stuffed, shift);
-                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16);
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16) +
+                                 align_up(huff_weave_dwords((uint32_t)chunks, shift) * 4, 256) + 256;
             }
         }
     }
@@ -1053,6 +1055,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 xcur += align_up((size_t)chunks * 4, 16);
                 sj->emit = reinterpret_cast<uint32_t *>(xs + xcur);
                 xcur += align_up((size_t)chunks * sj->emit_stride * 4, 16);
+                xcur = align_up(xcur, 256);  // the weave: rows of 256 bytes (the block's base is 256-byte aligned)
+                sj->weave = reinterpret_cast<const uint32_t *>(xs + xcur);
+                sj->data_dwords = (uint32_t)(scan_bytes / 4);
+                xcur += align_up(huff_weave_dwords(chunks, sj->chunk_shift) * 4, 256);
                 uint32_t block_h[4] = {0, 0, 0, 0};
                 for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
                 if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;

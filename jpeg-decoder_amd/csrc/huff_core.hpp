@@ -23,8 +23,9 @@
 
 namespace jpgpu {
 
-// How the stream is fetched: one aligned dword per refill, requested one refill AHEAD into the register the previous one just
-// left (the empty asm keeps the load behind the last use of the old value, so no copy and no wait until the next refill).
+// How the stream is fetched: one aligned dword per refill — from the lane's column of the weave (huff_job.hpp: the 64 chunks of a
+// wave side by side), requested one refill AHEAD into the register the previous one just left (the empty asm keeps the load behind
+// the last use of the old value, so no copy and no wait until the next refill).
 // Rounds 1-3 also carried a reader of 16-byte pieces (sync passes of 256 1080p images 2.53 ms against 2.14 with dwords) and an LDS
 // ring for the kernels that stored coefficients themselves (the write pass and the one-lane-per-restart-segment decoder, both
 // replaced by speculative emission + huff_expand_kernel and deleted in round 4: profiles/round3/14_emission_path.txt).
@@ -32,9 +33,10 @@ struct DevBits {
     uint64_t bits;   // unread bits, left-aligned
     uint32_t nbits;
     uint32_t wpos;   // dwords taken from the slot so far
-    const JP_GLOBAL v4u *g;  // the slot (16-byte aligned, zero padded: huff_stage_segment).  An address-space-1 pointer: through a generic
-                             // one the fetches are flat_load instructions, which count as LDS operations too — every wait for an LDS
-                             // read behind one (and the loop is full of them) then waits for the stream fetch as well
+    const JP_GLOBAL uint32_t *g;  // dword w of the scan is g[w * HUFF_WEAVE_LANES]: the lane's column of the weave (huff_job.hpp), moved back
+                                  // by the chunk's first dword.  An address-space-1 pointer: through a generic one the fetches are
+                                  // flat_load instructions, which count as LDS operations too — every wait for an LDS read behind one
+                                  // (and the loop is full of them) then waits for the stream fetch as well
     uint32_t ahead;  // dword wpos
     bool bad;
 };
@@ -48,7 +50,7 @@ __device__ __forceinline__ void huff_refill(DevBits &b) {
 #ifndef JPGPU_HOST_EMULATION
         asm volatile("" : "+v"(b.bits) : : "memory");  // the old `ahead` is dead from here on
 #endif
-        b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
+        b.ahead = b.g[(size_t)b.wpos * HUFF_WEAVE_LANES];
     }
 }
 __device__ __forceinline__ uint32_t huff_peek(const DevBits &b, uint32_t n) { return n ? (uint32_t)(b.bits >> (64u - n)) : 0u; }

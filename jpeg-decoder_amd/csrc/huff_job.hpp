@@ -167,6 +167,11 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     // block numbers and DC sums restart per segment.  n_seg <= 1: the one-slot scan of a stream without restart markers.
     uint32_t seg_chunks;
     uint32_t late_pass;     // from this sync pass on a lane stores its entries one by one (huff_sync_core.hpp, huff_sync_run<2>)
+    // The weave (round 4, huff_weave_*): what the sync passes read instead of `data` — the dwords of 64 neighbouring chunks side by
+    // side, so that a wave's 64 stream fetches of a step fall into a few cache lines instead of 64.  Device-only work space.
+    const uint32_t *weave;  // huff_weave_dwords(n_chunks, chunk_shift) dwords
+    uint32_t data_dwords;   // dwords that may be read from `data` (the scan's slots); what lies beyond counts as zeros
+    uint32_t pad_;
 };
 // Where chunk i lies: bits [start, end) of the job's data, whether a segment starts there, which segment it belongs to.
 struct HuffChunkSpan {
@@ -197,6 +202,40 @@ inline
     sp.start = seg_start + (lo < seg_bits ? lo : seg_bits);
     sp.end = seg_start + (hi < seg_bits ? hi : seg_bits);
     return sp;
+}
+// The weave.  A lane of a sync pass walks its chunk a dword at a time, and a wave's 64 lanes walk 64 neighbouring chunks at about
+// the same pace: in the staged scan those 64 fetches of a step are 64 cache lines, each of which the lane comes back to 32 times —
+// 270,000 lanes of a 256-image call keep 35 MB of such lines open, more than the L2s hold, and nearly every fetch was a miss that a
+// whole wave waited for (sync passes of 256 1080p files: 1.5 GB fetched for 0.1 GB of scans).  huff_weave_kernel therefore lays the
+// chunks of a job out side by side before the first pass — tile t holds chunks 64 t .. 64 t + 63, row r of a tile the r-th dword of
+// each of them (256 bytes, two cache lines) — and every chunk's column goes on HUFF_WEAVE_EXTRA dwords into what follows the
+// chunk, so a lane never leaves its column: it reads at most dword C + 1 of it (C = dwords per chunk; huff_sync_run stops at the
+// first symbol boundary at or behind the chunk's end and holds no more than 64 bits + one dword ahead).
+constexpr uint32_t HUFF_WEAVE_LANES = 64u, HUFF_WEAVE_EXTRA = 4u;
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint32_t huff_weave_height(uint32_t chunk_shift) { return (1u << (chunk_shift - 5u)) + HUFF_WEAVE_EXTRA; }  // dwords per column
+inline size_t huff_weave_dwords(uint32_t n_chunks, uint32_t chunk_shift) {
+    return (size_t)((n_chunks + HUFF_WEAVE_LANES - 1u) / HUFF_WEAVE_LANES) * HUFF_WEAVE_LANES * huff_weave_height(chunk_shift);
+}
+// where row r of chunk i's column sits in the weave (dwords)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline size_t huff_weave_at(uint32_t chunk_shift, uint32_t i, uint32_t r) {
+    return ((size_t)(i / HUFF_WEAVE_LANES) * huff_weave_height(chunk_shift) + r) * HUFF_WEAVE_LANES + i % HUFF_WEAVE_LANES;
+}
+// ... and what it holds: dword (first dword of the chunk) + r of the staged scan, zero beyond the scan's slots
+template <class Job>
+inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t
+    huff_weave_value(const Job &job, uint32_t first_dword, uint32_t r) {
+    const uint32_t w = first_dword + r;
+    return w < job.data_dwords ? reinterpret_cast<const uint32_t *>(job.data)[w] : 0u;
 }
 // blocks segment `seg` must hold, and the number of its first block
 template <class Job>

@@ -67,10 +67,11 @@ __device__ __forceinline__ void huff_sync_fill_lds(JP_LDS HuffSyncLds &L, uint32
     }
 }
 
-__device__ __forceinline__ void huff_open_at(DevBits &b, const uint8_t *slot, uint32_t bit_pos) {
-    b.g = (const JP_GLOBAL v4u *)(uintptr_t)slot;
+// column: row 0 of the chunk's column in the weave, first_dword: the dword of the scan that row holds
+__device__ __forceinline__ void huff_open_at(DevBits &b, const uint32_t *column, uint32_t first_dword, uint32_t bit_pos) {
+    b.g = (const JP_GLOBAL uint32_t *)((uintptr_t)column - (uintptr_t)first_dword * (HUFF_WEAVE_LANES * 4u));
     b.wpos = bit_pos >> 5;
-    b.ahead = ((const JP_GLOBAL uint32_t *)b.g)[b.wpos];
+    b.ahead = b.g[(size_t)b.wpos * HUFF_WEAVE_LANES];
     b.bits = 0;
     b.nbits = 0;
     b.bad = false;
@@ -158,11 +159,11 @@ __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
 // register, not a lane mask carried round the loop.  From (pos, q, k) until the bit position reaches `limit`; returns the
 // position reached, q, k, nblk (blocks completed) updated.
 template <int EMIT>  // 0: no entries; 1: entries in rounds of eight (a pass of every lane); 2: entry by entry (a late pass: few lanes, the wave's step is what counts)
-__device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint8_t *data, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
+__device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint32_t *column, uint32_t first_dword, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
                                                   uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em, uint32_t &last_block_end) {
     const JP_LDS HuffSyncJob &job = L.job;
     DevBits b;
-    huff_open_at(b, data, pos);
+    huff_open_at(b, column, first_dword, pos);
     uint32_t c = job.q_comp[q];  // component of block q
     const JP_LDS uint8_t *tbase = (const JP_LDS uint8_t *)L.tables;
     uint32_t qt = L.q_tables[q];  // table offsets of block q
@@ -288,9 +289,11 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     }
     const bool late = emit && pass >= job.late_pass;
     if (pos < limit) {
-        if (late) pos = huff_sync_run<2>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
-        else if (emit) pos = huff_sync_run<1>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
-        else pos = huff_sync_run<0>(L, job.data, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        const uint32_t *column = job.weave + huff_weave_at(job.chunk_shift, i, 0u);
+        const uint32_t w0 = span.start >> 5;
+        if (late) pos = huff_sync_run<2>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else if (emit) pos = huff_sync_run<1>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else pos = huff_sync_run<0>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
     }
     if (job.emit != nullptr) {
         job.blk_end[i] = last_block_end;

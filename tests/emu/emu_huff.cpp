@@ -239,6 +239,13 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     sj.in_qk[i] = sj.out_qk[i ? i - 1 : 0];
                     sj.n_blocks[i] = i % 9u;
                 }
+            // (huff_weave_kernel) the staged scan, 64 chunks side by side: what the passes read
+            sj.data_dwords = (uint32_t)(total / 4);
+            std::vector<uint32_t> weave(huff_weave_dwords(sj.n_chunks, sj.chunk_shift) + 1, 0xEFEFEFEFu);
+            for (uint32_t i = 0; i < (sj.n_chunks + HUFF_WEAVE_LANES - 1u) / HUFF_WEAVE_LANES * HUFF_WEAVE_LANES; i++)
+                for (uint32_t r = 0; r < huff_weave_height(sj.chunk_shift); r++)
+                    weave[huff_weave_at(sj.chunk_shift, i, r)] = i < sj.n_chunks ? huff_weave_value(sj, huff_chunk_span(sj, i).start >> 5, r) : 0u;
+            sj.weave = weave.data();
             memcpy(S->tables, ps.tables->t, sizeof(S->tables));
             for (uint32_t t = 0; t < 512; t++) huff_sync_fill_lds(*S, t);
             // Launches as huff.hip runs them: workgroups of 256 lanes, `iters` iterations each with a barrier in between.

@@ -15,6 +15,8 @@
 #   wl:<workload>[:batch[:subs[:ENV=VAL+...]]]  K of another workload (bench.py --workload)
 #   trace:<name>:<cmd with + for spaces>     rocprofv3 --kernel-trace --stats of a command -> <name>_kernel_stats.json
 #   pmc:<name>:<cmd>              instruction / wait / LDS counters of a command (two passes of eight counters) -> <name>_pmc.json
+#   disp:<name>:<kernel substr>:<last N>[:ENV]   three counter passes over the one-sub-batch pipeline calls, every dispatch of the
+#                                 matching kernels on its own line (launches of very different work: the sync passes) -> <name>_dispatches.jsonl
 #   lanes:<name>:<cmd>            SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU per kernel -> <name>_lanes.json
 #   traffic:<workload>:<path>:<kernel substr>[:extra bench args]   FETCH_SIZE / WRITE_SIZE passes -> pmc_traffic.json entry
 #   pipe256[:ENV=VAL+...]         kernel trace + traffic + instruction counters of a 256-file pipeline call as ONE sub-batch
@@ -108,6 +110,12 @@ for step in "$@"; do
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD -d $O/pmc1_$a1 -o p -- $cmd > $O/pmc1_$a1.log 2>&1)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_WAIT_ANY -d $O/pmc2_$a1 -o p -- $cmd > $O/pmc2_$a1.log 2>&1)
       python tools/prof_summary.py $O/pmc1_$a1 $O/pmc2_$a1 > $O/${a1}_pmc.json 2>> $O/summary.err; head -c 3000 $O/${a1}_pmc.json ;;
+    disp)
+      cmd=$PIPE_CMD; E=$(envs "$a4"); rm -rf $O/d1_$a1 $O/d2_$a1 $O/d3_$a1
+      (cd /tmp && env $E timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/d1_$a1 -o p -- $cmd > $O/d1_$a1.log 2>&1)
+      (cd /tmp && env $E timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/d2_$a1 -o p -- $cmd > $O/d2_$a1.log 2>&1)
+      (cd /tmp && env $E timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_FLAT -d $O/d3_$a1 -o p -- $cmd > $O/d3_$a1.log 2>&1)
+      python tools/prof_summary.py --dispatches "$a2" "$a3" $O/d1_$a1 $O/d2_$a1 $O/d3_$a1 > $O/${a1}_dispatches.jsonl 2>> $O/summary.err; head -c 6000 $O/${a1}_dispatches.jsonl ;;
     lanes)
       cmd=$(cmdline "$a2"); rm -rf $O/lanes_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES -d $O/lanes_$a1 -o p -- $cmd > $O/lanes_$a1.log 2>&1)

@@ -30,7 +30,34 @@ def summarize(d):
     return out
 
 
+def dispatches(dirs, substr, last):
+    """Every dispatch of kernels whose name holds `substr`, in launch order, with its own duration and counters (the last `last`
+    of them): kernels launched many times with very different work (the sync passes) do not average into anything."""
+    rows = {}
+    for d in dirs:
+        for f in glob.glob(d + "/*.db"):
+            c = sqlite3.connect(f)
+            order = [r for r in c.execute("select dispatch_id, name, duration, grid_x, grid_y from kernels where name like ? order by start", ("%" + substr + "%",))]
+            order = order[-last:]
+            pos = {r[0]: i for i, r in enumerate(order)}
+            for did, name, dur, gx, gy in order:
+                rows.setdefault(pos[did], {}).setdefault("us", []).append(round(dur / 1e3, 1))
+                rows[pos[did]]["grid"] = [gx, gy]
+            try:
+                for did, n, v in c.execute("select dispatch_id, counter_name, sum(value) from counters_collection where kernel_name like ? group by dispatch_id, counter_name",
+                                           ("%" + substr + "%",)):
+                    if did in pos:
+                        rows[pos[did]][n] = round(v, 1)
+            except sqlite3.Error as e:
+                print("pmc:", e)
+    return [dict(i=i, **rows[i]) for i in sorted(rows)]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[1] == "--dispatches":  # --dispatches <kernel substr> <last N> dir...
+        for r in dispatches(sys.argv[4:], sys.argv[2], int(sys.argv[3])):
+            print(json.dumps(r))
+        sys.exit(0)
     res = {}
     for d in sys.argv[1:]:
         for k, v in summarize(d).items():
