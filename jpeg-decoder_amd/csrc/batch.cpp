@@ -875,13 +875,6 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         g.seg_chunks = huff_sync_chunks(longest, g.shift);
         return g;
     };
-    // device-only work space of one scan (the layout: where the job records are filled in, below)
-    auto sync_scratch_bytes = [](size_t chunks, uint32_t shift) {
-        const uint32_t stride = huff_emit_stride(shift);
-        return align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * stride * 4, 16) + align_up(chunks * huff_emit_side(stride) * 4, 16) +
-               align_up(chunks * HUFF_LIST_WORDS * 4, 16) + align_up(chunks * HUFF_CP_N * HUFF_CP_WORDS * 4, 16) +
-               align_up(huff_weave_dwords((uint32_t)chunks, shift) * 4, 256) + 256;
-    };
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
     size_t n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
@@ -904,14 +897,16 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             n_sync_jobs++;  // every scan is a job of the chunk decoder, with its per-chunk state and entry buffers (device only)
             if (const DriGeom g = dri_geom(ps); g.chunked) {
                 const size_t chunks = g.too_large ? 0 : (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
-                scratch_bytes += sync_scratch_bytes(chunks, g.shift);
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16) +
+                                 align_up(huff_weave_dwords((uint32_t)chunks, g.shift) * 4, 256) + 256;
             } else {  // one segment: a scan without restart markers (or one whose restart interval covers it)
                 if (ps.seg_off.size() != 2 || stuffed >= (1u << 28)) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad plan");
                 uint32_t blocks = 0;
                 for (uint32_t c = 0; c < ps.ncomp; c++) blocks += ps.comp[c].h * ps.comp[c].v;
                 const uint32_t shift = huff_sync_chunk_shift((uint32_t)stuffed, blocks * ps.n_mcu, sync_blocks, sync_min_shift);
                 const size_t chunks = huff_sync_chunks((uint32_t)stuffed, shift);
-                scratch_bytes += sync_scratch_bytes(chunks, shift);
+                scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16) +
+                                 align_up(huff_weave_dwords((uint32_t)chunks, shift) * 4, 256) + 256;
             }
         }
     }
@@ -1060,12 +1055,6 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 xcur += align_up((size_t)chunks * 4, 16);
                 sj->emit = reinterpret_cast<uint32_t *>(xs + xcur);
                 xcur += align_up((size_t)chunks * sj->emit_stride * 4, 16);
-                sj->emit_side = reinterpret_cast<uint32_t *>(xs + xcur);
-                xcur += align_up((size_t)chunks * huff_emit_side(sj->emit_stride) * 4, 16);
-                sj->list_desc = reinterpret_cast<uint32_t *>(xs + xcur);
-                xcur += align_up((size_t)chunks * HUFF_LIST_WORDS * 4, 16);
-                sj->cps = reinterpret_cast<uint32_t *>(xs + xcur);
-                xcur += align_up((size_t)chunks * HUFF_CP_N * HUFF_CP_WORDS * 4, 16);
                 xcur = align_up(xcur, 256);  // the weave: rows of 256 bytes (the block's base is 256-byte aligned)
                 sj->weave = reinterpret_cast<const uint32_t *>(xs + xcur);
                 sj->data_dwords = (uint32_t)(scan_bytes / 4);

@@ -379,16 +379,15 @@ __device__ __forceinline__ uint32_t expand_put(JP_LDS ExpandLds &E, JP_LDS uint1
 // a wave's chunks at once, so that the entries of chunk i + 1 are on their way while chunk i is being assembled)
 struct ExpandMeta {
     uint32_t cw, nblk, qk_before, w0, w1;  // emit_cnt[i], n_blocks[i], out_qk[i - 1] (0 for the first chunk), dc_sum[2i], dc_sum[2i + 1]
-    uint32_t d0, a01, a23;                 // list_desc[4i], [4i + 2], [4i + 3]: where the list's entries sit, what its later ones add to their DC values
 };
 // the first EXP_LOADS x 64 entries of chunk i behind its leading ones (all there is of an ordinary chunk): requested, not waited for
 __device__ __forceinline__ void expand_request(const JP_LDS HuffSyncJob &job, uint32_t i, uint32_t stride, const ExpandMeta &m, uint32_t (&ent)[EXP_LOADS]) {
     const uint32_t lane = threadIdx.x & 63u, cnt = min(m.cw & 0xffffu, stride), lead = min(m.cw >> 16, cnt);
-    const HuffListAt list = huff_list_at(job.emit, job.emit_side, stride, i, m.d0);
+    const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
 #pragma unroll
     for (uint32_t r = 0; r < EXP_LOADS; r++) {
         const uint32_t e = lead + 64u * r + lane;
-        ent[r] = e < cnt ? stream_load((const JP_GLOBAL uint32_t *)huff_list_entry(list, e)) : 0u;
+        ent[r] = e < cnt ? stream_load(buf + e) : 0u;
     }
 }
 
@@ -420,9 +419,7 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
         at.mx0 = m - at.my0 * at.cols;
     }
     const uint32_t w0 = UNIFORM ? 0u : meta.w0, w1 = UNIFORM ? 0u : meta.w1;
-    // (entries behind the ones a late run put into the side buffer: DC values of an earlier run, off by what the two runs' sums differ by)
-    const uint32_t w0_late = UNIFORM ? 0u : huff_add16x2(meta.w0, meta.a01), w1_late = UNIFORM ? 0u : huff_add16x2(meta.w1, meta.a23), na = meta.d0 & 0xffffu;
-    const HuffListAt list = huff_list_at(job.emit, job.emit_side, stride, i, meta.d0);
+    const JP_GLOBAL uint32_t *buf = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)i * stride);
     uint32_t started = 0, base = 0;  // blocks started so far; which of them sits in slot 0
     for (uint32_t e0 = lead; e0 < cnt; e0 += 64u * EXP_LOADS) {
         uint32_t ent[EXP_LOADS];
@@ -432,7 +429,7 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
                 ent[r] = first[r];
             } else {
                 const uint32_t e = e0 + 64u * r + lane;
-                ent[r] = e < cnt ? stream_load((const JP_GLOBAL uint32_t *)huff_list_entry(list, e)) : 0u;
+                ent[r] = e < cnt ? stream_load(buf + e) : 0u;
             }
         }
 #pragma unroll
@@ -441,8 +438,7 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
             const bool valid = e0 + 64u * r + lane < cnt, flag = valid && huff_entry_is_dc(ent[r]);
             const uint64_t m = __ballot(flag);
             const uint32_t local = started + (uint32_t)__popcll(m & lt) + (flag ? 1u : 0u) - 1u;  // the entry's block, counted from S
-            const bool behind = e0 + 64u * r + lane >= na;
-            const uint32_t a = expand_put<UNIFORM>(E, ring, at, valid, ent[r], local, local - base, behind ? w0_late : w0, behind ? w1_late : w1);
+            const uint32_t a = expand_put<UNIFORM>(E, ring, at, valid, ent[r], local, local - base, w0, w1);
             if (S + local < total) {
                 if (flag) rg_dc = UNIFORM ? rg_dc : max(rg_dc, a);  // (uniform scans: huff_dc_prefix_kernel ranges the finished values)
                 else rg_ac = max(rg_ac, a);
@@ -470,10 +466,9 @@ __device__ __forceinline__ void expand_chunk(JP_LDS ExpandLds &E, JP_LDS uint16_
     // the last block: its remaining entries lead the lists of the chunks that follow
     const uint32_t last = started - 1u;  // (counted from S)
     for (uint32_t j = i + 1u; S + last < total && j < seg_end_chunk; j++) {
-        const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj), d0j = rfl(job.list_desc[(size_t)j * HUFF_LIST_WORDS]);
-        const HuffListAt lj = huff_list_at(job.emit, job.emit_side, stride, j, d0j);
-        for (uint32_t e = lane; e < leadj; e += 64u)
-            rg_ac = max(rg_ac, expand_put<UNIFORM>(E, ring, at, true, stream_load((const JP_GLOBAL uint32_t *)huff_list_entry(lj, e)), last, last - base, 0u, 0u));
+        const uint32_t cj = rfl(job.emit_cnt[j]), cntj = min(cj & 0xffffu, stride), leadj = min(cj >> 16, cntj);
+        const JP_GLOBAL uint32_t *bj = (const JP_GLOBAL uint32_t *)(job.emit + (size_t)j * stride);
+        for (uint32_t e = lane; e < leadj; e += 64u) rg_ac = max(rg_ac, expand_put<UNIFORM>(E, ring, at, true, stream_load(bj + e), last, last - base, 0u, 0u));
         if (leadj < cntj) break;  // a block starts in chunk j: ours ended there
     }
     __builtin_amdgcn_wave_barrier();
@@ -512,7 +507,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
     uint32_t rg_dc = 0, rg_ac = 0;
     // lanes 0 .. EXP_CHUNKS - 1 fetch what the wave has to know of its chunks (one wait for all of them) ...
     const uint32_t i0 = first_chunk + wave * EXP_CHUNKS;
-    uint32_t v_cw = 0, v_nblk = 0, v_qk = 0, v_w0 = 0, v_w1 = 0, v_d0 = 0, v_a01 = 0, v_a23 = 0;
+    uint32_t v_cw = 0, v_nblk = 0, v_qk = 0, v_w0 = 0, v_w1 = 0;
     {
         const uint32_t mine = i0 + (lane % EXP_CHUNKS);
         if (mine < n_chunks) {
@@ -523,17 +518,12 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
                 v_w0 = job.dc_sum[2u * mine];
                 v_w1 = job.dc_sum[2u * mine + 1u];
             }
-            const v4u d = *(const JP_GLOBAL v4u *)(job.list_desc + (size_t)mine * HUFF_LIST_WORDS);
-            v_d0 = d.x;
-            v_a01 = d.z;
-            v_a23 = d.w;
         }
     }
     auto meta_of = [&](uint32_t ci) {
         return ExpandMeta{(uint32_t)__builtin_amdgcn_readlane((int)v_cw, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)v_nblk, (int)ci),
                           (uint32_t)__builtin_amdgcn_readlane((int)v_qk, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)v_w0, (int)ci),
-                          (uint32_t)__builtin_amdgcn_readlane((int)v_w1, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)v_d0, (int)ci),
-                          (uint32_t)__builtin_amdgcn_readlane((int)v_a01, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)v_a23, (int)ci)};
+                          (uint32_t)__builtin_amdgcn_readlane((int)v_w1, (int)ci)};
     };
     // ... and the entries of chunk ci + 1 are requested before chunk ci is assembled
     uint32_t cur[EXP_LOADS], nxt[EXP_LOADS];

@@ -172,12 +172,6 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     const uint32_t *weave;  // huff_weave_dwords(n_chunks, chunk_shift) dwords
     uint32_t data_dwords;   // dwords that may be read from `data` (the scan's slots); what lies beyond counts as zeros
     uint32_t pad_;
-    // Late sync passes that stop where they meet what the chunk's last run decoded (round 4, "checkpoints" below): a side buffer
-    // of huff_emit_side(emit_stride) entries per chunk for the entries such a run decodes before that point, what the chunk's list
-    // is made of (HUFF_LIST_WORDS words per chunk), and the states the last run passed through (HUFF_CP_N records per chunk).
-    uint32_t *emit_side;
-    uint32_t *list_desc;
-    uint32_t *cps;
 };
 // Where chunk i lies: bits [start, end) of the job's data, whether a segment starts there, which segment it belongs to.
 struct HuffChunkSpan {
@@ -271,50 +265,6 @@ inline bool huff_scan_covers_planes(const HuffSyncJob &j, const uint32_t block_h
     return true;
 }
 constexpr uint32_t HUFF_EMIT_OVERFLOW = 0xffffffffu, HUFF_LATE_PASS = 2u;  // (HuffSyncJob::late_pass by default)
-// Checkpoints.  A lane whose start state is corrected in a late pass decodes the same bits as before from another state — and, the
-// code being self-synchronising, is soon in step with its earlier run: from there on it would decode what it decoded before, entry
-// for entry.  So every emitting run leaves its state at HUFF_CP_N places on its way — the first end of a block at or behind each
-// eighth of the chunk: bit position, block-within-MCU, entries / blocks / DC sums so far — and a late run that arrives at such a
-// place in the state the record holds stops there: the chunk's list is then what it has just decoded (in the chunk's side
-// buffer) followed by the old list from the record's entry on, the old DC values shifted by what the two runs' sums differ by
-// (huff_list_*; the expansion reads lists through them).  Without this a single corrected lane walked its whole chunk alone —
-// ~580 symbols at the latency of a lone wave, 0.45 ms per pass whatever the call's size (256 1080p files as one sub-batch: the
-// launch of passes 2 + 3 took 0.90 ms for 3 % of the lanes, profiles/round4).
-constexpr uint32_t HUFF_CP_N = 7u, HUFF_CP_WORDS = 8u;  // record: bit position | entries, blocks << 16 | DC sums 0,1 | DC sums 2,3 | block-within-MCU (5 of 8 words used)
-constexpr uint32_t HUFF_LIST_WORDS = 4u;  // entries in the side buffer (A), index in the main buffer of the entry that follows them << 16 | valid
-                                          // checkpoint records | what entries behind A add to their DC values, components 0,1 | 2,3
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-inline uint32_t huff_emit_side(uint32_t emit_stride) { return (emit_stride / 4u + 3u) & ~3u; }  // (typical lists hold a third of emit_stride)
-// entry e of chunk i's list: the first `na` entries sit in the side buffer, the others in the main one from index `bstart` on
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-struct HuffListAt {
-    const uint32_t *a, *b;  // entry e: a[e] if e < na, else b[e]
-    uint32_t na;
-};
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-inline HuffListAt huff_list_at(const uint32_t *emit, const uint32_t *emit_side, uint32_t stride, uint32_t i, uint32_t d0) {
-    const uint32_t na = d0 & 0xffffu, bstart = d0 >> 16;
-    return HuffListAt{emit_side + (size_t)i * huff_emit_side(stride), emit + (size_t)i * stride + bstart - na, na};
-}
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-inline const uint32_t *huff_list_entry(const HuffListAt &at, uint32_t e) { return (e < at.na ? at.a : at.b) + e; }
-// two 16-bit fields added to two 16-bit fields, each modulo 2^16
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-inline uint32_t huff_add16x2(uint32_t a, uint32_t b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-inline uint32_t huff_sub16x2(uint32_t a, uint32_t b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
 // An entry with zig-zag index 0 is a DC value — the first entry of its block (AC entries have indices 1..63).
 #ifdef __HIPCC__
 __host__ __device__

@@ -111,20 +111,6 @@ struct HuffEmit {
     uint32_t n = 0, cap = 0, lead = 0xffffffffu;  // entries so far (counts on past `cap`: overflow), capacity (a multiple of 4), entries before the first DC
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // the last entries, youngest in s3, not yet stored
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;      // the complete group of four before them, waiting for its neighbour
-    JP_GLOBAL uint32_t *side = nullptr;           // a late run that may stop at a checkpoint: its first `split` entries go here
-    uint32_t split = 0;                           // (entry e >= split: buf[e], as always)
-};
-// What a run knows of the chunk's checkpoints (huff_job.hpp): where the next one lies, and — a late run — how many records of the
-// chunk's last run it may compare itself with.
-#ifdef JPGPU_HOST_EMULATION
-inline uint32_t g_huff_emu_late_runs = 0, g_huff_emu_met = 0;  // tests/emu: late runs that could have stopped at a checkpoint, and those that did
-#endif
-struct HuffCp {
-    JP_GLOBAL uint32_t *recs = nullptr;
-    uint32_t next = 0xffffffffu, step = 0, j = 0;  // bit position from which the next end of a block is checkpoint j
-    uint32_t valid_old = 0, na_old = 0;            // records of the last run; entries of its list that sit in the side buffer
-    uint32_t met = 0;                              // 1: stopped at record j, in the state it holds; what it held:
-    uint32_t old_counts = 0, old_dc01 = 0, old_dc23 = 0;
 };
 // One step of a lane: an entry, or none (`put`) — register selects, not a divergent region (a wave would enter it in every step).
 __device__ __forceinline__ void huff_emit_entry_if(HuffEmit &em, uint32_t e, bool put) {
@@ -174,7 +160,7 @@ __device__ __forceinline__ void huff_emit_finish(HuffEmit &em) {
 // position reached, q, k, nblk (blocks completed) updated.
 template <int EMIT>  // 0: no entries; 1: entries in rounds of eight (a pass of every lane); 2: entry by entry (a late pass: few lanes, the wave's step is what counts)
 __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const uint32_t *column, uint32_t first_dword, uint32_t pos, uint32_t limit, uint32_t &q, uint32_t &k,
-                                                  uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em, uint32_t &last_block_end, HuffCp &cp) {
+                                                  uint32_t &nblk, JP_LDS uint32_t *dc, bool dc_sums, bool &bad_out, HuffEmit &em, uint32_t &last_block_end) {
     const JP_LDS HuffSyncJob &job = L.job;
     DevBits b;
     huff_open_at(b, column, first_dword, pos);
@@ -225,7 +211,7 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
             // (k - 1: the zig-zag index of the coefficient just read, 0 for a DC value; the expansion turns it into the natural position)
             const uint32_t ent = (((k - 1u) & 63u) << 16) | (c << 22) | (uint32_t)(uint16_t)val;
             if (EMIT == 2) {
-                if (put && em.n < em.cap) (em.n < em.split ? em.side : em.buf)[em.n] = ent;
+                if (put && em.n < em.cap) em.buf[em.n] = ent;
                 em.n += put ? 1u : 0u;
             } else {
                 huff_emit_entry_if(em, ent, put);
@@ -234,34 +220,12 @@ __device__ __forceinline__ uint32_t huff_sync_run(JP_LDS HuffSyncLds &L, const u
         if (k >= 64u && badv == 0u) {  // end of the block
             k = 0u;
             nblk++;
-            const uint32_t pe = huff_bit_pos(b);
-            last_block_end = pe;
+            last_block_end = huff_bit_pos(b);
             q = q + 1u == bpm ? 0u : q + 1u;
             qt = L.q_tables[q];
             c = job.q_comp[q];
-            if (EMIT && pe >= cp.next) {  // a checkpoint (several, if the block was long): the state goes into its record — or is the one it holds
-                const uint32_t qs = job.uniform ? 0u : q, counts = (em.n & 0xffffu) | (nblk << 16);
-                const uint32_t dc01 = dc_sums ? (dc[0] & 0xffffu) | (dc[1] << 16) : 0u, dc23 = dc_sums ? (dc[2] & 0xffffu) | (dc[3] << 16) : 0u;
-                do {
-                    JP_GLOBAL uint32_t *rec = cp.recs + cp.j * HUFF_CP_WORDS;
-                    if (EMIT == 2 && cp.j < cp.valid_old && em.n <= em.split) {
-                        const v4u old = *(const JP_GLOBAL v4u *)rec;
-                        if (old.x == pe && rec[4] == qs && (old.y & 0xffffu) >= cp.na_old) {
-                            cp.met = 1u;
-                            cp.old_counts = old.y;
-                            cp.old_dc01 = old.z;
-                            cp.old_dc23 = old.w;
-                        }
-                    }
-                    *(JP_GLOBAL v4u *)rec = v4u{pe, counts, dc01, dc23};
-                    rec[4] = qs;
-                    if (cp.met) break;
-                    cp.j++;
-                    cp.next = cp.j < HUFF_CP_N ? cp.next + cp.step : 0xffffffffu;
-                } while (pe >= cp.next);
-            }
         }
-    } while (badv == 0u && (EMIT != 2 || cp.met == 0u) && huff_bit_pos(b) < limit);
+    } while (badv == 0u && huff_bit_pos(b) < limit);
     bad_out = badv != 0u;
     return huff_bit_pos(b);
 }
@@ -307,8 +271,8 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     // mean walking half the scan) nor handed on (it would travel down the scan, one lane per pass, keeping the job unsettled).
     if (!span.first && pass != 0u && !huff_sync_state_plausible(job, span.start, pos, q, k)) return false;  // nothing to offer yet: keep what we have
     const bool emit = huff_emit_in_pass(job, pass);
-    const uint32_t qk_in = (q << 8) | k | (emit ? QK_EMITTED : 0u), qk_last = job.in_qk[i];
-    if (pass > 0u && pos == job.in_pos[i] && qk_in == qk_last) return false;  // same start as last time
+    const uint32_t qk_in = (q << 8) | k | (emit ? QK_EMITTED : 0u);
+    if (pass > 0u && pos == job.in_pos[i] && qk_in == job.in_qk[i]) return false;  // same start as last time
     job.in_pos[i] = pos;
     job.in_qk[i] = qk_in;
     const uint32_t limit = span.end;
@@ -319,74 +283,23 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     if (dc_sums) dc[0] = dc[1] = dc[2] = dc[3] = 0u;
     uint32_t last_block_end = 0;
     HuffEmit em;
-    HuffCp cp;
-    const bool late = emit && pass >= job.late_pass;
-    v4u desc_last = v4u{0u, 0u, 0u, 0u};
-    JP_GLOBAL v4u *desc = (JP_GLOBAL v4u *)(job.list_desc + (size_t)i * HUFF_LIST_WORDS);
     if (emit) {
         em.buf = (JP_GLOBAL uint32_t *)(job.emit + (size_t)i * job.emit_stride);
         em.cap = job.emit_stride;
-        cp.recs = (JP_GLOBAL uint32_t *)(job.cps + (size_t)i * (HUFF_CP_N * HUFF_CP_WORDS));
-        cp.step = (1u << job.chunk_shift) >> 3;
-        cp.next = span.start + cp.step;
-        // a late run over a chunk whose last run left a list and records: it may stop where it meets that run (huff_job.hpp, checkpoints)
-        if (late && (qk_last & QK_EMITTED) != 0u && job.emit_cnt[i] != HUFF_EMIT_OVERFLOW) {
-            desc_last = *desc;
-            cp.valid_old = desc_last.y & 0xffu;
-#ifdef JPGPU_HOST_EMULATION
-            if (getenv("EMU_NO_MEET")) cp.valid_old = 0u;
-#endif
-            cp.na_old = desc_last.x & 0xffffu;
-            if (cp.valid_old) {
-                em.side = (JP_GLOBAL uint32_t *)(job.emit_side + (size_t)i * huff_emit_side(job.emit_stride));
-                em.split = huff_emit_side(job.emit_stride);
-            }
-        }
     }
+    const bool late = emit && pass >= job.late_pass;
     if (pos < limit) {
         const uint32_t *column = job.weave + huff_weave_at(job.chunk_shift, i, 0u);
         const uint32_t w0 = span.start >> 5;
-        if (late) pos = huff_sync_run<2>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end, cp);
-        else if (emit) pos = huff_sync_run<1>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end, cp);
-        else pos = huff_sync_run<0>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end, cp);
-    }
-#ifdef JPGPU_HOST_EMULATION
-    g_huff_emu_late_runs += cp.valid_old ? 1u : 0u;
-    g_huff_emu_met += cp.met;
-#endif
-    if (cp.met) {
-        // In step with the chunk's last run at record cp.j: what that run decoded from there on stands — its end state (nothing new to
-        // publish), its entries from the record's on; what came before is what this run has put into the side buffer.  Counts and
-        // DC sums of the chunk, and of the records behind this one, move by what the two runs differ by up to here.
-        const uint32_t n_last = job.emit_cnt[i] & 0xffffu, n_rec = cp.old_counts & 0xffffu;
-        const uint32_t lead = em.lead != 0xffffffffu ? em.lead : em.n;  // (no block has started yet: the next entry, the old list's, starts one)
-        job.emit_cnt[i] = ((em.n + (n_last - n_rec)) & 0xffffu) | (lead << 16);
-        const uint32_t dc01 = dc_sums ? (dc[0] & 0xffffu) | (dc[1] << 16) : 0u, dc23 = dc_sums ? (dc[2] & 0xffffu) | (dc[3] << 16) : 0u;
-        const uint32_t by01 = huff_sub16x2(dc01, cp.old_dc01), by23 = huff_sub16x2(dc23, cp.old_dc23);
-        const uint32_t by_counts = huff_sub16x2((em.n & 0xffffu) | (nblk << 16), cp.old_counts);
-        *desc = v4u{em.n | (((desc_last.x >> 16) + (n_rec - cp.na_old)) << 16), desc_last.y, huff_add16x2(desc_last.z, by01), huff_add16x2(desc_last.w, by23)};
-        job.n_blocks[i] = (job.n_blocks[i] + (by_counts >> 16)) & 0xffffu;  // (fewer blocks than the last run counted, or more)
-        if (dc_sums) {
-            job.dc_sum[2u * i] = huff_add16x2(job.dc_sum[2u * i], by01);
-            job.dc_sum[2u * i + 1u] = huff_add16x2(job.dc_sum[2u * i + 1u], by23);
-        }
-        for (uint32_t j = cp.j + 1u; j < cp.valid_old; j++) {
-            JP_GLOBAL v4u *rec = (JP_GLOBAL v4u *)(cp.recs + j * HUFF_CP_WORDS);
-            const v4u r = *rec;
-            *rec = v4u{r.x, huff_add16x2(r.y, by_counts), huff_add16x2(r.z, by01), huff_add16x2(r.w, by23)};
-        }
-        return false;
+        if (late) pos = huff_sync_run<2>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else if (emit) pos = huff_sync_run<1>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        else pos = huff_sync_run<0>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
     }
     if (job.emit != nullptr) {
         job.blk_end[i] = last_block_end;
         if (!late) huff_emit_finish(em);  // (a late pass has stored every entry already)
         // (pass 0 leaves an empty list behind: the word is never what an earlier batch left there)
-        const bool overflow = em.n > em.cap;
-        job.emit_cnt[i] = !emit ? 0u : (overflow ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
-        if (emit) {  // the list: entries below em.split in the side buffer, the others where they always are; cp.j records
-            const uint32_t na = min(em.n, em.split);
-            *desc = v4u{na | (na << 16), overflow ? 0u : cp.j, 0u, 0u};
-        }
+        job.emit_cnt[i] = !emit ? 0u : (em.n > em.cap ? HUFF_EMIT_OVERFLOW : (em.n | (min(em.lead, em.n) << 16)));
     }
     if (dc_sums) {
         job.dc_sum[2u * i] = (dc[0] & 0xffffu) | (dc[1] << 16);

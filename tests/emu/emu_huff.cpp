@@ -48,14 +48,13 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
             if (open) blk++;
             open = false;
         };
-        uint32_t late_dc[4] = {0, 0, 0, 0};
-        auto put = [&](uint32_t ent, bool behind) {
+        auto put = [&](uint32_t ent) {
             static const uint8_t kUnzig[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
             const uint32_t c = sj.q_comp[blk % sj.bpm], z = kUnzig[(ent >> 16) & 63u];  // (an entry carries the zig-zag index)
             if (!sj.uniform && c != ((ent >> 22) & 3u)) g_emit_mismatch++;  // (the component the lane wrote into the entry)
             uint32_t v = ent & 0xffffu;
-            if (huff_entry_is_dc(ent) && !sj.uniform) v = (v + pred[c] + (behind ? late_dc[c] : 0u)) & 0xffffu;
+            if (huff_entry_is_dc(ent) && !sj.uniform) v = (v + pred[c]) & 0xffffu;
             cur[z] = (int16_t)(uint16_t)v;
             const int32_t sv = (int16_t)(uint16_t)v;
             const uint32_t a = (uint32_t)(sv < 0 ? -sv : sv) * sj.q[c][z];
@@ -67,23 +66,19 @@ static void emu_expand(const HuffSyncJob& sj, HuffRange& rg) {
                 }
             }
         };
-        // (the list may be in two pieces, and the second piece's DC values off by a constant: huff_job.hpp, checkpoints)
-        const uint32_t* desc = sj.list_desc + (size_t)i * HUFF_LIST_WORDS;
-        const HuffListAt list = huff_list_at(sj.emit, sj.emit_side, sj.emit_stride, i, desc[0]);
-        late_dc[0] = desc[2] & 0xffffu, late_dc[1] = desc[2] >> 16, late_dc[2] = desc[3] & 0xffffu, late_dc[3] = desc[3] >> 16;
+        const uint32_t* buf = sj.emit + (size_t)i * sj.emit_stride;
         for (uint32_t e = lead; e < cnt; e++) {
-            const uint32_t ent = *huff_list_entry(list, e);
-            if (huff_entry_is_dc(ent)) {
+            if (huff_entry_is_dc(buf[e])) {
                 flush();
                 memset(cur, 0, sizeof(cur));
                 open = true;
             }
-            put(ent, e >= list.na);
+            put(buf[e]);
         }
         for (uint32_t j = i + 1; open && j < seg_end_chunk; j++) {  // the rest of the last block
             const uint32_t cj = sj.emit_cnt[j], cntj = std::min(cj & 0xffffu, sj.emit_stride), leadj = std::min(cj >> 16, cntj);
-            const HuffListAt lj = huff_list_at(sj.emit, sj.emit_side, sj.emit_stride, j, sj.list_desc[(size_t)j * HUFF_LIST_WORDS]);
-            for (uint32_t e = 0; e < leadj; e++) put(*huff_list_entry(lj, e), false);
+            const uint32_t* bj = sj.emit + (size_t)j * sj.emit_stride;
+            for (uint32_t e = 0; e < leadj; e++) put(bj[e]);
             if (leadj < cntj) break;
         }
         flush();
@@ -105,11 +100,6 @@ void emu_huff_set_dri(uint32_t shift) { g_dri_shift = shift; }
 void emu_huff_set_late(uint32_t pass) { g_late = pass; }
 void emu_huff_set_tail(uint32_t eighths) { g_tail = eighths >= 1 && eighths <= 8 ? eighths : 8; }
 void emu_huff_last_range(uint32_t out[2]) { out[0] = g_range[0], out[1] = g_range[1]; }
-// late runs over chunks with checkpoint records since the last call, and how many of them stopped at one (huff_job.hpp, checkpoints)
-void emu_huff_late_runs(uint32_t out[2]) {
-    out[0] = g_huff_emu_late_runs, out[1] = g_huff_emu_met;
-    g_huff_emu_late_runs = g_huff_emu_met = 0;
-}
 void emu_huff_set_launch(uint32_t iters, uint32_t workgroup, uint32_t stale) {
     g_sync_stale = stale;
     g_sync_iters = iters ? iters : 1u;
@@ -233,11 +223,6 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             emit_cnt.assign(sj.n_chunks, 0xCDCDCDCDu);
             sj.emit = emit_buf.data();
             sj.emit_cnt = emit_cnt.data();
-            std::vector<uint32_t> side_buf((size_t)sj.n_chunks * huff_emit_side(sj.emit_stride) + 1, 0xBABABABAu), desc_buf((size_t)sj.n_chunks * HUFF_LIST_WORDS, 0xDCDCDCDCu),
-                cp_buf((size_t)sj.n_chunks * HUFF_CP_N * HUFF_CP_WORDS, 0xCECECECEu);
-            sj.emit_side = side_buf.data();
-            sj.list_desc = desc_buf.data();
-            sj.cps = cp_buf.data();
             std::vector<uint32_t> arr(8 * (size_t)sj.n_chunks, 0xCDCDCDCDu);
             sj.blk_end = arr.data() + 7 * (size_t)sj.n_chunks;
             sj.in_pos = arr.data();
@@ -296,7 +281,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
             if (pass == 32) status |= 1u | 64u;
             if (sj.n_seg > 1u) {  // (huff_sync_scan_kernel, restart segments: one thread per segment)
                 for (uint32_t seg = 0; seg < sj.n_seg; seg++) status |= huff_emit_segment_scan(sj, seg);
-                if (emit_buf.back() != 0xABABABABu || side_buf.back() != 0xBABABABAu) status |= 0x8000u;
+                if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;
             } else {
                 uint32_t run = 0;
                 for (uint32_t i = 0; i < sj.n_chunks; i++) {  // exclusive scan
@@ -306,7 +291,7 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                     status |= huff_emit_chunk_status(sj, i, run);
                 }
                 status |= huff_emit_final_status(sj, run);
-                if (emit_buf.back() != 0xABABABABu || side_buf.back() != 0xBABABABAu) status |= 0x8000u;  // a lane wrote past its buffer
+                if (emit_buf.back() != 0xABABABABu) status |= 0x8000u;  // a lane wrote past its buffer
                 if (!sj.uniform) {  // (huff_sync_scan_kernel) sums of DC differences -> predictors at the start of every chunk
                     uint32_t acc[4] = {0, 0, 0, 0};
                     for (uint32_t i = 0; i < sj.n_chunks; i++) {

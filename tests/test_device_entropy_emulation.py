@@ -457,40 +457,3 @@ def test_restart_streams_whose_components_share_their_tables(case, emission):
     for c in range(desc.ncomp):
         assert np.array_equal(planes[c], hcoefs[c]), c
     _check_range_by_product(desc, planes)
-
-
-def _late_runs():
-    out = (C.c_uint32 * 2)()
-    emu.lib().emu_huff_late_runs(out)
-    return int(out[0]), int(out[1])
-
-
-@pytest.mark.parametrize("tail", [1, 2, 3, 8])
-@pytest.mark.parametrize("case", [(1920, 1080, 2, 0, 85), (1280, 720, 0, 0, 92), (801, 603, 1, 0, 50), (1024, 768, 2, 4, 85), (640, 480, 2, 0, 20)],
-                         ids=lambda c: "%dx%d-s%d-r%d-q%d" % c)
-def test_late_runs_stop_where_they_meet_the_last_run(case, tail):
-    """Checkpoints (csrc/huff_job.hpp): a lane whose start state is corrected in a late pass stops at the first checkpoint it reaches
-    in the state its last run was in there, and the chunk's list becomes its entries + the old list's from that record on.  The
-    shorter the walk of the first pass (tail: eighths of a chunk), the more lanes start pass 1 from a wrong state and are corrected
-    late: most of them must stop early, and the planes must be the host decoder's whatever the lists are made of."""
-    w, h, sub, rrows, q = case
-    data = _pil_jpeg(w, h, sub, restart_rows=rrows, quality=q, seed=w + tail)
-    emu.lib().emu_huff_set_tail(tail)
-    emu.lib().emu_huff_set_late(2)
-    try:
-        _late_runs()
-        got = _device(data)
-    finally:
-        emu.lib().emu_huff_set_tail(8)
-    assert got is not None
-    st, desc, planes, _ns, _nseg = got
-    assert st == 0
-    hdesc, hcoefs = _host(data)
-    for c in range(desc.ncomp):
-        assert np.array_equal(planes[c], hcoefs[c]), c
-    _check_range_by_product(desc, planes)
-    runs, met = _late_runs()
-    print("late runs", runs, "stopped at a checkpoint", met)
-    assert met * 2 >= runs, (runs, met)  # (a run that does not meet the old one inside its chunk walks on: rare)
-    if tail <= 3 and w == 1920:
-        assert runs > 0
