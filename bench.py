@@ -89,7 +89,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (weak scaling; default: the workload's at N = 1)")
     ap.add_argument("--images-total", type=int, default=0,
                     help="images in the whole job, sharded over the ranks (strong scaling; default at N > 1: 4096)")
-    ap.add_argument("--sub-batches", type=int, default=0, help="launch groups per step (default: 1 at N = 1, 8 at N > 1)")
+    ap.add_argument("--sub-batches", type=int, default=0, help="launch groups per step (default: 1 at N = 1; at N > 1 up to 8, none smaller than 64 images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
     ap.add_argument("--generic", action="store_true", help="force the two-kernel generic path")
@@ -339,6 +339,9 @@ def e2e_files(synth, w, h, encoder, distinct=4, restart_rows=0):
     return [E.encode_rgb(rgb, 85, "420", ri) for rgb in rgbs], f"tools/baseline_encoder.py (this repo), quality 85, 4:2:0, Annex K Huffman tables, {rst}"
 
 
+VALU_CYCLES = 4.6  # issue cycles per wave64 vector instruction of the decoder's kind (measured: see sync_pass_instructions)
+
+
 def sync_pass_instructions(symbols_per_call):
     """Vector instructions of the chunk decoder's sync passes per Huffman symbol, from the committed counter passes of a 256-file
     call as one sub-batch (profiles/roundN/*pipeline_256*pmc*.json: SQ_INSTS_VALU per dispatch x dispatches, all sync launches of
@@ -350,15 +353,24 @@ def sync_pass_instructions(symbols_per_call):
                 doc = json.load(open(f))
             except (OSError, ValueError):
                 continue
-            wave_instr = 0.0
+            wave_instr = every = 0.0
             for name, e in doc.items():
-                if "huff_sync_pass_kernel" in name and "pmc" in e and "SQ_INSTS_VALU" in e["pmc"]:
+                if not isinstance(e, dict) or "pmc" not in e or "SQ_INSTS_VALU" not in e["pmc"]:
+                    continue
+                every += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
+                if "huff_sync_pass_kernel" in name:
                     wave_instr += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
             calls = doc.get("_calls_of_the_pipeline") or 6  # (tools/pipe_calls.py / round 3's script: six calls per profiled process)
             if wave_instr:
                 per_call = wave_instr / calls
+                # What the vector units alone need for a call's kernels: every wave-instruction occupies its SIMD for VALU_CYCLES cycles
+                # (profiles/round4/02_ubench_valu64.txt, round2/00_valu_issue_cost_ubench.txt: 4.5-4.9 for the shifts, selects and
+                # logic the decoder is made of), 1,024 SIMDs at 2.4 GHz — a floor no overlap of sub-batches gets under.
+                issue_ms_per_image = every / calls / 256.0 * VALU_CYCLES / (1024 * 2.4e9) * 1e3
                 return {"wave_instructions_per_symbol": round(per_call / symbols_per_call, 2), "lane_slots_per_symbol": round(64 * per_call / symbols_per_call, 1),
-                        "source": os.path.relpath(f, ROOT) + " (SQ_INSTS_VALU of every huff_sync_pass_kernel dispatch of one 256-file call; read from the file, not measured in this run)"}
+                        "all_kernels_wave_instructions_per_image": int(every / calls / 256.0), "vector_issue_floor_ms_per_image": round(issue_ms_per_image, 5),
+                        "vector_issue_floor_what": f"SQ_INSTS_VALU of every kernel of the call x {VALU_CYCLES} cycles / (1,024 SIMDs x 2.4 GHz)",
+                        "source": os.path.relpath(f, ROOT) + " (SQ_INSTS_VALU per dispatch of one 256-file call as one sub-batch; read from the file, not measured in this run)"}
     return None
 
 
@@ -432,8 +444,12 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
                     "kernels_only_images_per_s": round(256 / sum(km.values()) * 1e3, 1), "total_ms": round(best["total_ms"], 3)}
                 # every E entry against its own floors (VERDICT r3 next #1a)
                 symbols = sum(huffman_symbols(J, d) for d in distinct) / len(distinct)
+                spi = sync_pass_instructions(256 * symbols)
                 for key, b in bests.items():
                     e2e_floor_fields(out[key], b, h2d_gbps, sum(km.values()) / 256.0)
+                    if spi:
+                        out[key]["vector_issue_floor_ms"] = round(spi["vector_issue_floor_ms_per_image"] * out[key]["images"], 3)
+                        out[key]["frac_of_hard_floor"] = round(max(out[key]["vector_issue_floor_ms"], out[key]["link_floor_ms"] or 0.0) / out[key]["total_ms"], 4)
                 out["roofline"] = {
                     "h2d_gbps": round(h2d_gbps, 2) if h2d_gbps else None,
                     "h2d_what": "one pinned 1-GB host-to-device copy, best of 3, this run",
@@ -442,8 +458,11 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
                                         "(the late sync passes' chains included: an upper estimate of the work, a lower one of a lone sub-batch's latency)",
                     "huffman_symbols_per_image": int(symbols), "bits_per_symbol": round(out["jpeg_bytes_per_image"] * 8 / symbols, 2),
                     "sync_ns_per_symbol": round(km["sync_ms"] * 1e6 / (256 * symbols), 4),
-                    "sync_pass_vector_instructions": sync_pass_instructions(256 * symbols),
-                    "frac_of_floor": "max(link_floor_ms, device_work_ms) / total_ms per entry: 1.0 = the call takes what its larger floor takes"}
+                    "sync_pass_vector_instructions": spi,
+                    "frac_of_floor": "max(link_floor_ms, device_work_ms) / total_ms per entry: 1.0 = the call takes what its larger floor takes "
+                                     "(device_work_ms is measured, not a bound: overlapping sub-batches get under it)",
+                    "frac_of_hard_floor": "max(link_floor_ms, vector_issue_floor_ms) / total_ms: the two floors nothing gets under — the PCIe link and the "
+                                          "vector instructions the kernels issue"}
         finally:
             del os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"]
         files_for_cpu = [distinct[i % len(distinct)] for i in range(256)]
@@ -827,7 +846,9 @@ def main(argv=None):
     images_total = args.images_total or (CONFIG3_IMAGES_TOTAL if world > 1 and not args.batch else 0)
     import jpeg_decoder_amd.distributed as D
     n_img = len(D.shard(images_total, rank, world)) if images_total else (args.batch or default_batch)
-    n_sub = args.sub_batches or (1 if world == 1 else 8)
+    # N > 1: launch groups exist so that the gather of one group's pixels runs behind the decode of the next; a group below ~64 images does
+    # not fill the device (2160p, 8 images per group: 0.47 of the roofline against 0.58 in one launch, profiles/round3/10_other_workloads_bench.jsonl)
+    n_sub = args.sub_batches or (1 if world == 1 else min(8, max(1, n_img // 64)))
     steps = args.steps or (500 if world == 1 else 40)
     warmup = args.warmup if args.warmup >= 0 else (50 if world == 1 else 5)
     if args.dry_run:

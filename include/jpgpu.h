@@ -179,23 +179,6 @@ int jpgpu_batch_set_range_hint(jpgpu_batch *b, uint32_t image, int sane);
  * no device needed) — for feeders that stage coefficients themselves (jpgpu_pipeline_*, jpgpu_decoder.h). */
 int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, int range_class);
 int jpgpu_range_class(const int16_t *coefficients, size_t len, const uint16_t quantization_table[64]);
-/* Progressive accumulation ON THE DEVICE (the reference accumulates in host memory, src/decoder.rs:400-412; every update
- * it makes — :1118,1137,1164-1165,1191,1250,1286-1292 — is expressible as coefficient += delta): instead of uploading a
- * component's plane once its last scan has finished, send what each scan changed.
- *   jpgpu_batch_clear_coefficients: zero the image's planes (enqueued on hip_stream).
- *   jpgpu_batch_add_deltas: coefficient[entries[k].index] += entries[k].delta (i16 wrapping) in component `comp` of
- *   `image`; index = block number in raster order * 64 + position in natural order.  An index must not occur twice in
- *   one call; calls on the same stream are applied in order.  `entries` is host memory and must stay valid until the
- *   stream has been synchronised.  The image's range class is worked out on the device from what the kernel adds up
- *   (every value a coefficient takes is ranged with the component's quantization table as the device holds it; see
- *   jpgpu_batch_classify_on_device). */
-typedef struct jpgpu_coef_delta {
-    uint32_t index;
-    int32_t delta;
-} jpgpu_coef_delta;
-int jpgpu_batch_clear_coefficients(jpgpu_batch *b, uint32_t image, void *hip_stream);
-int jpgpu_batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const jpgpu_coef_delta *entries, size_t n,
-                           void *hip_stream);
 /* The same classification done ON THE DEVICE for every image of the batch, from the coefficients as they stand in the
  * arena (written there by the caller's own kernels or copies into a bound arena, or by the device entropy decoder):
  * one pass over the arena at HBM speed on `hip_stream`, blocking; afterwards every component has the range class
@@ -206,7 +189,7 @@ int jpgpu_batch_scan_ranges(jpgpu_batch *b, void *hip_stream, uint8_t *classes);
  * there (a few-microsecond kernel in front of the pixel kernels, which pick their arithmetic per workgroup) — no host
  * synchronisation between whoever wrote the coefficients and the pixel kernels.  The library's own writers leave the same
  * statistics as a by-product and need no pass at all: the device entropy decoder (jpgpu_pipeline_decode with
- * JPGPU_PIPELINE_DEVICE_ENTROPY), jpgpu_batch_upload_compact with range_class < 0, jpgpu_batch_add_deltas.  A class set from
+ * JPGPU_PIPELINE_DEVICE_ENTROPY), jpgpu_batch_upload_compact with range_class < 0.  A class set from
  * the host afterwards (upload, set_range_hint / set_range_class, scan_ranges) takes over again for that component. */
 int jpgpu_batch_classify_on_device(jpgpu_batch *b, void *hip_stream);
 /* Replace the quantization table given in the image descriptor (RowData.quantization_table of Worker::start,

@@ -121,10 +121,7 @@ enum {
                                    * per chunk of 64 bytes to 4 kB, csrc/huff_sync_core.hpp; a restart segment — src/decoder.rs:920-956:
                                    * segments are independent — is a scan in miniature with chunk slots of its own); every
                                    * other stream, and any stream the device decoder flags, takes the host path */
-    , JPGPU_PIPELINE_PROGRESSIVE_DELTAS = 8u /* progressive streams (host-decoded): accumulate the coefficients ON THE DEVICE —
-                                   * after every scan the host sends what the scan changed (jpgpu_batch_add_deltas) instead of
-                                   * the finished planes at the end; same pixels (A/B switch, off by default:
-                                   * more PCIe bytes than the compact planes and nothing off the critical path) */
+    /* (8u: round 2-3's per-scan delta transport for progressive streams — measured 2.5 x slower than the compact planes, deleted in round 4) */
     , JPGPU_PIPELINE_GATHER = 16u /* pipelines over several devices: after the decode copy every device's pixels to the FIRST device of
                                    * the list (peer-to-peer, one xGMI link per peer; SURVEY 8e, north_star's final gather);
                                    * jpgpu_pipeline_pixels_device then points into that copy */

@@ -71,7 +71,7 @@ class PipelineTimings(C.Structure):
                [("gather_bytes", C.c_uint64)]
 
 
-PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_PROGRESSIVE_DELTAS, PIPELINE_GATHER = 1, 2, 4, 8, 16
+PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_GATHER = 1, 2, 4, 16
 PIPELINE_MULTI_PIN_CPUS = 1
 
 
@@ -128,8 +128,6 @@ _PROTOS = {
     "jpgpu_batch_set_range_class": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "jpgpu_batch_scan_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jpgpu_batch_classify_on_device": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "jpgpu_batch_clear_coefficients": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
-    "jpgpu_batch_add_deltas": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_range_class": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "jpgpu_batch_set_quantization_table": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "jpgpu_compact_max_bytes": (C.c_size_t, [C.c_size_t]),

@@ -105,16 +105,6 @@ class Batch:
         """0 unknown/hostile, 1 every |c*q| < 2^15, 3 additionally every block-column sum of |c*q| <= 5900."""
         self._check(N.lib().jpgpu_batch_set_range_hint(self._h, image, int(range_class)))
 
-    def clear_coefficients(self, image, stream=None):
-        self._check(N.lib().jpgpu_batch_clear_coefficients(self._h, image, stream))
-
-    def add_deltas(self, image, comp, index, delta, stream=None):
-        """coefficient[index[k]] += delta[k] on the device (progressive accumulation, include/jpgpu.h); blocks until done."""
-        e = np.empty(len(index), dtype=[("index", np.uint32), ("delta", np.int32)])
-        e["index"], e["delta"] = index, delta
-        self._check(N.lib().jpgpu_batch_add_deltas(self._h, image, comp, e.ctypes.data, len(e), stream))
-        self.synchronize(stream)  # `e` is about to go away
-
     def scan_ranges(self, stream=None):
         """Range classes from the coefficients as they stand in the device arena (one pass at HBM speed): [image][comp]."""
         out = np.zeros((self.n_images, 4), np.uint8)
@@ -123,8 +113,8 @@ class Batch:
 
     def classify_on_device(self, stream=None):
         """jpgpu_batch_classify_on_device: range statistics of the arena's coefficients gathered and kept ON THE DEVICE
-        (asynchronous, no read-back); decode() then takes the classes from them there.  The device entropy decoder,
-        upload_compact(..., classify=False) and add_deltas leave the same statistics as a by-product."""
+        (asynchronous, no read-back); decode() then takes the classes from them there.  The device entropy decoder and
+        upload_compact(..., classify=False) leave the same statistics as a by-product."""
         self._check(N.lib().jpgpu_batch_classify_on_device(self._h, stream))
 
     def class_counts(self):

@@ -89,12 +89,6 @@ struct jpgpu_batch {
     size_t scan_cap = 0;
     bool scan_jobs_valid = false;  // the job table on the device matches the bound arena and the current q-tables
     uint8_t *h_bounce = nullptr;  // pinned: jpgpu_batch_download into pageable memory
-    struct DeltaScratch {          // jpgpu_batch_add_deltas: device copy of the entries, one per stream in use
-        hipStream_t stream;
-        uint8_t *d;
-        size_t cap;
-    };
-    std::deque<DeltaScratch> delta_scratch;
     size_t h_bounce_cap = 0;
     std::vector<uint32_t> entropy_images;  // images of the launch in flight
     size_t entropy_out_off = 0;            // offset of the status / stats words inside d_entropy
@@ -110,10 +104,6 @@ struct jpgpu_batch {
     uint32_t cls_next = 0;
     uint32_t *d_plane_job_slot = nullptr;  // generic path: plane job -> image * 4 + comp
     std::vector<uint8_t> cls_src;
-    // per image * 4 + comp: the device statistics miss some of this component's coefficients (an add_deltas while a changed
-    // quantization table was waiting to be sent, or values ranged with a table that has been replaced since): the component stays
-    // host-sourced at class 0 until the image's coefficients are cleared, re-scanned or written anew as a whole
-    std::vector<uint8_t> stats_incomplete;
     bool dev_classes = false;
     bool cls_dirty = true;              // class knowledge changed since the tables / the class table were last sent
     // JPGPU_BATCH_KERNEL_TIMES (diagnostics, jpgpu_pipeline_timings): events around the phases of the device entropy path
@@ -271,7 +261,6 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
     b->out_len.assign(n_images, 0);
     b->sane.assign((size_t)n_images * 4, 0);
     b->cls_src.assign((size_t)n_images * 4, 0);
-    b->stats_incomplete.assign((size_t)n_images * 4, 0);
     // path resolution: group the images that can share a fused launch, the rest is generic
     std::vector<uint32_t> kind_key(n_images, 0);
     if (!(flags & JPGPU_BATCH_FORCE_GENERIC))
@@ -419,8 +408,6 @@ void jpgpu_batch_destroy(jpgpu_batch *b) {
             if (e) hipEventDestroy(e);
         for (auto &e : b->ev_phase)
             if (e) hipEventDestroy(e);
-        for (auto &x : b->delta_scratch)
-            if (x.d) hipFree(x.d);
         if (b->d_plane_jobs) hipFree(b->d_plane_jobs);
         if (b->d_image_jobs) hipFree(b->d_image_jobs);
         if (b->d_scaled_geoms) hipFree(b->d_scaled_geoms);
@@ -497,82 +484,6 @@ int jpgpu_batch_set_range_class(jpgpu_batch *b, uint32_t image, uint32_t comp, i
     batch_set_host_class(b, (size_t)image * 4 + comp, (uint8_t)(range_class & 3));
     return JPGPU_OK;
 }
-
-int jpgpu_batch_clear_coefficients(jpgpu_batch *b, uint32_t image, void *hip_stream) {
-    if (!b || image >= b->descs.size()) return JPGPU_ERR_FORMAT;
-    int rc = use_device(b->device, b->err);
-    if (rc) return rc;
-    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
-    const uint32_t nc = b->descs[image].ncomp;
-    const size_t first = b->coef_off[(size_t)image * 4], last = b->coef_off[(size_t)image * 4 + nc - 1] + b->coef_len[(size_t)image * 4 + nc - 1];
-    B_HIP(hipMemsetAsync(b->d_coef + first, 0, last - first, (hipStream_t)hip_stream));
-    // an accumulation starts: so do the image's range statistics (jpgpu_batch_add_deltas raises them)
-    rc = batch_enable_dev_classes(b);
-    if (rc) return rc;
-    B_HIP(hipMemsetAsync(b->d_stats + (size_t)image * RS_WORDS, 0, RS_WORDS * sizeof(uint32_t), (hipStream_t)hip_stream));
-    for (uint32_t c = 0; c < 4; c++) b->stats_incomplete[(size_t)image * 4 + c] = 0;
-    return JPGPU_OK;
-}
-
-int jpgpu_batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const jpgpu_coef_delta *entries, size_t n, void *hip_stream) {
-    return jpgpu::batch_add_deltas(b, image, comp, entries, n, hip_stream, false);
-}
-
-}  // extern "C"
-
-int jpgpu::batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const jpgpu_coef_delta *entries, size_t n, void *hip_stream, bool trusted) {
-    if (!b || image >= b->descs.size() || comp >= b->descs[image].ncomp || (!entries && n)) return JPGPU_ERR_FORMAT;
-    int rc = use_device(b->device, b->err);
-    if (rc) return rc;
-    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
-    const size_t idx = (size_t)image * 4 + comp, plane = b->coef_len[idx] / sizeof(int16_t);
-    if (n > 0xFFFFFFFFu) return set_err(b->err, JPGPU_ERR_FORMAT, "add_deltas: too many entries");
-    for (size_t k = 0; !trusted && k < n; k++)
-        if (entries[k].index >= plane) return set_err(b->err, JPGPU_ERR_FORMAT, "add_deltas: index outside the component's plane");
-    // the finished plane's class comes from the statistics the kernel raises while it adds (every value a coefficient takes is
-    // ranged; a caller that never cleared the image keeps whatever the statistics held: they only grow)
-    // The kernel ranges with the table the device holds (the descriptor's, or the last one a decode sent): while a changed
-    // table is waiting to be sent, the statistics cannot be trusted and the component stays "unknown" (wrap-exact kernels);
-    // jpgpu_batch_set_quantization_table with a different table resets the class as well.
-    rc = batch_enable_dev_classes(b);
-    if (rc) return rc;
-    b->sane[idx] = 0;
-    // Once a call could not be ranged the statistics under-estimate this component for good: it stays "unknown" (host class 0)
-    // whatever later calls range, until jpgpu_batch_clear_coefficients / jpgpu_batch_classify_on_device start them afresh.
-    if (b->qt_dirty) b->stats_incomplete[idx] = 1;
-    const bool ranged = !b->stats_incomplete[idx];
-    batch_class_source(b, idx, ranged);
-    if (n == 0) return JPGPU_OK;
-    hipStream_t s = (hipStream_t)hip_stream;
-    // One device buffer per stream the caller uses, reused call after call: the stream orders "kernel k has read it" before
-    // "copy k+1 overwrites it".  (The stream-ordered allocator was the first choice — hipMallocAsync / hipFreeAsync per call —
-    // and lost the entries of the very first call of a process now and then.)
-    jpgpu_batch::DeltaScratch *sc = nullptr;
-    {
-        std::lock_guard<std::mutex> g(b->compact_mutex);
-        for (auto &x : b->delta_scratch)
-            if (x.stream == s) sc = &x;
-        if (!sc) {
-            b->delta_scratch.push_back(jpgpu_batch::DeltaScratch{s, nullptr, 0});
-            sc = &b->delta_scratch.back();
-        }
-    }
-    const size_t bytes = n * sizeof(jpgpu_coef_delta);
-    if (sc->cap < bytes) {
-        B_HIP(hipStreamSynchronize(s));  // (the buffer about to go may still be read)
-        if (sc->d) B_HIP(hipFree(sc->d));
-        sc->d = nullptr;
-        sc->cap = 0;
-        B_HIP(hipMalloc((void **)&sc->d, bytes + bytes / 2));
-        sc->cap = bytes + bytes / 2;
-    }
-    B_HIP(hipMemcpyAsync(sc->d, entries, bytes, hipMemcpyHostToDevice, s));
-    B_HIP(launch_delta_add(reinterpret_cast<const jpgpu_coef_delta *>(sc->d), (uint32_t)n, reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[idx]),
-                           (uint32_t)plane, b->d_qt + idx * 64, ranged ? b->d_stats + (size_t)image * RS_WORDS : nullptr, s));
-    return JPGPU_OK;
-}
-
-extern "C" {
 
 // the range-scan job table on the device (d_scan: [ stats of the blocking scan | RangeJob[] ]); slot = image * 4 + comp
 static int batch_scan_jobs(jpgpu_batch *b, uint32_t &n_jobs, uint32_t &max_blocks, size_t &jobs_off) {
@@ -660,7 +571,6 @@ int jpgpu_batch_classify_on_device(jpgpu_batch *b, void *hip_stream) {
     for (size_t i = 0; i < b->descs.size(); i++)
         for (uint32_t c = 0; c < b->descs[i].ncomp; c++) {
             b->sane[i * 4 + c] = 0;  // (the host does not know)
-            b->stats_incomplete[i * 4 + c] = 0;  // (a full scan with the current tables)
             batch_class_source(b, i * 4 + c, true);
         }
     return JPGPU_OK;
@@ -673,7 +583,6 @@ int jpgpu_batch_set_quantization_table(jpgpu_batch *b, uint32_t image, uint32_t 
     // the range class of coefficients already uploaded was computed with the old table (|c*q| bounds): unknown again
     // (statistics the device gathered with the old table included)
     batch_set_host_class(b, (size_t)image * 4 + comp, 0);
-    b->stats_incomplete[(size_t)image * 4 + comp] = 1;  // (what the device ranged so far was ranged with the old table)
     b->scan_jobs_valid = false;
     b->qt_dirty = true;
     b->jobs_dirty = true;
@@ -750,8 +659,7 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
             if (rc) return rc;
             b->sane[idx] = 0;
             // (the whole plane is replaced and ranged, at expansion time, with the table the device then holds — batch_refresh_jobs
-            // runs first: whatever was missing of this component's statistics no longer matters; older maxima only over-estimate)
-            b->stats_incomplete[idx] = 0;
+            // runs first; older maxima only over-estimate)
             batch_class_source(b, idx, true);
         }
     }
@@ -976,7 +884,6 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         stat_images.push_back(img);
         for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the expansion leaves in d_stats
             b->sane[(size_t)img * 4 + c] = 0;
-            b->stats_incomplete[(size_t)img * 4 + c] = 0;  // (statistics zeroed by this launch's fills, every block written anew)
             batch_class_source(b, (size_t)img * 4 + c, true);
         }
         for (const host::PlannedScan &ps : *images[k].scans) {

@@ -499,27 +499,12 @@ struct Frontend::Impl {
     std::vector<uint8_t> exif, xmp;
     std::vector<IccChunk> icc;
     std::vector<PlannedScan> *plan = nullptr;  // plan_device_scans: describe scans instead of decoding them
-    // RowSink::scan_deltas: where the block decoders note what they change (null: nobody asked)
     // Per block of a progressive frame: which coefficients (zig-zag positions) are non-zero.  The refinement scans walk
     // bands of up to 63 coefficients per symbol to find the few that exist (src/decoder.rs:1260-1298 does it one by one:
     // 20 of the 27 ms a 1080p progressive image took); with the bitmap the walk costs the non-zero ones only.
     std::vector<uint64_t> nzmask[JPGPU_MAX_COMPONENTS];
     uint64_t *nz = nullptr;  // the current block's bitmap (null outside progressive frames)
-    std::vector<ScanDelta> *rec = nullptr;
-    const int16_t *rec_base = nullptr;  // start of the plane the current block belongs to
-    // A scan reports a coefficient at most once: on damaged streams the refinement pass can correct the last coefficient of a
-    // band and overwrite it right away (src/decoder.rs:1241-1252 with nothing left to skip) — the two changes are merged.
-    inline void record(const int16_t &c, int32_t delta) {
-        const uint32_t index = (uint32_t)(&c - rec_base);
-        if (!rec->empty() && rec->back().index == index) {
-            rec->back().delta += delta;
-            if (rec->back().delta == 0) rec->pop_back();
-        } else {
-            rec->push_back(ScanDelta{index, delta});
-        }
-    }
     inline void put(int16_t &c, int16_t v, uint8_t zz) {  // zz: the coefficient's zig-zag position
-        if (rec && v != c) record(c, (int32_t)v - (int32_t)c);
         if (nz) *nz = v ? (*nz | (1ull << zz)) : (*nz & ~(1ull << zz));
         c = v;
     }
@@ -853,7 +838,6 @@ struct Frontend::Impl {
             const int32_t apply = (int32_t)br.get_bits(src, 1) & (int32_t)((c & bit) == 0);
             const int32_t v = (int32_t)c + (((int32_t)c >> 31) | 1) * (int32_t)bit * apply;
             if (v > 32767 || v < -32768) fail(JPGPU_ERR_FORMAT, "Coefficient overflow");
-            if (rec && apply) record(c, v - (int32_t)c);
             c = (int16_t)v;
         }
         return hit ? stop : (uint8_t)(end - 1);
@@ -1192,12 +1176,10 @@ struct Frontend::Impl {
 
         const bool progressive = f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE;
         const bool interleaved = nc > 1;
-        const bool want_deltas = progressive && sink.wants_scan_deltas();
-        std::vector<ScanDelta> deltas[JPGPU_MAX_COMPONENTS];
-        struct RecOff {  // (the block decoders must not record into a vector that is gone)
+        struct NzOff {  // (the block decoders must not write into a bitmap of another frame)
             Impl *self;
-            ~RecOff() { self->rec = nullptr, self->nz = nullptr; }
-        } rec_off{this};
+            ~NzOff() { self->nz = nullptr; }
+        } nz_off{this};
         int16_t dummy[64];
         memset(dummy, 0, sizeof(dummy));
         BitReader br;
@@ -1245,8 +1227,6 @@ struct Frontend::Impl {
                                 auto &store = coefficients[scan.component_indices[i]];
                                 if (off + 64 > store.size()) fail(JPGPU_ERR_INTERNAL, "reference would panic: coefficient index");
                                 co = store.data() + off;
-                                rec = want_deltas ? &deltas[i] : nullptr;
-                                rec_base = store.data();
                                 nz = &nzmask[scan.component_indices[i]][off / 64];
                             } else if (finished[i]) {
                                 const uint32_t batch_row = interleaved ? 0 : my % c.vertical_sampling_factor;
@@ -1278,10 +1258,9 @@ struct Frontend::Impl {
                 }
             }
         }
-        rec = nullptr;
         nz = nullptr;
-        if (want_deltas)
-            for (int i = 0; i < nc; i++) sink.scan_deltas((uint32_t)scan.component_indices[i], deltas[i].data(), deltas[i].size());
+        if (progressive)
+            for (int i = 0; i < nc; i++) sink.scan_finished((uint32_t)scan.component_indices[i]);
         Marker m;
         bool has = br.take_marker(src, m);
         while (has && m.kind == Mk::RST) {  // :1063-1066  marker = self.read_marker().ok()

@@ -26,25 +26,15 @@ struct DecodeError {
 // The Worker boundary as the front-end sees it (trait Worker, src/worker/mod.rs:24-35).
 // `index` is scan-local in decode_scan and frame-local in decode_planes, exactly as in the
 // reference; finish() carries the frame-level slot the plane belongs to.
-// One coefficient changed by a progressive scan: coefficient `index` of the component's plane (block number in raster
-// order * 64 + position in natural order) grew by `delta` (every update of src/decoder.rs:1118,1137,1164-1165,1191,1250,
-// 1286-1292 is expressible as coefficient += delta).
-struct ScanDelta {
-    uint32_t index;
-    int32_t delta;
-};
-
 void trim_coefficient_pool();  // frees the idle accumulation planes of progressive frames (see frontend.cpp, CoefPool)
 
 class RowSink {
 public:
     virtual ~RowSink() {}
-    // Progressive frames only: a sink that answers true is told after every scan, per component of the scan, what the
-    // scan changed (scan_deltas; every coefficient at most once per call, zero changes left out) — enough to accumulate
-    // the planes elsewhere, e.g. on the device, while the remaining scans are still being decoded.  start / append_row /
-    // finish are called as usual (with the accumulated rows) and may be ignored by such a sink.
-    virtual bool wants_scan_deltas() { return false; }
-    virtual void scan_deltas(uint32_t /*frame_slot*/, const ScanDelta * /*d*/, size_t /*n*/) {}
+    // Progressive frames only: called after every scan, once per component of the scan (a clock for tools/host_bench.cpp; round 2-3's
+    // per-scan change lists — SURVEY §8f n3, coefficients accumulated on the device — were measured 2.5 x slower than the compact
+    // planes and deleted in round 4: profiles/round4/04_progressive_sizing.txt).
+    virtual void scan_finished(uint32_t /*frame_slot*/) {}
     // called right before start(index, ...): the frame component this worker index will deliver (finish()'s frame_slot),
     // for sinks that place rows at their final address instead of collecting them
     virtual void frame_slot_hint(uint32_t /*index*/, uint32_t /*frame_slot*/) {}

@@ -48,8 +48,6 @@ int batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const vo
 // before a worker goes back to the decoder API's pool of idle workers
 void worker_recycle(jpgpu_worker *w);
 
-// jpgpu_batch_add_deltas for entries recorded by the host front-end inside this library (no index check)
-int batch_add_deltas(jpgpu_batch *b, uint32_t image, uint32_t comp, const jpgpu_coef_delta *entries, size_t n, void *hip_stream, bool trusted);
 
 // ---- device entropy decoding of restart-marker streams (huff_core.hpp), used by the pipeline ----------------------
 namespace host {

@@ -119,31 +119,6 @@ __global__ __launch_bounds__(256) void expand_compact_kernel(const ExpandJob *__
     }
 }
 
-// Progressive accumulation on the device: coefficient[index] += delta for the changes one scan made to
-// one component plane.  One lane per entry; a scan touches a coefficient at most once (host front-end, RowSink::scan_deltas),
-// so no atomics — launches of consecutive scans are ordered by their stream.  i16 wrapping add: the sum of all deltas is the
-// coefficient the host accumulated, which fits.
-// Range statistics on the way (range_stats.hpp): every value a coefficient takes is ranged, its final one among them, so the
-// maxima bound the finished plane from above.
-__global__ __launch_bounds__(256) void delta_add_kernel(const jpgpu_coef_delta *__restrict__ d, uint32_t n, int16_t *__restrict__ plane,
-                                                        uint32_t plane_coefficients, const uint16_t *__restrict__ qt, uint32_t *__restrict__ stats) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t max_dc = 0, max_ac = 0;
-    if (i < n) {
-        const jpgpu_coef_delta e = d[i];
-        if (e.index < plane_coefficients) {  // (checked on the host as well)
-            const int32_t v = (int16_t)(uint16_t)((uint32_t)(uint16_t)plane[e.index] + (uint32_t)e.delta);
-            plane[e.index] = (int16_t)v;
-            if (stats) {
-                const uint32_t z = e.index & 63u, p = (uint32_t)(v < 0 ? -v : v) * qt[z];
-                if (z == 0u) max_dc = p;
-                else max_ac = p;
-            }
-        }
-    }
-    if (stats) stat_publish_wave(stats, max_dc, max_ac);
-}
-
 // Device-side classes for the generic path: a plane job's class bits from the device statistics of its image (kept per image)
 // or from the class the host knows (fused kernels: class_finalize_fused_kernel, fused.hip).
 __global__ __launch_bounds__(256) void class_finalize_planes_kernel(PlaneJob *__restrict__ jobs, const uint32_t *__restrict__ slot, uint32_t n,
@@ -161,13 +136,6 @@ hipError_t launch_class_finalize_planes(PlaneJob *d_jobs, const uint32_t *d_slot
                                         hipStream_t stream) {
     if (n_jobs == 0 || !d_jobs || !d_slot || !d_stats || !d_host_cls) return hipSuccess;
     class_finalize_planes_kernel<<<dim3((n_jobs + 255u) / 256u), dim3(256), 0, stream>>>(d_jobs, d_slot, n_jobs, d_stats, d_host_cls);
-    return hipGetLastError();
-}
-
-hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, const uint16_t *d_qt,
-                            uint32_t *d_stats, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    delta_add_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, stream>>>(d_entries, n, d_plane, plane_coefficients, d_qt, d_stats);
     return hipGetLastError();
 }
 

@@ -10,9 +10,6 @@
 namespace jpgpu {
 
 struct ExpandJob;
-// d_qt / d_stats: the plane's quantization table and the image's RangeStats words (range_stats.hpp) on the device; null = no statistics
-hipError_t launch_delta_add(const jpgpu_coef_delta *d_entries, uint32_t n, int16_t *d_plane, uint32_t plane_coefficients, const uint16_t *d_qt,
-                            uint32_t *d_stats, hipStream_t stream);
 hipError_t launch_expand_compact(const ExpandJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, hipStream_t stream);
 hipError_t launch_idct_planes(const PlaneJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t scale,
                               hipStream_t stream);

@@ -196,55 +196,12 @@ private:
     std::unique_ptr<jpgpu::CompactWriter> writer_[4];
 };
 
-// JPGPU_PIPELINE_PROGRESSIVE_DELTAS: the planes of a progressive image are accumulated on the device from what every scan
-// changed (RowSink::scan_deltas -> jpgpu_batch_add_deltas); the rows the front-end appends at the end are not needed.
-class DeltaSink : public RowSink {
-public:
-    explicit DeltaSink(std::function<void(uint32_t, std::vector<jpgpu::host::ScanDelta> &&)> ship) : ship_(std::move(ship)) {
-        for (int c = 0; c < 4; c++) {
-            done_[c] = false;
-            slot_of_[c] = (uint32_t)c;
-        }
-    }
-    bool wants_scan_deltas() override { return true; }
-    // The reference hands a component's plane to the worker when a scan completes it (and again if a later scan completes it
-    // again); what scans change AFTER the last such hand-over never reaches the pixels (only damaged or unusual streams have
-    // such scans).  So: changes to a component that has been handed over once wait here until its next hand-over, if any.
-    void scan_deltas(uint32_t slot, const jpgpu::host::ScanDelta *d, size_t n) override {
-        if (!n) return;
-        if (done_[slot]) late_[slot].emplace_back(d, d + n);
-        else ship_(slot, std::vector<jpgpu::host::ScanDelta>(d, d + n));
-    }
-    void frame_slot_hint(uint32_t index, uint32_t slot) override { slot_of_[index] = slot; }
-    void start(uint32_t index, const jpgpu_component &, const uint16_t qt[64]) override { memcpy(qt_[index], qt, 128); }
-    void append_row(uint32_t, const int16_t *, size_t) override {}
-    void finish(uint32_t index, uint32_t slot) override {
-        if (slot != slot_of_[index]) throw DecodeError{JPGPU_ERR_INTERNAL, "pipeline: plane finished under another frame slot"};
-        memcpy(slot_qt_[slot], qt_[index], 128);
-        for (auto &v : late_[slot]) ship_(slot, std::move(v));
-        late_[slot].clear();
-        done_[slot] = true;
-    }
-    bool done(uint32_t slot) const { return done_[slot]; }
-    const uint16_t *qt(uint32_t slot) const { return slot_qt_[slot]; }
-
-private:
-    std::function<void(uint32_t, std::vector<jpgpu::host::ScanDelta> &&)> ship_;
-    std::vector<std::vector<jpgpu::host::ScanDelta>> late_[4];
-    uint32_t slot_of_[4];
-    uint16_t qt_[4][64], slot_qt_[4][64];
-    bool done_[4];
-};
-static_assert(sizeof(jpgpu::host::ScanDelta) == sizeof(jpgpu_coef_delta) && offsetof(jpgpu::host::ScanDelta, delta) == offsetof(jpgpu_coef_delta, delta),
-              "ScanDelta is passed to jpgpu_batch_add_deltas as it is");
-
 // Finished images are handed to one uploader thread: hipMemcpyAsync calls from hundreds of threads contend in the
 // runtime, one caller keeps the copy queues busy.  skip = the image failed and will never be uploaded.
 struct UploadQueue {
     std::mutex m;
     std::condition_variable cv;
-    std::vector<std::pair<uint32_t, int>> items;  // (image, 0 failed / 1 staged: upload it / 2 decode its entropy data on the device /
-                                                  //  3 one scan's deltas of a progressive image are waiting in its queue)
+    std::vector<std::pair<uint32_t, int>> items;  // (image, 0 failed / 1 staged: upload it / 2 decode its entropy data on the device)
     void push(uint32_t i, int kind) {
         {
             std::lock_guard<std::mutex> g(m);
@@ -515,7 +472,6 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const double t0 = now_ms();
     const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0, compact = (flags & JPGPU_PIPELINE_DENSE) == 0;
     const bool device_entropy = (flags & JPGPU_PIPELINE_DEVICE_ENTROPY) != 0;
-    const bool progressive_deltas = (flags & JPGPU_PIPELINE_PROGRESSIVE_DELTAS) != 0;
     p->n = n;
     p->fes.clear();
     p->fes.resize(n);
@@ -731,19 +687,6 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     uint32_t device_rejected = 0, device_images = 0;
     double dev_ms[4] = {0, 0, 0, 0};  // JPGPU_BATCH_KERNEL_TIMES: phases of the device entropy path, summed over the sub-batches
     bool dev_ms_valid = false;
-    // JPGPU_PIPELINE_PROGRESSIVE_DELTAS: per image the scans' deltas in the order they were decoded (workers push, the uploader
-    // pops); the uploader keeps the entry lists alive until the streams have drained (hipMemcpyAsync reads them later)
-    struct DeltaItem {
-        uint32_t comp;
-        std::vector<jpgpu::host::ScanDelta> entries;
-    };
-    std::vector<std::vector<DeltaItem>> delta_q(progressive_deltas ? n : 0);
-    std::vector<size_t> delta_next(progressive_deltas ? n : 0, 0);
-    std::vector<uint8_t> is_delta(n, 0), delta_cleared(n, 0);
-    // final quantization tables of the delta images: handed to the batch by the uploader thread, which is also the one that
-    // calls jpgpu_batch_add_deltas for them (the class bookkeeping of a component is touched by one thread only)
-    std::vector<std::array<uint16_t, 4 * 64>> delta_qt(progressive_deltas ? n : 0);
-    std::mutex delta_m;
     // the pool is idle while device-entropy images are staged (its tasks for them return at once): lend it to the copy
     std::mutex par_m;
     // (a team of its own, kept between calls: the pool proper may still be inside its run() of step 3 when the uploader thread gets
@@ -768,46 +711,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             for (const auto &it : take) {
                 const uint32_t i = it.first;
                 SubBatch &sb = p->subs[(uint32_t)p->sub_of[i]];
-                if (it.second == 3) {  // one scan's changes of a progressive image: accumulate them on the device
-                    if (hip_failed.load()) continue;
-                    const jpgpu::host::ScanDelta *ent = nullptr;
-                    size_t cnt = 0;
-                    uint32_t comp = 0;
-                    {
-                        std::lock_guard<std::mutex> g(delta_m);  // (the worker may be appending to this image's list)
-                        const DeltaItem &di = delta_q[i][delta_next[i]++];
-                        ent = di.entries.data();  // the vector's buffer does not move when the list grows
-                        cnt = di.entries.size();
-                        comp = di.comp;
-                    }
-                    hipStream_t ds = p->copy_streams[i % kCopyStreams];  // one stream per image: its scans stay in order
-                    const uint32_t bi = (uint32_t)p->slot[i];
-                    bool okd = true;
-                    if (!delta_cleared[i]) {
-                        okd = jpgpu_batch_clear_coefficients(sb.batch, bi, ds) == JPGPU_OK;
-                        delta_cleared[i] = 1;
-                    }
-                    okd = okd && jpgpu::batch_add_deltas(sb.batch, bi, comp, reinterpret_cast<const jpgpu_coef_delta *>(ent), cnt, ds, true) == JPGPU_OK;
-                    if (!okd) {
-                        launch_err = jpgpu_batch_last_error(sb.batch);
-                        hip_failed.store(1);
-                    }
-                    continue;  // (not one of the n_jobs final items)
-                }
                 if (it.second == 2) {
                     dev_images[(uint32_t)p->sub_of[i]].push_back(i);
                     device_images++;
                 }
-                if (it.second == 1 && is_delta[i] && !hip_failed.load()) {  // its planes are on the device already
-                    if (!delta_cleared[i]) {  // (an image whose scans changed nothing at all)
-                        if (jpgpu_batch_clear_coefficients(sb.batch, (uint32_t)p->slot[i], p->copy_streams[i % kCopyStreams]) != JPGPU_OK) hip_failed.store(1);
-                        delta_cleared[i] = 1;
-                    }
-                    // the tables its planes were finished with: if one differs from the table the deltas were ranged with
-                    // (the header's), that component's class goes back to "unknown" (jpgpu_batch_set_quantization_table)
-                    for (uint32_t c = 0; c < sb.descs[(uint32_t)p->slot[i]].ncomp; c++)
-                        jpgpu_batch_set_quantization_table(sb.batch, (uint32_t)p->slot[i], c, delta_qt[i].data() + 64 * c);
-                } else
                 if (it.second == 1 && !hip_failed.load()) {
                     hipStream_t cps = p->copy_streams[k++ % kCopyStreams];
                     if (sb.compact) {
@@ -933,29 +840,6 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 return;
             }
             Frontend &fe = *p->fes[i];
-            if (progressive_deltas && fe.info().coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
-                is_delta[i] = 1;
-                size_t sent = 0;
-                DeltaSink sink([&](uint32_t comp, std::vector<jpgpu::host::ScanDelta> &&v) {
-                    sent += v.size() * sizeof(jpgpu::host::ScanDelta);
-                    {
-                        std::lock_guard<std::mutex> g(delta_m);
-                        delta_q[i].push_back(DeltaItem{comp, std::move(v)});
-                    }
-                    q.push(i, 3);
-                });
-                fe.decode_to(sink);
-                for (uint32_t c = 0; c < nc; c++)
-                    if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
-                for (uint32_t c = 0; c < nc; c++) {
-                    memcpy(delta_qt[i].data() + 64 * c, sink.qt(c), 128);  // (the uploader passes them on; the class of the
-                    cbytes[(size_t)i * 4 + c] = 0;                        //  finished planes comes from the device's statistics)
-                }
-                jpeg_bytes += len[i];
-                coef_bytes += sent;
-                q.push(i, 1);
-                return;
-            }
             StageSink sink(sb.h_coef, off, ln, sb.compact);
             fe.decode_to(sink);
             if (trace) {

@@ -1,7 +1,7 @@
 // range_stats.hpp — the range statistics behind the arithmetic classes of include/jpgpu.h, as they are kept
 // ON THE DEVICE: four words per image, raised with atomicMax by whoever writes or reads the coefficients there —
-//   * the device entropy decoders' write passes (huff_sync_core.hpp) and huff_dc_prefix_kernel,
-//   * expand_compact_kernel (compact transport with an unknown class), delta_add_kernel (progressive accumulation),
+//   * the device entropy decoder's expansion (huff_expand_kernel) and huff_dc_prefix_kernel,
+//   * expand_compact_kernel (compact transport with an unknown class),
 //   * range_scan_kernel (jpgpu_batch_classify_on_device: coefficients a caller's own kernels put into a bound arena),
 // and turned into class bits by class_finalize_* right in front of the pixel kernels, without the host looking at them
 // (round 2 read them back: a host synchronisation between entropy decoding and the pixel kernels, and a second pass over

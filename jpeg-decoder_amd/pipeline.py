@@ -39,14 +39,13 @@ class Pipeline:
 
     __del__ = close
 
-    def decode(self, streams, download=True, dense=False, device_entropy=True, progressive_deltas=False, scale=None, color_transform=None, max_decoding_buffer_size=None,
+    def decode(self, streams, download=True, dense=False, device_entropy=True, scale=None, color_transform=None, max_decoding_buffer_size=None,
                gather=False):
         """-> list with, per stream, a numpy uint8 array of the decoded pixels (``Decoder.decode()``'s Vec<u8>) or the
         ``Error`` instance that stream produced.  download=False leaves the pixels in HBM (see ``device_pointer``); dense=True sends all
         64 coefficients of every block over PCIe instead of the compact form (same pixels, A/B switch); device_entropy=True
         (the default here; JPGPU_PIPELINE_DEVICE_ENTROPY in the C API) decodes 8-bit sequential Huffman streams (one scan with all components; with or without restart markers) on the
-        GPU, all other streams — and any the device decoder flags — on the host as usual; progressive_deltas=True accumulates
-        the coefficients of progressive streams on the device, scan by scan (same pixels; A/B switch); scale=(w, h): every image as
+        GPU, all other streams — and any the device decoder flags — on the host as usual; scale=(w, h): every image as
         after ``Decoder.scale(w, h)`` (the smallest DCT scale whose output is at least w x h; ``info(i)`` gives the scaled size);
         color_transform: every image as after ``Decoder.set_color_transform(...)`` ("None", "Grayscale", "RGB", "YCbCr", "CMYK", "YCCK");
         max_decoding_buffer_size: ``Decoder.set_max_decoding_buffer_size`` (images that would need more fail with the reference's error);
@@ -60,7 +59,7 @@ class Pipeline:
         ptrs = (C.c_char_p * max(n, 1))(*bufs)  # the bytes objects' own buffers (alive in `bufs` during the call): no copies
         lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
         st = L.jpgpu_pipeline_decode(self._h, C.cast(ptrs, C.POINTER(C.c_void_p)), lens, n, (N.PIPELINE_DOWNLOAD if download else 0) | (N.PIPELINE_DENSE if dense else 0) |
-                                     (N.PIPELINE_DEVICE_ENTROPY if device_entropy else 0) | (N.PIPELINE_PROGRESSIVE_DELTAS if progressive_deltas else 0) | (N.PIPELINE_GATHER if gather else 0))
+                                     (N.PIPELINE_DEVICE_ENTROPY if device_entropy else 0) | (N.PIPELINE_GATHER if gather else 0))
         check(st, L.jpgpu_pipeline_last_error(self._h) if st else b"")
         out = []
         for i in range(n):

@@ -36,8 +36,6 @@ def lib():
         L.emu_slot_bytes.restype = C.c_uint32
         L.emu_chunk_shift.argtypes = [C.c_uint32, C.c_uint32]
         L.emu_chunk_shift.restype = C.c_uint32
-        L.emu_progressive_deltas.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.emu_progressive_deltas.restype = C.c_longlong
         L.emu_huff_set_launch.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.emu_huff_set_launch.restype = None
         L.emu_huff_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]

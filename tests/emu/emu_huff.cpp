@@ -333,86 +333,3 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
 }
 }
 
-// ---- RowSink::scan_deltas (progressive accumulation elsewhere) -------------------------------------------
-// Decodes `data` with a sink that accumulates the per-scan deltas into its own zero-initialised planes and, on the side,
-// keeps the rows the front-end appends; returns the number of delta entries if both agree for every plane delivered, -1
-// if they differ, -2 if a scan reported a coefficient twice, -3 for an index outside the plane, -4 if decoding failed.
-namespace {
-using jpgpu::host::RowSink;
-using jpgpu::host::ScanDelta;
-using jpgpu::host::DecodeError;
-class DeltaCheckSink : public RowSink {
-public:
-    std::vector<int16_t> acc[4], rows[4], work[4];
-    std::vector<int> seen[4];  // call number that last touched the coefficient
-    bool delivered[4] = {false, false, false, false};
-    long long entries = 0;
-    int scans = 0, error = 0;
-    explicit DeltaCheckSink(const Frontend& fe) {
-        for (uint32_t c = 0; c < fe.ncomp(); c++) {
-            const size_t n = (size_t)fe.components()[c].block_width * fe.components()[c].block_height * 64;
-            acc[c].assign(n, 0);
-            seen[c].assign(n, -1);
-        }
-    }
-    bool wants_scan_deltas() override { return true; }
-    std::vector<std::vector<ScanDelta>> late[4];  // (pipeline.cpp, DeltaSink: changes after a hand-over wait for the next one)
-    void scan_deltas(uint32_t slot, const ScanDelta* d, size_t n) override {
-        if (delivered[slot]) {
-            late[slot].emplace_back(d, d + n);
-            scans++;
-            return;
-        }
-        apply(slot, d, n);
-    }
-    void apply(uint32_t slot, const ScanDelta* d, size_t n) {
-        scans++;
-        for (size_t i = 0; i < n; i++) {
-            if (d[i].index >= acc[slot].size()) {
-                error = -3;
-                return;
-            }
-            if (seen[slot][d[i].index] == scans || d[i].delta == 0) error = -2;
-            seen[slot][d[i].index] = scans;
-            acc[slot][d[i].index] = (int16_t)(uint16_t)((uint32_t)(uint16_t)acc[slot][d[i].index] + (uint32_t)d[i].delta);
-        }
-        entries += (long long)n;
-    }
-    void start(uint32_t index, const jpgpu_component&, const uint16_t*) override { work[index].clear(); }
-    void append_row(uint32_t index, const int16_t* co, size_t len) override { work[index].insert(work[index].end(), co, co + len); }
-    void finish(uint32_t index, uint32_t slot) override {
-        std::vector<int16_t> taken;
-        taken.swap(work[index]);
-        rows[slot].swap(taken);
-        for (auto& v : late[slot]) apply(slot, v.data(), v.size());
-        late[slot].clear();
-        delivered[slot] = true;
-    }
-};
-}  // namespace
-
-extern "C" long long emu_progressive_deltas(const uint8_t* data, size_t len, int* n_scan_calls, int* progressive) {
-    try {
-        Frontend fe(data, len);
-        fe.read_info();
-        if (progressive) *progressive = fe.info().coding_process == JPGPU_CODING_DCT_PROGRESSIVE;
-        size_t total = 0;
-        for (uint32_t c = 0; c < fe.ncomp(); c++) total += (size_t)fe.components()[c].block_width * fe.components()[c].block_height * 64;
-        if (total > (64u << 20)) return -4;  // (hostile headers announce gigabytes; not this test's business)
-        DeltaCheckSink sink(fe);
-        fe.decode_to(sink);
-        if (n_scan_calls) *n_scan_calls = sink.scans;
-        if (sink.error) return sink.error;
-        if (fe.info().coding_process != JPGPU_CODING_DCT_PROGRESSIVE) return sink.entries;  // (must be 0: nothing reported)
-        for (uint32_t c = 0; c < fe.ncomp(); c++) {
-            if (!sink.delivered[c]) continue;
-            const size_t n = std::min(sink.rows[c].size(), sink.acc[c].size());  // rows past the plane are dropped by the Worker
-            if (memcmp(sink.rows[c].data(), sink.acc[c].data(), n * 2) != 0) return -1;
-            for (size_t i = n; i < sink.acc[c].size(); i++)
-                if (sink.acc[c][i] != 0) return -1;
-        }
-        return sink.entries;
-    } catch (const DecodeError&) {
-        return -4;
-    }
-}

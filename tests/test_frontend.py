@@ -183,78 +183,3 @@ def test_mutated_streams_same_outcome_as_oracle(rel):
         else:
             n_err += 1
     assert n_ok >= 10 and n_err >= 5, (n_ok, n_err)
-
-
-def test_progressive_scan_deltas_add_up_to_the_accumulated_planes():
-    """RowSink::scan_deltas (SURVEY §8f n3: every progressive update is coefficient += delta): a sink that adds up what each
-    scan reports ends with exactly the planes the front-end appends at the end — for every file of the corpora (incl. the
-    partial / missing-scan ones), every coefficient at most once per scan; sequential files report nothing."""
-    import ctypes as C
-    import glob
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
-    import emu
-    L = emu.lib()
-    n_prog = 0
-    for name in ALL_GOOD + sorted(glob.glob(os.path.join(R.GOLDEN, "benches", "*.jp*g"))):
-        data = open(name, "rb").read()
-        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
-        calls, prog = C.c_int(0), C.c_int(0)
-        got = L.emu_progressive_deltas(buf, len(data), C.byref(calls), C.byref(prog))
-        if got == -4:
-            continue  # the stream fails to decode (crash corpus): nothing to compare
-        assert got >= 0, (name, got)
-        if prog.value:
-            n_prog += 1
-            assert calls.value >= 1, name
-            if "missing" not in name and "partial" not in name:
-                assert got > 0, name
-        else:
-            assert got == 0 and calls.value == 0, name
-    assert n_prog >= 6
-
-
-def test_progressive_scan_deltas_on_damaged_streams():
-    """The same accounting on damaged progressive streams: whenever the stream still decodes, the deltas — each coefficient at
-    most once per scan, changes after a component's last hand-over held back as the pipeline's DeltaSink holds them back — add
-    up to the planes that were handed over.  (Found this way: a refinement scan that corrects the last coefficient of a band
-    and overwrites it in the same block; two lanes of the add kernel would have raced on it.)"""
-    pytest.importorskip("PIL")
-    import ctypes as C
-    import io
-    import sys
-    from PIL import Image
-    import synth
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
-    import emu
-    L = emu.lib()
-
-    def pil(w, h, sub):
-        buf = io.BytesIO()
-        Image.fromarray(synth.synthetic_rgb(w, h, seed=w + h)).save(buf, format="JPEG", quality=85, subsampling=sub, progressive=True)
-        return buf.getvalue()
-
-    bases = [open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read(),
-             open(os.path.join(R.GOLDEN, "reftest", "progressive3.jpg"), "rb").read(), pil(200, 120, "4:2:0"), pil(96, 64, "4:4:4")]
-    rng = np.random.default_rng(3)
-    outcomes = {"ok": 0, "fails": 0}
-    for base in bases:
-        for _ in range(60):
-            d = bytearray(base)
-            for _ in range(int(rng.integers(1, 3))):
-                pos = int(rng.integers(max(2, len(d) // 4), len(d) - 2))
-                mode = int(rng.integers(0, 4))
-                if mode == 0:
-                    d[pos] ^= 1 << int(rng.integers(0, 8))
-                elif mode == 1:
-                    del d[pos]
-                elif mode == 2:
-                    d[pos] = 0xFF
-                else:
-                    del d[pos:pos + int(rng.integers(1, 40))]
-            data = bytes(d)
-            buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
-            got = L.emu_progressive_deltas(buf, len(data), None, None)
-            assert got >= 0 or got == -4, got
-            outcomes["ok" if got >= 0 else "fails"] += 1
-    assert outcomes["ok"] >= 60 and outcomes["fails"] >= 20, outcomes

@@ -848,34 +848,6 @@ def test_compact_upload_ranged_by_the_expansion_kernel(samp, ct):
         b.close()
 
 
-def test_deltas_ranged_by_the_accumulation_kernel():
-    """jpgpu_batch_add_deltas: the kernel ranges every value a coefficient takes; the finished plane's class comes from those
-    statistics on the device (round 2 ran such images wrap-exact)."""
-    rng = np.random.default_rng(4242)
-    w_, h_ = 96, 64
-    samp, ct = [(2, 2), (1, 1), (1, 1)], "YCbCr"
-    cases = [_batch_case(rng, w_, h_, samp, ct, kind=k) for k in ("tight", "full", "tight")]
-    descs = [J.image_desc(list(to_j(oc)), qts, w, h, ct_) for oc, qts, _c, ct_, w, h in cases]
-    b = J.Batch(descs)
-    try:
-        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
-            b.clear_coefficients(i)
-            for c in range(len(coefs)):
-                final = np.asarray(coefs[c], np.int64)
-                idx = np.flatnonzero(final)
-                first = rng.integers(-2, 3, idx.size)  # two "scans": a first value, then the correction to the final one
-                b.add_deltas(i, c, idx.astype(np.uint32), first.astype(np.int32))
-                b.add_deltas(i, c, idx.astype(np.uint32), (final[idx] - first).astype(np.int32))
-        b.decode()
-        b.synchronize()
-        for i, (oc, qts, coefs, ct_, _w, _h) in enumerate(cases):
-            assert np.array_equal(b.download(i), O.pixels_from_coefficients(oc, qts, coefs, w_, h_, ct_.upper())), i
-        counts = b.class_counts()
-        assert counts[0] == 1 and sum(counts) == 3, counts  # the hostile image runs wrap-exact, the tame ones do not
-    finally:
-        b.close()
-
-
 def _column_pile_case(w_, h_, samp):
     """Blocks whose first column holds ONE coefficient of |c*q| = 5000 (column sum 5000 <= 5900: the tight class), and the six
     values that pile the same column up to 35,000 without exceeding any per-coefficient maximum already seen."""
@@ -899,9 +871,10 @@ def _column_pile_case(w_, h_, samp):
 
 @pytest.mark.parametrize("samp,ct", [DYN_KINDS[0], DYN_KINDS[1], DYN_KINDS[3]], ids=["420", "444", "gray"])
 def test_exact_column_maximum_does_not_survive_a_by_product_writer(samp, ct):
-    """jpgpu_batch_classify_on_device stores an exact column maximum (RS_COL_EXACT); a later jpgpu_batch_add_deltas
-    raises a column's sum without raising any per-coefficient maximum.  The stale column word must not keep the image in the tight
-    class (i16 column outputs): pixels equal to the oracle's, and the image counted outside class 3."""
+    """jpgpu_batch_classify_on_device stores an exact column maximum (RS_COL_EXACT); a later writer that ranges
+    single coefficients only (here: the compact transport with an unknown class, expand_compact_kernel) can raise a column's sum
+    without raising any per-coefficient maximum.  The stale column word must not keep the image in the tight class (i16 column
+    outputs): pixels equal to the oracle's, and the image counted outside class 3."""
     w_, h_ = 96, 64
     ocomps, qts, base, piled, idx, delta = _column_pile_case(w_, h_, samp)
     desc = J.image_desc(list(to_j(ocomps)), qts, w_, h_, ct)
@@ -919,54 +892,13 @@ def test_exact_column_maximum_does_not_survive_a_by_product_writer(samp, ct):
         if b.path.startswith("fused"):
             assert b.class_counts() == (0, 0, 2)  # column sums of 5000: tight, by the scan's exact maximum
         for c in range(len(ocomps)):  # image 1 only
-            b.add_deltas(1, c, idx[c], delta[c])
+            b.upload_compact(1, c, piled[c], classify=False)
         b.decode()
         b.synchronize()
         assert np.array_equal(b.download(0), want0)
         assert np.array_equal(b.download(1), O.pixels_from_coefficients(ocomps, qts, piled, w_, h_, ct.upper()))
         if b.path.startswith("fused"):
             assert b.class_counts() == (0, 1, 1), b.class_counts()  # image 1: column sums of 35,000 -> sane, not tight
-    finally:
-        b.close()
-
-
-def test_unranged_deltas_keep_their_component_unclassified():
-    """an add_deltas issued while a changed quantization table is still waiting to be sent cannot be ranged; the
-    component must stay wrap-exact even if later calls are ranged again (the statistics miss the first call's values)."""
-    rng = np.random.default_rng(777)
-    w_, h_ = 96, 64
-    samp, ct = [(1, 1)], "Grayscale"
-    ocomps, _ = O.make_components(w_, h_, samp)
-    n = ocomps[0].block_w * ocomps[0].block_h
-    q_old, q_new = np.ones(64, np.uint16), np.full(64, 3, np.uint16)
-    final = np.zeros(n * 64, np.int16)
-    hostile = np.arange(n) * 64 + 9
-    final[hostile] = 30000  # x 3 wraps the i16 products: class 0 data under the new table
-    tame = np.arange(n) * 64 + 1
-    final[tame] = 5
-    b = J.Batch([J.image_desc(list(to_j(ocomps)), [q_old], w_, h_, ct)])
-    try:
-        b.clear_coefficients(0)
-        b.set_quantization_table(0, 0, q_new)  # pending: goes to the device with the next decode
-        b.add_deltas(0, 0, hostile.astype(np.uint32), final[hostile].astype(np.int32))  # cannot be ranged (table not sent yet)
-        b.decode()  # sends the table
-        b.synchronize()
-        b.add_deltas(0, 0, tame.astype(np.uint32), final[tame].astype(np.int32))  # ranged — but the statistics are incomplete
-        b.decode()
-        b.synchronize()
-        assert np.array_equal(b.download(0), O.pixels_from_coefficients(ocomps, [q_new], [final], w_, h_, ct.upper()))
-        if b.path.startswith("fused"):
-            assert b.class_counts() == (1, 0, 0), b.class_counts()
-        # a fresh accumulation with the table in place is classified on the device again
-        b.clear_coefficients(0)
-        b.add_deltas(0, 0, tame.astype(np.uint32), final[tame].astype(np.int32))
-        b.decode()
-        b.synchronize()
-        only_tame = np.zeros_like(final)
-        only_tame[tame] = 5
-        assert np.array_equal(b.download(0), O.pixels_from_coefficients(ocomps, [q_new], [only_tame], w_, h_, ct.upper()))
-        if b.path.startswith("fused"):
-            assert b.class_counts() == (0, 0, 1), b.class_counts()
     finally:
         b.close()
 

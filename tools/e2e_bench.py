@@ -26,7 +26,6 @@ def main():
     ap.add_argument("--device-entropy", action="store_true", help="entropy-decode sequential Huffman streams on the GPU (JPGPU_PIPELINE_DEVICE_ENTROPY)")
     ap.add_argument("--restart-rows", type=int, default=0, help="write the synthetic files with a restart marker every N MCU rows")
     ap.add_argument("--sleep", type=float, default=0.0, help="seconds to idle between rounds")
-    ap.add_argument("--progressive-deltas", action="store_true", help="accumulate progressive streams on the device, scan by scan (JPGPU_PIPELINE_PROGRESSIVE_DELTAS)")
     ap.add_argument("--dense", action="store_true", help="send dense coefficient planes (A/B against the compact transport)")
     ap.add_argument("--scale", default=None, help="WxH: Decoder::scale for every image (jpgpu_pipeline_set_scale)")
     ap.add_argument("--file", default=None, help="use this JPEG (replicated) instead of the synthetic images")
@@ -54,7 +53,7 @@ def main():
     import time
     for r in range(args.rounds):
         time.sleep(args.sleep)
-        out = p.decode(files, download=not args.no_download, dense=args.dense, device_entropy=args.device_entropy, progressive_deltas=args.progressive_deltas,
+        out = p.decode(files, download=not args.no_download, dense=args.dense, device_entropy=args.device_entropy,
                        scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None)
         bad = [o for o in out if isinstance(o, Exception)]
         assert not bad, bad[:1]
@@ -68,7 +67,7 @@ def main():
     t0 = time.perf_counter()
     reps = 6
     for _ in range(reps):
-        p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy, progressive_deltas=args.progressive_deltas,
+        p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy,
                  scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None)
     wall = time.perf_counter() - t0
     r1 = resource.getrusage(resource.RUSAGE_SELF)
@@ -77,7 +76,7 @@ def main():
     mp = args.images * args.width * args.height / 1e6
     print(json.dumps({
         "what": "jpgpu_pipeline_decode: JPEG bytes (host) -> RGB" + (" (left in HBM)" if args.no_download else " (pinned host memory)"),
-        "transport": "entropy-coded bytes, decoded on the device" if args.device_entropy else ("per-scan deltas, accumulated on the device" if args.progressive_deltas else ("dense" if args.dense else "compact")),
+        "transport": "entropy-coded bytes, decoded on the device" if args.device_entropy else ("dense" if args.dense else "compact"),
         "restart_rows": args.restart_rows, "images": args.images, "geometry": (os.path.basename(args.file) + f" {args.width}x{args.height}") if args.file else
         f"{args.width}x{args.height} {args.subsampling} q{args.quality}" + (" progressive" if args.progressive else ""), "kernel_path": p.kernel_path, "threads": best["threads"],
         "MP_per_s": round(mp / best["total_ms"] * 1e3, 1), "images_per_s": round(args.images / best["total_ms"] * 1e3, 1),

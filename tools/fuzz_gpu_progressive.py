@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzzing on the GPU, progressive streams: damaged variants of five base streams through the pipeline with the
-per-scan delta transport (with and without device entropy decoding for the sequential ones) and through the default transport;
+"""Differential fuzzing on the GPU, progressive streams: damaged variants of five base streams (four progressive, one sequential) through the pipeline, with and without
+device entropy decoding for the sequential ones;
 every result — pixels or the kind of error — must equal the oracle's.  python tools/fuzz_gpu_progressive.py <seed> <variants>"""
 import sys, os, io
 sys.path.insert(0,'tests'); sys.path.insert(0,'.'); sys.path.insert(0,'oracle')
@@ -30,7 +30,7 @@ for f in files:
     try: wants.append(O.decode(f).pixels)
     except O.OracleError as e: wants.append(e)
 p=J.Pipeline(threads=16)
-for flags in ({"progressive_deltas":True,"device_entropy":False},{"progressive_deltas":True,"device_entropy":True},{"progressive_deltas":False,"device_entropy":True}):
+for flags in ({"device_entropy":False},{"device_entropy":True}):
     out=p.decode(files, **flags)
     bad=ok=err=0
     for i,(want,got) in enumerate(zip(wants,out)):

@@ -56,15 +56,13 @@ struct CompactSink : RowSink {
     }
 };
 
-// progressive files: a sink that asks for the per-scan change lists only to read the clock when each one arrives
+// progressive files: a sink that reads the clock whenever the front-end reports a finished scan (RowSink::scan_finished, once per
+// component of the scan)
 struct ScanClockSink : NullSink {
     std::vector<double> at;
-    std::vector<size_t> entries;
     std::vector<uint32_t> comp;
-    bool wants_scan_deltas() override { return true; }
-    void scan_deltas(uint32_t slot, const ScanDelta *, size_t n) override {
+    void scan_finished(uint32_t slot) override {
         at.push_back(now_ms());
-        entries.push_back(n);
         comp.push_back(slot);
     }
 };
@@ -98,7 +96,6 @@ int main(int argc, char **argv) {
     printf("compact bytes %zu\n", cs.bytes);
     {  // scan by scan (median of `reps` runs per interval); sequential files report nothing here
         std::vector<std::vector<double>> dt;
-        std::vector<size_t> entries;
         std::vector<uint32_t> comp;
         double total = 0;
         for (int r = 0; r < reps; r++) {
@@ -108,20 +105,20 @@ int main(int argc, char **argv) {
             fe.decode_to(sc);
             const double t1 = now_ms();
             if (sc.at.empty()) break;
-            if (dt.empty()) dt.resize(sc.at.size() + 1), entries = sc.entries, comp = sc.comp;
+            if (dt.empty()) dt.resize(sc.at.size() + 1), comp = sc.comp;
             if (sc.at.size() + 1 != dt.size()) break;
             for (size_t k = 0; k < sc.at.size(); k++) dt[k].push_back(sc.at[k] - (k ? sc.at[k - 1] : t0));
             dt.back().push_back(t1 - sc.at.back());
             total += t1 - t0;
         }
         if (!dt.empty() && !dt[0].empty()) {
-            printf("progressive, change lists on: %.3f ms per image (mean); per reported scan x component (median ms, coefficients changed):\n", total / (double)dt[0].size());
+            printf("progressive: %.3f ms per image (mean); per reported scan x component (median ms):\n", total / (double)dt[0].size());
             double sum = 0;
             for (size_t k = 0; k < dt.size(); k++) {
                 std::sort(dt[k].begin(), dt[k].end());
                 const double m = dt[k][dt[k].size() / 2];
                 sum += m;
-                if (k + 1 < dt.size()) printf("  report %2zu  component %u  %8.4f ms  %7zu changes\n", k, comp[k], m, entries[k]);
+                if (k + 1 < dt.size()) printf("  report %2zu  component %u  %8.4f ms\n", k, comp[k], m);
                 else printf("  after the last report (finishing rows)  %8.4f ms\n", m);
             }
             printf("  sum of medians %.3f ms\n", sum);
