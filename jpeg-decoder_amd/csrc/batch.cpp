@@ -67,7 +67,7 @@ struct jpgpu_batch {
     ScaledGeom *d_scaled_geoms = nullptr;
     PlaneJob *d_s_plane_jobs = nullptr;
     ImageJob *d_s_image_jobs = nullptr;
-    uint32_t s_max_tiles_x = 0, s_max_mcu_h = 0, s_lds_bytes = 0;
+    uint32_t s_max_tiles_x = 0, s_max_bands = 0, s_lds_bytes = 0;
     bool s_scales[9] = {false, false, false, false, false, false, false, false, false};
     std::string scaled_name;            // path name of the scaled launch group ("fused420-s4", ...; "fusedscaled-mixed")
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -284,7 +284,7 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
             b->scaled_ids.push_back(i);
             b->scaled_geoms.push_back(sg);
             b->s_max_tiles_x = std::max(b->s_max_tiles_x, sg.tiles_x);
-            b->s_max_mcu_h = std::max(b->s_max_mcu_h, sg.mcu_h);
+            b->s_max_bands = std::max(b->s_max_bands, sg.bands);
             b->s_lds_bytes = std::max(b->s_lds_bytes, sg.lds_bytes);
             b->s_scales[sg.scale] = true;
             const char *nm = scaled_path_name(sg);
@@ -1200,7 +1200,7 @@ int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     const uint8_t *hc = b->dev_classes ? b->d_host_cls : nullptr;
     for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s, st, hc));
     if (!b->scaled_ids.empty())
-        B_HIP(launch_scaled_fused(b->d_scaled_geoms, b->d_s_image_jobs, b->d_s_plane_jobs, (uint32_t)b->scaled_ids.size(), b->s_max_tiles_x, b->s_max_mcu_h,
+        B_HIP(launch_scaled_fused(b->d_scaled_geoms, b->d_s_image_jobs, b->d_s_plane_jobs, (uint32_t)b->scaled_ids.size(), b->s_max_tiles_x, b->s_max_bands,
                                   b->s_lds_bytes, b->s_scales, s));
     if (!b->generic_ids.empty()) {
         const uint32_t n = (uint32_t)b->image_jobs.size();

@@ -3,8 +3,9 @@
 // generic pair of kernels (idct_planes_kernel<4|2|1> -> u8 planes in HBM -> upsample_color_kernel): 2.64 GB moved for 2.00 GB
 // algorithmic at scale 4, 0.36-0.40 of the roofline (profiles/round3/pmc_traffic.json).
 //
-// A ROW kernel in address order (what R4 is for full-size four-component frames, fused_x4.hpp): a workgroup owns `tx` MCUs of one
-// MCU row of one image.
+// A BAND kernel in address order (what R4 is for full-size four-component frames, fused_x4.hpp): a workgroup owns `tx` MCUs of `ry`
+// consecutive MCU rows of one image (ry = 1 in the first version: every chroma block row of a 4:2:0 image was then transformed by
+// three workgroups — its own and, as part of their rings, the ones above and below; 10 block transforms per MCU for 6 blocks).
 //   1. transform: one lane per block (up to FS_BLOCKS_PER_LANE rounds) — the tile's own blocks of every component and, for the
 //      components under one of the fancy upsamplers (UpsamplerH2V1 / H1V2 / H2V2, src/upsampler.rs:134-228: they read one sample
 //      beyond a block), the ring of blocks around them: at a reduced size a whole neighbour block is 16 / 4 / 1 samples and a
@@ -34,11 +35,13 @@ struct ScaledGeom {
     uint32_t scale, ncomp;
     uint32_t mcu_w, mcu_h;          // MCUs across / down
     uint32_t tx, tiles_x;           // MCUs per tile (a multiple of 8: tiles then begin at multiples of eight pixels at every scale)
+    uint32_t ry, bands;             // MCU rows per workgroup, workgroups down the image
+    uint32_t inv_full[4], inv_rest[4];  // ceil(2^20 / blocks of component c per block row of a full tile / of the last, narrower tile): b / n = b * inv >> 20 for b * n < 2^20
     uint32_t hmax, vmax;
     uint32_t h[4], v[4];            // blocks of component c per MCU
     uint32_t halo[4];               // 1: the ring of neighbour blocks is transformed as well (fancy upsamplers)
     uint32_t block_w[4], block_h[4];
-    uint32_t lds_off[4], pitch[4];  // the component's LDS plane: (v + 2 halo) * scale rows of `pitch` = tx * h * scale + 8 bytes — four bytes
+    uint32_t lds_off[4], pitch[4];  // the component's LDS plane: (ry * v + 2 halo) * scale rows of `pitch` = tx * h * scale + 8 bytes — four bytes
                                     // of margin either side of the tile's own samples (the ring's columns are the inner ones of them):
                                     // sample columns that are multiples of 4 in the plane are so in LDS (aligned dword reads)
     uint32_t lds_bytes;
@@ -63,46 +66,63 @@ inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, c
     g.mcu_w = comps[0].block_width / comps[0].horizontal_sampling_factor;
     g.mcu_h = comps[0].block_height / comps[0].vertical_sampling_factor;
     if (g.mcu_w == 0 || g.mcu_h == 0 || g.mcu_h > 65535u) return false;
-    uint32_t per_mcu = 0, ring = 0;  // blocks per MCU of the tile; blocks of the rings that do not grow with the tile
     for (uint32_t c = 0; c < ncomp; c++) {
         g.h[c] = comps[c].horizontal_sampling_factor, g.v[c] = comps[c].vertical_sampling_factor;
         g.block_w[c] = comps[c].block_width, g.block_h[c] = comps[c].block_height;
         if (g.block_w[c] != g.mcu_w * g.h[c] || g.block_h[c] != g.mcu_h * g.v[c]) return false;  // (not a grid update_component_sizes makes)
         const uint32_t k = job.comp[c].kind;
         g.halo[c] = (job.color_fn != CC_GRAY && (k == UP_H2V1 || k == UP_H1V2 || k == UP_H2V2)) ? 1u : 0u;
-        per_mcu += g.h[c] * (g.v[c] + 2u * g.halo[c]);
-        ring += 2u * g.halo[c] * (g.v[c] + 2u * g.halo[c]);
     }
     const uint32_t cap = FS_NT * FS_BLOCKS_PER_LANE;
-    if (ring + 8u * per_mcu > cap) return false;
-    uint32_t tx_max = ((cap - ring) / per_mcu) & ~7u;
+    auto blocks_of = [&](uint32_t te, uint32_t re) {  // what a workgroup of te x re MCUs transforms, rings included
+        uint32_t n = 0;
+        for (uint32_t c = 0; c < ncomp; c++) n += (te * g.h[c] + 2u * g.halo[c]) * (re * g.v[c] + 2u * g.halo[c]);
+        return n;
+    };
+    auto lds_of = [&](uint32_t tx, uint32_t ry) {
+        uint32_t off = 0;
+        for (uint32_t c = 0; c < ncomp; c++) off = (off + (tx * g.h[c] * scale + 8u) * (ry * g.v[c] + 2u * g.halo[c]) * scale + 15u) & ~15u;
+        return off;
+    };
+    if (blocks_of(8u, 1u) > cap) return false;
     tx_cap = (tx_cap < 8u ? 8u : (tx_cap > 64u ? 64u : tx_cap)) & ~7u;
-    if (tx_max > tx_cap) tx_max = tx_cap;
-    // Tile width: the transform phase deals blocks to 256 lanes in rounds, and what a round costs does not depend on how many of its
-    // lanes hold a block — the width whose tiles fill their rounds best wins (1080p 4:2:0, 256 images at scale 4: 24 MCUs = 252
-    // blocks, one full round, 0.507 ms; 64 MCUs = 652 blocks in three rounds 0.528; 40 = 412 in two 0.552; 32 = 332 in two 0.619;
-    // profiles/round4).  Among equally good widths the widest (fewer workgroups, fewer ring columns).
-    uint32_t best_tx = 8u;
-    uint64_t best_num = 0, best_den = 1;
-    for (uint32_t tx = 8u; tx <= tx_max; tx += 8u) {
-        const uint32_t full = g.mcu_w / tx, rest = g.mcu_w - full * tx;
-        uint64_t blocks = 0, slots = 0;
-        for (uint32_t k = 0; k < 2u; k++) {
-            const uint32_t te = k ? rest : tx, n_of = k ? (rest ? 1u : 0u) : full;
-            if (!n_of || !te) continue;
-            const uint32_t b = ring + te * per_mcu;
-            blocks += (uint64_t)n_of * b;
-            slots += (uint64_t)n_of * ((b + FS_NT - 1u) / FS_NT) * FS_NT;
+    // Tile width and rows per workgroup: the transform phase deals blocks to 256 lanes in rounds, and what a round costs does not depend
+    // on how many of its lanes hold a block — the shape whose workgroups need the fewest rounds for the whole image wins: full rounds,
+    // and rings that are small next to what they surround (1080p 4:2:0 at scale 4, 256 images: 24 x 1 MCUs = 252 blocks, one full
+    // round per MCU row, 0.507 ms; 64 x 1 = 652 blocks in three rounds 0.528; 40 x 1 0.552; 32 x 1 0.619; 24 x 4 = 696 blocks in three
+    // rounds for FOUR MCU rows: profiles/round4).  Among equally good shapes the one with fewer workgroups.
+    uint32_t best_tx = 8u, best_ry = 1u;
+    uint64_t best_slots = ~0ull, best_wgs = ~0ull;
+    static const uint32_t kRows[] = {1u, 2u, 3u, 4u, 6u, 8u};
+    for (uint32_t ry : kRows) {
+        if (ry > 1u && ry > g.mcu_h) break;
+        for (uint32_t tx = 8u; tx <= tx_cap; tx += 8u) {
+            if (blocks_of(tx, ry) > cap || lds_of(tx, ry) > 24u * 1024u) break;
+            const uint32_t full_x = g.mcu_w / tx, rest_x = g.mcu_w - full_x * tx, full_y = g.mcu_h / ry, rest_y = g.mcu_h - full_y * ry;
+            uint64_t slots = 0;
+            for (uint32_t ky = 0; ky < 2u; ky++)
+                for (uint32_t kx = 0; kx < 2u; kx++) {
+                    const uint32_t te = kx ? rest_x : tx, re = ky ? rest_y : ry;
+                    const uint64_t n_of = (uint64_t)(kx ? (rest_x ? 1u : 0u) : full_x) * (ky ? (rest_y ? 1u : 0u) : full_y);
+                    if (n_of && te && re) slots += n_of * ((blocks_of(te, re) + FS_NT - 1u) / FS_NT);
+                }
+            const uint64_t wgs = (uint64_t)(full_x + (rest_x ? 1u : 0u)) * (full_y + (rest_y ? 1u : 0u));
+            if (slots < best_slots || (slots == best_slots && wgs < best_wgs)) best_slots = slots, best_wgs = wgs, best_tx = tx, best_ry = ry;
+            if (tx >= g.mcu_w) break;  // (wider tiles change nothing)
         }
-        if (slots && blocks * best_den >= best_num * slots) best_num = blocks, best_den = slots, best_tx = tx;  // (>=: ties go to the wider tile)
     }
     g.tx = best_tx;
+    g.ry = best_ry;
     g.tiles_x = (g.mcu_w + g.tx - 1u) / g.tx;
+    g.bands = (g.mcu_h + g.ry - 1u) / g.ry;
+    const uint32_t rest_x = g.mcu_w - (g.tiles_x - 1u) * g.tx;
     uint32_t off = 0;
     for (uint32_t c = 0; c < ncomp; c++) {
+        g.inv_full[c] = ((1u << 20) + (g.tx * g.h[c] + 2u * g.halo[c]) - 1u) / (g.tx * g.h[c] + 2u * g.halo[c]);
+        g.inv_rest[c] = ((1u << 20) + (rest_x * g.h[c] + 2u * g.halo[c]) - 1u) / (rest_x * g.h[c] + 2u * g.halo[c]);
         g.pitch[c] = g.tx * g.h[c] * scale + 8u;
         g.lds_off[c] = off;
-        off += g.pitch[c] * (g.v[c] + 2u * g.halo[c]) * scale;
+        off += g.pitch[c] * (g.ry * g.v[c] + 2u * g.halo[c]) * scale;
         off = (off + 15u) & ~15u;
     }
     g.lds_bytes = off;
@@ -126,16 +146,17 @@ struct FScaled {
     static constexpr uint32_t R = SCALE == 4 ? 4u : (SCALE == 2 ? 2u : 1u);  // 16-byte pieces of a block the reduced IDCT reads
 
     static __device__ __forceinline__ uint32_t txe(const ScaledGeom &g, uint32_t tile) { return min(g.tx, g.mcu_w - tile * g.tx); }
-    static __device__ __forceinline__ uint32_t tile_blocks(const ScaledGeom &g, uint32_t te) {
+    static __device__ __forceinline__ uint32_t rye(const ScaledGeom &g, uint32_t band) { return min(g.ry, g.mcu_h - band * g.ry); }
+    static __device__ __forceinline__ uint32_t tile_blocks(const ScaledGeom &g, uint32_t te, uint32_t re) {
         uint32_t n = 0;
-        for (uint32_t c = 0; c < g.ncomp; c++) n += (te * g.h[c] + 2u * g.halo[c]) * (g.v[c] + 2u * g.halo[c]);
+        for (uint32_t c = 0; c < g.ncomp; c++) n += (te * g.h[c] + 2u * g.halo[c]) * (re * g.v[c] + 2u * g.halo[c]);
         return n;
     }
 
     // phase 1: blocks -> samples in the LDS planes
-    static __device__ __forceinline__ void transform(const ScaledGeom &g, const PlaneJob *__restrict__ pj, uint32_t tile, uint32_t my, uint32_t tid,
+    static __device__ __forceinline__ void transform(const ScaledGeom &g, const PlaneJob *__restrict__ pj, uint32_t tile, uint32_t band, uint32_t tid,
                                                      uint8_t *lds) {
-        const uint32_t te = txe(g, tile), x0m = tile * g.tx, total = tile_blocks(g, te);
+        const uint32_t te = txe(g, tile), re = rye(g, band), x0m = tile * g.tx, my = band * g.ry, total = tile_blocks(g, te, re);
         v4u pc[FS_BLOCKS_PER_LANE][R];
         uint32_t comp[FS_BLOCKS_PER_LANE], at[FS_BLOCKS_PER_LANE];  // component; LDS byte offset of the block's first sample (~0: no block)
 #pragma unroll
@@ -144,16 +165,14 @@ struct FScaled {
             at[i] = 0xffffffffu;
             comp[i] = 0;
             if (b >= total) continue;
-            uint32_t nbx = te * g.h[0] + 2u * g.halo[0], cnt = nbx * (g.v[0] + 2u * g.halo[0]);
+            uint32_t nbx = te * g.h[0] + 2u * g.halo[0], cnt = nbx * (re * g.v[0] + 2u * g.halo[0]);
             while (b >= cnt) {  // (<= 3 steps)
                 b -= cnt;
                 c++;
                 nbx = te * g.h[c] + 2u * g.halo[c];
-                cnt = nbx * (g.v[c] + 2u * g.halo[c]);
+                cnt = nbx * (re * g.v[c] + 2u * g.halo[c]);
             }
-            uint32_t by = 0;  // (<= 5 steps instead of a division: a component has at most 4 + 2 block rows in a tile)
-            while (b >= nbx) b -= nbx, by++;
-            const uint32_t bx = b;
+            const uint32_t by = (b * (te == g.tx ? g.inv_full[c] : g.inv_rest[c])) >> 20, bx = b - by * nbx;  // (b / nbx: exact, b * nbx < 2^20)
             const int32_t gbx = (int32_t)(x0m * g.h[c] + bx) - (int32_t)g.halo[c], gby = (int32_t)(my * g.v[c] + by) - (int32_t)g.halo[c];
             if (gbx < 0 || gby < 0 || gbx >= (int32_t)g.block_w[c] || gby >= (int32_t)g.block_h[c]) continue;  // outside the plane: never read
             comp[i] = c;
@@ -198,7 +217,8 @@ struct FScaled {
     struct View {
         uint32_t off0, pitch, kind, hf, vf, width, height;
     };
-    static __device__ __forceinline__ View view_of(const ScaledGeom &g, const ImageJob &job, uint32_t c, uint32_t tile, uint32_t my) {
+    static __device__ __forceinline__ View view_of(const ScaledGeom &g, const ImageJob &job, uint32_t c, uint32_t tile, uint32_t band) {
+        const uint32_t my = band * g.ry;
         const uint32_t col0 = tile * g.tx * g.h[c] * (uint32_t)SCALE - 4u, row0 = (my * g.v[c] - g.halo[c]) * (uint32_t)SCALE;  // (wrapping)
         const UpComp &u = job.comp[c];
         return View{g.lds_off[c] - (row0 * g.pitch[c] + col0), g.pitch[c], u.kind, u.hf, u.vf, u.width, u.height};
@@ -259,10 +279,10 @@ struct FScaled {
     // src/upsampler.rs:47-63, src/decoder.rs:1391-1484; the 1-component copy of compute_image, :1310-1332).  First version: four per
     // unit, byte reads, one switch per sample — 600 vector instructions per unit, the launch bound by them (0.91 ms per 256 x 1080p
     // at scale 4 where the generic pair of kernels took 0.62).
-    static __device__ __forceinline__ void pixels(const ScaledGeom &g, const ImageJob &job, uint32_t tile, uint32_t my, uint32_t tid, const uint8_t *lds) {
-        const uint32_t te = txe(g, tile), nc = g.ncomp, fn = job.color_fn;
-        const uint32_t x0 = tile * g.tx * g.hmax * (uint32_t)SCALE, y0 = my * g.vmax * (uint32_t)SCALE;
-        const uint32_t width = te * g.hmax * (uint32_t)SCALE, rows = g.vmax * (uint32_t)SCALE;
+    static __device__ __forceinline__ void pixels(const ScaledGeom &g, const ImageJob &job, uint32_t tile, uint32_t band, uint32_t tid, const uint8_t *lds) {
+        const uint32_t te = txe(g, tile), re = rye(g, band), nc = g.ncomp, fn = job.color_fn, my = band;
+        const uint32_t x0 = tile * g.tx * g.hmax * (uint32_t)SCALE, y0 = band * g.ry * g.vmax * (uint32_t)SCALE;
+        const uint32_t width = te * g.hmax * (uint32_t)SCALE, rows = re * g.vmax * (uint32_t)SCALE;
         const uint32_t upr = (width + 7u) / 8u, units = upr * rows;
         const View v0 = view_of(g, job, 0u, tile, my), v1 = view_of(g, job, nc > 1u ? 1u : 0u, tile, my), v2 = view_of(g, job, nc > 2u ? 2u : 0u, tile, my),
                    v3 = view_of(g, job, nc > 3u ? 3u : 0u, tile, my);

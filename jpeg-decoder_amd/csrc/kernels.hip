@@ -67,17 +67,17 @@ __global__ __launch_bounds__(256) void upsample_color_one_kernel(ImageJob job, u
 // own image's grid leaves at once.
 template <int SCALE>
 __global__ __launch_bounds__(FS_NT) void scaled_fused_kernel(const ScaledGeom *__restrict__ geoms, const ImageJob *__restrict__ jobs,
-                                                             const PlaneJob *__restrict__ planes, uint32_t max_tiles_x, uint32_t max_mcu_h, uint32_t n_images) {
+                                                             const PlaneJob *__restrict__ planes, uint32_t max_tiles_x, uint32_t max_bands, uint32_t n_images) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, col = (slot / max_mcu_h) * 8u + xcd, my = slot % max_mcu_h;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, col = (slot / max_bands) * 8u + xcd, band = slot % max_bands;
     const uint32_t image = col / max_tiles_x, tile = col - image * max_tiles_x;
     if (image >= n_images) return;
     const ScaledGeom &g = geoms[image];
-    if (g.scale != (uint32_t)SCALE || tile >= g.tiles_x || my >= g.mcu_h) return;  // (uniform)
+    if (g.scale != (uint32_t)SCALE || tile >= g.tiles_x || band >= g.bands) return;  // (uniform)
     typedef FScaled<SCALE> K;
-    K::transform(g, planes + g.first_plane_job, tile, my, threadIdx.x, lds_raw);
+    K::transform(g, planes + g.first_plane_job, tile, band, threadIdx.x, lds_raw);
     __syncthreads();
-    K::pixels(g, jobs[image], tile, my, threadIdx.x, lds_raw);
+    K::pixels(g, jobs[image], tile, band, threadIdx.x, lds_raw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -184,14 +184,14 @@ hipError_t launch_upsample_color(const ImageJob *d_jobs, uint32_t n_jobs, uint32
 }
 
 hipError_t launch_scaled_fused(const ScaledGeom *d_geoms, const ImageJob *d_jobs, const PlaneJob *d_planes, uint32_t n_images, uint32_t max_tiles_x,
-                               uint32_t max_mcu_h, uint32_t lds_bytes, const bool (&scales)[9], hipStream_t stream) {
-    if (n_images == 0 || max_tiles_x == 0 || max_mcu_h == 0) return hipSuccess;
-    const uint64_t cols = (uint64_t)n_images * max_tiles_x, wgs = ((cols + 7u) / 8u) * 8u * max_mcu_h;
+                               uint32_t max_bands, uint32_t lds_bytes, const bool (&scales)[9], hipStream_t stream) {
+    if (n_images == 0 || max_tiles_x == 0 || max_bands == 0) return hipSuccess;
+    const uint64_t cols = (uint64_t)n_images * max_tiles_x, wgs = ((cols + 7u) / 8u) * 8u * max_bands;
     if (wgs > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 grid((uint32_t)wgs), block(FS_NT);
-    if (scales[4]) scaled_fused_kernel<4><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes, max_tiles_x, max_mcu_h, n_images);
-    if (scales[2]) scaled_fused_kernel<2><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes, max_tiles_x, max_mcu_h, n_images);
-    if (scales[1]) scaled_fused_kernel<1><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes, max_tiles_x, max_mcu_h, n_images);
+    if (scales[4]) scaled_fused_kernel<4><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes, max_tiles_x, max_bands, n_images);
+    if (scales[2]) scaled_fused_kernel<2><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes, max_tiles_x, max_bands, n_images);
+    if (scales[1]) scaled_fused_kernel<1><<<grid, block, lds_bytes, stream>>>(d_geoms, d_jobs, d_planes, max_tiles_x, max_bands, n_images);
     return hipGetLastError();
 }
 

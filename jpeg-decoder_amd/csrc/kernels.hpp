@@ -24,6 +24,6 @@ hipError_t launch_upsample_color_one(const ImageJob &job, hipStream_t stream);
 // scales[s]: some image of the launch decodes at dct_scale s (one launch per scale present)
 struct ScaledGeom;
 hipError_t launch_scaled_fused(const ScaledGeom *d_geoms, const ImageJob *d_jobs, const PlaneJob *d_planes, uint32_t n_images, uint32_t max_tiles_x,
-                               uint32_t max_mcu_h, uint32_t lds_bytes, const bool (&scales)[9], hipStream_t stream);
+                               uint32_t max_bands, uint32_t lds_bytes, const bool (&scales)[9], hipStream_t stream);
 
 }  // namespace jpgpu

@@ -64,7 +64,7 @@ int emu_scaled_fused(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         pj[c].scale = desc->components[c].dct_scale;
     }
     std::vector<uint8_t> lds(g.lds_bytes + 64);
-    for (uint32_t my = 0; my < g.mcu_h; my++)
+    for (uint32_t my = 0; my < g.bands; my++)  // (a workgroup: a tile of a band of g.ry MCU rows)
         for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
             memset(lds.data(), 0xCD, lds.size());  // garbage, like real LDS
 #define RUNS(S)                                                                                            \
