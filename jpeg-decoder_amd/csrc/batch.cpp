@@ -279,7 +279,8 @@ int jpgpu_batch_create(int device, const jpgpu_image_desc *descs, uint32_t n_ima
         // reduced-size decodes (every component at one dct_scale < 8): one launch, planes in LDS (fused_scaled.hpp)
         ScaledGeom sg;
         static const uint32_t scaled_tx = getenv("JPGPU_SCALED_TX") ? (uint32_t)std::max(8, atoi(getenv("JPGPU_SCALED_TX"))) : 64u;  // (tuning / test knob)
-        const bool scaled = kind_key[i] == 0 && !(flags & JPGPU_BATCH_FORCE_GENERIC) && scaled_geom_from_job(d.components, d.ncomp, ij, sg, scaled_tx);
+        static const uint32_t scaled_ry = getenv("JPGPU_SCALED_RY") ? (uint32_t)std::max(1, atoi(getenv("JPGPU_SCALED_RY"))) : 8u;
+        const bool scaled = kind_key[i] == 0 && !(flags & JPGPU_BATCH_FORCE_GENERIC) && scaled_geom_from_job(d.components, d.ncomp, ij, sg, scaled_tx, scaled_ry);
         if (scaled) {
             b->scaled_ids.push_back(i);
             b->scaled_geoms.push_back(sg);

@@ -49,8 +49,8 @@ struct ScaledGeom {
 };
 
 // Which images take the kernel, and their tiling.  `job` = what build_image_job made of the frame (upsampler kinds).
-// tx_cap: widest tile in MCUs (test / tuning knob JPGPU_SCALED_TX; 64 by default)
-inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g, uint32_t tx_cap = 64u) {
+// tx_cap / ry_cap: widest tile in MCUs, most MCU rows per workgroup (test / tuning knobs JPGPU_SCALED_TX / JPGPU_SCALED_RY; 64 and 8 by default)
+inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g, uint32_t tx_cap = 64u, uint32_t ry_cap = 8u) {
     g = ScaledGeom{};
     if (ncomp == 0 || ncomp > 4) return false;
     const uint32_t scale = comps[0].dct_scale;
@@ -90,12 +90,13 @@ inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, c
     // on how many of its lanes hold a block — the shape whose workgroups need the fewest rounds for the whole image wins: full rounds,
     // and rings that are small next to what they surround (1080p 4:2:0 at scale 4, 256 images: 24 x 1 MCUs = 252 blocks, one full
     // round per MCU row, 0.507 ms; 64 x 1 = 652 blocks in three rounds 0.528; 40 x 1 0.552; 32 x 1 0.619; 24 x 4 = 696 blocks in three
-    // rounds for FOUR MCU rows: profiles/round4).  Among equally good shapes the one with fewer workgroups.
+    // rounds for FOUR MCU rows, 0.433 ms; 16 x 8 = 872 blocks in four rounds for EIGHT rows 0.424: profiles/round4/06_scaled_kernel.txt).
+    // Among equally good shapes the taller one, then the one with fewer workgroups.
     uint32_t best_tx = 8u, best_ry = 1u;
-    uint64_t best_slots = ~0ull, best_wgs = ~0ull;
+    uint64_t best_slots = ~0ull, best_wgs = ~0ull;  // (rows are tried in rising order: `<=` below lets the taller band win a tie)
     static const uint32_t kRows[] = {1u, 2u, 3u, 4u, 6u, 8u};
     for (uint32_t ry : kRows) {
-        if (ry > 1u && ry > g.mcu_h) break;
+        if (ry > 1u && (ry > g.mcu_h || ry > ry_cap)) break;
         for (uint32_t tx = 8u; tx <= tx_cap; tx += 8u) {
             if (blocks_of(tx, ry) > cap || lds_of(tx, ry) > 24u * 1024u) break;
             const uint32_t full_x = g.mcu_w / tx, rest_x = g.mcu_w - full_x * tx, full_y = g.mcu_h / ry, rest_y = g.mcu_h - full_y * ry;
@@ -107,7 +108,7 @@ inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, c
                     if (n_of && te && re) slots += n_of * ((blocks_of(te, re) + FS_NT - 1u) / FS_NT);
                 }
             const uint64_t wgs = (uint64_t)(full_x + (rest_x ? 1u : 0u)) * (full_y + (rest_y ? 1u : 0u));
-            if (slots < best_slots || (slots == best_slots && wgs < best_wgs)) best_slots = slots, best_wgs = wgs, best_tx = tx, best_ry = ry;
+            if (slots < best_slots || (slots == best_slots && (ry > best_ry || wgs < best_wgs))) best_slots = slots, best_wgs = wgs, best_tx = tx, best_ry = ry;
             if (tx >= g.mcu_w) break;  // (wider tiles change nothing)
         }
     }
