@@ -281,7 +281,7 @@ def measured_traffic(workload, path):
     """HBM bytes per decode from the committed rocprofv3 PMC passes (profiles/roundN/pmc_traffic.json,
     FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc runs) and where they come from; (None, why) if
     not measured.  The counters need rocprofv3 around the process: they are NOT taken in this run, and the line says so."""
-    for rnd in ("round3", "round2", "round1"):
+    for rnd in ("round4", "round3", "round2", "round1"):
         rel = os.path.join("profiles", rnd, "pmc_traffic.json")
         try:
             t = json.load(open(os.path.join(ROOT, rel)))
