@@ -599,7 +599,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         // passes of one run next to the full passes of another, and staging, upload and kernels of neighbours overlap: 128 images
         // per sub-batch, up to 32 of them (256 files per call 8.6 -> 7.5 ms, 1,024: 21.1 -> 18.8 ms, 4,096: 68.7 -> 63.5 ms against 256 x 16)
         const long dev_sub_env = getenv("JPGPU_PIPE_DEV_SUB") ? atol(getenv("JPGPU_PIPE_DEV_SUB")) : 0;  // tuning knob (read per call)
-        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : 2u * kSubBatchImages;
+        // (round 4: calls of up to 512 files in sub-batches of 64 — four of them for 256 files: the first enters the device after a
+        // quarter of the staging, and four chains of latency-bound passes overlap instead of two; 256 files 6.5-7.1 -> 6.15 ms on the
+        // same boxes, 1,024 and 4,096 files unchanged: profiles/round4/08_sub_batch_sizes.txt)
+        const uint32_t dev_sub_images = dev_sub_env > 0 ? (uint32_t)dev_sub_env : (n_dev <= 512u ? kSubBatchImages : 2u * kSubBatchImages);
         const long dev_cap_env = getenv("JPGPU_PIPE_MAX_DEV_SUBS") ? atol(getenv("JPGPU_PIPE_MAX_DEV_SUBS")) : 0;  // tuning knob (read per call)
         const uint32_t dev_cap = dev_cap_env > 0 ? (uint32_t)std::min<long>(dev_cap_env, kMaxSubBatches / 2u) : kMaxSubBatches / 2u;
         const uint32_t dev_subs = n_dev ? std::min<uint32_t>(dev_cap, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;
