@@ -17,11 +17,6 @@
 #include "host_common.hpp"
 #include "range_stats.hpp"
 
-#ifndef JPGPU_PRIO_WALK
-#define JPGPU_PRIO_WALK 1
-#define JPGPU_PRIO_COLOUR 0
-#endif
-
 namespace jpgpu {
 
 // Which image / tile a workgroup owns: from the work table (mixed-size batches, 1-D grid) or, when the batch is uniform
@@ -78,7 +73,7 @@ __device__ __forceinline__ void walk_item(const FusedGeom *__restrict__ geoms, c
     // wait for: 0.6655 -> 0.6495 ms per 256 x 1080p (same box, interleaved; any pair of levels with colour the lower one measures the
     // same; raising the colour phase instead: 0.662-0.681).  Box to box the gain is 0.2-2.4 %, never a loss; the ROW kernels (one pass per
     // workgroup, nothing to prefetch for) lose 2-6 % with the same split and keep equal priorities (profiles/round4/10_wave_priorities.txt).
-    __builtin_amdgcn_s_setprio(JPGPU_PRIO_WALK);
+    __builtin_amdgcn_s_setprio(1);
     K::init(img, tid, lds);
     if (k0 > 0 || k1 < g.mcu_h) {  // seam rows of the segments above / below
         K::seam_stage(g, img, strip, k0, k1, tid, lds);
@@ -104,9 +99,9 @@ __device__ __forceinline__ void walk_item(const FusedGeom *__restrict__ geoms, c
         __syncthreads();
         const bool more = k + 1u < k1;
         asm volatile("" : "+v"(t2));
-        __builtin_amdgcn_s_setprio(JPGPU_PRIO_COLOUR);
+        __builtin_amdgcn_s_setprio(0);
         K::colour(g, img, strip, k, 16u * k0, false, t2, lds);
-        __builtin_amdgcn_s_setprio(JPGPU_PRIO_WALK);
+        __builtin_amdgcn_s_setprio(1);
         __syncthreads();
         if (more) {
             asm volatile("" : "+v"(t0));
