@@ -38,7 +38,7 @@ import sys
 import time
 
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a
-# queue run one after the other: jpgpu_pipeline_decode keeps up to 16 sub-batches in flight on 16 compute + 4 copy streams.
+# queue run one after the other: jpgpu_pipeline_decode keeps up to 12 sub-batches in flight on 12 compute + 4 copy streams.
 # Read once when the runtime initialises, so it is set before anything touches HIP (jpeg_decoder_amd._native does the same).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 # (the library reads this once, at its first device-entropy launch: events around the phases, microseconds per sub-batch — the e2e

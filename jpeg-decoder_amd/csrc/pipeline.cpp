@@ -246,7 +246,9 @@ struct SubBatch {
 // streams shared round robin.  Round 3: with 8 sub-batches a call of 4,096 files made four device sub-batches of 1,024, whose
 // write pass took 11 us per image against 7 us in sub-batches of 256 (a 6.4 GB arena per sub-batch instead of 1.6 GB:
 // profiles/round3/08_subbatch_size.txt).
-constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 32, kComputeStreamsDefault = 16;  // (more than 16 in use is slower: 24 streams 109 ms, 32 streams 75 ms per 4,096 files against 53-60, whatever GPU_MAX_HW_QUEUES says — tools/gpu_streams.sh)
+constexpr uint32_t kSubBatchImages = 64, kMaxSubBatches = 64, kComputeStreams = 32, kComputeStreamsDefault = 12;  // (round 4: 12, not 16 — equal without a
+    // collective library in the process (54.8 vs 55.9 ms per 4,096 files), but next to RCCL's own streams 16 measure 69-72 ms against 55.5: profiles/round4/08_sub_batch_sizes.txt)
+     // (more than 16 in use is slower: 24 streams 109 ms, 32 streams 75 ms per 4,096 files against 53-60, whatever GPU_MAX_HW_QUEUES says — tools/gpu_streams.sh)
 
 }  // namespace
 
