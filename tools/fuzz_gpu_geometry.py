@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the batch kernels over geometry: random sizes x sampling kinds x colour transforms x coefficient
-classes, as batches of one kind (the fused kernels, with per-class launch groups) and as mixed batches (the generic path);
+classes x (every fifth round) reduced scales 4 / 2 / 1, as batches of one kind (the fused kernels, with per-class launch groups; the
+band kernel of csrc/fused_scaled.hpp for reduced sizes) and as mixed batches (several launch groups, the generic path);
 every image must equal the oracle's pixel pipeline byte for byte.
     python tools/fuzz_gpu_geometry.py <seed> <rounds>      (on the GPU box; prints "bad 0")"""
 import os, sys
@@ -32,6 +33,7 @@ def run(seed, rounds, verbose=True):
         mixed = r % 4 == 3
         n = int(rng.integers(2, 7))
         samp, ct = KINDS[int(rng.integers(0, len(KINDS)))]
+        scale = 8 if r % 5 else int(rng.choice([4, 2, 1]))  # every fifth round: Decoder::scale
         cases = []
         # sizes: mostly small, around the tile / strip / MCU boundaries now and then
         def size():
@@ -46,7 +48,10 @@ def run(seed, rounds, verbose=True):
             if mixed:
                 samp, ct = KINDS[int(rng.integers(0, len(KINDS)))]
                 w_, h_ = size()
-            cases.append(T._batch_case(rng, w_, h_, samp, ct, kind=COEF[int(rng.integers(0, 4))]))
+            if scale == 8:
+                cases.append(T._batch_case(rng, w_, h_, samp, ct, kind=COEF[int(rng.integers(0, 4))]))
+            else:  # (mixed rounds: every image at its own reduced scale)
+                cases.append(T._scaled_case(rng, w_, h_, samp, ct, int(rng.choice([4, 2, 1])) if mixed else scale, kind=("sparse", "full")[int(rng.integers(0, 2))]))
         outs, path = T._run_batch(cases)
         paths[path] = paths.get(path, 0) + 1
         for i, (oc, qts, coefs, ct_, cw, ch) in enumerate(cases):
