@@ -32,7 +32,8 @@ def test_valid_stream_fuzz_bit_exact():
 
 
 def test_extreme_geometries_bit_exact():
-    """tools/extreme_sizes.py: 65535-wide, 65535-tall, one-pixel and 8191x4097 images of every fused kind through the batch path
+    """tools/extreme_sizes.py: 65535-wide, 65535-tall, one-pixel and 8191x4097 images of every fused kind through the batch path, at full
+    size and (five kinds) at the reduced scales 4 / 2 / 1 of the band kernel
     (maximum sizes of SOF0: src/parser.rs:292-298)."""
     assert _fuzzer("extreme_sizes").run(verbose=False) == []
 

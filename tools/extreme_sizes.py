@@ -28,6 +28,20 @@ def run(verbose=True):
                 bad.append((w, h, name, path))
             if verbose:
                 print(f"{w}x{h} {name}: path {path} {'ok' if ok else 'MISMATCH'}", flush=True)
+    # reduced sizes (Decoder::scale -> dct_scale 4 / 2 / 1): the band kernel's longest grids — 8,192 MCU rows, 4,096 MCU columns
+    for w, h in [(65535, 17), (17, 65535), (8191, 4097), (1, 65535), (65535, 1)]:
+        for name in ("420", "444", "440", "gray", "cmyk"):
+            samp, ct = KINDS[name]
+            for scale in (4, 2, 1):
+                case = T._scaled_case(rng, w, h, samp, ct, scale)
+                outs, path = T._run_batch([case])
+                oc, qts, coefs, ct_, cw, ch = case
+                want = O.pixels_from_coefficients(oc, qts, coefs, cw, ch, ct_.upper())
+                ok = np.array_equal(np.asarray(outs[0]).ravel(), np.asarray(want).ravel()) and "-s%d" % scale in path
+                if not ok:
+                    bad.append((w, h, name, scale, path))
+                if verbose:
+                    print(f"{w}x{h} {name} scale {scale}: path {path} {'ok' if ok else 'MISMATCH'}", flush=True)
     return bad
 
 
