@@ -22,7 +22,7 @@
   At N = 1 the line also carries, OUTSIDE `value` (each verified against the oracle):
     k_4096            the same kernel-only figure on north_star's 4096-image batch (51 GB of arenas on one GPU);
     e2e               what the metric's words say — JPEG bytes in host memory -> RGB in HBM through jpgpu_pipeline_decode
-                      (entropy decoding on the device), 256, 1024 and 4096 files, best of 3 warm calls; the kernel time per phase
+                      (entropy decoding on the device), 256, 1024 and 4096 files, best of 5 warm calls; the kernel time per phase
                       from one sub-batch of 256 files alone on the device (kernels_256_one_sub_batch);
     cpu_baseline_e2e  the oracle's whole Decoder::decode() on the same files, one file per task on every granted core;
     sustained         the timed step repeated for --min-seconds (an independent look at `value`, long enough for a sampler).
@@ -391,7 +391,7 @@ def e2e_floor_fields(e, best, h2d_gbps, alone_ms_per_image):
 def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
     """What the metric's words say: JPEG bytes in host memory -> RGB in HBM, through jpgpu_pipeline_decode with the entropy
     decoding on the device (no host Huffman decoding, no range scan, no host synchronisation in front of the pixel kernels).
-    Per batch size: best of 3 warm calls (wall clock of the call, everything included: header parsing, staging, H2D, kernels) and a
+    Per batch size: best of 5 warm calls (wall clock of the call, everything included: header parsing, staging, H2D, kernels) and a
     check of first / middle / last image against the oracle; the kernel time per phase from one sub-batch run alone."""
     os.environ["JPGPU_BATCH_KERNEL_TIMES"] = "1"  # (read once by the library: events around the phases, microseconds per sub-batch)
     distinct, who = e2e_files(synth, w, h, encoder)
@@ -400,14 +400,14 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
            "jpeg_bytes_per_image": int(sum(len(d) for d in distinct) / len(distinct)),
            "what": "jpgpu_pipeline_decode: JPEG bytes in host memory -> RGB resident in HBM; entropy decoding ON THE DEVICE "
                    "(self-synchronising chunk decoder with speculative emission), classes from its statistics, pixel kernels right behind it; "
-                   "best of 3 warm calls; wall clock of the whole call"}
+                   "best of 5 warm calls; wall clock of the whole call"}
     p = J.Pipeline()
     bests = {}
     try:
         for n in sizes:
             files = [distinct[i % len(distinct)] for i in range(n)]
             best = None
-            for r in range(4):  # the first call allocates arenas and staging: not counted
+            for r in range(6):  # the first call allocates arenas and staging: not counted (and calls 2-3 still run ~20 % slower than the steady state)
                 res = p.decode(files, download=False, device_entropy=True)
                 bad = [x for x in res if isinstance(x, Exception)]
                 if bad:
@@ -565,7 +565,7 @@ def e2e_sharded(J, O, synth, D, dist, torch, dev, rank, local_rank, world, w, h,
     p = J.Pipeline(device=local_rank, threads=threads)
     try:
         best = None
-        for r in range(4):  # the first call allocates arenas and staging: not counted
+        for r in range(6):  # the first call allocates arenas and staging: not counted
             torch.cuda.synchronize(dev)
             if dist:
                 dist.barrier()
@@ -594,7 +594,7 @@ def e2e_sharded(J, O, synth, D, dist, torch, dev, rank, local_rank, world, w, h,
             "host_cpus_granted": effective_cpus_unpinned(), "kernel_path": kernel_path, "verified_vs_oracle": bool(all_ok >= 1.0),
             "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}",
             "what": "jpgpu_pipeline_decode per rank on its shard of the file list (entropy decoding on the device), every call behind a barrier; "
-                    "MAX over ranks of the best of 3 warm calls; pixels stay in each rank's HBM"}
+                    "MAX over ranks of the best of 5 warm calls; pixels stay in each rank's HBM"}
 
 
 _UNPINNED_CPUS = None
