@@ -216,6 +216,65 @@ __global__ __launch_bounds__(SYNC_NT, 4) void huff_sync_pass_kernel(const HuffSy
     if (threadIdx.x == 0 && n_pub) atomicAdd(cnt + launch % 3u, n_pub);
 }
 
+// Late launches (passes >= 2): a few per cent of the chunks are still being corrected — nearly every workgroup of the full grid would
+// hold one or two of them and sit on its wave slots and 23 kB of LDS for a whole chunk walk (0.4 ms) with one busy lane, and with a
+// dozen sub-batches in flight those mostly idle workgroups fill the device's slots and keep the FULL passes of other sub-batches
+// waiting (per-dispatch counters of a late launch: 70 % of the wave-cycles of a full one for 3 % of its work;
+// tools/probe_concurrency.hip: 1,792 workgroups of this footprint fit the device).  So a late launch gives one workgroup
+// SYNC_LATE_SPAN blocks of 256 chunks: it gathers the chunks with work from all of them, 256 at a time, and walks those.
+constexpr uint32_t SYNC_LATE_SPAN = 8u;
+template <uint32_t TABLES>
+__global__ __launch_bounds__(SYNC_NT, 4) void huff_sync_late_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t launch, uint32_t first_pass, uint32_t iters) {
+    static_assert(TABLES == 4u || TABLES == 8u, "");
+    __shared__ alignas(16) uint8_t L_raw[TABLES == 8u ? sizeof(HuffSyncLds) : HUFF_SYNC_LDS_COMPACT_BYTES];
+    JP_LDS HuffSyncLds &L = *(JP_LDS HuffSyncLds *)L_raw;
+    __shared__ uint32_t todo[SYNC_NT];  // chunks with work, gathered from the span
+    __shared__ uint32_t wave_cnt[SYNC_NT / 64u];
+    const HuffSyncJob *gj = &jobs[blockIdx.y];
+    uint32_t *cnt = gj->changed;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[(launch + 1u) % 3u] = 0u;
+    const uint32_t first = blockIdx.x * (SYNC_LATE_SPAN * SYNC_NT), n = gj->n_chunks;
+    if (first >= n) return;
+    if (launch > 0u && cnt[(launch - 1u) % 3u] == 0u) return;
+    const uint32_t last = min(n, first + SYNC_LATE_SPAN * SYNC_NT), lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool published = false, loaded = false;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t pass = first_pass + it;
+        uint32_t filled = 0;  // work items gathered so far (the same in every lane)
+        for (uint32_t base = first; base < last || filled; base += SYNC_NT) {
+            bool need = false;
+            uint32_t before = 0, total = 0;
+            if (base < last) {
+                need = base + threadIdx.x < last && sync_chunk_has_work(gj, base + threadIdx.x, pass);
+                const uint64_t m = __ballot(need);
+                if (lane == 0u) wave_cnt[wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+#pragma unroll
+                for (uint32_t w = 0; w < SYNC_NT / 64u; w++) {
+                    const uint32_t c = wave_cnt[w];
+                    before += w < wave ? c : 0u;
+                    total += c;
+                }
+                before += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            }
+            if (filled + total > SYNC_NT || (base >= last && filled)) {  // the list is full (or the span is through): walk what it holds
+                if (!loaded) {
+                    sync_load_lds<SYNC_NT, TABLES>(L, gj);
+                    loaded = true;
+                }
+                if (threadIdx.x < filled) published |= huff_sync_chunk(L, todo[threadIdx.x], pass, threadIdx.x);
+                __syncthreads();
+                filled = 0;
+            }
+            if (need) todo[filled + before] = base + threadIdx.x;
+            filled += total;
+            __syncthreads();
+        }
+    }
+    const uint32_t n_pub = (uint32_t)__syncthreads_count(published);
+    if (threadIdx.x == 0 && n_pub) atomicAdd(cnt + launch % 3u, n_pub);
+}
+
 // per job: unsettled after the last launch -> host; else blocks per chunk -> number of each chunk's first block
 __global__ __launch_bounds__(SYNC_NT) void huff_sync_scan_kernel(const HuffSyncJob *__restrict__ jobs, uint32_t last_launch) {
     __shared__ uint32_t wave_tot[SYNC_NT / 64u];
@@ -672,8 +731,12 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     }
     huff_weave_kernel<<<dim3((max_chunks + HUFF_WEAVE_LANES - 1u) / HUFF_WEAVE_LANES, n_jobs), dim3(256), 0, stream>>>(d_jobs);
     const dim3 grid((max_chunks + SYNC_NT - 1u) / SYNC_NT, n_jobs);
+    const dim3 late_grid((max_chunks + SYNC_LATE_SPAN * SYNC_NT - 1u) / (SYNC_LATE_SPAN * SYNC_NT), n_jobs);
     for (uint32_t l = 0; l < launches; l++) {
-        if (low_table_ids) huff_sync_pass_kernel<4u><<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
+        const bool late = l * iters >= 2u;  // (passes 0 and 1 are every lane's)
+        if (late && low_table_ids) huff_sync_late_kernel<4u><<<late_grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
+        else if (late) huff_sync_late_kernel<8u><<<late_grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
+        else if (low_table_ids) huff_sync_pass_kernel<4u><<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
         else huff_sync_pass_kernel<8u><<<grid, dim3(SYNC_NT), 0, stream>>>(d_jobs, l, l * iters, iters);
     }
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);

@@ -241,7 +241,9 @@ constexpr uint32_t QK_EMITTED = 0x80000000u;
 // same with 1 and with 2 (1080p 1.40-1.50 ms): 2 everywhere (HUFF_LATE_PASS, huff_job.hpp; JPGPU_SYNC_LATE_PASS pins another).
 __device__ __forceinline__ bool huff_emit_in_pass(const JP_LDS HuffSyncJob &job, uint32_t pass) { return job.emit != nullptr && pass > 0u; }
 
-__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass) {
+// dc_slot: which of the workgroup's HUFF_SYNC_LANES slots for DC sums the lane uses (default: the chunk's own; the late launches, whose
+// lanes take chunks from anywhere in a span of several blocks, pass their thread index)
+__device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t i, uint32_t pass, uint32_t dc_slot = 0xffffffffu) {
     const JP_LDS HuffSyncJob &job = L.job;
     // start state
     const HuffChunkSpan span = huff_chunk_span(job, i);
@@ -279,7 +281,7 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
     uint32_t nblk = 0;
     bool bad = false;
     const bool dc_sums = !job.uniform;
-    JP_LDS uint32_t *dc = L.dc[i % HUFF_SYNC_LANES];
+    JP_LDS uint32_t *dc = L.dc[dc_slot == 0xffffffffu ? i % HUFF_SYNC_LANES : dc_slot];
     if (dc_sums) dc[0] = dc[1] = dc[2] = dc[3] = 0u;
     uint32_t last_block_end = 0;
     HuffEmit em;
