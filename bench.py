@@ -358,7 +358,7 @@ def sync_pass_instructions(symbols_per_call):
                 if not isinstance(e, dict) or "pmc" not in e or "SQ_INSTS_VALU" not in e["pmc"]:
                     continue
                 every += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
-                if "huff_sync_pass_kernel" in name:
+                if "huff_sync_pass_kernel" in name or "huff_sync_late_kernel" in name:
                     wave_instr += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
             calls = doc.get("_calls_of_the_pipeline") or 6  # (tools/pipe_calls.py / round 3's script: six calls per profiled process)
             if wave_instr:
