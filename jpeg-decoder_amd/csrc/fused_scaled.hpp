@@ -50,7 +50,7 @@ struct ScaledGeom {
 
 // Which images take the kernel, and their tiling.  `job` = what build_image_job made of the frame (upsampler kinds).
 // tx_cap / ry_cap: widest tile in MCUs, most MCU rows per workgroup (test / tuning knobs JPGPU_SCALED_TX / JPGPU_SCALED_RY; 64 and 8 by default)
-inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g, uint32_t tx_cap = 64u, uint32_t ry_cap = 8u) {
+inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, const ImageJob &job, ScaledGeom &g, uint32_t tx_cap = 64u, uint32_t ry_cap = 8u) {  // (ry_cap up to 16)
     g = ScaledGeom{};
     if (ncomp == 0 || ncomp > 4) return false;
     const uint32_t scale = comps[0].dct_scale;
@@ -94,7 +94,7 @@ inline bool scaled_geom_from_job(const jpgpu_component *comps, uint32_t ncomp, c
     // Among equally good shapes the taller one, then the one with fewer workgroups.
     uint32_t best_tx = 8u, best_ry = 1u;
     uint64_t best_slots = ~0ull, best_wgs = ~0ull;  // (rows are tried in rising order: `<=` below lets the taller band win a tie)
-    static const uint32_t kRows[] = {1u, 2u, 3u, 4u, 6u, 8u};
+    static const uint32_t kRows[] = {1u, 2u, 3u, 4u, 6u, 8u, 12u, 16u};
     for (uint32_t ry : kRows) {
         if (ry > 1u && (ry > g.mcu_h || ry > ry_cap)) break;
         for (uint32_t tx = 8u; tx <= tx_cap; tx += 8u) {
