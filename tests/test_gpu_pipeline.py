@@ -360,7 +360,7 @@ import jpeg_decoder_amd as J
 from PIL import Image
 files = []
 for k, (w, h, sub, gray) in enumerate([(640, 480, "4:2:0", False), (321, 243, "4:2:2", False), (200, 120, "4:4:4", False), (300, 200, "4:4:4", True),
-                                       (1280, 720, "4:2:0", False), (64, 48, "4:2:0", False)] * 4):
+                                       (1280, 720, "4:2:0", False), (64, 48, "4:2:0", False)] * 4 + [(3840, 2160, "4:2:0", False)]):
     rgb = synth.synthetic_rgb(w, h, seed=100 + k)
     buf = io.BytesIO()
     Image.fromarray(rgb[..., 0] if gray else rgb).save(buf, format="JPEG", quality=70 + k, subsampling=sub)
@@ -388,11 +388,15 @@ print("ok")
 
 
 @pytest.mark.parametrize("env", [{"GPU_MAX_HW_QUEUES": "4"}, {"JPGPU_SYNC_TAIL": "8"}, {"JPGPU_SYNC_TAIL": "1", "JPGPU_SYNC_ITERS": "1"},
-                                 {"JPGPU_PIPE_DEV_SUB": "3", "JPGPU_PIPE_MAX_DEV_SUBS": "32"}, {"JPGPU_PIPE_STREAMS": "1"}],
+                                 {"JPGPU_PIPE_DEV_SUB": "3", "JPGPU_PIPE_MAX_DEV_SUBS": "32"}, {"JPGPU_PIPE_STREAMS": "1"},
+                                 # chunks of 12 blocks and a first pass over an eighth of each: thousands of chunks per image are still being
+                                 # corrected in the late launches — several spans per job, several rounds of 256 per span (huff_sync_late_kernel)
+                                 {"JPGPU_SYNC_BLOCKS": "12", "JPGPU_SYNC_MIN_SHIFT": "9", "JPGPU_SYNC_TAIL": "1", "JPGPU_SYNC_LAUNCHES": "40"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_pipeline_device_entropy_under_other_settings(env):
     """Settings a process reads once — the HIP runtime's default queue count, the
-    first sync pass over whole chunks or an eighth of them, tiny sub-batches, one compute stream: the device-entropy route of a
+    first sync pass over whole chunks or an eighth of them, tiny sub-batches, one compute stream, small chunks with most of them
+    corrected late: the device-entropy route of a
     process of its own must give the oracle's pixels (and the oracle's error for a truncated file) under each."""
     pytest.importorskip("PIL")
     import subprocess
