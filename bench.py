@@ -848,7 +848,8 @@ def main(argv=None):
     n_img = len(D.shard(images_total, rank, world)) if images_total else (args.batch or default_batch)
     # N > 1: launch groups exist so that the gather of one group's pixels runs behind the decode of the next; a group below ~64 images does
     # not fill the device (2160p, 8 images per group: 0.47 of the roofline against 0.58 in one launch, profiles/round3/10_other_workloads_bench.jsonl)
-    n_sub = args.sub_batches or (1 if world == 1 else min(8, max(1, n_img // 64)))
+    # (from the smallest shard, so that every rank makes the same number of groups: the gather pairs them up)
+    n_sub = args.sub_batches or (1 if world == 1 else min(8, max(1, ((images_total // world) if images_total else n_img) // 64)))
     steps = args.steps or (500 if world == 1 else 40)
     warmup = args.warmup if args.warmup >= 0 else (50 if world == 1 else 5)
     if args.dry_run:
