@@ -202,7 +202,10 @@ inline void s420_set_segments(FusedGeom &g, uint32_t n_images, uint32_t seg_rows
     uint32_t seg = seg_rows_override;
     if (seg == 0) {
         // (4:4:0: 0.766 / 0.758 / 0.754 ms with 2 / 3 / 4 segments of its five strips)
-        const uint32_t target = g.kind == FUSED_440 ? 4608u : 2304u;
+        // (round 4, with the colour phase at the lowest wave priority: 256 x 1080p — 768 strips — 2 segments of 34 rows 0.648 ms, 3 of 23
+        // 0.663, 4 of 17 0.6445-0.656, 5 of 14 0.652; 64 x 2160p — 384 strips — 4 of 34 0.641, 6 of 23 0.693, 8 of 17 0.660: about 1,536
+        // workgroups, one and a half times what the chip holds, instead of round 2's 2,304; profiles/round4/10_wave_priorities.txt)
+        const uint32_t target = g.kind == FUSED_440 ? 4608u : 1536u;
         const uint32_t per_seg = g.tiles_x * (n_images ? n_images : 1u);
         uint32_t n_seg = (target + per_seg / 2u) / per_seg;
         n_seg = n_seg < 1u ? 1u : n_seg;
