@@ -22,7 +22,7 @@
   At N = 1 the line also carries, OUTSIDE `value` (each verified against the oracle):
     k_4096            the same kernel-only figure on north_star's 4096-image batch (51 GB of arenas on one GPU);
     e2e               what the metric's words say — JPEG bytes in host memory -> RGB in HBM through jpgpu_pipeline_decode
-                      (entropy decoding on the device), 256, 1024 and 4096 files, best of 5 warm calls; the kernel time per phase
+                      (entropy decoding on the device), 256, 1024 and 4096 files, median and min of 7 warm calls; the kernel time per phase
                       from one sub-batch of 256 files alone on the device (kernels_256_one_sub_batch);
     cpu_baseline_e2e  the oracle's whole Decoder::decode() on the same files, one file per task on every granted core;
     sustained         the timed step repeated for --min-seconds (an independent look at `value`, long enough for a sampler).
@@ -102,6 +102,8 @@ def parse_args(argv=None):
                     help="after the K timed steps: repeat the step for at least this long and report it as `sustained` (0 = off)")
     ap.add_argument("--no-k4096", action="store_true", help="skip the 4096-image kernel-only figure (N = 1, default workload)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the JPEG-bytes -> RGB figures and their CPU comparator (N = 1, default workload)")
+    ap.add_argument("--no-scale-anchor", action="store_true", help="skip the N > 1 job (2160p x 4096) on this one GPU (N = 1, default workload)")
+    ap.add_argument("--no-cpu-budget", action="store_true", help="skip the E-against-host-CPUs sweep (N = 1, default workload)")
     ap.add_argument("--e2e-images", default="256,1024,4096", help="files per jpgpu_pipeline_decode call of the e2e block")
     ap.add_argument("--e2e-total", type=int, default=E2E_SHARDED_TOTAL, help="files of the e2e leg at N > 1 / --force-dist, sharded over the ranks")
     ap.add_argument("--e2e-encoder", default="auto", choices=["auto", "pillow", "builtin"],
@@ -181,20 +183,35 @@ def effective_cpus():
     return n
 
 
-def rank_cpu_share(rank, world):
-    """Host CPUs rank `rank` of `world` keeps its feeder threads on: a contiguous share of the CPUs this process may run on (on a
-    two-socket host the first ranks then sit on the first socket), and the thread budget that goes with it — the CPUs the cgroup
-    GRANTS, divided by the ranks (one pipeline keeps ~8 CPUs busy; `world` ranks that each started the default of one thread per
-    physical core would oversubscribe the host `world`-fold: VERDICT r3).  -> (cpu list, threads for jpgpu_pipeline_create)."""
+def rank_cpu_share(rank, world, bdfs=None, sysfs="/sys"):
+    """Host CPUs rank `rank` of `world` keeps its feeder threads on, and the thread budget that goes with it.  The CPUs: those of the
+    NUMA node the rank's GPU hangs off (its PCI bus id -> <sysfs>/bus/pci/devices/<id>/numa_node), split among the ranks whose GPUs
+    share the node; contiguous slices of the allowed list when the topology is unknown (jpeg_decoder_amd.distributed.cpu_shares, the
+    rule jpgpu_pipeline_create_multi applies in C).  The threads: the CPUs the cgroup GRANTS, divided by the ranks (one pipeline keeps
+    ~8 CPUs busy; `world` ranks that each started the default of one thread per physical core would oversubscribe the host
+    `world`-fold: VERDICT r3).  -> (cpu list, threads for jpgpu_pipeline_create)."""
+    import jpeg_decoder_amd.distributed as D
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         allowed = list(range(os.cpu_count() or 1))
-    a, b = len(allowed) * rank // world, len(allowed) * (rank + 1) // world
-    share = allowed[a:b] or allowed
+    shares, _nodes = D.cpu_shares(allowed, bdfs if bdfs else [""] * world, sysfs)
+    share = shares[rank] or allowed
     # (the library's own default for ONE pipeline is twice the granted CPUs — its threads wait for the device and the link a good
     # part of a call; 16 threads on 16 granted CPUs measured 71.9 ms per 4,096 files against 53.3 with 32)
     return share, max(2, 2 * effective_cpus() // world)
+
+
+def device_bdfs(J, world):
+    """PCI bus ids of devices 0 .. world-1 as this process sees them (rank r drives device r); [] if they cannot be read."""
+    import ctypes
+    out = []
+    for k in range(world):
+        buf = ctypes.create_string_buffer(64)
+        if J._native.lib().jpgpu_device_pci_bus_id(k, buf, 64) != 0:
+            return []
+        out.append(buf.value.decode())
+    return out
 
 
 def pin_to(share):
@@ -312,6 +329,39 @@ def k_4096(J, torch, O, variants, device_index, dev, stream, w, h, digest, n_img
         sh.close()
 
 
+def scale_anchor(J, torch, O, synth, D, device_index, dev, stream, steps=10):
+    """The N > 1 job on ONE GPU (VERDICT r4 #2c): configs[2] — 3840x2160 4:2:0 x 4,096, coefficients resident in HBM -> RGB in HBM, the
+    same launch groups the ranks of an N-GPU run make (8 groups) — so that the 1 -> 8 curve has a first point on its own workload
+    (`value` at N = 1 is configs[1]: 1080p x 256).  204 GB of arenas; shrunk, loudly, if this GPU has less free."""
+    w, h, sampling, mode, ct = WORKLOADS[CONFIG3_WORKLOAD][:5]
+    variants = build_variants(J, synth, w, h, sampling, mode, ct)
+    per_image = algorithmic_bytes_per_image(variants[0]["comps"], w * h * 3)
+    want_n = CONFIG3_IMAGES_TOTAL
+    free_b, _t = torch.cuda.mem_get_info(dev)
+    n_img = want_n
+    while n_img > 64 and n_img * per_image > 0.92 * free_b:
+        n_img = int(n_img * 0.9)
+    n_sub = min(8, max(1, n_img // 64))
+    sh = Shard(J, torch, variants, n_img, n_sub, device_index)
+    try:
+        for _ in range(3):
+            sh.decode(stream)
+        elapsed, ms = time_steps(torch, dev, None, stream, steps, lambda: sh.decode(stream))
+        ocomps, _ = O.make_components(w, h, sampling)
+        digest = hashlib.sha256(O.pixels_from_coefficients(ocomps, variants[0]["qts"], variants[0]["coefs"], w, h, ct.upper()).tobytes()).hexdigest()
+        ok = all(hashlib.sha256(sh.image_pixels(i).cpu().numpy().tobytes()).hexdigest() == digest for i in (0, n_img // 2 + 1, n_img - 1))
+        alg = per_image * n_img
+        return {"workload": f"{w}x{h} 4:2:0 x {n_img} on one GPU (BASELINE configs[2], the job bench.py --gpus N shards)", "name": CONFIG3_WORKLOAD,
+                "images": n_img, "images_requested": want_n, "shrunk_to_fit_hbm": n_img < want_n, "sub_batches": n_sub, "steps": steps,
+                "ms_per_step": round(elapsed / steps * 1e3, 3), "kernel_ms_per_step": round(ms, 3),
+                "value": round(n_img * w * h / 1e6 * steps / elapsed, 1), "unit": "MP/s",
+                "roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "arena_bytes": int(sh.coef_arena.numel() + sh.out_arena.numel()),
+                "kernel_path": sh.path, "verified_vs_oracle": bool(ok),
+                "what": "the N > 1 job's kernel-only figure at N = 1: divide the N-GPU `value` by this for the scaling efficiency on one workload"}
+    finally:
+        sh.close()
+
+
 def e2e_files(synth, w, h, encoder, distinct=4, restart_rows=0):
     """`distinct` baseline 4:2:0 q85 files of the bench's synthetic image (seeds 0x5EED + k); -> (files, who wrote them).
     restart_rows: a restart marker every that many MCU rows (DRI)."""
@@ -388,11 +438,66 @@ def e2e_floor_fields(e, best, h2d_gbps, alone_ms_per_image):
     e["bound"] = None if not floors else ("link" if link and link >= (work or 0) else "device work")
 
 
-def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
+def d2h_rate_gbps(torch, dev, nbytes=1 << 30):
+    """The other direction of the link: one pinned 1-GB device-to-host copy, best of 3, this run (the floor of an E call that hands its
+    pixels to a host consumer — Decoder::decode()'s Vec<u8>, src/decoder.rs:293-295 — is its pixel bytes at this rate)."""
+    dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    return nbytes / (best * 1e-3) / 1e9
+
+
+def warm_calls(p, files, calls, cold=1, **kw):
+    """`cold` uncounted calls (the first one allocates arenas and staging), then `calls` counted ones -> their timings, in call order.
+    Raises the first per-image error."""
+    out = []
+    for r in range(cold + calls):
+        res = p.decode(files, **kw)
+        bad = [x for x in res if isinstance(x, Exception)]
+        if bad:
+            raise bad[0]
+        if r >= cold:
+            out.append(p.timings())
+    return out
+
+
+def call_stats(ts, key="total_ms"):
+    """median + min of the counted calls.  -> (the timings of the median call, median ms, min ms)"""
+    order = sorted(ts, key=lambda t: t[key])
+    med = order[(len(order) - 1) // 2]  # (lower median: a call that really happened, whose other fields go with it)
+    return med, med[key], order[0][key]
+
+
+def e2e_entry(n, ts, w, h, p, ok, extra=None):
+    med, med_ms, min_ms = call_stats(ts)
+    e = {"images": n, "calls": len(ts), "total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3),
+         "images_per_s": round(n / med_ms * 1e3, 1), "images_per_s_best": round(n / min_ms * 1e3, 1),
+         "value": round(n * w * h / 1e6 / med_ms * 1e3, 1), "unit": "MP/s",
+         "wall_ms": {k[:-3]: round(med[k], 3) for k in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "download_ms")},
+         "cpu_ms_per_image": round(med["cpu_ms"] / max(n, 1), 5),
+         "images_device_entropy": int(med["images_device_entropy"]), "images_device_rejected": int(med["images_device_rejected"]),
+         "images_host_light": int(med["images_host_light"]), "threads": int(med["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(ok)}
+    if extra:
+        e.update(extra)
+    return e, med
+
+
+def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
     """What the metric's words say: JPEG bytes in host memory -> RGB in HBM, through jpgpu_pipeline_decode with the entropy
     decoding on the device (no host Huffman decoding, no range scan, no host synchronisation in front of the pixel kernels).
-    Per batch size: best of 5 warm calls (wall clock of the call, everything included: header parsing, staging, H2D, kernels) and a
-    check of first / middle / last image against the oracle; the kernel time per phase from one sub-batch run alone."""
+    Per batch size: median and min of 7 warm calls (wall clock of the call, everything included: header parsing, staging, H2D, kernels)
+    and a check of first / middle / last image against the oracle; the kernel time per phase from one sub-batch run alone."""
     os.environ["JPGPU_BATCH_KERNEL_TIMES"] = "1"  # (read once by the library: events around the phases, microseconds per sub-batch)
     distinct, who = e2e_files(synth, w, h, encoder)
     want = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in distinct]
@@ -400,29 +505,17 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
            "jpeg_bytes_per_image": int(sum(len(d) for d in distinct) / len(distinct)),
            "what": "jpgpu_pipeline_decode: JPEG bytes in host memory -> RGB resident in HBM; entropy decoding ON THE DEVICE "
                    "(self-synchronising chunk decoder with speculative emission), classes from its statistics, pixel kernels right behind it; "
-                   "best of 5 warm calls; wall clock of the whole call"}
+                   "per entry 7 warm calls after 2 uncounted ones: total_ms / images_per_s / value = their MEDIAN, min_ms / images_per_s_best = the "
+                   "fastest (SURVEY 8d); wall clock of the whole call; cpu_ms_per_image = process CPU time of the median call / images"}
     p = J.Pipeline()
     bests = {}
     try:
         for n in sizes:
             files = [distinct[i % len(distinct)] for i in range(n)]
-            best = None
-            for r in range(6):  # the first call allocates arenas and staging: not counted (and calls 2-3 still run ~20 % slower than the steady state)
-                res = p.decode(files, download=False, device_entropy=True)
-                bad = [x for x in res if isinstance(x, Exception)]
-                if bad:
-                    raise bad[0]
-                t = p.timings()
-                if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
-                    best = t
+            # (the first call allocates arenas and staging: not counted — and calls 2-3 still run ~20 % slower than the steady state)
+            ts = warm_calls(p, files, 7, cold=2, download=False, device_entropy=True)
             ok = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, 1, n // 2, n - 1}))
-            e = {"images": n, "total_ms": round(best["total_ms"], 3), "images_per_s": round(n / best["total_ms"] * 1e3, 1),
-                 "value": round(n * w * h / 1e6 / best["total_ms"] * 1e3, 1), "unit": "MP/s",
-                 "wall_ms": {k[:-3]: round(best[k], 3) for k in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "download_ms")},
-                 "images_device_entropy": int(best["images_device_entropy"]), "images_device_rejected": int(best["images_device_rejected"]),
-                 "threads": int(best["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(ok)}
-            out[str(n)] = e
-            bests[str(n)] = best
+            out[str(n)], bests[str(n)] = e2e_entry(n, ts, w, h, p, ok)
         # The kernels alone: the same 256 files as ONE sub-batch with the device to itself (the pipeline's default splits a call into
         # sub-batches of 128 that run side by side on their own streams: their phase times overlap and do not add up to anything).
         os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"] = "256", "1"
@@ -474,53 +567,110 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None):
                 rwant = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in rfiles]
                 n = 1024
                 files = [rfiles[i % len(rfiles)] for i in range(n)]
-                best = None
-                for r in range(4):
-                    res = p.decode(files, download=False, device_entropy=True)
-                    bad = [x for x in res if isinstance(x, Exception)]
-                    if bad:
-                        raise bad[0]
-                    t = p.timings()
-                    if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
-                        best = t
+                ts = warm_calls(p, files, 5, cold=1, download=False, device_entropy=True)
                 okr = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == rwant[i % len(rfiles)] for i in (0, 1, n // 2, n - 1))
-                out["restart_every_mcu_row_1024"] = {
-                    "images": n, "input": f"{len(rfiles)} distinct {w}x{h} files, repeated; written by {rwho}",
-                    "total_ms": round(best["total_ms"], 3), "images_per_s": round(n / best["total_ms"] * 1e3, 1),
-                    "value": round(n * w * h / 1e6 / best["total_ms"] * 1e3, 1), "unit": "MP/s",
-                    "images_device_entropy": int(best["images_device_entropy"]), "images_device_rejected": int(best["images_device_rejected"]),
-                    "threads": int(best["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(okr)}
+                out["restart_every_mcu_row_1024"], _ = e2e_entry(n, ts, w, h, p, okr, {"input": f"{len(rfiles)} distinct {w}x{h} files, repeated; written by {rwho}"})
             except Exception as e:  # noqa: BLE001 (this entry only)
                 out["restart_every_mcu_row_1024"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        # BASELINE configs[3]: benches/tower_progressive.jpg (512 x 512 progressive, 10 scans) x 256.  Progressive scans are
-        # entropy-decoded on the HOST (refinement scans depend on the accumulated coefficients: DESIGN.md 7), the finished
-        # planes go up in the compact form and the device does the pixel work: this figure is bound by the host's cores.
+        # E as SURVEY 8(d) words it for one GPU — JPEG bytes in host memory -> RGB in HOST memory, what Decoder::decode() returns
+        # (a Vec<u8>, src/decoder.rs:293-295): JPGPU_PIPELINE_DOWNLOAD, every sub-batch's pixels copied to pinned host memory behind its
+        # kernels on a download stream of its own.  Floor: the pixel bytes at the D2H rate one pinned 1-GB copy reached in this run.
+        for n in [x for x in (256, 4096) if sizes and x <= max(sizes)]:
+            key = f"to_host_{n}"
+            try:
+                files = [distinct[i % len(distinct)] for i in range(n)]
+                ts = warm_calls(p, files, 5, cold=1, download="pinned", device_entropy=True)
+                ok = all(hashlib.sha256(p.pixels_host(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, 1, n // 2, n - 1}))
+                e, med = e2e_entry(n, ts, w, h, p, ok)
+                e["pixel_bytes"] = int(med["pixel_bytes"])
+                if d2h_gbps:
+                    e["link_floor_ms"] = round(med["pixel_bytes"] / (d2h_gbps * 1e9) * 1e3, 3)
+                    e["frac_of_floor"] = round(e["link_floor_ms"] / e["total_ms"], 4)
+                    e["frac_of_floor_best"] = round(e["link_floor_ms"] / e["min_ms"], 4)
+                    e["bound"] = "link (device to host)"
+                    e["d2h_gbps"] = round(d2h_gbps, 2)
+                e["what"] = "JPEG bytes in host memory -> RGB in pinned HOST memory (JPGPU_PIPELINE_DOWNLOAD): the D2H copy of a sub-batch runs behind its kernels on a download stream, next to the decode of the following sub-batches"
+                out[key] = e
+            except Exception as e:  # noqa: BLE001 (this entry only)
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # BASELINE configs[3]: benches/tower_progressive.jpg (512 x 512 progressive, 10 scans) x 256 and x 4,096.  Round 5: the scans of a
+        # progressive frame are decoded ON THE DEVICE — one lane per chain of dependent scans, coefficients accumulated in the arena
+        # (csrc/huff_prog_core.hpp) — for as many of a call's frames as finish while the host's threads decode the rest.
         tp = os.path.join(ROOT, "tests", "golden", "benches", "tower_progressive.jpg")
         if os.path.exists(tp):
             data = open(tp, "rb").read()
             od = O.decode(data)
-            files = [data] * 256
-            best = None
-            for r in range(4):
-                res = p.decode(files, download=False, device_entropy=True)
-                bad = [x for x in res if isinstance(x, Exception)]
-                if bad:
-                    raise bad[0]
-                t = p.timings()
-                if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
-                    best = t
-            okp = all(np.array_equal(p.download(i), od.pixels) for i in (0, 128, 255))
-            out["tower_progressive_256"] = {
-                "images": 256, "file": "tests/golden/benches/tower_progressive.jpg (the reference's benches/tower_progressive.jpg: 512x512, 10 scans)",
-                "total_ms": round(best["total_ms"], 3), "images_per_s": round(256 / best["total_ms"] * 1e3, 1),
-                "value": round(256 * od.width * od.height / 1e6 / best["total_ms"] * 1e3, 1), "unit": "MP/s",
-                "images_device_entropy": int(best["images_device_entropy"]), "threads": int(best["threads"]), "kernel_path": p.kernel_path,
-                "verified_vs_oracle": bool(okp), "bound_by": "host entropy decoding (progressive refinement scans), then compact upload + pixel kernels"}
+            for n in [x for x in (256, 4096) if sizes and x <= max(sizes)]:
+                key = f"tower_progressive_{n}"
+                try:
+                    files = [data] * n
+                    ts = warm_calls(p, files, 5, cold=1, download=False, device_entropy=True)
+                    okp = all(np.array_equal(p.download(i), od.pixels) for i in sorted({0, 1, n // 2, n - 1}))
+                    e, med = e2e_entry(n, ts, od.width, od.height, p, okp)
+                    e["file"] = "tests/golden/benches/tower_progressive.jpg (the reference's benches/tower_progressive.jpg: 512x512, 10 scans)"
+                    e["images_device_progressive"] = int(med["images_device_progressive"])
+                    ts_h = warm_calls(p, files, 3, cold=1, download=False, device_entropy=True, progressive_on_host=True)
+                    _m, med_ms, min_ms = call_stats(ts_h)
+                    e["all_on_host_entropy_decoder"] = {"total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3), "images_per_s": round(n / med_ms * 1e3, 1),
+                                                        "what": "the same call with JPGPU_PIPELINE_PROGRESSIVE_ON_HOST (round 4's path: host entropy decoding, compact planes uploaded)"}
+                    out[key] = e
+                except Exception as e:  # noqa: BLE001 (this entry only)
+                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
             files_for_cpu = (files_for_cpu, [data] * 64, (od.width, od.height))
     finally:
         p.close()
         J._native.lib().jpgpu_trim_caches()
     return out, files_for_cpu
+
+
+def e2e_cpu_budget(J, O, synth, w, h, encoder, n=4096, points=(1, 2, 4, 8, 16)):
+    """E against the host CPUs a GPU's feeder gets: on an 8-GPU node with 16 granted CPUs every rank has two.  The
+    4,096-file call with the calling thread's affinity — and with it the pipeline's pools, created under it — narrowed to the first
+    1 / 2 / 4 / 8 / 16 allowed CPUs and threads = 2 x CPUs (rank_cpu_share's rule).  Per point two inputs: the files in ordinary
+    (pageable) memory, mode chosen by the library (host-light — raw scans copied, marker check + unstuffing on the device — for
+    pipelines of <= 4 threads, host staging above); and the same files in a pinned arena (PinnedFiles: what a loader that reads into
+    jpgpu_host_alloc memory holds) with JPGPU_PIPELINE_INPUT_PINNED, where the DMA engine reads the arena itself."""
+    distinct, who = e2e_files(synth, w, h, encoder)
+    want = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in distinct]
+    files = [distinct[i % len(distinct)] for i in range(n)]
+    allowed = sorted(os.sched_getaffinity(0))
+    granted = effective_cpus()
+    out = {"images": n, "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}", "host_cpus_granted": granted,
+           "what": "jpgpu_pipeline_decode of the same 4,096 files with affinity (sched_setaffinity before the pipeline's threads are created) and thread "
+                   "count limited: JPEG bytes in host memory -> RGB in HBM; per point median / min of 3 warm calls after one uncounted; "
+                   "cpu_ms_per_image = process CPU time of the median call / images",
+           "points": []}
+    arena = J.PinnedFiles(files)
+    try:
+        for c in points:
+            if c > min(granted, len(allowed)):
+                continue
+            row = {"cpus": c, "threads": max(2, 2 * c)}
+            os.sched_setaffinity(0, allowed[:c])
+            try:
+                p = J.Pipeline(threads=row["threads"])
+                try:
+                    for name, src, kw in (("pageable_input", files, {}), ("pinned_input", arena, {"input_pinned": True})):
+                        try:
+                            ts = warm_calls(p, src, 3, cold=1, download=False, device_entropy=True, **kw)
+                            ok = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, n // 2, n - 1}))
+                            med, med_ms, min_ms = call_stats(ts)
+                            row[name] = {"total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3), "images_per_s": round(n / med_ms * 1e3, 1),
+                                         "cpu_ms_per_image": round(med["cpu_ms"] / n, 5), "cpus_busy": round(med["cpu_ms"] / med_ms, 2),
+                                         "mode": "host-light" if med["images_host_light"] else "host staging",
+                                         "images_host_light": int(med["images_host_light"]), "images_device_entropy": int(med["images_device_entropy"]),
+                                         "verified_vs_oracle": bool(ok)}
+                        except Exception as e:  # noqa: BLE001 (this point only)
+                            row[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                finally:
+                    p.close()
+            finally:
+                os.sched_setaffinity(0, allowed)
+            out["points"].append(row)
+    finally:
+        arena.close()
+        J._native.lib().jpgpu_trim_caches()
+    return out
 
 
 def cpu_baseline_e2e(O, files, w, h, target_seconds):
@@ -557,44 +707,66 @@ def _cpu_e2e_sample(O, files, w, h, target_seconds):
 def e2e_sharded(J, O, synth, D, dist, torch, dev, rank, local_rank, world, w, h, total, encoder, share, threads, pinned):
     """E at N ranks (north_star: "throughput on synthetic 4:2:0 baseline JPEGs is reported at 1, 2, 4 and 8 GPUs"): `total` files, rank r
     decodes D.shard(total, r, world) of them through a pipeline of its own on ITS GPU with ITS share of the host (CPU affinity set,
-    threads = granted CPUs / ranks); every call starts behind a barrier, so the ranks contend for the host at the same moment; the
-    job's time is the slowest rank's best warm call (MAX over ranks).  No collective on the data path; pixels stay in each rank's HBM."""
-    distinct, who = e2e_files(synth, w, h, encoder)
+    threads = 2 x granted CPUs / ranks); every call starts behind a barrier, so the ranks contend for the host at the same moment; the
+    job's time is the slowest rank's (MAX over ranks) median — and min — of 5 warm calls.  No collective on the data path; pixels
+    stay in each rank's HBM.
+    Collectives and failures: every rank runs the SAME sequence of collectives whatever happens to it locally — a local
+    error is caught, kept, and an all-reduced flag after every call lets all ranks leave the loop together; the error is re-raised only
+    after the last collective."""
+    err, p, files, ts, distinct, who = None, None, [], [], [], ""
     mine = D.shard(total, rank, world)
-    files = [distinct[i % len(distinct)] for i in mine]
-    p = J.Pipeline(device=local_rank, threads=threads)
     try:
-        best = None
-        for r in range(6):  # the first call allocates arenas and staging: not counted
-            torch.cuda.synchronize(dev)
-            if dist:
-                dist.barrier()
-            res = p.decode(files, download=False, device_entropy=True)
-            bad = [x for x in res if isinstance(x, Exception)]
-            if bad:
-                raise bad[0]
-            t = p.timings()
-            if r > 0 and (best is None or t["total_ms"] < best["total_ms"]):
-                best = t
-        ok = 1.0
-        if files:
-            want = {k: hashlib.sha256(O.decode(distinct[k]).pixels.tobytes()).hexdigest() for k in {mine[0] % len(distinct), mine[len(mine) - 1] % len(distinct)}}
-            for j in (0, len(files) - 1):
-                ok = min(ok, 1.0 if hashlib.sha256(p.download(j).tobytes()).hexdigest() == want[mine[j] % len(distinct)] else 0.0)
-        mine_ms = best["total_ms"] if best else 0.0
-        slowest, = D.max_over_ranks([mine_ms], device=dev)
-        all_ok = D.min_over_ranks(ok, device=dev)
-        kernel_path = p.kernel_path
-    finally:
+        distinct, who = e2e_files(synth, w, h, encoder)
+        files = [distinct[i % len(distinct)] for i in mine]
+        p = J.Pipeline(device=local_rank, threads=threads)
+    except Exception as e:  # noqa: BLE001 (kept: see above)
+        err = e
+    for r in range(6):  # the first call allocates arenas and staging: not counted
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        if err is None:
+            try:
+                res = p.decode(files, download=False, device_entropy=True)
+                bad = [x for x in res if isinstance(x, Exception)]
+                if bad:
+                    raise bad[0]
+                if r > 0:
+                    ts.append(p.timings())
+            except Exception as e:  # noqa: BLE001
+                err = e
+        if D.min_over_ranks(0.0 if err else 1.0, device=dev) < 1.0:
+            break  # (every rank sees the same flag: all leave here together)
+    ok, mine_ms, mine_min, med, kernel_path = 0.0, 0.0, 0.0, None, ""
+    if err is None:
+        try:
+            ok = 1.0
+            if files:
+                want = {k: hashlib.sha256(O.decode(distinct[k]).pixels.tobytes()).hexdigest() for k in {mine[0] % len(distinct), mine[len(mine) - 1] % len(distinct)}}
+                for j in (0, len(files) - 1):
+                    ok = min(ok, 1.0 if hashlib.sha256(p.download(j).tobytes()).hexdigest() == want[mine[j] % len(distinct)] else 0.0)
+            if ts:
+                med, mine_ms, mine_min = call_stats(ts)
+            kernel_path = p.kernel_path
+        except Exception as e:  # noqa: BLE001
+            err, ok = e, 0.0
+    slowest, slowest_min, cpu_ms = D.max_over_ranks([mine_ms, mine_min, med["cpu_ms"] if med else 0.0], device=dev)
+    all_ok = D.min_over_ranks(ok if err is None else 0.0, device=dev)
+    if p is not None:
         p.close()
-    return {"images": total, "images_per_rank": len(files), "ranks": world, "total_ms": round(slowest, 3),
+    if err is not None:
+        raise err  # (after the last collective of this leg)
+    return {"images": total, "images_per_rank": len(files), "ranks": world, "calls": len(ts), "total_ms": round(slowest, 3), "min_ms": round(slowest_min, 3),
             "images_per_s": round(total / slowest * 1e3, 1) if slowest else None,
+            "images_per_s_best": round(total / slowest_min * 1e3, 1) if slowest_min else None,
             "value": round(total * w * h / 1e6 / slowest * 1e3, 1) if slowest else None, "unit": "MP/s",
             "rank0_ms": round(mine_ms, 3), "threads_per_rank": threads, "cpus_per_rank": len(share), "cpu_affinity_set": bool(pinned),
-            "host_cpus_granted": effective_cpus_unpinned(), "kernel_path": kernel_path, "verified_vs_oracle": bool(all_ok >= 1.0),
+            "cpu_ms_per_image_slowest_rank": round(cpu_ms / max(len(files), 1), 5),
+            "mode": ("host-light" if med and med["images_host_light"] else "host staging"),
+            "host_cpus_granted": effective_cpus_unpinned(), "kernel_path": kernel_path, "verified_vs_oracle": bool(all_ok >= 1.0), "every_rank_ok": bool(all_ok >= 1.0),
             "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}",
             "what": "jpgpu_pipeline_decode per rank on its shard of the file list (entropy decoding on the device), every call behind a barrier; "
-                    "MAX over ranks of the best of 5 warm calls; pixels stay in each rank's HBM"}
+                    "MAX over ranks of each rank's median (total_ms) and min (min_ms) of 5 warm calls; pixels stay in each rank's HBM"}
 
 
 _UNPINNED_CPUS = None
@@ -1105,6 +1277,16 @@ def main(argv=None):
         except Exception as e:  # noqa: BLE001
             line["k_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
+    if rank == 0 and default_run and not args.no_scale_anchor and not args.force_dist:
+        if shard is not None:
+            shard.close()
+            shard = None
+        torch.cuda.empty_cache()
+        try:
+            line["scale_anchor"] = scale_anchor(J, torch, O, synth, D, local_rank, dev, stream)
+        except Exception as e:  # noqa: BLE001
+            line["scale_anchor"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
     if dist and not args.no_e2e and not args.generic:
         # ---- N > 1 (and --force-dist): E per rank on its shard of the file list, with a per-rank host budget ----
         if shard is not None:
@@ -1115,12 +1297,12 @@ def main(argv=None):
         try:
             global _UNPINNED_CPUS
             _UNPINNED_CPUS = effective_cpus()
-            share, threads = rank_cpu_share(rank, world)
+            share, threads = rank_cpu_share(rank, world, device_bdfs(J, world))
             pinned = pin_to(share)
             import oracle as O_all  # (every rank checks two of its own images: the oracle as checker)
             w1, h1 = WORKLOADS["1080p-420"][0], WORKLOADS["1080p-420"][1]
             sharded = e2e_sharded(J, O_all, synth, D, dist, torch, dev, rank, local_rank, world, w1, h1, args.e2e_total, args.e2e_encoder, share, threads, pinned)
-        except Exception as e:  # noqa: BLE001 (never lose the line to this leg; the other ranks' collectives are bounded by their own try)
+        except Exception as e:  # noqa: BLE001 (never lose the line to this leg; e2e_sharded raises only after its last collective, so the ranks stay in step)
             e2e_error = f"{type(e).__name__}: {e}"[:300]
         if rank == 0:
             line.setdefault("e2e", {})["sharded"] = sharded if sharded else {"error": e2e_error}
@@ -1129,8 +1311,13 @@ def main(argv=None):
             shard.close()
             shard = None
         try:
-            e2e, files = e2e_block(J, O, synth, w, h, [int(x) for x in args.e2e_images.split(",") if x], args.e2e_encoder, h2d_rate_gbps(torch, dev))
+            e2e, files = e2e_block(J, O, synth, w, h, [int(x) for x in args.e2e_images.split(",") if x], args.e2e_encoder, h2d_rate_gbps(torch, dev), d2h_rate_gbps(torch, dev))
             line.setdefault("e2e", {}).update(e2e)
+            if not args.no_cpu_budget:
+                try:
+                    line["e2e"]["cpu_budget"] = e2e_cpu_budget(J, O, synth, w, h, args.e2e_encoder)
+                except Exception as e:  # noqa: BLE001
+                    line["e2e"]["cpu_budget"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if not args.no_cpu_baseline:
                 line["cpu_baseline_e2e"] = cpu_baseline_e2e(O, files, w, h, args.cpu_seconds)
         except Exception as e:  # noqa: BLE001

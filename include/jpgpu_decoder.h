@@ -110,6 +110,18 @@ typedef struct jpgpu_pipeline_timings {
      * MAXIMUM over the devices, the counts and byte totals the SUM; total_ms is always the whole call. */
     double decode_ms, gather_ms;
     uint64_t gather_bytes;
+    /* ---- appended in 0.2 (round 5) ---- */
+    /* JPGPU_PIPELINE_GATHER: every device copies a sub-batch's pixels to the first device behind that sub-batch's kernels, on a stream
+     * of its own: gather_ms (above) is what the call still WAITED for the copies once the last device had decoded — the exposed part;
+     * gather_copy_ms is the longest device's summed copy time (events around each copy).  copy - exposed ran under the decode. */
+    double gather_copy_ms;
+    /* CPU time the whole process used during the call, all threads (CLOCK_PROCESS_CPUTIME_ID): cpu_ms / images = what an image costs the
+     * host — the figure that decides how many GPUs a host with few cores can feed. */
+    double cpu_ms;
+    uint32_t images_host_light; /* of images_device_entropy: scans uploaded as the file holds them, marker check + unstuffing on the device */
+    uint32_t input_pinned;      /* JPGPU_PIPELINE_INPUT_PINNED was in force: the DMA engine read the caller's buffers, no staging copy */
+    uint32_t images_device_progressive; /* of images_device_entropy: progressive frames whose scans were decoded and accumulated on the device */
+    uint32_t _pad2;
 } jpgpu_pipeline_timings;
 
 enum {
@@ -121,24 +133,58 @@ enum {
                                    * per chunk of 64 bytes to 4 kB, csrc/huff_sync_core.hpp; a restart segment — src/decoder.rs:920-956:
                                    * segments are independent — is a scan in miniature with chunk slots of its own); every
                                    * other stream, and any stream the device decoder flags, takes the host path */
-    /* (8u: round 2-3's per-scan delta transport for progressive streams — measured 2.5 x slower than the compact planes, deleted in round 4) */
-    , JPGPU_PIPELINE_GATHER = 16u /* pipelines over several devices: after the decode copy every device's pixels to the FIRST device of
-                                   * the list (peer-to-peer, one xGMI link per peer; SURVEY 8e, north_star's final gather);
-                                   * jpgpu_pipeline_pixels_device then points into that copy */
+    /* (8u: round 2-3's per-scan delta transport for progressive streams — measured 2.5 x slower than the compact planes, deleted in round 4;
+     * the bit is REFUSED since 0.2, like every unknown bit: JPGPU_ERR_FORMAT) */
+    , JPGPU_PIPELINE_GATHER = 16u /* pipelines over several devices: every device copies each sub-batch's pixels to the FIRST device of
+                                   * the list as soon as the sub-batch is decoded (peer-to-peer on a stream of the source device: one
+                                   * xGMI link per peer, overlapped with the decode of the following sub-batches; SURVEY 8e, north_star's
+                                   * final gather); jpgpu_pipeline_pixels_device then points into that copy.  Ignored by a one-device pipeline. */
+    /* ---- host CPU per image (round 5).  With JPGPU_PIPELINE_DEVICE_ENTROPY the host's share of a baseline file is the staging pass:
+     * 0xFF00 -> 0xFF while copying the scan into pinned memory, ~80 us per 1080p file and core, which is what caps a host with two cores per
+     * GPU at ~20 k images/s.  "Host light": the scan goes up as the file holds it (one memcpy, ~35 us; or no copy at all with
+     * JPGPU_PIPELINE_INPUT_PINNED) and three small kernels check it for markers and drop the stuffing zeros on the device (a stream with
+     * anything but 0xFF00 pairs inside is handed back to the host decoder, as the staging pass does).  Chosen automatically when the
+     * pipeline was created with <= 4 worker threads; these two bits force either way.  Streams with restart markers are staged by the
+     * host in both modes (their markers must be found before the segments can be laid out). */
+    , JPGPU_PIPELINE_HOST_LIGHT = 32u
+    , JPGPU_PIPELINE_HOST_STAGED = 64u
+    , JPGPU_PIPELINE_INPUT_PINNED = 128u /* every `data[i]` lies in page-locked host memory (jpgpu_host_alloc, or the caller's own
+                                   * hipHostMalloc / hipHostRegister): host-light uploads then read the caller's buffers directly —
+                                   * files that follow one another in memory (gaps up to 4 kB) travel in one copy.  Passing pageable
+                                   * memory with this flag is an error the runtime may or may not report: do not. */
+    , JPGPU_PIPELINE_PROGRESSIVE_ON_HOST = 256u /* A/B switch: progressive frames take the host entropy decoder even with
+                                   * JPGPU_PIPELINE_DEVICE_ENTROPY (round 4's behaviour); default since 0.2: the device decodes as many
+                                   * of a call's progressive frames as finish while the host threads decode the rest */
 };
+/* Page-locked host memory for JPEG input (hipHostMalloc): read files straight into it and pass JPGPU_PIPELINE_INPUT_PINNED. */
+int jpgpu_host_alloc(size_t bytes, void **out);
+void jpgpu_host_free(void *p);
 /* flags of jpgpu_pipeline_create_multi */
 enum {
-    JPGPU_PIPELINE_MULTI_PIN_CPUS = 1u /* give every device's host threads their own contiguous share of the CPUs the calling thread
-                                   * may run on (sched_setaffinity) */
+    JPGPU_PIPELINE_MULTI_PIN_CPUS = 1u /* give every device's host threads their own share of the CPUs the calling thread may run on
+                                   * (sched_setaffinity): the CPUs of the NUMA node the device's PCIe root hangs off, split among the
+                                   * devices of that node; contiguous slices of the allowed list when the topology is unknown
+                                   * (jpgpu_plan_cpu_shares) */
 };
+/* The dealing rule itself, for deployments (and tests) that want to look at it: device k = PCI bus id pci_bus_ids[k]
+ * ("0000:c1:00.0", jpgpu_device_pci_bus_id), its NUMA node from <sysfs>/bus/pci/devices/<id>/numa_node, the node's CPUs from
+ * <sysfs>/devices/system/node/node<N>/cpulist (sysfs NULL: "/sys").  device_of_cpu[i] receives the device that gets allowed_cpus[i]
+ * (-1: none), numa_nodes[k] (optional) the node found for device k (-1: unknown -> contiguous slices for everybody). */
+int jpgpu_plan_cpu_shares(const char *sysfs, const char *const *pci_bus_ids, uint32_t n_devices, const int *allowed_cpus, uint32_t n_allowed,
+                          int *device_of_cpu, int *numa_nodes);
+int jpgpu_device_pci_bus_id(int device, char *buf, size_t cap); /* cap >= 13 */
 
-/* n_threads 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if there is one. */
+/* n_threads = entropy / header workers; 0 = one per physical core (half the hardware threads), capped at twice a cgroup CPU quota if
+ * there is one.  Half as many again (at least two) staging threads for the device-entropy route come on top, and one uploader thread
+ * per call that mostly waits: jpgpu_pipeline_timings::threads reports workers + staging threads. */
 int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out);
 /* The same object over SEVERAL devices (the reference has one Decoder per stream, src/decoder.rs:134-154 — images are
  * independent, so a batch shards by image and nothing crosses devices while it decodes): `devices` = n_devices HIP ordinals (an
  * ordinal may appear more than once: that many sub-pipelines share the device).  Image i of a call goes to devices[i mod n_devices];
- * every per-image accessor below takes the call's own image index.  n_threads = host threads for ALL devices together (0: what ONE
- * pipeline takes by default), split evenly — the host's cores are the shared resource, not the devices. */
+ * every per-image accessor below takes the call's own image index.  n_threads = host threads for ALL devices together, workers AND
+ * staging threads (0: what ONE pipeline's workers take by default), split evenly, two thirds workers — the host's cores are the
+ * shared resource, not the devices.  Peer access between every listed device and the first is switched on here; if the runtime
+ * refuses it, calls with JPGPU_PIPELINE_GATHER fail with the reason. */
 int jpgpu_pipeline_create_multi(const int *devices, uint32_t n_devices, uint32_t n_threads, uint32_t flags, jpgpu_pipeline **out);
 uint32_t jpgpu_pipeline_device_count(const jpgpu_pipeline *p);                    /* 1 for jpgpu_pipeline_create */
 int jpgpu_pipeline_image_device(const jpgpu_pipeline *p, uint32_t image);          /* HIP ordinal of the device that decoded it; -1 */

@@ -8,12 +8,12 @@ from ._native import Component, ImageDesc, build, device_count, lib, process_ini
 from .batch import Batch, image_desc
 from .decoder import CODING_PROCESSES, PIXEL_FORMATS, Decoder, ImageInfo, decode_batch
 from .error import Error, FormatError, InternalError, IoError, NoDeviceError, UnsupportedError
-from .pipeline import Pipeline
+from .pipeline import PinnedFiles, Pipeline
 from .parser import Dimensions, choose_idct_size, make_components, scaled_output_size, update_component_sizes
 from .worker import COLOR_TRANSFORMS, HipWorker, RowData, color_transform_id, compute_image_parallel
 
 __all__ = [
-    "Batch", "CODING_PROCESSES", "COLOR_TRANSFORMS", "Component", "Decoder", "Dimensions", "ImageInfo", "PIXEL_FORMATS", "Pipeline", "decode_batch", "Error", "FormatError", "HipWorker", "ImageDesc",
+    "Batch", "CODING_PROCESSES", "COLOR_TRANSFORMS", "Component", "Decoder", "Dimensions", "ImageInfo", "PIXEL_FORMATS", "PinnedFiles", "Pipeline", "decode_batch", "Error", "FormatError", "HipWorker", "ImageDesc",
     "InternalError", "IoError", "NoDeviceError", "RowData", "UnsupportedError", "build", "choose_idct_size",
     "color_transform_id", "compute_image_parallel", "device_count", "image_desc", "lib", "make_components",
     "scaled_output_size", "update_component_sizes",

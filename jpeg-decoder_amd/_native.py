@@ -13,11 +13,14 @@ _ROOT = os.path.dirname(_HERE)
 
 def process_init():
     """Opt-in (jpgpu_process_init of include/jpgpu.h, done here without loading the library): GPU_MAX_HW_QUEUES=24 unless set.
-    jpgpu_pipeline_decode keeps several sub-batches in flight on 16 compute + 4 copy streams; the HIP runtime maps a process's
+    jpgpu_pipeline_decode keeps several sub-batches in flight on 12 compute + 4 copy + 2 download streams; the HIP runtime maps a process's
     streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: streams that share one serialise — 4,096 1080p files per call
     91 ms with 4 queues, 64 ms with 16).  The runtime reads the variable once, when it initialises: call this before the first
     HIP call of the process.  Importing the package no longer does it (bench.py, tools/ and tests/conftest.py call it)."""
-    return os.environ.setdefault("GPU_MAX_HW_QUEUES", "24") == "24"
+    if "GPU_MAX_HW_QUEUES" in os.environ:  # (like the C function: True only if THIS call set the variable)
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = "24"
+    return True
 
 
 # JPGPU_LIBRARY: development knob for A/B builds of the same ABI (e.g. libjpgpu_alt.so built with other -D flags)
@@ -68,10 +71,12 @@ class PipelineTimings(C.Structure):
                 ("pixel_bytes", C.c_uint64), ("images_device_entropy", C.c_uint32), ("images_device_rejected", C.c_uint32),
                 ("dev_times_valid", C.c_uint32), ("_pad", C.c_uint32)] + \
                [(n, C.c_double) for n in ("dev_fill_ms", "dev_sync_ms", "dev_write_ms", "dev_pixel_ms", "decode_ms", "gather_ms")] + \
-               [("gather_bytes", C.c_uint64)]
+               [("gather_bytes", C.c_uint64), ("gather_copy_ms", C.c_double), ("cpu_ms", C.c_double), ("images_host_light", C.c_uint32),
+                ("input_pinned", C.c_uint32), ("images_device_progressive", C.c_uint32), ("_pad2", C.c_uint32)]
 
 
 PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_GATHER = 1, 2, 4, 16
+PIPELINE_HOST_LIGHT, PIPELINE_HOST_STAGED, PIPELINE_INPUT_PINNED, PIPELINE_PROGRESSIVE_ON_HOST = 32, 64, 128, 256
 PIPELINE_MULTI_PIN_CPUS = 1
 
 
@@ -156,6 +161,10 @@ _PROTOS = {
     "jpgpu_decoder_decode_coefficients": (C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "jpgpu_pipeline_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "jpgpu_pipeline_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "jpgpu_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "jpgpu_host_free": (None, [C.c_void_p]),
+    "jpgpu_plan_cpu_shares": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "jpgpu_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "jpgpu_pipeline_device_count": (C.c_uint32, [C.c_void_p]),
     "jpgpu_pipeline_image_device": (C.c_int, [C.c_void_p, C.c_uint32]),
     "jpgpu_pipeline_pixels_device_ordinal": (C.c_int, [C.c_void_p, C.c_uint32]),

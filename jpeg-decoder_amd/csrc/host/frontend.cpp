@@ -219,8 +219,10 @@ inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *
                 dst = *mine[i];
                 return;
             }
-    static std::mutex m;
-    static std::shared_ptr<const HuffTable> shared[kShared];
+    // (the registry is leaked on purpose: pool threads of a host that is shutting down may still be in here while statics are
+    // destroyed — ADVICE r4)
+    static std::mutex &m = *new std::mutex;
+    static std::shared_ptr<const HuffTable> *const shared = new std::shared_ptr<const HuffTable>[kShared];
     static int shared_next = 0;
     std::shared_ptr<const HuffTable> found;
     if (n > 0 && n <= 256) {
@@ -677,9 +679,15 @@ struct Frontend::Impl {
 
     void parse_dht() {  // src/parser.rs:536-589, merge of src/decoder.rs:501-518
         size_t length = read_length();
-        // (on the stack, 44 kB: two heap blocks per DHT segment, allocated and freed by every pool thread at once, had the threads
-        // queue up inside the allocator; rounds 2-3 kept them per thread for good)
-        HuffTable ndc[4], nac[4];
+        // (one heap block per THREAD, made at its first DHT segment and kept: round 4 had the eight tables — 44 kB — on the stack of
+        // whichever thread called the decoder, too much for hosts that run decoders on small-stack threads; two heap
+        // blocks per segment, allocated and freed by every pool thread at once, had the threads queue up inside the allocator)
+        struct DhtScratch {
+            HuffTable dc[4], ac[4];
+        };
+        thread_local std::unique_ptr<DhtScratch> scratch;
+        if (!scratch) scratch.reset(new DhtScratch);
+        HuffTable *const ndc = scratch->dc, *const nac = scratch->ac;
         for (int i = 0; i < 4; i++) ndc[i].present = nac[i].present = false;
         while (length > 17) {
             const uint8_t tc = src.u8(), cls = tc >> 4;
@@ -957,8 +965,8 @@ struct Frontend::Impl {
             // (per thread: a POINTER to the set it used last — compared without a lock; the sets themselves are shared, immutable,
             // and registered under a mutex that only a thread's first file of an encoder takes)
             constexpr int kSets = 8;
-            static std::mutex last_m;
-            static std::shared_ptr<const Last> last_sets[kSets];
+            static std::mutex &last_m = *new std::mutex;  // (leaked on purpose, like build_cached's registry)
+            static std::shared_ptr<const Last> *const last_sets = new std::shared_ptr<const Last>[kSets];
             static int last_next = 0;
             thread_local std::shared_ptr<const Last> mine;
             auto matches = [&](const Last &l) {

@@ -27,7 +27,7 @@ using namespace jpgpu;
 
 extern "C" {
 
-const char *jpgpu_version(void) { return "jpgpu 0.1 (gfx950)"; }
+const char *jpgpu_version(void) { return "jpgpu 0.2 (gfx950)"; }
 
 int jpgpu_device_count(int *count) {
     int n = 0;

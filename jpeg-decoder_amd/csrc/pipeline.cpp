@@ -3,6 +3,7 @@
 // one image per task, rows staged in pinned memory, per-image async H2D, then the batch kernels (batch.cpp).
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <time.h>
 
 #include <array>
 #include <atomic>
@@ -28,7 +29,7 @@ using jpgpu::host::RowSink;
 
 namespace {
 
-constexpr uint32_t kCopyStreams = 4;
+constexpr uint32_t kCopyStreams = 4, kD2HStreams = 2;
 
 // Default pool size: one thread per physical core (SMT siblings plus the uploader thread made 256 threads slower and
 // erratic on the 2 x 64-core host), but no more than twice the CPUs a cgroup quota grants the process: with
@@ -49,6 +50,12 @@ uint32_t default_threads() {
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// CPU time the whole process has used so far, all threads (jpgpu_pipeline_timings::cpu_ms: what a call costs the host)
+double process_cpu_ms() {
+    struct timespec ts;
+    if (clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts) != 0) return 0.0;
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
 
 // Minimal fork-join pool: run(n, fn) calls fn(i) for i in [0, n) on the workers and returns when all are done.
@@ -230,6 +237,7 @@ struct SubBatch {
     std::vector<size_t> stage_off;    // compact mode: [image*4 + comp] offset of the component's region in h_coef
     uint32_t remaining = 0;  // images not yet uploaded / failed (uploader thread only)
     hipEvent_t ready[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t decoded = nullptr;  // recorded on the compute stream behind the sub-batch's pixel kernels: downloads and the gather wait for it
     void drop() {
         if (batch) jpgpu_batch_destroy(batch);
         batch = nullptr;
@@ -272,22 +280,34 @@ struct jpgpu_pipeline {
     bool downloaded = false;  // the last call copied the pixels to host memory
     hipStream_t copy_streams[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t compute[kComputeStreams] = {};
+    // JPGPU_PIPELINE_DOWNLOAD: the device-to-host copies have streams of their own (round 5; on the compute stream a sub-batch's
+    // download held back the kernels of the next sub-batch that shares the stream, and the copies of a call did not run back to back)
+    hipStream_t d2h[kD2HStreams] = {};
     uint16_t req_w = 0, req_h = 0;  // jpgpu_pipeline_set_scale (0 x 0: full size)
     int color_transform = -1;       // jpgpu_pipeline_set_color_transform (< 0: what every image says itself)
     size_t max_bytes = SIZE_MAX;    // jpgpu_pipeline_set_max_decoding_buffer_size
     uint32_t n_compute = kComputeStreamsDefault;  // streams in use (JPGPU_PIPE_STREAMS: tuning knob, up to kComputeStreams)
     jpgpu::DeviceScratch scratch[kComputeStreams];  // work space of the chunk decoder, one per compute stream (launches on a stream run in turn)
     jpgpu_pipeline_timings t{};
+    // ---- a child of a multi-device pipeline with JPGPU_PIPELINE_GATHER in force: behind every sub-batch's pixel kernels its pixel arena
+    // is copied to `gather_device` (peer-to-peer; a plain device copy when that is this device) on a stream of THIS device — the copy
+    // of one sub-batch runs while the next ones decode, every child drives its own link (round 5; round 4 copied everything from one
+    // stream of the first device after all children had joined)
+    bool gather_on = false;
+    int gather_device = -1;
+    uint8_t *d_gather = nullptr;      // on gather_device
+    size_t gather_cap = 0;
+    std::vector<size_t> gather_off;   // [sub-batch] -> offset of its arena in d_gather
+    hipStream_t gather_stream = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gather_ev;  // [sub-batch] timing events around its copy
+    uint64_t gather_bytes = 0;
     // ---- several devices behind one object (jpgpu_pipeline_create_multi): this pipeline only deals the images of a call to its
     // children (one ordinary pipeline per listed device, image i -> child i mod n) and maps the per-image accessors back
     std::vector<jpgpu_pipeline *> children;
     std::vector<std::vector<int>> child_cpus;  // CPUs of each child's share (empty: no pinning)
     uint32_t multi_n = 0;                      // images of the last call
-    uint8_t *d_gather = nullptr;               // JPGPU_PIPELINE_GATHER: the children's pixel arenas, copied to devices[0]
-    size_t gather_cap = 0;
-    std::vector<std::vector<size_t>> gather_base;  // [child][sub-batch] -> offset of its arena in d_gather
-    bool gathered = false;
-    hipStream_t gather_stream = nullptr;
+    bool gathered = false;                     // JPGPU_PIPELINE_GATHER: the children's pixel arenas were copied to devices[0] (each child's d_gather)
+    std::vector<std::string> peer_error;       // [child] why its device cannot reach devices[0] (empty: it can)
 };
 
 static const jpgpu_pipeline *child_of(const jpgpu_pipeline *p, uint32_t &image) {
@@ -364,6 +384,7 @@ static void host_redecode_upload(jpgpu_pipeline *p, SubBatch &sb, Redecode &r) {
     }
 }
 
+ static int pipeline_create_sized(int device, uint32_t n_threads, uint32_t n_stage_threads, jpgpu_pipeline **out);
 #define P_HIP(call)                                                                                              \
     do {                                                                                                         \
         hipError_t _e = (call);                                                                                  \
@@ -373,44 +394,66 @@ static void host_redecode_upload(jpgpu_pipeline *p, SubBatch &sb, Redecode &r) {
 extern "C" {
 
 int jpgpu_pipeline_create(int device, uint32_t n_threads, jpgpu_pipeline **out) {
+    if (n_threads == 0) n_threads = default_threads();
+    return pipeline_create_sized(device, n_threads, std::max<uint32_t>(2u, n_threads / 2u), out);
+}
+}  // extern "C"
+
+// n_threads entropy / header workers + n_stage_threads for the staging copies of the device-entropy route (jpgpu_pipeline_create:
+// half as many again; a child of a multi-device pipeline: both out of its share of the budget)
+static int pipeline_create_sized(int device, uint32_t n_threads, uint32_t n_stage_threads, jpgpu_pipeline **out) {
     if (!out) return JPGPU_ERR_FORMAT;
     jpgpu_pipeline *p = new jpgpu_pipeline();
     *out = p;  // returned even on failure so that last_error can be read
     p->device = device;
     int rc = jpgpu::use_device(device, p->err);
     if (rc) return rc;  // no usable MI355X: there is no CPU fallback for the pixel work
-    if (n_threads == 0) n_threads = default_threads();
-    p->pool.reset(new Pool(n_threads));
-    p->stage_pool.reset(new Pool(std::max<uint32_t>(2u, n_threads / 2u)));
+    p->pool.reset(new Pool(std::max(1u, n_threads)));
+    p->stage_pool.reset(new Pool(std::max(1u, n_stage_threads)));
     p->subs.resize(kMaxSubBatches);
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->copy_streams[k], hipStreamNonBlocking));
     if (const char *e = getenv("JPGPU_PIPE_STREAMS")) p->n_compute = (uint32_t)std::min<long>(std::max<long>(atol(e), 1), kComputeStreams);
     for (uint32_t k = 0; k < p->n_compute; k++) P_HIP(hipStreamCreateWithFlags(&p->compute[k], hipStreamNonBlocking));
-    for (SubBatch &sb : p->subs)
+    for (uint32_t k = 0; k < kD2HStreams; k++) P_HIP(hipStreamCreateWithFlags(&p->d2h[k], hipStreamNonBlocking));
+    for (SubBatch &sb : p->subs) {
         for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipEventCreateWithFlags(&sb.ready[k], hipEventDisableTiming));
+        P_HIP(hipEventCreateWithFlags(&sb.decoded, hipEventDisableTiming));
+    }
     return JPGPU_OK;
 }
+
+extern "C" {
 
 void jpgpu_pipeline_destroy(jpgpu_pipeline *p) {
     if (!p) return;
     std::string e;
     if (!p->children.empty()) {
-        if (jpgpu::use_device(p->device, e) == JPGPU_OK) {
-            (void)hipDeviceSynchronize();
-            if (p->d_gather) (void)hipFree(p->d_gather);
-            if (p->gather_stream) (void)hipStreamDestroy(p->gather_stream);
-        }
         for (jpgpu_pipeline *c : p->children) jpgpu_pipeline_destroy(c);
         delete p;
         return;
     }
     if (jpgpu::use_device(p->device, e) == JPGPU_OK) {
         (void)hipDeviceSynchronize();
+        if (p->gather_stream) (void)hipStreamDestroy(p->gather_stream);
+        for (auto &ev : p->gather_ev) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        if (p->d_gather) {  // (lives on the gathering device)
+            if (hipSetDevice(p->gather_device) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(p->d_gather);
+            }
+            (void)hipSetDevice(p->device);
+        }
         for (SubBatch &sb : p->subs) {
             sb.drop();
             for (uint32_t k = 0; k < kCopyStreams; k++)
                 if (sb.ready[k]) (void)hipEventDestroy(sb.ready[k]);
+            if (sb.decoded) (void)hipEventDestroy(sb.decoded);
         }
+        for (uint32_t k = 0; k < kD2HStreams; k++)
+            if (p->d2h[k]) (void)hipStreamDestroy(p->d2h[k]);
         for (uint32_t k = 0; k < kCopyStreams; k++)
             if (p->copy_streams[k]) (void)hipStreamDestroy(p->copy_streams[k]);
         for (uint32_t k = 0; k < kComputeStreams; k++)
@@ -467,11 +510,17 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
 
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
     jpgpu::TraceRange roctx_range("jpgpu_pipeline_decode");
+    // (unknown bits are refused, not ignored: 8u was round 2-3's JPGPU_PIPELINE_PROGRESSIVE_DELTAS, removed in round 4 — a caller built
+    // against that header would otherwise silently get another transport: ADVICE r4)
+    constexpr uint32_t kKnownFlags = JPGPU_PIPELINE_DOWNLOAD | JPGPU_PIPELINE_DENSE | JPGPU_PIPELINE_DEVICE_ENTROPY | JPGPU_PIPELINE_GATHER |
+                                     JPGPU_PIPELINE_HOST_LIGHT | JPGPU_PIPELINE_HOST_STAGED | JPGPU_PIPELINE_INPUT_PINNED | JPGPU_PIPELINE_PROGRESSIVE_ON_HOST;
+    if (p && (flags & ~kKnownFlags)) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "jpgpu_pipeline_decode: unknown flag bits 0x%x (this library: %s)", flags & ~kKnownFlags, jpgpu_version());
     if (p && !p->children.empty()) return (n && (!data || !len)) ? JPGPU_ERR_FORMAT : multi_decode(p, data, len, n, flags);
     if (!p || !p->pool || (n && (!data || !len))) return JPGPU_ERR_FORMAT;
+    if ((flags & JPGPU_PIPELINE_GATHER) && !p->gather_on) flags &= ~(uint32_t)JPGPU_PIPELINE_GATHER;  // (one device: the pixels are where a gather would put them)
     int rc = jpgpu::use_device(p->device, p->err);
     if (rc) return rc;
-    const double t0 = now_ms();
+    const double t0 = now_ms(), cpu0 = process_cpu_ms();
     const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0, compact = (flags & JPGPU_PIPELINE_DENSE) == 0;
     const bool device_entropy = (flags & JPGPU_PIPELINE_DEVICE_ENTROPY) != 0;
     p->n = n;
@@ -489,7 +538,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->downloaded = download;
     p->path.clear();
     p->t = jpgpu_pipeline_timings{};
-    p->t.threads = p->pool->size();
+    p->t.threads = p->pool->size() + p->stage_pool->size();  // (+ one uploader thread per call, which mostly waits)
     std::vector<jpgpu_image_desc> cand(n);
 
     // 1. headers
@@ -672,6 +721,33 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         if (p->path.empty()) p->path = pth;
         else if (p->path != pth) p->path = "mixed";
     }
+    p->gather_bytes = 0;
+    if (p->gather_on) {  // (a child of a multi-device pipeline: where its sub-batches' pixels go on the gathering device)
+        size_t total = 0;
+        p->gather_off.assign(n_subs, 0);
+        for (uint32_t j = 0; j < n_subs; j++) {
+            p->gather_off[j] = total;
+            total += p->subs[j].batch ? jpgpu::align_up(jpgpu_batch_out_arena_bytes(p->subs[j].batch), 256) : 0;
+        }
+        if (total > p->gather_cap) {
+            // (allocated on the gathering device by this child's thread: hipSetDevice is per thread)
+            if (hipSetDevice(p->gather_device) != hipSuccess) return jpgpu::set_err(p->err, JPGPU_ERR_IO, "gather: cannot select device %d", p->gather_device);
+            if (p->d_gather) (void)hipFree(p->d_gather);
+            p->d_gather = nullptr;
+            p->gather_cap = 0;
+            const hipError_t ge = hipMalloc((void **)&p->d_gather, total + total / 8);
+            (void)hipSetDevice(p->device);
+            if (ge != hipSuccess) return jpgpu::set_err(p->err, JPGPU_ERR_IO, "gather: %zu bytes on device %d: %s", total + total / 8, p->gather_device, hipGetErrorString(ge));
+            p->gather_cap = total + total / 8;
+        }
+        if (!p->gather_stream) P_HIP(hipStreamCreateWithFlags(&p->gather_stream, hipStreamNonBlocking));  // on THIS device: the source drives the copy
+        while (p->gather_ev.size() < n_subs) {
+            hipEvent_t a = nullptr, b = nullptr;
+            P_HIP(hipEventCreate(&a));
+            P_HIP(hipEventCreate(&b));
+            p->gather_ev.emplace_back(a, b);
+        }
+    }
     const double t2 = now_ms();
 
     // 3. entropy decoding (pool) + per-image upload and per-sub-batch kernels / download (one uploader thread)
@@ -700,6 +776,32 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         p->stage_pool->run(cnt, fn);
     };
     (void)par_m;
+    // What follows the pixel kernels of sub-batch `sj` on its compute stream `cs`: the download to pinned host memory and / or the
+    // copy to the gathering device, each on a stream of its own behind the `decoded` event (the compute stream goes on with the next
+    // sub-batch that shares it).  Called again when a sub-batch is decoded a second time (an image the device decoder handed back).
+    auto after_decode = [&](uint32_t sj, hipStream_t cs) -> bool {
+        SubBatch &sb = p->subs[sj];
+        if (!download && !p->gather_on) return true;
+        if (hipEventRecord(sb.decoded, cs) != hipSuccess) return false;
+        if (download) {
+            hipStream_t ds = p->d2h[sj % kD2HStreams];
+            if (hipStreamWaitEvent(ds, sb.decoded, 0) != hipSuccess ||
+                hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, ds) != hipSuccess)
+                return false;
+        }
+        if (p->gather_on && p->d_gather) {
+            const size_t bytes = jpgpu_batch_out_arena_bytes(sb.batch);
+            uint8_t *dst = p->d_gather + p->gather_off[sj];
+            hipStream_t gs = p->gather_stream;
+            if (hipStreamWaitEvent(gs, sb.decoded, 0) != hipSuccess || hipEventRecord(p->gather_ev[sj].first, gs) != hipSuccess) return false;
+            const hipError_t ce = p->gather_device == p->device
+                                      ? hipMemcpyAsync(dst, jpgpu_batch_out_arena(sb.batch), bytes, hipMemcpyDeviceToDevice, gs)  // (a device listed twice: no peer)
+                                      : hipMemcpyPeerAsync(dst, p->gather_device, jpgpu_batch_out_arena(sb.batch), p->device, bytes, gs);
+            if (ce != hipSuccess || hipEventRecord(p->gather_ev[sj].second, gs) != hipSuccess) return false;
+            p->gather_bytes += bytes;
+        }
+        return true;
+    };
     std::thread uploader([&] {
         std::string e;
         if (jpgpu::use_device(p->device, e) != JPGPU_OK) hip_failed.store(1);
@@ -762,6 +864,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) okk = false;
                         if (!okk) launch_err = jpgpu_batch_last_error(sb.batch);
                         else pending_subs.push_back((uint32_t)p->sub_of[i]);
+                        // (download / gather at once, on the assumption that the device decoder hands nothing back — the rule; a
+                        // sub-batch it does hand an image back from is decoded and copied once more below)
+                        if (okk && !after_decode((uint32_t)p->sub_of[i], cs)) okk = false;
                         if (!okk) hip_failed.store(1);
                         continue;
                     }
@@ -769,8 +874,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         launch_err = jpgpu_batch_last_error(sb.batch);
                         okk = false;
                     }
-                    if (okk && download)
-                        okk = hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, cs) == hipSuccess;
+                    if (okk) okk = after_decode((uint32_t)p->sub_of[i], cs);
                     if (!okk) hip_failed.store(1);
                 }
             }
@@ -815,9 +919,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                             launch_err = jpgpu_batch_last_error(sb.batch);
                             okk = false;
                         }
+                        if (okk) okk = after_decode(sj, cs);
                     }
-                    if (okk && download)
-                        okk = hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, cs) == hipSuccess;
                     if (!okk) hip_failed.store(1);
                 }
                 pending_subs.clear();
@@ -890,6 +993,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     // 4. drain: whatever kernels and downloads are still in flight
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamSynchronize(p->copy_streams[k]));
     for (uint32_t k = 0; k < p->n_compute; k++) P_HIP(hipStreamSynchronize(p->compute[k]));
+    if (download)
+        for (uint32_t k = 0; k < kD2HStreams; k++) P_HIP(hipStreamSynchronize(p->d2h[k]));
+    // (a child's gather stream is NOT waited for here: the parent does, after every child has decoded — what it then still waits is the exposed part)
     const double t4 = now_ms();
     uint64_t pixel_bytes = 0;
     uint32_t okc = 0;
@@ -916,6 +1022,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.pixel_bytes = pixel_bytes;
     p->t.images_device_entropy = device_images;
     p->t.images_device_rejected = device_rejected;
+    p->t.cpu_ms = process_cpu_ms() - cpu0;
     (void)t_last_upload;
     return JPGPU_OK;
 }
@@ -960,8 +1067,8 @@ const void *jpgpu_pipeline_pixels_device(const jpgpu_pipeline *p, uint32_t i) {
         const jpgpu_pipeline *c = child_of(p, ci);
         if (!p->gathered) return jpgpu_pipeline_pixels_device(c, ci);
         const SubBatch *sb = sub_of(c, ci);  // the copy on the first device
-        if (!sb) return nullptr;
-        return p->d_gather + p->gather_base[i % p->children.size()][(uint32_t)c->sub_of[ci]] + jpgpu_batch_out_offset(sb->batch, (uint32_t)c->slot[ci]);
+        if (!sb || !c->d_gather) return nullptr;
+        return c->d_gather + c->gather_off[(uint32_t)c->sub_of[ci]] + jpgpu_batch_out_offset(sb->batch, (uint32_t)c->slot[ci]);
     }
     const SubBatch *sb = sub_of(p, i);
     return sb ? (const uint8_t *)jpgpu_batch_out_arena(sb->batch) + jpgpu_batch_out_offset(sb->batch, (uint32_t)p->slot[i]) : nullptr;
@@ -1017,8 +1124,7 @@ int jpgpu_pipeline_pixels_device_ordinal(const jpgpu_pipeline *p, uint32_t i) {
     if (!p->children.empty() && p->gathered) return i < p->multi_n ? p->device : -1;
     return jpgpu_pipeline_image_device(p, i);
 }
-// CPUs the calling thread may run on, in order (the shares of a multi-device pipeline are contiguous pieces of this list: on a
-// two-socket host the first devices' feeders then sit on the first socket)
+// CPUs the calling thread may run on, in order
 static std::vector<int> allowed_cpus() {
     std::vector<int> v;
     cpu_set_t set;
@@ -1029,30 +1135,194 @@ static std::vector<int> allowed_cpus() {
     return v;
 }
 
+// ---- CPU shares by NUMA node ("sub-linear unless feeder threads are pinned per NUMA node") -----------------------------
+// A device's feeder threads belong on the socket its PCIe root hangs off: <sysfs>/bus/pci/devices/<bdf>/numa_node names the node,
+// <sysfs>/devices/system/node/node<N>/cpulist its CPUs.  Devices of one node split the node's ALLOWED CPUs evenly, in list order.  If
+// any device's node is unknown (-1: one socket, a VM) or a node has fewer allowed CPUs than devices, every device falls back to a
+// contiguous slice of the allowed list (round 4's rule) — shares are always disjoint.
+static std::string read_small_file(const std::string &path) {
+    std::string out;
+    if (FILE *f = fopen(path.c_str(), "r")) {
+        char buf[4096];
+        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        out.assign(buf, n);
+    }
+    return out;
+}
+static int numa_node_of(const std::string &sysfs, const char *bdf) {
+    if (!bdf || !*bdf) return -1;
+    std::string id(bdf);
+    for (char &ch : id) ch = (char)tolower((unsigned char)ch);
+    const std::string txt = read_small_file(sysfs + "/bus/pci/devices/" + id + "/numa_node");
+    if (txt.empty()) return -1;
+    char *end = nullptr;
+    const long v = strtol(txt.c_str(), &end, 10);
+    return end == txt.c_str() ? -1 : (int)v;
+}
+static std::vector<int> parse_cpulist(const std::string &txt) {  // "0-63,128-191"
+    std::vector<int> v;
+    const char *q = txt.c_str();
+    while (*q) {
+        if (*q < '0' || *q > '9') {
+            q++;
+            continue;
+        }
+        char *end = nullptr;
+        long a = strtol(q, &end, 10), b = a;
+        q = end;
+        if (*q == '-') {
+            b = strtol(q + 1, &end, 10);
+            q = end;
+        }
+        for (long c = a; c <= b && c < 65536 && v.size() < 65536; c++) v.push_back((int)c);
+    }
+    return v;
+}
+static std::vector<std::vector<int>> plan_cpu_shares(const std::string &sysfs, const std::vector<std::string> &bdfs, const std::vector<int> &allowed,
+                                                     std::vector<int> *nodes_out) {
+    const size_t n = bdfs.size();
+    std::vector<std::vector<int>> shares(n);
+    std::vector<int> nodes(n, -1);
+    for (size_t k = 0; k < n; k++) nodes[k] = numa_node_of(sysfs, bdfs[k].c_str());
+    if (nodes_out) *nodes_out = nodes;
+    if (n == 0 || allowed.size() < n) return shares;  // (fewer CPUs than devices: nobody is pinned)
+    bool by_node = true;
+    std::vector<std::vector<int>> by(n);
+    for (size_t k = 0; k < n && by_node; k++) {
+        if (nodes[k] < 0) {
+            by_node = false;
+            break;
+        }
+        size_t rank_on_node = 0, on_node = 0;
+        for (size_t j = 0; j < n; j++)
+            if (nodes[j] == nodes[k]) {
+                if (j < k) rank_on_node++;
+                on_node++;
+            }
+        const std::vector<int> node_cpus = parse_cpulist(read_small_file(sysfs + "/devices/system/node/node" + std::to_string(nodes[k]) + "/cpulist"));
+        std::vector<int> cand;
+        for (int c : allowed)
+            if (std::find(node_cpus.begin(), node_cpus.end(), c) != node_cpus.end()) cand.push_back(c);
+        if (cand.size() < on_node) {
+            by_node = false;
+            break;
+        }
+        const size_t a = cand.size() * rank_on_node / on_node, b = cand.size() * (rank_on_node + 1) / on_node;
+        by[k].assign(cand.begin() + (long)a, cand.begin() + (long)b);
+    }
+    for (size_t k = 0; k < n; k++) {
+        if (by_node) {
+            shares[k] = by[k];
+        } else {
+            const size_t a = allowed.size() * k / n, b = allowed.size() * (k + 1) / n;
+            shares[k].assign(allowed.begin() + (long)a, allowed.begin() + (long)b);
+        }
+    }
+    return shares;
+}
+static const char *sysfs_root() {
+    const char *e = getenv("JPGPU_SYSFS_ROOT");  // (tests: a fake tree)
+    return e && *e ? e : "/sys";
+}
+
+int jpgpu_host_alloc(size_t bytes, void **out) {
+    if (!out) return JPGPU_ERR_FORMAT;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return JPGPU_ERR_IO;
+    }
+    return JPGPU_OK;
+}
+void jpgpu_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int jpgpu_device_pci_bus_id(int device, char *buf, size_t cap) {
+    if (!buf || cap < 13) return JPGPU_ERR_FORMAT;
+    buf[0] = 0;
+    if (hipDeviceGetPCIBusId(buf, (int)cap, device) != hipSuccess) {
+        (void)hipGetLastError();
+        buf[0] = 0;
+        return JPGPU_ERR_NO_DEVICE;
+    }
+    return JPGPU_OK;
+}
+
+int jpgpu_plan_cpu_shares(const char *sysfs, const char *const *pci_bus_ids, uint32_t n_devices, const int *allowed, uint32_t n_allowed,
+                          int *device_of_cpu, int *numa_nodes) {
+    if (!pci_bus_ids || !allowed || !device_of_cpu || n_devices == 0) return JPGPU_ERR_FORMAT;
+    std::vector<std::string> bdfs;
+    for (uint32_t k = 0; k < n_devices; k++) bdfs.emplace_back(pci_bus_ids[k] ? pci_bus_ids[k] : "");
+    const std::vector<int> al(allowed, allowed + n_allowed);
+    std::vector<int> nodes;
+    const auto shares = plan_cpu_shares(sysfs && *sysfs ? sysfs : sysfs_root(), bdfs, al, &nodes);
+    for (uint32_t i = 0; i < n_allowed; i++) device_of_cpu[i] = -1;
+    for (uint32_t k = 0; k < n_devices; k++)
+        for (int c : shares[k])
+            for (uint32_t i = 0; i < n_allowed; i++)
+                if (allowed[i] == c) device_of_cpu[i] = (int)k;
+    if (numa_nodes)
+        for (uint32_t k = 0; k < n_devices; k++) numa_nodes[k] = nodes[k];
+    return JPGPU_OK;
+}
+
 int jpgpu_pipeline_create_multi(const int *devices, uint32_t n_devices, uint32_t n_threads, uint32_t flags, jpgpu_pipeline **out) {
     if (!out) return JPGPU_ERR_FORMAT;
     jpgpu_pipeline *p = new jpgpu_pipeline();
     *out = p;  // returned even on failure so that last_error can be read
     if (!devices || n_devices == 0 || n_devices > 64) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "create_multi: 1..64 devices, got %u", n_devices);
+    if (flags & ~(uint32_t)JPGPU_PIPELINE_MULTI_PIN_CPUS) return jpgpu::set_err(p->err, JPGPU_ERR_FORMAT, "create_multi: unknown flag bits 0x%x", flags & ~(uint32_t)JPGPU_PIPELINE_MULTI_PIN_CPUS);
     p->device = devices[0];
     // Thread budget: `n_threads` host threads IN ALL (0: what one pipeline would take by default — one per physical core, capped by
-    // a cgroup CPU quota), dealt evenly; every child keeps at least two.  One pipeline keeps ~8 CPUs busy at 45-50 k 1080p images/s:
-    // N children that each started the default would oversubscribe the host N-fold.
+    // a cgroup CPU quota), dealt evenly; every child keeps at least two.  A child's share covers BOTH its pools (entropy / header
+    // workers and the staging team of the device-entropy route: ADVICE r4 — the staging teams came on top of the budget); what is
+    // not counted is one uploader thread per child and call, which mostly waits.
     const uint32_t budget = n_threads ? n_threads : default_threads();
     const uint32_t per_child = std::max<uint32_t>(2u, budget / n_devices);
-    const std::vector<int> cpus = (flags & JPGPU_PIPELINE_MULTI_PIN_CPUS) ? allowed_cpus() : std::vector<int>();
+    const uint32_t stage = std::max<uint32_t>(1u, per_child / 3u), workers = std::max<uint32_t>(1u, per_child - stage);
     p->child_cpus.assign(n_devices, std::vector<int>());
-    for (uint32_t k = 0; k < n_devices; k++) {
-        if (cpus.size() >= n_devices) {
-            const size_t a = cpus.size() * k / n_devices, b = cpus.size() * (k + 1) / n_devices;
-            p->child_cpus[k].assign(cpus.begin() + (long)a, cpus.begin() + (long)b);
+    if (flags & JPGPU_PIPELINE_MULTI_PIN_CPUS) {
+        std::vector<std::string> bdfs;
+        for (uint32_t k = 0; k < n_devices; k++) {
+            char id[64] = {0};
+            (void)jpgpu_device_pci_bus_id(devices[k], id, sizeof(id));
+            bdfs.emplace_back(id);
         }
+        p->child_cpus = plan_cpu_shares(sysfs_root(), bdfs, allowed_cpus(), nullptr);
+    }
+    p->peer_error.assign(n_devices, std::string());
+    for (uint32_t k = 0; k < n_devices; k++) {
         jpgpu_pipeline *c = nullptr;
         int rc = JPGPU_OK;
         // (created on a thread of its own that has moved to the child's CPUs first: the pool threads inherit the mask)
         std::thread maker([&] {
             pin_to(p->child_cpus[k]);
-            rc = jpgpu_pipeline_create(devices[k], per_child, &c);
+            rc = pipeline_create_sized(devices[k], workers, stage, &c);
+            // Peer access between this device and the gathering one, both ways (the copy engine of the source writes into the
+            // destination's memory; without it the runtime stages through the host).  A refusal is remembered and reported by the
+            // first call that asks for a gather — a pipeline without JPGPU_PIPELINE_GATHER does not need it.
+            if (rc == JPGPU_OK && devices[k] != devices[0]) {
+                int can = 0;
+                hipError_t e = hipDeviceCanAccessPeer(&can, devices[k], devices[0]);
+                if (e == hipSuccess && can) {
+                    e = hipSetDevice(devices[k]) == hipSuccess ? hipDeviceEnablePeerAccess(devices[0], 0) : hipErrorInvalidDevice;
+                    if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+                    if (e == hipSuccess) {
+                        e = hipSetDevice(devices[0]) == hipSuccess ? hipDeviceEnablePeerAccess(devices[k], 0) : hipErrorInvalidDevice;
+                        if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+                    }
+                    (void)hipSetDevice(devices[k]);
+                }
+                (void)hipGetLastError();
+                if (e != hipSuccess || !can) {
+                    char msg[200];
+                    snprintf(msg, sizeof(msg), "device %d cannot reach device %d peer-to-peer (%s)", devices[k], devices[0], e != hipSuccess ? hipGetErrorString(e) : "hipDeviceCanAccessPeer says no");
+                    p->peer_error[k] = msg;
+                }
+            }
         });
         maker.join();
         if (c) p->children.push_back(c);
@@ -1061,7 +1331,7 @@ int jpgpu_pipeline_create_multi(const int *devices, uint32_t n_devices, uint32_t
             return rc;
         }
     }
-    p->t.threads = per_child * n_devices;
+    p->t.threads = (workers + stage) * n_devices;
     return JPGPU_OK;
 }
 
@@ -1075,15 +1345,21 @@ int jpgpu_pipeline_last_timings(const jpgpu_pipeline *p, jpgpu_pipeline_timings 
 
 // One call over several devices: image i goes to child i mod n (north_star: "a batch of independent images shards one-image-per-GPU");
 // the children decode side by side, each on a thread that sits on the child's CPUs; there is no data-path exchange between
-// devices.  JPGPU_PIPELINE_GATHER: afterwards every child's pixel arenas are copied to the first device (hipMemcpyPeerAsync: one
-// xGMI link per peer, nothing to reduce — SURVEY 8e), where jpgpu_pipeline_pixels_device then points.
+// devices.  JPGPU_PIPELINE_GATHER: every child copies each sub-batch's pixel arena to the first device as soon as that sub-batch's
+// pixel kernels are done (after_decode: peer-to-peer on a stream of the SOURCE device — each child drives its own xGMI link, and the
+// copy of one sub-batch runs while the next ones decode; nothing to reduce — SURVEY 8e); jpgpu_pipeline_pixels_device then points
+// into the copies.  gather_ms = what the call still waited for the copies after the last child had decoded (the exposed part),
+// gather_copy_ms = the longest child's summed copy time (events around each copy).
 static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
-    const double t0 = now_ms();
+    const double t0 = now_ms(), cpu0 = process_cpu_ms();
     const uint32_t nc = (uint32_t)p->children.size();
     const bool gather = (flags & JPGPU_PIPELINE_GATHER) != 0;
     const uint32_t child_flags = flags & ~(uint32_t)JPGPU_PIPELINE_GATHER;
     p->multi_n = n;
     p->gathered = false;
+    if (gather)
+        for (uint32_t k = 0; k < nc; k++)
+            if (!p->peer_error[k].empty()) return jpgpu::set_err(p->err, JPGPU_ERR_IO, "gather: %s", p->peer_error[k].c_str());
     std::vector<std::vector<const uint8_t *>> cd(nc);
     std::vector<std::vector<size_t>> cl(nc);
     for (uint32_t i = 0; i < n; i++) {
@@ -1092,11 +1368,14 @@ static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const siz
     }
     std::vector<int> rcs(nc, JPGPU_OK);
     std::vector<std::thread> th;
-    for (uint32_t k = 0; k < nc; k++)
+    for (uint32_t k = 0; k < nc; k++) {
+        p->children[k]->gather_on = gather;
+        p->children[k]->gather_device = p->device;
         th.emplace_back([&, k] {
             pin_to(p->child_cpus[k]);  // (the call's uploader thread starts from here and inherits the mask)
             rcs[k] = jpgpu_pipeline_decode(p->children[k], cd[k].data(), cl[k].data(), (uint32_t)cd[k].size(), child_flags);
         });
+    }
     for (auto &t : th) t.join();
     const double t1 = now_ms();
     p->path.clear();
@@ -1105,6 +1384,8 @@ static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const siz
         const jpgpu_pipeline *c = p->children[k];
         if (rcs[k]) {
             p->err = c->err;
+            for (uint32_t j = 0; j < nc; j++)  // (never leave copies in flight behind an error)
+                if (p->children[j]->gather_stream) (void)hipStreamSynchronize(p->children[j]->gather_stream);
             return rcs[k];
         }
         if (cd[k].empty()) continue;
@@ -1121,39 +1402,28 @@ static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const siz
         p->t.pixel_bytes += c->t.pixel_bytes;
         p->t.images_device_entropy += c->t.images_device_entropy;
         p->t.images_device_rejected += c->t.images_device_rejected;
+        p->t.images_host_light += c->t.images_host_light;
+        p->t.input_pinned |= c->t.input_pinned;
     }
     p->t.decode_ms = t1 - t0;
     if (gather) {
-        int rc = jpgpu::use_device(p->device, p->err);
-        if (rc) return rc;
-        size_t total = 0;
-        p->gather_base.assign(nc, std::vector<size_t>());
-        for (uint32_t k = 0; k < nc; k++)
-            for (uint32_t j = 0; j < p->children[k]->n_subs; j++) {
-                const SubBatch &sb = p->children[k]->subs[j];
-                p->gather_base[k].push_back(total);
-                total += sb.batch ? jpgpu::align_up(jpgpu_batch_out_arena_bytes(sb.batch), 256) : 0;
+        for (uint32_t k = 0; k < nc; k++) {
+            jpgpu_pipeline *c = p->children[k];
+            if (!c->gather_stream) continue;
+            P_HIP(hipStreamSynchronize(c->gather_stream));
+            double copy_ms = 0;
+            for (uint32_t j = 0; j < c->n_subs && j < c->gather_ev.size(); j++) {
+                float ms = 0.f;
+                if (c->subs[j].batch && hipEventElapsedTime(&ms, c->gather_ev[j].first, c->gather_ev[j].second) == hipSuccess) copy_ms += ms;
+                else (void)hipGetLastError();
             }
-        if (total > p->gather_cap) {
-            if (p->d_gather) P_HIP(hipFree(p->d_gather));
-            p->d_gather = nullptr;
-            p->gather_cap = 0;
-            P_HIP(hipMalloc((void **)&p->d_gather, total + total / 8));
-            p->gather_cap = total + total / 8;
+            p->t.gather_copy_ms = std::max(p->t.gather_copy_ms, copy_ms);
+            p->t.gather_bytes += c->gather_bytes;
         }
-        if (!p->gather_stream) P_HIP(hipStreamCreateWithFlags(&p->gather_stream, hipStreamNonBlocking));
-        for (uint32_t k = 0; k < nc; k++)
-            for (uint32_t j = 0; j < p->children[k]->n_subs; j++) {
-                const SubBatch &sb = p->children[k]->subs[j];
-                if (!sb.batch) continue;
-                P_HIP(hipMemcpyPeerAsync(p->d_gather + p->gather_base[k][j], p->device, jpgpu_batch_out_arena(sb.batch), p->children[k]->device,
-                                         jpgpu_batch_out_arena_bytes(sb.batch), p->gather_stream));
-                p->t.gather_bytes += jpgpu_batch_out_arena_bytes(sb.batch);
-            }
-        P_HIP(hipStreamSynchronize(p->gather_stream));
         p->gathered = true;
     }
     p->t.gather_ms = now_ms() - t1;
     p->t.total_ms = now_ms() - t0;
+    p->t.cpu_ms = process_cpu_ms() - cpu0;
     return JPGPU_OK;
 }

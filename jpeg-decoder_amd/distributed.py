@@ -25,6 +25,64 @@ def shard(n_items, rank, world):
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+def _parse_cpulist(txt):
+    """"0-63,128-191" -> [0, ..., 63, 128, ..., 191]"""
+    out = []
+    for part in txt.replace("\n", "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        try:
+            a = int(lo)
+            b = int(hi) if hi else a
+        except ValueError:
+            continue
+        out.extend(range(a, b + 1))
+    return out
+
+
+def numa_node_of(bdf, sysfs="/sys"):
+    """NUMA node of the PCI device `bdf` ("0000:c1:00.0"); -1 if unknown (one socket, a VM, no such file)."""
+    if not bdf:
+        return -1
+    try:
+        return int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf.lower(), "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def cpu_shares(allowed, bdfs, sysfs="/sys"):
+    """Deal the CPUs `allowed` to the devices `bdfs` (PCI bus ids, one per rank / device): a device's feeder threads belong on the
+    socket its PCIe root hangs off.  Devices of one NUMA node split the node's allowed CPUs evenly, in list order; if any
+    device's node is unknown, or a node has fewer allowed CPUs than devices, EVERY device gets a contiguous slice of the allowed list
+    instead (shares stay disjoint).  Fewer CPUs than devices: nobody is pinned (empty shares).  The same rule as the library's
+    jpgpu_plan_cpu_shares (csrc/pipeline.cpp), which tests/test_distributed.py checks against this one on fake sysfs trees.
+    -> (list of CPU lists, list of NUMA nodes)"""
+    n = len(bdfs)
+    nodes = [numa_node_of(b, sysfs) for b in bdfs]
+    if n == 0 or len(allowed) < n:
+        return [[] for _ in range(n)], nodes
+    by, by_node = [], all(x >= 0 for x in nodes)
+    for k in range(n):
+        if not by_node:
+            break
+        same = [j for j in range(n) if nodes[j] == nodes[k]]
+        try:
+            node_cpus = set(_parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{nodes[k]}", "cpulist")).read()))
+        except OSError:
+            node_cpus = set()
+        cand = [c for c in allowed if c in node_cpus]
+        if len(cand) < len(same):
+            by_node = False
+            break
+        r = same.index(k)
+        by.append(cand[len(cand) * r // len(same): len(cand) * (r + 1) // len(same)])
+    if by_node:
+        return by, nodes
+    return [list(allowed[len(allowed) * k // n: len(allowed) * (k + 1) // n]) for k in range(n)], nodes
+
+
 def init(backend=None, force=False):
     """Initialise the default process group from the torchrun environment (no-op for world size 1 unless `force`:
     a one-rank group — the collective library's set-up and collectives exercised on a single GPU)."""

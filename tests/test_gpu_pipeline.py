@@ -525,6 +525,7 @@ def test_pipeline_over_several_devices_one_gpu_listed_more_than_once(devices):
     sizes = p.decode(files, download=False, gather=True)
     t = p.timings()
     assert t["gather_bytes"] > 0 and t["gather_ms"] >= 0 and t["total_ms"] >= t["decode_ms"]
+    assert t["gather_copy_ms"] > 0  # every sub-batch's copy was timed on its child's own stream (round 5: per child, behind the sub-batch's kernels)
     for i in good:
         assert sizes[i] == out[i].size
         assert p.device_of(i) == (devices[i % len(devices)], devices[0])
@@ -542,6 +543,49 @@ def test_pipeline_over_several_devices_one_gpu_listed_more_than_once(devices):
     want = O.decode(rgb, scale_to=(125, 84)).pixels
     assert all(np.array_equal(g, want) for g in got) and (p.info(4).width, p.info(4).height) == (125, 84)
     assert p.decode([]) == []
+    p.close()
+
+
+def test_pipeline_refuses_unknown_flag_bits():
+    """8u was round 2-3's JPGPU_PIPELINE_PROGRESSIVE_DELTAS (removed in round 4) — a caller built against that header must
+    get an error, not silently another transport; the same for any bit this library does not know."""
+    import ctypes as C
+    L = J.lib()
+    assert b"0.2" in L.jpgpu_version()
+    data = open(os.path.join(R.GOLDEN, "benches", "tower.jpg"), "rb").read()
+    for multi in (False, True):
+        p = J.Pipeline(devices=[0, 0], threads=4) if multi else J.Pipeline(threads=2)
+        ptrs = (C.c_char_p * 1)(data)
+        lens = (C.c_size_t * 1)(len(data))
+        for bad in (8, 512, 1 << 20, 4 | 8):
+            assert L.jpgpu_pipeline_decode(p._h, C.cast(ptrs, C.POINTER(C.c_void_p)), lens, 1, bad) == J._native.ERR_FORMAT
+            assert b"unknown flag" in L.jpgpu_pipeline_last_error(p._h)
+        assert L.jpgpu_pipeline_decode(p._h, C.cast(ptrs, C.POINTER(C.c_void_p)), lens, 1, 4) == 0  # and the object still works
+        assert np.array_equal(p.download(0), O.decode(data).pixels)
+        p.close()
+    with pytest.raises(J.Error):
+        J.Pipeline(devices=[0, 0], threads=4, pin_cpus=7)  # unknown create_multi flag bits
+
+
+def test_pipeline_download_to_pinned_host_memory_on_its_own_streams():
+    """JPGPU_PIPELINE_DOWNLOAD (what Decoder::decode() hands out is host memory, src/decoder.rs:293-295): the copies run on download
+    streams behind each sub-batch's kernels — also for sub-batches whose entropy data the device decodes, where the copy is enqueued
+    before the host has seen the status words and repeated if an image was handed back.  pixels_host() views == the device's bytes."""
+    names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
+    files = [open(n, "rb").read() for n in names] * 3  # (several sub-batches; broken and host-only files among them)
+    p = J.Pipeline(threads=8)
+    want = p.decode(files, download=False, device_entropy=True)
+    ref = [None if isinstance(x, Exception) else p.download(i).copy() for i, x in enumerate(want)]
+    sizes = p.decode(files, download="pinned", device_entropy=True)
+    assert p.timings()["images_device_entropy"] > 0
+    for i, r in enumerate(ref):
+        if r is None:
+            assert isinstance(sizes[i], Exception) and p.pixels_host(i) is None
+        else:
+            assert sizes[i] == r.size and np.array_equal(p.pixels_host(i), r), names[i % len(names)]
+    got = p.decode(files[:40], download=True, device_entropy=True)  # the copying form still returns arrays
+    for i in range(40):
+        assert (ref[i] is None and isinstance(got[i], Exception)) or np.array_equal(got[i], ref[i])
     p.close()
 
 

@@ -32,7 +32,7 @@ cd "$R" || exit 1
 OUT=$1; shift
 O=$R/gpurun_out/$OUT; mkdir -p "$O"
 PIPE_CMD="python $R/tools/pipe_calls.py --images 256 --calls 6 --one-sub-batch"
-KARGS="--steps 500 --warmup 50 --no-cpu-baseline --no-classes --no-k4096 --no-e2e --min-seconds 0"
+KARGS="--steps 500 --warmup 50 --no-cpu-baseline --no-classes --no-k4096 --no-scale-anchor --no-cpu-budget --no-e2e --min-seconds 0"
 
 envs() { echo "${1//+/ }"; }   # "A=1+B=2" -> "A=1 B=2"
 cmdline() { local c="${1//+/ }"; c="${c// bench.py/ $R/bench.py}"; echo "${c// tools\// $R/tools/}"; }  # the same for a command run from /tmp (rocprofv3): repo paths made absolute
@@ -85,14 +85,14 @@ for step in "$@"; do
     k)
       env $(envs "$a2") timeout 600 python bench.py $KARGS > $O/k_$a1.json 2> $O/k_$a1.err; summary_line $O/k_$a1.json "k_$a1" ;;
     e)
-      env JPGPU_BATCH_KERNEL_TIMES=1 $(envs "$a2") timeout 900 python bench.py --no-cpu-baseline --no-classes --no-k4096 --steps 30 --min-seconds 0 > $O/e_$a1.json 2> $O/e_$a1.err
+      env JPGPU_BATCH_KERNEL_TIMES=1 $(envs "$a2") timeout 900 python bench.py --no-cpu-baseline --no-classes --no-k4096 --no-scale-anchor --no-cpu-budget --steps 30 --min-seconds 0 > $O/e_$a1.json 2> $O/e_$a1.err
       summary_line $O/e_$a1.json "e_$a1" ;;
     ab|abe)
       for rep in $(seq 1 ${a1:-2}); do
         for lib in main $(ls jpeg-decoder_amd/libjpgpu_alt*.so 2>/dev/null); do
           n=$(basename $lib .so); L=""; [ $lib != main ] && L="JPGPU_LIBRARY=$R/$lib"
           if [ $what = ab ]; then env $L timeout 600 python bench.py $KARGS > $O/ab_${n}_$rep.json 2>> $O/ab.err
-          else env JPGPU_BATCH_KERNEL_TIMES=1 $L timeout 900 python bench.py --no-cpu-baseline --no-classes --no-k4096 --steps 30 --min-seconds 0 > $O/ab_${n}_$rep.json 2>> $O/ab.err; fi
+          else env JPGPU_BATCH_KERNEL_TIMES=1 $L timeout 900 python bench.py --no-cpu-baseline --no-classes --no-k4096 --no-scale-anchor --no-cpu-budget --steps 30 --min-seconds 0 > $O/ab_${n}_$rep.json 2>> $O/ab.err; fi
           summary_line $O/ab_${n}_$rep.json "${n}_$rep"
         done
       done ;;
@@ -122,7 +122,7 @@ for step in "$@"; do
       python tools/prof_summary.py $O/lanes_$a1 > $O/${a1}_lanes.json 2>> $O/summary.err; head -c 3000 $O/${a1}_lanes.json ;;
     traffic)
       extra=$(envs "$a4"); rm -rf $O/tf_$a1 $O/tw_$a1
-      B="python $R/bench.py --workload $a1 --steps 40 --warmup 10 --no-cpu-baseline --no-classes --no-k4096 --no-e2e --min-seconds 0 $extra"
+      B="python $R/bench.py --workload $a1 --steps 40 --warmup 10 --no-cpu-baseline --no-classes --no-k4096 --no-scale-anchor --no-cpu-budget --no-e2e --min-seconds 0 $extra"
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/tf_$a1 -o p -- $B > /dev/null 2>&1)
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/tw_$a1 -o p -- $B > /dev/null 2>&1)
       (cd tools && python make_pmc_traffic.py "$a1:$a2" $O/tf_$a1 $O/tw_$a1 $O/pmc_traffic.json $a3) ;;
@@ -155,7 +155,7 @@ for step in "$@"; do
     latency)
       timeout 600 python tools/decoder_latency.py > $O/decoder_latency.txt 2>&1; tail -n 12 $O/decoder_latency.txt ;;
     forcedist)
-      timeout 900 python bench.py --force-dist --no-k4096 --no-cpu-baseline --no-classes --e2e-images 256,1024 > $O/bench_force_dist.json 2> $O/bench_force_dist.err
+      timeout 900 python bench.py --force-dist --no-k4096 --no-scale-anchor --no-cpu-budget --no-cpu-baseline --no-classes --e2e-images 256,1024 > $O/bench_force_dist.json 2> $O/bench_force_dist.err
       summary_line $O/bench_force_dist.json force_dist ;;
     hostbench)
       g++ -O3 -march=native -std=c++17 -I. tools/host_bench.cpp jpeg-decoder_amd/csrc/host/frontend.cpp jpeg-decoder_amd/csrc/image_job.cpp -o /tmp/host_bench 2> $O/host_bench_build.err
