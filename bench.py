@@ -458,6 +458,26 @@ def d2h_rate_gbps(torch, dev, nbytes=1 << 30):
     return nbytes / (best * 1e-3) / 1e9
 
 
+def host_memory_available():
+    """Bytes of host memory this process may still take: MemAvailable, capped by what a cgroup limit leaves (None if unknown)."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+                break
+    except (OSError, ValueError):
+        pass
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            left = int(mx) - int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = left if avail is None else min(avail, left)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
 def warm_calls(p, files, calls, cold=1, **kw):
     """`cold` uncounted calls (the first one allocates arenas and staging), then `calls` counted ones -> their timings, in call order.
     Raises the first per-image error."""
@@ -578,6 +598,11 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
         for n in [x for x in (256, 4096) if sizes and x <= max(sizes)]:
             key = f"to_host_{n}"
             try:
+                # (the pixels of the call stay in pinned host memory: 25.5 GB for 4,096 files — not on a box that cannot spare twice that)
+                need, avail = n * w * h * 3, host_memory_available()
+                if avail is not None and avail < 2 * need + (8 << 30):
+                    out[key] = {"skipped": f"{need >> 20} MB of pinned host memory needed, {avail >> 20} MB available to this process"}
+                    continue
                 files = [distinct[i % len(distinct)] for i in range(n)]
                 ts = warm_calls(p, files, 5, cold=1, download="pinned", device_entropy=True)
                 ok = all(hashlib.sha256(p.pixels_host(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, 1, n // 2, n - 1}))
