@@ -109,6 +109,7 @@ struct jpgpu_batch {
     // JPGPU_BATCH_KERNEL_TIMES (diagnostics, jpgpu_pipeline_timings): events around the phases of the device entropy path
     hipEvent_t ev_phase[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool phase_events_valid = false;
+    bool progressive_launch = false;  // the last device entropy launch was batch_device_progressive_launch
 };
 
 #define B_HIP(call)                                                                                     \
@@ -1082,6 +1083,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     // JPGPU_BATCH_KERNEL_TIMES: events between the phases (fills | sync passes | write pass + DC sums | pixel kernels)
     static const bool phase_times = getenv("JPGPU_BATCH_KERNEL_TIMES") != nullptr;
     b->phase_events_valid = false;
+    b->progressive_launch = false;
     if (phase_times) {
         for (auto &e : b->ev_phase)
             if (!e) B_HIP(hipEventCreate(&e));
@@ -1125,6 +1127,200 @@ bool jpgpu::batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]) {
     }
     if (!ok) (void)hipGetLastError();
     return ok;
+}
+
+// ---- progressive frames on the device (huff_prog_core.hpp) ------------------------------------------------------------------------
+// Staging block (same offsets in the pinned and the device copy):
+//   [ status: n x u32 | ProgTrack[] | ProgScan[] | ProgHuffTable[] | scan bytes ]     device only: the masks (16 bytes per block)
+int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressiveImage *images, uint32_t n, void *hip_stream,
+                                           const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream,
+                                           DeviceScratch *scratch) {
+    if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
+    int rc = use_device(b->device, b->err);
+    if (rc) return rc;
+    if (!b->d_coef) return set_err(b->err, JPGPU_ERR_FORMAT, "batch has no device buffers bound");
+    if (n != b->descs.size()) return set_err(b->err, JPGPU_ERR_FORMAT, "device progressive: every image of the batch must be listed");
+    hipStream_t s = (hipStream_t)hip_stream;
+    rc = batch_enable_dev_classes(b);
+    if (rc) return rc;
+    size_t n_scans = 0, n_tracks = 0, n_tables = 0, data_bytes = 0, mask_bytes = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        if (images[k].image >= b->descs.size() || !images[k].plan || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device progressive: bad image");
+        const host::ProgPlan &pl = *images[k].plan;
+        n_scans += pl.scans.size();
+        n_tracks += pl.n_tracks;
+        for (const host::ProgPlannedScan &ps : pl.scans) {
+            for (int t = 0; t < 4; t++)
+                if (ps.table[t]) n_tables++;
+            data_bytes += huff_slot_bytes(ps.stuffed_bytes);
+        }
+        const jpgpu_image_desc &desc = b->descs[images[k].image];
+        for (uint32_t c = 0; c < desc.ncomp; c++) mask_bytes += align_up(b->coef_len[(size_t)images[k].image * 4 + c] / 128 * 16, 256);
+    }
+    const size_t off_status = 0, off_tracks = align_up((size_t)n * 4, 16), off_scans = align_up(off_tracks + n_tracks * sizeof(ProgTrack), 16);
+    const size_t off_tables = align_up(off_scans + n_scans * sizeof(ProgScan), 16), off_data = align_up(off_tables + n_tables * sizeof(ProgHuffTable), 16);
+    const size_t total = off_data + data_bytes;
+    const size_t off_masks = align_up(total, 256), total_dev = scratch ? total : off_masks + mask_bytes;
+    if (scratch && mask_bytes > scratch->cap) {
+        if (scratch->d) (void)hipFree(scratch->d);
+        scratch->d = nullptr;
+        scratch->cap = 0;
+        B_HIP(hipMalloc((void **)&scratch->d, mask_bytes + mask_bytes / 4));
+        scratch->cap = mask_bytes + mask_bytes / 4;
+    }
+    if (total_dev > b->entropy_cap) {
+        if (b->d_entropy) (void)hipFree(b->d_entropy);
+        b->d_entropy = nullptr;
+        b->entropy_cap = 0;
+        B_HIP(hipMalloc((void **)&b->d_entropy, total_dev + total_dev / 4));
+        b->entropy_cap = total_dev + total_dev / 4;
+    }
+    if (total > b->entropy_host_cap) {
+        if (b->h_entropy) (void)hipHostFree(b->h_entropy);
+        b->h_entropy = nullptr;
+        b->entropy_host_cap = 0;
+        B_HIP(hipHostMalloc((void **)&b->h_entropy, total + total / 4, hipHostMallocDefault));
+        b->entropy_host_cap = total + total / 4;
+    }
+    if ((size_t)n > b->entropy_out_cap) {
+        if (b->h_entropy_out) (void)hipHostFree(b->h_entropy_out);
+        b->h_entropy_out = nullptr;
+        B_HIP(hipHostMalloc((void **)&b->h_entropy_out, ((size_t)n + 64) * 4, hipHostMallocDefault));
+        b->entropy_out_cap = (size_t)n + 64;
+    }
+    uint8_t *h = b->h_entropy, *d = b->d_entropy, *dm = scratch ? scratch->d : d + off_masks;
+    memset(h, 0, off_tracks);  // status words
+    ProgTrack *tracks = reinterpret_cast<ProgTrack *>(h + off_tracks);
+    ProgScan *scans = reinterpret_cast<ProgScan *>(h + off_scans);
+    struct StageTask {
+        const host::ProgPlannedScan *ps;
+        const uint8_t *src;
+        uint8_t *dst;       // the scan's slot in the pinned block
+        uint8_t *tables;    // where its tables go in the pinned block
+        ProgScan *scan;
+        uint32_t *h_status;
+    };
+    std::vector<StageTask> tasks;
+    tasks.reserve(n_scans);
+    struct TrackOrder {
+        uint32_t first_scan, n_scans, image_k;
+        uint64_t weight;  // bytes of entropy-coded data the lane walks
+    };
+    std::vector<TrackOrder> order;
+    order.reserve(n_tracks);
+    size_t si = 0, tcur = off_tables, dcur = off_data, mcur = 0;
+    b->entropy_images.clear();
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t img = images[k].image;
+        b->entropy_images.push_back(img);
+        const jpgpu_image_desc &desc = b->descs[img];
+        const host::ProgPlan &pl = *images[k].plan;
+        uint64_t *mask_of[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (uint32_t c = 0; c < desc.ncomp; c++) {
+            mask_of[c] = reinterpret_cast<uint64_t *>(dm + mcur);
+            mcur += align_up(b->coef_len[(size_t)img * 4 + c] / 128 * 16, 256);
+        }
+        // the scans of a track, contiguous and in stream order
+        for (uint32_t t = 0; t < pl.n_tracks; t++) {
+            TrackOrder to{(uint32_t)si, 0u, k, 0u};
+            for (const host::ProgPlannedScan &ps : pl.scans) {
+                if (ps.track != t) continue;
+                ProgScan &sc = scans[si];
+                memset(&sc, 0, sizeof(sc));
+                sc.data = d + dcur;
+                sc.ss = ps.ss, sc.se = ps.se, sc.ah = ps.ah, sc.al = ps.al;
+                sc.ncomp = ps.ncomp, sc.cols = ps.cols, sc.rows = ps.rows;
+                for (uint32_t c = 0; c < ps.ncomp; c++) {
+                    const uint32_t fi = ps.comp[c].frame_index;
+                    if (fi >= desc.ncomp || ps.comp[c].block_w != desc.components[fi].block_width)
+                        return set_err(b->err, JPGPU_ERR_FORMAT, "device progressive: plan does not match the image descriptor");
+                    sc.comp[c].coefs = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
+                    sc.comp[c].masks = mask_of[fi];
+                    sc.comp[c].block_w = ps.comp[c].block_w;
+                    sc.comp[c].h = ps.comp[c].h;
+                    sc.comp[c].v = ps.comp[c].v;
+                    sc.comp[c].table = ps.comp[c].table;
+                }
+                StageTask st{&ps, images[k].file + ps.data_off, h + dcur, h + tcur, &sc, reinterpret_cast<uint32_t *>(h + off_status) + k};
+                for (int tb = 0; tb < 4; tb++)
+                    if (ps.table[tb]) {
+                        sc.table[tb] = reinterpret_cast<const ProgHuffTable *>(d + tcur);
+                        tcur += sizeof(ProgHuffTable);
+                    }
+                tasks.push_back(st);
+                to.weight += ps.stuffed_bytes;
+                to.n_scans++;
+                dcur += huff_slot_bytes(ps.stuffed_bytes);
+                si++;
+            }
+            if (to.n_scans) order.push_back(to);
+        }
+        for (uint32_t c = 0; c < desc.ncomp; c++) {  // the classes of the finished planes: from the range scan below
+            b->sane[(size_t)img * 4 + c] = 0;
+            batch_class_source(b, (size_t)img * 4 + c, true);
+        }
+    }
+    // heavy tracks first, like with like: the 64 lanes of a wave then walk scans of the same kind and about the same length
+    std::stable_sort(order.begin(), order.end(), [](const TrackOrder &a, const TrackOrder &c) { return a.weight > c.weight; });
+    for (size_t t = 0; t < order.size(); t++) {
+        tracks[t].scans = reinterpret_cast<const ProgScan *>(d + off_scans) + order[t].first_scan;
+        tracks[t].n_scans = order[t].n_scans;
+        tracks[t].status = reinterpret_cast<uint32_t *>(d + off_status) + order[t].image_k;
+    }
+    const bool two_streams = copy_stream && copy_stream != hip_stream;
+    hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
+    if (two_streams && !b->entropy_uploaded) B_HIP(hipEventCreateWithFlags(&b->entropy_uploaded, hipEventDisableTiming));
+    // zeros: the planes (the Worker's zero-initialised plane: src/decoder.rs:400-412), the masks, the statistics
+    // (the masks on the kernels' own stream: with a caller's `scratch` they are shared by the launches of that stream, which run one
+    // after the other there — a fill on the copy stream would run into the previous launch's walk)
+    B_HIP(hipMemsetAsync(b->d_coef, 0, b->coef_bytes, cps));
+    B_HIP(hipMemsetAsync(dm, 0, mask_bytes, s));
+    const std::function<void(uint32_t)> stage = [&](uint32_t t) {
+        const StageTask &st = tasks[t];
+        bool clean = true;
+        st.scan->n_bytes = huff_stage_segment(st.dst, st.src, st.ps->stuffed_bytes, &clean);
+        if (!clean) *st.h_status |= PROG_ST_HOST | PROG_ST_STAGING;  // (cannot happen: the planner walked the same bytes)
+        uint8_t *tp = st.tables;
+        for (int tb = 0; tb < 4; tb++)
+            if (st.ps->table[tb]) {
+                memcpy(tp, st.ps->table[tb].get(), sizeof(ProgHuffTable));
+                tp += sizeof(ProgHuffTable);
+            }
+    };
+    if (par && tasks.size() > 1) (*par)((uint32_t)tasks.size(), stage);
+    else
+        for (uint32_t t = 0; t < tasks.size(); t++) stage(t);
+    B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, cps));
+    if (two_streams) {
+        B_HIP(hipEventRecord(b->entropy_uploaded, cps));
+        B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));
+    }
+    // events around the track kernel: always (the pipeline's dispatcher learns the device's latency from them), and the phase events of
+    // JPGPU_BATCH_KERNEL_TIMES ([1]..[2] "sync" = the track kernel, [2]..[3] "write" = the range scan)
+    for (auto &e : b->ev_phase)
+        if (!e) B_HIP(hipEventCreate(&e));
+    B_HIP(hipEventRecord(b->ev_phase[0], s));
+    B_HIP(hipEventRecord(b->ev_phase[1], s));
+    B_HIP(launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)order.size(), s));
+    B_HIP(hipEventRecord(b->ev_phase[2], s));
+    {
+        const int crc = jpgpu_batch_classify_on_device(b, s);
+        if (crc) return crc;
+    }
+    B_HIP(hipEventRecord(b->ev_phase[3], s));
+    b->phase_events_valid = true;
+    b->progressive_launch = true;
+    B_HIP(hipMemcpyAsync(b->h_entropy_out, d + off_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    return JPGPU_OK;
+}
+
+bool jpgpu::batch_progressive_kernel_ms(jpgpu_batch *b, float *ms) {
+    if (!b || !ms || !b->progressive_launch || !b->ev_phase[1] || !b->ev_phase[2]) return false;
+    if (hipEventElapsedTime(ms, b->ev_phase[1], b->ev_phase[2]) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
 }
 
 int jpgpu::batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n) {

@@ -501,6 +501,9 @@ struct Frontend::Impl {
     std::vector<uint8_t> exif, xmp;
     std::vector<IccChunk> icc;
     std::vector<PlannedScan> *plan = nullptr;  // plan_device_scans: describe scans instead of decoding them
+    ProgPlan *prog_plan = nullptr;             // plan_progressive_scans: the same for the scans of a progressive frame
+    uint8_t prog_state[JPGPU_MAX_COMPONENTS][64];  // per coefficient: 0 = no scan yet, else (Al of the last scan that covered it) + 1
+    uint16_t prog_cell_track[JPGPU_MAX_COMPONENTS][64];  // union-find over (component, coefficient) cells: parent cell (c * 64 + k)
     // Per block of a progressive frame: which coefficients (zig-zag positions) are non-zero.  The refinement scans walk
     // bands of up to 63 coefficients per symbol to find the few that exist (src/decoder.rs:1260-1298 does it one by one:
     // 20 of the 27 ms a 1080p progressive image took); with the bitmap the walk costs the non-zero ones only.
@@ -1147,6 +1150,126 @@ struct Frontend::Impl {
     }
     std::vector<uint32_t> seg_start_after;
 
+    // ---- plan_progressive_scans: one scan of a progressive frame --------------------------------------------------------------------
+    uint16_t prog_find(uint16_t cell) {
+        while (prog_cell_track[cell >> 6][cell & 63] != cell) {
+            const uint16_t up = prog_cell_track[cell >> 6][cell & 63];
+            prog_cell_track[cell >> 6][cell & 63] = prog_cell_track[up >> 6][up & 63];  // (path halving)
+            cell = up;
+        }
+        return cell;
+    }
+    static std::shared_ptr<const ProgHuffTable> prog_table_of(const HuffTable &h) {
+        auto t = std::make_shared<ProgHuffTable>();
+        memset(t.get(), 0, sizeof(*t));
+        // the reference's 8-bit table (src/huffman.rs:190-222): codes of up to eight bits under every prefix that begins with them —
+        // read off the host's wider cache of the same procedure; longer codes are left to the walk, as in the reference
+        for (int i = 0; i < 256; i++) {
+            const int w = i << (kLutBits - 8);
+            if (h.lut_size[w] && h.lut_size[w] <= 8) t->lut[i] = (uint16_t)(h.lut_value[w] | ((uint32_t)h.lut_size[w] << 8));
+        }
+        memcpy(t->maxcode, h.maxcode, sizeof(t->maxcode));
+        memcpy(t->delta, h.delta, sizeof(t->delta));
+        memcpy(t->values, h.values, sizeof(t->values));
+        t->nvalues = h.nvalues;
+        return t;
+    }
+    bool plan_prog_scan(const ScanInfo &scan, const bool (&finished)[JPGPU_MAX_COMPONENTS], Marker &pending) {
+        const FrameInfo &f = frame;
+        const int nc = scan.n;
+        if (f.coding_process != JPGPU_CODING_DCT_PROGRESSIVE || f.precision != 8) throw NotEligible{21};
+        if (restart_interval != 0) throw NotEligible{22};
+        if (prog_plan->scans.size() >= 256u) throw NotEligible{23};
+        jpgpu_component comps[JPGPU_MAX_COMPONENTS];
+        for (int i = 0; i < nc; i++) {
+            comps[i] = f.components[scan.component_indices[i]];
+            if (!has_qt[comps[i].quantization_table_index]) throw NotEligible{24};  // decode_scan: "use of unset quantization table"
+        }
+        if (is_mjpeg) throw NotEligible{25};
+        const bool dc_scan = scan.ss_start == 0;
+        const uint8_t se = (uint8_t)(scan.ss_end - 1);
+        if (dc_scan)
+            for (int i = 0; i < nc; i++)
+                if (!dc[scan.dc_tables[i]].present) throw NotEligible{26};
+        if (scan.ss_end > 1)
+            for (int i = 0; i < nc; i++)
+                if (!ac[scan.ac_tables[i]].present) throw NotEligible{27};
+        if (!dc_scan && nc != 1) throw NotEligible{28};  // (parse_sos has refused it already)
+        // successive approximation, one bit at a time from a first scan on, per coefficient
+        uint16_t first_cell = 0xffffu;
+        for (int i = 0; i < nc; i++) {
+            const int ci = scan.component_indices[i];
+            for (int k = scan.ss_start; k <= se; k++) {
+                uint8_t &st = prog_state[ci][k];
+                if (scan.ah == 0) {
+                    if (st != 0) throw NotEligible{29};
+                } else if (st != scan.ah + 1 || scan.al + 1 != scan.ah) {
+                    throw NotEligible{30};
+                }
+                st = (uint8_t)(scan.al + 1);
+                const uint16_t cell = prog_find((uint16_t)(ci * 64 + k));
+                if (first_cell == 0xffffu) first_cell = cell;
+                else if (cell != first_cell) prog_cell_track[cell >> 6][cell & 63] = first_cell;
+            }
+        }
+        for (int i = 0; i < nc; i++)
+            if (finished[i]) memcpy(plane_qt[scan.component_indices[i]], qt[comps[i].quantization_table_index], 128);
+        ProgPlannedScan ps;
+        const bool interleaved = nc > 1;
+        const uint32_t max_x = interleaved ? f.mcu_w : comps[0].block_width, max_y = interleaved ? f.mcu_h : comps[0].block_height;
+        ps.cols = std::min<uint32_t>(max_x, ((uint32_t)f.image_w + 7u) / 8u);  // (the MCU loops of decode_scan stop at the image edge)
+        ps.rows = std::min<uint32_t>(max_y, ((uint32_t)f.image_h + 7u) / 8u);
+        if (ps.cols == 0 || ps.rows == 0) throw NotEligible{31};
+        ps.ss = scan.ss_start;
+        ps.se = se;
+        ps.ah = scan.ah;
+        ps.al = scan.al;
+        ps.ncomp = (uint32_t)nc;
+        ps.track = first_cell;  // (a cell for now: numbered when the stream is through)
+        for (int i = 0; i < nc; i++) {
+            ps.comp[i].frame_index = (uint32_t)scan.component_indices[i];
+            ps.comp[i].block_w = comps[i].block_width;
+            ps.comp[i].h = interleaved ? comps[i].horizontal_sampling_factor : 1u;
+            ps.comp[i].v = interleaved ? comps[i].vertical_sampling_factor : 1u;
+            ps.comp[i].table = dc_scan ? (uint32_t)scan.dc_tables[i] : 0u;
+            // (what decode_scan answers with "reference would panic: coefficient index")
+            if ((uint64_t)ps.rows * ps.comp[i].v > comps[i].block_height || (uint64_t)ps.cols * ps.comp[i].h > comps[i].block_width) throw NotEligible{32};
+        }
+        if (dc_scan && scan.ah == 0) {
+            for (int i = 0; i < nc; i++) {
+                const HuffTable &h = dc[scan.dc_tables[i]];
+                for (int v = 0; v < h.nvalues; v++)
+                    if (h.values[v] > 15) throw NotEligible{33};  // (the lanes keep DC symbols in four bits; a category above 11 is an error anyway)
+                if (!ps.table[scan.dc_tables[i]]) ps.table[scan.dc_tables[i]] = prog_table_of(h);
+            }
+        } else if (!dc_scan) {
+            ps.table[0] = prog_table_of(ac[scan.ac_tables[0]]);
+        }
+        // the scan's data: up to the first 0xFF that is not followed by its stuffing zero — a marker, which ends the scan
+        const uint8_t *p = src.p;
+        size_t pos = src.pos;
+        ps.data_off = pos;
+        for (;;) {
+            const void *ff = pos < src.len ? memchr(p + pos, 0xFF, src.len - pos) : nullptr;
+            if (!ff) throw NotEligible{34};  // ran off the end without a marker: the host reports it
+            pos = (size_t)(static_cast<const uint8_t *>(ff) - p);
+            if (pos + 1 >= src.len) throw NotEligible{35};
+            const uint8_t nb = p[pos + 1];
+            if (nb == 0x00) {
+                pos += 2;
+                continue;
+            }
+            if (nb == 0xFF || (nb >= 0xD0 && nb <= 0xD7)) throw NotEligible{36};  // fill bytes, a restart marker without an interval
+            if (pos - ps.data_off > 0x0FFFFFF0u) throw NotEligible{37};
+            ps.stuffed_bytes = (uint32_t)(pos - ps.data_off);
+            pending = marker_from(nb);
+            src.pos = pos + 2;
+            break;
+        }
+        prog_plan->scans.push_back(std::move(ps));
+        return true;
+    }
+
     bool decode_scan(const ScanInfo &scan, const bool (&finished)[JPGPU_MAX_COMPONENTS], RowSink &sink, Marker &pending) {
         const FrameInfo &f = frame;
         jpgpu_component comps[JPGPU_MAX_COMPONENTS];
@@ -1313,7 +1436,8 @@ struct Frontend::Impl {
                 if (!has_frame) fail(JPGPU_ERR_FORMAT, "scan encountered before frame");
                 const ScanInfo scan = parse_sos();
                 const FrameInfo &f = frame;
-                if (f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE && !have_coefficients) {
+                if (prog_plan && f.coding_process != JPGPU_CODING_DCT_PROGRESSIVE) throw NotEligible{20};
+                if (f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE && !have_coefficients && !prog_plan) {
                     for (size_t i = 0; i < f.components.size(); i++)
                         coefficients[i] = coef_pool().take((size_t)f.components[i].block_width * f.components[i].block_height * 64);
                     for (size_t i = 0; i < f.components.size(); i++)
@@ -1330,7 +1454,7 @@ struct Frontend::Impl {
                         for (int j = scan.ss_start; j < scan.ss_end; j++) finished_mask[i] |= (uint64_t)1 << j;
                         if (finished_mask[i] == ~(uint64_t)0) finished[k] = true;
                     }
-                has_pending = plan ? plan_scan(scan, finished, pending) : decode_scan(scan, finished, *sink, pending);
+                has_pending = prog_plan ? plan_prog_scan(scan, finished, pending) : (plan ? plan_scan(scan, finished, pending) : decode_scan(scan, finished, *sink, pending));
                 scans++;
                 break;
             }
@@ -1366,7 +1490,17 @@ struct Frontend::Impl {
             const unsigned __int128 need = (unsigned __int128)ncomp * f.output_w * f.output_h;
             if (need > (unsigned __int128)buffer_limit) fail(JPGPU_ERR_FORMAT, "size of decoded image exceeds maximum allowed size");
         }
-        if (f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE && have_coefficients)
+        if (prog_plan) {  // (plan_progressive_scans: every component gets a plane — finished in some scan, or rendered as it stands)
+            if (prog_plan->scans.empty()) throw NotEligible{38};
+            for (size_t i = 0; i < ncomp; i++) {
+                const jpgpu_component &c = f.components[i];
+                if (finished_mask[i] != ~(uint64_t)0) {
+                    if (!has_qt[c.quantization_table_index]) throw NotEligible{39};  // (its plane would be missing: "not all components have data")
+                    memcpy(plane_qt[i], qt[c.quantization_table_index], 128);
+                }
+                plane_present[i] = true;
+            }
+        } else if (f.coding_process == JPGPU_CODING_DCT_PROGRESSIVE && have_coefficients)
             for (size_t i = 0; i < ncomp; i++) {  // render what we have of unfinished components
                 if (finished_mask[i] == ~(uint64_t)0) continue;
                 const jpgpu_component &c = f.components[i];
@@ -1469,6 +1603,41 @@ bool Frontend::plan_device_scans(std::vector<PlannedScan> &scans) {
     }
     impl_->plan = nullptr;
     if (!ok) scans.clear();
+    return ok;
+}
+bool Frontend::plan_progressive_scans(ProgPlan &plan) {
+    plan.scans.clear();
+    plan.n_tracks = 0;
+    Impl &im = *impl_;
+    im.prog_plan = &plan;
+    memset(im.prog_state, 0, sizeof(im.prog_state));
+    for (int c = 0; c < JPGPU_MAX_COMPONENTS; c++)
+        for (int k = 0; k < 64; k++) im.prog_cell_track[c][k] = (uint16_t)(c * 64 + k);
+    bool ok = true;
+    try {
+        im.run(false, nullptr);
+        ok = !plan.scans.empty();
+    } catch (const Impl::NotEligible &ne) {
+        if (getenv("JPGPU_PLAN_TRACE")) fprintf(stderr, "plan_progressive_scans: not eligible (check %d)\n", ne.where);
+        ok = false;
+    } catch (const DecodeError &) {
+        ok = false;  // the host decoder reports it
+    }
+    im.prog_plan = nullptr;
+    if (ok) {  // cells -> track numbers, in order of first appearance
+        uint16_t roots[256];
+        uint32_t n = 0;
+        for (ProgPlannedScan &ps : plan.scans) {
+            const uint16_t root = im.prog_find((uint16_t)ps.track);
+            uint32_t t = 0;
+            while (t < n && roots[t] != root) t++;
+            if (t == n) roots[n++] = root;
+            ps.track = t;
+        }
+        plan.n_tracks = n;
+    } else {
+        plan.scans.clear();
+    }
     return ok;
 }
 bool Frontend::has_frame() const { return impl_->has_frame; }

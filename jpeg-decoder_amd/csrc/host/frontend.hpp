@@ -14,6 +14,7 @@
 #include "../../../include/jpgpu.h"
 #include "../../../include/jpgpu_decoder.h"
 #include "../huff_job.hpp"
+#include "../huff_prog_job.hpp"
 
 namespace jpgpu {
 namespace host {
@@ -63,6 +64,25 @@ struct PlannedScan {
     std::shared_ptr<const TableSet> tables;
 };
 
+// What the device decoder for PROGRESSIVE frames (csrc/huff_prog_core.hpp) needs for one scan of such a frame, and which scans of
+// the frame depend on one another: scans that (transitively) share a coefficient of a component form a TRACK, decoded by one lane in
+// stream order; different tracks touch disjoint coefficients and run side by side.
+struct ProgPlannedScan {
+    size_t data_off = 0;          // offset of the scan's entropy-coded bytes in the stream
+    uint32_t stuffed_bytes = 0;   // up to the marker that ends the scan: nothing but 0xFF00 pairs inside (checked here)
+    uint8_t ss = 0, se = 0, ah = 0, al = 0;  // se inclusive
+    uint32_t ncomp = 0, cols = 0, rows = 0;
+    struct Comp {
+        uint32_t frame_index, block_w, h, v, table;
+    } comp[4];
+    std::shared_ptr<const ProgHuffTable> table[4];  // DC first scans: indexed by DC table id; AC scans: [0]
+    uint32_t track = 0;
+};
+struct ProgPlan {
+    std::vector<ProgPlannedScan> scans;  // stream order
+    uint32_t n_tracks = 0;
+};
+
 struct IccChunk {
     uint8_t num_markers, seq_no;
     std::vector<uint8_t> data;
@@ -89,6 +109,12 @@ public:
     // decoder is the one whose behaviour on odd streams is pinned.  On success the tables handed to Worker::start
     // (qtable_of_component) and planes_present() are set as decode_to would have set them.
     bool plan_device_scans(std::vector<PlannedScan> &scans);
+    // The same for a PROGRESSIVE frame.  Eligible: 8-bit, Huffman, no restart interval in force at any scan, every scan's
+    // data free of markers and fill bytes, every coefficient of every component refined one bit at a time from a first scan on (the
+    // order the standard prescribes: the device's refinement scans rely on it), every component with a quantization table at the end
+    // of the stream (so that every plane exists, finished or not: src/decoder.rs:643-684), DC tables whose symbols are categories.
+    // As with plan_device_scans the object is spent afterwards; qtable_of_component() / planes_present() are set on success.
+    bool plan_progressive_scans(ProgPlan &plan);
 
     const uint8_t *stream_bytes(size_t *len) const;  // the copy of the stream this object works on
     bool has_frame() const;

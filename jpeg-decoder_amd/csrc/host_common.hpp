@@ -52,6 +52,7 @@ void worker_recycle(jpgpu_worker *w);
 // ---- device entropy decoding of restart-marker streams (huff_core.hpp), used by the pipeline ----------------------
 namespace host {
 struct PlannedScan;
+struct ProgPlan;
 }
 struct DeviceEntropyImage {
     uint32_t image;                                  // index in the batch
@@ -77,6 +78,20 @@ int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images
                                 const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
                                 void *copy_stream = nullptr, DeviceScratch *scratch = nullptr, bool alone = false);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
+// The same for PROGRESSIVE frames (huff_prog_core.hpp): the scans of every listed image are staged and uploaded, the
+// images' planes and non-zero / sign masks zero-filled, ONE launch walks all tracks (a lane per track of dependent scans; the
+// coefficients are accumulated in the arena in place), then the range scan classifies the finished planes on the device.  Every image of
+// the batch must be listed (the range scan covers the whole arena).  Collect with batch_device_entropy_collect.
+// kernel_ms (optional, after the stream has been synchronised): batch_progressive_kernel_ms.
+struct DeviceProgressiveImage {
+    uint32_t image;
+    const uint8_t *file;
+    const host::ProgPlan *plan;  // Frontend::plan_progressive_scans
+};
+int batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressiveImage *images, uint32_t n, void *hip_stream,
+                                    const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
+                                    void *copy_stream = nullptr, DeviceScratch *scratch = nullptr);
+bool batch_progressive_kernel_ms(jpgpu_batch *b, float *ms);  // duration of the last launch's track kernel (events; stream synchronised)
 bool batch_phase_times(jpgpu_batch *b, float ms[4]);  // JPGPU_BATCH_KERNEL_TIMES, batch.cpp
 bool batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]);  // (+ JPGPU_PIPE_TRACE) event times relative to ref's first event
 

@@ -6,6 +6,7 @@
 
 #include "huff.hpp"
 #include "huff_core.hpp"
+#include "huff_prog_core.hpp"
 #include "huff_sync_core.hpp"
 #include "range_stats.hpp"
 
@@ -707,6 +708,25 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
         __syncthreads();
     }
     publish_range(job.stats, HuffRange{max_dc, 0u});
+}
+
+// ---- progressive frames: one lane per track (huff_prog_core.hpp) ---------------------------------------------------------------------
+// grid = ceil(tracks / 64) workgroups of ONE wave: a lane's table region is 1 kB of LDS (66 kB per workgroup, two workgroups per CU),
+// and the lanes of a wave do not talk to each other — the host sorts the tracks so that a wave's 64 walk scans of the same kind and
+// of similar length.
+__global__ __launch_bounds__(64) void huff_prog_kernel(const ProgTrack *__restrict__ tracks, uint32_t n_tracks) {
+    __shared__ ProgLds L;
+    huff_fill_unzigzag((JP_LDS uint8_t *)L.unzig, threadIdx.x);
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= n_tracks) return;
+    prog_run_track(*(JP_LDS ProgLds *)&L, threadIdx.x, tracks[t]);
+}
+
+hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream) {
+    if (n_tracks == 0) return hipSuccess;
+    huff_prog_kernel<<<dim3((n_tracks + 63u) / 64u), dim3(64), 0, stream>>>(d_tracks, n_tracks);
+    return hipGetLastError();
 }
 
 hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream) {

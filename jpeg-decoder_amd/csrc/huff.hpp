@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "huff_job.hpp"
+#include "huff_prog_job.hpp"
 
 namespace jpgpu {
 
@@ -20,6 +21,8 @@ struct RangeJob {  // one component plane to classify
 // low_table_ids: every job's components use Huffman table ids 0 and 1 only — the sync passes run with four table slots in LDS
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
                             hipEvent_t after_sync = nullptr, bool low_table_ids = false);
+// progressive frames: one lane per track of dependent scans, coefficients accumulated in the arena (huff_prog_core.hpp)
+hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);
 hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t *d_stats, hipStream_t stream);
 // one plane whose quantization table sits in device memory; raises the RS_WORDS statistics words at d_stats
 hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream);

@@ -1,0 +1,401 @@
+// huff_prog_core.hpp — the device decoder for progressive frames: one lane walks one track (huff_prog_job.hpp) scan by scan, block by
+// block, symbol by symbol, exactly as the reference's decode_block / decode_block_successive_approximation / refine_non_zeroes do
+// (src/decoder.rs:1086-1298; the host restatement this file was written against is csrc/host/frontend.cpp: decode_block,
+// decode_block_refine, refine_non_zeroes with its bitmap walk).  Compiled by hipcc for huff_prog_kernel (huff.hip) and by g++ for
+// tests/emu (one lane at a time).
+//
+// Anything the reference would answer with an error, and the few places where an INVALID stream makes it do something that depends
+// on its table layout (a run that leaves the band, src/decoder.rs:1138-1146 — see decode_block in frontend.cpp), raise the image's
+// status word instead: the host decoder, whose behaviour on odd streams is pinned, then decodes that image.
+#pragma once
+#include "huff_prog_job.hpp"
+#include "pixel_math.hpp"
+
+namespace jpgpu {
+
+struct ProgLds {
+    uint32_t tab[64][PROG_LANE_DWORDS];  // per lane: the table of its current scan (AC: a whole ProgHuffTable; DC: four byte lookups)
+    uint8_t unzig[64];
+};
+
+// ---- memory operations other lanes / later scans of the same lane must see: past the L1 -------------------------------------------
+__device__ __forceinline__ void prog_or32(uint32_t *p, uint32_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p |= v;
+#else
+    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (result unused: the no-return form)
+#endif
+}
+__device__ __forceinline__ void prog_add32(uint32_t *p, uint32_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p += v;
+#else
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void prog_or64(uint64_t *p, uint64_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p |= v;
+#else
+    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ uint64_t prog_load64(const uint64_t *p) {
+#ifdef JPGPU_HOST_EMULATION
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void prog_store64(uint64_t *p, uint64_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void prog_flag(uint32_t *status, uint32_t bits) { prog_or32(status, bits | PROG_ST_HOST); }
+
+// ---- bit reader: one aligned dword per refill, requested a refill ahead; zeros behind the scan's data ------------------------------
+struct ProgBits {
+    uint64_t bits;  // unread bits, left-aligned
+    uint32_t nbits;
+    const uint32_t *next, *end;  // the dword `ahead` was read from + 1; first dword behind the data
+    uint32_t ahead;
+};
+__device__ __forceinline__ void prog_bits_open(ProgBits &b, const ProgScan &s) {
+    b.bits = 0;
+    b.nbits = 0;
+    b.next = reinterpret_cast<const uint32_t *>(s.data);
+    b.end = b.next + (s.n_bytes + 3u) / 4u;  // (the staging pass zero-fills the slot behind the data: the last dword's tail is zeros)
+    b.ahead = b.next < b.end ? *b.next : 0u;
+    b.next++;
+}
+// afterwards more than 32 bits are available (a step reads at most 16 + 15)
+__device__ __forceinline__ void prog_refill(ProgBits &b) {
+    if (b.nbits <= 32u) {
+        b.bits |= (uint64_t)__builtin_bswap32(b.ahead) << (32u - b.nbits);
+        b.nbits += 32u;
+        b.ahead = b.next < b.end ? *b.next : 0u;
+        b.next++;
+    }
+}
+__device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? (uint32_t)(b.bits >> (64u - n)) : 0u; }
+__device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) {
+    b.bits <<= n;
+    b.nbits -= n;
+}
+__device__ __forceinline__ uint32_t prog_get(ProgBits &b, uint32_t n) {  // n <= 32, after a refill
+    const uint32_t v = prog_peek(b, n);
+    prog_consume(b, n);
+    return v;
+}
+__device__ __forceinline__ int32_t prog_extend(uint32_t v, uint32_t n) {  // src/huffman.rs:165-173 (n >= 1)
+    const int32_t vt = 1 << (n - 1u);
+    return (int32_t)v < vt ? (int32_t)v + (int32_t)(0xffffffffu << n) + 1 : (int32_t)v;
+}
+
+// ---- a lane's table region --------------------------------------------------------------------------------------------------------
+// AC scans (and single-table use in general): the ProgHuffTable as it is
+__device__ __forceinline__ void prog_load_table(JP_LDS uint32_t *T, const ProgHuffTable *t) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(t);
+    for (uint32_t i = 0; i < PROG_TABLE_DWORDS; i++) T[i] = src[i];
+}
+// DC first scans: up to four tables, each as 256 bytes: category | code length << 4 (0: the walk, from the table in global memory —
+// codes of nine bits and more are rare in tables of twelve symbols)
+__device__ __forceinline__ void prog_load_dc_tables(JP_LDS uint32_t *T, const ProgScan &s) {
+    for (uint32_t t = 0; t < 4u; t++) {
+        const ProgHuffTable *src = s.table[t];
+        for (uint32_t i = 0; i < 64u; i++) {
+            uint32_t w = 0;
+            if (src)
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t e = src->lut[4u * i + j], len = e >> 8, sym = e & 0xffu;
+                    // (a symbol above 15 cannot be packed; the planner refuses such tables — category > 11 is an error anyway)
+                    w |= (len && sym < 16u ? (len << 4) | sym : 0u) << (8u * j);
+                }
+            T[64u * t + i] = w;
+        }
+    }
+}
+// the walk for codes the 8-bit lookup does not resolve (src/huffman.rs:44-58); `lds`: the table is the lane's LDS copy
+template <class TablePtr>
+__device__ __forceinline__ uint32_t prog_walk(ProgBits &b, TablePtr t, bool &bad) {
+    const uint32_t b16 = prog_peek(b, 16);
+    for (uint32_t i = 8; i < 16u; i++) {
+        const int32_t code = (int32_t)(b16 >> (15u - i));
+        if (code <= t->maxcode[i]) {
+            prog_consume(b, i + 1u);
+            const int32_t index = code + t->delta[i];
+            if (index < 0 || index >= t->nvalues) {  // ("reference would panic": the host reports it)
+                bad = true;
+                return 0u;
+            }
+            return t->values[index];
+        }
+    }
+    bad = true;  // "failed to decode huffman code"
+    return 0u;
+}
+__device__ __forceinline__ uint32_t prog_decode_ac(ProgBits &b, const JP_LDS uint32_t *T, bool &bad) {
+    const JP_LDS ProgHuffTable *t = reinterpret_cast<const JP_LDS ProgHuffTable *>(T);
+    const uint32_t e = t->lut[prog_peek(b, 8)];
+    if (e >> 8) {
+        prog_consume(b, e >> 8);
+        return e & 0xffu;
+    }
+    return prog_walk(b, t, bad);
+}
+__device__ __forceinline__ uint32_t prog_decode_dc(ProgBits &b, const JP_LDS uint32_t *T, uint32_t table, const ProgScan &s, bool &bad) {
+    const uint32_t e = reinterpret_cast<const JP_LDS uint8_t *>(T)[256u * table + prog_peek(b, 8)];
+    if (e >> 4) {
+        prog_consume(b, e >> 4);
+        return e & 15u;
+    }
+    return prog_walk(b, s.table[table], bad);
+}
+
+// where block (mx, my) x (hp, vp) of scan component c lies
+__device__ __forceinline__ size_t prog_block_index(const ProgScanComp &c, uint32_t mx, uint32_t my, uint32_t hp, uint32_t vp) {
+    return (size_t)(my * c.v + vp) * c.block_w + (mx * c.h + hp);
+}
+
+// ---- DC scans (ss == se == 0; one to four components, src/decoder.rs:1100-1126 and :1181-1190) ------------------------------------
+// Returns false if the scan raised the status word.
+__device__ inline bool prog_scan_dc(const ProgScan &s, JP_LDS uint32_t *T, uint32_t *status) {
+    ProgBits b;
+    prog_bits_open(b, s);
+    const bool first = s.ah == 0;
+    if (first) prog_load_dc_tables(T, s);
+    uint64_t pred = 0;  // four 16-bit predictors (wrapping_add on i16 in the reference)
+    bool bad = false;
+    for (uint32_t my = 0; my < s.rows; my++)
+        for (uint32_t mx = 0; mx < s.cols; mx++)
+            for (uint32_t c = 0; c < s.ncomp; c++) {
+                const ProgScanComp &sc = s.comp[c];
+                for (uint32_t vp = 0; vp < sc.v; vp++)
+                    for (uint32_t hp = 0; hp < sc.h; hp++) {
+                        int16_t *co = sc.coefs + prog_block_index(sc, mx, my, hp, vp) * 64u;
+                        prog_refill(b);
+                        if (first) {
+                            const uint32_t cat = prog_decode_dc(b, T, sc.table, s, bad);
+                            if (bad || cat > 11u) {  // "invalid DC difference magnitude category"
+                                prog_flag(status, bad ? PROG_ST_BAD_CODE : PROG_ST_BAD_DC);
+                                return false;
+                            }
+                            uint32_t diff = 0;
+                            if (cat) {
+                                prog_refill(b);
+                                diff = (uint32_t)prog_extend(prog_get(b, cat), cat);
+                            }
+                            const uint32_t p = (uint32_t)((pred >> (16u * c)) + diff) & 0xffffu;
+                            pred = (pred & ~(0xffffull << (16u * c))) | ((uint64_t)p << (16u * c));
+                            co[0] = (int16_t)(uint16_t)(p << s.al);
+                        } else if (prog_get(b, 1)) {
+                            prog_or32(reinterpret_cast<uint32_t *>(co), 1u << s.al);  // co[0] |= bit (the low half of the block's first dword)
+                        }
+                    }
+            }
+    return true;
+}
+
+// ---- AC first scan (one component, ah == 0, ss >= 1; src/decoder.rs:1128-1172) -----------------------------------------------------
+__device__ inline bool prog_scan_ac_first(const ProgScan &s, JP_LDS uint32_t *T, const JP_LDS uint8_t *unzig, uint32_t *status) {
+    ProgBits b;
+    prog_bits_open(b, s);
+    prog_load_table(T, s.table[0]);
+    const ProgScanComp &sc = s.comp[0];
+    uint32_t eob_run = 0;
+    bool bad = false;
+    for (uint32_t my = 0; my < s.rows; my++)
+        for (uint32_t mx = 0; mx < s.cols; mx++) {
+            if (eob_run > 0u) {
+                eob_run--;
+                continue;
+            }
+            const size_t blk = prog_block_index(sc, mx, my, 0u, 0u);
+            int16_t *co = sc.coefs + blk * 64u;
+            uint64_t nz = 0, neg = 0;
+            uint32_t k = s.ss;
+            while (k <= s.se) {
+                prog_refill(b);
+                const uint32_t rs = prog_decode_ac(b, T, bad), r = rs >> 4, sz = rs & 15u;
+                if (bad) {
+                    prog_flag(status, PROG_ST_BAD_CODE);
+                    return false;
+                }
+                if (sz == 0u) {
+                    if (r == 15u) {
+                        k += 16u;
+                        continue;
+                    }
+                    eob_run = (1u << r) - 1u;
+                    if (r) {
+                        prog_refill(b);
+                        eob_run += prog_get(b, r);
+                    }
+                    break;
+                }
+                k += r;
+                // a run that leaves the band: what the reference then does with the magnitude bits depends on its table layout
+                // (frontend.cpp, decode_block) — the host's business; so is a magnitude that could make a later correction carry
+                if (k > s.se || sz + s.al > 14u) {
+                    prog_flag(status, k > s.se ? PROG_ST_BAND : PROG_ST_RANGE);
+                    return false;
+                }
+                prog_refill(b);
+                const int32_t v = prog_extend(prog_get(b, sz), sz);
+                co[unzig[k]] = (int16_t)(uint16_t)((uint32_t)v << s.al);
+                nz |= 1ull << k;
+                if (v < 0) neg |= 1ull << k;
+                k++;
+            }
+            if (nz) {  // (OR, not store: another first scan of this track may own other bands of the block)
+                prog_or64(sc.masks + 2u * blk, nz);
+                if (neg) prog_or64(sc.masks + 2u * blk + 1u, neg);
+            }
+        }
+    return true;
+}
+
+// ---- AC refinement scan (one component, ah > 0, ss >= 1; src/decoder.rs:1192-1298) -------------------------------------------------
+struct ProgRefine {
+    ProgBits b;
+    uint64_t nz, neg;  // the current block's masks as they were when the scan reached it
+    int16_t *co;
+    uint32_t bit;      // 1 << al
+};
+// refine_non_zeroes(start .. end-1, zrl): a correction bit for every non-zero coefficient until `zrl` zero ones have been passed;
+// returns where the walk stopped (the (zrl + 1)-th zero coefficient, or end - 1)
+__device__ __forceinline__ uint32_t prog_refine_non_zeroes(ProgRefine &R, const JP_LDS uint8_t *unzig, uint32_t start, uint32_t end, uint32_t zrl) {
+    if (start >= end) return end - 1u;
+    const uint64_t below_end = end >= 64u ? ~0ull : ((1ull << end) - 1ull), range = below_end & ~((1ull << start) - 1ull);
+    uint64_t zeros = ~R.nz & range;
+    uint32_t stop = end;
+    bool hit = false;
+    if ((uint32_t)__builtin_popcountll(zeros) > zrl) {
+        for (uint32_t skip = 0; skip < zrl; skip++) zeros &= zeros - 1ull;
+        stop = (uint32_t)__builtin_ctzll(zeros);
+        hit = true;
+    }
+    uint64_t todo = R.nz & range & (stop >= 64u ? ~0ull : ((1ull << stop) - 1ull));
+    uint32_t n = (uint32_t)__builtin_popcountll(todo);
+    while (n) {  // the correction bits, up to 32 at a time: the first coefficient's bit is the first in the stream
+        const uint32_t take = n < 32u ? n : 32u;
+        prog_refill(R.b);
+        const uint32_t corr = prog_get(R.b, take);
+        for (uint32_t j = 0; j < take; j++) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            if ((corr >> (take - 1u - j)) & 1u) {
+                // c += sign(c) * bit.  (c & bit) == 0 always: the planner admits only streams whose scans refine a band one bit at
+                // a time (plan_progressive_scans), so every non-zero coefficient is a multiple of 2 * bit here; and |c| < 2^14
+                // (first scans check sz + al <= 14), so the addition cannot carry out of the coefficient's half of the dword.
+                const uint32_t z = unzig[i];
+                const uint32_t delta = ((R.neg >> i) & 1ull) ? 0u - R.bit : R.bit;
+                prog_add32(reinterpret_cast<uint32_t *>(R.co) + (z >> 1), (z & 1u) ? delta << 16 : delta);
+            }
+        }
+        n -= take;
+    }
+    return hit ? stop : end - 1u;
+}
+
+__device__ inline bool prog_scan_ac_refine(const ProgScan &s, JP_LDS uint32_t *T, const JP_LDS uint8_t *unzig, uint32_t *status) {
+    ProgRefine R;
+    prog_bits_open(R.b, s);
+    prog_load_table(T, s.table[0]);
+    const ProgScanComp &sc = s.comp[0];
+    R.bit = 1u << s.al;
+    uint32_t eob_run = 0;
+    bool bad = false;
+    const uint32_t end = (uint32_t)s.se + 1u;
+    // the masks of the block after this one are requested while this one is decoded
+    uint64_t nz_next = 0, neg_next = 0;
+    {
+        const size_t blk0 = prog_block_index(sc, 0u, 0u, 0u, 0u);
+        if (s.rows && s.cols) {
+            nz_next = prog_load64(sc.masks + 2u * blk0);
+            neg_next = prog_load64(sc.masks + 2u * blk0 + 1u);
+        }
+    }
+    for (uint32_t my = 0; my < s.rows; my++)
+        for (uint32_t mx = 0; mx < s.cols; mx++) {
+            const size_t blk = prog_block_index(sc, mx, my, 0u, 0u);
+            R.co = sc.coefs + blk * 64u;
+            R.nz = nz_next;
+            R.neg = neg_next;
+            {
+                uint32_t nx = mx + 1u, ny = my;
+                if (nx == s.cols) nx = 0u, ny++;
+                if (ny < s.rows) {
+                    const size_t nb = prog_block_index(sc, nx, ny, 0u, 0u);
+                    nz_next = prog_load64(sc.masks + 2u * nb);
+                    neg_next = prog_load64(sc.masks + 2u * nb + 1u);
+                }
+            }
+            uint64_t new_nz = 0, new_neg = 0;
+            if (eob_run > 0u) {
+                eob_run--;
+                prog_refine_non_zeroes(R, unzig, s.ss, end, 64u);
+                continue;
+            }
+            uint32_t k = s.ss;
+            while (k < end) {
+                prog_refill(R.b);
+                const uint32_t rs = prog_decode_ac(R.b, T, bad), r = rs >> 4, sz = rs & 15u;
+                if (bad) {
+                    prog_flag(status, PROG_ST_BAD_CODE);
+                    return false;
+                }
+                uint32_t zrl = r;
+                int32_t value = 0;
+                if (sz == 0u) {
+                    if (r != 15u) {
+                        eob_run = (1u << r) - 1u;
+                        if (r) {
+                            prog_refill(R.b);
+                            eob_run += prog_get(R.b, r);
+                        }
+                        zrl = 64u;
+                    }
+                } else if (sz == 1u) {
+                    prog_refill(R.b);
+                    value = prog_get(R.b, 1) ? (int32_t)R.bit : -(int32_t)R.bit;
+                } else {  // "unexpected huffman code"
+                    prog_flag(status, PROG_ST_REFINE_SYMBOL);
+                    return false;
+                }
+                k = prog_refine_non_zeroes(R, unzig, k, end, zrl);
+                if (value != 0) {
+                    R.co[unzig[k]] = (int16_t)value;
+                    new_nz |= 1ull << k;
+                    if (value < 0) new_neg |= 1ull << k;
+                }
+                k++;
+            }
+            if (new_nz) {  // (this lane owns the block's AC positions: plain stores, past the L1 for the scans that follow)
+                prog_store64(sc.masks + 2u * blk, R.nz | new_nz);
+                // (a damaged stream can make the walk end ON a non-zero coefficient — at the band's last position, when it runs out of
+                // zeros — and the new value then REPLACES it, src/decoder.rs:1251-1256: the sign is the new value's)
+                const uint64_t neg = (R.neg & ~new_nz) | new_neg;
+                if (neg != R.neg) prog_store64(sc.masks + 2u * blk + 1u, neg);
+            }
+        }
+    return true;
+}
+
+// ---- one lane: its track --------------------------------------------------------------------------------------------------------------
+__device__ inline void prog_run_track(JP_LDS ProgLds &L, uint32_t lane, const ProgTrack &tr) {
+    JP_LDS uint32_t *T = L.tab[lane];
+    for (uint32_t i = 0; i < tr.n_scans; i++) {
+        const ProgScan &s = tr.scans[i];
+        bool ok;
+        if (s.ss == 0u) ok = prog_scan_dc(s, T, tr.status);
+        else if (s.ah == 0u) ok = prog_scan_ac_first(s, T, L.unzig, tr.status);
+        else ok = prog_scan_ac_refine(s, T, L.unzig, tr.status);
+        if (!ok) return;
+    }
+}
+
+}  // namespace jpgpu

@@ -8,6 +8,7 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -274,6 +275,11 @@ struct jpgpu_pipeline {
     std::vector<jpgpu_image_info> infos;
     std::vector<int32_t> sub_of, slot;  // image -> sub-batch / index in it, -1 if it never got there
     std::vector<std::vector<jpgpu::host::PlannedScan>> plans;  // per image: scans for the device entropy decoder (empty: host)
+    std::vector<jpgpu::host::ProgPlan> prog_plans;             // per image: the scans of a PROGRESSIVE frame for the device (no scans: host)
+    // What the dispatcher of progressive frames has learnt from this pipeline's earlier calls (nanoseconds per byte of JPEG file):
+    // a host thread's entropy decoding + staging of one such frame, and the device's walk of the longest track (a launch's duration
+    // does not depend on how many frames it holds while they fit the machine: every track has a lane of its own).  0: not measured yet.
+    double prog_host_ns_per_byte = 0.0, prog_dev_ns_per_byte = 0.0;
     std::vector<SubBatch> subs;          // kept across calls while the geometry sequence repeats
     uint32_t n_subs = 0;                 // sub-batches used by the last call
     std::string path;
@@ -317,6 +323,7 @@ static const jpgpu_pipeline *child_of(const jpgpu_pipeline *p, uint32_t &image) 
     return c;
 }
 static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags);
+static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n);
 static void pin_to(const std::vector<int> &cpus) {
     if (cpus.empty()) return;
     cpu_set_t set;
@@ -508,6 +515,72 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
         }
 }
 
+// Progressive frames: the device walks every frame's tracks side by side, one lane each — a launch takes as long as ONE
+// lane's walk of the longest track, whether it holds ten frames or ten thousand (while they fit the machine: 512 waves of 64 lanes) —
+// and a host thread decodes a frame in a fraction of that time, one after the other.  So a call's eligible frames are SPLIT: the
+// device takes as many as the host's threads would not have finished by the time the walk ends; the host decodes the rest meanwhile
+// (entropy decoding on its threads, compact planes uploaded, as in round 4).  A few hundred frames on many cores: nearly all stay on
+// the host; thousands, or few cores: most go to the device.  The two rates come from this pipeline's earlier calls (first call: a
+// guess, and a probe of a few frames so that the next call knows).  JPGPU_PIPE_PROG_DEVICE_PERCENT pins the share (tests, A/B).
+// Returns how many frames keep their device plan; the others get a fresh front-end for the host path.
+static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
+    std::vector<uint32_t> elig;
+    uint64_t bytes = 0, tracks = 0;
+    uint32_t n_prog_host = 0;  // progressive frames the host decodes anyway (not eligible)
+    for (uint32_t i = 0; i < n; i++) {
+        if (p->status[i] != JPGPU_OK) continue;
+        if (!p->prog_plans[i].scans.empty()) {
+            elig.push_back(i);
+            bytes += len[i];
+            tracks += p->prog_plans[i].n_tracks;
+        } else if (p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
+            n_prog_host++;
+        }
+    }
+    const uint32_t e = (uint32_t)elig.size();
+    if (e == 0) return 0;
+    uint32_t d;
+    if (const char *pin = getenv("JPGPU_PIPE_PROG_DEVICE_PERCENT")) {
+        d = (uint32_t)((uint64_t)e * (uint64_t)std::min<long>(std::max<long>(atol(pin), 0), 100) / 100u);
+    } else {
+        const double avg = (double)bytes / e;
+        const double host_ns = p->prog_host_ns_per_byte > 0 ? p->prog_host_ns_per_byte : 20.0;   // (1.2 ms per 60 kB frame)
+        const double dev_ns = p->prog_dev_ns_per_byte > 0 ? p->prog_dev_ns_per_byte : 330.0;     // (20 ms per 60 kB frame)
+        const double threads = (double)p->pool->size();
+        // lanes the machine holds at a time (two one-wave workgroups of 66 kB LDS per CU x 256 CUs x 64 lanes); more tracks than that
+        // walk in rounds
+        const double lanes = 32768.0, tracks_per_frame = (double)tracks / e;
+        uint32_t best_d = 0;
+        double best_t = (double)(e + n_prog_host) * avg * host_ns / threads * 1e-6;  // everything on the host (ms)
+        for (uint32_t cand = std::min<uint32_t>(e, 16u); cand <= e; cand = cand < e ? std::min<uint32_t>(e, cand + std::max<uint32_t>(16u, e / 64u)) : e + 1u) {
+            const double rounds = std::ceil(cand * tracks_per_frame / lanes);
+            const double t_dev = 1.0 + rounds * avg * dev_ns * 1e-6 + cand * 0.002;  // launch overheads + the walk + staging / upload of its frames
+            const double t_host = (double)(e - cand + n_prog_host) * avg * host_ns / threads * 1e-6;
+            const double t = std::max(t_dev, t_host);
+            if (t < best_t * 0.97) {  // (a tie goes to the host: its path is the pinned one)
+                best_t = t;
+                best_d = cand;
+            }
+        }
+        d = best_d;
+        if (p->prog_dev_ns_per_byte <= 0 && e >= 32u) d = std::max(d, std::min<uint32_t>(32u, e / 4u));  // the probe
+    }
+    // the LAST (e - d) eligible frames go back to the host (its threads start from the front of the list)
+    for (uint32_t k = d; k < e; k++) {
+        const uint32_t i = elig[k];
+        p->prog_plans[i].scans.clear();
+        p->prog_plans[i].n_tracks = 0;
+        try {
+            p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
+            read_info_with_options(p, *p->fes[i]);
+        } catch (const DecodeError &err) {
+            p->status[i] = err.code;
+            p->errors[i] = err.message;
+        }
+    }
+    return d;
+}
+
 int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags) {
     jpgpu::TraceRange roctx_range("jpgpu_pipeline_decode");
     // (unknown bits are refused, not ignored: 8u was round 2-3's JPGPU_PIPELINE_PROGRESSIVE_DELTAS, removed in round 4 — a caller built
@@ -523,6 +596,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const double t0 = now_ms(), cpu0 = process_cpu_ms();
     const bool download = (flags & JPGPU_PIPELINE_DOWNLOAD) != 0, compact = (flags & JPGPU_PIPELINE_DENSE) == 0;
     const bool device_entropy = (flags & JPGPU_PIPELINE_DEVICE_ENTROPY) != 0;
+    const bool device_progressive = device_entropy && (flags & JPGPU_PIPELINE_PROGRESSIVE_ON_HOST) == 0 && !getenv("JPGPU_PIPE_PROGRESSIVE_ON_HOST");
     p->n = n;
     p->fes.clear();
     p->fes.resize(n);
@@ -533,6 +607,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->sub_of.assign(n, -1);
     p->plans.clear();
     p->plans.resize(n);
+    p->prog_plans.clear();
+    p->prog_plans.resize(n);
     p->slot.assign(n, -1);
     p->n_subs = 0;
     p->downloaded = download;
@@ -599,7 +675,19 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 }
             }
             cand[i] = d;
-            if (device_entropy) {  // eligible for the device entropy decoder?  (the planning pass spends the object)
+            if (device_entropy && p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
+                // a progressive frame: its scans as tracks for the device (huff_prog_core.hpp), if the stream is plainly eligible;
+                // how many of a call's eligible frames really go there is decided below, once all headers are read
+                if (device_progressive && fe.plan_progressive_scans(p->prog_plans[i])) {
+                    for (uint32_t c = 0; c < d.ncomp; c++) memcpy(cand[i].quantization_tables[c], fe.qtable_of_component(c), 128);
+                    p->has_frame[i] = 1;
+                    p->fes[i].reset();
+                } else if (device_progressive) {
+                    p->prog_plans[i].scans.clear();
+                    p->fes[i].reset(new Frontend(data[i], len[i], Frontend::Borrowed{}));
+                    read_info_with_options(p, *p->fes[i]);
+                }
+            } else if (device_entropy) {  // eligible for the device entropy decoder?  (the planning pass spends the object)
                 if (fe.plan_device_scans(p->plans[i])) {
                     for (uint32_t c = 0; c < d.ncomp; c++) memcpy(cand[i].quantization_tables[c], fe.qtable_of_component(c), 128);
                     // The plan holds all the device route needs: the front-end (45 kB of table space) goes back to the allocator of
@@ -624,6 +712,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         }
     });
     if (device_entropy) keep_on_host_what_the_device_would_decode_slower(p, data, len, n);
+    const uint32_t n_prog_dev = device_progressive ? progressive_share_for_the_device(p, data, len, n) : 0u;
     const double t1 = now_ms();
 
     // 2. sub-batches of the images that have a frame (each kept while its geometry sequence repeats)
@@ -634,16 +723,20 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::vector<uint32_t> ok;
     for (uint32_t i = 0; i < n; i++)
         if (p->status[i] == JPGPU_OK && !p->plans[i].empty()) ok.push_back(i);
-    const uint32_t n_dev = (uint32_t)ok.size();
+    const uint32_t n_dev = (uint32_t)ok.size();  // sequential streams for the chunk decoder; then the progressive frames for the track walker
     for (uint32_t i = 0; i < n; i++)
-        if (p->status[i] == JPGPU_OK && p->plans[i].empty()) ok.push_back(i);
+        if (p->status[i] == JPGPU_OK && !p->prog_plans[i].scans.empty()) ok.push_back(i);
+    if ((uint32_t)ok.size() - n_dev != n_prog_dev) return jpgpu::set_err(p->err, JPGPU_ERR_INTERNAL, "pipeline: progressive dispatch count");
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK && p->plans[i].empty() && p->prog_plans[i].scans.empty()) ok.push_back(i);
     if (ok.empty()) {
         p->t.headers_ms = t1 - t0;
         p->t.total_ms = now_ms() - t0;
         return JPGPU_OK;
     }
     std::vector<uint32_t> bounds{0u};  // sub-batch j = ok[bounds[j] .. bounds[j+1])
-    uint32_t n_dev_subs = 0;           // the first sub-batches hold the images whose entropy data goes to the device
+    uint32_t n_dev_subs = 0;           // the first sub-batches hold the images whose entropy data goes to the device ...
+    uint32_t first_prog_sub = 0;       // ... of which those from this one on hold progressive frames (the track walker)
     {
         // one lane per chunk of a scan: 256 images fill the machine — but several sub-batches are in flight at a time (one compute
         // stream each, and a hardware queue each when GPU_MAX_HW_QUEUES allows: jpgpu_process_init), the latency-bound late sync
@@ -658,10 +751,19 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         const uint32_t dev_cap = dev_cap_env > 0 ? (uint32_t)std::min<long>(dev_cap_env, kMaxSubBatches / 2u) : kMaxSubBatches / 2u;
         const uint32_t dev_subs = n_dev ? std::min<uint32_t>(dev_cap, (n_dev + dev_sub_images - 1u) / dev_sub_images) : 0u;
         for (uint32_t j = 1; j <= dev_subs; j++) bounds.push_back((uint32_t)((uint64_t)n_dev * j / dev_subs));
-        n_dev_subs = dev_subs;
-        const uint32_t n_host = (uint32_t)ok.size() - n_dev;
-        const uint32_t host_subs = n_host ? std::min<uint32_t>(kMaxSubBatches - dev_subs, (n_host + kSubBatchImages - 1u) / kSubBatchImages) : 0u;
-        for (uint32_t j = 1; j <= host_subs; j++) bounds.push_back(n_dev + (uint32_t)((uint64_t)n_host * j / host_subs));
+        // Progressive frames for the device: FEW, large sub-batches — a launch lasts as long as one lane's walk of the longest track
+        // whatever the number of frames (every track has a lane of its own while they fit the machine: 512 waves), so frames split
+        // over sub-batches that share a stream would pay that walk once per sub-batch; up to four, for the overlap of one's staging
+        // and upload with another's walk
+        const long prog_sub_env = getenv("JPGPU_PIPE_PROG_SUBS") ? atol(getenv("JPGPU_PIPE_PROG_SUBS")) : 0;  // tuning knob (read per call)
+        const uint32_t prog_subs = n_prog_dev ? std::min<uint32_t>({(uint32_t)(prog_sub_env > 0 ? prog_sub_env : 4), kMaxSubBatches / 2u - std::min(dev_subs, kMaxSubBatches / 2u - 1u),
+                                                                    (n_prog_dev + 255u) / 256u}) : 0u;
+        first_prog_sub = dev_subs;
+        for (uint32_t j = 1; j <= prog_subs; j++) bounds.push_back(n_dev + (uint32_t)((uint64_t)n_prog_dev * j / prog_subs));
+        n_dev_subs = dev_subs + prog_subs;
+        const uint32_t n_devs = n_dev + n_prog_dev, n_host = (uint32_t)ok.size() - n_devs;
+        const uint32_t host_subs = n_host ? std::min<uint32_t>(kMaxSubBatches - n_dev_subs, (n_host + kSubBatchImages - 1u) / kSubBatchImages) : 0u;
+        for (uint32_t j = 1; j <= host_subs; j++) bounds.push_back(n_devs + (uint32_t)((uint64_t)n_host * j / host_subs));
     }
     const uint32_t n_subs = (uint32_t)bounds.size() - 1u;
     p->n_subs = n_subs;
@@ -764,7 +866,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     double t_last_upload = t2;
     const bool trace = getenv("JPGPU_PIPE_TRACE") != nullptr;
     std::mutex trace_m;
-    double busy_sum = 0, busy_max = 0, last_end = 0;
+    double busy_sum = 0, busy_max = 0, last_end = 0, prog_host_ms = 0, prog_dev_ms = 0;
+    uint64_t prog_host_bytes = 0, prog_dev_bytes = 0;
+    uint32_t device_prog_images = 0;
     uint32_t device_rejected = 0, device_images = 0;
     double dev_ms[4] = {0, 0, 0, 0};  // JPGPU_BATCH_KERNEL_TIMES: phases of the device entropy path, summed over the sub-batches
     bool dev_ms_valid = false;
@@ -850,12 +954,24 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         // entropy decoding on the device: enqueue now, finish the sub-batch (collect, stragglers, pixel
                         // kernels, download) when nothing else is waiting — the launches of several sub-batches then
                         // run side by side (one wave per SIMD each: they do not compete)
-                        std::vector<jpgpu::DeviceEntropyImage> list;
-                        for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
                         const double l0 = now_ms();
-                        okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
-                                                                 p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
-                                                                 &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u) == JPGPU_OK;
+                        if ((uint32_t)p->sub_of[i] >= first_prog_sub) {  // progressive frames: one lane per track (huff_prog_core.hpp)
+                            std::vector<jpgpu::DeviceProgressiveImage> list;
+                            for (uint32_t di : dv) {
+                                list.push_back(jpgpu::DeviceProgressiveImage{(uint32_t)p->slot[di], data[di], &p->prog_plans[di]});
+                                prog_dev_bytes += len[di];
+                            }
+                            device_prog_images += (uint32_t)dv.size();
+                            okk = jpgpu::batch_device_progressive_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
+                                                                         p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
+                                                                         &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute]) == JPGPU_OK;
+                        } else {
+                            std::vector<jpgpu::DeviceEntropyImage> list;
+                            for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
+                            okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
+                                                                     p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
+                                                                     &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u) == JPGPU_OK;
+                        }
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         // The pixel kernels follow at once on the same stream: the classes of the decoded coefficients are a
                         // by-product of the write pass and stay on the device (range_stats.hpp), so nothing has to come
@@ -892,6 +1008,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     if (trace) fprintf(stderr, "pipeline trace: sub-batch %u synchronised at +%.2f ms after waiting %.2f ms\n", sj, now_ms() - t2, now_ms() - s0);
                     okk = okk &&
                                jpgpu::batch_device_entropy_collect(sb.batch, st.data(), (uint32_t)st.size()) == JPGPU_OK;
+                    if (okk && sj >= first_prog_sub) {  // (what the dispatcher learns: the walk of this launch)
+                        float kms = 0.f;
+                        if (jpgpu::batch_progressive_kernel_ms(sb.batch, &kms)) prog_dev_ms = std::max(prog_dev_ms, (double)kms);
+                    }
                     std::vector<Redecode> redo;
                     for (size_t k2 = 0; okk && k2 < dv.size(); k2++)
                         if (st[k2]) {
@@ -939,23 +1059,28 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             ln[c] = jpgpu_batch_coef_bytes(sb.batch, bi, c);
         }
         try {
-            const double w0 = trace ? now_ms() : 0.0;
-            if (!p->plans[i].empty()) {  // planned in the headers phase: the entropy-coded bytes go to the device as they are
+            const double w0 = now_ms();
+            if (!p->plans[i].empty() || !p->prog_plans[i].scans.empty()) {  // planned in the headers phase: the entropy-coded bytes go to the device as they are
                 for (uint32_t c = 0; c < nc; c++) jpgpu_batch_set_quantization_table(sb.batch, bi, c, cand[i].quantization_tables[c]);
                 jpeg_bytes += len[i];
                 for (const auto &ps : p->plans[i]) coef_bytes += ps.seg_off.back();  // bytes that cross PCIe for this image
+                for (const auto &ps : p->prog_plans[i].scans) coef_bytes += ps.stuffed_bytes;
                 q.push(i, 2);
                 return;
             }
             Frontend &fe = *p->fes[i];
             StageSink sink(sb.h_coef, off, ln, sb.compact);
             fe.decode_to(sink);
-            if (trace) {
+            {
                 const double w1 = now_ms();
                 std::lock_guard<std::mutex> g(trace_m);
                 busy_sum += w1 - w0;
                 busy_max = std::max(busy_max, w1 - w0);
                 last_end = std::max(last_end, w1);
+                if (p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
+                    prog_host_ms += w1 - w0;
+                    prog_host_bytes += len[i];
+                }
             }
             for (uint32_t c = 0; c < nc; c++)
                 if (!sink.done(c) || !fe.planes_present()[c]) throw DecodeError{JPGPU_ERR_FORMAT, "not all components have data"};
@@ -1022,6 +1147,20 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.pixel_bytes = pixel_bytes;
     p->t.images_device_entropy = device_images;
     p->t.images_device_rejected = device_rejected;
+    p->t.images_device_progressive = device_prog_images;
+    // the dispatcher's rates, smoothed over calls: a host thread's time per byte of progressive file, the device's walk per byte of the
+    // AVERAGE file of the launch (frames of a call are assumed alike: the walk lasts as long as its longest track)
+    if (prog_host_bytes) {
+        const double r = prog_host_ms * 1e6 / (double)prog_host_bytes;
+        p->prog_host_ns_per_byte = p->prog_host_ns_per_byte > 0 ? 0.5 * (p->prog_host_ns_per_byte + r) : r;
+    }
+    if (device_prog_images && prog_dev_ms > 0) {
+        const double r = prog_dev_ms * 1e6 / ((double)prog_dev_bytes / device_prog_images);
+        p->prog_dev_ns_per_byte = p->prog_dev_ns_per_byte > 0 ? 0.5 * (p->prog_dev_ns_per_byte + r) : r;
+    }
+    if (trace && (prog_host_bytes || device_prog_images))
+        fprintf(stderr, "pipeline trace: progressive frames: %u on the device (walk %.2f ms), host %.1f ns per byte and thread, device %.1f ns per byte of one file\n",
+                device_prog_images, prog_dev_ms, p->prog_host_ns_per_byte, p->prog_dev_ns_per_byte);
     p->t.cpu_ms = process_cpu_ms() - cpu0;
     (void)t_last_upload;
     return JPGPU_OK;
@@ -1402,6 +1541,7 @@ static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const siz
         p->t.pixel_bytes += c->t.pixel_bytes;
         p->t.images_device_entropy += c->t.images_device_entropy;
         p->t.images_device_rejected += c->t.images_device_rejected;
+        p->t.images_device_progressive += c->t.images_device_progressive;
         p->t.images_host_light += c->t.images_host_light;
         p->t.input_pinned |= c->t.input_pinned;
     }

@@ -1,0 +1,106 @@
+// emu_prog.cpp — TEST-ONLY CPU run of the device decoder for progressive frames (csrc/huff_prog_core.hpp) on the plan the host
+// front-end makes (Frontend::plan_progressive_scans): the tracks of a frame one lane at a time, in the order given (any order must
+// give the same planes: tracks share no coefficient).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include "hip_shim.hpp"
+#include <vector>
+#include "../../jpeg-decoder_amd/csrc/host/frontend.hpp"
+#include "../../jpeg-decoder_amd/csrc/huff_core.hpp"
+#include "../../jpeg-decoder_amd/csrc/huff_prog_core.hpp"
+
+using namespace jpgpu;
+using jpgpu::host::Frontend;
+using jpgpu::host::ProgPlan;
+using jpgpu::host::ProgPlannedScan;
+
+extern "C" {
+
+// -> 0 and the frame's descriptor, scans and tracks if the planner takes the stream; 1: it stays with the host
+int emu_prog_plan(const uint8_t *data, size_t len, jpgpu_image_desc *desc, uint32_t *n_scans, uint32_t *n_tracks) {
+    try {
+        Frontend fe(data, len, Frontend::Borrowed{});
+        fe.read_info();
+        ProgPlan plan;
+        if (!fe.plan_progressive_scans(plan)) return 1;
+        memset(desc, 0, sizeof(*desc));
+        desc->ncomp = fe.ncomp();
+        for (uint32_t c = 0; c < desc->ncomp; c++) {
+            desc->components[c] = fe.components()[c];
+            memcpy(desc->quantization_tables[c], fe.qtable_of_component(c), 128);
+        }
+        desc->out_w = fe.output_width();
+        desc->out_h = fe.output_height();
+        desc->color_transform = fe.color_transform();
+        *n_scans = (uint32_t)plan.scans.size();
+        *n_tracks = plan.n_tracks;
+        return 0;
+    } catch (...) {
+        return 1;
+    }
+}
+
+// Decode into planes[c] (zero-filled by the caller).  order: 0 = tracks in plan order, 1 = reversed, 2 = interleaved scan by scan
+// across tracks (round robin: what concurrent lanes may do to one another's dwords).  Returns the status word (0: decoded).
+int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], int order) {
+    Frontend fe(data, len, Frontend::Borrowed{});
+    fe.read_info();
+    ProgPlan plan;
+    if (!fe.plan_progressive_scans(plan)) return -1;
+    const uint32_t nc = fe.ncomp();
+    std::vector<std::vector<uint64_t>> masks(nc);
+    for (uint32_t c = 0; c < nc; c++) masks[c].assign((size_t)fe.components()[c].block_width * fe.components()[c].block_height * 2u, 0);
+    // staging: every scan unstuffed into its own slot (huff_stage_segment), as batch.cpp does
+    std::vector<std::vector<uint8_t>> slots(plan.scans.size());
+    std::vector<ProgScan> scans(plan.scans.size());
+    uint32_t status = 0;
+    for (size_t i = 0; i < plan.scans.size(); i++) {
+        const ProgPlannedScan &ps = plan.scans[i];
+        slots[i].assign(huff_slot_bytes(ps.stuffed_bytes) + 16, 0xEE);
+        bool clean = true;
+        const uint32_t n = huff_stage_segment(slots[i].data(), data + ps.data_off, ps.stuffed_bytes, &clean);
+        if (!clean) status |= PROG_ST_STAGING | PROG_ST_HOST;
+        ProgScan &s = scans[i];
+        memset(&s, 0, sizeof(s));
+        s.data = slots[i].data();
+        s.n_bytes = n;
+        s.ss = ps.ss, s.se = ps.se, s.ah = ps.ah, s.al = ps.al;
+        s.ncomp = ps.ncomp, s.cols = ps.cols, s.rows = ps.rows;
+        for (uint32_t c = 0; c < ps.ncomp; c++) {
+            s.comp[c].coefs = planes[ps.comp[c].frame_index];
+            s.comp[c].masks = masks[ps.comp[c].frame_index].data();
+            s.comp[c].block_w = ps.comp[c].block_w;
+            s.comp[c].h = ps.comp[c].h;
+            s.comp[c].v = ps.comp[c].v;
+            s.comp[c].table = ps.comp[c].table;
+        }
+        for (int t = 0; t < 4; t++) s.table[t] = ps.table[t].get();
+    }
+    if (status) return (int)status;
+    // tracks: the scans of each, in stream order, contiguous (the product sorts them the same way)
+    std::vector<std::vector<ProgScan>> per_track(plan.n_tracks);
+    for (size_t i = 0; i < plan.scans.size(); i++) per_track[plan.scans[i].track].push_back(scans[i]);
+    ProgLds *L = new ProgLds;
+    memset(L, 0xAB, sizeof(*L));
+    for (uint32_t l = 0; l < 64; l++) huff_fill_unzigzag(L->unzig, l);
+    if (order == 2) {
+        size_t longest = 0;
+        for (auto &t : per_track) longest = std::max(longest, t.size());
+        for (size_t step = 0; step < longest; step++)
+            for (uint32_t t = 0; t < plan.n_tracks; t++)
+                if (step < per_track[t].size() && !(status & 1u)) {
+                    ProgTrack tr{&per_track[t][step], 1u, &status};
+                    prog_run_track(*L, (t * 7u + (uint32_t)step) % 64u, tr);
+                }
+    } else {
+        for (uint32_t k = 0; k < plan.n_tracks; k++) {
+            const uint32_t t = order == 1 ? plan.n_tracks - 1u - k : k;
+            ProgTrack tr{per_track[t].data(), (uint32_t)per_track[t].size(), &status};
+            prog_run_track(*L, (t * 13u) % 64u, tr);
+        }
+    }
+    delete L;
+    return (int)status;
+}
+}

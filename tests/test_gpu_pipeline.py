@@ -589,6 +589,93 @@ def test_pipeline_download_to_pinned_host_memory_on_its_own_streams():
     p.close()
 
 
+def _pil_progressive(w, h, sub, quality=85, seed=1, gray=False):
+    import io
+    from PIL import Image
+    import synth
+    rgb = synth.synthetic_rgb(w, h, seed=seed)
+    buf = io.BytesIO()
+    Image.fromarray(rgb[..., 0] if gray else rgb).save(buf, format="JPEG", quality=quality, subsampling=sub, progressive=True)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("percent", ["100", "50", None], ids=["all-on-the-device", "half", "dispatcher"])
+def test_pipeline_progressive_frames_on_the_device(percent, monkeypatch):
+    """SURVEY 8f n3 / BASELINE configs[3]: the scans of a progressive frame decoded ON THE DEVICE — one lane per track of dependent scans,
+    coefficients accumulated in the arena (csrc/huff_prog_core.hpp) — for the share of a call's frames the dispatcher gives the device
+    (JPGPU_PIPE_PROG_DEVICE_PERCENT pins it).  Every progressive file of the reference's corpora plus encoder-written ones of several
+    sizes and samplings, mixed with sequential and broken files: same pixels / same errors as the oracle."""
+    pytest.importorskip("PIL")
+    if percent is None:
+        monkeypatch.delenv("JPGPU_PIPE_PROG_DEVICE_PERCENT", raising=False)
+    else:
+        monkeypatch.setenv("JPGPU_PIPE_PROG_DEVICE_PERCENT", percent)
+    names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
+    files = [open(n, "rb").read() for n in names]
+    made = [_pil_progressive(*a) for a in ((64, 48, "4:2:0"), (250, 130, "4:2:0", 35), (129, 257, "4:2:2"), (200, 120, "4:4:4", 98), (33, 17, "4:2:0"),
+                                           (1, 1, "4:2:0"), (640, 480, "4:2:0"), (512, 16, "4:4:4"))] + [_pil_progressive(300, 200, "4:4:4", gray=True)]
+    names += [f"made-{k}" for k in range(len(made))]
+    files += made
+    tower = open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read()
+    names += ["tower_progressive"] * 40
+    files += [tower] * 40
+    p = J.Pipeline(threads=8)
+    for rep in range(2):  # (the second call runs on what the dispatcher learnt in the first)
+        out = p.decode(files, device_entropy=True)
+        _check(names, files, out)
+        t = p.timings()
+        if percent == "100":
+            assert t["images_device_progressive"] >= 40 + len(made) + 3  # tower x 40, the made ones, jpg-progressive / progressive3 / tower_progressive
+        elif percent == "50":
+            assert 20 <= t["images_device_progressive"] < 40 + len(made) + 8
+        assert t["images_device_entropy"] >= t["images_device_progressive"]
+    on_host = p.decode(files, device_entropy=True, progressive_on_host=True)
+    assert p.timings()["images_device_progressive"] == 0
+    for a, b_ in zip(out, on_host):
+        assert (isinstance(a, Exception) and isinstance(b_, Exception) and a.kind == b_.kind) or np.array_equal(a, b_)
+    p.close()
+
+
+def test_pipeline_progressive_device_decoder_hands_damaged_frames_back(monkeypatch):
+    """Damaged progressive streams through the device route: whatever the planner lets through and the walk does not flag must be the
+    oracle's pixels; everything else is decoded by the host (same pixels / same kind of error as the oracle)."""
+    pytest.importorskip("PIL")
+    monkeypatch.setenv("JPGPU_PIPE_PROG_DEVICE_PERCENT", "100")
+    rng = np.random.default_rng(5150)
+    bases = [open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read(), _pil_progressive(120, 72, "4:2:0", seed=3),
+             _pil_progressive(64, 64, "4:4:4", 60, seed=12), open(os.path.join(R.GOLDEN, "reftest", "progressive3.jpg"), "rb").read()]
+    files = []
+    for t in range(160):
+        d = bytearray(bases[t % len(bases)])
+        lo = max(2, len(d) // 5)
+        for _ in range(int(rng.integers(0, 3))):
+            pos = int(rng.integers(lo, len(d) - 2))
+            mode = int(rng.integers(0, 4))
+            if mode == 0:
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                del d[pos]
+            elif mode == 2:
+                d[pos] = 0xFF
+            else:
+                del d[pos:pos + int(rng.integers(1, 40))]
+        files.append(bytes(d))
+    p = J.Pipeline(threads=8)
+    out = p.decode(files, device_entropy=True)
+    t = p.timings()
+    assert t["images_device_progressive"] > 20
+    bad = 0
+    for i, (f, got) in enumerate(zip(files, out)):
+        try:
+            want = O.decode(f).pixels
+        except O.OracleError as e:
+            bad += not (isinstance(got, J.Error) and got.kind == e.kind)
+            continue
+        bad += isinstance(got, Exception) or not np.array_equal(got, want)
+    assert bad == 0
+    p.close()
+
+
 def test_pipeline_multi_refuses_nonsense():
     with pytest.raises(J.Error):
         J.Pipeline(devices=[], threads=4)

@@ -1,0 +1,174 @@
+"""Device decoder for PROGRESSIVE frames (csrc/huff_prog_core.hpp: one lane per track of dependent scans, coefficients accumulated in
+place; SURVEY 8f n3 / BASELINE configs[3]) run on the CPU by tests/emu against the host front-end, which restates
+src/decoder.rs:1086-1298: the same coefficient planes for every stream the planner (Frontend::plan_progressive_scans) declares eligible,
+whatever the order the tracks are walked in; damaged streams stay with the host (not eligible), raise the status word, or decode to
+exactly what the host decodes."""
+import ctypes as C
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu  # noqa: E402
+import jpeg_decoder_amd as J
+import refimages as R
+import synth
+
+N = J._native
+
+
+def _host(data):
+    return J.Decoder(data, device=-1).decode_coefficients()
+
+
+def _plan(data):
+    L = emu.lib()
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+    desc = N.ImageDesc()
+    ns, nt = C.c_uint32(0), C.c_uint32(0)
+    if L.emu_prog_plan(buf, len(data), C.byref(desc), C.byref(ns), C.byref(nt)) != 0:
+        return None
+    return desc, ns.value, nt.value
+
+
+def _device(data, order=0):
+    """-> (status, desc, planes, scans, tracks) or None if the planner keeps the stream on the host."""
+    pl = _plan(data)
+    if pl is None:
+        return None
+    desc, ns, nt = pl
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data)
+    planes = [np.zeros(desc.components[c].block_width * desc.components[c].block_height * 64, np.int16) for c in range(desc.ncomp)]
+    ptrs = (C.c_void_p * 4)(*([p.ctypes.data for p in planes] + [None] * (4 - len(planes))))
+    st = emu.lib().emu_prog_decode(buf, len(data), ptrs, order)
+    return st, desc, planes, ns, nt
+
+
+def _pil(w, h, subsampling, gray=False, quality=85, seed=1, **kw):
+    from PIL import Image
+    rgb = synth.synthetic_rgb(w, h, seed=seed)
+    im = Image.fromarray(rgb[..., 0] if gray else rgb)
+    buf = io.BytesIO()
+    im.save(buf, format="JPEG", quality=quality, subsampling=subsampling, progressive=True, **kw)
+    return buf.getvalue()
+
+
+def _same_as_host(data, order=0):
+    got = _device(data, order)
+    assert got is not None, "the planner refused a plain progressive stream"
+    st, desc, planes, ns, nt = got
+    assert st == 0, hex(st)
+    hdesc, hcoefs = _host(data)
+    assert desc.ncomp == hdesc.ncomp
+    for c in range(desc.ncomp):
+        assert np.array_equal(planes[c], np.asarray(hcoefs[c], np.int16)), c
+        assert list(desc.quantization_tables[c]) == list(hdesc.quantization_tables[c])
+    return ns, nt
+
+
+FIXTURES = {  # file: (scans, tracks) — every progressive file of the reference's corpora that decodes (the others stay with the host)
+    "benches/tower_progressive.jpg": (10, 4), "reftest/mozilla/jpg-progressive.jpg": (10, 4), "reftest/progressive3.jpg": (11, 8),
+    "reftest/progressive-missing-ac.jpg": (1, 1), "reftest/progressive-missing-dc.jpg": (1, 1),
+}
+
+
+@pytest.mark.parametrize("rel", sorted(FIXTURES))
+@pytest.mark.parametrize("order", [0, 1, 2], ids=["tracks-in-order", "tracks-reversed", "scan-by-scan-round-robin"])
+def test_reference_fixtures(rel, order):
+    data = open(os.path.join(R.GOLDEN, rel), "rb").read()
+    assert _same_as_host(data, order) == FIXTURES[rel]
+
+
+def test_streams_the_host_keeps():
+    for rel in ("reftest/partial_progressive.jpg",    # ends inside a scan: the reference's partial render is the host's business
+                "benches/tower.jpg",                  # not progressive
+                "reftest/non-interleaved-mcu.jpg"):
+        assert _plan(open(os.path.join(R.GOLDEN, rel), "rb").read()) is None, rel
+
+
+@pytest.mark.parametrize("case", [(64, 48, "4:2:0"), (250, 130, "4:2:0"), (129, 257, "4:2:2"), (200, 120, "4:4:4"), (33, 17, "4:2:0"), (300, 200, None),
+                                  (8, 8, "4:4:4"), (1, 1, "4:2:0"), (17, 9, "4:2:2"), (512, 16, "4:2:0"), (16, 512, "4:4:4"), (640, 480, "4:2:0")],
+                         ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}")
+@pytest.mark.parametrize("quality", [35, 85, 98])
+def test_encoder_written_progressive_streams(case, quality):
+    """libjpeg-turbo's default progressive script (DC first, AC bands with successive approximation, optimised tables per scan) at
+    several sizes and samplings: ragged edges, one-MCU images, non-interleaved AC scans of subsampled components."""
+    pytest.importorskip("PIL")
+    w, h, sub = case
+    data = _pil(w, h, sub or "4:4:4", gray=sub is None, quality=quality, seed=w + h)
+    ns, nt = _same_as_host(data, order=(w + quality) % 3)
+    assert ns >= 3 and nt >= 2 - (sub is None)
+
+
+def test_tracks_are_the_connected_bands():
+    """Scans that share a coefficient of a component are one track; the DC scans of all components another; nothing else joins."""
+    pytest.importorskip("PIL")
+    data = _pil(96, 64, "4:2:0")
+    _desc, ns, nt = _plan(data)
+    assert (ns, nt) == (10, 4)  # DC first + refine | Y: 1-5, 6-63, two refinements | Cb: 1-63 + refinement | Cr likewise
+    _desc, ns, nt = _plan(_pil(96, 64, "4:4:4", gray=True))
+    assert nt == 2  # DC | AC
+
+
+def _damage(rng, base):
+    d = bytearray(base)
+    lo = max(2, len(d) // 5)
+    for _ in range(int(rng.integers(1, 4))):
+        pos = int(rng.integers(lo, len(d) - 2))
+        mode = int(rng.integers(0, 5))
+        if mode == 0:
+            d[pos] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 1:
+            del d[pos]
+        elif mode == 2:
+            d[pos] = 0xFF
+        elif mode == 3:
+            del d[pos:pos + int(rng.integers(1, 40))]
+        else:
+            d[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8))
+    return bytes(d)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_damaged_streams_never_differ_from_the_host(seed):
+    """Bit flips, deletions, stray 0xFF bytes and insertions anywhere behind the first fifth of a progressive file (headers of later
+    scans and their Huffman tables included): the planner refuses the stream, or the walk raises the status word (the host then decodes
+    the image), or the planes are the host's — never different planes with a clean status."""
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(7100 + seed)
+    bases = [open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read(), _pil(120, 72, "4:2:0", seed=seed), _pil(64, 64, "4:4:4", quality=60, seed=seed + 9)]
+    kept = flagged = same = 0
+    for t in range(60):
+        data = _damage(rng, bases[t % len(bases)])
+        got = _device(data, order=t % 3)
+        if got is None:
+            kept += 1
+            continue
+        st, desc, planes, _ns, _nt = got
+        if st != 0:
+            assert st & 1
+            flagged += 1
+            continue
+        try:
+            _hdesc, hcoefs = _host(data)
+        except J.Error:
+            # the host's marker loop or entropy decoder raises where the device decoded something: only acceptable if the device's
+            # result is never used — the pipeline decodes such a stream on the host when the PLANNER refuses it; a clean device
+            # status with a host error would be a wrong answer
+            raise AssertionError("device decoded a stream the host refuses")
+        for c in range(desc.ncomp):
+            assert np.array_equal(planes[c], np.asarray(hcoefs[c], np.int16)), (t, c)
+        same += 1
+    assert kept + flagged + same == 60 and same > 0
+
+
+def test_prog_table_is_the_reference_procedure():
+    """ProgHuffTable = the reference's 8-bit lookup + maxcode walk (src/huffman.rs:31-58): every code of an optimised table decodes
+    to its symbol through the emulated lane (covered by the stream tests) — here: the struct's size, which the LDS layout is built on."""
+    assert N.lib() is not None
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jpeg-decoder_amd", "csrc", "huff_prog_job.hpp")).read()
+    assert re.search(r"sizeof\(ProgHuffTable\) == 912", text)
