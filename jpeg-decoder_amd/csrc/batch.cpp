@@ -670,6 +670,16 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
 }
 
 // ---- device entropy decoding -----------------------------------------------------------------------------------
+// the status words of a launch into b->h_entropy_out (pinned), behind the kernels on `s`: by a kernel, not by the copy engine (huff.hip)
+static hipError_t batch_status_to_host(jpgpu_batch *b, const uint32_t *d_status, uint32_t n, hipStream_t s) {
+    void *mapped = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&mapped, b->h_entropy_out, 0);
+    if (e != hipSuccess) {  // (no mapping: the copy engine after all)
+        (void)hipGetLastError();
+        return hipMemcpyAsync(b->h_entropy_out, d_status, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    }
+    return launch_copy_words_to_host(static_cast<uint32_t *>(mapped), d_status, n, s);
+}
 static uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
     const char *e = getenv(name);
     if (!e || !*e) return dflt;
@@ -1098,7 +1108,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     }
     clk.mark("kernels");
     // the status words into pinned memory (the only thing the host needs to look at: which images it has to decode itself)
-    B_HIP(hipMemcpyAsync(b->h_entropy_out, d + off_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    B_HIP(batch_status_to_host(b, reinterpret_cast<const uint32_t *>(d + off_status), n, s));
     clk.mark("status copy");
     return JPGPU_OK;
 }
@@ -1310,7 +1320,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     B_HIP(hipEventRecord(b->ev_phase[3], s));
     b->phase_events_valid = true;
     b->progressive_launch = true;
-    B_HIP(hipMemcpyAsync(b->h_entropy_out, d + off_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    B_HIP(batch_status_to_host(b, reinterpret_cast<const uint32_t *>(d + off_status), n, s));
     return JPGPU_OK;
 }
 

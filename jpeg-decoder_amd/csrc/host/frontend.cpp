@@ -210,7 +210,8 @@ inline bool same_definition(const HuffTable &t, const uint8_t bits[16], const ui
 // reader-writer lock around the registry made the header phase of 4,096 files 18 ms instead of 1.8: 32 threads x 16 k lock
 // operations on one cache line).
 inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
-    constexpr int kSlots = 8, kShared = 32;
+    constexpr int kSlots = 32, kShared = 64;  // (round 5: 8 / 32 — a progressive file of libjpeg's default script defines twelve tables: with eight slots per
+    // thread every file of a batch went through the shared registry's mutex a dozen times, 4,096 files on 32 threads)
     thread_local std::shared_ptr<const HuffTable> mine[kSlots];
     thread_local int next = 0;
     if (n > 0 && n <= 256)

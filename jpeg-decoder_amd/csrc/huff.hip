@@ -723,6 +723,19 @@ __global__ __launch_bounds__(64) void huff_prog_kernel(const ProgTrack *__restri
     prog_run_track(*(JP_LDS ProgLds *)&L, threadIdx.x, tracks[t]);
 }
 
+// The status words of a launch -> pinned host memory, by a kernel (one workgroup) instead of a device-to-host copy: a copy command queues up
+// behind whatever the copy engine of that direction has in flight — with JPGPU_PIPELINE_DOWNLOAD that is hundreds of megabytes of
+// pixels per sub-batch, and the host waited 300 ms for 512 bytes of status words before it could finish a sub-batch (round 5).
+__global__ __launch_bounds__(256) void copy_words_kernel(uint32_t *__restrict__ dst_host, const uint32_t *__restrict__ src, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) dst_host[i] = src[i];
+    __threadfence_system();
+}
+hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *d_src, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    copy_words_kernel<<<dim3(1), dim3(256), 0, stream>>>(dst_host_mapped, d_src, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream) {
     if (n_tracks == 0) return hipSuccess;
     huff_prog_kernel<<<dim3((n_tracks + 63u) / 64u), dim3(64), 0, stream>>>(d_tracks, n_tracks);

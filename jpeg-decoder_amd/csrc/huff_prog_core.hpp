@@ -13,71 +13,121 @@
 
 namespace jpgpu {
 
+constexpr uint32_t PROG_RING_DWORDS = 32u;  // a lane's window on its scan: two halves of 16 dwords
 struct ProgLds {
     uint32_t tab[64][PROG_LANE_DWORDS];  // per lane: the table of its current scan (AC: a whole ProgHuffTable; DC: four byte lookups)
+    uint32_t ring[64][PROG_RING_DWORDS + 1u];  // per lane: the next 512-1,024 bits of its scan (skewed by one dword, like `tab`)
     uint8_t unzig[64];
 };
 
 // ---- memory operations other lanes / later scans of the same lane must see: past the L1 -------------------------------------------
+// (through address-space-1 pointers: a generic pointer makes them flat_* operations, which count as LDS operations as well — every
+// wait for a table or ring read would then wait for every store and atomic in flight)
 __device__ __forceinline__ void prog_or32(uint32_t *p, uint32_t v) {
 #ifdef JPGPU_HOST_EMULATION
     *p |= v;
 #else
-    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (result unused: the no-return form)
+    (void)__hip_atomic_fetch_or((JP_GLOBAL uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (result unused: the no-return form)
 #endif
 }
 __device__ __forceinline__ void prog_add32(uint32_t *p, uint32_t v) {
 #ifdef JPGPU_HOST_EMULATION
     *p += v;
 #else
-    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add((JP_GLOBAL uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
 __device__ __forceinline__ void prog_or64(uint64_t *p, uint64_t v) {
 #ifdef JPGPU_HOST_EMULATION
     *p |= v;
 #else
-    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_or((JP_GLOBAL uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
 __device__ __forceinline__ uint64_t prog_load64(const uint64_t *p) {
 #ifdef JPGPU_HOST_EMULATION
     return *p;
 #else
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const JP_GLOBAL uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
 __device__ __forceinline__ void prog_store64(uint64_t *p, uint64_t v) {
 #ifdef JPGPU_HOST_EMULATION
     *p = v;
 #else
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((JP_GLOBAL uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+__device__ __forceinline__ void prog_store16(int16_t *p, int16_t v) { *(JP_GLOBAL int16_t *)p = v; }
 __device__ __forceinline__ void prog_flag(uint32_t *status, uint32_t bits) { prog_or32(status, bits | PROG_ST_HOST); }
 
-// ---- bit reader: one aligned dword per refill, requested a refill ahead; zeros behind the scan's data ------------------------------
+// (tests/emu only: how many steps of each kind a track takes — the numbers behind DESIGN.md's ns-per-step figures)
+#ifdef JPGPU_PROG_COUNTERS
+struct ProgCounters {
+    unsigned long long symbols, corrections, blocks, refills;
+};
+extern ProgCounters g_prog_counters;
+#define PROG_COUNT(what, n) (g_prog_counters.what += (n))
+#else
+#define PROG_COUNT(what, n) ((void)0)
+#endif
+
+typedef const JP_GLOBAL ProgScan &ProgScanRef;  // (the descriptors are read through address space 1 as well)
+typedef const JP_GLOBAL ProgScanComp &ProgScanCompRef;
+
+// ---- bit reader: zeros behind the scan's data ------------------------------------------------------------------------------------------
+// A lane's refill takes ONE dword from the lane's ring in LDS; the ring is fed from global memory sixteen dwords at a time, requested
+// half a ring ahead and written into the half the reader has just left.  Why not straight from global memory, a dword per refill
+// requested one refill ahead (the first version, and what the chunk decoder of sequential scans does): on gfx9 a wait for a load is a
+// wait for EVERY memory operation issued before it — and this loop is full of fire-and-forget stores and atomics that take a
+// microsecond to retire; a refill every 32 bits paid that latency every few symbols (tower_progressive.jpg: 65 ms for the longest
+// track).  LDS reads have a counter of their own; the global loads are waited for once per 512 bits.
 struct ProgBits {
     uint64_t bits;  // unread bits, left-aligned
     uint32_t nbits;
-    const uint32_t *next, *end;  // the dword `ahead` was read from + 1; first dword behind the data
-    uint32_t ahead;
+    uint32_t r;              // dwords taken from the ring so far
+    JP_LDS uint32_t *ring;   // the lane's PROG_RING_DWORDS dwords
+    const JP_GLOBAL v4u *src;  // the scan's data, 16 bytes at a time
+    uint32_t n16;            // pieces of 16 bytes that hold data (what follows: zeros)
+    v4u pre[4];              // the sixteen dwords that go into the ring next (pieces r / 4 + 4 .. + 7 at the time they are stored)
 };
-__device__ __forceinline__ void prog_bits_open(ProgBits &b, const ProgScan &s) {
+__device__ __forceinline__ v4u prog_piece(const ProgBits &b, uint32_t i) { return i < b.n16 ? b.src[i] : v4u{0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ void prog_ring_put(ProgBits &b, uint32_t half) {  // `pre` -> dwords [16 half, 16 half + 16) of the ring
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+        JP_LDS uint32_t *d = b.ring + 16u * half + 4u * j;
+        d[0] = b.pre[j].x, d[1] = b.pre[j].y, d[2] = b.pre[j].z, d[3] = b.pre[j].w;
+    }
+}
+__device__ __forceinline__ void prog_bits_open(ProgBits &b, const uint8_t *data, uint32_t n_bytes, JP_LDS uint32_t *ring) {
     b.bits = 0;
     b.nbits = 0;
-    b.next = reinterpret_cast<const uint32_t *>(s.data);
-    b.end = b.next + (s.n_bytes + 3u) / 4u;  // (the staging pass zero-fills the slot behind the data: the last dword's tail is zeros)
-    b.ahead = b.next < b.end ? *b.next : 0u;
-    b.next++;
+    b.r = 0;
+    b.ring = ring;
+    b.src = (const JP_GLOBAL v4u *)data;  // (16-byte aligned slots, zero-filled behind the data: huff_stage_segment)
+    b.n16 = (n_bytes + 15u) / 16u;
+#pragma unroll
+    for (uint32_t h = 0; h < 2u; h++) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, 4u * h + j);
+        prog_ring_put(b, h);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, 8u + j);
 }
 // afterwards more than 32 bits are available (a step reads at most 16 + 15)
 __device__ __forceinline__ void prog_refill(ProgBits &b) {
     if (b.nbits <= 32u) {
-        b.bits |= (uint64_t)__builtin_bswap32(b.ahead) << (32u - b.nbits);
+        PROG_COUNT(refills, 1);
+        b.bits |= (uint64_t)__builtin_bswap32(b.ring[b.r & (PROG_RING_DWORDS - 1u)]) << (32u - b.nbits);
         b.nbits += 32u;
-        b.ahead = b.next < b.end ? *b.next : 0u;
-        b.next++;
+        b.r++;
+        if ((b.r & 15u) == 0u) {  // a half of the ring has been read: what was requested when the other half was begun goes there ...
+            prog_ring_put(b, ((b.r >> 4) - 1u) & 1u);
+            const uint32_t p0 = (b.r >> 2) + 8u;  // ... and the half after the next is requested
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, p0 + j);
+        }
     }
 }
 __device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? (uint32_t)(b.bits >> (64u - n)) : 0u; }
@@ -98,14 +148,17 @@ __device__ __forceinline__ int32_t prog_extend(uint32_t v, uint32_t n) {  // src
 // ---- a lane's table region --------------------------------------------------------------------------------------------------------
 // AC scans (and single-table use in general): the ProgHuffTable as it is
 __device__ __forceinline__ void prog_load_table(JP_LDS uint32_t *T, const ProgHuffTable *t) {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(t);
-    for (uint32_t i = 0; i < PROG_TABLE_DWORDS; i++) T[i] = src[i];
+    const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)t;  // (912 bytes: 57 pieces of 16)
+    for (uint32_t i = 0; i < PROG_TABLE_DWORDS / 4u; i++) {
+        const v4u w = src[i];
+        T[4u * i] = w.x, T[4u * i + 1u] = w.y, T[4u * i + 2u] = w.z, T[4u * i + 3u] = w.w;
+    }
 }
 // DC first scans: up to four tables, each as 256 bytes: category | code length << 4 (0: the walk, from the table in global memory —
 // codes of nine bits and more are rare in tables of twelve symbols)
-__device__ __forceinline__ void prog_load_dc_tables(JP_LDS uint32_t *T, const ProgScan &s) {
+__device__ __forceinline__ void prog_load_dc_tables(JP_LDS uint32_t *T, ProgScanRef s) {
     for (uint32_t t = 0; t < 4u; t++) {
-        const ProgHuffTable *src = s.table[t];
+        const JP_GLOBAL ProgHuffTable *src = (const JP_GLOBAL ProgHuffTable *)s.table[t];
         for (uint32_t i = 0; i < 64u; i++) {
             uint32_t w = 0;
             if (src)
@@ -139,6 +192,7 @@ __device__ __forceinline__ uint32_t prog_walk(ProgBits &b, TablePtr t, bool &bad
 }
 __device__ __forceinline__ uint32_t prog_decode_ac(ProgBits &b, const JP_LDS uint32_t *T, bool &bad) {
     const JP_LDS ProgHuffTable *t = reinterpret_cast<const JP_LDS ProgHuffTable *>(T);
+    PROG_COUNT(symbols, 1);
     const uint32_t e = t->lut[prog_peek(b, 8)];
     if (e >> 8) {
         prog_consume(b, e >> 8);
@@ -146,39 +200,41 @@ __device__ __forceinline__ uint32_t prog_decode_ac(ProgBits &b, const JP_LDS uin
     }
     return prog_walk(b, t, bad);
 }
-__device__ __forceinline__ uint32_t prog_decode_dc(ProgBits &b, const JP_LDS uint32_t *T, uint32_t table, const ProgScan &s, bool &bad) {
+__device__ __forceinline__ uint32_t prog_decode_dc(ProgBits &b, const JP_LDS uint32_t *T, uint32_t table, ProgScanRef s, bool &bad) {
     const uint32_t e = reinterpret_cast<const JP_LDS uint8_t *>(T)[256u * table + prog_peek(b, 8)];
     if (e >> 4) {
         prog_consume(b, e >> 4);
         return e & 15u;
     }
-    return prog_walk(b, s.table[table], bad);
+    return prog_walk(b, (const JP_GLOBAL ProgHuffTable *)s.table[table], bad);
 }
 
 // where block (mx, my) x (hp, vp) of scan component c lies
-__device__ __forceinline__ size_t prog_block_index(const ProgScanComp &c, uint32_t mx, uint32_t my, uint32_t hp, uint32_t vp) {
+__device__ __forceinline__ size_t prog_block_index(ProgScanCompRef c, uint32_t mx, uint32_t my, uint32_t hp, uint32_t vp) {
     return (size_t)(my * c.v + vp) * c.block_w + (mx * c.h + hp);
 }
 
 // ---- DC scans (ss == se == 0; one to four components, src/decoder.rs:1100-1126 and :1181-1190) ------------------------------------
 // Returns false if the scan raised the status word.
-__device__ inline bool prog_scan_dc(const ProgScan &s, JP_LDS uint32_t *T, uint32_t *status) {
+__device__ inline bool prog_scan_dc(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, uint32_t *status) {
     ProgBits b;
-    prog_bits_open(b, s);
+    prog_bits_open(b, s.data, s.n_bytes, ring);
     const bool first = s.ah == 0;
+    const uint32_t al = s.al, rows = s.rows, cols = s.cols, ncomp = s.ncomp;
     if (first) prog_load_dc_tables(T, s);
     uint64_t pred = 0;  // four 16-bit predictors (wrapping_add on i16 in the reference)
     bool bad = false;
-    for (uint32_t my = 0; my < s.rows; my++)
-        for (uint32_t mx = 0; mx < s.cols; mx++)
-            for (uint32_t c = 0; c < s.ncomp; c++) {
-                const ProgScanComp &sc = s.comp[c];
-                for (uint32_t vp = 0; vp < sc.v; vp++)
-                    for (uint32_t hp = 0; hp < sc.h; hp++) {
+    for (uint32_t my = 0; my < rows; my++)
+        for (uint32_t mx = 0; mx < cols; mx++)
+            for (uint32_t c = 0; c < ncomp; c++) {
+                ProgScanCompRef sc = s.comp[c];
+                const uint32_t ch = sc.h, cv = sc.v, ctable = sc.table;
+                for (uint32_t vp = 0; vp < cv; vp++)
+                    for (uint32_t hp = 0; hp < ch; hp++) {
                         int16_t *co = sc.coefs + prog_block_index(sc, mx, my, hp, vp) * 64u;
                         prog_refill(b);
                         if (first) {
-                            const uint32_t cat = prog_decode_dc(b, T, sc.table, s, bad);
+                            const uint32_t cat = prog_decode_dc(b, T, ctable, s, bad);
                             if (bad || cat > 11u) {  // "invalid DC difference magnitude category"
                                 prog_flag(status, bad ? PROG_ST_BAD_CODE : PROG_ST_BAD_DC);
                                 return false;
@@ -190,9 +246,9 @@ __device__ inline bool prog_scan_dc(const ProgScan &s, JP_LDS uint32_t *T, uint3
                             }
                             const uint32_t p = (uint32_t)((pred >> (16u * c)) + diff) & 0xffffu;
                             pred = (pred & ~(0xffffull << (16u * c))) | ((uint64_t)p << (16u * c));
-                            co[0] = (int16_t)(uint16_t)(p << s.al);
+                            prog_store16(co, (int16_t)(uint16_t)(p << al));
                         } else if (prog_get(b, 1)) {
-                            prog_or32(reinterpret_cast<uint32_t *>(co), 1u << s.al);  // co[0] |= bit (the low half of the block's first dword)
+                            prog_or32(reinterpret_cast<uint32_t *>(co), 1u << al);  // co[0] |= bit (the low half of the block's first dword)
                         }
                     }
             }
@@ -200,24 +256,27 @@ __device__ inline bool prog_scan_dc(const ProgScan &s, JP_LDS uint32_t *T, uint3
 }
 
 // ---- AC first scan (one component, ah == 0, ss >= 1; src/decoder.rs:1128-1172) -----------------------------------------------------
-__device__ inline bool prog_scan_ac_first(const ProgScan &s, JP_LDS uint32_t *T, const JP_LDS uint8_t *unzig, uint32_t *status) {
+__device__ inline bool prog_scan_ac_first(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, const JP_LDS uint8_t *unzig, uint32_t *status) {
     ProgBits b;
-    prog_bits_open(b, s);
+    prog_bits_open(b, s.data, s.n_bytes, ring);
     prog_load_table(T, s.table[0]);
-    const ProgScanComp &sc = s.comp[0];
+    // (everything the loop needs of the descriptor, once: one component, h = v = 1)
+    int16_t *const coefs = s.comp[0].coefs;
+    uint64_t *const masks = s.comp[0].masks;
+    const uint32_t block_w = s.comp[0].block_w, rows = s.rows, cols = s.cols, ss = s.ss, se = s.se, al = s.al;
     uint32_t eob_run = 0;
     bool bad = false;
-    for (uint32_t my = 0; my < s.rows; my++)
-        for (uint32_t mx = 0; mx < s.cols; mx++) {
+    for (uint32_t my = 0; my < rows; my++)
+        for (uint32_t mx = 0; mx < cols; mx++) {
             if (eob_run > 0u) {
                 eob_run--;
                 continue;
             }
-            const size_t blk = prog_block_index(sc, mx, my, 0u, 0u);
-            int16_t *co = sc.coefs + blk * 64u;
+            const size_t blk = (size_t)my * block_w + mx;
+            int16_t *co = coefs + blk * 64u;
             uint64_t nz = 0, neg = 0;
-            uint32_t k = s.ss;
-            while (k <= s.se) {
+            uint32_t k = ss;
+            while (k <= se) {
                 prog_refill(b);
                 const uint32_t rs = prog_decode_ac(b, T, bad), r = rs >> 4, sz = rs & 15u;
                 if (bad) {
@@ -239,20 +298,20 @@ __device__ inline bool prog_scan_ac_first(const ProgScan &s, JP_LDS uint32_t *T,
                 k += r;
                 // a run that leaves the band: what the reference then does with the magnitude bits depends on its table layout
                 // (frontend.cpp, decode_block) — the host's business; so is a magnitude that could make a later correction carry
-                if (k > s.se || sz + s.al > 14u) {
-                    prog_flag(status, k > s.se ? PROG_ST_BAND : PROG_ST_RANGE);
+                if (k > se || sz + al > 14u) {
+                    prog_flag(status, k > se ? PROG_ST_BAND : PROG_ST_RANGE);
                     return false;
                 }
                 prog_refill(b);
                 const int32_t v = prog_extend(prog_get(b, sz), sz);
-                co[unzig[k]] = (int16_t)(uint16_t)((uint32_t)v << s.al);
+                prog_store16(co + unzig[k], (int16_t)(uint16_t)((uint32_t)v << al));
                 nz |= 1ull << k;
                 if (v < 0) neg |= 1ull << k;
                 k++;
             }
             if (nz) {  // (OR, not store: another first scan of this track may own other bands of the block)
-                prog_or64(sc.masks + 2u * blk, nz);
-                if (neg) prog_or64(sc.masks + 2u * blk + 1u, neg);
+                prog_or64(masks + 2u * blk, nz);
+                if (neg) prog_or64(masks + 2u * blk + 1u, neg);
             }
         }
     return true;
@@ -284,6 +343,7 @@ __device__ __forceinline__ uint32_t prog_refine_non_zeroes(ProgRefine &R, const 
         const uint32_t take = n < 32u ? n : 32u;
         prog_refill(R.b);
         const uint32_t corr = prog_get(R.b, take);
+        PROG_COUNT(corrections, take);
         for (uint32_t j = 0; j < take; j++) {
             const uint32_t i = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;
@@ -301,46 +361,46 @@ __device__ __forceinline__ uint32_t prog_refine_non_zeroes(ProgRefine &R, const 
     return hit ? stop : end - 1u;
 }
 
-__device__ inline bool prog_scan_ac_refine(const ProgScan &s, JP_LDS uint32_t *T, const JP_LDS uint8_t *unzig, uint32_t *status) {
+__device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, const JP_LDS uint8_t *unzig, uint32_t *status) {
     ProgRefine R;
-    prog_bits_open(R.b, s);
+    prog_bits_open(R.b, s.data, s.n_bytes, ring);
     prog_load_table(T, s.table[0]);
-    const ProgScanComp &sc = s.comp[0];
+    int16_t *const coefs = s.comp[0].coefs;
+    uint64_t *const masks = s.comp[0].masks;
+    const uint32_t block_w = s.comp[0].block_w, rows = s.rows, cols = s.cols, ss = s.ss;
     R.bit = 1u << s.al;
     uint32_t eob_run = 0;
     bool bad = false;
     const uint32_t end = (uint32_t)s.se + 1u;
     // the masks of the block after this one are requested while this one is decoded
     uint64_t nz_next = 0, neg_next = 0;
-    {
-        const size_t blk0 = prog_block_index(sc, 0u, 0u, 0u, 0u);
-        if (s.rows && s.cols) {
-            nz_next = prog_load64(sc.masks + 2u * blk0);
-            neg_next = prog_load64(sc.masks + 2u * blk0 + 1u);
-        }
+    if (rows && cols) {
+        nz_next = prog_load64(masks);
+        neg_next = prog_load64(masks + 1u);
     }
-    for (uint32_t my = 0; my < s.rows; my++)
-        for (uint32_t mx = 0; mx < s.cols; mx++) {
-            const size_t blk = prog_block_index(sc, mx, my, 0u, 0u);
-            R.co = sc.coefs + blk * 64u;
+    for (uint32_t my = 0; my < rows; my++)
+        for (uint32_t mx = 0; mx < cols; mx++) {
+            const size_t blk = (size_t)my * block_w + mx;
+            PROG_COUNT(blocks, 1);
+            R.co = coefs + blk * 64u;
             R.nz = nz_next;
             R.neg = neg_next;
             {
                 uint32_t nx = mx + 1u, ny = my;
-                if (nx == s.cols) nx = 0u, ny++;
-                if (ny < s.rows) {
-                    const size_t nb = prog_block_index(sc, nx, ny, 0u, 0u);
-                    nz_next = prog_load64(sc.masks + 2u * nb);
-                    neg_next = prog_load64(sc.masks + 2u * nb + 1u);
+                if (nx == cols) nx = 0u, ny++;
+                if (ny < rows) {
+                    const size_t nb = (size_t)ny * block_w + nx;
+                    nz_next = prog_load64(masks + 2u * nb);
+                    neg_next = prog_load64(masks + 2u * nb + 1u);
                 }
             }
             uint64_t new_nz = 0, new_neg = 0;
             if (eob_run > 0u) {
                 eob_run--;
-                prog_refine_non_zeroes(R, unzig, s.ss, end, 64u);
+                prog_refine_non_zeroes(R, unzig, ss, end, 64u);
                 continue;
             }
-            uint32_t k = s.ss;
+            uint32_t k = ss;
             while (k < end) {
                 prog_refill(R.b);
                 const uint32_t rs = prog_decode_ac(R.b, T, bad), r = rs >> 4, sz = rs & 15u;
@@ -368,18 +428,18 @@ __device__ inline bool prog_scan_ac_refine(const ProgScan &s, JP_LDS uint32_t *T
                 }
                 k = prog_refine_non_zeroes(R, unzig, k, end, zrl);
                 if (value != 0) {
-                    R.co[unzig[k]] = (int16_t)value;
+                    prog_store16(R.co + unzig[k], (int16_t)value);
                     new_nz |= 1ull << k;
                     if (value < 0) new_neg |= 1ull << k;
                 }
                 k++;
             }
             if (new_nz) {  // (this lane owns the block's AC positions: plain stores, past the L1 for the scans that follow)
-                prog_store64(sc.masks + 2u * blk, R.nz | new_nz);
+                prog_store64(masks + 2u * blk, R.nz | new_nz);
                 // (a damaged stream can make the walk end ON a non-zero coefficient — at the band's last position, when it runs out of
                 // zeros — and the new value then REPLACES it, src/decoder.rs:1251-1256: the sign is the new value's)
                 const uint64_t neg = (R.neg & ~new_nz) | new_neg;
-                if (neg != R.neg) prog_store64(sc.masks + 2u * blk + 1u, neg);
+                if (neg != R.neg) prog_store64(masks + 2u * blk + 1u, neg);
             }
         }
     return true;
@@ -387,13 +447,13 @@ __device__ inline bool prog_scan_ac_refine(const ProgScan &s, JP_LDS uint32_t *T
 
 // ---- one lane: its track --------------------------------------------------------------------------------------------------------------
 __device__ inline void prog_run_track(JP_LDS ProgLds &L, uint32_t lane, const ProgTrack &tr) {
-    JP_LDS uint32_t *T = L.tab[lane];
+    JP_LDS uint32_t *T = L.tab[lane], *ring = L.ring[lane];
     for (uint32_t i = 0; i < tr.n_scans; i++) {
-        const ProgScan &s = tr.scans[i];
+        ProgScanRef s = *(const JP_GLOBAL ProgScan *)(tr.scans + i);
         bool ok;
-        if (s.ss == 0u) ok = prog_scan_dc(s, T, tr.status);
-        else if (s.ah == 0u) ok = prog_scan_ac_first(s, T, L.unzig, tr.status);
-        else ok = prog_scan_ac_refine(s, T, L.unzig, tr.status);
+        if (s.ss == 0u) ok = prog_scan_dc(s, T, ring, tr.status);
+        else if (s.ah == 0u) ok = prog_scan_ac_first(s, T, ring, L.unzig, tr.status);
+        else ok = prog_scan_ac_refine(s, T, ring, L.unzig, tr.status);
         if (!ok) return;
     }
 }

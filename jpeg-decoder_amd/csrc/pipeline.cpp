@@ -280,6 +280,13 @@ struct jpgpu_pipeline {
     // a host thread's entropy decoding + staging of one such frame, and the device's walk of the longest track (a launch's duration
     // does not depend on how many frames it holds while they fit the machine: every track has a lane of its own).  0: not measured yet.
     double prog_host_ns_per_byte = 0.0, prog_dev_ns_per_byte = 0.0;
+    // ... and, in wall-clock terms: what ONE more frame costs the host's pool as a whole (entropy phase / frames, measured when the pool
+    // was saturated — CPU contention with the device route's staging included), and what one more frame adds to the device route on
+    // top of the walk (staging, upload, range scan, pixel kernels)
+    double prog_host_ms_per_image = 0.0, prog_dev_ms_per_image = 0.0;
+    uint32_t prog_last_e = 0, prog_last_d = 0;  // the last call's eligible frames and how many of them the device got (a call of the same
+                                                 // shape keeps the split unless the rates say it is off by a fifth: sub-batches — arenas,
+                                                 // pinned staging — are reused only while their composition repeats)
     std::vector<SubBatch> subs;          // kept across calls while the geometry sequence repeats
     uint32_t n_subs = 0;                 // sub-batches used by the last call
     std::string path;
@@ -544,27 +551,36 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         d = (uint32_t)((uint64_t)e * (uint64_t)std::min<long>(std::max<long>(atol(pin), 0), 100) / 100u);
     } else {
         const double avg = (double)bytes / e;
-        const double host_ns = p->prog_host_ns_per_byte > 0 ? p->prog_host_ns_per_byte : 20.0;   // (1.2 ms per 60 kB frame)
-        const double dev_ns = p->prog_dev_ns_per_byte > 0 ? p->prog_dev_ns_per_byte : 330.0;     // (20 ms per 60 kB frame)
-        const double threads = (double)p->pool->size();
-        // lanes the machine holds at a time (two one-wave workgroups of 66 kB LDS per CU x 256 CUs x 64 lanes); more tracks than that
-        // walk in rounds
+        // the walk: nanoseconds per byte of ONE file (it lasts as long as the longest track, whatever the number of frames); the host: what a
+        // frame costs the whole pool; first call: guesses (an EPYC core decodes a 60 kB frame in 1.9 ms, the device walks it in 25 ms)
+        const double walk_ms = avg * (p->prog_dev_ns_per_byte > 0 ? p->prog_dev_ns_per_byte : 400.0) * 1e-6;
+        const double per_dev = p->prog_dev_ms_per_image > 0 ? p->prog_dev_ms_per_image : 0.012;
+        const double per_host = p->prog_host_ms_per_image > 0 ? p->prog_host_ms_per_image : avg * 32.0e-6 / (double)std::max<uint32_t>(1u, std::min<uint32_t>(p->pool->size(), 16u));
+        // lanes the machine holds at a time (two one-wave workgroups of 74 kB LDS per CU x 256 CUs x 64 lanes); more tracks than that walk in rounds
         const double lanes = 32768.0, tracks_per_frame = (double)tracks / e;
-        uint32_t best_d = 0;
-        double best_t = (double)(e + n_prog_host) * avg * host_ns / threads * 1e-6;  // everything on the host (ms)
-        for (uint32_t cand = std::min<uint32_t>(e, 16u); cand <= e; cand = cand < e ? std::min<uint32_t>(e, cand + std::max<uint32_t>(16u, e / 64u)) : e + 1u) {
+        auto cost = [&](uint32_t cand) {
+            const double t_host = (double)(e - cand + n_prog_host) * per_host;
+            if (cand == 0) return t_host;
             const double rounds = std::ceil(cand * tracks_per_frame / lanes);
-            const double t_dev = 1.0 + rounds * avg * dev_ns * 1e-6 + cand * 0.002;  // launch overheads + the walk + staging / upload of its frames
-            const double t_host = (double)(e - cand + n_prog_host) * avg * host_ns / threads * 1e-6;
-            const double t = std::max(t_dev, t_host);
+            return std::max(t_host, 1.0 + rounds * walk_ms + cand * per_dev);
+        };
+        uint32_t best_d = 0;
+        double best_t = cost(0);
+        for (uint32_t cand = 64u; cand <= e + 63u; cand += 64u) {  // (multiples of 64: a wave of tracks each)
+            const uint32_t c = std::min(cand, e);
+            const double t = cost(c);
             if (t < best_t * 0.97) {  // (a tie goes to the host: its path is the pinned one)
                 best_t = t;
-                best_d = cand;
+                best_d = c;
             }
         }
         d = best_d;
-        if (p->prog_dev_ns_per_byte <= 0 && e >= 32u) d = std::max(d, std::min<uint32_t>(32u, e / 4u));  // the probe
+        if (p->prog_dev_ns_per_byte <= 0 && e >= 128u) d = std::max(d, 64u);  // the probe: the next call knows the walk
+        // a call of the same shape as the last one keeps its split while the model does not object by more than a tenth in time
+        if (e == p->prog_last_e && p->prog_last_d <= e && cost(p->prog_last_d) <= 1.10 * cost(d) && !(p->prog_last_d == 0 && d > 0 && p->prog_dev_ns_per_byte <= 0)) d = p->prog_last_d;
     }
+    p->prog_last_e = e;
+    p->prog_last_d = d;
     // the LAST (e - d) eligible frames go back to the host (its threads start from the front of the list)
     for (uint32_t k = d; k < e; k++) {
         const uint32_t i = elig[k];
@@ -868,7 +884,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0, prog_host_ms = 0, prog_dev_ms = 0;
     uint64_t prog_host_bytes = 0, prog_dev_bytes = 0;
-    uint32_t device_prog_images = 0;
+    uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0;
+    double prog_dev_extra_ms = 0;  // launches of progressive sub-batches: host time of the launch calls + range scan + pixel kernels (device), summed
     uint32_t device_rejected = 0, device_images = 0;
     double dev_ms[4] = {0, 0, 0, 0};  // JPGPU_BATCH_KERNEL_TIMES: phases of the device entropy path, summed over the sub-batches
     bool dev_ms_valid = false;
@@ -888,10 +905,13 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         if (!download && !p->gather_on) return true;
         if (hipEventRecord(sb.decoded, cs) != hipSuccess) return false;
         if (download) {
-            hipStream_t ds = p->d2h[sj % kD2HStreams];
+            static const uint32_t n_d2h = (uint32_t)std::min<long>(std::max<long>(getenv("JPGPU_PIPE_D2H_STREAMS") ? atol(getenv("JPGPU_PIPE_D2H_STREAMS")) : kD2HStreams, 1), kD2HStreams);
+            hipStream_t ds = p->d2h[sj % n_d2h];
+            const double c0 = trace ? now_ms() : 0.0;
             if (hipStreamWaitEvent(ds, sb.decoded, 0) != hipSuccess ||
                 hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, ds) != hipSuccess)
                 return false;
+            if (trace) fprintf(stderr, "pipeline trace: download of sub-batch %u (%zu MB) enqueued at +%.2f ms, the call took %.2f ms\n", sj, sb.h_out_bytes >> 20, c0 - t2, now_ms() - c0);
         }
         if (p->gather_on && p->d_gather) {
             const size_t bytes = jpgpu_batch_out_arena_bytes(sb.batch);
@@ -965,6 +985,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                             okk = jpgpu::batch_device_progressive_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
                                                                          p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
                                                                          &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute]) == JPGPU_OK;
+                            prog_dev_extra_ms += now_ms() - l0;
                         } else {
                             std::vector<jpgpu::DeviceEntropyImage> list;
                             for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
@@ -1011,6 +1032,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     if (okk && sj >= first_prog_sub) {  // (what the dispatcher learns: the walk of this launch)
                         float kms = 0.f;
                         if (jpgpu::batch_progressive_kernel_ms(sb.batch, &kms)) prog_dev_ms = std::max(prog_dev_ms, (double)kms);
+                        // (what the frames of this sub-batch cost on top of the walk: the host side of the launch — staging, job records —
+                        // and the device's range scan + pixel kernels, from the phase events)
+                        float ph[4];
+                        if (jpgpu::batch_phase_times(sb.batch, ph)) prog_dev_extra_ms += ph[2] + ph[3];
                     }
                     std::vector<Redecode> redo;
                     for (size_t k2 = 0; okk && k2 < dv.size(); k2++)
@@ -1077,9 +1102,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                 busy_sum += w1 - w0;
                 busy_max = std::max(busy_max, w1 - w0);
                 last_end = std::max(last_end, w1);
+                n_host_images++;
                 if (p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
                     prog_host_ms += w1 - w0;
                     prog_host_bytes += len[i];
+                    prog_host_images++;
                 }
             }
             for (uint32_t c = 0; c < nc; c++)
@@ -1118,8 +1145,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     // 4. drain: whatever kernels and downloads are still in flight
     for (uint32_t k = 0; k < kCopyStreams; k++) P_HIP(hipStreamSynchronize(p->copy_streams[k]));
     for (uint32_t k = 0; k < p->n_compute; k++) P_HIP(hipStreamSynchronize(p->compute[k]));
+    if (trace) fprintf(stderr, "pipeline trace: copy and compute streams drained at +%.2f ms\n", now_ms() - t2);
     if (download)
-        for (uint32_t k = 0; k < kD2HStreams; k++) P_HIP(hipStreamSynchronize(p->d2h[k]));
+        for (uint32_t k = 0; k < kD2HStreams; k++) {
+            P_HIP(hipStreamSynchronize(p->d2h[k]));
+            if (trace) fprintf(stderr, "pipeline trace: download stream %u drained at +%.2f ms\n", k, now_ms() - t2);
+        }
     // (a child's gather stream is NOT waited for here: the parent does, after every child has decoded — what it then still waits is the exposed part)
     const double t4 = now_ms();
     uint64_t pixel_bytes = 0;
@@ -1154,13 +1185,21 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         const double r = prog_host_ms * 1e6 / (double)prog_host_bytes;
         p->prog_host_ns_per_byte = p->prog_host_ns_per_byte > 0 ? 0.5 * (p->prog_host_ns_per_byte + r) : r;
     }
+    if (prog_host_images >= 2u * p->pool->size() && prog_host_images == n_host_images) {  // (a saturated pool that decoded nothing else)
+        const double r = (t3 - t2) / prog_host_images;
+        p->prog_host_ms_per_image = p->prog_host_ms_per_image > 0 ? 0.5 * (p->prog_host_ms_per_image + r) : r;
+    }
     if (device_prog_images && prog_dev_ms > 0) {
         const double r = prog_dev_ms * 1e6 / ((double)prog_dev_bytes / device_prog_images);
         p->prog_dev_ns_per_byte = p->prog_dev_ns_per_byte > 0 ? 0.5 * (p->prog_dev_ns_per_byte + r) : r;
+        if (prog_dev_extra_ms > 0) {
+            const double o = prog_dev_extra_ms / device_prog_images;
+            p->prog_dev_ms_per_image = p->prog_dev_ms_per_image > 0 ? 0.5 * (p->prog_dev_ms_per_image + o) : o;
+        }
     }
     if (trace && (prog_host_bytes || device_prog_images))
-        fprintf(stderr, "pipeline trace: progressive frames: %u on the device (walk %.2f ms), host %.1f ns per byte and thread, device %.1f ns per byte of one file\n",
-                device_prog_images, prog_dev_ms, p->prog_host_ns_per_byte, p->prog_dev_ns_per_byte);
+        fprintf(stderr, "pipeline trace: progressive frames: %u on the device (walk %.2f ms, launches + range scan + pixels %.2f ms), %u on the host (entropy phase %.2f ms); rates: host %.4f ms per frame (pool), device walk %.1f ns per byte of one file + %.4f ms per frame\n",
+                device_prog_images, prog_dev_ms, prog_dev_extra_ms, prog_host_images, t3 - t2, p->prog_host_ms_per_image, p->prog_dev_ns_per_byte, p->prog_dev_ms_per_image);
     p->t.cpu_ms = process_cpu_ms() - cpu0;
     (void)t_last_upload;
     return JPGPU_OK;

@@ -5,12 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-int main() {
-    const size_t chunk = 796u << 20;
-    const int n_chunks = 8;
+int main(int argc, char **argv) {
+    const size_t chunk = 759u << 20;
+    const int n_chunks = argc > 1 ? atoi(argv[1]) : 8;  // (32: the footprint of a 4,096-file call that downloads its pixels, 24 GB)
     char *dev = nullptr;
     CK(hipMalloc((void **)&dev, chunk * 2));
     CK(hipMemset(dev, 1, chunk * 2));
@@ -19,7 +20,9 @@ int main() {
     CK(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
     struct Kind { const char *name; unsigned flags; } kinds[] = {{"hipHostMallocDefault", hipHostMallocDefault}, {"hipHostMallocNonCoherent", hipHostMallocNonCoherent},
                                                                  {"hipHostMallocNumaUser", hipHostMallocNumaUser}, {"hipHostMallocPortable", hipHostMallocPortable}};
-    for (const Kind &k : kinds) {
+    const int n_kinds = argc > 2 ? atoi(argv[2]) : 4;
+    for (int ki = 0; ki < n_kinds && ki < 4; ki++) {
+        const Kind &k = kinds[ki];
         std::vector<char *> h(n_chunks, nullptr);
         bool ok = true;
         const double a0 = now();
