@@ -642,6 +642,28 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                 except Exception as e:  # noqa: BLE001 (this entry only)
                     out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
             files_for_cpu = (files_for_cpu, [data] * 64, (od.width, od.height))
+            # The same size and script, 64 DIFFERENT frames (Pillow: 512 x 512 4:4:4 progressive, quality 85, seeds 0x700 + k): the lanes of a
+            # wave then walk different streams — every divergent step costs the wave — which copies of one file hide
+            if sizes and max(sizes) >= 4096:
+                try:
+                    import io
+                    from PIL import Image
+                    frames = []
+                    for k in range(64):
+                        buf = io.BytesIO()
+                        Image.fromarray(synth.synthetic_rgb(512, 512, seed=0x700 + k)).save(buf, format="JPEG", quality=85, subsampling="4:4:4", progressive=True)
+                        frames.append(buf.getvalue())
+                    n = 4096
+                    files = [frames[i % 64] for i in range(n)]
+                    ts = warm_calls(p, files, 5, cold=2, download=False, device_entropy=True)
+                    okd = all(np.array_equal(p.download(i), O.decode(frames[i % 64]).pixels) for i in (0, 1, 63, n // 2 + 7, n - 1))
+                    e, med = e2e_entry(n, ts, 512, 512, p, okd)
+                    e["input"] = "64 distinct 512x512 4:4:4 progressive frames (Pillow / libjpeg-turbo, quality 85, default script: 10 scans), repeated"
+                    e["jpeg_bytes_per_image"] = int(sum(len(f) for f in frames) / 64)
+                    e["images_device_progressive"] = int(med["images_device_progressive"])
+                    out["progressive_distinct_4096"] = e
+                except Exception as e:  # noqa: BLE001 (this entry only)
+                    out["progressive_distinct_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     finally:
         p.close()
         J._native.lib().jpgpu_trim_caches()

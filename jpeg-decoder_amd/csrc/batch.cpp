@@ -669,6 +669,25 @@ int jpgpu::batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, c
     return JPGPU_OK;
 }
 
+int jpgpu::copy_device_to_pinned_host(void *host_pinned, const void *d_src, size_t bytes, void *hip_stream) {
+    static const bool engine = getenv("JPGPU_DOWNLOAD_BY_COPY_ENGINE") != nullptr;  // A/B: hipMemcpyAsync instead of the copy kernel
+    void *mapped = nullptr;
+    if (!engine && ((uintptr_t)host_pinned & 15u) == 0 && ((uintptr_t)d_src & 15u) == 0 && hipHostGetDevicePointer(&mapped, host_pinned, 0) == hipSuccess)
+        return launch_copy_to_host(mapped, d_src, bytes, (hipStream_t)hip_stream) == hipSuccess ? JPGPU_OK : JPGPU_ERR_IO;
+    (void)hipGetLastError();
+    return hipMemcpyAsync(host_pinned, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream) == hipSuccess ? JPGPU_OK : JPGPU_ERR_IO;
+}
+
+// staged bytes of the device-entropy route: pinned block -> its device twin (offsets and lengths are multiples of 16 by construction)
+static hipError_t upload_staged(void *d_dst, const void *h_src, size_t bytes, hipStream_t s) {
+    static const bool by_kernel = getenv("JPGPU_UPLOAD_BY_KERNEL") != nullptr;
+    void *mapped = nullptr;
+    if (by_kernel && ((uintptr_t)h_src & 15u) == 0 && ((uintptr_t)d_dst & 15u) == 0 && hipHostGetDevicePointer(&mapped, const_cast<void *>(h_src), 0) == hipSuccess)
+        return launch_copy_from_host(d_dst, mapped, bytes, s);
+    if (by_kernel) (void)hipGetLastError();
+    return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s);
+}
+
 // ---- device entropy decoding -----------------------------------------------------------------------------------
 // the status words of a launch into b->h_entropy_out (pinned), behind the kernels on `s`: by a kernel, not by the copy engine (huff.hip)
 static hipError_t batch_status_to_host(jpgpu_batch *b, const uint32_t *d_status, uint32_t n, hipStream_t s) {
@@ -1067,7 +1086,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t t0 = slice_first(g), t1 = slice_first(g + 1u);
                 const size_t lo = off_data + copies[t0].dst_off, hi = t1 < n_tasks ? off_data + copies[t1].dst_off : total;
                 const auto c0 = std::chrono::steady_clock::now();
-                if (hipSetDevice(device) != hipSuccess || hipMemcpyAsync(d + lo, h + lo, hi - lo, hipMemcpyHostToDevice, cps) != hipSuccess)
+                if (hipSetDevice(device) != hipSuccess || upload_staged(d + lo, h + lo, hi - lo, cps) != hipSuccess)
                     copy_failed.store(1);
                 if (clk.on) {
                     const uint32_t us = (uint32_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
@@ -1083,7 +1102,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         if (clk.on) clk.used += (size_t)snprintf(clk.text + clk.used, clk.used < sizeof(clk.text) ? sizeof(clk.text) - clk.used : 0, " (slowest staging task %.2f, slowest hipMemcpyAsync call %.2f)", max_task_us.load() / 1e3, max_copy_us.load() / 1e3);
         if (copy_failed.load()) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
         // the head of the block last: the staging tasks wrote into its job records (unstuffed lengths, chunk counts, status)
-        B_HIP(hipMemcpyAsync(d, h, off_data, hipMemcpyHostToDevice, cps));
+        B_HIP(upload_staged(d, h, off_data, cps));
         if (two_streams) {
             B_HIP(hipEventRecord(b->entropy_uploaded, cps));
             B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));
@@ -1300,7 +1319,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     if (par && tasks.size() > 1) (*par)((uint32_t)tasks.size(), stage);
     else
         for (uint32_t t = 0; t < tasks.size(); t++) stage(t);
-    B_HIP(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, cps));
+    B_HIP(upload_staged(d, h, total, cps));
     if (two_streams) {
         B_HIP(hipEventRecord(b->entropy_uploaded, cps));
         B_HIP(hipStreamWaitEvent(s, b->entropy_uploaded, 0));

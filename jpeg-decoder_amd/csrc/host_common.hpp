@@ -45,6 +45,10 @@ struct TraceRange {
 int batch_upload_compact(jpgpu_batch *b, uint32_t image, uint32_t comp, const void *compact, size_t bytes, int range_class,
                          void *hip_stream, bool trusted);
 
+// `bytes` of device memory -> a pinned host block (its host address), behind what `hip_stream` holds: by a copy kernel that writes the
+// mapped block itself (huff.hip, launch_copy_to_host); falls back to the copy engine if the block has no device mapping
+int copy_device_to_pinned_host(void *host_pinned, const void *d_src, size_t bytes, void *hip_stream);
+
 // before a worker goes back to the decoder API's pool of idle workers
 void worker_recycle(jpgpu_worker *w);
 

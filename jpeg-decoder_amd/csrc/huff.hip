@@ -2,6 +2,7 @@
 // expansion of the entry lists into whole blocks, DC sums of scans whose components share their tables) and the range scan for
 // coefficients a caller's own kernels put into an arena (jpgpu_batch_classify_on_device / _scan_ranges, the Worker's fused route).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 
 #include "huff.hpp"
@@ -733,6 +734,34 @@ __global__ __launch_bounds__(256) void copy_words_kernel(uint32_t *__restrict__ 
 hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *d_src, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     copy_words_kernel<<<dim3(1), dim3(256), 0, stream>>>(dst_host_mapped, d_src, n);
+    return hipGetLastError();
+}
+
+// A sub-batch's pixels -> pinned host memory (JPGPU_PIPELINE_DOWNLOAD), by a kernel of a few workgroups that writes the mapped host
+// block itself (16-byte non-temporal stores): tools/probe_d2h2.hip measures 55 GB/s for it — what the copy engine gives the same
+// copies ALONE (57) — where hipMemcpyAsync inside jpgpu_pipeline_decode reached 33 with a host core busy the whole time.
+__global__ __launch_bounds__(256) void copy_to_host_kernel(v4u *__restrict__ dst, const v4u *__restrict__ src, size_t n16, uint8_t *__restrict__ dst_tail,
+                                                           const uint8_t *__restrict__ src_tail, uint32_t tail) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) __builtin_nontemporal_store(src[i], dst + i);
+    if (blockIdx.x == 0 && threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+// ... and the other way: staged entropy-coded bytes out of pinned host memory (A/B partner of the copy engine for the uploads of the
+// device-entropy route; JPGPU_UPLOAD_BY_KERNEL).  Reads over the link are not posted: 128 workgroups keep enough of them in flight.
+__global__ __launch_bounds__(256) void copy_from_host_kernel(v4u *__restrict__ dst, const v4u *__restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = __builtin_nontemporal_load(src + i);
+}
+hipError_t launch_copy_from_host(void *d_dst, const void *src_host_mapped, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const size_t n16 = (bytes + 15u) / 16u;  // (both blocks are 16-byte aligned and padded by their owner)
+    const uint32_t wgs = (uint32_t)std::min<size_t>(128u, (n16 + 255u) / 256u);
+    copy_from_host_kernel<<<dim3(wgs), dim3(256), 0, stream>>>((v4u *)d_dst, (const v4u *)src_host_mapped, n16);
+    return hipGetLastError();
+}
+hipError_t launch_copy_to_host(void *dst_host_mapped, const void *d_src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const size_t n16 = bytes / 16u;
+    copy_to_host_kernel<<<dim3(64), dim3(256), 0, stream>>>((v4u *)dst_host_mapped, (const v4u *)d_src, n16, (uint8_t *)dst_host_mapped + n16 * 16u,
+                                                          (const uint8_t *)d_src + n16 * 16u, (uint32_t)(bytes - n16 * 16u));
     return hipGetLastError();
 }
 

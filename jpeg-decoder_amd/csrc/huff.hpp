@@ -25,6 +25,9 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
 hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);
 // n words from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block), by a kernel
 hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *d_src, uint32_t n, hipStream_t stream);
+// `bytes` from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block, 16-byte aligned), by a kernel
+hipError_t launch_copy_to_host(void *dst_host_mapped, const void *d_src, size_t bytes, hipStream_t stream);
+hipError_t launch_copy_from_host(void *d_dst, const void *src_host_mapped, size_t bytes, hipStream_t stream);  // bytes rounded up to 16
 hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t *d_stats, hipStream_t stream);
 // one plane whose quantization table sits in device memory; raises the RS_WORDS statistics words at d_stats
 hipError_t launch_range_scan_one(const int16_t *d_coefs, uint32_t n_blocks, const uint16_t *d_q, uint32_t *d_stats, hipStream_t stream);

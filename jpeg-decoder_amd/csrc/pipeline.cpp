@@ -908,8 +908,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             static const uint32_t n_d2h = (uint32_t)std::min<long>(std::max<long>(getenv("JPGPU_PIPE_D2H_STREAMS") ? atol(getenv("JPGPU_PIPE_D2H_STREAMS")) : kD2HStreams, 1), kD2HStreams);
             hipStream_t ds = p->d2h[sj % n_d2h];
             const double c0 = trace ? now_ms() : 0.0;
+            // (by a copy kernel that writes the pinned block itself: the copy engine's hipMemcpyAsync reached 33 GB/s in here — with a
+            // host core busy the whole time — against 57 for the same copies alone: tools/probe_d2h*.hip, profiles/round5)
             if (hipStreamWaitEvent(ds, sb.decoded, 0) != hipSuccess ||
-                hipMemcpyAsync(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, hipMemcpyDeviceToHost, ds) != hipSuccess)
+                jpgpu::copy_device_to_pinned_host(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, ds) != JPGPU_OK)
                 return false;
             if (trace) fprintf(stderr, "pipeline trace: download of sub-batch %u (%zu MB) enqueued at +%.2f ms, the call took %.2f ms\n", sj, sb.h_out_bytes >> 20, c0 - t2, now_ms() - c0);
         }
