@@ -673,10 +673,10 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
 def e2e_cpu_budget(J, O, synth, w, h, encoder, n=4096, points=(1, 2, 4, 8, 16)):
     """E against the host CPUs a GPU's feeder gets: on an 8-GPU node with 16 granted CPUs every rank has two.  The
     4,096-file call with the calling thread's affinity — and with it the pipeline's pools, created under it — narrowed to the first
-    1 / 2 / 4 / 8 / 16 allowed CPUs and threads = 2 x CPUs (rank_cpu_share's rule).  Per point two inputs: the files in ordinary
-    (pageable) memory, mode chosen by the library (host-light — raw scans copied, marker check + unstuffing on the device — for
-    pipelines of <= 4 threads, host staging above); and the same files in a pinned arena (PinnedFiles: what a loader that reads into
-    jpgpu_host_alloc memory holds) with JPGPU_PIPELINE_INPUT_PINNED, where the DMA engine reads the arena itself."""
+    1 / 2 / 4 / 8 / 16 allowed CPUs and threads = 2 x CPUs (rank_cpu_share's rule).  Per point: the files in ordinary (pageable) memory
+    with the mode the library chooses (host-light — raw scans copied, marker check + unstuffing on the device — for pipelines of <= 4
+    threads, host staging above), the same with either mode forced (A/B), and the files in a pinned arena (PinnedFiles: what a loader
+    that reads into jpgpu_host_alloc memory holds) with JPGPU_PIPELINE_INPUT_PINNED, where the copy engine reads the arena itself."""
     distinct, who = e2e_files(synth, w, h, encoder)
     want = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in distinct]
     files = [distinct[i % len(distinct)] for i in range(n)]
@@ -684,7 +684,7 @@ def e2e_cpu_budget(J, O, synth, w, h, encoder, n=4096, points=(1, 2, 4, 8, 16)):
     granted = effective_cpus()
     out = {"images": n, "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}", "host_cpus_granted": granted,
            "what": "jpgpu_pipeline_decode of the same 4,096 files with affinity (sched_setaffinity before the pipeline's threads are created) and thread "
-                   "count limited: JPEG bytes in host memory -> RGB in HBM; per point median / min of 3 warm calls after one uncounted; "
+                   "count limited: JPEG bytes in host memory -> RGB in HBM; per point and input median / min of 5 warm calls after two uncounted; "
                    "cpu_ms_per_image = process CPU time of the median call / images",
            "points": []}
     arena = J.PinnedFiles(files)
@@ -697,9 +697,10 @@ def e2e_cpu_budget(J, O, synth, w, h, encoder, n=4096, points=(1, 2, 4, 8, 16)):
             try:
                 p = J.Pipeline(threads=row["threads"])
                 try:
-                    for name, src, kw in (("pageable_input", files, {}), ("pinned_input", arena, {"input_pinned": True})):
+                    for name, src, kw in (("pageable_input", files, {}), ("pageable_input_host_staging", files, {"host_light": False}),
+                                          ("pageable_input_host_light", files, {"host_light": True}), ("pinned_input", arena, {"input_pinned": True})):
                         try:
-                            ts = warm_calls(p, src, 3, cold=1, download=False, device_entropy=True, **kw)
+                            ts = warm_calls(p, src, 5, cold=2, download=False, device_entropy=True, **kw)
                             ok = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, n // 2, n - 1}))
                             med, med_ms, min_ms = call_stats(ts)
                             row[name] = {"total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3), "images_per_s": round(n / med_ms * 1e3, 1),

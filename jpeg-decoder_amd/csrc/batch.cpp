@@ -732,7 +732,7 @@ struct LaunchClock {  // JPGPU_PIPE_TRACE: where a slow launch spent its time (h
 
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream,
-                                       DeviceScratch *scratch, bool alone) {
+                                       DeviceScratch *scratch, bool alone, uint32_t mode, uint32_t *n_light) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
     LaunchClock clk;
     int rc = use_device(b->device, b->err);
@@ -816,6 +816,14 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     };
     rc = batch_enable_dev_classes(b);
     if (rc) return rc;
+    // "Host light" (include/jpgpu_decoder.h): scans without restart markers go up as the file holds them — the staging task is a plain
+    // memcpy, or nothing at all when the caller's buffers are pinned (DEVICE_ENTROPY_INPUT_PINNED: the copy engine reads them) — into a
+    // MIRROR of the data area, and huff_unstuff_* (huff.hip) does what huff_stage_segment does: marker check, unstuffing into the
+    // scan's slot, the job record's lengths.  Scans with restart markers are staged by the host as ever (into the mirror too: their
+    // jobs then read them there).
+    const bool light = (mode & DEVICE_ENTROPY_LIGHT) != 0, input_pinned = light && (mode & DEVICE_ENTROPY_INPUT_PINNED) != 0;
+    size_t n_raw_jobs = 0;
+    uint32_t max_pieces = 0, light_images = 0;
     size_t n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     // Files of one encoder repeat the same Huffman tables (27 kB per scan in device form): a scan whose tables equal those of
     // the scan before it shares that copy — one in the staging block, one upload, one set of lines in the L2.
@@ -834,6 +842,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 stuffed += ps.seg_off[sg + 1] - ps.seg_off[sg];
             }
             n_sync_jobs++;  // every scan is a job of the chunk decoder, with its per-chunk state and entry buffers (device only)
+            if (light && ps.check_at_staging && ps.seg_off.size() == 2) {
+                n_raw_jobs++;
+                const uint32_t pieces = (uint32_t)((stuffed + 15u + UNSTUFF_PIECE - 1u) / UNSTUFF_PIECE);
+                max_pieces = std::max(max_pieces, pieces);
+                scratch_bytes += align_up(((size_t)pieces + 1u) * 4u, 16);
+            }
             if (const DriGeom g = dri_geom(ps); g.chunked) {
                 const size_t chunks = g.too_large ? 0 : (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
                 scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(g.shift) * 4, 16) +
@@ -851,10 +865,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     }
     const size_t off_status = 0, off_cnt = align_up(off_status + (size_t)n * 4, 16);
     const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = off_jobs;
-    const size_t off_tables = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
+    const size_t off_ujobs = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
+    const size_t off_tables = align_up(off_ujobs + n_raw_jobs * sizeof(UnstuffJob), 16);
     const size_t off_seg = align_up(off_tables + n_table_sets * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
-    const size_t off_scratch = align_up(total, 256), total_dev = scratch ? total : off_scratch + scratch_bytes;
+    const size_t off_mirror = align_up(total, 256), dev_end = light ? off_mirror + data_bytes + 64 : total;  // (light: what is uploaded lands in the mirror)
+    const size_t off_scratch = align_up(dev_end, 256), total_dev = scratch ? dev_end : off_scratch + scratch_bytes;
     if (scratch && scratch_bytes > scratch->cap) {  // (hipFree waits for whatever still uses the block)
         if (scratch->d) (void)hipFree(scratch->d);
         scratch->d = nullptr;
@@ -903,8 +919,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const host::PlannedScan *ps;
         HuffSyncJob *sync;   // its job record (a scan of one segment: the unstuffed length goes there)
         uint32_t *h_status;  // the image's status word in the pinned block (set here if the staging pass refuses the stream)
+        bool raw;            // host light: the bytes go up as they are (huff_unstuff_* does the rest on the device)
     };
     std::vector<CopyTask> copies;
+    UnstuffJob *ujobs = reinterpret_cast<UnstuffJob *>(h + off_ujobs);
+    size_t ui = 0;
     std::vector<std::pair<size_t, size_t>> zero_ranges;  // coefficient planes of the listed images
     b->entropy_images.clear();
     for (uint32_t k = 0; k < n; k++) {
@@ -912,6 +931,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         b->entropy_images.push_back(img);
         const jpgpu_image_desc &desc = b->descs[img];
         bool needs_zeros = false;  // (the expansion writes every block of a scan, zeros included; planes a scan does not cover: below)
+        bool image_is_light = false;
         stat_images.push_back(img);
         for (uint32_t c = 0; c < desc.ncomp; c++) {  // the class of every component: from what the expansion leaves in d_stats
             b->sane[(size_t)img * 4 + c] = 0;
@@ -921,8 +941,13 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             // one staging task per scan: its segments, unstuffed, each in its own aligned slot (huff_stage_segment)
             const DriGeom dg = dri_geom(ps);
             HuffSyncJob *sj = &sjobs[si];
+            const bool raw_scan = light && ps.check_at_staging && ps.seg_off.size() == 2;
             copies.push_back(CopyTask{h + dcur, reinterpret_cast<uint32_t *>(h + scur), (uint32_t)(dcur - off_data), images[k].file + ps.data_off, &ps, sj,
-                                      reinterpret_cast<uint32_t *>(h + off_status) + k});
+                                      reinterpret_cast<uint32_t *>(h + off_status) + k, raw_scan});
+            if (raw_scan && !image_is_light) {
+                image_is_light = true;
+                light_images++;
+            }
             size_t scan_bytes = 0, stuffed = 0;
             for (size_t sg = 0; sg + 1 < ps.seg_off.size(); sg += 2) {
                 scan_bytes += huff_slot_bytes(ps.seg_off[sg + 1] - ps.seg_off[sg]);
@@ -965,7 +990,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t chunks = dg.chunked ? (dg.too_large ? 0u : (uint32_t)(ps.seg_off.size() / 2) * dg.seg_chunks)
                                                    : huff_sync_chunks((uint32_t)stuffed, sj->chunk_shift);
                 uint32_t *st = reinterpret_cast<uint32_t *>(xs + xcur);
-                sj->data = d + dcur;  // (bit positions and segment offsets are relative to the scan's first slot)
+                // (bit positions and segment offsets are relative to the scan's first slot; light: a scan the host staged itself — restart
+                // segments — lies in the mirror, where the uploads of such a launch land)
+                sj->data = (light && !raw_scan) ? d + off_mirror + (dcur - off_data) : d + dcur;
                 if (dg.chunked) {
                     sj->seg_off = reinterpret_cast<const uint32_t *>(d + scur);
                     sj->n_seg = (uint32_t)(ps.seg_off.size() / 2);
@@ -997,6 +1024,20 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 sj->weave = reinterpret_cast<const uint32_t *>(xs + xcur);
                 sj->data_dwords = (uint32_t)(scan_bytes / 4);
                 xcur += align_up(huff_weave_dwords(chunks, sj->chunk_shift) * 4, 256);
+                if (raw_scan) {
+                    UnstuffJob &uj = ujobs[ui++];
+                    memset(&uj, 0, sizeof(uj));
+                    uj.raw = d + off_mirror + (dcur - off_data);  // (16-byte aligned: the kernels take any alignment)
+                    uj.raw_bytes = (uint32_t)stuffed;
+                    uj.n_pieces = (uint32_t)((stuffed + UNSTUFF_PIECE - 1u) / UNSTUFF_PIECE);
+                    uj.dst = d + dcur;
+                    uj.piece_kept = reinterpret_cast<uint32_t *>(xs + xcur);
+                    xcur += align_up(((size_t)uj.n_pieces + 1u) * 4u, 16);
+                    uj.job = reinterpret_cast<HuffSyncJob *>(d + off_sjobs) + si;
+                    uj.status = sj->status;
+                    sj->n_chunks = chunks;  // (an upper bound until huff_unstuff_scan_kernel has counted)
+                    sj->n_bits = 0;
+                }
                 uint32_t block_h[4] = {0, 0, 0, 0};
                 for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
                 if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;
@@ -1009,8 +1050,24 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
     }
     {
+        const int device_for_copies = b->device;
+        hipStream_t raw_stream = (copy_stream && copy_stream != hip_stream) ? (hipStream_t)copy_stream : s;
+        std::atomic<int> raw_copy_failed{0};
         const std::function<void(uint32_t)> body = [&](uint32_t t) {
             const CopyTask &ct = copies[t];
+            if (ct.raw) {  // host light: as the file holds it — one memcpy, or none (the copy engine reads the caller's pinned buffer)
+                const uint32_t nraw = ct.ps->seg_off[1] - ct.ps->seg_off[0];
+                ct.seg_table[0] = 0;
+                ct.seg_table[1] = nraw;  // (the stuffed length; the job's lengths come from huff_unstuff_scan_kernel)
+                if (input_pinned) {
+                    if (hipSetDevice(device_for_copies) != hipSuccess ||
+                        hipMemcpyAsync(d + off_mirror + ct.dst_off, ct.src + ct.ps->seg_off[0], nraw, hipMemcpyHostToDevice, raw_stream) != hipSuccess)
+                        raw_copy_failed.store(1);
+                } else {
+                    memcpy(ct.dst, ct.src + ct.ps->seg_off[0], nraw);
+                }
+                return;
+            }
             uint32_t o = 0;
             for (size_t sg = 0; sg + 1 < ct.ps->seg_off.size(); sg += 2) {
                 const uint32_t first = ct.ps->seg_off[sg], n = ct.ps->seg_off[sg + 1] - first;
@@ -1076,6 +1133,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         const std::function<void(uint32_t)> staged = [&](uint32_t t) {
             const auto b0 = std::chrono::steady_clock::now();
             body(t);
+            if (input_pinned && !copies[t].raw) {  // (its slots, out of the pinned block into the mirror)
+                size_t bytes = 0;
+                for (size_t sg = 0; sg + 1 < copies[t].ps->seg_off.size(); sg += 2) bytes += huff_slot_bytes(copies[t].ps->seg_off[sg + 1] - copies[t].ps->seg_off[sg]);
+                if (hipSetDevice(device) != hipSuccess || upload_staged(d + off_mirror + copies[t].dst_off, copies[t].dst, bytes, cps) != hipSuccess) copy_failed.store(1);
+            }
             if (clk.on) {
                 const uint32_t us = (uint32_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - b0).count();
                 uint32_t cur = max_task_us.load();
@@ -1086,7 +1148,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t t0 = slice_first(g), t1 = slice_first(g + 1u);
                 const size_t lo = off_data + copies[t0].dst_off, hi = t1 < n_tasks ? off_data + copies[t1].dst_off : total;
                 const auto c0 = std::chrono::steady_clock::now();
-                if (hipSetDevice(device) != hipSuccess || upload_staged(d + lo, h + lo, hi - lo, cps) != hipSuccess)
+                // (light: into the mirror.  With pinned input there are no slice uploads: the raw scans have gone up on their own, straight
+                // from the caller's buffers, and a slice's copy out of the pinned block would overwrite them with whatever that block
+                // holds — the scans the host staged itself, restart segments, go up one by one as well: `staged` below)
+                if (!input_pinned && (hipSetDevice(device) != hipSuccess || upload_staged(d + (light ? off_mirror + (lo - off_data) : lo), h + lo, hi - lo, cps) != hipSuccess))
                     copy_failed.store(1);
                 if (clk.on) {
                     const uint32_t us = (uint32_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
@@ -1100,7 +1165,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             for (uint32_t t = 0; t < n_tasks; t++) staged(t);
         clk.mark("staging+uploads");
         if (clk.on) clk.used += (size_t)snprintf(clk.text + clk.used, clk.used < sizeof(clk.text) ? sizeof(clk.text) - clk.used : 0, " (slowest staging task %.2f, slowest hipMemcpyAsync call %.2f)", max_task_us.load() / 1e3, max_copy_us.load() / 1e3);
-        if (copy_failed.load()) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
+        if (copy_failed.load() || raw_copy_failed.load()) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
         // the head of the block last: the staging tasks wrote into its job records (unstuffed lengths, chunk counts, status)
         B_HIP(upload_staged(d, h, off_data, cps));
         if (two_streams) {
@@ -1119,6 +1184,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         B_HIP(hipEventRecord(b->ev_phase[0], s));
     }
     if (phase_times) B_HIP(hipEventRecord(b->ev_phase[1], s));
+    if (n_raw_jobs) B_HIP(launch_huff_unstuff(reinterpret_cast<const UnstuffJob *>(d + off_ujobs), (uint32_t)n_raw_jobs, max_pieces, s));
+    if (n_light) *n_light = light_images;
     B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, sync_iters, s,
                            phase_times ? b->ev_phase[2] : nullptr, low_table_ids));
     if (phase_times) {

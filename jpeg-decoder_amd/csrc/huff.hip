@@ -8,6 +8,7 @@
 #include "huff.hpp"
 #include "huff_core.hpp"
 #include "huff_prog_core.hpp"
+#include "huff_unstuff_core.hpp"
 #include "huff_sync_core.hpp"
 #include "range_stats.hpp"
 
@@ -104,6 +105,131 @@ __global__ __launch_bounds__(256) void range_scan_kernel(const RangeJob *__restr
 __global__ __launch_bounds__(256) void range_scan_one_kernel(const int16_t *__restrict__ coefs, uint32_t n_blocks, const uint16_t *__restrict__ q,
                                                              uint32_t *__restrict__ stats) {
     range_scan_body(RangeView{coefs, n_blocks, 0u, q}, stats);
+}
+
+// ---- "host light": the staging pass on the device (huff_unstuff_core.hpp) ---------------------------------------------------------------
+// grid = (ceil(max pieces), jobs), 256 lanes x 16 bytes per workgroup.  A lane's 16-byte piece, the byte in front of it and the byte
+// behind it (neighbours' registers through LDS; the workgroup's first and last lane read theirs from memory).
+struct UnstuffView {
+    uint32_t w[4];
+    uint32_t keep;   // which of the 16 bytes stay
+    uint32_t first, last;
+    bool bad;
+};
+__device__ __forceinline__ UnstuffView unstuff_view(const UnstuffJob &job, uint32_t piece, JP_LDS uint8_t *edge /* [2][256] */) {
+    const uint32_t lead = (uint32_t)((uintptr_t)job.raw & 15u), total = lead + job.raw_bytes;  // bytes from the aligned base to the scan's end
+    const JP_GLOBAL v4u *base = (const JP_GLOBAL v4u *)(job.raw - lead);
+    const uint32_t c = piece * 256u + threadIdx.x, lo = c * 16u;  // this lane's 16 bytes: [lo, lo + 16) from the aligned base
+    UnstuffView v;
+    v.bad = false;
+    v4u x = v4u{0u, 0u, 0u, 0u};
+    if (lo < total) x = stream_load(base + c);
+    v.w[0] = x.x, v.w[1] = x.y, v.w[2] = x.z, v.w[3] = x.w;
+    edge[threadIdx.x] = (uint8_t)(x.w >> 24);          // my last byte, for the lane behind me
+    edge[256u + threadIdx.x] = (uint8_t)(x.x & 0xffu);  // my first byte, for the lane in front of me
+    __syncthreads();
+    const JP_GLOBAL uint8_t *bytes = (const JP_GLOBAL uint8_t *)(job.raw - lead);
+    uint32_t prev = 0, next = 0;
+    if (lo > lead && lo < total) prev = threadIdx.x ? edge[threadIdx.x - 1u] : bytes[lo - 1u];
+    const bool has_next = lo + 16u < total;
+    if (has_next) next = threadIdx.x < 255u ? edge[256u + threadIdx.x + 1u] : bytes[lo + 16u];
+    v.first = lo >= lead ? 0u : min(16u, lead - lo);
+    v.last = lo >= total ? 0u : min(16u, total - lo);
+    v.keep = unstuff_piece_flags(v.w, prev, next, has_next, v.first, v.last, v.bad);
+    __syncthreads();
+    return v;
+}
+__global__ __launch_bounds__(256) void huff_unstuff_count_kernel(const UnstuffJob *__restrict__ jobs) {
+    __shared__ uint8_t edge[512];
+    __shared__ uint32_t wave_sum[4];
+    const UnstuffJob &job = jobs[blockIdx.y];
+    if (blockIdx.x >= job.n_pieces) return;
+    const UnstuffView v = unstuff_view(job, blockIdx.x, (JP_LDS uint8_t *)edge);
+    uint32_t kept = (uint32_t)__popc(v.keep);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += (uint32_t)__shfl_xor((int)kept, off);
+    if ((threadIdx.x & 63u) == 0u) wave_sum[threadIdx.x >> 6] = kept;
+    const bool any_bad = __syncthreads_or(v.bad);
+    if (threadIdx.x == 0) {
+        job.piece_kept[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        if (any_bad) atomicOr(job.status, 1u | 16u);  // something other than 0xFF00 pairs inside the scan: the host decodes this image
+    }
+}
+// one workgroup per job: piece_kept -> exclusive prefix sums (in place, n_pieces + 1 entries: the last is the unstuffed length), and the
+// job record's length fields (what the host's staging task fills in on the other route: batch.cpp)
+__global__ __launch_bounds__(256) void huff_unstuff_scan_kernel(const UnstuffJob *__restrict__ jobs) {
+    __shared__ uint32_t wave_tot[4];
+    const UnstuffJob &job = jobs[blockIdx.x];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < job.n_pieces; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < job.n_pieces ? job.piece_kept[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+            if ((threadIdx.x & 63u) >= (uint32_t)off) incl += o;
+        }
+        if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) {
+            before += w < (threadIdx.x >> 6) ? wave_tot[w] : 0u;
+            total += wave_tot[w];
+        }
+        if (i < job.n_pieces) job.piece_kept[i] = carry + before + incl - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        job.piece_kept[job.n_pieces] = carry;
+        const bool refused = (*job.status & 1u) != 0u;
+        HuffSyncJob *sj = job.job;
+        sj->n_bits = refused ? 0u : carry * 8u;
+        uint32_t n_chunks = (uint32_t)(((uint64_t)carry * 8u + (1u << sj->chunk_shift) - 1u) >> sj->chunk_shift);  // (huff_sync_chunks)
+        if (n_chunks == 0u) n_chunks = 1u;
+        sj->n_chunks = refused ? 0u : n_chunks;
+        sj->data_dwords = (carry + 3u) / 4u;  // (the weave reads nothing beyond: what follows the data counts as zeros)
+    }
+}
+__global__ __launch_bounds__(256) void huff_unstuff_compact_kernel(const UnstuffJob *__restrict__ jobs) {
+    __shared__ uint8_t edge[512];
+    __shared__ uint32_t wave_tot[4];
+    const UnstuffJob &job = jobs[blockIdx.y];
+    if (blockIdx.x >= job.n_pieces || (*job.status & 1u)) return;
+    const UnstuffView v = unstuff_view(job, blockIdx.x, (JP_LDS uint8_t *)edge);
+    const uint32_t mine = (uint32_t)__popc(v.keep);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if ((threadIdx.x & 63u) >= (uint32_t)off) incl += o;
+    }
+    if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; w++) before += w < (threadIdx.x >> 6) ? wave_tot[w] : 0u;
+    uint32_t o = job.piece_kept[blockIdx.x] + before + incl - mine;
+    JP_GLOBAL uint8_t *dst = (JP_GLOBAL uint8_t *)job.dst;
+    uint32_t keep = v.keep;
+    while (keep) {  // (byte stores: 0.1 GB per 256 files in all — the L2 merges them)
+        const uint32_t j = (uint32_t)__builtin_ctz(keep);
+        keep &= keep - 1u;
+        dst[o++] = (uint8_t)(v.w[j >> 2] >> (8u * (j & 3u)));
+    }
+    // behind the last byte: zeros up to the dword boundary (the weave reads whole dwords)
+    const uint32_t total = job.piece_kept[job.n_pieces];
+    if (mine && o == total)
+        for (uint32_t z = total; z & 3u; z++) dst[z] = 0u;
+}
+hipError_t launch_huff_unstuff(const UnstuffJob *d_jobs, uint32_t n_jobs, uint32_t max_pieces, hipStream_t stream) {
+    if (n_jobs == 0 || max_pieces == 0) return hipSuccess;
+    huff_unstuff_count_kernel<<<dim3(max_pieces, n_jobs), dim3(256), 0, stream>>>(d_jobs);
+    huff_unstuff_scan_kernel<<<dim3(n_jobs), dim3(256), 0, stream>>>(d_jobs);
+    huff_unstuff_compact_kernel<<<dim3(max_pieces, n_jobs), dim3(256), 0, stream>>>(d_jobs);
+    return hipGetLastError();
 }
 
 // ---- the weave (huff_job.hpp): the staged scans, 64 chunks side by side -------------------------------------------------

@@ -5,6 +5,7 @@
 
 #include "huff_job.hpp"
 #include "huff_prog_job.hpp"
+#include "huff_unstuff_core.hpp"
 
 namespace jpgpu {
 
@@ -27,6 +28,8 @@ hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStr
 hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *d_src, uint32_t n, hipStream_t stream);
 // `bytes` from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block, 16-byte aligned), by a kernel
 hipError_t launch_copy_to_host(void *dst_host_mapped, const void *d_src, size_t bytes, hipStream_t stream);
+// "host light": the staging pass of scans that went up as the file holds them — marker check, unstuffing, the job records' lengths — in front of launch_huff_sync
+hipError_t launch_huff_unstuff(const UnstuffJob *d_jobs, uint32_t n_jobs, uint32_t max_pieces, hipStream_t stream);
 hipError_t launch_copy_from_host(void *d_dst, const void *src_host_mapped, size_t bytes, hipStream_t stream);  // bytes rounded up to 16
 hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t max_blocks, uint32_t *d_stats, hipStream_t stream);
 // one plane whose quantization table sits in device memory; raises the RS_WORDS statistics words at d_stats

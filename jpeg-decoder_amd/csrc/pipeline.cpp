@@ -564,14 +564,21 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
             const double rounds = std::ceil(cand * tracks_per_frame / lanes);
             return std::max(t_host, 1.0 + rounds * walk_ms + cand * per_dev);
         };
+        // Three candidates before any split: everything on the host (the pinned path: a tie goes there), everything on the device, and the
+        // best split — which must beat BOTH by 15 % of the model's time to be chosen: with both routes busy the host's threads and
+        // the device route's staging team compete for the same cores and the host's sub-batches queue behind the device's (measured:
+        // 3,008 of 4,096 frames on the device 125 ms, all of them 81 ms, where the model saw 3 % in favour of the split)
         uint32_t best_d = 0;
         double best_t = cost(0);
-        for (uint32_t cand = 64u; cand <= e + 63u; cand += 64u) {  // (multiples of 64: a wave of tracks each)
-            const uint32_t c = std::min(cand, e);
-            const double t = cost(c);
-            if (t < best_t * 0.97) {  // (a tie goes to the host: its path is the pinned one)
+        if (cost(e) < best_t * 0.97) {
+            best_t = cost(e);
+            best_d = e;
+        }
+        for (uint32_t cand = 64u; cand + 64u <= e; cand += 64u) {  // (multiples of 64: a wave of tracks each)
+            const double t = cost(cand);
+            if (t < best_t * 0.85) {
                 best_t = t;
-                best_d = c;
+                best_d = cand;
             }
         }
         d = best_d;
@@ -884,7 +891,14 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0, prog_host_ms = 0, prog_dev_ms = 0;
     uint64_t prog_host_bytes = 0, prog_dev_bytes = 0;
-    uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0;
+    uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0, light_images = 0;
+    // Host light (include/jpgpu_decoder.h): forced by a flag, implied by pinned input, else chosen for pipelines of few worker threads —
+    // where the staging pass (80 us per 1080p file and core) is what bounds the call
+    const bool input_pinned = (flags & JPGPU_PIPELINE_INPUT_PINNED) != 0;
+    const char *light_env = getenv("JPGPU_PIPE_HOST_LIGHT");  // (tests, fuzzers, A/B: 1 / 0 force the mode for calls that do not say themselves)
+    const bool light_default = light_env ? atoi(light_env) != 0 : p->pool->size() <= 4u;
+    const bool host_light = input_pinned || (flags & JPGPU_PIPELINE_HOST_LIGHT) != 0 || ((flags & JPGPU_PIPELINE_HOST_STAGED) == 0 && light_default);
+    const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u);
     double prog_dev_extra_ms = 0;  // launches of progressive sub-batches: host time of the launch calls + range scan + pixel kernels (device), summed
     uint32_t device_rejected = 0, device_images = 0;
     double dev_ms[4] = {0, 0, 0, 0};  // JPGPU_BATCH_KERNEL_TIMES: phases of the device entropy path, summed over the sub-batches
@@ -991,9 +1005,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         } else {
                             std::vector<jpgpu::DeviceEntropyImage> list;
                             for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
+                            uint32_t n_light = 0;
                             okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
                                                                      p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
-                                                                     &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u) == JPGPU_OK;
+                                                                     &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u, entropy_mode, &n_light) == JPGPU_OK;
+                            light_images += n_light;
                         }
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         // The pixel kernels follow at once on the same stream: the classes of the decoded coefficients are a
@@ -1181,6 +1197,8 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.images_device_entropy = device_images;
     p->t.images_device_rejected = device_rejected;
     p->t.images_device_progressive = device_prog_images;
+    p->t.images_host_light = light_images;
+    p->t.input_pinned = input_pinned ? 1u : 0u;
     // the dispatcher's rates, smoothed over calls: a host thread's time per byte of progressive file, the device's walk per byte of the
     // AVERAGE file of the launch (frames of a call are assumed alike: the walk lasts as long as its longest track)
     if (prog_host_bytes) {

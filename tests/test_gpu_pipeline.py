@@ -676,6 +676,54 @@ def test_pipeline_progressive_device_decoder_hands_damaged_frames_back(monkeypat
     p.close()
 
 
+@pytest.mark.parametrize("variant", ["pageable", "pinned"])
+def test_pipeline_host_light_mode_equals_host_staging(variant):
+    """VERDICT r4 #1b: scans uploaded as the files hold them (one memcpy — or none: PinnedFiles + JPGPU_PIPELINE_INPUT_PINNED), marker check
+    and unstuffing on the device (csrc/huff_unstuff_core.hpp).  Every file of the reference's corpora, encoder-written files with and
+    without restart markers, and streams the staging pass must refuse — a marker inside the scan, a fill byte, a 0xFF as the scan's last
+    byte, data behind the end-of-image marker: same pixels / same errors as the oracle, whichever side does the staging."""
+    pytest.importorskip("PIL")
+    import bench
+    import synth
+    names = sorted(glob.glob(os.path.join(R.GOLDEN, "**", "*.jp*g"), recursive=True))
+    files = [open(n, "rb").read() for n in names]
+    big, _ = bench.e2e_files(synth, 1920, 1080, "auto", distinct=2)
+    rst, _ = bench.e2e_files(synth, 640, 360, "auto", distinct=2, restart_rows=2)
+    base = big[0]
+    sos = base.rindex(b"\xff\xda")
+    mid = sos + 14 + (len(base) - sos) // 2
+    odd = [base[:mid] + b"\xff\xd3" + base[mid:],          # a restart marker where no interval is in force
+           base[:mid] + b"\xff\xff" + base[mid:],          # fill bytes
+           base[:-2] + b"\xff" + base[-2:],                 # a 0xFF right in front of the end-of-image marker
+           base + b"garbage behind the end \xff\xd9 with another EOI",
+           base[:mid] + b"\xff\x00" + base[mid:],          # a stuffed pair that was not there (decodes to something else, or fails — as on the host)
+           base[:sos + 14 + 5]]                            # cut right behind the scan header
+    names += ["1080p-a", "1080p-b", "rst-a", "rst-b"] + [f"odd-{k}" for k in range(len(odd))]
+    files += big + rst + odd
+    files = files * 2  # (several sub-batches)
+    names = names * 2
+    p = J.Pipeline(threads=8)
+    staged = p.decode(files, device_entropy=True, host_light=False)
+    assert p.timings()["images_host_light"] == 0
+    src = J.PinnedFiles(files) if variant == "pinned" else files
+    for rep in range(2):
+        got = p.decode(src, device_entropy=True, host_light=True, input_pinned=variant == "pinned")
+        t = p.timings()
+        assert t["images_host_light"] >= 20 and t["images_device_entropy"] >= t["images_host_light"] and t["input_pinned"] == (variant == "pinned")
+        _check(names, files, got)
+        for a, b_ in zip(got, staged):
+            assert (isinstance(a, Exception) and isinstance(b_, Exception) and a.kind == b_.kind) or np.array_equal(a, b_)
+    # few worker threads: the library picks the mode itself
+    q = J.Pipeline(threads=2)
+    out = q.decode(files[:40], device_entropy=True)
+    assert q.timings()["images_host_light"] > 0
+    _check(names[:40], files[:40], out)
+    q.close()
+    p.close()
+    if variant == "pinned":
+        src.close()
+
+
 def test_pipeline_multi_refuses_nonsense():
     with pytest.raises(J.Error):
         J.Pipeline(devices=[], threads=4)
