@@ -140,12 +140,13 @@ enum {
                                    * xGMI link per peer, overlapped with the decode of the following sub-batches; SURVEY 8e, north_star's
                                    * final gather); jpgpu_pipeline_pixels_device then points into that copy.  Ignored by a one-device pipeline. */
     /* ---- host CPU per image (round 5).  With JPGPU_PIPELINE_DEVICE_ENTROPY the host's share of a baseline file is the staging pass:
-     * 0xFF00 -> 0xFF while copying the scan into pinned memory, ~80 us per 1080p file and core, which is what caps a host with two cores per
-     * GPU at ~20 k images/s.  "Host light": the scan goes up as the file holds it (one memcpy, ~35 us; or no copy at all with
+     * 0xFF00 -> 0xFF while copying the scan into pinned memory, 20-80 us per 1080p file and core — measured: 4,096 files per call reach
+     * 50-54 k images/s on 1 to 8 CPUs that way.  "Host light": the scan goes up as the file holds it (one memcpy; or no copy at all with
      * JPGPU_PIPELINE_INPUT_PINNED) and three small kernels check it for markers and drop the stuffing zeros on the device (a stream with
-     * anything but 0xFF00 pairs inside is handed back to the host decoder, as the staging pass does).  Chosen automatically when the
-     * pipeline was created with <= 4 worker threads; these two bits force either way.  Streams with restart markers are staged by the
-     * host in both modes (their markers must be found before the segments can be laid out). */
+     * anything but 0xFF00 pairs inside is handed back to the host decoder, as the staging pass does): 73-78 k images/s on the same 1 to
+     * 8 CPUs.  Chosen automatically when the pipeline was created with <= 16 worker threads (on 16 CPUs and 32 threads host staging
+     * wins: 81 k against 71 k); these two bits force either way.  Streams with restart markers are staged by the host in both modes
+     * (their markers must be found before the segments can be laid out). */
     , JPGPU_PIPELINE_HOST_LIGHT = 32u
     , JPGPU_PIPELINE_HOST_STAGED = 64u
     , JPGPU_PIPELINE_INPUT_PINNED = 128u /* every `data[i]` lies in page-locked host memory (jpgpu_host_alloc, or the caller's own

@@ -1059,14 +1059,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t nraw = ct.ps->seg_off[1] - ct.ps->seg_off[0];
                 ct.seg_table[0] = 0;
                 ct.seg_table[1] = nraw;  // (the stuffed length; the job's lengths come from huff_unstuff_scan_kernel)
-                if (input_pinned) {
-                    if (hipSetDevice(device_for_copies) != hipSuccess ||
-                        hipMemcpyAsync(d + off_mirror + ct.dst_off, ct.src + ct.ps->seg_off[0], nraw, hipMemcpyHostToDevice, raw_stream) != hipSuccess)
-                        raw_copy_failed.store(1);
-                } else {
-                    memcpy(ct.dst, ct.src + ct.ps->seg_off[0], nraw);
-                }
-                return;
+                if (!input_pinned) memcpy(ct.dst, ct.src + ct.ps->seg_off[0], nraw);
+                return;  // (pinned input: the copy engine reads the caller's buffer — enqueued below, by this thread alone)
             }
             uint32_t o = 0;
             for (size_t sg = 0; sg + 1 < ct.ps->seg_off.size(); sg += 2) {
@@ -1160,6 +1154,15 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 }
             }
         };
+        if (input_pinned) {
+            // one caller: 4,096 hipMemcpyAsync calls from a team of sixteen threads made the call twice as long as from one (108 against
+            // 53 ms; the runtime serialises them)
+            (void)device_for_copies;
+            for (uint32_t t = 0; t < n_tasks; t++)
+                if (copies[t].raw &&
+                    hipMemcpyAsync(d + off_mirror + copies[t].dst_off, copies[t].src + copies[t].ps->seg_off[0], copies[t].ps->seg_off[1] - copies[t].ps->seg_off[0], hipMemcpyHostToDevice, raw_stream) != hipSuccess)
+                    raw_copy_failed.store(1);
+        }
         if (par && n_tasks > 1) (*par)(n_tasks, staged);
         else
             for (uint32_t t = 0; t < n_tasks; t++) staged(t);

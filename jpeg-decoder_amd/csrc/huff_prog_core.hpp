@@ -83,9 +83,12 @@ typedef const JP_GLOBAL ProgScanComp &ProgScanCompRef;
 // microsecond to retire; a refill every 32 bits paid that latency every few symbols (tower_progressive.jpg: 65 ms for the longest
 // track).  LDS reads have a counter of their own; the global loads are waited for once per 512 bits.
 struct ProgBits {
-    uint64_t bits;  // unread bits, left-aligned
-    uint32_t nbits;
-    uint32_t r;              // dwords taken from the ring so far
+    // The next 64 bits of the stream in two dwords, `pos` (0..31 after a refill) of them read already.  A 32-bit WINDOW at `pos` is one
+    // v_alignbit_b32; the first version kept 64 left-aligned bits and shifted them by variable amounts — quarter-rate instructions in
+    // a loop that is one long chain of dependent ones (profiles/round5/04_progressive_on_device.txt: 24 cycles per instruction).
+    uint32_t hi, lo, nx;     // nx: the dword after lo, read from the ring when lo was taken (so that a refill never waits for LDS)
+    uint32_t pos;
+    uint32_t r;              // dwords taken from the ring so far (nx included)
     JP_LDS uint32_t *ring;   // the lane's PROG_RING_DWORDS dwords
     const JP_GLOBAL v4u *src;  // the scan's data, 16 bytes at a time
     uint32_t n16;            // pieces of 16 bytes that hold data (what follows: zeros)
@@ -99,9 +102,21 @@ __device__ __forceinline__ void prog_ring_put(ProgBits &b, uint32_t half) {  // 
         d[0] = b.pre[j].x, d[1] = b.pre[j].y, d[2] = b.pre[j].z, d[3] = b.pre[j].w;
     }
 }
+// the next dword of the stream (big-endian bit order), the ring fed as a half of it has been read
+__device__ __forceinline__ uint32_t prog_next_dword(ProgBits &b) {
+    PROG_COUNT(refills, 1);
+    const uint32_t w = __builtin_bswap32(b.ring[b.r & (PROG_RING_DWORDS - 1u)]);
+    b.r++;
+    if ((b.r & 15u) == 0u) {  // a half of the ring has been read: what was requested when the other half was begun goes there ...
+        prog_ring_put(b, ((b.r >> 4) - 1u) & 1u);
+        const uint32_t p0 = (b.r >> 2) + 8u;  // ... and the half after the next is requested
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, p0 + j);
+    }
+    return w;
+}
 __device__ __forceinline__ void prog_bits_open(ProgBits &b, const uint8_t *data, uint32_t n_bytes, JP_LDS uint32_t *ring) {
-    b.bits = 0;
-    b.nbits = 0;
+    b.pos = 0;
     b.r = 0;
     b.ring = ring;
     b.src = (const JP_GLOBAL v4u *)data;  // (16-byte aligned slots, zero-filled behind the data: huff_stage_segment)
@@ -114,27 +129,29 @@ __device__ __forceinline__ void prog_bits_open(ProgBits &b, const uint8_t *data,
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, 8u + j);
+    b.hi = prog_next_dword(b);
+    b.lo = prog_next_dword(b);
+    b.nx = prog_next_dword(b);
 }
-// afterwards more than 32 bits are available (a step reads at most 16 + 15)
+// afterwards pos <= 31: more than 32 bits ahead (a step reads at most 16 + 15; a batch of correction bits 32).  At most 32 bits are
+// consumed between two refills.
 __device__ __forceinline__ void prog_refill(ProgBits &b) {
-    if (b.nbits <= 32u) {
-        PROG_COUNT(refills, 1);
-        b.bits |= (uint64_t)__builtin_bswap32(b.ring[b.r & (PROG_RING_DWORDS - 1u)]) << (32u - b.nbits);
-        b.nbits += 32u;
-        b.r++;
-        if ((b.r & 15u) == 0u) {  // a half of the ring has been read: what was requested when the other half was begun goes there ...
-            prog_ring_put(b, ((b.r >> 4) - 1u) & 1u);
-            const uint32_t p0 = (b.r >> 2) + 8u;  // ... and the half after the next is requested
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, p0 + j);
-        }
+    if (b.pos >= 32u) {
+        b.hi = b.lo;
+        b.lo = b.nx;
+        b.pos -= 32u;
+        b.nx = prog_next_dword(b);
     }
 }
-__device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? (uint32_t)(b.bits >> (64u - n)) : 0u; }
-__device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) {
-    b.bits <<= n;
-    b.nbits -= n;
+__device__ __forceinline__ uint32_t prog_window(const ProgBits &b) {  // the 32 bits at `pos`
+#ifdef JPGPU_HOST_EMULATION
+    return b.pos ? (uint32_t)((((uint64_t)b.hi << 32) | b.lo) >> (32u - b.pos)) : b.hi;
+#else
+    return b.pos ? __builtin_amdgcn_alignbit(b.hi, b.lo, 32u - b.pos) : b.hi;
+#endif
 }
+__device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? prog_window(b) >> (32u - n) : 0u; }
+__device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) { b.pos += n; }
 __device__ __forceinline__ uint32_t prog_get(ProgBits &b, uint32_t n) {  // n <= 32, after a refill
     const uint32_t v = prog_peek(b, n);
     prog_consume(b, n);

@@ -893,10 +893,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     uint64_t prog_host_bytes = 0, prog_dev_bytes = 0;
     uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0, light_images = 0;
     // Host light (include/jpgpu_decoder.h): forced by a flag, implied by pinned input, else chosen for pipelines of few worker threads —
-    // where the staging pass (80 us per 1080p file and core) is what bounds the call
+    // where the staging pass (20-80 us per 1080p file and core) is what bounds the call
     const bool input_pinned = (flags & JPGPU_PIPELINE_INPUT_PINNED) != 0;
     const char *light_env = getenv("JPGPU_PIPE_HOST_LIGHT");  // (tests, fuzzers, A/B: 1 / 0 force the mode for calls that do not say themselves)
-    const bool light_default = light_env ? atoi(light_env) != 0 : p->pool->size() <= 4u;
+    // (measured, 4,096 x 1080p, affinity and threads limited — bench.py e2e.cpu_budget, profiles/round5: light 73-78 k images/s against 50-54 k for
+    // host staging on 1 / 2 / 4 / 8 CPUs = up to 16 worker threads; on 16 CPUs = 32 threads staging wins, 81 k against 71 k)
+    const bool light_default = light_env ? atoi(light_env) != 0 : p->pool->size() <= 16u;
     const bool host_light = input_pinned || (flags & JPGPU_PIPELINE_HOST_LIGHT) != 0 || ((flags & JPGPU_PIPELINE_HOST_STAGED) == 0 && light_default);
     const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u);
     double prog_dev_extra_ms = 0;  // launches of progressive sub-batches: host time of the launch calls + range scan + pixel kernels (device), summed
