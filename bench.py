@@ -296,18 +296,23 @@ def cpu_baseline(O, ocomps, qts, coefs, w, h, ct, target_seconds):
 
 def measured_traffic(workload, path):
     """HBM bytes per decode from the committed rocprofv3 PMC passes (profiles/roundN/pmc_traffic.json,
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc runs) and where they come from; (None, why) if
-    not measured.  The counters need rocprofv3 around the process: they are NOT taken in this run, and the line says so."""
-    for rnd in ("round4", "round3", "round2", "round1"):
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc runs) and where they come from; (None, why, None) if
+    not measured.  The counters need rocprofv3 around the process: they are NOT taken in this run, and the line says so — with the
+    commit the passes were taken on and whether the pixel kernels' sources have changed since (tools/kernel_sources.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_sources
+    for rnd in ("round5", "round4", "round3", "round2", "round1"):
         rel = os.path.join("profiles", rnd, "pmc_traffic.json")
         try:
             t = json.load(open(os.path.join(ROOT, rel)))
             e = t.get(f"{workload}:{path}")
             if e:
-                return e["hbm_bytes_per_decode"], f"{rel} (rocprofv3 --pmc passes of this workload committed with {rnd}; read from the file, not measured in this run)"
+                same = e.get("pixel_kernel_sources_sha256") == kernel_sources.sha256() if e.get("pixel_kernel_sources_sha256") else None
+                return (e["hbm_bytes_per_decode"], f"{rel} (rocprofv3 --pmc passes of this workload committed with {rnd}; read from the file, not measured in this run)",
+                        {"traffic_commit": e.get("commit"), "traffic_taken_on_these_kernel_sources": same})
         except (OSError, ValueError, KeyError):
             continue
-    return None, "not measured for this workload / kernel path"
+    return None, "not measured for this workload / kernel path", None
 
 
 def k_4096(J, torch, O, variants, device_index, dev, stream, w, h, digest, n_img=4096, steps=30):
@@ -1172,8 +1177,8 @@ def main(argv=None):
         alg_bytes = sum(algorithmic_bytes_per_image(v["comps"], shard.image_pixels(k).numel()) * len(range(k, n_img, nv))
                         for k, v in enumerate(variants) if k < n_img)  # per step of this rank's shard
         achieved = alg_bytes / (gpu_ms_per_step * 1e-3) / 1e9
-        traffic, traffic_source = (measured_traffic(workload, shard.path) if (n_img == default_batch and world == 1)
-                                   else (None, "only measured for the default batch on one GPU"))
+        traffic, traffic_source, traffic_prov = (measured_traffic(workload, shard.path) if (n_img == default_batch and world == 1)
+                                                 else (None, "only measured for the default batch on one GPU", None))
         line = {
             "metric": "megapixels/s decoded (batch, whole node)", "value": round(value, 1), "unit": "MP/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "settle_launches_before_warmup": settle,
@@ -1191,7 +1196,7 @@ def main(argv=None):
                        "parallelism": f"images sharded {n_img}/GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic": traffic, "traffic_source": traffic_source, **(traffic_prov or {}),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": round(gpu_ms_per_step, 4),
                          "launch": "one step of this rank's shard" + (f" = {len(shard.batches)} launch groups" if len(shard.batches) > 1 else "")},
             "verified_vs_oracle": verified,

@@ -129,12 +129,18 @@ __device__ __forceinline__ void prog_bits_open(ProgBits &b, const uint8_t *data,
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, 8u + j);
+#ifndef JPGPU_PROG_BITS64
     b.hi = prog_next_dword(b);
     b.lo = prog_next_dword(b);
     b.nx = prog_next_dword(b);
+#else
+    b.hi = b.lo = 0u;
+    b.nx = prog_next_dword(b);
+#endif
 }
 // afterwards pos <= 31: more than 32 bits ahead (a step reads at most 16 + 15; a batch of correction bits 32).  At most 32 bits are
 // consumed between two refills.
+#ifndef JPGPU_PROG_BITS64
 __device__ __forceinline__ void prog_refill(ProgBits &b) {
     if (b.pos >= 32u) {
         b.hi = b.lo;
@@ -152,6 +158,25 @@ __device__ __forceinline__ uint32_t prog_window(const ProgBits &b) {  // the 32 
 }
 __device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? prog_window(b) >> (32u - n) : 0u; }
 __device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) { b.pos += n; }
+#else
+// (A/B build: the first version's reader — 64 unread bits left-aligned in {hi, lo}, shifted as they are read; `pos` = bits held)
+__device__ __forceinline__ void prog_refill(ProgBits &b) {
+    if (b.pos <= 32u) {
+        const uint64_t bits = (((uint64_t)b.hi << 32) | b.lo) | ((uint64_t)b.nx << (32u - b.pos));
+        b.hi = (uint32_t)(bits >> 32);
+        b.lo = (uint32_t)bits;
+        b.pos += 32u;
+        b.nx = prog_next_dword(b);
+    }
+}
+__device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? (uint32_t)((((uint64_t)b.hi << 32) | b.lo) >> (64u - n)) : 0u; }
+__device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) {
+    const uint64_t bits = (((uint64_t)b.hi << 32) | b.lo) << n;
+    b.hi = (uint32_t)(bits >> 32);
+    b.lo = (uint32_t)bits;
+    b.pos -= n;
+}
+#endif
 __device__ __forceinline__ uint32_t prog_get(ProgBits &b, uint32_t n) {  // n <= 32, after a refill
     const uint32_t v = prog_peek(b, n);
     prog_consume(b, n);

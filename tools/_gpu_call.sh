@@ -1,5 +1,8 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r5j; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q -x -k "host_light" > $O/pytest_new.log 2>&1; tail -4 $O/pytest_new.log
-bash tools/gpu.sh r5j bench
+bash tools/gpu.sh r5k tests
+O=gpurun_out/r5k
+python tools/prog_calls.py --images 256 | tail -2
+python tools/prog_calls.py --images 4096 | tail -2
+python tools/prog_calls.py --images 4096 --distinct | tail -2
+JPGPU_PIPE_HOST_LIGHT=1 bash tools/gpu.sh r5k fuzz:150

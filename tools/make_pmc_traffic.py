@@ -6,6 +6,7 @@ counters are KB) + WRITE_SIZE, each averaged per dispatch."""
 import json
 import sys
 
+import kernel_sources
 from prof_summary import summarize
 
 
@@ -28,7 +29,8 @@ def main():
         doc = json.load(open(out))
     except (OSError, ValueError):
         doc = {}
-    doc[key] = {"hbm_bytes_per_decode": total, "per_kernel": per,
+    doc[key] = {"hbm_bytes_per_decode": total, "per_kernel": per, "commit": kernel_sources.head_commit(),
+                "pixel_kernel_sources_sha256": kernel_sources.sha256(),
                 "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled (gfx950: 128-B "
                           "requests tallied at 64 B, MI355X_MICROARCH.md §HBM); counters are KB; average per dispatch; sum over "
                           "the kernels of one decode of the batch"}
