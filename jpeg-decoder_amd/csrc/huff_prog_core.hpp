@@ -83,10 +83,10 @@ typedef const JP_GLOBAL ProgScanComp &ProgScanCompRef;
 // microsecond to retire; a refill every 32 bits paid that latency every few symbols (tower_progressive.jpg: 65 ms for the longest
 // track).  LDS reads have a counter of their own; the global loads are waited for once per 512 bits.
 struct ProgBits {
-    // The next 64 bits of the stream in two dwords, `pos` (0..31 after a refill) of them read already.  A 32-bit WINDOW at `pos` is one
-    // v_alignbit_b32; the first version kept 64 left-aligned bits and shifted them by variable amounts — quarter-rate instructions in
-    // a loop that is one long chain of dependent ones (profiles/round5/04_progressive_on_device.txt: 24 cycles per instruction).
-    uint32_t hi, lo, nx;     // nx: the dword after lo, read from the ring when lo was taken (so that a refill never waits for LDS)
+    // The unread bits, left-aligned in {hi, lo}; `pos` of them are held.  (A 32-bit window at a bit position — one v_alignbit_b32 per
+    // look instead of 64-bit shifts — measured 3 % SLOWER: profiles/round5/08_progressive_reader_ab.txt; 64-bit shifts issue like
+    // 32-bit ones on this part, round 4's 02_ubench_valu64.txt.)
+    uint32_t hi, lo, nx;     // nx: the next dword of the stream, read from the ring when the last one was taken (so that a refill never waits for LDS)
     uint32_t pos;
     uint32_t r;              // dwords taken from the ring so far (nx included)
     JP_LDS uint32_t *ring;   // the lane's PROG_RING_DWORDS dwords
@@ -129,37 +129,10 @@ __device__ __forceinline__ void prog_bits_open(ProgBits &b, const uint8_t *data,
     }
 #pragma unroll
     for (uint32_t j = 0; j < 4u; j++) b.pre[j] = prog_piece(b, 8u + j);
-#ifndef JPGPU_PROG_BITS64
-    b.hi = prog_next_dword(b);
-    b.lo = prog_next_dword(b);
-    b.nx = prog_next_dword(b);
-#else
     b.hi = b.lo = 0u;
     b.nx = prog_next_dword(b);
-#endif
 }
-// afterwards pos <= 31: more than 32 bits ahead (a step reads at most 16 + 15; a batch of correction bits 32).  At most 32 bits are
-// consumed between two refills.
-#ifndef JPGPU_PROG_BITS64
-__device__ __forceinline__ void prog_refill(ProgBits &b) {
-    if (b.pos >= 32u) {
-        b.hi = b.lo;
-        b.lo = b.nx;
-        b.pos -= 32u;
-        b.nx = prog_next_dword(b);
-    }
-}
-__device__ __forceinline__ uint32_t prog_window(const ProgBits &b) {  // the 32 bits at `pos`
-#ifdef JPGPU_HOST_EMULATION
-    return b.pos ? (uint32_t)((((uint64_t)b.hi << 32) | b.lo) >> (32u - b.pos)) : b.hi;
-#else
-    return b.pos ? __builtin_amdgcn_alignbit(b.hi, b.lo, 32u - b.pos) : b.hi;
-#endif
-}
-__device__ __forceinline__ uint32_t prog_peek(const ProgBits &b, uint32_t n) { return n ? prog_window(b) >> (32u - n) : 0u; }
-__device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) { b.pos += n; }
-#else
-// (A/B build: the first version's reader — 64 unread bits left-aligned in {hi, lo}, shifted as they are read; `pos` = bits held)
+// afterwards more than 32 bits are held (a step reads at most 16 + 15; a batch of correction bits 32)
 __device__ __forceinline__ void prog_refill(ProgBits &b) {
     if (b.pos <= 32u) {
         const uint64_t bits = (((uint64_t)b.hi << 32) | b.lo) | ((uint64_t)b.nx << (32u - b.pos));
@@ -176,7 +149,6 @@ __device__ __forceinline__ void prog_consume(ProgBits &b, uint32_t n) {
     b.lo = (uint32_t)bits;
     b.pos -= n;
 }
-#endif
 __device__ __forceinline__ uint32_t prog_get(ProgBits &b, uint32_t n) {  // n <= 32, after a refill
     const uint32_t v = prog_peek(b, n);
     prog_consume(b, n);
