@@ -402,7 +402,7 @@ def sync_pass_instructions(symbols_per_call):
     call as one sub-batch (profiles/roundN/*pipeline_256*pmc*.json: SQ_INSTS_VALU per dispatch x dispatches, all sync launches of
     the call): wave-instructions per symbol, and x 64 = lane slots per symbol (a scalar decoder's step is ~100 instructions)."""
     import glob
-    for rnd in ("round4", "round3"):
+    for rnd in ("round5", "round4", "round3"):
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", rnd, "*pipeline_256*pmc*.json")) + glob.glob(os.path.join(ROOT, "profiles", rnd, "*pipe256*stats*.json"))):
             try:
                 doc = json.load(open(f))

@@ -898,7 +898,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const char *light_env = getenv("JPGPU_PIPE_HOST_LIGHT");  // (tests, fuzzers, A/B: 1 / 0 force the mode for calls that do not say themselves)
     // (measured, 4,096 x 1080p, affinity and threads limited — bench.py e2e.cpu_budget, profiles/round5: light 73-78 k images/s against 50-54 k for
     // host staging on 1 / 2 / 4 / 8 CPUs = up to 16 worker threads; on 16 CPUs = 32 threads staging wins, 81 k against 71 k)
-    const bool light_default = light_env ? atoi(light_env) != 0 : p->pool->size() <= 16u;
+    // (and for small calls whatever the thread count: 256 files 6.5-7.0 ms against 6.8-7.2 interleaved on one box — the first sub-batch reaches
+    // the device a staging pass earlier; 1,024 files the other way round: profiles/round5/06_*)
+    const bool light_default = light_env ? atoi(light_env) != 0 : (p->pool->size() <= 16u || n_dev <= 384u);
     const bool host_light = input_pinned || (flags & JPGPU_PIPELINE_HOST_LIGHT) != 0 || ((flags & JPGPU_PIPELINE_HOST_STAGED) == 0 && light_default);
     const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u);
     double prog_dev_extra_ms = 0;  // launches of progressive sub-batches: host time of the launch calls + range scan + pixel kernels (device), summed
