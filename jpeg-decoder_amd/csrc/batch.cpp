@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -1256,6 +1257,14 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         const jpgpu_image_desc &desc = b->descs[images[k].image];
         for (uint32_t c = 0; c < desc.ncomp; c++) mask_bytes += align_up(b->coef_len[(size_t)images[k].image * 4 + c] / 128 * 16, 256);
     }
+    // Scans of a track pipelined over lanes (huff_prog_job.hpp): one lane per SCAN, a progress word each (behind the masks, zeroed with
+    // them), lanes of one dependency rank in waves of their own — a lane must never wait for a lane of its own wave, and the
+    // producers must come first in launch order.  JPGPU_PROG_SERIAL=1: one lane per track, as first built (A/B).
+    static const bool serial_tracks = getenv("JPGPU_PROG_SERIAL") != nullptr;
+    const size_t progress_off = mask_bytes;
+    mask_bytes += align_up(n_scans * 4u, 256);
+    const size_t max_lanes = n_tracks + n_scans + 64u * 64u;  // (a padding of < 64 lanes per rank, up to 64 ranks: more are walked serially, as tracks)
+    n_tracks = max_lanes;
     const size_t off_status = 0, off_tracks = align_up((size_t)n * 4, 16), off_scans = align_up(off_tracks + n_tracks * sizeof(ProgTrack), 16);
     const size_t off_tables = align_up(off_scans + n_scans * sizeof(ProgScan), 16), off_data = align_up(off_tables + n_tables * sizeof(ProgHuffTable), 16);
     const size_t total = off_data + data_bytes;
@@ -1304,6 +1313,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     struct TrackOrder {
         uint32_t first_scan, n_scans, image_k;
         uint64_t weight;  // bytes of entropy-coded data the lane walks
+        uint32_t rank;    // pipelined scans: how many scans deep its dependencies go (0: none); serial tracks: 0
     };
     std::vector<TrackOrder> order;
     order.reserve(n_tracks);
@@ -1319,52 +1329,96 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
             mask_of[c] = reinterpret_cast<uint64_t *>(dm + mcur);
             mcur += align_up(b->coef_len[(size_t)img * 4 + c] / 128 * 16, 256);
         }
-        // the scans of a track, contiguous and in stream order
-        for (uint32_t t = 0; t < pl.n_tracks; t++) {
-            TrackOrder to{(uint32_t)si, 0u, k, 0u};
-            for (const host::ProgPlannedScan &ps : pl.scans) {
-                if (ps.track != t) continue;
-                ProgScan &sc = scans[si];
-                memset(&sc, 0, sizeof(sc));
-                sc.data = d + dcur;
-                sc.ss = ps.ss, sc.se = ps.se, sc.ah = ps.ah, sc.al = ps.al;
-                sc.ncomp = ps.ncomp, sc.cols = ps.cols, sc.rows = ps.rows;
-                for (uint32_t c = 0; c < ps.ncomp; c++) {
-                    const uint32_t fi = ps.comp[c].frame_index;
-                    if (fi >= desc.ncomp || ps.comp[c].block_w != desc.components[fi].block_width)
-                        return set_err(b->err, JPGPU_ERR_FORMAT, "device progressive: plan does not match the image descriptor");
-                    sc.comp[c].coefs = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
-                    sc.comp[c].masks = mask_of[fi];
-                    sc.comp[c].block_w = ps.comp[c].block_w;
-                    sc.comp[c].h = ps.comp[c].h;
-                    sc.comp[c].v = ps.comp[c].v;
-                    sc.comp[c].table = ps.comp[c].table;
-                }
-                StageTask st{&ps, images[k].file + ps.data_off, h + dcur, h + tcur, &sc, reinterpret_cast<uint32_t *>(h + off_status) + k};
-                for (int tb = 0; tb < 4; tb++)
-                    if (ps.table[tb]) {
-                        sc.table[tb] = reinterpret_cast<const ProgHuffTable *>(d + tcur);
-                        tcur += sizeof(ProgHuffTable);
-                    }
-                tasks.push_back(st);
-                to.weight += ps.stuffed_bytes;
-                to.n_scans++;
-                dcur += huff_slot_bytes(ps.stuffed_bytes);
-                si++;
+        // Which scans does a scan depend on?  For every coefficient it covers, the LAST earlier scan that covered it (that one waited
+        // for its own predecessors block by block, so staying behind it is staying behind them all).  More than three, or more than
+        // 64 levels: the frame's tracks are walked serially, one lane each.
+        const size_t first_si = si;
+        const uint32_t ns = (uint32_t)pl.scans.size();
+        const host::ProgDependencies pd = serial_tracks ? host::ProgDependencies{} : host::prog_plan_dependencies(pl);
+        const bool pipelined = !serial_tracks && pd.ok;
+        const std::vector<uint32_t> &rank = pd.rank;
+        const std::vector<std::array<int32_t, 3>> &deps = pd.deps;
+        // the scans, in stream order (serial tracks: grouped by track, each track's scans contiguous)
+        std::vector<uint32_t> scan_order;
+        if (pipelined) {
+            for (uint32_t j = 0; j < ns; j++) scan_order.push_back(j);
+        } else {
+            for (uint32_t t = 0; t < pl.n_tracks; t++)
+                for (uint32_t j = 0; j < ns; j++)
+                    if (pl.scans[j].track == t) scan_order.push_back(j);
+        }
+        std::vector<size_t> si_of(ns, 0);
+        for (uint32_t j : scan_order) {
+            const host::ProgPlannedScan &ps = pl.scans[j];
+            ProgScan &sc = scans[si];
+            si_of[j] = si;
+            memset(&sc, 0, sizeof(sc));
+            sc.data = d + dcur;
+            sc.ss = ps.ss, sc.se = ps.se, sc.ah = ps.ah, sc.al = ps.al;
+            sc.ncomp = ps.ncomp, sc.cols = ps.cols, sc.rows = ps.rows;
+            for (uint32_t c = 0; c < ps.ncomp; c++) {
+                const uint32_t fi = ps.comp[c].frame_index;
+                if (fi >= desc.ncomp || ps.comp[c].block_w != desc.components[fi].block_width)
+                    return set_err(b->err, JPGPU_ERR_FORMAT, "device progressive: plan does not match the image descriptor");
+                sc.comp[c].coefs = reinterpret_cast<int16_t *>(b->d_coef + b->coef_off[(size_t)img * 4 + fi]);
+                sc.comp[c].masks = mask_of[fi];
+                sc.comp[c].block_w = ps.comp[c].block_w;
+                sc.comp[c].h = ps.comp[c].h;
+                sc.comp[c].v = ps.comp[c].v;
+                sc.comp[c].table = ps.comp[c].table;
             }
-            if (to.n_scans) order.push_back(to);
+            StageTask st{&ps, images[k].file + ps.data_off, h + dcur, h + tcur, &sc, reinterpret_cast<uint32_t *>(h + off_status) + k};
+            for (int tb = 0; tb < 4; tb++)
+                if (ps.table[tb]) {
+                    sc.table[tb] = reinterpret_cast<const ProgHuffTable *>(d + tcur);
+                    tcur += sizeof(ProgHuffTable);
+                }
+            tasks.push_back(st);
+            dcur += huff_slot_bytes(ps.stuffed_bytes);
+            si++;
+        }
+        if (pipelined) {
+            for (uint32_t j = 0; j < ns; j++) {
+                ProgScan &sc = scans[si_of[j]];
+                sc.progress = reinterpret_cast<uint32_t *>(dm + progress_off) + si_of[j];
+                for (uint32_t w = 0; w < 3u; w++) {
+                    if (deps[j][w] < 0) continue;
+                    sc.wait[w] = reinterpret_cast<const uint32_t *>(dm + progress_off) + si_of[(uint32_t)deps[j][w]];
+                    if (!host::prog_same_walk(pl.scans[j], pl.scans[(uint32_t)deps[j][w]])) sc.wait_whole |= 1u << w;  // (else block for block)
+                }
+                order.push_back(TrackOrder{(uint32_t)si_of[j], 1u, k, pl.scans[j].stuffed_bytes, rank[j]});
+            }
+        } else {
+            size_t at = first_si;
+            for (uint32_t t = 0; t < pl.n_tracks; t++) {
+                TrackOrder to{(uint32_t)at, 0u, k, 0u, 0u};
+                for (uint32_t j = 0; j < ns; j++)
+                    if (pl.scans[j].track == t) {
+                        to.weight += pl.scans[j].stuffed_bytes;
+                        to.n_scans++;
+                    }
+                at += to.n_scans;
+                if (to.n_scans) order.push_back(to);
+            }
         }
         for (uint32_t c = 0; c < desc.ncomp; c++) {  // the classes of the finished planes: from the range scan below
             b->sane[(size_t)img * 4 + c] = 0;
             batch_class_source(b, (size_t)img * 4 + c, true);
         }
     }
-    // heavy tracks first, like with like: the 64 lanes of a wave then walk scans of the same kind and about the same length
-    std::stable_sort(order.begin(), order.end(), [](const TrackOrder &a, const TrackOrder &c) { return a.weight > c.weight; });
+    // Lanes in launch order: by dependency rank (producers in front: workgroups are dispatched in order, so whatever a lane waits for is
+    // resident or done), every rank starting a wave of its own (a lane never waits for a lane of its own wave), and inside a rank heavy
+    // lanes first, like with like: the 64 lanes of a wave then walk scans of the same kind and about the same length
+    std::stable_sort(order.begin(), order.end(), [](const TrackOrder &a, const TrackOrder &c) { return a.rank != c.rank ? a.rank < c.rank : a.weight > c.weight; });
+    size_t n_lanes = 0;
     for (size_t t = 0; t < order.size(); t++) {
-        tracks[t].scans = reinterpret_cast<const ProgScan *>(d + off_scans) + order[t].first_scan;
-        tracks[t].n_scans = order[t].n_scans;
-        tracks[t].status = reinterpret_cast<uint32_t *>(d + off_status) + order[t].image_k;
+        if (t > 0 && order[t].rank != order[t - 1].rank)
+            while (n_lanes % 64u) tracks[n_lanes++] = ProgTrack{nullptr, 0u, nullptr};
+        if (n_lanes >= max_lanes) return set_err(b->err, JPGPU_ERR_INTERNAL, "device progressive: lane table");
+        tracks[n_lanes].scans = reinterpret_cast<const ProgScan *>(d + off_scans) + order[t].first_scan;
+        tracks[n_lanes].n_scans = order[t].n_scans;
+        tracks[n_lanes].status = reinterpret_cast<uint32_t *>(d + off_status) + order[t].image_k;
+        n_lanes++;
     }
     const bool two_streams = copy_stream && copy_stream != hip_stream;
     hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
@@ -1400,7 +1454,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         if (!e) B_HIP(hipEventCreate(&e));
     B_HIP(hipEventRecord(b->ev_phase[0], s));
     B_HIP(hipEventRecord(b->ev_phase[1], s));
-    B_HIP(launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)order.size(), s));
+    B_HIP(launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s));
     B_HIP(hipEventRecord(b->ev_phase[2], s));
     {
         const int crc = jpgpu_batch_classify_on_device(b, s);

@@ -7,6 +7,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
+#include <array>
 #include <memory>
 #include <string>
 #include <vector>
@@ -82,6 +84,49 @@ struct ProgPlan {
     std::vector<ProgPlannedScan> scans;  // stream order
     uint32_t n_tracks = 0;
 };
+
+// Which scans does a scan of a progressive frame depend on (huff_prog_job.hpp: scans pipelined over lanes)?  For every coefficient it
+// covers, the LAST earlier scan that covered it — that one stayed behind ITS predecessors block by block, so staying behind it is
+// staying behind them all.  deps[j]: up to three scan numbers (-1: none); rank[j]: how deep the dependencies go; ok = false: some scan
+// depends on more than three others or a chain is 64 scans deep — such a frame is walked one lane per track.
+struct ProgDependencies {
+    std::vector<std::array<int32_t, 3>> deps;
+    std::vector<uint32_t> rank;
+    bool ok = true;
+};
+inline ProgDependencies prog_plan_dependencies(const ProgPlan &pl) {
+    ProgDependencies out;
+    const uint32_t ns = (uint32_t)pl.scans.size();
+    out.deps.assign(ns, std::array<int32_t, 3>{-1, -1, -1});
+    out.rank.assign(ns, 0u);
+    int16_t last[4][64];
+    for (auto &row : last)
+        for (auto &v : row) v = -1;
+    for (uint32_t j = 0; j < ns && out.ok; j++) {
+        const ProgPlannedScan &ps = pl.scans[j];
+        uint32_t nd = 0;
+        for (uint32_t c = 0; c < ps.ncomp && out.ok; c++)
+            for (uint32_t k = ps.ss; k <= ps.se; k++) {
+                const int32_t w = last[ps.comp[c].frame_index & 3u][k];
+                last[ps.comp[c].frame_index & 3u][k] = (int16_t)j;
+                if (w < 0 || (nd > 0 && out.deps[j][0] == w) || (nd > 1 && out.deps[j][1] == w) || (nd > 2 && out.deps[j][2] == w)) continue;
+                if (nd == 3) {
+                    out.ok = false;
+                    break;
+                }
+                out.deps[j][nd++] = w;
+                out.rank[j] = std::max(out.rank[j], out.rank[(uint32_t)w] + 1u);
+            }
+        if (out.rank[j] >= 64u) out.ok = false;
+    }
+    return out;
+}
+// do two scans walk the same blocks in the same order (then one can stay behind the other block for block)?
+inline bool prog_same_walk(const ProgPlannedScan &a, const ProgPlannedScan &b) {
+    bool same = a.ncomp == b.ncomp && a.cols == b.cols && a.rows == b.rows;
+    for (uint32_t c = 0; same && c < a.ncomp; c++) same = a.comp[c].frame_index == b.comp[c].frame_index && a.comp[c].h == b.comp[c].h && a.comp[c].v == b.comp[c].v;
+    return same;
+}
 
 struct IccChunk {
     uint8_t num_markers, seq_no;

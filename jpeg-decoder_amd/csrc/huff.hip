@@ -838,9 +838,9 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
 }
 
 // ---- progressive frames: one lane per track (huff_prog_core.hpp) ---------------------------------------------------------------------
-// grid = ceil(tracks / 64) workgroups of ONE wave: a lane's table region is 1 kB of LDS (66 kB per workgroup, two workgroups per CU),
-// and the lanes of a wave do not talk to each other — the host sorts the tracks so that a wave's 64 walk scans of the same kind and
-// of similar length.
+// grid = ceil(lanes / 64) workgroups of ONE wave: a lane keeps the 8-bit lookup of its scan's table (512 B) and a 128-byte window on
+// its stream in LDS (42 kB per workgroup, three workgroups per CU), and the lanes of a wave do not talk to each other — the host
+// sorts them so that a wave's 64 walk scans of the same kind and of similar length, producers in front of the scans that wait for them.
 __global__ __launch_bounds__(64) void huff_prog_kernel(const ProgTrack *__restrict__ tracks, uint32_t n_tracks) {
     __shared__ ProgLds L;
     huff_fill_unzigzag((JP_LDS uint8_t *)L.unzig, threadIdx.x);

@@ -15,7 +15,7 @@ namespace jpgpu {
 
 constexpr uint32_t PROG_RING_DWORDS = 32u;  // a lane's window on its scan: two halves of 16 dwords
 struct ProgLds {
-    uint32_t tab[64][PROG_LANE_DWORDS];  // per lane: the table of its current scan (AC: a whole ProgHuffTable; DC: four byte lookups)
+    uint32_t tab[64][PROG_LANE_DWORDS];  // per lane: the 8-bit lookup of its current scan's table (AC: 256 x u16; DC: two tables of 256 bytes)
     uint32_t ring[64][PROG_RING_DWORDS + 1u];  // per lane: the next 512-1,024 bits of its scan (skewed by one dword, like `tab`)
     uint8_t unzig[64];
 };
@@ -160,18 +160,18 @@ __device__ __forceinline__ int32_t prog_extend(uint32_t v, uint32_t n) {  // src
 }
 
 // ---- a lane's table region --------------------------------------------------------------------------------------------------------
-// AC scans (and single-table use in general): the ProgHuffTable as it is
+// AC scans: the table's 8-bit lookup (the head of ProgHuffTable: 512 bytes = 32 pieces of 16)
 __device__ __forceinline__ void prog_load_table(JP_LDS uint32_t *T, const ProgHuffTable *t) {
-    const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)t;  // (912 bytes: 57 pieces of 16)
-    for (uint32_t i = 0; i < PROG_TABLE_DWORDS / 4u; i++) {
+    const JP_GLOBAL v4u *src = (const JP_GLOBAL v4u *)t;
+    for (uint32_t i = 0; i < 32u; i++) {
         const v4u w = src[i];
         T[4u * i] = w.x, T[4u * i + 1u] = w.y, T[4u * i + 2u] = w.z, T[4u * i + 3u] = w.w;
     }
 }
-// DC first scans: up to four tables, each as 256 bytes: category | code length << 4 (0: the walk, from the table in global memory —
-// codes of nine bits and more are rare in tables of twelve symbols)
+// DC first scans: the tables of ids 0 and 1 — what encoders use — each as 256 bytes: category | code length << 4 (0: the walk; codes of
+// nine bits and more are rare in tables of twelve symbols).  Components with table ids 2 and 3 look their codes up in global memory.
 __device__ __forceinline__ void prog_load_dc_tables(JP_LDS uint32_t *T, ProgScanRef s) {
-    for (uint32_t t = 0; t < 4u; t++) {
+    for (uint32_t t = 0; t < 2u; t++) {
         const JP_GLOBAL ProgHuffTable *src = (const JP_GLOBAL ProgHuffTable *)s.table[t];
         for (uint32_t i = 0; i < 64u; i++) {
             uint32_t w = 0;
@@ -204,23 +204,111 @@ __device__ __forceinline__ uint32_t prog_walk(ProgBits &b, TablePtr t, bool &bad
     bad = true;  // "failed to decode huffman code"
     return 0u;
 }
-__device__ __forceinline__ uint32_t prog_decode_ac(ProgBits &b, const JP_LDS uint32_t *T, bool &bad) {
-    const JP_LDS ProgHuffTable *t = reinterpret_cast<const JP_LDS ProgHuffTable *>(T);
+__device__ __forceinline__ uint32_t prog_decode_ac(ProgBits &b, const JP_LDS uint32_t *T, const JP_GLOBAL ProgHuffTable *gt, bool &bad) {
     PROG_COUNT(symbols, 1);
-    const uint32_t e = t->lut[prog_peek(b, 8)];
+    const uint32_t e = reinterpret_cast<const JP_LDS uint16_t *>(T)[prog_peek(b, 8)];
     if (e >> 8) {
         prog_consume(b, e >> 8);
         return e & 0xffu;
     }
-    return prog_walk(b, t, bad);
+    return prog_walk(b, gt, bad);
 }
 __device__ __forceinline__ uint32_t prog_decode_dc(ProgBits &b, const JP_LDS uint32_t *T, uint32_t table, ProgScanRef s, bool &bad) {
-    const uint32_t e = reinterpret_cast<const JP_LDS uint8_t *>(T)[256u * table + prog_peek(b, 8)];
-    if (e >> 4) {
-        prog_consume(b, e >> 4);
-        return e & 15u;
+    const JP_GLOBAL ProgHuffTable *gt = (const JP_GLOBAL ProgHuffTable *)s.table[table];
+    if (table < 2u) {
+        const uint32_t e = reinterpret_cast<const JP_LDS uint8_t *>(T)[256u * table + prog_peek(b, 8)];
+        if (e >> 4) {
+            prog_consume(b, e >> 4);
+            return e & 15u;
+        }
+    } else {  // (table ids 2 and 3: CMYK files at most)
+        const uint32_t e = gt->lut[prog_peek(b, 8)];
+        if (e >> 8) {
+            prog_consume(b, e >> 8);
+            return e & 0xffu;
+        }
     }
-    return prog_walk(b, (const JP_GLOBAL ProgHuffTable *)s.table[table], bad);
+    return prog_walk(b, gt, bad);
+}
+
+// ---- scans of a track pipelined over lanes: stay behind the scans this one depends on, tell the ones that depend on this one ---------
+#ifndef PROG_SPIN_SLEEP  // (A/B builds)
+#define PROG_SPIN_SLEEP 120  // x 64 cycles: ~3 us
+#endif
+#ifndef PROG_SPIN_NAPS_MAX
+#define PROG_SPIN_NAPS_MAX 16u
+#endif
+#ifndef PROG_PUBLISH_EVERY
+#define PROG_PUBLISH_EVERY 64u
+#endif
+struct ProgSync {
+    uint32_t *progress;
+    const uint32_t *wait[3];
+    uint32_t seen[3];   // what wait[i] said last (blocks below it are complete)
+    uint32_t whole;
+    uint32_t *status;
+};
+__device__ __forceinline__ void prog_sync_open(ProgSync &y, ProgScanRef s, uint32_t *status) {
+    y.progress = s.progress;
+    y.whole = s.wait_whole;
+    y.status = status;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        y.wait[i] = s.wait[i];
+        y.seen[i] = 0u;
+    }
+}
+// may the lane work on block `bi` (its blocks counted in walk order)?  Spins until the scans it depends on are past it; false: it
+// gave up (a producer that never moves: cannot happen while workgroups are dispatched in launch order — the launch puts producers in
+// front — but a lane that spins for good would hang the device; the image then goes to the host).
+__device__ __forceinline__ bool prog_wait_for(ProgSync &y, uint32_t bi) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (y.wait[i] == nullptr) continue;
+        const uint32_t need = ((y.whole >> i) & 1u) ? PROG_DONE - 1u : bi;  // (a value ABOVE need lets the lane go: PROG_DONE always does)
+        if (y.seen[i] > need) continue;
+#ifdef JPGPU_HOST_EMULATION
+        y.seen[i] = *y.wait[i];  // (tests/emu runs the lanes one after the other, producers first)
+        if (y.seen[i] <= need) {
+            prog_flag(y.status, PROG_ST_WAIT);
+            return false;
+        }
+#else
+        // (every look is a read at the L2; tens of thousands of lanes looking every microsecond slowed the walks of everybody — 4,096
+        // frames 86 ms against 68 with rarer looks, profiles/round5/11_*: a lane that finds its producer behind sleeps longer each time,
+        // up to ~50 us — by then the producer has moved a dozen blocks and the next look covers them all)
+        uint32_t spins = 0, naps = 1;
+        for (;;) {
+            y.seen[i] = __hip_atomic_load((const JP_GLOBAL uint32_t *)y.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (y.seen[i] > need) break;
+            spins += naps;
+            if (spins > (1u << 20)) {  // (seconds: a producer that never moves — cannot happen, see above — must not hang the device)
+                prog_flag(y.status, PROG_ST_WAIT);
+                return false;
+            }
+            for (uint32_t k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(PROG_SPIN_SLEEP);
+            naps = naps < PROG_SPIN_NAPS_MAX ? naps * 2u : naps;
+        }
+#endif
+    }
+    return true;
+}
+// `done` blocks are complete: everything this lane has stored into them is made visible first (release)
+__device__ __forceinline__ void prog_publish(ProgSync &y, uint32_t done) {
+    if (y.progress == nullptr || (done & (PROG_PUBLISH_EVERY - 1u)) != 0u) return;
+#ifdef JPGPU_HOST_EMULATION
+    *y.progress = done;
+#else
+    __hip_atomic_store((JP_GLOBAL uint32_t *)y.progress, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void prog_publish_end(ProgSync &y) {
+    if (y.progress == nullptr) return;
+#ifdef JPGPU_HOST_EMULATION
+    *y.progress = PROG_DONE;
+#else
+    __hip_atomic_store((JP_GLOBAL uint32_t *)y.progress, PROG_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 // where block (mx, my) x (hp, vp) of scan component c lies
@@ -230,8 +318,9 @@ __device__ __forceinline__ size_t prog_block_index(ProgScanCompRef c, uint32_t m
 
 // ---- DC scans (ss == se == 0; one to four components, src/decoder.rs:1100-1126 and :1181-1190) ------------------------------------
 // Returns false if the scan raised the status word.
-__device__ inline bool prog_scan_dc(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, uint32_t *status) {
+__device__ inline bool prog_scan_dc(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, uint32_t *status, ProgSync &y) {
     ProgBits b;
+    uint32_t bi = 0;
     prog_bits_open(b, s.data, s.n_bytes, ring);
     const bool first = s.ah == 0;
     const uint32_t al = s.al, rows = s.rows, cols = s.cols, ncomp = s.ncomp;
@@ -246,6 +335,7 @@ __device__ inline bool prog_scan_dc(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS ui
                 for (uint32_t vp = 0; vp < cv; vp++)
                     for (uint32_t hp = 0; hp < ch; hp++) {
                         int16_t *co = sc.coefs + prog_block_index(sc, mx, my, hp, vp) * 64u;
+                        if (!prog_wait_for(y, bi)) return false;
                         prog_refill(b);
                         if (first) {
                             const uint32_t cat = prog_decode_dc(b, T, ctable, s, bad);
@@ -264,16 +354,19 @@ __device__ inline bool prog_scan_dc(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS ui
                         } else if (prog_get(b, 1)) {
                             prog_or32(reinterpret_cast<uint32_t *>(co), 1u << al);  // co[0] |= bit (the low half of the block's first dword)
                         }
+                        prog_publish(y, ++bi);
                     }
             }
     return true;
 }
 
 // ---- AC first scan (one component, ah == 0, ss >= 1; src/decoder.rs:1128-1172) -----------------------------------------------------
-__device__ inline bool prog_scan_ac_first(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, const JP_LDS uint8_t *unzig, uint32_t *status) {
+__device__ inline bool prog_scan_ac_first(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, const JP_LDS uint8_t *unzig, uint32_t *status, ProgSync &y) {
     ProgBits b;
+    uint32_t bi = 0;
     prog_bits_open(b, s.data, s.n_bytes, ring);
     prog_load_table(T, s.table[0]);
+    const JP_GLOBAL ProgHuffTable *const gt = (const JP_GLOBAL ProgHuffTable *)s.table[0];
     // (everything the loop needs of the descriptor, once: one component, h = v = 1)
     int16_t *const coefs = s.comp[0].coefs;
     uint64_t *const masks = s.comp[0].masks;
@@ -284,15 +377,17 @@ __device__ inline bool prog_scan_ac_first(ProgScanRef s, JP_LDS uint32_t *T, JP_
         for (uint32_t mx = 0; mx < cols; mx++) {
             if (eob_run > 0u) {
                 eob_run--;
+                prog_publish(y, ++bi);
                 continue;
             }
+            if (!prog_wait_for(y, bi)) return false;
             const size_t blk = (size_t)my * block_w + mx;
             int16_t *co = coefs + blk * 64u;
             uint64_t nz = 0, neg = 0;
             uint32_t k = ss;
             while (k <= se) {
                 prog_refill(b);
-                const uint32_t rs = prog_decode_ac(b, T, bad), r = rs >> 4, sz = rs & 15u;
+                const uint32_t rs = prog_decode_ac(b, T, gt, bad), r = rs >> 4, sz = rs & 15u;
                 if (bad) {
                     prog_flag(status, PROG_ST_BAD_CODE);
                     return false;
@@ -327,6 +422,7 @@ __device__ inline bool prog_scan_ac_first(ProgScanRef s, JP_LDS uint32_t *T, JP_
                 prog_or64(masks + 2u * blk, nz);
                 if (neg) prog_or64(masks + 2u * blk + 1u, neg);
             }
+            prog_publish(y, ++bi);
         }
     return true;
 }
@@ -375,10 +471,12 @@ __device__ __forceinline__ uint32_t prog_refine_non_zeroes(ProgRefine &R, const 
     return hit ? stop : end - 1u;
 }
 
-__device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, const JP_LDS uint8_t *unzig, uint32_t *status) {
+__device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP_LDS uint32_t *ring, const JP_LDS uint8_t *unzig, uint32_t *status, ProgSync &y) {
     ProgRefine R;
+    uint32_t bi = 0;
     prog_bits_open(R.b, s.data, s.n_bytes, ring);
     prog_load_table(T, s.table[0]);
+    const JP_GLOBAL ProgHuffTable *const gt = (const JP_GLOBAL ProgHuffTable *)s.table[0];
     int16_t *const coefs = s.comp[0].coefs;
     uint64_t *const masks = s.comp[0].masks;
     const uint32_t block_w = s.comp[0].block_w, rows = s.rows, cols = s.cols, ss = s.ss;
@@ -387,8 +485,10 @@ __device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP
     bool bad = false;
     const uint32_t end = (uint32_t)s.se + 1u;
     // the masks of the block after this one are requested while this one is decoded
+    // (pipelined scans: only once the scans this one depends on are past that block — its masks are what they leave behind)
     uint64_t nz_next = 0, neg_next = 0;
     if (rows && cols) {
+        if (!prog_wait_for(y, 0u)) return false;
         nz_next = prog_load64(masks);
         neg_next = prog_load64(masks + 1u);
     }
@@ -403,6 +503,7 @@ __device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP
                 uint32_t nx = mx + 1u, ny = my;
                 if (nx == cols) nx = 0u, ny++;
                 if (ny < rows) {
+                    if (!prog_wait_for(y, bi + 1u)) return false;
                     const size_t nb = (size_t)ny * block_w + nx;
                     nz_next = prog_load64(masks + 2u * nb);
                     neg_next = prog_load64(masks + 2u * nb + 1u);
@@ -412,12 +513,13 @@ __device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP
             if (eob_run > 0u) {
                 eob_run--;
                 prog_refine_non_zeroes(R, unzig, ss, end, 64u);
+                prog_publish(y, ++bi);
                 continue;
             }
             uint32_t k = ss;
             while (k < end) {
                 prog_refill(R.b);
-                const uint32_t rs = prog_decode_ac(R.b, T, bad), r = rs >> 4, sz = rs & 15u;
+                const uint32_t rs = prog_decode_ac(R.b, T, gt, bad), r = rs >> 4, sz = rs & 15u;
                 if (bad) {
                     prog_flag(status, PROG_ST_BAD_CODE);
                     return false;
@@ -455,6 +557,7 @@ __device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP
                 const uint64_t neg = (R.neg & ~new_nz) | new_neg;
                 if (neg != R.neg) prog_store64(masks + 2u * blk + 1u, neg);
             }
+            prog_publish(y, ++bi);
         }
     return true;
 }
@@ -464,10 +567,13 @@ __device__ inline void prog_run_track(JP_LDS ProgLds &L, uint32_t lane, const Pr
     JP_LDS uint32_t *T = L.tab[lane], *ring = L.ring[lane];
     for (uint32_t i = 0; i < tr.n_scans; i++) {
         ProgScanRef s = *(const JP_GLOBAL ProgScan *)(tr.scans + i);
+        ProgSync y;
+        prog_sync_open(y, s, tr.status);
         bool ok;
-        if (s.ss == 0u) ok = prog_scan_dc(s, T, ring, tr.status);
-        else if (s.ah == 0u) ok = prog_scan_ac_first(s, T, ring, L.unzig, tr.status);
-        else ok = prog_scan_ac_refine(s, T, ring, L.unzig, tr.status);
+        if (s.ss == 0u) ok = prog_scan_dc(s, T, ring, tr.status, y);
+        else if (s.ah == 0u) ok = prog_scan_ac_first(s, T, ring, L.unzig, tr.status, y);
+        else ok = prog_scan_ac_refine(s, T, ring, L.unzig, tr.status, y);
+        prog_publish_end(y);  // (also when the scan gave up: whoever waits for it must not wait for good — the image is the host's by then)
         if (!ok) return;
     }
 }

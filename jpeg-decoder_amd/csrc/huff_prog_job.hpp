@@ -24,7 +24,9 @@
 namespace jpgpu {
 
 // One Huffman table in the form the progressive lanes use: the reference's own two-step procedure (src/huffman.rs:31-58) — an 8-bit
-// lookup, then the maxcode walk from length 9.  912 bytes: a lane keeps the table of its current scan in LDS.
+// lookup, then the maxcode walk from length 9.  912 bytes; a lane keeps the LOOKUP of its current scan's table in LDS (512 bytes: 42 kB
+// per workgroup of 64 lanes with their stream windows, three workgroups per CU) and takes the walk's tables — codes of nine bits and more
+// — from global memory.
 struct alignas(16) ProgHuffTable {
     uint16_t lut[256];  // per 8-bit prefix: symbol | code length << 8 (length 0: not a code of up to 8 bits — the walk decides)
     int32_t maxcode[16], delta[16];
@@ -34,7 +36,7 @@ struct alignas(16) ProgHuffTable {
 };
 static_assert(sizeof(ProgHuffTable) == 912, "layout");
 constexpr uint32_t PROG_TABLE_DWORDS = sizeof(ProgHuffTable) / 4u;  // 228
-constexpr uint32_t PROG_LANE_DWORDS = 257u;                          // a lane's LDS region: one table (or four DC lookups), skewed by one dword so that lane l starts in bank l
+constexpr uint32_t PROG_LANE_DWORDS = 129u;                          // a lane's LDS region: the 8-bit lookup of its scan's table (or two DC lookups of a byte per entry), skewed by one dword so that lane l starts in bank l
 
 struct ProgScanComp {
     int16_t *coefs;      // the component's plane in the coefficient arena (block-raster, natural order inside a block)
@@ -52,7 +54,14 @@ struct ProgScan {
     uint32_t ncomp, cols, rows;  // components; MCUs per row / rows the scan walks (decode_scan's loops, src/decoder.rs:871-1000)
     ProgScanComp comp[4];
     const ProgHuffTable *table[4];  // DC first: the distinct DC tables of the scan (comp[].table indexes them); AC scans: table[0]
+    // Scans of a track PIPELINED over lanes (one lane per scan instead of one per track): a scan may work on block b as soon as the
+    // scans it depends on — for every coefficient it covers, the last earlier scan that covered it — have completed block b.
+    uint32_t *progress;       // blocks (in walk order) this scan has completed, published every few blocks; PROG_DONE at its end.  nullptr: nobody waits
+    const uint32_t *wait[3];  // the progress words of the scans this one stays behind (nullptr: none)
+    uint32_t wait_whole;      // bit i: wait[i] walks its blocks in another order: it must have ENDED before this scan starts
+    uint32_t pad_;
 };
+constexpr uint32_t PROG_DONE = 0xffffffffu;
 
 struct ProgTrack {
     const ProgScan *scans;  // in stream order
@@ -62,6 +71,6 @@ struct ProgTrack {
 
 // status bits of a progressive image (bit 0 set with every one of them: the host decodes the image)
 constexpr uint32_t PROG_ST_HOST = 1u, PROG_ST_BAD_CODE = 2u, PROG_ST_BAD_DC = 4u, PROG_ST_BAND = 8u, PROG_ST_STAGING = 16u, PROG_ST_RANGE = 32u,
-                   PROG_ST_REFINE_SYMBOL = 128u;
+                   PROG_ST_REFINE_SYMBOL = 128u, PROG_ST_WAIT = 512u /* a lane gave up waiting for the scan it depends on */;
 
 }  // namespace jpgpu

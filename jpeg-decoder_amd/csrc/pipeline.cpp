@@ -539,7 +539,7 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         if (!p->prog_plans[i].scans.empty()) {
             elig.push_back(i);
             bytes += len[i];
-            tracks += p->prog_plans[i].n_tracks;
+            tracks += getenv("JPGPU_PROG_SERIAL") ? p->prog_plans[i].n_tracks : (uint32_t)p->prog_plans[i].scans.size();  // lanes: one per scan (pipelined) or per track
         } else if (p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
             n_prog_host++;
         }
@@ -556,8 +556,8 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         const double walk_ms = avg * (p->prog_dev_ns_per_byte > 0 ? p->prog_dev_ns_per_byte : 400.0) * 1e-6;
         const double per_dev = p->prog_dev_ms_per_image > 0 ? p->prog_dev_ms_per_image : 0.012;
         const double per_host = p->prog_host_ms_per_image > 0 ? p->prog_host_ms_per_image : avg * 32.0e-6 / (double)std::max<uint32_t>(1u, std::min<uint32_t>(p->pool->size(), 16u));
-        // lanes the machine holds at a time (two one-wave workgroups of 74 kB LDS per CU x 256 CUs x 64 lanes); more tracks than that walk in rounds
-        const double lanes = 32768.0, tracks_per_frame = (double)tracks / e;
+        // lanes the machine holds at a time (three one-wave workgroups of 42 kB LDS per CU x 256 CUs x 64 lanes); more than that walk in rounds
+        const double lanes = 49152.0, tracks_per_frame = (double)tracks / e;
         auto cost = [&](uint32_t cand) {
             const double t_host = (double)(e - cand + n_prog_host) * per_host;
             if (cand == 0) return t_host;

@@ -84,7 +84,27 @@ int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], i
     ProgLds *L = new ProgLds;
     memset(L, 0xAB, sizeof(*L));
     for (uint32_t l = 0; l < 64; l++) huff_fill_unzigzag(L->unzig, l);
-    if (order == 2) {
+    if (order == 3) {  // scans pipelined over lanes (huff_prog_job.hpp): one lane per scan with its waits, producers first (stream order)
+        const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
+        if (!pd.ok) {
+            delete L;
+            return -2;
+        }
+        std::vector<uint32_t> progress(plan.scans.size(), 0u);
+        for (size_t i = 0; i < plan.scans.size(); i++) {
+            scans[i].progress = &progress[i];
+            for (int w = 0; w < 3; w++)
+                if (pd.deps[i][w] >= 0) {
+                    scans[i].wait[w] = &progress[(size_t)pd.deps[i][w]];
+                    if (!host::prog_same_walk(plan.scans[i], plan.scans[(size_t)pd.deps[i][w]])) scans[i].wait_whole |= 1u << w;
+                }
+        }
+        for (size_t i = 0; i < plan.scans.size() && !(status & 1u); i++) {
+            ProgTrack tr{&scans[i], 1u, &status};
+            prog_run_track(*L, (uint32_t)(i * 5u) % 64u, tr);
+            if (progress[i] != PROG_DONE) status |= 0x8000u;  // a scan must announce its end, whatever happened
+        }
+    } else if (order == 2) {
         size_t longest = 0;
         for (auto &t : per_track) longest = std::max(longest, t.size());
         for (size_t step = 0; step < longest; step++)
