@@ -582,9 +582,14 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
             }
         }
         d = best_d;
-        if (p->prog_dev_ns_per_byte <= 0 && e >= 128u) d = std::max(d, 64u);  // the probe: the next call knows the walk
+        // Until BOTH rates have been measured the host keeps the frames — its route is the pinned one, and a guess in the device's favour
+        // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames) —
+        // except a probe of 64 frames, so that the next call knows the walk.
+        const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_ms_per_image > 0;
+        if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : (p->prog_host_ms_per_image <= 0 ? std::min<uint32_t>(d, e >= 128u ? e - 64u : 0u) : d);
         // a call of the same shape as the last one keeps its split while the model does not object by more than a tenth in time
-        if (e == p->prog_last_e && p->prog_last_d <= e && cost(p->prog_last_d) <= 1.10 * cost(d) && !(p->prog_last_d == 0 && d > 0 && p->prog_dev_ns_per_byte <= 0)) d = p->prog_last_d;
+        else if (e == p->prog_last_e && p->prog_last_d <= e && cost(p->prog_last_d) <= 1.10 * cost(d))
+            d = p->prog_last_d;
     }
     p->prog_last_e = e;
     p->prog_last_d = d;
