@@ -825,6 +825,12 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const bool light = (mode & DEVICE_ENTROPY_LIGHT) != 0, input_pinned = light && (mode & DEVICE_ENTROPY_INPUT_PINNED) != 0;
     size_t n_raw_jobs = 0;
     uint32_t max_pieces = 0, light_images = 0;
+    struct PinnedSpan {
+        const uint8_t *start, *end;  // the caller's bytes [start, end): the scans of consecutive files and what lies between them
+        size_t mirror_off;           // where `start` lands in the span region of the mirror
+    };
+    std::vector<PinnedSpan> spans;
+    std::vector<size_t> raw_mirror_off;  // per raw scan, in listing order: its offset in the span region
     size_t n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     // Files of one encoder repeat the same Huffman tables (27 kB per scan in device form): a scan whose tables equal those of
     // the scan before it shares that copy — one in the staging block, one upload, one set of lines in the L2.
@@ -848,6 +854,18 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t pieces = (uint32_t)((stuffed + 15u + UNSTUFF_PIECE - 1u) / UNSTUFF_PIECE);
                 max_pieces = std::max(max_pieces, pieces);
                 scratch_bytes += align_up(((size_t)pieces + 1u) * 4u, 16);
+                if (input_pinned) {
+                    // Pinned input: files that follow one another in the caller's memory (a loader's arena: gaps of up to 8 kB — the
+                    // next file's headers) travel in ONE copy, headers and gaps included; a scan's place in the mirror is then its
+                    // place in the span.  (One hipMemcpyAsync per file: 4,096 calls per call of 4,096 files — 114 ms on 16 CPUs.)
+                    const uint8_t *src = images[k].file + ps.data_off;
+                    if (spans.empty() || src < spans.back().end || (size_t)(src - spans.back().end) > 8192u) {
+                        const size_t at = spans.empty() ? 0 : align_up(spans.back().mirror_off + (size_t)(spans.back().end - spans.back().start), 16) + 16;
+                        spans.push_back(PinnedSpan{src, src, at});
+                    }
+                    raw_mirror_off.push_back(spans.back().mirror_off + (size_t)(src - spans.back().start));
+                    spans.back().end = src + stuffed;
+                }
             }
             if (const DriGeom g = dri_geom(ps); g.chunked) {
                 const size_t chunks = g.too_large ? 0 : (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
@@ -870,7 +888,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const size_t off_tables = align_up(off_ujobs + n_raw_jobs * sizeof(UnstuffJob), 16);
     const size_t off_seg = align_up(off_tables + n_table_sets * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
-    const size_t off_mirror = align_up(total, 256), dev_end = light ? off_mirror + data_bytes + 64 : total;  // (light: what is uploaded lands in the mirror)
+    // (light: what is uploaded lands in the mirror — a copy of the data area's layout, and behind it, with pinned input, the spans)
+    const size_t span_bytes = spans.empty() ? 0 : spans.back().mirror_off + (size_t)(spans.back().end - spans.back().start) + 64;
+    const size_t off_mirror = align_up(total, 256), off_spans = align_up(off_mirror + data_bytes + 64, 256), dev_end = light ? off_spans + span_bytes : total;
     const size_t off_scratch = align_up(dev_end, 256), total_dev = scratch ? dev_end : off_scratch + scratch_bytes;
     if (scratch && scratch_bytes > scratch->cap) {  // (hipFree waits for whatever still uses the block)
         if (scratch->d) (void)hipFree(scratch->d);
@@ -1028,9 +1048,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 if (raw_scan) {
                     UnstuffJob &uj = ujobs[ui++];
                     memset(&uj, 0, sizeof(uj));
-                    uj.raw = d + off_mirror + (dcur - off_data);  // (16-byte aligned: the kernels take any alignment)
+                    // (the data area's layout in the mirror, 16-byte aligned — or the scan's place in its span: the kernels take any alignment)
+                    uj.raw = input_pinned ? d + off_spans + raw_mirror_off[ui - 1u] : d + off_mirror + (dcur - off_data);
                     uj.raw_bytes = (uint32_t)stuffed;
-                    uj.n_pieces = (uint32_t)((stuffed + UNSTUFF_PIECE - 1u) / UNSTUFF_PIECE);
+                    uj.n_pieces = (uint32_t)((((uintptr_t)uj.raw & 15u) + stuffed + UNSTUFF_PIECE - 1u) / UNSTUFF_PIECE);
                     uj.dst = d + dcur;
                     uj.piece_kept = reinterpret_cast<uint32_t *>(xs + xcur);
                     xcur += align_up(((size_t)uj.n_pieces + 1u) * 4u, 16);
@@ -1156,13 +1177,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             }
         };
         if (input_pinned) {
-            // one caller: 4,096 hipMemcpyAsync calls from a team of sixteen threads made the call twice as long as from one (108 against
-            // 53 ms; the runtime serialises them)
+            // one caller, one copy per span of adjacent files (4,096 hipMemcpyAsync calls from a team of sixteen threads made the call
+            // twice as long as from one: 108 against 53 ms; and from one thread on 16 CPUs still 114 ms)
             (void)device_for_copies;
-            for (uint32_t t = 0; t < n_tasks; t++)
-                if (copies[t].raw &&
-                    hipMemcpyAsync(d + off_mirror + copies[t].dst_off, copies[t].src + copies[t].ps->seg_off[0], copies[t].ps->seg_off[1] - copies[t].ps->seg_off[0], hipMemcpyHostToDevice, raw_stream) != hipSuccess)
-                    raw_copy_failed.store(1);
+            for (const PinnedSpan &sp : spans)
+                if (hipMemcpyAsync(d + off_spans + sp.mirror_off, sp.start, (size_t)(sp.end - sp.start), hipMemcpyHostToDevice, raw_stream) != hipSuccess) raw_copy_failed.store(1);
         }
         if (par && n_tasks > 1) (*par)(n_tasks, staged);
         else
