@@ -41,6 +41,7 @@ def lib():
         L.emu_huff_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.emu_prog_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.emu_prog_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_int]
+        L.emu_prog_dependencies.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.emu_unstuff.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.emu_unstuff.restype = C.c_int
         _LIB = L

@@ -41,6 +41,25 @@ int emu_prog_plan(const uint8_t *data, size_t len, jpgpu_image_desc *desc, uint3
     }
 }
 
+// The dependencies of scan j as the launch sees them (host::prog_plan_dependencies): deps[3] (-1: none), rank, whole[3] (1: the producer
+// must have ended before the scan starts: another walk order).  Returns the number of scans, -1: not eligible, -2: walked as tracks.
+int emu_prog_dependencies(const uint8_t *data, size_t len, int32_t *deps, uint32_t *rank, uint32_t *whole, uint32_t cap) {
+    Frontend fe(data, len, Frontend::Borrowed{});
+    fe.read_info();
+    ProgPlan plan;
+    if (!fe.plan_progressive_scans(plan)) return -1;
+    const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
+    if (!pd.ok) return -2;
+    for (size_t j = 0; j < plan.scans.size() && j < cap; j++) {
+        rank[j] = pd.rank[j];
+        for (int w = 0; w < 3; w++) {
+            deps[3 * j + w] = pd.deps[j][w];
+            whole[3 * j + w] = pd.deps[j][w] >= 0 && !host::prog_same_walk(plan.scans[j], plan.scans[(size_t)pd.deps[j][w]]) ? 1u : 0u;
+        }
+    }
+    return (int)plan.scans.size();
+}
+
 // Decode into planes[c] (zero-filled by the caller).  order: 0 = tracks in plan order, 1 = reversed, 2 = interleaved scan by scan
 // across tracks (round robin: what concurrent lanes may do to one another's dwords).  Returns the status word (0: decoded).
 int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], int order) {

@@ -113,6 +113,31 @@ def test_tracks_are_the_connected_bands():
     assert nt == 2  # DC | AC
 
 
+def test_scans_pipelined_over_lanes_wait_for_the_last_writer_of_their_coefficients():
+    """huff_prog_job.hpp, "a lane per scan": a scan stays behind, block for block, the LAST earlier scan that covered each of its
+    coefficients — tower_progressive.jpg (libjpeg's default script): DC refinement behind DC first; Y's first refinement behind BOTH
+    first scans of its band (1-5 and 6-63), its second behind the first; the first scans behind nobody."""
+    data = open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    deps = np.full(3 * 16, -7, np.int32)
+    rank = np.zeros(16, np.uint32)
+    whole = np.zeros(3 * 16, np.uint32)
+    n = emu.lib().emu_prog_dependencies(buf, len(data), deps.ctypes.data, rank.ctypes.data, whole.ctypes.data, 16)
+    assert n == 10
+    d = [sorted(int(x) for x in deps[3 * j:3 * j + 3] if x >= 0) for j in range(n)]
+    # scans in stream order: 0 DC first | 1 Y 1-5 | 2 Cr 1-63 | 3 Cb 1-63 | 4 Y 6-63 | 5 Y refine 2:1 | 6 DC refine | 7 Cr refine | 8 Cb refine | 9 Y refine 1:0
+    assert d == [[], [], [], [], [], [1, 4], [0], [2], [3], [5]]
+    assert list(rank[:n]) == [0, 0, 0, 0, 0, 1, 1, 1, 1, 2]
+    assert not whole[:3 * n].any()  # every pair walks the same blocks in the same order: block for block
+    # a frame whose DC refinement is NOT interleaved like its first DC scan must wait for the whole of it
+    pytest.importorskip("PIL")
+    for sub in ("4:2:0", "4:4:4"):
+        f = _pil(64, 48, sub)
+        b2 = (C.c_uint8 * len(f)).from_buffer_copy(f)
+        n2 = emu.lib().emu_prog_dependencies(b2, len(f), deps.ctypes.data, rank.ctypes.data, whole.ctypes.data, 16)
+        assert n2 == 10 and max(rank[:n2]) == 2
+
+
 def _damage(rng, base):
     d = bytearray(base)
     lo = max(2, len(d) // 5)
