@@ -6,7 +6,8 @@
  * parser (src/parser.rs), Huffman / progressive entropy decoder (src/huffman.rs,
  * src/decoder.rs:794-1298) and the marker loop (src/decoder.rs:297-615) are restated in C++
  * (jpeg-decoder_amd/csrc/host) and feed exactly what the crate hands to `Worker::append_row`.
- * Entropy decoding runs on the host (inherently serial); every pixel is produced on the GPU.
+ * Entropy decoding runs on the host (inherently serial per stream) for single images and whatever the device routes of the pipeline
+ * below do not take; every pixel is produced on the GPU.
  */
 #ifndef JPGPU_DECODER_H
 #define JPGPU_DECODER_H
@@ -131,8 +132,12 @@ enum {
     JPGPU_PIPELINE_DEVICE_ENTROPY = 4u /* 8-bit sequential Huffman streams with one all-component scan: send the entropy-coded
                                    * bytes and decode them on the device with the self-synchronising chunk decoder (one lane
                                    * per chunk of 64 bytes to 4 kB, csrc/huff_sync_core.hpp; a restart segment — src/decoder.rs:920-956:
-                                   * segments are independent — is a scan in miniature with chunk slots of its own); every
-                                   * other stream, and any stream the device decoder flags, takes the host path */
+                                   * segments are independent — is a scan in miniature with chunk slots of its own); since 0.2 also
+                                   * PROGRESSIVE frames (src/decoder.rs:1086-1298: 8-bit, no restart interval, every coefficient
+                                   * refined one bit at a time): one lane per scan, the scans of a band pipelined block by block,
+                                   * coefficients accumulated in the arena (csrc/huff_prog_core.hpp) — for as many of a call's frames as
+                                   * the dispatcher gives the device (see JPGPU_PIPELINE_PROGRESSIVE_ON_HOST); every other stream, and
+                                   * any stream a device decoder flags, takes the host path */
     /* (8u: round 2-3's per-scan delta transport for progressive streams — measured 2.5 x slower than the compact planes, deleted in round 4;
      * the bit is REFUSED since 0.2, like every unknown bit: JPGPU_ERR_FORMAT) */
     , JPGPU_PIPELINE_GATHER = 16u /* pipelines over several devices: every device copies each sub-batch's pixels to the FIRST device of

@@ -1253,7 +1253,7 @@ bool jpgpu::batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]) {
 //   [ status: n x u32 | ProgTrack[] | ProgScan[] | ProgHuffTable[] | scan bytes ]     device only: the masks (16 bytes per block)
 int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressiveImage *images, uint32_t n, void *hip_stream,
                                            const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream,
-                                           DeviceScratch *scratch) {
+                                           DeviceScratch *scratch, bool allow_pipelined) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
     int rc = use_device(b->device, b->err);
     if (rc) return rc;
@@ -1279,7 +1279,8 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     // Scans of a track pipelined over lanes (huff_prog_job.hpp): one lane per SCAN, a progress word each (behind the masks, zeroed with
     // them), lanes of one dependency rank in waves of their own — a lane must never wait for a lane of its own wave, and the
     // producers must come first in launch order.  JPGPU_PROG_SERIAL=1: one lane per track, as first built (A/B).
-    static const bool serial_tracks = getenv("JPGPU_PROG_SERIAL") != nullptr;
+    static const bool serial_env = getenv("JPGPU_PROG_SERIAL") != nullptr;
+    const bool serial_tracks = serial_env || !allow_pipelined;
     const size_t progress_off = mask_bytes;
     mask_bytes += align_up(n_scans * 4u, 256);
     const size_t max_lanes = n_tracks + n_scans + 64u * 64u;  // (a padding of < 64 lanes per rank, up to 64 ranks: more are walked serially, as tracks)

@@ -205,42 +205,67 @@ inline bool same_definition(const HuffTable &t, const uint8_t bits[16], const ui
 }
 // Where the tables live (round 4; rounds 2-3 kept eight 5.5 kB copies per calling thread — the C API is driven by a thousand
 // decoding threads in tests/test_gpu_concurrency.py, and whatever a thread-local holds stays until its thread ends):
-// ONE immutable copy per definition in a process-wide registry (a mutex, taken only when a thread meets a definition for the
-// first time), and per thread eight POINTERS to the tables it used last — the hit path takes no lock (a first version with a
-// reader-writer lock around the registry made the header phase of 4,096 files 18 ms instead of 1.8: 32 threads x 16 k lock
-// operations on one cache line).
+// ONE immutable copy per definition in a process-wide registry, and per thread POINTERS to the tables it used last — the hit
+// path takes no lock (a first version with a reader-writer lock around the registry made the header phase of 4,096 files 18 ms
+// instead of 1.8: 32 threads x 16 k lock operations on one cache line).
+// Round 5: the registry is cut into 64 shards by a hash of the definition, a mutex and four tables each.  With ONE mutex and 64
+// tables behind it a batch of progressive files from a real encoder — twelve OPTIMISED tables per file, no two files alike — sent
+// every thread through that mutex two dozen times per file: the header phase of 4,096 such files took 108 ms on 16 CPUs (10 ms of
+// work), 8 threads planned 87 k files/s where one plans 26 k.
+inline uint32_t definition_hash(const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)(ac ? 1 : 0);
+    auto mix = [&](uint64_t x) { h = (h ^ x) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; };
+    uint64_t w;
+    memcpy(&w, bits, 8), mix(w);
+    memcpy(&w, bits + 8, 8), mix(w);
+    int i = 0;
+    for (; i + 8 <= n; i += 8) memcpy(&w, vals + i, 8), mix(w);
+    w = 0;
+    if (i < n) memcpy(&w, vals + i, (size_t)(n - i)), mix(w);
+    mix((uint64_t)n);
+    return (uint32_t)(h >> 32);
+}
 inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
-    constexpr int kSlots = 32, kShared = 64;  // (round 5: 8 / 32 — a progressive file of libjpeg's default script defines twelve tables: with eight slots per
-    // thread every file of a batch went through the shared registry's mutex a dozen times, 4,096 files on 32 threads)
+    constexpr int kSlots = 32, kShards = 64, kPerShard = 4;  // (slots: a progressive file of libjpeg's default script defines twelve tables)
     thread_local std::shared_ptr<const HuffTable> mine[kSlots];
+    thread_local uint32_t mine_hash[kSlots];
     thread_local int next = 0;
-    if (n > 0 && n <= 256)
+    const bool sane = n > 0 && n <= 256;
+    const uint32_t hash = sane ? definition_hash(bits, vals, n, ac) : 0u;
+    if (sane)
         for (int i = 0; i < kSlots; i++)
-            if (mine[i] && same_definition(*mine[i], bits, vals, n, ac)) {
+            if (mine[i] && mine_hash[i] == hash && same_definition(*mine[i], bits, vals, n, ac)) {
                 dst = *mine[i];
                 return;
             }
     // (the registry is leaked on purpose: pool threads of a host that is shutting down may still be in here while statics are
     // destroyed — ADVICE r4)
-    static std::mutex &m = *new std::mutex;
-    static std::shared_ptr<const HuffTable> *const shared = new std::shared_ptr<const HuffTable>[kShared];
-    static int shared_next = 0;
+    struct alignas(64) Shard {
+        std::mutex m;
+        std::shared_ptr<const HuffTable> e[kPerShard];
+        uint32_t hash[kPerShard] = {0, 0, 0, 0};
+        int next = 0;
+    };
+    static Shard *const shards = new Shard[kShards];
+    Shard &sh = shards[hash % kShards];
     std::shared_ptr<const HuffTable> found;
-    if (n > 0 && n <= 256) {
-        std::lock_guard<std::mutex> g(m);
-        for (int i = 0; i < kShared && !found; i++)
-            if (shared[i] && same_definition(*shared[i], bits, vals, n, ac)) found = shared[i];
+    if (sane) {
+        std::lock_guard<std::mutex> g(sh.m);
+        for (int i = 0; i < kPerShard && !found; i++)
+            if (sh.e[i] && sh.hash[i] == hash && same_definition(*sh.e[i], bits, vals, n, ac)) found = sh.e[i];
     }
     if (!found) {
         auto fresh = std::make_shared<HuffTable>();
         fresh->build(bits, vals, n, ac);  // (throws on a malformed definition: nothing is cached)
         found = fresh;
-        std::lock_guard<std::mutex> g(m);
-        shared[shared_next] = found;
-        shared_next = (shared_next + 1) % kShared;
+        std::lock_guard<std::mutex> g(sh.m);
+        sh.e[sh.next] = found;
+        sh.hash[sh.next] = hash;
+        sh.next = (sh.next + 1) % kPerShard;
     }
     dst = *found;
     mine[next] = std::move(found);
+    mine_hash[next] = hash;
     next = (next + 1) % kSlots;
 }
 

@@ -97,9 +97,13 @@ struct DeviceProgressiveImage {
     const uint8_t *file;
     const host::ProgPlan *plan;  // Frontend::plan_progressive_scans
 };
+// `pipelined`: a lane per SCAN, scans of a band staying behind one another block by block (huff_prog_job.hpp) — only for launches whose
+// lanes, together with those of the launches that run beside them, FIT the device (48 k lanes): waiting lanes hold their slots, and two
+// oversubscribed launches could keep each other's producers from ever being dispatched (a lane gives up after seconds and flags its
+// image, so the answer stays right — but slow).  false: a lane per track, nobody waits for anybody.
 int batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressiveImage *images, uint32_t n, void *hip_stream,
                                     const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
-                                    void *copy_stream = nullptr, DeviceScratch *scratch = nullptr);
+                                    void *copy_stream = nullptr, DeviceScratch *scratch = nullptr, bool pipelined = true);
 bool batch_progressive_kernel_ms(jpgpu_batch *b, float *ms);  // duration of the last launch's track kernel (events; stream synchronised)
 bool batch_phase_times(jpgpu_batch *b, float ms[4]);  // JPGPU_BATCH_KERNEL_TIMES, batch.cpp
 bool batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]);  // (+ JPGPU_PIPE_TRACE) event times relative to ref's first event

@@ -285,7 +285,7 @@ struct jpgpu_pipeline {
     // top of the walk (staging, upload, range scan, pixel kernels)
     double prog_host_ms_per_image = 0.0, prog_dev_ms_per_image = 0.0;
     uint32_t prog_last_e = 0, prog_last_d = 0;  // the last call's eligible frames and how many of them the device got (a call of the same
-                                                 // shape keeps the split unless the rates say it is off by a fifth: sub-batches — arenas,
+                                                 // shape keeps its route unless the rates say it is off by a tenth: sub-batches — arenas,
                                                  // pinned staging — are reused only while their composition repeats)
     std::vector<SubBatch> subs;          // kept across calls while the geometry sequence repeats
     uint32_t n_subs = 0;                 // sub-batches used by the last call
@@ -330,6 +330,15 @@ static const jpgpu_pipeline *child_of(const jpgpu_pipeline *p, uint32_t &image) 
     return c;
 }
 static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags);
+// Lanes up to which a call's progressive frames are walked a lane per SCAN (pipelined, huff_prog_job.hpp): all the call's launches run
+// side by side and lanes that wait hold their slots, so they must fit the device at once (host_common.hpp) — 46 k of the 48 k lanes
+// it holds (every rank of every launch is padded to whole waves).  Beyond: a lane per track.  JPGPU_PROG_LANES_MAX: tests, A/B.
+static uint64_t prog_lanes_max() {
+    if (getenv("JPGPU_PROG_SERIAL")) return 0;
+    const char *e = getenv("JPGPU_PROG_LANES_MAX");
+    return e ? (uint64_t)std::max<long>(atol(e), 0) : 46000u;
+}
+
 static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n);
 static void pin_to(const std::vector<int> &cpus) {
     if (cpus.empty()) return;
@@ -524,22 +533,22 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
 
 // Progressive frames: the device walks every frame's tracks side by side, one lane each — a launch takes as long as ONE
 // lane's walk of the longest track, whether it holds ten frames or ten thousand (while they fit the machine: 512 waves of 64 lanes) —
-// and a host thread decodes a frame in a fraction of that time, one after the other.  So a call's eligible frames are SPLIT: the
-// device takes as many as the host's threads would not have finished by the time the walk ends; the host decodes the rest meanwhile
-// (entropy decoding on its threads, compact planes uploaded, as in round 4).  A few hundred frames on many cores: nearly all stay on
-// the host; thousands, or few cores: most go to the device.  The two rates come from this pipeline's earlier calls (first call: a
-// guess, and a probe of a few frames so that the next call knows).  JPGPU_PIPE_PROG_DEVICE_PERCENT pins the share (tests, A/B).
+// and a host thread decodes a frame in a fraction of that time, one after the other.  So a call's eligible frames go to ONE of the
+// two: the host (entropy decoding on its threads, compact planes uploaded, as in round 4) — a few hundred frames on many cores — or
+// the device: thousands, or few cores.  The two rates come from this pipeline's earlier calls (first call: the host, and a probe of
+// 64 frames on the device so that the next call knows).  JPGPU_PIPE_PROG_DEVICE_PERCENT pins the device's share (tests, A/B).
 // Returns how many frames keep their device plan; the others get a fresh front-end for the host path.
 static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
     std::vector<uint32_t> elig;
-    uint64_t bytes = 0, tracks = 0;
+    uint64_t bytes = 0, tracks = 0, scans = 0;
     uint32_t n_prog_host = 0;  // progressive frames the host decodes anyway (not eligible)
     for (uint32_t i = 0; i < n; i++) {
         if (p->status[i] != JPGPU_OK) continue;
         if (!p->prog_plans[i].scans.empty()) {
             elig.push_back(i);
             bytes += len[i];
-            tracks += getenv("JPGPU_PROG_SERIAL") ? p->prog_plans[i].n_tracks : (uint32_t)p->prog_plans[i].scans.size();  // lanes: one per scan (pipelined) or per track
+            tracks += p->prog_plans[i].n_tracks;
+            scans += p->prog_plans[i].scans.size();
         } else if (p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
             n_prog_host++;
         }
@@ -557,38 +566,28 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         const double per_dev = p->prog_dev_ms_per_image > 0 ? p->prog_dev_ms_per_image : 0.012;
         const double per_host = p->prog_host_ms_per_image > 0 ? p->prog_host_ms_per_image : avg * 32.0e-6 / (double)std::max<uint32_t>(1u, std::min<uint32_t>(p->pool->size(), 16u));
         // lanes the machine holds at a time (three one-wave workgroups of 42 kB LDS per CU x 256 CUs x 64 lanes); more than that walk in rounds
-        const double lanes = 49152.0, tracks_per_frame = (double)tracks / e;
+        // (a lane per scan while they all fit — prog_lanes_max() — else a lane per track)
+        const double lanes = 49152.0, tracks_per_frame = (double)(scans <= prog_lanes_max() ? scans : tracks) / e;
         auto cost = [&](uint32_t cand) {
             const double t_host = (double)(e - cand + n_prog_host) * per_host;
             if (cand == 0) return t_host;
             const double rounds = std::ceil(cand * tracks_per_frame / lanes);
             return std::max(t_host, 1.0 + rounds * walk_ms + cand * per_dev);
         };
-        // Three candidates before any split: everything on the host (the pinned path: a tie goes there), everything on the device, and the
-        // best split — which must beat BOTH by 15 % of the model's time to be chosen: with both routes busy the host's threads and
-        // the device route's staging team compete for the same cores and the host's sub-batches queue behind the device's (measured:
-        // 3,008 of 4,096 frames on the device 125 ms, all of them 81 ms, where the model saw 3 % in favour of the split)
+        // Two candidates: everything on the host (the pinned path: a tie goes there) or everything on the device.  A SPLIT — the device
+        // takes what the host's threads would not finish during the walk — was built and is gone: with both routes busy the host's
+        // threads and the device route's staging team compete for the same cores and the host's sub-batches queue behind the
+        // device's (measured twice: 3,008 of 4,096 frames on the device 125 ms, 3,136 of them 104 ms — all of them 61-81 ms)
         uint32_t best_d = 0;
-        double best_t = cost(0);
-        if (cost(e) < best_t * 0.97) {
-            best_t = cost(e);
-            best_d = e;
-        }
-        for (uint32_t cand = 64u; cand + 64u <= e; cand += 64u) {  // (multiples of 64: a wave of tracks each)
-            const double t = cost(cand);
-            if (t < best_t * 0.85) {
-                best_t = t;
-                best_d = cand;
-            }
-        }
+        if (cost(e) < cost(0) * 0.97) best_d = e;
         d = best_d;
         // Until BOTH rates have been measured the host keeps the frames — its route is the pinned one, and a guess in the device's favour
         // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames) —
         // except a probe of 64 frames, so that the next call knows the walk.
         const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_ms_per_image > 0;
         if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : (p->prog_host_ms_per_image <= 0 ? std::min<uint32_t>(d, e >= 128u ? e - 64u : 0u) : d);
-        // a call of the same shape as the last one keeps its split while the model does not object by more than a tenth in time
-        else if (e == p->prog_last_e && p->prog_last_d <= e && cost(p->prog_last_d) <= 1.10 * cost(d))
+        // a call of the same shape as the last one keeps its route while the model does not object by more than a tenth in time
+        else if (e == p->prog_last_e && (p->prog_last_d == 0u || p->prog_last_d == e) && cost(p->prog_last_d) <= 1.10 * cost(d))
             d = p->prog_last_d;
     }
     p->prog_last_e = e;
@@ -908,6 +907,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const bool light_default = light_env ? atoi(light_env) != 0 : (p->pool->size() <= 16u || n_dev <= 384u);
     const bool host_light = input_pinned || (flags & JPGPU_PIPELINE_HOST_LIGHT) != 0 || ((flags & JPGPU_PIPELINE_HOST_STAGED) == 0 && light_default);
     const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u);
+    // Progressive frames for the device: a lane per scan only while ALL the call's lanes fit the device at once (prog_lanes_max())
+    uint64_t prog_lanes = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (p->status[i] == JPGPU_OK) prog_lanes += p->prog_plans[i].scans.size();
+    const bool prog_pipelined = prog_lanes <= prog_lanes_max();
     double prog_dev_extra_ms = 0;  // launches of progressive sub-batches: host time of the launch calls + range scan + pixel kernels (device), summed
     uint32_t device_rejected = 0, device_images = 0;
     double dev_ms[4] = {0, 0, 0, 0};  // JPGPU_BATCH_KERNEL_TIMES: phases of the device entropy path, summed over the sub-batches
@@ -1009,7 +1013,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                             device_prog_images += (uint32_t)dv.size();
                             okk = jpgpu::batch_device_progressive_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
                                                                          p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
-                                                                         &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute]) == JPGPU_OK;
+                                                                         &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], prog_pipelined) == JPGPU_OK;
                             prog_dev_extra_ms += now_ms() - l0;
                         } else {
                             std::vector<jpgpu::DeviceEntropyImage> list;
