@@ -1334,6 +1334,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         uint32_t first_scan, n_scans, image_k;
         uint64_t weight;  // bytes of entropy-coded data the lane walks
         uint32_t rank;    // pipelined scans: how many scans deep its dependencies go (0: none); serial tracks: 0
+        uint32_t kind;    // pipelined scans: which scan of its frame's script it is (band, approximation, first component); serial tracks: 0
     };
     std::vector<TrackOrder> order;
     order.reserve(n_tracks);
@@ -1406,12 +1407,14 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
                     sc.wait[w] = reinterpret_cast<const uint32_t *>(dm + progress_off) + si_of[(uint32_t)deps[j][w]];
                     if (!host::prog_same_walk(pl.scans[j], pl.scans[(uint32_t)deps[j][w]])) sc.wait_whole |= 1u << w;  // (else block for block)
                 }
-                order.push_back(TrackOrder{(uint32_t)si_of[j], 1u, k, pl.scans[j].stuffed_bytes, rank[j]});
+                const host::ProgPlannedScan &pj = pl.scans[j];
+                const uint32_t kind = ((uint32_t)pj.ss << 24) | ((uint32_t)pj.se << 16) | ((uint32_t)pj.ah << 12) | ((uint32_t)pj.al << 8) | (pj.comp[0].frame_index << 4) | pj.ncomp;
+                order.push_back(TrackOrder{(uint32_t)si_of[j], 1u, k, pj.stuffed_bytes, rank[j], kind});
             }
         } else {
             size_t at = first_si;
             for (uint32_t t = 0; t < pl.n_tracks; t++) {
-                TrackOrder to{(uint32_t)at, 0u, k, 0u, 0u};
+                TrackOrder to{(uint32_t)at, 0u, k, 0u, 0u, 0u};
                 for (uint32_t j = 0; j < ns; j++)
                     if (pl.scans[j].track == t) {
                         to.weight += pl.scans[j].stuffed_bytes;
@@ -1427,9 +1430,12 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         }
     }
     // Lanes in launch order: by dependency rank (producers in front: workgroups are dispatched in order, so whatever a lane waits for is
-    // resident or done), every rank starting a wave of its own (a lane never waits for a lane of its own wave), and inside a rank heavy
-    // lanes first, like with like: the 64 lanes of a wave then walk scans of the same kind and about the same length
-    std::stable_sort(order.begin(), order.end(), [](const TrackOrder &a, const TrackOrder &c) { return a.rank != c.rank ? a.rank < c.rank : a.weight > c.weight; });
+    // resident or done), every rank starting a wave of its own (a lane never waits for a lane of its own wave), and inside a rank like
+    // with like — the same scan of the frames' scripts side by side (a wave whose lanes walk DC, first AC and refinement scans runs the
+    // three loops one after the other), heavy lanes first: the 64 lanes of a wave walk scans of the same kind and about the same length
+    std::stable_sort(order.begin(), order.end(), [](const TrackOrder &a, const TrackOrder &c) {
+        return a.rank != c.rank ? a.rank < c.rank : (a.kind != c.kind ? a.kind < c.kind : a.weight > c.weight);
+    });
     size_t n_lanes = 0;
     for (size_t t = 0; t < order.size(); t++) {
         if (t > 0 && order[t].rank != order[t - 1].rank)

@@ -284,6 +284,7 @@ struct jpgpu_pipeline {
     // was saturated — CPU contention with the device route's staging included), and what one more frame adds to the device route on
     // top of the walk (staging, upload, range scan, pixel kernels)
     double prog_host_ms_per_image = 0.0, prog_dev_ms_per_image = 0.0;
+    uint32_t prog_calls = 0;                     // calls with eligible progressive frames so far (the first one's host times are cold: not a rate)
     uint32_t prog_last_e = 0, prog_last_d = 0;  // the last call's eligible frames and how many of them the device got (a call of the same
                                                  // shape keeps its route unless the rates say it is off by a tenth: sub-batches — arenas,
                                                  // pinned staging — are reused only while their composition repeats)
@@ -582,10 +583,11 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         if (cost(e) < cost(0) * 0.97) best_d = e;
         d = best_d;
         // Until BOTH rates have been measured the host keeps the frames — its route is the pinned one, and a guess in the device's favour
-        // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames) —
-        // except a probe of 64 frames, so that the next call knows the walk.
+        // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames).
+        // First call: a probe of 64 frames on the device, so that the next call knows the walk (the host's times of that call are
+        // cold — allocations, first touches — and not taken for a rate); second call: the host, all of them; from the third on, the model.
         const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_ms_per_image > 0;
-        if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : (p->prog_host_ms_per_image <= 0 ? std::min<uint32_t>(d, e >= 128u ? e - 64u : 0u) : d);
+        if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : 0u;
         // a call of the same shape as the last one keeps its route while the model does not object by more than a tenth in time
         else if (e == p->prog_last_e && (p->prog_last_d == 0u || p->prog_last_d == e) && cost(p->prog_last_d) <= 1.10 * cost(d))
             d = p->prog_last_d;
@@ -1218,15 +1220,20 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         const double r = prog_host_ms * 1e6 / (double)prog_host_bytes;
         p->prog_host_ns_per_byte = p->prog_host_ns_per_byte > 0 ? 0.5 * (p->prog_host_ns_per_byte + r) : r;
     }
-    if (prog_host_images >= 2u * p->pool->size() && prog_host_images == n_host_images) {  // (a saturated pool that decoded nothing else)
+    if (prog_host_bytes || device_prog_images) p->prog_calls++;
+    // (a saturated pool that decoded next to nothing else, and not in the first such call: allocations and first touches are in there)
+    if (p->prog_calls >= 2u && prog_host_images >= 2u * p->pool->size() && (uint64_t)prog_host_images * 10u >= (uint64_t)n_host_images * 9u) {
         const double r = (t3 - t2) / prog_host_images;
         p->prog_host_ms_per_image = p->prog_host_ms_per_image > 0 ? 0.5 * (p->prog_host_ms_per_image + r) : r;
     }
     if (device_prog_images && prog_dev_ms > 0) {
         const double r = prog_dev_ms * 1e6 / ((double)prog_dev_bytes / device_prog_images);
         p->prog_dev_ns_per_byte = p->prog_dev_ns_per_byte > 0 ? 0.5 * (p->prog_dev_ns_per_byte + r) : r;
-        if (prog_dev_extra_ms > 0) {
-            const double o = prog_dev_extra_ms / device_prog_images;
+        // (what a frame adds on top of the walk: only from launches of some size — the probe's 64 frames carry the launch's fixed
+        // costs, in a pipeline's first call the allocations too: a figure of 5 ms per frame from there kept 4,096-frame calls on the
+        // host for good, 410-490 ms against 65)
+        if (prog_dev_extra_ms > 0 && device_prog_images >= 512u) {
+            const double o = std::min(prog_dev_extra_ms / device_prog_images, 0.05);
             p->prog_dev_ms_per_image = p->prog_dev_ms_per_image > 0 ? 0.5 * (p->prog_dev_ms_per_image + o) : o;
         }
     }
