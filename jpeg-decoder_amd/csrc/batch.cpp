@@ -713,6 +713,36 @@ static uint32_t env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t h
 // The range statistics of the decoded coefficients are a by-product of the kernels that write them (HuffSyncJob::stats ->
 // the batch's d_stats; round 2 ran range_scan_kernel over the arena afterwards and read the result back).
 namespace {
+// A scan as the file holds it, into the pinned staging block (host light): the destination is read by the copy engine and never by
+// this CPU, so the stores go past the caches — a plain memcpy of 400 kB reads every destination line before it overwrites it, and
+// the staging team of a sub-batch is bound by exactly that traffic (25 MB per 64 files: 0.7-0.8 ms on 16 CPUs, the launches of a
+// 256-file call one after the other).  JPGPU_STAGE_PLAIN_MEMCPY=1: memcpy (A/B).
+inline void copy_past_the_caches(uint8_t *dst, const uint8_t *src, size_t n) {
+#if defined(__x86_64__) && defined(__clang__)
+    static const bool plain = getenv("JPGPU_STAGE_PLAIN_MEMCPY") != nullptr;
+    if (plain || n < 4096u) {
+        memcpy(dst, src, n);
+        return;
+    }
+    typedef long long v2di __attribute__((vector_size(16)));
+    const size_t head = (16u - ((uintptr_t)dst & 15u)) & 15u;
+    memcpy(dst, src, head);
+    dst += head, src += head, n -= head;
+    size_t i = 0;
+    for (; i + 64u <= n; i += 64u) {
+        v2di a, b, c, d;
+        memcpy(&a, src + i, 16), memcpy(&b, src + i + 16, 16), memcpy(&c, src + i + 32, 16), memcpy(&d, src + i + 48, 16);
+        __builtin_nontemporal_store(a, (v2di *)(dst + i));
+        __builtin_nontemporal_store(b, (v2di *)(dst + i + 16));
+        __builtin_nontemporal_store(c, (v2di *)(dst + i + 32));
+        __builtin_nontemporal_store(d, (v2di *)(dst + i + 48));
+    }
+    __builtin_ia32_sfence();
+    memcpy(dst + i, src + i, n - i);
+#else
+    memcpy(dst, src, n);
+#endif
+}
 struct LaunchClock {  // JPGPU_PIPE_TRACE: where a slow launch spent its time (host)
     bool on = getenv("JPGPU_PIPE_TRACE") != nullptr;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
@@ -831,6 +861,11 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     };
     std::vector<PinnedSpan> spans;
     std::vector<size_t> raw_mirror_off;  // per raw scan, in listing order: its offset in the span region
+    struct RawScan {
+        const uint8_t *src;
+        size_t bytes, listed;  // (listed: its place in listing order)
+    };
+    std::vector<RawScan> raw_scans;
     size_t n_sync_jobs = 0, seg_words = 0, data_bytes = 0, scratch_bytes = 0;
     // Files of one encoder repeat the same Huffman tables (27 kB per scan in device form): a scan whose tables equal those of
     // the scan before it shares that copy — one in the staging block, one upload, one set of lines in the L2.
@@ -854,18 +889,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t pieces = (uint32_t)((stuffed + 15u + UNSTUFF_PIECE - 1u) / UNSTUFF_PIECE);
                 max_pieces = std::max(max_pieces, pieces);
                 scratch_bytes += align_up(((size_t)pieces + 1u) * 4u, 16);
-                if (input_pinned) {
-                    // Pinned input: files that follow one another in the caller's memory (a loader's arena: gaps of up to 8 kB — the
-                    // next file's headers) travel in ONE copy, headers and gaps included; a scan's place in the mirror is then its
-                    // place in the span.  (One hipMemcpyAsync per file: 4,096 calls per call of 4,096 files — 114 ms on 16 CPUs.)
-                    const uint8_t *src = images[k].file + ps.data_off;
-                    if (spans.empty() || src < spans.back().end || (size_t)(src - spans.back().end) > 8192u) {
-                        const size_t at = spans.empty() ? 0 : align_up(spans.back().mirror_off + (size_t)(spans.back().end - spans.back().start), 16) + 16;
-                        spans.push_back(PinnedSpan{src, src, at});
-                    }
-                    raw_mirror_off.push_back(spans.back().mirror_off + (size_t)(src - spans.back().start));
-                    spans.back().end = src + stuffed;
-                }
+                if (input_pinned) raw_scans.push_back(RawScan{images[k].file + ps.data_off, stuffed, raw_scans.size()});
             }
             if (const DriGeom g = dri_geom(ps); g.chunked) {
                 const size_t chunks = g.too_large ? 0 : (size_t)(ps.seg_off.size() / 2) * g.seg_chunks;
@@ -880,6 +904,22 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 scratch_bytes += align_up(chunks * 8 * 4, 16) + align_up(chunks * 4, 16) + align_up(chunks * huff_emit_stride(shift) * 4, 16) +
                                  align_up(huff_weave_dwords((uint32_t)chunks, shift) * 4, 256) + 256;
             }
+        }
+    }
+    if (input_pinned && !raw_scans.empty()) {
+        // Pinned input: files that follow one another in the caller's memory (a loader's arena: gaps of up to 8 kB — the next file's
+        // headers) travel in ONE copy, headers and gaps included; a scan's place in the mirror is then its place in the span.  (One
+        // hipMemcpyAsync per file: 4,096 calls per call of 4,096 files — 114 ms on 16 CPUs.)  By ADDRESS, not in listing order: the
+        // pipeline lists a sub-batch's images as its threads finish their headers, and an arena need not hold files in call order.
+        std::sort(raw_scans.begin(), raw_scans.end(), [](const RawScan &a, const RawScan &c) { return a.src < c.src; });
+        raw_mirror_off.assign(raw_scans.size(), 0);
+        for (const RawScan &r : raw_scans) {
+            if (spans.empty() || r.src < spans.back().end || (size_t)(r.src - spans.back().end) > 8192u) {
+                const size_t at = spans.empty() ? 0 : align_up(spans.back().mirror_off + (size_t)(spans.back().end - spans.back().start), 16) + 16;
+                spans.push_back(PinnedSpan{r.src, r.src, at});
+            }
+            raw_mirror_off[r.listed] = spans.back().mirror_off + (size_t)(r.src - spans.back().start);
+            spans.back().end = r.src + r.bytes;
         }
     }
     const size_t off_status = 0, off_cnt = align_up(off_status + (size_t)n * 4, 16);
@@ -1081,7 +1121,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 const uint32_t nraw = ct.ps->seg_off[1] - ct.ps->seg_off[0];
                 ct.seg_table[0] = 0;
                 ct.seg_table[1] = nraw;  // (the stuffed length; the job's lengths come from huff_unstuff_scan_kernel)
-                if (!input_pinned) memcpy(ct.dst, ct.src + ct.ps->seg_off[0], nraw);
+                if (!input_pinned) copy_past_the_caches(ct.dst, ct.src + ct.ps->seg_off[0], nraw);
                 return;  // (pinned input: the copy engine reads the caller's buffer — enqueued below, by this thread alone)
             }
             uint32_t o = 0;

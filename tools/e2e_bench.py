@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--sleep", type=float, default=0.0, help="seconds to idle between rounds")
     ap.add_argument("--dense", action="store_true", help="send dense coefficient planes (A/B against the compact transport)")
     ap.add_argument("--scale", default=None, help="WxH: Decoder::scale for every image (jpgpu_pipeline_set_scale)")
+    ap.add_argument("--input-pinned", action="store_true", help="the files in one pinned arena (PinnedFiles, JPGPU_PIPELINE_INPUT_PINNED)")
+    ap.add_argument("--host-light", default=None, choices=("0", "1"), help="force host light (1) / host staging (0); default: the library's choice")
     ap.add_argument("--file", default=None, help="use this JPEG (replicated) instead of the synthetic images")
     args = ap.parse_args()
     from PIL import Image
@@ -49,12 +51,18 @@ def main():
         distinct.append(buf.getvalue())
     files = [distinct[i % len(distinct)] for i in range(args.images)]
     p = J.Pipeline(threads=args.threads)
+    kw = {}
+    if args.input_pinned:
+        files = J.PinnedFiles(files)
+        kw["input_pinned"] = True
+    if args.host_light is not None:
+        kw["host_light"] = args.host_light == "1"
     best = None
     import time
     for r in range(args.rounds):
         time.sleep(args.sleep)
         out = p.decode(files, download=not args.no_download, dense=args.dense, device_entropy=args.device_entropy,
-                       scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None)
+                       scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None, **kw)
         bad = [o for o in out if isinstance(o, Exception)]
         assert not bad, bad[:1]
         t = p.timings()
@@ -68,7 +76,7 @@ def main():
     reps = 6
     for _ in range(reps):
         p.decode(files, download=False, dense=args.dense, device_entropy=args.device_entropy,
-                 scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None)
+                 scale=tuple(int(v) for v in args.scale.split("x")) if args.scale else None, **kw)
     wall = time.perf_counter() - t0
     r1 = resource.getrusage(resource.RUSAGE_SELF)
     sustained = reps * args.images / wall

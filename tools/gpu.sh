@@ -14,13 +14,14 @@
 #   abe:<reps>                    the same for the E figures
 #   wl:<workload>[:batch[:subs[:ENV=VAL+...]]]  K of another workload (bench.py --workload)
 #   trace:<name>:<cmd with + for spaces>     rocprofv3 --kernel-trace --stats of a command -> <name>_kernel_stats.json
+#   tl:<name>:<cmd>[:min us]      kernels AND copies of the command's last burst of device activity on one time axis (tools/prof_timeline.py) -> <name>_device_timeline.txt
 #   pmc:<name>:<cmd>              instruction / wait / LDS counters of a command (two passes of eight counters) -> <name>_pmc.json
 #   disp:<name>:<kernel substr>:<last N>[:ENV]   three counter passes over the one-sub-batch pipeline calls, every dispatch of the
 #                                 matching kernels on its own line (launches of very different work: the sync passes) -> <name>_dispatches.jsonl
 #   lanes:<name>:<cmd>            SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU per kernel -> <name>_lanes.json
 #   traffic:<workload>:<path>:<kernel substr>[:extra bench args]   FETCH_SIZE / WRITE_SIZE passes -> pmc_traffic.json entry
 #   pipe256[:ENV=VAL+...]         kernel trace + traffic + instruction counters of a 256-file pipeline call as ONE sub-batch
-#   timeline:<n files>            JPGPU_PIPE_TRACE host + device timeline of an <n>-file call (tools/e2e_bench.py)
+#   timeline:<n files>[:<e2e_bench flags, + for spaces>[:ENV=VAL+...]]   JPGPU_PIPE_TRACE host + device timeline of an <n>-file call (tools/e2e_bench.py)
 #   kinds                         other sampling kinds / restart markers / 2160p through E (tools/e2e_bench.py) -> e2e_other_kinds.jsonl
 #   fuzz[:n]                      the differential fuzzers, n cases each (default 200)
 #   latency                       one image through Decoder / a one-image pipeline (tools/decoder_latency.py)
@@ -53,6 +54,8 @@ if "classes_on_device" in bc: out += ["| dev classes", bc["classes_on_device"]["
 e = d.get("e2e") or {}
 for k in ("256", "1024", "4096"):
     if k in e: out += ["| E%s" % k, e[k]["total_ms"], "ms", e[k]["images_per_s"], "img/s", e[k].get("frac_of_floor"), e[k]["verified_vs_oracle"]]
+for k in ("256_pinned_input", "4096_pinned_input"):
+    if k in e: out += ["| E" + k, e[k].get("total_ms"), e[k].get("verified_vs_oracle", e[k].get("error"))]
 if "kernels_256_one_sub_batch" in e: out += ["| alone", e["kernels_256_one_sub_batch"]["kernel_ms"]]
 if "tower_progressive_256" in e: out += ["| prog", e["tower_progressive_256"].get("images_per_s"), e["tower_progressive_256"].get("images_device_entropy")]
 if "error" in e: out += ["| E ERROR", e["error"]]
@@ -105,6 +108,10 @@ for step in "$@"; do
       cmd=$(cmdline "$a2"); rm -rf $O/trace_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_$a1 -o t -- $cmd > $O/trace_$a1.log 2>&1)
       python tools/prof_summary.py $O/trace_$a1 > $O/${a1}_kernel_stats.json 2>> $O/summary.err; kernel_table $O/trace_$a1 ;;
+    tl)
+      cmd=$(cmdline "$a2"); rm -rf $O/tl_$a1
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --memory-copy-trace -d $O/tl_$a1 -o t -- $cmd > $O/tl_$a1.log 2>&1)
+      python tools/prof_timeline.py $O/tl_$a1 --min-us ${a3:-30} > $O/${a1}_device_timeline.txt 2>> $O/summary.err; head -n 3 $O/${a1}_device_timeline.txt; rm -rf $O/tl_$a1 ;;
     pmc)
       cmd=$(cmdline "$a2"); rm -rf $O/pmc1_$a1 $O/pmc2_$a1
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD -d $O/pmc1_$a1 -o p -- $cmd > $O/pmc1_$a1.log 2>&1)
@@ -135,7 +142,7 @@ for step in "$@"; do
       python tools/prof_summary.py $O/pipe256_pmc1 $O/pipe256_fetch $O/pipe256_write $O/pipe256 > $O/pipe256_kernel_stats.json 2>> $O/summary.err
       grep "call ms" $O/pipe256.log | tail -3; kernel_table $O/pipe256 ;;
     timeline)
-      JPGPU_PIPE_TRACE=1 JPGPU_BATCH_KERNEL_TIMES=1 timeout 400 python tools/e2e_bench.py --images ${a1:-4096} --device-entropy --no-download --rounds 3 > $O/timeline_${a1:-4096}.txt 2>&1; tail -n 3 $O/timeline_${a1:-4096}.txt ;;
+      env $(envs "$a3") JPGPU_PIPE_TRACE=1 JPGPU_BATCH_KERNEL_TIMES=1 timeout 400 python tools/e2e_bench.py --images ${a1:-4096} --device-entropy --no-download --rounds 3 $(envs "$a2") > $O/timeline_${a1:-4096}${a2//+/}.txt 2>&1; tail -n 3 $O/timeline_${a1:-4096}${a2//+/}.txt ;;
     kinds)
       : > $O/e2e_other_kinds.jsonl
       for r in 1 4; do timeout 300 python tools/e2e_bench.py --images 1024 --device-entropy --no-download --rounds 4 --restart-rows $r 2>/dev/null | tail -1 >> $O/e2e_other_kinds.jsonl; done
