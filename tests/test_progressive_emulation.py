@@ -190,6 +190,45 @@ def test_damaged_streams_never_differ_from_the_host(seed):
     assert kept + flagged + same == 60 and same > 0
 
 
+def test_many_threads_many_table_definitions():
+    """The front-end keeps ONE copy of every Huffman table definition in a process-wide registry (64 shards by a hash of the definition,
+    csrc/host/frontend.cpp build_cached) and per thread pointers to the tables it used last.  Progressive files from a real encoder carry
+    twelve optimised tables each, no two files alike: eight threads plan and decode 48 different frames over and over — more definitions
+    than the registry and the threads' slots hold, so entries are replaced all the time — and every plan and every coefficient plane
+    equals what one thread alone gets."""
+    pytest.importorskip("PIL")
+    import threading
+    frames = [_pil(64 + 8 * (i % 5), 48 + 8 * (i % 3), ("4:2:0", "4:4:4", "4:2:2")[i % 3], quality=50 + (i * 7) % 45, seed=500 + i) for i in range(48)]
+    alone = []
+    for f in frames:
+        st, desc, planes, ns, nt = _device(f, 0)
+        assert st == 0
+        alone.append((ns, nt, [p.copy() for p in planes]))
+    bad = []
+
+    def work(t):
+        try:
+            for rep in range(3):
+                for i in range(len(frames)):
+                    j = (i * 5 + t * 7 + rep) % len(frames)
+                    st, desc, planes, ns, nt = _device(frames[j], (t + rep) % 4)
+                    if st != 0 or (ns, nt) != alone[j][:2] or not all(np.array_equal(a, b_) for a, b_ in zip(planes, alone[j][2])):
+                        bad.append((t, rep, j))
+                    if (i + t) % 6 == 0:  # (the host decoder goes through the same registry)
+                        _hd, hc = _host(frames[j])
+                        if not all(np.array_equal(np.asarray(hc[c], np.int16), alone[j][2][c]) for c in range(len(alone[j][2]))):
+                            bad.append((t, rep, j, "host"))
+        except Exception as e:  # noqa: BLE001
+            bad.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad[:3]
+
+
 def test_prog_table_is_the_reference_procedure():
     """ProgHuffTable = the reference's 8-bit lookup + maxcode walk (src/huffman.rs:31-58): every code of an optimised table decodes
     to its symbol through the emulated lane (covered by the stream tests) — here: the struct's size, which the LDS layout is built on."""
