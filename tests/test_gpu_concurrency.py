@@ -111,3 +111,42 @@ def test_1024_decoding_threads_like_the_reference_rayon_2_test():
         threading.stack_size(old)
     assert not errors, errors[:5]
     assert done[0] == n_threads
+
+
+@pytest.mark.timeout(600)
+def test_two_pipelines_walk_progressive_frames_at_the_same_time(monkeypatch):
+    """Progressive frames on the device are walked a lane per scan, and a lane that waits for the scan it depends on holds its
+    workgroup slot (csrc/huff_prog_core.hpp).  One call's launches fit the device by construction (csrc/pipeline.cpp, prog_lanes_max);
+    two pipelines walking at the same moment together need MORE slots than the device has (2 x 2,560 frames x 10 scans = 51 k lanes
+    against 49 k).  Both must come through — nothing hangs — and every frame must be right, whether its lanes ran as planned or gave
+    up waiting and left the frame to the host."""
+    import jpeg_decoder_amd as J
+    monkeypatch.setenv("JPGPU_PIPE_PROG_DEVICE_PERCENT", "100")
+    tower = open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read()
+    want = O.decode(tower).pixels
+    n = 2560
+    problems, on_device = [], []
+
+    def work(t):
+        try:
+            p = J.Pipeline(threads=8)
+            for _ in range(3):
+                res = p.decode([tower] * n, device_entropy=True, download=False)
+                if any(isinstance(x, Exception) for x in res):
+                    problems.append((t, "error"))
+                on_device.append(int(p.timings()["images_device_progressive"]))
+                for i in (0, 1, 63, 64, n // 2, n - 2, n - 1):
+                    if p.download(i).tobytes() != np.ascontiguousarray(want).tobytes():
+                        problems.append((t, i))
+            p.close()
+        except Exception as e:  # noqa: BLE001
+            problems.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=240)
+    assert not any(th.is_alive() for th in threads), "a pipeline hangs"
+    assert not problems, problems[:4]
+    assert on_device and min(on_device) == n, on_device
