@@ -1112,9 +1112,8 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
             zero_ranges.emplace_back(b->coef_off[(size_t)img * 4], b->coef_off[(size_t)img * 4 + desc.ncomp - 1] + b->coef_len[(size_t)img * 4 + desc.ncomp - 1]);
     }
     {
-        const int device_for_copies = b->device;
         hipStream_t raw_stream = (copy_stream && copy_stream != hip_stream) ? (hipStream_t)copy_stream : s;
-        std::atomic<int> raw_copy_failed{0};
+        bool raw_copy_failed = false;
         const std::function<void(uint32_t)> body = [&](uint32_t t) {
             const CopyTask &ct = copies[t];
             if (ct.raw) {  // host light: as the file holds it — one memcpy, or none (the copy engine reads the caller's pinned buffer)
@@ -1219,16 +1218,15 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         if (input_pinned) {
             // one caller, one copy per span of adjacent files (4,096 hipMemcpyAsync calls from a team of sixteen threads made the call
             // twice as long as from one: 108 against 53 ms; and from one thread on 16 CPUs still 114 ms)
-            (void)device_for_copies;
             for (const PinnedSpan &sp : spans)
-                if (hipMemcpyAsync(d + off_spans + sp.mirror_off, sp.start, (size_t)(sp.end - sp.start), hipMemcpyHostToDevice, raw_stream) != hipSuccess) raw_copy_failed.store(1);
+                if (hipMemcpyAsync(d + off_spans + sp.mirror_off, sp.start, (size_t)(sp.end - sp.start), hipMemcpyHostToDevice, raw_stream) != hipSuccess) raw_copy_failed = true;
         }
         if (par && n_tasks > 1) (*par)(n_tasks, staged);
         else
             for (uint32_t t = 0; t < n_tasks; t++) staged(t);
         clk.mark("staging+uploads");
         if (clk.on) clk.used += (size_t)snprintf(clk.text + clk.used, clk.used < sizeof(clk.text) ? sizeof(clk.text) - clk.used : 0, " (slowest staging task %.2f, slowest hipMemcpyAsync call %.2f)", max_task_us.load() / 1e3, max_copy_us.load() / 1e3);
-        if (copy_failed.load() || raw_copy_failed.load()) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
+        if (copy_failed.load() || raw_copy_failed) return set_err(b->err, JPGPU_ERR_IO, "device entropy: upload of the staged scans failed");
         // the head of the block last: the staging tasks wrote into its job records (unstuffed lengths, chunk counts, status)
         B_HIP(upload_staged(d, h, off_data, cps));
         if (two_streams) {
