@@ -200,52 +200,24 @@ __global__ __launch_bounds__(256, 4) void fgen_kernel_dyn(const FusedGeom *__res
 #undef JP_CALL
 }
 
-// four components, some at half size: a = tile, b = MCU row (fused_x4.hpp)
+// four components, some at half size: a strip walk (W4, fused_x4.hpp): a = strip, MCU rows [b, c) of it
 template <int ARITH, bool K_FULL>
-__device__ __forceinline__ void r4_body(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs, const FusedWork *__restrict__ work,
-                                        uint8_t *lds_raw) {
-    typedef R4<ARITH, K_FULL> K;
-    const FusedWork w = locate(work);
-    const FusedGeom g = geoms[w.image];
-    const FusedImage img = imgs[w.image];
-    const R4Lds lds = R4Lds::make(lds_raw, g.tx, K::NL, K::NH);
-    const uint32_t tid = threadIdx.x;
-    S420Regs r;
-    K::init(img, tid, lds);
-    {
-        typename K::Pre pre;
-        K::stage_load(g, img, w.a, w.b, tid, pre);
-        K::stage_store(g, w.a, tid, lds, pre);
-    }
-    __syncthreads();
-    // Which wave transforms which blocks rotates from workgroup to workgroup: the first waves hold the blocks that are
-    // transformed in full (660 instructions), the last ones only one-row transforms (150), and wave i of every workgroup runs
-    // on SIMD i of its CU — unrotated, one SIMD did most of every workgroup's arithmetic while two idled.
-    const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const uint32_t rot = (lin ^ (lin >> 2) ^ (lin >> 5) ^ (lin >> 8) ^ (lin >> 11)) & 3u;
-    const uint32_t role = ((((tid >> 6) + rot) & 3u) << 6) | (tid & 63u);  // the lane whose block this lane takes
-    K::read_block(g, w.a, w.b, role, lds, r);
-    __syncthreads();  // the tiles alias the staging area
-    K::transform(g, w.a, w.b, role, lds, r);
-    __syncthreads();
-    K::colour(g, img, w.a, w.b, tid, lds);
-}
-template <int ARITH, bool K_FULL>
-__global__ __launch_bounds__(256, 4) void r4_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(256, 4) void w4_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                     const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    r4_body<ARITH, K_FULL>(geoms, imgs, work, lds_raw);
+    walk_item<W4<ARITH, K_FULL>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
 }
-template <bool K_FULL, bool EXACT_PASS>  // (two launches, like the walks: the wrap-exact body spills)
-__global__ __launch_bounds__(256, 4) void r4_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+template <bool K_FULL, bool EXACT_PASS>  // (two launches, like the other walks: the wrap-exact body spills)
+__global__ __launch_bounds__(256, 4) void w4_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                         const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const uint32_t fl = image_flags(imgs, work);
+    const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
+    const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags);
     if constexpr (EXACT_PASS) {
-        if (!(fl & 1u)) r4_body<ARITH_EXACT, K_FULL>(geoms, imgs, work, lds_raw);
+        if (!(fl & 1u)) walk_item<W4<ARITH_EXACT, K_FULL>>(geoms, imgs, w, lds_raw);
     } else {
-        if (fl & 2u) r4_body<ARITH_TIGHT, K_FULL>(geoms, imgs, work, lds_raw);
-        else if (fl & 1u) r4_body<ARITH_SANE, K_FULL>(geoms, imgs, work, lds_raw);
+        if (fl & 2u) walk_item<W4<ARITH_TIGHT, K_FULL>>(geoms, imgs, w, lds_raw);
+        else if (fl & 1u) walk_item<W4<ARITH_SANE, K_FULL>>(geoms, imgs, w, lds_raw);
     }
 }
 
@@ -408,7 +380,7 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     plan.name = name;
     plan.n_images = n;
     plan.ncomp = descs[0].ncomp;
-    plan.strip = (plan.kind == FUSED_420 || plan.kind == FUSED_440) && plan.geoms[0].strip != 0;
+    plan.strip = (plan.kind == FUSED_420 || plan.kind == FUSED_440 || plan.kind == FUSED_420X4) && plan.geoms[0].strip != 0;
     if (plan.strip) {
         // segments per strip by the heuristic of s420_set_segments, one (strip, segment) per workgroup; JPGPU_S420_SEG = n: fixed
         // segments of n MCU rows (test knob)
@@ -420,7 +392,7 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
     for (const auto &g : plan.geoms) tx_max = std::max(tx_max, g.tx);
     plan.nt = 256;
     plan.lds_bytes = plan.kind == FUSED_440 ? S440Lds::total_bytes(tx_max) : (plan.kind == FUSED_420 ? S420Lds::total_bytes(tx_max) : 0);
-    if (plan.kind == FUSED_420X4) plan.lds_bytes = R4Lds::total_bytes(tx_max, plan.geoms[0].k_full ? 2u : 1u, plan.geoms[0].k_full ? 2u : 3u);
+    if (plan.kind == FUSED_420X4) plan.lds_bytes = plan.geoms[0].k_full ? W4Lds<2, 2>::total_bytes(tx_max) : W4Lds<1, 3>::total_bytes(tx_max);
     if (plan.kind == FUSED_GEN) {  // (images of one launch group may differ in H x V: the largest claim)
         plan.lds_bytes = 0;
         for (const auto &g : plan.geoms) plan.lds_bytes = std::max<size_t>(plan.lds_bytes, FGenLds::total_bytes(g.tx, g.hs, g.vs));
@@ -545,20 +517,20 @@ static hipError_t fused_launch_one(FusedPlan &plan, hipStream_t stream, int ar, 
     case FUSED_420X4:
         if (ar < 0) {
             if (g0.k_full) {
-                r4_kernel_dyn<true, false><<<grid, block, shm, stream>>>(G, I, W);
-                r4_kernel_dyn<true, true><<<grid, block, shm, stream>>>(G, I, W);
+                w4_kernel_dyn<true, false><<<grid, block, shm, stream>>>(G, I, W);
+                w4_kernel_dyn<true, true><<<grid, block, shm, stream>>>(G, I, W);
             } else {
-                r4_kernel_dyn<false, false><<<grid, block, shm, stream>>>(G, I, W);
-                r4_kernel_dyn<false, true><<<grid, block, shm, stream>>>(G, I, W);
+                w4_kernel_dyn<false, false><<<grid, block, shm, stream>>>(G, I, W);
+                w4_kernel_dyn<false, true><<<grid, block, shm, stream>>>(G, I, W);
             }
         } else if (g0.k_full) {
-            if (ar == ARITH_TIGHT) r4_kernel<ARITH_TIGHT, true><<<grid, block, shm, stream>>>(G, I, W);
-            else if (ar == ARITH_SANE) r4_kernel<ARITH_SANE, true><<<grid, block, shm, stream>>>(G, I, W);
-            else r4_kernel<ARITH_EXACT, true><<<grid, block, shm, stream>>>(G, I, W);
+            if (ar == ARITH_TIGHT) w4_kernel<ARITH_TIGHT, true><<<grid, block, shm, stream>>>(G, I, W);
+            else if (ar == ARITH_SANE) w4_kernel<ARITH_SANE, true><<<grid, block, shm, stream>>>(G, I, W);
+            else w4_kernel<ARITH_EXACT, true><<<grid, block, shm, stream>>>(G, I, W);
         } else {
-            if (ar == ARITH_TIGHT) r4_kernel<ARITH_TIGHT, false><<<grid, block, shm, stream>>>(G, I, W);
-            else if (ar == ARITH_SANE) r4_kernel<ARITH_SANE, false><<<grid, block, shm, stream>>>(G, I, W);
-            else r4_kernel<ARITH_EXACT, false><<<grid, block, shm, stream>>>(G, I, W);
+            if (ar == ARITH_TIGHT) w4_kernel<ARITH_TIGHT, false><<<grid, block, shm, stream>>>(G, I, W);
+            else if (ar == ARITH_SANE) w4_kernel<ARITH_SANE, false><<<grid, block, shm, stream>>>(G, I, W);
+            else w4_kernel<ARITH_EXACT, false><<<grid, block, shm, stream>>>(G, I, W);
         }
         break;
     case FUSED_444: ARITH_SWITCH(f444_kernel, f444_kernel_dyn); break;

@@ -159,7 +159,10 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
             why = "inconsistent block grid";
             return FUSED_NONE;
         }
-        tx_max = r4_tx_max(g.k_full != 0u);
+        // (a strip walk like 4:2:0's since round 5: W4, fused_x4.hpp; the same test knob narrows its strips)
+        tx_max = w4_tx_max(g.k_full != 0u);
+        if (s420_tx_max < tx_max) tx_max = s420_tx_max < 1u ? 1u : s420_tx_max;
+        g.strip = 1u;
     } else if (d0.ncomp == 1 && hv(0, 1, 1)) {
         kind = FUSED_GRAY;
         name = "fusedgray";
@@ -183,10 +186,10 @@ inline int fused_geom_from_desc(const jpgpu_image_desc &d0, FusedGeom &g, const 
     g.kind = (uint32_t)kind;
     uint32_t n_tiles = (g.mcu_w + tx_max - 1) / tx_max;
     g.tx = (g.mcu_w + n_tiles - 1) / n_tiles;
-    // four components (32-bit pixels, 16 pixels per MCU): tiles of 16 MCUs write whole 1024-byte pieces of a row — seven of them
-    // and a narrow one for 1080p measured 0.80 ms where eight balanced tiles of 15 (960-byte pieces, every one of them starting
-    // and ending inside a 128-byte line) took 0.97
-    if (kind == FUSED_420X4) g.tx = tx_max < g.mcu_w ? tx_max : g.mcu_w;
+    // four components (32-bit pixels, 16 pixels per MCU = 64 bytes of an output row): an even number of MCUs per strip makes every
+    // strip's piece of a row a whole number of 128-byte lines (the row kernel of rounds 3-4: eight balanced tiles of 15 MCUs, every
+    // piece starting and ending inside a line, 0.97 ms against 0.80 with tiles of 16)
+    if (kind == FUSED_420X4 && (g.tx & 1u) && g.tx < tx_max && g.tx < g.mcu_w) g.tx++;
     g.tiles_x = (g.mcu_w + g.tx - 1) / g.tx;
     g.seg_rows = g.mcu_h;
     g.n_seg = 1;
@@ -205,7 +208,9 @@ inline void s420_set_segments(FusedGeom &g, uint32_t n_images, uint32_t seg_rows
         // (round 4, with the colour phase at the lowest wave priority: 256 x 1080p — 768 strips — 2 segments of 34 rows 0.648 ms, 3 of 23
         // 0.663, 4 of 17 0.6445-0.656, 5 of 14 0.652; 64 x 2160p — 384 strips — 4 of 34 0.641, 6 of 23 0.693, 8 of 17 0.660: about 1,536
         // workgroups, one and a half times what the chip holds, instead of round 2's 2,304; profiles/round4/10_wave_priorities.txt)
-        const uint32_t target = g.kind == FUSED_440 ? 4608u : 1536u;
+        // (four components with half-size ones, 192 x 1080p, 4-5 strips: 2 segments of 34 rows 0.687 / 0.774 ms (CMYK 22 11 11 11 / YCCK
+        // 22 11 11 22), 3 of 23 0.671 / 0.770, 4 of 17 0.629-0.644 / 0.709-0.731, 5 of 14 0.651 / 0.750, 8 of 9 0.642 / 0.741: profiles/round5/17_*)
+        const uint32_t target = g.kind == FUSED_440 ? 4608u : (g.kind == FUSED_420X4 ? 3400u : 1536u);
         const uint32_t per_seg = g.tiles_x * (n_images ? n_images : 1u);
         uint32_t n_seg = (target + per_seg / 2u) / per_seg;
         n_seg = n_seg < 1u ? 1u : n_seg;

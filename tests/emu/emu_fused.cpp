@@ -82,7 +82,8 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         else run_walk<S420<ARITH_EXACT, 256>>(g, im);
         return kind;
     }
-    if (kind == FUSED_420X4) {  // r4_kernel (fused_x4.hpp), phase by phase
+    if (kind == FUSED_420X4) {  // w4_kernel (fused_x4.hpp): a strip walk like the two above
+        s420_set_segments(g, 1, seg_rows);
         FusedImage im{};
         for (uint32_t c = 0; c < desc->ncomp; c++) {
             im.coefs[c] = coefs[c];
@@ -90,35 +91,15 @@ int emu_fused_decode(const jpgpu_image_desc* desc, const int16_t* const* coefs, 
         }
         im.out = out;
         if (tx_out) *tx_out = g.tx;
-        if (s420_tx_max) {  // (test hook: narrower tiles)
-            g.tx = std::min(g.tx, s420_tx_max);
-            g.tiles_x = (g.mcu_w + g.tx - 1) / g.tx;
-        }
-        std::vector<S420Regs> regs(256);
-        auto run = [&](auto K) {
-            typedef decltype(K) KK;
-            std::vector<uint8_t> mem(R4Lds::total_bytes(g.tx, KK::NL, KK::NH) + 64);
-            std::vector<typename KK::Pre> pre(256);
-            for (uint32_t my = 0; my < g.mcu_h; my++)
-                for (uint32_t tile = 0; tile < g.tiles_x; tile++) {
-                    memset(mem.data(), 0xCD, mem.size());
-                    const R4Lds lds = R4Lds::make(mem.data(), g.tx, KK::NL, KK::NH);
-                    for (uint32_t t = 0; t < 256; t++) KK::init(im, t, lds);
-                    for (uint32_t t = 0; t < 256; t++) KK::stage_load(g, im, tile, my, t, pre[t]);
-                    for (uint32_t t = 0; t < 256; t++) KK::stage_store(g, tile, t, lds, pre[t]);
-                    for (uint32_t t = 0; t < 256; t++) KK::read_block(g, tile, my, t, lds, regs[t]);
-                    for (uint32_t t = 0; t < 256; t++) KK::transform(g, tile, my, t, lds, regs[t]);
-                    for (uint32_t t = 0; t < 256; t++) KK::colour(g, im, tile, my, t, lds);
-                }
-        };
+        im.flags = sane == 2 ? 3u : (sane ? 1u : 0u);
         if (g.k_full) {
-            if (sane == 2) run(R4<ARITH_TIGHT, true>{});
-            else if (sane) run(R4<ARITH_SANE, true>{});
-            else run(R4<ARITH_EXACT, true>{});
+            if (sane == 2) run_walk<W4<ARITH_TIGHT, true>>(g, im);
+            else if (sane) run_walk<W4<ARITH_SANE, true>>(g, im);
+            else run_walk<W4<ARITH_EXACT, true>>(g, im);
         } else {
-            if (sane == 2) run(R4<ARITH_TIGHT, false>{});
-            else if (sane) run(R4<ARITH_SANE, false>{});
-            else run(R4<ARITH_EXACT, false>{});
+            if (sane == 2) run_walk<W4<ARITH_TIGHT, false>>(g, im);
+            else if (sane) run_walk<W4<ARITH_SANE, false>>(g, im);
+            else run_walk<W4<ARITH_EXACT, false>>(g, im);
         }
         return kind;
     }

@@ -166,6 +166,10 @@ GEOMS = [
     (600, 40, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (577, 33, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
     (16, 16, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (2, 2, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
     (13, 90, [(2, 2), (1, 1), (1, 1), (1, 1)], "YCCK"), (38, 10, [(2, 2), (1, 1), (1, 1), (2, 2)], "CMYK"), (290, 18, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"),
+    # (round 5: a strip walk like 4:2:0's — W4 — so: several strips AND several MCU rows, seams, carry rows, the closing row)
+    (250, 130, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (250, 130, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"), (673, 79, [(2, 2), (1, 1), (1, 1), (1, 1)], "YCCK"),
+    (1130, 50, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (830, 66, [(2, 2), (1, 1), (1, 1), (2, 2)], "CMYK"), (30, 160, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
+    (4, 355, [(2, 2), (1, 1), (1, 1), (1, 1)], "CMYK"), (36, 20, [(2, 2), (1, 1), (1, 1), (2, 2)], "YCCK"),
 ]
 
 
@@ -173,7 +177,7 @@ GEOMS = [
 @pytest.mark.parametrize("kind", ["sane", "tight", "hostile"])
 @pytest.mark.parametrize("walk_shape", ["default", "seg1", "seg3", "tx20", "tx20-seg2", "tx7", "tx7-seg1"])
 def test_fused_kernel_logic_matches_oracle(geom, kind, walk_shape):
-    walk = len(geom[2]) == 3 and geom[2][0] in ((2, 2), (1, 2))
+    walk = (len(geom[2]) == 3 and geom[2][0] in ((2, 2), (1, 2))) or (len(geom[2]) == 4 and geom[2][0] == (2, 2))
     if walk_shape != "default" and not walk:
         pytest.skip("the shape knobs only affect the strip walks (4:2:0 / 4:4:0)")
     # strip walks: (MCU rows per workgroup, widest strip) — short segments and narrow strips exercise seams and halos
