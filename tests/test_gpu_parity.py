@@ -923,7 +923,7 @@ def test_worker_fused_route_classifies_on_the_device(kind, want_cls):
             assert w.last_class == _exact_image_class(qts, coefs) == want_cls
 
 
-# ---- four components with half-size ones: the row kernel of csrc/fused_x4.hpp ----
+# ---- four components with half-size ones: the strip walk W4 of csrc/fused_x4.hpp (rounds 3-4: a row kernel) ----
 X4_LAYOUTS = [([(2, 2), (1, 1), (1, 1), (1, 1)], "fused420x4-2211"), ([(2, 2), (1, 1), (1, 1), (2, 2)], "fused420x4-2212")]
 
 
@@ -932,9 +932,8 @@ X4_LAYOUTS = [([(2, 2), (1, 1), (1, 1), (1, 1)], "fused420x4-2211"), ([(2, 2), (
 @pytest.mark.parametrize("samp,path", X4_LAYOUTS, ids=["2211", "2212"])
 @pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
 def test_batch_four_components_with_half_size_ones_fused(samp, path, ct, size, kind):
-    """jpg-cmyk-2.jpg's layout (22 11 11 11) and YCCK with K at full size (22 11 11 22), both colour functions: the fused row
-    kernel (own blocks in full, of the rows above and below the one sample row the upsampler touches) equals the oracle and the
-    generic kernel pair, for every arithmetic class, several tiles / MCU rows and sizes that end inside a block / an MCU / a tile."""
+    """jpg-cmyk-2.jpg's layout (22 11 11 11) and YCCK with K at full size (22 11 11 22), both colour functions: the fused
+    kernel (a strip walk: carry rows between MCU rows, seam rounds between segments) equals the oracle and the generic kernel pair, for every arithmetic class, several tiles / MCU rows and sizes that end inside a block / an MCU / a tile."""
     w_, h_ = size
     rng = np.random.default_rng(w_ * 13 + h_ + len(kind))
     cases = [_batch_case(rng, w_, h_, samp, ct, kind=kind) for _ in range(3)]
