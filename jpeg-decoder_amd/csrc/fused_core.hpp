@@ -47,7 +47,7 @@ struct FusedGeom {
     uint32_t seg_rows; // S420: MCU rows per workgroup
     uint32_t n_seg;    // S420: ceil(mcu_h / seg_rows)
     uint32_t hs, vs;   // FGen: log2 of the luma sampling factors (H x V luma blocks per MCU)
-    uint32_t k_full;   // R4 (fused_x4.hpp): component 3 is at full size (sampling 22 11 11 22) instead of half size (22 11 11 11)
+    uint32_t k_full;   // W4 (fused_x4.hpp): component 3 is at full size (sampling 22 11 11 22) instead of half size (22 11 11 11)
 };
 
 // One work item of a fused launch: which image, and which of its tiles (meaning of a / b / c per kernel, fused.hip).

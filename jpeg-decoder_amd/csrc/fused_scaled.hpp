@@ -3,7 +3,7 @@
 // generic pair of kernels (idct_planes_kernel<4|2|1> -> u8 planes in HBM -> upsample_color_kernel): 2.64 GB moved for 2.00 GB
 // algorithmic at scale 4, 0.36-0.40 of the roofline (profiles/round3/pmc_traffic.json).
 //
-// A BAND kernel in address order (what R4 is for full-size four-component frames, fused_x4.hpp): a workgroup owns `tx` MCUs of `ry`
+// A BAND kernel in address order (what the row kernel of rounds 3-4 was for four-component frames with half-size components, fused_x4.hpp): a workgroup owns `tx` MCUs of `ry`
 // consecutive MCU rows of one image (ry = 1 in the first version: every chroma block row of a 4:2:0 image was then transformed by
 // three workgroups — its own and, as part of their rings, the ones above and below; 10 block transforms per MCU for 6 blocks).
 //   1. transform: one lane per block (up to FS_BLOCKS_PER_LANE rounds) — the tile's own blocks of every component and, for the

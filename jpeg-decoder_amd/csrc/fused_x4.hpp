@@ -14,9 +14,9 @@
 namespace jpgpu {
 
 #ifdef JPGPU_HOST_EMULATION
-typedef v4u r4_v4u_a4;
+typedef v4u x4_v4u_a4;
 #else
-typedef v4u r4_v4u_a4 __attribute__((aligned(4)));  // a 4-byte pixel is all the alignment an output row has
+typedef v4u x4_v4u_a4 __attribute__((aligned(4)));  // a 4-byte pixel is all the alignment an output row has
 #endif
 
 // Which components are which, and the colour function of one output row of one 8-pixel chunk.
@@ -88,8 +88,8 @@ struct X4Colour {
             }
         }
         if (n == 8u) {
-            *reinterpret_cast<JP_GLOBAL r4_v4u_a4 *>(o) = v4u{px[0], px[1], px[2], px[3]};
-            *reinterpret_cast<JP_GLOBAL r4_v4u_a4 *>(o + 16) = v4u{px[4], px[5], px[6], px[7]};
+            *reinterpret_cast<JP_GLOBAL x4_v4u_a4 *>(o) = v4u{px[0], px[1], px[2], px[3]};
+            *reinterpret_cast<JP_GLOBAL x4_v4u_a4 *>(o + 16) = v4u{px[4], px[5], px[6], px[7]};
         } else {
 #pragma unroll
             for (uint32_t kk = 0; kk < 8; kk++)

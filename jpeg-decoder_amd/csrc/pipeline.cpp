@@ -284,7 +284,6 @@ struct jpgpu_pipeline {
     // was saturated — CPU contention with the device route's staging included), and what one more frame adds to the device route on
     // top of the walk (staging, upload, range scan, pixel kernels)
     double prog_host_ms_per_image = 0.0, prog_dev_ms_per_image = 0.0;
-    uint32_t prog_calls = 0;                     // calls with eligible progressive frames so far (the first one's host times are cold: not a rate)
     uint32_t prog_last_e = 0, prog_last_d = 0;  // the last call's eligible frames and how many of them the device got (a call of the same
                                                  // shape keeps its route unless the rates say it is off by a tenth: sub-batches — arenas,
                                                  // pinned staging — are reused only while their composition repeats)
@@ -584,8 +583,9 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         d = best_d;
         // Until BOTH rates have been measured the host keeps the frames — its route is the pinned one, and a guess in the device's favour
         // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames).
-        // First call: a probe of 64 frames on the device, so that the next call knows the walk (the host's times of that call are
-        // cold — allocations, first touches — and not taken for a rate); second call: the host, all of them; from the third on, the model.
+        // First call: a probe of 64 frames on the device, so that the next call knows the walk; then the host, all of them, until a
+        // call that REUSED its sub-batches has given the host's rate (the first call on fresh sub-batches touches its pinned blocks
+        // for the first time: not a rate) — the third call as a rule; from then on, the model.
         const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_ms_per_image > 0;
         if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : 0u;
         // a call of the same shape as the last one keeps its route while the model does not object by more than a tenth in time
@@ -796,6 +796,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     }
     const uint32_t n_subs = (uint32_t)bounds.size() - 1u;
     p->n_subs = n_subs;
+    bool fresh_sub_batches = false;  // some sub-batch of this call is new: its arenas and pinned blocks are touched for the first time
     for (uint32_t j = 0; j < n_subs; j++) {
         SubBatch &sb = p->subs[j];
         const uint32_t first = bounds[j], last = bounds[j + 1];
@@ -813,6 +814,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         bool reuse = sb.batch && descs.size() == sb.descs.size() && sb.compact == compact && (sb.h_coef != nullptr) == staged;
         for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], sb.descs[k]);
         if (!reuse) {
+            fresh_sub_batches = true;
             sb.drop();
             rc = jpgpu_batch_create(p->device, descs.data(), (uint32_t)descs.size(), JPGPU_BATCH_DEFAULT, &sb.batch);
             if (rc) {
@@ -1220,9 +1222,10 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         const double r = prog_host_ms * 1e6 / (double)prog_host_bytes;
         p->prog_host_ns_per_byte = p->prog_host_ns_per_byte > 0 ? 0.5 * (p->prog_host_ns_per_byte + r) : r;
     }
-    if (prog_host_bytes || device_prog_images) p->prog_calls++;
-    // (a saturated pool that decoded next to nothing else, and not in the first such call: allocations and first touches are in there)
-    if (p->prog_calls >= 2u && prog_host_images >= 2u * p->pool->size() && (uint64_t)prog_host_images * 10u >= (uint64_t)n_host_images * 9u) {
+    // (a saturated pool that decoded next to nothing else — and only from a call that reused its sub-batches: a call on fresh ones writes
+    // its planes into pinned memory nobody has touched yet, and a rate from there made a 256-frame call look like 41 ms of host work;
+    // the model then chose the device, 33 ms, and never saw the host's 16 ms again: `bench.py --force-dist`, profiles/round5/12_*)
+    if (!fresh_sub_batches && prog_host_images >= 2u * p->pool->size() && (uint64_t)prog_host_images * 10u >= (uint64_t)n_host_images * 9u) {
         const double r = (t3 - t2) / prog_host_images;
         p->prog_host_ms_per_image = p->prog_host_ms_per_image > 0 ? 0.5 * (p->prog_host_ms_per_image + r) : r;
     }
