@@ -6,8 +6,8 @@
 // go through UpsamplerH2V2) and of YCCK files as Photoshop writes them (22 11 11 22).
 // History: the generic kernel pair (planes through HBM, 25-28 % of the roofline); rounds 3-4 a ROW kernel — a workgroup owned tx
 // MCUs of ONE MCU row and transformed, besides its own blocks, one sample row of every half-size block above and below (0.46 / 0.52
-// of the roofline, 1.85 M vector instructions per 1080p image: profiles/round4/13_*); round 5 the strip walk below (0.58-0.60 /
-// 0.62-0.64: profiles/round5/17_*), the row kernel is in the git history.
+// of the roofline, 1.85 M vector instructions per 1080p image: profiles/round4/13_*); round 5 the strip walk below (0.62 / 0.62:
+// profiles/round5/17_*), the row kernel is in the git history.
 #pragma once
 #include "fused_core.hpp"
 
@@ -139,7 +139,9 @@ struct W4Lds {
         return l;
     }
 };
-constexpr uint32_t w4_tx_max(bool k_full) { return k_full ? 25u : 35u; }
+// (30, not the 35 the lanes would allow: one load round less per plane and the body stays inside 128 registers — with 35 two spilled
+// registers gave the kernel a scratch segment, and a kernel with scratch is dispatched more slowly even where no wave touches it)
+constexpr uint32_t w4_tx_max(bool k_full) { return k_full ? 25u : 30u; }
 
 template <int ARITH, bool K_FULL>
 struct W4 {
