@@ -649,9 +649,9 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                 key = f"tower_progressive_{n}"
                 try:
                     files = [data] * n
-                    # (four uncounted calls: the dispatcher's probe, two all-host calls — the second one gives it the host's rate —, and the
+                    # (five uncounted calls: the dispatcher's probe, three all-host calls — the last two give it the host's rate —, and the
                     # first call of the route it then picks)
-                    ts = warm_calls(p, files, 5, cold=4, download=False, device_entropy=True)
+                    ts = warm_calls(p, files, 5, cold=5, download=False, device_entropy=True)
                     okp = all(np.array_equal(p.download(i), od.pixels) for i in sorted({0, 1, n // 2, n - 1}))
                     e, med = e2e_entry(n, ts, od.width, od.height, p, okp)
                     e["file"] = "tests/golden/benches/tower_progressive.jpg (the reference's benches/tower_progressive.jpg: 512x512, 10 scans)"
@@ -677,7 +677,7 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                         frames.append(buf.getvalue())
                     n = 4096
                     files = [frames[i % 64] for i in range(n)]
-                    ts = warm_calls(p, files, 5, cold=4, download=False, device_entropy=True)
+                    ts = warm_calls(p, files, 5, cold=5, download=False, device_entropy=True)
                     okd = all(np.array_equal(p.download(i), O.decode(frames[i % 64]).pixels) for i in (0, 1, 63, n // 2 + 7, n - 1))
                     e, med = e2e_entry(n, ts, 512, 512, p, okd)
                     e["input"] = "64 distinct 512x512 4:4:4 progressive frames (Pillow / libjpeg-turbo, quality 85, default script: 10 scans), repeated"

@@ -284,6 +284,7 @@ struct jpgpu_pipeline {
     // was saturated — CPU contention with the device route's staging included), and what one more frame adds to the device route on
     // top of the walk (staging, upload, range scan, pixel kernels)
     double prog_host_ms_per_image = 0.0, prog_dev_ms_per_image = 0.0;
+    uint32_t prog_host_samples = 0;  // calls the host's rate has been taken from (the model is trusted from two on)
     uint32_t prog_last_e = 0, prog_last_d = 0;  // the last call's eligible frames and how many of them the device got (a call of the same
                                                  // shape keeps its route unless the rates say it is off by a tenth: sub-batches — arenas,
                                                  // pinned staging — are reused only while their composition repeats)
@@ -579,14 +580,17 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
         // threads and the device route's staging team compete for the same cores and the host's sub-batches queue behind the
         // device's (measured twice: 3,008 of 4,096 frames on the device 125 ms, 3,136 of them 104 ms — all of them 61-81 ms)
         uint32_t best_d = 0;
-        if (cost(e) < cost(0) * 0.97) best_d = e;
+        // (the device must be ahead by a sixth: the host's route is the pinned one, and what sends a call to the device wrongly — a
+        // host rate taken on a busy box — is never corrected from there)
+        if (cost(e) < cost(0) * 0.85) best_d = e;
         d = best_d;
         // Until BOTH rates have been measured the host keeps the frames — its route is the pinned one, and a guess in the device's favour
         // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames).
-        // First call: a probe of 64 frames on the device, so that the next call knows the walk; then the host, all of them, until a
-        // call that REUSED its sub-batches has given the host's rate (the first call on fresh sub-batches touches its pinned blocks
-        // for the first time: not a rate) — the third call as a rule; from then on, the model.
-        const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_ms_per_image > 0;
+        // First call: a probe of 64 frames on the device, so that the next call knows the walk; then the host, all of them, until TWO
+        // calls that REUSED their sub-batches have given the host's rate (the first call on fresh sub-batches touches its pinned
+        // blocks for the first time: not a rate; the lower of two samples: not a neighbour's burst) — calls three and four as a
+        // rule; from then on, the model.
+        const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_samples >= 2u;
         if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : 0u;
         // a call of the same shape as the last one keeps its route while the model does not object by more than a tenth in time
         else if (e == p->prog_last_e && (p->prog_last_d == 0u || p->prog_last_d == e) && cost(p->prog_last_d) <= 1.10 * cost(d))
@@ -1227,7 +1231,11 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     // the model then chose the device, 33 ms, and never saw the host's 16 ms again: `bench.py --force-dist`, profiles/round5/12_*)
     if (!fresh_sub_batches && prog_host_images >= 2u * p->pool->size() && (uint64_t)prog_host_images * 10u >= (uint64_t)n_host_images * 9u) {
         const double r = (t3 - t2) / prog_host_images;
-        p->prog_host_ms_per_image = p->prog_host_ms_per_image > 0 ? 0.5 * (p->prog_host_ms_per_image + r) : r;
+        // (a box with neighbours gives a call twice its time now and then, never half of it: a sample below the rate replaces it, one
+        // above it moves it by a twentieth at most — one such sample, taken for the rate, made 256 frames look like 37 ms of host work
+        // and the device route, 33 ms, stuck: a call on the device never measures the host again)
+        p->prog_host_ms_per_image = p->prog_host_ms_per_image > 0 ? std::min(r, 1.05 * p->prog_host_ms_per_image) : r;
+        p->prog_host_samples++;
     }
     if (device_prog_images && prog_dev_ms > 0) {
         const double r = prog_dev_ms * 1e6 / ((double)prog_dev_bytes / device_prog_images);
