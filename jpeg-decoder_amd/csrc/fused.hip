@@ -117,8 +117,12 @@ __device__ __forceinline__ void walk_item(const FusedGeom *__restrict__ geoms, c
     }
 }
 
+// Workgroups per CU the walks are compiled for: four — 128 registers per lane — except the wrap-exact bodies (class 0: hostile
+// coefficients, exact 32-bit arithmetic), which need 140 and get three (170 registers).  At four they spilled 58 registers into a
+// scratch segment: 1.19 ms per 256 x 1080p = 0.335 of the roofline; at three (or two: the same) 0.815 ms = 0.49 (round 5).
+constexpr uint32_t walk_wgs(bool exact) { return exact ? 3u : 4u; }
 template <int ARITH, uint32_t NT>
-__global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(NT, walk_wgs(ARITH == ARITH_EXACT)) void s420_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                      const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     walk_item<S420<ARITH, NT>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel(const FusedGeom *__restrict
 // kernel with scratch is dispatched more slowly even where no wave touches it: measured 0.737 ms against 0.676 for the tight
 // kernel on the same box (profiles/round3/10_kernel_trace_stats_and_pmc.json).
 template <uint32_t NT, bool EXACT_PASS>
-__global__ __launch_bounds__(NT, 4) void s420_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(NT, walk_wgs(EXACT_PASS)) void s420_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                          const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
@@ -143,13 +147,13 @@ __global__ __launch_bounds__(NT, 4) void s420_kernel_dyn(const FusedGeom *__rest
 }
 
 template <int ARITH>
-__global__ __launch_bounds__(256, 4) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(256, walk_wgs(ARITH == ARITH_EXACT)) void s440_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                       const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     walk_item<S440<ARITH>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
 }
 template <bool EXACT_PASS>
-__global__ __launch_bounds__(256, 4) void s440_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(256, walk_wgs(EXACT_PASS)) void s440_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                           const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
@@ -202,13 +206,13 @@ __global__ __launch_bounds__(256, 4) void fgen_kernel_dyn(const FusedGeom *__res
 
 // four components, some at half size: a strip walk (W4, fused_x4.hpp): a = strip, MCU rows [b, c) of it
 template <int ARITH, bool K_FULL>
-__global__ __launch_bounds__(256, 4) void w4_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+__global__ __launch_bounds__(256, walk_wgs(ARITH == ARITH_EXACT)) void w4_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                     const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     walk_item<W4<ARITH, K_FULL>>(geoms, imgs, walk_item_at(geoms, work, blockIdx.x), lds_raw);
 }
-template <bool K_FULL, bool EXACT_PASS>  // (two launches, like the other walks: the wrap-exact body spills)
-__global__ __launch_bounds__(256, 4) void w4_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+template <bool K_FULL, bool EXACT_PASS>  // (two launches, like the other walks: the wrap-exact body wants more registers)
+__global__ __launch_bounds__(256, walk_wgs(EXACT_PASS)) void w4_kernel_dyn(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
                                                         const FusedWork *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
