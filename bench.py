@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's configs.
+"""bench.py — BASELINE.json's metric on BASELINE.json's configs: the headline driver.
 
   metric : megapixels/s decoded (batch, whole node); % of HBM roofline for the pixel kernels
   A "step" = one pass of the hot path (dequantize + IDCT + upsample + YCbCr->RGB) over the rank's whole shard,
@@ -8,26 +8,21 @@
   N = 1 (configs[1]): 1920x1080 baseline 4:2:0 YCbCr, batch of 256 images, one launch group per step.
   N > 1 (configs[2]): 3840x2160 baseline 4:2:0, 4096 images in total, sharded by image with
           jpeg_decoder_amd.distributed.shard() (512 per GPU at N = 8; STRONG scaling: the total stays 4096), decoded
-          in sub-batches; `value` has no collective in it (there is no data-path collective), `value_with_gather`
+          in launch groups; `value` has no collective in it (there is no data-path collective), `value_with_gather`
           is the same job with north_star's final RCCL gather of the pixels to rank 0 inside the timed region,
-          issued per sub-batch so that it overlaps the decode of the next one (peer -> root point-to-point
-          transfers, one xGMI link each, no ring).
+          issued per launch group so that it overlaps the decode of the next one.
 
   Launch: `python bench.py --gpus N` spawns the N ranks itself (torch.distributed.run, 127.0.0.1) when it is not
-  already running under a launcher; under torchrun (RANK / WORLD_SIZE in the environment) it is one rank.  A
-  mismatch between --gpus and WORLD_SIZE, or fewer visible GPUs than N, is an error — never a silent 1-GPU run.
-  `--dry-run` walks the same launcher / sharding / gather / JSON code on CPU (gloo) without touching a GPU; it
-  is what the CPU tests use and measures nothing.
+  already running under a launcher; under torchrun it is one rank.  A mismatch between --gpus and WORLD_SIZE, or fewer
+  visible GPUs than N, is an error — never a silent 1-GPU run.  `--dry-run` walks launcher / sharding / gather / JSON on
+  CPU (gloo) and measures nothing.
 
-  At N = 1 the line also carries, OUTSIDE `value` (each verified against the oracle):
-    k_4096            the same kernel-only figure on north_star's 4096-image batch (51 GB of arenas on one GPU);
-    e2e               what the metric's words say — JPEG bytes in host memory -> RGB in HBM through jpgpu_pipeline_decode
-                      (entropy decoding on the device), 256, 1024 and 4096 files, median and min of 7 warm calls; the kernel time per phase
-                      from one sub-batch of 256 files alone on the device (kernels_256_one_sub_batch);
-    cpu_baseline_e2e  the oracle's whole Decoder::decode() on the same files, one file per task on every granted core;
-    sustained         the timed step repeated for --min-seconds (an independent look at `value`, long enough for a sampler).
-
-Prints ONE JSON line on rank 0."""
+  OUTPUT.  Rank 0 prints TWO lines: first `bench_detail: {...}` — everything measured, also written to
+  gpurun_out/bench_detail.json — and LAST the contract line: one JSON object of at most 4 KB (contract_line(): the
+  headline, `roofline`, `cpu_baseline`, and ten scalars of the side legs as `e2e_summary`).  The side legs themselves
+  (kernel-only figure at 4,096 images, the N > 1 job on one GPU, arithmetic classes, JPEG bytes -> RGB through
+  jpgpu_pipeline_decode incl. BASELINE configs[3], the CPU-budget points, the oracle's whole decode) are
+  tools/bench_e2e.py; each is checked against the oracle and none of them is inside `value`."""
 import argparse
 import hashlib
 import json
@@ -41,21 +36,23 @@ import time
 # queue run one after the other: jpgpu_pipeline_decode keeps up to 12 sub-batches in flight on 12 compute + 4 copy streams.
 # Read once when the runtime initialises, so it is set before anything touches HIP (jpeg_decoder_amd._native does the same).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-# (the library reads this once, at its first device-entropy launch: events around the phases, microseconds per sub-batch — the e2e
-# legs report kernel time per phase)
+# (the library reads this once, at its first device-entropy launch: events around the phases — the e2e legs report kernel time per phase)
 os.environ.setdefault("JPGPU_BATCH_KERNEL_TIMES", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
+sys.modules.setdefault("bench", sys.modules[__name__])  # (tools/bench_e2e.py does `import bench`: the same module when this file is the script)
 
-import numpy as np
+import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+CONTRACT_LINE_MAX = 4096  # bytes of the last stdout line (the driver keeps the tail of stdout; round 5's 21 KB line was cut)
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
 
 WORKLOADS = {
-    # name: (width, height, sampling, mode, colour transform, default images per GPU at N = 1)
+    # name: (width, height, sampling, mode, colour transform, default images per GPU at N = 1[, dct_scale])
     "1080p-420": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
     "2160p-420": (3840, 2160, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 64),
     "1080p-444": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),
@@ -64,16 +61,14 @@ WORKLOADS = {
     "1080p-411": (1920, 1080, [(4, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256),  # UpsamplerGeneric layout (fusedgen)
     "1080p-gray": (1920, 1080, [(1, 1)], "gray", "Grayscale", 256),
     "1080p-cmyk": (1920, 1080, [(1, 1)] * 4, "cmyk", "CMYK", 192),
-    # layouts the reference's own fixtures have (jpg-cmyk-2.jpg: one full-size and three half-size components; YCCK as Photoshop
-    # writes it: K at full size) and reduced-size decodes (Decoder::scale, src/idct.rs:456-565: dct_scale 4 / 2 / 1)
+    # layouts the reference's own fixtures have (jpg-cmyk-2.jpg; YCCK as Photoshop writes it) and reduced-size decodes (Decoder::scale)
     "1080p-cmyk-2211": (1920, 1080, [(2, 2), (1, 1), (1, 1), (1, 1)], "cmyk", "CMYK", 192),
     "1080p-ycck-2212": (1920, 1080, [(2, 2), (1, 1), (1, 1), (2, 2)], "ycck", "YCCK", 192),
     "1080p-420-scale4": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 4),
     "1080p-420-scale2": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 2),
     "1080p-420-scale1": (1920, 1080, [(2, 2), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 1),
     "1080p-444-scale4": (1920, 1080, [(1, 1), (1, 1), (1, 1)], "ycbcr", "YCbCr", 256, 4),
-    # 4:4:4 and grayscale images interleaved in one batch (two fused launch groups, path "mixed")
-    "1080p-444+gray": (1920, 1080, None, "mixed", None, 1024),  # BASELINE configs[4]: batch 1024 (512 + 512)
+    "1080p-444+gray": (1920, 1080, None, "mixed", None, 1024),  # BASELINE configs[4]: batch 1024 (512 + 512), two fused launch groups
 }
 CONFIG3_WORKLOAD, CONFIG3_IMAGES_TOTAL = "2160p-420", 4096
 E2E_SHARDED_TOTAL = 4096  # files of the e2e leg at N > 1 (north_star's batch), sharded over the ranks
@@ -91,7 +86,7 @@ def parse_args(argv=None):
                     help="images in the whole job, sharded over the ranks (strong scaling; default at N > 1: 4096)")
     ap.add_argument("--sub-batches", type=int, default=0, help="launch groups per step (default: 1 at N = 1; at N > 1 up to 8, none smaller than 64 images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU work for the cpu_baseline sample (the whole-decode comparator takes half)")
     ap.add_argument("--generic", action="store_true", help="force the two-kernel generic path")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-steps", type=int, default=3, help="timed steps of the decode + gather region (N > 1)")
@@ -101,19 +96,20 @@ def parse_args(argv=None):
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="after the K timed steps: repeat the step for at least this long and report it as `sustained` (0 = off)")
     ap.add_argument("--no-k4096", action="store_true", help="skip the 4096-image kernel-only figure (N = 1, default workload)")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the JPEG-bytes -> RGB figures and their CPU comparator (N = 1, default workload)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the JPEG-bytes -> RGB legs and their CPU comparator (N = 1, default workload)")
     ap.add_argument("--no-scale-anchor", action="store_true", help="skip the N > 1 job (2160p x 4096) on this one GPU (N = 1, default workload)")
-    ap.add_argument("--no-cpu-budget", action="store_true", help="skip the E-against-host-CPUs sweep (N = 1, default workload)")
+    ap.add_argument("--no-cpu-budget", action="store_true", help="skip the E-against-host-CPUs points (N = 1, default workload)")
+    ap.add_argument("--cpu-budget-matrix", action="store_true", help="all five CPU counts x four inputs (default: 2 / 8 / 16 CPUs x the library's mode and forced host staging)")
     ap.add_argument("--e2e-images", default="256,1024,4096", help="files per jpgpu_pipeline_decode call of the e2e block")
     ap.add_argument("--e2e-total", type=int, default=E2E_SHARDED_TOTAL, help="files of the e2e leg at N > 1 / --force-dist, sharded over the ranks")
     ap.add_argument("--e2e-encoder", default="auto", choices=["auto", "pillow", "builtin"],
                     help="who writes the e2e block's JPEG files: Pillow (libjpeg-turbo) or tools/baseline_encoder.py; auto = Pillow if importable")
     ap.add_argument("--force-dist", action="store_true",
-                    help="N = 1: initialise torch.distributed (nccl = RCCL) with one rank anyway and run the collectives of the N > 1 path "
-                         "(max over ranks, all_gather of sizes, all_reduce) on the device: the RCCL set-up exercised on one GPU")
+                    help="N = 1: initialise torch.distributed (nccl = RCCL) with one rank anyway and run the collectives of the N > 1 path on the device")
     ap.add_argument("--settle", type=int, default=-1,
-                    help="untimed launches BEFORE the warm-up steps that let the GPU leave its clock transient after an idle "
-                         "period (DESIGN.md §5); default: enough to make settle + warm-up = 50 launches at N = 1")
+                    help="untimed launches BEFORE the warm-up steps (the GPU leaves its clock transient after an idle period); "
+                         "default: enough to make settle + warm-up = 50 launches at N = 1")
+    ap.add_argument("--detail", default=DETAIL_PATH, help="where the detail document goes (also printed as the `bench_detail:` line)")
     return ap.parse_args(argv)
 
 
@@ -183,84 +179,6 @@ def effective_cpus():
     return n
 
 
-def rank_cpu_share(rank, world, bdfs=None, sysfs="/sys"):
-    """Host CPUs rank `rank` of `world` keeps its feeder threads on, and the thread budget that goes with it.  The CPUs: those of the
-    NUMA node the rank's GPU hangs off (its PCI bus id -> <sysfs>/bus/pci/devices/<id>/numa_node), split among the ranks whose GPUs
-    share the node; contiguous slices of the allowed list when the topology is unknown (jpeg_decoder_amd.distributed.cpu_shares, the
-    rule jpgpu_pipeline_create_multi applies in C).  The threads: the CPUs the cgroup GRANTS, divided by the ranks (one pipeline keeps
-    ~8 CPUs busy; `world` ranks that each started the default of one thread per physical core would oversubscribe the host
-    `world`-fold: VERDICT r3).  -> (cpu list, threads for jpgpu_pipeline_create)."""
-    import jpeg_decoder_amd.distributed as D
-    try:
-        allowed = sorted(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        allowed = list(range(os.cpu_count() or 1))
-    shares, _nodes = D.cpu_shares(allowed, bdfs if bdfs else [""] * world, sysfs)
-    share = shares[rank] or allowed
-    # (the library's own default for ONE pipeline is twice the granted CPUs — its threads wait for the device and the link a good
-    # part of a call; 16 threads on 16 granted CPUs measured 71.9 ms per 4,096 files against 53.3 with 32)
-    return share, max(2, 2 * effective_cpus() // world)
-
-
-def device_bdfs(J, world):
-    """PCI bus ids of devices 0 .. world-1 as this process sees them (rank r drives device r); [] if they cannot be read."""
-    import ctypes
-    out = []
-    for k in range(world):
-        buf = ctypes.create_string_buffer(64)
-        if J._native.lib().jpgpu_device_pci_bus_id(k, buf, 64) != 0:
-            return []
-        out.append(buf.value.decode())
-    return out
-
-
-def pin_to(share):
-    try:
-        os.sched_setaffinity(0, share)
-        return True
-    except (AttributeError, OSError):
-        return False
-
-
-def h2d_rate_gbps(torch, dev, nbytes=1 << 30):
-    """What the host link gives ONE pinned copy of 1 GB, in this run (the floor of an E call is its entropy-coded bytes at this rate)."""
-    src = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize(dev)
-    best = None
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dst.copy_(src, non_blocking=True)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1)
-        best = ms if best is None else min(best, ms)
-    del src, dst
-    return nbytes / (best * 1e-3) / 1e9
-
-
-def huffman_symbols(J, data):
-    """Huffman symbols of a baseline file's scan(s), from the coefficients the host front-end decodes: per block one DC symbol,
-    one symbol per non-zero AC coefficient, a ZRL per 16 zeros inside a run, an EOB unless the last coefficient is non-zero."""
-    _desc, planes = J.Decoder(data, device=-1).decode_coefficients()
-    zz = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
-                   57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
-    total = 0
-    for pl in planes:
-        b = np.asarray(pl, np.int16).reshape(-1, 64)[:, zz]  # zig-zag order
-        nz = b[:, 1:] != 0
-        total += b.shape[0] + int(nz.sum())                   # DC symbols + coefficient symbols
-        last = np.where(nz.any(axis=1), 62 - np.argmax(nz[:, ::-1], axis=1), -1)  # index (0..62) of the last non-zero AC coefficient
-        total += int((last < 62).sum())                        # EOB
-        # ZRL: one per 16 zeros in front of a non-zero coefficient
-        idx = np.arange(63)
-        pos_idx = np.where(nz, idx[None, :], -1)
-        prev = np.maximum.accumulate(np.concatenate([np.full((b.shape[0], 1), -1), pos_idx[:, :-1]], axis=1), axis=1)
-        total += int((np.where(nz, idx[None, :] - prev - 1, 0) // 16).sum())
-    return total
-
 
 def cpu_model():
     try:
@@ -301,7 +219,7 @@ def measured_traffic(workload, path):
     commit the passes were taken on and whether the pixel kernels' sources have changed since (tools/kernel_sources.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_sources
-    for rnd in ("round5", "round4", "round3", "round2", "round1"):
+    for rnd in ("round6", "round5", "round4", "round3", "round2", "round1"):
         rel = os.path.join("profiles", rnd, "pmc_traffic.json")
         try:
             t = json.load(open(os.path.join(ROOT, rel)))
@@ -313,538 +231,6 @@ def measured_traffic(workload, path):
         except (OSError, ValueError, KeyError):
             continue
     return None, "not measured for this workload / kernel path", None
-
-
-def k_4096(J, torch, O, variants, device_index, dev, stream, w, h, digest, n_img=4096, steps=30):
-    """The kernel-only figure (coefficients resident in HBM -> RGB in HBM) on a 4096-image batch of the default workload."""
-    sh = Shard(J, torch, variants, n_img, 1, device_index)
-    try:
-        for _ in range(5):
-            sh.decode(stream)
-        elapsed, ms = time_steps(torch, dev, None, stream, steps, lambda: sh.decode(stream))
-        ok = all(hashlib.sha256(sh.image_pixels(i).cpu().numpy().tobytes()).hexdigest() == digest for i in (0, n_img // 2 + 1, n_img - 1))
-        alg = algorithmic_bytes_per_image(variants[0]["comps"], sh.image_pixels(0).numel()) * n_img
-        return {"images": n_img, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4), "kernel_ms_per_launch": round(ms, 4),
-                "value": round(n_img * w * h / 1e6 * steps / elapsed, 1), "unit": "MP/s",
-                "roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": alg,
-                "arena_bytes": int(sh.coef_arena.numel() + sh.out_arena.numel()), "kernel_path": sh.path, "arena_fill_copies": sh.fill_copies,
-                "verified_vs_oracle": bool(ok),
-                "what": f"{n_img} x {w}x{h} 4:2:0 in ONE launch on one GPU, coefficients resident in HBM -> RGB in HBM (north_star's batch)"}
-    finally:
-        sh.close()
-
-
-def scale_anchor(J, torch, O, synth, D, device_index, dev, stream, steps=10):
-    """The N > 1 job on ONE GPU (VERDICT r4 #2c): configs[2] — 3840x2160 4:2:0 x 4,096, coefficients resident in HBM -> RGB in HBM, the
-    same launch groups the ranks of an N-GPU run make (8 groups) — so that the 1 -> 8 curve has a first point on its own workload
-    (`value` at N = 1 is configs[1]: 1080p x 256).  204 GB of arenas; shrunk, loudly, if this GPU has less free."""
-    w, h, sampling, mode, ct = WORKLOADS[CONFIG3_WORKLOAD][:5]
-    variants = build_variants(J, synth, w, h, sampling, mode, ct)
-    per_image = algorithmic_bytes_per_image(variants[0]["comps"], w * h * 3)
-    want_n = CONFIG3_IMAGES_TOTAL
-    free_b, _t = torch.cuda.mem_get_info(dev)
-    n_img = want_n
-    while n_img > 64 and n_img * per_image > 0.92 * free_b:
-        n_img = int(n_img * 0.9)
-    n_sub = min(8, max(1, n_img // 64))
-    sh = Shard(J, torch, variants, n_img, n_sub, device_index)
-    try:
-        for _ in range(3):
-            sh.decode(stream)
-        elapsed, ms = time_steps(torch, dev, None, stream, steps, lambda: sh.decode(stream))
-        ocomps, _ = O.make_components(w, h, sampling)
-        digest = hashlib.sha256(O.pixels_from_coefficients(ocomps, variants[0]["qts"], variants[0]["coefs"], w, h, ct.upper()).tobytes()).hexdigest()
-        ok = all(hashlib.sha256(sh.image_pixels(i).cpu().numpy().tobytes()).hexdigest() == digest for i in (0, n_img // 2 + 1, n_img - 1))
-        alg = per_image * n_img
-        return {"workload": f"{w}x{h} 4:2:0 x {n_img} on one GPU (BASELINE configs[2], the job bench.py --gpus N shards)", "name": CONFIG3_WORKLOAD,
-                "images": n_img, "images_requested": want_n, "shrunk_to_fit_hbm": n_img < want_n, "sub_batches": n_sub, "steps": steps,
-                "ms_per_step": round(elapsed / steps * 1e3, 3), "kernel_ms_per_step": round(ms, 3),
-                "value": round(n_img * w * h / 1e6 * steps / elapsed, 1), "unit": "MP/s",
-                "roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "arena_bytes": int(sh.coef_arena.numel() + sh.out_arena.numel()),
-                "kernel_path": sh.path, "verified_vs_oracle": bool(ok),
-                "what": "the N > 1 job's kernel-only figure at N = 1: divide the N-GPU `value` by this for the scaling efficiency on one workload"}
-    finally:
-        sh.close()
-
-
-def e2e_files(synth, w, h, encoder, distinct=4, restart_rows=0):
-    """`distinct` baseline 4:2:0 q85 files of the bench's synthetic image (seeds 0x5EED + k); -> (files, who wrote them).
-    restart_rows: a restart marker every that many MCU rows (DRI)."""
-    rgbs = [synth.synthetic_rgb(w, h, seed=0x5EED + k) for k in range(distinct)]
-    rst = f"a restart marker every {restart_rows} MCU row(s)" if restart_rows else "no restart markers"
-    if encoder in ("auto", "pillow"):
-        try:
-            import io
-            import PIL
-            from PIL import Image
-            out = []
-            for rgb in rgbs:
-                buf = io.BytesIO()
-                Image.fromarray(rgb).save(buf, format="JPEG", quality=85, subsampling="4:2:0",
-                                          **({"restart_marker_rows": restart_rows} if restart_rows else {}))
-                out.append(buf.getvalue())
-            if not restart_rows or all(b"\xff\xdd\x00\x04" in d[:1024] for d in out):  # (an older Pillow ignores the keyword)
-                return out, f"Pillow {PIL.__version__} (libjpeg-turbo), quality 85, 4:2:0, default (Annex K) Huffman tables, {rst}"
-        except ImportError:
-            if encoder == "pillow":
-                raise
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import baseline_encoder as E
-    ri = restart_rows * ((w + 15) // 16)
-    return [E.encode_rgb(rgb, 85, "420", ri) for rgb in rgbs], f"tools/baseline_encoder.py (this repo), quality 85, 4:2:0, Annex K Huffman tables, {rst}"
-
-
-VALU_CYCLES = 4.6  # issue cycles per wave64 vector instruction of the decoder's kind (measured: see sync_pass_instructions)
-
-
-def sync_pass_instructions(symbols_per_call):
-    """Vector instructions of the chunk decoder's sync passes per Huffman symbol, from the committed counter passes of a 256-file
-    call as one sub-batch (profiles/roundN/*pipeline_256*pmc*.json: SQ_INSTS_VALU per dispatch x dispatches, all sync launches of
-    the call): wave-instructions per symbol, and x 64 = lane slots per symbol (a scalar decoder's step is ~100 instructions)."""
-    import glob
-    for rnd in ("round5", "round4", "round3"):
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", rnd, "*pipeline_256*pmc*.json")) + glob.glob(os.path.join(ROOT, "profiles", rnd, "*pipe256*stats*.json"))):
-            try:
-                doc = json.load(open(f))
-            except (OSError, ValueError):
-                continue
-            wave_instr = every = 0.0
-            for name, e in doc.items():
-                if not isinstance(e, dict) or "pmc" not in e or "SQ_INSTS_VALU" not in e["pmc"]:
-                    continue
-                every += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
-                if "huff_sync_pass_kernel" in name or "huff_sync_late_kernel" in name:
-                    wave_instr += e["pmc"]["SQ_INSTS_VALU"] * e["calls"]
-            calls = doc.get("_calls_of_the_pipeline") or 6  # (tools/pipe_calls.py / round 3's script: six calls per profiled process)
-            if wave_instr:
-                per_call = wave_instr / calls
-                # What the vector units alone need for a call's kernels: every wave-instruction occupies its SIMD for VALU_CYCLES cycles
-                # (profiles/round4/02_ubench_valu64.txt, round2/00_valu_issue_cost_ubench.txt: 4.5-4.9 for the shifts, selects and
-                # logic the decoder is made of), 1,024 SIMDs at 2.4 GHz — a floor no overlap of sub-batches gets under.
-                issue_ms_per_image = every / calls / 256.0 * VALU_CYCLES / (1024 * 2.4e9) * 1e3
-                return {"wave_instructions_per_symbol": round(per_call / symbols_per_call, 2), "lane_slots_per_symbol": round(64 * per_call / symbols_per_call, 1),
-                        "all_kernels_wave_instructions_per_image": int(every / calls / 256.0), "vector_issue_floor_ms_per_image": round(issue_ms_per_image, 5),
-                        "vector_issue_floor_what": f"SQ_INSTS_VALU of every kernel of the call x {VALU_CYCLES} cycles / (1,024 SIMDs x 2.4 GHz)",
-                        "source": os.path.relpath(f, ROOT) + " (SQ_INSTS_VALU per dispatch of one 256-file call as one sub-batch; read from the file, not measured in this run)"}
-    return None
-
-
-def e2e_floor_fields(e, best, h2d_gbps, alone_ms_per_image):
-    """An E entry on its own roofline: the link floor (entropy-coded bytes that cross PCIe at the H2D rate one pinned 1-GB copy
-    reached in this run), the device-work floor (the kernels' time per image with the device to itself — sync passes, expansion,
-    pixel kernels of one sub-batch of 256 alone — times the images), and how close the call's wall clock is to the larger one."""
-    link = best["coefficient_bytes"] / (h2d_gbps * 1e9) * 1e3 if h2d_gbps else None
-    work = alone_ms_per_image * e["images"] if alone_ms_per_image else None
-    floors = [x for x in (link, work) if x]
-    e["pcie_bytes"] = int(best["coefficient_bytes"])
-    e["link_floor_ms"] = round(link, 3) if link else None
-    e["device_work_ms"] = round(work, 3) if work else None
-    e["frac_of_floor"] = round(max(floors) / e["total_ms"], 4) if floors else None
-    e["bound"] = None if not floors else ("link" if link and link >= (work or 0) else "device work")
-
-
-def d2h_rate_gbps(torch, dev, nbytes=1 << 30):
-    """The other direction of the link: one pinned 1-GB device-to-host copy, best of 3, this run (the floor of an E call that hands its
-    pixels to a host consumer — Decoder::decode()'s Vec<u8>, src/decoder.rs:293-295 — is its pixel bytes at this rate)."""
-    dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize(dev)
-    best = None
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dst.copy_(src, non_blocking=True)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1)
-        best = ms if best is None else min(best, ms)
-    del src, dst
-    return nbytes / (best * 1e-3) / 1e9
-
-
-def host_memory_available():
-    """Bytes of host memory this process may still take: MemAvailable, capped by what a cgroup limit leaves (None if unknown)."""
-    avail = None
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable:"):
-                avail = int(line.split()[1]) * 1024
-                break
-    except (OSError, ValueError):
-        pass
-    try:
-        mx = open("/sys/fs/cgroup/memory.max").read().strip()
-        if mx != "max":
-            left = int(mx) - int(open("/sys/fs/cgroup/memory.current").read().strip())
-            avail = left if avail is None else min(avail, left)
-    except (OSError, ValueError):
-        pass
-    return avail
-
-
-def warm_calls(p, files, calls, cold=1, **kw):
-    """`cold` uncounted calls (the first one allocates arenas and staging), then `calls` counted ones -> their timings, in call order.
-    Raises the first per-image error."""
-    out = []
-    for r in range(cold + calls):
-        res = p.decode(files, **kw)
-        bad = [x for x in res if isinstance(x, Exception)]
-        if bad:
-            raise bad[0]
-        if r >= cold:
-            out.append(p.timings())
-    return out
-
-
-def call_stats(ts, key="total_ms"):
-    """median + min of the counted calls.  -> (the timings of the median call, median ms, min ms)"""
-    order = sorted(ts, key=lambda t: t[key])
-    med = order[(len(order) - 1) // 2]  # (lower median: a call that really happened, whose other fields go with it)
-    return med, med[key], order[0][key]
-
-
-def e2e_entry(n, ts, w, h, p, ok, extra=None):
-    med, med_ms, min_ms = call_stats(ts)
-    e = {"images": n, "calls": len(ts), "total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3),
-         "images_per_s": round(n / med_ms * 1e3, 1), "images_per_s_best": round(n / min_ms * 1e3, 1),
-         "value": round(n * w * h / 1e6 / med_ms * 1e3, 1), "unit": "MP/s",
-         "wall_ms": {k[:-3]: round(med[k], 3) for k in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "download_ms")},
-         "cpu_ms_per_image": round(med["cpu_ms"] / max(n, 1), 5),
-         "images_device_entropy": int(med["images_device_entropy"]), "images_device_rejected": int(med["images_device_rejected"]),
-         "images_host_light": int(med["images_host_light"]), "threads": int(med["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(ok)}
-    if extra:
-        e.update(extra)
-    return e, med
-
-
-def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
-    """What the metric's words say: JPEG bytes in host memory -> RGB in HBM, through jpgpu_pipeline_decode with the entropy
-    decoding on the device (no host Huffman decoding, no range scan, no host synchronisation in front of the pixel kernels).
-    Per batch size: median and min of 7 warm calls (wall clock of the call, everything included: header parsing, staging, H2D, kernels)
-    and a check of first / middle / last image against the oracle; the kernel time per phase from one sub-batch run alone."""
-    os.environ["JPGPU_BATCH_KERNEL_TIMES"] = "1"  # (read once by the library: events around the phases, microseconds per sub-batch)
-    distinct, who = e2e_files(synth, w, h, encoder)
-    want = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in distinct]
-    out = {"input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}",
-           "jpeg_bytes_per_image": int(sum(len(d) for d in distinct) / len(distinct)),
-           "what": "jpgpu_pipeline_decode: JPEG bytes in host memory -> RGB resident in HBM; entropy decoding ON THE DEVICE "
-                   "(self-synchronising chunk decoder with speculative emission), classes from its statistics, pixel kernels right behind it; "
-                   "per entry 7 warm calls after 2 uncounted ones: total_ms / images_per_s / value = their MEDIAN, min_ms / images_per_s_best = the "
-                   "fastest (SURVEY 8d); wall clock of the whole call; cpu_ms_per_image = process CPU time of the median call / images"}
-    p = J.Pipeline()
-    bests = {}
-    try:
-        for n in sizes:
-            files = [distinct[i % len(distinct)] for i in range(n)]
-            # (the first call allocates arenas and staging: not counted — and calls 2-3 still run ~20 % slower than the steady state)
-            ts = warm_calls(p, files, 7, cold=2, download=False, device_entropy=True)
-            ok = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, 1, n // 2, n - 1}))
-            out[str(n)], bests[str(n)] = e2e_entry(n, ts, w, h, p, ok)
-        # The same calls with the files in PINNED host memory (JPGPU_PIPELINE_INPUT_PINNED, PinnedFiles: what a loader that reads into
-        # jpgpu_host_alloc memory hands over): the copy engine reads the scans where they lie — no staging copy on the host at all, and
-        # the sub-batches' launches follow one another in tenths of a millisecond instead of 0.8 ms each (the host's memcpy of 25 MB)
-        for n in [x for x in (256, 4096) if x in sizes]:
-            key = f"{n}_pinned_input"
-            try:
-                arena = J.PinnedFiles([distinct[i % len(distinct)] for i in range(n)])
-                try:
-                    ts = warm_calls(p, arena, 7, cold=2, download=False, device_entropy=True, input_pinned=True)
-                    ok = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, 1, n // 2, n - 1}))
-                    out[key], _ = e2e_entry(n, ts, w, h, p, ok, {"input": "the same files in one pinned arena (jpgpu_host_alloc), JPGPU_PIPELINE_INPUT_PINNED"})
-                finally:
-                    arena.close()
-            except Exception as e:  # noqa: BLE001 (this entry only)
-                out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        # The kernels alone: the same 256 files as ONE sub-batch with the device to itself (the pipeline's default splits a call into
-        # sub-batches of 128 that run side by side on their own streams: their phase times overlap and do not add up to anything).
-        os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"] = "256", "1"
-        try:
-            files = [distinct[i % len(distinct)] for i in range(256)]
-            best = None
-            for r in range(4):
-                res = p.decode(files, download=False, device_entropy=True)
-                t = p.timings()
-                if r > 0 and t["dev_times_valid"] and (best is None or t["dev_sync_ms"] + t["dev_write_ms"] + t["dev_pixel_ms"] < best["dev_sync_ms"] + best["dev_write_ms"] + best["dev_pixel_ms"]):
-                    best = t
-            if best is not None:
-                km = {"sync_ms": best["dev_sync_ms"], "expand_ms": best["dev_write_ms"], "pixel_ms": best["dev_pixel_ms"]}
-                out["kernels_256_one_sub_batch"] = {
-                    "what": "256 files as one sub-batch, nothing else on the device: events between the phases on its stream — sync passes "
-                            "(with speculative emission) + block numbering | expansion of the emitted lists into whole blocks + DC sums of "
-                            "uniform scans | class finalize + pixel kernels.  No zero fill, no range scan, no write pass.",
-                    "kernel_ms": {**{k: round(v, 3) for k, v in km.items()}, "sum": round(sum(km.values()), 3)},
-                    "kernels_only_images_per_s": round(256 / sum(km.values()) * 1e3, 1), "total_ms": round(best["total_ms"], 3)}
-                # every E entry against its own floors (VERDICT r3 next #1a)
-                symbols = sum(huffman_symbols(J, d) for d in distinct) / len(distinct)
-                spi = sync_pass_instructions(256 * symbols)
-                for key, b in bests.items():
-                    e2e_floor_fields(out[key], b, h2d_gbps, sum(km.values()) / 256.0)
-                    if spi:
-                        out[key]["vector_issue_floor_ms"] = round(spi["vector_issue_floor_ms_per_image"] * out[key]["images"], 3)
-                        out[key]["frac_of_hard_floor"] = round(max(out[key]["vector_issue_floor_ms"], out[key]["link_floor_ms"] or 0.0) / out[key]["total_ms"], 4)
-                out["roofline"] = {
-                    "h2d_gbps": round(h2d_gbps, 2) if h2d_gbps else None,
-                    "h2d_what": "one pinned 1-GB host-to-device copy, best of 3, this run",
-                    "device_work_ms_per_image": round(sum(km.values()) / 256.0, 5),
-                    "device_work_what": "kernels_256_one_sub_batch.kernel_ms.sum / 256: sync passes + block numbering + expansion + pixel kernels with the device to themselves "
-                                        "(the late sync passes' chains included: an upper estimate of the work, a lower one of a lone sub-batch's latency)",
-                    "huffman_symbols_per_image": int(symbols), "bits_per_symbol": round(out["jpeg_bytes_per_image"] * 8 / symbols, 2),
-                    "sync_ns_per_symbol": round(km["sync_ms"] * 1e6 / (256 * symbols), 4),
-                    "sync_pass_vector_instructions": spi,
-                    "frac_of_floor": "max(link_floor_ms, device_work_ms) / total_ms per entry: 1.0 = the call takes what its larger floor takes "
-                                     "(device_work_ms is measured, not a bound: overlapping sub-batches get under it)",
-                    "frac_of_hard_floor": "max(link_floor_ms, vector_issue_floor_ms) / total_ms: the two floors nothing gets under — the PCIe link and the "
-                                          "vector instructions the kernels issue"}
-        finally:
-            del os.environ["JPGPU_PIPE_DEV_SUB"], os.environ["JPGPU_PIPE_MAX_DEV_SUBS"]
-        files_for_cpu = [distinct[i % len(distinct)] for i in range(256)]
-        # The same images written with a restart marker after every MCU row (DRI): the chunk decoder takes each restart interval as
-        # its own run of chunks (csrc/huff_job.hpp huff_chunk_span) — same kernels, no host entropy decoding either.
-        if sizes and max(sizes) >= 1024:
-            try:
-                rfiles, rwho = e2e_files(synth, w, h, encoder, restart_rows=1)
-                rwant = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in rfiles]
-                n = 1024
-                files = [rfiles[i % len(rfiles)] for i in range(n)]
-                ts = warm_calls(p, files, 5, cold=1, download=False, device_entropy=True)
-                okr = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == rwant[i % len(rfiles)] for i in (0, 1, n // 2, n - 1))
-                out["restart_every_mcu_row_1024"], _ = e2e_entry(n, ts, w, h, p, okr, {"input": f"{len(rfiles)} distinct {w}x{h} files, repeated; written by {rwho}"})
-            except Exception as e:  # noqa: BLE001 (this entry only)
-                out["restart_every_mcu_row_1024"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        # E as SURVEY 8(d) words it for one GPU — JPEG bytes in host memory -> RGB in HOST memory, what Decoder::decode() returns
-        # (a Vec<u8>, src/decoder.rs:293-295): JPGPU_PIPELINE_DOWNLOAD, every sub-batch's pixels copied to pinned host memory behind its
-        # kernels on a download stream of its own.  Floor: the pixel bytes at the D2H rate one pinned 1-GB copy reached in this run.
-        for n in [x for x in (256, 4096) if sizes and x <= max(sizes)]:
-            key = f"to_host_{n}"
-            try:
-                # (the pixels of the call stay in pinned host memory: 25.5 GB for 4,096 files — not on a box that cannot spare twice that)
-                need, avail = n * w * h * 3, host_memory_available()
-                if avail is not None and avail < 2 * need + (8 << 30):
-                    out[key] = {"skipped": f"{need >> 20} MB of pinned host memory needed, {avail >> 20} MB available to this process"}
-                    continue
-                files = [distinct[i % len(distinct)] for i in range(n)]
-                ts = warm_calls(p, files, 5, cold=1, download="pinned", device_entropy=True)
-                ok = all(hashlib.sha256(p.pixels_host(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, 1, n // 2, n - 1}))
-                e, med = e2e_entry(n, ts, w, h, p, ok)
-                e["pixel_bytes"] = int(med["pixel_bytes"])
-                if d2h_gbps:
-                    e["link_floor_ms"] = round(med["pixel_bytes"] / (d2h_gbps * 1e9) * 1e3, 3)
-                    e["frac_of_floor"] = round(e["link_floor_ms"] / e["total_ms"], 4)
-                    e["frac_of_floor_best"] = round(e["link_floor_ms"] / e["min_ms"], 4)
-                    e["bound"] = "link (device to host)"
-                    e["d2h_gbps"] = round(d2h_gbps, 2)
-                e["what"] = "JPEG bytes in host memory -> RGB in pinned HOST memory (JPGPU_PIPELINE_DOWNLOAD): the D2H copy of a sub-batch runs behind its kernels on a download stream, next to the decode of the following sub-batches"
-                out[key] = e
-            except Exception as e:  # noqa: BLE001 (this entry only)
-                out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        # BASELINE configs[3]: benches/tower_progressive.jpg (512 x 512 progressive, 10 scans) x 256 and x 4,096.  Round 5: the scans of a
-        # progressive frame are decoded ON THE DEVICE — one lane per chain of dependent scans, coefficients accumulated in the arena
-        # (csrc/huff_prog_core.hpp; SURVEY 8f n3) — for as many of a call's frames as finish while the host's threads decode the rest.
-        tp = os.path.join(ROOT, "tests", "golden", "benches", "tower_progressive.jpg")
-        if os.path.exists(tp):
-            data = open(tp, "rb").read()
-            od = O.decode(data)
-            for n in [x for x in (256, 4096) if sizes and x <= max(sizes)]:
-                key = f"tower_progressive_{n}"
-                try:
-                    files = [data] * n
-                    # (five uncounted calls: the dispatcher's probe, three all-host calls — the last two give it the host's rate —, and the
-                    # first call of the route it then picks)
-                    ts = warm_calls(p, files, 5, cold=5, download=False, device_entropy=True)
-                    okp = all(np.array_equal(p.download(i), od.pixels) for i in sorted({0, 1, n // 2, n - 1}))
-                    e, med = e2e_entry(n, ts, od.width, od.height, p, okp)
-                    e["file"] = "tests/golden/benches/tower_progressive.jpg (the reference's benches/tower_progressive.jpg: 512x512, 10 scans)"
-                    e["images_device_progressive"] = int(med["images_device_progressive"])
-                    ts_h = warm_calls(p, files, 3, cold=1, download=False, device_entropy=True, progressive_on_host=True)
-                    _m, med_ms, min_ms = call_stats(ts_h)
-                    e["all_on_host_entropy_decoder"] = {"total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3), "images_per_s": round(n / med_ms * 1e3, 1),
-                                                        "what": "the same call with JPGPU_PIPELINE_PROGRESSIVE_ON_HOST (round 4's path: host entropy decoding, compact planes uploaded)"}
-                    out[key] = e
-                except Exception as e:  # noqa: BLE001 (this entry only)
-                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            files_for_cpu = (files_for_cpu, [data] * 64, (od.width, od.height))
-            # The same size and script, 64 DIFFERENT frames (Pillow: 512 x 512 4:4:4 progressive, quality 85, seeds 0x700 + k): the lanes of a
-            # wave then walk different streams — every divergent step costs the wave — which copies of one file hide
-            if sizes and max(sizes) >= 4096:
-                try:
-                    import io
-                    from PIL import Image
-                    frames = []
-                    for k in range(64):
-                        buf = io.BytesIO()
-                        Image.fromarray(synth.synthetic_rgb(512, 512, seed=0x700 + k)).save(buf, format="JPEG", quality=85, subsampling="4:4:4", progressive=True)
-                        frames.append(buf.getvalue())
-                    n = 4096
-                    files = [frames[i % 64] for i in range(n)]
-                    ts = warm_calls(p, files, 5, cold=5, download=False, device_entropy=True)
-                    okd = all(np.array_equal(p.download(i), O.decode(frames[i % 64]).pixels) for i in (0, 1, 63, n // 2 + 7, n - 1))
-                    e, med = e2e_entry(n, ts, 512, 512, p, okd)
-                    e["input"] = "64 distinct 512x512 4:4:4 progressive frames (Pillow / libjpeg-turbo, quality 85, default script: 10 scans), repeated"
-                    e["jpeg_bytes_per_image"] = int(sum(len(f) for f in frames) / 64)
-                    e["images_device_progressive"] = int(med["images_device_progressive"])
-                    out["progressive_distinct_4096"] = e
-                except Exception as e:  # noqa: BLE001 (this entry only)
-                    out["progressive_distinct_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-    finally:
-        p.close()
-        J._native.lib().jpgpu_trim_caches()
-    return out, files_for_cpu
-
-
-def e2e_cpu_budget(J, O, synth, w, h, encoder, n=4096, points=(1, 2, 4, 8, 16)):
-    """E against the host CPUs a GPU's feeder gets: on an 8-GPU node with 16 granted CPUs every rank has two.  The
-    4,096-file call with the calling thread's affinity — and with it the pipeline's pools, created under it — narrowed to the first
-    1 / 2 / 4 / 8 / 16 allowed CPUs and threads = 2 x CPUs (rank_cpu_share's rule).  Per point: the files in ordinary (pageable) memory
-    with the mode the library chooses (host-light — raw scans copied, marker check + unstuffing on the device — for pipelines of <= 4
-    threads, host staging above), the same with either mode forced (A/B), and the files in a pinned arena (PinnedFiles: what a loader
-    that reads into jpgpu_host_alloc memory holds) with JPGPU_PIPELINE_INPUT_PINNED, where the copy engine reads the arena itself."""
-    distinct, who = e2e_files(synth, w, h, encoder)
-    want = [hashlib.sha256(O.decode(d).pixels.tobytes()).hexdigest() for d in distinct]
-    files = [distinct[i % len(distinct)] for i in range(n)]
-    allowed = sorted(os.sched_getaffinity(0))
-    granted = effective_cpus()
-    out = {"images": n, "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}", "host_cpus_granted": granted,
-           "what": "jpgpu_pipeline_decode of the same 4,096 files with affinity (sched_setaffinity before the pipeline's threads are created) and thread "
-                   "count limited: JPEG bytes in host memory -> RGB in HBM; per point and input median / min of 5 warm calls after two uncounted; "
-                   "cpu_ms_per_image = process CPU time of the median call / images",
-           "points": []}
-    arena = J.PinnedFiles(files)
-    try:
-        for c in points:
-            if c > min(granted, len(allowed)):
-                continue
-            row = {"cpus": c, "threads": max(2, 2 * c)}
-            os.sched_setaffinity(0, allowed[:c])
-            try:
-                p = J.Pipeline(threads=row["threads"])
-                try:
-                    for name, src, kw in (("pageable_input", files, {}), ("pageable_input_host_staging", files, {"host_light": False}),
-                                          ("pageable_input_host_light", files, {"host_light": True}), ("pinned_input", arena, {"input_pinned": True})):
-                        try:
-                            ts = warm_calls(p, src, 5, cold=2, download=False, device_entropy=True, **kw)
-                            ok = all(hashlib.sha256(p.download(i).tobytes()).hexdigest() == want[i % len(distinct)] for i in sorted({0, n // 2, n - 1}))
-                            med, med_ms, min_ms = call_stats(ts)
-                            row[name] = {"total_ms": round(med_ms, 3), "min_ms": round(min_ms, 3), "images_per_s": round(n / med_ms * 1e3, 1),
-                                         "cpu_ms_per_image": round(med["cpu_ms"] / n, 5), "cpus_busy": round(med["cpu_ms"] / med_ms, 2),
-                                         "mode": "host-light" if med["images_host_light"] else "host staging",
-                                         "images_host_light": int(med["images_host_light"]), "images_device_entropy": int(med["images_device_entropy"]),
-                                         "verified_vs_oracle": bool(ok)}
-                        except Exception as e:  # noqa: BLE001 (this point only)
-                            row[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                finally:
-                    p.close()
-            finally:
-                os.sched_setaffinity(0, allowed)
-            out["points"].append(row)
-    finally:
-        arena.close()
-        J._native.lib().jpgpu_trim_caches()
-    return out
-
-
-def cpu_baseline_e2e(O, files, w, h, target_seconds):
-    """The oracle's whole Decoder::decode() (marker parsing, Huffman decoding, IDCT, upsampling, colour conversion) on the e2e
-    block's files, one file per task on every core the process may use; bounded sample."""
-    progressive = None
-    if isinstance(files, tuple):
-        files, pfiles, (pw, ph) = files
-        progressive = cpu_baseline_e2e(O, pfiles, pw, ph, max(2.0, target_seconds / 3))
-    out = _cpu_e2e_sample(O, files, w, h, target_seconds)
-    if progressive:
-        out["tower_progressive"] = progressive
-    return out
-
-
-def _cpu_e2e_sample(O, files, w, h, target_seconds):
-    cores = effective_cpus()
-    flags = O.use_native_build()
-    n0 = max(2 * cores, 8)
-    t0 = time.perf_counter()
-    ok, _px = O.batch_decode([files[i % len(files)] for i in range(n0)], cores)
-    dt = time.perf_counter() - t0
-    n = int(max(n0, min(65536, n0 * target_seconds / max(dt, 1e-3))))
-    n = (n // cores) * cores or cores
-    t0 = time.perf_counter()
-    ok, px = O.batch_decode([files[i % len(files)] for i in range(n)], cores)
-    dt = time.perf_counter() - t0
-    return {"value": round(n * w * h / 1e6 / dt, 2), "unit": "MP/s", "images_per_s": round(n / dt, 1), "cores": cores, "kind": "port",
-            "sample": f"{n} decodes of the e2e block's {w}x{h} files ({ok} ok, {px} pixel bytes), JPEG bytes -> RGB in host memory, whole decode "
-                      f"(parse + Huffman + IDCT + upsampling + colour), {cores} threads one file per task, {dt:.1f} s; gcc {flags}; {cpu_model()}; "
-                      f"the crate's own x86 build would add SSSE3 IDCT / colour kernels (not bit-compatible with its scalar path)"}
-
-
-def e2e_sharded(J, O, synth, D, dist, torch, dev, rank, local_rank, world, w, h, total, encoder, share, threads, pinned):
-    """E at N ranks (north_star: "throughput on synthetic 4:2:0 baseline JPEGs is reported at 1, 2, 4 and 8 GPUs"): `total` files, rank r
-    decodes D.shard(total, r, world) of them through a pipeline of its own on ITS GPU with ITS share of the host (CPU affinity set,
-    threads = 2 x granted CPUs / ranks); every call starts behind a barrier, so the ranks contend for the host at the same moment; the
-    job's time is the slowest rank's (MAX over ranks) median — and min — of 5 warm calls.  No collective on the data path; pixels
-    stay in each rank's HBM.
-    Collectives and failures: every rank runs the SAME sequence of collectives whatever happens to it locally — a local
-    error is caught, kept, and an all-reduced flag after every call lets all ranks leave the loop together; the error is re-raised only
-    after the last collective."""
-    err, p, files, ts, distinct, who = None, None, [], [], [], ""
-    mine = D.shard(total, rank, world)
-    try:
-        distinct, who = e2e_files(synth, w, h, encoder)
-        files = [distinct[i % len(distinct)] for i in mine]
-        p = J.Pipeline(device=local_rank, threads=threads)
-    except Exception as e:  # noqa: BLE001 (kept: see above)
-        err = e
-    for r in range(6):  # the first call allocates arenas and staging: not counted
-        torch.cuda.synchronize(dev)
-        if dist:
-            dist.barrier()
-        if err is None:
-            try:
-                res = p.decode(files, download=False, device_entropy=True)
-                bad = [x for x in res if isinstance(x, Exception)]
-                if bad:
-                    raise bad[0]
-                if r > 0:
-                    ts.append(p.timings())
-            except Exception as e:  # noqa: BLE001
-                err = e
-        if D.min_over_ranks(0.0 if err else 1.0, device=dev) < 1.0:
-            break  # (every rank sees the same flag: all leave here together)
-    ok, mine_ms, mine_min, med, kernel_path = 0.0, 0.0, 0.0, None, ""
-    if err is None:
-        try:
-            ok = 1.0
-            if files:
-                want = {k: hashlib.sha256(O.decode(distinct[k]).pixels.tobytes()).hexdigest() for k in {mine[0] % len(distinct), mine[len(mine) - 1] % len(distinct)}}
-                for j in (0, len(files) - 1):
-                    ok = min(ok, 1.0 if hashlib.sha256(p.download(j).tobytes()).hexdigest() == want[mine[j] % len(distinct)] else 0.0)
-            if ts:
-                med, mine_ms, mine_min = call_stats(ts)
-            kernel_path = p.kernel_path
-        except Exception as e:  # noqa: BLE001
-            err, ok = e, 0.0
-    slowest, slowest_min, cpu_ms = D.max_over_ranks([mine_ms, mine_min, med["cpu_ms"] if med else 0.0], device=dev)
-    all_ok = D.min_over_ranks(ok if err is None else 0.0, device=dev)
-    if p is not None:
-        p.close()
-    if err is not None:
-        raise err  # (after the last collective of this leg)
-    return {"images": total, "images_per_rank": len(files), "ranks": world, "calls": len(ts), "total_ms": round(slowest, 3), "min_ms": round(slowest_min, 3),
-            "images_per_s": round(total / slowest * 1e3, 1) if slowest else None,
-            "images_per_s_best": round(total / slowest_min * 1e3, 1) if slowest_min else None,
-            "value": round(total * w * h / 1e6 / slowest * 1e3, 1) if slowest else None, "unit": "MP/s",
-            "rank0_ms": round(mine_ms, 3), "threads_per_rank": threads, "cpus_per_rank": len(share), "cpu_affinity_set": bool(pinned),
-            "cpu_ms_per_image_slowest_rank": round(cpu_ms / max(len(files), 1), 5),
-            "mode": ("host-light" if med and med["images_host_light"] else "host staging"),
-            "host_cpus_granted": effective_cpus_unpinned(), "kernel_path": kernel_path, "verified_vs_oracle": bool(all_ok >= 1.0), "every_rank_ok": bool(all_ok >= 1.0),
-            "input": f"{len(distinct)} distinct {w}x{h} files, repeated; written by {who}",
-            "what": "jpgpu_pipeline_decode per rank on its shard of the file list (entropy decoding on the device), every call behind a barrier; "
-                    "MAX over ranks of each rank's median (total_ms) and min (min_ms) of 5 warm calls; pixels stay in each rank's HBM"}
-
-
-_UNPINNED_CPUS = None
-
-
-def effective_cpus_unpinned():
-    """effective_cpus() as it was before this process narrowed its own affinity mask (rank_cpu_share / pin_to)."""
-    return _UNPINNED_CPUS if _UNPINNED_CPUS is not None else effective_cpus()
 
 
 class Shard:
@@ -982,73 +368,6 @@ class PixelGather:
         self.pending = []
 
 
-# ---------------------------------------------------------------------------------------------------------------
-def dry_run(args, rank, world, workload, images_total, n_img, n_sub):
-    """No GPU: the N>1 bookkeeping on CPU tensors over gloo — shard sizes, per-sub-batch gather to rank 0, max over
-    ranks, the per-rank host budget of the e2e leg (CPU share, thread count, its shard of the file list) and the JSON contract.
-    Measures nothing (value is null)."""
-    import torch
-    import jpeg_decoder_amd.distributed as D
-
-    dist = D.init(backend="gloo") if world > 1 else None
-    # the e2e leg's host budget, exactly as the GPU run sets it up (rank_cpu_share + pin_to), checked across ranks below
-    global _UNPINNED_CPUS
-    _UNPINNED_CPUS = effective_cpus()
-    share, threads = rank_cpu_share(rank, world)
-    pinned = pin_to(share)
-    e2e_mine = D.shard(E2E_SHARDED_TOTAL, rank, world)
-    budget = torch.tensor([float(threads), float(len(share)), float(min(share)), float(max(share)), float(len(e2e_mine)), 1.0 if pinned else 0.0], dtype=torch.float64)
-    budgets = [torch.zeros_like(budget) for _ in range(world)]
-    if dist:
-        dist.all_gather(budgets, budget)
-    else:
-        budgets = [budget]
-    mine = D.shard(images_total, rank, world) if images_total else range(rank * n_img, (rank + 1) * n_img)
-    n_sub = max(1, min(n_sub, len(mine)))
-    bounds = [(len(mine) * s // n_sub, len(mine) * (s + 1) // n_sub) for s in range(n_sub)]
-    tag = 5  # bytes standing in for one image's pixels: the image's global index
-    slices = []
-    for a, b in bounds:
-        t = torch.zeros((b - a) * tag, dtype=torch.uint8)
-        for k in range(a, b):
-            t[(k - a) * tag:(k - a + 1) * tag] = mine[k] % 251
-        slices.append(t)
-    ok = True
-    if dist:
-        g = PixelGather(dist, torch, rank, world, slices, "cpu")
-        for s in range(n_sub):
-            g.post(s)
-        g.wait()
-        dist.barrier()
-        if rank == 0:
-            for r in range(1, world):
-                theirs = D.shard(images_total, r, world) if images_total else range(r * n_img, (r + 1) * n_img)
-                tb = [(len(theirs) * s // n_sub, len(theirs) * (s + 1) // n_sub) for s in range(n_sub)]
-                for s, (a, b) in enumerate(tb):
-                    ok = ok and g.recv[r - 1][s].numel() == (b - a) * tag
-                    for k in range(a, b):
-                        ok = ok and bool((g.recv[r - 1][s][(k - a) * tag:(k - a + 1) * tag] == theirs[k] % 251).all())
-        t = D.max_over_ranks([float(rank)])
-        ok = ok and t == [float(world - 1)]
-    if rank == 0:
-        w, h = WORKLOADS[workload][0], WORKLOADS[workload][1]
-        rows = [[float(x) for x in b] for b in budgets]
-        disjoint = all(rows[i][3] < rows[i + 1][2] for i in range(len(rows) - 1)) or len(sorted(os.sched_getaffinity(0))) < world
-        print(json.dumps({"metric": "megapixels/s decoded (batch, whole node)", "value": None, "unit": "MP/s", "n_gpus": world,
-                          "dry_run": True, "scaling": "strong" if images_total else "weak",
-                          "config": {"workload": f"{w}x{h}", "name": workload, "images_total": images_total or world * n_img,
-                                     "images_per_gpu": len(mine), "sub_batches": n_sub},
-                          "gather_checked": ok, "value_with_gather": None, "gather_ms": None,
-                          "e2e": {"sharded": {"images": E2E_SHARDED_TOTAL, "ranks": world, "images_per_rank": [int(r[4]) for r in rows],
-                                              "threads_per_rank": [int(r[0]) for r in rows], "cpus_per_rank": [int(r[1]) for r in rows],
-                                              "cpu_shares_disjoint": bool(disjoint), "cpu_affinity_set": [bool(r[5]) for r in rows],
-                                              "host_cpus_granted": _UNPINNED_CPUS, "total_ms": None}}}), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0 if ok else 1
-
-
 def time_steps(torch, dev, dist, stream, steps, body):
     """`steps` calls of body() between barrier + synchronize on both sides; (wall seconds, GPU ms per step from events
     on the stream the kernels are launched on)."""
@@ -1069,9 +388,123 @@ def time_steps(torch, dev, dist, stream, steps, body):
     return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the contract line (the LAST stdout line; everything else is the detail document)
+# ---------------------------------------------------------------------------------------------------------------
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _num(d, *path):
+    """d[path...] if it is there and a number / bool / None-free scalar, else None."""
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d if isinstance(d, (int, float, bool)) else None
+
+
+def e2e_summary(detail):
+    """Ten scalars of the side legs for the contract line (VERDICT r5 #1); None where a leg did not run."""
+    e = detail.get("e2e") or {}
+    pts = (e.get("cpu_budget") or {}).get("points") or []
+    at2 = next((p for p in pts if p.get("cpus") == 2), None)
+    worst = None  # the library's own choice against the better of the two forced modes, worst point (1.0 = the default is the better one)
+    for p in pts:
+        mine = _num(p, "pageable_input", "images_per_s")
+        forced = [x for x in (_num(p, "pageable_input_host_staging", "images_per_s"), _num(p, "pageable_input_host_light", "images_per_s")) if x]
+        if mine and forced:
+            worst = min(worst, mine / max(forced)) if worst is not None else mine / max(forced)
+    out = {
+        "e2e_256_ms": _num(e, "256", "total_ms"), "e2e_4096_ms": _num(e, "4096", "total_ms"),
+        "e2e_4096_images_per_s": _num(e, "4096", "images_per_s"),
+        "to_host_4096_frac_of_floor": _num(e, "to_host_4096", "frac_of_floor"),
+        "progressive_256_images_per_s": _num(e, "tower_progressive_256", "images_per_s"),
+        "progressive_256_on_device": _num(e, "tower_progressive_256", "images_device_progressive"),
+        "progressive_4096_images_per_s": _num(e, "tower_progressive_4096", "images_per_s"),
+        "progressive_distinct_4096_images_per_s": _num(e, "progressive_distinct_4096", "images_per_s"),
+        "cpu_budget_2cpus_images_per_s": _num(at2, "pageable_input", "images_per_s"),
+        "cpu_budget_default_vs_best_forced_worst": round(worst, 4) if worst is not None else None,
+    }
+    if isinstance(e.get("sharded"), dict):  # N > 1 / --force-dist: E per rank, the job's rate
+        out = {"sharded_images_per_s": _num(e, "sharded", "images_per_s"), "sharded_total_ms": _num(e, "sharded", "total_ms"),
+               "sharded_mode": e["sharded"].get("mode"), **{k: v for k, v in out.items() if v is not None}}
+    return out
+
+
+def contract_line(detail, detail_path=None):
+    """The driver's record: bench.py's contract keys + `roofline` + `cpu_baseline` + `e2e_summary`, at most CONTRACT_LINE_MAX
+    bytes as JSON (free text is cut, never a number).  `detail` is the full document of this run."""
+    line = _pick(detail, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                          "dtype", "data", "verified_vs_oracle", "n_ranks_seen", "value_with_gather", "ms_per_step_with_gather", "gather_ms",
+                          "gather_verified", "gather_error", "dry_run", "gather_checked"))
+    cfg = detail.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "name", "images_total", "images_per_gpu", "sub_batches", "kernel_path", "range_class", "parallelism",
+                                  "collective_backend", "images_total_requested", "shrunk_to_fit_hbm"))
+    if isinstance(line["config"].get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:240]
+    if "roofline" in detail:
+        line["roofline"] = _pick(detail["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_commit",
+                                                      "traffic_taken_on_these_kernel_sources", "algorithmic_bytes_per_launch", "kernel_ms_per_launch"))
+        ref = detail["roofline"].get("stream_reference")
+        if ref:
+            line["roofline"]["kernel_vs_torch_add"] = ref.get("kernel_vs_reference")
+    if "cpu_baseline" in detail:
+        line["cpu_baseline"] = _pick(detail["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(detail["cpu_baseline"].get("sample", ""))[:200]
+    if "sustained" in detail:
+        line["sustained_value"] = _num(detail, "sustained", "value")
+    for k, sub in (("k_4096_frac", ("k_4096", "roofline_frac")), ("scale_anchor_frac", ("scale_anchor", "roofline_frac")),
+                   ("scale_anchor_value", ("scale_anchor", "value")), ("class0_frac", ("roofline_by_class", "class0", "frac")),
+                   ("classes_on_device_frac", ("roofline_by_class", "classes_on_device", "frac")),
+                   ("cpu_baseline_e2e_images_per_s", ("cpu_baseline_e2e", "images_per_s"))):
+        v = _num(detail, *sub)
+        if v is not None:
+            line[k] = v
+    if detail.get("e2e"):
+        line["e2e_summary"] = e2e_summary(detail)
+        if isinstance(detail["e2e"], dict) and detail["e2e"].get("error"):
+            line["e2e_summary"]["error"] = str(detail["e2e"]["error"])[:160]
+    if "bench_seconds" in detail:
+        line["bench_seconds"] = detail["bench_seconds"]
+    if detail_path:
+        line["detail"] = detail_path
+    txt = json.dumps(line)
+    if len(txt) > CONTRACT_LINE_MAX:  # (cannot happen with the keys above; the cap is the contract, so enforce it anyway)
+        for k in ("e2e_summary", "sustained_value", "detail", "bench_seconds"):
+            line.pop(k, None)
+        line["config"].pop("parallelism", None)
+        line["config"]["workload"] = line["config"].get("workload", "")[:80]
+        txt = json.dumps(line)
+    assert len(txt) <= CONTRACT_LINE_MAX, len(txt)
+    return txt
+
+
+def emit(detail, detail_path):
+    """Rank 0: the detail document (file + an earlier stdout line), then — LAST — the contract line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # (the collective library's banner sits in the C library's stdout buffer: out with it first)
+    except OSError:
+        pass
+    where = None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(detail_path) or ".", exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(detail, f, indent=1)
+            where = detail_path
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+    print("bench_detail: " + json.dumps(detail), flush=True)
+    print(contract_line(detail, where), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    t_start = time.perf_counter()
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not under_launcher and args.gpus > 1:
         sys.exit(launch_ranks(args, argv))
@@ -1089,13 +522,13 @@ def main(argv=None):
     import jpeg_decoder_amd.distributed as D
     n_img = len(D.shard(images_total, rank, world)) if images_total else (args.batch or default_batch)
     # N > 1: launch groups exist so that the gather of one group's pixels runs behind the decode of the next; a group below ~64 images does
-    # not fill the device (2160p, 8 images per group: 0.47 of the roofline against 0.58 in one launch, profiles/round3/10_other_workloads_bench.jsonl)
-    # (from the smallest shard, so that every rank makes the same number of groups: the gather pairs them up)
+    # not fill the device (from the smallest shard, so that every rank makes the same number of groups: the gather pairs them up)
     n_sub = args.sub_batches or (1 if world == 1 else min(8, max(1, ((images_total // world) if images_total else n_img) // 64)))
     steps = args.steps or (500 if world == 1 else 40)
     warmup = args.warmup if args.warmup >= 0 else (50 if world == 1 else 5)
+    import bench_e2e as E
     if args.dry_run:
-        sys.exit(dry_run(args, rank, world, workload, images_total, n_img, n_sub))
+        sys.exit(E.dry_run(args, rank, world, workload, images_total, n_img, n_sub))
 
     import torch
     if not torch.cuda.is_available():
@@ -1106,7 +539,13 @@ def main(argv=None):
     import jpeg_decoder_amd as J
     import synth
 
+    legs = {}  # seconds per leg (detail document): what the default run spends where
+
+    def leg(name, t0):
+        legs[name] = round(legs.get(name, 0.0) + time.perf_counter() - t0, 2)
+
     dist = D.init(backend="nccl", force=args.force_dist) if (world > 1 or args.force_dist) else None
+    t0 = time.perf_counter()
     variants = build_variants(J, synth, w, h, sampling, mode, ct, dct_scale)
     full_w, full_h = w, h
     if dct_scale != 8:  # a reduced-size decode produces ceil(W * scale / 8) x ceil(H * scale / 8) pixels (src/parser.rs:127-130)
@@ -1122,6 +561,7 @@ def main(argv=None):
         per_image = sum(algorithmic_bytes_per_image(v["comps"], w * h * (1 if v["ct"] == "Grayscale" else (4 if len(v["comps"]) == 4 else 3))) for v in variants) / nv
         free_b, _total_b = torch.cuda.mem_get_info(dev)
         budget = 0.92 * free_b
+
         def need(total):
             mine = len(D.shard(total, rank, world))
             recv = (total - mine) * (w * h * 3) if (rank == 0 and world > 1 and not args.no_gather) else 0
@@ -1138,7 +578,9 @@ def main(argv=None):
                 print(f"bench.py: {shrunk_from} images do not fit the free HBM of every rank (arenas + gather buffers): running {images_total}", file=sys.stderr)
     shard = Shard(J, torch, variants, n_img, n_sub, local_rank, generic=args.generic)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    leg("setup", t0)
 
+    t0 = time.perf_counter()
     settle = (max(0, 50 - warmup) if world == 1 else 0) if args.settle < 0 else args.settle
     for _ in range(settle + warmup):
         shard.decode(stream)
@@ -1164,10 +606,12 @@ def main(argv=None):
             s_elapsed += e
             chunk = min(chunk * 2, max(steps, int(chunk * args.min_seconds / max(e, 1e-6)) + 1))
         sustained = (s_steps, s_elapsed)
+    leg("headline", t0)
 
     # parity spot check inside the bench (oracle = checker only, never the thing measured)
-    verified = None
+    verified, digest, O = None, None, None
     if rank == 0:
+        t0 = time.perf_counter()
         import oracle as O
         verified = True
         for k, v in enumerate(variants):
@@ -1185,6 +629,7 @@ def main(argv=None):
                     print(f"bench.py: image {i} differs from the oracle in {bad.size} bytes, first at {bad[:8].tolist()}: got {got[bad[:8]].tolist()} want {want[bad[:8]].tolist()}", file=sys.stderr)
                 verified = verified and same
         ocomps, _ = O.make_components(full_w, full_h, sampling, dct_scale=dct_scale)
+        leg("verify", t0)
 
     total_images = images_total or world * n_img
     mp_per_step = total_images * w * h / 1e6
@@ -1201,9 +646,9 @@ def main(argv=None):
             "n_gpus": world, "steps": steps, "warmup": warmup, "settle_launches_before_warmup": settle,
             "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if images_total else "weak",
-            "vs_baseline": None, "dtype": "i32 fixed-point (i16 coefficients -> u8 pixels)", "data": "synthetic",
-            "config": {"workload": f"{full_w}x{full_h} baseline " + (f"decoded at {dct_scale}/8 ({w}x{h}) " if dct_scale != 8 else "") + " + ".join('x'.join(str(hh) + str(vv) for hh, vv in v["sampling"]) + " " + v["ct"]
-                                                                     for v in variants) +
+            "vs_baseline": None, "dtype": "i32", "dtype_note": "i32 fixed point: i16 coefficients -> u8 pixels", "data": "synthetic",
+            "config": {"workload": f"{full_w}x{full_h} baseline " + (f"decoded at {dct_scale}/8 ({w}x{h}) " if dct_scale != 8 else "") +
+                                   " + ".join('x'.join(str(hh) + str(vv) for hh, vv in v["sampling"]) + " " + v["ct"] for v in variants) +
                                    (" interleaved" if nv > 1 else "") +
                                    (f", {total_images} images in the job, {n_img} per GPU" if images_total else f", batch of {n_img} images per GPU") +
                                    " (coefficients resident in HBM -> RGB in HBM)",
@@ -1230,9 +675,10 @@ def main(argv=None):
             line["config"]["shrunk_to_fit_hbm"] = True
         line["config"]["arena_fill_copies"] = shard.fill_copies
 
-    # ---- N > 1: the same job with the final gather inside the timed region, overlapped per sub-batch ----
+    # ---- N > 1: the same job with the final gather inside the timed region, overlapped per launch group ----
     if dist and not args.no_gather:
         # (never lose the bench line to the collective: whatever goes wrong in here is reported in the line instead)
+        t0 = time.perf_counter()
         gather_error = None
         try:
             gather = PixelGather(dist, torch, rank, world, [shard.pixel_slice(s) for s in range(len(shard.batches))], dev)
@@ -1240,7 +686,7 @@ def main(argv=None):
             def step_with_gather():
                 for s, b in enumerate(shard.batches):
                     b.decode(stream)
-                    gather.post(s)  # behind sub-batch s on the stream; sub-batch s + 1 decodes while it moves
+                    gather.post(s)  # behind launch group s on the stream; group s + 1 decodes while it moves
                 gather.wait()
 
             def gather_only():
@@ -1263,7 +709,7 @@ def main(argv=None):
                 line["ms_per_step_with_gather"] = round(g_elapsed / args.gather_steps * 1e3, 3)
                 line["gather_ms"] = round(o_elapsed * 1e3, 3)
                 line["gather"] = {"bytes_into_root": int(sum(sum(t) for t in gather.sizes[1:])),
-                                  "form": "per sub-batch isend/irecv peer -> rank 0 (RCCL), overlapped with the next sub-batch's decode",
+                                  "form": "per launch group isend/irecv peer -> rank 0 (RCCL), overlapped with the next group's decode",
                                   "steps": args.gather_steps}
             del gather
         except Exception as e:  # noqa: BLE001
@@ -1272,144 +718,88 @@ def main(argv=None):
             line["value_with_gather"] = None
             line["gather_ms"] = None
             line["gather_error"] = gather_error
+        leg("gather", t0)
 
-    # ---- N = 1: what the arithmetic class is worth, and what finding it out on the device costs ----
-    if rank == 0 and world == 1 and not args.no_classes and not args.generic:
-        by_class = {}
-        top = min(v["sane"] for v in variants)
-        for cap in (0, 1, 3):
-            if cap > top:
-                continue
-            shard.set_classes(cap)
-            for _ in range(10):
-                shard.decode(stream)
-            _, ms = time_steps(torch, dev, None, stream, args.class_steps, lambda: shard.decode(stream))
-            by_class[f"class{cap}"] = {"kernel_ms_per_launch": round(ms, 4), "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-        shard.set_classes(None)
-        def scan_and_decode():  # the classification done where the coefficients are: range_scan_kernel + read-back of its result, every step
-            for b in shard.batches:
-                b.scan_ranges(stream)
-            shard.decode(stream)
+    # ---- N = 1 side legs (tools/bench_e2e.py); none of them is inside `value` ----
+    if rank == 0 and world == 1 and not args.no_classes:
+        t0 = time.perf_counter()
+        if not args.generic:
+            line["roofline_by_class"] = E.class_sweep(torch, shard, variants, dev, stream, alg_bytes, digest, n_img, args.class_steps)
+        line["roofline"]["stream_reference"] = E.stream_reference(torch, shard, dev, stream, line["roofline"]["achieved"])
+        leg("classes", t0)
 
-        for _ in range(5):
-            scan_and_decode()
-        _, ms = time_steps(torch, dev, None, stream, args.class_steps, scan_and_decode)
-        by_class["with_device_range_scan"] = {"kernel_ms_per_launch": round(ms, 4), "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                              "note": "jpgpu_batch_scan_ranges (range_scan_kernel over the arena + read-back of the classes, a host "
-                                                      "synchronisation) inside every timed step, then the decode: what a feeder pays that puts "
-                                                      "coefficients into HBM without looking at them"}
-        # The classification WITHOUT the host (round 3): the device keeps range statistics of the coefficients — the library's own
-        # writers (device entropy decoder, compact expansion, delta accumulation) raise them as a by-product; here one
-        # jpgpu_batch_classify_on_device pass outside the timed region stands in for them — and every decode turns them into the
-        # images' classes on the device: a finalize kernel + ONE `_dyn` pixel launch that branches per workgroup.  Nothing is
-        # read back, nothing synchronises.  This is what the pixel stage costs behind the repo's own entropy decoder (e2e).
-        for b in shard.batches:
-            b.classify_on_device(stream)
-        for _ in range(10):
-            shard.decode(stream)
-        _, ms = time_steps(torch, dev, None, stream, args.class_steps, lambda: shard.decode(stream))
-        counts = [sum(x) for x in zip(*[b.class_counts() for b in shard.batches])]
-        got_dyn = shard.image_pixels(n_img - 1).cpu().numpy()
-        by_class["classes_on_device"] = {
-            "kernel_ms_per_launch": round(ms, 4), "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "images_per_class_0_1_3": counts,
-            "verified_vs_oracle": bool(hashlib.sha256(got_dyn.tobytes()).hexdigest() == digest) if nv == 1 else None,
-            "note": "class statistics resident on the device, class_finalize kernel + the _dyn pixel kernel inside every timed step; no "
-                    "range scan, no read-back, no host synchronisation (replaces round 2's with_device_range_scan on the repo's own paths)"}
-        shard.set_classes(None)
-        by_class["note"] = ("class 3 = every |c*q| < 2^15 and every block column sum <= 5900 (legal 8-bit JPEG data), class 1 = the first only, "
-                            "class 0 = arbitrary i16 coefficients (wrap-exact kernels)")
-        line["roofline_by_class"] = by_class
-
-    if world == 1 and not args.no_classes:
-        # What the memory system gives an address-ordered stream of the same size and read/write mix, on this box, in this
-        # run: an elementwise add from the coefficient arena into the pixel arena (the pixels are verified by now).  Context
-        # for roofline.frac, which is quoted against the 8 TB/s peak: DESIGN.md 5.0.
-        n4 = min(shard.coef_arena.numel(), shard.out_arena.numel()) // 4 * 4
-        src, dst = shard.coef_arena[:n4].view(torch.int32), shard.out_arena[:n4].view(torch.int32)
-        for _ in range(3):
-            torch.add(src, 1, out=dst)
-        _, ms = time_steps(torch, dev, None, stream, 20, lambda: torch.add(src, 1, out=dst))
-        ref = 2.0 * n4 / (ms * 1e-3) / 1e9
-        line["roofline"]["stream_reference"] = {
-            "achieved": round(ref, 1), "unit": "GB/s", "ms": round(ms, 4), "frac_of_peak": round(ref / HBM_PEAK_GBPS, 4),
-            "kernel_vs_reference": round(line["roofline"]["achieved"] / ref, 4),
-            "what": "torch.add over this workload's own arenas (as many bytes read as written, address order), same box, same run"}
-
-    default_run = world == 1 and workload == "1080p-420" and not args.generic and not args.dry_run
-    if rank == 0 and default_run and not args.no_k4096:
-        # north_star's literal batch: 4096 images on one GPU (51 GB of arenas), same kernels, same verification
-        shard.close()
-        shard = None
-        torch.cuda.empty_cache()
-        try:
-            line["k_4096"] = k_4096(J, torch, O, variants, local_rank, dev, stream, w, h, digest)
-        except Exception as e:  # noqa: BLE001
-            line["k_4096"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        torch.cuda.empty_cache()
-    if rank == 0 and default_run and not args.no_scale_anchor and not args.force_dist:
+    def drop_shard():
+        nonlocal shard
         if shard is not None:
             shard.close()
             shard = None
         torch.cuda.empty_cache()
+
+    def guarded(key, fn, into=None):
+        """Never lose the line to a side leg: its error goes where its result would have gone."""
+        t0 = time.perf_counter()
+        into = line if into is None else into
         try:
-            line["scale_anchor"] = scale_anchor(J, torch, O, synth, D, local_rank, dev, stream)
+            into[key] = fn()
         except Exception as e:  # noqa: BLE001
-            line["scale_anchor"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            into[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        leg(key, t0)
         torch.cuda.empty_cache()
+
+    default_run = world == 1 and workload == "1080p-420" and not args.generic
+    if rank == 0 and default_run and not args.no_k4096:
+        drop_shard()  # north_star's literal batch: 4096 images on one GPU (51 GB of arenas), same kernels, same verification
+        guarded("k_4096", lambda: E.k_4096(J, torch, O, variants, local_rank, dev, stream, w, h, digest))
+    if rank == 0 and default_run and not args.no_scale_anchor and not args.force_dist:
+        drop_shard()
+        guarded("scale_anchor", lambda: E.scale_anchor(J, torch, O, synth, D, local_rank, dev, stream))
     if dist and not args.no_e2e and not args.generic:
         # ---- N > 1 (and --force-dist): E per rank on its shard of the file list, with a per-rank host budget ----
-        if shard is not None:
-            shard.close()
-            shard = None
-        torch.cuda.empty_cache()
+        drop_shard()
+        t0 = time.perf_counter()
         e2e_error, sharded = None, None
         try:
-            global _UNPINNED_CPUS
-            _UNPINNED_CPUS = effective_cpus()
-            share, threads = rank_cpu_share(rank, world, device_bdfs(J, world))
-            pinned = pin_to(share)
+            E.note_unpinned_cpus()
+            share, threads = E.rank_cpu_share(rank, world, E.device_bdfs(J, world))
+            pinned = E.pin_to(share)
             import oracle as O_all  # (every rank checks two of its own images: the oracle as checker)
             w1, h1 = WORKLOADS["1080p-420"][0], WORKLOADS["1080p-420"][1]
-            sharded = e2e_sharded(J, O_all, synth, D, dist, torch, dev, rank, local_rank, world, w1, h1, args.e2e_total, args.e2e_encoder, share, threads, pinned)
-        except Exception as e:  # noqa: BLE001 (never lose the line to this leg; e2e_sharded raises only after its last collective, so the ranks stay in step)
+            sharded = E.e2e_sharded(J, O_all, synth, D, dist, torch, dev, rank, local_rank, world, w1, h1, args.e2e_total, args.e2e_encoder, share, threads, pinned)
+        except Exception as e:  # noqa: BLE001 (e2e_sharded raises only after its last collective, so the ranks stay in step)
             e2e_error = f"{type(e).__name__}: {e}"[:300]
         if rank == 0:
             line.setdefault("e2e", {})["sharded"] = sharded if sharded else {"error": e2e_error}
+        leg("e2e_sharded", t0)
     if rank == 0 and default_run and not args.no_e2e:
-        if shard is not None:
-            shard.close()
-            shard = None
+        drop_shard()
+        t0 = time.perf_counter()
         try:
-            e2e, files = e2e_block(J, O, synth, w, h, [int(x) for x in args.e2e_images.split(",") if x], args.e2e_encoder, h2d_rate_gbps(torch, dev), d2h_rate_gbps(torch, dev))
+            e2e, files = E.e2e_block(J, O, synth, w, h, [int(x) for x in args.e2e_images.split(",") if x], args.e2e_encoder,
+                                     E.h2d_rate_gbps(torch, dev), E.d2h_rate_gbps(torch, dev))
             line.setdefault("e2e", {}).update(e2e)
+            leg("e2e_block", t0)
             if not args.no_cpu_budget:
-                try:
-                    line["e2e"]["cpu_budget"] = e2e_cpu_budget(J, O, synth, w, h, args.e2e_encoder)
-                except Exception as e:  # noqa: BLE001
-                    line["e2e"]["cpu_budget"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                guarded("cpu_budget", lambda: E.e2e_cpu_budget(J, O, synth, w, h, args.e2e_encoder, matrix=args.cpu_budget_matrix), into=line["e2e"])
             if not args.no_cpu_baseline:
-                line["cpu_baseline_e2e"] = cpu_baseline_e2e(O, files, w, h, args.cpu_seconds)
+                guarded("cpu_baseline_e2e", lambda: E.cpu_baseline_e2e(O, files, w, h, args.cpu_seconds / 2))
         except Exception as e:  # noqa: BLE001
             line.setdefault("e2e", {})["error"] = f"{type(e).__name__}: {e}"[:300]
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and nv == 1:
-            line["cpu_baseline"] = cpu_baseline(O, ocomps, qts, coefs, w, h, ct, args.cpu_seconds)
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and nv == 1:
+        t0 = time.perf_counter()
+        line["cpu_baseline"] = cpu_baseline(O, ocomps, qts, coefs, w, h, ct, args.cpu_seconds)
+        leg("cpu_baseline", t0)
     if shard is not None:
         shard.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # The line goes out LAST: the collective library writes a version banner to the C library's stdout, which (not being a
-        # terminal) holds it back until it is flushed — after a line printed here, were it printed earlier.
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(line), flush=True)
+        line["leg_seconds"] = legs
+        line["bench_seconds"] = round(time.perf_counter() - t_start, 1)
+        emit(line, args.detail)
 
+
+from bench_e2e import e2e_files, rank_cpu_share  # noqa: E402,F401 (tests reach them through this module)
 
 if __name__ == "__main__":
     main()

@@ -108,3 +108,65 @@ def test_e2e_input_files_with_and_without_restart_markers(encoder):
         assert b"\xff\xdd\x00\x04" not in a and b"\xff\xdd\x00\x04" in b and b.count(b"\xff\xd0") >= 1
         pa, pb = O.decode(a).pixels, O.decode(b).pixels
         assert pa.size == 96 * 160 * 3 and np.array_equal(pa, pb)
+
+
+# ---- the contract line (round 5's one line had grown to 21 KB and the driver's record lost its headline) ----
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline", "verified_vs_oracle")
+
+
+def _canned_detail():
+    """A whole detail document as a default run produces it: round 5's 21 KB line, kept under profiles/."""
+    return json.load(open(os.path.join(ROOT, "profiles", "round5", "07_bench_driver_command_final.json")))
+
+
+def test_contract_line_is_small_and_complete():
+    sys.path.insert(0, ROOT)
+    import bench
+    detail = _canned_detail()
+    assert len(json.dumps(detail)) > 20000  # (the thing that did not fit)
+    txt = bench.contract_line(detail, "gpurun_out/bench_detail.json")
+    assert "\n" not in txt and len(txt) < 4096 == bench.CONTRACT_LINE_MAX
+    line = json.loads(txt)
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert line["value"] == detail["value"] and line["ms_per_step"] == detail["ms_per_step"]
+    assert set(line["config"]) >= {"workload", "name", "images_total", "images_per_gpu", "kernel_path", "range_class"}
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_commit", "algorithmic_bytes_per_launch", "kernel_ms_per_launch"}
+    assert line["roofline"]["frac"] == detail["roofline"]["frac"]
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 200
+    s = line["e2e_summary"]
+    assert len(s) <= 10 and all(v is None or isinstance(v, (int, float, bool)) for v in s.values())
+    assert s["e2e_4096_ms"] == detail["e2e"]["4096"]["total_ms"] and s["progressive_256_on_device"] == 0
+    assert s["cpu_budget_2cpus_images_per_s"] == next(p for p in detail["e2e"]["cpu_budget"]["points"] if p["cpus"] == 2)["pageable_input"]["images_per_s"]
+
+
+def test_contract_line_stays_small_whatever_the_side_legs_hold():
+    """Errors, long texts, the N > 1 keys and a sharded E leg: the line keeps its cap and its required keys."""
+    sys.path.insert(0, ROOT)
+    import bench
+    detail = _canned_detail()
+    detail["config"]["workload"] = "w" * 5000
+    detail["cpu_baseline"]["sample"] = "s" * 5000
+    detail["e2e"] = {"error": "x" * 3000, "sharded": {"images_per_s": 1.0, "total_ms": 2.0, "mode": "host-light", "what": "y" * 4000}}
+    detail.update({"n_ranks_seen": 8, "value_with_gather": 1.0, "ms_per_step_with_gather": 2.0, "gather_ms": 3.0, "gather_verified": True,
+                   "gather": {"form": "z" * 3000}, "k_4096": {"error": "e" * 300}, "scale_anchor": {"error": "e" * 300}})
+    txt = bench.contract_line(detail, "gpurun_out/bench_detail.json")
+    assert len(txt) < 4096
+    line = json.loads(txt)
+    for k in CONTRACT_KEYS + ("value_with_gather", "gather_ms", "n_ranks_seen"):
+        assert k in line, k
+    assert line["e2e_summary"]["sharded_images_per_s"] == 1.0
+
+
+def test_emit_prints_the_detail_first_and_the_contract_line_last(tmp_path, capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+    detail = _canned_detail()
+    path = str(tmp_path / "d" / "bench_detail.json")
+    bench.emit(detail, path)
+    out = capsys.readouterr().out.splitlines()
+    assert out[-2].startswith("bench_detail: {") and json.loads(out[-2][len("bench_detail: "):]) == detail
+    last = json.loads(out[-1])
+    assert len(out[-1]) < 4096 and last["value"] == detail["value"] and last["detail"] == path
+    assert json.load(open(path)) == detail
