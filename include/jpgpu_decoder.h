@@ -149,14 +149,16 @@ enum {
      * 50-54 k images/s on 1 to 8 CPUs that way.  "Host light": the scan goes up as the file holds it (one memcpy; or no copy at all with
      * JPGPU_PIPELINE_INPUT_PINNED) and three small kernels check it for markers and drop the stuffing zeros on the device (a stream with
      * anything but 0xFF00 pairs inside is handed back to the host decoder, as the staging pass does): 73-78 k images/s on the same 1 to
-     * 8 CPUs.  Chosen automatically when the pipeline was created with <= 16 worker threads (on 16 CPUs and 32 threads host staging
-     * wins: 81 k against 71 k); these two bits force either way.  Streams with restart markers are staged by the host in both modes
+     * 8 CPUs.  Host light is the DEFAULT since round 6, at every thread count (host staging is 1-2 ms of 50 faster on a quiet 16-CPU box
+     * and up to 2 x slower on a busy one; light took 48-53 ms per 4,096 files on every box measured); JPGPU_PIPELINE_HOST_STAGED asks
+     * for the host's staging pass, JPGPU_PIPELINE_HOST_LIGHT says the default out loud.  Streams with restart markers are staged by the host in both modes
      * (their markers must be found before the segments can be laid out). */
     , JPGPU_PIPELINE_HOST_LIGHT = 32u
     , JPGPU_PIPELINE_HOST_STAGED = 64u
     , JPGPU_PIPELINE_INPUT_PINNED = 128u /* every `data[i]` lies in page-locked host memory (jpgpu_host_alloc, or the caller's own
                                    * hipHostMalloc / hipHostRegister): host-light uploads then read the caller's buffers directly —
-                                   * files that follow one another in memory (gaps up to 4 kB) travel in one copy.  Passing pageable
+                                   * files that follow one another in memory (gaps of LESS than one 4-kB page: only pages that hold bytes
+                                   * of a file are ever read) travel in one copy.  Passing pageable
                                    * memory with this flag is an error the runtime may or may not report: do not. */
     , JPGPU_PIPELINE_PROGRESSIVE_ON_HOST = 256u /* A/B switch: progressive frames take the host entropy decoder even with
                                    * JPGPU_PIPELINE_DEVICE_ENTROPY (round 4's behaviour); default since 0.2: the device decodes as many

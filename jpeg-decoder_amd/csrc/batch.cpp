@@ -855,6 +855,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const bool light = (mode & DEVICE_ENTROPY_LIGHT) != 0, input_pinned = light && (mode & DEVICE_ENTROPY_INPUT_PINNED) != 0;
     size_t n_raw_jobs = 0;
     uint32_t max_pieces = 0, light_images = 0;
+    constexpr size_t PINNED_SPAN_GAP_MAX = 4096u;  // (bytes; below one page: see where the spans are built)
     struct PinnedSpan {
         const uint8_t *start, *end;  // the caller's bytes [start, end): the scans of consecutive files and what lies between them
         size_t mirror_off;           // where `start` lands in the span region of the mirror
@@ -907,14 +908,17 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
         }
     }
     if (input_pinned && !raw_scans.empty()) {
-        // Pinned input: files that follow one another in the caller's memory (a loader's arena: gaps of up to 8 kB — the next file's
-        // headers) travel in ONE copy, headers and gaps included; a scan's place in the mirror is then its place in the span.  (One
+        // Pinned input: files that follow one another in the caller's memory (a loader's arena) travel in ONE copy, headers and gaps
+        // included; a scan's place in the mirror is then its place in the span.  Two scans share a span only if the gap between them is
+        // SHORTER THAN ONE PAGE (it was 8 kB): the caller vouches for the bytes of its files only, and a gap of a page or more
+        // may hold a page that is not mapped or not pinned; a gap below 4,096 bytes lies in the page of the byte in front of it and the
+        // page of the byte behind it, both of which hold bytes of a file (pinning and mapping are per page).  (One
         // hipMemcpyAsync per file: 4,096 calls per call of 4,096 files — 114 ms on 16 CPUs.)  By ADDRESS, not in listing order: the
         // pipeline lists a sub-batch's images as its threads finish their headers, and an arena need not hold files in call order.
         std::sort(raw_scans.begin(), raw_scans.end(), [](const RawScan &a, const RawScan &c) { return a.src < c.src; });
         raw_mirror_off.assign(raw_scans.size(), 0);
         for (const RawScan &r : raw_scans) {
-            if (spans.empty() || r.src < spans.back().end || (size_t)(r.src - spans.back().end) > 8192u) {
+            if (spans.empty() || r.src < spans.back().end || (size_t)(r.src - spans.back().end) >= PINNED_SPAN_GAP_MAX) {
                 const size_t at = spans.empty() ? 0 : align_up(spans.back().mirror_off + (size_t)(spans.back().end - spans.back().start), 16) + 16;
                 spans.push_back(PinnedSpan{r.src, r.src, at});
             }

@@ -225,7 +225,8 @@ inline uint32_t definition_hash(const uint8_t bits[16], const uint8_t *vals, int
     mix((uint64_t)n);
     return (uint32_t)(h >> 32);
 }
-inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
+// -> the registry's own (immutable) copy of the table: callers keep the pointer, nothing of a table's 5.5 kB is copied or kept per thread
+inline std::shared_ptr<const HuffTable> build_cached(const uint8_t bits[16], const uint8_t *vals, int n, bool ac) {
     constexpr int kSlots = 32, kShards = 64, kPerShard = 4;  // (slots: a progressive file of libjpeg's default script defines twelve tables)
     thread_local std::shared_ptr<const HuffTable> mine[kSlots];
     thread_local uint32_t mine_hash[kSlots];
@@ -234,10 +235,7 @@ inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *
     const uint32_t hash = sane ? definition_hash(bits, vals, n, ac) : 0u;
     if (sane)
         for (int i = 0; i < kSlots; i++)
-            if (mine[i] && mine_hash[i] == hash && same_definition(*mine[i], bits, vals, n, ac)) {
-                dst = *mine[i];
-                return;
-            }
+            if (mine[i] && mine_hash[i] == hash && same_definition(*mine[i], bits, vals, n, ac)) return mine[i];
     // (the registry is leaked on purpose: pool threads of a host that is shutting down may still be in here while statics are
     // destroyed — ADVICE r4)
     struct alignas(64) Shard {
@@ -263,10 +261,10 @@ inline void build_cached(HuffTable &dst, const uint8_t bits[16], const uint8_t *
         sh.hash[sh.next] = hash;
         sh.next = (sh.next + 1) % kPerShard;
     }
-    dst = *found;
-    mine[next] = std::move(found);
+    mine[next] = found;
     mine_hash[next] = hash;
     next = (next + 1) % kSlots;
+    return found;
 }
 
 // Annex K default tables for MJPEG (src/huffman.rs:295-346)
@@ -708,16 +706,11 @@ struct Frontend::Impl {
 
     void parse_dht() {  // src/parser.rs:536-589, merge of src/decoder.rs:501-518
         size_t length = read_length();
-        // (one heap block per THREAD, made at its first DHT segment and kept: round 4 had the eight tables — 44 kB — on the stack of
-        // whichever thread called the decoder, too much for hosts that run decoders on small-stack threads; two heap
-        // blocks per segment, allocated and freed by every pool thread at once, had the threads queue up inside the allocator)
-        struct DhtScratch {
-            HuffTable dc[4], ac[4];
-        };
-        thread_local std::unique_ptr<DhtScratch> scratch;
-        if (!scratch) scratch.reset(new DhtScratch);
-        HuffTable *const ndc = scratch->dc, *const nac = scratch->ac;
-        for (int i = 0; i < 4; i++) ndc[i].present = nac[i].present = false;
+        // The segment's tables as POINTERS to the registry's copies until the whole segment has parsed (the reference merges nothing of
+        // a segment that fails, src/decoder.rs:501-518): 128 bytes of stack.  History: round 4 had eight tables — 44 kB — on the stack of
+        // whichever thread called the decoder (too much for small-stack threads); round 5 a 44 kB heap block per THREAD, kept
+        // until the thread ends — 44 MB on a host with a thousand decoding threads.
+        std::shared_ptr<const HuffTable> ndc[4], nac[4];
         while (length > 17) {
             const uint8_t tc = src.u8(), cls = tc >> 4;
             const size_t index = tc & 15;
@@ -732,13 +725,13 @@ struct Frontend::Impl {
             if (size > 256) fail(JPGPU_ERR_FORMAT, "encountered table with excessive length in DHT");
             if (size > length - 17) fail(JPGPU_ERR_FORMAT, "invalid length in DHT");
             const uint8_t *vals = src.take(size);
-            build_cached(cls == 0 ? ndc[index] : nac[index], counts, vals, (int)size, cls == 1);
+            (cls == 0 ? ndc[index] : nac[index]) = build_cached(counts, vals, (int)size, cls == 1);
             length -= 17 + size;
         }
         if (length != 0) fail(JPGPU_ERR_FORMAT, "invalid length in DHT");
         for (int i = 0; i < 4; i++) {
-            if (ndc[i].present) dc[i] = ndc[i];
-            if (nac[i].present) ac[i] = nac[i];
+            if (ndc[i]) dc[i] = *ndc[i];
+            if (nac[i]) ac[i] = *nac[i];
         }
     }
 

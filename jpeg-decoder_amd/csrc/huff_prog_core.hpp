@@ -44,6 +44,13 @@ __device__ __forceinline__ void prog_or64(uint64_t *p, uint64_t v) {
     (void)__hip_atomic_fetch_or((JP_GLOBAL uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+__device__ __forceinline__ void prog_and64(uint64_t *p, uint64_t v) {
+#ifdef JPGPU_HOST_EMULATION
+    *p &= v;
+#else
+    (void)__hip_atomic_fetch_and((JP_GLOBAL uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ uint64_t prog_load64(const uint64_t *p) {
 #ifdef JPGPU_HOST_EMULATION
     return *p;
@@ -550,12 +557,17 @@ __device__ inline bool prog_scan_ac_refine(ProgScanRef s, JP_LDS uint32_t *T, JP
                 }
                 k++;
             }
-            if (new_nz) {  // (this lane owns the block's AC positions: plain stores, past the L1 for the scans that follow)
-                prog_store64(masks + 2u * blk, R.nz | new_nz);
+            if (new_nz) {
+                // Atomic OR, never a store of the whole word: a mask word covers all 63 AC positions of the block, a scan
+                // only its band — with a script such as Y 1-5 | Y 6-63 | refine 1-5 | refine 6-63 the lane of "refine 1-5" runs beside the
+                // lane of "6-63 first" on the same blocks, and a store of `R.nz | new_nz` (R.nz read a block ahead) would wipe out what
+                // the other lane ORed in between; the later refinement of 6-63 would then count too few non-zero coefficients.
+                prog_or64(masks + 2u * blk, new_nz);
                 // (a damaged stream can make the walk end ON a non-zero coefficient — at the band's last position, when it runs out of
                 // zeros — and the new value then REPLACES it, src/decoder.rs:1251-1256: the sign is the new value's)
-                const uint64_t neg = (R.neg & ~new_nz) | new_neg;
-                if (neg != R.neg) prog_store64(masks + 2u * blk + 1u, neg);
+                if (new_neg) prog_or64(masks + 2u * blk + 1u, new_neg);
+                const uint64_t flip = R.neg & new_nz & ~new_neg;  // (bits of this scan's own band only)
+                if (flip) prog_and64(masks + 2u * blk + 1u, ~flip);
             }
             prog_publish(y, ++bi);
         }

@@ -904,15 +904,14 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     double busy_sum = 0, busy_max = 0, last_end = 0, prog_host_ms = 0, prog_dev_ms = 0;
     uint64_t prog_host_bytes = 0, prog_dev_bytes = 0;
     uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0, light_images = 0;
-    // Host light (include/jpgpu_decoder.h): forced by a flag, implied by pinned input, else chosen for pipelines of few worker threads —
-    // where the staging pass (20-80 us per 1080p file and core) is what bounds the call
+    // Host light (include/jpgpu_decoder.h) is the DEFAULT at every thread count (round 6); JPGPU_PIPELINE_HOST_STAGED asks for the host's
+    // staging pass.  Why no rule by thread count any more (round 5 chose staging above 16 worker threads): host staging swings 2 x with the
+    // box and with what else runs on it — 4,096 x 1080p at 16 CPUs / 32 threads: 49-51 ms on quiet boxes, 60.7 ms on the driver's, 115-119 ms
+    // there at 2-8 CPUs — while light sat at 48-53 ms in every run on every box (profiles/round5/07_*, round6/).  What
+    // staging wins where it wins (1-2 ms of 50) is not worth what it loses where it loses.
     const bool input_pinned = (flags & JPGPU_PIPELINE_INPUT_PINNED) != 0;
     const char *light_env = getenv("JPGPU_PIPE_HOST_LIGHT");  // (tests, fuzzers, A/B: 1 / 0 force the mode for calls that do not say themselves)
-    // (measured, 4,096 x 1080p, affinity and threads limited — bench.py e2e.cpu_budget, profiles/round5: light 73-78 k images/s against 50-54 k for
-    // host staging on 1 / 2 / 4 / 8 CPUs = up to 16 worker threads; on 16 CPUs = 32 threads staging wins, 81 k against 71 k)
-    // (and for small calls whatever the thread count: 256 files 6.5-7.0 ms against 6.8-7.2 interleaved on one box — the first sub-batch reaches
-    // the device a staging pass earlier; 1,024 files the other way round: profiles/round5/06_*)
-    const bool light_default = light_env ? atoi(light_env) != 0 : (p->pool->size() <= 16u || n_dev <= 384u);
+    const bool light_default = light_env ? atoi(light_env) != 0 : true;
     const bool host_light = input_pinned || (flags & JPGPU_PIPELINE_HOST_LIGHT) != 0 || ((flags & JPGPU_PIPELINE_HOST_STAGED) == 0 && light_default);
     const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u);
     // Progressive frames for the device: a lane per scan only while ALL the call's lanes fit the device at once (prog_lanes_max())
@@ -935,7 +934,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     // What follows the pixel kernels of sub-batch `sj` on its compute stream `cs`: the download to pinned host memory and / or the
     // copy to the gathering device, each on a stream of its own behind the `decoded` event (the compute stream goes on with the next
     // sub-batch that shares it).  Called again when a sub-batch is decoded a second time (an image the device decoder handed back).
-    auto after_decode = [&](uint32_t sj, hipStream_t cs) -> bool {
+    // `again`: the sub-batch's second decode: the first copies have been waited for by the caller (the second decode writes
+    // the arena they read), the second ones replace them — their bytes are counted once, their timing events are the ones that stay.
+    auto after_decode = [&](uint32_t sj, hipStream_t cs, bool again = false) -> bool {
         SubBatch &sb = p->subs[sj];
         if (!download && !p->gather_on) return true;
         if (hipEventRecord(sb.decoded, cs) != hipSuccess) return false;
@@ -955,12 +956,22 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             uint8_t *dst = p->d_gather + p->gather_off[sj];
             hipStream_t gs = p->gather_stream;
             if (hipStreamWaitEvent(gs, sb.decoded, 0) != hipSuccess || hipEventRecord(p->gather_ev[sj].first, gs) != hipSuccess) return false;
-            const hipError_t ce = p->gather_device == p->device
+            // (JPGPU_PIPE_FORCE_PEER_COPY=1, tests: hipMemcpyPeerAsync also when the gathering device is this one — legal with identical
+            // ordinals —, so that a box with one GPU drives the call and its event bookkeeping, not the plain-copy branch)
+            static const bool force_peer = getenv("JPGPU_PIPE_FORCE_PEER_COPY") != nullptr && atoi(getenv("JPGPU_PIPE_FORCE_PEER_COPY")) != 0;
+            const hipError_t ce = p->gather_device == p->device && !force_peer
                                       ? hipMemcpyAsync(dst, jpgpu_batch_out_arena(sb.batch), bytes, hipMemcpyDeviceToDevice, gs)  // (a device listed twice: no peer)
                                       : hipMemcpyPeerAsync(dst, p->gather_device, jpgpu_batch_out_arena(sb.batch), p->device, bytes, gs);
             if (ce != hipSuccess || hipEventRecord(p->gather_ev[sj].second, gs) != hipSuccess) return false;
-            p->gather_bytes += bytes;
+            if (!again) p->gather_bytes += bytes;
         }
+        return true;
+    };
+    // the copies after_decode() started for sub-batch `sj` have left the arena (before it is written a second time)
+    auto wait_for_copies = [&](uint32_t sj) -> bool {
+        static const uint32_t n_d2h = (uint32_t)std::min<long>(std::max<long>(getenv("JPGPU_PIPE_D2H_STREAMS") ? atol(getenv("JPGPU_PIPE_D2H_STREAMS")) : kD2HStreams, 1), kD2HStreams);
+        if (download && hipStreamSynchronize(p->d2h[sj % n_d2h]) != hipSuccess) return false;
+        if (p->gather_on && p->d_gather && hipStreamSynchronize(p->gather_stream) != hipSuccess) return false;
         return true;
     };
     std::thread uploader([&] {
@@ -1099,11 +1110,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         if (redo.size() > 1) par_for((uint32_t)redo.size(), body);
                         else body(0);
                         for (Redecode &r : redo) host_redecode_upload(p, sb, r);
+                        okk = okk && wait_for_copies(sj);  // (write after read, made explicit: the first download / gather read the arena the kernels now rewrite)
                         if (okk && jpgpu_batch_decode(sb.batch, cs) != JPGPU_OK) {  // (the whole sub-batch once more: rare)
                             launch_err = jpgpu_batch_last_error(sb.batch);
                             okk = false;
                         }
-                        if (okk) okk = after_decode(sj, cs);
+                        if (okk) okk = after_decode(sj, cs, true);
                     }
                     if (!okk) hip_failed.store(1);
                 }

@@ -85,8 +85,8 @@ class Pipeline:
         max_decoding_buffer_size: ``Decoder.set_max_decoding_buffer_size`` (images that would need more fail with the reference's error);
         gather=True (pipelines over several devices): copy every device's pixels to the first device, per sub-batch behind its kernels (JPGPU_PIPELINE_GATHER);
         download="pinned": copy the pixels to the pipeline's pinned host buffers but return byte counts — look at them with ``pixels_host(i)``
-        (no Python copy per image); host_light=True / False: JPGPU_PIPELINE_HOST_LIGHT / _HOST_STAGED (None: the library's choice — light
-        for pipelines of <= 4 threads); streams may be a ``PinnedFiles`` arena, with input_pinned=True the device reads it directly;
+        (no Python copy per image); host_light=True / False: JPGPU_PIPELINE_HOST_LIGHT / _HOST_STAGED (None: the library's default — host light,
+        at every thread count); streams may be a ``PinnedFiles`` arena, with input_pinned=True the device reads it directly;
         progressive_on_host=True: progressive frames on the host entropy decoder even with device_entropy (A/B)."""
         L = N.lib()
         check(L.jpgpu_pipeline_set_max_decoding_buffer_size(self._h, (1 << 64) - 1 if max_decoding_buffer_size is None else int(max_decoding_buffer_size)), b"set_max")

@@ -539,8 +539,8 @@ def e2e_cpu_budget(J, O, synth, w, h, encoder, n=4096, points=None, matrix=False
     """E against the host CPUs a GPU's feeder gets: on an 8-GPU node with 16 granted CPUs every rank has two.  The
     4,096-file call with the calling thread's affinity — and with it the pipeline's pools, created under it — narrowed to the first
     1 / 2 / 4 / 8 / 16 allowed CPUs and threads = 2 x CPUs (rank_cpu_share's rule).  Per point: the files in ordinary (pageable) memory
-    with the mode the library chooses (host-light — raw scans copied, marker check + unstuffing on the device — for pipelines of <= 4
-    threads, host staging above), the same with either mode forced (A/B), and the files in a pinned arena (PinnedFiles: what a loader
+    with the library's default (host light — raw scans copied, marker check + unstuffing on the device — at every thread count since
+    round 6), the same with either mode forced (A/B), and the files in a pinned arena (PinnedFiles: what a loader
     that reads into jpgpu_host_alloc memory holds) with JPGPU_PIPELINE_INPUT_PINNED, where the copy engine reads the arena itself."""
     # Default run (VERDICT r5 #1: the whole bench under 45 s): 2 / 8 / 16 CPUs x {the library's own mode, host staging forced}, 3 warm
     # calls — enough to see whether the default is the better mode at every point.  --cpu-budget-matrix: 1 / 2 / 4 / 8 / 16 CPUs x
