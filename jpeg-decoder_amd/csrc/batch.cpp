@@ -1321,11 +1321,16 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     // Scans of a track pipelined over lanes (huff_prog_job.hpp): one lane per SCAN, a progress word each (behind the masks, zeroed with
     // them), lanes of one dependency rank in waves of their own — a lane must never wait for a lane of its own wave, and the
     // producers must come first in launch order.  JPGPU_PROG_SERIAL=1: one lane per track, as first built (A/B).
+    // Round 6: one WAVE per scan (huff_prog_wave.hpp) — always pipelined: the launch order below keeps a frame's waves on one XCD,
+    // producers in front, so an oversubscribed launch cannot starve a producer.  JPGPU_PROG_LANES=1: round 5's walk (A/B).
     static const bool serial_env = getenv("JPGPU_PROG_SERIAL") != nullptr;
-    const bool serial_tracks = serial_env || !allow_pipelined;
+    static const bool lanes_env = getenv("JPGPU_PROG_LANES") != nullptr && atoi(getenv("JPGPU_PROG_LANES")) != 0;
+    const bool waves = !lanes_env;
+    const bool serial_tracks = serial_env || (!waves && !allow_pipelined);
     const size_t progress_off = mask_bytes;
     mask_bytes += align_up(n_scans * 4u, 256);
-    const size_t max_lanes = n_tracks + n_scans + 64u * 64u;  // (a padding of < 64 lanes per rank, up to 64 ranks: more are walked serially, as tracks)
+    // (lanes: a padding of < 64 lanes per rank, up to 64 ranks — more are walked serially, as tracks; waves: eight lists that differ by less than one frame's 256 scans)
+    const size_t max_lanes = n_tracks + n_scans + 64u * 64u;
     n_tracks = max_lanes;
     const size_t off_status = 0, off_tracks = align_up((size_t)n * 4, 16), off_scans = align_up(off_tracks + n_tracks * sizeof(ProgTrack), 16);
     const size_t off_tables = align_up(off_scans + n_scans * sizeof(ProgScan), 16), off_data = align_up(off_tables + n_tables * sizeof(ProgHuffTable), 16);
@@ -1479,14 +1484,53 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         return a.rank != c.rank ? a.rank < c.rank : (a.kind != c.kind ? a.kind < c.kind : a.weight > c.weight);
     });
     size_t n_lanes = 0;
-    for (size_t t = 0; t < order.size(); t++) {
-        if (t > 0 && order[t].rank != order[t - 1].rank)
-            while (n_lanes % 64u) tracks[n_lanes++] = ProgTrack{nullptr, 0u, nullptr};
-        if (n_lanes >= max_lanes) return set_err(b->err, JPGPU_ERR_INTERNAL, "device progressive: lane table");
-        tracks[n_lanes].scans = reinterpret_cast<const ProgScan *>(d + off_scans) + order[t].first_scan;
-        tracks[n_lanes].n_scans = order[t].n_scans;
-        tracks[n_lanes].status = reinterpret_cast<uint32_t *>(d + off_status) + order[t].image_k;
-        n_lanes++;
+    const auto entry_of = [&](const TrackOrder &o) {
+        return ProgTrack{reinterpret_cast<const ProgScan *>(d + off_scans) + o.first_scan, o.n_scans, reinterpret_cast<uint32_t *>(d + off_status) + o.image_k};
+    };
+    if (waves) {
+        // Waves in launch order (huff.hip, huff_progw_kernel): workgroup i runs on XCD i mod 8 and every XCD dispatches its workgroups in
+        // order.  So: every frame's waves on ONE XCD (the frame with the fewest waves so far takes the next frame: lists of equal length),
+        // and inside an XCD's list by dependency rank, in groups of JPGPU_PROG_GROUP frames (default: all — rank-major: the waves of a
+        // rank run at full occupancy before the next rank's are dispatched; a wave that catches up with its producer sleeps), inside a
+        // rank the heavy scans first.  A producer is in front of its consumers in the list of their XCD: when a consumer runs, the
+        // producer is resident or done — no deadlock however many waves the launch has, and a frame's planes and masks stay in one L2.
+        static const uint32_t group = getenv("JPGPU_PROG_GROUP") ? (uint32_t)std::max(1, atoi(getenv("JPGPU_PROG_GROUP"))) : 0x7fffffffu;
+        constexpr uint32_t XCDS = 8u;
+        std::vector<uint32_t> xcd_of(n, 0u), seq_of(n, 0u);  // per listed image: its XCD, its number among that XCD's frames
+        {
+            std::vector<uint32_t> per_image(n, 0u);
+            for (const TrackOrder &o : order) per_image[o.image_k]++;
+            size_t load[XCDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t frames[XCDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t k = 0; k < n; k++) {
+                uint32_t x = 0;
+                for (uint32_t j = 1; j < XCDS; j++)
+                    if (load[j] < load[x]) x = j;
+                xcd_of[k] = x;
+                seq_of[k] = frames[x]++;
+                load[x] += per_image[k];
+            }
+        }
+        std::vector<TrackOrder> lists[XCDS];
+        for (const TrackOrder &o : order) lists[xcd_of[o.image_k]].push_back(o);
+        size_t longest = 0;
+        for (auto &l : lists) {
+            std::stable_sort(l.begin(), l.end(), [&](const TrackOrder &a, const TrackOrder &c) {
+                const uint32_t ga = seq_of[a.image_k] / group, gc = seq_of[c.image_k] / group;
+                return ga != gc ? ga < gc : (a.rank != c.rank ? a.rank < c.rank : a.weight > c.weight);
+            });
+            longest = std::max(longest, l.size());
+        }
+        if (longest * XCDS > max_lanes) return set_err(b->err, JPGPU_ERR_INTERNAL, "device progressive: wave table");
+        for (size_t j = 0; j < longest; j++)
+            for (uint32_t x = 0; x < XCDS; x++) tracks[n_lanes++] = j < lists[x].size() ? entry_of(lists[x][j]) : ProgTrack{nullptr, 0u, nullptr};
+    } else {
+        for (size_t t = 0; t < order.size(); t++) {
+            if (t > 0 && order[t].rank != order[t - 1].rank)
+                while (n_lanes % 64u) tracks[n_lanes++] = ProgTrack{nullptr, 0u, nullptr};
+            if (n_lanes >= max_lanes) return set_err(b->err, JPGPU_ERR_INTERNAL, "device progressive: lane table");
+            tracks[n_lanes++] = entry_of(order[t]);
+        }
     }
     const bool two_streams = copy_stream && copy_stream != hip_stream;
     hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
@@ -1522,7 +1566,8 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         if (!e) B_HIP(hipEventCreate(&e));
     B_HIP(hipEventRecord(b->ev_phase[0], s));
     B_HIP(hipEventRecord(b->ev_phase[1], s));
-    B_HIP(launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s));
+    B_HIP(waves ? launch_huff_progw(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s)
+                : launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s));
     B_HIP(hipEventRecord(b->ev_phase[2], s));
     {
         const int crc = jpgpu_batch_classify_on_device(b, s);

@@ -8,6 +8,7 @@
 #include "huff.hpp"
 #include "huff_core.hpp"
 #include "huff_prog_core.hpp"
+#include "huff_prog_wave.hpp"
 #include "huff_unstuff_core.hpp"
 #include "huff_sync_core.hpp"
 #include "range_stats.hpp"
@@ -913,6 +914,55 @@ hipError_t launch_copy_to_host(void *dst_host_mapped, const void *d_src, size_t 
     const size_t n16 = bytes / 16u;
     copy_to_host_kernel<<<dim3(64), dim3(256), 0, stream>>>((v4u *)dst_host_mapped, (const v4u *)d_src, n16, (uint8_t *)dst_host_mapped + n16 * 16u,
                                                           (const uint8_t *)d_src + n16 * 16u, (uint32_t)(bytes - n16 * 16u));
+    return hipGetLastError();
+}
+
+// ---- progressive frames, round 6: one WAVE per scan (huff_prog_wave.hpp) -----------------------------------------------------------------
+// grid = one workgroup of one wave per table entry; no LDS.  Entry i belongs to XCD i mod 8 (workgroups are handed to the XCDs
+// round-robin in launch order): the host puts all scans of a frame on one XCD, producers in front — whatever a wave waits for was
+// dispatched before it by the same XCD's dispatcher, so it is resident or done however oversubscribed the launch is.
+__global__ __launch_bounds__(64) void huff_progw_kernel(const ProgTrack *__restrict__ tracks, uint32_t n_tracks) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tracks) return;
+    const ProgTrack tr = tracks[t];
+    if (tr.scans == nullptr || tr.n_scans == 0u) return;  // (padding of the shorter XCD lists)
+    progw_run_track(tr);
+}
+#if !defined(PROGW_PORTABLE)
+// (test hook, not part of the C ABI's headers: the hand-scheduled refinement loop on given states — tests/test_gpu_progw_asm.py)
+__global__ __launch_bounds__(64) void progw_refine_fast_case_kernel(PwFastCase *cases, uint32_t n) {
+    if (blockIdx.x >= n) return;
+    PwFastCase *g = cases + blockIdx.x;
+    PwFastCase c;
+    c.win = g->win, c.nz = g->nz, c.neg = g->neg, c.new_nz = g->new_nz, c.new_neg = g->new_neg;
+    c.pos = g->pos, c.nx = g->nx, c.dp = g->dp, c.k = g->k, c.end = g->end, c.al = g->al, c.eob = g->eob, c.code = 0u;
+    // (per-lane arrays: every lane reads and writes its own element only)
+    const uint32_t lane = threadIdx.x;
+    c.lut6[lane] = g->lut6[lane], c.w[lane] = g->w[lane], c.acc[lane] = g->acc[lane];
+    pw_refine_fast_case(c);
+    g->acc[lane] = c.acc[lane];
+    if (lane == 0u) {
+        g->win = c.win, g->pos = c.pos, g->nx = c.nx, g->dp = c.dp, g->k = c.k, g->eob = c.eob, g->new_nz = c.new_nz, g->new_neg = c.new_neg, g->code = c.code;
+    }
+}
+extern "C" int jpgpu_selftest_refine_fast(void *host_cases, uint32_t n) {
+    PwFastCase *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * sizeof(PwFastCase)) != hipSuccess) return 1;
+    int rc = 0;
+    if (hipMemcpy(d, host_cases, (size_t)n * sizeof(PwFastCase), hipMemcpyHostToDevice) != hipSuccess) rc = 2;
+    if (!rc) {
+        progw_refine_fast_case_kernel<<<dim3(n), dim3(64)>>>(d, n);
+        if (hipDeviceSynchronize() != hipSuccess) rc = 3;
+    }
+    if (!rc && hipMemcpy(host_cases, d, (size_t)n * sizeof(PwFastCase), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
+    (void)hipFree(d);
+    return rc;
+}
+#endif
+
+hipError_t launch_huff_progw(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream) {
+    if (n_tracks == 0) return hipSuccess;
+    huff_progw_kernel<<<dim3(n_tracks), dim3(64), 0, stream>>>(d_tracks, n_tracks);
     return hipGetLastError();
 }
 

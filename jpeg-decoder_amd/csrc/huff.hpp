@@ -23,7 +23,8 @@ struct RangeJob {  // one component plane to classify
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
                             hipEvent_t after_sync = nullptr, bool low_table_ids = false);
 // progressive frames: one lane per track of dependent scans, coefficients accumulated in the arena (huff_prog_core.hpp)
-hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);
+hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);   // round 5: a lane per scan (JPGPU_PROG_LANES=1)
+hipError_t launch_huff_progw(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);  // round 6: a wave per scan
 // n words from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block), by a kernel
 hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *d_src, uint32_t n, hipStream_t stream);
 // `bytes` from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block, 16-byte aligned), by a kernel

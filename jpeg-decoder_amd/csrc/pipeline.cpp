@@ -1079,6 +1079,19 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     if (trace) fprintf(stderr, "pipeline trace: sub-batch %u synchronised at +%.2f ms after waiting %.2f ms\n", sj, now_ms() - t2, now_ms() - s0);
                     okk = okk &&
                                jpgpu::batch_device_entropy_collect(sb.batch, st.data(), (uint32_t)st.size()) == JPGPU_OK;
+                    if (const char *dump = getenv("JPGPU_PIPE_DUMP_COEFS")) {  // (debugging aid: the first image's planes as the device decoders left them -> <path>.c<component>.bin)
+                        for (uint32_t c = 0; okk && c < 4u; c++) {
+                            const size_t nb = jpgpu_batch_coef_bytes(sb.batch, 0, c);
+                            if (!nb) continue;
+                            std::vector<uint8_t> h(nb);
+                            if (hipMemcpy(h.data(), (const uint8_t *)jpgpu_batch_coef_arena(sb.batch) + jpgpu_batch_coef_offset(sb.batch, 0, c), nb, hipMemcpyDeviceToHost) != hipSuccess) break;
+                            const std::string name = std::string(dump) + ".c" + std::to_string(c) + ".bin";
+                            if (FILE *f = fopen(name.c_str(), "wb")) {
+                                fwrite(h.data(), 1, nb, f);
+                                fclose(f);
+                            }
+                        }
+                    }
                     if (okk && sj >= first_prog_sub) {  // (what the dispatcher learns: the walk of this launch)
                         float kms = 0.f;
                         if (jpgpu::batch_progressive_kernel_ms(sb.batch, &kms)) prog_dev_ms = std::max(prog_dev_ms, (double)kms);

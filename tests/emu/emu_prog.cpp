@@ -9,6 +9,7 @@
 #include "../../jpeg-decoder_amd/csrc/host/frontend.hpp"
 #include "../../jpeg-decoder_amd/csrc/huff_core.hpp"
 #include "../../jpeg-decoder_amd/csrc/huff_prog_core.hpp"
+#include "../../jpeg-decoder_amd/csrc/huff_prog_wave.hpp"
 
 using namespace jpgpu;
 using jpgpu::host::Frontend;
@@ -103,7 +104,36 @@ int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], i
     ProgLds *L = new ProgLds;
     memset(L, 0xAB, sizeof(*L));
     for (uint32_t l = 0; l < 64; l++) huff_fill_unzigzag(L->unzig, l);
-    if (order == 3) {  // scans pipelined over lanes (huff_prog_job.hpp): one lane per scan with its waits, producers first (stream order)
+    if (order == 4 || order == 5) {  // round 6: a WAVE per scan with its waits, producers first (4) / a wave per track, its scans one after the other (5)
+        const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
+        if (order == 4 && !pd.ok) {
+            delete L;
+            return -2;
+        }
+        std::vector<uint32_t> progress(plan.scans.size(), 0u);
+        if (order == 4) {
+            for (size_t i = 0; i < plan.scans.size(); i++) {
+                scans[i].progress = &progress[i];
+                for (int w = 0; w < 3; w++)
+                    if (pd.deps[i][w] >= 0) {
+                        scans[i].wait[w] = &progress[(size_t)pd.deps[i][w]];
+                        if (!host::prog_same_walk(plan.scans[i], plan.scans[(size_t)pd.deps[i][w]])) scans[i].wait_whole |= 1u << w;
+                    }
+            }
+            for (size_t i = 0; i < plan.scans.size() && !(status & 1u); i++) {
+                ProgTrack tr{&scans[i], 1u, &status};
+                progw_run_track(tr);
+                if (progress[i] != PROG_DONE) status |= 0x8000u;  // a scan must announce its end, whatever happened
+            }
+        } else {
+            std::vector<std::vector<ProgScan>> pt(plan.n_tracks);
+            for (size_t i = 0; i < plan.scans.size(); i++) pt[plan.scans[i].track].push_back(scans[i]);
+            for (uint32_t t = 0; t < plan.n_tracks; t++) {
+                ProgTrack tr{pt[t].data(), (uint32_t)pt[t].size(), &status};
+                progw_run_track(tr);
+            }
+        }
+    } else if (order == 3) {  // scans pipelined over lanes (huff_prog_job.hpp): one lane per scan with its waits, producers first (stream order)
         const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
         if (!pd.ok) {
             delete L;
@@ -141,5 +171,11 @@ int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], i
     }
     delete L;
     return (int)status;
+}
+
+// the C++ twin of the hand-scheduled refinement loop on given states (tests/test_gpu_progw_asm.py compares the device with this)
+void emu_progw_refine_fast(void *cases, uint32_t n) {
+    PwFastCase *c = static_cast<PwFastCase *>(cases);
+    for (uint32_t i = 0; i < n; i++) pw_refine_fast_case(c[i]);
 }
 }

@@ -1,0 +1,105 @@
+"""The hand-scheduled refinement loop of the wave-per-scan progressive decoder (csrc/huff_prog_wave.hpp, pw_refine_fast: inline
+gfx950 assembly) against its C++ twin (the same function as tests/emu compiles it), on random states: every output — window,
+bit count, position, masks, end-of-band run, exit code and the 64 accumulator lanes — must be the same.  The twin is what the CPU
+tests run against the host decoder; this test is what ties the device's instructions to it."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+pytestmark = pytest.mark.gpu
+
+
+class Case(C.Structure):
+    _fields_ = [("win", C.c_uint64), ("nz", C.c_uint64), ("neg", C.c_uint64), ("new_nz", C.c_uint64), ("new_neg", C.c_uint64),
+                ("pos", C.c_uint32), ("nx", C.c_uint32), ("dp", C.c_uint32), ("k", C.c_uint32), ("end", C.c_uint32), ("al", C.c_uint32),
+                ("eob", C.c_uint32), ("code", C.c_uint32), ("lut6", C.c_uint32 * 64), ("w", C.c_uint32 * 64), ("acc", C.c_uint32 * 64)]
+
+
+def _entry(length, extra, run, kind, size=0):
+    return length | (extra << 5) | (run << 10) | (kind << 17) | (size << 19)
+
+
+def _random_table(rng):
+    """64 entries as pw_table_load makes them for a refinement scan: new coefficients (run 0..15), end-of-band symbols, ZRL, and
+    the holes (length 0: longer codes) and bad symbols the loop must hand back."""
+    t = []
+    for _ in range(64):
+        r = rng.random()
+        length = int(rng.integers(1, 7))
+        if r < 0.55:
+            t.append(_entry(length, 1, int(rng.integers(0, 16)) if rng.random() < 0.5 else 0, 0, 1))
+        elif r < 0.75:
+            e = int(rng.integers(0, 15))
+            t.append(_entry(length, e, 64, 1, e))
+        elif r < 0.85:
+            t.append(_entry(length, 0, 15, 2))
+        elif r < 0.93:
+            t.append(0)
+        else:
+            t.append(_entry(length, 0, 0, 3, 2))
+    return t
+
+
+def _cases(rng, n):
+    arr = (Case * n)()
+    for c in arr:
+        c.pos = int(rng.integers(0, 64))
+        win = int(rng.integers(0, 1 << 63)) << 1 | int(rng.integers(0, 2))
+        c.win = (win >> (64 - c.pos)) << (64 - c.pos) if c.pos else 0  # (nothing below the valid bits)
+        c.nx = int(rng.integers(0, 1 << 32))
+        c.dp = int(rng.choice([1, 2, 17, 40, 62, 63, 64, 64]))
+        c.end = int(rng.choice([64, 64, 64, 6, 2, 33]))
+        c.k = int(rng.integers(1, c.end)) if c.end > 1 else 1
+        dens = rng.choice([0.0, 0.05, 0.3, 0.7, 0.97])
+        bits = rng.random(64) < dens
+        c.nz = int(sum(1 << i for i in range(1, 64) if bits[i]))
+        c.neg = c.nz & int(rng.integers(0, 1 << 63))
+        c.new_nz = int(rng.integers(0, 1 << 63)) & ~c.nz & ((1 << c.k) - 2)
+        c.new_neg = c.new_nz & int(rng.integers(0, 1 << 63))
+        c.al = int(rng.integers(0, 4))
+        c.eob = int(rng.integers(0, 3))
+        t = _random_table(rng)
+        for i in range(64):
+            c.lut6[i] = t[i]
+            c.w[i] = int(rng.integers(0, 1 << 32)) if rng.random() < 0.9 else 0
+            c.acc[i] = int(rng.choice([0, 0, 0, 1 << c.al, (-(1 << c.al)) & 0xffffffff]))
+    return arr
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hand_scheduled_refinement_loop_equals_its_twin(seed):
+    import emu
+    import jpeg_decoder_amd as J
+    assert J.device_count() >= 1
+    dev = C.CDLL(J._native.LIB_PATH)
+    dev.jpgpu_selftest_refine_fast.argtypes = [C.c_void_p, C.c_uint32]
+    cpu = emu.lib()
+    cpu.emu_progw_refine_fast.argtypes = [C.c_void_p, C.c_uint32]
+    cpu.emu_progw_refine_fast.restype = None
+    rng = np.random.default_rng(9100 + seed)
+    n = 4096
+    a = _cases(rng, n)
+    b = (Case * n)()
+    C.memmove(b, a, C.sizeof(a))
+    cpu.emu_progw_refine_fast(C.byref(a), n)
+    assert dev.jpgpu_selftest_refine_fast(C.byref(b), n) == 0
+    bad = []
+    codes = [0, 0, 0]
+    for i in range(n):
+        x, y = a[i], b[i]
+        codes[x.code] += 1
+        same = all(getattr(x, f) == getattr(y, f) for f in ("win", "pos", "nx", "dp", "k", "new_nz", "new_neg", "eob", "code")) and list(x.acc) == list(y.acc)
+        if not same:
+            bad.append(i)
+    if bad:
+        i = bad[0]
+        x, y = a[i], b[i]
+        msg = {f: (hex(getattr(x, f)), hex(getattr(y, f))) for f in ("win", "pos", "nx", "dp", "k", "new_nz", "new_neg", "eob", "code") if getattr(x, f) != getattr(y, f)}
+        lanes = [(l, hex(x.acc[l]), hex(y.acc[l])) for l in range(64) if x.acc[l] != y.acc[l]]
+        raise AssertionError(f"{len(bad)} of {n} states differ; case {i}: twin vs device {msg}, lanes {lanes[:8]}")
+    assert min(codes) > 50, codes  # all three exits were taken

@@ -76,7 +76,8 @@ FIXTURES = {  # file: (scans, tracks) — every progressive file of the referenc
 
 
 @pytest.mark.parametrize("rel", sorted(FIXTURES))
-@pytest.mark.parametrize("order", [0, 1, 2, 3], ids=["tracks-in-order", "tracks-reversed", "scan-by-scan-round-robin", "a-lane-per-scan-with-its-waits"])
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 5], ids=["tracks-in-order", "tracks-reversed", "scan-by-scan-round-robin", "a-lane-per-scan-with-its-waits",
+                                                            "a-WAVE-per-scan-with-its-waits", "a-wave-per-track"])
 def test_reference_fixtures(rel, order):
     data = open(os.path.join(R.GOLDEN, rel), "rb").read()
     assert _same_as_host(data, order) == FIXTURES[rel]
@@ -100,6 +101,7 @@ def test_encoder_written_progressive_streams(case, quality):
     w, h, sub = case
     data = _pil(w, h, sub or "4:4:4", gray=sub is None, quality=quality, seed=w + h)
     ns, nt = _same_as_host(data, order=(w + quality) % 4)
+    assert _same_as_host(data, order=4 + (w + quality) % 2) == (ns, nt)  # round 6: the wave-per-scan walk (huff_prog_wave.hpp)
     assert ns >= 3 and nt >= 2 - (sub is None)
 
 
@@ -168,7 +170,7 @@ def test_damaged_streams_never_differ_from_the_host(seed):
     kept = flagged = same = 0
     for t in range(60):
         data = _damage(rng, bases[t % len(bases)])
-        got = _device(data, order=t % 4)
+        got = _device(data, order=t % 6)
         if got is None:
             kept += 1
             continue
