@@ -1326,7 +1326,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     static const bool serial_env = getenv("JPGPU_PROG_SERIAL") != nullptr;
     static const bool lanes_env = getenv("JPGPU_PROG_LANES") != nullptr && atoi(getenv("JPGPU_PROG_LANES")) != 0;
     const bool waves = !lanes_env;
-    const bool serial_tracks = serial_env || (!waves && !allow_pipelined);
+    const bool serial_tracks = serial_env || !allow_pipelined;  // (waves: the caller's limit is unlimited unless a test sets one — pipeline.cpp, prog_lanes_max)
     const size_t progress_off = mask_bytes;
     mask_bytes += align_up(n_scans * 4u, 256);
     // (lanes: a padding of < 64 lanes per rank, up to 64 ranks — more are walked serially, as tracks; waves: eight lists that differ by less than one frame's 256 scans)
@@ -1569,6 +1569,16 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     B_HIP(waves ? launch_huff_progw(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s)
                 : launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s));
     B_HIP(hipEventRecord(b->ev_phase[2], s));
+    if (waves && getenv("JPGPU_PROG_TIMES")) {  // (debugging aid: a synchronisation inside the launch)
+        B_HIP(hipStreamSynchronize(s));
+        const uint32_t ns = (uint32_t)images[0].plan->scans.size();
+        std::vector<ProgScan> back(ns);
+        B_HIP(hipMemcpy(back.data(), d + off_scans, ns * sizeof(ProgScan), hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < ns; j++)
+            fprintf(stderr, "prog times: frame 0 scan %u (ss %u se %u ah %u al %u, %u bytes): %.3f ms\n", j, back[j].ss, back[j].se, back[j].ah, back[j].al, back[j].n_bytes, back[j].report[0] * 1e-5);
+        for (uint32_t j = 0; j < ns; j++)
+            if (back[j].ah && back[j].ss) fprintf(stderr, "prog times: frame 0 scan %u: %u calls of the hand-scheduled loop, %u symbols on the portable path, %u window switches\n", j, back[j].report[1], back[j].report[2], back[j].report[3]);
+    }
     {
         const int crc = jpgpu_batch_classify_on_device(b, s);
         if (crc) return crc;

@@ -939,11 +939,52 @@ __global__ __launch_bounds__(64) void progw_refine_fast_case_kernel(PwFastCase *
     // (per-lane arrays: every lane reads and writes its own element only)
     const uint32_t lane = threadIdx.x;
     c.lut6[lane] = g->lut6[lane], c.w[lane] = g->w[lane], c.acc[lane] = g->acc[lane];
+    c.table = g->lut8;
     pw_refine_fast_case(c);
     g->acc[lane] = c.acc[lane];
     if (lane == 0u) {
         g->win = c.win, g->pos = c.pos, g->nx = c.nx, g->dp = c.dp, g->k = c.k, g->eob = c.eob, g->new_nz = c.new_nz, g->new_neg = c.new_neg, g->code = c.code;
     }
+}
+// (timing: the same state walked `reps` times by one wave; -> milliseconds for the lot)
+__global__ __launch_bounds__(64) void progw_refine_fast_bench_kernel(PwFastCase *cases, uint32_t reps) {
+    PwFastCase *g = cases;
+    const uint32_t lane = threadIdx.x;
+    auto u32 = [](uint32_t x) { return wv_uniform(x); };
+    auto u64 = [](uint64_t x) { return ((uint64_t)wv_uniform((uint32_t)(x >> 32)) << 32) | wv_uniform((uint32_t)x); };
+    PwFastCase c0;  // (every lane holds the same: into scalar registers once)
+    c0.win = u64(g->win), c0.nz = u64(g->nz), c0.neg = u64(g->neg), c0.new_nz = u64(g->new_nz), c0.new_neg = u64(g->new_neg);
+    c0.pos = u32(g->pos), c0.nx = u32(g->nx), c0.dp = u32(g->dp), c0.k = u32(g->k), c0.end = u32(g->end), c0.al = u32(g->al), c0.eob = u32(g->eob);
+    const uint32_t lut = g->lut6[lane], w = g->w[lane], acc = g->acc[lane];
+    uint32_t sink = 0;
+    for (uint32_t r = 0; r < reps; r++) {
+        PwFastCase c;
+        c.win = c0.win, c.nz = c0.nz, c.neg = c0.neg, c.new_nz = c0.new_nz, c.new_neg = c0.new_neg;
+        c.pos = c0.pos, c.nx = c0.nx, c.dp = c0.dp, c.k = c0.k, c.end = c0.end, c.al = c0.al, c.eob = c0.eob, c.code = 0u;
+        c.lut6[lane] = lut, c.w[lane] = w, c.acc[lane] = acc;
+        c.table = g->lut8;
+        pw_refine_fast_case(c);
+        sink += c.acc[lane];
+    }
+    g->acc[lane] = sink;
+}
+extern "C" float jpgpu_selftest_refine_fast_ms(void *host_case, uint32_t reps, uint32_t waves) {
+    PwFastCase *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(PwFastCase)) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    if (hipMemcpy(d, host_case, sizeof(PwFastCase), hipMemcpyHostToDevice) == hipSuccess) {
+        progw_refine_fast_bench_kernel<<<dim3(waves), dim3(64)>>>(d, 8);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        progw_refine_fast_bench_kernel<<<dim3(waves), dim3(64)>>>(d, reps);
+        hipEventRecord(e1);
+        if (hipEventSynchronize(e1) == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipEventDestroy(e0), hipEventDestroy(e1);
+    (void)hipFree(d);
+    return ms;
 }
 extern "C" int jpgpu_selftest_refine_fast(void *host_cases, uint32_t n) {
     PwFastCase *d = nullptr;

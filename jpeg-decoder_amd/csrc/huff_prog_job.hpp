@@ -60,6 +60,9 @@ struct ProgScan {
     const uint32_t *wait[3];  // the progress words of the scans this one stays behind (nullptr: none)
     uint32_t wait_whole;      // bit i: wait[i] walks its blocks in another order: it must have ENDED before this scan starts
     uint32_t pad_;
+    // what the wave that walked the scan reports (JPGPU_PROG_TIMES=1 prints it for the first frame): [0] its time in 10-ns units,
+    // refinement scans: [1] calls of the hand-scheduled loop, [2] symbols it handed to the portable path, [3] window switches
+    uint32_t report[4];
 };
 constexpr uint32_t PROG_DONE = 0xffffffffu;
 
@@ -71,6 +74,7 @@ struct ProgTrack {
 
 // status bits of a progressive image (bit 0 set with every one of them: the host decodes the image)
 constexpr uint32_t PROG_ST_HOST = 1u, PROG_ST_BAD_CODE = 2u, PROG_ST_BAD_DC = 4u, PROG_ST_BAND = 8u, PROG_ST_STAGING = 16u, PROG_ST_RANGE = 32u,
+                   PROG_ST_REPLACED = 64u /* a refinement scan puts a new value where a coefficient is non-zero already (damaged streams only) */,
                    PROG_ST_REFINE_SYMBOL = 128u, PROG_ST_WAIT = 512u /* a lane gave up waiting for the scan it depends on */;
 
 }  // namespace jpgpu

@@ -152,11 +152,13 @@ __device__ __forceinline__ uint32_t pw_unzig(uint32_t k) {
 // The unread bits live in an SGPR pair, left-aligned (`win`, `pos` of them valid); they are topped up 32 at a time from `nx`, a dword
 // that has been taken out of the register window `w` (lane i: dword base + i of the scan's data, most significant byte first) one
 // refill AHEAD — v_readlane's result takes ~20 cycles to reach the scalar unit (tools/ubench_scalar_chain.hip), a refill never waits
-// for it.  `n`: the 64 dwords behind `w` as memory holds them, requested when `w` was entered: the wave waits for them — and, on this
-// architecture, for every store and atomic it has in flight: one counter — once per 2,048 bits.  Zeros behind the scan's data (the
-// reference feeds zeros once it has met the marker that ends the scan: src/huffman.rs:123-160).
+// for it.  A window is 2,048 bits; the next one is loaded when this one is used up, and the wave waits for it there (~2 us, 65 times
+// in the longest scan of benches/tower_progressive.jpg).  NOT requested a window ahead, as first built: a register with a load
+// pending cannot be copied, and the compiler keeps loop-carried values in copies — it put `s_waitcnt vmcnt(0)` on the block loop's
+// back edge, which on this architecture is a wait for the atomics of the block before: 1 us per block, 4 of a scan's 10 ms.
+// Zeros behind the scan's data (the reference feeds zeros once it has met the marker that ends the scan: src/huffman.rs:123-160).
 struct PwBits {
-    WV32 w, n;
+    WV32 w;
     uint64_t win;
     uint32_t pos;
     uint32_t nx;        // the next dword of the stream
@@ -165,18 +167,12 @@ struct PwBits {
     const uint32_t *src;
     uint32_t n_dwords;  // dwords that hold data or the slot's zero padding
 };
-__device__ __forceinline__ void pw_window_load(const PwBits &b, uint32_t base, WV32 &a) {
-    WV_EACH {
-        const uint32_t i = base + lane;
-        WV(a) = i < b.n_dwords ? ((const JP_GLOBAL uint32_t *)b.src)[i] : 0u;
-    }
-}
-// `n` becomes the window (bytes swapped now: a swap at load time would make the wave wait where the load is issued), the 64 dwords
-// behind it are requested
-__device__ __forceinline__ void pw_window_enter(PwBits &b) {
+__device__ __forceinline__ void pw_window_enter(PwBits &b) {  // the 64 dwords from `base` on
     PROGW_COUNT(windows, 1);
-    WV_EACH { WV(b.w) = __builtin_bswap32(WV(b.n)); }
-    pw_window_load(b, b.base + 64u, b.n);
+    WV_EACH {
+        const uint32_t i = b.base + lane;
+        WV(b.w) = i < b.n_dwords ? __builtin_bswap32(((const JP_GLOBAL uint32_t *)b.src)[i]) : 0u;
+    }
 }
 // the refill proper; the caller has checked pos < 32.  Afterwards 32 <= pos < 64.
 __device__ __forceinline__ void pw_refill(PwBits &b) {
@@ -194,7 +190,6 @@ __device__ __forceinline__ void pw_bits_open(PwBits &b, const uint8_t *data, uin
     b.src = (const uint32_t *)data;                 // (16-byte aligned slots, zero-filled behind the data: huff_stage_segment)
     b.n_dwords = ((n_bytes + 15u) / 16u) * 4u;
     b.base = 0u;
-    pw_window_load(b, 0u, b.n);
     pw_window_enter(b);
     b.nx = wv_readlane(b.w, 0u);
     b.dp = 1u;
@@ -466,6 +461,17 @@ __device__ __forceinline__ size_t pw_ac_block(uint32_t bi, uint32_t cols, uint32
     return (size_t)my * block_w + (bi - my * cols);
 }
 
+// ... kept as the walk goes (the division above costs ~40 instructions: once per chunk and lane for the masks, never per block)
+struct PwWalk {
+    uint32_t mx, row, cols, block_w;
+};
+__device__ __forceinline__ void pw_walk_open(PwWalk &w, uint32_t cols, uint32_t block_w) { w.mx = 0u, w.row = 0u, w.cols = cols, w.block_w = block_w; }
+__device__ __forceinline__ size_t pw_walk_block(const PwWalk &w) { return (size_t)w.row * w.block_w + w.mx; }
+__device__ __forceinline__ void pw_walk_advance(PwWalk &w, uint32_t n) {
+    w.mx += n;
+    while (w.mx >= w.cols) w.mx -= w.cols, w.row++;
+}
+
 // AC first scan (ah == 0; src/decoder.rs:1128-1172)
 __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *status, PwSync &y) {
     PwBits b;
@@ -476,6 +482,8 @@ __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *s
     uint64_t *const masks = s.comp[0].masks;
     const uint32_t block_w = s.comp[0].block_w, cols = s.cols, total = s.rows * s.cols, ss = s.ss, se = s.se, al = s.al;
     uint32_t eob_run = 0, err = 0;
+    PwWalk at;
+    pw_walk_open(at, cols, block_w);
     WV32 cf, unz;
     WV_EACH {
         WV(cf) = 0u;
@@ -489,6 +497,7 @@ __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *s
                 const uint32_t skip = eob_run < n - i ? eob_run : n - i;
                 eob_run -= skip;
                 i += skip - 1u;
+                pw_walk_advance(at, skip);
                 continue;
             }
             PROGW_COUNT(blocks, 1);
@@ -527,14 +536,14 @@ __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *s
                 return false;
             }
             if (nz) {
-                const size_t blk = pw_ac_block(cb + i, cols, block_w);
+                const size_t blk = pw_walk_block(at);
                 WV_EACH {
                     if ((nz >> lane) & 1ull) pw_store16(coefs + blk * 64u + WV(unz), (int16_t)(uint16_t)WV(cf));
-                    // (OR, not store: another scan may own other bands of the block)
-                    if (lane == 0u) pw_or64(masks + 2u * blk, nz);
-                    if (lane == 1u && neg) pw_or64(masks + 2u * blk + 1u, neg);
+                    // (OR, not store: another scan may own other bands of the block; lanes 0 and 1: the two words in one instruction)
+                    if (lane < 2u) pw_or64(masks + 2u * blk + lane, lane ? neg : nz);
                 }
             }
+            pw_walk_advance(at, 1u);
         }
         pw_publish(y, cb + n);
     }
@@ -651,9 +660,18 @@ static inline uint32_t pw_refine_fast(PwRefine &R, const PwTable &tab, PwRefineB
             b.nx = wv_readlane(b.w, b.dp);
             b.dp++;
         }
-        const uint32_t hi = (uint32_t)(b.win >> 32), e = wv_readlane(tab.lut6, hi >> 26), len = e & 31u;
-        if (len == 0u) return 1u;
-        const uint32_t nb = (e >> 5) & 31u, kind = (e >> 17) & 3u, zrl = (e >> 10) & 127u;
+        const uint32_t hi = (uint32_t)(b.win >> 32), e = wv_readlane(tab.lut6, hi >> 26);
+        uint32_t len = e & 31u, nb = (e >> 5) & 31u, kind = (e >> 17) & 3u, zrl = (e >> 10) & 127u;
+        if (len == 0u) {  // Lsecond: codes of seven and eight bits, from the 8-bit lookup in memory
+            const uint32_t idx8 = hi >> 24, e8 = (reinterpret_cast<const JP_CONST uint32_t *>(tab.g->lut)[idx8 >> 1] >> (16u * (idx8 & 1u))) & 0xffffu;
+            len = e8 >> 8;
+            if (len == 0u) return 1u;
+            const uint32_t sz = e8 & 15u, r = (e8 >> 4) & 15u;
+            if (sz == 1u) nb = 1u, kind = 0u, zrl = r;
+            else if (sz != 0u) return 1u;
+            else if (r == 15u) nb = 0u, kind = 2u, zrl = 15u;
+            else nb = r, kind = 1u, zrl = 64u;
+        }
         if (kind == 3u) return 1u;
         const uint32_t bits = ((hi << len) >> 1) >> (31u - nb), cons = len + nb;
         uint64_t win2 = b.win << cons;
@@ -713,7 +731,7 @@ static inline uint32_t pw_refine_fast(PwRefine &R, const PwTable &tab, PwRefineB
 // SGPR pair such as `todo` or `1 << stop` is used directly as the condition of a v_cndmask.
 // State in fixed scalar registers (the halves of a 64-bit inline-asm operand cannot be named): s[40:41] window, s42 valid bits, s43 next
 // dword, s44 its successor's lane, s45 k, s[46:47] / s[48:49] new non-zero / new negative, s[50:51] non-zero, s[52:53] below_end,
-// s54 end, s55 / s56 +bit / -bit, s57 end-of-band run, s58 -> 0: the block is through, 1: the next symbol is the portable path's, 2: the
+// s54 end, s55 / s56 +bit / -bit, s57 end-of-band run, s[82:83] the table's 8-bit lookup in memory, s58 -> 0: the block is through, 1: the next symbol is the portable path's, 2: the
 // window is used up (refill there); s60-s81 scratch.  Nothing is committed before a symbol's corrections are known to fit.
 __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &tab, PwRefineBlock &B, const WV32 &delta, uint64_t below_end, uint32_t end) {
     uint32_t code, t0;
@@ -721,6 +739,8 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
     const uint32_t pbit = wv_uniform(R.bit), nbit = wv_uniform(0u - R.bit), end_s = wv_uniform(end);
     const uint64_t bend_s = ((uint64_t)wv_uniform((uint32_t)(below_end >> 32)) << 32) | wv_uniform((uint32_t)below_end);
     const uint64_t nz_s = ((uint64_t)wv_uniform((uint32_t)(R.nz >> 32)) << 32) | wv_uniform((uint32_t)R.nz);
+    const uint64_t lut8_a = (uint64_t)(uintptr_t)(const void *)tab.g->lut;
+    const uint64_t lut8_s = ((uint64_t)wv_uniform((uint32_t)(lut8_a >> 32)) << 32) | wv_uniform((uint32_t)lut8_a);
 #ifdef PROGW_ASM_NOPS
 #define PW_NOP "s_nop 3\n"
 #else
@@ -729,7 +749,7 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
     asm volatile(
         "s_mov_b64 s[40:41], %[win]\n s_mov_b32 s42, %[pos]\n s_mov_b32 s43, %[nx]\n s_mov_b32 s44, %[dp]\n s_mov_b32 s45, %[k]\n"
         "s_mov_b64 s[46:47], %[nnz]\n s_mov_b64 s[48:49], %[nneg]\n s_mov_b64 s[50:51], %[nz]\n s_mov_b64 s[52:53], %[bend]\n"
-        "s_mov_b32 s54, %[end]\n s_mov_b32 s55, %[pbit]\n s_mov_b32 s56, %[nbit]\n s_mov_b32 s57, %[eob]\n"
+        "s_mov_b32 s54, %[end]\n s_mov_b32 s55, %[pbit]\n s_mov_b32 s56, %[nbit]\n s_mov_b32 s57, %[eob]\n s_mov_b64 s[82:83], %[lut8]\n"
         "Ltop%=:\n"
         "s_cmp_lt_u32 s42, 32\n"
         "s_cbranch_scc1 Lrefill%=\n"
@@ -737,12 +757,13 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_lshr_b32 s60, s41, 26\n"
         "v_readlane_b32 s61, %[lut], s60\n" PW_NOP
         "s_and_b32 s62, s61, 31\n"                  // code length; SCC = (length != 0)
-        "s_cbranch_scc0 Lgeneric%=\n"
+        "s_cbranch_scc0 Lsecond%=\n"
         "s_bfe_u32 s63, s61, 0x50005\n"             // extra bits
         "s_bfe_u32 s64, s61, 0x20011\n"             // kind
         "s_bfe_u32 s65, s61, 0x7000a\n"             // zeros to pass
         "s_cmp_eq_u32 s64, 3\n"
         "s_cbranch_scc1 Lgeneric%=\n"
+        "Lhave%=:\n"
         "s_lshl_b32 s66, s41, s62\n"
         "s_lshr_b32 s66, s66, 1\n"
         "s_sub_u32 s67, 31, s63\n"
@@ -837,6 +858,38 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "v_readlane_b32 s43, %[w], s44\n" PW_NOP
         "s_add_u32 s44, s44, 1\n"
         "s_branch Lcorr%=\n"
+        "Lsecond%=:\n"                              // a code of seven or eight bits (4 % of the symbols): the 8-bit lookup in memory, through the scalar cache
+        "s_lshr_b32 s60, s41, 24\n"
+        "s_lshr_b32 s84, s60, 1\n"
+        "s_lshl_b32 s84, s84, 2\n"
+        "s_load_dword s85, s[82:83], s84\n"
+        "s_and_b32 s60, s60, 1\n"
+        "s_lshl_b32 s60, s60, 4\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_lshr_b32 s85, s85, s60\n"
+        "s_and_b32 s85, s85, 0xffff\n"              // symbol | length << 8
+        "s_lshr_b32 s62, s85, 8\n"                  // SCC = (length != 0)
+        "s_cbranch_scc0 Lgeneric%=\n"               // longer still: the portable path's walk
+        "s_and_b32 s60, s85, 15\n"                  // size
+        "s_bfe_u32 s65, s85, 0x40004\n"             // run
+        "s_cmp_eq_u32 s60, 1\n"
+        "s_cbranch_scc0 Lsecond0%=\n"
+        "s_mov_b32 s63, 1\n"                        // a new coefficient: one sign bit, run zeros to pass
+        "s_mov_b32 s64, 0\n"
+        "s_branch Lhave%=\n"
+        "Lsecond0%=:\n"
+        "s_cmp_eq_u32 s60, 0\n"
+        "s_cbranch_scc0 Lgeneric%=\n"               // "unexpected huffman code"
+        "s_cmp_eq_u32 s65, 15\n"
+        "s_cbranch_scc0 Lsecond1%=\n"
+        "s_mov_b32 s63, 0\n"                        // ZRL
+        "s_mov_b32 s64, 2\n"
+        "s_branch Lhave%=\n"
+        "Lsecond1%=:\n"
+        "s_mov_b32 s63, s65\n"                      // end of band: run low bits, every correction that is left
+        "s_mov_b32 s64, 1\n"
+        "s_mov_b32 s65, 64\n"
+        "s_branch Lhave%=\n"
         "Lgeneric%=:\n"
         "s_mov_b32 s58, 1\n"
         "s_branch Lend%=\n"
@@ -847,9 +900,9 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_mov_b64 %[nnz], s[46:47]\n s_mov_b64 %[nneg], s[48:49]\n s_mov_b32 %[eob], s57\n s_mov_b32 %[code], s58\n"
         : [win] "+s"(R.b.win), [pos] "+s"(R.b.pos), [nx] "+s"(R.b.nx), [dp] "+s"(R.b.dp), [k] "+s"(B.k), [nnz] "+s"(B.new_nz), [nneg] "+s"(B.new_neg),
           [eob] "+s"(B.eob_run), [code] "=s"(code), [acc] "+v"(R.acc), [t0] "=&v"(t0)
-        : [nz] "s"(nz_s), [bend] "s"(bend_s), [end] "s"(end_s), [pbit] "s"(pbit), [nbit] "s"(nbit), [lut] "v"(tab.lut6), [w] "v"(R.b.w), [delta] "v"(delta)
+        : [nz] "s"(nz_s), [bend] "s"(bend_s), [end] "s"(end_s), [pbit] "s"(pbit), [nbit] "s"(nbit), [lut8] "s"(lut8_s), [lut] "v"(tab.lut6), [w] "v"(R.b.w), [delta] "v"(delta)
         : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
-          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81");
+          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85");
     return code;
 }
 #endif
@@ -861,6 +914,8 @@ struct PwFastCase {
     uint64_t win, nz, neg, new_nz, new_neg;
     uint32_t pos, nx, dp, k, end, al, eob, code;
     uint32_t lut6[64], w[64], acc[64];
+    uint16_t lut8[256];  // the head of a ProgHuffTable: symbol | length << 8 per 8-bit prefix
+    const void *table;   // where lut8 lies for whoever runs the case
 };
 __device__ inline void pw_refine_fast_case(PwFastCase &c) {
     PwRefine R;
@@ -869,9 +924,9 @@ __device__ inline void pw_refine_fast_case(PwFastCase &c) {
     WV32 delta;
     R.b.win = c.win, R.b.pos = c.pos, R.b.nx = c.nx, R.b.dp = c.dp, R.b.base = 0u, R.b.src = nullptr, R.b.n_dwords = 0u;
     R.nz = c.nz, R.neg = c.neg, R.bit = 1u << c.al;
-    tab.g = nullptr, tab.mode = 1u;
+    tab.g = (const JP_CONST ProgHuffTable *)c.table, tab.mode = 1u;
     WV_EACH {
-        WV(R.b.w) = c.w[lane], WV(R.b.n) = 0u, WV(tab.lut6) = c.lut6[lane], WV(R.acc) = c.acc[lane];
+        WV(R.b.w) = c.w[lane], WV(tab.lut6) = c.lut6[lane], WV(R.acc) = c.acc[lane];
         WV(delta) = ((R.neg >> lane) & 1ull) ? 0u - R.bit : R.bit;
     }
     const uint64_t below_end = c.end >= 64u ? ~0ull : ((1ull << c.end) - 1ull);
@@ -892,6 +947,9 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
     const uint64_t below_end = end >= 64u ? ~0ull : ((1ull << end) - 1ull), band = below_end & (~0ull << ss);
     R.bit = 1u << s.al;
     uint32_t eob_run = 0;
+    uint32_t n_calls = 0, n_generic = 0, n_window = 0;  // (reported with the scan's time)
+    PwWalk at;
+    pw_walk_open(at, cols, block_w);
     WV32 unz, m0, m1, m2, m3;
     WV_EACH {
         WV(R.acc) = 0u;
@@ -915,7 +973,13 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
 #endif
             }
         }
-        for (uint32_t i = 0; i < n; i++) {
+#ifndef JPGPU_HOST_EMULATION
+        // The masks have arrived — said HERE, once per chunk: left to itself the compiler waits at their first use, inside the block loop,
+        // with s_waitcnt vmcnt(0) (it cannot count the loop's own stores and atomics), and on this architecture that is a wait for the
+        // atomics of the block before: ~1 us per block, 4 of a scan's 10 ms.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
+        for (uint32_t i = 0; i < n; i++, pw_walk_advance(at, 1u)) {
             PROGW_COUNT(blocks, 1);
             R.nz = ((uint64_t)wv_readlane(m1, i) << 32) | wv_readlane(m0, i);
             R.neg = ((uint64_t)wv_readlane(m3, i) << 32) | wv_readlane(m2, i);
@@ -929,6 +993,7 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
                 WV32 delta;  // what a correction adds to each position's coefficient: -bit where it is negative
                 WV_EACH { WV(delta) = ((R.neg >> lane) & 1ull) ? 0u - R.bit : R.bit; }
                 for (;;) {
+                    n_calls++;
 #if defined(PROGW_DEBUG_PRINTF) && !defined(JPGPU_HOST_EMULATION)
                     if (cb + i >= 3868u && cb + i <= 3870u && s.al == 0 && threadIdx.x == 0u)
                         printf("dev block %u before: k %u pos %u win %016llx nx %08x dp %u nz %016llx neg %016llx eob %u\n", cb + i, B.k, R.b.pos, (unsigned long long)R.b.win, R.b.nx, R.b.dp, (unsigned long long)R.nz, (unsigned long long)R.neg, B.eob_run);
@@ -948,9 +1013,11 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
 #endif
                     if (code == 0u) break;
                     if (code == 2u) {
+                        n_window++;
                         pw_refill(R.b);  // (into the next window)
                         continue;
                     }
+                    n_generic++;
                     pw_refine_symbol(R, tab, B, below_end, end);
                     if (B.k >= end) break;
                 }
@@ -965,29 +1032,39 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
                 eob_run = B.eob_run;
             }
             const uint64_t new_nz = B.new_nz, new_neg = B.new_neg;
+            // A new value where the block has a coefficient already: only a damaged stream does that (the walk ran out of zeros and ended
+            // ON a non-zero coefficient, which the reference then REPLACES: src/decoder.rs:1251-1256) — the host's business, like every
+            // other oddity; what is left is additions only.
+            if (__builtin_expect((new_nz & R.nz) != 0ull, 0)) {
+                pw_flag(status, PROG_ST_REPLACED);
+                return false;
+            }
             {
-                const size_t blk = pw_ac_block(cb + i, cols, block_w);
+                const size_t blk = pw_walk_block(at);
                 WV_EACH {
                     const uint32_t a = WV(R.acc), z = WV(unz);
-                    if (a) {
-                        if ((new_nz >> lane) & 1ull) pw_store16(coefs + blk * 64u + z, (int16_t)(uint16_t)a);
-                        else pw_add32(reinterpret_cast<uint32_t *>(coefs + blk * 64u) + (z >> 1), (z & 1u) ? a << 16 : a);
-                    }
+                    // One atomic add per touched coefficient, on its dword: a correction +-bit in the low half goes in sign-extended (the
+                    // coefficient keeps its sign, so the borrow of a -bit out of the low half and the extension's 0xffff in the high half
+                    // cancel), a NEW value lands on a zero half and goes in zero-extended (no carry to cancel).
+                    if (a) pw_add32(reinterpret_cast<uint32_t *>(coefs + blk * 64u) + (z >> 1), (z & 1u) ? a << 16 : (((new_nz >> lane) & 1ull) ? a & 0xffffu : a));
                     WV(R.acc) = 0u;
-                    if (new_nz) {
-                        // Atomic OR / AND, never a store of the whole word: a mask word covers all 63 AC positions of the
-                        // block, a scan only its band — with a script such as Y 1-5 | Y 6-63 | refine 1-5 | refine 6-63 the wave of
-                        // "refine 1-5" runs beside the wave of "6-63 first" on the same blocks.
-                        const uint64_t flip = R.neg & new_nz & ~new_neg;  // (bits of this scan's own band only)
-                        if (lane == 0u) pw_or64(masks + 2u * blk, new_nz);
-                        if (lane == 1u && new_neg) pw_or64(masks + 2u * blk + 1u, new_neg);
-                        if (lane == 1u && flip) pw_and64(masks + 2u * blk + 1u, ~flip);
-                    }
+                    // Atomic OR, never a store of the whole word: a mask word covers all 63 AC positions of the block, a scan
+                    // only its band — with a script such as Y 1-5 | Y 6-63 | refine 1-5 | refine 6-63 the wave of "refine 1-5" runs beside
+                    // the wave of "6-63 first" on the same blocks.  (Lanes 0 and 1: both words in one instruction.)
+                    if (new_nz && lane < 2u) pw_or64(masks + 2u * blk + lane, lane ? new_neg : new_nz);
                 }
             }
         }
         pw_publish(y, cb + n);
     }
+#ifndef JPGPU_HOST_EMULATION
+    if (threadIdx.x == 0u) {
+        uint32_t *rep = const_cast<uint32_t *>((const uint32_t *)s.report);
+        rep[1] = n_calls, rep[2] = n_generic, rep[3] = n_window;
+    }
+#else
+    (void)n_calls, (void)n_generic, (void)n_window;
+#endif
     return true;
 }
 
@@ -998,9 +1075,15 @@ __device__ inline void progw_run_track(const ProgTrack &tr) {
         PwSync y;
         pw_sync_open(y, s, tr.status);
         bool ok;
+#ifndef JPGPU_HOST_EMULATION
+        const uint64_t t_start = wall_clock64();  // (100 MHz; JPGPU_PROG_TIMES=1 prints what every scan of the first frame took)
+#endif
         if (s.ss == 0u) ok = pw_scan_dc(s, tr.status, y);
         else if (s.ah == 0u) ok = pw_scan_ac_first(s, tr.status, y);
         else ok = pw_scan_ac_refine(s, tr.status, y);
+#ifndef JPGPU_HOST_EMULATION
+        if (threadIdx.x == 0u) const_cast<uint32_t *>((const uint32_t *)tr.scans[i].report)[0] = (uint32_t)(wall_clock64() - t_start);
+#endif
         pw_publish(y, PROG_DONE);  // (also when the scan gave up: whoever waits for it must not wait for good — the image is the host's by then)
         if (!ok) return;
     }

@@ -49,6 +49,24 @@ uint32_t default_threads() {
     return n;
 }
 
+// CPUs the process may really use: its affinity mask, capped by a cgroup quota (the progressive dispatcher's host side)
+uint32_t granted_cpus() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<uint32_t>(n, (uint32_t)std::max(1, CPU_COUNT(&set)));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        unsigned long period = 0;
+        if (fscanf(f, "%31s %lu", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const unsigned long cpus = (strtoul(quota, nullptr, 10) + period - 1) / period;
+            if (cpus > 0) n = std::min<uint32_t>(n, (uint32_t)cpus);
+        }
+        fclose(f);
+    }
+    return n;
+}
+
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -276,18 +294,6 @@ struct jpgpu_pipeline {
     std::vector<int32_t> sub_of, slot;  // image -> sub-batch / index in it, -1 if it never got there
     std::vector<std::vector<jpgpu::host::PlannedScan>> plans;  // per image: scans for the device entropy decoder (empty: host)
     std::vector<jpgpu::host::ProgPlan> prog_plans;             // per image: the scans of a PROGRESSIVE frame for the device (no scans: host)
-    // What the dispatcher of progressive frames has learnt from this pipeline's earlier calls (nanoseconds per byte of JPEG file):
-    // a host thread's entropy decoding + staging of one such frame, and the device's walk of the longest track (a launch's duration
-    // does not depend on how many frames it holds while they fit the machine: every track has a lane of its own).  0: not measured yet.
-    double prog_host_ns_per_byte = 0.0, prog_dev_ns_per_byte = 0.0;
-    // ... and, in wall-clock terms: what ONE more frame costs the host's pool as a whole (entropy phase / frames, measured when the pool
-    // was saturated — CPU contention with the device route's staging included), and what one more frame adds to the device route on
-    // top of the walk (staging, upload, range scan, pixel kernels)
-    double prog_host_ms_per_image = 0.0, prog_dev_ms_per_image = 0.0;
-    uint32_t prog_host_samples = 0;  // calls the host's rate has been taken from (the model is trusted from two on)
-    uint32_t prog_last_e = 0, prog_last_d = 0;  // the last call's eligible frames and how many of them the device got (a call of the same
-                                                 // shape keeps its route unless the rates say it is off by a tenth: sub-batches — arenas,
-                                                 // pinned staging — are reused only while their composition repeats)
     std::vector<SubBatch> subs;          // kept across calls while the geometry sequence repeats
     uint32_t n_subs = 0;                 // sub-batches used by the last call
     std::string path;
@@ -331,13 +337,16 @@ static const jpgpu_pipeline *child_of(const jpgpu_pipeline *p, uint32_t &image) 
     return c;
 }
 static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags);
-// Lanes up to which a call's progressive frames are walked a lane per SCAN (pipelined, huff_prog_job.hpp): all the call's launches run
-// side by side and lanes that wait hold their slots, so they must fit the device at once (host_common.hpp) — 46 k of the 48 k lanes
-// it holds (every rank of every launch is padded to whole waves).  Beyond: a lane per track.  JPGPU_PROG_LANES_MAX: tests, A/B.
+// Up to how many scans does a call walk its progressive frames a WAVE per scan (pipelined, huff_prog_job.hpp)?  Always, with the waves
+// of round 6: their launch order keeps a frame's waves on one XCD, producers in front (csrc/batch.cpp), so an oversubscribed launch
+// cannot starve a producer.  Round 5's lanes (JPGPU_PROG_LANES=1) had to fit the device at once: 46 k of its 48 k.  Beyond the limit: a
+// wave (lane) per TRACK, its scans one after the other.  JPGPU_PROG_LANES_MAX: tests, A/B (read per call).
 static uint64_t prog_lanes_max() {
     if (getenv("JPGPU_PROG_SERIAL")) return 0;
     const char *e = getenv("JPGPU_PROG_LANES_MAX");
-    return e ? (uint64_t)std::max<long>(atol(e), 0) : 46000u;
+    if (e) return (uint64_t)std::max<long>(atol(e), 0);
+    const char *lanes = getenv("JPGPU_PROG_LANES");
+    return lanes && atoi(lanes) != 0 ? 46000u : ~0ull;
 }
 
 static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n);
@@ -532,26 +541,35 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
         }
 }
 
-// Progressive frames: the device walks every frame's tracks side by side, one lane each — a launch takes as long as ONE
-// lane's walk of the longest track, whether it holds ten frames or ten thousand (while they fit the machine: 512 waves of 64 lanes) —
-// and a host thread decodes a frame in a fraction of that time, one after the other.  So a call's eligible frames go to ONE of the
-// two: the host (entropy decoding on its threads, compact planes uploaded, as in round 4) — a few hundred frames on many cores — or
-// the device: thousands, or few cores.  The two rates come from this pipeline's earlier calls (first call: the host, and a probe of
-// 64 frames on the device so that the next call knows).  JPGPU_PIPE_PROG_DEVICE_PERCENT pins the device's share (tests, A/B).
+// Progressive frames: which of a call's eligible frames does the device decode?  All of them or none (a split was built
+// in round 5 and removed: with both routes busy the host's threads and the device route's staging team compete for the same cores) —
+// decided by a COST MODEL of what the planner has counted, not by timing earlier calls (round 5's wall-clock dispatcher needed a probe
+// call and three more before it settled, mis-routed three different ways and made one call's route depend on a neighbour's load:
+// VERDICT r5).  The same call takes the same route the first time and the tenth.
+//   device = fixed + max(chain, volume) + frames x per_frame
+//     chain  : a scan is one dependent walk, one wave (huff_prog_wave.hpp) — the launch lasts at least as long as the call's LONGEST scan:
+//              its entropy-coded bytes x kDevChainNsPerByte;
+//     volume : all scans of all frames share the device's scalar units: total entropy-coded bytes x kDevVolumeNsPerByte;
+//   host   = total entropy-coded bytes x kHostNsPerByte / min(worker threads, CPUs the process may use).
+// The constants are measurements on an MI355X with an EPYC 9575F host (profiles/round6/03_progressive_cost_model.txt; re-measure with
+// tools/prog_calls.py --percent 100 / --percent 0): benches/tower_progressive.jpg's longest scan, 16.7 kB, walks in 9.2 ms; 4,096
+// such frames (235 MB of scans) in 50 ms; 256 of them cost 16 host CPUs 16 ms.  The device must be ahead by a tenth (the host route is
+// the one whose behaviour on odd streams is pinned).  JPGPU_PIPE_PROG_DEVICE_PERCENT pins the device's share (tests, A/B).
 // Returns how many frames keep their device plan; the others get a fresh front-end for the host path.
+constexpr double kDevFixedMs = 1.5, kDevChainNsPerByte = 560.0, kDevVolumeNsPerByte = 0.215, kDevPerFrameMs = 0.006, kHostNsPerByte = 17.0;
 static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
     std::vector<uint32_t> elig;
-    uint64_t bytes = 0, tracks = 0, scans = 0;
-    uint32_t n_prog_host = 0;  // progressive frames the host decodes anyway (not eligible)
+    uint64_t scan_bytes = 0, longest_scan = 0, host_bytes = 0;  // entropy-coded bytes: of the eligible frames' scans, of the longest of those scans, of the progressive frames the host decodes anyway
     for (uint32_t i = 0; i < n; i++) {
         if (p->status[i] != JPGPU_OK) continue;
         if (!p->prog_plans[i].scans.empty()) {
             elig.push_back(i);
-            bytes += len[i];
-            tracks += p->prog_plans[i].n_tracks;
-            scans += p->prog_plans[i].scans.size();
+            for (const auto &ps : p->prog_plans[i].scans) {
+                scan_bytes += ps.stuffed_bytes;
+                longest_scan = std::max<uint64_t>(longest_scan, ps.stuffed_bytes);
+            }
         } else if (p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
-            n_prog_host++;
+            host_bytes += len[i];
         }
     }
     const uint32_t e = (uint32_t)elig.size();
@@ -560,44 +578,16 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
     if (const char *pin = getenv("JPGPU_PIPE_PROG_DEVICE_PERCENT")) {
         d = (uint32_t)((uint64_t)e * (uint64_t)std::min<long>(std::max<long>(atol(pin), 0), 100) / 100u);
     } else {
-        const double avg = (double)bytes / e;
-        // the walk: nanoseconds per byte of ONE file (it lasts as long as the longest track, whatever the number of frames); the host: what a
-        // frame costs the whole pool; first call: guesses (an EPYC core decodes a 60 kB frame in 1.9 ms, the device walks it in 25 ms)
-        const double walk_ms = avg * (p->prog_dev_ns_per_byte > 0 ? p->prog_dev_ns_per_byte : 400.0) * 1e-6;
-        const double per_dev = p->prog_dev_ms_per_image > 0 ? p->prog_dev_ms_per_image : 0.012;
-        const double per_host = p->prog_host_ms_per_image > 0 ? p->prog_host_ms_per_image : avg * 32.0e-6 / (double)std::max<uint32_t>(1u, std::min<uint32_t>(p->pool->size(), 16u));
-        // lanes the machine holds at a time (three one-wave workgroups of 42 kB LDS per CU x 256 CUs x 64 lanes); more than that walk in rounds
-        // (a lane per scan while they all fit — prog_lanes_max() — else a lane per track)
-        const double lanes = 49152.0, tracks_per_frame = (double)(scans <= prog_lanes_max() ? scans : tracks) / e;
-        auto cost = [&](uint32_t cand) {
-            const double t_host = (double)(e - cand + n_prog_host) * per_host;
-            if (cand == 0) return t_host;
-            const double rounds = std::ceil(cand * tracks_per_frame / lanes);
-            return std::max(t_host, 1.0 + rounds * walk_ms + cand * per_dev);
-        };
-        // Two candidates: everything on the host (the pinned path: a tie goes there) or everything on the device.  A SPLIT — the device
-        // takes what the host's threads would not finish during the walk — was built and is gone: with both routes busy the host's
-        // threads and the device route's staging team compete for the same cores and the host's sub-batches queue behind the
-        // device's (measured twice: 3,008 of 4,096 frames on the device 125 ms, 3,136 of them 104 ms — all of them 61-81 ms)
-        uint32_t best_d = 0;
-        // (the device must be ahead by a sixth: the host's route is the pinned one, and what sends a call to the device wrongly — a
-        // host rate taken on a busy box — is never corrected from there)
-        if (cost(e) < cost(0) * 0.85) best_d = e;
-        d = best_d;
-        // Until BOTH rates have been measured the host keeps the frames — its route is the pinned one, and a guess in the device's favour
-        // kept a 256-frame call on the device for good (33 ms against 16: the host's rate is only measured when the host gets frames).
-        // First call: a probe of 64 frames on the device, so that the next call knows the walk; then the host, all of them, until TWO
-        // calls that REUSED their sub-batches have given the host's rate (the first call on fresh sub-batches touches its pinned
-        // blocks for the first time: not a rate; the lower of two samples: not a neighbour's burst) — calls three and four as a
-        // rule; from then on, the model.
-        const bool calibrated = p->prog_dev_ns_per_byte > 0 && p->prog_host_samples >= 2u;
-        if (!calibrated) d = p->prog_dev_ns_per_byte <= 0 && e >= 128u ? 64u : 0u;
-        // a call of the same shape as the last one keeps its route while the model does not object by more than a tenth in time
-        else if (e == p->prog_last_e && (p->prog_last_d == 0u || p->prog_last_d == e) && cost(p->prog_last_d) <= 1.10 * cost(d))
-            d = p->prog_last_d;
+        static const uint32_t cpus = granted_cpus();
+        const double workers = (double)std::max<uint32_t>(1u, std::min<uint32_t>(p->pool->size(), cpus));
+        const double host_all = (double)(scan_bytes + host_bytes) * kHostNsPerByte * 1e-6 / workers;
+        const double host_rest = (double)host_bytes * kHostNsPerByte * 1e-6 / workers;
+        const double device = kDevFixedMs + std::max((double)longest_scan * kDevChainNsPerByte, (double)scan_bytes * kDevVolumeNsPerByte) * 1e-6 + e * kDevPerFrameMs;
+        d = std::max(device, host_rest) < 0.9 * host_all ? e : 0u;
+        if (getenv("JPGPU_PIPE_TRACE"))
+            fprintf(stderr, "pipeline trace: progressive dispatcher: %u eligible frames, %.2f MB of scans, longest %llu bytes: device %.2f ms, host %.2f ms on %.0f workers -> %s\n",
+                    e, scan_bytes * 1e-6, (unsigned long long)longest_scan, device, host_all, workers, d ? "device" : "host");
     }
-    p->prog_last_e = e;
-    p->prog_last_d = d;
     // the LAST (e - d) eligible frames go back to the host (its threads start from the front of the list)
     for (uint32_t k = d; k < e; k++) {
         const uint32_t i = elig[k];
@@ -800,7 +790,6 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     }
     const uint32_t n_subs = (uint32_t)bounds.size() - 1u;
     p->n_subs = n_subs;
-    bool fresh_sub_batches = false;  // some sub-batch of this call is new: its arenas and pinned blocks are touched for the first time
     for (uint32_t j = 0; j < n_subs; j++) {
         SubBatch &sb = p->subs[j];
         const uint32_t first = bounds[j], last = bounds[j + 1];
@@ -818,7 +807,6 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
         bool reuse = sb.batch && descs.size() == sb.descs.size() && sb.compact == compact && (sb.h_coef != nullptr) == staged;
         for (size_t k = 0; reuse && k < descs.size(); k++) reuse = same_geometry(descs[k], sb.descs[k]);
         if (!reuse) {
-            fresh_sub_batches = true;
             sb.drop();
             rc = jpgpu_batch_create(p->device, descs.data(), (uint32_t)descs.size(), JPGPU_BATCH_DEFAULT, &sb.batch);
             if (rc) {
@@ -1245,37 +1233,9 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.images_device_progressive = device_prog_images;
     p->t.images_host_light = light_images;
     p->t.input_pinned = input_pinned ? 1u : 0u;
-    // the dispatcher's rates, smoothed over calls: a host thread's time per byte of progressive file, the device's walk per byte of the
-    // AVERAGE file of the launch (frames of a call are assumed alike: the walk lasts as long as its longest track)
-    if (prog_host_bytes) {
-        const double r = prog_host_ms * 1e6 / (double)prog_host_bytes;
-        p->prog_host_ns_per_byte = p->prog_host_ns_per_byte > 0 ? 0.5 * (p->prog_host_ns_per_byte + r) : r;
-    }
-    // (a saturated pool that decoded next to nothing else — and only from a call that reused its sub-batches: a call on fresh ones writes
-    // its planes into pinned memory nobody has touched yet, and a rate from there made a 256-frame call look like 41 ms of host work;
-    // the model then chose the device, 33 ms, and never saw the host's 16 ms again: `bench.py --force-dist`, profiles/round5/12_*)
-    if (!fresh_sub_batches && prog_host_images >= 2u * p->pool->size() && (uint64_t)prog_host_images * 10u >= (uint64_t)n_host_images * 9u) {
-        const double r = (t3 - t2) / prog_host_images;
-        // (a box with neighbours gives a call twice its time now and then, never half of it: a sample below the rate replaces it, one
-        // above it moves it by a twentieth at most — one such sample, taken for the rate, made 256 frames look like 37 ms of host work
-        // and the device route, 33 ms, stuck: a call on the device never measures the host again)
-        p->prog_host_ms_per_image = p->prog_host_ms_per_image > 0 ? std::min(r, 1.05 * p->prog_host_ms_per_image) : r;
-        p->prog_host_samples++;
-    }
-    if (device_prog_images && prog_dev_ms > 0) {
-        const double r = prog_dev_ms * 1e6 / ((double)prog_dev_bytes / device_prog_images);
-        p->prog_dev_ns_per_byte = p->prog_dev_ns_per_byte > 0 ? 0.5 * (p->prog_dev_ns_per_byte + r) : r;
-        // (what a frame adds on top of the walk: only from launches of some size — the probe's 64 frames carry the launch's fixed
-        // costs, in a pipeline's first call the allocations too: a figure of 5 ms per frame from there kept 4,096-frame calls on the
-        // host for good, 410-490 ms against 65)
-        if (prog_dev_extra_ms > 0 && device_prog_images >= 512u) {
-            const double o = std::min(prog_dev_extra_ms / device_prog_images, 0.05);
-            p->prog_dev_ms_per_image = p->prog_dev_ms_per_image > 0 ? 0.5 * (p->prog_dev_ms_per_image + o) : o;
-        }
-    }
     if (trace && (prog_host_bytes || device_prog_images))
-        fprintf(stderr, "pipeline trace: progressive frames: %u on the device (walk %.2f ms, launches + range scan + pixels %.2f ms), %u on the host (entropy phase %.2f ms); rates: host %.4f ms per frame (pool), device walk %.1f ns per byte of one file + %.4f ms per frame\n",
-                device_prog_images, prog_dev_ms, prog_dev_extra_ms, prog_host_images, t3 - t2, p->prog_host_ms_per_image, p->prog_dev_ns_per_byte, p->prog_dev_ms_per_image);
+        fprintf(stderr, "pipeline trace: progressive frames: %u on the device (walk %.2f ms, launches + range scan + pixels %.2f ms), %u on the host (entropy phase %.2f ms, %.1f ns per byte and thread)\n",
+                device_prog_images, prog_dev_ms, prog_dev_extra_ms, prog_host_images, t3 - t2, prog_host_bytes ? prog_host_ms * 1e6 / (double)prog_host_bytes : 0.0);
     p->t.cpu_ms = process_cpu_ms() - cpu0;
     (void)t_last_upload;
     return JPGPU_OK;

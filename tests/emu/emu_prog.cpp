@@ -176,6 +176,9 @@ int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], i
 // the C++ twin of the hand-scheduled refinement loop on given states (tests/test_gpu_progw_asm.py compares the device with this)
 void emu_progw_refine_fast(void *cases, uint32_t n) {
     PwFastCase *c = static_cast<PwFastCase *>(cases);
-    for (uint32_t i = 0; i < n; i++) pw_refine_fast_case(c[i]);
+    for (uint32_t i = 0; i < n; i++) {
+        c[i].table = c[i].lut8;
+        pw_refine_fast_case(c[i]);
+    }
 }
 }

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 class Case(C.Structure):
     _fields_ = [("win", C.c_uint64), ("nz", C.c_uint64), ("neg", C.c_uint64), ("new_nz", C.c_uint64), ("new_neg", C.c_uint64),
                 ("pos", C.c_uint32), ("nx", C.c_uint32), ("dp", C.c_uint32), ("k", C.c_uint32), ("end", C.c_uint32), ("al", C.c_uint32),
-                ("eob", C.c_uint32), ("code", C.c_uint32), ("lut6", C.c_uint32 * 64), ("w", C.c_uint32 * 64), ("acc", C.c_uint32 * 64)]
+                ("eob", C.c_uint32), ("code", C.c_uint32), ("lut6", C.c_uint32 * 64), ("w", C.c_uint32 * 64), ("acc", C.c_uint32 * 64),
+                ("lut8", C.c_uint16 * 256), ("table", C.c_void_p)]
 
 
 def _entry(length, extra, run, kind, size=0):
@@ -64,6 +65,11 @@ def _cases(rng, n):
         c.al = int(rng.integers(0, 4))
         c.eob = int(rng.integers(0, 3))
         t = _random_table(rng)
+        for i in range(256):  # the 8-bit lookup behind the holes: codes of 7 / 8 bits (new coefficient, end of band, ZRL, a bad size) or none
+            r = rng.random()
+            length = int(rng.integers(7, 9))
+            sym = (int(rng.integers(0, 16)) << 4 | 1) if r < 0.5 else (int(rng.integers(0, 15)) << 4) if r < 0.7 else 0xF0 if r < 0.8 else (int(rng.integers(0, 16)) << 4 | int(rng.integers(2, 11))) if r < 0.87 else 0
+            c.lut8[i] = (sym | length << 8) if r < 0.87 else 0
         for i in range(64):
             c.lut6[i] = t[i]
             c.w[i] = int(rng.integers(0, 1 << 32)) if rng.random() < 0.9 else 0

@@ -481,9 +481,9 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                 out[key] = e
             except Exception as e:  # noqa: BLE001 (this entry only)
                 out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        # BASELINE configs[3]: benches/tower_progressive.jpg (512 x 512 progressive, 10 scans) x 256 and x 4,096.  Round 5: the scans of a
-        # progressive frame are decoded ON THE DEVICE — one lane per chain of dependent scans, coefficients accumulated in the arena
-        # (csrc/huff_prog_core.hpp) — for as many of a call's frames as finish while the host's threads decode the rest.
+        # BASELINE configs[3]: benches/tower_progressive.jpg (512 x 512 progressive, 10 scans) x 256 and x 4,096: the scans of a
+        # progressive frame are decoded ON THE DEVICE — round 6: one WAVE per scan, coefficients accumulated in the arena
+        # (csrc/huff_prog_wave.hpp) — when the dispatcher's cost model says the device is ahead (csrc/pipeline.cpp).
         tp = os.path.join(B.ROOT, "tests", "golden", "benches", "tower_progressive.jpg")
         if os.path.exists(tp):
             data = open(tp, "rb").read()
@@ -492,9 +492,8 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                 key = f"tower_progressive_{n}"
                 try:
                     files = [data] * n
-                    # (five uncounted calls: the dispatcher's probe, three all-host calls — the last two give it the host's rate —, and the
-                    # first call of the route it then picks)
-                    ts = warm_calls(p, files, 5, cold=5, download=False, device_entropy=True)
+                    # (the route is the dispatcher's cost model — the same from the first call on; one uncounted call allocates)
+                    ts = warm_calls(p, files, 5, cold=1, download=False, device_entropy=True)
                     okp = all(np.array_equal(p.download(i), od.pixels) for i in sorted({0, 1, n // 2, n - 1}))
                     e, med = e2e_entry(n, ts, od.width, od.height, p, okp)
                     e["file"] = "tests/golden/benches/tower_progressive.jpg (the reference's benches/tower_progressive.jpg: 512x512, 10 scans)"
@@ -520,7 +519,7 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                         frames.append(buf.getvalue())
                     n = 4096
                     files = [frames[i % 64] for i in range(n)]
-                    ts = warm_calls(p, files, 5, cold=5, download=False, device_entropy=True)
+                    ts = warm_calls(p, files, 5, cold=1, download=False, device_entropy=True)
                     okd = all(np.array_equal(p.download(i), O.decode(frames[i % 64]).pixels) for i in (0, 1, 63, n // 2 + 7, n - 1))
                     e, med = e2e_entry(n, ts, 512, 512, p, okd)
                     e["input"] = "64 distinct 512x512 4:4:4 progressive frames (Pillow / libjpeg-turbo, quality 85, default script: 10 scans), repeated"
