@@ -946,6 +946,31 @@ __global__ __launch_bounds__(64) void progw_refine_fast_case_kernel(PwFastCase *
         g->win = c.win, g->pos = c.pos, g->nx = c.nx, g->dp = c.dp, g->k = c.k, g->eob = c.eob, g->new_nz = c.new_nz, g->new_neg = c.new_neg, g->code = c.code;
     }
 }
+__global__ __launch_bounds__(64) void progw_first_fast_case_kernel(PwFirstCase *cases, uint32_t n) {
+    if (blockIdx.x >= n) return;
+    PwFirstCase *g = cases + blockIdx.x;
+    PwFirstCase c;
+    c.win = g->win, c.nz = g->nz, c.neg = g->neg, c.pos = g->pos, c.nx = g->nx, c.dp = g->dp, c.k = g->k, c.se = g->se, c.al = g->al, c.eob = g->eob, c.code = 0u;
+    const uint32_t lane = threadIdx.x;
+    c.lut6[lane] = g->lut6[lane], c.w[lane] = g->w[lane], c.cf[lane] = g->cf[lane];
+    c.table = g->lut8;
+    pw_first_fast_case(c);
+    g->cf[lane] = c.cf[lane];
+    if (lane == 0u) g->win = c.win, g->pos = c.pos, g->nx = c.nx, g->dp = c.dp, g->k = c.k, g->eob = c.eob, g->nz = c.nz, g->neg = c.neg, g->code = c.code;
+}
+extern "C" int jpgpu_selftest_first_fast(void *host_cases, uint32_t n) {
+    PwFirstCase *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * sizeof(PwFirstCase)) != hipSuccess) return 1;
+    int rc = 0;
+    if (hipMemcpy(d, host_cases, (size_t)n * sizeof(PwFirstCase), hipMemcpyHostToDevice) != hipSuccess) rc = 2;
+    if (!rc) {
+        progw_first_fast_case_kernel<<<dim3(n), dim3(64)>>>(d, n);
+        if (hipDeviceSynchronize() != hipSuccess) rc = 3;
+    }
+    if (!rc && hipMemcpy(host_cases, d, (size_t)n * sizeof(PwFirstCase), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
+    (void)hipFree(d);
+    return rc;
+}
 // (timing: the same state walked `reps` times by one wave; -> milliseconds for the lot)
 __global__ __launch_bounds__(64) void progw_refine_fast_bench_kernel(PwFastCase *cases, uint32_t reps) {
     PwFastCase *g = cases;

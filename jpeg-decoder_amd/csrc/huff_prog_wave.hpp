@@ -69,6 +69,8 @@ __device__ __forceinline__ uint32_t wv_uniform(uint32_t x) { return (uint32_t)__
 __device__ __forceinline__ void wv_sleep() { __builtin_amdgcn_s_sleep(32); }  // ~2k cycles
 #endif
 
+__device__ __forceinline__ uint64_t wv_uniform64(uint64_t x) { return ((uint64_t)wv_uniform((uint32_t)(x >> 32)) << 32) | wv_uniform((uint32_t)x); }
+
 // ---- memory operations other waves must see: agent scope (past this XCD's L2 where another XCD may look) ----------------------------
 // EVERY access to memory that two waves share — coefficients, masks, progress words, status — is an agent-scope atomic (sc1: stores and
 // read-modify-writes go through to the point where the agent's XCDs agree, loads come from there); nothing shared is ever read or
@@ -472,6 +474,257 @@ __device__ __forceinline__ void pw_walk_advance(PwWalk &w, uint32_t n) {
     while (w.mx >= w.cols) w.mx -= w.cols, w.row++;
 }
 
+// the state of an AC first scan inside a block
+struct PwFirstBlock {
+    uint32_t k, eob_run, err;
+    uint64_t nz, neg;
+};
+// ONE symbol of an AC first scan's block, in portable C++ (the hand-scheduled loop below hands back what it does not take itself);
+// the block is through when B.k > se
+__device__ __forceinline__ void pw_first_symbol(PwBits &b, const PwTable &tab, WV32 &cf, PwFirstBlock &B, uint32_t se, uint32_t al) {
+    PW_NEED32(b);
+    const uint32_t look = pw_look(b), e = pw_symbol(tab, look);
+    const uint32_t len = pw_e_len(e), nb = pw_e_extra(e), kind = pw_e_kind(e);
+    const uint32_t bits = pw_field(look, len, nb);  // the magnitude bits of a coefficient / the low bits of an end-of-band run
+    pw_consume(b, len + nb);
+    const uint32_t k = B.k + pw_e_run(e);  // (ZRL: 16; an end-of-band symbol: 0)
+    if (__builtin_expect(kind != PW_KIND_COEF, 0)) {
+        if (kind == PW_KIND_ZRL) {
+            B.k = k;
+            return;
+        }
+        if (kind == PW_KIND_EOB) B.eob_run = (1u << nb) - 1u + bits;
+        else B.err = PROG_ST_BAD_CODE;
+        B.k = se + 1u;
+        return;
+    }
+    // a run that leaves the band: what the reference then does with the magnitude bits depends on its table layout
+    // (frontend.cpp, decode_block) — the host's business; so is a magnitude that could make a later correction carry
+    if (__builtin_expect(k > se || nb + al > 14u, 0)) {
+        B.err = k > se ? PROG_ST_BAND : PROG_ST_RANGE;
+        B.k = se + 1u;
+        return;
+    }
+    const int32_t v = pw_extend(bits, nb);
+    wv_writelane(cf, k, ((uint32_t)v << al) & 0xffffu);
+    B.nz |= 1ull << k;
+    B.neg |= (uint64_t)((uint32_t)v >> 31) << k;
+    B.k = k + 1u;
+}
+#if defined(JPGPU_HOST_EMULATION) && !defined(PROGW_PORTABLE)
+// tests/emu: the hand-scheduled loop below in C++ (-> 0: the block is through, 1: the next symbol is the portable path's, 2: the window is used up)
+static inline uint32_t pw_first_fast(PwBits &b, const PwTable &tab, WV32 &cf, PwFirstBlock &B, uint32_t se, uint32_t al) {
+    for (;;) {
+        if (b.pos < 32u) {
+            if (b.dp == 64u) return 2u;
+            b.win |= (uint64_t)b.nx << (32u - b.pos);
+            b.pos += 32u;
+            b.nx = wv_readlane(b.w, b.dp);
+            b.dp++;
+        }
+        const uint32_t hi = (uint32_t)(b.win >> 32), e = wv_readlane(tab.lut6, hi >> 26);
+        uint32_t len = e & 31u, nb = (e >> 5) & 31u, kind = (e >> 17) & 3u, run = (e >> 10) & 127u;
+        if (len == 0u) {  // codes of seven and eight bits, from the 8-bit lookup in memory
+            const uint32_t idx8 = hi >> 24, e8 = (reinterpret_cast<const JP_CONST uint32_t *>(tab.g->lut)[idx8 >> 1] >> (16u * (idx8 & 1u))) & 0xffffu;
+            len = e8 >> 8;
+            if (len == 0u) return 1u;
+            const uint32_t sz = e8 & 15u, r = (e8 >> 4) & 15u;
+            if (sz) nb = sz, kind = 0u, run = r;
+            else if (r == 15u) nb = 0u, kind = 2u, run = 16u;
+            else nb = r, kind = 1u, run = 0u;
+        }
+        const uint32_t bits = ((hi << len) >> 1) >> (31u - nb), cons = len + nb, k2 = B.k + run;
+        if (kind == 0u) {
+            if (k2 > se || nb + al > 14u) return 1u;
+            b.win <<= cons, b.pos -= cons;
+            PROGW_COUNT(symbols, 1);
+            const bool negative = bits < (1u << (nb - 1u));
+            const uint32_t v = negative ? bits + (0xffffffffu << nb) + 1u : bits, val = (v << al) & 0xffffu;
+            WV_EACH {
+                if (lane == k2) WV(cf) = val;
+            }
+            B.nz |= 1ull << k2;
+            if (negative) B.neg |= 1ull << k2;
+            B.k = k2 + 1u;
+            if (!(B.k <= se)) return 0u;
+            continue;
+        }
+        if (kind == 3u) return 1u;
+        b.win <<= cons, b.pos -= cons;
+        PROGW_COUNT(symbols, 1);
+        if (kind == 2u) {
+            B.k = k2;
+            if (!(B.k <= se)) return 0u;
+            continue;
+        }
+        B.eob_run = (1u << nb) + bits - 1u;
+        B.k = se + 1u;
+        return 0u;
+    }
+}
+#endif
+#if !defined(JPGPU_HOST_EMULATION) && !defined(PROGW_PORTABLE)
+// The symbols of an AC first scan's block, as many in a row as go without help, hand-scheduled (gfx950) like pw_refine_fast below.
+// s[40:41] window, s42 valid bits, s43 next dword, s44 its successor's lane, s45 k, s[46:47] / s[48:49] non-zero / negative, s54 se,
+// s55 al, s57 end-of-band run, s[82:83] the table's 8-bit lookup in memory, s58 -> 0: the block is through (k > se), 1: the next symbol is
+// the portable path's (a code of nine bits and more, a run that leaves the band, a bad symbol), 2: the window is used up.
+__device__ __forceinline__ uint32_t pw_first_fast(PwBits &b, const PwTable &tab, WV32 &cf, PwFirstBlock &B, uint32_t se, uint32_t al) {
+    uint32_t code, t0;
+    // (every scalar the loop takes or gives back: into scalar registers by hand — the compiler keeps some of them in vector registers
+    // although every lane holds the same, and "s" then fails with "illegal VGPR to SGPR copy"; a no-op where the value is scalar already)
+    const uint32_t se_s = wv_uniform(se), al_s = wv_uniform(al);
+    const uint64_t lut8_s = wv_uniform64((uint64_t)(uintptr_t)(const void *)tab.g->lut);
+    uint64_t win = wv_uniform64(b.win), nz = wv_uniform64(B.nz), neg = wv_uniform64(B.neg);
+    uint32_t pos = wv_uniform(b.pos), nx = wv_uniform(b.nx), dp = wv_uniform(b.dp), k = wv_uniform(B.k), eob = wv_uniform(B.eob_run);
+    asm volatile(
+        "s_mov_b64 s[40:41], %[win]\n s_mov_b32 s42, %[pos]\n s_mov_b32 s43, %[nx]\n s_mov_b32 s44, %[dp]\n s_mov_b32 s45, %[k]\n"
+        "s_mov_b64 s[46:47], %[nz]\n s_mov_b64 s[48:49], %[neg]\n s_mov_b32 s54, %[se]\n s_mov_b32 s55, %[al]\n s_mov_b32 s57, %[eob]\n s_mov_b64 s[82:83], %[lut8]\n"
+        "Ltop%=:\n"
+        "s_cmp_lt_u32 s42, 32\n"
+        "s_cbranch_scc1 Lrefill%=\n"
+        "Lsym%=:\n"
+        "s_lshr_b32 s60, s41, 26\n"
+        "v_readlane_b32 s61, %[lut], s60\n"
+        "s_and_b32 s62, s61, 31\n"                  // code length; SCC = (length != 0)
+        "s_cbranch_scc0 Lsecond%=\n"
+        "s_bfe_u32 s63, s61, 0x50005\n"             // extra bits
+        "s_bfe_u32 s64, s61, 0x20011\n"             // kind
+        "s_bfe_u32 s65, s61, 0x7000a\n"             // run (ZRL: 16, end of band: 0)
+        "Lhave%=:\n"
+        "s_lshl_b32 s66, s41, s62\n"
+        "s_lshr_b32 s66, s66, 1\n"
+        "s_sub_u32 s67, 31, s63\n"
+        "s_lshr_b32 s66, s66, s67\n"                // the extra bits' value
+        "s_add_u32 s67, s62, s63\n"                 // bits the symbol takes
+        "s_add_u32 s68, s45, s65\n"                 // k + run
+        "s_cmp_lg_u32 s64, 0\n"
+        "s_cbranch_scc1 Lother%=\n"
+        "s_cmp_gt_u32 s68, s54\n"                   // a run that leaves the band: the portable path (and the host's business)
+        "s_cbranch_scc1 Lgeneric%=\n"
+        "s_add_u32 s69, s63, s55\n"
+        "s_cmp_gt_u32 s69, 14\n"                    // a magnitude that could make a later correction carry: likewise
+        "s_cbranch_scc1 Lgeneric%=\n"
+        "s_lshl_b64 s[40:41], s[40:41], s67\n"
+        "s_sub_u32 s42, s42, s67\n"
+        "s_sub_u32 s69, s63, 1\n"
+        "s_lshl_b32 s69, 1, s69\n"                  // 1 << (size - 1): below it the value is negative (src/huffman.rs:165-173)
+        "s_lshl_b32 s70, -1, s63\n"
+        "s_add_u32 s70, s70, 1\n"
+        "s_add_u32 s70, s66, s70\n"
+        "s_lshl_b64 s[72:73], 1, s68\n"             // the coefficient's position as a lane mask
+        "s_cmp_lt_u32 s66, s69\n"
+        "s_cselect_b32 s70, s70, s66\n"
+        "s_cselect_b64 s[74:75], s[72:73], 0\n"
+        "s_lshl_b32 s70, s70, s55\n"
+        "s_and_b32 s70, s70, 0xffff\n"
+        "v_mov_b32_e32 %[t0], s70\n"
+        "s_or_b64 s[46:47], s[46:47], s[72:73]\n"
+        "s_or_b64 s[48:49], s[48:49], s[74:75]\n"
+        "v_cndmask_b32_e64 %[cf], %[cf], %[t0], s[72:73]\n"
+        "s_add_u32 s45, s68, 1\n"
+        "s_cmp_le_u32 s45, s54\n"
+        "s_cbranch_scc1 Ltop%=\n"
+        "s_mov_b32 s58, 0\n"
+        "s_branch Lend%=\n"
+        "Lother%=:\n"
+        "s_cmp_eq_u32 s64, 3\n"
+        "s_cbranch_scc1 Lgeneric%=\n"
+        "s_lshl_b64 s[40:41], s[40:41], s67\n"
+        "s_sub_u32 s42, s42, s67\n"
+        "s_cmp_eq_u32 s64, 2\n"
+        "s_cbranch_scc0 Leob%=\n"
+        "s_mov_b32 s45, s68\n"                      // ZRL: sixteen zeros
+        "s_cmp_le_u32 s45, s54\n"
+        "s_cbranch_scc1 Ltop%=\n"
+        "s_mov_b32 s58, 0\n"
+        "s_branch Lend%=\n"
+        "Leob%=:\n"
+        "s_lshl_b32 s57, 1, s63\n"                  // end of band: (1 << extra) - 1 + bits more blocks hold nothing of this band
+        "s_add_u32 s57, s57, s66\n"
+        "s_sub_u32 s57, s57, 1\n"
+        "s_add_u32 s45, s54, 1\n"
+        "s_mov_b32 s58, 0\n"
+        "s_branch Lend%=\n"
+        "Lrefill%=:\n"
+        "s_cmp_eq_u32 s44, 64\n"
+        "s_cbranch_scc1 Lwindow%=\n"
+        "s_sub_u32 s60, 32, s42\n"
+        "s_mov_b32 s62, s43\n"
+        "s_mov_b32 s63, 0\n"
+        "s_lshl_b64 s[62:63], s[62:63], s60\n"
+        "s_or_b64 s[40:41], s[40:41], s[62:63]\n"
+        "s_add_u32 s42, s42, 32\n"
+        "v_readlane_b32 s43, %[w], s44\n"
+        "s_add_u32 s44, s44, 1\n"
+        "s_branch Lsym%=\n"
+        "Lsecond%=:\n"                              // a code of seven or eight bits: the 8-bit lookup in memory, through the scalar cache
+        "s_lshr_b32 s60, s41, 24\n"
+        "s_lshr_b32 s84, s60, 1\n"
+        "s_lshl_b32 s84, s84, 2\n"
+        "s_load_dword s85, s[82:83], s84\n"
+        "s_and_b32 s60, s60, 1\n"
+        "s_lshl_b32 s60, s60, 4\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_lshr_b32 s85, s85, s60\n"
+        "s_and_b32 s85, s85, 0xffff\n"              // symbol | length << 8
+        "s_lshr_b32 s62, s85, 8\n"                  // SCC = (length != 0)
+        "s_cbranch_scc0 Lgeneric%=\n"               // longer still: the portable path's walk
+        "s_bfe_u32 s65, s85, 0x40004\n"             // run
+        "s_and_b32 s63, s85, 15\n"                  // size; SCC = (size != 0)
+        "s_cbranch_scc0 Lsecond0%=\n"
+        "s_mov_b32 s64, 0\n"                        // a coefficient: `size` magnitude bits behind `run` zeros
+        "s_branch Lhave%=\n"
+        "Lsecond0%=:\n"
+        "s_cmp_eq_u32 s65, 15\n"
+        "s_cbranch_scc0 Lsecond1%=\n"
+        "s_mov_b32 s64, 2\n"                        // ZRL
+        "s_mov_b32 s65, 16\n"
+        "s_branch Lhave%=\n"
+        "Lsecond1%=:\n"
+        "s_mov_b32 s63, s65\n"                      // end of band: `run` low bits of the run of blocks
+        "s_mov_b32 s64, 1\n"
+        "s_mov_b32 s65, 0\n"
+        "s_branch Lhave%=\n"
+        "Lgeneric%=:\n"
+        "s_mov_b32 s58, 1\n"
+        "s_branch Lend%=\n"
+        "Lwindow%=:\n"
+        "s_mov_b32 s58, 2\n"
+        "Lend%=:\n"
+        "s_mov_b64 %[win], s[40:41]\n s_mov_b32 %[pos], s42\n s_mov_b32 %[nx], s43\n s_mov_b32 %[dp], s44\n s_mov_b32 %[k], s45\n"
+        "s_mov_b64 %[nz], s[46:47]\n s_mov_b64 %[neg], s[48:49]\n s_mov_b32 %[eob], s57\n s_mov_b32 %[code], s58\n"
+        : [win] "+s"(win), [pos] "+s"(pos), [nx] "+s"(nx), [dp] "+s"(dp), [k] "+s"(k), [nz] "+s"(nz), [neg] "+s"(neg), [eob] "+s"(eob),
+          [code] "=s"(code), [cf] "+v"(cf), [t0] "=&v"(t0)
+        : [se] "s"(se_s), [al] "s"(al_s), [lut8] "s"(lut8_s), [lut] "v"(tab.lut6), [w] "v"(b.w)
+        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s54", "s55", "s57", "s58", "s60", "s61", "s62", "s63", "s64", "s65",
+          "s66", "s67", "s68", "s69", "s70", "s72", "s73", "s74", "s75", "s82", "s83", "s84", "s85");
+    b.win = win, b.pos = pos, b.nx = nx, b.dp = dp, B.k = k, B.nz = nz, B.neg = neg, B.eob_run = eob;
+    return code;
+}
+#endif
+#if !defined(PROGW_PORTABLE)
+// One call of pw_first_fast on a given state (tests: the device against the C++ twin)
+struct PwFirstCase {
+    uint64_t win, nz, neg;
+    uint32_t pos, nx, dp, k, se, al, eob, code;
+    uint32_t lut6[64], w[64], cf[64];
+    uint16_t lut8[256];
+    const void *table;
+};
+__device__ inline void pw_first_fast_case(PwFirstCase &c) {
+    PwBits b;
+    PwTable tab;
+    PwFirstBlock B{c.k, c.eob, 0u, c.nz, c.neg};
+    WV32 cf;
+    b.win = c.win, b.pos = c.pos, b.nx = c.nx, b.dp = c.dp, b.base = 0u, b.src = nullptr, b.n_dwords = 0u;
+    tab.g = (const JP_CONST ProgHuffTable *)c.table, tab.mode = 0u;
+    WV_EACH { WV(b.w) = c.w[lane], WV(tab.lut6) = c.lut6[lane], WV(cf) = c.cf[lane]; }
+    const uint32_t code = pw_first_fast(b, tab, cf, B, c.se, c.al);
+    WV_EACH { c.cf[lane] = WV(cf); }
+    c.win = b.win, c.pos = b.pos, c.nx = b.nx, c.dp = b.dp, c.k = B.k, c.eob = B.eob_run, c.nz = B.nz, c.neg = B.neg, c.code = code;
+}
+#endif
+
 // AC first scan (ah == 0; src/decoder.rs:1128-1172)
 __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *status, PwSync &y) {
     PwBits b;
@@ -480,8 +733,9 @@ __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *s
     pw_table_load(tab, s.table[0], 0u);
     int16_t *const coefs = s.comp[0].coefs;
     uint64_t *const masks = s.comp[0].masks;
-    const uint32_t block_w = s.comp[0].block_w, cols = s.cols, total = s.rows * s.cols, ss = s.ss, se = s.se, al = s.al;
-    uint32_t eob_run = 0, err = 0;
+    // (into scalar registers by hand: byte loads are vector loads, and the hand-scheduled loop takes its state in SGPRs)
+    const uint32_t block_w = s.comp[0].block_w, cols = s.cols, total = s.rows * s.cols, ss = wv_uniform(s.ss), se = wv_uniform(s.se), al = wv_uniform(s.al);
+    uint32_t eob_run = 0;
     PwWalk at;
     pw_walk_open(at, cols, block_w);
     WV32 cf, unz;
@@ -501,40 +755,28 @@ __device__ inline bool pw_scan_ac_first(const JP_GLOBAL ProgScan &s, uint32_t *s
                 continue;
             }
             PROGW_COUNT(blocks, 1);
-            uint64_t nz = 0, neg = 0;
-            uint32_t k = ss;
-            do {
-                PW_NEED32(b);
-                const uint32_t look = pw_look(b), e = pw_symbol(tab, look);
-                const uint32_t len = pw_e_len(e), nb = pw_e_extra(e), kind = pw_e_kind(e);
-                const uint32_t bits = pw_field(look, len, nb);  // the magnitude bits of a coefficient / the low bits of an end-of-band run
-                pw_consume(b, len + nb);
-                k += pw_e_run(e);  // (ZRL: 16; an end-of-band symbol: 0)
-                if (__builtin_expect(kind != PW_KIND_COEF, 0)) {
-                    if (kind == PW_KIND_ZRL) continue;
-                    if (kind == PW_KIND_EOB) {
-                        eob_run = (1u << nb) - 1u + bits;
-                        break;
-                    }
-                    err = PROG_ST_BAD_CODE;
-                    break;
+            PwFirstBlock B{ss, 0u, 0u, 0ull, 0ull};
+#if !defined(PROGW_PORTABLE)
+            for (;;) {
+                const uint32_t code = pw_first_fast(b, tab, cf, B, se, al);
+                if (code == 0u) break;
+                if (code == 2u) {
+                    pw_refill(b);  // (into the next window)
+                    continue;
                 }
-                // a run that leaves the band: what the reference then does with the magnitude bits depends on its table layout
-                // (frontend.cpp, decode_block) — the host's business; so is a magnitude that could make a later correction carry
-                if (__builtin_expect(k > se || nb + al > 14u, 0)) {
-                    err = k > se ? PROG_ST_BAND : PROG_ST_RANGE;
-                    break;
-                }
-                const int32_t v = pw_extend(bits, nb);
-                wv_writelane(cf, k, ((uint32_t)v << al) & 0xffffu);
-                nz |= 1ull << k;
-                neg |= (uint64_t)((uint32_t)v >> 31) << k;
-                k++;
-            } while (k <= se);
-            if (__builtin_expect(err != 0u, 0)) {
-                pw_flag(status, err);
+                pw_first_symbol(b, tab, cf, B, se, al);
+                if (B.k > se) break;
+            }
+#else
+            do pw_first_symbol(b, tab, cf, B, se, al);
+            while (B.k <= se);
+#endif
+            if (__builtin_expect(B.err != 0u, 0)) {
+                pw_flag(status, B.err);
                 return false;
             }
+            eob_run = B.eob_run;
+            const uint64_t nz = B.nz, neg = B.neg;
             if (nz) {
                 const size_t blk = pw_walk_block(at);
                 WV_EACH {
@@ -738,9 +980,9 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
     // (values the compiler keeps in vector registers although every lane holds the same: into scalar ones, or "s" gets a VGPR)
     const uint32_t pbit = wv_uniform(R.bit), nbit = wv_uniform(0u - R.bit), end_s = wv_uniform(end);
     const uint64_t bend_s = ((uint64_t)wv_uniform((uint32_t)(below_end >> 32)) << 32) | wv_uniform((uint32_t)below_end);
-    const uint64_t nz_s = ((uint64_t)wv_uniform((uint32_t)(R.nz >> 32)) << 32) | wv_uniform((uint32_t)R.nz);
-    const uint64_t lut8_a = (uint64_t)(uintptr_t)(const void *)tab.g->lut;
-    const uint64_t lut8_s = ((uint64_t)wv_uniform((uint32_t)(lut8_a >> 32)) << 32) | wv_uniform((uint32_t)lut8_a);
+    const uint64_t nz_s = wv_uniform64(R.nz), lut8_s = wv_uniform64((uint64_t)(uintptr_t)(const void *)tab.g->lut);
+    uint64_t win = wv_uniform64(R.b.win), nnz = wv_uniform64(B.new_nz), nneg = wv_uniform64(B.new_neg);
+    uint32_t pos = wv_uniform(R.b.pos), nx = wv_uniform(R.b.nx), dp = wv_uniform(R.b.dp), k = wv_uniform(B.k), eob = wv_uniform(B.eob_run);
 #ifdef PROGW_ASM_NOPS
 #define PW_NOP "s_nop 3\n"
 #else
@@ -898,11 +1140,12 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "Lend%=:\n"
         "s_mov_b64 %[win], s[40:41]\n s_mov_b32 %[pos], s42\n s_mov_b32 %[nx], s43\n s_mov_b32 %[dp], s44\n s_mov_b32 %[k], s45\n"
         "s_mov_b64 %[nnz], s[46:47]\n s_mov_b64 %[nneg], s[48:49]\n s_mov_b32 %[eob], s57\n s_mov_b32 %[code], s58\n"
-        : [win] "+s"(R.b.win), [pos] "+s"(R.b.pos), [nx] "+s"(R.b.nx), [dp] "+s"(R.b.dp), [k] "+s"(B.k), [nnz] "+s"(B.new_nz), [nneg] "+s"(B.new_neg),
-          [eob] "+s"(B.eob_run), [code] "=s"(code), [acc] "+v"(R.acc), [t0] "=&v"(t0)
+        : [win] "+s"(win), [pos] "+s"(pos), [nx] "+s"(nx), [dp] "+s"(dp), [k] "+s"(k), [nnz] "+s"(nnz), [nneg] "+s"(nneg),
+          [eob] "+s"(eob), [code] "=s"(code), [acc] "+v"(R.acc), [t0] "=&v"(t0)
         : [nz] "s"(nz_s), [bend] "s"(bend_s), [end] "s"(end_s), [pbit] "s"(pbit), [nbit] "s"(nbit), [lut8] "s"(lut8_s), [lut] "v"(tab.lut6), [w] "v"(R.b.w), [delta] "v"(delta)
         : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
           "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85");
+    R.b.win = win, R.b.pos = pos, R.b.nx = nx, R.b.dp = dp, B.k = k, B.new_nz = nnz, B.new_neg = nneg, B.eob_run = eob;
     return code;
 }
 #endif

@@ -181,4 +181,11 @@ void emu_progw_refine_fast(void *cases, uint32_t n) {
         pw_refine_fast_case(c[i]);
     }
 }
+void emu_progw_first_fast(void *cases, uint32_t n) {
+    PwFirstCase *c = static_cast<PwFirstCase *>(cases);
+    for (uint32_t i = 0; i < n; i++) {
+        c[i].table = c[i].lut8;
+        pw_first_fast_case(c[i]);
+    }
+}
 }

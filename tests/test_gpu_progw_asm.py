@@ -109,3 +109,81 @@ def test_hand_scheduled_refinement_loop_equals_its_twin(seed):
         lanes = [(l, hex(x.acc[l]), hex(y.acc[l])) for l in range(64) if x.acc[l] != y.acc[l]]
         raise AssertionError(f"{len(bad)} of {n} states differ; case {i}: twin vs device {msg}, lanes {lanes[:8]}")
     assert min(codes) > 50, codes  # all three exits were taken
+
+
+# ---- the AC first scans' loop (pw_first_fast) --------------------------------------------------------------------------------------------
+class FirstCase(C.Structure):
+    _fields_ = [("win", C.c_uint64), ("nz", C.c_uint64), ("neg", C.c_uint64),
+                ("pos", C.c_uint32), ("nx", C.c_uint32), ("dp", C.c_uint32), ("k", C.c_uint32), ("se", C.c_uint32), ("al", C.c_uint32),
+                ("eob", C.c_uint32), ("code", C.c_uint32), ("lut6", C.c_uint32 * 64), ("w", C.c_uint32 * 64), ("cf", C.c_uint32 * 64),
+                ("lut8", C.c_uint16 * 256), ("table", C.c_void_p)]
+
+
+def _first_cases(rng, n):
+    arr = (FirstCase * n)()
+    for c in arr:
+        c.pos = int(rng.integers(0, 64))
+        win = int(rng.integers(0, 1 << 63)) << 1 | int(rng.integers(0, 2))
+        c.win = (win >> (64 - c.pos)) << (64 - c.pos) if c.pos else 0
+        c.nx = int(rng.integers(0, 1 << 32))
+        c.dp = int(rng.choice([1, 2, 17, 40, 62, 63, 64, 64]))
+        c.se = int(rng.choice([63, 63, 63, 5, 1, 32]))
+        c.k = int(rng.integers(1, c.se + 1))
+        c.al = int(rng.integers(0, 5))
+        c.eob = 0
+        c.nz = int(rng.integers(0, 1 << 63)) & ((1 << c.k) - 2)
+        c.neg = c.nz & int(rng.integers(0, 1 << 63))
+        for i in range(64):
+            r = rng.random()
+            length = int(rng.integers(1, 7))
+            if r < 0.6:     # a coefficient: size 1..12 (some too large for al: the portable path), run 0..15
+                size = int(rng.integers(1, 13)) if rng.random() < 0.2 else int(rng.integers(1, 5))
+                c.lut6[i] = _entry(length, size, int(rng.integers(0, 16)) if rng.random() < 0.4 else 0, 0, size)
+            elif r < 0.75:  # end of band
+                e = int(rng.integers(0, 15))
+                c.lut6[i] = _entry(length, e, 0, 1, e)
+            elif r < 0.85:  # ZRL
+                c.lut6[i] = _entry(length, 0, 16, 2)
+            elif r < 0.95:
+                c.lut6[i] = 0
+            else:
+                c.lut6[i] = _entry(length, 0, 0, 3)
+            c.w[i] = int(rng.integers(0, 1 << 32)) if rng.random() < 0.9 else 0
+            c.cf[i] = int(rng.integers(0, 1 << 16)) if (c.nz >> i) & 1 else 0
+        for i in range(256):
+            r = rng.random()
+            length = int(rng.integers(7, 9))
+            sym = (int(rng.integers(0, 16)) << 4 | int(rng.integers(1, 11))) if r < 0.55 else (int(rng.integers(0, 15)) << 4) if r < 0.75 else 0xF0
+            c.lut8[i] = (sym | length << 8) if r < 0.87 else 0
+    return arr
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hand_scheduled_first_scan_loop_equals_its_twin(seed):
+    import emu
+    import jpeg_decoder_amd as J
+    assert J.device_count() >= 1
+    dev = C.CDLL(J._native.LIB_PATH)
+    dev.jpgpu_selftest_first_fast.argtypes = [C.c_void_p, C.c_uint32]
+    cpu = emu.lib()
+    cpu.emu_progw_first_fast.argtypes = [C.c_void_p, C.c_uint32]
+    cpu.emu_progw_first_fast.restype = None
+    rng = np.random.default_rng(9300 + seed)
+    n = 4096
+    a = _first_cases(rng, n)
+    b = (FirstCase * n)()
+    C.memmove(b, a, C.sizeof(a))
+    cpu.emu_progw_first_fast(C.byref(a), n)
+    assert dev.jpgpu_selftest_first_fast(C.byref(b), n) == 0
+    fields = ("win", "pos", "nx", "dp", "k", "nz", "neg", "eob", "code")
+    bad = [i for i in range(n) if any(getattr(a[i], f) != getattr(b[i], f) for f in fields) or list(a[i].cf) != list(b[i].cf)]
+    codes = [0, 0, 0]
+    for x in a:
+        codes[x.code] += 1
+    if bad:
+        i = bad[0]
+        x, y = a[i], b[i]
+        msg = {f: (hex(getattr(x, f)), hex(getattr(y, f))) for f in fields if getattr(x, f) != getattr(y, f)}
+        lanes = [(l, hex(x.cf[l]), hex(y.cf[l])) for l in range(64) if x.cf[l] != y.cf[l]]
+        raise AssertionError(f"{len(bad)} of {n} states differ; case {i}: twin vs device {msg}, lanes {lanes[:8]}")
+    assert min(codes) > 50, codes
