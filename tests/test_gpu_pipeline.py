@@ -692,6 +692,36 @@ def test_pipeline_progressive_dispatcher_takes_the_same_route_every_time(monkeyp
     p.close()
 
 
+def test_pipeline_progressive_split_band_and_random_scan_scripts(monkeypatch):
+    """scripts that refine the parts of a band separately make TWO scans of a frame work on the same blocks' mask words
+    at the same time on the device (Y 1-5 refinement beside the first scan of Y 6-63 ...).  Frames written by tools/progressive_encoder.py
+    with such scripts and with randomly cut / randomly ordered ones, hundreds per call so that their waves do run side by side: the
+    oracle's pixels, every frame, on the device route."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import progressive_encoder as P
+    import synth
+    monkeypatch.setenv("JPGPU_PIPE_PROG_DEVICE_PERCENT", "100")
+    rng = np.random.default_rng(8800)
+    distinct = []
+    for k, (w, h, samp, script) in enumerate([(256, 192, "444", P.SPLIT_REFINEMENT_YCC), (250, 130, "420", P.SPLIT_REFINEMENT_YCC), (160, 120, "gray", P.SPLIT_REFINEMENT_GRAY),
+                                              (200, 136, "422", P.SPLIT_REFINEMENT_YCC)] +
+                                             [(96 + 16 * t, 64 + 8 * t, ("444", "420", "422", "gray")[t % 4], None) for t in range(8)]):
+        if script is None:
+            script = P.random_script(rng, 1 if samp == "gray" else 3)
+        distinct.append(P.encode_rgb(synth.synthetic_rgb(w, h, seed=40 + k), script, quality=70 + 2 * k, sampling=samp))
+    want = [O.decode(d).pixels for d in distinct]
+    files = [distinct[i % len(distinct)] for i in range(384)]
+    p = J.Pipeline(threads=8)
+    for _rep in range(2):
+        out = p.decode(files, device_entropy=True)
+        t = p.timings()
+        assert t["images_device_progressive"] == len(files), t["images_device_progressive"]
+        for i, got in enumerate(out):
+            assert not isinstance(got, Exception) and np.array_equal(got, want[i % len(distinct)]), i
+    p.close()
+
+
 def test_pipeline_progressive_device_decoder_hands_damaged_frames_back(monkeypatch):
     """Damaged progressive streams through the device route: whatever the planner lets through and the walk does not flag must be the
     oracle's pixels; everything else is decoded by the host (same pixels / same kind of error as the oracle)."""

@@ -238,3 +238,47 @@ def test_prog_table_is_the_reference_procedure():
     import re
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jpeg-decoder_amd", "csrc", "huff_prog_job.hpp")).read()
     assert re.search(r"sizeof\(ProgHuffTable\) == 912", text)
+
+
+# ---- scan scripts no Pillow writes (tools/progressive_encoder.py: what `jpegtran -scans` would make) ------------------------------------
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _scripted(w, h, sampling, script, quality=85, seed=3):
+    import progressive_encoder as P
+    return P.encode_rgb(synth.synthetic_rgb(w, h, seed=seed), script, quality=quality, sampling=sampling)
+
+
+@pytest.mark.parametrize("order", [0, 2, 3, 4, 5], ids=["tracks-in-order", "scan-by-scan-round-robin", "a-lane-per-scan", "a-WAVE-per-scan", "a-wave-per-track"])
+def test_split_band_refinement_scripts(order):
+    """a mask word covers all 63 AC positions of a block, a scan only its band — with Y 1-5 | Y 6-63 | refine 1-5 |
+    refine 6-63 the refinement of one band runs beside the first scan of the other on the same blocks (the device publishes its mask
+    bits with atomic ORs; here the walks run one after the other and must agree with the host whatever the order)."""
+    import progressive_encoder as P
+    for w, h, samp, script in ((96, 64, "444", P.SPLIT_REFINEMENT_YCC), (120, 72, "420", P.SPLIT_REFINEMENT_YCC), (77, 53, "gray", P.SPLIT_REFINEMENT_GRAY),
+                               (250, 130, "422", P.SPLIT_REFINEMENT_YCC)):
+        ns, nt = _same_as_host(_scripted(w, h, samp, script), order)
+        assert ns == len(script) and nt >= 3
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scan_scripts(seed):
+    """Bands cut at random places, refinements in random order between the scans of other bands and components, DC interleaved or
+    per component: every legal script decodes to the host's planes on every walk."""
+    import progressive_encoder as P
+    rng = np.random.default_rng(4200 + seed)
+    for t in range(6):
+        nc = 1 if (seed + t) % 4 == 0 else 3
+        samp = "gray" if nc == 1 else ("444", "420", "422")[t % 3]
+        script = P.random_script(rng, nc)
+        data = _scripted(40 + 9 * t + seed, 33 + 7 * t, samp, script, quality=50 + 6 * t, seed=seed * 10 + t)
+        for order in (0, 3, 4, 5):
+            got = _device(data, order)
+            if order == 3 and got is not None and got[0] == -2:  # (more than three producers for one scan: walked as tracks)
+                continue
+            assert got is not None, script
+            st, desc, planes, ns, _nt = got
+            assert st == 0 and ns == len(script), (hex(st), script)
+            _hdesc, hcoefs = _host(data)
+            for c in range(desc.ncomp):
+                assert np.array_equal(planes[c], np.asarray(hcoefs[c], np.int16)), (order, c, script)
