@@ -402,6 +402,37 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
         for (const auto &g : plan.geoms) plan.lds_bytes = std::max<size_t>(plan.lds_bytes, FGenLds::total_bytes(g.tx, g.hs, g.vs));
     }
     if (const char *pad = getenv("JPGPU_LDS_PAD")) plan.lds_bytes += (size_t)atoi(pad);  // occupancy experiments: claim more LDS than needed
+    // Unequal segments, longest first (round 6).  When the equal split comes out at TWO segments per strip the launch is
+    // one and a half rounds of the device's resident workgroups (256 x 1080p: 1,536 workgroups of 34 MCU rows on 1,024 slots) — the
+    // second round runs on half the machine.  Cut every strip at 65 / 82 / 94 % of its rows instead and put ALL first segments in front
+    // of all second ones, and so on (work table in segment order): the 1,024 slots take the 768 long segments and a third of the short
+    // ones, the short ones' slots work through the rest, and everybody ends together — 256 x 1080p 0.633-0.668 -> 0.608-0.657 ms on two
+    // boxes (+1.7 % / +4 %; cuts 44,56,64 of 68 rows best of 24 variants: profiles/round6/04_launch_shape.txt).  JPGPU_S420_CUTS="r1,r2,..."
+    // sets the cuts by hand (experiments), JPGPU_S420_EQUAL=1 keeps the equal split (A/B).
+    std::vector<uint32_t> cuts;
+    if (const char *cs = plan.strip ? getenv("JPGPU_S420_CUTS") : nullptr) {
+        for (const char *q = cs; *q;) {
+            cuts.push_back((uint32_t)strtoul(q, const_cast<char **>(&q), 10));
+            if (*q == ',') q++;
+        }
+    } else if (plan.strip && plan.kind == FUSED_420 && uniform && plan.geoms[0].n_seg == 2u && plan.geoms[0].mcu_h >= 16u && !getenv("JPGPU_S420_SEG") &&
+               !getenv("JPGPU_S420_EQUAL")) {
+        const uint32_t h = plan.geoms[0].mcu_h;
+        for (uint32_t pct : {65u, 82u, 94u}) cuts.push_back((h * pct + 50u) / 100u);
+    }
+    if (!cuts.empty()) {
+        cuts.push_back(0xffffffffu);
+        uint32_t lo = 0;
+        for (uint32_t hi : cuts) {
+            for (uint32_t i = 0; i < n; i++) {
+                const FusedGeom &g = plan.geoms[i];
+                const uint32_t a = std::min(lo, g.mcu_h), b = std::min(hi, g.mcu_h);
+                for (uint32_t x = 0; a < b && x < g.tiles_x; x++) plan.work_main.push_back(FusedWork{i, x, a, b});
+            }
+            lo = hi;
+        }
+        plan.uniform = false;
+    } else
     for (uint32_t i = 0; i < n; i++) {
         const FusedGeom &g = plan.geoms[i];
         const uint32_t ny = plan.strip ? g.n_seg : g.mcu_h;

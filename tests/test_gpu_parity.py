@@ -381,8 +381,9 @@ STRIP_GEOMETRY = [(64, 48), (33, 17), (2, 2), (250, 130), (129, 257), (673, 79),
 
 
 @pytest.mark.parametrize("size", STRIP_GEOMETRY, ids=lambda s: f"{s[0]}x{s[1]}")
-@pytest.mark.parametrize("knobs", [{}, {"JPGPU_S420_SEG": "1"}, {"JPGPU_S420_SEG": "3", "JPGPU_S420_TX": "20"}, {"JPGPU_S420_TX": "7"}],
-                         ids=["default", "seg1", "seg3-tx20", "tx7"])
+@pytest.mark.parametrize("knobs", [{}, {"JPGPU_S420_SEG": "1"}, {"JPGPU_S420_SEG": "3", "JPGPU_S420_TX": "20"}, {"JPGPU_S420_TX": "7"},
+                                   {"JPGPU_S420_CUTS": "3,4,9"}, {"JPGPU_S420_CUTS": "1,2,5,6,12,13", "JPGPU_S420_TX": "11"}],
+                         ids=["default", "seg1", "seg3-tx20", "tx7", "unequal-segments-longest-first", "unequal-segments-tx11"])
 @pytest.mark.parametrize("kind", ["sparse", "tight", "full"])
 def test_batch_420_strip_walk_variant_bit_exact(size, knobs, kind, monkeypatch):
     """The 4:2:0 strip walk: strip / segment seams, carry rows, image edges."""
