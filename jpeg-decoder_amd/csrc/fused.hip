@@ -402,8 +402,8 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
         for (const auto &g : plan.geoms) plan.lds_bytes = std::max<size_t>(plan.lds_bytes, FGenLds::total_bytes(g.tx, g.hs, g.vs));
     }
     if (const char *pad = getenv("JPGPU_LDS_PAD")) plan.lds_bytes += (size_t)atoi(pad);  // occupancy experiments: claim more LDS than needed
-    // Unequal segments, longest first (round 6).  When the equal split comes out at TWO segments per strip the launch is
-    // one and a half rounds of the device's resident workgroups (256 x 1080p: 1,536 workgroups of 34 MCU rows on 1,024 slots) — the
+    // Unequal segments, longest first (round 6).  When the equal split comes out at two or a few segments per strip the launch
+    // is between one and two rounds of the device's resident workgroups (256 x 1080p: 1,536 workgroups of 34 MCU rows on 1,024 slots) — the
     // second round runs on half the machine.  Cut every strip at 65 / 82 / 94 % of its rows instead and put ALL first segments in front
     // of all second ones, and so on (work table in segment order): the 1,024 slots take the 768 long segments and a third of the short
     // ones, the short ones' slots work through the rest, and everybody ends together — 256 x 1080p 0.633-0.668 -> 0.608-0.657 ms on two
@@ -415,8 +415,11 @@ bool fused_plan(const std::vector<jpgpu_image_desc> &descs, const std::vector<ui
             cuts.push_back((uint32_t)strtoul(q, const_cast<char **>(&q), 10));
             if (*q == ',') q++;
         }
-    } else if (plan.strip && plan.kind == FUSED_420 && uniform && plan.geoms[0].n_seg == 2u && plan.geoms[0].mcu_h >= 16u && !getenv("JPGPU_S420_SEG") &&
-               !getenv("JPGPU_S420_EQUAL")) {
+    } else if (plan.strip && uniform && plan.geoms[0].n_seg >= 2u && plan.geoms[0].mcu_h >= 16u && (uint64_t)plan.geoms[0].tiles_x * n >= 512u &&
+               !getenv("JPGPU_S420_SEG") && !getenv("JPGPU_S420_EQUAL")) {
+        // (every strip walk — 4:2:0, 4:4:0, the four-component ones — whose launch has at least half as many strips as the device has
+        // slots: 256 x 1080p 4:4:0 0.6244 -> 0.6355 of the roofline, CMYK 22 11 11 11 0.631 -> 0.664, YCCK 22 11 11 22 0.628 -> 0.647;
+        // launches of fewer strips keep many short equal segments: they need the workgroups)
         const uint32_t h = plan.geoms[0].mcu_h;
         for (uint32_t pct : {65u, 82u, 94u}) cuts.push_back((h * pct + 50u) / 100u);
     }
