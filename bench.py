@@ -66,7 +66,7 @@ def parse_args(argv=None):
                     help="images in the whole job, sharded over the ranks (strong scaling; default at N > 1: 4096)")
     ap.add_argument("--sub-batches", type=int, default=0, help="launch groups per step (default: 1 at N = 1; at N > 1 up to 8, none smaller than 64 images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU work for the cpu_baseline sample (the whole-decode comparator takes half)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU work for the cpu_baseline sample (the whole-decode comparator takes half)")
     ap.add_argument("--generic", action="store_true", help="force the two-kernel generic path")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-steps", type=int, default=3, help="timed steps of the decode + gather region (N > 1)")

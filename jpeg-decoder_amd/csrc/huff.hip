@@ -374,7 +374,7 @@ __global__ __launch_bounds__(SYNC_NT, 4) void huff_sync_pass_kernel(const HuffSy
 // hold one or two of them and sit on its wave slots and 23 kB of LDS for a whole chunk walk (0.4 ms) with one busy lane, and with a
 // dozen sub-batches in flight those mostly idle workgroups fill the device's slots and keep the FULL passes of other sub-batches
 // waiting (per-dispatch counters of a late launch: 70 % of the wave-cycles of a full one for 3 % of its work;
-// tools/probe_concurrency.hip: 1,792 workgroups of this footprint fit the device).  So a late launch gives one workgroup
+// tools/attic/probe_concurrency.hip: 1,792 workgroups of this footprint fit the device).  So a late launch gives one workgroup
 // SYNC_LATE_SPAN blocks of 256 chunks: it gathers the chunks with work from all of them, 256 at a time, and walks those.
 constexpr uint32_t SYNC_LATE_SPAN = 8u;
 template <uint32_t TABLES>
@@ -890,7 +890,7 @@ hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *
 }
 
 // A sub-batch's pixels -> pinned host memory (JPGPU_PIPELINE_DOWNLOAD), by a kernel of a few workgroups that writes the mapped host
-// block itself (16-byte non-temporal stores): tools/probe_d2h2.hip measures 55 GB/s for it — what the copy engine gives the same
+// block itself (16-byte non-temporal stores): tools/attic/probe_d2h2.hip measures 55 GB/s for it — what the copy engine gives the same
 // copies ALONE (57) — where hipMemcpyAsync inside jpgpu_pipeline_decode reached 33 with a host core busy the whole time.
 __global__ __launch_bounds__(256) void copy_to_host_kernel(v4u *__restrict__ dst, const v4u *__restrict__ src, size_t n16, uint8_t *__restrict__ dst_tail,
                                                            const uint8_t *__restrict__ src_tail, uint32_t tail) {

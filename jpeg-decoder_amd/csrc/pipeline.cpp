@@ -933,7 +933,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             hipStream_t ds = p->d2h[sj % n_d2h];
             const double c0 = trace ? now_ms() : 0.0;
             // (by a copy kernel that writes the pinned block itself: the copy engine's hipMemcpyAsync reached 33 GB/s in here — with a
-            // host core busy the whole time — against 57 for the same copies alone: tools/probe_d2h*.hip, profiles/round5)
+            // host core busy the whole time — against 57 for the same copies alone: tools/attic/probe_d2h*.hip, profiles/round5)
             if (hipStreamWaitEvent(ds, sb.decoded, 0) != hipSuccess ||
                 jpgpu::copy_device_to_pinned_host(sb.h_out, jpgpu_batch_out_arena(sb.batch), sb.h_out_bytes, ds) != JPGPU_OK)
                 return false;

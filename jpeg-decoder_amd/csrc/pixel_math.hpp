@@ -74,7 +74,7 @@ typedef uint32_t w32;
 #define stream_store(p, ...) (*(p) = (__VA_ARGS__))
 #endif
 // (What the hint does to PARTIAL lines — a lane writing 12-byte pieces 24 bytes apart fills half of each line per
-// instruction: tools/ubench_store.hip, profiles/round2/01_store_patterns.txt — alone 2.5 TB/s against 5.3 TB/s for plain
+// instruction: tools/attic/ubench_store.hip, profiles/round2/01_store_patterns.txt — alone 2.5 TB/s against 5.3 TB/s for plain
 // stores.  The single-launch 4:2:0 kernel therefore stores plainly, PixelOps::row_pixels<.., NTS = false>.)
 
 typedef const JP_CONST uint32_t *qtab_t;  // 64 u16 quantization values packed two per dword, 4-B aligned
