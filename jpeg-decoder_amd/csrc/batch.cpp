@@ -1382,6 +1382,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         uint64_t weight;  // bytes of entropy-coded data the lane walks
         uint32_t rank;    // pipelined scans: how many scans deep its dependencies go (0: none); serial tracks: 0
         uint32_t kind;    // pipelined scans: which scan of its frame's script it is (band, approximation, first component); serial tracks: 0
+        uint64_t chain;   // pipelined scans: the place of this scan's track among its frame's tracks by the bytes along the longest chain of dependent scans (0: the longest; waves: the launch order)
     };
     std::vector<TrackOrder> order;
     order.reserve(n_tracks);
@@ -1456,12 +1457,32 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
                 }
                 const host::ProgPlannedScan &pj = pl.scans[j];
                 const uint32_t kind = ((uint32_t)pj.ss << 24) | ((uint32_t)pj.se << 16) | ((uint32_t)pj.ah << 12) | ((uint32_t)pj.al << 8) | (pj.comp[0].frame_index << 4) | pj.ncomp;
-                order.push_back(TrackOrder{(uint32_t)si_of[j], 1u, k, pj.stuffed_bytes, rank[j], kind});
+                order.push_back(TrackOrder{(uint32_t)si_of[j], 1u, k, pj.stuffed_bytes, rank[j], kind, 0u});
+            }
+            {   // the longest chain of every track: a scan's bytes + the longest chain of the scans that wait for it, the maximum per track
+                std::vector<uint64_t> down(ns, 0u), best(pl.n_tracks + 1u, 0u);
+                for (uint32_t j = ns; j-- > 0;) {  // (consumers come later in the stream: down[j] is final when the loop reaches j)
+                    down[j] += pl.scans[j].stuffed_bytes;
+                    for (uint32_t w = 0; w < 3u; w++)
+                        if (deps[j][w] >= 0) down[(uint32_t)deps[j][w]] = std::max(down[(uint32_t)deps[j][w]], down[j]);
+                }
+                for (uint32_t j = 0; j < ns; j++) {
+                    uint64_t &bt = best[std::min<uint32_t>(pl.scans[j].track, pl.n_tracks)];
+                    bt = std::max(bt, down[j]);
+                }
+                // ... as the track's PLACE among the frame's tracks (0: the longest chain): frames differ in their bytes, the places compare
+                for (uint32_t j = 0; j < ns; j++) {
+                    const uint64_t mine = best[std::min<uint32_t>(pl.scans[j].track, pl.n_tracks)];
+                    uint32_t place = 0;
+                    for (uint32_t t = 0; t < pl.n_tracks; t++)
+                        if (best[t] > mine || (best[t] == mine && t < std::min<uint32_t>(pl.scans[j].track, pl.n_tracks))) place++;
+                    order[order.size() - ns + j].chain = place;
+                }
             }
         } else {
             size_t at = first_si;
             for (uint32_t t = 0; t < pl.n_tracks; t++) {
-                TrackOrder to{(uint32_t)at, 0u, k, 0u, 0u, 0u};
+                TrackOrder to{(uint32_t)at, 0u, k, 0u, 0u, 0u, 0u};
                 for (uint32_t j = 0; j < ns; j++)
                     if (pl.scans[j].track == t) {
                         to.weight += pl.scans[j].stuffed_bytes;
@@ -1515,9 +1536,15 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         for (const TrackOrder &o : order) lists[xcd_of[o.image_k]].push_back(o);
         size_t longest = 0;
         for (auto &l : lists) {
+            // (round 6, second half: the tracks with the longest chains FIRST — Y's first scans, their refinements, then the short tracks:
+            // with ranks only, the last scans of the long chains were dispatched last and the launch ended with a 9 ms tail of a few
+            // waves per SIMD; scans of one track share `chain`, and inside a track the rank keeps producers in front.  JPGPU_PROG_ORDER=rank: as before)
+            static const bool by_rank = getenv("JPGPU_PROG_ORDER") && !strcmp(getenv("JPGPU_PROG_ORDER"), "rank");
             std::stable_sort(l.begin(), l.end(), [&](const TrackOrder &a, const TrackOrder &c) {
                 const uint32_t ga = seq_of[a.image_k] / group, gc = seq_of[c.image_k] / group;
-                return ga != gc ? ga < gc : (a.rank != c.rank ? a.rank < c.rank : a.weight > c.weight);
+                if (ga != gc) return ga < gc;
+                if (!by_rank && a.chain != c.chain) return a.chain < c.chain;
+                return a.rank != c.rank ? a.rank < c.rank : a.weight > c.weight;
             });
             longest = std::max(longest, l.size());
         }

@@ -971,6 +971,31 @@ extern "C" int jpgpu_selftest_first_fast(void *host_cases, uint32_t n) {
     (void)hipFree(d);
     return rc;
 }
+__global__ __launch_bounds__(64) void progw_dc_fast_case_kernel(PwDcCase *cases, uint32_t n) {
+    if (blockIdx.x >= n) return;
+    PwDcCase *g = cases + blockIdx.x;
+    PwDcCase c;
+    c.win = g->win, c.pred = g->pred, c.cm0 = g->cm0, c.cm1 = g->cm1, c.ts0 = g->ts0, c.ts1 = g->ts1;
+    c.pos = g->pos, c.nx = g->nx, c.dp = g->dp, c.i = g->i, c.n = g->n, c.al = g->al, c.code = 0u;
+    const uint32_t lane = threadIdx.x;
+    c.lut0[lane] = g->lut0[lane], c.lut1[lane] = g->lut1[lane], c.w[lane] = g->w[lane], c.val[lane] = g->val[lane];
+    pw_dc_fast_case(c);
+    g->val[lane] = c.val[lane];
+    if (lane == 0u) g->win = c.win, g->pos = c.pos, g->nx = c.nx, g->dp = c.dp, g->i = c.i, g->pred = c.pred, g->code = c.code;
+}
+extern "C" int jpgpu_selftest_dc_fast(void *host_cases, uint32_t n) {
+    PwDcCase *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * sizeof(PwDcCase)) != hipSuccess) return 1;
+    int rc = 0;
+    if (hipMemcpy(d, host_cases, (size_t)n * sizeof(PwDcCase), hipMemcpyHostToDevice) != hipSuccess) rc = 2;
+    if (!rc) {
+        progw_dc_fast_case_kernel<<<dim3(n), dim3(64)>>>(d, n);
+        if (hipDeviceSynchronize() != hipSuccess) rc = 3;
+    }
+    if (!rc && hipMemcpy(host_cases, d, (size_t)n * sizeof(PwDcCase), hipMemcpyDeviceToHost) != hipSuccess) rc = 4;
+    (void)hipFree(d);
+    return rc;
+}
 // (timing: the same state walked `reps` times by one wave; -> milliseconds for the lot)
 __global__ __launch_bounds__(64) void progw_refine_fast_bench_kernel(PwFastCase *cases, uint32_t reps) {
     PwFastCase *g = cases;

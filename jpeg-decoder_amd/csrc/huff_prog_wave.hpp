@@ -391,6 +391,198 @@ __device__ __forceinline__ int16_t *pw_block_of(const PwGeom &g, uint32_t idx) {
 }
 
 // ---- DC scans (ss == se == 0; one to four components, src/decoder.rs:1100-1126 and :1181-1190), 64 blocks per chunk ----------------------
+// A DC first scan's chunk: which component block i of the chunk belongs to, and which of the scan's tables decodes it, as bit masks
+// over the chunk's 64 blocks (bit i of cm0 / cm1: the component's index bits, of ts0 / ts1: its table's) — the lanes work them out once
+// per chunk, the walk shifts them.
+// the component of block `idx` of a scan's walk (decode_scan's loops: components in order inside an MCU, h * v blocks each).  Per lane.
+__device__ __forceinline__ uint32_t pw_dc_comp_of(const PwGeom &g, uint32_t idx) {
+    uint32_t r = idx % g.bpm, c = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; k++) {
+        const uint32_t nb = (g.nblk >> (8u * k)) & 0xffu;
+        if (c == k && k + 1u < g.ncomp && r >= nb) r -= nb, c = k + 1u;
+    }
+    return c;
+}
+struct PwDcChunk {
+    uint64_t cm0, cm1, ts0, ts1;
+    uint32_t i, n, err;  // the next block, how many the chunk has
+    uint64_t pred;       // four 16-bit predictors (wrapping_add on i16 in the reference)
+};
+// ONE block of a DC first scan, in portable C++
+__device__ __forceinline__ void pw_dc_symbol(PwBits &b, const PwTable &tab0, const PwTable &tab1, const PwTable &tab2, const PwTable &tab3, WV32 &val, PwDcChunk &D, uint32_t al) {
+    PW_NEED32(b);
+    const uint32_t i = D.i, look = pw_look(b);
+    const uint32_t c = (uint32_t)((D.cm0 >> i) & 1ull) | ((uint32_t)((D.cm1 >> i) & 1ull) << 1), t = (uint32_t)((D.ts0 >> i) & 1ull) | ((uint32_t)((D.ts1 >> i) & 1ull) << 1);
+    // (the tables live in registers: the choice between them is a scalar branch, not an index)
+    const uint32_t e = t == 0u ? pw_symbol(tab0, look) : t == 1u ? pw_symbol(tab1, look) : t == 2u ? pw_symbol(tab2, look) : pw_symbol(tab3, look);
+    if (__builtin_expect(pw_e_kind(e) == PW_KIND_BAD, 0)) {  // no such code / "invalid DC difference magnitude category"
+        D.err = pw_e_len(e) ? PROG_ST_BAD_DC : PROG_ST_BAD_CODE;
+        D.i = D.n;
+        return;
+    }
+    const uint32_t len = pw_e_len(e), cat = pw_e_extra(e);
+    uint32_t diff = 0;
+    if (cat) diff = (uint32_t)pw_extend(pw_field(look, len, cat), cat);  // len + cat <= 16 + 11
+    pw_consume(b, len + cat);
+    const uint32_t pv = (uint32_t)((D.pred >> (16u * c)) + diff) & 0xffffu;
+    D.pred = (D.pred & ~(0xffffull << (16u * c))) | ((uint64_t)pv << (16u * c));
+    wv_writelane(val, i, (pv << al) & 0xffffu);
+    D.i = i + 1u;
+}
+#if defined(JPGPU_HOST_EMULATION) && !defined(PROGW_PORTABLE)
+// tests/emu: the hand-scheduled loop below in C++ (-> 0: the chunk is through, 1: the next block is the portable path's, 2: the window is
+// used up).  It knows tables 0 and 1 (what encoders use); a block of tables 2 / 3 and a code of seven bits and more are handed back.
+static inline uint32_t pw_dc_fast(PwBits &b, const PwTable &tab0, const PwTable &tab1, WV32 &val, PwDcChunk &D, uint32_t al) {
+    for (;;) {
+        if (b.pos < 32u) {
+            if (b.dp == 64u) return 2u;
+            b.win |= (uint64_t)b.nx << (32u - b.pos);
+            b.pos += 32u;
+            b.nx = wv_readlane(b.w, b.dp);
+            b.dp++;
+        }
+        const uint32_t i = D.i, hi = (uint32_t)(b.win >> 32);
+        if ((D.ts1 >> i) & 1ull) return 1u;
+        const uint32_t e = ((D.ts0 >> i) & 1ull) ? wv_readlane(tab1.lut6, hi >> 26) : wv_readlane(tab0.lut6, hi >> 26), len = e & 31u;
+        if (len == 0u || ((e >> 17) & 3u) == 3u) return 1u;
+        const uint32_t cat = (e >> 5) & 31u, bits = ((hi << len) >> 1) >> (31u - cat), cons = len + cat;
+        b.win <<= cons, b.pos -= cons;
+        PROGW_COUNT(symbols, 1);
+        const uint32_t diff = bits < (1u << ((cat - 1u) & 31u)) ? bits + (0xffffffffu << cat) + 1u : bits;  // (category 0: 0)
+        const uint32_t sh = 16u * ((uint32_t)((D.cm0 >> i) & 1ull) | ((uint32_t)((D.cm1 >> i) & 1ull) << 1));
+        const uint32_t pv = (uint32_t)((D.pred >> sh) + diff) & 0xffffu, v = (pv << al) & 0xffffu;
+        D.pred = (D.pred & ~(0xffffull << sh)) | ((uint64_t)pv << sh);
+        WV_EACH {
+            if (lane == i) WV(val) = v;
+        }
+        D.i = i + 1u;
+        if (!(D.i < D.n)) return 0u;
+    }
+}
+#endif
+#if !defined(JPGPU_HOST_EMULATION) && !defined(PROGW_PORTABLE)
+// The blocks of a DC first scan's chunk, hand-scheduled (gfx950) like pw_refine_fast below.  s[40:41] window, s42 valid bits, s43 next
+// dword, s44 its successor's lane, s45 the block, s46 the chunk's count, s[48:49] the predictors, s[50:51] / s[52:53] component index
+// bits, s[72:73] / s[74:75] table index bits, s55 al, s58 -> 0 / 1 / 2 as in the twin above.
+__device__ __forceinline__ uint32_t pw_dc_fast(PwBits &b, const PwTable &tab0, const PwTable &tab1, WV32 &val, PwDcChunk &D, uint32_t al) {
+    uint32_t code, t0;
+    const uint32_t al_s = wv_uniform(al), n_s = wv_uniform(D.n);
+    const uint64_t cm0 = wv_uniform64(D.cm0), cm1 = wv_uniform64(D.cm1), ts0 = wv_uniform64(D.ts0), ts1 = wv_uniform64(D.ts1);
+    uint64_t win = wv_uniform64(b.win), pred = wv_uniform64(D.pred);
+    uint32_t pos = wv_uniform(b.pos), nx = wv_uniform(b.nx), dp = wv_uniform(b.dp), i = wv_uniform(D.i);
+    asm volatile(
+        "s_mov_b64 s[40:41], %[win]\n s_mov_b32 s42, %[pos]\n s_mov_b32 s43, %[nx]\n s_mov_b32 s44, %[dp]\n s_mov_b32 s45, %[i]\n s_mov_b32 s46, %[n]\n"
+        "s_mov_b64 s[48:49], %[pred]\n s_mov_b64 s[50:51], %[cm0]\n s_mov_b64 s[52:53], %[cm1]\n s_mov_b64 s[72:73], %[ts0]\n s_mov_b64 s[74:75], %[ts1]\n s_mov_b32 s55, %[al]\n"
+        "Ltop%=:\n"
+        "s_cmp_lt_u32 s42, 32\n"
+        "s_cbranch_scc1 Lrefill%=\n"
+        "Lsym%=:\n"
+        "s_lshr_b64 s[60:61], s[74:75], s45\n"
+        "s_bitcmp1_b32 s60, 0\n"                    // a block of table 2 / 3: the portable path
+        "s_cbranch_scc1 Lgeneric%=\n"
+        "s_lshr_b32 s62, s41, 26\n"
+        "v_readlane_b32 s63, %[lut0], s62\n"
+        "v_readlane_b32 s64, %[lut1], s62\n"
+        "s_lshr_b64 s[60:61], s[72:73], s45\n"
+        "s_bitcmp1_b32 s60, 0\n"
+        "s_cselect_b32 s63, s64, s63\n"             // the entry of this block's table
+        "s_and_b32 s62, s63, 31\n"                  // code length; SCC = (length != 0)
+        "s_cbranch_scc0 Lgeneric%=\n"
+        "s_bfe_u32 s64, s63, 0x20011\n"
+        "s_cmp_eq_u32 s64, 3\n"
+        "s_cbranch_scc1 Lgeneric%=\n"
+        "s_bfe_u32 s65, s63, 0x50005\n"             // category = extra bits
+        "s_lshl_b32 s66, s41, s62\n"
+        "s_lshr_b32 s66, s66, 1\n"
+        "s_sub_u32 s67, 31, s65\n"
+        "s_lshr_b32 s66, s66, s67\n"                // their value
+        "s_add_u32 s67, s62, s65\n"
+        "s_lshl_b64 s[40:41], s[40:41], s67\n"
+        "s_sub_u32 s42, s42, s67\n"
+        "s_sub_u32 s67, s65, 1\n"
+        "s_lshl_b32 s67, 1, s67\n"                  // 1 << (category - 1); category 0: 1 << 31, and the difference comes out 0
+        "s_lshl_b32 s68, -1, s65\n"
+        "s_add_u32 s68, s68, 1\n"
+        "s_add_u32 s68, s66, s68\n"
+        "s_cmp_lt_u32 s66, s67\n"
+        "s_cselect_b32 s68, s68, s66\n"             // the difference (src/huffman.rs:165-173)
+        "s_lshr_b64 s[60:61], s[50:51], s45\n"
+        "s_and_b32 s69, s60, 1\n"
+        "s_lshr_b64 s[60:61], s[52:53], s45\n"
+        "s_and_b32 s60, s60, 1\n"
+        "s_lshl_b32 s60, s60, 1\n"
+        "s_or_b32 s69, s69, s60\n"
+        "s_lshl_b32 s69, s69, 4\n"                  // 16 x the block's component
+        "s_lshr_b64 s[60:61], s[48:49], s69\n"
+        "s_add_u32 s68, s60, s68\n"
+        "s_and_b32 s68, s68, 0xffff\n"              // the predictor + the difference, 16 bits
+        "s_mov_b32 s60, 0xffff\n"
+        "s_mov_b32 s61, 0\n"
+        "s_lshl_b64 s[60:61], s[60:61], s69\n"
+        "s_andn2_b64 s[48:49], s[48:49], s[60:61]\n"
+        "s_mov_b32 s60, s68\n"
+        "s_mov_b32 s61, 0\n"
+        "s_lshl_b64 s[60:61], s[60:61], s69\n"
+        "s_or_b64 s[48:49], s[48:49], s[60:61]\n"
+        "s_lshl_b32 s68, s68, s55\n"
+        "s_and_b32 s68, s68, 0xffff\n"
+        "v_mov_b32_e32 %[t0], s68\n"
+        "s_lshl_b64 s[60:61], 1, s45\n"
+        "s_add_u32 s45, s45, 1\n"
+        "v_cndmask_b32_e64 %[val], %[val], %[t0], s[60:61]\n"
+        "s_cmp_lt_u32 s45, s46\n"
+        "s_cbranch_scc1 Ltop%=\n"
+        "s_mov_b32 s58, 0\n"
+        "s_branch Lend%=\n"
+        "Lrefill%=:\n"
+        "s_cmp_eq_u32 s44, 64\n"
+        "s_cbranch_scc1 Lwindow%=\n"
+        "s_sub_u32 s60, 32, s42\n"
+        "s_mov_b32 s62, s43\n"
+        "s_mov_b32 s63, 0\n"
+        "s_lshl_b64 s[62:63], s[62:63], s60\n"
+        "s_or_b64 s[40:41], s[40:41], s[62:63]\n"
+        "s_add_u32 s42, s42, 32\n"
+        "v_readlane_b32 s43, %[w], s44\n"
+        "s_add_u32 s44, s44, 1\n"
+        "s_branch Lsym%=\n"
+        "Lgeneric%=:\n"
+        "s_mov_b32 s58, 1\n"
+        "s_branch Lend%=\n"
+        "Lwindow%=:\n"
+        "s_mov_b32 s58, 2\n"
+        "Lend%=:\n"
+        "s_mov_b64 %[win], s[40:41]\n s_mov_b32 %[pos], s42\n s_mov_b32 %[nx], s43\n s_mov_b32 %[dp], s44\n s_mov_b32 %[i], s45\n s_mov_b64 %[pred], s[48:49]\n s_mov_b32 %[code], s58\n"
+        : [win] "+s"(win), [pos] "+s"(pos), [nx] "+s"(nx), [dp] "+s"(dp), [i] "+s"(i), [pred] "+s"(pred), [code] "=s"(code), [val] "+v"(val), [t0] "=&v"(t0)
+        : [n] "s"(n_s), [al] "s"(al_s), [cm0] "s"(cm0), [cm1] "s"(cm1), [ts0] "s"(ts0), [ts1] "s"(ts1), [lut0] "v"(tab0.lut6), [lut1] "v"(tab1.lut6), [w] "v"(b.w)
+        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s48", "s49", "s50", "s51", "s52", "s53", "s55", "s58", "s60", "s61", "s62", "s63", "s64", "s65",
+          "s66", "s67", "s68", "s69", "s72", "s73", "s74", "s75");
+    b.win = win, b.pos = pos, b.nx = nx, b.dp = dp, D.i = i, D.pred = pred;
+    return code;
+}
+#endif
+#if !defined(PROGW_PORTABLE)
+// One call of pw_dc_fast on a given state (tests: the device against the C++ twin)
+struct PwDcCase {
+    uint64_t win, pred, cm0, cm1, ts0, ts1;
+    uint32_t pos, nx, dp, i, n, al, code, pad_;
+    uint32_t lut0[64], lut1[64], w[64], val[64];
+};
+__device__ inline void pw_dc_fast_case(PwDcCase &c) {
+    PwBits b;
+    PwTable tab0, tab1;
+    PwDcChunk D{c.cm0, c.cm1, c.ts0, c.ts1, c.i, c.n, 0u, c.pred};
+    WV32 val;
+    b.win = c.win, b.pos = c.pos, b.nx = c.nx, b.dp = c.dp, b.base = 0u, b.src = nullptr, b.n_dwords = 0u;
+    tab0.g = tab1.g = nullptr, tab0.mode = tab1.mode = 2u;
+    WV_EACH { WV(b.w) = c.w[lane], WV(tab0.lut6) = c.lut0[lane], WV(tab1.lut6) = c.lut1[lane], WV(val) = c.val[lane]; }
+    const uint32_t code = pw_dc_fast(b, tab0, tab1, val, D, c.al);
+    WV_EACH { c.val[lane] = WV(val); }
+    c.win = b.win, c.pos = b.pos, c.nx = b.nx, c.dp = b.dp, c.i = D.i, c.pred = D.pred, c.code = code;
+}
+#endif
+
 __device__ inline bool pw_scan_dc(const JP_GLOBAL ProgScan &s, uint32_t *status, PwSync &y) {
     PwBits b;
     PwGeom g;
@@ -404,35 +596,38 @@ __device__ inline bool pw_scan_dc(const JP_GLOBAL ProgScan &s, uint32_t *status,
     for (uint32_t c = 0; c < 4u; c++) table_of |= (c < g.ncomp ? s.comp[c].table & 3u : 0u) << (2u * c);
     if (first) pw_table_load(tab0, s.table[0], 2u), pw_table_load(tab1, s.table[1], 2u), pw_table_load(tab2, s.table[2], 2u), pw_table_load(tab3, s.table[3], 2u);
     uint64_t pred = 0;  // four 16-bit predictors (wrapping_add on i16 in the reference)
-    // the walk's position inside the MCU: component `c`, its block `r` of the h * v
-    uint32_t c = 0, r = 0;
     for (uint32_t cb = 0; cb < total; cb += 64u) {
         const uint32_t n = total - cb < 64u ? total - cb : 64u;
         if (!pw_wait_for(y, cb + n)) return false;
         if (first) {
             WV32 val;
+            PwDcChunk D{0ull, 0ull, 0ull, 0ull, 0u, n, 0u, pred};
+            // which component — and with it which table — every block of the chunk belongs to, as masks over the chunk
             WV_EACH { WV(val) = 0u; }
-            for (uint32_t i = 0; i < n; i++) {
-                PW_NEED32(b);
-                const uint32_t look = pw_look(b), t = (table_of >> (2u * c)) & 3u;
-                // (the tables live in registers: the choice between them is a scalar branch, not an index)
-                const uint32_t e = t == 0u ? pw_symbol(tab0, look) : t == 1u ? pw_symbol(tab1, look) : t == 2u ? pw_symbol(tab2, look) : pw_symbol(tab3, look);
-                if (__builtin_expect(pw_e_kind(e) == PW_KIND_BAD, 0)) {  // no such code / "invalid DC difference magnitude category"
-                    pw_flag(status, pw_e_len(e) ? PROG_ST_BAD_DC : PROG_ST_BAD_CODE);
-                    return false;
+            WV_BALLOT(D.cm0, lane < n && (pw_dc_comp_of(g, cb + lane) & 1u) != 0u);
+            WV_BALLOT(D.cm1, lane < n && (pw_dc_comp_of(g, cb + lane) & 2u) != 0u);
+            WV_BALLOT(D.ts0, lane < n && ((table_of >> (2u * pw_dc_comp_of(g, cb + lane))) & 1u) != 0u);
+            WV_BALLOT(D.ts1, lane < n && ((table_of >> (2u * pw_dc_comp_of(g, cb + lane))) & 2u) != 0u);
+#if !defined(PROGW_PORTABLE) && !defined(PROGW_NO_DC_FAST)
+            for (;;) {
+                const uint32_t code = pw_dc_fast(b, tab0, tab1, val, D, al);
+                if (code == 0u) break;
+                if (code == 2u) {
+                    pw_refill(b);  // (into the next window)
+                    continue;
                 }
-                const uint32_t len = pw_e_len(e), cat = pw_e_extra(e);
-                uint32_t diff = 0;
-                if (cat) diff = (uint32_t)pw_extend(pw_field(look, len, cat), cat);  // len + cat <= 16 + 11
-                pw_consume(b, len + cat);
-                const uint32_t pv = (uint32_t)((pred >> (16u * c)) + diff) & 0xffffu;
-                pred = (pred & ~(0xffffull << (16u * c))) | ((uint64_t)pv << (16u * c));
-                wv_writelane(val, i, (pv << al) & 0xffffu);
-                if (++r == ((g.nblk >> (8u * c)) & 0xffu)) {
-                    r = 0;
-                    if (++c == g.ncomp) c = 0;
-                }
+                pw_dc_symbol(b, tab0, tab1, tab2, tab3, val, D, al);
+                if (D.i >= n) break;
             }
+#else
+            do pw_dc_symbol(b, tab0, tab1, tab2, tab3, val, D, al);
+            while (D.i < n);
+#endif
+            if (__builtin_expect(D.err != 0u, 0)) {
+                pw_flag(status, D.err);
+                return false;
+            }
+            pred = D.pred;
             WV_EACH {
                 if (lane < n) pw_store16(pw_block_of(g, cb + lane), (int16_t)(uint16_t)WV(val));
             }

@@ -550,13 +550,14 @@ static void keep_on_host_what_the_device_would_decode_slower(jpgpu_pipeline *p, 
 //     chain  : a scan is one dependent walk, one wave (huff_prog_wave.hpp) — the launch lasts at least as long as the call's LONGEST scan:
 //              its entropy-coded bytes x kDevChainNsPerByte;
 //     volume : all scans of all frames share the device's scalar units: total entropy-coded bytes x kDevVolumeNsPerByte;
-//   host   = total entropy-coded bytes x kHostNsPerByte / min(worker threads, CPUs the process may use).
+//   host   = fixed + total entropy-coded bytes x kHostNsPerByte / min(worker threads, CPUs the process may use).
 // The constants are measurements on an MI355X with an EPYC 9575F host (profiles/round6/03_progressive_cost_model.txt; re-measure with
-// tools/prog_calls.py --percent 100 / --percent 0): benches/tower_progressive.jpg's longest scan, 16.7 kB, walks in 9.2 ms; 4,096
-// such frames (235 MB of scans) in 50 ms; 256 of them cost 16 host CPUs 16 ms.  The device must be ahead by a tenth (the host route is
+// tools/prog_calls.py --percent 100 / --percent 0): benches/tower_progressive.jpg's longest scan, 16.7 kB, walks in 7.8 ms; 4,096
+// such frames (235 MB of scans) take 62-66 ms, 4,096 distinct ones (268 MB) 78-82; 128 / 192 / 256 of them cost 16 host CPUs 9.7 / 13.1 /
+// 16.0-16.7 ms (the device: 9.0 / 9.8 / 10.1-10.6).  The device must be ahead by a tenth (the host route is
 // the one whose behaviour on odd streams is pinned).  JPGPU_PIPE_PROG_DEVICE_PERCENT pins the device's share (tests, A/B).
 // Returns how many frames keep their device plan; the others get a fresh front-end for the host path.
-constexpr double kDevFixedMs = 1.5, kDevChainNsPerByte = 560.0, kDevVolumeNsPerByte = 0.215, kDevPerFrameMs = 0.006, kHostNsPerByte = 17.0;
+constexpr double kDevFixedMs = 1.1, kDevChainNsPerByte = 470.0, kDevVolumeNsPerByte = 0.19, kDevPerFrameMs = 0.006, kHostFixedMs = 1.5, kHostNsPerByte = 17.0;
 static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n) {
     std::vector<uint32_t> elig;
     uint64_t scan_bytes = 0, longest_scan = 0, host_bytes = 0;  // entropy-coded bytes: of the eligible frames' scans, of the longest of those scans, of the progressive frames the host decodes anyway
@@ -580,7 +581,7 @@ static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_
     } else {
         static const uint32_t cpus = granted_cpus();
         const double workers = (double)std::max<uint32_t>(1u, std::min<uint32_t>(p->pool->size(), cpus));
-        const double host_all = (double)(scan_bytes + host_bytes) * kHostNsPerByte * 1e-6 / workers;
+        const double host_all = kHostFixedMs + (double)(scan_bytes + host_bytes) * kHostNsPerByte * 1e-6 / workers;
         const double host_rest = (double)host_bytes * kHostNsPerByte * 1e-6 / workers;
         const double device = kDevFixedMs + std::max((double)longest_scan * kDevChainNsPerByte, (double)scan_bytes * kDevVolumeNsPerByte) * 1e-6 + e * kDevPerFrameMs;
         d = std::max(device, host_rest) < 0.9 * host_all ? e : 0u;

@@ -188,4 +188,8 @@ void emu_progw_first_fast(void *cases, uint32_t n) {
         pw_first_fast_case(c[i]);
     }
 }
+void emu_progw_dc_fast(void *cases, uint32_t n) {
+    PwDcCase *c = static_cast<PwDcCase *>(cases);
+    for (uint32_t i = 0; i < n; i++) pw_dc_fast_case(c[i]);
+}
 }

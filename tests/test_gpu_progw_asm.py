@@ -187,3 +187,71 @@ def test_hand_scheduled_first_scan_loop_equals_its_twin(seed):
         lanes = [(l, hex(x.cf[l]), hex(y.cf[l])) for l in range(64) if x.cf[l] != y.cf[l]]
         raise AssertionError(f"{len(bad)} of {n} states differ; case {i}: twin vs device {msg}, lanes {lanes[:8]}")
     assert min(codes) > 50, codes
+
+
+# ---- the DC first scans' loop (pw_dc_fast) -----------------------------------------------------------------------------------------------
+class DcCase(C.Structure):
+    _fields_ = [("win", C.c_uint64), ("pred", C.c_uint64), ("cm0", C.c_uint64), ("cm1", C.c_uint64), ("ts0", C.c_uint64), ("ts1", C.c_uint64),
+                ("pos", C.c_uint32), ("nx", C.c_uint32), ("dp", C.c_uint32), ("i", C.c_uint32), ("n", C.c_uint32), ("al", C.c_uint32),
+                ("code", C.c_uint32), ("pad_", C.c_uint32), ("lut0", C.c_uint32 * 64), ("lut1", C.c_uint32 * 64), ("w", C.c_uint32 * 64), ("val", C.c_uint32 * 64)]
+
+
+def _dc_cases(rng, n):
+    arr = (DcCase * n)()
+    for c in arr:
+        c.pos = int(rng.integers(0, 64))
+        win = int(rng.integers(0, 1 << 63)) << 1 | int(rng.integers(0, 2))
+        c.win = (win >> (64 - c.pos)) << (64 - c.pos) if c.pos else 0
+        c.nx = int(rng.integers(0, 1 << 32))
+        c.dp = int(rng.choice([1, 2, 17, 40, 62, 63, 64, 64]))
+        c.n = int(rng.choice([64, 64, 37, 1, 12]))
+        c.i = int(rng.integers(0, c.n))
+        c.al = int(rng.integers(0, 4))
+        c.pred = int(rng.integers(0, 1 << 63)) << 1 | int(rng.integers(0, 2))
+        ncomp = int(rng.integers(1, 5))
+        comp = [int(rng.integers(0, ncomp)) for _ in range(64)]
+        tab = [int(rng.choice([0, 1, 0, 1, 2])) if rng.random() < 0.1 else k & 1 for k in comp]
+        c.cm0 = sum(((comp[i] >> 0) & 1) << i for i in range(c.n))
+        c.cm1 = sum(((comp[i] >> 1) & 1) << i for i in range(c.n))
+        c.ts0 = sum(((tab[i] >> 0) & 1) << i for i in range(c.n))
+        c.ts1 = sum(((tab[i] >> 1) & 1) << i for i in range(c.n))
+        for i in range(64):
+            for lut in (c.lut0, c.lut1):
+                r = rng.random()
+                length = int(rng.integers(1, 7))
+                cat = int(rng.integers(0, 12))
+                lut[i] = _entry(length, cat, 0, 0, cat) if r < 0.88 else (0 if r < 0.95 else _entry(length, 0, 0, 3, 12))
+            c.w[i] = int(rng.integers(0, 1 << 32)) if rng.random() < 0.9 else 0
+            c.val[i] = int(rng.integers(0, 1 << 16)) if i < c.i else 0
+    return arr
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hand_scheduled_dc_first_loop_equals_its_twin(seed):
+    import emu
+    import jpeg_decoder_amd as J
+    assert J.device_count() >= 1
+    dev = C.CDLL(J._native.LIB_PATH)
+    dev.jpgpu_selftest_dc_fast.argtypes = [C.c_void_p, C.c_uint32]
+    cpu = emu.lib()
+    cpu.emu_progw_dc_fast.argtypes = [C.c_void_p, C.c_uint32]
+    cpu.emu_progw_dc_fast.restype = None
+    rng = np.random.default_rng(9500 + seed)
+    n = 4096
+    a = _dc_cases(rng, n)
+    b = (DcCase * n)()
+    C.memmove(b, a, C.sizeof(a))
+    cpu.emu_progw_dc_fast(C.byref(a), n)
+    assert dev.jpgpu_selftest_dc_fast(C.byref(b), n) == 0
+    fields = ("win", "pos", "nx", "dp", "i", "pred", "code")
+    bad = [k for k in range(n) if any(getattr(a[k], f) != getattr(b[k], f) for f in fields) or list(a[k].val) != list(b[k].val)]
+    codes = [0, 0, 0]
+    for x in a:
+        codes[x.code] += 1
+    if bad:
+        k = bad[0]
+        x, y = a[k], b[k]
+        msg = {f: (hex(getattr(x, f)), hex(getattr(y, f))) for f in fields if getattr(x, f) != getattr(y, f)}
+        lanes = [(l, hex(x.val[l]), hex(y.val[l])) for l in range(64) if x.val[l] != y.val[l]]
+        raise AssertionError(f"{len(bad)} of {n} states differ; case {k}: twin vs device {msg}, lanes {lanes[:8]}")
+    assert min(codes) > 50, codes
