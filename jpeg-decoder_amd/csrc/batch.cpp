@@ -1290,7 +1290,7 @@ bool jpgpu::batch_phase_stamps(jpgpu_batch *ref, jpgpu_batch *b, float ms[6]) {
     return ok;
 }
 
-// ---- progressive frames on the device (huff_prog_core.hpp) ------------------------------------------------------------------------
+// ---- progressive frames on the device (huff_prog_wave.hpp) ------------------------------------------------------------------------
 // Staging block (same offsets in the pinned and the device copy):
 //   [ status: n x u32 | ProgTrack[] | ProgScan[] | ProgHuffTable[] | scan bytes ]     device only: the masks (16 bytes per block)
 int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressiveImage *images, uint32_t n, void *hip_stream,
@@ -1318,18 +1318,15 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         const jpgpu_image_desc &desc = b->descs[images[k].image];
         for (uint32_t c = 0; c < desc.ncomp; c++) mask_bytes += align_up(b->coef_len[(size_t)images[k].image * 4 + c] / 128 * 16, 256);
     }
-    // Scans of a track pipelined over lanes (huff_prog_job.hpp): one lane per SCAN, a progress word each (behind the masks, zeroed with
-    // them), lanes of one dependency rank in waves of their own — a lane must never wait for a lane of its own wave, and the
-    // producers must come first in launch order.  JPGPU_PROG_SERIAL=1: one lane per track, as first built (A/B).
-    // Round 6: one WAVE per scan (huff_prog_wave.hpp) — always pipelined: the launch order below keeps a frame's waves on one XCD,
-    // producers in front, so an oversubscribed launch cannot starve a producer.  JPGPU_PROG_LANES=1: round 5's walk (A/B).
+    // One WAVE per scan (huff_prog_wave.hpp), the scans of a track pipelined (huff_prog_job.hpp): a progress word each (behind the masks,
+    // zeroed with them); the launch order below keeps a frame's waves on one XCD, producers in front, so an oversubscribed launch
+    // cannot starve a producer.  JPGPU_PROG_SERIAL=1 / !allow_pipelined (tests): a wave per TRACK, its scans one after the other.
+    // (Round 5 walked a LANE per scan — huff_prog_core.hpp, in the git history: 3 x slower at 256 frames, 25 % at 4,096 distinct ones.)
     static const bool serial_env = getenv("JPGPU_PROG_SERIAL") != nullptr;
-    static const bool lanes_env = getenv("JPGPU_PROG_LANES") != nullptr && atoi(getenv("JPGPU_PROG_LANES")) != 0;
-    const bool waves = !lanes_env;
-    const bool serial_tracks = serial_env || !allow_pipelined;  // (waves: the caller's limit is unlimited unless a test sets one — pipeline.cpp, prog_lanes_max)
+    const bool serial_tracks = serial_env || !allow_pipelined;
     const size_t progress_off = mask_bytes;
     mask_bytes += align_up(n_scans * 4u, 256);
-    // (lanes: a padding of < 64 lanes per rank, up to 64 ranks — more are walked serially, as tracks; waves: eight lists that differ by less than one frame's 256 scans)
+    // (eight lists that differ by less than one frame's 256 scans)
     const size_t max_lanes = n_tracks + n_scans + 64u * 64u;
     n_tracks = max_lanes;
     const size_t off_status = 0, off_tracks = align_up((size_t)n * 4, 16), off_scans = align_up(off_tracks + n_tracks * sizeof(ProgTrack), 16);
@@ -1508,7 +1505,7 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
     const auto entry_of = [&](const TrackOrder &o) {
         return ProgTrack{reinterpret_cast<const ProgScan *>(d + off_scans) + o.first_scan, o.n_scans, reinterpret_cast<uint32_t *>(d + off_status) + o.image_k};
     };
-    if (waves) {
+    {
         // Waves in launch order (huff.hip, huff_progw_kernel): workgroup i runs on XCD i mod 8 and every XCD dispatches its workgroups in
         // order.  So: every frame's waves on ONE XCD (the frame with the fewest waves so far takes the next frame: lists of equal length),
         // and inside an XCD's list by dependency rank, in groups of JPGPU_PROG_GROUP frames (default: all — rank-major: the waves of a
@@ -1551,13 +1548,6 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         if (longest * XCDS > max_lanes) return set_err(b->err, JPGPU_ERR_INTERNAL, "device progressive: wave table");
         for (size_t j = 0; j < longest; j++)
             for (uint32_t x = 0; x < XCDS; x++) tracks[n_lanes++] = j < lists[x].size() ? entry_of(lists[x][j]) : ProgTrack{nullptr, 0u, nullptr};
-    } else {
-        for (size_t t = 0; t < order.size(); t++) {
-            if (t > 0 && order[t].rank != order[t - 1].rank)
-                while (n_lanes % 64u) tracks[n_lanes++] = ProgTrack{nullptr, 0u, nullptr};
-            if (n_lanes >= max_lanes) return set_err(b->err, JPGPU_ERR_INTERNAL, "device progressive: lane table");
-            tracks[n_lanes++] = entry_of(order[t]);
-        }
     }
     const bool two_streams = copy_stream && copy_stream != hip_stream;
     hipStream_t cps = two_streams ? (hipStream_t)copy_stream : s;
@@ -1593,10 +1583,9 @@ int jpgpu::batch_device_progressive_launch(jpgpu_batch *b, const DeviceProgressi
         if (!e) B_HIP(hipEventCreate(&e));
     B_HIP(hipEventRecord(b->ev_phase[0], s));
     B_HIP(hipEventRecord(b->ev_phase[1], s));
-    B_HIP(waves ? launch_huff_progw(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s)
-                : launch_huff_prog(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s));
+    B_HIP(launch_huff_progw(reinterpret_cast<const ProgTrack *>(d + off_tracks), (uint32_t)n_lanes, s));
     B_HIP(hipEventRecord(b->ev_phase[2], s));
-    if (waves && getenv("JPGPU_PROG_TIMES")) {  // (debugging aid: a synchronisation inside the launch)
+    if (getenv("JPGPU_PROG_TIMES")) {  // (debugging aid: a synchronisation inside the launch)
         B_HIP(hipStreamSynchronize(s));
         const uint32_t ns = (uint32_t)images[0].plan->scans.size();
         std::vector<ProgScan> back(ns);

@@ -66,7 +66,7 @@ struct PlannedScan {
     std::shared_ptr<const TableSet> tables;
 };
 
-// What the device decoder for PROGRESSIVE frames (csrc/huff_prog_core.hpp) needs for one scan of such a frame, and which scans of
+// What the device decoder for PROGRESSIVE frames (csrc/huff_prog_wave.hpp) needs for one scan of such a frame, and which scans of
 // the frame depend on one another: scans that (transitively) share a coefficient of a component form a TRACK, decoded by one lane in
 // stream order; different tracks touch disjoint coefficients and run side by side.
 struct ProgPlannedScan {

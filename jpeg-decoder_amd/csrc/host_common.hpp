@@ -87,7 +87,7 @@ int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images
                                 void *copy_stream = nullptr, DeviceScratch *scratch = nullptr, bool alone = false, uint32_t mode = 0u,
                                 uint32_t *n_light = nullptr);
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
-// The same for PROGRESSIVE frames (huff_prog_core.hpp): the scans of every listed image are staged and uploaded, the
+// The same for PROGRESSIVE frames (huff_prog_wave.hpp): the scans of every listed image are staged and uploaded, the
 // images' planes and non-zero / sign masks zero-filled, ONE launch walks all tracks (a lane per track of dependent scans; the
 // coefficients are accumulated in the arena in place), then the range scan classifies the finished planes on the device.  Every image of
 // the batch must be listed (the range scan covers the whole arena).  Collect with batch_device_entropy_collect.

@@ -7,7 +7,6 @@
 
 #include "huff.hpp"
 #include "huff_core.hpp"
-#include "huff_prog_core.hpp"
 #include "huff_prog_wave.hpp"
 #include "huff_unstuff_core.hpp"
 #include "huff_sync_core.hpp"
@@ -863,19 +862,6 @@ __global__ __launch_bounds__(DC_NT) void huff_dc_prefix_kernel(const HuffSyncJob
     publish_range(job.stats, HuffRange{max_dc, 0u});
 }
 
-// ---- progressive frames: one lane per track (huff_prog_core.hpp) ---------------------------------------------------------------------
-// grid = ceil(lanes / 64) workgroups of ONE wave: a lane keeps the 8-bit lookup of its scan's table (512 B) and a 128-byte window on
-// its stream in LDS (42 kB per workgroup, three workgroups per CU), and the lanes of a wave do not talk to each other — the host
-// sorts them so that a wave's 64 walk scans of the same kind and of similar length, producers in front of the scans that wait for them.
-__global__ __launch_bounds__(64) void huff_prog_kernel(const ProgTrack *__restrict__ tracks, uint32_t n_tracks) {
-    __shared__ ProgLds L;
-    huff_fill_unzigzag((JP_LDS uint8_t *)L.unzig, threadIdx.x);
-    __syncthreads();
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    if (t >= n_tracks) return;
-    prog_run_track(*(JP_LDS ProgLds *)&L, threadIdx.x, tracks[t]);
-}
-
 // The status words of a launch -> pinned host memory, by a kernel (one workgroup) instead of a device-to-host copy: a copy command queues up
 // behind whatever the copy engine of that direction has in flight — with JPGPU_PIPELINE_DOWNLOAD that is hundreds of megabytes of
 // pixels per sub-batch, and the host waited 300 ms for 512 bytes of status words before it could finish a sub-batch (round 5).
@@ -1054,12 +1040,6 @@ extern "C" int jpgpu_selftest_refine_fast(void *host_cases, uint32_t n) {
 hipError_t launch_huff_progw(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream) {
     if (n_tracks == 0) return hipSuccess;
     huff_progw_kernel<<<dim3(n_tracks), dim3(64), 0, stream>>>(d_tracks, n_tracks);
-    return hipGetLastError();
-}
-
-hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream) {
-    if (n_tracks == 0) return hipSuccess;
-    huff_prog_kernel<<<dim3((n_tracks + 63u) / 64u), dim3(64), 0, stream>>>(d_tracks, n_tracks);
     return hipGetLastError();
 }
 

@@ -22,8 +22,7 @@ struct RangeJob {  // one component plane to classify
 // low_table_ids: every job's components use Huffman table ids 0 and 1 only — the sync passes run with four table slots in LDS
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
                             hipEvent_t after_sync = nullptr, bool low_table_ids = false);
-// progressive frames: one lane per track of dependent scans, coefficients accumulated in the arena (huff_prog_core.hpp)
-hipError_t launch_huff_prog(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);   // round 5: a lane per scan (JPGPU_PROG_LANES=1)
+// progressive frames: one wave per scan, coefficients accumulated in the arena (huff_prog_wave.hpp)
 hipError_t launch_huff_progw(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);  // round 6: a wave per scan
 // n words from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block), by a kernel
 hipError_t launch_copy_words_to_host(uint32_t *dst_host_mapped, const uint32_t *d_src, uint32_t n, hipStream_t stream);

@@ -1,4 +1,4 @@
-// huff_prog_job.hpp — job descriptors of the device decoder for PROGRESSIVE frames (huff_prog_core.hpp); no HIP dependency: the
+// huff_prog_job.hpp — job descriptors of the device decoder for PROGRESSIVE frames (huff_prog_wave.hpp); no HIP dependency: the
 // host front-end fills them (csrc/host/frontend.cpp, plan_progressive_scans).  SURVEY §8f n3 / BASELINE configs[3]: "multi-scan
 // coefficient accumulation on device".
 //
@@ -8,25 +8,24 @@
 // a band are a chain, and a scan is one long dependent walk.  What is independent: different images, and inside an image the bands that
 // share no coefficient — the DC coefficients of all components on one side, the AC band of each component on the other.
 //
-// So: one LANE per track, a track being the scans of one image that (transitively) share a coefficient, in stream order; the planes
-// live in the batch's coefficient arena from the start (zero-filled), every scan of every track works on them in place:
+// So: one WAVE per scan (huff_prog_wave.hpp; a track = the scans of one image that transitively share a coefficient, and a scan stays
+// behind the scans of its track it depends on, chunk by chunk); the planes live in the batch's coefficient arena from the start
+// (zero-filled), every scan works on them in place:
 //   * first scans (Ah = 0) store the coefficients they decode (2-byte stores, nothing read),
 //   * refinement scans never read a coefficient either: per block they need only WHICH coefficients are non-zero and their signs —
 //     two 64-bit masks per block, kept beside the planes — and change a coefficient with a no-return atomic add on its dword
 //     (a correction of +-(1 << Al) cannot carry into the neighbouring half: |c| stays below 2^14, checked by the first scans),
 //   * DC refinement is an atomic OR of one bit.
-// A lane's step is therefore an LDS table read, bit arithmetic and fire-and-forget memory operations: the chain a lane walks holds no
-// global-memory round trip except the masks of the next block (requested a block ahead).
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
 namespace jpgpu {
 
-// One Huffman table in the form the progressive lanes use: the reference's own two-step procedure (src/huffman.rs:31-58) — an 8-bit
-// lookup, then the maxcode walk from length 9.  912 bytes; a lane keeps the LOOKUP of its current scan's table in LDS (512 bytes: 42 kB
-// per workgroup of 64 lanes with their stream windows, three workgroups per CU) and takes the walk's tables — codes of nine bits and more
-// — from global memory.
+// One Huffman table in the form the progressive walk uses: the reference's own two-step procedure (src/huffman.rs:31-58) — an 8-bit
+// lookup, then the maxcode walk from length 9.  912 bytes in memory; a wave keeps what the six bits at the head of its stream mean in
+// ONE vector register (built from the lookup when the scan starts), reads codes of seven and eight bits from the lookup through the
+// scalar cache and walks maxcode for longer ones.
 struct alignas(16) ProgHuffTable {
     uint16_t lut[256];  // per 8-bit prefix: symbol | code length << 8 (length 0: not a code of up to 8 bits — the walk decides)
     int32_t maxcode[16], delta[16];
@@ -56,7 +55,7 @@ struct ProgScan {
     const ProgHuffTable *table[4];  // DC first: the distinct DC tables of the scan (comp[].table indexes them); AC scans: table[0]
     // Scans of a track PIPELINED over lanes (one lane per scan instead of one per track): a scan may work on block b as soon as the
     // scans it depends on — for every coefficient it covers, the last earlier scan that covered it — have completed block b.
-    uint32_t *progress;       // blocks (in walk order) this scan has completed, published every few blocks; PROG_DONE at its end.  nullptr: nobody waits
+    uint32_t *progress;       // blocks (in walk order) this scan has completed, published per chunk; PROG_DONE at its end.  nullptr: nobody waits
     const uint32_t *wait[3];  // the progress words of the scans this one stays behind (nullptr: none)
     uint32_t wait_whole;      // bit i: wait[i] walks its blocks in another order: it must have ENDED before this scan starts
     uint32_t pad_;
@@ -75,6 +74,6 @@ struct ProgTrack {
 // status bits of a progressive image (bit 0 set with every one of them: the host decodes the image)
 constexpr uint32_t PROG_ST_HOST = 1u, PROG_ST_BAD_CODE = 2u, PROG_ST_BAD_DC = 4u, PROG_ST_BAND = 8u, PROG_ST_STAGING = 16u, PROG_ST_RANGE = 32u,
                    PROG_ST_REPLACED = 64u /* a refinement scan puts a new value where a coefficient is non-zero already (damaged streams only) */,
-                   PROG_ST_REFINE_SYMBOL = 128u, PROG_ST_WAIT = 512u /* a lane gave up waiting for the scan it depends on */;
+                   PROG_ST_REFINE_SYMBOL = 128u, PROG_ST_WAIT = 512u /* a wave gave up waiting for the scan it depends on */;
 
 }  // namespace jpgpu

@@ -337,16 +337,14 @@ static const jpgpu_pipeline *child_of(const jpgpu_pipeline *p, uint32_t &image) 
     return c;
 }
 static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n, uint32_t flags);
-// Up to how many scans does a call walk its progressive frames a WAVE per scan (pipelined, huff_prog_job.hpp)?  Always, with the waves
-// of round 6: their launch order keeps a frame's waves on one XCD, producers in front (csrc/batch.cpp), so an oversubscribed launch
-// cannot starve a producer.  Round 5's lanes (JPGPU_PROG_LANES=1) had to fit the device at once: 46 k of its 48 k.  Beyond the limit: a
-// wave (lane) per TRACK, its scans one after the other.  JPGPU_PROG_LANES_MAX: tests, A/B (read per call).
+// Up to how many scans does a call walk its progressive frames a WAVE per scan (pipelined, huff_prog_job.hpp)?  Always: the launch
+// order keeps a frame's waves on one XCD, producers in front (csrc/batch.cpp), so an oversubscribed launch cannot starve a producer
+// (round 5's lanes had to fit the device at once).  Beyond the limit: a wave per TRACK, its scans one after the other —
+// JPGPU_PROG_LANES_MAX (tests, A/B; read per call) / JPGPU_PROG_SERIAL.
 static uint64_t prog_lanes_max() {
     if (getenv("JPGPU_PROG_SERIAL")) return 0;
     const char *e = getenv("JPGPU_PROG_LANES_MAX");
-    if (e) return (uint64_t)std::max<long>(atol(e), 0);
-    const char *lanes = getenv("JPGPU_PROG_LANES");
-    return lanes && atoi(lanes) != 0 ? 46000u : ~0ull;
+    return e ? (uint64_t)std::max<long>(atol(e), 0) : ~0ull;
 }
 
 static uint32_t progressive_share_for_the_device(jpgpu_pipeline *p, const uint8_t *const *data, const size_t *len, uint32_t n);
@@ -700,7 +698,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
             }
             cand[i] = d;
             if (device_entropy && p->infos[i].coding_process == JPGPU_CODING_DCT_PROGRESSIVE) {
-                // a progressive frame: its scans as tracks for the device (huff_prog_core.hpp), if the stream is plainly eligible;
+                // a progressive frame: its scans as tracks for the device (huff_prog_wave.hpp), if the stream is plainly eligible;
                 // how many of a call's eligible frames really go there is decided below, once all headers are read
                 if (device_progressive && fe.plan_progressive_scans(p->prog_plans[i])) {
                     for (uint32_t c = 0; c < d.ncomp; c++) memcpy(cand[i].quantization_tables[c], fe.qtable_of_component(c), 128);
@@ -1012,7 +1010,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         // kernels, download) when nothing else is waiting — the launches of several sub-batches then
                         // run side by side (one wave per SIMD each: they do not compete)
                         const double l0 = now_ms();
-                        if ((uint32_t)p->sub_of[i] >= first_prog_sub) {  // progressive frames: one lane per track (huff_prog_core.hpp)
+                        if ((uint32_t)p->sub_of[i] >= first_prog_sub) {  // progressive frames: one lane per track (huff_prog_wave.hpp)
                             std::vector<jpgpu::DeviceProgressiveImage> list;
                             for (uint32_t di : dv) {
                                 list.push_back(jpgpu::DeviceProgressiveImage{(uint32_t)p->slot[di], data[di], &p->prog_plans[di]});

@@ -1,4 +1,4 @@
-// emu_prog.cpp — TEST-ONLY CPU run of the device decoder for progressive frames (csrc/huff_prog_core.hpp) on the plan the host
+// emu_prog.cpp — TEST-ONLY CPU run of the device decoder for progressive frames (csrc/huff_prog_wave.hpp) on the plan the host
 // front-end makes (Frontend::plan_progressive_scans): the tracks of a frame one lane at a time, in the order given (any order must
 // give the same planes: tracks share no coefficient).
 #include <algorithm>
@@ -8,7 +8,6 @@
 #include <vector>
 #include "../../jpeg-decoder_amd/csrc/host/frontend.hpp"
 #include "../../jpeg-decoder_amd/csrc/huff_core.hpp"
-#include "../../jpeg-decoder_amd/csrc/huff_prog_core.hpp"
 #include "../../jpeg-decoder_amd/csrc/huff_prog_wave.hpp"
 
 using namespace jpgpu;
@@ -98,48 +97,12 @@ int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], i
         for (int t = 0; t < 4; t++) s.table[t] = ps.table[t].get();
     }
     if (status) return (int)status;
-    // tracks: the scans of each, in stream order, contiguous (the product sorts them the same way)
-    std::vector<std::vector<ProgScan>> per_track(plan.n_tracks);
-    for (size_t i = 0; i < plan.scans.size(); i++) per_track[plan.scans[i].track].push_back(scans[i]);
-    ProgLds *L = new ProgLds;
-    memset(L, 0xAB, sizeof(*L));
-    for (uint32_t l = 0; l < 64; l++) huff_fill_unzigzag(L->unzig, l);
-    if (order == 4 || order == 5) {  // round 6: a WAVE per scan with its waits, producers first (4) / a wave per track, its scans one after the other (5)
-        const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
-        if (order == 4 && !pd.ok) {
-            delete L;
-            return -2;
-        }
-        std::vector<uint32_t> progress(plan.scans.size(), 0u);
-        if (order == 4) {
-            for (size_t i = 0; i < plan.scans.size(); i++) {
-                scans[i].progress = &progress[i];
-                for (int w = 0; w < 3; w++)
-                    if (pd.deps[i][w] >= 0) {
-                        scans[i].wait[w] = &progress[(size_t)pd.deps[i][w]];
-                        if (!host::prog_same_walk(plan.scans[i], plan.scans[(size_t)pd.deps[i][w]])) scans[i].wait_whole |= 1u << w;
-                    }
-            }
-            for (size_t i = 0; i < plan.scans.size() && !(status & 1u); i++) {
-                ProgTrack tr{&scans[i], 1u, &status};
-                progw_run_track(tr);
-                if (progress[i] != PROG_DONE) status |= 0x8000u;  // a scan must announce its end, whatever happened
-            }
-        } else {
-            std::vector<std::vector<ProgScan>> pt(plan.n_tracks);
-            for (size_t i = 0; i < plan.scans.size(); i++) pt[plan.scans[i].track].push_back(scans[i]);
-            for (uint32_t t = 0; t < plan.n_tracks; t++) {
-                ProgTrack tr{pt[t].data(), (uint32_t)pt[t].size(), &status};
-                progw_run_track(tr);
-            }
-        }
-    } else if (order == 3) {  // scans pipelined over lanes (huff_prog_job.hpp): one lane per scan with its waits, producers first (stream order)
-        const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
-        if (!pd.ok) {
-            delete L;
-            return -2;
-        }
-        std::vector<uint32_t> progress(plan.scans.size(), 0u);
+    // order 0 / 1: a wave per track, tracks in plan order / reversed; 2: scan by scan, round robin over the tracks (what concurrent waves
+    // may do to one another's dwords); 3 / 4: a wave per SCAN with its waits, producers first (stream order); 5: a wave per track
+    const host::ProgDependencies pd = host::prog_plan_dependencies(plan);
+    std::vector<uint32_t> progress(plan.scans.size(), 0u);
+    if (order == 3 || order == 4) {
+        if (!pd.ok) return -2;
         for (size_t i = 0; i < plan.scans.size(); i++) {
             scans[i].progress = &progress[i];
             for (int w = 0; w < 3; w++)
@@ -150,26 +113,29 @@ int emu_prog_decode(const uint8_t *data, size_t len, int16_t *const planes[4], i
         }
         for (size_t i = 0; i < plan.scans.size() && !(status & 1u); i++) {
             ProgTrack tr{&scans[i], 1u, &status};
-            prog_run_track(*L, (uint32_t)(i * 5u) % 64u, tr);
+            progw_run_track(tr);
             if (progress[i] != PROG_DONE) status |= 0x8000u;  // a scan must announce its end, whatever happened
         }
     } else if (order == 2) {
+        std::vector<std::vector<ProgScan>> pt(plan.n_tracks);
+        for (size_t i = 0; i < plan.scans.size(); i++) pt[plan.scans[i].track].push_back(scans[i]);
         size_t longest = 0;
-        for (auto &t : per_track) longest = std::max(longest, t.size());
+        for (auto &t : pt) longest = std::max(longest, t.size());
         for (size_t step = 0; step < longest; step++)
             for (uint32_t t = 0; t < plan.n_tracks; t++)
-                if (step < per_track[t].size() && !(status & 1u)) {
-                    ProgTrack tr{&per_track[t][step], 1u, &status};
-                    prog_run_track(*L, (t * 7u + (uint32_t)step) % 64u, tr);
+                if (step < pt[t].size() && !(status & 1u)) {
+                    ProgTrack tr{&pt[t][step], 1u, &status};
+                    progw_run_track(tr);
                 }
     } else {
+        std::vector<std::vector<ProgScan>> pt(plan.n_tracks);
+        for (size_t i = 0; i < plan.scans.size(); i++) pt[plan.scans[i].track].push_back(scans[i]);
         for (uint32_t k = 0; k < plan.n_tracks; k++) {
             const uint32_t t = order == 1 ? plan.n_tracks - 1u - k : k;
-            ProgTrack tr{per_track[t].data(), (uint32_t)per_track[t].size(), &status};
-            prog_run_track(*L, (t * 13u) % 64u, tr);
+            ProgTrack tr{pt[t].data(), (uint32_t)pt[t].size(), &status};
+            progw_run_track(tr);
         }
     }
-    delete L;
     return (int)status;
 }
 

@@ -115,11 +115,11 @@ def test_1024_decoding_threads_like_the_reference_rayon_2_test():
 
 @pytest.mark.timeout(600)
 def test_two_pipelines_walk_progressive_frames_at_the_same_time(monkeypatch):
-    """Progressive frames on the device are walked a lane per scan, and a lane that waits for the scan it depends on holds its
-    workgroup slot (csrc/huff_prog_core.hpp).  One call's launches fit the device by construction (csrc/pipeline.cpp, prog_lanes_max);
-    two pipelines walking at the same moment together need MORE slots than the device has (2 x 2,560 frames x 10 scans = 51 k lanes
-    against 49 k).  Both must come through — nothing hangs — and every frame must be right, whether its lanes ran as planned or gave
-    up waiting and left the frame to the host."""
+    """Progressive frames on the device are walked a WAVE per scan, and a wave that waits for the scan it depends on holds its slot
+    (csrc/huff_prog_wave.hpp).  Two pipelines walking at the same moment — 2 x 2,560 frames x 10 scans = 51 k waves, six times what
+    the device holds at once — must both come through: the launch order keeps producers in front of their consumers on every XCD, so
+    nothing can wait for a wave that is not resident or done; every frame must be right, whether its waves ran as planned or gave up
+    waiting and left the frame to the host."""
     import jpeg_decoder_amd as J
     monkeypatch.setenv("JPGPU_PIPE_PROG_DEVICE_PERCENT", "100")
     tower = open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read()

@@ -632,8 +632,8 @@ def _pil_progressive(w, h, sub, quality=85, seed=1, gray=False):
 
 @pytest.mark.parametrize("percent", ["100", "50", None, "100-lane-per-track"], ids=["all-on-the-device", "half", "dispatcher", "all-on-the-device-a-lane-per-track"])
 def test_pipeline_progressive_frames_on_the_device(percent, monkeypatch):
-    """SURVEY 8f n3 / BASELINE configs[3]: the scans of a progressive frame decoded ON THE DEVICE — one lane per track of dependent scans,
-    coefficients accumulated in the arena (csrc/huff_prog_core.hpp) — for the share of a call's frames the dispatcher gives the device
+    """SURVEY 8f n3 / BASELINE configs[3]: the scans of a progressive frame decoded ON THE DEVICE — one wave per scan,
+    coefficients accumulated in the arena (csrc/huff_prog_wave.hpp) — for the share of a call's frames the dispatcher gives the device
     (JPGPU_PIPE_PROG_DEVICE_PERCENT pins it).  Every progressive file of the reference's corpora plus encoder-written ones of several
     sizes and samplings, mixed with sequential and broken files: same pixels / same errors as the oracle."""
     pytest.importorskip("PIL")

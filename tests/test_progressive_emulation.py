@@ -1,4 +1,4 @@
-"""Device decoder for PROGRESSIVE frames (csrc/huff_prog_core.hpp: one lane per track of dependent scans, coefficients accumulated in
+"""Device decoder for PROGRESSIVE frames (csrc/huff_prog_wave.hpp: one wave per scan, coefficients accumulated in
 place; SURVEY 8f n3 / BASELINE configs[3]) run on the CPU by tests/emu against the host front-end, which restates
 src/decoder.rs:1086-1298: the same coefficient planes for every stream the planner (Frontend::plan_progressive_scans) declares eligible,
 whatever the order the tracks are walked in; damaged streams stay with the host (not eligible), raise the status word, or decode to
@@ -76,8 +76,8 @@ FIXTURES = {  # file: (scans, tracks) — every progressive file of the referenc
 
 
 @pytest.mark.parametrize("rel", sorted(FIXTURES))
-@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 5], ids=["tracks-in-order", "tracks-reversed", "scan-by-scan-round-robin", "a-lane-per-scan-with-its-waits",
-                                                            "a-WAVE-per-scan-with-its-waits", "a-wave-per-track"])
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 5], ids=["tracks-in-order", "tracks-reversed", "scan-by-scan-round-robin", "a-wave-per-scan-with-its-waits",
+                                                            "a-wave-per-scan-with-its-waits-again", "a-wave-per-track"])
 def test_reference_fixtures(rel, order):
     data = open(os.path.join(R.GOLDEN, rel), "rb").read()
     assert _same_as_host(data, order) == FIXTURES[rel]
@@ -116,7 +116,7 @@ def test_tracks_are_the_connected_bands():
 
 
 def test_scans_pipelined_over_lanes_wait_for_the_last_writer_of_their_coefficients():
-    """huff_prog_job.hpp, "a lane per scan": a scan stays behind, block for block, the LAST earlier scan that covered each of its
+    """huff_prog_job.hpp, "a wave per scan": a scan stays behind, block for block, the LAST earlier scan that covered each of its
     coefficients — tower_progressive.jpg (libjpeg's default script): DC refinement behind DC first; Y's first refinement behind BOTH
     first scans of its band (1-5 and 6-63), its second behind the first; the first scans behind nobody."""
     data = open(os.path.join(R.GOLDEN, "benches", "tower_progressive.jpg"), "rb").read()
@@ -249,7 +249,7 @@ def _scripted(w, h, sampling, script, quality=85, seed=3):
     return P.encode_rgb(synth.synthetic_rgb(w, h, seed=seed), script, quality=quality, sampling=sampling)
 
 
-@pytest.mark.parametrize("order", [0, 2, 3, 4, 5], ids=["tracks-in-order", "scan-by-scan-round-robin", "a-lane-per-scan", "a-WAVE-per-scan", "a-wave-per-track"])
+@pytest.mark.parametrize("order", [0, 2, 3, 4, 5], ids=["tracks-in-order", "scan-by-scan-round-robin", "a-wave-per-scan", "a-wave-per-scan-again", "a-wave-per-track"])
 def test_split_band_refinement_scripts(order):
     """a mask word covers all 63 AC positions of a block, a scan only its band — with Y 1-5 | Y 6-63 | refine 1-5 |
     refine 6-63 the refinement of one band runs beside the first scan of the other on the same blocks (the device publishes its mask

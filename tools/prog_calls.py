@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A few jpgpu_pipeline_decode calls over N copies of a progressive file with every frame's scans decoded on the device
 (JPGPU_PIPE_PROG_DEVICE_PERCENT=100): the command rocprofv3 wraps for the kernel trace / counter passes of the track walker
-(huff_prog_kernel), and a quick look at call times.  --distinct: N different encoder-written frames instead of copies of one file."""
+(huff_progw_kernel), and a quick look at call times.  --distinct: N different encoder-written frames instead of copies of one file."""
 import argparse
 import io
 import os
