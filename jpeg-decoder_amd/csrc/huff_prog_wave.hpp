@@ -589,7 +589,7 @@ __device__ inline bool pw_scan_dc(const JP_GLOBAL ProgScan &s, uint32_t *status,
     pw_bits_open(b, s.data, s.n_bytes);
     pw_geom(g, s);
     const bool first = s.ah == 0;
-    const uint32_t al = s.al, total = g.rows * g.cols * g.bpm;
+    const uint32_t al = wv_uniform(s.al), total = g.rows * g.cols * g.bpm;
     PwTable tab0, tab1, tab2, tab3;
     uint32_t table_of = 0u;  // two bits per component
 #pragma unroll
@@ -1012,9 +1012,6 @@ __device__ __forceinline__ uint32_t pw_refine_non_zeroes(PwRefine &R, uint32_t s
     }
     if (todo) {
         uint32_t n = (uint32_t)__builtin_popcountll(todo), done = 0;
-#ifdef PROGW_DEBUG_TRACE
-        if (n > 32u) fprintf(stderr, "   [trace] %u corrections at once (start %u, zrl %u)\n", n, start, zrl);
-#endif
         do {  // the correction bits, up to 32 at a time: the first coefficient's bit is the first in the stream
             const uint32_t take = n < 32u ? n : 32u;
             if (__builtin_expect(R.b.pos < take, 0)) pw_refill(R.b);
@@ -1055,10 +1052,6 @@ __device__ __forceinline__ void pw_refine_symbol(PwRefine &R, const PwTable &tab
         B.k = end;
         return;
     }
-#ifdef PROGW_DEBUG_TRACE
-    if (g_progw_counters.blocks >= 3870ull && g_progw_counters.blocks <= 3872ull)
-        fprintf(stderr, "   [trace] block %llu k %u: len %u extra %u kind %u run %u bits %u pos %u nz %016llx\n", g_progw_counters.blocks - 1ull, B.k, len, nb, kind, pw_e_run(e), bits, R.b.pos, (unsigned long long)R.nz);
-#endif
     const uint32_t k = pw_refine_non_zeroes(R, B.k, below_end, end, pw_e_run(e));  // (an end-of-band symbol: 64 — every correction that is left)
     // What the symbol leaves behind, without branches (a taken branch costs this walk 27 cycles, a select 4): a new
     // coefficient at k — for the other kinds the "lane" is 64, which no lane is, and the mask bit falls off the word.
@@ -1178,11 +1171,6 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
     const uint64_t nz_s = wv_uniform64(R.nz), lut8_s = wv_uniform64((uint64_t)(uintptr_t)(const void *)tab.g->lut);
     uint64_t win = wv_uniform64(R.b.win), nnz = wv_uniform64(B.new_nz), nneg = wv_uniform64(B.new_neg);
     uint32_t pos = wv_uniform(R.b.pos), nx = wv_uniform(R.b.nx), dp = wv_uniform(R.b.dp), k = wv_uniform(B.k), eob = wv_uniform(B.eob_run);
-#ifdef PROGW_ASM_NOPS
-#define PW_NOP "s_nop 3\n"
-#else
-#define PW_NOP
-#endif
     asm volatile(
         "s_mov_b64 s[40:41], %[win]\n s_mov_b32 s42, %[pos]\n s_mov_b32 s43, %[nx]\n s_mov_b32 s44, %[dp]\n s_mov_b32 s45, %[k]\n"
         "s_mov_b64 s[46:47], %[nnz]\n s_mov_b64 s[48:49], %[nneg]\n s_mov_b64 s[50:51], %[nz]\n s_mov_b64 s[52:53], %[bend]\n"
@@ -1192,7 +1180,7 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_cbranch_scc1 Lrefill%=\n"
         "Lsym%=:\n"
         "s_lshr_b32 s60, s41, 26\n"
-        "v_readlane_b32 s61, %[lut], s60\n" PW_NOP
+        "v_readlane_b32 s61, %[lut], s60\n"
         "s_and_b32 s62, s61, 31\n"                  // code length; SCC = (length != 0)
         "s_cbranch_scc0 Lsecond%=\n"
         "s_bfe_u32 s63, s61, 0x50005\n"             // extra bits
@@ -1220,7 +1208,7 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_cbranch_scc1 Lzero%=\n"
         "v_mbcnt_lo_u32_b32 %[t0], s74, 0\n"
         "v_mbcnt_hi_u32_b32 %[t0], s75, %[t0]\n"    // zero coefficients below each lane
-        "v_cmp_eq_u32_e32 vcc, s65, %[t0]\n" PW_NOP
+        "v_cmp_eq_u32_e32 vcc, s65, %[t0]\n"
         "s_and_b64 s[74:75], vcc, s[74:75]\n"       // the zero coefficient with exactly `run` zero ones below it
         "Lzero%=:\n"
         "s_ff1_i32_b64 s76, s[74:75]\n"
@@ -1245,8 +1233,8 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "v_sub_u32_e32 %[t0], s79, %[t0]\n"
         "v_lshrrev_b32_e64 %[t0], %[t0], s78\n"
         "v_and_b32_e32 %[t0], 1, %[t0]\n"
-        "v_cmp_eq_u32_e32 vcc, 1, %[t0]\n" PW_NOP
-        "s_and_b64 vcc, vcc, s[72:73]\n" PW_NOP
+        "v_cmp_eq_u32_e32 vcc, 1, %[t0]\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
         "v_cndmask_b32_e32 %[acc], %[acc], %[delta], vcc\n"
         "Lplace%=:\n"
         "s_mov_b64 s[40:41], s[68:69]\n"            // committed
@@ -1262,9 +1250,9 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_cmp_lg_u32 s66, 0\n"
         "s_cselect_b32 s78, s55, s56\n"
         "s_cselect_b64 s[80:81], 0, s[74:75]\n"
-        "v_mov_b32_e32 %[t0], s78\n" PW_NOP
+        "v_mov_b32_e32 %[t0], s78\n"
         "s_or_b64 s[46:47], s[46:47], s[74:75]\n"
-        "s_or_b64 s[48:49], s[48:49], s[80:81]\n" PW_NOP
+        "s_or_b64 s[48:49], s[48:49], s[80:81]\n"
         "v_cndmask_b32_e64 %[acc], %[acc], %[t0], s[74:75]\n"
         "s_add_u32 s45, s76, 1\n"
         "s_cmp_lt_u32 s45, s54\n"
@@ -1280,7 +1268,7 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_lshl_b64 s[62:63], s[62:63], s60\n"
         "s_or_b64 s[40:41], s[40:41], s[62:63]\n"
         "s_add_u32 s42, s42, 32\n"
-        "v_readlane_b32 s43, %[w], s44\n" PW_NOP
+        "v_readlane_b32 s43, %[w], s44\n"
         "s_add_u32 s44, s44, 1\n"
         "s_branch Lsym%=\n"
         "Lrefill2%=:\n"                             // (behind the symbol, in front of its correction bits; nothing committed)
@@ -1292,7 +1280,7 @@ __device__ __forceinline__ uint32_t pw_refine_fast(PwRefine &R, const PwTable &t
         "s_lshl_b64 s[80:81], s[80:81], s60\n"
         "s_or_b64 s[68:69], s[68:69], s[80:81]\n"
         "s_add_u32 s70, s70, 32\n"
-        "v_readlane_b32 s43, %[w], s44\n" PW_NOP
+        "v_readlane_b32 s43, %[w], s44\n"
         "s_add_u32 s44, s44, 1\n"
         "s_branch Lcorr%=\n"
         "Lsecond%=:\n"                              // a code of seven or eight bits (4 % of the symbols): the 8-bit lookup in memory, through the scalar cache
@@ -1381,9 +1369,10 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
     pw_table_load(tab, s.table[0], 1u);
     int16_t *const coefs = s.comp[0].coefs;
     uint64_t *const masks = s.comp[0].masks;
-    const uint32_t block_w = s.comp[0].block_w, cols = s.cols, total = s.rows * s.cols, ss = s.ss, end = (uint32_t)s.se + 1u;
+    // (into scalar registers once, by hand: byte loads are vector loads, and the hand-scheduled loop takes these in SGPRs at every call)
+    const uint32_t block_w = s.comp[0].block_w, cols = s.cols, total = s.rows * s.cols, ss = wv_uniform(s.ss), end = wv_uniform((uint32_t)s.se + 1u);
     const uint64_t below_end = end >= 64u ? ~0ull : ((1ull << end) - 1ull), band = below_end & (~0ull << ss);
-    R.bit = 1u << s.al;
+    R.bit = wv_uniform(1u << s.al);
     uint32_t eob_run = 0;
     uint32_t n_calls = 0, n_generic = 0, n_window = 0;  // (reported with the scan's time)
     PwWalk at;
@@ -1432,23 +1421,7 @@ __device__ inline bool pw_scan_ac_refine(const JP_GLOBAL ProgScan &s, uint32_t *
                 WV_EACH { WV(delta) = ((R.neg >> lane) & 1ull) ? 0u - R.bit : R.bit; }
                 for (;;) {
                     n_calls++;
-#if defined(PROGW_DEBUG_PRINTF) && !defined(JPGPU_HOST_EMULATION)
-                    if (cb + i >= 3868u && cb + i <= 3870u && s.al == 0 && threadIdx.x == 0u)
-                        printf("dev block %u before: k %u pos %u win %016llx nx %08x dp %u nz %016llx neg %016llx eob %u\n", cb + i, B.k, R.b.pos, (unsigned long long)R.b.win, R.b.nx, R.b.dp, (unsigned long long)R.nz, (unsigned long long)R.neg, B.eob_run);
-#endif
-#if defined(PROGW_DEBUG_TRACE) && defined(JPGPU_HOST_EMULATION)
-                    if (cb + i >= 3868u && cb + i <= 3870u && s.al == 0)
-                        fprintf(stderr, "emu block %u before: k %u pos %u win %016llx nx %08x dp %u nz %016llx neg %016llx eob %u\n", cb + i, B.k, R.b.pos, (unsigned long long)R.b.win, R.b.nx, R.b.dp, (unsigned long long)R.nz, (unsigned long long)R.neg, B.eob_run);
-#endif
                     const uint32_t code = pw_refine_fast(R, tab, B, delta, below_end, end);
-#if defined(PROGW_DEBUG_PRINTF) && !defined(JPGPU_HOST_EMULATION)
-                    if (cb + i == 3869u && s.al == 0 && R.nz == 0x040005097fcffffeull)
-                        printf("dev after code %u k %u lane %u acc %08x delta %08x\n", code, B.k, threadIdx.x, R.acc, delta);
-#endif
-#if defined(PROGW_DEBUG_TRACE) && defined(JPGPU_HOST_EMULATION)
-                    if (cb + i == 3869u && s.al == 0 && R.nz == 0x040005097fcffffeull)
-                        for (uint32_t l = 0; l < 64u; l++) fprintf(stderr, "emu after code %u k %u lane %u acc %08x delta %08x\n", code, B.k, l, R.acc.l[l], delta.l[l]);
-#endif
                     if (code == 0u) break;
                     if (code == 2u) {
                         n_window++;
