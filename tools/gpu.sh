@@ -137,7 +137,10 @@ for step in "$@"; do
       B="python $R/bench.py --workload $a1 --steps 40 --warmup 10 --no-cpu-baseline --no-classes --no-k4096 --no-scale-anchor --no-cpu-budget --no-e2e --min-seconds 0 $extra"
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/tf_$a1 -o p -- $B > /dev/null 2>&1)
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/tw_$a1 -o p -- $B > /dev/null 2>&1)
-      (cd tools && python make_pmc_traffic.py "$a1:$a2" $O/tf_$a1 $O/tw_$a1 $O/pmc_traffic.json $a3) ;;
+      (cd tools && python make_pmc_traffic.py "$a1:$a2" $O/tf_$a1 $O/tw_$a1 $O/pmc_traffic.json $a3)
+      # the same entry into THIS copy's profiles/ (where bench.py reads it), so that a `bench` step later in the same call prints the
+      # traffic taken on the code it runs; the file comes back under $O and is committed from there
+      [ -n "$TRAFFIC_INSTALL" ] && (cd tools && python make_pmc_traffic.py "$a1:$a2" $O/tf_$a1 $O/tw_$a1 $R/$TRAFFIC_INSTALL $a3 > /dev/null) ;;
     pipe256)
       E=$(envs "$a1"); rm -rf $O/pipe256 $O/pipe256_fetch $O/pipe256_write $O/pipe256_pmc1
       (cd /tmp && env $E timeout 400 rocprofv3 --kernel-trace --stats -d $O/pipe256 -o k -- $PIPE_CMD > $O/pipe256.log 2>&1)

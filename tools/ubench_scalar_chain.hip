@@ -15,7 +15,7 @@
     X(0, "s_add_u32 (dependent)", 1, "s_add_u32 %0, %0, 1\n")                                                                            \
     X(1, "s_lshl_b64 (dependent)", 1, "s_lshl_b64 %1, %1, 1\n")                                                                          \
     X(2, "s_bfe_u32 + s_add (dependent pair)", 2, "s_bfe_u32 s10, %0, 0x100004\n s_add_u32 %0, %0, s10\n")                               \
-    X(3, "s_bcnt1_i32_b64 + s_ff1 + s_lshl_b64 (dependent triple)", 3, "s_bcnt1_i32_b64 s10, %1\n s_ff1_i32_b64 s11, %1\n s_add_u32 s10, s10, s11\n s_lshl_b64 %1, %1, 0\n s_add_u32 %0, %0, s10\n") \
+    X(3, "s_bcnt1_i32_b64 + s_ff1 + s_add + s_lshl_b64 + s_add (dependent)", 5, "s_bcnt1_i32_b64 s10, %1\n s_ff1_i32_b64 s11, %1\n s_add_u32 s10, s10, s11\n s_lshl_b64 %1, %1, 0\n s_add_u32 %0, %0, s10\n") \
     X(4, "v_add_u32 (dependent)", 1, "v_add_u32 %2, %2, 1\n")                                                                            \
     X(5, "v_readlane -> s_and -> v_readlane (lane select depends)", 2, "v_readlane_b32 s10, %2, %0\n s_and_b32 %0, s10, 63\n")            \
     X(6, "v_readlane -> s_add -> v_add(sgpr) -> v_readlane", 3, "v_readlane_b32 s10, %2, 5\n s_add_u32 s10, s10, 1\n v_add_u32 %2, %2, s10\n") \
