@@ -122,7 +122,8 @@ typedef struct jpgpu_pipeline_timings {
     uint32_t images_host_light; /* of images_device_entropy: scans uploaded as the file holds them, marker check + unstuffing on the device */
     uint32_t input_pinned;      /* JPGPU_PIPELINE_INPUT_PINNED was in force: the DMA engine read the caller's buffers, no staging copy */
     uint32_t images_device_progressive; /* of images_device_entropy: progressive frames whose scans were decoded and accumulated on the device */
-    uint32_t _pad2;
+    uint32_t images_entry_pixels; /* (round 6, in what was padding) of images_device_entropy: 4:2:0 images whose pixel walk read the chunk
+                                   * decoder's entry lists itself — nothing of their scan went through the coefficient arena */
 } jpgpu_pipeline_timings;
 
 enum {

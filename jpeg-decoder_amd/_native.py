@@ -72,7 +72,7 @@ class PipelineTimings(C.Structure):
                 ("dev_times_valid", C.c_uint32), ("_pad", C.c_uint32)] + \
                [(n, C.c_double) for n in ("dev_fill_ms", "dev_sync_ms", "dev_write_ms", "dev_pixel_ms", "decode_ms", "gather_ms")] + \
                [("gather_bytes", C.c_uint64), ("gather_copy_ms", C.c_double), ("cpu_ms", C.c_double), ("images_host_light", C.c_uint32),
-                ("input_pinned", C.c_uint32), ("images_device_progressive", C.c_uint32), ("_pad2", C.c_uint32)]
+                ("input_pinned", C.c_uint32), ("images_device_progressive", C.c_uint32), ("images_entry_pixels", C.c_uint32)]
 
 
 PIPELINE_DOWNLOAD, PIPELINE_DENSE, PIPELINE_DEVICE_ENTROPY, PIPELINE_GATHER = 1, 2, 4, 16

@@ -25,6 +25,7 @@
 #include "host/frontend.hpp"
 #include "huff.hpp"
 #include "fused.hpp"
+#include "fused_entries.hpp"
 #include "fused_scaled.hpp"
 #include "host_common.hpp"
 #include "kernels.hpp"
@@ -111,6 +112,14 @@ struct jpgpu_batch {
     hipEvent_t ev_phase[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool phase_events_valid = false;
     bool progressive_launch = false;  // the last device entropy launch was batch_device_progressive_launch
+    // Entry-list pixel path (fused_entries.hpp): images whose last device entropy launch kept their scan as entry lists.  entry_img[image]
+    // = 1 until the host uploads coefficients for the image (a re-decode): the dense kernels skip it (CLS_SKIP), the decode that follows
+    // the launch on its stream runs s420_entries_kernel over the plan(s) and copies the status words once more behind it.
+    std::vector<uint8_t> entry_img;
+    bool entries_pending = false;
+    const EntrySrc *d_entry_srcs = nullptr;   // per batch image, inside d_entropy
+    const uint32_t *d_entry_status = nullptr; // the launch's status words (device) and how many
+    uint32_t entry_status_n = 0;
 };
 
 #define B_HIP(call)                                                                                     \
@@ -142,6 +151,10 @@ static void batch_class_source(jpgpu_batch *b, size_t idx, bool from_device) {
     if (from_device) b->dev_classes = true;
 }
 static void batch_set_host_class(jpgpu_batch *b, size_t idx, uint8_t cls) {
+    if (idx / 4 < b->entry_img.size() && b->entry_img[idx / 4]) {  // coefficients from the host: the image is a dense one again
+        b->entry_img[idx / 4] = 0;
+        b->cls_dirty = true;
+    }
     if (b->sane[idx] != cls) {
         b->sane[idx] = cls;
         b->cls_dirty = true;
@@ -160,7 +173,7 @@ static int batch_refresh_jobs(jpgpu_batch *b, hipStream_t stream = nullptr) {
         const uint32_t k = b->cls_next++ % jpgpu_batch::kClsRing;
         uint8_t *h = b->h_host_cls + (size_t)k * n4;
         B_HIP(hipEventSynchronize(b->cls_sent[k]));  // (its previous copy, four refreshes ago: long gone)
-        for (size_t i = 0; i < n4; i++) h[i] = b->cls_src[i] ? CLS_FROM_DEVICE : b->sane[i];
+        for (size_t i = 0; i < n4; i++) h[i] = (i / 4 < b->entry_img.size() && b->entry_img[i / 4]) ? CLS_SKIP : (b->cls_src[i] ? CLS_FROM_DEVICE : b->sane[i]);
         B_HIP(hipMemcpyAsync(b->d_host_cls, h, n4, hipMemcpyHostToDevice, stream));
         B_HIP(hipEventRecord(b->cls_sent[k], stream));
     }
@@ -763,7 +776,7 @@ struct LaunchClock {  // JPGPU_PIPE_TRACE: where a slow launch spent its time (h
 
 int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                        const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par, void *copy_stream,
-                                       DeviceScratch *scratch, bool alone, uint32_t mode, uint32_t *n_light) {
+                                       DeviceScratch *scratch, bool alone, uint32_t mode, uint32_t *n_light, uint32_t *n_entry) {
     if (!b || !images || n == 0) return JPGPU_ERR_FORMAT;
     LaunchClock clk;
     int rc = use_device(b->device, b->err);
@@ -853,6 +866,17 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     // scan's slot, the job record's lengths.  Scans with restart markers are staged by the host as ever (into the mirror too: their
     // jobs then read them there).
     const bool light = (mode & DEVICE_ENTROPY_LIGHT) != 0, input_pinned = light && (mode & DEVICE_ENTROPY_INPUT_PINNED) != 0;
+    // Entry-list pixel path: which 4:2:0 strip walk (if any) a batch image belongs to
+    const bool entry_pixels = (mode & DEVICE_ENTROPY_ENTRY_PIXELS) != 0;
+    std::vector<const FusedGeom *> walk_geom(entry_pixels ? b->descs.size() : 0, nullptr);
+    if (entry_pixels)
+        for (const FusedPlan &fp : b->fused)
+            if (fp.kind == FUSED_420 && fp.strip)
+                for (uint32_t i = 0; i < fp.n_images; i++) walk_geom[fp.ids[i]] = &fp.geoms[i];
+    if (b->entry_img.size() != b->descs.size()) b->entry_img.assign(b->descs.size(), 0);
+    for (uint8_t &e : b->entry_img)
+        if (e) e = 0, b->cls_dirty = true;
+    b->entries_pending = false;
     size_t n_raw_jobs = 0;
     uint32_t max_pieces = 0, light_images = 0;
     constexpr size_t PINNED_SPAN_GAP_MAX = 4096u;  // (bytes; below one page: see where the spans are built)
@@ -874,6 +898,7 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     size_t n_table_sets = 0;
     for (uint32_t k = 0; k < n; k++) {
         if (images[k].image >= b->descs.size() || !images[k].scans || !images[k].file) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: bad image");
+        if (entry_pixels && walk_geom[images[k].image]) scratch_bytes += align_up((size_t)walk_geom[images[k].image]->mcu_h * walk_geom[images[k].image]->tiles_x * 8u, 16);
         for (const host::PlannedScan &ps : *images[k].scans) {
             if (!ps.tables) return set_err(b->err, JPGPU_ERR_FORMAT, "device entropy: scan without tables");
             if (!prev_tables || (prev_tables != ps.tables.get() && memcmp(prev_tables, ps.tables.get(), sizeof(*prev_tables)) != 0)) n_table_sets++;
@@ -929,7 +954,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     const size_t off_status = 0, off_cnt = align_up(off_status + (size_t)n * 4, 16);
     const size_t off_jobs = align_up(off_cnt + n_sync_jobs * 16, 16), off_sjobs = off_jobs;
     const size_t off_ujobs = align_up(off_sjobs + n_sync_jobs * sizeof(HuffSyncJob), 16);
-    const size_t off_tables = align_up(off_ujobs + n_raw_jobs * sizeof(UnstuffJob), 16);
+    const size_t off_esrc = align_up(off_ujobs + n_raw_jobs * sizeof(UnstuffJob), 16);  // entry-list pixel path: EntrySrc per BATCH image, EntryIndexJob per listed image
+    const size_t off_ijobs = align_up(off_esrc + (entry_pixels ? b->descs.size() * sizeof(EntrySrc) : 0), 16);
+    const size_t off_tables = align_up(off_ijobs + (entry_pixels ? (size_t)n * sizeof(EntryIndexJob) : 0), 16);
     const size_t off_seg = align_up(off_tables + n_table_sets * 8 * sizeof(DevHuffTable), 16), off_data = align_up(off_seg + seg_words * 4, 16);
     const size_t total = off_data + data_bytes;              // uploaded
     // (light: what is uploaded lands in the mirror — a copy of the data area's layout, and behind it, with pinned input, the spans)
@@ -989,6 +1016,10 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     std::vector<CopyTask> copies;
     UnstuffJob *ujobs = reinterpret_cast<UnstuffJob *>(h + off_ujobs);
     size_t ui = 0;
+    EntrySrc *esrc = reinterpret_cast<EntrySrc *>(h + off_esrc);
+    EntryIndexJob *ijobs = reinterpret_cast<EntryIndexJob *>(h + off_ijobs);
+    uint32_t n_index = 0, max_index_items = 0;
+    if (entry_pixels) memset(esrc, 0, b->descs.size() * sizeof(EntrySrc));
     std::vector<std::pair<size_t, size_t>> zero_ranges;  // coefficient planes of the listed images
     b->entropy_images.clear();
     for (uint32_t k = 0; k < n; k++) {
@@ -1107,6 +1138,25 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 uint32_t block_h[4] = {0, 0, 0, 0};
                 for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
                 if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;
+                // Entry-list pixel path: the image's ONE scan holds its three components interleaved in frame order, 2x2 / 1x1 / 1x1, with
+                // tables of their own for luma and chroma (the entries then carry their component), no restart segments, and covers the
+                // planes of the 4:2:0 walk the image belongs to.
+                if (const FusedGeom *wg = entry_pixels ? walk_geom[img] : nullptr; wg && images[k].scans->size() == 1 && !dg.chunked && !needs_zeros &&
+                                                                                    ps.ncomp == 3 && !sj->uniform && sj->bpm == 6u && sj->cols == wg->mcu_w &&
+                                                                                    sj->n_mcu == wg->mcu_w * wg->mcu_h && wg->tiles_x * wg->tx >= wg->mcu_w) {
+                    bool ok = true;
+                    for (uint32_t c = 0; c < 3; c++) ok = ok && ps.comp[c].frame_index == c && ps.comp[c].h == (c ? 1u : 2u) && ps.comp[c].v == (c ? 1u : 2u);
+                    if (ok) {
+                        sj->keep_lists = 1u;
+                        uint32_t *tab = reinterpret_cast<uint32_t *>(xs + xcur);
+                        xcur += align_up((size_t)wg->mcu_h * wg->tiles_x * 8u, 16);
+                        ijobs[n_index++] = EntryIndexJob{(uint32_t)si, wg->tx, wg->tiles_x, wg->mcu_h, tab};
+                        max_index_items = std::max(max_index_items, wg->mcu_h * wg->tiles_x);
+                        esrc[img] = EntrySrc{reinterpret_cast<const HuffSyncJob *>(d + off_sjobs) + si, tab};
+                        b->entry_img[img] = 1;
+                        b->cls_dirty = true;
+                    }
+                }
                 si++;
             }
             dcur += scan_bytes;
@@ -1252,7 +1302,14 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
     if (n_raw_jobs) B_HIP(launch_huff_unstuff(reinterpret_cast<const UnstuffJob *>(d + off_ujobs), (uint32_t)n_raw_jobs, max_pieces, s));
     if (n_light) *n_light = light_images;
     B_HIP(launch_huff_sync(reinterpret_cast<const HuffSyncJob *>(d + off_sjobs), (uint32_t)n_sync_jobs, max_chunks, sync_launches, sync_iters, s,
-                           phase_times ? b->ev_phase[2] : nullptr, low_table_ids));
+                           phase_times ? b->ev_phase[2] : nullptr, low_table_ids, reinterpret_cast<const EntryIndexJob *>(d + off_ijobs), n_index, max_index_items));
+    if (n_entry) *n_entry = n_index;
+    if (n_index) {
+        b->entries_pending = true;
+        b->d_entry_srcs = reinterpret_cast<const EntrySrc *>(d + off_esrc);
+        b->d_entry_status = reinterpret_cast<const uint32_t *>(d + off_status);
+        b->entry_status_n = n;
+    }
     if (phase_times) {
         B_HIP(hipEventRecord(b->ev_phase[3], s));
         b->phase_events_valid = true;
@@ -1687,7 +1744,20 @@ int jpgpu_batch_decode(jpgpu_batch *b, void *hip_stream) {
     // device-side classes: statistics -> class bits in the launch tables (class_finalize_*), then the `_dyn` kernels
     const uint32_t *st = b->dev_classes ? b->d_stats : nullptr;
     const uint8_t *hc = b->dev_classes ? b->d_host_cls : nullptr;
-    for (FusedPlan &fp : b->fused) B_HIP(fused_launch(fp, s, st, hc));
+    auto entry_images_of = [&](const FusedPlan &fp) {
+        uint32_t e = 0;
+        if (fp.kind == FUSED_420 && fp.strip && !b->entry_img.empty())
+            for (uint32_t id : fp.ids) e += b->entry_img[id];
+        return e;
+    };
+    if (b->entries_pending) {  // the walk that reads the entry lists of the launch in front of this decode, and what it flagged
+        b->entries_pending = false;
+        for (FusedPlan &fp : b->fused)
+            if (entry_images_of(fp)) B_HIP(fused_launch_entries(fp, s, b->d_entry_srcs));
+        B_HIP(batch_status_to_host(b, b->d_entry_status, b->entry_status_n, s));
+    }
+    for (FusedPlan &fp : b->fused)
+        if (entry_images_of(fp) < fp.n_images) B_HIP(fused_launch(fp, s, st, hc));  // (a plan of entry-list images only has nothing for the dense kernels)
     if (!b->scaled_ids.empty())
         B_HIP(launch_scaled_fused(b->d_scaled_geoms, b->d_s_image_jobs, b->d_s_plane_jobs, (uint32_t)b->scaled_ids.size(), b->s_max_tiles_x, b->s_max_bands,
                                   b->s_lds_bytes, b->s_scales, s));

@@ -17,6 +17,8 @@
 #include "host_common.hpp"
 #include "range_stats.hpp"
 
+#include "fused_entries.hpp"
+
 namespace jpgpu {
 
 // Which image / tile a workgroup owns: from the work table (mixed-size batches, 1-D grid) or, when the batch is uniform
@@ -138,12 +140,86 @@ __global__ __launch_bounds__(NT, walk_wgs(EXACT_PASS)) void s420_kernel_dyn(cons
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
     const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)imgs[w.image].flags);
+    if (fl & 8u) return;  // the image's pixels come from the entry lists (s420_entries_kernel, fused_entries.hpp)
     if constexpr (EXACT_PASS) {
         if (!(fl & 1u)) walk_item<S420<ARITH_EXACT, NT>>(geoms, imgs, w, lds_raw);
     } else {
         if (fl & 2u) walk_item<S420<ARITH_TIGHT, NT>>(geoms, imgs, w, lds_raw);
         else if (fl & 1u) walk_item<S420<ARITH_SANE, NT>>(geoms, imgs, w, lds_raw);
     }
+}
+
+// The 4:2:0 walk fed by the device entropy decoder's entry lists (fused_entries.hpp): the staging step of walk_item replaced by
+// "clear the staging area, scatter the run's entries into it"; everything else is S420<ARITH_SANE>'s.
+__global__ __launch_bounds__(256, 4) void s420_entries_kernel(const FusedGeom *__restrict__ geoms, const FusedImage *__restrict__ imgs,
+                                                              const FusedWork *__restrict__ work, const uint32_t *__restrict__ ids,
+                                                              const EntrySrc *__restrict__ srcs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    typedef S420E::K K;
+    const FusedWork w = walk_item_at(geoms, work, blockIdx.x);
+    const EntrySrc src = srcs[ids[w.image]];
+    if (!src.job) return;  // (a dense image of a mixed launch group)
+    const HuffSyncJob *__restrict__ job = src.job;
+    if (__hip_atomic_load(job->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // refused by the decoder: the host decodes the image
+    const FusedGeom g = geoms[w.image];
+    const FusedImage img = imgs[w.image];
+    const S420Lds lds = S420Lds::make(lds_raw, g.tx);
+    const S420ELds el = S420ELds::make(lds_raw + S420Lds::total_bytes(g.tx), g.tx);
+    const uint32_t strip = w.a, tid = threadIdx.x, k0 = w.b, k1 = w.c, te = K::txe(g, strip);
+    S420Regs r;
+    // {chunk, entry} of MCU row k of this strip — written by huff_strip_index_kernel before this launch: constant here, read with scalar loads
+    // (a scalar load waits where its result is used, so the next row's pair, asked for a step ahead, costs no register a lane owns)
+    const JP_CONST uint32_t *tab = (const JP_CONST uint32_t *)src.tab + 2u * strip;
+    auto at = [&](uint32_t k, uint32_t i) { return tab[2u * k * g.tiles_x + i]; };
+    __builtin_amdgcn_s_setprio(1);
+    K::init(img, tid, lds);
+    S420E::init(img, te, tid, el);
+    if (k0 > 0 || k1 < g.mcu_h) {  // seam rows of the segments above / below: the chroma blocks of MCU rows k0 - 1 and k1
+        S420E::clear_stage(lds, 4u * (te + 2u), tid);
+        __syncthreads();
+        if (k0 > 0) S420E::scatter_row(job, at(k0 - 1u, 0u), at(k0 - 1u, 1u), g, strip, k0 - 1u, tid, lds, el.blk[1], el);
+        if (k1 < g.mcu_h) S420E::scatter_row(job, at(k1, 0u), at(k1, 1u), g, strip, k1, tid, lds, el.blk[2], el);
+        __syncthreads();
+        K::seam_transform(g, strip, k0, k1, tid, lds);
+        __syncthreads();
+    }
+    S420E::clear_stage(lds, 6u * te + 4u, tid);
+    __syncthreads();
+    S420E::scatter_row(job, at(k0, 0u), at(k0, 1u), g, strip, k0, tid, lds, el.blk[0], el);
+    uint32_t nc0 = k0 + 1u < k1 ? at(k0 + 1u, 0u) : 0u, ne0 = k0 + 1u < k1 ? at(k0 + 1u, 1u) : 0u;  // (the next row's place in the lists: asked for a step ahead)
+    __syncthreads();
+    for (uint32_t k = k0; k < k1; k++) {
+        uint32_t t0 = tid, t1 = tid, t2 = tid;  // (opaque copies of the lane id per phase: walk_item)
+        asm volatile("" : "+v"(t1));
+        K::read_block(g, strip, t1, lds, r);
+        __syncthreads();  // the tiles alias the staging area
+        K::transform(g, strip, t1, lds, r);
+        __syncthreads();
+        const bool more = k + 1u < k1;
+        asm volatile("" : "+v"(t2));
+        __builtin_amdgcn_s_setprio(0);
+        K::colour(g, img, strip, k, 16u * k0, false, t2, lds);
+        __builtin_amdgcn_s_setprio(1);
+        __syncthreads();
+        if (more) {
+            asm volatile("" : "+v"(t0));
+            S420E::clear_stage(lds, 6u * te + 4u, t0);
+            __syncthreads();
+            S420E::scatter_row(job, nc0, ne0, g, strip, k + 1u, t0, lds, el.blk[0], el);
+            if (k + 2u < k1) nc0 = at(k + 2u, 0u), ne0 = at(k + 2u, 1u);
+            __syncthreads();
+        }
+    }
+    if (16u * k1 - 1u < g.out_h) {
+        K::closing_tiles(tid, lds);
+        __syncthreads();
+        K::colour(g, img, strip, k1, 16u * k0, true, tid, lds);
+    }
+    // the sane body was run on trust: an image with a coefficient outside its range goes back to the host
+    __syncthreads();
+    uint32_t t3 = tid;
+    asm volatile("" : "+v"(t3));  // (or the address of el.rg[tid], computed in init, is kept — spilled — across the whole walk)
+    if (t3 < 4u && el.rg[t3] >= (1u << 15)) atomicOr(job->status, 1u | ENTRY_ST_RANGE);
 }
 
 template <int ARITH>
@@ -320,12 +396,14 @@ __global__ __launch_bounds__(256) void class_finalize_fused_kernel(FusedImage *_
     const uint32_t *st = stats + (size_t)gi * RS_WORDS;
     const uint32_t dev = range_class_from_stats(st[RS_MAX_DC], st[RS_MAX_AC], st[RS_MAX_COL], st[RS_COL_EXACT]);
     uint32_t fl = 3u;
+    bool skip = false;  // CLS_SKIP: the entry-list walk makes this image's pixels; the dense kernels leave it alone (flag bit 3)
     for (uint32_t c = 0; c < ncomp; c++) {
         const uint32_t h = host_cls[gi * 4u + c];
+        skip = skip || h == CLS_SKIP;
         fl &= h == CLS_FROM_DEVICE ? dev : h;
     }
     if (!(fl & 1u)) fl = 0u;  // tight implies sane
-    imgs[i].flags = fl & cap_bits;
+    imgs[i].flags = skip ? (8u | 1u) : (fl & cap_bits);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -607,6 +685,18 @@ hipError_t fused_launch(FusedPlan &plan, hipStream_t stream, const uint32_t *d_s
             w += plan.n_main_cls[c];
         }
     }
+    if (e == hipSuccess && plan.launched && hipEventRecord(plan.launched, stream) == hipSuccess) plan.launch_pending = true;
+    return e;
+}
+
+// The images of a 4:2:0 plan whose coefficients are entry lists (srcs[batch image].job set): one launch over the plan's work table.
+hipError_t fused_launch_entries(FusedPlan &plan, hipStream_t stream, const EntrySrc *d_srcs) {
+    if (plan.kind != FUSED_420 || !plan.strip || !d_srcs || plan.work_main.empty()) return hipErrorInvalidValue;
+    uint32_t tx_max = 0;
+    for (const auto &g : plan.geoms) tx_max = std::max(tx_max, g.tx);
+    const size_t shm = S420Lds::total_bytes(tx_max) + S420ELds::total_bytes(tx_max);
+    s420_entries_kernel<<<dim3((uint32_t)plan.work_main.size()), dim3(256), shm, stream>>>(plan.d_geoms, plan.d_images, plan.d_work_main, plan.d_ids, d_srcs);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess && plan.launched && hipEventRecord(plan.launched, stream) == hipSuccess) plan.launch_pending = true;
     return e;
 }

@@ -50,6 +50,9 @@ int fused_bind(FusedPlan &plan, uint8_t *d_coef, uint8_t *d_out, uint16_t *d_qt,
 // CLS_FROM_DEVICE) given: the classes are taken from the device's own statistics and the `_dyn` kernels run; else the
 // classes fused_bind was given (one launch per class present).
 hipError_t fused_launch(FusedPlan &plan, hipStream_t stream, const uint32_t *d_stats = nullptr, const uint8_t *d_host_cls = nullptr);
+// fused_entries.hpp: the plan's images whose coefficients are the device entropy decoder's entry lists (d_srcs: per BATCH image)
+struct EntrySrc;
+hipError_t fused_launch_entries(FusedPlan &plan, hipStream_t stream, const EntrySrc *d_srcs);
 // the finalize step alone (jpgpu_batch_class_counts)
 hipError_t fused_finalize_classes(FusedPlan &plan, hipStream_t stream, const uint32_t *d_stats, const uint8_t *d_host_cls);
 // class bits (bit 0 sane, bit 1 tight) of the plan's images as the last launch saw them (blocking read-back; diagnostics)

@@ -81,11 +81,13 @@ struct DeviceScratch {
 // `mode`: DEVICE_ENTROPY_LIGHT — scans without restart markers go up as the file holds them and the device does the staging pass
 // (marker check, unstuffing: huff_unstuff_core.hpp); | DEVICE_ENTROPY_INPUT_PINNED — the files lie in page-locked memory: no staging copy
 // either, the copy engine reads them.  n_light (optional): how many of the listed images took that route.
-constexpr uint32_t DEVICE_ENTROPY_LIGHT = 1u, DEVICE_ENTROPY_INPUT_PINNED = 2u;
+// | DEVICE_ENTROPY_ENTRY_PIXELS — 4:2:0 images whose scan qualifies keep their entry lists and the next jpgpu_batch_decode on the same
+// stream runs the walk that reads them (fused_entries.hpp): nothing of such an image goes through the coefficient arena.
+constexpr uint32_t DEVICE_ENTROPY_LIGHT = 1u, DEVICE_ENTROPY_INPUT_PINNED = 2u, DEVICE_ENTROPY_ENTRY_PIXELS = 4u;
 int batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage *images, uint32_t n, void *hip_stream,
                                 const std::function<void(uint32_t, const std::function<void(uint32_t)> &)> *par = nullptr,
                                 void *copy_stream = nullptr, DeviceScratch *scratch = nullptr, bool alone = false, uint32_t mode = 0u,
-                                uint32_t *n_light = nullptr);
+                                uint32_t *n_light = nullptr, uint32_t *n_entry = nullptr);  // n_entry: images on the entry-list pixel path
 int batch_device_entropy_collect(jpgpu_batch *b, uint32_t *status, uint32_t n);
 // The same for PROGRESSIVE frames (huff_prog_wave.hpp): the scans of every listed image are staged and uploaded, the
 // images' planes and non-zero / sign masks zero-filled, ONE launch walks all tracks (a lane per track of dependent scans; the

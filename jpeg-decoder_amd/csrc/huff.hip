@@ -693,7 +693,7 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
     JP_LDS ExpandLds &E = *(JP_LDS ExpandLds *)&E_;
     const HuffSyncJob *gj = &jobs[blockIdx.y];
     const uint32_t first_chunk = blockIdx.x * (EXP_WAVES * EXP_CHUNKS);
-    if (first_chunk >= gj->n_chunks || gj->emit == nullptr || *gj->status != 0u) return;  // (flagged: the host decodes the image)
+    if (first_chunk >= gj->n_chunks || gj->emit == nullptr || gj->keep_lists || *gj->status != 0u) return;  // (flagged: the host decodes the image)
     {
         const JP_GLOBAL uint32_t *src = (const JP_GLOBAL uint32_t *)gj;
         JP_LDS uint32_t *dst = (JP_LDS uint32_t *)&E.job;
@@ -768,6 +768,49 @@ __global__ __launch_bounds__(EXP_WAVES * 64) void huff_expand_kernel(const HuffS
         for (uint32_t w = 0; w < EXP_WAVES; w++) v = max(v, E.wg_rg[threadIdx.x][w]);
         if (threadIdx.x == 0u) stat_mark_inexact(job.stats);
         stat_raise(job.stats + (threadIdx.x ? RS_MAX_AC : RS_MAX_DC), v);
+    }
+}
+
+// The strip index of the entry-list pixel path (fused_entries.hpp): for every (MCU row k, strip s) of a job's 4:2:0 walk, where in the
+// lists the run of MCUs [max(s * tx - 1, 0), ...) of row k begins — the chunk in which its first block STARTS (the last chunk whose
+// first-block number is not above the block's: a 64-ary search over the chunks) and the place of that block's DC entry in the chunk's
+// list (a count of DC entries).  One wave per pair.
+__global__ __launch_bounds__(256) void huff_strip_index_kernel(const HuffSyncJob *__restrict__ jobs, const EntryIndexJob *__restrict__ ijobs) {
+    const EntryIndexJob ij = ijobs[blockIdx.y];
+    const HuffSyncJob &job = jobs[ij.job];
+    const uint32_t lane = threadIdx.x & 63u, item = rfl(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (item >= ij.rows * ij.tiles_x || *job.status != 0u) return;
+    const uint32_t k = item / ij.tiles_x, s = item - k * ij.tiles_x, a = s ? s * ij.tx - 1u : 0u;
+    const uint32_t B0 = job.bpm * (k * job.cols + a), n_chunks = job.n_chunks, stride = job.emit_stride;
+    auto first_block = [&](uint32_t c) { return job.n_blocks[c] + ((c && (job.out_qk[c - 1u] & 0xffu)) ? 1u : 0u); };
+    uint32_t lo = 0, hi = n_chunks;  // the answer lies in [lo, hi); first_block(lo) <= B0 (chunk 0 starts block 0)
+    while (hi - lo > 1u) {
+        const uint32_t step = (hi - lo + 63u) / 64u, c = lo + lane * step;
+        const bool le = c < hi && first_block(c) <= B0;
+        const uint32_t t = (uint32_t)__popcll(__ballot(le));  // (monotone: the lanes that say yes are the first t; lane 0 always does)
+        const uint32_t nlo = lo + (t - 1u) * step;
+        hi = min(hi, nlo + step);
+        lo = nlo;
+    }
+    const uint32_t c0 = lo, cw = job.emit_cnt[c0], cnt = min(cw & 0xffffu, stride);
+    uint32_t want = B0 - first_block(c0), e0 = cnt;  // the (want + 1)-th DC entry of the list
+    const uint32_t *buf = job.emit + (size_t)c0 * stride;
+    for (uint32_t eb = min(cw >> 16, cnt); eb < cnt; eb += 64u) {
+        const bool flag = eb + lane < cnt && huff_entry_is_dc(buf[eb + lane]);
+        const uint64_t m = __ballot(flag);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (want < n) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint64_t hit = __ballot(flag && before == want);
+            e0 = eb + (uint32_t)__builtin_ctzll(hit);
+            break;
+        }
+        want -= n;
+    }
+    if (lane == 0u) {
+        if (e0 >= cnt) atomicOr(job.status, 1u | 1024u);  // (lists that do not hold the block their numbering promises: the host decodes the image)
+        ij.tab[2u * item] = c0;
+        ij.tab[2u * item + 1u] = e0;
     }
 }
 
@@ -1058,7 +1101,7 @@ hipError_t launch_range_scan(const RangeJob *d_jobs, uint32_t n_jobs, uint32_t m
 // Everything for a sub-batch's scans, enqueued blind: a fixed number of sync launches (settled jobs cost an empty workgroup
 // each), block numbering, the expansion of the entry lists and the DC sums of `uniform` scans.
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync, bool low_table_ids) {
+                            hipEvent_t after_sync, bool low_table_ids, const EntryIndexJob *d_index, uint32_t n_index, uint32_t max_index_items) {
     if (n_jobs == 0 || max_chunks == 0 || launches == 0 || iters == 0) {
         if (after_sync) (void)hipEventRecord(after_sync, stream);
         return hipSuccess;
@@ -1075,8 +1118,11 @@ hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t
     }
     huff_sync_scan_kernel<<<dim3(n_jobs), dim3(SYNC_NT), 0, stream>>>(d_jobs, launches - 1u);
     if (after_sync) (void)hipEventRecord(after_sync, stream);
-    huff_expand_kernel<<<dim3((max_chunks + EXP_WAVES * EXP_CHUNKS - 1u) / (EXP_WAVES * EXP_CHUNKS), n_jobs), dim3(EXP_WAVES * 64u), 0, stream>>>(d_jobs);
-    huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(DC_NT), 0, stream>>>(d_jobs);
+    if (n_index < n_jobs) {  // (every job's lists kept as lists: nothing to expand, and such jobs are never `uniform`)
+        huff_expand_kernel<<<dim3((max_chunks + EXP_WAVES * EXP_CHUNKS - 1u) / (EXP_WAVES * EXP_CHUNKS), n_jobs), dim3(EXP_WAVES * 64u), 0, stream>>>(d_jobs);
+        huff_dc_prefix_kernel<<<dim3(4, n_jobs), dim3(DC_NT), 0, stream>>>(d_jobs);
+    }
+    if (d_index && n_index && max_index_items) huff_strip_index_kernel<<<dim3((max_index_items + 3u) / 4u, n_index), dim3(256), 0, stream>>>(d_jobs, d_index);
     return hipGetLastError();
 }
 

@@ -17,11 +17,21 @@ struct RangeJob {  // one component plane to classify
     uint16_t q[64];
 };
 
+// Entry lists read by the pixel kernel itself (fused_entries.hpp): instead of huff_expand_kernel, per (MCU row, strip) of the image's
+// 4:2:0 walk the chunk and the entry at which the run of that row's MCUs starts.
+struct EntryIndexJob {
+    uint32_t job;             // which HuffSyncJob of the launch
+    uint32_t tx, tiles_x, rows;  // strip width in MCUs, strips per MCU row, MCU rows
+    uint32_t *tab;            // rows x tiles_x x {chunk, entry}
+};
 // Sync passes (with speculative emission) + block numbering | expansion of the entry lists + DC sums of `uniform` scans.
 // after_sync (optional): recorded between the two (phase timing)
 // low_table_ids: every job's components use Huffman table ids 0 and 1 only — the sync passes run with four table slots in LDS
+// d_index (n_index jobs, at most max_index_items (row, strip) pairs each): those jobs' lists stay lists (HuffSyncJob::keep_lists:
+// huff_expand_kernel leaves them alone) and get their strip index instead
 hipError_t launch_huff_sync(const HuffSyncJob *d_jobs, uint32_t n_jobs, uint32_t max_chunks, uint32_t launches, uint32_t iters, hipStream_t stream,
-                            hipEvent_t after_sync = nullptr, bool low_table_ids = false);
+                            hipEvent_t after_sync = nullptr, bool low_table_ids = false, const EntryIndexJob *d_index = nullptr, uint32_t n_index = 0,
+                            uint32_t max_index_items = 0);
 // progressive frames: one wave per scan, coefficients accumulated in the arena (huff_prog_wave.hpp)
 hipError_t launch_huff_progw(const ProgTrack *d_tracks, uint32_t n_tracks, hipStream_t stream);  // round 6: a wave per scan
 // n words from device memory into pinned host memory (dst: the DEVICE address of a hipHostMalloc'ed block), by a kernel

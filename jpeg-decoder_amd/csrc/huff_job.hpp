@@ -171,7 +171,7 @@ struct HuffSyncJob {             // one scan of one image, for either device dec
     // side, so that a wave's 64 stream fetches of a step fall into a few cache lines instead of 64.  Device-only work space.
     const uint32_t *weave;  // huff_weave_dwords(n_chunks, chunk_shift) dwords
     uint32_t data_dwords;   // dwords that may be read from `data` (the scan's slots); what lies beyond counts as zeros
-    uint32_t pad_;
+    uint32_t keep_lists;    // 1: the pixel kernel reads the entry lists itself (fused_entries.hpp) — no expansion into the arena
 };
 // Where chunk i lies: bits [start, end) of the job's data, whether a segment starts there, which segment it belongs to.
 struct HuffChunkSpan {

@@ -890,7 +890,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     std::mutex trace_m;
     double busy_sum = 0, busy_max = 0, last_end = 0, prog_host_ms = 0, prog_dev_ms = 0;
     uint64_t prog_host_bytes = 0, prog_dev_bytes = 0;
-    uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0, light_images = 0;
+    uint32_t device_prog_images = 0, prog_host_images = 0, n_host_images = 0, light_images = 0, entry_images = 0;
     // Host light (include/jpgpu_decoder.h) is the DEFAULT at every thread count (round 6); JPGPU_PIPELINE_HOST_STAGED asks for the host's
     // staging pass.  Why no rule by thread count any more (round 5 chose staging above 16 worker threads): host staging swings 2 x with the
     // box and with what else runs on it — 4,096 x 1080p at 16 CPUs / 32 threads: 49-51 ms on quiet boxes, 60.7 ms on the driver's, 115-119 ms
@@ -900,7 +900,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     const char *light_env = getenv("JPGPU_PIPE_HOST_LIGHT");  // (tests, fuzzers, A/B: 1 / 0 force the mode for calls that do not say themselves)
     const bool light_default = light_env ? atoi(light_env) != 0 : true;
     const bool host_light = input_pinned || (flags & JPGPU_PIPELINE_HOST_LIGHT) != 0 || ((flags & JPGPU_PIPELINE_HOST_STAGED) == 0 && light_default);
-    const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u);
+    // JPGPU_PIPE_ENTRY_PIXELS (default 1): 4:2:0 images keep their scan as the chunk decoder's entry lists and the pixel walk reads those
+    // (csrc/fused_entries.hpp) instead of whole blocks expanded into the coefficient arena; 0: round 5's expansion kernel for every image
+    const char *entry_env = getenv("JPGPU_PIPE_ENTRY_PIXELS");  // (read per call: tests switch it)
+    const bool entry_pixels = entry_env ? atoi(entry_env) != 0 : true;
+    const uint32_t entropy_mode = (host_light ? jpgpu::DEVICE_ENTROPY_LIGHT : 0u) | (input_pinned ? jpgpu::DEVICE_ENTROPY_INPUT_PINNED : 0u) |
+                                  (entry_pixels ? jpgpu::DEVICE_ENTROPY_ENTRY_PIXELS : 0u);
     // Progressive frames for the device: a lane per scan only while ALL the call's lanes fit the device at once (prog_lanes_max())
     uint64_t prog_lanes = 0;
     for (uint32_t i = 0; i < n; i++)
@@ -1024,11 +1029,12 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                         } else {
                             std::vector<jpgpu::DeviceEntropyImage> list;
                             for (uint32_t di : dv) list.push_back(jpgpu::DeviceEntropyImage{(uint32_t)p->slot[di], data[di], &p->plans[di]});
-                            uint32_t n_light = 0;
+                            uint32_t n_light = 0, n_entry = 0;
                             okk = jpgpu::batch_device_entropy_launch(sb.batch, list.data(), (uint32_t)list.size(), cs, &par_for,
                                                                      p->copy_streams[(uint32_t)p->sub_of[i] % kCopyStreams],
-                                                                     &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u, entropy_mode, &n_light) == JPGPU_OK;
+                                                                     &p->scratch[(uint32_t)p->sub_of[i] % p->n_compute], n_dev_subs <= 2u, entropy_mode, &n_light, &n_entry) == JPGPU_OK;
                             light_images += n_light;
+                            entry_images += n_entry;
                         }
                         if (trace) fprintf(stderr, "pipeline trace: device entropy launch of sub-batch %d at +%.2f ms took %.2f ms (host)\n", p->sub_of[i], l0 - t2, now_ms() - l0);
                         // The pixel kernels follow at once on the same stream: the classes of the decoded coefficients are a
@@ -1231,6 +1237,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
     p->t.images_device_rejected = device_rejected;
     p->t.images_device_progressive = device_prog_images;
     p->t.images_host_light = light_images;
+    p->t.images_entry_pixels = entry_images;
     p->t.input_pinned = input_pinned ? 1u : 0u;
     if (trace && (prog_host_bytes || device_prog_images))
         fprintf(stderr, "pipeline trace: progressive frames: %u on the device (walk %.2f ms, launches + range scan + pixels %.2f ms), %u on the host (entropy phase %.2f ms, %.1f ns per byte and thread)\n",
@@ -1617,6 +1624,7 @@ static int multi_decode(jpgpu_pipeline *p, const uint8_t *const *data, const siz
         p->t.images_device_rejected += c->t.images_device_rejected;
         p->t.images_device_progressive += c->t.images_device_progressive;
         p->t.images_host_light += c->t.images_host_light;
+        p->t.images_entry_pixels += c->t.images_entry_pixels;
         p->t.input_pinned |= c->t.input_pinned;
     }
     p->t.decode_ms = t1 - t0;

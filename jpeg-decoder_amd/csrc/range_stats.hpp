@@ -25,6 +25,7 @@ namespace jpgpu {
 
 enum : uint32_t { RS_MAX_DC = 0, RS_MAX_AC = 1, RS_MAX_COL = 2, RS_COL_EXACT = 3, RS_WORDS = 4 };
 constexpr uint8_t CLS_FROM_DEVICE = 0xffu;  // host-side class table entry: "look at the device statistics"
+constexpr uint8_t CLS_SKIP = 0xfeu;         // ...: "the entry-list walk makes this image's pixels, leave it alone" (fused_entries.hpp)
 
 inline
 #if defined(__HIPCC__)
