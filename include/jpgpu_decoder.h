@@ -102,7 +102,8 @@ typedef struct jpgpu_pipeline_timings {
      *   dev_fill_ms   zero fill of the coefficient planes and statistics
      *   dev_sync_ms   the chunk decoder's sync passes (with speculative emission) + block numbering
      *   dev_write_ms  expansion of the sync passes' entry lists into coefficient blocks (and, as a by-product, their range statistics)
-     *                 + DC sums of scans whose components share their tables
+     *                 + DC sums of scans whose components share their tables; images_entry_pixels (below): only the strip index of
+     *                 their lists — the pixel walk reads the lists itself
      *   dev_pixel_ms  class finalize + pixel kernels (dequantize, IDCT, upsampling, colour conversion) */
     uint32_t dev_times_valid, _pad;
     double dev_fill_ms, dev_sync_ms, dev_write_ms, dev_pixel_ms;

@@ -177,15 +177,15 @@ __global__ __launch_bounds__(256, 4) void s420_entries_kernel(const FusedGeom *_
     if (k0 > 0 || k1 < g.mcu_h) {  // seam rows of the segments above / below: the chroma blocks of MCU rows k0 - 1 and k1
         S420E::clear_stage(lds, 4u * (te + 2u), tid);
         __syncthreads();
-        if (k0 > 0) S420E::scatter_row(job, at(k0 - 1u, 0u), at(k0 - 1u, 1u), g, strip, k0 - 1u, tid, lds, el.blk[1], el);
-        if (k1 < g.mcu_h) S420E::scatter_row(job, at(k1, 0u), at(k1, 1u), g, strip, k1, tid, lds, el.blk[2], el);
+        if (k0 > 0) S420E::scatter_row<false>(job, at(k0 - 1u, 0u), at(k0 - 1u, 1u), g, strip, k0 - 1u, tid, lds, el.blk[1], el, S420E::Meta{});
+        if (k1 < g.mcu_h) S420E::scatter_row<false>(job, at(k1, 0u), at(k1, 1u), g, strip, k1, tid, lds, el.blk[2], el, S420E::Meta{});
         __syncthreads();
         K::seam_transform(g, strip, k0, k1, tid, lds);
         __syncthreads();
     }
     S420E::clear_stage(lds, 6u * te + 4u, tid);
     __syncthreads();
-    S420E::scatter_row(job, at(k0, 0u), at(k0, 1u), g, strip, k0, tid, lds, el.blk[0], el);
+    S420E::scatter_row<false>(job, at(k0, 0u), at(k0, 1u), g, strip, k0, tid, lds, el.blk[0], el, S420E::Meta{});
     uint32_t nc0 = k0 + 1u < k1 ? at(k0 + 1u, 0u) : 0u, ne0 = k0 + 1u < k1 ? at(k0 + 1u, 1u) : 0u;  // (the next row's place in the lists: asked for a step ahead)
     __syncthreads();
     for (uint32_t k = k0; k < k1; k++) {
@@ -197,6 +197,8 @@ __global__ __launch_bounds__(256, 4) void s420_entries_kernel(const FusedGeom *_
         __syncthreads();
         const bool more = k + 1u < k1;
         asm volatile("" : "+v"(t2));
+        S420E::Meta pre{};
+        if (more) pre = S420E::request_meta(job, nc0, t2);  // (the next row's chunks: on their way during the colour phase)
         __builtin_amdgcn_s_setprio(0);
         K::colour(g, img, strip, k, 16u * k0, false, t2, lds);
         __builtin_amdgcn_s_setprio(1);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void s420_entries_kernel(const FusedGeom *_
             asm volatile("" : "+v"(t0));
             S420E::clear_stage(lds, 6u * te + 4u, t0);
             __syncthreads();
-            S420E::scatter_row(job, nc0, ne0, g, strip, k + 1u, t0, lds, el.blk[0], el);
+            S420E::scatter_row<true>(job, nc0, ne0, g, strip, k + 1u, t0, lds, el.blk[0], el, pre);
             if (k + 2u < k1) nc0 = at(k + 2u, 0u), ne0 = at(k + 2u, 1u);
             __syncthreads();
         }

@@ -795,17 +795,25 @@ __global__ __launch_bounds__(256) void huff_strip_index_kernel(const HuffSyncJob
     const uint32_t c0 = lo, cw = job.emit_cnt[c0], cnt = min(cw & 0xffffu, stride);
     uint32_t want = B0 - first_block(c0), e0 = cnt;  // the (want + 1)-th DC entry of the list
     const uint32_t *buf = job.emit + (size_t)c0 * stride;
-    for (uint32_t eb = min(cw >> 16, cnt); eb < cnt; eb += 64u) {
-        const bool flag = eb + lane < cnt && huff_entry_is_dc(buf[eb + lane]);
-        const uint64_t m = __ballot(flag);
-        const uint32_t n = (uint32_t)__popcll(m);
-        if (want < n) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const uint64_t hit = __ballot(flag && before == want);
-            e0 = eb + (uint32_t)__builtin_ctzll(hit);
-            break;
+    constexpr uint32_t IR = 8;  // rounds of 64 entries requested at once (a wave that waits for every 256 bytes in turn: 59 us per 256 images)
+    for (uint32_t eb = min(cw >> 16, cnt); eb < cnt && e0 == cnt; eb += 64u * IR) {
+        uint32_t ent[IR];
+#pragma unroll
+        for (uint32_t r = 0; r < IR; r++) ent[r] = buf[min(eb + 64u * r + lane, cnt - 1u)];
+#pragma unroll
+        for (uint32_t r = 0; r < IR; r++) {
+            if (eb + 64u * r >= cnt) break;
+            const bool flag = eb + 64u * r + lane < cnt && huff_entry_is_dc(ent[r]);
+            const uint64_t m = __ballot(flag);
+            const uint32_t n = (uint32_t)__popcll(m);
+            if (want < n) {
+                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint64_t hit = __ballot(flag && before == want);
+                e0 = eb + 64u * r + (uint32_t)__builtin_ctzll(hit);
+                break;
+            }
+            want -= n;
         }
-        want -= n;
     }
     if (lane == 0u) {
         if (e0 >= cnt) atomicOr(job.status, 1u | 1024u);  // (lists that do not hold the block their numbering promises: the host decodes the image)

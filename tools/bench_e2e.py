@@ -355,7 +355,8 @@ def e2e_entry(n, ts, w, h, p, ok, extra=None):
          "wall_ms": {k[:-3]: round(med[k], 3) for k in ("headers_ms", "setup_ms", "entropy_and_upload_ms", "download_ms")},
          "cpu_ms_per_image": round(med["cpu_ms"] / max(n, 1), 5),
          "images_device_entropy": int(med["images_device_entropy"]), "images_device_rejected": int(med["images_device_rejected"]),
-         "images_host_light": int(med["images_host_light"]), "threads": int(med["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(ok)}
+         "images_host_light": int(med["images_host_light"]), "images_entry_pixels": int(med.get("images_entry_pixels", 0)),
+         "threads": int(med["threads"]), "kernel_path": p.kernel_path, "verified_vs_oracle": bool(ok)}
     if extra:
         e.update(extra)
     return e, med
@@ -414,8 +415,10 @@ def e2e_block(J, O, synth, w, h, sizes, encoder, h2d_gbps=None, d2h_gbps=None):
                 km = {"sync_ms": best["dev_sync_ms"], "expand_ms": best["dev_write_ms"], "pixel_ms": best["dev_pixel_ms"]}
                 out["kernels_256_one_sub_batch"] = {
                     "what": "256 files as one sub-batch, nothing else on the device: events between the phases on its stream — sync passes "
-                            "(with speculative emission) + block numbering | expansion of the emitted lists into whole blocks + DC sums of "
-                            "uniform scans | class finalize + pixel kernels.  No zero fill, no range scan, no write pass.",
+                            "(with speculative emission) + block numbering | `expand_ms`: the strip index of the entry lists (round 6: the 4:2:0 "
+                            "walk reads the lists itself, csrc/fused_entries.hpp; JPGPU_PIPE_ENTRY_PIXELS=0: their expansion into whole blocks, "
+                            "0.55 ms) | class finalize + pixel kernels.  No zero fill, no range scan, no write pass.",
+                    "images_entry_pixels": int(best.get("images_entry_pixels", 0)),
                     "kernel_ms": {**{k: round(v, 3) for k, v in km.items()}, "sum": round(sum(km.values()), 3)},
                     "kernels_only_images_per_s": round(256 / sum(km.values()) * 1e3, 1), "total_ms": round(best["total_ms"], 3)}
                 # every E entry against its own floors (VERDICT r3 next #1a)
