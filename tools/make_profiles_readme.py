@@ -80,12 +80,13 @@ ROWS = [  # file, what (typed), how the facts are read
     ("05_pytest_gpu.txt", "`pytest -m gpu` + `smoke()`", facts_pytest),
     ("pmc_traffic.json", "HBM traffic of the headline kernel by the counters (FETCH_SIZE x 2 + WRITE_SIZE, separate `--pmc` passes); `tests/test_profiles.py` fails when the pixel-kernel sources change", facts_traffic),
     ("06_kernel_trace_stats_bench_K.json", "`rocprofv3 --kernel-trace --stats` of the bench command's K region (tracer attached)", facts_trace),
-    ("07_fuzz.txt", "the differential fuzzers, 150 cases each", facts_fuzz),
+    ("07_fuzz.txt", "the differential fuzzers, 300 cases each (the entry-list walk as the default)", facts_fuzz),
     ("09_other_workloads_bench.jsonl", "K of every other workload of `bench.py` (fraction of 8 TB/s)", facts_jsonl),
     ("01_scalar_chain_ubench.txt", "`tools/ubench_scalar_chain.hip`: cycles per instruction of a dependent chain, by instruction kind — what the wave-per-scan design was sized with", None),
     ("02_progressive_wave_per_scan.txt", "row n3 this round: calls by frame count on both routes, the hand-scheduled loop alone, kernel trace and counters of the walk, the build history", None),
     ("03_progressive_cost_model.txt", "the dispatcher's cost model against the measured calls", None),
     ("11_entry_list_walk.txt", "VERDICT r5 #4: the 4:2:0 walk that reads the entry lists against the expansion kernel — four builds, same-box A/Bs, segment lengths, kernel trace and counters", None),
+    ("12_pipe256_one_sub_batch_kernel_stats_and_pmc.json", "the device-entropy pipeline's kernels, 256 files as ONE sub-batch: durations, registers, LDS, traffic, instruction counters", None),
     ("04_launch_shape.txt", "headline kernel: segment cuts, work-table forms and workgroup counts on three boxes (VERDICT r5 #5)", None),
 ]
 
