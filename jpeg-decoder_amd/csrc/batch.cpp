@@ -1139,9 +1139,9 @@ int jpgpu::batch_device_entropy_launch(jpgpu_batch *b, const DeviceEntropyImage 
                 for (uint32_t c = 0; c < ps.ncomp; c++) block_h[c] = desc.components[ps.comp[c].frame_index].block_height;
                 if (!huff_scan_covers_planes(*sj, block_h)) needs_zeros = true;
                 // Entry-list pixel path: the image's ONE scan holds its three components interleaved in frame order, 2x2 / 1x1 / 1x1, with
-                // tables of their own for luma and chroma (the entries then carry their component), no restart segments, and covers the
-                // planes of the 4:2:0 walk the image belongs to.
-                if (const FusedGeom *wg = entry_pixels ? walk_geom[img] : nullptr; wg && images[k].scans->size() == 1 && !dg.chunked && !needs_zeros &&
+                // tables of their own for luma and chroma (the entries then carry their component), with or without restart segments, and
+                // covers the planes of the 4:2:0 walk the image belongs to.
+                if (const FusedGeom *wg = entry_pixels ? walk_geom[img] : nullptr; wg && images[k].scans->size() == 1 && !(dg.chunked && dg.too_large) && !needs_zeros &&
                                                                                     ps.ncomp == 3 && !sj->uniform && sj->bpm == 6u && sj->cols == wg->mcu_w &&
                                                                                     sj->n_mcu == wg->mcu_w * wg->mcu_h && wg->tiles_x * wg->tx >= wg->mcu_w) {
                     bool ok = true;

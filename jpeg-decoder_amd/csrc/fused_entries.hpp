@@ -18,8 +18,8 @@
 //   * Arithmetic class: the walk runs the "sane" body (every |coefficient x quantization value| < 2^15, pixel_math.hpp) — true of
 //     every legal 8-bit stream.  The scatter sees every coefficient anyway and checks: an image that breaks the bound is flagged in its
 //     status word (bit 9) and the host decodes it, like any stream the device decoder refuses.
-// Only for scans huff.hip's numbering has settled without restart segments and with per-component tables (`uniform` == 0: the
-// entries then carry their component); everything else keeps the expansion kernel.
+// Only for scans with per-component tables (`uniform` == 0: the entries then carry their component), with or without restart
+// segments; everything else keeps the expansion kernel.
 #pragma once
 #include "fused_core.hpp"
 #include "huff_job.hpp"
@@ -125,6 +125,9 @@ struct S420E {
         Meta m;
         m.cw = emit_cnt[cl], m.nb = n_blocks[cl], m.qk = cl ? out_qk[cl - 1u] : 0u;
         m.w = dc_sum[cl];
+        // restart segments: a segment's first chunk continues nothing (huff_chunk_span(..).first)
+        const uint32_t seg_chunks = e_rfl(job->n_seg) > 1u ? e_rfl(job->seg_chunks) : 0u;
+        if (seg_chunks && cl % seg_chunks == 0u) m.qk = 0u;
         return m;
     }
     // `pre`: request_meta(job, c0, tid), asked for earlier (the walk asks before the colour phase of the row before: one round trip less
@@ -137,6 +140,9 @@ struct S420E {
         const uint32_t a = x0m ? x0m - 1u : 0u, b = min(x0m + te + 1u, g.mcu_w);
         const uint32_t B0 = 6u * (k * g.mcu_w + a), nB = 6u * (b - a), shift = x0m ? 0u : 6u;  // (no halo MCU in front of the first strip)
         const uint32_t n_chunks = e_rfl(job->n_chunks), stride = e_rfl(job->emit_stride);
+        // restart segments (HuffSyncJob::seg_chunks): chunk c belongs to segment c / seg_chunks, whose blocks end at (segment + 1) x restart
+        // interval; what its last chunk decodes out of the bits behind the segment's last block is nobody's (huff_expand_kernel: `total`)
+        const uint32_t seg_chunks = e_rfl(job->n_seg) > 1u ? e_rfl(job->seg_chunks) : 0u, seg_blocks = e_rfl(job->ri) * 6u, all_blocks = e_rfl(job->n_mcu) * 6u;
         const JP_GLOBAL uint32_t *emit = (const JP_GLOBAL uint32_t *)e_uniform(job->emit);
         uint8_t *stage = lds.stage;
         const uint32_t dump = (uint32_t)(reinterpret_cast<uint8_t *>(e.rg + 4) - stage);  // (two bytes nobody reads)
@@ -154,8 +160,14 @@ struct S420E {
                     break;
                 }
                 const uint32_t cw = e_lane(m_cw, j), nblk = e_lane(m_nb, j), qk = e_lane(m_qk, j);
-                const uint32_t S = nblk + ((qk & 0xffu) ? 1u : 0u);  // number of the first block that starts in the chunk
-                if (c != c0 && S >= B0 + nB + 1u) {                 // even the block it continues lies behind the run
+                uint32_t S = nblk + ((qk & 0xffu) ? 1u : 0u);  // number of the first block that starts in the chunk
+                uint32_t nBc = nB;                              // blocks of the run this chunk may write: those of its own segment
+                if (seg_chunks) {
+                    const uint32_t seg_end = min((c / seg_chunks + 1u) * seg_blocks, all_blocks);
+                    S = min(S, seg_end);  // (huff_strip_index_kernel: the state behind a segment's last block)
+                    nBc = seg_end > B0 ? min(nB, seg_end - B0) : 0u;
+                }
+                if (c != c0 && S >= B0 + nB + 1u) {             // even the block it continues lies behind the run
                     done = true;
                     break;
                 }
@@ -188,7 +200,7 @@ struct S420E {
                         const uint32_t t = blk[min((uint32_t)d, nB - 1u) + shift], zq = e.zq[min(czz, 191u)];
                         const uint32_t comp = czz >> 6;
                         const uint32_t v = (ent[r] + (flag ? (comp == 0u ? wy : (comp == 1u ? wcb : wcr)) : 0u)) & 0xffffu;  // DC: + what the chunks before add up to
-                        const bool ok = valid && (uint32_t)d < nB && !(t >> 31);
+                        const bool ok = valid && (uint32_t)d < nBc && !(t >> 31);
                         const int32_t sv = (int16_t)(uint16_t)v;
                         rg = max(rg, (uint32_t)(sv < 0 ? -sv : sv) * (ok ? zq & 0xffffu : 0u));
                         const uint32_t addr = (t & 0xffffu) + ((zq ^ t) >> 16 & 0x7eu);

@@ -782,7 +782,16 @@ __global__ __launch_bounds__(256) void huff_strip_index_kernel(const HuffSyncJob
     if (item >= ij.rows * ij.tiles_x || *job.status != 0u) return;
     const uint32_t k = item / ij.tiles_x, s = item - k * ij.tiles_x, a = s ? s * ij.tx - 1u : 0u;
     const uint32_t B0 = job.bpm * (k * job.cols + a), n_chunks = job.n_chunks, stride = job.emit_stride;
-    auto first_block = [&](uint32_t c) { return job.n_blocks[c] + ((c && (job.out_qk[c - 1u] & 0xffu)) ? 1u : 0u); };
+    // (restart segments: a segment's first chunk continues nothing, huff_chunk_span(..).first; block numbers run on across segments)
+    // ... and a segment's blocks end with its restart interval: what its last chunk made of the bits behind the last block (a state
+    // that says "inside a block", handed on through the segment's empty slots) is nobody's — without the clamp the numbers of those
+    // slots lie one above the next segment's first block, and the search below needs them in order
+    const uint32_t seg_chunks = job.n_seg > 1u ? job.seg_chunks : 0u, seg_blocks = job.ri * job.bpm, all_blocks = job.n_mcu * job.bpm;
+    auto first_block = [&](uint32_t c) {
+        const bool continues = c && !(seg_chunks && c % seg_chunks == 0u) && (job.out_qk[c - 1u] & 0xffu);
+        const uint32_t f = job.n_blocks[c] + (continues ? 1u : 0u);
+        return seg_chunks ? min(f, min((c / seg_chunks + 1u) * seg_blocks, all_blocks)) : f;
+    };
     uint32_t lo = 0, hi = n_chunks;  // the answer lies in [lo, hi); first_block(lo) <= B0 (chunk 0 starts block 0)
     while (hi - lo > 1u) {
         const uint32_t step = (hi - lo + 63u) / 64u, c = lo + lane * step;

@@ -1096,6 +1096,7 @@ int jpgpu_pipeline_decode(jpgpu_pipeline *p, const uint8_t *const *data, const s
                     std::vector<Redecode> redo;
                     for (size_t k2 = 0; okk && k2 < dv.size(); k2++)
                         if (st[k2]) {
+                            if (trace) fprintf(stderr, "pipeline trace: image %u handed back by the device decoder, status 0x%x\n", dv[k2], st[k2]);
                             device_rejected++;
                             redo.emplace_back();
                             redo.back().image = dv[k2];

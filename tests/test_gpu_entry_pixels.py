@@ -38,10 +38,11 @@ def _jpeg(w, h, quality=85, seed=1, kind="photo", subsampling=2):
     return buf.getvalue()
 
 
-def _decode_and_check(p, files, expect_entry):
+def _decode_and_check(p, files, expect_entry, expect_rejected=0):
     out = p.decode(files)
     t = p.timings()
     assert t["images_entry_pixels"] == expect_entry, t
+    assert t["images_device_rejected"] == expect_rejected, t  # (pixels equal to the oracle's are not enough: a host re-decode makes them too)
     for i, (f, got) in enumerate(zip(files, out)):
         try:
             want = O.decode(f).pixels
@@ -87,11 +88,30 @@ def test_entry_lists_off_by_knob_and_other_layouts_keep_the_expansion(monkeypatc
     _decode_and_check(p, f420 + f444, 0)
     monkeypatch.delenv("JPGPU_PIPE_ENTRY_PIXELS")
     _decode_and_check(p, f420, len(f420))
-    # restart markers: segments have chunk slots of their own — the expansion kernel's business
+    p.close()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"JPGPU_S420_TX": "3", "JPGPU_S420_SEG": "2"}, {"JPGPU_SYNC_BLOCKS": "6", "JPGPU_SYNC_MIN_SHIFT": "7", "JPGPU_S420_TX": "5"}])
+def test_entry_lists_of_streams_with_restart_markers(monkeypatch, knobs):
+    """Restart segments have chunk slots of their own and block numbers that run on across them; a segment's first chunk continues
+    nothing, and what its last chunk makes of the bits behind the segment's last block is nobody's.  Intervals of whole MCU rows, of a
+    few MCUs (runs that span segments) and of one MCU."""
     from PIL import Image
-    buf = io.BytesIO()
-    Image.fromarray(synth.synthetic_rgb(320, 240, seed=5)).save(buf, format="JPEG", quality=85, subsampling=2, restart_marker_rows=1)
-    _decode_and_check(p, [buf.getvalue()] * 3 + f420[:2], 2)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    files = []
+    sizes = [(320, 240, {"restart_marker_rows": 1}), (320, 240, {"restart_marker_rows": 3}), (320, 240, {"restart_marker_blocks": 7}),
+             (700, 260, {"restart_marker_blocks": 5}), (100, 75, {"restart_marker_blocks": 1}), (640, 480, {"restart_marker_rows": 2})]
+    if not knobs:
+        sizes += [(1920, 1080, {"restart_marker_rows": 1}), (1920, 1080, {"restart_marker_blocks": 50})]
+    for i, (w, h, kw) in enumerate(sizes):
+        for q in (85, 40):
+            buf = io.BytesIO()
+            Image.fromarray(synth.synthetic_rgb(w, h, seed=60 + i)).save(buf, format="JPEG", quality=q, subsampling=2, **kw)
+            files.append(buf.getvalue())
+    p = J.Pipeline(threads=4)
+    _decode_and_check(p, files, len(files))
+    _decode_and_check(p, [files[0]] * 5 + [_jpeg(320, 240, seed=1)] * 3, 8)
     p.close()
 
 
@@ -186,7 +206,7 @@ def test_entry_lists_many_files_every_image_checked():
     p = J.Pipeline(threads=8)
     for _ in range(2):
         out = p.decode(files)
-        assert p.timings()["images_entry_pixels"] == len(files)
+        assert p.timings()["images_entry_pixels"] == len(files) and p.timings()["images_device_rejected"] == 0
         for (k, s), got in zip(idx, out):
             assert np.array_equal(got, want[k][s]), (k, s)
     p.close()
