@@ -149,7 +149,107 @@ int emu_huff_covered(const uint8_t* data, size_t len) {
     }
     return 1;
 }
-int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint32_t* n_passes) {
+// What the 4:2:0 pixel walk makes of the same settled lists when it reads them itself (csrc/fused_entries.hpp S420E::scatter_row +
+// huff.hip huff_strip_index_kernel), one entry after the other and for a strip width `tx`: per (MCU row, strip) the chunk in which the
+// run's first block starts and the place of its DC entry; then, chunk by chunk, entries -> blocks by counting DC entries from the chunk's
+// first-block number — a segment's first chunk continues nothing, numbers are clamped to the segment's end, a chunk writes no block beyond
+// its own segment, the strip's own MCUs take all six blocks, the halo MCU either side only its chroma.  True if every block of the
+// planes comes out as emu_expand left it.
+static bool emu_entry_walk_equals(const HuffSyncJob& sj, uint32_t tx, uint32_t* where) {
+    static const uint8_t kUnzig[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    const uint32_t cols = sj.cols, rows = sj.n_mcu / cols, tiles_x = (cols + tx - 1u) / tx, all = sj.n_mcu * 6u;
+    const uint32_t seg_chunks = sj.n_seg > 1u ? sj.seg_chunks : 0u, seg_blocks = sj.ri * 6u;
+    auto seg_end = [&](uint32_t c) { return seg_chunks ? std::min((c / seg_chunks + 1u) * seg_blocks, all) : 0xffffffffu; };
+    auto first_block = [&](uint32_t c) {
+        const bool continues = c && !(seg_chunks && c % seg_chunks == 0u) && (sj.out_qk[c - 1u] & 0xffu);
+        return std::min(sj.n_blocks[c] + (continues ? 1u : 0u), seg_end(c));
+    };
+    std::vector<std::vector<int16_t>> planes(3);
+    const uint32_t bw[3] = {sj.comp[0].block_w, sj.comp[1].block_w, sj.comp[2].block_w};
+    planes[0].assign((size_t)bw[0] * 2u * rows * 64u, 0);
+    planes[1].assign((size_t)bw[1] * rows * 64u, 0);
+    planes[2].assign((size_t)bw[2] * rows * 64u, 0);
+    for (uint32_t k = 0; k < rows; k++)
+        for (uint32_t s = 0; s < tiles_x; s++) {
+            const uint32_t x0m = s * tx, te = std::min(tx, cols - x0m), a = x0m ? x0m - 1u : 0u, b = std::min(x0m + te + 1u, cols);
+            const uint32_t B0 = 6u * (k * cols + a), nB = 6u * (b - a);
+            // the kernel's search, as it runs it: 64 probes per round, the answer among the probes that say "not above B0" — COUNTED
+            // (a ballot's population count), which is only right if the numbers are in order
+            uint32_t lo = 0, hi = sj.n_chunks;
+            while (hi - lo > 1u) {
+                const uint32_t step = (hi - lo + 63u) / 64u;
+                uint32_t t = 0;
+                for (uint32_t lane = 0; lane < 64u; lane++) {
+                    const uint32_t c = lo + lane * step;
+                    if (c < hi && first_block(c) <= B0) t++;
+                }
+                const uint32_t nlo = lo + (t - 1u) * step;
+                hi = std::min(hi, nlo + step);
+                lo = nlo;
+            }
+            const uint32_t c0 = lo;
+            uint32_t e0 = 0xffffffffu;
+            {
+                const uint32_t cw = sj.emit_cnt[c0], cnt = std::min(cw & 0xffffu, sj.emit_stride);
+                uint32_t want = B0 - first_block(c0);
+                for (uint32_t e = std::min(cw >> 16, cnt); e < cnt; e++)
+                    if (huff_entry_is_dc(sj.emit[(size_t)c0 * sj.emit_stride + e]) && want-- == 0u) {
+                        e0 = e;
+                        break;
+                    }
+            }
+            if (e0 == 0xffffffffu) {
+                *where = 0x10000u | k;
+                return false;
+            }
+            for (uint32_t c = c0; c < sj.n_chunks; c++) {
+                const uint32_t cw = sj.emit_cnt[c], cnt = std::min(cw & 0xffffu, sj.emit_stride);
+                const uint32_t S = first_block(c);
+                if (c != c0 && S >= B0 + nB + 1u) break;
+                const uint32_t end = seg_end(c), nBc = end > B0 ? std::min(nB, end - B0) : 0u;
+                const uint32_t w0 = sj.dc_sum[2 * c], w1 = sj.dc_sum[2 * c + 1];
+                const uint32_t pred[3] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu};
+                const int64_t dbase = c == c0 ? 0 : (int64_t)S - (int64_t)B0;
+                uint32_t started = 0;
+                for (uint32_t e = c == c0 ? e0 : 0u; e < cnt; e++) {
+                    const uint32_t ent = sj.emit[(size_t)c * sj.emit_stride + e];
+                    const bool dc = huff_entry_is_dc(ent);
+                    if (dc) started++;
+                    const int64_t d = dbase + (int64_t)started - 1;
+                    if (d >= 0 && d < (int64_t)nBc) {
+                        const uint32_t mx = a + (uint32_t)d / 6u, q = (uint32_t)d % 6u, comp = q < 4u ? 0u : q - 3u;
+                        const bool own = mx >= x0m && mx < x0m + te;
+                        if (comp != ((ent >> 22) & 3u)) {
+                            *where = 0x20000u | k;
+                            return false;
+                        }
+                        uint32_t v = ent & 0xffffu;
+                        if (dc) v = (v + pred[comp]) & 0xffffu;
+                        if (comp == 0u && own)
+                            planes[0][((size_t)(2u * k + (q >> 1)) * bw[0] + 2u * mx + (q & 1u)) * 64u + kUnzig[(ent >> 16) & 63u]] = (int16_t)(uint16_t)v;
+                        else if (comp != 0u)
+                            planes[comp][((size_t)k * bw[comp] + mx) * 64u + kUnzig[(ent >> 16) & 63u]] = (int16_t)(uint16_t)v;
+                    }
+                    if (dbase + (int64_t)started >= (int64_t)nB + 1) break;
+                }
+            }
+        }
+    for (uint32_t c = 0; c < 3; c++)
+        if (memcmp(planes[c].data(), sj.comp[c].dst, planes[c].size() * 2u) != 0) {
+            *where = 0x30000u | c;
+            return false;
+        }
+    return true;
+}
+static uint32_t g_entry_walk_checked = 0;  // scans the twin above has read since the last emu_huff_entry_walk_checked()
+extern "C" uint32_t emu_huff_entry_walk_checked() {
+    const uint32_t n = g_entry_walk_checked;
+    g_entry_walk_checked = 0;
+    return n;
+}
+
+extern "C" int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint32_t* n_passes) {
     Frontend fe(data, len);
     std::vector<PlannedScan> scans;
     fe.read_info();
@@ -307,6 +407,24 @@ int emu_huff_decode(const uint8_t* data, size_t len, int16_t* const* coefs, uint
                 g_emit_mismatch = 0;
                 emu_expand(sj, rg);
                 if (g_emit_mismatch) status |= 0x4000u;  // entries that name another component than the block numbering does
+                // the entry-list walk's reading of the same lists (batch.cpp's eligibility rule): strips of 42, 3 and 1 MCUs
+                bool walk = ps.ncomp == 3 && !sj.uniform && sj.bpm == 6u && scans.size() == 1 && sj.n_mcu % sj.cols == 0;
+                for (uint32_t c = 0; walk && c < 3; c++)
+                    walk = ps.comp[c].frame_index == c && ps.comp[c].h == (c ? 1u : 2u) && ps.comp[c].v == (c ? 1u : 2u);
+                if (walk && status == 0) {
+                    uint32_t bh[4] = {0, 0, 0, 0};
+                    for (uint32_t c = 0; c < 3; c++) bh[c] = fe.components()[c].block_height;
+                    walk = huff_scan_covers_planes(sj, bh);
+                }
+                if (walk && status == 0) {
+                    uint32_t where = 0;
+                    for (uint32_t tx : {42u, 3u, 1u})
+                        if (!emu_entry_walk_equals(sj, tx, &where)) {
+                            if (getenv("EMU_HUFF_TRACE")) fprintf(stderr, "entry walk twin differs: tx %u where %x\n", tx, where);
+                            status |= 0x2000u;
+                        }
+                    g_entry_walk_checked++;
+                }
             }
             // (huff_dc_prefix_kernel, uniform scans only) DC differences -> values, per component in stream order (i16 wrapping)
             for (uint32_t c = 0; sj.uniform && c < ps.ncomp; c++) {

@@ -510,3 +510,54 @@ def test_device_staging_pass_equals_the_hosts():
     assert _unstuff_both(b"\xff\x00" * 40, 9)[0] == b"\xff" * 40
     assert _unstuff_both(b"\x01\x02\xff", 0)[0] is None and _unstuff_both(b"\xff\xd9", 5)[0] is None and _unstuff_both(b"\xff\xff\x00", 0)[0] is None
     assert _unstuff_both(b"", 4)[0] == b""
+
+
+@pytest.mark.parametrize("case", [(64, 48, 0, 0), (250, 130, 0, 0), (700, 260, 0, 0), (1920, 128, 0, 0), (320, 240, 0, 1), (320, 240, 0, 3), (320, 240, 7, 0),
+                                  (700, 260, 5, 0), (100, 75, 1, 0), (1920, 64, 0, 1), (1920, 96, 50, 0)],
+                         ids=lambda c: f"{c[0]}x{c[1]}-b{c[2]}r{c[3]}")
+@pytest.mark.parametrize("quality", [85, 30, 97])
+def test_entry_list_walk_reads_the_lists_as_the_expansion_does(case, quality, emission):
+    """csrc/fused_entries.hpp, round 6: the 4:2:0 pixel walk reads the settled entry lists itself.  tests/emu holds a twin of its
+    reading (strip index + scatter, one entry after the other, strips of 42 / 3 / 1 MCUs) that emu_huff_decode runs on every eligible
+    scan next to the expansion's twin: status bit 13 if a single coefficient differs.  Restart segments: a segment's first chunk
+    continues nothing, block numbers are clamped to the segment's end (the bench's restart leg found the version without the clamp:
+    every image went back to the host), a chunk writes nothing beyond its segment."""
+    pytest.importorskip("PIL")
+    w, h, rb, rr = case
+    emu.lib().emu_huff_entry_walk_checked.restype = C.c_uint32
+    emu.lib().emu_huff_entry_walk_checked()
+    data = _pil_jpeg(w, h, "4:2:0", rb, rr, quality=quality, seed=w + quality) if (rb or rr) else _pil_jpeg_plain(w, h, quality, seed=w + quality)
+    got = _device(data)
+    assert got is not None
+    st, desc, planes, _ns, _nseg = got
+    assert st == 0, hex(st)
+    assert emu.lib().emu_huff_entry_walk_checked() == 1  # (the twin did read this scan)
+    _hdesc, hcoefs = _host(data)
+    for c in range(desc.ncomp):
+        assert np.array_equal(planes[c], hcoefs[c]), c
+
+
+def _pil_jpeg_plain(w, h, quality, seed):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(synth.synthetic_rgb(w, h, seed=seed)).save(buf, format="JPEG", quality=quality, subsampling="4:2:0")
+    return buf.getvalue()
+
+
+def test_entry_list_walk_twin_sees_the_reference_fixtures():
+    n = 0
+    emu.lib().emu_huff_entry_walk_checked.restype = C.c_uint32
+    emu.lib().emu_huff_entry_walk_checked()
+    import glob
+    for name in sorted(glob.glob(os.path.join(R.GOLDEN, "reftest", "**", "*.jp*g"), recursive=True)):
+        data = open(name, "rb").read()
+        try:
+            got = _device(data)
+        except Exception:
+            continue
+        if got is None:
+            continue
+        st = got[0]
+        assert not (st & 0x2000), name  # (whatever else the stream's status says, the two readings of its lists agree)
+        n += emu.lib().emu_huff_entry_walk_checked()
+    assert n >= 3, n
