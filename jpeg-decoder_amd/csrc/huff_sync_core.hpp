@@ -295,7 +295,12 @@ __device__ __forceinline__ bool huff_sync_chunk(JP_LDS HuffSyncLds &L, uint32_t 
         const uint32_t w0 = span.start >> 5;
         if (late) pos = huff_sync_run<2>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
         else if (emit) pos = huff_sync_run<1>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
-        else pos = huff_sync_run<0>(L, column, w0, pos, limit, q, k, nblk, dc, dc_sums, bad, em, last_block_end);
+        // (a pass without emission — pass 0, whose start states are guesses — is there for the end states: its sums of DC differences
+        // would be overwritten by pass 1, which every lane runs; without them the loop loses a divergent region with an LDS
+        // read-modify-write in it and the sign extension of every value: sync passes of 256 files alone 2.25 -> 2.17 ms.  The sums in
+        // REGISTERS instead of LDS for the emitting passes — four selects each way — measured 2.26 against 2.18: the loop is bound by the
+        // vector instructions it issues, not by that round trip)
+        else pos = huff_sync_run<0>(L, column, w0, pos, limit, q, k, nblk, dc, false, bad, em, last_block_end);
     }
     if (job.emit != nullptr) {
         job.blk_end[i] = last_block_end;
