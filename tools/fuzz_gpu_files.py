@@ -69,12 +69,15 @@ def run(seed, n_files, verbose=True):
             bad += 1
             if verbose: print("MISMATCH scaled", i, meta[i], req, flush=True)
     p = J.Pipeline(threads=8)
+    on_device = entry_walk = handed_back = 0  # (valid streams: what the device decoders took, how many through the walk that reads the entry lists, how many came back)
     for flags in ({"device_entropy": False}, {"device_entropy": True}, {"device_entropy": True, "dense": True}):
         for a in range(0, n_files, 24):
             out = p.decode(list(files[a:a + 24]), **flags)
             for k, got in enumerate(out): check("pipeline" + str(flags), a + k, got)
+            t = p.timings()
+            on_device += t["images_device_entropy"]; entry_walk += t["images_entry_pixels"]; handed_back += t["images_device_rejected"]
     p.close()
-    if verbose: print("seed", seed, "files", n_files, "scaled decodes", scaled, "bad", bad, flush=True)
+    if verbose: print("seed", seed, "files", n_files, "scaled decodes", scaled, "on the device", on_device, "entry-list walk", entry_walk, "handed back", handed_back, "bad", bad, flush=True)
     return bad
 
 
