@@ -210,3 +210,11 @@ def test_entry_lists_many_files_every_image_checked():
         for (k, s), got in zip(idx, out):
             assert np.array_equal(got, want[k][s]), (k, s)
     p.close()
+
+
+def test_entry_lists_of_2160p_frames_six_strips():
+    """3840x2160 (BASELINE configs[2]'s frame): six strips of 40 MCUs, 135 MCU rows, lists of a few thousand chunks."""
+    files = [_jpeg(3840, 2160, quality=q, seed=70 + q) for q in (85, 60)]
+    p = J.Pipeline(threads=4)
+    _decode_and_check(p, files * 2, 4)
+    p.close()
